@@ -1,0 +1,287 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+TEST INFRASTRUCTURE.  Imports the reference package from /root/reference with
+`sys.modules` stubs for its absent third-party dependencies (fastai,
+GANsynth_pytorch, discretization), runs its own `VQVAE` / `QuantizedBottleneck`
+/ `Rosinality*` / codemap helper classes on fixed-seed inputs and stores inputs
++ weights + outputs as small .npz fixtures.  The fixtures are data only; no
+reference source travels.  Run:
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The reference never runs on the GPU box: tests read only the .npz files.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import pathlib
+
+import numpy as np
+import torch
+from torch import nn
+
+sys.dont_write_bytecode = True
+REF = pathlib.Path("/root/reference")
+OUT = pathlib.Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+def _install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        if "." in name:  # expose as attribute of the parent package too
+            parent, leaf = name.rsplit(".", 1)
+            if parent in sys.modules:
+                setattr(sys.modules[parent], leaf, m)
+        return m
+
+    class _Dummy(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    def _noop(*a, **k):
+        return None
+
+    def _delegates(*a, **k):
+        def deco(f):
+            return f
+        return deco
+
+    mod("fastai")
+    mod("fastai.vision")
+    unet = mod("fastai.vision.models.unet", UnetBlock=_Dummy, _get_sz_change_idxs=_noop)
+    xresnet = mod("fastai.vision.models.xresnet", XResNet=_Dummy, delegates=_delegates)
+    mod("fastai.vision.models", unet=unet, xresnet=xresnet)
+    mod("fastai.layers", BatchNorm=_Dummy, ConvLayer=_Dummy, SequentialEx=_Dummy,
+        PixelShuffle_ICNR=_Dummy, SigmoidRange=_Dummy, ResBlock=_Dummy)
+    mod("fastai.torch_core", apply_init=_noop, defaults=types.SimpleNamespace(activation=nn.ReLU),
+        Module=_Dummy)
+    mod("fastai.callback")
+    mod("fastai.callback.hook", model_sizes=_noop, dummy_eval=_noop)
+    mod("GANsynth_pytorch")
+    mod("GANsynth_pytorch.loader", make_masked_phase_transform=_noop)
+
+    class DataNormalizerStatistics:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    mod("GANsynth_pytorch.normalizer", DataNormalizer=_Dummy,
+        DataNormalizerStatistics=DataNormalizerStatistics)
+    mod("discretization", ProductVectorQuantizer=_Dummy)
+
+
+def _np(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def _save(name, **arrays):
+    OUT.mkdir(parents=True, exist_ok=True)
+    path = OUT / name
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path} ({path.stat().st_size / 1024:.1f} KiB)")
+
+
+@torch.no_grad()
+def _calibrate_codebooks(model, x, seed):
+    """Replace each codebook by a random subset of that level's own
+    pre-quantisation vectors (non-degenerate code usage)."""
+    g = torch.Generator().manual_seed(seed)
+    enc_b = model.enc_b(x.clone())
+    enc_t = model.enc_t(enc_b)
+    z_t = model.quantize_conv_t(enc_t).permute(0, 2, 3, 1)
+    flat = z_t.reshape(-1, model.embed_dim)
+    pick = torch.randint(0, flat.shape[0], (model.n_embed_t,), generator=g)
+    model.quantize_t.embed.copy_(flat[pick].t())
+    model.quantize_t.embed_avg.copy_(model.quantize_t.embed)
+    q_t, *_ = model.quantize_t(z_t)
+    dec_t = model.dec_t(q_t.permute(0, 3, 1, 2))
+    z_b = model.quantize_conv_b(torch.cat([dec_t, enc_b], 1)).permute(0, 2, 3, 1)
+    flat = z_b.reshape(-1, model.embed_dim)
+    pick = torch.randint(0, flat.shape[0], (model.n_embed_b,), generator=g)
+    model.quantize_b.embed.copy_(flat[pick].t())
+    model.quantize_b.embed_avg.copy_(model.quantize_b.embed)
+
+
+@torch.no_grad()
+def vqvae_fixture(name, ctor_kwargs, in_shape, seed):
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    torch.manual_seed(seed)
+    model = VQVAE(**ctor_kwargs).eval()
+    x = torch.randn(*in_shape)
+    _calibrate_codebooks(model, torch.randn(*in_shape), seed + 100)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+
+    enc_b = model.enc_b(x.clone())
+    enc_t = model.enc_t(enc_b.clone())
+    z_t = model.quantize_conv_t(enc_t)
+    q_t, q_b, diff, id_t, id_b, perp_t, perp_b = model.encode(x.clone())
+    dec, diff2, perp_t2, perp_b2, id_t2, id_b2 = model(x.clone())
+    assert torch.equal(id_t, id_t2) and torch.equal(id_b, id_b2)
+    dec_code = model.decode_code(id_t, id_b)
+    used_t = len(torch.unique(id_t)) / model.n_embed_t
+    used_b = len(torch.unique(id_b)) / model.n_embed_b
+    print(f"{name}: code usage top {used_t:.2f} bottom {used_b:.2f}, "
+          f"perplexity {perp_t.item():.1f}/{perp_b.item():.1f}")
+    arrays = {"w::" + k: v for k, v in _np(sd).items()}
+    arrays.update(
+        x=x.numpy(), enc_b=enc_b.numpy(), enc_t=enc_t.numpy(), z_t=z_t.numpy(),
+        quant_t=q_t.contiguous().numpy(), quant_b=q_b.contiguous().numpy(),
+        diff=diff.numpy(), id_t=id_t.numpy(), id_b=id_b.numpy(),
+        perplexity_t=perp_t.numpy(), perplexity_b=perp_b.numpy(),
+        dec=dec.numpy(), dec_code=dec_code.numpy(),
+        cfg_in_channel=np.int64(ctor_kwargs["in_channel"]),
+        cfg_num_hidden_channels=np.int64(ctor_kwargs.get("num_hidden_channels", 128)),
+        cfg_n_res_block=np.int64(ctor_kwargs.get("n_res_block", 2)),
+        cfg_num_residual_channels=np.int64(ctor_kwargs.get("num_residual_channels", 32)),
+        cfg_embed_dim=np.int64(ctor_kwargs.get("embed_dim", 64)),
+        cfg_num_embeddings=np.int64(ctor_kwargs.get("num_embeddings", 512)),
+        cfg_factor_bottom=np.int64(ctor_kwargs.get("resolution_factors", {"bottom": 4})["bottom"]),
+        cfg_factor_top=np.int64(ctor_kwargs.get("resolution_factors", {"top": 2})["top"]),
+    )
+    _save(name, **arrays)
+
+
+@torch.no_grad()
+def resblock_fixture():
+    from interactive_spectrogram_inpainting.vqvae.encoder_decoder import RosinalityResBlock
+    torch.manual_seed(11)
+    blk = RosinalityResBlock(16, 8).eval()
+    x = torch.randn(2, 16, 5, 7)
+    x_in = x.clone()
+    y = blk(x_in)
+    # x_in has been overwritten by relu(x): proof of the in-place semantics
+    assert torch.equal(x_in, torch.relu(x))
+    _save("resblock.npz", x=x.numpy(), y=y.numpy(), x_after=x_in.numpy(),
+          **{"w::" + k: v for k, v in _np(blk.state_dict()).items()})
+
+
+@torch.no_grad()
+def layer_fixtures():
+    """Each layer type alone at odd sizes."""
+    torch.manual_seed(12)
+    out = {}
+    specs = {
+        "conv_k4s2": (nn.Conv2d(6, 10, 4, stride=2, padding=1), (2, 6, 10, 14)),
+        "conv_k4s2_odd": (nn.Conv2d(3, 5, 4, stride=2, padding=1), (1, 3, 9, 13)),
+        "conv_k3": (nn.Conv2d(7, 9, 3, padding=1), (2, 7, 5, 11)),
+        "conv_k1": (nn.Conv2d(12, 6, 1), (2, 12, 3, 5)),
+        "convT_k4s2": (nn.ConvTranspose2d(6, 10, 4, stride=2, padding=1), (2, 6, 5, 7)),
+        "convT_k4s2_c2": (nn.ConvTranspose2d(8, 2, 4, stride=2, padding=1), (1, 8, 6, 9)),
+    }
+    for name, (layer, shape) in specs.items():
+        x = torch.randn(*shape)
+        y = layer(x)
+        out[name + "::x"] = x.numpy()
+        out[name + "::y"] = y.numpy()
+        out[name + "::weight"] = layer.weight.detach().numpy()
+        out[name + "::bias"] = layer.bias.detach().numpy()
+    _save("layers.npz", **out)
+
+
+@torch.no_grad()
+def quantizer_fixtures():
+    from interactive_spectrogram_inpainting.vqvae.bottleneck import QuantizedBottleneck
+    torch.manual_seed(13)
+    # (1) Gaussian case at the default D=64, K=512
+    q = QuantizedBottleneck(64, 512).eval()
+    z = torch.randn(3, 8, 16, 64)
+    quant, diff, ind, perp = q(z)
+    out = dict(g_z=z.numpy(), g_embed=q.embed.numpy(), g_quant=quant.numpy(), g_diff=diff.numpy(),
+               g_ind=ind.numpy(), g_perp=perp.numpy(),
+               g_embed_code=q.embed_code(ind).numpy())
+    # (2) engineered exact tie: codes 5 and 9 identical, inputs equal to them
+    q2 = QuantizedBottleneck(8, 16).eval()
+    q2.embed[:, 9] = q2.embed[:, 5]
+    q2.embed[:, 12] = q2.embed[:, 2]
+    z2 = torch.randn(1, 4, 6, 8)
+    z2[0, 0, 0] = q2.embed[:, 5]
+    z2[0, 1, 2] = q2.embed[:, 12] * 1.0
+    z2[0, 3, 3] = 0.5 * (q2.embed[:, 1] + q2.embed[:, 3])
+    quant2, diff2, ind2, perp2 = q2(z2)
+    assert ind2[0, 0, 0].item() == 5 and ind2[0, 1, 2].item() == 2
+    out.update(t_z=z2.numpy(), t_embed=q2.embed.numpy(), t_quant=quant2.numpy(),
+               t_diff=diff2.numpy(), t_ind=ind2.numpy(), t_perp=perp2.numpy())
+    # (3) train mode: EMA buffers after 1 and 2 steps
+    torch.manual_seed(14)
+    q3 = QuantizedBottleneck(16, 32).train()
+    e0 = q3.embed.clone()
+    out["e_embed0"] = e0.numpy()
+    import warnings
+    for step in (1, 2):
+        zt = torch.randn(2, 5, 7, 16)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            quant3, diff3, ind3, perp3 = q3(zt)
+        out[f"e_z{step}"] = zt.numpy()
+        out[f"e_ind{step}"] = ind3.numpy()
+        out[f"e_embed{step}"] = q3.embed.clone().numpy()
+        out[f"e_cluster_size{step}"] = q3.cluster_size.clone().numpy()
+        out[f"e_embed_avg{step}"] = q3.embed_avg.clone().numpy()
+        out[f"e_diff{step}"] = diff3.numpy()
+        out[f"e_perp{step}"] = perp3.numpy()
+    _save("quantizer.npz", **out)
+
+
+@torch.no_grad()
+def codemap_fixtures():
+    from interactive_spectrogram_inpainting.priors.codemaps_helpers import (
+        SimpleCodemapsHelper, ZigZagCodemapsHelper)
+    import inspect
+    out = {}
+    print("ZigZag signature:", inspect.signature(ZigZagCodemapsHelper.__init__))
+    for (F_, T_) in [(4, 4), (4, 3), (64, 64), (32, 128), (256, 32)]:
+        cm = torch.arange(F_ * T_).reshape(1, F_, T_)
+        h = SimpleCodemapsHelper(F_, T_)
+        seq = h.to_sequence(cm)
+        assert torch.equal(h.to_time_frequency_map(seq), cm)
+        out[f"simple_{F_}x{T_}"] = seq.numpy()
+    for (F_, T_, pf, pt) in [(4, 4, 2, 2), (64, 64, 2, 2), (32, 128, 2, 2), (256, 32, 2, 2),
+                             (16, 8, 4, 2)]:
+        cm = torch.arange(F_ * T_).reshape(1, F_, T_)
+        h = ZigZagCodemapsHelper(F_, T_, pf, pt)
+        seq = h.to_sequence(cm)
+        assert torch.equal(h.to_time_frequency_map(seq), cm)
+        out[f"zigzag_{F_}x{T_}_{pf}x{pt}"] = seq.numpy()
+        # 4-D (embedding) input
+        cm4 = torch.arange(2 * F_ * T_ * 3).reshape(2, F_, T_, 3)
+        seq4 = h.to_sequence(cm4)
+        assert torch.equal(h.to_time_frequency_map(seq4), cm4)
+        if F_ * T_ <= 1024:
+            out[f"zigzag4d_{F_}x{T_}_{pf}x{pt}"] = seq4.numpy()
+            out[f"zigzag4d_logits_{F_}x{T_}_{pf}x{pt}"] = h.to_time_frequency_map(
+                seq4, permute_output_as_logits=True).numpy()
+    _save("codemaps.npz", **out)
+
+
+def main():
+    os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+    _install_stubs()
+    sys.path.insert(0, str(REF))
+    torch.set_num_threads(4)
+    # reduced config
+    vqvae_fixture("vqvae_small.npz",
+                  dict(in_channel=2, num_hidden_channels=32, n_res_block=2,
+                       num_residual_channels=8, embed_dim=16, num_embeddings=64,
+                       resolution_factors={"bottom": 4, "top": 2}),
+                  (2, 2, 32, 48), seed=21)
+    # default config at tiny spatial size
+    vqvae_fixture("vqvae_default_tiny.npz",
+                  dict(in_channel=2, resolution_factors={"bottom": 4, "top": 2}),
+                  (2, 2, 32, 64), seed=22)
+    # other resolution factors (8 bottom / 4 top) on a reduced config
+    vqvae_fixture("vqvae_f8_f4.npz",
+                  dict(in_channel=2, num_hidden_channels=16, n_res_block=1,
+                       num_residual_channels=8, embed_dim=8, num_embeddings=32,
+                       resolution_factors={"bottom": 8, "top": 4}),
+                  (1, 2, 64, 64), seed=23)
+    resblock_fixture()
+    layer_fixtures()
+    quantizer_fixtures()
+    codemap_fixtures()
+
+
+if __name__ == "__main__":
+    main()

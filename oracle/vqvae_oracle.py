@@ -1,0 +1,320 @@
+"""CPU oracle for the VQ-VAE-2 hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+This file restates, in plain functional PyTorch-CPU fp32, the arithmetic of
+the reference's `VQVAE.forward` path.  Only `tests/`, `__graft_entry__.smoke()`
+and `bench.py`'s `cpu_baseline` leg may import it; the product package
+(`interactive-spectrogram-inpainting_amd/`) never does.
+
+Pinned: `tests/test_oracle_golden.py` checks every function here against the
+fixtures in `tests/golden/` which were produced by importing the reference
+itself in the build container (`oracle/make_golden.py`).
+
+Reference citations (paths relative to /root/reference):
+  res_block      interactive_spectrogram_inpainting/vqvae/encoder_decoder.py:18-35
+  encoder        .../vqvae/encoder_decoder.py:38-126
+  decoder        .../vqvae/encoder_decoder.py:129-227
+  quantize       .../vqvae/bottleneck.py:53-104
+  encode/decode  .../vqvae/vqvae.py:245-302
+
+All tensors are NCHW fp32 like the reference; state dict keys are the
+reference's own (`enc_b.blocks.0.weight`, `quantize_t.embed`, ...).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Mapping, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+StateDict = Mapping[str, Tensor]
+
+# number of stride-2 stages for each supported resolution factor
+_STAGES = {2: 1, 4: 2, 8: 3, 16: 4}
+
+
+def _down_channels(in_channel: int, channel: int, factor: int):
+    """(cin, cout) of every strided conv of an encoder
+    (encoder_decoder.py:53-113)."""
+    if factor == 16:
+        chans = [in_channel, channel // 4, channel // 2, 3 * channel // 4, channel]
+    elif factor == 8:
+        chans = [in_channel, channel // 2, channel // 2, channel]
+    elif factor == 4:
+        chans = [in_channel, channel // 2, channel]
+    elif factor == 2:
+        chans = [in_channel, channel // 2]
+    else:
+        raise ValueError(f"Unexpected resolution factor {factor}")
+    return list(zip(chans[:-1], chans[1:]))
+
+
+def _up_channels(channel: int, out_channel: int, factor: int):
+    """(cin, cout) of every transposed conv of a decoder
+    (encoder_decoder.py:153-216)."""
+    if factor == 16:
+        chans = [channel, 3 * channel // 4, channel // 2, channel // 4, out_channel]
+    elif factor == 8:
+        chans = [channel, channel // 2, channel // 2, out_channel]
+    elif factor == 4:
+        chans = [channel, channel // 2, out_channel]
+    elif factor == 2:
+        chans = [channel, out_channel]
+    else:
+        raise ValueError(f"Unexpected resolution factor {factor}")
+    return list(zip(chans[:-1], chans[1:]))
+
+
+def res_block(x: Tensor, sd: StateDict, prefix: str) -> Tensor:
+    """RosinalityResBlock (encoder_decoder.py:18-35).
+
+    The first ReLU of the block is in-place, so it overwrites the tensor the
+    residual connection later reads: the block returns
+    relu(x) + conv1x1(relu(conv3x3(relu(x)))), NOT x + ... .
+    """
+    r = F.relu(x)
+    h = F.conv2d(r, sd[prefix + "conv.1.weight"], sd[prefix + "conv.1.bias"], padding=1)
+    h = F.relu(h)
+    h = F.conv2d(h, sd[prefix + "conv.3.weight"], sd[prefix + "conv.3.bias"])
+    return h + r
+
+
+def encoder(x: Tensor, sd: StateDict, prefix: str, factor: int, n_res_block: int,
+            use_local_kernels: bool = False) -> Tensor:
+    """RosinalityEncoder.forward (encoder_decoder.py:38-126)."""
+    k = 2 if use_local_kernels else 4
+    idx = 0
+    n_stages = _STAGES[factor]
+    for s in range(n_stages):
+        x = F.conv2d(x, sd[f"{prefix}blocks.{idx}.weight"], sd[f"{prefix}blocks.{idx}.bias"],
+                     stride=2, padding=1)
+        idx += 1
+        # every strided conv is followed by a ReLU (encoder_decoder.py:53-113)
+        x = F.relu(x)
+        idx += 1
+    assert k == sd[f"{prefix}blocks.0.weight"].shape[-1]
+    x = F.conv2d(x, sd[f"{prefix}blocks.{idx}.weight"], sd[f"{prefix}blocks.{idx}.bias"],
+                 padding=1)
+    idx += 1
+    for _ in range(n_res_block):
+        x = res_block(x, sd, f"{prefix}blocks.{idx}.")
+        idx += 1
+    return F.relu(x)
+
+
+def decoder(x: Tensor, sd: StateDict, prefix: str, factor: int, n_res_block: int) -> Tensor:
+    """RosinalityDecoder.forward (encoder_decoder.py:129-227)."""
+    idx = 0
+    x = F.conv2d(x, sd[f"{prefix}blocks.{idx}.weight"], sd[f"{prefix}blocks.{idx}.bias"],
+                 padding=1)
+    idx += 1
+    for _ in range(n_res_block):
+        x = res_block(x, sd, f"{prefix}blocks.{idx}.")
+        idx += 1
+    x = F.relu(x)
+    idx += 1
+    n_stages = _STAGES[factor]
+    for s in range(n_stages):
+        x = F.conv_transpose2d(x, sd[f"{prefix}blocks.{idx}.weight"],
+                               sd[f"{prefix}blocks.{idx}.bias"], stride=2, padding=1)
+        idx += 1
+        if s != n_stages - 1:
+            x = F.relu(x)
+            idx += 1
+    return x
+
+
+def quantize(z: Tensor, embed: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
+    """QuantizedBottleneck.forward in eval mode (bottleneck.py:53-101).
+
+    z      [..., D]  (channels-last)
+    embed  [D, K]    (column = code)
+    returns (straight-through quantize [..., D], diff [], idx int64 [...],
+             perplexity [])
+    """
+    dim, n_embed = embed.shape
+    flat = z.reshape(-1, dim)
+    dist = (flat.pow(2).sum(1, keepdim=True)
+            - 2 * flat @ embed
+            + embed.pow(2).sum(0, keepdim=True))
+    _, ind = (-dist).max(1)
+    onehot_mean = torch.bincount(ind, minlength=n_embed).to(flat.dtype) / flat.shape[0]
+    ind = ind.view(*z.shape[:-1])
+    q = F.embedding(ind, embed.t())
+    diff = (q - z).pow(2).mean()
+    q_st = z + (q - z)
+    perplexity = torch.exp(-torch.sum(onehot_mean * torch.log(onehot_mean.clamp(min=1e-7))))
+    return q_st, diff, ind, perplexity
+
+
+def ema_update(flat: Tensor, ind: Tensor, embed: Tensor, cluster_size: Tensor,
+               embed_avg: Tensor, decay: float = 0.99, eps: float = 1e-5
+               ) -> Tuple[Tensor, Tensor, Tensor]:
+    """Train-mode EMA codebook update (bottleneck.py:79-92); returns the new
+    (embed, cluster_size, embed_avg) without mutating the arguments."""
+    n_embed = embed.shape[1]
+    onehot = F.one_hot(ind.reshape(-1), n_embed).to(flat.dtype)
+    cs = cluster_size * decay + (1 - decay) * onehot.sum(0)
+    ea = embed_avg * decay + (1 - decay) * (flat.t() @ onehot)
+    n = cs.sum()
+    cs_norm = (cs + eps) / (n + n_embed * eps) * n
+    return ea / cs_norm.unsqueeze(0), cs, ea
+
+
+def embed_code(ind: Tensor, embed: Tensor) -> Tensor:
+    """QuantizedBottleneck.embed_code (bottleneck.py:103-104)."""
+    return F.embedding(ind, embed.t())
+
+
+class Config:
+    """Constructor arguments that shape the arithmetic (vqvae.py:65-93)."""
+
+    def __init__(self, in_channel=2, num_hidden_channels=128, n_res_block=2,
+                 num_residual_channels=32, embed_dim=64, num_embeddings=512,
+                 resolution_factors=None, adapt_quantized_durations=True):
+        self.in_channel = in_channel
+        self.num_hidden_channels = num_hidden_channels
+        self.n_res_block = n_res_block
+        self.num_residual_channels = num_residual_channels
+        self.embed_dim = embed_dim
+        self.num_embeddings = num_embeddings
+        self.resolution_factors = dict(resolution_factors or {"bottom": 4, "top": 2})
+        self.adapt_quantized_durations = adapt_quantized_durations
+
+
+def encode(x: Tensor, sd: StateDict, cfg: Config):
+    """VQVAE.encode (vqvae.py:251-278) without the GANSynth normaliser."""
+    fb, ft = cfg.resolution_factors["bottom"], cfg.resolution_factors["top"]
+    enc_b = encoder(x, sd, "enc_b.", fb, cfg.n_res_block)
+    enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
+
+    z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    q_t, diff_t, id_t, perp_t = quantize(z_t, sd["quantize_t.embed"])
+    q_t = q_t.permute(0, 3, 1, 2)
+
+    dec_t = decoder(q_t, sd, "dec_t.", ft, cfg.n_res_block)
+    if cfg.adapt_quantized_durations:
+        w = min(dec_t.shape[-1], enc_b.shape[-1])
+        dec_t = dec_t[..., :w]
+        enc_b = enc_b[..., :w]
+    cat = torch.cat([dec_t, enc_b], 1)
+    z_b = F.conv2d(cat, sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+    q_b, diff_b, id_b, perp_b = quantize(z_b, sd["quantize_b.embed"])
+    q_b = q_b.permute(0, 3, 1, 2)
+    diff = diff_t.unsqueeze(0) + diff_b.unsqueeze(0)
+    return q_t, q_b, diff, id_t, id_b, perp_t, perp_b
+
+
+def decode(q_t: Tensor, q_b: Tensor, sd: StateDict, cfg: Config) -> Tensor:
+    """VQVAE.decode (vqvae.py:280-286), post_process being the identity when
+    no normaliser statistics / min magnitude are configured."""
+    up = q_t
+    n_up = int(math.log2(cfg.resolution_factors["top"]))
+    for i in range(n_up):
+        up = F.conv_transpose2d(up, sd[f"upsample_top_to_bottom.{i}.weight"],
+                                sd[f"upsample_top_to_bottom.{i}.bias"], stride=2, padding=1)
+    quant = torch.cat([up, q_b], 1)
+    return decoder(quant, sd, "dec.", cfg.resolution_factors["bottom"], cfg.n_res_block)
+
+
+def decode_code(id_t: Tensor, id_b: Tensor, sd: StateDict, cfg: Config) -> Tensor:
+    """VQVAE.decode_code (vqvae.py:288-295)."""
+    q_t = embed_code(id_t, sd["quantize_t.embed"]).permute(0, 3, 1, 2)
+    q_b = embed_code(id_b, sd["quantize_b.embed"]).permute(0, 3, 1, 2)
+    return decode(q_t, q_b, sd, cfg)
+
+
+def forward(x: Tensor, sd: StateDict, cfg: Config):
+    """VQVAE.forward (vqvae.py:245-249): (dec, diff, perp_t, perp_b, id_t, id_b)."""
+    q_t, q_b, diff, id_t, id_b, perp_t, perp_b = encode(x, sd, cfg)
+    dec = decode(q_t, q_b, sd, cfg)
+    return dec, diff, perp_t, perp_b, id_t, id_b
+
+
+def init_state_dict(cfg: Config, seed: int = 1) -> Dict[str, Tensor]:
+    """Random fp32 weights with the reference's key names and shapes and the
+    default torch init distributions (uniform(-1/sqrt(fan_in), ..)); used for
+    synthetic benchmarks only.  Not bit-equal to nn.Module's init stream."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+
+    def conv(name, cout, cin, k):
+        bound = 1.0 / math.sqrt(cin * k * k)
+        sd[name + ".weight"] = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
+
+    def convT(name, cin, cout, k):
+        bound = 1.0 / math.sqrt(cout * k * k)
+        sd[name + ".weight"] = (torch.rand(cin, cout, k, k, generator=g) * 2 - 1) * bound
+        sd[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
+
+    C, R, D = cfg.num_hidden_channels, cfg.num_residual_channels, cfg.embed_dim
+
+    def enc(prefix, cin, factor):
+        idx = 0
+        for (a, b) in _down_channels(cin, C, factor):
+            conv(f"{prefix}blocks.{idx}", b, a, 4)
+            idx += 2
+            last = b
+        conv(f"{prefix}blocks.{idx}", C, last, 3)
+        idx += 1
+        for _ in range(cfg.n_res_block):
+            conv(f"{prefix}blocks.{idx}.conv.1", R, C, 3)
+            conv(f"{prefix}blocks.{idx}.conv.3", C, R, 1)
+            idx += 1
+
+    def dec(prefix, cin, cout, factor):
+        idx = 0
+        conv(f"{prefix}blocks.{idx}", C, cin, 3)
+        idx += 1
+        for _ in range(cfg.n_res_block):
+            conv(f"{prefix}blocks.{idx}.conv.1", R, C, 3)
+            conv(f"{prefix}blocks.{idx}.conv.3", C, R, 1)
+            idx += 1
+        idx += 1  # ReLU
+        for (a, b) in _up_channels(C, cout, factor):
+            convT(f"{prefix}blocks.{idx}", a, b, 4)
+            idx += 2
+
+    fb, ft = cfg.resolution_factors["bottom"], cfg.resolution_factors["top"]
+    enc("enc_b.", cfg.in_channel, fb)
+    enc("enc_t.", C, ft)
+    conv("quantize_conv_t", D, C, 1)
+    dec("dec_t.", D, D, ft)
+    conv("quantize_conv_b", D, D + C, 1)
+    for i in range(int(math.log2(ft))):
+        convT(f"upsample_top_to_bottom.{i}", D, D, 4)
+    dec("dec.", D + D, cfg.in_channel, fb)
+    for lvl in ("t", "b"):
+        e = torch.randn(D, cfg.num_embeddings, generator=g)
+        sd[f"quantize_{lvl}.embed"] = e
+        sd[f"quantize_{lvl}.cluster_size"] = torch.zeros(cfg.num_embeddings)
+        sd[f"quantize_{lvl}.embed_avg"] = e.clone()
+    return sd
+
+
+@torch.no_grad()
+def calibrate_codebooks(sd: Dict[str, Tensor], cfg: Config, x: Tensor, seed: int = 3) -> None:
+    """Re-seed each level's codebook from that level's own pre-quantisation
+    vectors on a calibration batch so that code usage is non-degenerate
+    (a randomly-initialised VQ-VAE maps everything to 1-2 codes).  In place."""
+    g = torch.Generator().manual_seed(seed)
+    fb, ft = cfg.resolution_factors["bottom"], cfg.resolution_factors["top"]
+    enc_b = encoder(x, sd, "enc_b.", fb, cfg.n_res_block)
+    enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
+    z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    flat = z_t.reshape(-1, cfg.embed_dim)
+    K = cfg.num_embeddings
+    pick = torch.randint(0, flat.shape[0], (K,), generator=g)
+    sd["quantize_t.embed"] = flat[pick].t().contiguous()
+    sd["quantize_t.embed_avg"] = sd["quantize_t.embed"].clone()
+    q_t, _, _, _ = quantize(z_t, sd["quantize_t.embed"])
+    dec_t = decoder(q_t.permute(0, 3, 1, 2), sd, "dec_t.", ft, cfg.n_res_block)
+    w = min(dec_t.shape[-1], enc_b.shape[-1])
+    cat = torch.cat([dec_t[..., :w], enc_b[..., :w]], 1)
+    z_b = F.conv2d(cat, sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+    flat = z_b.reshape(-1, cfg.embed_dim)
+    pick = torch.randint(0, flat.shape[0], (K,), generator=g)
+    sd["quantize_b.embed"] = flat[pick].t().contiguous()
+    sd["quantize_b.embed_avg"] = sd["quantize_b.embed"].clone()

@@ -1,0 +1,109 @@
+"""Pins the CPU oracle (oracle/vqvae_oracle.py) against fixtures produced by
+the reference itself (oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqvae_oracle as O
+
+
+def _load(golden_dir, name):
+    z = np.load(golden_dir / name)
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    return z, sd
+
+
+def _cfg(z):
+    return O.Config(
+        in_channel=int(z["cfg_in_channel"]), num_hidden_channels=int(z["cfg_num_hidden_channels"]),
+        n_res_block=int(z["cfg_n_res_block"]), num_residual_channels=int(z["cfg_num_residual_channels"]),
+        embed_dim=int(z["cfg_embed_dim"]), num_embeddings=int(z["cfg_num_embeddings"]),
+        resolution_factors={"bottom": int(z["cfg_factor_bottom"]), "top": int(z["cfg_factor_top"])})
+
+
+def _close(a, b, tol=1e-5):
+    a = torch.as_tensor(a, dtype=torch.float32)
+    b = torch.as_tensor(b, dtype=torch.float32)
+    denom = b.abs().max().clamp(min=1e-12)
+    err = (a - b).abs().max() / denom
+    assert err <= tol, f"max rel-to-max error {err:.3e} > {tol}"
+
+
+@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz"])
+def test_vqvae_forward_matches_reference(golden_dir, name):
+    z, sd = _load(golden_dir, name)
+    cfg = _cfg(z)
+    x = torch.from_numpy(z["x"])
+    enc_b = O.encoder(x, sd, "enc_b.", cfg.resolution_factors["bottom"], cfg.n_res_block)
+    _close(enc_b, z["enc_b"])
+    enc_t = O.encoder(enc_b, sd, "enc_t.", cfg.resolution_factors["top"], cfg.n_res_block)
+    _close(enc_t, z["enc_t"])
+    q_t, q_b, diff, id_t, id_b, p_t, p_b = O.encode(x, sd, cfg)
+    # bit-exact integer outputs
+    assert torch.equal(id_t, torch.from_numpy(z["id_t"]))
+    assert torch.equal(id_b, torch.from_numpy(z["id_b"]))
+    _close(q_t, z["quant_t"]); _close(q_b, z["quant_b"])
+    _close(diff, z["diff"]); _close(p_t, z["perplexity_t"]); _close(p_b, z["perplexity_b"])
+    dec, diff2, p_t2, p_b2, id_t2, id_b2 = O.forward(x, sd, cfg)
+    assert torch.equal(id_t2, id_t) and torch.equal(id_b2, id_b)
+    _close(dec, z["dec"])
+    _close(O.decode_code(id_t, id_b, sd, cfg), z["dec_code"])
+
+
+def test_resblock_inplace_semantics(golden_dir):
+    z, sd = _load(golden_dir, "resblock.npz")
+    x = torch.from_numpy(z["x"])
+    y = O.res_block(x, sd, "")
+    _close(y, z["y"], 1e-6)
+    # the reference mutated its input into relu(x)
+    assert np.array_equal(z["x_after"], np.maximum(z["x"], 0))
+    # and the result is NOT x + f(relu(x))
+    wrong = y - torch.relu(x) + x
+    assert (wrong - torch.from_numpy(z["y"])).abs().max() > 1e-3
+
+
+def test_layers(golden_dir):
+    import torch.nn.functional as F
+    z = np.load(golden_dir / "layers.npz")
+    t = lambda k: torch.from_numpy(z[k])
+    for name in ["conv_k4s2", "conv_k4s2_odd"]:
+        _close(F.conv2d(t(name + "::x"), t(name + "::weight"), t(name + "::bias"), stride=2, padding=1),
+               z[name + "::y"], 1e-6)
+    _close(F.conv2d(t("conv_k3::x"), t("conv_k3::weight"), t("conv_k3::bias"), padding=1), z["conv_k3::y"], 1e-6)
+    for name in ["convT_k4s2", "convT_k4s2_c2"]:
+        _close(F.conv_transpose2d(t(name + "::x"), t(name + "::weight"), t(name + "::bias"), stride=2, padding=1),
+               z[name + "::y"], 1e-6)
+
+
+def test_quantizer(golden_dir):
+    z = np.load(golden_dir / "quantizer.npz")
+    t = lambda k: torch.from_numpy(z[k])
+    for p in ("g", "t"):
+        q, diff, ind, perp = O.quantize(t(p + "_z"), t(p + "_embed"))
+        assert torch.equal(ind, t(p + "_ind"))
+        _close(q, z[p + "_quant"], 1e-6); _close(diff, z[p + "_diff"], 1e-6); _close(perp, z[p + "_perp"], 1e-6)
+    assert torch.equal(O.embed_code(t("g_ind"), t("g_embed")), t("g_embed_code"))
+    # engineered ties resolve to the lowest index
+    assert int(z["t_ind"][0, 0, 0]) == 5 and int(z["t_ind"][0, 1, 2]) == 2
+    # train-mode EMA trajectory
+    embed = t("e_embed0"); cs = torch.zeros(embed.shape[1]); ea = embed.clone()
+    for step in (1, 2):
+        zt = t(f"e_z{step}")
+        _, diff, ind, perp = O.quantize(zt, embed)
+        assert torch.equal(ind, t(f"e_ind{step}"))
+        embed, cs, ea = O.ema_update(zt.reshape(-1, zt.shape[-1]), ind, embed, cs, ea)
+        _close(embed, z[f"e_embed{step}"], 1e-5); _close(cs, z[f"e_cluster_size{step}"], 1e-6)
+        _close(ea, z[f"e_embed_avg{step}"], 1e-6)
+
+
+def test_init_state_dict_keys_match_reference(golden_dir):
+    z, sd = _load(golden_dir, "vqvae_default_tiny.npz")
+    mine = O.init_state_dict(_cfg(z))
+    assert set(mine) == set(sd)
+    for k in sd:
+        assert mine[k].shape == sd[k].shape, k
+    z, sd = _load(golden_dir, "vqvae_f8_f4.npz")
+    mine = O.init_state_dict(_cfg(z))
+    assert set(mine) == set(sd)
+    for k in sd:
+        assert mine[k].shape == sd[k].shape, k

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: VQVAE.forward (encode + 2x quantize + decode),
+eval / no-grad, batch 64 of synthetic [2,128,512] spectrograms per GPU
+(BASELINE.json configs[1]).  One process per GPU; ranks are independent
+replicas of the path over disjoint batches (no data-path collective: weak
+scaling), a barrier + synchronize brackets the timed region and the slowest
+rank's time is used.
+
+Prints ONE JSON line on rank 0:
+  value     spectrograms/s over all ranks, inputs resident in HBM
+  roofline  the dominant kernel (by summed HIP-event time inside the timed
+            region) priced on its algorithmic FLOPs against the gfx950 fp32
+            matrix peak (157.3 TFLOP/s; the path computes in exact fp32)
+  cpu_baseline  the CPU oracle (oracle/vqvae_oracle.py, torch-CPU fp32) timed
+            on this host on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+for _p in (str(ROOT), str(ROOT / "interactive-spectrogram-inpainting_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+HBM_PEAK_GBS = 8000.0
+
+
+def _build_model(device, seed=1):
+    """Default-constructed VQVAE with torch's default init; each codebook is
+    then re-seeded from that level's own pre-quantisation vectors (computed by
+    the HIP path itself) so that code usage is non-degenerate."""
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    torch.manual_seed(seed)
+    m = VQVAE(in_channel=2).to(device).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        xc = torch.randn(2, 2, 128, 512, generator=g).to(device)
+        enc_b = m.enc_b(xc)
+        enc_t = m.enc_t(enc_b)
+        z_t = m.quantize_conv_t.run(enc_t, relu=False).permute(0, 2, 3, 1).reshape(-1, m.embed_dim)
+        pick = torch.randint(0, z_t.shape[0], (m.n_embed_t,), generator=g).to(device)
+        m.quantize_t.embed.copy_(z_t[pick].t())
+        q_t = m.quantize_t(z_t.reshape(2, enc_t.shape[2], enc_t.shape[3], -1))[0].permute(0, 3, 1, 2)
+        dec_t = m.dec_t(q_t)
+        z_b = m.quantize_conv_b.run(dec_t, relu=False, x2=enc_b).permute(0, 2, 3, 1).reshape(-1, m.embed_dim)
+        pick = torch.randint(0, z_b.shape[0], (m.n_embed_b,), generator=g).to(device)
+        m.quantize_b.embed.copy_(z_b[pick].t())
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    return m, sd
+
+
+def _cpu_baseline(sd, batch=16, iters=2):
+    """Oracle forward on the host cores: bounded sample (batch 16, same tensor shape)."""
+    from oracle import vqvae_oracle as O
+    cfg = O.Config(in_channel=2)
+    cores = torch.get_num_threads()
+    x = torch.randn(batch, 2, 128, 512, generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        O.forward(x[:2], sd, cfg)  # warm-up
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            O.forward(x, sd, cfg)
+        dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 3), "unit": "spectrograms/s", "cores": cores,
+            "kind": "port", "sample": f"{iters} x VQVAE.forward on batch {batch} of [2,128,512] fp32 "
+                                       f"(oracle/vqvae_oracle.py, torch-CPU)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from interactive_spectrogram_inpainting import _hip
+    model, sd = _build_model(device)
+    x = torch.randn(args.batch, 2, 128, 512, generator=torch.Generator().manual_seed(100 + rank)).to(device)
+    L = _hip.lib()
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = model(x)
+        barrier()
+        L.isi_prof_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(x)
+        barrier()
+        dt = time.perf_counter() - t0
+        L.isi_prof_enable(0)
+    assert torch.isfinite(out[0]).all()
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    # ---- per-kernel HIP-event timing recorded inside the timed region
+    kernels = []
+    for kid in range(L.isi_prof_num_kernels()):
+        n, ms, fl, by = C.c_longlong(), C.c_double(), C.c_double(), C.c_double()
+        _hip.check(L.isi_prof_read(kid, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "isi_prof_read")
+        if n.value:
+            kernels.append({"kernel": L.isi_prof_kernel_name(kid).decode(), "launches": n.value,
+                            "ms": ms.value, "flops": fl.value, "bytes": by.value})
+    kernels.sort(key=lambda k: -k["ms"])
+
+    if rank == 0:
+        dom = kernels[0]
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
+                "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
+                "launches_per_step": dom["launches"] // args.steps,
+                "share_of_step_time": round(dom["ms"] / (dt * 1e3), 3),
+                "hbm_algorithmic_GBs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1)}
+        line = {
+            "metric": "spectrograms/sec VQ-VAE fwd+quantize @B64",
+            "value": round(world * args.batch * args.steps / dt, 2),
+            "unit": "spectrograms/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VQVAE.forward (encode + quantize x2 + decode), eval, default ctor "
+                                   "(128 hidden, 2 res blocks, D=64, K=512, factors 4/2)",
+                       "batch_per_gpu": args.batch, "input": "[2,128,512] fp32 randn",
+                       "weights": "random init, codebooks calibrated on encoder outputs",
+                       "parallelism": f"replicas x{world} (no data-path collective)"},
+            "roofline": roof,
+            "kernels": [{"kernel": k["kernel"], "launches_per_step": k["launches"] // args.steps,
+                         "ms_per_step": round(k["ms"] / args.steps, 4),
+                         "TFLOPs": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
+                         "GBs": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)} for k in kernels],
+        }
+        if not args.no_cpu_baseline and world >= 1:
+            line["cpu_baseline"] = _cpu_baseline(sd)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

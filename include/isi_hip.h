@@ -1,0 +1,220 @@
+/*
+ * isi_hip.h -- C-ABI of the MI355X (gfx950) compute library behind the
+ * `interactive_spectrogram_inpainting.vqvae` module API.
+ *
+ * Boundary B4 of SURVEY.md section 8(b): plain `extern "C"` functions, raw
+ * device pointers + sizes + the caller's HIP stream (passed as void*), no
+ * allocation inside (workspace is passed in), no global mutable state,
+ * re-entrant.  Every function returns 0 on success or a negative ISI_E_* code;
+ * nothing is thrown across the boundary.
+ *
+ * The reference has no native code: each entry point replaces the stock
+ * torch.nn op(s) reached from the cited reference line(s).  Paths are relative
+ * to the reference repository root.
+ *
+ * All activations handled by this library are fp32.  Internal activations are
+ * channels-last (N,H,W,C); tensors crossing the reference's API are N,C,H,W and
+ * are described to the kernels by explicit element strides.
+ */
+#ifndef ISI_HIP_H
+#define ISI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISI_OK 0
+#define ISI_E_INVALID (-1)     /* bad argument / unsupported shape            */
+#define ISI_E_LAUNCH (-2)      /* HIP launch or runtime failure               */
+#define ISI_E_WORKSPACE (-3)   /* workspace too small                         */
+#define ISI_E_UNSUPPORTED (-4) /* configuration outside the implemented range */
+
+/* Library / build identification ("isi_hip gfx950 <n>"). */
+const char *isi_version(void);
+/* Last HIP error string seen by this thread's most recent failing call. */
+const char *isi_last_error(void);
+
+/* sizeof() of the structs below as compiled into the library, so that FFI
+ * bindings can verify their own layout: which = 0 isi_src, 1 isi_dst,
+ * 2 isi_conv_w, 3 isi_encoder_w, 4 isi_decoder_w, 5 isi_codebook_w,
+ * 6 isi_vqvae_w, 7 isi_vqvae_out.  Returns 0 for an unknown id. */
+size_t isi_abi_struct_bytes(int which);
+
+/* x = max(x, 0) in place over n floats: the in-place nn.ReLU with which
+ * RosinalityResBlock overwrites its caller's tensor (encoder_decoder.py:23). */
+int isi_relu_inplace_f32(float *x, int64_t n, void *stream);
+
+/* ------------------------------------------------- measurement (bench.py) */
+/* Per-launch timing with HIP events recorded on the launch stream.  State is
+ * per calling thread; enabling clears earlier records.  isi_prof_read blocks
+ * until the recorded events have completed and returns, for one kernel id in
+ * [0, isi_prof_num_kernels()), the number of launches, their summed duration
+ * (ms) and their summed algorithmic FLOPs / bytes. */
+int isi_prof_enable(int on);
+int isi_prof_num_kernels(void);
+const char *isi_prof_kernel_name(int kernel_id);
+int isi_prof_read(int kernel_id, long long *launches, double *ms, double *flops,
+                  double *bytes);
+
+/* ---------------------------------------------------------------- packing */
+
+/* Conv2d weight [Cout,Cin,KH,KW] (torch layout) -> [Cout][Kpad] with
+ * k = (kh*KW + kw)*Cin + ci, zero padded up to Kpad = roundup(KH*KW*Cin, 32).
+ * Replaces nothing in the reference: layout preparation for
+ * isi_conv2d_f32 (encoder_decoder.py:95-112,138; vqvae.py:149-150,175-177). */
+int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin,
+                             int KH, int KW, void *stream);
+size_t isi_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
+
+/* ConvTranspose2d(k=4,s=2,p=1) weight [Cin,Cout,4,4] -> 4 phase matrices
+ * [phase=py*2+px][Cout][Kpad], k = (ty*2+tx)*Cin + ci, tap (ty,tx) of phase
+ * (py,px) reading torch tap (ky,kx) = (3-py-2ty, 3-px-2tx).
+ * (encoder_decoder.py:199-215; vqvae.py:193-201). */
+int isi_pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin,
+                                   int Cout, void *stream);
+size_t isi_packed_convT_k4s2_weight_floats(int Cin, int Cout);
+
+/* Codebook `embed` [D,K] (column = code, bottleneck.py:47-51) -> row-major
+ * [K][D] plus e2[K] = sum_d embed[d,k]^2 (the third term of bottleneck.py:59). */
+int isi_pack_codebook_f32(const float *embed, float *codes_kd, float *e2, int D,
+                          int K, void *stream);
+
+/* ------------------------------------------------------------ convolution */
+
+/* One source of a (possibly channel-concatenated) convolution input. */
+typedef struct isi_src {
+  const float *ptr;
+  int C;                   /* channels taken from this source              */
+  int64_t sn, sc, sh, sw;  /* element strides                              */
+} isi_src;
+
+typedef struct isi_dst {
+  float *ptr;
+  int64_t sn, sc, sh, sw; /* element strides of the FULL output tensor     */
+} isi_dst;
+
+/* Conv2d, groups=1, square stride, symmetric zero padding, fp32.
+ *   out = [relu]( conv(cat(src0, src1), W) + bias [+ residual] )
+ * src1.ptr may be NULL (single source); residual.ptr may be NULL.  `residual`
+ * has the logical shape of the output.  `packed_w` comes from
+ * isi_pack_conv_weight_f32.  Replaces nn.Conv2d (+ nn.ReLU, + the residual add
+ * and torch.cat) at encoder_decoder.py:22-35,95-112,138 and vqvae.py:260,270-272,282. */
+int isi_conv2d_f32(const isi_src *src0, const isi_src *src1,
+                   const float *packed_w, const float *bias,
+                   const isi_src *residual, const isi_dst *dst, int B, int H,
+                   int W, int Cout, int KH, int KW, int stride, int pad,
+                   int relu, void *stream);
+
+/* ConvTranspose2d(kernel 4, stride 2, padding 1), groups=1, fp32:
+ *   out[B, 2H, 2W, Cout] = [relu]( convT(src, W) + bias )
+ * computed as four stride-1 2x2 phase convolutions.  `packed_w` comes from
+ * isi_pack_convT_k4s2_weight_f32.  Replaces nn.ConvTranspose2d (+ nn.ReLU) at
+ * encoder_decoder.py:199-215 and vqvae.py:193-201. */
+int isi_conv_transpose2d_k4s2_f32(const isi_src *src, const float *packed_w,
+                                  const float *bias, const isi_dst *dst, int B,
+                                  int H, int W, int Cout, int relu,
+                                  void *stream);
+
+/* ----------------------------------------------------------- quantization */
+
+/* L2 nearest-neighbour vector quantisation, eval mode
+ * (QuantizedBottleneck.forward, bottleneck.py:53-61,75-77,94-101).
+ *   z        [N, D]   channels-last pre-quantisation vectors
+ *   codes_kd [K, D], e2 [K]  from isi_pack_codebook_f32
+ *   idx_out  [N] int64   argmin_k ( (|z|^2 - 2 z.e_k) + |e_k|^2 ), ties -> lowest k
+ *   q_out    [N, D]   z + (e_idx - z)      (straight-through value, :95)
+ *   counts   [K] int32  histogram of idx (caller zeroes; accumulated)
+ *   sse_part [isi_vq_num_partials(N)] fp32 per-workgroup sum (e_idx - z)^2
+ * Requirements: D in {8,16,32,64}, K % 32 == 0, K*(D+4)*4 + K*4 <= 150 KiB. */
+int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2,
+                       int64_t *idx_out, float *q_out, int32_t *counts,
+                       float *sse_part, int64_t N, int D, int K, void *stream);
+int isi_vq_num_partials(int64_t N);
+
+/* diff = sum(sse_part)/(N*D); perplexity = exp(-sum p log(max(p,1e-7))),
+ * p = counts/N  (bottleneck.py:94,97-100).  Writes out2[0]=diff, out2[1]=perplexity. */
+int isi_vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts,
+                        int K, int64_t N, int D, float *out2, void *stream);
+
+/* embed_code: out[N, D] = codes_kd[idx[n], :]  (bottleneck.py:103-104).
+ * Index range is not reported from the device: callers validate 0 <= idx < K
+ * (out-of-range values are clamped so that no read leaves the codebook). */
+int isi_embed_code_f32(const int64_t *idx, const float *codes_kd, float *out,
+                       int64_t N, int D, int K, void *stream);
+
+/* ------------------------------------------------- whole VQ-VAE-2 forward */
+
+#define ISI_MAX_STAGES 4
+#define ISI_MAX_RES 8
+
+typedef struct isi_conv_w {
+  const float *w;    /* packed weight */
+  const float *bias; /* [Cout]        */
+  int Cin, Cout;
+} isi_conv_w;
+
+typedef struct isi_encoder_w { /* RosinalityEncoder, encoder_decoder.py:38-126 */
+  int n_down;                          /* number of k4 s2 convs              */
+  isi_conv_w down[ISI_MAX_STAGES];
+  isi_conv_w conv3;                    /* k3 conv after the strided stack    */
+  int n_res;
+  isi_conv_w res3[ISI_MAX_RES];        /* ResBlock conv.1 (k3, C -> R)       */
+  isi_conv_w res1[ISI_MAX_RES];        /* ResBlock conv.3 (k1, R -> C)       */
+} isi_encoder_w;
+
+typedef struct isi_decoder_w { /* RosinalityDecoder, encoder_decoder.py:129-227 */
+  isi_conv_w conv3;
+  int n_res;
+  isi_conv_w res3[ISI_MAX_RES];
+  isi_conv_w res1[ISI_MAX_RES];
+  int n_up;
+  isi_conv_w up[ISI_MAX_STAGES];       /* packed transposed convs            */
+} isi_decoder_w;
+
+typedef struct isi_codebook_w {
+  const float *codes_kd; /* [K][D] */
+  const float *e2;       /* [K]    */
+  int D, K;
+} isi_codebook_w;
+
+typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
+  int in_channel;
+  isi_encoder_w enc_b, enc_t;
+  isi_conv_w quantize_conv_t, quantize_conv_b;
+  isi_codebook_w quantize_t, quantize_b;
+  isi_decoder_w dec_t, dec;
+  int n_upsample;
+  isi_conv_w upsample[ISI_MAX_STAGES];
+} isi_vqvae_w;
+
+/* Outputs of VQVAE.encode / forward (vqvae.py:245-278).  Any pointer may be
+ * NULL except the ones the requested mode needs. */
+typedef struct isi_vqvae_out {
+  float *dec;        /* [B, in_channel, H, W]  NCHW      (forward/decode)   */
+  float *quant_t;    /* [B, Ht, Wt, D]  channels-last    (encode/forward)   */
+  float *quant_b;    /* [B, Hb, Wb, D]  channels-last                        */
+  int64_t *id_t;     /* [B, Ht, Wt]                                          */
+  int64_t *id_b;     /* [B, Hb, Wb]                                          */
+  float *scalars;    /* [4]: diff_t, perplexity_t, diff_b, perplexity_b      */
+} isi_vqvae_out;
+
+#define ISI_MODE_ENCODE 1  /* VQVAE.encode        vqvae.py:251-278 */
+#define ISI_MODE_DECODE 2  /* VQVAE.decode        vqvae.py:280-286 (quant_t/b are inputs) */
+#define ISI_MODE_FORWARD 3 /* VQVAE.forward       vqvae.py:245-249 */
+
+/* Bytes of scratch `isi_vqvae_run` needs for this shape. */
+size_t isi_vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W);
+
+/* x: [B, in_channel, H, W] NCHW contiguous fp32 (ignored in DECODE mode).
+ * H and W must be divisible by the total down-sampling factor. */
+int isi_vqvae_run(const isi_vqvae_w *w, int mode, const float *x, int B, int H,
+                  int W, const isi_vqvae_out *out, void *workspace,
+                  size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISI_HIP_H */

@@ -1,0 +1,97 @@
+// extern "C" surface of libisi_hip.so (declared in include/isi_hip.h).
+#include "isi_common.h"
+#include "isi_internal.h"
+#include "prof.h"
+
+namespace isi {
+static thread_local char g_last_error[512] = "";
+void set_last_error(const char *msg) {
+  strncpy(g_last_error, msg ? msg : "", sizeof g_last_error - 1);
+  g_last_error[sizeof g_last_error - 1] = 0;
+}
+}  // namespace isi
+
+using namespace isi;
+static inline hipStream_t S(void *s) { return static_cast<hipStream_t>(s); }
+
+extern "C" {
+
+const char *isi_version(void) { return "isi_hip gfx950 1"; }
+const char *isi_last_error(void) { return g_last_error; }
+
+size_t isi_abi_struct_bytes(int which) {
+  switch (which) {
+    case 0: return sizeof(isi_src);
+    case 1: return sizeof(isi_dst);
+    case 2: return sizeof(isi_conv_w);
+    case 3: return sizeof(isi_encoder_w);
+    case 4: return sizeof(isi_decoder_w);
+    case 5: return sizeof(isi_codebook_w);
+    case 6: return sizeof(isi_vqvae_w);
+    case 7: return sizeof(isi_vqvae_out);
+    default: return 0;
+  }
+}
+int isi_relu_inplace_f32(float *x, int64_t n, void *stream) { return relu_inplace_f32(x, n, S(stream)); }
+
+int isi_prof_enable(int on) { return prof::enable(on); }
+int isi_prof_num_kernels(void) { return prof::K_COUNT; }
+const char *isi_prof_kernel_name(int kernel_id) { return prof::kernel_name(kernel_id); }
+int isi_prof_read(int kernel_id, long long *launches, double *ms, double *flops, double *bytes) {
+  return prof::read(kernel_id, launches, ms, flops, bytes);
+}
+
+int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
+                             void *stream) {
+  return pack_conv_weight_f32(w, packed, Cout, Cin, KH, KW, S(stream));
+}
+size_t isi_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW) {
+  return packed_conv_weight_floats(Cout, Cin, KH, KW);
+}
+int isi_pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout, void *stream) {
+  return pack_convT_k4s2_weight_f32(w, packed, Cin, Cout, S(stream));
+}
+size_t isi_packed_convT_k4s2_weight_floats(int Cin, int Cout) {
+  return packed_convT_k4s2_weight_floats(Cin, Cout);
+}
+int isi_pack_codebook_f32(const float *embed, float *codes_kd, float *e2, int D, int K,
+                          void *stream) {
+  return pack_codebook_f32(embed, codes_kd, e2, D, K, S(stream));
+}
+
+int isi_conv2d_f32(const isi_src *src0, const isi_src *src1, const float *packed_w,
+                   const float *bias, const isi_src *residual, const isi_dst *dst, int B, int H,
+                   int W, int Cout, int KH, int KW, int stride, int pad, int relu, void *stream) {
+  return conv2d_f32(src0, src1, packed_w, bias, residual, dst, B, H, W, Cout, KH, KW, stride, pad,
+                    relu, S(stream));
+}
+int isi_conv_transpose2d_k4s2_f32(const isi_src *src, const float *packed_w, const float *bias,
+                                  const isi_dst *dst, int B, int H, int W, int Cout, int relu,
+                                  void *stream) {
+  return conv_transpose2d_k4s2_f32(src, packed_w, bias, dst, B, H, W, Cout, relu, S(stream));
+}
+
+int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,
+                       float *q_out, int32_t *counts, float *sse_part, int64_t N, int D, int K,
+                       void *stream) {
+  return vq_nearest_f32(z, codes_kd, e2, idx_out, q_out, counts, sse_part, N, D, K, S(stream));
+}
+int isi_vq_num_partials(int64_t N) { return vq_num_partials(N); }
+int isi_vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,
+                        int D, float *out2, void *stream) {
+  return vq_finalize_f32(sse_part, n_part, counts, K, N, D, out2, S(stream));
+}
+int isi_embed_code_f32(const int64_t *idx, const float *codes_kd, float *out, int64_t N, int D,
+                       int K, void *stream) {
+  return embed_code_f32(idx, codes_kd, out, N, D, K, S(stream));
+}
+
+size_t isi_vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W) {
+  return vqvae_workspace_bytes(w, B, H, W);
+}
+int isi_vqvae_run(const isi_vqvae_w *w, int mode, const float *x, int B, int H, int W,
+                  const isi_vqvae_out *out, void *workspace, size_t workspace_bytes, void *stream) {
+  return vqvae_run(w, mode, x, B, H, W, out, workspace, workspace_bytes, S(stream));
+}
+
+}  // extern "C"

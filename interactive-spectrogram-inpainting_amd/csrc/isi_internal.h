@@ -1,0 +1,40 @@
+// Internal (C++-linkage) entry points behind the extern "C" API of isi_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "isi_hip.h"
+
+namespace isi {
+
+int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
+               const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
+               int KW, int stride, int pad, int relu, hipStream_t stream);
+int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const float *bias,
+                              const isi_dst *dst, int B, int H, int W, int Cout, int relu,
+                              hipStream_t stream);
+
+int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
+                   int32_t *counts, float *sse_part, int64_t N, int D, int K, hipStream_t stream);
+int vq_num_partials(int64_t N);
+int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,
+                    int D, float *out2, hipStream_t stream);
+int embed_code_f32(const int64_t *idx, const float *codes, float *out, int64_t N, int D, int K,
+                   hipStream_t stream);
+
+int relu_inplace_f32(float *x, int64_t n, hipStream_t stream);
+
+size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
+size_t packed_convT_k4s2_weight_floats(int Cin, int Cout);
+int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
+                         hipStream_t stream);
+int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,
+                               hipStream_t stream);
+int pack_codebook_f32(const float *embed, float *codes_kd, float *e2, int D, int K,
+                      hipStream_t stream);
+
+size_t vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W);
+int vqvae_run(const isi_vqvae_w *w, int mode, const float *x, int B, int H, int W,
+              const isi_vqvae_out *out, void *workspace, size_t workspace_bytes,
+              hipStream_t stream);
+
+}  // namespace isi

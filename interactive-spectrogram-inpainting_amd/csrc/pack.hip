@@ -1,0 +1,111 @@
+// Weight layout preparation kernels (run once per weight version, not on the hot path).
+//   conv    [Cout,Cin,KH,KW]  -> [Cout][Kpad], k = (kh*KW + kw)*Cin + ci
+//   convT   [Cin,Cout,4,4]    -> [phase][Cout][Kpad], k = (ty*2 + tx)*Cin + ci,
+//                                torch tap (ky,kx) = (3 - py - 2 ty, 3 - px - 2 tx)
+//   embed   [D,K]             -> [K][D] and e2[k] = sum_d embed[d,k]^2
+// Reference weight layouts: torch.nn.Conv2d / ConvTranspose2d as instantiated at
+// vqvae/encoder_decoder.py:95-112,138,199-215 and the `embed` buffer of
+// vqvae/bottleneck.py:47-51.
+#include "isi_common.h"
+
+namespace isi {
+
+__global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict__ out, int Cout,
+                                 int Cin, int KH, int KW, int Kpad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Cout * Kpad) return;
+  const int co = (int)(i / Kpad);
+  const int k = (int)(i - (int64_t)co * Kpad);
+  float v = 0.f;
+  if (k < KH * KW * Cin) {
+    const int tap = k / Cin, ci = k - tap * Cin;
+    const int kh = tap / KW, kw = tap - kh * KW;
+    v = w[(((int64_t)co * Cin + ci) * KH + kh) * KW + kw];
+  }
+  out[i] = v;
+}
+
+__global__ void pack_convT_kernel(const float *__restrict__ w, float *__restrict__ out, int Cin,
+                                  int Cout, int Kpad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)4 * Cout * Kpad) return;
+  const int ph = (int)(i / ((int64_t)Cout * Kpad));
+  const int64_t rem = i - (int64_t)ph * Cout * Kpad;
+  const int co = (int)(rem / Kpad);
+  const int k = (int)(rem - (int64_t)co * Kpad);
+  const int py = ph >> 1, px = ph & 1;
+  float v = 0.f;
+  if (k < 4 * Cin) {
+    const int tap = k / Cin, ci = k - tap * Cin;
+    const int ty = tap >> 1, tx = tap & 1;
+    const int ky = 3 - py - 2 * ty, kx = 3 - px - 2 * tx;
+    v = w[(((int64_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+  }
+  out[i] = v;
+}
+
+__global__ void pack_codebook_kernel(const float *__restrict__ embed, float *__restrict__ codes,
+                                     float *__restrict__ e2, int D, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float v = embed[(int64_t)d * K + k];
+    codes[(int64_t)k * D + d] = v;
+    s += v * v;  // sequential over d like a dim-0 reduction
+  }
+  e2[k] = s;
+}
+
+__global__ void relu_inplace_kernel(float *__restrict__ x, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    x[i] = fmaxf(x[i], 0.f);
+}
+
+int relu_inplace_f32(float *x, int64_t n, hipStream_t stream) {
+  if (!x || n < 0) return invalid("relu_inplace: bad argument");
+  if (n == 0) return ISI_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     stream, x, n);
+  return check_launch("relu_inplace_f32");
+}
+
+size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW) {
+  return (size_t)Cout * round_up((size_t)KH * KW * Cin, kBK);
+}
+size_t packed_convT_k4s2_weight_floats(int Cin, int Cout) {
+  return (size_t)4 * Cout * round_up((size_t)4 * Cin, kBK);
+}
+
+int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
+                         hipStream_t stream) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0)
+    return invalid("pack_conv_weight: bad argument");
+  const int Kpad = (int)round_up((size_t)KH * KW * Cin, kBK);
+  const int64_t total = (int64_t)Cout * Kpad;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     w, packed, Cout, Cin, KH, KW, Kpad);
+  return check_launch("pack_conv_weight_f32");
+}
+
+int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,
+                               hipStream_t stream) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0) return invalid("pack_convT_weight: bad argument");
+  const int Kpad = (int)round_up((size_t)4 * Cin, kBK);
+  const int64_t total = (int64_t)4 * Cout * Kpad;
+  hipLaunchKernelGGL(pack_convT_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     w, packed, Cin, Cout, Kpad);
+  return check_launch("pack_convT_k4s2_weight_f32");
+}
+
+int pack_codebook_f32(const float *embed, float *codes_kd, float *e2, int D, int K,
+                      hipStream_t stream) {
+  if (!embed || !codes_kd || !e2 || D <= 0 || K <= 0) return invalid("pack_codebook: bad argument");
+  hipLaunchKernelGGL(pack_codebook_kernel, dim3((K + 127) / 128), dim3(128), 0, stream, embed,
+                     codes_kd, e2, D, K);
+  return check_launch("pack_codebook_f32");
+}
+
+}  // namespace isi

@@ -1,0 +1,231 @@
+// L2 nearest-neighbour vector quantiser for gfx950 (eval mode).
+//
+// Restates QuantizedBottleneck.forward (reference vqvae/bottleneck.py:53-61,
+// 75-77,94-101) without materialising the [N,K] distance and one-hot matrices:
+//
+//   d[n,k]  = (|z_n|^2 - 2 z_n.e_k) + |e_k|^2          (fp32, same association)
+//   idx[n]  = first k attaining min_k d[n,k]            ((-dist).max(1), ties -> lowest)
+//   q[n]    = z_n + (e_idx - z_n)                        (straight-through value)
+//   sse    += sum (e_idx - z_n)^2 ;  counts[idx[n]] += 1
+//
+// The whole codebook ([K][D+4] fp32, 136 KiB at K=512, D=64) stays in LDS for
+// the lifetime of a persistent workgroup.  Each wave handles 32 vectors at a
+// time: z.e_k runs on the exact-fp32 matrix pipe with the operands swapped
+// (codes = MFMA rows, vectors = MFMA columns) so that the 16 accumulators of a
+// lane all belong to ONE vector and the running arg-min is lane-local; the two
+// half-waves (lanes l and l+32 hold interleaved code rows of the same vector)
+// are merged with a single cross-lane exchange at the end.
+#include "isi_common.h"
+#include "prof.h"
+
+namespace isi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int VQ_BLOCK = 256;
+constexpr int VQ_VEC_PER_BLOCK_ITER = 128;  // 4 waves x 32 vectors
+
+template <int D>
+__global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
+    const float *__restrict__ z, const float *__restrict__ codes, const float *__restrict__ e2g,
+    int64_t *__restrict__ idx_out, float *__restrict__ q_out, int32_t *__restrict__ counts,
+    float *__restrict__ sse_part, int64_t N, int K) {
+  constexpr int LDD = D + 4;  // padded row: conflict-free b128 fragment reads
+  constexpr int NQ = D / 8;   // k-quads held per lane (half-waves interleave quads)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *cb = smem;            // [K][LDD]
+  float *e2 = smem + (size_t)K * LDD;  // [K]
+  float *red = e2 + K;         // [4] per-wave sse
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;   // vector (MFMA column) handled by this lane
+  const int half = lane >> 5;
+
+  // ---- codebook -> LDS (once per persistent workgroup)
+  for (int i = tid; i < K * (D / 4); i += VQ_BLOCK) {
+    const int k = i / (D / 4), qd = i - k * (D / 4);
+    *reinterpret_cast<float4 *>(cb + (size_t)k * LDD + qd * 4) =
+        *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4);
+  }
+  for (int i = tid; i < K; i += VQ_BLOCK) e2[i] = e2g[i];
+  __syncthreads();
+
+  float sse = 0.f;
+  const int64_t n_iter = (N + VQ_VEC_PER_BLOCK_ITER - 1) / VQ_VEC_PER_BLOCK_ITER;
+  for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
+    const bool valid = n < N;
+    // this lane's quads of z_n: quad index 2*j + half
+    float4 zq[NQ];
+    float x2p = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) v = *reinterpret_cast<const float4 *>(z + n * D + (2 * j + half) * 4);
+      zq[j] = v;
+      x2p += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    const float x2 = x2p + __shfl_xor(x2p, 32);
+
+    float best = INFINITY;
+    int besti = 0;
+    for (int kt = 0; kt < K; kt += 32) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float *arow = cb + (size_t)(kt + col) * LDD + half * 4;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const float4 a = *reinterpret_cast<const float4 *>(arow + j * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zq[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zq[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zq[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zq[j].w, acc, 0, 0, 0);
+      }
+      // rows (codes) of this lane, ascending: (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int code = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float d = (x2 - 2.f * acc[r]) + e2[code];
+        if (d < best) { best = d; besti = code; }
+      }
+    }
+    // merge the two half-waves (same vector, disjoint code rows)
+    {
+      const float ob = __shfl_xor(best, 32);
+      const int oi = __shfl_xor(besti, 32);
+      if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    if (valid) {
+      const float *crow = cb + (size_t)besti * LDD + half * 4;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const float4 e = *reinterpret_cast<const float4 *>(crow + j * 8);
+        const float4 v = zq[j];
+        float4 dq = make_float4(e.x - v.x, e.y - v.y, e.z - v.z, e.w - v.w);
+        sse += dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w;
+        *reinterpret_cast<float4 *>(q_out + n * D + (2 * j + half) * 4) =
+            make_float4(v.x + dq.x, v.y + dq.y, v.z + dq.z, v.w + dq.w);
+      }
+      if (half == 0) {
+        idx_out[n] = besti;
+        atomicAdd(&counts[besti], 1);
+      }
+    }
+  }
+
+  // ---- deterministic per-workgroup partial of the squared error
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
+  if (lane == 0) red[wave] = sse;
+  __syncthreads();
+  if (tid == 0) sse_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void vq_finalize_kernel(const float *__restrict__ sse_part, int n_part,
+                                   const int32_t *__restrict__ counts, int K, int64_t N, int D,
+                                   float *__restrict__ out2) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = tid; i < n_part; i += 256) s += sse_part[i];
+  red[tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const float sse = red[0];
+  __syncthreads();
+  float h = 0.f;
+  for (int i = tid; i < K; i += 256) {
+    const float pr = (float)counts[i] / (float)N;
+    h += pr * logf(fmaxf(pr, 1e-7f));
+  }
+  red[tid] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out2[0] = sse / ((float)N * (float)D);
+    out2[1] = expf(-red[0]);
+  }
+}
+
+__global__ void embed_code_kernel(const int64_t *__restrict__ idx, const float *__restrict__ codes,
+                                  float *__restrict__ out, int64_t N, int D4, int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D4) return;
+  const int64_t n = i / D4;
+  const int qd = (int)(i - n * D4);
+  int64_t k = idx[n];
+  k = k < 0 ? 0 : (k >= K ? K - 1 : k);  // callers validate; clamp keeps reads in bounds
+  reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(codes)[k * D4 + qd];
+}
+
+static int vq_grid(int64_t N) {
+  const int64_t n_iter = (N + VQ_VEC_PER_BLOCK_ITER - 1) / VQ_VEC_PER_BLOCK_ITER;
+  return (int)(n_iter < 256 ? (n_iter < 1 ? 1 : n_iter) : 256);
+}
+
+int vq_num_partials(int64_t N) { return vq_grid(N); }
+
+template <int D>
+static int launch_vq(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
+                     int32_t *counts, float *sse_part, int64_t N, int K, hipStream_t stream) {
+  const size_t smem = ((size_t)K * (D + 4) + K + 4) * sizeof(float);
+  if (smem > 150 * 1024) return unsupported("vq: codebook does not fit in LDS");
+  auto kern = vq_nearest_kernel<D>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return check_launch("hipFuncSetAttribute(vq)");
+  {
+    prof::Scope scope(prof::K_VQ_NEAREST, 2.0 * N * K * D, 4.0 * (2.0 * N * D + (double)K * D) + 8.0 * N,
+                      stream);
+    hipLaunchKernelGGL(kern, dim3(vq_grid(N)), dim3(VQ_BLOCK), smem, stream, z, codes, e2, idx, q,
+                       counts, sse_part, N, K);
+  }
+  return check_launch("vq_nearest_f32");
+}
+
+int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
+                   int32_t *counts, float *sse_part, int64_t N, int D, int K,
+                   hipStream_t stream) {
+  if (!z || !codes || !e2 || !idx || !q || !counts || !sse_part) return invalid("vq: null pointer");
+  if (N <= 0 || K <= 0 || (K % 32) != 0) return invalid("vq: need N > 0 and K % 32 == 0");
+  if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(codes) |
+       reinterpret_cast<uintptr_t>(q)) & 15)
+    return invalid("vq: z, codes and q must be 16-byte aligned");
+  switch (D) {
+    case 8: return launch_vq<8>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
+    case 16: return launch_vq<16>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
+    case 32: return launch_vq<32>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
+    case 64: return launch_vq<64>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
+    default: return unsupported("vq: embed_dim must be 8, 16, 32 or 64");
+  }
+}
+
+int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,
+                    int D, float *out2, hipStream_t stream) {
+  if (!sse_part || !counts || !out2 || n_part <= 0 || K <= 0 || N <= 0 || D <= 0)
+    return invalid("vq_finalize: bad argument");
+  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, stream, sse_part, n_part, counts, K,
+                     N, D, out2);
+  return check_launch("vq_finalize_f32");
+}
+
+int embed_code_f32(const int64_t *idx, const float *codes, float *out, int64_t N, int D, int K,
+                   hipStream_t stream) {
+  if (!idx || !codes || !out || N <= 0 || D <= 0 || (D % 4) != 0 || K <= 0)
+    return invalid("embed_code: bad argument");
+  const int64_t total = N * (D / 4);
+  hipLaunchKernelGGL(embed_code_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     idx, codes, out, N, D / 4, K);
+  return check_launch("embed_code_f32");
+}
+
+}  // namespace isi

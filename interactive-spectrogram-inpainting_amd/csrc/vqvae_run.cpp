@@ -1,0 +1,325 @@
+// Host-side launch sequence of the two-level VQ-VAE (no allocation, no sync:
+// every kernel is enqueued on the caller's stream, scratch comes from the
+// caller's workspace).  Mirrors VQVAE.encode / decode / forward of the
+// reference (vqvae/vqvae.py:245-286) and the Rosinality encoder / decoder
+// stacks (vqvae/encoder_decoder.py:38-227), with these fusions:
+//   * every ReLU is folded into the epilogue of the producing convolution
+//     (all ReLUs on this path are in-place in the reference, so the tensor a
+//     consumer sees is always the rectified one -- including the residual
+//     input of RosinalityResBlock, encoder_decoder.py:22-35);
+//   * torch.cat (vqvae.py:270,282) is replaced by two-source convolutions;
+//   * NCHW<->NHWC permutes (vqvae.py:260-262,272-274) vanish: internal
+//     activations are channels-last, strides describe the API tensors.
+#include <algorithm>
+
+#include "isi_common.h"
+#include "isi_internal.h"
+
+namespace isi {
+
+namespace {
+
+struct Act {  // dense channels-last activation
+  float *p;
+  int C, H, W;
+  size_t elems(int B) const { return (size_t)B * H * W * C; }
+};
+
+isi_src src_nhwc(const float *p, int C, int H, int W, int Wstride = -1) {
+  if (Wstride < 0) Wstride = W;
+  isi_src s;
+  s.ptr = p; s.C = C; s.sc = 1; s.sw = C; s.sh = (int64_t)Wstride * C; s.sn = (int64_t)H * Wstride * C;
+  return s;
+}
+isi_dst dst_nhwc(float *p, int C, int H, int W) {
+  isi_dst d;
+  d.ptr = p; d.sc = 1; d.sw = C; d.sh = (int64_t)W * C; d.sn = (int64_t)H * W * C;
+  return d;
+}
+isi_src src_nchw(const float *p, int C, int H, int W) {
+  isi_src s;
+  s.ptr = p; s.C = C; s.sw = 1; s.sh = W; s.sc = (int64_t)H * W; s.sn = (int64_t)C * H * W;
+  return s;
+}
+isi_dst dst_nchw(float *p, int C, int H, int W) {
+  isi_dst d;
+  d.ptr = p; d.sw = 1; d.sh = W; d.sc = (int64_t)H * W; d.sn = (int64_t)C * H * W;
+  return d;
+}
+
+inline int down_dim(int x) { return (x + 2 - 4) / 2 + 1; }
+
+struct Bump {
+  char *base;
+  size_t cap, off;
+  bool dry;  // size query only
+  void *take(size_t bytes) {
+    off = round_up(off, 256);
+    void *p = dry ? nullptr : base + off;
+    off += bytes;
+    return p;
+  }
+  float *floats(size_t n) { return static_cast<float *>(take(n * sizeof(float))); }
+};
+
+struct Shapes {
+  int Hb, Wb, Cb;  // bottom latent grid / hidden channels
+  int Ht, Wt;
+  int Wq;          // cropped bottom width (adapt_quantized_durations)
+  size_t max_act;  // largest intermediate activation (floats)
+};
+
+bool encoder_out_dims(const isi_encoder_w &e, int &H, int &W, int B, size_t &max_act) {
+  for (int i = 0; i < e.n_down; ++i) {
+    H = down_dim(H); W = down_dim(W);
+    if (H <= 0 || W <= 0) return false;
+    max_act = std::max(max_act, (size_t)B * H * W * e.down[i].Cout);
+  }
+  max_act = std::max(max_act, (size_t)B * H * W * e.conv3.Cout);
+  return true;
+}
+
+void decoder_max_act(const isi_decoder_w &d, int H, int W, int B, size_t &max_act) {
+  max_act = std::max(max_act, (size_t)B * H * W * d.conv3.Cout);
+  for (int i = 0; i < d.n_up; ++i) {
+    H *= 2; W *= 2;
+    max_act = std::max(max_act, (size_t)B * H * W * d.up[i].Cout);
+  }
+}
+
+bool compute_shapes(const isi_vqvae_w &w, int B, int H, int W, Shapes &s) {
+  s.max_act = 0;
+  int h = H, ww = W;
+  if (!encoder_out_dims(w.enc_b, h, ww, B, s.max_act)) return false;
+  s.Hb = h; s.Wb = ww; s.Cb = w.enc_b.conv3.Cout;
+  if (!encoder_out_dims(w.enc_t, h, ww, B, s.max_act)) return false;
+  s.Ht = h; s.Wt = ww;
+  int up = 1;
+  for (int i = 0; i < w.dec_t.n_up; ++i) up *= 2;
+  if (s.Ht * up != s.Hb) return false;  // torch.cat would fail in the reference
+  s.Wq = std::min(s.Wt * up, s.Wb);
+  decoder_max_act(w.dec_t, s.Ht, s.Wt, B, s.max_act);
+  decoder_max_act(w.dec, s.Hb, s.Wq, B, s.max_act);
+  return true;
+}
+
+// Rosinality residual stack shared by encoder and decoder: `cur` holds the
+// rectified input r; each block writes relu(r + conv1(relu(conv3(r)))).
+// The last block writes to `final_out` when that is non-null.
+int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act &cur, int B,
+                  float *s0, float *s1, float *hid, float *final_out, hipStream_t st) {
+  for (int i = 0; i < n_res; ++i) {
+    const int R = res3[i].Cout;
+    isi_src in = src_nhwc(cur.p, cur.C, cur.H, cur.W);
+    isi_dst dh = dst_nhwc(hid, R, cur.H, cur.W);
+    int rc = conv2d_f32(&in, nullptr, res3[i].w, res3[i].bias, nullptr, &dh, B, cur.H, cur.W, R, 3,
+                        3, 1, 1, /*relu*/ 1, st);
+    if (rc) return rc;
+    float *outp = (i == n_res - 1 && final_out) ? final_out : (cur.p == s0 ? s1 : s0);
+    isi_src hin = src_nhwc(hid, R, cur.H, cur.W);
+    isi_dst dout = dst_nhwc(outp, cur.C, cur.H, cur.W);
+    rc = conv2d_f32(&hin, nullptr, res1[i].w, res1[i].bias, &in, &dout, B, cur.H, cur.W, cur.C, 1,
+                    1, 1, 0, /*relu*/ 1, st);
+    if (rc) return rc;
+    cur.p = outp;
+  }
+  return ISI_OK;
+}
+
+// RosinalityEncoder (encoder_decoder.py:38-126).  `in` may be NCHW.
+int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *s0, float *s1,
+                float *hid, float *final_out, Act &out, hipStream_t st) {
+  Act cur{nullptr, in.C, H, W};
+  isi_src cs = in;
+  for (int i = 0; i < e.n_down; ++i) {
+    const int OH = down_dim(cur.H), OW = down_dim(cur.W);
+    float *o = (cur.p == s0) ? s1 : s0;
+    isi_dst d = dst_nhwc(o, e.down[i].Cout, OH, OW);
+    int rc = conv2d_f32(&cs, nullptr, e.down[i].w, e.down[i].bias, nullptr, &d, B, cur.H, cur.W,
+                        e.down[i].Cout, 4, 4, 2, 1, 1, st);
+    if (rc) return rc;
+    cur = Act{o, e.down[i].Cout, OH, OW};
+    cs = src_nhwc(cur.p, cur.C, cur.H, cur.W);
+  }
+  {
+    float *o = (e.n_res == 0) ? final_out : ((cur.p == s0) ? s1 : s0);
+    isi_dst d = dst_nhwc(o, e.conv3.Cout, cur.H, cur.W);
+    int rc = conv2d_f32(&cs, nullptr, e.conv3.w, e.conv3.bias, nullptr, &d, B, cur.H, cur.W,
+                        e.conv3.Cout, 3, 3, 1, 1, 1, st);
+    if (rc) return rc;
+    cur = Act{o, e.conv3.Cout, cur.H, cur.W};
+  }
+  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, st);
+  if (rc) return rc;
+  out = cur;
+  return ISI_OK;
+}
+
+// RosinalityDecoder (encoder_decoder.py:129-227).  Input = cat(in0, in1) on
+// channels (in1 optional); the last transposed conv writes through `final_dst`.
+int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, int B, int H, int W,
+                float *s0, float *s1, float *hid, const isi_dst &final_dst, hipStream_t st) {
+  Act cur{s0, d.conv3.Cout, H, W};
+  {
+    isi_dst dd = dst_nhwc(cur.p, cur.C, H, W);
+    int rc = conv2d_f32(&in0, in1, d.conv3.w, d.conv3.bias, nullptr, &dd, B, H, W, cur.C, 3, 3, 1,
+                        1, 1, st);
+    if (rc) return rc;
+  }
+  {
+    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, st);
+    if (rc) return rc;
+  }
+  for (int i = 0; i < d.n_up; ++i) {
+    const bool last = (i == d.n_up - 1);
+    isi_src s = src_nhwc(cur.p, cur.C, cur.H, cur.W);
+    float *o = (cur.p == s0) ? s1 : s0;
+    isi_dst dd = last ? final_dst : dst_nhwc(o, d.up[i].Cout, 2 * cur.H, 2 * cur.W);
+    int rc = conv_transpose2d_k4s2_f32(&s, d.up[i].w, d.up[i].bias, &dd, B, cur.H, cur.W,
+                                       d.up[i].Cout, last ? 0 : 1, st);
+    if (rc) return rc;
+    cur = Act{o, d.up[i].Cout, 2 * cur.H, 2 * cur.W};
+  }
+  return ISI_OK;
+}
+
+int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *idx, float *q,
+                  int32_t *counts, float *sse_part, float *scalars2, hipStream_t st) {
+  if (hipMemsetAsync(counts, 0, (size_t)cb.K * sizeof(int32_t), st) != hipSuccess)
+    return check_launch("hipMemsetAsync(counts)");
+  int rc = vq_nearest_f32(z, cb.codes_kd, cb.e2, idx, q, counts, sse_part, N, cb.D, cb.K, st);
+  if (rc) return rc;
+  return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);
+}
+
+int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
+         const isi_vqvae_out *out, Bump &ws, hipStream_t st) {
+  Shapes sh;
+  if (!compute_shapes(w, B, H, W, sh)) return invalid("vqvae: input too small or odd top/bottom grid");
+  const int D = w.quantize_t.D;
+  const bool dry = ws.dry;
+  if (w.n_upsample != w.dec_t.n_up) return invalid("vqvae: upsample depth must equal dec_t depth");
+
+  float *s0 = ws.floats(sh.max_act);
+  float *s1 = ws.floats(sh.max_act);
+  const int Rmax = std::max({w.enc_b.n_res ? w.enc_b.res3[0].Cout : 0, w.enc_t.n_res ? w.enc_t.res3[0].Cout : 0,
+                             w.dec_t.n_res ? w.dec_t.res3[0].Cout : 0, w.dec.n_res ? w.dec.res3[0].Cout : 0, 1});
+  float *hid = ws.floats((size_t)B * sh.Hb * sh.Wb * Rmax);
+  float *enc_b = ws.floats((size_t)B * sh.Hb * sh.Wb * sh.Cb);
+  float *enc_t = ws.floats((size_t)B * sh.Ht * sh.Wt * w.enc_t.conv3.Cout);
+  float *dec_t = ws.floats((size_t)B * sh.Hb * sh.Wb * D);
+  float *zbuf = ws.floats((size_t)B * sh.Hb * sh.Wb * D);
+  float *up = ws.floats((size_t)B * sh.Hb * sh.Wb * D);
+  float *up2 = ws.floats((size_t)B * sh.Hb * sh.Wb * D);
+  float *q_t_ws = ws.floats((size_t)B * sh.Ht * sh.Wt * D);
+  float *q_b_ws = ws.floats((size_t)B * sh.Hb * sh.Wq * D);
+  int64_t *id_t_ws = static_cast<int64_t *>(ws.take((size_t)B * sh.Ht * sh.Wt * sizeof(int64_t)));
+  int64_t *id_b_ws = static_cast<int64_t *>(ws.take((size_t)B * sh.Hb * sh.Wq * sizeof(int64_t)));
+  const int Kmax = std::max(w.quantize_t.K, w.quantize_b.K);
+  int32_t *counts = static_cast<int32_t *>(ws.take((size_t)Kmax * sizeof(int32_t)));
+  float *sse_part = ws.floats(256);
+  float *scal_ws = ws.floats(4);
+  if (dry) return ISI_OK;
+  if (ws.off > ws.cap) {
+    set_last_error("vqvae: workspace too small");
+    return ISI_E_WORKSPACE;
+  }
+
+  float *quant_t = out->quant_t ? out->quant_t : q_t_ws;
+  float *quant_b = out->quant_b ? out->quant_b : q_b_ws;
+  int64_t *id_t = out->id_t ? out->id_t : id_t_ws;
+  int64_t *id_b = out->id_b ? out->id_b : id_b_ws;
+  float *scal = out->scalars ? out->scalars : scal_ws;
+  int rc;
+
+  if (mode & ISI_MODE_ENCODE) {
+    if (!x) return invalid("vqvae: x is null");
+    Act eb, et;
+    rc = run_encoder(w.enc_b, src_nchw(x, w.in_channel, H, W), B, H, W, s0, s1, hid, enc_b, eb, st);
+    if (rc) return rc;
+    rc = run_encoder(w.enc_t, src_nhwc(eb.p, eb.C, eb.H, eb.W), B, eb.H, eb.W, s0, s1, hid, enc_t, et, st);
+    if (rc) return rc;
+    // quantize_conv_t + quantize_t (vqvae.py:260-263)
+    {
+      isi_src s = src_nhwc(et.p, et.C, et.H, et.W);
+      isi_dst d = dst_nhwc(zbuf, D, et.H, et.W);
+      rc = conv2d_f32(&s, nullptr, w.quantize_conv_t.w, w.quantize_conv_t.bias, nullptr, &d, B, et.H,
+                      et.W, D, 1, 1, 1, 0, 0, st);
+      if (rc) return rc;
+      rc = run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
+                         sse_part, scal + 0, st);
+      if (rc) return rc;
+    }
+    // dec_t (vqvae.py:265): [B,Ht,Wt,D] -> [B,Hb,2^n Wt,D]
+    int Wd = et.W;
+    for (int i = 0; i < w.dec_t.n_up; ++i) Wd *= 2;
+    {
+      isi_src s = src_nhwc(quant_t, D, et.H, et.W);
+      isi_dst d = dst_nhwc(dec_t, w.dec_t.up[w.dec_t.n_up - 1].Cout, sh.Hb, Wd);
+      rc = run_decoder(w.dec_t, s, nullptr, B, et.H, et.W, s0, s1, hid, d, st);
+      if (rc) return rc;
+    }
+    // quantize_conv_b on cat([dec_t, enc_b]) cropped to Wq (vqvae.py:266-273)
+    {
+      const int Cd = w.dec_t.up[w.dec_t.n_up - 1].Cout;
+      isi_src a = src_nhwc(dec_t, Cd, sh.Hb, sh.Wq, Wd);
+      isi_src b = src_nhwc(eb.p, eb.C, sh.Hb, sh.Wq, eb.W);
+      isi_dst d = dst_nhwc(zbuf, D, sh.Hb, sh.Wq);
+      rc = conv2d_f32(&a, &b, w.quantize_conv_b.w, w.quantize_conv_b.bias, nullptr, &d, B, sh.Hb,
+                      sh.Wq, D, 1, 1, 1, 0, 0, st);
+      if (rc) return rc;
+      rc = run_quantizer(w.quantize_b, zbuf, (int64_t)B * sh.Hb * sh.Wq, id_b, quant_b, counts,
+                         sse_part, scal + 2, st);
+      if (rc) return rc;
+    }
+  }
+
+  if (mode & ISI_MODE_DECODE) {
+    if (!out->dec) return invalid("vqvae: dec output is null");
+    if (!(mode & ISI_MODE_ENCODE) && (!out->quant_t || !out->quant_b))
+      return invalid("vqvae: decode needs quant_t and quant_b");
+    // upsample_top_to_bottom: plain transposed convs, no ReLU (vqvae.py:183-201,281)
+    const float *cur = quant_t;
+    int h = sh.Ht, ww = sh.Wt;
+    for (int i = 0; i < w.n_upsample; ++i) {
+      float *o = (i % 2 == 0) ? up : up2;
+      isi_src s = src_nhwc(cur, w.upsample[i].Cin, h, ww);
+      isi_dst d = dst_nhwc(o, w.upsample[i].Cout, 2 * h, 2 * ww);
+      rc = conv_transpose2d_k4s2_f32(&s, w.upsample[i].w, w.upsample[i].bias, &d, B, h, ww,
+                                     w.upsample[i].Cout, 0, st);
+      if (rc) return rc;
+      cur = o; h *= 2; ww *= 2;
+    }
+    if (h != sh.Hb || ww != sh.Wq) return invalid("vqvae: upsampled top grid != bottom grid");
+    isi_src a = src_nhwc(cur, D, h, ww);
+    isi_src b = src_nhwc(quant_b, D, sh.Hb, sh.Wq);
+    int OHf = sh.Hb, OWf = sh.Wq;
+    for (int i = 0; i < w.dec.n_up; ++i) { OHf *= 2; OWf *= 2; }
+    isi_dst d = dst_nchw(out->dec, w.in_channel, OHf, OWf);
+    rc = run_decoder(w.dec, a, &b, B, sh.Hb, sh.Wq, s0, s1, hid, d, st);
+    if (rc) return rc;
+  }
+  return ISI_OK;
+}
+
+}  // namespace
+
+size_t vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W) {
+  if (!w || B <= 0 || H <= 0 || W <= 0) return 0;
+  Bump ws{nullptr, 0, 0, true};
+  if (plan(*w, ISI_MODE_FORWARD, nullptr, B, H, W, nullptr, ws, nullptr) != ISI_OK) return 0;
+  return round_up(ws.off, 256);
+}
+
+int vqvae_run(const isi_vqvae_w *w, int mode, const float *x, int B, int H, int W,
+              const isi_vqvae_out *out, void *workspace, size_t workspace_bytes,
+              hipStream_t stream) {
+  if (!w || !out || !workspace) return invalid("vqvae_run: null pointer");
+  if (mode < 1 || mode > 3) return invalid("vqvae_run: bad mode");
+  if (B <= 0 || H <= 0 || W <= 0) return invalid("vqvae_run: bad shape");
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return invalid("vqvae_run: workspace must be 256-byte aligned");
+  Bump ws{static_cast<char *>(workspace), workspace_bytes, 0, false};
+  return plan(*w, mode, x, B, H, W, out, ws, stream);
+}
+
+}  // namespace isi

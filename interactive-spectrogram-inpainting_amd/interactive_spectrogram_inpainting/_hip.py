@@ -1,0 +1,169 @@
+"""ctypes binding of libisi_hip.so (C-ABI declared in include/isi_hip.h).
+
+PyTorch is used only as the owner of device memory and of the HIP stream;
+every tensor is handed to the library as a raw device pointer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import pathlib
+import threading
+from typing import Optional
+
+import torch
+
+_PKG_DIR = pathlib.Path(__file__).resolve().parent
+_LIB_PATH = _PKG_DIR.parent / "lib" / "libisi_hip.so"
+
+ISI_MAX_STAGES = 4
+ISI_MAX_RES = 8
+MODE_ENCODE, MODE_DECODE, MODE_FORWARD = 1, 2, 3
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class isi_src(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int),
+                ("sn", C.c_int64), ("sc", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)]
+
+
+class isi_dst(C.Structure):
+    _fields_ = [("ptr", C.c_void_p),
+                ("sn", C.c_int64), ("sc", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64)]
+
+
+class isi_conv_w(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("Cin", C.c_int), ("Cout", C.c_int)]
+
+
+class isi_encoder_w(C.Structure):
+    _fields_ = [("n_down", C.c_int), ("down", isi_conv_w * ISI_MAX_STAGES), ("conv3", isi_conv_w),
+                ("n_res", C.c_int), ("res3", isi_conv_w * ISI_MAX_RES), ("res1", isi_conv_w * ISI_MAX_RES)]
+
+
+class isi_decoder_w(C.Structure):
+    _fields_ = [("conv3", isi_conv_w), ("n_res", C.c_int),
+                ("res3", isi_conv_w * ISI_MAX_RES), ("res1", isi_conv_w * ISI_MAX_RES),
+                ("n_up", C.c_int), ("up", isi_conv_w * ISI_MAX_STAGES)]
+
+
+class isi_codebook_w(C.Structure):
+    _fields_ = [("codes_kd", C.c_void_p), ("e2", C.c_void_p), ("D", C.c_int), ("K", C.c_int)]
+
+
+class isi_vqvae_w(C.Structure):
+    _fields_ = [("in_channel", C.c_int),
+                ("enc_b", isi_encoder_w), ("enc_t", isi_encoder_w),
+                ("quantize_conv_t", isi_conv_w), ("quantize_conv_b", isi_conv_w),
+                ("quantize_t", isi_codebook_w), ("quantize_b", isi_codebook_w),
+                ("dec_t", isi_decoder_w), ("dec", isi_decoder_w),
+                ("n_upsample", C.c_int), ("upsample", isi_conv_w * ISI_MAX_STAGES)]
+
+
+class isi_vqvae_out(C.Structure):
+    _fields_ = [("dec", C.c_void_p), ("quant_t", C.c_void_p), ("quant_b", C.c_void_p),
+                ("id_t", C.c_void_p), ("id_b", C.c_void_p), ("scalars", C.c_void_p)]
+
+
+# name -> (restype, argtypes); must list every symbol include/isi_hip.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "isi_version": (C.c_char_p, []),
+    "isi_last_error": (C.c_char_p, []),
+    "isi_abi_struct_bytes": (C.c_size_t, [C.c_int]),
+    "isi_relu_inplace_f32": (C.c_int, [_P, C.c_int64, _P]),
+    "isi_prof_enable": (C.c_int, [C.c_int]),
+    "isi_prof_num_kernels": (C.c_int, []),
+    "isi_prof_kernel_name": (C.c_char_p, [C.c_int]),
+    "isi_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "isi_pack_conv_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "isi_pack_convT_k4s2_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "isi_packed_convT_k4s2_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "isi_pack_codebook_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "isi_conv2d_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.POINTER(isi_src),
+                                 C.POINTER(isi_dst), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_conv_transpose2d_k4s2_f32": (C.c_int, [C.POINTER(isi_src), _P, _P, C.POINTER(isi_dst), C.c_int,
+                                                C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_vq_nearest_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "isi_vq_num_partials": (C.c_int, [C.c_int64]),
+    "isi_vq_finalize_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
+    "isi_embed_code_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "isi_vqvae_workspace_bytes": (C.c_size_t, [C.POINTER(isi_vqvae_w), C.c_int, C.c_int, C.c_int]),
+    "isi_vqvae_run": (C.c_int, [C.POINTER(isi_vqvae_w), C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(isi_vqvae_out), _P, C.c_size_t, _P]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def library_path() -> pathlib.Path:
+    return pathlib.Path(os.environ.get("ISI_HIP_LIBRARY", str(_LIB_PATH)))
+
+
+def lib() -> C.CDLL:
+    """Load libisi_hip.so once; raises HipLibraryError if it is not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                path = library_path()
+                if not path.exists():
+                    raise HipLibraryError(
+                        f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C interactive-spectrogram-inpainting_amd/csrc`; there is no fallback path")
+                handle = C.CDLL(str(path))
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                structs = [isi_src, isi_dst, isi_conv_w, isi_encoder_w, isi_decoder_w, isi_codebook_w,
+                           isi_vqvae_w, isi_vqvae_out]
+                for i, st in enumerate(structs):
+                    if handle.isi_abi_struct_bytes(i) != C.sizeof(st):
+                        raise HipLibraryError(f"ABI mismatch for {st.__name__}: library "
+                                              f"{handle.isi_abi_struct_bytes(i)} B, binding {C.sizeof(st)} B")
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().isi_last_error().decode("utf-8", "replace")
+        raise HipLibraryError(f"{what} failed with code {rc}: {msg}")
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise HipLibraryError(
+            f"{name} lives on {t.device}: this package computes only on an MI355X "
+            "(HIP kernels, no CPU fallback)")
+    if t.dtype != torch.float32 and t.dtype != torch.int64:
+        raise HipLibraryError(f"{name} has dtype {t.dtype}; expected float32 / int64")
+
+
+def src_nhwc(t: torch.Tensor) -> isi_src:
+    """Descriptor of a dense channels-last [B,H,W,C] tensor."""
+    B, H, W, Cc = t.shape
+    return isi_src(t.data_ptr(), Cc, H * W * Cc, 1, W * Cc, Cc)
+
+
+def src_nchw_view(t: torch.Tensor) -> isi_src:
+    """Descriptor of any 4-D tensor indexed as [B,C,H,W] (arbitrary strides)."""
+    sn, sc, sh, sw = t.stride()
+    return isi_src(t.data_ptr(), t.shape[1], sn, sc, sh, sw)
+
+
+def dst_nchw_view(t: torch.Tensor) -> isi_dst:
+    sn, sc, sh, sw = t.stride()
+    return isi_dst(t.data_ptr(), sn, sc, sh, sw)

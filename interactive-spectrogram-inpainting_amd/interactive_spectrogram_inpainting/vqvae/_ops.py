@@ -1,0 +1,142 @@
+"""Thin Python wrappers over the per-operator C-ABI entry points.
+
+Tensors are channels-last `[B,H,W,C]` fp32 unless a name says otherwise.  These
+helpers only allocate outputs (torch = device memory owner) and marshal
+pointers; all arithmetic happens in libisi_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from .. import _hip
+
+
+def _s(t):
+    return C.c_void_p(_hip.stream_ptr(t.device))
+
+
+def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
+    """torch Conv2d weight [Cout,Cin,KH,KW] -> packed [Cout, Kpad]."""
+    _hip.require_gpu(weight, "conv weight")
+    w = weight.detach().contiguous()
+    cout, cin, kh, kw = w.shape
+    n = _hip.lib().isi_packed_conv_weight_floats(cout, cin, kh, kw)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    _hip.check(_hip.lib().isi_pack_conv_weight_f32(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, _s(w)),
+               "isi_pack_conv_weight_f32")
+    return out
+
+
+def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
+    """torch ConvTranspose2d(k4,s2,p1) weight [Cin,Cout,4,4] -> 4 packed phase matrices."""
+    _hip.require_gpu(weight, "convT weight")
+    w = weight.detach().contiguous()
+    cin, cout, kh, kw = w.shape
+    if (kh, kw) != (4, 4):
+        raise NotImplementedError("only ConvTranspose2d(kernel 4, stride 2, padding 1) is built")
+    n = _hip.lib().isi_packed_convT_k4s2_weight_floats(cin, cout)
+    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    _hip.check(_hip.lib().isi_pack_convT_k4s2_weight_f32(w.data_ptr(), out.data_ptr(), cin, cout, _s(w)),
+               "isi_pack_convT_k4s2_weight_f32")
+    return out
+
+
+def pack_codebook(embed: torch.Tensor):
+    """`embed` buffer [D,K] -> (codes [K,D], e2 [K])."""
+    _hip.require_gpu(embed, "embed")
+    e = embed.detach().contiguous()
+    d, k = e.shape
+    codes = torch.empty(k, d, dtype=torch.float32, device=e.device)
+    e2 = torch.empty(k, dtype=torch.float32, device=e.device)
+    _hip.check(_hip.lib().isi_pack_codebook_f32(e.data_ptr(), codes.data_ptr(), e2.data_ptr(), d, k, _s(e)),
+               "isi_pack_codebook_f32")
+    return codes, e2
+
+
+def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
+           k: int, stride: int, pad: int, relu: bool, x2_bchw: Optional[torch.Tensor] = None,
+           residual_bchw: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Convolution of a tensor indexed [B,C,H,W] (any strides); returns a
+    [B,Cout,OH,OW]-shaped view of freshly allocated channels-last storage."""
+    _hip.require_gpu(x_bchw, "conv input")
+    B, _, H, W = x_bchw.shape
+    OH = (H + 2 * pad - k) // stride + 1
+    OW = (W + 2 * pad - k) // stride + 1
+    out = torch.empty(B, OH, OW, cout, dtype=torch.float32, device=x_bchw.device).permute(0, 3, 1, 2)
+    s0 = _hip.src_nchw_view(x_bchw)
+    s1 = _hip.src_nchw_view(x2_bchw) if x2_bchw is not None else None
+    res = _hip.src_nchw_view(residual_bchw) if residual_bchw is not None else None
+    dst = _hip.dst_nchw_view(out)
+    rc = _hip.lib().isi_conv2d_f32(
+        C.byref(s0), C.byref(s1) if s1 is not None else None, packed_w.data_ptr(),
+        bias.data_ptr() if bias is not None else None, C.byref(res) if res is not None else None,
+        C.byref(dst), B, H, W, cout, k, k, stride, pad, int(relu), _s(x_bchw))
+    _hip.check(rc, "isi_conv2d_f32")
+    return out
+
+
+def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor],
+                          cout: int, relu: bool, out_nchw: bool = False) -> torch.Tensor:
+    _hip.require_gpu(x_bchw, "convT input")
+    B, _, H, W = x_bchw.shape
+    if out_nchw:
+        out = torch.empty(B, cout, 2 * H, 2 * W, dtype=torch.float32, device=x_bchw.device)
+    else:
+        out = torch.empty(B, 2 * H, 2 * W, cout, dtype=torch.float32, device=x_bchw.device).permute(0, 3, 1, 2)
+    s0 = _hip.src_nchw_view(x_bchw)
+    dst = _hip.dst_nchw_view(out)
+    rc = _hip.lib().isi_conv_transpose2d_k4s2_f32(
+        C.byref(s0), packed_w.data_ptr(), bias.data_ptr() if bias is not None else None,
+        C.byref(dst), B, H, W, cout, int(relu), _s(x_bchw))
+    _hip.check(rc, "isi_conv_transpose2d_k4s2_f32")
+    return out
+
+
+def vq_nearest(z: torch.Tensor, codes: torch.Tensor, e2: torch.Tensor):
+    """z [..., D] dense channels-last -> (q_st [..., D], diff [], idx int64 [...], perplexity [])."""
+    _hip.require_gpu(z, "quantizer input")
+    if not z.is_contiguous():
+        z = z.contiguous()
+    D = z.shape[-1]
+    K = codes.shape[0]
+    N = z.numel() // D
+    L = _hip.lib()
+    idx = torch.empty(z.shape[:-1], dtype=torch.int64, device=z.device)
+    q = torch.empty_like(z)
+    counts = torch.zeros(K, dtype=torch.int32, device=z.device)
+    n_part = L.isi_vq_num_partials(N)
+    part = torch.empty(n_part, dtype=torch.float32, device=z.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=z.device)
+    _hip.check(L.isi_vq_nearest_f32(z.data_ptr(), codes.data_ptr(), e2.data_ptr(), idx.data_ptr(),
+                                    q.data_ptr(), counts.data_ptr(), part.data_ptr(), N, D, K, _s(z)),
+               "isi_vq_nearest_f32")
+    _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D,
+                                     out2.data_ptr(), _s(z)), "isi_vq_finalize_f32")
+    return q, out2[0], idx, out2[1]
+
+
+def embed_code(idx: torch.Tensor, codes: torch.Tensor) -> torch.Tensor:
+    """idx int64 [...] -> [..., D] rows of the codebook."""
+    _hip.require_gpu(idx, "code indices")
+    if idx.dtype != torch.int64:
+        raise TypeError(f"code indices must be int64, got {idx.dtype}")
+    idx = idx.contiguous()
+    K, D = codes.shape
+    out = torch.empty(*idx.shape, D, dtype=torch.float32, device=idx.device)
+    if idx.numel() == 0:
+        return out
+    _hip.check(_hip.lib().isi_embed_code_f32(idx.data_ptr(), codes.data_ptr(), out.data_ptr(),
+                                             idx.numel(), D, K, _s(idx)), "isi_embed_code_f32")
+    return out
+
+
+def relu_(x: torch.Tensor) -> torch.Tensor:
+    """In-place ReLU on a dense tensor (any memory format that is non-overlapping and dense)."""
+    _hip.require_gpu(x, "relu input")
+    if not (x.is_contiguous() or x.permute(0, 2, 3, 1).is_contiguous()):
+        raise NotImplementedError("in-place ReLU needs dense NCHW or channels-last storage")
+    _hip.check(_hip.lib().isi_relu_inplace_f32(x.data_ptr(), x.numel(), _s(x)), "isi_relu_inplace_f32")
+    return x

@@ -24,35 +24,50 @@ namespace isi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// All fields are scalars so the whole struct stays in SGPRs (s_load from the
+// kernarg segment); element strides / offsets are 32-bit (launchers reject
+// tensors spanning 4 GiB or more, which also bounds the buffer descriptors).
 struct ConvKArgs {
   const float *in0, *in1, *w, *bias, *res;
   float *out;
-  int C0, C1, Cin;
-  int64_t s0n, s0c, s0h, s0w;  // source 0 element strides
-  int64_t s1n, s1h, s1w;       // source 1 (channel stride 1)
-  int64_t rn, rc, rh, rw;      // residual strides (logical output coordinates)
-  int64_t on, oc, oh, ow;      // output strides, in units of GEMM-grid pixels
-  int H, W, OH, OW, Cout, K, Kpad, KH, KW, stride, relu, M;
-  int nphase;
-  int pad_y[4], pad_x[4];
-  int64_t w_off[4], out_off[4], res_off[4];
+  unsigned in0_bytes, in1_bytes, w_bytes;
+  int C0, Cin, src_uniform;  // src_uniform: a 32-wide K chunk never straddles the two sources
+  int s0n, s0c, s0h, s0w;    // source 0 element strides
+  int s1n, s1h, s1w;         // source 1 (channel stride 1)
+  int rn, rc, rh, rw;        // residual strides (logical output coordinates)
+  int on, oc, oh, ow;        // output strides, in units of GEMM-grid pixels
+  int H, W, OH, OW, Cout, K, Kpad, KW, stride, relu, M;
+  int pad;                   // plain convolution: symmetric zero padding
+  int convT;                 // 1: blockIdx.z = phase (py,px) of ConvTranspose2d(k4,s2,p1)
+  int w_phase_stride;        // convT: floats between two phase weight matrices
+  int dst_sh, dst_sw;        // convT: strides of the full output tensor (phase offset)
 };
 
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, 16-B aligned, bank-conflict free
+constexpr unsigned OOB = 0xFFFFFFF0u;  // buffer_load beyond num_records returns 0: free zero padding
 
-template <int BM, int BN, int WM, int WN, bool SCALAR_A>
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+  return *reinterpret_cast<float4 *>(&v);
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) {
   constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int RA = BM / 32;  // A rows staged per thread
   constexpr int RB = BN / 32;
+  constexpr bool SCALAR_A = MODE == 2;  // element-wise gather loader
+  constexpr bool DUAL = MODE == 1;      // quads of one chunk may come from either source
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TM >= 1 && TN >= 1, "tile too small");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *As = smem;                      // [2][BM*LDK]
   float *Bs = smem + 2 * BM * LDK;       // [2][BN*LDK]
-  int *row_b = reinterpret_cast<int *>(Bs + 2 * BN * LDK);  // [BM]
+  int *row_b = reinterpret_cast<int *>(Bs + 2 * BN * LDK);  // [BM] batch index or -1
   int *row_y = row_b + BM;
   int *row_x = row_y + BM;
 
@@ -61,7 +76,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   const int wave = tid >> 6;
   const int wm0 = (wave / WN) * (BM / WM);
   const int wn0 = (wave % WN) * (BN / WN);
-  const int phase = blockIdx.z;
+
+  // phase of the transposed convolution (uniform)
+  const int py = p.convT ? (int)(blockIdx.z >> 1) : 0;
+  const int px = p.convT ? (int)(blockIdx.z & 1) : 0;
+  const int pad_y = p.convT ? 1 - py : p.pad;
+  const int pad_x = p.convT ? 1 - px : p.pad;
+  const int w_off = p.convT ? (int)blockIdx.z * p.w_phase_stride : 0;
+  const int out_off = p.convT ? py * p.dst_sh + px * p.dst_sw : 0;
 
   // XCD-aware tile order: consecutive M tiles (neighbouring pixels, shared
   // halo rows) are given to one XCD so their re-reads hit that XCD's L2.
@@ -93,42 +115,76 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 
   const int lrow = tid >> 3;  // 0..31
   const int lq = tid & 7;     // quad inside the 32-wide K chunk
-  const int pad_y = p.pad_y[phase], pad_x = p.pad_x[phase];
-  const float *wbase = p.w + p.w_off[phase];
 
-  int a_b[RA], a_y0[RA], a_x0[RA];
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in0), 0, p.in0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in1), 0, p.in1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // per staged A row: validity, top-left input coordinate, batch offsets (elements)
+  int a_y0[RA], a_x0[RA], a_n0[RA], a_n1[RA];
+  bool a_ok[RA];
 #pragma unroll
   for (int j = 0; j < RA; ++j) {
     const int r = lrow + 32 * j;
-    a_b[j] = row_b[r];
+    const int b = row_b[r];
+    a_ok[j] = b >= 0;
     a_y0[j] = row_y[r] * p.stride - pad_y;
     a_x0[j] = row_x[r] * p.stride - pad_x;
+    a_n0[j] = b * p.s0n;
+    a_n1[j] = b * p.s1n;
+  }
+  // per staged B row: byte offset of the packed weight row (OOB past Cout: zeros)
+  unsigned b_off[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    const int n = n0 + lrow + 32 * j;
+    b_off[j] = n < p.Cout ? (unsigned)(w_off + n * p.Kpad + lq * 4) * 4u : OOB;
   }
 
-  float4 ra[RA], rb[RB];
+  // this thread's position in K: tap (kh,kw) and channel c of its quad, advanced by 32 per chunk
+  int kc_c, kc_kh, kc_kw;
+  {
+    const int kk = lq * 4;
+    const int tap = kk / p.Cin;
+    kc_c = kk - tap * p.Cin;
+    kc_kh = tap / p.KW;
+    kc_kw = tap - kc_kh * p.KW;
+  }
+  int kk_next = lq * 4;  // K index of the quad the next load_chunk() fetches
 
-  auto load_chunk = [&](int kc) {
-    const int kk = kc * kBK + lq * 4;
+  float4 ra[RA], rb[RB];
+  float4 ra1[DUAL ? RA : 1];  // second-source candidates (DUAL only)
+  bool sel1 = false;
+
+  auto load_chunk = [&]() {
     if constexpr (!SCALAR_A) {
-      const bool kvalid = kk < p.K;
-      const int tap = kk / p.Cin;
-      int c = kk - tap * p.Cin;
-      const int kh = tap / p.KW;
-      const int kw = tap - kh * p.KW;
-      const float *src = p.in0;
-      int64_t sn = p.s0n, sh = p.s0h, sw = p.s0w;
-      if (c >= p.C0) {
-        c -= p.C0;
-        src = p.in1;
-        sn = p.s1n; sh = p.s1h; sw = p.s1w;
-      }
+      const bool kvalid = kk_next < p.K;
+      const bool second = kc_c >= p.C0;
+      const int c = second ? kc_c - p.C0 : kc_c;
+      if constexpr (!DUAL) {
+        // the whole workgroup reads one source in this chunk: uniform descriptor
+        const bool sec_u = __builtin_amdgcn_readfirstlane((int)second) != 0;
+        const __amdgpu_buffer_rsrc_t rs = sec_u ? rs1 : rs0;
+        const int sh = sec_u ? p.s1h : p.s0h, sw = sec_u ? p.s1w : p.s0w;
 #pragma unroll
-      for (int j = 0; j < RA; ++j) {
-        const int iy = a_y0[j] + kh, ix = a_x0[j] + kw;
-        const bool ok = kvalid && a_b[j] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4 *>(src + a_b[j] * sn + iy * sh + ix * sw + c);
-        ra[j] = v;
+        for (int j = 0; j < RA; ++j) {
+          const int iy = a_y0[j] + kc_kh, ix = a_x0[j] + kc_kw;
+          const bool ok = kvalid && a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          const int nb = sec_u ? a_n1[j] : a_n0[j];
+          ra[j] = buf_load4(rs, ok ? (unsigned)(nb + iy * sh + ix * sw + c) * 4u : OOB);
+        }
+      } else {
+        // one masked load per source; the pick happens when the chunk is written to LDS
+        sel1 = second;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+          const int iy = a_y0[j] + kc_kh, ix = a_x0[j] + kc_kw;
+          const bool ok = kvalid && a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+          const unsigned o0 = (ok && !second) ? (unsigned)(a_n0[j] + iy * p.s0h + ix * p.s0w + c) * 4u : OOB;
+          const unsigned o1 = (ok && second) ? (unsigned)(a_n1[j] + iy * p.s1h + ix * p.s1w + c) * 4u : OOB;
+          ra[j] = buf_load4(rs0, o0);
+          ra1[j] = buf_load4(rs1, o1);
+        }
       }
     } else {
       // element-wise gather with arbitrary strides (NCHW sources, Cin % 4 != 0)
@@ -137,17 +193,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int k1 = kk + e;
+          const int k1 = kk_next + e;
           const int tap = k1 / p.Cin;
           const int c = k1 - tap * p.Cin;
           const int kh = tap / p.KW;
           const int kw = tap - kh * p.KW;
           const int iy = a_y0[j] + kh, ix = a_x0[j] + kw;
-          const bool ok = k1 < p.K && a_b[j] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+          const bool ok = k1 < p.K && a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
           float t = 0.f;
           if (ok) {
-            if (c < p.C0) t = p.in0[a_b[j] * p.s0n + c * p.s0c + iy * p.s0h + ix * p.s0w];
-            else t = p.in1[a_b[j] * p.s1n + (c - p.C0) + iy * p.s1h + ix * p.s1w];
+            if (c < p.C0) t = p.in0[a_n0[j] + c * p.s0c + iy * p.s0h + ix * p.s0w];
+            else t = p.in1[a_n1[j] + (c - p.C0) + iy * p.s1h + ix * p.s1w];
           }
           v[e] = t;
         }
@@ -156,10 +212,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-      const int n = n0 + lrow + 32 * j;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < p.Cout) v = *reinterpret_cast<const float4 *>(wbase + (int64_t)n * p.Kpad + kk);
-      rb[j] = v;
+      rb[j] = buf_load4(rsw, b_off[j]);
+      if (b_off[j] != OOB) b_off[j] += kBK * 4u;
+    }
+    // advance this thread's K position by one chunk
+    kk_next += kBK;
+    kc_c += kBK;
+    while (kc_c >= p.Cin) {
+      kc_c -= p.Cin;
+      if (++kc_kw == p.KW) { kc_kw = 0; ++kc_kh; }
     }
   };
 
@@ -167,8 +228,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     float *a = As + buf * BM * LDK;
     float *b = Bs + buf * BN * LDK;
 #pragma unroll
-    for (int j = 0; j < RA; ++j)
-      *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lq * 4) = ra[j];
+    for (int j = 0; j < RA; ++j) {
+      float4 v = ra[j];
+      if constexpr (DUAL) v = sel1 ? ra1[j] : v;
+      *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lq * 4) = v;
+    }
 #pragma unroll
     for (int j = 0; j < RB; ++j)
       *reinterpret_cast<float4 *>(b + (lrow + 32 * j) * LDK + lq * 4) = rb[j];
@@ -183,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = p.Kpad / kBK;
-  load_chunk(0);
+  load_chunk();
   store_chunk(0);
   __syncthreads();
 
@@ -192,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 
   for (int kc = 0; kc < nk; ++kc) {
     const int buf = kc & 1;
-    if (kc + 1 < nk) load_chunk(kc + 1);  // global loads in flight under the MFMAs
+    if (kc + 1 < nk) load_chunk();  // global loads in flight under the MFMAs
 
     const float *a = As + buf * BM * LDK + (wm0 + frow) * LDK + fq * 4;
     const float *b = Bs + buf * BN * LDK + (wn0 + frow) * LDK + fq * 4;
@@ -221,7 +285,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 
   // ---- epilogue: bias, residual, ReLU, store.  C layout of the 32x32 tile:
   // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-  const int64_t out_off = p.out_off[phase], res_off = p.res_off[phase];
+  // Row offsets (elements) are prepared once in LDS (the A/B tiles are dead now).
+  int *row_oo = reinterpret_cast<int *>(smem);  // [BM] output offset or -1
+  int *row_ro = row_oo + BM;                    // [BM] residual offset
+  if (tid < BM) {
+    const int b = row_b[tid], oy = row_y[tid], ox = row_x[tid];
+    row_oo[tid] = b < 0 ? -1 : out_off + b * p.on + oy * p.oh + ox * p.ow;
+    row_ro[tid] = b < 0 ? 0 : b * p.rn + oy * p.rh + ox * p.rw;
+  }
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + frow;
@@ -232,13 +304,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
-        const int b = row_b[row];
-        if (b < 0) continue;
-        const int oy = row_y[row], ox = row_x[row];
+        const int oo = row_oo[row];
+        if (oo < 0) continue;
         float v = acc[i][j][r] + bias;
-        if (p.res) v += p.res[res_off + b * p.rn + n * p.rc + oy * p.rh + ox * p.rw];
+        if (p.res) v += p.res[row_ro[row] + n * p.rc];
         if (p.relu) v = fmaxf(v, 0.f);
-        p.out[out_off + b * p.on + n * p.oc + oy * p.oh + ox * p.ow] = v;
+        p.out[oo + n * p.oc] = v;
       }
     }
   }
@@ -249,9 +320,9 @@ constexpr size_t conv_smem_bytes() {
   return (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + 3 * BM * sizeof(int);
 }
 
-template <int BM, int BN, int WM, int WN, bool SCALAR_A>
-static int launch_cfg(const ConvKArgs &a, hipStream_t stream) {
-  auto kern = conv_igemm_f32_kernel<BM, BN, WM, WN, SCALAR_A>;
+template <int BM, int BN, int WM, int WN, int MODE>
+static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
+  auto kern = conv_igemm_f32_kernel<BM, BN, WM, WN, MODE>;
   constexpr size_t smem = conv_smem_bytes<BM, BN>();
   static bool attr_set = false;  // idempotent; racing threads set the same value
   if (!attr_set) {
@@ -260,16 +331,16 @@ static int launch_cfg(const ConvKArgs &a, hipStream_t stream) {
       return check_launch("hipFuncSetAttribute(conv_igemm)");
     attr_set = true;
   }
-  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.nphase);
+  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, nphase);
   {
     // algorithmic work: every MAC of the convolution once; input read once,
     // output written once, weights once (DESIGN.md "roofline accounting")
-    const double np = a.nphase;
+    const double np = nphase;
     const double flops = 2.0 * a.M * np * a.Cout * a.K;
-    const double in_px = a.nphase == 1 ? (double)a.M / (a.OH * a.OW) * a.H * a.W : (double)a.M;
+    const double in_px = nphase == 1 ? (double)a.M / (a.OH * a.OW) * a.H * a.W : (double)a.M;
     const double bytes = 4.0 * (in_px * a.Cin + (double)a.M * np * a.Cout * (a.res ? 2 : 1) +
                                 np * a.Cout * a.K);
-    const int kid = SCALAR_A ? prof::K_CONV_GATHER
+    const int kid = MODE == 2 ? prof::K_CONV_GATHER
                              : (BN == 128 ? prof::K_CONV_128x128 : BN == 64 ? prof::K_CONV_128x64 : prof::K_CONV_128x32);
     prof::Scope scope(kid, flops, bytes, stream);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
@@ -277,18 +348,28 @@ static int launch_cfg(const ConvKArgs &a, hipStream_t stream) {
   return check_launch("conv_igemm_f32");
 }
 
-static int launch_conv(const ConvKArgs &a, bool scalar_a, hipStream_t stream) {
-  if (scalar_a) {
-    if (a.Cout <= 32) return launch_cfg<128, 32, 4, 1, true>(a, stream);
-    if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, true>(a, stream);
-    return launch_cfg<128, 128, 2, 2, true>(a, stream);
-  }
-  if (a.Cout <= 32) return launch_cfg<128, 32, 4, 1, false>(a, stream);
-  if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, false>(a, stream);
-  return launch_cfg<128, 128, 2, 2, false>(a, stream);
+static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_t stream) {
+  const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
+#define ISI_CONV_DISPATCH(MODE)                                                        \
+  do {                                                                                  \
+    if (a.Cout <= 32) return launch_cfg<128, 32, 4, 1, MODE>(a, nphase, stream);        \
+    if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, MODE>(a, nphase, stream);        \
+    return launch_cfg<128, 128, 2, 2, MODE>(a, nphase, stream);                         \
+  } while (0)
+  if (mode == 2) ISI_CONV_DISPATCH(2);
+  if (mode == 1) ISI_CONV_DISPATCH(1);
+  ISI_CONV_DISPATCH(0);
+#undef ISI_CONV_DISPATCH
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Largest element offset reachable through a strided 4-D view, +1.
+static int64_t extent(int64_t n, int64_t sn, int64_t c, int64_t sc, int64_t h, int64_t sh, int64_t w,
+                      int64_t sw) {
+  return (n - 1) * sn + (c - 1) * sc + (h - 1) * sh + (w - 1) * sw + 1;
+}
+constexpr int64_t kMaxElems = (int64_t)1 << 30;  // 4 GiB of fp32: 32-bit byte offsets
 
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
@@ -300,29 +381,38 @@ int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, cons
   const int OW = (W + 2 * pad - KW) / stride + 1;
   if (OH <= 0 || OW <= 0) return invalid("conv2d: empty output");
   if ((int64_t)B * OH * OW > INT32_MAX) return unsupported("conv2d: more than 2^31 output pixels");
+  const bool two = s1 && s1->ptr;
+  if (two && s1->sc != 1) return unsupported("conv2d: second source must be channels-last");
+  const int64_t e0 = extent(B, s0->sn, s0->C, s0->sc, H, s0->sh, W, s0->sw);
+  const int64_t e1 = two ? extent(B, s1->sn, s1->C, 1, H, s1->sh, W, s1->sw) : 1;
+  const int64_t eo = extent(B, dst->sn, Cout, dst->sc, OH, dst->sh, OW, dst->sw);
+  const int64_t er = (res && res->ptr) ? extent(B, res->sn, Cout, res->sc, OH, res->sh, OW, res->sw) : 1;
+  if (e0 > kMaxElems || e1 > kMaxElems || eo > kMaxElems || er > kMaxElems)
+    return unsupported("conv2d: a tensor spans 4 GiB or more");
   ConvKArgs a;
   memset(&a, 0, sizeof a);
-  a.in0 = s0->ptr; a.C0 = s0->C;
-  a.s0n = s0->sn; a.s0c = s0->sc; a.s0h = s0->sh; a.s0w = s0->sw;
-  const bool two = s1 && s1->ptr;
+  a.in0 = s0->ptr; a.C0 = s0->C; a.in0_bytes = (unsigned)(e0 * 4);
+  a.s0n = (int)s0->sn; a.s0c = (int)s0->sc; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;
   a.in1 = two ? s1->ptr : s0->ptr;
-  a.C1 = two ? s1->C : 0;
-  if (two) { a.s1n = s1->sn; a.s1h = s1->sh; a.s1w = s1->sw; }
-  a.Cin = a.C0 + a.C1;
+  a.in1_bytes = two ? (unsigned)(e1 * 4) : a.in0_bytes;
+  const int C1 = two ? s1->C : 0;
+  if (two) { a.s1n = (int)s1->sn; a.s1h = (int)s1->sh; a.s1w = (int)s1->sw; }
+  a.Cin = a.C0 + C1;
+  a.src_uniform = (!two || (a.C0 % kBK == 0 && C1 % kBK == 0)) ? 1 : 0;
   a.w = packed_w; a.bias = bias;
   a.res = (res && res->ptr) ? res->ptr : nullptr;
-  if (a.res) { a.rn = res->sn; a.rc = res->sc; a.rh = res->sh; a.rw = res->sw; }
-  a.out = dst->ptr; a.on = dst->sn; a.oc = dst->sc; a.oh = dst->sh; a.ow = dst->sw;
+  if (a.res) { a.rn = (int)res->sn; a.rc = (int)res->sc; a.rh = (int)res->sh; a.rw = (int)res->sw; }
+  a.out = dst->ptr; a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)dst->sh; a.ow = (int)dst->sw;
   a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.Cout = Cout;
   a.K = KH * KW * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
-  a.KH = KH; a.KW = KW; a.stride = stride; a.relu = relu; a.M = B * OH * OW;
-  a.nphase = 1; a.pad_y[0] = pad; a.pad_x[0] = pad;
-  if (two && s1->sc != 1) return unsupported("conv2d: second source must be channels-last");
-  bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (a.C1 % 4 == 0) && aligned16(s0->ptr) &&
+  a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
+  a.KW = KW; a.stride = stride; a.relu = relu; a.M = B * OH * OW;
+  a.pad = pad; a.convT = 0;
+  bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (C1 % 4 == 0) && aligned16(s0->ptr) &&
              (s0->sn % 4 == 0) && (s0->sh % 4 == 0) && (s0->sw % 4 == 0);
   if (two) vec = vec && aligned16(s1->ptr) && (s1->sn % 4 == 0) && (s1->sh % 4 == 0) && (s1->sw % 4 == 0);
   if (!aligned16(packed_w)) return invalid("conv2d: packed weight must be 16-byte aligned");
-  return launch_conv(a, !vec, stream);
+  return launch_conv(a, !vec, 1, stream);
 }
 
 int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const float *bias,
@@ -331,30 +421,29 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   if (!s || !s->ptr || !packed_w || !dst || !dst->ptr) return invalid("convT: null pointer");
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return invalid("convT: bad shape");
   if ((int64_t)B * H * W > INT32_MAX) return unsupported("convT: more than 2^31 pixels per phase");
+  const int64_t e0 = extent(B, s->sn, s->C, s->sc, H, s->sh, W, s->sw);
+  const int64_t eo = extent(B, dst->sn, Cout, dst->sc, 2 * H, dst->sh, 2 * W, dst->sw);
+  if (e0 > kMaxElems || eo > kMaxElems) return unsupported("convT: a tensor spans 4 GiB or more");
   ConvKArgs a;
   memset(&a, 0, sizeof a);
-  a.in0 = s->ptr; a.in1 = s->ptr; a.C0 = s->C; a.C1 = 0; a.Cin = s->C;
-  a.s0n = s->sn; a.s0c = s->sc; a.s0h = s->sh; a.s0w = s->sw;
+  a.in0 = s->ptr; a.in1 = s->ptr; a.C0 = s->C; a.Cin = s->C; a.src_uniform = 1;
+  a.in0_bytes = a.in1_bytes = (unsigned)(e0 * 4);
+  a.s0n = (int)s->sn; a.s0c = (int)s->sc; a.s0h = (int)s->sh; a.s0w = (int)s->sw;
   a.w = packed_w; a.bias = bias; a.res = nullptr;
   a.out = dst->ptr;
   // GEMM-grid pixel (m_y, m_x) of phase (py,px) is output pixel (2 m_y + py, 2 m_x + px)
-  a.on = dst->sn; a.oc = dst->sc; a.oh = 2 * dst->sh; a.ow = 2 * dst->sw;
+  a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)(2 * dst->sh); a.ow = (int)(2 * dst->sw);
+  a.dst_sh = (int)dst->sh; a.dst_sw = (int)dst->sw;
   a.H = H; a.W = W; a.OH = H; a.OW = W; a.Cout = Cout;
   a.K = 4 * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
-  a.KH = 2; a.KW = 2; a.stride = 1; a.relu = relu; a.M = B * H * W;
-  a.nphase = 4;
-  for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
-      const int ph = py * 2 + px;
-      a.pad_y[ph] = 1 - py;
-      a.pad_x[ph] = 1 - px;
-      a.w_off[ph] = (int64_t)ph * Cout * a.Kpad;
-      a.out_off[ph] = py * dst->sh + px * dst->sw;
-    }
+  a.w_phase_stride = Cout * a.Kpad;
+  a.w_bytes = (unsigned)((size_t)4 * Cout * a.Kpad * 4);
+  a.KW = 2; a.stride = 1; a.relu = relu; a.M = B * H * W;
+  a.convT = 1;
   const bool vec = s->sc == 1 && (a.C0 % 4 == 0) && aligned16(s->ptr) && (s->sn % 4 == 0) &&
                    (s->sh % 4 == 0) && (s->sw % 4 == 0);
   if (!aligned16(packed_w)) return invalid("convT: packed weight must be 16-byte aligned");
-  return launch_conv(a, !vec, stream);
+  return launch_conv(a, !vec, 4, stream);
 }
 
 }  // namespace isi

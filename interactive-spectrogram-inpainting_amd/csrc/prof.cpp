@@ -25,10 +25,10 @@ constexpr size_t kMaxRecords = 1 << 18;
 
 const char *kernel_name(int id) {
   switch (id) {
-    case K_CONV_128x128: return "conv_igemm_f32_kernel<128,128,2,2,false>";
-    case K_CONV_128x64: return "conv_igemm_f32_kernel<128,64,2,2,false>";
-    case K_CONV_128x32: return "conv_igemm_f32_kernel<128,32,4,1,false>";
-    case K_CONV_GATHER: return "conv_igemm_f32_kernel<*,true>";
+    case K_CONV_128x128: return "conv_igemm_f32_kernel<128,128,2,2,*>";
+    case K_CONV_128x64: return "conv_igemm_f32_kernel<128,64,2,2,*>";
+    case K_CONV_128x32: return "conv_igemm_f32_kernel<128,32,4,1,*>";
+    case K_CONV_GATHER: return "conv_igemm_f32_kernel<*,2> (gather)";
     case K_VQ_NEAREST: return "vq_nearest_kernel";
     default: return "?";
   }

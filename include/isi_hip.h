@@ -72,7 +72,10 @@ size_t isi_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
 /* ConvTranspose2d(k=4,s=2,p=1) weight [Cin,Cout,4,4] -> 4 phase matrices
  * [phase=py*2+px][Cout][Kpad], k = (ty*2+tx)*Cin + ci, tap (ty,tx) of phase
  * (py,px) reading torch tap (ky,kx) = (3-py-2ty, 3-px-2tx).
- * (encoder_decoder.py:199-215; vqvae.py:193-201). */
+ * When Cout <= 4 and Cin % 32 == 0 (the decoder's last layer) the layout is
+ * instead [ky][kx][Cin][Cout] for the direct small-Cout kernel; the choice is a
+ * function of (Cin, Cout) only and isi_conv_transpose2d_k4s2_f32 applies the
+ * same rule.  (encoder_decoder.py:199-215; vqvae.py:193-201). */
 int isi_pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin,
                                    int Cout, void *stream);
 size_t isi_packed_convT_k4s2_weight_floats(int Cin, int Cout);
@@ -117,6 +120,17 @@ int isi_conv_transpose2d_k4s2_f32(const isi_src *src, const float *packed_w,
                                   const float *bias, const isi_dst *dst, int B,
                                   int H, int W, int Cout, int relu,
                                   void *stream);
+
+/* Fused RosinalityResBlock on a rectified input r (encoder_decoder.py:22-35):
+ *   out = [relu]( r + conv1x1(relu(conv3x3(r) + b3)) + b1 )
+ * in/out dense channels-last [B,H,W,C]; packed_w3 = isi_pack_conv_weight_f32 of
+ * conv.1 ([R,C,3,3]), packed_w1 of conv.3 ([C,R,1,1]).  Available when
+ * isi_resblock_fusable(C, R) (C % 32 == 0, C <= 128, R <= 32); otherwise compose
+ * two isi_conv2d_f32 calls. */
+int isi_resblock_fusable(int C, int R);
+int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3,
+                     const float *packed_w1, const float *b1, float *out, int B,
+                     int H, int W, int C, int R, int relu, void *stream);
 
 /* ----------------------------------------------------------- quantization */
 

@@ -18,6 +18,7 @@
 // residual add / torch.cat at vqvae/encoder_decoder.py:22-35,95-112,138,199-215
 // and vqvae/vqvae.py:193-201,260,270-272,282.
 #include "isi_common.h"
+#include "isi_internal.h"
 #include "prof.h"
 
 namespace isi {
@@ -424,6 +425,14 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   const int64_t e0 = extent(B, s->sn, s->C, s->sc, H, s->sh, W, s->sw);
   const int64_t eo = extent(B, dst->sn, Cout, dst->sc, 2 * H, dst->sh, 2 * W, dst->sw);
   if (e0 > kMaxElems || eo > kMaxElems) return unsupported("convT: a tensor spans 4 GiB or more");
+  if (convT_small_applicable(s->C, Cout)) {
+    // few output channels: direct VALU kernel (weights were packed in its layout)
+    const bool dense = s->sc == 1 && s->sw == s->C && s->sh == (int64_t)W * s->C &&
+                       s->sn == (int64_t)H * W * s->C && aligned16(s->ptr);
+    if (!dense) return unsupported("convT: small-Cout path needs a dense channels-last source");
+    return convT_k4s2_small_f32(s->ptr, packed_w, bias, dst->ptr, B, H, W, s->C, Cout, (int)dst->sn,
+                                (int)dst->sc, (int)dst->sh, (int)dst->sw, relu, stream);
+  }
   ConvKArgs a;
   memset(&a, 0, sizeof a);
   a.in0 = s->ptr; a.in1 = s->ptr; a.C0 = s->C; a.Cin = s->C; a.src_uniform = 1;

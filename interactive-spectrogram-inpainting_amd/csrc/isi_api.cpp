@@ -71,6 +71,13 @@ int isi_conv_transpose2d_k4s2_f32(const isi_src *src, const float *packed_w, con
   return conv_transpose2d_k4s2_f32(src, packed_w, bias, dst, B, H, W, Cout, relu, S(stream));
 }
 
+int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3, const float *packed_w1,
+                     const float *b1, float *out, int B, int H, int W, int C, int R, int relu,
+                     void *stream) {
+  return resblock_f32(in, packed_w3, b3, packed_w1, b1, out, B, H, W, C, R, relu, S(stream));
+}
+int isi_resblock_fusable(int C, int R) { return resblock_fusable(C, R) ? 1 : 0; }
+
 int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,
                        float *q_out, int32_t *counts, float *sse_part, int64_t N, int D, int K,
                        void *stream) {

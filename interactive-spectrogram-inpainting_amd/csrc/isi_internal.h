@@ -13,6 +13,15 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
                               const isi_dst *dst, int B, int H, int W, int Cout, int relu,
                               hipStream_t stream);
 
+bool resblock_fusable(int C, int R);
+int resblock_f32(const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
+                 float *out, int B, int H, int W, int C, int R, int relu, hipStream_t stream);
+bool convT_small_applicable(int Cin, int Cout);
+int pack_convT_small_weight_f32(const float *w, float *packed, int Cin, int Cout, hipStream_t stream);
+int convT_k4s2_small_f32(const float *in, const float *wk, const float *bias, float *out, int B, int H,
+                         int W, int Cin, int Cout, int on, int oc, int oh, int ow, int relu,
+                         hipStream_t stream);
+
 int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                    int32_t *counts, float *sse_part, int64_t N, int D, int K, hipStream_t stream);
 int vq_num_partials(int64_t N);

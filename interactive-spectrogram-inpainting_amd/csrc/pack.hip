@@ -7,6 +7,7 @@
 // vqvae/encoder_decoder.py:95-112,138,199-215 and the `embed` buffer of
 // vqvae/bottleneck.py:47-51.
 #include "isi_common.h"
+#include "isi_internal.h"
 
 namespace isi {
 
@@ -76,6 +77,7 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW) {
   return (size_t)Cout * round_up((size_t)KH * KW * Cin, kBK);
 }
 size_t packed_convT_k4s2_weight_floats(int Cin, int Cout) {
+  if (convT_small_applicable(Cin, Cout)) return (size_t)16 * Cin * Cout;  // wk[ky][kx][ci][co]
   return (size_t)4 * Cout * round_up((size_t)4 * Cin, kBK);
 }
 
@@ -93,6 +95,7 @@ int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int K
 int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,
                                hipStream_t stream) {
   if (!w || !packed || Cout <= 0 || Cin <= 0) return invalid("pack_convT_weight: bad argument");
+  if (convT_small_applicable(Cin, Cout)) return pack_convT_small_weight_f32(w, packed, Cin, Cout, stream);
   const int Kpad = (int)round_up((size_t)4 * Cin, kBK);
   const int64_t total = (int64_t)4 * Cout * Kpad;
   hipLaunchKernelGGL(pack_convT_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,

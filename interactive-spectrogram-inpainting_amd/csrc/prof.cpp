@@ -30,6 +30,8 @@ const char *kernel_name(int id) {
     case K_CONV_128x32: return "conv_igemm_f32_kernel<128,32,4,1,*>";
     case K_CONV_GATHER: return "conv_igemm_f32_kernel<*,2> (gather)";
     case K_VQ_NEAREST: return "vq_nearest_kernel";
+    case K_RESBLOCK: return "resblock_f32_kernel";
+    case K_CONVT_SMALL: return "convT_k4s2_small_kernel";
     default: return "?";
   }
 }

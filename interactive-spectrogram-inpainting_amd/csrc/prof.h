@@ -13,6 +13,8 @@ enum KernelId {
   K_CONV_128x32,
   K_CONV_GATHER,   // element-wise gather A loader (NCHW / odd channel counts)
   K_VQ_NEAREST,
+  K_RESBLOCK,
+  K_CONVT_SMALL,
   K_COUNT
 };
 

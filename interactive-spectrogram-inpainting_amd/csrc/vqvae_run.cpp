@@ -110,12 +110,19 @@ int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act
                   float *s0, float *s1, float *hid, float *final_out, hipStream_t st) {
   for (int i = 0; i < n_res; ++i) {
     const int R = res3[i].Cout;
+    float *outp = (i == n_res - 1 && final_out) ? final_out : (cur.p == s0 ? s1 : s0);
+    if (resblock_fusable(cur.C, R)) {
+      int rc = resblock_f32(cur.p, res3[i].w, res3[i].bias, res1[i].w, res1[i].bias, outp, B, cur.H,
+                            cur.W, cur.C, R, /*relu*/ 1, st);
+      if (rc) return rc;
+      cur.p = outp;
+      continue;
+    }
     isi_src in = src_nhwc(cur.p, cur.C, cur.H, cur.W);
     isi_dst dh = dst_nhwc(hid, R, cur.H, cur.W);
     int rc = conv2d_f32(&in, nullptr, res3[i].w, res3[i].bias, nullptr, &dh, B, cur.H, cur.W, R, 3,
                         3, 1, 1, /*relu*/ 1, st);
     if (rc) return rc;
-    float *outp = (i == n_res - 1 && final_out) ? final_out : (cur.p == s0 ? s1 : s0);
     isi_src hin = src_nhwc(hid, R, cur.H, cur.W);
     isi_dst dout = dst_nhwc(outp, cur.C, cur.H, cur.W);
     rc = conv2d_f32(&hin, nullptr, res1[i].w, res1[i].bias, &in, &dout, B, cur.H, cur.W, cur.C, 1,

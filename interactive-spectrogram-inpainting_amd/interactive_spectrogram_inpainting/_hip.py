@@ -90,6 +90,9 @@ SIGNATURES = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_conv_transpose2d_k4s2_f32": (C.c_int, [C.POINTER(isi_src), _P, _P, C.POINTER(isi_dst), C.c_int,
                                                 C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_resblock_fusable": (C.c_int, [C.c_int, C.c_int]),
+    "isi_resblock_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, _P]),
     "isi_vq_nearest_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "isi_vq_num_partials": (C.c_int, [C.c_int64]),
     "isi_vq_finalize_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),

@@ -95,6 +95,24 @@ def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Op
     return out
 
 
+def resblock_fusable(C_: int, R: int) -> bool:
+    return bool(_hip.lib().isi_resblock_fusable(C_, R))
+
+
+def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: bool) -> torch.Tensor:
+    """Fused residual block on a rectified, dense channels-last input viewed as [B,C,H,W]."""
+    _hip.require_gpu(r_bchw, "resblock input")
+    B, C_, H, W = r_bchw.shape
+    nhwc = r_bchw.permute(0, 2, 3, 1)
+    if not nhwc.is_contiguous():
+        nhwc = nhwc.contiguous()
+    out = torch.empty_like(nhwc)
+    rc = _hip.lib().isi_resblock_f32(nhwc.data_ptr(), packed_w3.data_ptr(), b3.data_ptr(), packed_w1.data_ptr(),
+                                     b1.data_ptr(), out.data_ptr(), B, H, W, C_, R, int(relu), _s(r_bchw))
+    _hip.check(rc, "isi_resblock_f32")
+    return out.permute(0, 3, 1, 2)
+
+
 def vq_nearest(z: torch.Tensor, codes: torch.Tensor, e2: torch.Tensor):
     """z [..., D] dense channels-last -> (q_st [..., D], diff [], idx int64 [...], perplexity [])."""
     _hip.require_gpu(z, "quantizer input")

@@ -214,7 +214,7 @@ def test_vqvae_full_size_properties():
         z_t = torch.nn.functional.conv2d(enc_t, sd["quantize_conv_t.weight"],
                                          sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
         n_bad = _certify_index_mismatches(z_t, sd["quantize_t.embed"], id_t[:2].cpu(), ref[4])
-        assert n_bad <= 4, f"{n_bad} top indices differ from the oracle"
+        assert n_bad <= 0.005 * ref[4].numel(), f"{n_bad} top indices differ from the oracle"
     else:
         # same top codes => the bottom quantiser saw (numerically) the same input
         q_t = O.embed_code(ref[4], sd["quantize_t.embed"]).permute(0, 3, 1, 2)
@@ -222,6 +222,6 @@ def test_vqvae_full_size_properties():
         z_b = torch.nn.functional.conv2d(cat, sd["quantize_conv_b.weight"],
                                          sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
         n_bad = _certify_index_mismatches(z_b, sd["quantize_b.embed"], id_b[:2].cpu(), ref[5])
-        assert n_bad <= 8, f"{n_bad} bottom indices differ from the oracle"
+        assert n_bad <= 0.005 * ref[5].numel(), f"{n_bad} bottom indices differ from the oracle"
         if n_bad == 0:
             _close(dec[:2], ref[0], TOL, "dec vs oracle")

@@ -33,7 +33,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct ConvKArgs {
   const float *in0, *in1, *w, *bias, *res;
   float *out;
-  unsigned in0_bytes, in1_bytes, w_bytes;
+  unsigned in0_bytes, in1_bytes, w_bytes, out_bytes, res_bytes;
   int C0, Cin, src_uniform;  // src_uniform: a 32-wide K chunk never straddles the two sources
   int s0n, s0c, s0h, s0w;    // source 0 element strides
   int s1n, s1h, s1w;         // source 1 (channel stride 1)
@@ -286,7 +286,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 
   // ---- epilogue: bias, residual, ReLU, store.  C layout of the 32x32 tile:
   // col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-  // Row offsets (elements) are prepared once in LDS (the A/B tiles are dead now).
+  // Row offsets (elements) are prepared once in LDS (the A/B tiles are dead now);
+  // invalid rows / columns get an out-of-range buffer offset, so loads and stores
+  // are unconditional and all residual loads of a tile are in flight together.
   int *row_oo = reinterpret_cast<int *>(smem);  // [BM] output offset or -1
   int *row_ro = row_oo + BM;                    // [BM] residual offset
   if (tid < BM) {
@@ -295,22 +297,33 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     row_ro[tid] = b < 0 ? 0 : b * p.rn + oy * p.rh + ox * p.rw;
   }
   __syncthreads();
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.in0), 0, p.res_bytes, 0x00020000);
+  const bool has_res = p.res != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + frow;
-    if (n >= p.Cout) continue;
-    const float bias = p.bias ? p.bias[n] : 0.f;
+    const bool nok = n < p.Cout;
+    const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      unsigned oo[16];
+      float res[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
-        const int oo = row_oo[row];
-        if (oo < 0) continue;
-        float v = acc[i][j][r] + bias;
-        if (p.res) v += p.res[row_ro[row] + n * p.rc];
+        const int o = row_oo[row];
+        oo[r] = (nok && o >= 0) ? (unsigned)(o + n * p.oc) * 4u : OOB;
+        res[r] = 0.f;
+        if (has_res)
+          res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                 rsr, oo[r] == OOB ? OOB : (unsigned)(row_ro[row] + n * p.rc) * 4u, 0, 0));
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + bias + res[r];
         if (p.relu) v = fmaxf(v, 0.f);
-        p.out[oo + n * p.oc] = v;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso, oo[r], 0, 0);
       }
     }
   }
@@ -404,6 +417,7 @@ int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, cons
   a.res = (res && res->ptr) ? res->ptr : nullptr;
   if (a.res) { a.rn = (int)res->sn; a.rc = (int)res->sc; a.rh = (int)res->sh; a.rw = (int)res->sw; }
   a.out = dst->ptr; a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)dst->sh; a.ow = (int)dst->sw;
+  a.out_bytes = (unsigned)(eo * 4); a.res_bytes = (unsigned)(er * 4);
   a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.Cout = Cout;
   a.K = KH * KW * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
@@ -443,6 +457,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   // GEMM-grid pixel (m_y, m_x) of phase (py,px) is output pixel (2 m_y + py, 2 m_x + px)
   a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)(2 * dst->sh); a.ow = (int)(2 * dst->sw);
   a.dst_sh = (int)dst->sh; a.dst_sw = (int)dst->sw;
+  a.out_bytes = (unsigned)(eo * 4); a.res_bytes = 4;
   a.H = H; a.W = W; a.OH = H; a.OW = W; a.Cout = Cout;
   a.K = 4 * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_phase_stride = Cout * a.Kpad;

@@ -99,9 +99,11 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
     for (int t = 0; t < 9; ++t) *reinterpret_cast<float4 *>(W1s + (t * 32 + ln) * LDK + lq * 4) = rw[t];
   };
 
-  f32x16 acc1;
+  // Two accumulators (even / odd K steps): back-to-back MFMAs on ONE accumulator
+  // stall whenever anything else issues between them, alternating chains do not.
+  f32x16 acc1, acc1b;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc1[r] = 0.f; acc1b[r] = 0.f; }
 
   const int frow = lane & 31, fq = lane >> 5;
   const int ry = wave >> 1, rx = (wave & 1) * 32 + frow;  // this lane's pixel inside the tile
@@ -118,16 +120,22 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
       const float *a = a_base + ((t / 3) * HWD + (t % 3)) * LDK;
       const float *bb = b_base + t * 32 * LDK;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float4 af = *reinterpret_cast<const float4 *>(a + s * 8);
-        const float4 bf = *reinterpret_cast<const float4 *>(bb + s * 8);
+      for (int s = 0; s < 4; s += 2) {
+        const float4 af0 = *reinterpret_cast<const float4 *>(a + s * 8);
+        const float4 bf0 = *reinterpret_cast<const float4 *>(bb + s * 8);
+        const float4 af1 = *reinterpret_cast<const float4 *>(a + s * 8 + 8);
+        const float4 bf1 = *reinterpret_cast<const float4 *>(bb + s * 8 + 8);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(af, e), elem(bf, e), acc1, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(af0, e), elem(bf0, e), acc1, 0, 0, 0);
+          acc1b = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(af1, e), elem(bf1, e), acc1b, 0, 0, 0);
+        }
       }
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
 
   // ---- W2 -> LDS (over the dead W1 slice), h = relu(acc1 + b1) -> LDS (over the dead halo)
   float *W2s = W1s;
@@ -156,33 +164,45 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const float4 af = *reinterpret_cast<const float4 *>(hs + frow * LDK + fq * 4 + s * 8);
+    float4 bf[TC];
 #pragma unroll
-    for (int j = 0; j < TC; ++j) {
-      const float4 bf = *reinterpret_cast<const float4 *>(W2s + (j * 32 + frow) * LDK + fq * 4 + s * 8);
+    for (int j = 0; j < TC; ++j)
+      bf[j] = *reinterpret_cast<const float4 *>(W2s + (j * 32 + frow) * LDK + fq * 4 + s * 8);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(af, e), elem(bf, e), acc2[j], 0, 0, 0);
-    }
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int j = 0; j < TC; ++j)  // rotate over the accumulators
+        acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(af, e), elem(bf[j], e), acc2[j], 0, 0, 0);
   }
 
   // ---- epilogue: + b2 + r, ReLU, store.  Row r of this wave's tile = pixel
-  // (y0 + ry, x0 + (wave&1)*32 + row); lanes = 32 consecutive channels.
+  // (y0 + ry, x0 + (wave&1)*32 + row); lanes = 32 consecutive channels.  All
+  // residual loads of a channel tile are issued before the first use and
+  // out-of-image pixels are dropped by out-of-range buffer offsets: no branches,
+  // no load -> wait -> store serialisation.
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.in_bytes, 0x00020000);
   const int gy = y0 + ry;
-  if (gy < p.H) {
-    const int rowbase = (b * p.H + gy) * p.W;
+  const int rowbase = (b * p.H + gy) * p.W;
+  unsigned eoff[16];
 #pragma unroll
-    for (int j = 0; j < TC; ++j) {
-      const int n = j * 32 + frow;
-      const float b2 = p.b2[n];
+  for (int r = 0; r < 16; ++r) {
+    const int gx = x0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
+    eoff[r] = (gy < p.H && gx < p.W) ? (unsigned)((rowbase + gx) * C + frow) * 4u : OOB;
+  }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int gx = x0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
-        if (gx >= p.W) continue;
-        const int off = (rowbase + gx) * C + n;
-        float v = acc2[j][r] + b2 + p.in[off];
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.out[off] = v;
-      }
+  for (int j = 0; j < TC; ++j) {
+    const float b2 = p.b2[j * 32 + frow];
+    float res[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                             rsi, eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc2[j][r] + b2 + res[r];
+      if (p.relu) v = fmaxf(v, 0.f);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso,
+                                            eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0);
     }
   }
 }

@@ -1,0 +1,115 @@
+"""CPU tests of the host-side pieces around the hot path: codemap orderings
+(pinned by the reference's own outputs and its only test's round-trip
+property), mask samplers, and the 2-process (gloo) sharding logic."""
+import numpy as np
+import pytest
+import torch
+
+
+def test_codemap_orderings_match_reference(golden_dir):
+    from interactive_spectrogram_inpainting.priors.codemaps_helpers import (
+        SimpleCodemapsHelper, ZigZagCodemapsHelper)
+    z = np.load(golden_dir / "codemaps.npz")
+    checked = 0
+    for key in z.files:
+        parts = key.split("_")
+        if parts[0] == "simple":
+            F, T = map(int, parts[1].split("x"))
+            h = SimpleCodemapsHelper(F, T)
+            cm = torch.arange(F * T).reshape(1, F, T)
+            assert torch.equal(h.to_sequence(cm), torch.from_numpy(z[key])), key
+            checked += 1
+        elif parts[0] == "zigzag":
+            F, T = map(int, parts[1].split("x"))
+            pf, pt = map(int, parts[2].split("x"))
+            h = ZigZagCodemapsHelper(F, T, pf, pt)
+            cm = torch.arange(F * T).reshape(1, F, T)
+            seq = h.to_sequence(cm)
+            assert torch.equal(seq, torch.from_numpy(z[key])), key
+            assert torch.equal(h.to_time_frequency_map(seq), cm)
+            checked += 1
+        elif parts[0] == "zigzag4d" and parts[1] != "logits":
+            F, T = map(int, parts[1].split("x"))
+            pf, pt = map(int, parts[2].split("x"))
+            h = ZigZagCodemapsHelper(F, T, pf, pt)
+            cm4 = torch.arange(2 * F * T * 3).reshape(2, F, T, 3)
+            seq4 = h.to_sequence(cm4)
+            assert torch.equal(seq4, torch.from_numpy(z[key])), key
+            assert torch.equal(h.to_time_frequency_map(seq4), cm4)
+            logits = h.to_time_frequency_map(seq4, permute_output_as_logits=True)
+            assert torch.equal(logits, torch.from_numpy(z[f"zigzag4d_logits_{parts[1]}_{parts[2]}"]))
+            checked += 1
+    assert checked >= 12
+
+
+def test_codemap_properties_of_reference_test():
+    """tests/check_relative_transformer.py:59-123 of the reference: round trips on
+    arange maps with a trailing embedding dim of 3, and the first
+    target_events_per_source_patch entries of the zig-zag order."""
+    from interactive_spectrogram_inpainting.priors.codemaps_helpers import (
+        SimpleCodemapsHelper, ZigZagCodemapsHelper)
+    for cond, tgt in zip([[32, 4], [64, 8], [128, 16]], [[64, 8], [128, 16], [256, 32]]):
+        pf, pt = tgt[0] // cond[0], tgt[1] // cond[1]
+        src_h, tgt_h = SimpleCodemapsHelper(*cond), ZigZagCodemapsHelper(*tgt, pf, pt)
+        for h, (F, T) in ((src_h, cond), (tgt_h, tgt)):
+            cm = torch.arange(2 * F * T * 3).reshape(2, F, T, 3)
+            assert torch.equal(h.to_time_frequency_map(h.to_sequence(cm)), cm)
+        cm = torch.arange(tgt[0] * tgt[1]).reshape(1, *tgt)
+        first = tgt_h.to_sequence(cm)[0, :pf * pt]
+        # reference check (:106-119): arange(pf)[:,None] + arange(pt)[None,:]*duration, flattened
+        expect = (torch.arange(pf)[:, None] * tgt[1] + torch.arange(pt)[None, :]).t().flatten()
+        assert torch.equal(first, expect)
+
+
+def test_sequence_masks():
+    from interactive_spectrogram_inpainting.priors import sequence_mask as M
+    torch.manual_seed(0)
+    m = M.BernoulliSequenceMask(0.3, 1000, 512).sample_mask(8)
+    assert m.shape == (8, 1000) and m.dtype == torch.bool and 0.25 < m.float().mean() < 0.35
+    m = M.UniformMaskedAmountSequenceMask(0.5, 64, 512).sample_mask(5)
+    counts = m.sum(1)
+    assert (counts == counts[0]).all() and 32 <= counts[0] <= 64
+    x = torch.zeros(3, 64, dtype=torch.int64)
+    y = M.UniformProbabilityBernoulliSequenceMask(0.2, 0.9, 64, 512).apply_mask(x)
+    assert set(y.unique().tolist()) <= {0, 512}
+
+
+def _worker(rank, world, port, q):
+    import os
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "interactive-spectrogram-inpainting_amd"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from interactive_spectrogram_inpainting.utils.distributed import (
+        DistributedEvalSampler, is_distributed, is_master_process, max_over_ranks)
+    assert is_distributed() and is_master_process() == (rank == 0)
+    ds = list(range(11))
+    s = DistributedEvalSampler(ds, shuffle=False)
+    idx = list(s)
+    assert len(idx) == len(s)
+    slow = max_over_ranks(1.0 + rank)
+    q.put((rank, idx, slow))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_sharding_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + int(torch.randint(0, 2000, (1,)).item())
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shards = {r: idx for r, idx, _ in out}
+    assert sorted(shards[0] + shards[1]) == list(range(11))       # nothing added, nothing dropped
+    assert not set(shards[0]) & set(shards[1]) and len(shards[0]) == 6 and len(shards[1]) == 5
+    assert all(abs(slow - 2.0) < 1e-12 for _, _, slow in out)        # max over ranks

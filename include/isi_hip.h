@@ -40,7 +40,7 @@ const char *isi_last_error(void);
 /* sizeof() of the structs below as compiled into the library, so that FFI
  * bindings can verify their own layout: which = 0 isi_src, 1 isi_dst,
  * 2 isi_conv_w, 3 isi_encoder_w, 4 isi_decoder_w, 5 isi_codebook_w,
- * 6 isi_vqvae_w, 7 isi_vqvae_out.  Returns 0 for an unknown id. */
+ * 6 isi_vqvae_w, 7 isi_vqvae_out, 8 isi_attn_args.  Returns 0 for an unknown id. */
 size_t isi_abi_struct_bytes(int which);
 
 /* x = max(x, 0) in place over n floats: the in-place nn.ReLU with which
@@ -131,6 +131,56 @@ int isi_resblock_fusable(int C, int R);
 int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3,
                      const float *packed_w1, const float *b1, float *out, int B,
                      int H, int W, int C, int R, int relu, void *stream);
+
+/* ------------------------------------------------------ transformer prior */
+/* The prior's layers are instantiated by the reference from the absent package
+ * VQCPCB.transformer.transformer_custom (priors/transformer.py:12-15,370-417);
+ * their arithmetic is specified in oracle/prior_oracle.py (parity unpinned). */
+
+/* Multi-head attention with relative-position logits, flash style:
+ *   logit[i,j] = (q_i.k_j + q_i.e[h, r(i,j)]) * scale + mask(i,j)
+ *   r(i,j) = floor(i/Cq) - floor(j/Ck) + Ek - 1 ;  out_i = softmax_j(logit) v_j
+ * q/k/v/out are addressed as [seq, batch, head, head_dim] with element strides
+ * (ss, sb, sh) and contiguous head_dim (16, 32 or 64).  rel_embeddings
+ * [H, rel_rows, head_dim] may be NULL (no bias).  mask_mode: 0 none, 1 causal
+ * (j <= i), 2 anti-causal (j >= i); dense_mask [Sq,Sk] additive, may be NULL. */
+typedef struct isi_attn_args {
+  const float *q, *k, *v, *rel_embeddings, *dense_mask;
+  float *out;
+  int Sq, Sk, B, H, head_dim;
+  int64_t q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;
+  int Cq, Ck, Ek, rel_rows;
+  int mask_mode;
+  float scale;
+} isi_attn_args;
+int isi_rel_attention_f32(const isi_attn_args *args, void *stream);
+
+/* out[m,:] = LayerNorm(x[m,:] + residual[m,:]) * gamma + beta  (residual may be NULL). */
+int isi_layernorm_f32(const float *x, const float *residual, const float *gamma,
+                      const float *beta, float *out, int64_t M, int D, float eps,
+                      void *stream);
+
+/* Single-token decoding: out[m,n] = [relu](x[m,:].W[n,:] + bias[n] + residual[m,n])
+ * for M <= 8 rows; W in torch layout [N,K].  (Whole sequences go through
+ * isi_conv2d_f32 with a 1x1 kernel, which is a GEMM.) */
+int isi_linear_rows_f32(const float *x, int x_stride, const float *W, const float *bias,
+                        const float *residual, int res_stride, float *out, int out_stride,
+                        int M, int N, int K, int relu, void *stream);
+
+/* Decoding step: ONE query row per (batch, head) at sequence position q_pos
+ * against args->Sk cached keys/values (same logits as isi_rel_attention_f32;
+ * args->Sq, q_ss, o_ss, mask_mode and dense_mask are ignored: the caller passes
+ * Sk = q_pos + 1 for causal self-attention). */
+int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, void *stream);
+
+/* One categorical draw per row (sample.py:286-295): logits/temperature ->
+ * top_k_top_p_filtering (sample.py:36-65) -> softmax -> inverse-CDF draw with the
+ * host-supplied uniform u[row] (first index whose cumulative probability exceeds
+ * u * total).  filtered [rows, n] (optional) receives the filtered logits
+ * (-inf where removed).  n <= 1024. */
+int isi_sample_row_f32(const float *logits, int stride, int rows, int n, float temperature,
+                       int top_k, float top_p, const float *u, int64_t *out,
+                       float *filtered, void *stream);
 
 /* ----------------------------------------------------------- quantization */
 

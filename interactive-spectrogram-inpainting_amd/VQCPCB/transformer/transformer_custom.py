@@ -1,0 +1,278 @@
+"""Relative-attention transformer layers on MI355X.
+
+Same class names, constructor keywords and call / return conventions as the
+module the reference imports (priors/transformer.py:370-417,756-779):
+
+    TransformerEncoderLayerCustom(d_model, nhead, attention_bias_type, num_channels, num_events)
+    TransformerDecoderLayerCustom(d_model, nhead, attention_bias_type_self, attention_bias_type_cross,
+                                  num_channels_encoder, num_events_encoder,
+                                  num_channels_decoder, num_events_decoder)
+    TransformerEncoderCustom(encoder_layer, num_layers).forward(src, mask=)            -> (memory, [])
+    TransformerDecoderCustom(decoder_layer, num_layers).forward(tgt, memory, tgt_mask=, memory_mask=) -> (out, [])
+    TransformerCustom(nhead, custom_encoder, custom_decoder, d_model)   .encoder / .decoder
+
+Inputs are time-major `[S, B, d_model]` fp32.  Masks may be the additive float
+matrices the reference builds (`causal_mask`, its transpose; recognised and
+replaced by an in-kernel predicate) or the strings 'causal' / 'anticausal'.
+Arithmetic: see oracle/prior_oracle.py (specification; parity unpinned because
+the original package is not available).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import List, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from interactive_spectrogram_inpainting.priors import _ops
+
+MaskArg = Union[None, str, torch.Tensor]
+
+
+class _LinearParams(nn.Module):
+    """nn.Linear-shaped parameter holder (same default init); GEMM operand cached per version."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+        self._packed, self._key = None, None
+
+    def packed(self):
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._key != key:
+            self._packed, self._key = _ops.pack_linear_weight(self.weight), key
+        return self._packed
+
+    def run(self, x, relu=False, residual=None):
+        return _ops.linear(x, self.packed(), self.bias, self.out_features, relu=relu, residual=residual)
+
+
+class _LayerNormParams(nn.Module):
+    def __init__(self, d: int, eps: float = 1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+        self.eps = eps
+
+    def run(self, x):
+        return _ops.layernorm(x, self.weight, self.bias, self.eps)
+
+
+def _classify_mask(mask: MaskArg, Sq: int, Sk: int, device) -> Tuple[int, Optional[torch.Tensor]]:
+    """-> (mask_mode, dense_mask): 0 none, 1 causal, 2 anti-causal."""
+    if mask is None:
+        return 0, None
+    if isinstance(mask, str):
+        return {"causal": 1, "anticausal": 2, "none": 0}[mask], None
+    m = mask.detach()
+    if m.shape != (Sq, Sk):
+        raise RuntimeError(f"attention mask of shape {tuple(m.shape)} for a {Sq}x{Sk} score matrix")
+    key = (m.data_ptr(), m._version, tuple(m.shape), m.device)
+    hit = _classify_mask.cache.get(key)
+    if hit is None:
+        allowed = (m.cpu() == 0)
+        tril = torch.ones(Sq, Sk, dtype=torch.bool).tril()
+        if Sq == Sk and torch.equal(allowed, tril):
+            hit = 1
+        elif Sq == Sk and torch.equal(allowed, tril.t()):
+            hit = 2
+        elif bool(allowed.all()):
+            hit = 0
+        else:
+            hit = -1
+        if len(_classify_mask.cache) > 64:
+            _classify_mask.cache.clear()
+        _classify_mask.cache[key] = hit
+    if hit >= 0:
+        return hit, None
+    return 0, m.to(device=device, dtype=torch.float32).contiguous()
+
+
+_classify_mask.cache = {}
+
+
+class RelativeMultiheadAttention(nn.Module):
+    """q.k + q.e[r] attention; r(i,j) = i//Cq - j//Ck + Ek - 1 (oracle/prior_oracle.py)."""
+
+    def __init__(self, d_model: int, nhead: int, attention_bias_type: str, num_channels_q: int,
+                 num_events_q: int, num_channels_k: int, num_events_k: int):
+        super().__init__()
+        if d_model % nhead:
+            raise ValueError("d_model must be divisible by nhead")
+        if attention_bias_type not in ("relative_attention", "relative_attention_target_source", "no_bias"):
+            raise ValueError(f"unknown attention_bias_type {attention_bias_type}")
+        self.d_model, self.nhead, self.head_dim = d_model, nhead, d_model // nhead
+        self.attention_bias_type = attention_bias_type
+        self.Cq, self.Eq, self.Ck, self.Ek = num_channels_q, num_events_q, num_channels_k, num_events_k
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        self.out_proj = _LinearParams(d_model, d_model)
+        if attention_bias_type != "no_bias":
+            self.rel_embeddings = nn.Parameter(
+                torch.randn(nhead, num_events_q + num_events_k - 1, self.head_dim) * self.head_dim ** -0.5)
+        else:
+            self.register_parameter("rel_embeddings", None)
+        self._packed, self._key = None, None
+
+    def _packs(self):
+        key = (self.in_proj_weight._version, self.in_proj_weight.data_ptr())
+        if self._key != key:
+            d = self.d_model
+            W = self.in_proj_weight.detach()
+            self._packed = (_ops.pack_linear_weight(W), _ops.pack_linear_weight(W[:d]),
+                            _ops.pack_linear_weight(W[d:]))
+            self._key = key
+        return self._packed
+
+    def project_kv(self, mem: torch.Tensor) -> torch.Tensor:
+        """[Sk,B,d] -> fused [Sk,B,2d] keys|values (cacheable: depends on mem only)."""
+        d = self.d_model
+        return _ops.linear(mem, self._packs()[2], self.in_proj_bias[d:], 2 * d)
+
+    def forward(self, x: torch.Tensor, mem: Optional[torch.Tensor], mask: MaskArg = None,
+                kv: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Attention output BEFORE the output projection ([Sq,B,d]); `mem is None` = self-attention."""
+        d = self.d_model
+        Sq = x.shape[0]
+        w_all, w_q, _ = self._packs()
+        if mem is None and kv is None:
+            qkv = _ops.linear(x, w_all, self.in_proj_bias, 3 * d)
+            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        else:
+            q = _ops.linear(x, w_q, self.in_proj_bias[:d], d)
+            if kv is None:
+                kv = self.project_kv(mem)
+            k, v = kv[..., :d], kv[..., d:]
+        mode, dense = _classify_mask(mask, Sq, k.shape[0], x.device)
+        return _ops.rel_attention(q, k, v, self.rel_embeddings, self.nhead, self.Cq, self.Ck, self.Ek,
+                                  mask_mode=mode, dense_mask=dense)
+
+
+
+
+class TransformerEncoderLayerCustom(nn.Module):
+    def __init__(self, d_model: int, nhead: int, attention_bias_type: str = "relative_attention",
+                 num_channels: int = 1, num_events: int = 1, dim_feedforward: int = 2048,
+                 dropout: float = 0.1):
+        super().__init__()
+        self.self_attn = RelativeMultiheadAttention(d_model, nhead, attention_bias_type, num_channels,
+                                                    num_events, num_channels, num_events)
+        self.linear1 = _LinearParams(d_model, dim_feedforward)
+        self.linear2 = _LinearParams(dim_feedforward, d_model)
+        self.norm1 = _LayerNormParams(d_model)
+        self.norm2 = _LayerNormParams(d_model)
+        self.dropout = dropout  # eval-only path: dropout is the identity
+
+    def forward(self, src: torch.Tensor, src_mask: MaskArg = None) -> torch.Tensor:
+        a = self.self_attn(src, None, src_mask)
+        x = self.norm1.run(self.self_attn.out_proj.run(a, residual=src))
+        h = self.linear1.run(x, relu=True)
+        return self.norm2.run(self.linear2.run(h, residual=x))
+
+
+class TransformerDecoderLayerCustom(nn.Module):
+    def __init__(self, d_model: int, nhead: int, attention_bias_type_self: str = "relative_attention",
+                 attention_bias_type_cross: str = "relative_attention_target_source",
+                 num_channels_encoder: int = 1, num_events_encoder: int = 1,
+                 num_channels_decoder: int = 1, num_events_decoder: int = 1,
+                 dim_feedforward: int = 2048, dropout: float = 0.1):
+        super().__init__()
+        self.self_attn = RelativeMultiheadAttention(d_model, nhead, attention_bias_type_self,
+                                                    num_channels_decoder, num_events_decoder,
+                                                    num_channels_decoder, num_events_decoder)
+        self.multihead_attn = RelativeMultiheadAttention(d_model, nhead, attention_bias_type_cross,
+                                                         num_channels_decoder, num_events_decoder,
+                                                         num_channels_encoder, num_events_encoder)
+        self.linear1 = _LinearParams(d_model, dim_feedforward)
+        self.linear2 = _LinearParams(dim_feedforward, d_model)
+        self.norm1 = _LayerNormParams(d_model)
+        self.norm2 = _LayerNormParams(d_model)
+        self.norm3 = _LayerNormParams(d_model)
+        self.dropout = dropout
+
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, tgt_mask: MaskArg = None,
+                memory_mask: MaskArg = None, memory_kv: Optional[torch.Tensor] = None) -> torch.Tensor:
+        a = self.self_attn(tgt, None, tgt_mask)
+        x = self.norm1.run(self.self_attn.out_proj.run(a, residual=tgt))
+        c = self.multihead_attn(x, memory, memory_mask, kv=memory_kv)
+        x = self.norm2.run(self.multihead_attn.out_proj.run(c, residual=x))
+        h = self.linear1.run(x, relu=True)
+        return self.norm3.run(self.linear2.run(h, residual=x))
+
+
+class TransformerAlignedDecoderLayerCustom(TransformerDecoderLayerCustom):
+    """The reference's hierarchical 'aligned' variant restricts cross-attention to
+    the source token a target patch sits under (priors/transformer.py:388-396).  Its
+    definition lives only in the absent package; not built."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("TransformerAlignedDecoderLayerCustom (use_aligned_decoder=True) is not built")
+
+
+class TransformerEncoderCustom(nn.Module):
+    def __init__(self, encoder_layer: nn.Module, num_layers: int):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(encoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        for layer in self.layers[1:]:
+            _reinit(layer)
+
+    def forward(self, src: torch.Tensor, mask: MaskArg = None) -> Tuple[torch.Tensor, List]:
+        x = src.contiguous()
+        for layer in self.layers:
+            x = layer(x, mask)
+        return x, []
+
+
+class TransformerDecoderCustom(nn.Module):
+    def __init__(self, decoder_layer: nn.Module, num_layers: int):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(decoder_layer) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        for layer in self.layers[1:]:
+            _reinit(layer)
+
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, tgt_mask: MaskArg = None,
+                memory_mask: MaskArg = None, condition: Optional[torch.Tensor] = None
+                ) -> Tuple[torch.Tensor, List]:
+        if condition is not None:
+            raise NotImplementedError("local class conditioning is deprecated in the reference "
+                                      "(priors/transformer.py:107-109)")
+        x = tgt.contiguous()
+        memory = memory.contiguous()
+        for layer in self.layers:
+            x = layer(x, memory, tgt_mask, memory_mask)
+        return x, []
+
+
+class TransformerCustom(nn.Module):
+    def __init__(self, nhead: int, custom_encoder: nn.Module, custom_decoder: nn.Module, d_model: int):
+        super().__init__()
+        self.nhead, self.d_model = nhead, d_model
+        self.encoder = custom_encoder
+        self.decoder = custom_decoder
+
+    def forward(self, src, tgt=None, mask: MaskArg = None, **kw):
+        raise NotImplementedError("the unconditional (encoder-only) model is not used by the reference's "
+                                  "Self-attentive / Upsampling priors and is not built")
+
+
+def _reinit(layer: nn.Module) -> None:
+    """Deep copies share initial values; give every copy its own draw (like torch's
+    _get_clones users usually re-initialise with xavier)."""
+    for m in layer.modules():
+        if isinstance(m, _LinearParams):
+            nn.init.kaiming_uniform_(m.weight, a=math.sqrt(5))
+            nn.init.uniform_(m.bias, -1 / math.sqrt(m.in_features), 1 / math.sqrt(m.in_features))
+        elif isinstance(m, RelativeMultiheadAttention):
+            nn.init.xavier_uniform_(m.in_proj_weight)
+            if m.rel_embeddings is not None:
+                nn.init.normal_(m.rel_embeddings, std=m.head_dim ** -0.5)

@@ -29,6 +29,7 @@ size_t isi_abi_struct_bytes(int which) {
     case 5: return sizeof(isi_codebook_w);
     case 6: return sizeof(isi_vqvae_w);
     case 7: return sizeof(isi_vqvae_out);
+    case 8: return sizeof(isi_attn_args);
     default: return 0;
   }
 }
@@ -77,6 +78,25 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3, c
   return resblock_f32(in, packed_w3, b3, packed_w1, b1, out, B, H, W, C, R, relu, S(stream));
 }
 int isi_resblock_fusable(int C, int R) { return resblock_fusable(C, R) ? 1 : 0; }
+
+int isi_rel_attention_f32(const isi_attn_args *args, void *stream) { return rel_attention_f32(args, S(stream)); }
+int isi_layernorm_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *out,
+                      int64_t M, int D, float eps, void *stream) {
+  return layernorm_f32(x, residual, gamma, beta, out, M, D, eps, S(stream));
+}
+int isi_linear_rows_f32(const float *x, int x_stride, const float *W, const float *bias, const float *residual,
+                        int res_stride, float *out, int out_stride, int M, int N, int K, int relu,
+                        void *stream) {
+  return linear_rows_f32(x, x_stride, W, bias, residual, res_stride, out, out_stride, M, N, K, relu, S(stream));
+}
+
+int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, void *stream) {
+  return rel_attention_decode_f32(args, q_pos, S(stream));
+}
+int isi_sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k,
+                       float top_p, const float *u, int64_t *out, float *filtered, void *stream) {
+  return sample_row_f32(logits, stride, rows, n, temperature, top_k, top_p, u, out, filtered, S(stream));
+}
 
 int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,
                        float *q_out, int32_t *counts, float *sse_part, int64_t N, int D, int K,

@@ -22,6 +22,17 @@ int convT_k4s2_small_f32(const float *in, const float *wk, const float *bias, fl
                          int W, int Cin, int Cout, int on, int oc, int oh, int ow, int relu,
                          hipStream_t stream);
 
+int rel_attention_f32(const isi_attn_args *g, hipStream_t stream);
+int layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,
+                  int64_t M, int D, float eps, hipStream_t stream);
+int linear_rows_f32(const float *x, int x_stride, const float *W, const float *bias, const float *res,
+                    int res_stride, float *out, int out_stride, int M, int N, int K, int relu,
+                    hipStream_t stream);
+
+int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, hipStream_t stream);
+int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
+                   const float *u, int64_t *out, float *filtered, hipStream_t stream);
+
 int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                    int32_t *counts, float *sse_part, int64_t N, int D, int K, hipStream_t stream);
 int vq_num_partials(int64_t N);

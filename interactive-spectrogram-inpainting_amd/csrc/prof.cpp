@@ -32,6 +32,7 @@ const char *kernel_name(int id) {
     case K_VQ_NEAREST: return "vq_nearest_kernel";
     case K_RESBLOCK: return "resblock_f32_kernel";
     case K_CONVT_SMALL: return "convT_k4s2_small_kernel";
+    case K_REL_ATTENTION: return "rel_attention_f32_kernel";
     default: return "?";
   }
 }

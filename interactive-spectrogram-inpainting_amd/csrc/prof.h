@@ -15,6 +15,7 @@ enum KernelId {
   K_VQ_NEAREST,
   K_RESBLOCK,
   K_CONVT_SMALL,
+  K_REL_ATTENTION,
   K_COUNT
 };
 

@@ -1,0 +1,306 @@
+// Multi-head attention with learned relative-position logits for gfx950
+// (exact-fp32 matrix pipe), flash style: the Sq x Sk score matrix and the
+// causal / anti-causal masks are never materialised.
+//
+//   logit[i,j] = ( q_i.k_j + q_i.e[h, r(i,j)] ) * scale + mask(i,j)
+//   r(i,j)     = floor(i/Cq) - floor(j/Ck) + (Ek - 1)
+//   out_i      = sum_j softmax_j(logit[i,:]) v_j
+//
+// This is the operator the reference reaches through the absent package
+// VQCPCB.transformer.transformer_custom (priors/transformer.py:370-417,756-777);
+// its specification for this repository is oracle/prior_oracle.py (parity
+// unpinned).
+//
+// Workgroup = 4 waves = 128 consecutive queries of one (batch, head); each wave
+// owns 32 queries.  Per tile of 32 keys (K, V and the needed band of e staged in
+// LDS, zero-filled past the ends by out-of-range buffer offsets):
+//   S^T   = K Q^T            (MFMA 32x32x2 f32, operands swapped: a lane's 16
+//                             accumulators are 16 keys of ONE query, so the row
+//                             max / sum of the online softmax are lane-local
+//                             plus one exchange with lane^32)
+//   Srel  = E_band Q^T       (same shape; the entry a (query,key) pair needs is
+//                             read back through a per-wave LDS buffer: the skew)
+//   O^T  += V^T P^T          (P^T is already the B fragment: accumulator r of a
+//                             lane is the k-slot of MFMA step r)
+#include "isi_common.h"
+#include "isi_internal.h"
+#include "prof.h"
+
+namespace isi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct AttnKArgs {
+  const float *q, *k, *v, *e, *mask;
+  float *out;
+  unsigned q_bytes, k_bytes, v_bytes, e_bytes;
+  int Sq, Sk, H;
+  int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
+  int Cq, Ck, Ek, R;
+  int mask_mode;  // 0 none, 1 causal (j <= i), 2 anti-causal (j >= i)
+  float scale;
+};
+
+namespace {
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr float NEG = -1e30f;
+constexpr int QB = 128;        // queries per workgroup
+constexpr int BAND = 160;      // rows of e staged per key tile (>= 127/Cq + 31/Ck + 1)
+constexpr int SRLD = 65;       // per-query row of the skew buffer (64 + 1: conflict-free)
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+  return *reinterpret_cast<float4 *>(&v);
+}
+__device__ __forceinline__ float elem(const float4 &v, int e) {
+  return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+}  // namespace
+
+template <int HD>
+__global__ __launch_bounds__(256) void rel_attention_f32_kernel(const AttnKArgs p) {
+  constexpr int LDH = HD + 4;  // padded LDS row
+  constexpr int NQ = HD / 8;   // float4 fragments per lane along the head dim
+  constexpr int NDB = (HD + 31) / 32;  // 32-wide blocks of the head dim in O
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Ks = smem;                 // [32][LDH]
+  float *Vs = Ks + 32 * LDH;        // [32][LDH]
+  float *Eb = Vs + 32 * LDH;        // [BAND][LDH]
+  float *Sr = Eb + BAND * LDH;      // [4][32][SRLD]
+  int *evk = reinterpret_cast<int *>(Sr + 4 * 32 * SRLD);  // [32] evk_max - event(key)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB, qw0 = q0 + 32 * wave, qi = qw0 + ql;
+  const bool has_e = p.e != nullptr;
+
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.v), 0, p.v_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_e ? p.e : p.q), 0, has_e ? p.e_bytes : 4u, 0x00020000);
+
+  // ---- Q fragment of this lane's query: quads (2s + half)
+  float4 qf[NQ];
+#pragma unroll
+  for (int s = 0; s < NQ; ++s) {
+    const unsigned off = qi < p.Sq ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + (2 * s + half) * 4) * 4u : OOB;
+    qf[s] = buf_load4(rq, off);
+  }
+  const int evq = qi / p.Cq;
+  const int evq_w0 = qw0 / p.Cq, evq_b0 = q0 / p.Cq;
+
+  float m_run = NEG, l_run = 0.f;
+  f32x16 O[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+
+  // key range this workgroup has to visit
+  int k_begin = 0, k_end = p.Sk;
+  if (p.mask_mode == 1) k_end = min(p.Sk, q0 + QB);
+  if (p.mask_mode == 2) k_begin = (q0 / 32) * 32;
+
+  const int srow = tid >> 3, squad = tid & 7;  // staging: 32 rows x 8 quads per pass
+
+  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+    const int evk_max = (k0 + 31) / p.Ck;
+    const int rb = evq_b0 - evk_max + p.Ek - 1;  // first table row of the band
+    __syncthreads();
+    // ---- stage K, V (32 x HD) and the band of e (BAND x HD)
+    for (int qd = squad; qd < HD / 4; qd += 8) {
+      const int kj = k0 + srow;
+      const bool ok = kj < p.Sk;
+      *reinterpret_cast<float4 *>(Ks + srow * LDH + qd * 4) =
+          buf_load4(rk, ok ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + qd * 4) * 4u : OOB);
+      *reinterpret_cast<float4 *>(Vs + srow * LDH + qd * 4) =
+          buf_load4(rv, ok ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + qd * 4) * 4u : OOB);
+    }
+    if (has_e) {
+      for (int row = srow; row < BAND; row += 32) {
+        const int r = rb + row;
+        const bool ok = r >= 0 && r < p.R;
+        for (int qd = squad; qd < HD / 4; qd += 8)
+          *reinterpret_cast<float4 *>(Eb + row * LDH + qd * 4) =
+              buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      }
+    }
+    if (tid < 32) evk[tid] = evk_max - (k0 + tid) / p.Ck;
+    __syncthreads();
+
+    // does this wave's query tile see any key of this tile?
+    bool live = qw0 < p.Sq;
+    if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
+    if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
+    if (!live) continue;  // wave-uniform
+
+    // ---- S^T = K Q^T
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    {
+      const float *kr = Ks + ql * LDH + half * 4;
+#pragma unroll
+      for (int s = 0; s < NQ; ++s) {
+        const float4 kf = *reinterpret_cast<const float4 *>(kr + s * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(kf, e), elem(qf[s], e), sacc, 0, 0, 0);
+      }
+    }
+    float sv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
+
+    // ---- relative logits through the skew buffer
+    if (has_e) {
+      float *sr = Sr + wave * 32 * SRLD + ql * SRLD;
+      const int wrow0 = evq_w0 - evq_b0;  // this wave's first band row
+      const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;  // 32-row tiles of the band actually reachable
+      for (int t = 0; t < nt; ++t) {
+        f32x16 racc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+        const float *er = Eb + (wrow0 + 32 * t + ql) * LDH + half * 4;
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+          const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(ef, e), elem(qf[s], e), racc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sr[32 * t + mfma_row(r, half)] = racc[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int dq = evq - evq_w0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evk[mfma_row(r, half)]];
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- scale, mask, online softmax (this lane: query qi, 16 of the tile's keys)
+    float tmax = NEG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kj = k0 + mfma_row(r, half);
+      bool ok = kj < p.Sk;
+      if (p.mask_mode == 1) ok = ok && kj <= qi;
+      if (p.mask_mode == 2) ok = ok && kj >= qi;
+      float s = sv[r] * p.scale;
+      if (p.mask && ok && qi < p.Sq) s += p.mask[(size_t)qi * p.Sk + kj];
+      s = ok ? s : NEG;
+      sv[r] = s;
+      tmax = fmaxf(tmax, s);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pr = sv[r] <= -1e29f ? 0.f : expf(sv[r] - m_new);
+      sv[r] = pr;
+      psum += pr;
+    }
+    psum += __shfl_xor(psum, 32);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+
+    // ---- O^T = alpha * O^T + V^T P^T
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+      const int dcol = d * 32 + ql;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float vv = dcol < HD ? Vs[mfma_row(t, half) * LDH + dcol] : 0.f;
+        O[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sv[t], O[d], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: accumulator regs 4g..4g+3 are 4 consecutive head dims
+  if (qi < p.Sq) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float *orow = p.out + (size_t)qi * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * half;
+        if (dd < HD)
+          *reinterpret_cast<float4 *>(orow + dd) =
+              make_float4(O[d][4 * g] * inv, O[d][4 * g + 1] * inv, O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv);
+      }
+  }
+}
+
+template <int HD>
+static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
+  auto kern = rel_attention_f32_kernel<HD>;
+  constexpr size_t smem = (size_t)((64 + BAND) * (HD + 4) + 4 * 32 * SRLD) * sizeof(float) + 32 * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(rel_attention)");
+    attr_set = true;
+  }
+  const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * B;
+  prof::Scope scope(prof::K_REL_ATTENTION, 2.0 * pairs * HD * (a.e ? 3 : 2),
+                    4.0 * B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), stream);
+  hipLaunchKernelGGL(kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(256), smem, stream, a);
+  return check_launch("rel_attention_f32");
+}
+
+static int64_t span(int64_t S, int64_t ss, int64_t B, int64_t sb, int64_t H, int64_t sh, int64_t hd) {
+  return (S - 1) * ss + (B - 1) * sb + (H - 1) * sh + hd;
+}
+
+int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
+  if (!g || !g->q || !g->k || !g->v || !g->out) return invalid("rel_attention: null pointer");
+  if (g->Sq <= 0 || g->Sk <= 0 || g->B <= 0 || g->H <= 0) return invalid("rel_attention: bad shape");
+  if (g->Cq <= 0 || g->Ck <= 0 || g->Ek <= 0) return invalid("rel_attention: bad event layout");
+  if (g->mask_mode < 0 || g->mask_mode > 2) return invalid("rel_attention: bad mask mode");
+  if (127 / g->Cq + 31 / g->Ck + 1 > BAND) return unsupported("rel_attention: band too wide");
+  const int64_t lim = (int64_t)1 << 30;
+  const int64_t eq = span(g->Sq, g->q_ss, g->B, g->q_sb, g->H, g->q_sh, g->head_dim);
+  const int64_t ek = span(g->Sk, g->k_ss, g->B, g->k_sb, g->H, g->k_sh, g->head_dim);
+  const int64_t ev = span(g->Sk, g->v_ss, g->B, g->v_sb, g->H, g->v_sh, g->head_dim);
+  const int64_t eo = span(g->Sq, g->o_ss, g->B, g->o_sb, g->H, g->o_sh, g->head_dim);
+  if (eq > lim || ek > lim || ev > lim || eo > lim) return unsupported("rel_attention: tensor spans 4 GiB or more");
+  const int64_t all = g->q_ss | g->q_sb | g->q_sh | g->k_ss | g->k_sb | g->k_sh | g->v_ss | g->v_sb | g->v_sh |
+                      g->o_ss | g->o_sb | g->o_sh;
+  if ((all & 3) || ((reinterpret_cast<uintptr_t>(g->q) | reinterpret_cast<uintptr_t>(g->k) |
+                     reinterpret_cast<uintptr_t>(g->v) | reinterpret_cast<uintptr_t>(g->out) |
+                     reinterpret_cast<uintptr_t>(g->rel_embeddings)) & 15))
+    return invalid("rel_attention: strides must be multiples of 4 floats and pointers 16-byte aligned");
+  AttnKArgs a;
+  a.q = g->q; a.k = g->k; a.v = g->v; a.e = g->rel_embeddings; a.mask = g->dense_mask; a.out = g->out;
+  a.q_bytes = (unsigned)(eq * 4); a.k_bytes = (unsigned)(ek * 4); a.v_bytes = (unsigned)(ev * 4);
+  a.R = g->rel_rows;
+  a.e_bytes = (unsigned)((size_t)g->H * g->rel_rows * g->head_dim * 4);
+  a.Sq = g->Sq; a.Sk = g->Sk; a.H = g->H;
+  a.q_ss = (int)g->q_ss; a.q_sb = (int)g->q_sb; a.q_sh = (int)g->q_sh;
+  a.k_ss = (int)g->k_ss; a.k_sb = (int)g->k_sb; a.k_sh = (int)g->k_sh;
+  a.v_ss = (int)g->v_ss; a.v_sb = (int)g->v_sb; a.v_sh = (int)g->v_sh;
+  a.o_ss = (int)g->o_ss; a.o_sb = (int)g->o_sb; a.o_sh = (int)g->o_sh;
+  a.Cq = g->Cq; a.Ck = g->Ck; a.Ek = g->Ek;
+  a.mask_mode = g->mask_mode; a.scale = g->scale;
+  if (a.e && a.R <= 0) return invalid("rel_attention: rel_rows must be positive");
+  switch (g->head_dim) {
+    case 16: return launch_attn<16>(a, g->B, stream);
+    case 32: return launch_attn<32>(a, g->B, stream);
+    case 64: return launch_attn<64>(a, g->B, stream);
+    default: return unsupported("rel_attention: head_dim must be 16, 32 or 64");
+  }
+}
+
+}  // namespace isi

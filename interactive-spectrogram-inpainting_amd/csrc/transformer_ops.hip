@@ -1,0 +1,350 @@
+// Small fp32 operators of the transformer prior (gfx950): LayerNorm with fused
+// residual add, and a "few rows" linear layer for single-token decoding.
+// They implement the non-attention parts of the layers specified in
+// oracle/prior_oracle.py (the reference reaches them through the absent
+// VQCPCB package, priors/transformer.py:370-417).
+#include "isi_common.h"
+#include "isi_internal.h"
+
+namespace isi {
+
+// out[m,:] = LayerNorm(x[m,:] + res[m,:]) * gamma + beta ; one wave per row.
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float *__restrict__ x,
+                                                            const float *__restrict__ res,
+                                                            const float *__restrict__ gamma,
+                                                            const float *__restrict__ beta,
+                                                            float *__restrict__ out, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float *xr = x + (size_t)row * D;
+  const float *rr = res ? res + (size_t)row * D : nullptr;
+  constexpr int MAXV = 8;  // D <= 64 * 4 * MAXV = 2048
+  float4 v[MAXV];
+  float sum = 0.f;
+  const int nq = D >> 2;  // float4 per row
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int qd = lane + 64 * i;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qd < nq) {
+      t = reinterpret_cast<const float4 *>(xr)[qd];
+      if (rr) {
+        const float4 u = reinterpret_cast<const float4 *>(rr)[qd];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      sum += (t.x + t.y) + (t.z + t.w);
+    }
+    v[i] = t;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  const float mean = sum / (float)D;
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int qd = lane + 64 * i;
+    if (qd < nq) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      var += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = 1.0f / sqrtf(var / (float)D + eps);
+  float *orow = out + (size_t)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int qd = lane + 64 * i;
+    if (qd < nq) {
+      const float4 g = reinterpret_cast<const float4 *>(gamma)[qd];
+      const float4 bb = reinterpret_cast<const float4 *>(beta)[qd];
+      float4 o;
+      o.x = (v[i].x - mean) * rstd * g.x + bb.x;
+      o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+      o.z = (v[i].z - mean) * rstd * g.z + bb.z;
+      o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+      reinterpret_cast<float4 *>(orow)[qd] = o;
+    }
+  }
+}
+
+int layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,
+                  int64_t M, int D, float eps, hipStream_t stream) {
+  if (!x || !gamma || !beta || !out || M <= 0 || D <= 0) return invalid("layernorm: bad argument");
+  if ((D & 3) || D > 2048) return unsupported("layernorm: need D % 4 == 0 and D <= 2048");
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(gamma) |
+       reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(out)) & 15)
+    return invalid("layernorm: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, res, gamma,
+                     beta, out, (int)M, D, eps);
+  return check_launch("layernorm_f32");
+}
+
+// out[m, n] = [relu]( x[m,:] . W[n,:] + bias[n] + res[m,n] ) for a handful of rows
+// m < MR (single-token decoding): one wave per output feature n streams W[n,:]
+// (torch layout [N,K], K contiguous) once with 16-B loads; the MR activations
+// rows come from L2.  Weight-bandwidth bound by construction.
+template <int MR>
+__global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float *__restrict__ x, int x_stride,
+                                                              const float *__restrict__ W,
+                                                              const float *__restrict__ bias,
+                                                              const float *__restrict__ res, int res_stride,
+                                                              float *__restrict__ out, int out_stride, int M,
+                                                              int N, int K, int relu) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float4 *wr = reinterpret_cast<const float4 *>(W + (size_t)n * K);
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = 0.f;
+  const int nq = K >> 2;
+  for (int qd = lane; qd < nq; qd += 64) {
+    const float4 w = wr[qd];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)m * x_stride)[qd];
+        acc[m] += (w.x * xv.x + w.y * xv.y) + (w.z * xv.z + w.w * xv.w);
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[m] += __shfl_xor(acc[m], o);
+  }
+  if (lane == 0) {
+    const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      if (m < M) {
+        float v = acc[m] + b;
+        if (res) v += res[(size_t)m * res_stride + n];
+        if (relu) v = fmaxf(v, 0.f);
+        out[(size_t)m * out_stride + n] = v;
+      }
+    }
+  }
+}
+
+int linear_rows_f32(const float *x, int x_stride, const float *W, const float *bias, const float *res,
+                    int res_stride, float *out, int out_stride, int M, int N, int K, int relu,
+                    hipStream_t stream) {
+  if (!x || !W || !out || M <= 0 || N <= 0 || K <= 0) return invalid("linear_rows: bad argument");
+  if (M > 8) return unsupported("linear_rows: at most 8 rows (use isi_conv2d_f32 as a GEMM beyond)");
+  if ((K & 3) || (x_stride & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15))
+    return invalid("linear_rows: K and x_stride must be multiples of 4, pointers 16-byte aligned");
+  dim3 grid((N + 3) / 4), block(256);
+  if (M <= 1)
+    hipLaunchKernelGGL(linear_rows_f32_kernel<1>, grid, block, 0, stream, x, x_stride, W, bias, res, res_stride,
+                       out, out_stride, M, N, K, relu);
+  else if (M <= 4)
+    hipLaunchKernelGGL(linear_rows_f32_kernel<4>, grid, block, 0, stream, x, x_stride, W, bias, res, res_stride,
+                       out, out_stride, M, N, K, relu);
+  else
+    hipLaunchKernelGGL(linear_rows_f32_kernel<8>, grid, block, 0, stream, x, x_stride, W, bias, res, res_stride,
+                       out, out_stride, M, N, K, relu);
+  return check_launch("linear_rows_f32");
+}
+
+
+// ------------------------------------------------------------------ decoding
+// One query row per (batch, head) against Sk cached keys / values with the same
+// relative-position logits as rel_attention_f32_kernel:
+//   s_j = (q.k_j + q.e[h, floor(q_pos/Cq) - floor(j/Ck) + Ek - 1]) * scale ; out = softmax(s) V
+// Bandwidth bound (each K, V and e row is read once): VALU dot products, no MFMA.
+template <int HD>
+__global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
+    const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+    const float *__restrict__ e, float *__restrict__ out, int Sk, int64_t q_sb, int64_t q_sh, int64_t k_ss,
+    int64_t k_sb, int64_t k_sh, int64_t v_ss, int64_t v_sb, int64_t v_sh, int64_t o_sb, int64_t o_sh,
+    int q_pos, int Cq, int Ck, int Ek, int R, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *qs = sm;            // [HD]
+  float *red = qs + HD;      // [8 + 4*HD]
+  float *sc = red + 8 + 4 * HD;  // [Sk]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const float *qr = q + b * q_sb + h * q_sh;
+  if (tid < HD) qs[tid] = qr[tid];
+  __syncthreads();
+  const int evq = q_pos / Cq;
+  // ---- scores
+  float lmax = -1e30f;
+  for (int j = tid; j < Sk; j += 256) {
+    const float4 *kr = reinterpret_cast<const float4 *>(k + (size_t)j * k_ss + b * k_sb + h * k_sh);
+    float acc = 0.f;
+    if (e) {
+      int r = evq - j / Ck + Ek - 1;
+      r = r < 0 ? 0 : (r >= R ? R - 1 : r);
+      const float4 *er = reinterpret_cast<const float4 *>(e + ((size_t)h * R + r) * HD);
+#pragma unroll
+      for (int i = 0; i < HD / 4; ++i) {
+        const float4 kk = kr[i], ee = er[i], qq = *reinterpret_cast<const float4 *>(qs + 4 * i);
+        acc += (qq.x * (kk.x + ee.x) + qq.y * (kk.y + ee.y)) + (qq.z * (kk.z + ee.z) + qq.w * (kk.w + ee.w));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < HD / 4; ++i) {
+        const float4 kk = kr[i], qq = *reinterpret_cast<const float4 *>(qs + 4 * i);
+        acc += (qq.x * kk.x + qq.y * kk.y) + (qq.z * kk.z + qq.w * kk.w);
+      }
+    }
+    acc *= scale;
+    sc[j] = acc;
+    lmax = fmaxf(lmax, acc);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float lsum = 0.f;
+  for (int j = tid; j < Sk; j += 256) {
+    const float pj = expf(sc[j] - gmax);
+    sc[j] = pj;
+    lsum += pj;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+  if (lane == 0) red[4 + wave] = lsum;
+  __syncthreads();
+  const float gsum = (red[4] + red[5]) + (red[6] + red[7]);
+  // ---- out[d] = sum_j p_j v_j[d] : lanes = head dims, waves stride over keys
+  float acc = 0.f;
+  if (lane < HD) {
+    for (int j = wave; j < Sk; j += 4) acc += sc[j] * v[(size_t)j * v_ss + b * v_sb + h * v_sh + lane];
+    red[8 + wave * HD + lane] = acc;
+  }
+  __syncthreads();
+  if (tid < HD) {
+    const float o = (red[8 + tid] + red[8 + HD + tid]) + (red[8 + 2 * HD + tid] + red[8 + 3 * HD + tid]);
+    out[b * o_sb + h * o_sh + tid] = o / gsum;
+  }
+}
+
+int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, hipStream_t stream) {
+  if (!g || !g->q || !g->k || !g->v || !g->out) return invalid("attention_decode: null pointer");
+  if (g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->Cq <= 0 || g->Ck <= 0) return invalid("attention_decode: bad shape");
+  if (g->Sk > 32768) return unsupported("attention_decode: more than 32768 keys");
+  const size_t smem = (size_t)(g->head_dim + 8 + 4 * g->head_dim + g->Sk) * sizeof(float);
+  dim3 grid(g->H, g->B), block(256);
+#define ISI_DEC(HD)                                                                                         \
+  do {                                                                                                      \
+    auto kern = rel_attention_decode_f32_kernel<HD>;                                                        \
+    if (smem > 48 * 1024 &&                                                                                 \
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)smem) != hipSuccess)                                                       \
+      return check_launch("hipFuncSetAttribute(attention_decode)");                                         \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, g->q, g->k, g->v, g->rel_embeddings, g->out, g->Sk, \
+                       g->q_sb, g->q_sh, g->k_ss, g->k_sb, g->k_sh, g->v_ss, g->v_sb, g->v_sh, g->o_sb,     \
+                       g->o_sh, q_pos, g->Cq, g->Ck, g->Ek, g->rel_rows, g->scale);                         \
+  } while (0)
+  switch (g->head_dim) {
+    case 16: ISI_DEC(16); break;
+    case 32: ISI_DEC(32); break;
+    case 64: ISI_DEC(64); break;
+    default: return unsupported("attention_decode: head_dim must be 16, 32 or 64");
+  }
+#undef ISI_DEC
+  return check_launch("rel_attention_decode_f32");
+}
+
+// ------------------------------------------------------------------ sampling
+// One categorical draw per row from logits[row, 0:n] (sample.py:286-295 of the
+// reference: temperature, top_k_top_p_filtering (sample.py:36-65), softmax,
+// multinomial), with a host-supplied uniform u[row] in [0,1) replacing torch's
+// RNG stream: the sample is the first index whose inclusive cumulative
+// probability exceeds u * total.  One workgroup per row; n <= 1024.
+__global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__restrict__ logits, int stride,
+                                                              int n, float inv_temperature, int top_k,
+                                                              float top_p, const float *__restrict__ u,
+                                                              int64_t *__restrict__ out,
+                                                              float *__restrict__ filtered) {
+  __shared__ float val[1024];
+  __shared__ int idx[1024];
+  __shared__ float scan[1024];
+  __shared__ int keep[1024];
+  __shared__ float sh_f[2];
+  __shared__ int sh_i;
+  const int tid = threadIdx.x, np = blockDim.x, row = blockIdx.x;
+  const float NEGI = -INFINITY;
+  const float lg = tid < n ? logits[(size_t)row * stride + tid] * inv_temperature : NEGI;
+  val[tid] = lg;
+  idx[tid] = tid;
+  __syncthreads();
+  // bitonic sort, descending by value (ties: lower index first)
+  for (int k = 2; k <= np; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int partner = tid ^ j;
+      if (partner > tid) {
+        const bool desc = (tid & k) == 0;
+        const float a = val[tid], c = val[partner];
+        const int ia = idx[tid], ic = idx[partner];
+        const bool a_first = a > c || (a == c && ia < ic);
+        if (desc ? !a_first : a_first) {
+          val[tid] = c; val[partner] = a;
+          idx[tid] = ic; idx[partner] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // top-k: drop everything strictly below the k-th largest value
+  float kth = NEGI;
+  if (top_k > 0) kth = val[min(top_k, n) - 1];
+  const float sv = (top_k > 0 && val[tid] < kth) ? NEGI : val[tid];
+  const float vmax = val[0];
+  // top-p on the sorted, top-k-filtered row
+  bool removed = sv == NEGI;
+  if (top_p > 0.f) {
+    const float ex = sv == NEGI ? 0.f : expf(sv - vmax);
+    scan[tid] = ex;
+    __syncthreads();
+    for (int o = 1; o < np; o <<= 1) {
+      const float t = tid >= o ? scan[tid - o] : 0.f;
+      __syncthreads();
+      scan[tid] += t;
+      __syncthreads();
+    }
+    const float total = scan[np - 1];
+    // remove position s when the cumulative probability up to s-1 already exceeds top_p
+    if (tid > 0 && scan[tid - 1] / total > top_p) removed = true;
+    __syncthreads();
+  }
+  keep[idx[tid]] = removed ? 0 : 1;
+  __syncthreads();
+  // probabilities in index order, inverse-CDF draw
+  const bool kp = tid < n && keep[tid];
+  const float fl = kp ? lg : NEGI;
+  if (filtered && tid < n) filtered[(size_t)row * n + tid] = fl;
+  const float pe = kp ? expf(lg - vmax) : 0.f;
+  scan[tid] = pe;
+  __syncthreads();
+  for (int o = 1; o < np; o <<= 1) {
+    const float t = tid >= o ? scan[tid - o] : 0.f;
+    __syncthreads();
+    scan[tid] += t;
+    __syncthreads();
+  }
+  if (tid == 0) { sh_i = n - 1; sh_f[0] = u[row] * scan[np - 1]; }
+  __syncthreads();
+  if (tid < n && scan[tid] > sh_f[0]) atomicMin(&sh_i, tid);
+  __syncthreads();
+  if (tid == 0) out[row] = sh_i;
+}
+
+int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
+                   const float *u, int64_t *out, float *filtered, hipStream_t stream) {
+  if (!logits || !u || !out || rows <= 0 || n <= 0 || temperature <= 0.f) return invalid("sample_row: bad argument");
+  if (n > 1024) return unsupported("sample_row: at most 1024 classes");
+  int np = 64;
+  while (np < n) np <<= 1;
+  hipLaunchKernelGGL(sample_row_f32_kernel, dim3(rows), dim3(np), 0, stream, logits, stride, n, 1.0f / temperature,
+                     top_k, top_p, u, out, filtered);
+  return check_launch("sample_row_f32");
+}
+
+}  // namespace isi

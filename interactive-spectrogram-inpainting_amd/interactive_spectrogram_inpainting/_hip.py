@@ -68,6 +68,18 @@ class isi_vqvae_out(C.Structure):
                 ("id_t", C.c_void_p), ("id_b", C.c_void_p), ("scalars", C.c_void_p)]
 
 
+class isi_attn_args(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("rel_embeddings", C.c_void_p),
+                ("dense_mask", C.c_void_p), ("out", C.c_void_p),
+                ("Sq", C.c_int), ("Sk", C.c_int), ("B", C.c_int), ("H", C.c_int), ("head_dim", C.c_int),
+                ("q_ss", C.c_int64), ("q_sb", C.c_int64), ("q_sh", C.c_int64),
+                ("k_ss", C.c_int64), ("k_sb", C.c_int64), ("k_sh", C.c_int64),
+                ("v_ss", C.c_int64), ("v_sb", C.c_int64), ("v_sh", C.c_int64),
+                ("o_ss", C.c_int64), ("o_sb", C.c_int64), ("o_sh", C.c_int64),
+                ("Cq", C.c_int), ("Ck", C.c_int), ("Ek", C.c_int), ("rel_rows", C.c_int),
+                ("mask_mode", C.c_int), ("scale", C.c_float)]
+
+
 # name -> (restype, argtypes); must list every symbol include/isi_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -93,6 +105,13 @@ SIGNATURES = {
     "isi_resblock_fusable": (C.c_int, [C.c_int, C.c_int]),
     "isi_resblock_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, _P]),
+    "isi_rel_attention_f32": (C.c_int, [C.POINTER(isi_attn_args), _P]),
+    "isi_rel_attention_decode_f32": (C.c_int, [C.POINTER(isi_attn_args), C.c_int, _P]),
+    "isi_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "isi_linear_rows_f32": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, _P]),
+    "isi_sample_row_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _P, _P, _P,
+                                     _P]),
     "isi_vq_nearest_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "isi_vq_num_partials": (C.c_int, [C.c_int64]),
     "isi_vq_finalize_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
@@ -127,7 +146,7 @@ def lib() -> C.CDLL:
                     fn.restype = res
                     fn.argtypes = args
                 structs = [isi_src, isi_dst, isi_conv_w, isi_encoder_w, isi_decoder_w, isi_codebook_w,
-                           isi_vqvae_w, isi_vqvae_out]
+                           isi_vqvae_w, isi_vqvae_out, isi_attn_args]
                 for i, st in enumerate(structs):
                     if handle.isi_abi_struct_bytes(i) != C.sizeof(st):
                         raise HipLibraryError(f"ABI mismatch for {st.__name__}: library "

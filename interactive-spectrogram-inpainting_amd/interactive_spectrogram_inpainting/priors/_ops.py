@@ -1,0 +1,147 @@
+"""Python wrappers over the transformer-prior entry points of libisi_hip.so.
+Sequences are time-major `[S, B, d]` fp32 like at the reference's call sites
+(priors/transformer.py:736-738)."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from .. import _hip
+from ..vqvae._ops import pack_conv_weight
+
+
+def _s(t):
+    return C.c_void_p(_hip.stream_ptr(t.device))
+
+
+def pack_linear_weight(weight: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [N,K] -> packed GEMM operand (a 1x1 convolution weight)."""
+    return pack_conv_weight(weight.detach().reshape(weight.shape[0], weight.shape[1], 1, 1))
+
+
+def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], n_out: int,
+           relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[..., n_out] = x[..., K] W^T + b (+ residual) on the fp32 matrix pipe: the
+    implicit-GEMM convolution kernel with a 1x1 window (rows = "pixels")."""
+    _hip.require_gpu(x, "linear input")
+    K = x.shape[-1]
+    x2 = x.reshape(-1, K)
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    out = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
+    s0 = _hip.isi_src(x2.data_ptr(), K, 0, 1, 0, x2.stride(0))
+    dst = _hip.isi_dst(out.data_ptr(), 0, 1, 0, n_out)
+    res = None
+    if residual is not None:
+        r2 = residual.reshape(M, n_out)
+        if r2.stride(1) != 1:
+            r2 = r2.contiguous()
+        res = _hip.isi_src(r2.data_ptr(), n_out, 0, 1, 0, r2.stride(0))
+    rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, packed_w.data_ptr(),
+                                   bias.data_ptr() if bias is not None else None,
+                                   C.byref(res) if res is not None else None, C.byref(dst),
+                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu), _s(x))
+    _hip.check(rc, "isi_conv2d_f32 (linear)")
+    return out.reshape(*x.shape[:-1], n_out)
+
+
+def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False,
+                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Single-token path: x [M<=8, K] against the unpacked torch weight [N, K];
+    `out` may be a row-strided view (e.g. a slot of a key/value cache)."""
+    _hip.require_gpu(x, "linear_rows input")
+    M, K = x.shape
+    N = weight.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    rc = _hip.lib().isi_linear_rows_f32(
+        x.data_ptr(), x.stride(0), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+        residual.data_ptr() if residual is not None else None,
+        residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), M, N, K, int(relu),
+        _s(x))
+    _hip.check(rc, "isi_linear_rows_f32")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _hip.require_gpu(x, "layernorm input")
+    x = x.contiguous()
+    D = x.shape[-1]
+    out = torch.empty_like(x)
+    if residual is not None:
+        residual = residual.contiguous()
+    rc = _hip.lib().isi_layernorm_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                      gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), x.numel() // D, D,
+                                      eps, _s(x))
+    _hip.check(rc, "isi_layernorm_f32")
+    return out
+
+
+def _attn_args(q, k, v, rel, out, Sq, Sk, B, H, hd, Cq, Ck, Ek, mask_mode, dense_mask):
+    a = _hip.isi_attn_args()
+    a.q, a.k, a.v, a.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    a.rel_embeddings = rel.data_ptr() if rel is not None else None
+    a.dense_mask = dense_mask.data_ptr() if dense_mask is not None else None
+    a.Sq, a.Sk, a.B, a.H, a.head_dim = Sq, Sk, B, H, hd
+    a.Cq, a.Ck, a.Ek = Cq, Ck, Ek
+    a.rel_rows = rel.shape[1] if rel is not None else 0
+    a.mask_mode = mask_mode
+    a.scale = 1.0 / math.sqrt(hd)
+    return a
+
+
+def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Optional[torch.Tensor], nhead: int,
+                  Cq: int, Ck: int, Ek: int, mask_mode: int = 0,
+                  dense_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [Sq,B,d], k/v [Sk,B,d] (any row strides, last dim contiguous; views into a
+    fused qkv buffer are consumed in place) -> [Sq,B,d]."""
+    _hip.require_gpu(q, "attention input")
+    Sq, B, d = q.shape
+    Sk = k.shape[0]
+    hd = d // nhead
+    out = torch.empty(Sq, B, d, dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, v, rel, out, Sq, Sk, B, nhead, hd, Cq, Ck, Ek, mask_mode, dense_mask)
+    a.q_ss, a.q_sb, a.q_sh = q.stride(0), q.stride(1), hd
+    a.k_ss, a.k_sb, a.k_sh = k.stride(0), k.stride(1), hd
+    a.v_ss, a.v_sb, a.v_sh = v.stride(0), v.stride(1), hd
+    a.o_ss, a.o_sb, a.o_sh = out.stride(0), out.stride(1), hd
+    _hip.check(_hip.lib().isi_rel_attention_f32(C.byref(a), _s(q)), "isi_rel_attention_f32")
+    return out
+
+
+def rel_attention_decode(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Optional[torch.Tensor],
+                         nhead: int, n_keys: int, q_pos: int, Cq: int, Ck: int, Ek: int) -> torch.Tensor:
+    """q [B,d] (one position), k/v caches [S_max,B,d]; attends to keys 0..n_keys-1."""
+    _hip.require_gpu(q, "attention input")
+    B, d = q.shape
+    hd = d // nhead
+    out = torch.empty(B, d, dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, v, rel, out, 1, n_keys, B, nhead, hd, Cq, Ck, Ek, 0, None)
+    a.q_ss, a.q_sb, a.q_sh = 0, q.stride(0), hd
+    a.k_ss, a.k_sb, a.k_sh = k.stride(0), k.stride(1), hd
+    a.v_ss, a.v_sb, a.v_sh = v.stride(0), v.stride(1), hd
+    a.o_ss, a.o_sb, a.o_sh = 0, out.stride(0), hd
+    _hip.check(_hip.lib().isi_rel_attention_decode_f32(C.byref(a), q_pos, _s(q)), "isi_rel_attention_decode_f32")
+    return out
+
+
+def sample_rows(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, u: torch.Tensor,
+                return_filtered: bool = False):
+    """logits [rows, n] -> int64 [rows] (and the filtered logits when asked)."""
+    _hip.require_gpu(logits, "logits")
+    rows, n = logits.shape
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    filt = torch.empty(rows, n, dtype=torch.float32, device=logits.device) if return_filtered else None
+    u = u.to(device=logits.device, dtype=torch.float32).contiguous()
+    rc = _hip.lib().isi_sample_row_f32(logits.data_ptr(), logits.stride(0), rows, n, float(temperature),
+                                       int(top_k), float(top_p), u.data_ptr(), out.data_ptr(),
+                                       filt.data_ptr() if filt is not None else None, _s(logits))
+    _hip.check(rc, "isi_sample_row_f32")
+    return (out, filt) if return_filtered else out

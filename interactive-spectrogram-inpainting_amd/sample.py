@@ -1,0 +1,107 @@
+"""Autoregressive / inpainting sampling of codemaps on MI355X.
+
+Drop-in for `sample_model` and `top_k_top_p_filtering` of the reference's
+`sample.py:36-65,131-347` (the CLI, audio and PNG writing of that script are
+harness code outside the compute path).  Contract kept:
+positions with `mask == False` keep `initial_code`; masked positions are sampled
+left to right in the target helper's order; `temperature` divides the logits;
+the result is an int64 codemap `[B, F, T]`.
+
+Differences by design: the decoder runs incrementally on cached keys / values
+(same logits as the reference's full pass per token, O(S) instead of O(S^2) layer
+passes); filtering + softmax + the categorical draw are one kernel on the single
+row that is consumed; the draw uses uniforms from `generator` (or given `uniforms`)
+instead of torch.multinomial's stream.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Mapping, Optional, Union
+
+import torch
+
+from interactive_spectrogram_inpainting.priors import _ops
+from interactive_spectrogram_inpainting.priors._decode import IncrementalDecoder
+from interactive_spectrogram_inpainting.priors.transformer import Seq2SeqInputKind, VQNSynthTransformer
+
+
+def top_k_top_p_filtering(logits: torch.Tensor, top_k: int = 0, top_p: float = 0.0,
+                          filter_value: float = -float('Inf')) -> torch.Tensor:
+    """Filter logits `[..., n_class]` in place (like the reference) with top-k and/or
+    nucleus filtering; runs `isi_sample_row_f32`'s filtering stage on every row."""
+    if filter_value != -float('Inf'):
+        raise NotImplementedError("only filter_value = -inf is built")
+    rows = logits.reshape(-1, logits.shape[-1])
+    u = torch.zeros(rows.shape[0], device=logits.device)
+    _, filt = _ops.sample_rows(rows, 1.0, top_k, top_p, u, return_filtered=True)
+    logits.copy_(filt.reshape(logits.shape))
+    return logits
+
+
+@torch.no_grad()
+def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], batch_size: int,
+                 codemap_size: Iterable[int], temperature: float,
+                 condition: Optional[torch.Tensor] = None, constraint: Optional[torch.Tensor] = None,
+                 class_conditioning: Mapping[str, Iterable[int]] = {},
+                 initial_code: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                 local_class_conditioning_map=None,
+                 time_indexes_source: Optional[Iterable[int]] = None,
+                 time_indexes_target: Optional[Iterable[int]] = None,
+                 top_k_sampling_k: int = 0, top_p_sampling_p: float = 0.0,
+                 progressbar_decorator=None, use_predictive_sampling: bool = False,
+                 generator: Optional[torch.Generator] = None,
+                 uniforms: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if constraint is not None:
+        raise NotImplementedError
+    if use_predictive_sampling:
+        raise NotImplementedError("predictive sampling (sample.py:251-261,308-342) is not built")
+    device = torch.device(device)
+    model.eval()
+    if initial_code is None:
+        fill = model.mask_token_index if model.self_conditional_model else 0
+        codemap = torch.full([batch_size] + list(codemap_size), fill, dtype=torch.int64, device=device)
+    else:
+        codemap = initial_code.to(device)
+    cls = {}
+    for name, value in class_conditioning.items():
+        value = torch.as_tensor(value).long().reshape(-1)
+        cls[name] = (value.expand(batch_size) if value.numel() == 1 else value).reshape(batch_size, 1).to(device)
+    if model.self_conditional_model:
+        condition = codemap
+    if mask is not None:
+        mask = mask.to(device)
+    source_seq, target_seq = model.to_sequences(
+        codemap, condition.to(device), class_conditioning=cls, mask=mask,
+        time_indexes_source=time_indexes_source, time_indexes_target=time_indexes_target)
+
+    S = model.target_transformer_sequence_length
+    start_len = model.target_start_symbol.shape[1]
+    code_seq = model.target_codemaps_helper.to_sequence(codemap).clone()
+    if mask is not None:
+        mask_seq = model.target_codemaps_helper.to_sequence(mask).reshape(-1, S)[0].cpu().numpy()
+    else:
+        mask_seq = [True] * S
+    if uniforms is None:
+        uniforms = torch.rand(S, batch_size, generator=generator)
+    uniforms = uniforms.to(device=device, dtype=torch.float32)
+
+    # encoder memory once (anti-causal for the self-conditional top prior)
+    src = source_seq.transpose(0, 1).contiguous()
+    memory, *_ = model.transformer.encoder(src, mask='anticausal' if model.self_conditional_model else None)
+    dec = IncrementalDecoder(model, memory, batch_size)
+    x_seq = target_seq.transpose(0, 1).contiguous()          # [S_t, B, d]; rows are rewritten as we sample
+    table = model._embedding_table(Seq2SeqInputKind.Target)
+    eff = model.embeddings_effective_dim
+
+    positions = range(S + start_len - 1)
+    if progressbar_decorator is not None:
+        positions = progressbar_decorator(positions)
+    for p in positions:
+        out_row = dec.step(p, x_seq[p])
+        i = p - (start_len - 1)                               # token predicted from position p
+        if i < 0 or not mask_seq[i]:
+            continue
+        logits = dec.logits(out_row)
+        sample = _ops.sample_rows(logits, temperature, top_k_sampling_k, top_p_sampling_p, uniforms[i])
+        code_seq[:, i] = sample
+        x_seq[i + start_len, :, :eff] = table[sample]          # embed_data(sample) into the next input row
+    return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()

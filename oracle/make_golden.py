@@ -72,6 +72,19 @@ def _install_stubs():
         DataNormalizerStatistics=DataNormalizerStatistics)
     mod("discretization", ProductVectorQuantizer=_Dummy)
 
+    # the prior's layers live in the absent VQCPCB package: stand-ins that only
+    # record their constructor arguments (the wrapper around them is what we pin)
+    class _Layer(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            self.kwargs = k
+
+    mod("VQCPCB")
+    mod("VQCPCB.transformer")
+    mod("VQCPCB.transformer.transformer_custom", TransformerCustom=_Layer, TransformerDecoderCustom=_Layer,
+        TransformerEncoderCustom=_Layer, TransformerDecoderLayerCustom=_Layer,
+        TransformerEncoderLayerCustom=_Layer, TransformerAlignedDecoderLayerCustom=_Layer)
+
 
 def _np(sd):
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
@@ -256,6 +269,95 @@ def codemap_fixtures():
     _save("codemaps.npz", **out)
 
 
+@torch.no_grad()
+def prior_wrapper_fixtures():
+    """Everything of the prior that IS in the reference tree: token / positional /
+    class embeddings, start symbols, sequence construction (to_sequences), causal
+    mask, the constructor arguments it hands to the (absent) transformer layers,
+    and the label-smoothing loss."""
+    from interactive_spectrogram_inpainting.priors.transformer import (
+        SelfAttentiveVQTransformer, UpsamplingVQTransformer)
+    from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss
+    common = dict(n_class=32, channel=8, kernel_size=5, n_block=1, n_res_block=1, res_channel=8,
+                  d_model=64, embeddings_dim=8, positional_embeddings_dim=8,
+                  use_relative_transformer=True, predict_frequencies_first=True,
+                  conditional_model=True, class_conditioning_prepend_to_dummy_input=True,
+                  class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+                  class_conditioning_embedding_dim_per_modality={"instrument_family_str": 16, "pitch": 16},
+                  conditional_model_nhead=4, conditional_model_num_encoder_layers=2,
+                  conditional_model_num_decoder_layers=3)
+    out = {}
+    torch.manual_seed(31)
+    top = SelfAttentiveVQTransformer(shape=[8, 4], condition_shape=[8, 4], self_conditional_model=True,
+                                     add_mask_token_to_symbols=True, **common).eval()
+    bottom = UpsamplingVQTransformer(shape=[16, 8], condition_shape=[8, 4], **common).eval()
+    for name, m in (("top", top), ("bottom", bottom)):
+        for k, v in m.state_dict().items():
+            out[f"{name}::w::{k}"] = v.numpy()
+        out[f"{name}::causal_mask"] = m.causal_mask.numpy()
+        enc_layer = m.transformer.kwargs["custom_encoder"].kwargs["encoder_layer"].kwargs
+        dec_layer = m.transformer.kwargs["custom_decoder"].kwargs["decoder_layer"].kwargs
+        out[f"{name}::enc_layer_args"] = np.array([enc_layer["d_model"], enc_layer["nhead"],
+                                                   enc_layer["num_channels"], enc_layer["num_events"]])
+        out[f"{name}::dec_layer_args"] = np.array([
+            dec_layer["d_model"], dec_layer["nhead"], dec_layer["num_channels_encoder"],
+            dec_layer["num_events_encoder"], dec_layer["num_channels_decoder"], dec_layer["num_events_decoder"]])
+        print(name, "enc", enc_layer, "dec", dec_layer)
+    B = 2
+    g = torch.Generator().manual_seed(32)
+    cls = {"instrument_family_str": torch.randint(0, 11, (B, 1), generator=g),
+           "pitch": torch.randint(0, 61, (B, 1), generator=g)}
+    top_code = torch.randint(0, 32, (B, 8, 4), generator=g)
+    mask = torch.rand(B, 8, 4, generator=g) < 0.4
+    src, tgt = top.to_sequences(top_code, top_code, class_conditioning=cls, mask=mask)
+    out.update({"top::code": top_code.numpy(), "top::mask": mask.numpy(), "top::src": src.numpy(),
+                "top::tgt": tgt.numpy()})
+    tidx = [1, 2, 3, 3]
+    src2, tgt2 = top.to_sequences(top_code, top_code, class_conditioning=cls, mask=None,
+                                  time_indexes_source=tidx, time_indexes_target=tidx)
+    out.update({"top::tidx": np.array(tidx), "top::src_tidx": src2.numpy(), "top::tgt_tidx": tgt2.numpy()})
+    bottom_code = torch.randint(0, 32, (B, 16, 8), generator=g)
+    src3, tgt3 = bottom.to_sequences(bottom_code, top_code, class_conditioning=cls)
+    out.update({"bottom::code": bottom_code.numpy(), "bottom::src": src3.numpy(), "bottom::tgt": tgt3.numpy()})
+    for k, v in cls.items():
+        out[f"cls::{k}"] = v.numpy()
+    # label smoothing loss (utils/losses/prediction.py)
+    pred = torch.randn(3, 32, 5, 7, generator=g)
+    target = torch.randint(0, 32, (3, 5, 7), generator=g)
+    out["ls::pred"], out["ls::target"] = pred.numpy(), target.numpy()
+    out["ls::loss_0.1"] = LabelSmoothingLoss(32, 0.1, dim=1)(pred, target).numpy()
+    out["ls::loss_0.0"] = LabelSmoothingLoss(32, 0.0, dim=1)(pred, target).numpy()
+    _save("prior_wrapper.npz", **out)
+
+
+@torch.no_grad()
+def filtering_fixtures():
+    """top_k_top_p_filtering (sample.py:36-65), imported with its heavy script
+    dependencies stubbed."""
+    import types as _t
+    for name in ("soundfile", "torchaudio", "torchvision", "torchvision.utils"):
+        if name not in sys.modules:
+            sys.modules[name] = _t.ModuleType(name)
+    sys.modules["torchvision.utils"].save_image = lambda *a, **k: None
+    gs = _t.ModuleType("GANsynth_pytorch.spectrograms_helper")
+    gs.SpectrogramsHelper = gs.MelSpectrogramsHelper = object
+    sys.modules["GANsynth_pytorch.spectrograms_helper"] = gs
+    gl = sys.modules["GANsynth_pytorch.loader"]
+    for n in ("WavToSpectrogramDataLoader", "MaskedPhaseWavToSpectrogramDataLoader"):
+        setattr(gl, n, object)
+    try:
+        import lmdb  # noqa: F401
+    except ImportError:
+        sys.modules["lmdb"] = _t.ModuleType("lmdb")
+    import sample as ref_sample
+    g = torch.Generator().manual_seed(41)
+    logits = torch.randn(2, 5, 32, generator=g) * 2
+    out = {"logits": logits.numpy()}
+    for (k, p) in [(0, 0.0), (5, 0.0), (0, 0.8), (8, 0.6), (40, 0.0), (0, 0.05)]:
+        out[f"k{k}_p{p}"] = ref_sample.top_k_top_p_filtering(logits.clone(), top_k=k, top_p=p).numpy()
+    _save("filtering.npz", **out)
+
+
 def main():
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     _install_stubs()
@@ -281,6 +383,8 @@ def main():
     layer_fixtures()
     quantizer_fixtures()
     codemap_fixtures()
+    prior_wrapper_fixtures()
+    filtering_fixtures()
 
 
 if __name__ == "__main__":

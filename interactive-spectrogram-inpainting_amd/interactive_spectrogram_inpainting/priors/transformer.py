@@ -250,6 +250,8 @@ class VQNSynthTransformer(nn.Module):
 
     def embed_data(self, input: torch.Tensor, kind: Seq2SeqInputKind) -> torch.Tensor:
         table = self._embedding_table(kind)
+        if input.numel() and (int(input.min()) < 0 or int(input.max()) >= table.shape[0]):
+            raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
         return table[input]
 
     def _get_combined_positional_embeddings(self, kind: Seq2SeqInputKind) -> torch.Tensor:

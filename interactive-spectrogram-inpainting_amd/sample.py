@@ -69,8 +69,13 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
         condition = codemap
     if mask is not None:
         mask = mask.to(device)
+    # With no initial_code the reference fills the map with the mask token, which its
+    # target embedding cannot index (sample.py:167-171 vs priors/transformer.py:286: an
+    # IndexError there).  Those target rows are always overwritten by samples before the
+    # decoder reads them, so the target side is built from in-range placeholders.
+    target_codemap = codemap.clamp(max=model.n_class_target - 1) if initial_code is None else codemap
     source_seq, target_seq = model.to_sequences(
-        codemap, condition.to(device), class_conditioning=cls, mask=mask,
+        target_codemap, condition.to(device), class_conditioning=cls, mask=mask,
         time_indexes_source=time_indexes_source, time_indexes_target=time_indexes_target)
 
     S = model.target_transformer_sequence_length

@@ -40,7 +40,8 @@ const char *isi_last_error(void);
 /* sizeof() of the structs below as compiled into the library, so that FFI
  * bindings can verify their own layout: which = 0 isi_src, 1 isi_dst,
  * 2 isi_conv_w, 3 isi_encoder_w, 4 isi_decoder_w, 5 isi_codebook_w,
- * 6 isi_vqvae_w, 7 isi_vqvae_out, 8 isi_attn_args.  Returns 0 for an unknown id. */
+ * 6 isi_vqvae_w, 7 isi_vqvae_out, 8 isi_attn_args, 9 isi_prior_w,
+ * 10 isi_prior_state.  Returns 0 for an unknown id. */
 size_t isi_abi_struct_bytes(int which);
 
 /* x = max(x, 0) in place over n floats: the in-place nn.ReLU with which
@@ -181,6 +182,48 @@ int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, void *str
 int isi_sample_row_f32(const float *logits, int stride, int rows, int n, float temperature,
                        int top_k, float top_p, const float *u, int64_t *out,
                        float *filtered, void *stream);
+
+/* Native key/value-cached sampling loop of the decoder (replaces the per-token
+ * full decoder pass of sample.py:268-305).  Weights are the torch-layout
+ * parameters themselves ([N,K] row-major), no packing. */
+#define ISI_MAX_LAYERS 16
+typedef struct isi_attn_w {
+  const float *in_proj_weight, *in_proj_bias;   /* [3d,d], [3d]                      */
+  const float *out_proj_weight, *out_proj_bias; /* [d,d], [d]                        */
+  const float *rel_embeddings;                  /* [H, rel_rows, d/H] or NULL        */
+  int rel_rows;
+} isi_attn_w;
+typedef struct isi_decoder_layer_w {
+  isi_attn_w self_attn, cross_attn;
+  const float *linear1_w, *linear1_b, *linear2_w, *linear2_b;
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+} isi_decoder_layer_w;
+typedef struct isi_prior_w {
+  int d_model, nhead, dim_feedforward, n_layers, n_class;
+  int Cd, Ed, Ce, Ee;          /* channels / events (incl. start symbol) of decoder and encoder sequences */
+  isi_decoder_layer_w layers[ISI_MAX_LAYERS];
+  const float *logits_w, *logits_b;             /* project_transformer_outputs_to_logits */
+  const float *embed_table;                     /* [n_class, eff_dim] = Linear(Embedding) of target tokens */
+  int eff_dim;
+} isi_prior_w;
+typedef struct isi_prior_state {
+  float *x_seq;            /* [S_t, B, d] decoder input rows; rows of sampled tokens are rewritten    */
+  float *kv_cache;         /* [n_layers, S_t, B, 2d] self-attention keys|values                       */
+  const float *memory_kv;  /* [n_layers, S_src, B, 2d] projected encoder memory keys|values           */
+  int64_t *codes;          /* [B, S] codes in sequence order (in: known codes, out: sampled)          */
+  const uint8_t *mask;     /* [S] HOST array, 1 = sample this position                                */
+  const float *uniforms;   /* [S, B] device, uniforms in [0,1)                                        */
+  float *scratch;          /* device, isi_prior_decode_scratch_floats(w, B) floats                    */
+  size_t scratch_floats;
+  int S_t, S_src, S, B, start_len;
+} isi_prior_state;
+size_t isi_prior_decode_scratch_floats(const isi_prior_w *w, int B);
+/* Enqueues positions [p_begin, p_end) of the decoder (one new row each, all layers),
+ * and for every masked position the logits head, the draw (isi_sample_row_f32
+ * semantics) and the write of the sampled token into codes / the next input row.
+ * No host synchronisation.  B <= 8. */
+int isi_prior_sample_run(const isi_prior_w *w, const isi_prior_state *state, int p_begin,
+                         int p_end, float temperature, int top_k, float top_p, void *stream);
 
 /* ----------------------------------------------------------- quantization */
 

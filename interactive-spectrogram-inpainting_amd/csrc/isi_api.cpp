@@ -30,6 +30,8 @@ size_t isi_abi_struct_bytes(int which) {
     case 6: return sizeof(isi_vqvae_w);
     case 7: return sizeof(isi_vqvae_out);
     case 8: return sizeof(isi_attn_args);
+    case 9: return sizeof(isi_prior_w);
+    case 10: return sizeof(isi_prior_state);
     default: return 0;
   }
 }
@@ -96,6 +98,12 @@ int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, void *str
 int isi_sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k,
                        float top_p, const float *u, int64_t *out, float *filtered, void *stream) {
   return sample_row_f32(logits, stride, rows, n, temperature, top_k, top_p, u, out, filtered, S(stream));
+}
+
+size_t isi_prior_decode_scratch_floats(const isi_prior_w *w, int B) { return prior_decode_scratch_floats(w, B); }
+int isi_prior_sample_run(const isi_prior_w *w, const isi_prior_state *state, int p_begin, int p_end,
+                         float temperature, int top_k, float top_p, void *stream) {
+  return prior_sample_run(w, state, p_begin, p_end, temperature, top_k, top_p, S(stream));
 }
 
 int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,

@@ -33,6 +33,10 @@ int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, hipStream_t stre
 int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                    const float *u, int64_t *out, float *filtered, hipStream_t stream);
 
+size_t prior_decode_scratch_floats(const isi_prior_w *w, int B);
+int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin, int p_end, float temperature,
+                     int top_k, float top_p, hipStream_t stream);
+
 int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                    int32_t *counts, float *sse_part, int64_t N, int D, int K, hipStream_t stream);
 int vq_num_partials(int64_t N);

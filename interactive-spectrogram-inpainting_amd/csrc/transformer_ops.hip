@@ -161,40 +161,54 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     const float *__restrict__ e, float *__restrict__ out, int Sk, int64_t q_sb, int64_t q_sh, int64_t k_ss,
     int64_t k_sb, int64_t k_sh, int64_t v_ss, int64_t v_sb, int64_t v_sh, int64_t o_sb, int64_t o_sh,
     int q_pos, int Cq, int Ck, int Ek, int R, float scale) {
+  // A group of G = HD/4 lanes owns one key row (one coalesced 16-B load per lane);
+  // 256/G rows are in flight per pass, 4 passes unrolled.
+  constexpr int G = HD / 4;        // lanes per row: 4, 8 or 16
+  constexpr int RPP = 256 / G;     // rows per pass
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float *qs = sm;            // [HD]
-  float *red = qs + HD;      // [8 + 4*HD]
-  float *sc = red + 8 + 4 * HD;  // [Sk]
+  float *red = sm;                 // [8]
+  float *part = red + 8;           // [RPP][HD] partial outputs
+  float *sc = part + RPP * HD;     // [Sk]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = tid / G, gl = tid % G;
   const int h = blockIdx.x, b = blockIdx.y;
-  const float *qr = q + b * q_sb + h * q_sh;
-  if (tid < HD) qs[tid] = qr[tid];
-  __syncthreads();
+  const float4 qq = *reinterpret_cast<const float4 *>(q + b * q_sb + h * q_sh + gl * 4);
   const int evq = q_pos / Cq;
+  const float *kb = k + b * k_sb + h * k_sh + gl * 4;
+  const float *vb = v + b * v_sb + h * v_sh + gl * 4;
+  const float *eb = e ? e + (size_t)h * R * HD + gl * 4 : nullptr;
   // ---- scores
   float lmax = -1e30f;
-  for (int j = tid; j < Sk; j += 256) {
-    const float4 *kr = reinterpret_cast<const float4 *>(k + (size_t)j * k_ss + b * k_sb + h * k_sh);
-    float acc = 0.f;
-    if (e) {
-      int r = evq - j / Ck + Ek - 1;
-      r = r < 0 ? 0 : (r >= R ? R - 1 : r);
-      const float4 *er = reinterpret_cast<const float4 *>(e + ((size_t)h * R + r) * HD);
+  for (int j0 = grp; j0 < Sk; j0 += 4 * RPP) {
+    float part_s[4];
 #pragma unroll
-      for (int i = 0; i < HD / 4; ++i) {
-        const float4 kk = kr[i], ee = er[i], qq = *reinterpret_cast<const float4 *>(qs + 4 * i);
-        acc += (qq.x * (kk.x + ee.x) + qq.y * (kk.y + ee.y)) + (qq.z * (kk.z + ee.z) + qq.w * (kk.w + ee.w));
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * RPP;
+      float acc = 0.f;
+      if (j < Sk) {
+        float4 kk = *reinterpret_cast<const float4 *>(kb + (size_t)j * k_ss);
+        if (eb) {
+          int r = evq - j / Ck + Ek - 1;
+          r = r < 0 ? 0 : (r >= R ? R - 1 : r);
+          const float4 ee = *reinterpret_cast<const float4 *>(eb + (size_t)r * HD);
+          kk.x += ee.x; kk.y += ee.y; kk.z += ee.z; kk.w += ee.w;
+        }
+        acc = (qq.x * kk.x + qq.y * kk.y) + (qq.z * kk.z + qq.w * kk.w);
       }
-    } else {
+      part_s[u] = acc;
+    }
 #pragma unroll
-      for (int i = 0; i < HD / 4; ++i) {
-        const float4 kk = kr[i], qq = *reinterpret_cast<const float4 *>(qs + 4 * i);
-        acc += (qq.x * kk.x + qq.y * kk.y) + (qq.z * kk.z + qq.w * kk.w);
+    for (int u = 0; u < 4; ++u) {
+      float acc = part_s[u];
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      const int j = j0 + u * RPP;
+      if (j < Sk) {
+        acc *= scale;
+        if (gl == 0) sc[j] = acc;
+        lmax = fmaxf(lmax, acc);
       }
     }
-    acc *= scale;
-    sc[j] = acc;
-    lmax = fmaxf(lmax, acc);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
@@ -212,16 +226,28 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   if (lane == 0) red[4 + wave] = lsum;
   __syncthreads();
   const float gsum = (red[4] + red[5]) + (red[6] + red[7]);
-  // ---- out[d] = sum_j p_j v_j[d] : lanes = head dims, waves stride over keys
-  float acc = 0.f;
-  if (lane < HD) {
-    for (int j = wave; j < Sk; j += 4) acc += sc[j] * v[(size_t)j * v_ss + b * v_sb + h * v_sh + lane];
-    red[8 + wave * HD + lane] = acc;
+  // ---- out = sum_j p_j v_j : each lane group accumulates its rows, 4 loads in flight
+  float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0, o3 = o0;
+  for (int j0 = grp; j0 < Sk; j0 += 4 * RPP) {
+    const int ja = j0, jb = j0 + RPP, jc = j0 + 2 * RPP, jd = j0 + 3 * RPP;
+    const float pa = sc[ja], pb = jb < Sk ? sc[jb] : 0.f, pc = jc < Sk ? sc[jc] : 0.f, pd = jd < Sk ? sc[jd] : 0.f;
+    const float4 va = *reinterpret_cast<const float4 *>(vb + (size_t)ja * v_ss);
+    const float4 vbb = *reinterpret_cast<const float4 *>(vb + (size_t)(jb < Sk ? jb : ja) * v_ss);
+    const float4 vc = *reinterpret_cast<const float4 *>(vb + (size_t)(jc < Sk ? jc : ja) * v_ss);
+    const float4 vd = *reinterpret_cast<const float4 *>(vb + (size_t)(jd < Sk ? jd : ja) * v_ss);
+    o0.x += pa * va.x; o0.y += pa * va.y; o0.z += pa * va.z; o0.w += pa * va.w;
+    o1.x += pb * vbb.x; o1.y += pb * vbb.y; o1.z += pb * vbb.z; o1.w += pb * vbb.w;
+    o2.x += pc * vc.x; o2.y += pc * vc.y; o2.z += pc * vc.z; o2.w += pc * vc.w;
+    o3.x += pd * vd.x; o3.y += pd * vd.y; o3.z += pd * vd.z; o3.w += pd * vd.w;
   }
+  o0.x = (o0.x + o1.x) + (o2.x + o3.x); o0.y = (o0.y + o1.y) + (o2.y + o3.y);
+  o0.z = (o0.z + o1.z) + (o2.z + o3.z); o0.w = (o0.w + o1.w) + (o2.w + o3.w);
+  *reinterpret_cast<float4 *>(part + grp * HD + gl * 4) = o0;
   __syncthreads();
   if (tid < HD) {
-    const float o = (red[8 + tid] + red[8 + HD + tid]) + (red[8 + 2 * HD + tid] + red[8 + 3 * HD + tid]);
-    out[b * o_sb + h * o_sh + tid] = o / gsum;
+    float acc = 0.f;
+    for (int g = 0; g < RPP; ++g) acc += part[g * HD + tid];
+    out[b * o_sb + h * o_sh + tid] = acc / gsum;
   }
 }
 
@@ -229,7 +255,7 @@ int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, hipStream_t stre
   if (!g || !g->q || !g->k || !g->v || !g->out) return invalid("attention_decode: null pointer");
   if (g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->Cq <= 0 || g->Ck <= 0) return invalid("attention_decode: bad shape");
   if (g->Sk > 32768) return unsupported("attention_decode: more than 32768 keys");
-  const size_t smem = (size_t)(g->head_dim + 8 + 4 * g->head_dim + g->Sk) * sizeof(float);
+  const size_t smem = (size_t)(8 + 256 * 4 + g->Sk) * sizeof(float);  // red + part[256/G][HD] + scores
   dim3 grid(g->H, g->B), block(256);
 #define ISI_DEC(HD)                                                                                         \
   do {                                                                                                      \

@@ -80,6 +80,35 @@ class isi_attn_args(C.Structure):
                 ("mask_mode", C.c_int), ("scale", C.c_float)]
 
 
+ISI_MAX_LAYERS = 16
+
+
+class isi_attn_w(C.Structure):
+    _fields_ = [("in_proj_weight", C.c_void_p), ("in_proj_bias", C.c_void_p), ("out_proj_weight", C.c_void_p),
+                ("out_proj_bias", C.c_void_p), ("rel_embeddings", C.c_void_p), ("rel_rows", C.c_int)]
+
+
+class isi_decoder_layer_w(C.Structure):
+    _fields_ = [("self_attn", isi_attn_w), ("cross_attn", isi_attn_w),
+                ("linear1_w", C.c_void_p), ("linear1_b", C.c_void_p), ("linear2_w", C.c_void_p),
+                ("linear2_b", C.c_void_p), ("norm1_w", C.c_void_p), ("norm1_b", C.c_void_p),
+                ("norm2_w", C.c_void_p), ("norm2_b", C.c_void_p), ("norm3_w", C.c_void_p), ("norm3_b", C.c_void_p)]
+
+
+class isi_prior_w(C.Structure):
+    _fields_ = [("d_model", C.c_int), ("nhead", C.c_int), ("dim_feedforward", C.c_int), ("n_layers", C.c_int),
+                ("n_class", C.c_int), ("Cd", C.c_int), ("Ed", C.c_int), ("Ce", C.c_int), ("Ee", C.c_int),
+                ("layers", isi_decoder_layer_w * ISI_MAX_LAYERS), ("logits_w", C.c_void_p),
+                ("logits_b", C.c_void_p), ("embed_table", C.c_void_p), ("eff_dim", C.c_int)]
+
+
+class isi_prior_state(C.Structure):
+    _fields_ = [("x_seq", C.c_void_p), ("kv_cache", C.c_void_p), ("memory_kv", C.c_void_p), ("codes", C.c_void_p),
+                ("mask", C.c_void_p), ("uniforms", C.c_void_p), ("scratch", C.c_void_p),
+                ("scratch_floats", C.c_size_t), ("S_t", C.c_int), ("S_src", C.c_int), ("S", C.c_int),
+                ("B", C.c_int), ("start_len", C.c_int)]
+
+
 # name -> (restype, argtypes); must list every symbol include/isi_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -112,6 +141,9 @@ SIGNATURES = {
                                       C.c_int, _P]),
     "isi_sample_row_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_float, _P, _P, _P,
                                      _P]),
+    "isi_prior_decode_scratch_floats": (C.c_size_t, [C.POINTER(isi_prior_w), C.c_int]),
+    "isi_prior_sample_run": (C.c_int, [C.POINTER(isi_prior_w), C.POINTER(isi_prior_state), C.c_int, C.c_int,
+                                       C.c_float, C.c_int, C.c_float, _P]),
     "isi_vq_nearest_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "isi_vq_num_partials": (C.c_int, [C.c_int64]),
     "isi_vq_finalize_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
@@ -146,7 +178,7 @@ def lib() -> C.CDLL:
                     fn.restype = res
                     fn.argtypes = args
                 structs = [isi_src, isi_dst, isi_conv_w, isi_encoder_w, isi_decoder_w, isi_codebook_w,
-                           isi_vqvae_w, isi_vqvae_out, isi_attn_args]
+                           isi_vqvae_w, isi_vqvae_out, isi_attn_args, isi_prior_w, isi_prior_state]
                 for i, st in enumerate(structs):
                     if handle.isi_abi_struct_bytes(i) != C.sizeof(st):
                         raise HipLibraryError(f"ABI mismatch for {st.__name__}: library "

@@ -66,3 +66,87 @@ class IncrementalDecoder:
     def logits(self, out_row: torch.Tensor) -> torch.Tensor:
         head = self.model.project_transformer_outputs_to_logits
         return self._linear(out_row, head.weight, head.bias)
+
+
+class NativeSampler:
+    """The whole sampling loop in one native call (`isi_prior_sample_run`): all
+    per-position launches are enqueued without returning to Python and without
+    host synchronisation; sampled indices stay on the device."""
+
+    def __init__(self, model, memory: torch.Tensor, x_seq: torch.Tensor, codes: torch.Tensor,
+                 mask_seq, uniforms: torch.Tensor):
+        import ctypes as C
+        import numpy as np
+        from .. import _hip
+        from .transformer import Seq2SeqInputKind
+        self._C, self._hip = C, _hip
+        dec_layers = list(model.transformer.decoder.layers)
+        if len(dec_layers) > _hip.ISI_MAX_LAYERS:
+            raise NotImplementedError(f"more than {_hip.ISI_MAX_LAYERS} decoder layers")
+        dev = memory.device
+        d, B = model.d_model, x_seq.shape[1]
+        if B > 8:
+            raise NotImplementedError("native sampling supports batch sizes up to 8")
+        self.model = model
+        self.keep = []
+        w = _hip.isi_prior_w()
+        w.d_model, w.nhead = d, model.conditional_model_nhead
+        w.dim_feedforward = dec_layers[0].linear1.out_features
+        w.n_layers, w.n_class = len(dec_layers), model.n_class_target
+        w.Cd, w.Ed = model.target_num_channels, model.target_num_events_with_start_symbol
+        w.Ce, w.Ee = model.source_num_channels, model.source_num_events_with_start_symbol
+
+        def ptr(t):
+            t = t.detach()
+            if not t.is_contiguous():
+                t = t.contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def attn(m):
+            a = _hip.isi_attn_w()
+            a.in_proj_weight, a.in_proj_bias = ptr(m.in_proj_weight), ptr(m.in_proj_bias)
+            a.out_proj_weight, a.out_proj_bias = ptr(m.out_proj.weight), ptr(m.out_proj.bias)
+            if m.rel_embeddings is not None:
+                a.rel_embeddings, a.rel_rows = ptr(m.rel_embeddings), m.rel_embeddings.shape[1]
+            return a
+
+        for i, layer in enumerate(dec_layers):
+            L = w.layers[i]
+            L.self_attn, L.cross_attn = attn(layer.self_attn), attn(layer.multihead_attn)
+            L.linear1_w, L.linear1_b = ptr(layer.linear1.weight), ptr(layer.linear1.bias)
+            L.linear2_w, L.linear2_b = ptr(layer.linear2.weight), ptr(layer.linear2.bias)
+            for k in (1, 2, 3):
+                norm = getattr(layer, f"norm{k}")
+                setattr(L, f"norm{k}_w", ptr(norm.weight))
+                setattr(L, f"norm{k}_b", ptr(norm.bias))
+        head = model.project_transformer_outputs_to_logits
+        w.logits_w, w.logits_b = ptr(head.weight), ptr(head.bias)
+        table = model._embedding_table(Seq2SeqInputKind.Target)
+        w.embed_table, w.eff_dim = ptr(table), table.shape[1]
+        self.w = w
+
+        memory = memory.contiguous()
+        self.memory_kv = torch.stack([l.multihead_attn.project_kv(memory) for l in dec_layers]).contiguous()
+        S_t = x_seq.shape[0]
+        self.kv_cache = torch.zeros(len(dec_layers), S_t, B, 2 * d, dtype=torch.float32, device=dev)
+        self.x_seq, self.codes = x_seq, codes
+        self.mask_host = np.ascontiguousarray(np.asarray(mask_seq, dtype=np.uint8))
+        self.uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()
+        n_scratch = _hip.lib().isi_prior_decode_scratch_floats(C.byref(w), B)
+        self.scratch = torch.empty(n_scratch, dtype=torch.float32, device=dev)
+        st = _hip.isi_prior_state()
+        st.x_seq, st.kv_cache, st.memory_kv = x_seq.data_ptr(), self.kv_cache.data_ptr(), self.memory_kv.data_ptr()
+        st.codes, st.mask = codes.data_ptr(), self.mask_host.ctypes.data
+        st.uniforms, st.scratch, st.scratch_floats = self.uniforms.data_ptr(), self.scratch.data_ptr(), n_scratch
+        st.S_t, st.S_src, st.S, st.B = S_t, memory.shape[0], codes.shape[1], B
+        st.start_len = model.target_start_symbol.shape[1]
+        self.state = st
+
+    @torch.no_grad()
+    def run(self, p_begin: int, p_end: int, temperature: float, top_k: int, top_p: float) -> None:
+        C, _hip = self._C, self._hip
+        rc = _hip.lib().isi_prior_sample_run(C.byref(self.w), C.byref(self.state), p_begin, p_end,
+                                             float(temperature), int(top_k), float(top_p),
+                                             C.c_void_p(_hip.stream_ptr(self.x_seq.device)))
+        _hip.check(rc, "isi_prior_sample_run")

@@ -20,7 +20,7 @@ from typing import Iterable, Mapping, Optional, Union
 import torch
 
 from interactive_spectrogram_inpainting.priors import _ops
-from interactive_spectrogram_inpainting.priors._decode import IncrementalDecoder
+from interactive_spectrogram_inpainting.priors._decode import IncrementalDecoder, NativeSampler
 from interactive_spectrogram_inpainting.priors.transformer import Seq2SeqInputKind, VQNSynthTransformer
 
 
@@ -92,21 +92,33 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
     # encoder memory once (anti-causal for the self-conditional top prior)
     src = source_seq.transpose(0, 1).contiguous()
     memory, *_ = model.transformer.encoder(src, mask='anticausal' if model.self_conditional_model else None)
-    dec = IncrementalDecoder(model, memory, batch_size)
     x_seq = target_seq.transpose(0, 1).contiguous()          # [S_t, B, d]; rows are rewritten as we sample
-    table = model._embedding_table(Seq2SeqInputKind.Target)
-    eff = model.embeddings_effective_dim
-
-    positions = range(S + start_len - 1)
-    if progressbar_decorator is not None:
-        positions = progressbar_decorator(positions)
-    for p in positions:
-        out_row = dec.step(p, x_seq[p])
-        i = p - (start_len - 1)                               # token predicted from position p
-        if i < 0 or not mask_seq[i]:
-            continue
-        logits = dec.logits(out_row)
-        sample = _ops.sample_rows(logits, temperature, top_k_sampling_k, top_p_sampling_p, uniforms[i])
-        code_seq[:, i] = sample
-        x_seq[i + start_len, :, :eff] = table[sample]          # embed_data(sample) into the next input row
+    if not code_seq.is_contiguous():
+        code_seq = code_seq.contiguous()
+    n_pos = S + start_len - 1
+    if batch_size <= 8:
+        # the whole loop natively: no per-token return to Python, no host sync
+        sampler = NativeSampler(model, memory, x_seq, code_seq, mask_seq, uniforms)
+        chunk = n_pos if progressbar_decorator is None else 64
+        starts = range(0, n_pos, chunk)
+        if progressbar_decorator is not None:
+            starts = progressbar_decorator(starts)
+        for p0 in starts:
+            sampler.run(p0, min(n_pos, p0 + chunk), temperature, top_k_sampling_k, top_p_sampling_p)
+    else:
+        dec = IncrementalDecoder(model, memory, batch_size)
+        table = model._embedding_table(Seq2SeqInputKind.Target)
+        eff = model.embeddings_effective_dim
+        positions = range(n_pos)
+        if progressbar_decorator is not None:
+            positions = progressbar_decorator(positions)
+        for p in positions:
+            out_row = dec.step(p, x_seq[p])
+            i = p - (start_len - 1)                           # token predicted from position p
+            if i < 0 or not mask_seq[i]:
+                continue
+            logits = dec.logits(out_row)
+            sample = _ops.sample_rows(logits, temperature, top_k_sampling_k, top_p_sampling_p, uniforms[i])
+            code_seq[:, i] = sample
+            x_seq[i + start_len, :, :eff] = table[sample]      # embed_data(sample) into the next input row
     return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()

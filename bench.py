@@ -76,6 +76,38 @@ def _cpu_baseline(sd, batch=16, iters=2):
                                        f"(oracle/vqvae_oracle.py, torch-CPU)"}
 
 
+def _prior_sampling(device):
+    """Secondary metric of BASELINE.json: prior-sampled codes/s at seq 1024 (top prior,
+    shape [32,32], d_model 512, 6 encoder + 8 decoder layers, 8 heads, full mask,
+    temperature 1, top-p 0.8, random weights), KV-cached native sampling loop."""
+    import sample as S
+    from interactive_spectrogram_inpainting.priors.transformer import SelfAttentiveVQTransformer
+    torch.manual_seed(2)
+    m = SelfAttentiveVQTransformer(
+        shape=[32, 32], condition_shape=[32, 32], n_class=512, channel=256, kernel_size=5, n_block=4,
+        n_res_block=4, res_channel=256, d_model=512, embeddings_dim=32, positional_embeddings_dim=16,
+        use_relative_transformer=True, predict_frequencies_first=True, conditional_model=True,
+        self_conditional_model=True, add_mask_token_to_symbols=True,
+        class_conditioning_prepend_to_dummy_input=True,
+        class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+        class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device).eval()
+    cls = {"pitch": torch.tensor([24]), "instrument_family_str": torch.tensor([0])}
+    out = {}
+    for B in (1, 8):
+        kw = dict(class_conditioning=cls, top_p_sampling_p=0.8)
+        S.sample_model(m, device, B, [32, 32], 1.0, generator=torch.Generator().manual_seed(0), **kw)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        S.sample_model(m, device, B, [32, 32], 1.0, generator=torch.Generator().manual_seed(1), **kw)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        out[f"codes_per_s_B{B}"] = round(B * 1024 / dt, 1)
+        out[f"ms_per_codemap_B{B}"] = round(dt * 1e3, 1)
+    out["unit"] = "codes/s"
+    out["config"] = "SelfAttentiveVQTransformer shape [32,32] (1024 tokens + start), d_model 512, 6+8 layers, 8 heads, fp32"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prior", action="store_true", help="skip the secondary prior-sampling metric")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -169,6 +202,8 @@ def main():
                          "TFLOPs": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
                          "GBs": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)} for k in kernels],
         }
+        if not args.no_prior:
+            line["prior_sampling"] = _prior_sampling(device)
         if not args.no_cpu_baseline and world >= 1:
             line["cpu_baseline"] = _cpu_baseline(sd)
         print(json.dumps(line), flush=True)

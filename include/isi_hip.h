@@ -171,8 +171,13 @@ int isi_linear_rows_f32(const float *x, int x_stride, const float *W, const floa
 /* Decoding step: ONE query row per (batch, head) at sequence position q_pos
  * against args->Sk cached keys/values (same logits as isi_rel_attention_f32;
  * args->Sq, q_ss, o_ss, mask_mode and dense_mask are ignored: the caller passes
- * Sk = q_pos + 1 for causal self-attention). */
-int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, void *stream);
+ * Sk = q_pos + 1 for causal self-attention).  With a workspace of
+ * isi_rel_attention_decode_workspace_floats(B, H, head_dim) floats the keys are split
+ * over up to 8 workgroups per (batch, head) and merged by a second small kernel;
+ * workspace may be NULL (single workgroup per head). */
+size_t isi_rel_attention_decode_workspace_floats(int B, int H, int head_dim);
+int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, float *workspace,
+                                 void *stream);
 
 /* One categorical draw per row (sample.py:286-295): logits/temperature ->
  * top_k_top_p_filtering (sample.py:36-65) -> softmax -> inverse-CDF draw with the

@@ -92,8 +92,11 @@ int isi_linear_rows_f32(const float *x, int x_stride, const float *W, const floa
   return linear_rows_f32(x, x_stride, W, bias, residual, res_stride, out, out_stride, M, N, K, relu, S(stream));
 }
 
-int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, void *stream) {
-  return rel_attention_decode_f32(args, q_pos, S(stream));
+int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, float *workspace, void *stream) {
+  return rel_attention_decode_f32(args, q_pos, workspace, S(stream));
+}
+size_t isi_rel_attention_decode_workspace_floats(int B, int H, int head_dim) {
+  return rel_attention_decode_workspace_floats(B, H, head_dim);
 }
 int isi_sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k,
                        float top_p, const float *u, int64_t *out, float *filtered, void *stream) {

@@ -161,7 +161,8 @@ size_t prior_decode_scratch_floats(const isi_prior_w *w, int B) {
   if (!w || B <= 0) return 0;
   const size_t d = w->d_model;
   // q, attn out, y1, y2, y3(a), y3(b), hidden, logits, sampled(int64)
-  return (size_t)B * (6 * d + w->dim_feedforward + w->n_class) + 2 * (size_t)B + 64;
+  return (size_t)B * (6 * d + w->dim_feedforward + w->n_class) + 2 * (size_t)B + 64 +
+         rel_attention_decode_workspace_floats(B, w->nhead, w->d_model / w->nhead);
 }
 
 int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin, int p_end, float temperature,
@@ -182,6 +183,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   float *y3a = y2 + (size_t)B * d, *y3b = y3a + (size_t)B * d, *hid = y3b + (size_t)B * d;
   float *logits = hid + (size_t)B * ff;
   int64_t *sampled = reinterpret_cast<int64_t *>(logits + (size_t)B * w->n_class + ((B * w->n_class) & 1));
+  float *attn_ws = reinterpret_cast<float *>(sampled + B) + 2;
   const size_t cache_layer = (size_t)s->S_t * B * 2 * d, mem_layer = (size_t)s->S_src * B * 2 * d;
   const float scale = 1.0f / sqrtf((float)hd);
 
@@ -206,7 +208,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       g.q_sb = d; g.q_sh = hd; g.k_ss = (int64_t)B * 2 * d; g.k_sb = 2 * d; g.k_sh = hd;
       g.v_ss = g.k_ss; g.v_sb = g.k_sb; g.v_sh = hd; g.o_sb = d; g.o_sh = hd;
       g.Cq = w->Cd; g.Ck = w->Cd; g.Ek = w->Ed; g.rel_rows = L.self_attn.rel_rows; g.scale = scale;
-      if ((rc = rel_attention_decode_f32(&g, p, st))) return rc;
+      if ((rc = rel_attention_decode_f32(&g, p, attn_ws, st))) return rc;
       // y1 = LN_in(yin) + ao Wo^T + bo
       a = RowLinArgs{ao, d, nullptr, nullptr, L.self_attn.out_proj_weight, L.self_attn.out_proj_bias, yin, d, ln_g,
                      ln_b, y1, d, nullptr, 0, d, B, d, d, 0, 1e-5f};
@@ -217,7 +219,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       if ((rc = launch_row_linear(a, st))) return rc;
       g.k = memkv; g.v = memkv + d; g.rel_embeddings = L.cross_attn.rel_embeddings; g.Sk = s->S_src;
       g.Ck = w->Ce; g.Ek = w->Ee; g.rel_rows = L.cross_attn.rel_rows;
-      if ((rc = rel_attention_decode_f32(&g, p, st))) return rc;
+      if ((rc = rel_attention_decode_f32(&g, p, attn_ws, st))) return rc;
       a = RowLinArgs{ao, d, nullptr, nullptr, L.cross_attn.out_proj_weight, L.cross_attn.out_proj_bias, y1, d,
                      L.norm1_w, L.norm1_b, y2, d, nullptr, 0, d, B, d, d, 0, 1e-5f};
       if ((rc = launch_row_linear(a, st))) return rc;

@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ e, float *__restrict__ out, int Sk, int64_t q_sb, int64_t q_sh, int64_t k_ss,
     int64_t k_sb, int64_t k_sh, int64_t v_ss, int64_t v_sb, int64_t v_sh, int64_t o_sb, int64_t o_sh,
-    int q_pos, int Cq, int Ck, int Ek, int R, float scale) {
+    int q_pos, int Cq, int Ck, int Ek, int R, float scale, int chunk, float *__restrict__ partial) {
+  // blockIdx.z = key split: this workgroup handles keys [z*chunk, min(Sk, (z+1)*chunk)) and,
+  // when there are several splits, writes an un-normalised partial (o, max, sum) that
+  // rel_attention_combine_kernel merges.
   // A group of G = HD/4 lanes owns one key row (one coalesced 16-B load per lane);
   // 256/G rows are in flight per pass, 4 passes unrolled.
   constexpr int G = HD / 4;        // lanes per row: 4, 8 or 16
@@ -172,6 +175,11 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = tid / G, gl = tid % G;
   const int h = blockIdx.x, b = blockIdx.y;
+  const int kbeg = blockIdx.z * chunk;
+  k += (size_t)kbeg * k_ss;
+  v += (size_t)kbeg * v_ss;
+  const int key0 = kbeg;              // absolute index of local key 0 (relative positions)
+  Sk = min(Sk - kbeg, chunk);         // local key count
   const float4 qq = *reinterpret_cast<const float4 *>(q + b * q_sb + h * q_sh + gl * 4);
   const int evq = q_pos / Cq;
   const float *kb = k + b * k_sb + h * k_sh + gl * 4;
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
       if (j < Sk) {
         float4 kk = *reinterpret_cast<const float4 *>(kb + (size_t)j * k_ss);
         if (eb) {
-          int r = evq - j / Ck + Ek - 1;
+          int r = evq - (key0 + j) / Ck + Ek - 1;
           r = r < 0 ? 0 : (r >= R ? R - 1 : r);
           const float4 ee = *reinterpret_cast<const float4 *>(eb + (size_t)r * HD);
           kk.x += ee.x; kk.y += ee.y; kk.z += ee.z; kk.w += ee.w;
@@ -247,16 +255,46 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   if (tid < HD) {
     float acc = 0.f;
     for (int g = 0; g < RPP; ++g) acc += part[g * HD + tid];
-    out[b * o_sb + h * o_sh + tid] = acc / gsum;
+    if (gridDim.z == 1) {
+      out[b * o_sb + h * o_sh + tid] = acc / gsum;
+    } else {
+      float *pp = partial + (((size_t)b * gridDim.x + h) * gridDim.z + blockIdx.z) * (HD + 2);
+      pp[tid] = acc;
+      if (tid == 0) { pp[HD] = gmax; pp[HD + 1] = gsum; }
+    }
   }
 }
 
-int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, hipStream_t stream) {
+// Merge the key splits of one (batch, head): softmax-weighted sum of the partials.
+__global__ void rel_attention_combine_kernel(const float *__restrict__ partial, float *__restrict__ out,
+                                             int HD, int NS, int64_t o_sb, int64_t o_sh) {
+  const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+  const float *pp = partial + ((size_t)b * gridDim.x + h) * NS * (HD + 2);
+  float M = -1e30f;
+  for (int s = 0; s < NS; ++s) M = fmaxf(M, pp[s * (HD + 2) + HD]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < NS; ++s) {
+    const float w = expf(pp[s * (HD + 2) + HD] - M);
+    num += w * pp[s * (HD + 2) + d];
+    den += w * pp[s * (HD + 2) + HD + 1];
+  }
+  out[b * o_sb + h * o_sh + d] = num / den;
+}
+
+int rel_attention_decode_splits(int Sk) { return Sk <= 192 ? 1 : (Sk + 127) / 128 > 8 ? 8 : (Sk + 127) / 128; }
+
+size_t rel_attention_decode_workspace_floats(int B, int H, int head_dim) {
+  return (size_t)B * H * 8 * (head_dim + 2);
+}
+
+int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, float *workspace, hipStream_t stream) {
   if (!g || !g->q || !g->k || !g->v || !g->out) return invalid("attention_decode: null pointer");
   if (g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->Cq <= 0 || g->Ck <= 0) return invalid("attention_decode: bad shape");
-  if (g->Sk > 32768) return unsupported("attention_decode: more than 32768 keys");
-  const size_t smem = (size_t)(8 + 256 * 4 + g->Sk) * sizeof(float);  // red + part[256/G][HD] + scores
-  dim3 grid(g->H, g->B), block(256);
+  if (g->Sk > 65536) return unsupported("attention_decode: more than 65536 keys");
+  const int ns = workspace ? rel_attention_decode_splits(g->Sk) : 1;
+  const int chunk = (g->Sk + ns - 1) / ns;
+  const size_t smem = (size_t)(8 + 256 * 4 + chunk) * sizeof(float);  // red + part[256/G][HD] + scores
+  dim3 grid(g->H, g->B, ns), block(256);
 #define ISI_DEC(HD)                                                                                         \
   do {                                                                                                      \
     auto kern = rel_attention_decode_f32_kernel<HD>;                                                        \
@@ -266,7 +304,7 @@ int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, hipStream_t stre
       return check_launch("hipFuncSetAttribute(attention_decode)");                                         \
     hipLaunchKernelGGL(kern, grid, block, smem, stream, g->q, g->k, g->v, g->rel_embeddings, g->out, g->Sk, \
                        g->q_sb, g->q_sh, g->k_ss, g->k_sb, g->k_sh, g->v_ss, g->v_sb, g->v_sh, g->o_sb,     \
-                       g->o_sh, q_pos, g->Cq, g->Ck, g->Ek, g->rel_rows, g->scale);                         \
+                       g->o_sh, q_pos, g->Cq, g->Ck, g->Ek, g->rel_rows, g->scale, chunk, workspace);       \
   } while (0)
   switch (g->head_dim) {
     case 16: ISI_DEC(16); break;
@@ -275,7 +313,11 @@ int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, hipStream_t stre
     default: return unsupported("attention_decode: head_dim must be 16, 32 or 64");
   }
 #undef ISI_DEC
-  return check_launch("rel_attention_decode_f32");
+  int rc = check_launch("rel_attention_decode_f32");
+  if (rc || ns == 1) return rc;
+  hipLaunchKernelGGL(rel_attention_combine_kernel, dim3(g->H, g->B), dim3(g->head_dim), 0, stream, workspace,
+                     g->out, g->head_dim, ns, g->o_sb, g->o_sh);
+  return check_launch("rel_attention_combine");
 }
 
 // ------------------------------------------------------------------ sampling

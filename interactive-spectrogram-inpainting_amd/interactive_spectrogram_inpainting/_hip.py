@@ -135,7 +135,8 @@ SIGNATURES = {
     "isi_resblock_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, _P]),
     "isi_rel_attention_f32": (C.c_int, [C.POINTER(isi_attn_args), _P]),
-    "isi_rel_attention_decode_f32": (C.c_int, [C.POINTER(isi_attn_args), C.c_int, _P]),
+    "isi_rel_attention_decode_f32": (C.c_int, [C.POINTER(isi_attn_args), C.c_int, _P, _P]),
+    "isi_rel_attention_decode_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "isi_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "isi_linear_rows_f32": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, _P]),

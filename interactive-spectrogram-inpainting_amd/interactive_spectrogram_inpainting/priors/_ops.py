@@ -126,7 +126,11 @@ def rel_attention_decode(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel:
     a.k_ss, a.k_sb, a.k_sh = k.stride(0), k.stride(1), hd
     a.v_ss, a.v_sb, a.v_sh = v.stride(0), v.stride(1), hd
     a.o_ss, a.o_sb, a.o_sh = 0, out.stride(0), hd
-    _hip.check(_hip.lib().isi_rel_attention_decode_f32(C.byref(a), q_pos, _s(q)), "isi_rel_attention_decode_f32")
+    L = _hip.lib()
+    ws = torch.empty(L.isi_rel_attention_decode_workspace_floats(B, nhead, hd), dtype=torch.float32,
+                     device=q.device)
+    _hip.check(L.isi_rel_attention_decode_f32(C.byref(a), q_pos, ws.data_ptr(), _s(q)),
+               "isi_rel_attention_decode_f32")
     return out
 
 

@@ -133,6 +133,45 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3,
                      const float *packed_w1, const float *b1, float *out, int B,
                      int H, int W, int C, int R, int relu, void *stream);
 
+/* ----------------------------------------------------- training (backward) */
+/* These replace the autograd kernels behind `loss.backward()` (train_vqvae.py:181)
+ * and the in-forward EMA codebook update (vqvae/bottleneck.py:79-92).
+ * Input gradients of the convolutions reuse the forward entry points:
+ *   d/dx Conv2d(k, s=1)      = isi_conv2d_f32 with the flipped / transposed weight
+ *   d/dx Conv2d(k4,s2,p1)    = isi_conv_transpose2d_k4s2_f32 with the same weight tensor
+ *   d/dx ConvTranspose(k4s2) = isi_conv2d_f32(k4,s2,p1) with the same weight tensor. */
+
+/* Weight gradient dW (packed like the forward weight: [nphase][Cout][Kpad]) of a
+ * convolution (transposed = 0) or ConvTranspose2d(k4,s2,p1) (transposed = 1) whose input
+ * was cat(src0, src1) [B,*,H,W] and whose output gradient is dy, dense channels-last
+ * [B, OH, OW, Cout] (transposed: [B, 2H, 2W, Cout]).  Deterministic split reduction;
+ * workspace of isi_conv_wgrad_workspace_floats(Cout, K, M, nphase) floats with
+ * K = KH*KW*Cin (transposed: 4*Cin), M = B*OH*OW (transposed: B*H*W), nphase = 1 (4). */
+size_t isi_conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
+int isi_conv_wgrad_f32(const isi_src *src0, const isi_src *src1, const float *dy,
+                       float *dw_packed, float *workspace, size_t workspace_floats, int B,
+                       int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                       int transposed, void *stream);
+/* dy *= (y > 0) : ReLU backward through an output rectified in the producer's epilogue. */
+int isi_relu_bwd_f32(float *dy, const float *y, int64_t n, void *stream);
+/* a += alpha * b */
+int isi_axpy_f32(float *a, const float *b, float alpha, int64_t n, void *stream);
+/* Quantiser backward (bottleneck.py:94-95): dz = dq + 2 g_diff (z - q_st) / n. */
+int isi_vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st,
+                   const float *g_diff, int64_t n, void *stream);
+/* out[C] = column sums of x [M, C] (bias gradients); workspace isi_colsum_num_partials(M)*C floats. */
+int isi_colsum_num_partials(int64_t M);
+int isi_colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M,
+                   int C, void *stream);
+/* embed_sum_kd[k,:] = sum of z_n with idx[n] == k  (the `flatten^T @ onehot` of bottleneck.py:83). */
+int isi_vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_kd, int64_t N,
+                         int D, int K, void *stream);
+/* EMA codebook update (bottleneck.py:80-92) on the [D,K] buffers from batch statistics
+ * counts [K] (float) and embed_sum_kd [K,D] (all-reduced across ranks by the caller). */
+int isi_vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg,
+                          const float *counts, const float *embed_sum_kd, int D, int K,
+                          float decay, float eps, void *stream);
+
 /* ------------------------------------------------------ transformer prior */
 /* The prior's layers are instantiated by the reference from the absent package
  * VQCPCB.transformer.transformer_custom (priors/transformer.py:12-15,370-417);

@@ -1,0 +1,287 @@
+// Weight gradient of the (transposed) convolutions, gfx950 exact-fp32 matrix pipe.
+//
+//   dW[co][k] = sum over output pixels m of  dY[m][co] * A[m][k]
+//   A = the im2col view of the layer input the forward implicit GEMM used
+//       (k = (kh*KW + kw)*Cin + ci, zero padded; conv_igemm_f32.hip)
+//
+// i.e. the GEMM  dY^T (Cout x M)  x  A (M x K), reduced over pixels.  A workgroup
+// owns a 128(co) x 128(k) tile of dW and a contiguous range of 32-pixel chunks
+// (blockIdx.z = phase * nsplit + split); both operands are staged pixel-major in
+// LDS ([32 pixels][128 + 4]) and read with conflict-free ds_read_b32 as MFMA
+// fragments.  Splits write partial tiles; reduce_partials_kernel sums them in a
+// fixed order (deterministic, no float atomics).
+//
+// Replaces autograd's conv weight-gradient kernels behind `loss.backward()`
+// (reference train_vqvae.py:181) for nn.Conv2d / nn.ConvTranspose2d of
+// vqvae/encoder_decoder.py:95-112,138,199-215 and vqvae/vqvae.py:149-150,175-201.
+#include <algorithm>
+
+#include "isi_common.h"
+#include "isi_internal.h"
+
+namespace isi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct WgradKArgs {
+  const float *x0, *x1, *dy;
+  float *partial;
+  unsigned x0_bytes, x1_bytes, dy_bytes;
+  int C0, Cin, vec, dvec;      // vec: sources are channels-last with 16-B aligned quads; dvec: Cout % 4 == 0
+  int s0n, s0c, s0h, s0w, s1n, s1h, s1w;
+  int dn, dh, dw;              // dY element strides in GEMM-grid pixels (channel stride 1)
+  int H, W, OH, OW, Cout, K, Kpad, KW, stride, pad, M;
+  int convT, dst_sh, dst_sw;   // transposed conv: phase offset into dY
+  int nsplit, chunks_per_split;
+};
+
+namespace {
+constexpr int LDT = 132;  // LDS row (floats): 128 + 4
+constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+  return *reinterpret_cast<float4 *>(&v);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Ds = smem;                  // [2][32][LDT]  dY chunk  (pixel-major, co inner)
+  float *Xs = smem + 2 * 32 * LDT;   // [2][32][LDT]  im2col chunk (pixel-major, k inner)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int co0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int phase = blockIdx.z / p.nsplit, split = blockIdx.z - phase * p.nsplit;
+  const int py = p.convT ? phase >> 1 : 0, px = p.convT ? phase & 1 : 0;
+  const int pad_y = p.convT ? 1 - py : p.pad, pad_x = p.convT ? 1 - px : p.pad;
+  const int dy_off = p.convT ? py * p.dst_sh + px * p.dst_sw : 0;
+
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x1), 0, p.x1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+  // staging role: pixel row tid/32 + 8j (j < 4), quad tid%32 of the 128-wide tile
+  const int srow = tid >> 5, sq = tid & 31;
+  // this thread's K position is fixed for the whole kernel
+  const int kk = k0 + sq * 4;
+  const bool kvalid = kk < p.K;
+  int tap = 0, c = 0, kh = 0, kw = 0;
+  if (kvalid) { tap = kk / p.Cin; c = kk - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW; }
+  const bool second = c >= p.C0;
+  const int cc = second ? c - p.C0 : c;
+  const int co = co0 + sq * 4;
+  const bool covalid = co < p.Cout;  // Cout % 4 == 0 is required by the launcher when vec
+
+  const int chunk_begin = split * p.chunks_per_split;
+  const int nchunks_total = (p.M + 31) / 32;
+  const int chunk_end = min(nchunks_total, chunk_begin + p.chunks_per_split);
+
+  float4 rdq[4], rxq[4];
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = ch * 32 + srow + 8 * j;
+      unsigned doff = OOB, xoff = OOB;
+      float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < p.M) {
+        const int b = m / (p.OH * p.OW);
+        const int rem = m - b * (p.OH * p.OW);
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        if (covalid) doff = (unsigned)(dy_off + b * p.dn + oy * p.dh + ox * p.dw + co) * 4u;
+        if (p.vec) {
+          const int iy = oy * p.stride - pad_y + kh, ix = ox * p.stride - pad_x + kw;
+          if (kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            xoff = second ? (unsigned)(b * p.s1n + iy * p.s1h + ix * p.s1w + cc) * 4u
+                          : (unsigned)(b * p.s0n + iy * p.s0h + ix * p.s0w + cc) * 4u;
+        } else {
+          // element-wise gather (NCHW input / Cin % 4 != 0): a quad may straddle taps
+          float t[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int k1 = kk + e;
+            float val = 0.f;
+            if (k1 < p.K) {
+              const int tp = k1 / p.Cin, c1 = k1 - tp * p.Cin;
+              const int kh1 = tp / p.KW, kw1 = tp - kh1 * p.KW;
+              const int iy1 = oy * p.stride - pad_y + kh1, ix1 = ox * p.stride - pad_x + kw1;
+              if ((unsigned)iy1 < (unsigned)p.H && (unsigned)ix1 < (unsigned)p.W)
+                val = c1 < p.C0 ? p.x0[b * p.s0n + c1 * p.s0c + iy1 * p.s0h + ix1 * p.s0w]
+                                : p.x1[b * p.s1n + (c1 - p.C0) + iy1 * p.s1h + ix1 * p.s1w];
+            }
+            t[e] = val;
+          }
+          xs = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+      if (p.dvec) {
+        rdq[j] = buf_load4(rd, doff);
+      } else {
+        // Cout % 4 != 0 (e.g. the 2-channel spectrogram gradient): element-wise
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        if (doff != OOB) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.Cout) t[e] = p.dy[(doff >> 2) + e];
+        }
+        rdq[j] = make_float4(t[0], t[1], t[2], t[3]);
+      }
+      rxq[j] = p.vec ? (second ? buf_load4(r1, xoff) : buf_load4(r0, xoff)) : xs;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *reinterpret_cast<float4 *>(Ds + buf * 32 * LDT + (srow + 8 * j) * LDT + sq * 4) = rdq[j];
+      *reinterpret_cast<float4 *>(Xs + buf * 32 * LDT + (srow + 8 * j) * LDT + sq * 4) = rxq[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fl = lane & 31, half = lane >> 5;
+  if (chunk_begin < chunk_end) {
+    load_chunk(chunk_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+    const int buf = (ch - chunk_begin) & 1;
+    if (ch + 1 < chunk_end) load_chunk(ch + 1);
+    const float *d = Ds + buf * 32 * LDT + half * LDT + wm0 + fl;
+    const float *x = Xs + buf * 32 * LDT + half * LDT + wn0 + fl;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {  // pixel pair (2t, 2t+1): k-slot = half
+      const float a0 = d[2 * t * LDT], a1 = d[2 * t * LDT + 32];
+      const float b0 = x[2 * t * LDT], b1 = x[2 * t * LDT + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (ch + 1 < chunk_end) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- partial tile: rows = co, cols = k
+  float *out = p.partial + (size_t)blockIdx.z * p.Cout * p.Kpad;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kcol = k0 + wn0 + j * 32 + fl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int corow = co0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (corow < p.Cout && kcol < p.Kpad) out[(size_t)corow * p.Kpad + kcol] = acc[i][j][r];
+      }
+    }
+}
+
+// out[i] = sum_s partial[s * stride + i]  (fixed order)
+__global__ void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, int64_t n,
+                                       int nsplit, int64_t stride, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * stride + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+static int64_t extent4(int64_t n, int64_t sn, int64_t c, int64_t sc, int64_t h, int64_t sh, int64_t w, int64_t sw) {
+  return (n - 1) * sn + (c - 1) * sc + (h - 1) * sh + (w - 1) * sw + 1;
+}
+
+size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
+  const int Kpad = (int)round_up(K, kBK);
+  const int tiles = ((Cout + 127) / 128) * ((Kpad + 127) / 128) * nphase;
+  const int nchunks = (M + 31) / 32;
+  int nsplit = std::max(1, 768 / tiles);
+  nsplit = std::min(nsplit, std::max(1, nchunks / 8));
+  return (size_t)nsplit * nphase * Cout * Kpad;
+}
+
+// dW packed like the forward weights: [nphase][Cout][Kpad].  x = layer input (two sources allowed), dy = gradient
+// of the layer output, dense channels-last [B, OH(, *2), OW(, *2), Cout].
+int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *workspace,
+                   size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                   int transposed, hipStream_t stream) {
+  if (!s0 || !s0->ptr || !dy || !dw_packed || !workspace) return invalid("conv_wgrad: null pointer");
+  const bool two = s1 && s1->ptr;
+  const int Cin = s0->C + (two ? s1->C : 0);
+  int OH, OW, nphase = 1, K;
+  if (transposed) {
+    if (KH != 4 || KW != 4 || stride != 2 || pad != 1) return unsupported("conv_wgrad: transposed conv must be k4 s2 p1");
+    OH = H; OW = W; nphase = 4; K = 4 * Cin;
+  } else {
+    OH = (H + 2 * pad - KH) / stride + 1; OW = (W + 2 * pad - KW) / stride + 1; K = KH * KW * Cin;
+  }
+  if (OH <= 0 || OW <= 0) return invalid("conv_wgrad: empty output");
+  const int64_t M64 = (int64_t)B * OH * OW;
+  if (M64 > INT32_MAX) return unsupported("conv_wgrad: too many pixels");
+  WgradKArgs a;
+  memset(&a, 0, sizeof a);
+  const int64_t lim = (int64_t)1 << 30;
+  const int64_t e0 = extent4(B, s0->sn, s0->C, s0->sc, H, s0->sh, W, s0->sw);
+  const int64_t e1 = two ? extent4(B, s1->sn, s1->C, 1, H, s1->sh, W, s1->sw) : 1;
+  const int64_t ed = transposed ? (int64_t)B * 2 * H * 2 * W * Cout : M64 * Cout;
+  if (e0 > lim || e1 > lim || ed > lim) return unsupported("conv_wgrad: a tensor spans 4 GiB or more");
+  a.x0 = s0->ptr; a.x1 = two ? s1->ptr : s0->ptr; a.dy = dy; a.partial = workspace;
+  a.x0_bytes = (unsigned)(e0 * 4); a.x1_bytes = two ? (unsigned)(e1 * 4) : a.x0_bytes; a.dy_bytes = (unsigned)(ed * 4);
+  a.C0 = s0->C; a.Cin = Cin;
+  a.s0n = (int)s0->sn; a.s0c = (int)s0->sc; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;
+  if (two) { a.s1n = (int)s1->sn; a.s1h = (int)s1->sh; a.s1w = (int)s1->sw; }
+  bool vec = s0->sc == 1 && (s0->C % 4 == 0) && aligned16(s0->ptr) && (s0->sn % 4 == 0) && (s0->sh % 4 == 0) &&
+             (s0->sw % 4 == 0);
+  if (two) vec = vec && s1->sc == 1 && (s1->C % 4 == 0) && aligned16(s1->ptr) && (s1->sn % 4 == 0) &&
+                 (s1->sh % 4 == 0) && (s1->sw % 4 == 0);
+  if (two && s1->sc != 1) return unsupported("conv_wgrad: second source must be channels-last");
+  a.vec = vec ? 1 : 0;
+  a.dvec = ((Cout % 4) == 0 && aligned16(dy)) ? 1 : 0;
+  a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.Cout = Cout; a.K = K; a.Kpad = (int)round_up(K, kBK);
+  a.KW = transposed ? 2 : KW; a.stride = transposed ? 1 : stride; a.pad = pad; a.M = (int)M64;
+  a.convT = transposed ? 1 : 0;
+  if (transposed) {
+    const int OWf = 2 * W;
+    a.dn = 2 * H * OWf * Cout; a.dh = 2 * OWf * Cout; a.dw = 2 * Cout;
+    a.dst_sh = OWf * Cout; a.dst_sw = Cout;
+  } else {
+    a.dn = OH * OW * Cout; a.dh = OW * Cout; a.dw = Cout;
+  }
+  const int tiles = ((Cout + 127) / 128) * ((a.Kpad + 127) / 128) * nphase;
+  const int nchunks = (a.M + 31) / 32;
+  int nsplit = std::max(1, 768 / tiles);
+  nsplit = std::min(nsplit, std::max(1, nchunks / 8));
+  a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
+  const size_t need = (size_t)nsplit * nphase * Cout * a.Kpad;
+  if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
+  constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_f32_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(conv_wgrad)");
+    attr_set = true;
+  }
+  dim3 grid((Cout + 127) / 128, (a.Kpad + 127) / 128, nphase * nsplit);
+  hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(256), smem, stream, a);
+  int rc = check_launch("conv_wgrad_f32");
+  if (rc) return rc;
+  // partial layout: [phase][split][Cout][Kpad] -> out [phase][Cout][Kpad]
+  const int64_t per = (int64_t)Cout * a.Kpad;
+  for (int ph = 0; ph < nphase; ++ph) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream,
+                       workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0);
+  }
+  return check_launch("reduce_partials");
+}
+
+}  // namespace isi

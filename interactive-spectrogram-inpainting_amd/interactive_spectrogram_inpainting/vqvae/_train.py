@@ -1,0 +1,437 @@
+"""Training step of the VQ-VAE on MI355X: train-mode forward that keeps what the
+backward needs, the EMA codebook update, and a hand-written backward.
+
+Replaces what the reference gets from autograd + DDP in `train_vqvae.train`
+(train_vqvae.py:168-192): `out, latent_loss, ... = model(img)` stays differentiable
+for the caller's `loss = criterion(out, img) + 0.25 * latent_loss.mean();
+loss.backward()` through one `torch.autograd.Function` whose backward enqueues
+
+  * input gradients  = the forward convolution kernels with re-laid-out weights
+  * weight gradients = `isi_conv_wgrad_f32` (implicit GEMM over pixels)
+  * bias gradients   = column sums, ReLU masks, the straight-through / commitment
+                       gradient of the quantiser (bottleneck.py:94-95)
+
+Every ReLU of the forward is folded into its producer, so the tape stores
+rectified outputs `y` and the backward masks with `y > 0`.
+
+Data parallelism (one process per GPU, torch.distributed "nccl" = RCCL): the
+EMA statistics (counts, embed_sum) are all-reduced before the codebook update so
+all ranks keep identical codebooks, and parameter gradients live in one flat
+buffer whose buckets are all-reduced asynchronously as soon as the backward has
+produced them (decoder first), overlapping the remaining backward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .. import _hip
+from . import _ops
+from .encoder_decoder import RosinalityDecoder, RosinalityEncoder, RosinalityResBlock, _ConvParams
+
+
+def _s(t):
+    return C.c_void_p(_hip.stream_ptr(t.device))
+
+
+def _nhwc(t: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W]-shaped view -> dense channels-last storage (copy only if needed)."""
+    p = t.permute(0, 2, 3, 1)
+    return p if p.is_contiguous() else p.contiguous()
+
+
+def _as_bchw(nhwc: torch.Tensor) -> torch.Tensor:
+    return nhwc.permute(0, 3, 1, 2)
+
+
+def relu_bwd_(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """dy, y: dense tensors of identical layout; dy *= (y > 0) in place."""
+    _hip.check(_hip.lib().isi_relu_bwd_f32(dy.data_ptr(), y.data_ptr(), dy.numel(), _s(dy)), "isi_relu_bwd_f32")
+    return dy
+
+
+def axpy_(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    _hip.check(_hip.lib().isi_axpy_f32(a.data_ptr(), b.data_ptr(), alpha, a.numel(), _s(a)), "isi_axpy_f32")
+    return a
+
+
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    """x [M, C] (row stride arbitrary, unit column stride) -> [C]."""
+    M, Cc = x2d.shape
+    L = _hip.lib()
+    ws = torch.empty(L.isi_colsum_num_partials(M) * Cc, dtype=torch.float32, device=x2d.device)
+    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    _hip.check(L.isi_colsum_f32(x2d.data_ptr(), x2d.stride(0), out.data_ptr(), ws.data_ptr(), M, Cc, _s(x2d)),
+               "isi_colsum_f32")
+    return out
+
+
+def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
+               x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient of layer.weight in torch layout.  x (and x2): layer input(s) as [B,C,H,W] views;
+    dy_nhwc: dense [B,OH,OW,Cout]."""
+    L = _hip.lib()
+    B, _, H, W = x.shape
+    cin = layer.in_channels
+    cout = layer.out_channels
+    k = layer.kernel_size
+    tr = layer.transposed
+    K = (4 if tr else k * k) * cin
+    Kpad = (K + 31) // 32 * 32
+    nph = 4 if tr else 1
+    if tr:
+        M = B * H * W
+    else:
+        OH = (H + 2 * layer.padding - k) // layer.stride + 1
+        OW = (W + 2 * layer.padding - k) // layer.stride + 1
+        M = B * OH * OW
+    nws = L.isi_conv_wgrad_workspace_floats(cout, K, M, nph)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    packed = torch.empty(nph, cout, Kpad, dtype=torch.float32, device=x.device)
+    s0 = _hip.src_nchw_view(x)
+    s1 = _hip.src_nchw_view(x2) if x2 is not None else None
+    rc = L.isi_conv_wgrad_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, dy_nhwc.data_ptr(),
+                              packed.data_ptr(), ws.data_ptr(), nws, B, H, W, cout, k, k, layer.stride,
+                              layer.padding, int(tr), _s(x))
+    _hip.check(rc, "isi_conv_wgrad_f32")
+    if not tr:
+        # [Cout][kh][kw][Cin] -> [Cout, Cin, kh, kw]
+        return packed[0, :, :K].reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+    # phases [py,px][Cout][ty,tx][Cin] -> torch ConvTranspose2d layout [Cin, Cout, 4, 4], tap (3-py-2ty, 3-px-2tx)
+    g = packed[:, :, :K].reshape(2, 2, cout, 2, 2, cin)             # py px co ty tx ci
+    out = torch.empty(cin, cout, 4, 4, dtype=torch.float32, device=x.device)
+    for py in range(2):
+        for px in range(2):
+            for ty in range(2):
+                for tx in range(2):
+                    out[:, :, 3 - py - 2 * ty, 3 - px - 2 * tx] = g[py, px, :, ty, tx, :].t()
+    return out
+
+
+class _DgradWeights:
+    """Packed weights of the input-gradient convolutions, cached per weight version."""
+
+    def __init__(self):
+        self.cache: Dict[int, Tuple[tuple, torch.Tensor]] = {}
+
+    def get(self, layer: _ConvParams) -> torch.Tensor:
+        key = (layer.weight._version, layer.weight.data_ptr())
+        hit = self.cache.get(id(layer))
+        if hit is None or hit[0] != key:
+            w = layer.weight.detach()
+            if layer.transposed:
+                # d/dx ConvT(k4,s2,p1) = Conv(k4,s2,p1) with weight [out=Cin_T, in=Cout_T]: same tensor
+                packed = _ops.pack_conv_weight(w)
+            elif layer.stride == 2:
+                # d/dx Conv(k4,s2,p1) = ConvT(k4,s2,p1) with weight [in=Cout, out=Cin]: same tensor
+                packed = _ops.pack_convT_weight(w)
+            else:
+                # d/dx Conv(k, s=1) = Conv(k, s=1, p=k-1-p) with the 180-degree rotated, transposed weight
+                packed = _ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous())
+            hit = (key, packed)
+            self.cache[id(layer)] = hit
+        return hit[1]
+
+
+def conv_dgrad(dw: _DgradWeights, layer: _ConvParams, dy: torch.Tensor,
+               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Gradient w.r.t. the layer input ([B,Cin,H,W] view of channels-last storage);
+    dy: [B,Cout,OH,OW] view (any strides)."""
+    packed = dw.get(layer)
+    cin = layer.in_channels
+    if layer.transposed:
+        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False)
+    if layer.stride == 2:
+        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False)
+    k = layer.kernel_size
+    return _ops.conv2d(dy, packed, None, cin, k, 1, k - 1 - layer.padding, relu=False, residual_bchw=residual)
+
+
+class Tape:
+    """Activations kept by the train-mode forward."""
+
+    def __init__(self):
+        self.t: Dict[str, torch.Tensor] = {}
+
+    def __setitem__(self, k, v):
+        self.t[k] = v
+
+    def __getitem__(self, k):
+        return self.t[k]
+
+
+class Grads:
+    """Parameter gradients in one flat buffer (views per parameter).  With data
+    parallelism the buffer is cut into buckets of consecutive parameters; the backward
+    fills it from the last layers to the first, and a bucket is all-reduced
+    asynchronously (RCCL, its own stream) as soon as all of its gradients are written,
+    overlapping the rest of the backward."""
+
+    def __init__(self, model, n_buckets: int = 4):
+        self.params = list(model.parameters())
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        sizes = [p.numel() for p in self.params]
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.params[0].device)
+        self.views: List[torch.Tensor] = []
+        offsets = [0]
+        for p, n in zip(self.params, sizes):
+            self.views.append(self.flat[offsets[-1]:offsets[-1] + n].view_as(p))
+            offsets.append(offsets[-1] + n)
+        self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        # buckets = contiguous parameter ranges of roughly equal size
+        self.bucket_of = [min(n_buckets - 1, offsets[i] * n_buckets // max(1, offsets[-1])) for i in range(len(sizes))]
+        self.bucket_span = [[None, None] for _ in range(n_buckets)]
+        self.bucket_left = [0] * n_buckets
+        for i, b in enumerate(self.bucket_of):
+            span = self.bucket_span[b]
+            span[0] = offsets[i] if span[0] is None else span[0]
+            span[1] = offsets[i + 1]
+            self.bucket_left[b] += 1
+        self.handles = []
+
+    def set(self, p: torch.nn.Parameter, g: torch.Tensor) -> None:
+        i = self.index[id(p)]
+        self.views[i].copy_(g.reshape(self.views[i].shape))
+        b = self.bucket_of[i]
+        self.bucket_left[b] -= 1
+        if self.world > 1 and self.bucket_left[b] == 0:
+            a, e = self.bucket_span[b]
+            self.handles.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> List[torch.Tensor]:
+        missing = [i for i, left in enumerate(self.bucket_left) if left > 0]
+        assert not missing, "backward did not produce every parameter gradient"
+        if self.world > 1:
+            for h in self.handles:
+                h.wait()
+            self.flat.div_(self.world)   # DDP semantics: average over ranks
+        return self.views
+
+
+# ------------------------------------------------------------------ forward (train mode)
+def _conv_fwd(layer: _ConvParams, x, relu, x2=None, out_nchw=False):
+    return layer.run(x, relu=relu, x2=x2, out_nchw=out_nchw)
+
+
+def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
+    tape[f"{tag}.in"] = x
+    for j, i in enumerate(m._down):
+        x = _conv_fwd(m.blocks[i], x, True)
+        tape[f"{tag}.down{j}"] = x
+    x = _conv_fwd(m.blocks[m._conv3], x, True)
+    tape[f"{tag}.c3"] = x
+    for j, i in enumerate(m._res):
+        blk: RosinalityResBlock = m.blocks[i]
+        h = blk.conv[1].run(x, relu=True)
+        y = blk.conv[3].run(h, relu=True, residual=x)
+        tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
+        x = y
+    return x
+
+
+def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_last: bool):
+    tape[f"{tag}.in"], tape[f"{tag}.in2"] = x, x2
+    x = m.blocks[0].run(x, relu=True, x2=x2)
+    tape[f"{tag}.c3"] = x
+    for j, i in enumerate(m._res):
+        blk = m.blocks[i]
+        h = blk.conv[1].run(x, relu=True)
+        y = blk.conv[3].run(h, relu=True, residual=x)
+        tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
+        x = y
+    for j, i in enumerate(m._up):
+        last = j == len(m._up) - 1
+        x = m.blocks[i].run(x, relu=not last, out_nchw=(last and out_nchw_last))
+        tape[f"{tag}.up{j}"] = x
+    return x
+
+
+def _res_stack_backward(blocks, idxs, tape, tag, d_y, x_in_key, dw, grads: Grads):
+    """d_y: dense NHWC gradient w.r.t. the (rectified) stack output; returns NHWC gradient
+    w.r.t. the stack input (the rectified conv3 output)."""
+    for j in reversed(range(len(idxs))):
+        blk = blocks[idxs[j]]
+        y, h = tape[f"{tag}.res{j}.y"], tape[f"{tag}.res{j}.h"]
+        r = tape[f"{tag}.res{j - 1}.y"] if j > 0 else tape[x_in_key]
+        g = relu_bwd_(d_y, _nhwc(y))                                   # through relu(r + conv1(h))
+        c1, c3 = blk.conv[3], blk.conv[1]
+        grads.set(c1.weight, conv_wgrad(c1, h, g))
+        grads.set(c1.bias, colsum(g.reshape(-1, g.shape[-1])))
+        dh = _nhwc(conv_dgrad(dw, c1, _as_bchw(g)))
+        relu_bwd_(dh, _nhwc(h))
+        grads.set(c3.weight, conv_wgrad(c3, r, dh))
+        grads.set(c3.bias, colsum(dh.reshape(-1, dh.shape[-1])))
+        d_y = _nhwc(conv_dgrad(dw, c3, _as_bchw(dh), residual=_as_bchw(g)))   # + skip connection
+    return d_y
+
+
+def encoder_backward(m: RosinalityEncoder, tape: Tape, tag: str, d_out, dw, grads: Grads, need_input_grad: bool):
+    """d_out: dense NHWC gradient w.r.t. the encoder output."""
+    d = _res_stack_backward(m.blocks, m._res, tape, tag, d_out, f"{tag}.c3", dw, grads)
+    c3 = m.blocks[m._conv3]
+    g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
+    prev = tape[f"{tag}.down{len(m._down) - 1}"]
+    grads.set(c3.weight, conv_wgrad(c3, prev, g))
+    grads.set(c3.bias, colsum(g.reshape(-1, g.shape[-1])))
+    d = _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
+    for j in reversed(range(len(m._down))):
+        layer = m.blocks[m._down[j]]
+        g = relu_bwd_(d, _nhwc(tape[f"{tag}.down{j}"]))
+        prev = tape[f"{tag}.down{j - 1}"] if j > 0 else tape[f"{tag}.in"]
+        grads.set(layer.weight, conv_wgrad(layer, prev, g))
+        grads.set(layer.bias, colsum(g.reshape(-1, g.shape[-1])))
+        if j > 0 or need_input_grad:
+            d = _nhwc(conv_dgrad(dw, layer, _as_bchw(g)))
+    return d if need_input_grad else None
+
+
+def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw, grads: Grads):
+    """d_out_bchw: gradient w.r.t. the decoder output as a [B,C,H,W] view (any layout).
+    Returns the dense NHWC gradient w.r.t. cat(in, in2)."""
+    d_view = d_out_bchw
+    for j in reversed(range(len(m._up))):
+        layer = m.blocks[m._up[j]]
+        last = j == len(m._up) - 1
+        g = _nhwc(d_view)
+        if not last:
+            g = relu_bwd_(g, _nhwc(tape[f"{tag}.up{j}"]))   # g is our own dgrad output here
+        prev = tape[f"{tag}.up{j - 1}"] if j > 0 else tape[f"{tag}.res{len(m._res) - 1}.y" if m._res else f"{tag}.c3"]
+        grads.set(layer.weight, conv_wgrad(layer, prev, g))
+        grads.set(layer.bias, colsum(g.reshape(-1, g.shape[-1])))
+        d_view = conv_dgrad(dw, layer, _as_bchw(g))
+    d = _res_stack_backward(m.blocks, m._res, tape, tag, _nhwc(d_view), f"{tag}.c3", dw, grads)
+    c3 = m.blocks[0]
+    g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
+    grads.set(c3.weight, conv_wgrad(c3, tape[f"{tag}.in"], g, x2=tape[f"{tag}.in2"]))
+    grads.set(c3.bias, colsum(g.reshape(-1, g.shape[-1])))
+    return _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
+
+
+# ------------------------------------------------------------------ quantiser (train mode)
+def quantize_train(q, z_nhwc: torch.Tensor):
+    """Eval-identical search with the CURRENT codebook, then the EMA update of the buffers
+    (bottleneck.py:75-92) from statistics all-reduced over the data-parallel ranks."""
+    if q.corruption_weights is not None:
+        raise NotImplementedError("index corruption (bottleneck.py:63-73) is not built")
+    codes, e2 = q.packed()
+    L = _hip.lib()
+    D, K = q.dim, q.n_embed
+    N = z_nhwc.numel() // D
+    idx = torch.empty(z_nhwc.shape[:-1], dtype=torch.int64, device=z_nhwc.device)
+    q_st = torch.empty_like(z_nhwc)
+    counts = torch.zeros(K, dtype=torch.int32, device=z_nhwc.device)
+    n_part = L.isi_vq_num_partials(N)
+    part = torch.empty(n_part, dtype=torch.float32, device=z_nhwc.device)
+    out2 = torch.empty(2, dtype=torch.float32, device=z_nhwc.device)
+    _hip.check(L.isi_vq_nearest_f32(z_nhwc.data_ptr(), codes.data_ptr(), e2.data_ptr(), idx.data_ptr(),
+                                    q_st.data_ptr(), counts.data_ptr(), part.data_ptr(), N, D, K, _s(z_nhwc)),
+               "isi_vq_nearest_f32")
+    _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D, out2.data_ptr(),
+                                     _s(z_nhwc)), "isi_vq_finalize_f32")
+    embed_sum = torch.empty(K, D, dtype=torch.float32, device=z_nhwc.device)
+    _hip.check(L.isi_vq_embed_sum_f32(z_nhwc.data_ptr(), idx.data_ptr(), embed_sum.data_ptr(), N, D, K,
+                                      _s(z_nhwc)), "isi_vq_embed_sum_f32")
+    countsf = counts.float()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        packed = torch.cat([countsf, embed_sum.reshape(-1)])
+        dist.all_reduce(packed)                     # one exchange: [K] + [K*D] statistics
+        countsf, embed_sum = packed[:K], packed[K:].reshape(K, D)
+    _hip.check(L.isi_vq_ema_update_f32(q.embed.data_ptr(), q.cluster_size.data_ptr(), q.embed_avg.data_ptr(),
+                                       countsf.data_ptr(), embed_sum.contiguous().data_ptr(), D, K, q.decay,
+                                       q.eps, _s(z_nhwc)), "isi_vq_ema_update_f32")
+    # the buffers were written through raw pointers (no torch version bump): invalidate caches
+    q._packed_key = None
+    q._ema_steps = getattr(q, "_ema_steps", 0) + 1
+    return q_st, out2[0], idx, out2[1]
+
+
+def vq_backward(dq_nhwc, z_nhwc, q_st_nhwc, g_diff):
+    dz = torch.empty_like(z_nhwc)
+    _hip.check(_hip.lib().isi_vq_bwd_f32(dz.data_ptr(), dq_nhwc.data_ptr(), z_nhwc.data_ptr(),
+                                         q_st_nhwc.data_ptr(), g_diff.data_ptr(), z_nhwc.numel(), _s(z_nhwc)),
+               "isi_vq_bwd_f32")
+    return dz
+
+
+# ------------------------------------------------------------------ whole model
+class VQVAETrainFunction(torch.autograd.Function):
+    """forward(x, *params) -> (dec, diff); backward -> parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        tape = Tape()
+        D = model.embed_dim
+        x = x.contiguous()
+        enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
+        enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
+        z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False))
+        q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t)
+        tape["z_t"], tape["q_t"] = z_t, q_t
+        dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
+        if dec_t.shape[-1] != enc_b.shape[-1]:
+            raise NotImplementedError("training needs input sizes divisible by the total down-sampling factor")
+        z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b))
+        q_b, diff_b, id_b, perp_b = quantize_train(model.quantize_b, z_b)
+        tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
+        up = _as_bchw(q_t)
+        for j, layer in enumerate(model.upsample_top_to_bottom):
+            tape[f"up.in{j}"] = up
+            up = layer.run(up, relu=False)
+        dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True)
+        diff = (diff_t + diff_b).reshape(1)
+        ctx.model, ctx.tape = model, tape
+        ctx.mark_non_differentiable(id_t, id_b, perp_t, perp_b)
+        return dec, diff, perp_t, perp_b, id_t, id_b
+
+    @staticmethod
+    @torch.no_grad()
+    def backward(ctx, g_dec, g_diff, *_unused):
+        model, tape = ctx.model, ctx.tape
+        dev = tape["z_t"].device
+        if g_dec is None:
+            g_dec = torch.zeros_like(tape[f"dec.up{len(model.dec._up) - 1}"])
+        if g_diff is None:
+            g_diff = torch.zeros(1, device=dev)
+        g_diff = g_diff.reshape(1).contiguous().float()
+        dw = model._dgrad_weights
+        grads = Grads(model)
+        D = model.embed_dim
+        # decoder (bottom): d cat(up, q_b)
+        d_cat = decoder_backward(model.dec, tape, "dec", g_dec, dw, grads)
+        d_up = _as_bchw(d_cat)[:, :D]
+        d_qb = _nhwc(_as_bchw(d_cat)[:, D:])
+        # upsample_top_to_bottom: plain transposed convs
+        d_view = d_up
+        for j in reversed(range(len(model.upsample_top_to_bottom))):
+            layer = model.upsample_top_to_bottom[j]
+            g = _nhwc(d_view)
+            grads.set(layer.weight, conv_wgrad(layer, tape[f"up.in{j}"], g))
+            grads.set(layer.bias, colsum(g.reshape(-1, g.shape[-1])))
+            d_view = conv_dgrad(dw, layer, _as_bchw(g))
+        d_qt = _nhwc(d_view).clone()
+        # bottom quantiser and its 1x1 conv on cat(dec_t, enc_b)
+        d_zb = vq_backward(d_qb, tape["z_b"], tape["q_b"], g_diff)
+        qcb = model.quantize_conv_b
+        grads.set(qcb.weight, conv_wgrad(qcb, tape["dec_t"], d_zb, x2=tape["enc_b"]))
+        grads.set(qcb.bias, colsum(d_zb.reshape(-1, D)))
+        d_cat2 = conv_dgrad(dw, qcb, _as_bchw(d_zb))
+        Cd = tape["dec_t"].shape[1]
+        d_dect, d_encb = d_cat2[:, :Cd], _nhwc(d_cat2[:, Cd:]).clone()
+        # dec_t
+        d_qt2 = decoder_backward(model.dec_t, tape, "dec_t", d_dect, dw, grads)
+        axpy_(d_qt, d_qt2)
+        # top quantiser and its 1x1 conv
+        d_zt = vq_backward(d_qt, tape["z_t"], tape["q_t"], g_diff)
+        qct = model.quantize_conv_t
+        grads.set(qct.weight, conv_wgrad(qct, tape["enc_t"], d_zt))
+        grads.set(qct.bias, colsum(d_zt.reshape(-1, D)))
+        d_enct = _nhwc(conv_dgrad(dw, qct, _as_bchw(d_zt)))
+        d_encb2 = encoder_backward(model.enc_t, tape, "enc_t", d_enct, dw, grads, need_input_grad=True)
+        axpy_(d_encb, d_encb2)
+        encoder_backward(model.enc_b, tape, "enc_b", d_encb, dw, grads, need_input_grad=False)
+        views = grads.finish()
+        ctx.tape = None
+        return (None, None) + tuple(views)

@@ -136,6 +136,7 @@ class VQVAE(nn.Module):
         key = []
         for t in list(self.parameters()) + [self.quantize_t.embed, self.quantize_b.embed]:
             key.append((t._version, t.data_ptr()))
+        key.append((getattr(self.quantize_t, "_ema_steps", 0), getattr(self.quantize_b, "_ema_steps", 0)))
         return tuple(key)
 
     def _native_weights(self) -> _hip.isi_vqvae_w:
@@ -259,8 +260,22 @@ class VQVAE(nn.Module):
                 scalars[1], scalars[3])
 
     def forward(self, input: Tensor):
+        if self.training:
+            return self._forward_train(input)
         dec, _, _, diff, id_t, id_b, perp_t, perp_b = self._encode_impl(input, with_decode=True)
         return dec, diff, perp_t, perp_b, id_t, id_b
+
+    def _forward_train(self, input: Tensor):
+        """Train-mode forward (EMA codebook update in-forward, bottleneck.py:79-92) whose
+        `dec` / `diff` outputs are differentiable w.r.t. every parameter through a
+        hand-written backward (`vqvae/_train.py`)."""
+        from ._train import VQVAETrainFunction, _DgradWeights
+        _hip.require_gpu(input, "input")
+        if self.disable_quantization:
+            raise NotImplementedError("disable_quantization=True has no training path")
+        if not hasattr(self, "_dgrad_weights"):
+            self._dgrad_weights = _DgradWeights()
+        return VQVAETrainFunction.apply(self, input, *self.parameters())
 
     def encode(self, input: Tensor):
         _, q_t, q_b, diff, id_t, id_b, perp_t, perp_b = self._encode_impl(input, with_decode=False)

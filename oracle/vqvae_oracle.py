@@ -162,6 +162,46 @@ def ema_update(flat: Tensor, ind: Tensor, embed: Tensor, cluster_size: Tensor,
     return ea / cs_norm.unsqueeze(0), cs, ea
 
 
+def quantize_train(z: Tensor, embed: Tensor, cluster_size: Tensor, embed_avg: Tensor, decay: float = 0.99,
+                   eps: float = 1e-5):
+    """QuantizedBottleneck.forward in train mode with autograd semantics
+    (bottleneck.py:53-101, corruption disabled): search with the current codebook,
+    EMA update of the buffers, commitment `diff`, straight-through output.
+    Returns (q_st, diff, ind, perplexity, (embed', cluster_size', embed_avg'))."""
+    dim, n_embed = embed.shape
+    with torch.no_grad():
+        flat = z.detach().reshape(-1, dim)
+        dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ embed + embed.pow(2).sum(0, keepdim=True)
+        _, ind = (-dist).max(1)
+        new = ema_update(flat, ind, embed, cluster_size, embed_avg, decay, eps)
+        onehot_mean = torch.bincount(ind, minlength=n_embed).to(flat.dtype) / flat.shape[0]
+        perplexity = torch.exp(-torch.sum(onehot_mean * torch.log(onehot_mean.clamp(min=1e-7))))
+    ind = ind.view(*z.shape[:-1])
+    q = F.embedding(ind, embed.t())
+    diff = (q.detach() - z).pow(2).mean()
+    q_st = z + (q - z).detach()
+    return q_st, diff, ind, perplexity, new
+
+
+def forward_train(x: Tensor, sd: StateDict, cfg: "Config"):
+    """Train-mode VQVAE.forward: (dec, diff, id_t, id_b, new_buffers) with autograd through sd."""
+    fb, ft = cfg.resolution_factors["bottom"], cfg.resolution_factors["top"]
+    enc_b = encoder(x, sd, "enc_b.", fb, cfg.n_res_block)
+    enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
+    z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    q_t, diff_t, id_t, _, new_t = quantize_train(z_t, sd["quantize_t.embed"], sd["quantize_t.cluster_size"],
+                                                 sd["quantize_t.embed_avg"])
+    q_t = q_t.permute(0, 3, 1, 2)
+    dec_t = decoder(q_t, sd, "dec_t.", ft, cfg.n_res_block)
+    z_b = F.conv2d(torch.cat([dec_t, enc_b], 1), sd["quantize_conv_b.weight"],
+                   sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+    q_b, diff_b, id_b, _, new_b = quantize_train(z_b, sd["quantize_b.embed"], sd["quantize_b.cluster_size"],
+                                                 sd["quantize_b.embed_avg"])
+    q_b = q_b.permute(0, 3, 1, 2)
+    dec = decode(q_t, q_b, sd, cfg)
+    return dec, diff_t.unsqueeze(0) + diff_b.unsqueeze(0), id_t, id_b, (new_t, new_b)
+
+
 def embed_code(ind: Tensor, embed: Tensor) -> Tensor:
     """QuantizedBottleneck.embed_code (bottleneck.py:103-104)."""
     return F.embedding(ind, embed.t())

@@ -146,11 +146,13 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3,
  * was cat(src0, src1) [B,*,H,W] and whose output gradient is dy, dense channels-last
  * [B, OH, OW, Cout] (transposed: [B, 2H, 2W, Cout]).  Deterministic split reduction;
  * workspace of isi_conv_wgrad_workspace_floats(Cout, K, M, nphase) floats with
- * K = KH*KW*Cin (transposed: 4*Cin), M = B*OH*OW (transposed: B*H*W), nphase = 1 (4). */
+ * K = KH*KW*Cin (transposed: 4*Cin), M = B*OH*OW (transposed: B*H*W), nphase = 1 (4).
+ * db [Cout] (optional) receives the bias gradient = column sums of dy, computed on the
+ * staged dY tiles at no extra pass. */
 size_t isi_conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
 int isi_conv_wgrad_f32(const isi_src *src0, const isi_src *src1, const float *dy,
-                       float *dw_packed, float *workspace, size_t workspace_floats, int B,
-                       int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                       float *dw_packed, float *db, float *workspace, size_t workspace_floats,
+                       int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                        int transposed, void *stream);
 /* dy *= (y > 0) : ReLU backward through an output rectified in the producer's epilogue. */
 int isi_relu_bwd_f32(float *dy, const float *y, int64_t n, void *stream);
@@ -163,13 +165,17 @@ int isi_vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st
 int isi_colsum_num_partials(int64_t M);
 int isi_colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M,
                    int C, void *stream);
-/* embed_sum_kd[k,:] = sum of z_n with idx[n] == k  (the `flatten^T @ onehot` of bottleneck.py:83). */
-int isi_vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_kd, int64_t N,
-                         int D, int K, void *stream);
+/* embed_sum_dk [D,K] = z^T @ onehot(idx) (bottleneck.py:83): the pixel-reduction GEMM of
+ * isi_conv_wgrad_f32 with the one-hot operand generated on the fly (never materialised);
+ * deterministic.  workspace: isi_vq_embed_sum_workspace_floats(D, K, N) floats. */
+size_t isi_vq_embed_sum_workspace_floats(int D, int K, int64_t N);
+int isi_vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk,
+                         float *workspace, size_t workspace_floats, int64_t N, int D, int K,
+                         void *stream);
 /* EMA codebook update (bottleneck.py:80-92) on the [D,K] buffers from batch statistics
- * counts [K] (float) and embed_sum_kd [K,D] (all-reduced across ranks by the caller). */
+ * counts [K] (float) and embed_sum_dk [D,K] (all-reduced across ranks by the caller). */
 int isi_vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg,
-                          const float *counts, const float *embed_sum_kd, int D, int K,
+                          const float *counts, const float *embed_sum_dk, int D, int K,
                           float decay, float eps, void *stream);
 
 /* ------------------------------------------------------ transformer prior */

@@ -26,7 +26,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct WgradKArgs {
   const float *x0, *x1, *dy;
+  const int64_t *onehot_idx;   // when set, A[m][k] = (onehot_idx[m] == k): the one-hot matrix of bottleneck.py:75
   float *partial;
+  float *db_partial;           // optional [splits][Cout] column sums of dY (bias gradient)
   unsigned x0_bytes, x1_bytes, dy_bytes;
   int C0, Cin, vec, dvec;      // vec: sources are channels-last with 16-B aligned quads; dvec: Cout % 4 == 0
   int s0n, s0c, s0h, s0w, s1n, s1h, s1w;
@@ -90,7 +92,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
         const int rem = m - b * (p.OH * p.OW);
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
         if (covalid) doff = (unsigned)(dy_off + b * p.dn + oy * p.dh + ox * p.dw + co) * 4u;
-        if (p.vec) {
+        if (p.onehot_idx) {
+          const int id = (int)p.onehot_idx[m];
+          xs = make_float4(id == kk ? 1.f : 0.f, id == kk + 1 ? 1.f : 0.f, id == kk + 2 ? 1.f : 0.f,
+                           id == kk + 3 ? 1.f : 0.f);
+        } else if (p.vec) {
           const int iy = oy * p.stride - pad_y + kh, ix = ox * p.stride - pad_x + kw;
           if (kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
             xoff = second ? (unsigned)(b * p.s1n + iy * p.s1h + ix * p.s1w + cc) * 4u
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
         }
         rdq[j] = make_float4(t[0], t[1], t[2], t[3]);
       }
-      rxq[j] = p.vec ? (second ? buf_load4(r1, xoff) : buf_load4(r0, xoff)) : xs;
+      rxq[j] = (p.vec && !p.onehot_idx) ? (second ? buf_load4(r1, xoff) : buf_load4(r0, xoff)) : xs;
     }
   };
   auto store_chunk = [&](int buf) {
@@ -147,6 +153,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int fl = lane & 31, half = lane >> 5;
+  float bsum = 0.f;  // column sum of dY for co0 + tid (threads < 128 of the k-tile-0 workgroups)
+  const bool do_bias = p.db_partial != nullptr && blockIdx.y == 0 && tid < 128;
   if (chunk_begin < chunk_end) {
     load_chunk(chunk_begin);
     store_chunk(0);
@@ -166,9 +174,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
     }
+    if (do_bias) {
+      const float *dcol = Ds + buf * 32 * LDT + tid;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) bsum += dcol[r * LDT];
+    }
     if (ch + 1 < chunk_end) store_chunk(buf ^ 1);
     __syncthreads();
   }
+  if (do_bias && co0 + tid < p.Cout) p.db_partial[(size_t)blockIdx.z * p.Cout + co0 + tid] = bsum;
 
   // ---- partial tile: rows = co, cols = k
   float *out = p.partial + (size_t)blockIdx.z * p.Cout * p.Kpad;
@@ -206,14 +220,14 @@ size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
   const int nchunks = (M + 31) / 32;
   int nsplit = std::max(1, 768 / tiles);
   nsplit = std::min(nsplit, std::max(1, nchunks / 8));
-  return (size_t)nsplit * nphase * Cout * Kpad;
+  return (size_t)nsplit * nphase * Cout * Kpad + (size_t)nsplit * nphase * Cout;
 }
 
 // dW packed like the forward weights: [nphase][Cout][Kpad].  x = layer input (two sources allowed), dy = gradient
 // of the layer output, dense channels-last [B, OH(, *2), OW(, *2), Cout].
-int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *workspace,
-                   size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
-                   int transposed, hipStream_t stream) {
+int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
+                   float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
+                   int stride, int pad, int transposed, hipStream_t stream) {
   if (!s0 || !s0->ptr || !dy || !dw_packed || !workspace) return invalid("conv_wgrad: null pointer");
   const bool two = s1 && s1->ptr;
   const int Cin = s0->C + (two ? s1->C : 0);
@@ -261,8 +275,9 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
   int nsplit = std::max(1, 768 / tiles);
   nsplit = std::min(nsplit, std::max(1, nchunks / 8));
   a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
-  const size_t need = (size_t)nsplit * nphase * Cout * a.Kpad;
+  const size_t need = (size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout;
   if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
+  a.db_partial = db ? workspace + (size_t)nsplit * nphase * Cout * a.Kpad : nullptr;
   constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
@@ -281,7 +296,49 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream,
                        workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0);
   }
-  return check_launch("reduce_partials");
+  rc = check_launch("reduce_partials");
+  if (rc || !db) return rc;
+  // bias gradient: every (phase, split) partial covers a disjoint pixel set
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, a.db_partial, db,
+                     (int64_t)Cout, nsplit * nphase, (int64_t)Cout, 0);
+  return check_launch("reduce_partials(bias)");
+}
+
+// embed_sum[d][k] = sum over vectors n with idx[n] == k of z[n][d]  ==  z^T @ onehot(idx)
+// (bottleneck.py:83), as the same pixel-reduction GEMM with the one-hot operand generated on the fly.
+// out: [D][K] like the reference's `embed_avg`; deterministic.
+size_t vq_embed_sum_workspace_floats(int D, int K, int64_t N) { return conv_wgrad_workspace_floats(D, K, (int)N, 1); }
+
+int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, float *workspace,
+                     size_t workspace_floats, int64_t N, int D, int K, hipStream_t stream) {
+  if (!z || !idx || !embed_sum_dk || !workspace || N <= 0 || N > INT32_MAX || D <= 0 || (D & 3) || K <= 0 || (K % 32))
+    return invalid("vq_embed_sum: bad argument (D % 4 == 0, K % 32 == 0)");
+  if ((int64_t)N * D > ((int64_t)1 << 30)) return unsupported("vq_embed_sum: tensor spans 4 GiB or more");
+  WgradKArgs a;
+  memset(&a, 0, sizeof a);
+  a.x0 = z; a.x1 = z; a.dy = z; a.onehot_idx = idx; a.partial = workspace;
+  a.x0_bytes = a.x1_bytes = a.dy_bytes = (unsigned)((size_t)N * D * 4);
+  a.C0 = K; a.Cin = K; a.vec = 1; a.dvec = 1;
+  a.dn = 0; a.dh = 0; a.dw = D;           // "pixels" = vectors: one row of N
+  a.H = 1; a.W = (int)N; a.OH = 1; a.OW = (int)N; a.Cout = D; a.K = K; a.Kpad = K;
+  a.KW = 1; a.stride = 1; a.pad = 0; a.M = (int)N;
+  const int tiles = ((D + 127) / 128) * ((K + 127) / 128);
+  const int nchunks = (a.M + 31) / 32;
+  int nsplit = std::max(1, 768 / tiles);
+  nsplit = std::min(nsplit, std::max(1, nchunks / 8));
+  a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
+  if (workspace_floats < (size_t)nsplit * D * K) { set_last_error("vq_embed_sum: workspace too small"); return ISI_E_WORKSPACE; }
+  constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_f32_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return check_launch("hipFuncSetAttribute(conv_wgrad)");
+  hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3((D + 127) / 128, (K + 127) / 128, nsplit), dim3(256), smem, stream, a);
+  int rc = check_launch("vq_embed_sum(wgrad)");
+  if (rc) return rc;
+  const int64_t per = (int64_t)D * K;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream, workspace,
+                     embed_sum_dk, per, nsplit, per, 0);
+  return check_launch("vq_embed_sum(reduce)");
 }
 
 }  // namespace isi

@@ -112,11 +112,11 @@ int isi_prior_sample_run(const isi_prior_w *w, const isi_prior_state *state, int
 size_t isi_conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
   return conv_wgrad_workspace_floats(Cout, K, M, nphase);
 }
-int isi_conv_wgrad_f32(const isi_src *src0, const isi_src *src1, const float *dy, float *dw_packed,
+int isi_conv_wgrad_f32(const isi_src *src0, const isi_src *src1, const float *dy, float *dw_packed, float *db,
                        float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                        int stride, int pad, int transposed, void *stream) {
-  return conv_wgrad_f32(src0, src1, dy, dw_packed, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride, pad,
-                        transposed, S(stream));
+  return conv_wgrad_f32(src0, src1, dy, dw_packed, db, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride,
+                        pad, transposed, S(stream));
 }
 int isi_relu_bwd_f32(float *dy, const float *y, int64_t n, void *stream) { return relu_bwd_f32(dy, y, n, S(stream)); }
 int isi_axpy_f32(float *a, const float *b, float alpha, int64_t n, void *stream) {
@@ -130,13 +130,14 @@ int isi_colsum_num_partials(int64_t M) { return colsum_num_partials(M); }
 int isi_colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, void *stream) {
   return colsum_f32(x, x_stride, out, workspace, M, C, S(stream));
 }
-int isi_vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_kd, int64_t N, int D, int K,
-                         void *stream) {
-  return vq_embed_sum_f32(z, idx, embed_sum_kd, N, D, K, S(stream));
+size_t isi_vq_embed_sum_workspace_floats(int D, int K, int64_t N) { return vq_embed_sum_workspace_floats(D, K, N); }
+int isi_vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, float *workspace,
+                         size_t workspace_floats, int64_t N, int D, int K, void *stream) {
+  return vq_embed_sum_f32(z, idx, embed_sum_dk, workspace, workspace_floats, N, D, K, S(stream));
 }
 int isi_vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg, const float *counts,
-                          const float *embed_sum_kd, int D, int K, float decay, float eps, void *stream) {
-  return vq_ema_update_f32(embed, cluster_size, embed_avg, counts, embed_sum_kd, D, K, decay, eps, S(stream));
+                          const float *embed_sum_dk, int D, int K, float decay, float eps, void *stream) {
+  return vq_ema_update_f32(embed, cluster_size, embed_avg, counts, embed_sum_dk, D, K, decay, eps, S(stream));
 }
 
 int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,

@@ -39,19 +39,20 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
                      int top_k, float top_p, hipStream_t stream);
 
 size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
-int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *workspace,
-                   size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
-                   int transposed, hipStream_t stream);
+int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
+                   float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
+                   int stride, int pad, int transposed, hipStream_t stream);
+size_t vq_embed_sum_workspace_floats(int D, int K, int64_t N);
 int relu_bwd_f32(float *dy, const float *y, int64_t n, hipStream_t st);
 int axpy_f32(float *a, const float *b, float alpha, int64_t n, hipStream_t st);
 int vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st, const float *g_diff, int64_t n,
                hipStream_t st);
 int colsum_num_partials(int64_t M);
 int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, hipStream_t st);
-int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_kd, int64_t N, int D, int K,
-                     hipStream_t st);
+int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, float *workspace,
+                     size_t workspace_floats, int64_t N, int D, int K, hipStream_t stream);
 int vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg, const float *counts,
-                      const float *embed_sum_kd, int D, int K, float decay, float eps, hipStream_t st);
+                      const float *embed_sum_dk, int D, int K, float decay, float eps, hipStream_t st);
 
 int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                    int32_t *counts, float *sse_part, int64_t N, int D, int K, hipStream_t stream);

@@ -63,28 +63,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
   }
 }
 
-// Codebook statistics of one batch: embed_sum[k][:] += z_n for idx[n] == k (per-block partial
-// tables would be K*D each; atomics into a zeroed [K][D] table are used instead --
-// cluster sizes come from the integer histogram of the forward).
-__global__ void vq_embed_sum_kernel(const float *__restrict__ z, const int64_t *__restrict__ idx,
-                                    float *__restrict__ embed_sum_kd, int64_t N, int D) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int D4 = D >> 2;
-  if (i >= N * D4) return;
-  const int64_t n = i / D4;
-  const int qd = (int)(i - n * D4);
-  const float4 v = reinterpret_cast<const float4 *>(z)[i];
-  float *dst = embed_sum_kd + (size_t)idx[n] * D + qd * 4;
-  atomicAdd(dst, v.x); atomicAdd(dst + 1, v.y); atomicAdd(dst + 2, v.z); atomicAdd(dst + 3, v.w);
-}
-
 // EMA update of the codebook buffers (bottleneck.py:79-92), layout [D][K] like the reference:
 //   cluster_size = g cs + (1-g) counts ; embed_avg = g ea + (1-g) embed_sum^T
 //   n = sum(cluster_size) ; cs' = (cs + eps) / (n + K eps) n ; embed = embed_avg / cs'
 __global__ __launch_bounds__(1024) void vq_ema_update_kernel(float *__restrict__ embed, float *__restrict__ cluster_size,
                                                              float *__restrict__ embed_avg,
                                                              const float *__restrict__ counts,
-                                                             const float *__restrict__ embed_sum_kd, int D, int K,
+                                                             const float *__restrict__ embed_sum_dk, int D, int K,
                                                              float decay, float eps) {
   __shared__ float red[1024];
   const int tid = threadIdx.x;
@@ -102,8 +87,8 @@ __global__ __launch_bounds__(1024) void vq_ema_update_kernel(float *__restrict__
   }
   const float n = red[0];
   for (int i = tid; i < D * K; i += blockDim.x) {
-    const int d = i / K, k = i - d * K;
-    const float ea = embed_avg[i] * decay + (1.f - decay) * embed_sum_kd[(size_t)k * D + d];
+    const int k = i % K;
+    const float ea = embed_avg[i] * decay + (1.f - decay) * embed_sum_dk[i];
     embed_avg[i] = ea;
     const float csn = (cluster_size[k] + eps) / (n + K * eps) * n;
     embed[i] = ea / csn;
@@ -158,23 +143,12 @@ int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, i
   return check_launch("colsum_reduce");
 }
 
-int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_kd, int64_t N, int D, int K,
-                     hipStream_t st) {
-  if (!z || !idx || !embed_sum_kd || N <= 0 || D <= 0 || (D & 3) || K <= 0) return invalid("vq_embed_sum: bad argument");
-  if (hipMemsetAsync(embed_sum_kd, 0, (size_t)K * D * sizeof(float), st) != hipSuccess)
-    return check_launch("hipMemsetAsync(embed_sum)");
-  const int64_t total = N * (D / 4);
-  hipLaunchKernelGGL(vq_embed_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, idx,
-                     embed_sum_kd, N, D);
-  return check_launch("vq_embed_sum_f32");
-}
-
 int vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg, const float *counts,
-                      const float *embed_sum_kd, int D, int K, float decay, float eps, hipStream_t st) {
-  if (!embed || !cluster_size || !embed_avg || !counts || !embed_sum_kd || D <= 0 || K <= 0)
+                      const float *embed_sum_dk, int D, int K, float decay, float eps, hipStream_t st) {
+  if (!embed || !cluster_size || !embed_avg || !counts || !embed_sum_dk || D <= 0 || K <= 0)
     return invalid("vq_ema_update: bad argument");
   hipLaunchKernelGGL(vq_ema_update_kernel, dim3(1), dim3(1024), 0, st, embed, cluster_size, embed_avg, counts,
-                     embed_sum_kd, D, K, decay, eps);
+                     embed_sum_dk, D, K, decay, eps);
   return check_launch("vq_ema_update_f32");
 }
 

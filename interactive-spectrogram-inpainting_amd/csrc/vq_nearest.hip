@@ -36,6 +36,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
   float *cb = smem;            // [K][LDD]
   float *e2 = smem + (size_t)K * LDD;  // [K]
   float *red = e2 + K;         // [4] per-wave sse
+  int *hist = reinterpret_cast<int *>(red + 4);  // [K] workgroup histogram (flushed once at the end)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
     *reinterpret_cast<float4 *>(cb + (size_t)k * LDD + qd * 4) =
         *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4);
   }
-  for (int i = tid; i < K; i += VQ_BLOCK) e2[i] = e2g[i];
+  for (int i = tid; i < K; i += VQ_BLOCK) { e2[i] = e2g[i]; hist[i] = 0; }
   __syncthreads();
 
   float sse = 0.f;
@@ -111,10 +112,14 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
       }
       if (half == 0) {
         idx_out[n] = besti;
-        atomicAdd(&counts[besti], 1);
+        atomicAdd(&hist[besti], 1);
       }
     }
   }
+
+  __syncthreads();
+  for (int i = tid; i < K; i += VQ_BLOCK)
+    if (hist[i]) atomicAdd(&counts[i], hist[i]);
 
   // ---- deterministic per-workgroup partial of the squared error
 #pragma unroll
@@ -177,7 +182,7 @@ int vq_num_partials(int64_t N) { return vq_grid(N); }
 template <int D>
 static int launch_vq(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                      int32_t *counts, float *sse_part, int64_t N, int K, hipStream_t stream) {
-  const size_t smem = ((size_t)K * (D + 4) + K + 4) * sizeof(float);
+  const size_t smem = ((size_t)K * (D + 4) + 2 * K + 4) * sizeof(float);
   if (smem > 150 * 1024) return unsupported("vq: codebook does not fit in LDS");
   auto kern = vq_nearest_kernel<D>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

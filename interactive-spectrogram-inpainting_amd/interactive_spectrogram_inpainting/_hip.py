@@ -146,14 +146,15 @@ SIGNATURES = {
     "isi_prior_sample_run": (C.c_int, [C.POINTER(isi_prior_w), C.POINTER(isi_prior_state), C.c_int, C.c_int,
                                        C.c_float, C.c_int, C.c_float, _P]),
     "isi_conv_wgrad_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "isi_conv_wgrad_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, _P, C.c_size_t, C.c_int,
+    "isi_conv_wgrad_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, _P, _P, C.c_size_t, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_relu_bwd_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "isi_axpy_f32": (C.c_int, [_P, _P, C.c_float, C.c_int64, _P]),
     "isi_vq_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
     "isi_colsum_num_partials": (C.c_int, [C.c_int64]),
     "isi_colsum_f32": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int, _P]),
-    "isi_vq_embed_sum_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "isi_vq_embed_sum_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),
+    "isi_vq_embed_sum_f32": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_int64, C.c_int, C.c_int, _P]),
     "isi_vq_ema_update_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     "isi_vq_nearest_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "isi_vq_num_partials": (C.c_int, [C.c_int64]),

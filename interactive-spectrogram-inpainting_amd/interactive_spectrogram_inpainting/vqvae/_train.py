@@ -70,9 +70,9 @@ def colsum(x2d: torch.Tensor) -> torch.Tensor:
 
 
 def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
-               x2: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Gradient of layer.weight in torch layout.  x (and x2): layer input(s) as [B,C,H,W] views;
-    dy_nhwc: dense [B,OH,OW,Cout]."""
+               x2: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(weight gradient in torch layout, bias gradient).  x (and x2): layer input(s) as
+    [B,C,H,W] views; dy_nhwc: dense [B,OH,OW,Cout]."""
     L = _hip.lib()
     B, _, H, W = x.shape
     cin = layer.in_channels
@@ -91,15 +91,16 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
     nws = L.isi_conv_wgrad_workspace_floats(cout, K, M, nph)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     packed = torch.empty(nph, cout, Kpad, dtype=torch.float32, device=x.device)
+    db = torch.empty(cout, dtype=torch.float32, device=x.device)
     s0 = _hip.src_nchw_view(x)
     s1 = _hip.src_nchw_view(x2) if x2 is not None else None
     rc = L.isi_conv_wgrad_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, dy_nhwc.data_ptr(),
-                              packed.data_ptr(), ws.data_ptr(), nws, B, H, W, cout, k, k, layer.stride,
+                              packed.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, cout, k, k, layer.stride,
                               layer.padding, int(tr), _s(x))
     _hip.check(rc, "isi_conv_wgrad_f32")
     if not tr:
         # [Cout][kh][kw][Cin] -> [Cout, Cin, kh, kw]
-        return packed[0, :, :K].reshape(cout, k, k, cin).permute(0, 3, 1, 2)
+        return packed[0, :, :K].reshape(cout, k, k, cin).permute(0, 3, 1, 2), db
     # phases [py,px][Cout][ty,tx][Cin] -> torch ConvTranspose2d layout [Cin, Cout, 4, 4], tap (3-py-2ty, 3-px-2tx)
     g = packed[:, :, :K].reshape(2, 2, cout, 2, 2, cin)             # py px co ty tx ci
     out = torch.empty(cin, cout, 4, 4, dtype=torch.float32, device=x.device)
@@ -108,7 +109,7 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
             for ty in range(2):
                 for tx in range(2):
                     out[:, :, 3 - py - 2 * ty, 3 - px - 2 * tx] = g[py, px, :, ty, tx, :].t()
-    return out
+    return out, db
 
 
 class _DgradWeights:
@@ -148,6 +149,11 @@ def conv_dgrad(dw: _DgradWeights, layer: _ConvParams, dy: torch.Tensor,
         return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False)
     k = layer.kernel_size
     return _ops.conv2d(dy, packed, None, cin, k, 1, k - 1 - layer.padding, relu=False, residual_bchw=residual)
+
+
+def _set_wb(grads, layer: _ConvParams, wb) -> None:
+    grads.set(layer.weight, wb[0])
+    grads.set(layer.bias, wb[1])
 
 
 class Tape:
@@ -258,12 +264,10 @@ def _res_stack_backward(blocks, idxs, tape, tag, d_y, x_in_key, dw, grads: Grads
         r = tape[f"{tag}.res{j - 1}.y"] if j > 0 else tape[x_in_key]
         g = relu_bwd_(d_y, _nhwc(y))                                   # through relu(r + conv1(h))
         c1, c3 = blk.conv[3], blk.conv[1]
-        grads.set(c1.weight, conv_wgrad(c1, h, g))
-        grads.set(c1.bias, colsum(g.reshape(-1, g.shape[-1])))
+        _set_wb(grads, c1, conv_wgrad(c1, h, g))
         dh = _nhwc(conv_dgrad(dw, c1, _as_bchw(g)))
         relu_bwd_(dh, _nhwc(h))
-        grads.set(c3.weight, conv_wgrad(c3, r, dh))
-        grads.set(c3.bias, colsum(dh.reshape(-1, dh.shape[-1])))
+        _set_wb(grads, c3, conv_wgrad(c3, r, dh))
         d_y = _nhwc(conv_dgrad(dw, c3, _as_bchw(dh), residual=_as_bchw(g)))   # + skip connection
     return d_y
 
@@ -274,15 +278,13 @@ def encoder_backward(m: RosinalityEncoder, tape: Tape, tag: str, d_out, dw, grad
     c3 = m.blocks[m._conv3]
     g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
     prev = tape[f"{tag}.down{len(m._down) - 1}"]
-    grads.set(c3.weight, conv_wgrad(c3, prev, g))
-    grads.set(c3.bias, colsum(g.reshape(-1, g.shape[-1])))
+    _set_wb(grads, c3, conv_wgrad(c3, prev, g))
     d = _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
     for j in reversed(range(len(m._down))):
         layer = m.blocks[m._down[j]]
         g = relu_bwd_(d, _nhwc(tape[f"{tag}.down{j}"]))
         prev = tape[f"{tag}.down{j - 1}"] if j > 0 else tape[f"{tag}.in"]
-        grads.set(layer.weight, conv_wgrad(layer, prev, g))
-        grads.set(layer.bias, colsum(g.reshape(-1, g.shape[-1])))
+        _set_wb(grads, layer, conv_wgrad(layer, prev, g))
         if j > 0 or need_input_grad:
             d = _nhwc(conv_dgrad(dw, layer, _as_bchw(g)))
     return d if need_input_grad else None
@@ -299,14 +301,12 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
         if not last:
             g = relu_bwd_(g, _nhwc(tape[f"{tag}.up{j}"]))   # g is our own dgrad output here
         prev = tape[f"{tag}.up{j - 1}"] if j > 0 else tape[f"{tag}.res{len(m._res) - 1}.y" if m._res else f"{tag}.c3"]
-        grads.set(layer.weight, conv_wgrad(layer, prev, g))
-        grads.set(layer.bias, colsum(g.reshape(-1, g.shape[-1])))
+        _set_wb(grads, layer, conv_wgrad(layer, prev, g))
         d_view = conv_dgrad(dw, layer, _as_bchw(g))
     d = _res_stack_backward(m.blocks, m._res, tape, tag, _nhwc(d_view), f"{tag}.c3", dw, grads)
     c3 = m.blocks[0]
     g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
-    grads.set(c3.weight, conv_wgrad(c3, tape[f"{tag}.in"], g, x2=tape[f"{tag}.in2"]))
-    grads.set(c3.bias, colsum(g.reshape(-1, g.shape[-1])))
+    _set_wb(grads, c3, conv_wgrad(c3, tape[f"{tag}.in"], g, x2=tape[f"{tag}.in2"]))
     return _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
 
 
@@ -331,14 +331,16 @@ def quantize_train(q, z_nhwc: torch.Tensor):
                "isi_vq_nearest_f32")
     _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D, out2.data_ptr(),
                                      _s(z_nhwc)), "isi_vq_finalize_f32")
-    embed_sum = torch.empty(K, D, dtype=torch.float32, device=z_nhwc.device)
-    _hip.check(L.isi_vq_embed_sum_f32(z_nhwc.data_ptr(), idx.data_ptr(), embed_sum.data_ptr(), N, D, K,
-                                      _s(z_nhwc)), "isi_vq_embed_sum_f32")
+    embed_sum = torch.empty(D, K, dtype=torch.float32, device=z_nhwc.device)
+    nws = L.isi_vq_embed_sum_workspace_floats(D, K, N)
+    ws = torch.empty(nws, dtype=torch.float32, device=z_nhwc.device)
+    _hip.check(L.isi_vq_embed_sum_f32(z_nhwc.data_ptr(), idx.data_ptr(), embed_sum.data_ptr(), ws.data_ptr(), nws,
+                                      N, D, K, _s(z_nhwc)), "isi_vq_embed_sum_f32")
     countsf = counts.float()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         packed = torch.cat([countsf, embed_sum.reshape(-1)])
         dist.all_reduce(packed)                     # one exchange: [K] + [K*D] statistics
-        countsf, embed_sum = packed[:K], packed[K:].reshape(K, D)
+        countsf, embed_sum = packed[:K], packed[K:].reshape(D, K)
     _hip.check(L.isi_vq_ema_update_f32(q.embed.data_ptr(), q.cluster_size.data_ptr(), q.embed_avg.data_ptr(),
                                        countsf.data_ptr(), embed_sum.contiguous().data_ptr(), D, K, q.decay,
                                        q.eps, _s(z_nhwc)), "isi_vq_ema_update_f32")
@@ -408,15 +410,13 @@ class VQVAETrainFunction(torch.autograd.Function):
         for j in reversed(range(len(model.upsample_top_to_bottom))):
             layer = model.upsample_top_to_bottom[j]
             g = _nhwc(d_view)
-            grads.set(layer.weight, conv_wgrad(layer, tape[f"up.in{j}"], g))
-            grads.set(layer.bias, colsum(g.reshape(-1, g.shape[-1])))
+            _set_wb(grads, layer, conv_wgrad(layer, tape[f"up.in{j}"], g))
             d_view = conv_dgrad(dw, layer, _as_bchw(g))
         d_qt = _nhwc(d_view).clone()
         # bottom quantiser and its 1x1 conv on cat(dec_t, enc_b)
         d_zb = vq_backward(d_qb, tape["z_b"], tape["q_b"], g_diff)
         qcb = model.quantize_conv_b
-        grads.set(qcb.weight, conv_wgrad(qcb, tape["dec_t"], d_zb, x2=tape["enc_b"]))
-        grads.set(qcb.bias, colsum(d_zb.reshape(-1, D)))
+        _set_wb(grads, qcb, conv_wgrad(qcb, tape["dec_t"], d_zb, x2=tape["enc_b"]))
         d_cat2 = conv_dgrad(dw, qcb, _as_bchw(d_zb))
         Cd = tape["dec_t"].shape[1]
         d_dect, d_encb = d_cat2[:, :Cd], _nhwc(d_cat2[:, Cd:]).clone()
@@ -426,8 +426,7 @@ class VQVAETrainFunction(torch.autograd.Function):
         # top quantiser and its 1x1 conv
         d_zt = vq_backward(d_qt, tape["z_t"], tape["q_t"], g_diff)
         qct = model.quantize_conv_t
-        grads.set(qct.weight, conv_wgrad(qct, tape["enc_t"], d_zt))
-        grads.set(qct.bias, colsum(d_zt.reshape(-1, D)))
+        _set_wb(grads, qct, conv_wgrad(qct, tape["enc_t"], d_zt))
         d_enct = _nhwc(conv_dgrad(dw, qct, _as_bchw(d_zt)))
         d_encb2 = encoder_backward(model.enc_t, tape, "enc_t", d_enct, dw, grads, need_input_grad=True)
         axpy_(d_encb, d_encb2)

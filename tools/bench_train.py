@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Training-step micro-benchmark: VQVAE forward(train) + backward + Adam at B=64,
+[2,128,512] synthetic spectrograms, default constructor (BASELINE configs[2] per-GPU shard)."""
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
+import torch  # noqa: E402
+from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE  # noqa: E402
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    m = VQVAE(in_channel=2).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    x = torch.randn(B, 2, 128, 512, device=dev)
+
+    def step():
+        m.zero_grad()
+        out, latent, *_ = m(x)
+        loss = torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"B={B}: {dt * 1e3:.2f} ms/step, {B / dt:.1f} spectrograms/s, loss {loss.item():.4f}, "
+          f"peak mem {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -199,14 +199,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
     }
 }
 
-// out[i] = sum_s partial[s * stride + i]  (fixed order)
-__global__ void reduce_partials_kernel(const float *__restrict__ partial, float *__restrict__ out, int64_t n,
-                                       int nsplit, int64_t stride, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
+                                                              float *__restrict__ out, int64_t n, int nsplit,
+                                                              int64_t stride, int accumulate) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + e;
   float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * stride + i];
-  out[i] = accumulate ? out[i] + s : s;
+  if (i < n)
+    for (int k = g; k < nsplit; k += 4) s += partial[(size_t)k * stride + i];
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && i < n) {
+    const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    out[i] = accumulate ? out[i] + t : t;
+  }
 }
 
 static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -218,7 +226,7 @@ size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
   const int Kpad = (int)round_up(K, kBK);
   const int tiles = ((Cout + 127) / 128) * ((Kpad + 127) / 128) * nphase;
   const int nchunks = (M + 31) / 32;
-  int nsplit = std::max(1, 768 / tiles);
+  int nsplit = std::min(256, std::max(1, 768 / tiles));
   nsplit = std::min(nsplit, std::max(1, nchunks / 8));
   return (size_t)nsplit * nphase * Cout * Kpad + (size_t)nsplit * nphase * Cout;
 }
@@ -272,7 +280,7 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
   }
   const int tiles = ((Cout + 127) / 128) * ((a.Kpad + 127) / 128) * nphase;
   const int nchunks = (a.M + 31) / 32;
-  int nsplit = std::max(1, 768 / tiles);
+  int nsplit = std::min(256, std::max(1, 768 / tiles));
   nsplit = std::min(nsplit, std::max(1, nchunks / 8));
   a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   const size_t need = (size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout;
@@ -293,13 +301,13 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
   // partial layout: [phase][split][Cout][Kpad] -> out [phase][Cout][Kpad]
   const int64_t per = (int64_t)Cout * a.Kpad;
   for (int ph = 0; ph < nphase; ++ph) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, stream,
                        workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0);
   }
   rc = check_launch("reduce_partials");
   if (rc || !db) return rc;
   // bias gradient: every (phase, split) partial covers a disjoint pixel set
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cout + 255) / 256), dim3(256), 0, stream, a.db_partial, db,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cout + 63) / 64), dim3(256), 0, stream, a.db_partial, db,
                      (int64_t)Cout, nsplit * nphase, (int64_t)Cout, 0);
   return check_launch("reduce_partials(bias)");
 }
@@ -324,7 +332,7 @@ int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, fl
   a.KW = 1; a.stride = 1; a.pad = 0; a.M = (int)N;
   const int tiles = ((D + 127) / 128) * ((K + 127) / 128);
   const int nchunks = (a.M + 31) / 32;
-  int nsplit = std::max(1, 768 / tiles);
+  int nsplit = std::min(256, std::max(1, 768 / tiles));
   nsplit = std::min(nsplit, std::max(1, nchunks / 8));
   a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   if (workspace_floats < (size_t)nsplit * D * K) { set_last_error("vq_embed_sum: workspace too small"); return ISI_E_WORKSPACE; }
@@ -336,7 +344,7 @@ int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, fl
   int rc = check_launch("vq_embed_sum(wgrad)");
   if (rc) return rc;
   const int64_t per = (int64_t)D * K;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, stream, workspace,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, stream, workspace,
                      embed_sum_dk, per, nsplit, per, 0);
   return check_launch("vq_embed_sum(reduce)");
 }

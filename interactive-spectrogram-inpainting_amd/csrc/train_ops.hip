@@ -54,12 +54,19 @@ __global__ void vq_bwd_kernel(float *__restrict__ dz, const float *__restrict__ 
 // Column sums of a dense [M, C] matrix (bias gradients): per-block partials [nblk][C].
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ x, float *__restrict__ partial,
                                                              int64_t M, int C, int64_t x_stride, int rows_per_block) {
+  __shared__ float red[4][64];
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + e;
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += x[r * x_stride + c];
-    partial[(size_t)blockIdx.x * C + c] = s;
+    if (c < C)
+      for (int64_t r = r0 + g; r < r1; r += 4) s += x[r * x_stride + c];
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    __syncthreads();
   }
 }
 
@@ -119,17 +126,22 @@ int vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st, co
   return check_launch("vq_bwd_f32");
 }
 
-int colsum_num_partials(int64_t M) { return (int)std::min<int64_t>((M + 255) / 256, 1024); }
+int colsum_num_partials(int64_t M) { return (int)std::min<int64_t>((M + 255) / 256, 256); }
 
 // out[C] = column sums of x [M, C] (row stride x_stride); workspace: colsum_num_partials(M) * C floats
 int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, hipStream_t st);
 
-__global__ void reduce_rows_kernel(const float *__restrict__ partial, float *__restrict__ out, int C, int nblk) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restrict__ partial,
+                                                          float *__restrict__ out, int C, int nblk) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + e;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * C + c];
-  out[c] = s;
+  if (c < C)
+    for (int b = g; b < nblk; b += 4) s += partial[(size_t)b * C + c];
+  red[g][e] = s;
+  __syncthreads();
+  if (g == 0 && c < C) out[c] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, hipStream_t st) {
@@ -139,7 +151,7 @@ int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, i
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, x, workspace, M, C, x_stride, rows);
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, out, C, nblk);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, out, C, nblk);
   return check_launch("colsum_reduce");
 }
 

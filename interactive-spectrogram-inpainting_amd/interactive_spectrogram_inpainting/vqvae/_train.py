@@ -72,44 +72,43 @@ def colsum(x2d: torch.Tensor) -> torch.Tensor:
 def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
                x2: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(weight gradient in torch layout, bias gradient).  x (and x2): layer input(s) as
-    [B,C,H,W] views; dy_nhwc: dense [B,OH,OW,Cout]."""
+    [B,C,H,W] views; dy_nhwc: dense [B,OH,OW,Cout].
+
+    A transposed convolution is the adjoint of the stride-2 convolution with the SAME
+    weight tensor ([Cin_T, Cout_T, 4, 4] read as [out, in, 4, 4]), so its weight gradient
+    is that convolution's with the roles swapped: "input" = dy, "output gradient" = x.
+    No 4-phase decomposition, and for the 2-channel last layer the GEMM becomes
+    [Cin x 16*Cout] instead of a [Cout = 2 x ...] sliver."""
     L = _hip.lib()
-    B, _, H, W = x.shape
-    cin = layer.in_channels
-    cout = layer.out_channels
-    k = layer.kernel_size
     tr = layer.transposed
-    K = (4 if tr else k * k) * cin
-    Kpad = (K + 31) // 32 * 32
-    nph = 4 if tr else 1
+    k = layer.kernel_size
     if tr:
-        M = B * H * W
+        src, grad = _as_bchw(dy_nhwc), _nhwc(x)              # roles swapped
+        rows, cin_role = layer.in_channels, layer.out_channels
     else:
-        OH = (H + 2 * layer.padding - k) // layer.stride + 1
-        OW = (W + 2 * layer.padding - k) // layer.stride + 1
-        M = B * OH * OW
-    nws = L.isi_conv_wgrad_workspace_floats(cout, K, M, nph)
+        src, grad = x, dy_nhwc
+        rows, cin_role = layer.out_channels, layer.in_channels
+    B, _, H, W = src.shape
+    K = k * k * cin_role
+    Kpad = (K + 31) // 32 * 32
+    OH = (H + 2 * layer.padding - k) // layer.stride + 1
+    OW = (W + 2 * layer.padding - k) // layer.stride + 1
+    M = B * OH * OW
+    nws = L.isi_conv_wgrad_workspace_floats(rows, K, M, 1)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-    packed = torch.empty(nph, cout, Kpad, dtype=torch.float32, device=x.device)
-    db = torch.empty(cout, dtype=torch.float32, device=x.device)
-    s0 = _hip.src_nchw_view(x)
-    s1 = _hip.src_nchw_view(x2) if x2 is not None else None
-    rc = L.isi_conv_wgrad_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, dy_nhwc.data_ptr(),
-                              packed.data_ptr(), db.data_ptr(), ws.data_ptr(), nws, B, H, W, cout, k, k, layer.stride,
-                              layer.padding, int(tr), _s(x))
+    packed = torch.empty(rows, Kpad, dtype=torch.float32, device=x.device)
+    db = None if tr else torch.empty(rows, dtype=torch.float32, device=x.device)
+    s0 = _hip.src_nchw_view(src)
+    s1 = _hip.src_nchw_view(x2) if (x2 is not None and not tr) else None
+    rc = L.isi_conv_wgrad_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
+                              packed.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), nws,
+                              B, H, W, rows, k, k, layer.stride, layer.padding, 0, _s(x))
     _hip.check(rc, "isi_conv_wgrad_f32")
-    if not tr:
-        # [Cout][kh][kw][Cin] -> [Cout, Cin, kh, kw]
-        return packed[0, :, :K].reshape(cout, k, k, cin).permute(0, 3, 1, 2), db
-    # phases [py,px][Cout][ty,tx][Cin] -> torch ConvTranspose2d layout [Cin, Cout, 4, 4], tap (3-py-2ty, 3-px-2tx)
-    g = packed[:, :, :K].reshape(2, 2, cout, 2, 2, cin)             # py px co ty tx ci
-    out = torch.empty(cin, cout, 4, 4, dtype=torch.float32, device=x.device)
-    for py in range(2):
-        for px in range(2):
-            for ty in range(2):
-                for tx in range(2):
-                    out[:, :, 3 - py - 2 * ty, 3 - px - 2 * tx] = g[py, px, :, ty, tx, :].t()
-    return out, db
+    # [rows][kh][kw][cin_role] -> [rows, cin_role, kh, kw]  (= torch layout for both layer kinds)
+    dw = packed[:, :K].reshape(rows, k, k, cin_role).permute(0, 3, 1, 2)
+    if tr:
+        db = colsum(dy_nhwc.reshape(-1, dy_nhwc.shape[-1]))
+    return dw, db
 
 
 class _DgradWeights:

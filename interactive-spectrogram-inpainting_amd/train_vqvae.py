@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""VQ-VAE training / evaluation loops on MI355X.
+
+Counterpart of the loop semantics of the reference's `train_vqvae.py:133-370`
+ -- not of its CLI, dataloaders, tensorboard or audio dumps:
+
+  loss = criterion(out, img) + latent_loss_weight (0.25) * latent_loss.mean()    (:177-179)
+  Adam(lr 3e-4) step, optional clip_grad_norm_, optional scheduler step          (:181-192,777)
+  per-sample-weighted running means of reconstruction / latent loss / perplexities
+  evaluate(): sample-weighted sums, one packed all-reduce over ranks, / world     (:327-365)
+
+Differences by design: metrics are accumulated ON DEVICE and read once per epoch
+(the reference calls .item() five times per step), and data parallelism does not
+wrap the model in DDP: the model's own backward all-reduces gradient buckets (RCCL)
+while it is still running, and the EMA codebook statistics are all-reduced so that
+every rank keeps the same codebook (vqvae/_train.py).
+
+Run (one process per GPU):
+  python train_vqvae.py --synthetic 64 --batch-size 8 --epochs 1
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train_vqvae.py --synthetic 4096 --batch-size 64
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pathlib
+import sys
+import time
+from typing import Callable, Dict, Iterable, Optional, Tuple
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from torch import nn  # noqa: E402
+
+from interactive_spectrogram_inpainting.utils.distributed import (  # noqa: E402
+    DistributedEvalSampler, is_distributed, is_master_process)
+from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE  # noqa: E402
+
+
+class RunningMeans:
+    """Sample-weighted sums kept on the device: no host sync inside the step."""
+
+    NAMES = ("reconstruction_loss", "latent_loss", "perplexity_t", "perplexity_b")
+
+    def __init__(self, device):
+        self.sums = torch.zeros(len(self.NAMES), dtype=torch.float64, device=device)
+        self.count = 0
+
+    def update(self, batch_size: int, *values: torch.Tensor) -> None:
+        vals = torch.stack([v.detach().reshape(-1)[0].double() for v in values])
+        self.sums += vals * batch_size
+        self.count += batch_size
+
+    def means(self) -> Dict[str, float]:
+        m = (self.sums / max(1, self.count)).tolist()
+        return dict(zip(self.NAMES, m))
+
+
+def train(epoch: int, loader: Iterable, model: VQVAE, reconstruction_criterion: Callable,
+          optimizer: torch.optim.Optimizer, scheduler=None, device="cuda", latent_loss_weight: float = 0.25,
+          clip_grad_norm: Optional[float] = None, dry_run: bool = False) -> Dict[str, float]:
+    model.train()
+    stats = RunningMeans(device)
+    for batch_index, (img, *_) in enumerate(loader):
+        model.zero_grad()
+        img = img.to(device, non_blocking=True)
+        out, latent_loss, perplexity_t, perplexity_b, *_ = model(img)
+        reconstruction_loss = reconstruction_criterion(out, img)
+        latent_loss = latent_loss.mean()
+        loss = reconstruction_loss + latent_loss_weight * latent_loss
+        loss.backward()
+        if clip_grad_norm is not None:
+            nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm)
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step()
+        stats.update(img.shape[0], reconstruction_loss, latent_loss, perplexity_t, perplexity_b)
+        if dry_run:
+            break
+    return stats.means()
+
+
+@torch.no_grad()
+def evaluate(loader: Iterable, model: VQVAE, reconstruction_criterion: Callable, device="cuda",
+             latent_loss_weight: float = 0.25, dry_run: bool = False) -> Tuple[float, Dict[str, float]]:
+    """Sample-weighted averages over the (sharded) validation set; one packed all-reduce
+    (sum, then / world size, like train_vqvae.py:342-365)."""
+    model.eval()
+    stats = RunningMeans(device)
+    for img, *_ in loader:
+        img = img.to(device, non_blocking=True)
+        out, latent_loss, perplexity_t, perplexity_b, *_ = model(img)
+        # the reference adds latent_loss.sum() per batch UNWEIGHTED and divides by the number of
+        # samples at the end (train_vqvae.py:333,351): reproduce that by pre-dividing by the batch size
+        stats.update(img.shape[0], reconstruction_criterion(out, img), latent_loss.sum() / img.shape[0],
+                     perplexity_t, perplexity_b)
+        if dry_run:
+            break
+    packed = stats.sums / max(1, stats.count)
+    if is_distributed():
+        dist.all_reduce(packed)
+        packed = packed / dist.get_world_size()
+    means = dict(zip(RunningMeans.NAMES, packed.tolist()))
+    validation_loss = means["reconstruction_loss"] + latent_loss_weight * means["latent_loss"]
+    return validation_loss, means
+
+
+class SyntheticSpectrograms(torch.utils.data.Dataset):
+    """NSynth-shape stand-in: [2, 128, 512] fp32 (log-mel magnitude, mel-IF in [-1,1])."""
+
+    def __init__(self, n: int, shape=(2, 128, 512), seed: int = 0):
+        self.n, self.shape, self.seed = n, shape, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed * 1_000_003 + i)
+        x = torch.randn(*self.shape, generator=g)
+        x[1].tanh_()
+        return (x,)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic spectrograms")
+    ap.add_argument("--batch-size", type=int, default=8)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--clip-grad-norm", type=float, default=None)
+    ap.add_argument("--latent-loss-weight", type=float, default=0.25)
+    ap.add_argument("--dry-run", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "training runs on MI355X GPUs only (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    torch.manual_seed(1)   # identical initial weights on every rank
+    model = VQVAE(in_channel=2).to(device)
+    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    criterion = nn.MSELoss()
+    data = SyntheticSpectrograms(args.synthetic)
+    sampler = DistributedEvalSampler(data, shuffle=True, seed=20200117) if world > 1 else None
+    loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, sampler=sampler, shuffle=sampler is None,
+                                         drop_last=True, num_workers=0)
+    for epoch in range(args.epochs):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        means = train(epoch, loader, model, criterion, optimizer, device=device,
+                      latent_loss_weight=args.latent_loss_weight, clip_grad_norm=args.clip_grad_norm,
+                      dry_run=args.dry_run)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        val_loss, val = evaluate(loader, model, criterion, device=device,
+                                 latent_loss_weight=args.latent_loss_weight, dry_run=args.dry_run)
+        if is_master_process():
+            print(f"epoch {epoch}: train {means} ({len(loader) * args.batch_size * world / dt:.1f} spectrograms/s) "
+                  f"| validation loss {val_loss:.5f} {val}", flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

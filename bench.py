@@ -103,6 +103,28 @@ def _prior_sampling(device):
         dt = time.perf_counter() - t0
         out[f"codes_per_s_B{B}"] = round(B * 1024 / dt, 1)
         out[f"ms_per_codemap_B{B}"] = round(dt * 1e3, 1)
+    # CPU baseline with the reference's loop semantics (sample.py:268-283: one FULL decoder pass per
+    # sampled token, encoder memory cached), oracle layers on the host cores, bounded to 3 tokens
+    from oracle import prior_oracle as P
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    code = torch.randint(0, 512, (1, 32, 32))
+    clsd = {k: v.reshape(1, 1).to(device) for k, v in cls.items()}
+    src, tgt = m.to_sequences(code.to(device), code.to(device), class_conditioning=clsd)
+    s_, t_ = src.cpu().transpose(0, 1), tgt.cpu().transpose(0, 1)
+    H, E = m.conditional_model_nhead, m.source_num_events_with_start_symbol
+    with torch.no_grad():
+        memory = P.encoder(s_, sd, "transformer.encoder.", m.conditional_model_num_encoder_layers, H, 1, E,
+                           P.causal_mask(s_.shape[0]).t())
+        t0 = time.perf_counter()
+        n_tok = 3
+        for _ in range(n_tok):
+            o = P.decoder(t_, memory, sd, "transformer.decoder.", m.conditional_model_num_decoder_layers, H, 1, E,
+                          1, E, P.causal_mask(t_.shape[0]), None)
+            torch.nn.functional.linear(o[:-1].transpose(0, 1), sd["project_transformer_outputs_to_logits.weight"],
+                                       sd["project_transformer_outputs_to_logits.bias"])
+        out["cpu_baseline"] = {"value": round(n_tok / (time.perf_counter() - t0), 3), "unit": "codes/s",
+                               "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{n_tok} tokens, one full decoder pass each (reference loop, oracle/prior_oracle.py)"}
     out["unit"] = "codes/s"
     out["config"] = "SelfAttentiveVQTransformer shape [32,32] (1024 tokens + start), d_model 512, 6+8 layers, 8 heads, fp32"
     return out

@@ -225,3 +225,20 @@ def test_vqvae_full_size_properties():
         assert n_bad <= 0.005 * ref[5].numel(), f"{n_bad} bottom indices differ from the oracle"
         if n_bad == 0:
             _close(dec[:2], ref[0], TOL, "dec vs oracle")
+
+
+def test_extract_rows(golden_dir):
+    """extract_code.extract contract: one CodeRow per sample with the codes of VQVAE.encode."""
+    import extract_code as E
+    z = np.load(golden_dir / "vqvae_small.npz")
+    m = _model_from_golden(z)
+    x = torch.from_numpy(z["x"])
+    names = [f"note_{i}" for i in range(x.shape[0])]
+    loader = [(x, torch.arange(x.shape[0]), {"note_str": names})]
+    rows = {}
+    n = E.extract(loader, m, _dev(), lambda k, r: rows.__setitem__(k, r), label_encoders={"pitch": None})
+    assert n == x.shape[0] and list(rows) == names
+    for i, name in enumerate(names):
+        r = rows[name]
+        assert r.filename == name and r.attributes == {"pitch": loader[0][1][i]}
+        assert r.top.dtype == np.int64 and np.array_equal(r.top, z["id_t"][i]) and np.array_equal(r.bottom, z["id_b"][i])

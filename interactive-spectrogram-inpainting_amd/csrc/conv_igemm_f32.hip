@@ -47,6 +47,10 @@ struct ConvKArgs {
 };
 
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, 16-B aligned, bank-conflict free
+// LDS stages: 2 = one barrier per K chunk; 1 = two barriers but half the LDS, i.e. more
+// workgroups per CU.  Measured (profiles/): 1 stage is +14 % on the 128x64 tile (3 -> 5
+// workgroups per CU), neutral-to-worse on 128x128.
+template <int BN> constexpr int nbuf_for() { return BN == 64 ? 1 : 2; }
 constexpr unsigned OOB = 0xFFFFFFF0u;  // buffer_load beyond num_records returns 0: free zero padding
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -62,13 +66,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   constexpr int RB = BN / 32;
   constexpr bool SCALAR_A = MODE == 2;  // element-wise gather loader
   constexpr bool DUAL = MODE == 1;      // quads of one chunk may come from either source
+  constexpr int NBUF = nbuf_for<BN>();
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TM >= 1 && TN >= 1, "tile too small");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *As = smem;                      // [2][BM*LDK]
-  float *Bs = smem + 2 * BM * LDK;       // [2][BN*LDK]
-  int *row_b = reinterpret_cast<int *>(Bs + 2 * BN * LDK);  // [BM] batch index or -1
+  float *As = smem;                         // [NBUF][BM*LDK]
+  float *Bs = smem + NBUF * BM * LDK;       // [NBUF][BN*LDK]
+  int *row_b = reinterpret_cast<int *>(Bs + NBUF * BN * LDK);  // [BM] batch index or -1
   int *row_y = row_b + BM;
   int *row_x = row_y + BM;
 
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   const int fq = lane >> 5;
 
   for (int kc = 0; kc < nk; ++kc) {
-    const int buf = kc & 1;
+    const int buf = NBUF == 2 ? (kc & 1) : 0;
     if (kc + 1 < nk) load_chunk();  // global loads in flight under the MFMAs
 
     const float *a = As + buf * BM * LDK + (wm0 + frow) * LDK + fq * 4;
@@ -280,7 +285,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
           }
       }
     }
-    if (kc + 1 < nk) store_chunk(buf ^ 1);
+    if (NBUF == 1) __syncthreads();  // everyone has read the single stage before it is overwritten
+    if (kc + 1 < nk) store_chunk(NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
 
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 
 template <int BM, int BN>
 constexpr size_t conv_smem_bytes() {
-  return (size_t)(2 * BM * LDK + 2 * BN * LDK) * sizeof(float) + 3 * BM * sizeof(int);
+  return (size_t)(nbuf_for<BN>() * BM * LDK + nbuf_for<BN>() * BN * LDK) * sizeof(float) + 3 * BM * sizeof(int);
 }
 
 template <int BM, int BN, int WM, int WN, int MODE>

@@ -22,8 +22,11 @@ namespace isi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int VQ_BLOCK = 256;
-constexpr int VQ_VEC_PER_BLOCK_ITER = 128;  // 4 waves x 32 vectors
+#ifndef ISI_VQ_WAVES
+#define ISI_VQ_WAVES 8
+#endif
+constexpr int VQ_BLOCK = 64 * ISI_VQ_WAVES;
+constexpr int VQ_VEC_PER_BLOCK_ITER = 32 * ISI_VQ_WAVES;  // each wave owns 32 vectors per pass
 
 template <int D>
 __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
   float *cb = smem;            // [K][LDD]
   float *e2 = smem + (size_t)K * LDD;  // [K]
   float *red = e2 + K;         // [4] per-wave sse
-  int *hist = reinterpret_cast<int *>(red + 4);  // [K] workgroup histogram (flushed once at the end)
+  int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);  // [K] workgroup histogram (flushed once at the end)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -126,7 +129,11 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
   for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
   if (lane == 0) red[wave] = sse;
   __syncthreads();
-  if (tid == 0) sse_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < ISI_VQ_WAVES; ++w) t += red[w];
+    sse_part[blockIdx.x] = t;
+  }
 }
 
 __global__ void vq_finalize_kernel(const float *__restrict__ sse_part, int n_part,
@@ -182,7 +189,7 @@ int vq_num_partials(int64_t N) { return vq_grid(N); }
 template <int D>
 static int launch_vq(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                      int32_t *counts, float *sse_part, int64_t N, int K, hipStream_t stream) {
-  const size_t smem = ((size_t)K * (D + 4) + 2 * K + 4) * sizeof(float);
+  const size_t smem = ((size_t)K * (D + 4) + 2 * K + ISI_VQ_WAVES) * sizeof(float);
   if (smem > 150 * 1024) return unsupported("vq: codebook does not fit in LDS");
   auto kern = vq_nearest_kernel<D>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

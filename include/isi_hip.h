@@ -100,6 +100,12 @@ typedef struct isi_dst {
   int64_t sn, sc, sh, sw; /* element strides of the FULL output tensor     */
 } isi_dst;
 
+/* `relu` argument of the convolution entry points is a flag word: */
+#define ISI_CONV_RELU 1   /* rectify the output                                            */
+#define ISI_CONV_BF16X3 2 /* opt-in: split-bf16 products (a_hi b_hi + a_hi b_lo + a_lo b_hi on
+                           * the bf16 matrix pipe, fp32 accumulate; per-product relative error
+                           * ~2^-16 instead of 2^-24).  Default is exact fp32.              */
+
 /* Conv2d, groups=1, square stride, symmetric zero padding, fp32.
  *   out = [relu]( conv(cat(src0, src1), W) + bias [+ residual] )
  * src1.ptr may be NULL (single source); residual.ptr may be NULL.  `residual`
@@ -345,6 +351,9 @@ typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
   isi_decoder_w dec_t, dec;
   int n_upsample;
   isi_conv_w upsample[ISI_MAX_STAGES];
+  int precision; /* 0: exact fp32 everywhere (default).  1: ISI_CONV_BF16X3 in `dec` and
+                  * `upsample` only (code indices stay bit-exact).  2: in every convolution
+                  * (indices may differ at near-ties).                                     */
 } isi_vqvae_w;
 
 /* Outputs of VQVAE.encode / forward (vqvae.py:245-278).  Any pointer may be

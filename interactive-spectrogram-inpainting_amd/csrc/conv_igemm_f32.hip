@@ -40,6 +40,7 @@ struct ConvKArgs {
   int rn, rc, rh, rw;        // residual strides (logical output coordinates)
   int on, oc, oh, ow;        // output strides, in units of GEMM-grid pixels
   int H, W, OH, OW, Cout, K, Kpad, KW, stride, relu, M;
+  int bf16x3;                // opt-in split-bf16 products (flags & ISI_CONV_BF16X3)
   int pad;                   // plain convolution: symmetric zero padding
   int convT;                 // 1: blockIdx.z = phase (py,px) of ConvTranspose2d(k4,s2,p1)
   int w_phase_stride;        // convT: floats between two phase weight matrices
@@ -58,22 +59,54 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigne
   return *reinterpret_cast<float4 *>(&v);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+// ---- split-bf16 ("bf16x3") products: x = hi + lo with hi = bf16(x), lo = bf16(x - hi);
+// a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+// The dropped a_lo.b_lo term and the rounding of lo bound the relative error of every product
+// by ~2^-16 (fp32: 2^-24); opt-in (ISI_CONV_BF16X3), never the default.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDB = 40;  // padded LDS row of a bf16 plane (elements): 80 B, conflict-free b128 reads
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void split_bf16x4(const float4 v, uint2 &hi, uint2 &lo) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = bf16_rne(f[i]);
+    l[i] = bf16_rne(f[i] - __builtin_bit_cast(float, h[i] << 16));
+  }
+  hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+
+template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) {
+  constexpr bool BF = PREC == 1;
   constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int RA = BM / 32;  // A rows staged per thread
   constexpr int RB = BN / 32;
   constexpr bool SCALAR_A = MODE == 2;  // element-wise gather loader
   constexpr bool DUAL = MODE == 1;      // quads of one chunk may come from either source
-  constexpr int NBUF = nbuf_for<BN>();
+  constexpr int NBUF = BF ? 1 : nbuf_for<BN>();
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TM >= 1 && TN >= 1, "tile too small");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *As = smem;                         // [NBUF][BM*LDK]
   float *Bs = smem + NBUF * BM * LDK;       // [NBUF][BN*LDK]
-  int *row_b = reinterpret_cast<int *>(Bs + NBUF * BN * LDK);  // [BM] batch index or -1
+  // bf16x3: four bf16 planes [rows][LDB] (A hi, A lo, B hi, B lo), single stage
+  unsigned short *Ahi = reinterpret_cast<unsigned short *>(smem);
+  unsigned short *Alo = Ahi + BM * LDB;
+  unsigned short *Bhi = Alo + BM * LDB;
+  unsigned short *Blo = Bhi + BN * LDB;
+  int *row_b = BF ? reinterpret_cast<int *>(Blo + BN * LDB)
+                  : reinterpret_cast<int *>(Bs + NBUF * BN * LDK);  // [BM] batch index or -1
   int *row_y = row_b + BM;
   int *row_x = row_y + BM;
 
@@ -237,11 +270,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     for (int j = 0; j < RA; ++j) {
       float4 v = ra[j];
       if constexpr (DUAL) v = sel1 ? ra1[j] : v;
-      *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lq * 4) = v;
+      if constexpr (BF) {
+        uint2 hi, lo;
+        split_bf16x4(v, hi, lo);
+        *reinterpret_cast<uint2 *>(Ahi + (lrow + 32 * j) * LDB + lq * 4) = hi;
+        *reinterpret_cast<uint2 *>(Alo + (lrow + 32 * j) * LDB + lq * 4) = lo;
+      } else {
+        *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lq * 4) = v;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < RB; ++j)
-      *reinterpret_cast<float4 *>(b + (lrow + 32 * j) * LDK + lq * 4) = rb[j];
+    for (int j = 0; j < RB; ++j) {
+      if constexpr (BF) {
+        uint2 hi, lo;
+        split_bf16x4(rb[j], hi, lo);
+        *reinterpret_cast<uint2 *>(Bhi + (lrow + 32 * j) * LDB + lq * 4) = hi;
+        *reinterpret_cast<uint2 *>(Blo + (lrow + 32 * j) * LDB + lq * 4) = lo;
+      } else {
+        *reinterpret_cast<float4 *>(b + (lrow + 32 * j) * LDK + lq * 4) = rb[j];
+      }
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -264,10 +312,41 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     const int buf = NBUF == 2 ? (kc & 1) : 0;
     if (kc + 1 < nk) load_chunk();  // global loads in flight under the MFMAs
 
+    if constexpr (BF) {
+      // 32x32x16 bf16 MFMA: lane (row = lane & 31, k-block = lane >> 5) holds 8 consecutive k
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        s16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int off = (wm0 + i * 32 + frow) * LDB + s * 16 + fq * 8;
+          ah[i] = *reinterpret_cast<const s16x8 *>(Ahi + off);
+          al[i] = *reinterpret_cast<const s16x8 *>(Alo + off);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int off = (wn0 + j * 32 + frow) * LDB + s * 16 + fq * 8;
+          bh[j] = *reinterpret_cast<const s16x8 *>(Bhi + off);
+          bl[j] = *reinterpret_cast<const s16x8 *>(Blo + off);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {  // lo terms first, the dominant hi.hi last
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const s16x8 av = t == 0 ? al[i] : ah[i];
+              const s16x8 bv = t == 1 ? bl[j] : bh[j];
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                  __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+    }
     const float *a = As + buf * BM * LDK + (wm0 + frow) * LDK + fq * 4;
     const float *b = Bs + buf * BN * LDK + (wn0 + frow) * LDK + fq * 4;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < (BF ? 0 : 4); ++s) {
       float4 af[TM], bf[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4 *>(a + i * 32 * LDK + s * 8);
@@ -335,15 +414,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PREC>
 constexpr size_t conv_smem_bytes() {
+  if (PREC == 1) return (size_t)(2 * BM * LDB + 2 * BN * LDB) * sizeof(unsigned short) + 3 * BM * sizeof(int);
   return (size_t)(nbuf_for<BN>() * BM * LDK + nbuf_for<BN>() * BN * LDK) * sizeof(float) + 3 * BM * sizeof(int);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
 static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
-  auto kern = conv_igemm_f32_kernel<BM, BN, WM, WN, MODE>;
-  constexpr size_t smem = conv_smem_bytes<BM, BN>();
+  auto kern = conv_igemm_f32_kernel<BM, BN, WM, WN, MODE, PREC>;
+  constexpr size_t smem = conv_smem_bytes<BM, BN, PREC>();
   static bool attr_set = false;  // idempotent; racing threads set the same value
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -360,7 +440,7 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
     const double in_px = nphase == 1 ? (double)a.M / (a.OH * a.OW) * a.H * a.W : (double)a.M;
     const double bytes = 4.0 * (in_px * a.Cin + (double)a.M * np * a.Cout * (a.res ? 2 : 1) +
                                 np * a.Cout * a.K);
-    const int kid = MODE == 2 ? prof::K_CONV_GATHER
+    const int kid = PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
                              : (BN == 128 ? prof::K_CONV_128x128 : BN == 64 ? prof::K_CONV_128x64 : prof::K_CONV_128x32);
     prof::Scope scope(kid, flops, bytes, stream);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
@@ -370,6 +450,10 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
 
 static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_t stream) {
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
+  if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
+    if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 1>(a, nphase, stream);
+    return launch_cfg<128, 128, 2, 2, 0, 1>(a, nphase, stream);
+  }
 #define ISI_CONV_DISPATCH(MODE)                                                        \
   do {                                                                                  \
     if (a.Cout <= 32) return launch_cfg<128, 32, 4, 1, MODE>(a, nphase, stream);        \
@@ -427,7 +511,7 @@ int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, cons
   a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.Cout = Cout;
   a.K = KH * KW * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
-  a.KW = KW; a.stride = stride; a.relu = relu; a.M = B * OH * OW;
+  a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = (relu >> 1) & 1; a.M = B * OH * OW;
   a.pad = pad; a.convT = 0;
   bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (C1 % 4 == 0) && aligned16(s0->ptr) &&
              (s0->sn % 4 == 0) && (s0->sh % 4 == 0) && (s0->sw % 4 == 0);
@@ -468,7 +552,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.K = 4 * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_phase_stride = Cout * a.Kpad;
   a.w_bytes = (unsigned)((size_t)4 * Cout * a.Kpad * 4);
-  a.KW = 2; a.stride = 1; a.relu = relu; a.M = B * H * W;
+  a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = (relu >> 1) & 1; a.M = B * H * W;
   a.convT = 1;
   const bool vec = s->sc == 1 && (a.C0 % 4 == 0) && aligned16(s->ptr) && (s->sn % 4 == 0) &&
                    (s->sh % 4 == 0) && (s->sw % 4 == 0);

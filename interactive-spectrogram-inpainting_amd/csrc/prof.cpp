@@ -33,6 +33,7 @@ const char *kernel_name(int id) {
     case K_RESBLOCK: return "resblock_f32_kernel";
     case K_CONVT_SMALL: return "convT_k4s2_small_kernel";
     case K_REL_ATTENTION: return "rel_attention_f32_kernel";
+    case K_CONV_BF16X3: return "conv_igemm_f32_kernel<..,bf16x3>";
     default: return "?";
   }
 }

@@ -16,6 +16,7 @@ enum KernelId {
   K_RESBLOCK,
   K_CONVT_SMALL,
   K_REL_ATTENTION,
+  K_CONV_BF16X3,
   K_COUNT
 };
 

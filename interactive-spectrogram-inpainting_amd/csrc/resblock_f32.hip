@@ -244,7 +244,7 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
   a.in_bytes = (unsigned)(elems * 4);
   a.w1_bytes = (unsigned)((size_t)R * 9 * C * 4);  // packed [R][9C], 9C % 32 == 0
   a.w2_bytes = (unsigned)((size_t)C * 32 * 4);
-  a.C = C; a.R = R; a.H = H; a.W = W; a.relu = relu;
+  a.C = C; a.R = R; a.H = H; a.W = W; a.relu = relu & 1;
   switch (C / 32) {
     case 1: return launch_res<1>(a, B, stream);
     case 2: return launch_res<2>(a, B, stream);

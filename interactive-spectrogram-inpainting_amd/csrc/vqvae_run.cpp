@@ -107,13 +107,13 @@ bool compute_shapes(const isi_vqvae_w &w, int B, int H, int W, Shapes &s) {
 // rectified input r; each block writes relu(r + conv1(relu(conv3(r)))).
 // The last block writes to `final_out` when that is non-null.
 int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act &cur, int B,
-                  float *s0, float *s1, float *hid, float *final_out, hipStream_t st) {
+                  float *s0, float *s1, float *hid, float *final_out, int pf, hipStream_t st) {
   for (int i = 0; i < n_res; ++i) {
     const int R = res3[i].Cout;
     float *outp = (i == n_res - 1 && final_out) ? final_out : (cur.p == s0 ? s1 : s0);
     if (resblock_fusable(cur.C, R)) {
       int rc = resblock_f32(cur.p, res3[i].w, res3[i].bias, res1[i].w, res1[i].bias, outp, B, cur.H,
-                            cur.W, cur.C, R, /*relu*/ 1, st);
+                            cur.W, cur.C, R, /*relu*/ 1 | pf, st);
       if (rc) return rc;
       cur.p = outp;
       continue;
@@ -121,12 +121,12 @@ int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act
     isi_src in = src_nhwc(cur.p, cur.C, cur.H, cur.W);
     isi_dst dh = dst_nhwc(hid, R, cur.H, cur.W);
     int rc = conv2d_f32(&in, nullptr, res3[i].w, res3[i].bias, nullptr, &dh, B, cur.H, cur.W, R, 3,
-                        3, 1, 1, /*relu*/ 1, st);
+                        3, 1, 1, /*relu*/ 1 | pf, st);
     if (rc) return rc;
     isi_src hin = src_nhwc(hid, R, cur.H, cur.W);
     isi_dst dout = dst_nhwc(outp, cur.C, cur.H, cur.W);
     rc = conv2d_f32(&hin, nullptr, res1[i].w, res1[i].bias, &in, &dout, B, cur.H, cur.W, cur.C, 1,
-                    1, 1, 0, /*relu*/ 1, st);
+                    1, 1, 0, /*relu*/ 1 | pf, st);
     if (rc) return rc;
     cur.p = outp;
   }
@@ -135,7 +135,7 @@ int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act
 
 // RosinalityEncoder (encoder_decoder.py:38-126).  `in` may be NCHW.
 int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *s0, float *s1,
-                float *hid, float *final_out, Act &out, hipStream_t st) {
+                float *hid, float *final_out, Act &out, int pf, hipStream_t st) {
   Act cur{nullptr, in.C, H, W};
   isi_src cs = in;
   for (int i = 0; i < e.n_down; ++i) {
@@ -143,7 +143,7 @@ int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *
     float *o = (cur.p == s0) ? s1 : s0;
     isi_dst d = dst_nhwc(o, e.down[i].Cout, OH, OW);
     int rc = conv2d_f32(&cs, nullptr, e.down[i].w, e.down[i].bias, nullptr, &d, B, cur.H, cur.W,
-                        e.down[i].Cout, 4, 4, 2, 1, 1, st);
+                        e.down[i].Cout, 4, 4, 2, 1, 1 | pf, st);
     if (rc) return rc;
     cur = Act{o, e.down[i].Cout, OH, OW};
     cs = src_nhwc(cur.p, cur.C, cur.H, cur.W);
@@ -152,11 +152,11 @@ int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *
     float *o = (e.n_res == 0) ? final_out : ((cur.p == s0) ? s1 : s0);
     isi_dst d = dst_nhwc(o, e.conv3.Cout, cur.H, cur.W);
     int rc = conv2d_f32(&cs, nullptr, e.conv3.w, e.conv3.bias, nullptr, &d, B, cur.H, cur.W,
-                        e.conv3.Cout, 3, 3, 1, 1, 1, st);
+                        e.conv3.Cout, 3, 3, 1, 1, 1 | pf, st);
     if (rc) return rc;
     cur = Act{o, e.conv3.Cout, cur.H, cur.W};
   }
-  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, st);
+  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, pf, st);
   if (rc) return rc;
   out = cur;
   return ISI_OK;
@@ -165,16 +165,16 @@ int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *
 // RosinalityDecoder (encoder_decoder.py:129-227).  Input = cat(in0, in1) on
 // channels (in1 optional); the last transposed conv writes through `final_dst`.
 int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, int B, int H, int W,
-                float *s0, float *s1, float *hid, const isi_dst &final_dst, hipStream_t st) {
+                float *s0, float *s1, float *hid, const isi_dst &final_dst, int pf, hipStream_t st) {
   Act cur{s0, d.conv3.Cout, H, W};
   {
     isi_dst dd = dst_nhwc(cur.p, cur.C, H, W);
     int rc = conv2d_f32(&in0, in1, d.conv3.w, d.conv3.bias, nullptr, &dd, B, H, W, cur.C, 3, 3, 1,
-                        1, 1, st);
+                        1, 1 | pf, st);
     if (rc) return rc;
   }
   {
-    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, st);
+    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, pf, st);
     if (rc) return rc;
   }
   for (int i = 0; i < d.n_up; ++i) {
@@ -183,7 +183,7 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
     float *o = (cur.p == s0) ? s1 : s0;
     isi_dst dd = last ? final_dst : dst_nhwc(o, d.up[i].Cout, 2 * cur.H, 2 * cur.W);
     int rc = conv_transpose2d_k4s2_f32(&s, d.up[i].w, d.up[i].bias, &dd, B, cur.H, cur.W,
-                                       d.up[i].Cout, last ? 0 : 1, st);
+                                       d.up[i].Cout, (last ? 0 : 1) | pf, st);
     if (rc) return rc;
     cur = Act{o, d.up[i].Cout, 2 * cur.H, 2 * cur.W};
   }
@@ -238,20 +238,22 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   int64_t *id_b = out->id_b ? out->id_b : id_b_ws;
   float *scal = out->scalars ? out->scalars : scal_ws;
   int rc;
+  const int pf_enc = w.precision >= 2 ? ISI_CONV_BF16X3 : 0;   // path that feeds the quantisers
+  const int pf_dec = w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
 
   if (mode & ISI_MODE_ENCODE) {
     if (!x) return invalid("vqvae: x is null");
     Act eb, et;
-    rc = run_encoder(w.enc_b, src_nchw(x, w.in_channel, H, W), B, H, W, s0, s1, hid, enc_b, eb, st);
+    rc = run_encoder(w.enc_b, src_nchw(x, w.in_channel, H, W), B, H, W, s0, s1, hid, enc_b, eb, pf_enc, st);
     if (rc) return rc;
-    rc = run_encoder(w.enc_t, src_nhwc(eb.p, eb.C, eb.H, eb.W), B, eb.H, eb.W, s0, s1, hid, enc_t, et, st);
+    rc = run_encoder(w.enc_t, src_nhwc(eb.p, eb.C, eb.H, eb.W), B, eb.H, eb.W, s0, s1, hid, enc_t, et, pf_enc, st);
     if (rc) return rc;
     // quantize_conv_t + quantize_t (vqvae.py:260-263)
     {
       isi_src s = src_nhwc(et.p, et.C, et.H, et.W);
       isi_dst d = dst_nhwc(zbuf, D, et.H, et.W);
       rc = conv2d_f32(&s, nullptr, w.quantize_conv_t.w, w.quantize_conv_t.bias, nullptr, &d, B, et.H,
-                      et.W, D, 1, 1, 1, 0, 0, st);
+                      et.W, D, 1, 1, 1, 0, pf_enc, st);
       if (rc) return rc;
       rc = run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
                          sse_part, scal + 0, st);
@@ -263,7 +265,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
     {
       isi_src s = src_nhwc(quant_t, D, et.H, et.W);
       isi_dst d = dst_nhwc(dec_t, w.dec_t.up[w.dec_t.n_up - 1].Cout, sh.Hb, Wd);
-      rc = run_decoder(w.dec_t, s, nullptr, B, et.H, et.W, s0, s1, hid, d, st);
+      rc = run_decoder(w.dec_t, s, nullptr, B, et.H, et.W, s0, s1, hid, d, pf_enc, st);
       if (rc) return rc;
     }
     // quantize_conv_b on cat([dec_t, enc_b]) cropped to Wq (vqvae.py:266-273)
@@ -273,7 +275,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       isi_src b = src_nhwc(eb.p, eb.C, sh.Hb, sh.Wq, eb.W);
       isi_dst d = dst_nhwc(zbuf, D, sh.Hb, sh.Wq);
       rc = conv2d_f32(&a, &b, w.quantize_conv_b.w, w.quantize_conv_b.bias, nullptr, &d, B, sh.Hb,
-                      sh.Wq, D, 1, 1, 1, 0, 0, st);
+                      sh.Wq, D, 1, 1, 1, 0, pf_enc, st);
       if (rc) return rc;
       rc = run_quantizer(w.quantize_b, zbuf, (int64_t)B * sh.Hb * sh.Wq, id_b, quant_b, counts,
                          sse_part, scal + 2, st);
@@ -293,7 +295,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       isi_src s = src_nhwc(cur, w.upsample[i].Cin, h, ww);
       isi_dst d = dst_nhwc(o, w.upsample[i].Cout, 2 * h, 2 * ww);
       rc = conv_transpose2d_k4s2_f32(&s, w.upsample[i].w, w.upsample[i].bias, &d, B, h, ww,
-                                     w.upsample[i].Cout, 0, st);
+                                     w.upsample[i].Cout, pf_dec, st);
       if (rc) return rc;
       cur = o; h *= 2; ww *= 2;
     }
@@ -303,7 +305,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
     int OHf = sh.Hb, OWf = sh.Wq;
     for (int i = 0; i < w.dec.n_up; ++i) { OHf *= 2; OWf *= 2; }
     isi_dst d = dst_nchw(out->dec, w.in_channel, OHf, OWf);
-    rc = run_decoder(w.dec, a, &b, B, sh.Hb, sh.Wq, s0, s1, hid, d, st);
+    rc = run_decoder(w.dec, a, &b, B, sh.Hb, sh.Wq, s0, s1, hid, d, pf_dec, st);
     if (rc) return rc;
   }
   return ISI_OK;

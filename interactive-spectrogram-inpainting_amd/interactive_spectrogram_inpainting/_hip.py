@@ -60,7 +60,7 @@ class isi_vqvae_w(C.Structure):
                 ("quantize_conv_t", isi_conv_w), ("quantize_conv_b", isi_conv_w),
                 ("quantize_t", isi_codebook_w), ("quantize_b", isi_codebook_w),
                 ("dec_t", isi_decoder_w), ("dec", isi_decoder_w),
-                ("n_upsample", C.c_int), ("upsample", isi_conv_w * ISI_MAX_STAGES)]
+                ("n_upsample", C.c_int), ("upsample", isi_conv_w * ISI_MAX_STAGES), ("precision", C.c_int)]
 
 
 class isi_vqvae_out(C.Structure):

@@ -58,7 +58,7 @@ def pack_codebook(embed: torch.Tensor):
 
 def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
            k: int, stride: int, pad: int, relu: bool, x2_bchw: Optional[torch.Tensor] = None,
-           residual_bchw: Optional[torch.Tensor] = None) -> torch.Tensor:
+           residual_bchw: Optional[torch.Tensor] = None, bf16x3: bool = False) -> torch.Tensor:
     """Convolution of a tensor indexed [B,C,H,W] (any strides); returns a
     [B,Cout,OH,OW]-shaped view of freshly allocated channels-last storage."""
     _hip.require_gpu(x_bchw, "conv input")
@@ -73,13 +73,13 @@ def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Te
     rc = _hip.lib().isi_conv2d_f32(
         C.byref(s0), C.byref(s1) if s1 is not None else None, packed_w.data_ptr(),
         bias.data_ptr() if bias is not None else None, C.byref(res) if res is not None else None,
-        C.byref(dst), B, H, W, cout, k, k, stride, pad, int(relu), _s(x_bchw))
+        C.byref(dst), B, H, W, cout, k, k, stride, pad, int(relu) | (2 if bf16x3 else 0), _s(x_bchw))
     _hip.check(rc, "isi_conv2d_f32")
     return out
 
 
 def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor],
-                          cout: int, relu: bool, out_nchw: bool = False) -> torch.Tensor:
+                          cout: int, relu: bool, out_nchw: bool = False, bf16x3: bool = False) -> torch.Tensor:
     _hip.require_gpu(x_bchw, "convT input")
     B, _, H, W = x_bchw.shape
     if out_nchw:
@@ -90,7 +90,7 @@ def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Op
     dst = _hip.dst_nchw_view(out)
     rc = _hip.lib().isi_conv_transpose2d_k4s2_f32(
         C.byref(s0), packed_w.data_ptr(), bias.data_ptr() if bias is not None else None,
-        C.byref(dst), B, H, W, cout, int(relu), _s(x_bchw))
+        C.byref(dst), B, H, W, cout, int(relu) | (2 if bf16x3 else 0), _s(x_bchw))
     _hip.check(rc, "isi_conv_transpose2d_k4s2_f32")
     return out
 

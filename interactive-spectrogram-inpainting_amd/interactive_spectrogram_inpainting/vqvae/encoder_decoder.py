@@ -66,12 +66,12 @@ class _ConvParams(nn.Module):
         return (f"{kind}({self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
                 f"stride={self.stride}, padding={self.padding})")
 
-    def run(self, x, relu: bool, x2=None, residual=None, out_nchw: bool = False):
+    def run(self, x, relu: bool, x2=None, residual=None, out_nchw: bool = False, bf16x3: bool = False):
         if self.transposed:
             return _ops.conv_transpose2d_k4s2(x, self.packed(), self.bias, self.out_channels, relu,
-                                              out_nchw=out_nchw)
+                                              out_nchw=out_nchw, bf16x3=bf16x3)
         return _ops.conv2d(x, self.packed(), self.bias, self.out_channels, self.kernel_size,
-                           self.stride, self.padding, relu, x2_bchw=x2, residual_bchw=residual)
+                           self.stride, self.padding, relu, x2_bchw=x2, residual_bchw=residual, bf16x3=bf16x3)
 
 
 def _check_groups(groups: int):

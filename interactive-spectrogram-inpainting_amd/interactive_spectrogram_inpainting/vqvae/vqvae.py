@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import ctypes as C
 import json
+import os
 import pathlib
 import warnings
 from typing import Iterable, List, Mapping, Optional, Tuple, Union
@@ -130,6 +131,9 @@ class VQVAE(nn.Module):
         self.adapt_quantized_durations = adapt_quantized_durations
         self._plan = None
         self._plan_key = None
+        # 'f32' (default, exact) | 'bf16x3_decoder' (split-bf16 products in `dec` + `upsample` only:
+        # code indices unaffected) | 'bf16x3' (every convolution)
+        self.conv_precision = os.environ.get("ISI_CONV_PRECISION", "f32")
 
     # ------------------------------------------------------------ native plan
     def _plan_fingerprint(self):
@@ -137,6 +141,7 @@ class VQVAE(nn.Module):
         for t in list(self.parameters()) + [self.quantize_t.embed, self.quantize_b.embed]:
             key.append((t._version, t.data_ptr()))
         key.append((getattr(self.quantize_t, "_ema_steps", 0), getattr(self.quantize_b, "_ema_steps", 0)))
+        key.append(self.conv_precision)
         return tuple(key)
 
     def _native_weights(self) -> _hip.isi_vqvae_w:
@@ -190,6 +195,7 @@ class VQVAE(nn.Module):
         w.quantize_conv_t, w.quantize_conv_b = conv(self.quantize_conv_t), conv(self.quantize_conv_b)
         w.quantize_t, w.quantize_b = book(self.quantize_t), book(self.quantize_b)
         w.dec_t, w.dec = dec(self.dec_t), dec(self.dec)
+        w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2}[self.conv_precision]
         w.n_upsample = len(self.upsample_top_to_bottom)
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)

@@ -535,7 +535,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
                        s->sn == (int64_t)H * W * s->C && aligned16(s->ptr);
     if (!dense) return unsupported("convT: small-Cout path needs a dense channels-last source");
     return convT_k4s2_small_f32(s->ptr, packed_w, bias, dst->ptr, B, H, W, s->C, Cout, (int)dst->sn,
-                                (int)dst->sc, (int)dst->sh, (int)dst->sw, relu, stream);
+                                (int)dst->sc, (int)dst->sh, (int)dst->sw, relu & ISI_CONV_RELU, stream);
   }
   ConvKArgs a;
   memset(&a, 0, sizeof a);

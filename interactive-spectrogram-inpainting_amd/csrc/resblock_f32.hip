@@ -53,11 +53,43 @@ __device__ __forceinline__ float elem(const float4 &v, int e) {
 // LDS (global -> registers -> LDS, the next slice's loads in flight under the
 // MFMAs); the nine taps then read shifted windows of the same halo: 144 MFMAs
 // per wave between barriers and 4.4x less global->LDS traffic than im2col.
-template <int TC>  // TC = C / 32
+// ---- opt-in split-bf16 products (ISI_CONV_BF16X3, see conv_igemm_f32.hip)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDB = 40;  // bf16 plane row (elements): 80 B
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+  unsigned u = __builtin_bit_cast(unsigned, x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return u >> 16;
+}
+__device__ __forceinline__ void split_bf16x4(const float4 v, uint2 &hi, uint2 &lo) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = bf16_rne(f[i]);
+    l[i] = bf16_rne(f[i] - __builtin_bit_cast(float, h[i] << 16));
+  }
+  hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+  lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+}
+__device__ __forceinline__ f32x16 mfma3(const s16x8 ah, const s16x8 al, const s16x8 bh, const s16x8 bl, f32x16 acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+  return acc;
+}
+
+template <int TC, bool BF = false>  // TC = C / 32
 __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *Ah = smem;                     // [HPIX][LDK]      halo slice   (later: h, [128][LDK])
   float *W1s = Ah + HPIX * LDK;         // [9][32][LDK]     W1 slice     (later: W2, [C][LDK])
+  // bf16x3: bf16 planes instead -- halo hi/lo [HPIX][LDB], W1 slice hi/lo [9*32][LDB]
+  unsigned short *Ahi = reinterpret_cast<unsigned short *>(smem);
+  unsigned short *Alo = Ahi + HPIX * LDB;
+  unsigned short *Whi = Alo + HPIX * LDB;
+  unsigned short *Wlo = Whi + 9 * 32 * LDB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int C = TC * 32;
@@ -93,10 +125,28 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int i = tid + 256 * j;
-      if (j < NA - 1 || i < HPIX * 8) *reinterpret_cast<float4 *>(Ah + (i >> 3) * LDK + lq * 4) = ra[j];
+      if (j < NA - 1 || i < HPIX * 8) {
+        if constexpr (BF) {
+          uint2 hi, lo;
+          split_bf16x4(ra[j], hi, lo);
+          *reinterpret_cast<uint2 *>(Ahi + (i >> 3) * LDB + lq * 4) = hi;
+          *reinterpret_cast<uint2 *>(Alo + (i >> 3) * LDB + lq * 4) = lo;
+        } else {
+          *reinterpret_cast<float4 *>(Ah + (i >> 3) * LDK + lq * 4) = ra[j];
+        }
+      }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) *reinterpret_cast<float4 *>(W1s + (t * 32 + ln) * LDK + lq * 4) = rw[t];
+    for (int t = 0; t < 9; ++t) {
+      if constexpr (BF) {
+        uint2 hi, lo;
+        split_bf16x4(rw[t], hi, lo);
+        *reinterpret_cast<uint2 *>(Whi + (t * 32 + ln) * LDB + lq * 4) = hi;
+        *reinterpret_cast<uint2 *>(Wlo + (t * 32 + ln) * LDB + lq * 4) = lo;
+      } else {
+        *reinterpret_cast<float4 *>(W1s + (t * 32 + ln) * LDK + lq * 4) = rw[t];
+      }
+    }
   };
 
   // Two accumulators (even / odd K steps): back-to-back MFMAs on ONE accumulator
@@ -115,8 +165,24 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
     store_slice();
     __syncthreads();
     if (c + 1 < TC) load_slice(c + 1);  // in flight under the 144 MFMAs below
+    if constexpr (BF) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+      for (int t = 0; t < 9; ++t) {
+        const int ao = ((ry + t / 3) * HWD + rx + (t % 3)) * LDB + fq * 8;
+        const int bo = (t * 32 + frow) * LDB + fq * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const s16x8 ah = *reinterpret_cast<const s16x8 *>(Ahi + ao + s * 16);
+          const s16x8 al = *reinterpret_cast<const s16x8 *>(Alo + ao + s * 16);
+          const s16x8 bh = *reinterpret_cast<const s16x8 *>(Whi + bo + s * 16);
+          const s16x8 bl = *reinterpret_cast<const s16x8 *>(Wlo + bo + s * 16);
+          if (s == 0) acc1 = mfma3(ah, al, bh, bl, acc1);
+          else acc1b = mfma3(ah, al, bh, bl, acc1b);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < (BF ? 0 : 9); ++t) {
       const float *a = a_base + ((t / 3) * HWD + (t % 3)) * LDK;
       const float *bb = b_base + t * 32 * LDK;
 #pragma unroll
@@ -138,6 +204,44 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
 
   // ---- W2 -> LDS (over the dead W1 slice), h = relu(acc1 + b1) -> LDS (over the dead halo)
+  f32x16 acc2[TC];
+#pragma unroll
+  for (int j = 0; j < TC; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+  if constexpr (BF) {
+#pragma unroll
+    for (int j = 0; j < TC; ++j) {
+      const int n = ln + 32 * j;
+      uint2 hi, lo;
+      split_bf16x4(buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u), hi, lo);
+      *reinterpret_cast<uint2 *>(Whi + n * LDB + lq * 4) = hi;
+      *reinterpret_cast<uint2 *>(Wlo + n * LDB + lq * 4) = lo;
+    }
+    const float b1 = frow < p.R ? p.b1[frow] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
+      const float hv = frow < p.R ? fmaxf(acc1[r] + b1, 0.f) : 0.f;
+      const unsigned hh = bf16_rne(hv);
+      const unsigned hl = bf16_rne(hv - __builtin_bit_cast(float, hh << 16));
+      Ahi[row * LDB + frow] = (unsigned short)hh;
+      Alo[row * LDB + frow] = (unsigned short)hl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ao = (wave * 32 + frow) * LDB + s * 16 + fq * 8;
+      const s16x8 ah = *reinterpret_cast<const s16x8 *>(Ahi + ao);
+      const s16x8 al = *reinterpret_cast<const s16x8 *>(Alo + ao);
+#pragma unroll
+      for (int j = 0; j < TC; ++j) {
+        const int bo = (j * 32 + frow) * LDB + s * 16 + fq * 8;
+        acc2[j] = mfma3(ah, al, *reinterpret_cast<const s16x8 *>(Whi + bo), *reinterpret_cast<const s16x8 *>(Wlo + bo),
+                        acc2[j]);
+      }
+    }
+  } else {
   float *W2s = W1s;
 #pragma unroll
   for (int j = 0; j < TC; ++j) {
@@ -156,11 +260,6 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   __syncthreads();
 
   // ---- GEMM2: [32 px x 32] x [32 x C]
-  f32x16 acc2[TC];
-#pragma unroll
-  for (int j = 0; j < TC; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const float4 af = *reinterpret_cast<const float4 *>(hs + frow * LDK + fq * 4 + s * 8);
@@ -173,6 +272,7 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
 #pragma unroll
       for (int j = 0; j < TC; ++j)  // rotate over the accumulators
         acc2[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(af, e), elem(bf[j], e), acc2[j], 0, 0, 0);
+  }
   }
 
   // ---- epilogue: + b2 + r, ReLU, store.  Row r of this wave's tile = pixel
@@ -207,10 +307,11 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   }
 }
 
-template <int TC>
+template <int TC, bool BF>
 static int launch_res(const ResKArgs &a, int B, hipStream_t stream) {
-  auto kern = resblock_f32_kernel<TC>;
-  constexpr size_t smem = (size_t)(HPIX * LDK + 9 * 32 * LDK) * sizeof(float);
+  auto kern = resblock_f32_kernel<TC, BF>;
+  constexpr size_t smem = BF ? (size_t)(HPIX + 9 * 32) * LDB * 2 * sizeof(unsigned short)
+                             : (size_t)(HPIX * LDK + 9 * 32 * LDK) * sizeof(float);
   static_assert(9 * 32 >= TC * 32 && HPIX >= 128, "aliased regions must fit");
   static bool attr_set = false;
   if (!attr_set) {
@@ -245,11 +346,19 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
   a.w1_bytes = (unsigned)((size_t)R * 9 * C * 4);  // packed [R][9C], 9C % 32 == 0
   a.w2_bytes = (unsigned)((size_t)C * 32 * 4);
   a.C = C; a.R = R; a.H = H; a.W = W; a.relu = relu & 1;
+  if (relu & ISI_CONV_BF16X3) {
+    switch (C / 32) {
+      case 1: return launch_res<1, true>(a, B, stream);
+      case 2: return launch_res<2, true>(a, B, stream);
+      case 3: return launch_res<3, true>(a, B, stream);
+      default: return launch_res<4, true>(a, B, stream);
+    }
+  }
   switch (C / 32) {
-    case 1: return launch_res<1>(a, B, stream);
-    case 2: return launch_res<2>(a, B, stream);
-    case 3: return launch_res<3>(a, B, stream);
-    default: return launch_res<4>(a, B, stream);
+    case 1: return launch_res<1, false>(a, B, stream);
+    case 2: return launch_res<2, false>(a, B, stream);
+    case 3: return launch_res<3, false>(a, B, stream);
+    default: return launch_res<4, false>(a, B, stream);
   }
 }
 

@@ -99,7 +99,8 @@ def resblock_fusable(C_: int, R: int) -> bool:
     return bool(_hip.lib().isi_resblock_fusable(C_, R))
 
 
-def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: bool) -> torch.Tensor:
+def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: bool,
+             bf16x3: bool = False) -> torch.Tensor:
     """Fused residual block on a rectified, dense channels-last input viewed as [B,C,H,W]."""
     _hip.require_gpu(r_bchw, "resblock input")
     B, C_, H, W = r_bchw.shape
@@ -108,7 +109,8 @@ def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: b
         nhwc = nhwc.contiguous()
     out = torch.empty_like(nhwc)
     rc = _hip.lib().isi_resblock_f32(nhwc.data_ptr(), packed_w3.data_ptr(), b3.data_ptr(), packed_w1.data_ptr(),
-                                     b1.data_ptr(), out.data_ptr(), B, H, W, C_, R, int(relu), _s(r_bchw))
+                                     b1.data_ptr(), out.data_ptr(), B, H, W, C_, R, int(relu) | (2 if bf16x3 else 0),
+                                     _s(r_bchw))
     _hip.check(rc, "isi_resblock_f32")
     return out.permute(0, 3, 1, 2)
 

@@ -91,10 +91,12 @@ class RosinalityResBlock(nn.Module):
             _Slot(), _ConvParams(in_channel, channel, 3, padding=1),
             _Slot(), _ConvParams(channel, in_channel, 1)])
 
-    def forward_rectified(self, r: torch.Tensor, relu_out: bool, fused: bool = True) -> torch.Tensor:
+    def forward_rectified(self, r: torch.Tensor, relu_out: bool, fused: bool = True,
+                          bf16x3: bool = False) -> torch.Tensor:
         c3, c1 = self.conv[1], self.conv[3]
         if fused and _ops.resblock_fusable(c3.in_channels, c3.out_channels):
-            return _ops.resblock(r, c3.packed(), c3.bias, c1.packed(), c1.bias, c3.out_channels, relu_out)
+            return _ops.resblock(r, c3.packed(), c3.bias, c1.packed(), c1.bias, c3.out_channels, relu_out,
+                                 bf16x3=bf16x3)
         h = self.conv[1].run(r, relu=True)
         return self.conv[3].run(h, relu=relu_out, residual=r)
 

@@ -242,3 +242,33 @@ def test_extract_rows(golden_dir):
         r = rows[name]
         assert r.filename == name and r.attributes == {"pitch": loader[0][1][i]}
         assert r.top.dtype == np.int64 and np.array_equal(r.top, z["id_t"][i]) and np.array_equal(r.bottom, z["id_b"][i])
+
+
+def test_split_bf16_precision_modes():
+    """Opt-in bf16x3 products: decoder-only mode must leave every code index untouched and
+    the reconstruction within 1e-4 of the exact-fp32 path; the all-layers mode may only move
+    indices that are near-ties."""
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    cfg = O.Config(in_channel=2)
+    sd = O.init_state_dict(cfg, seed=1)
+    g = torch.Generator().manual_seed(0)
+    O.calibrate_codebooks(sd, cfg, torch.randn(2, 2, 64, 128, generator=g))
+    x = torch.randn(4, 2, 64, 128, generator=g).to(_dev())
+    m = VQVAE(in_channel=2)
+    m.load_state_dict(sd)
+    m = m.to(_dev()).eval()
+    assert m.conv_precision == "f32"
+    ref = m(x)
+    m.conv_precision = "bf16x3_decoder"
+    got = m(x)
+    assert torch.equal(got[4], ref[4]) and torch.equal(got[5], ref[5])
+    _close(got[0], ref[0], 1e-4, "dec (bf16x3 decoder)")
+    assert not torch.equal(got[0], ref[0]), "the mode switch must actually change the arithmetic"
+    m.conv_precision = "bf16x3"
+    got = m(x)
+    agree_t = (got[4] == ref[4]).float().mean().item()
+    agree_b = (got[5] == ref[5]).float().mean().item()
+    assert agree_t > 0.98 and agree_b > 0.98, (agree_t, agree_b)
+    m.conv_precision = "f32"
+    assert torch.equal(m(x)[0], ref[0])

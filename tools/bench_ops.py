@@ -50,7 +50,8 @@ def main():
             if bf: print("  bf16x3 max err / max|ref|:", err(l.run(x, relu=True, bf16x3=True), l.run(x, relu=True)))
         if "resblock" in ops or "all" in ops:
             l = RosinalityResBlock(128, 32).to(dev); x = torch.relu(nhwc(B, 128, 32, 128))
-            t = timeit(lambda: l.forward_rectified(x, relu_out=True)); res.append(("resblock 128/32 @32x128", t, 2 * B * 32 * 128 * (32 * 1152 + 128 * 32)))
+            t = timeit(lambda: l.forward_rectified(x, relu_out=True, bf16x3=bf)); res.append(("resblock 128/32 @32x128", t, 2 * B * 32 * 128 * (32 * 1152 + 128 * 32)))
+            if bf: print("  bf16x3 max err / max|ref|:", err(l.forward_rectified(x, relu_out=True, bf16x3=True), l.forward_rectified(x, relu_out=True)))
         if "convT" in ops or "all" in ops:
             l = _ConvParams(128, 64, 4, stride=2, padding=1, transposed=True).to(dev); x = nhwc(B, 128, 32, 128)
             t = timeit(lambda: l.run(x, relu=True, bf16x3=bf)); res.append(("convT 128->64 @32x128", t, 2 * B * 32 * 128 * 4 * 64 * 512))

@@ -197,10 +197,22 @@ def main():
 
     if rank == 0:
         dom = kernels[0]
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH doubled as the
+        # gfx950 guide prescribes; tools/pmc_traffic.py): a measured constant, not re-measured here
+        traffic = None
+        try:
+            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_hbm_traffic.json"))
+            for name, d in pmc.items():
+                if "conv_igemm_f32_kernel<128, 128, 2, 2, 0, 0>" in name:
+                    traffic = round(d["hbm_bytes_per_launch_corrected"])
+        except (OSError, ValueError, KeyError):
+            pass
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
                 "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                 "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                 "launches_per_step": dom["launches"] // args.steps,
                 "share_of_step_time": round(dom["ms"] / (dt * 1e3), 3),
@@ -224,6 +236,27 @@ def main():
                          "TFLOPs": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2),
                          "GBs": round(k["bytes"] / (k["ms"] * 1e-3) / 1e9, 1)} for k in kernels],
         }
+        # opt-in split-bf16 products (never the default / never `value`): decoder-only keeps every code
+        # index bit-exact and the reconstruction within 5e-6 of the exact path; all-layers may move near-tie indices
+        alt = {}
+        with torch.no_grad():
+            ref_out = [o.clone() for o in model(x)]
+            for mode in ("bf16x3_decoder", "bf16x3"):
+                model.conv_precision = mode
+                for _ in range(2):
+                    o = model(x)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    o = model(x)
+                torch.cuda.synchronize(device)
+                dt2 = (time.perf_counter() - t0) / 10
+                alt[mode] = {"spectrograms_per_s": round(args.batch / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3),
+                             "dec_max_err_over_max": float((o[0] - ref_out[0]).abs().max() / ref_out[0].abs().max()),
+                             "id_t_agreement": float((o[4] == ref_out[4]).float().mean()),
+                             "id_b_agreement": float((o[5] == ref_out[5]).float().mean())}
+            model.conv_precision = "f32"
+        line["alt_precision_single_gpu"] = alt
         if not args.no_prior:
             line["prior_sampling"] = _prior_sampling(device)
         if not args.no_cpu_baseline and world >= 1:

@@ -103,3 +103,36 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_hip, "_lib", None)
     with pytest.raises(_hip.HipLibraryError):
         _hip.lib()
+
+
+def test_oversize_and_bad_shapes_are_rejected_before_any_launch():
+    """Limits are enforced on the host (no GPU needed): tensors of 4 GiB or more,
+    codebooks that do not fit the kernel's tiling, bad quantiser shapes."""
+    import ctypes as C
+    from interactive_spectrogram_inpainting import _hip
+    lib = _hip.lib()
+    fake = 0x10000  # non-null, 16-byte aligned, never dereferenced on the host
+    # 1 x 4 x 40000 x 40000 fp32 = 25.6 GB: beyond the 32-bit offset range of the kernels
+    H = W = 40000
+    src = _hip.isi_src(fake, 4, H * W * 4, 1, W * 4, 4)
+    dst = _hip.isi_dst(fake, H * W * 4, 1, W * 4, 4)
+    rc = lib.isi_conv2d_f32(C.byref(src), None, fake, None, None, C.byref(dst), 1, H, W, 4, 3, 3, 1, 1, 0, None)
+    assert rc == -4 and b"4 GiB" in lib.isi_last_error()
+    # more than 2^31 output pixels
+    src = _hip.isi_src(fake, 4, 0, 1, 0, 4)
+    rc = lib.isi_conv2d_f32(C.byref(src), None, fake, None, None, C.byref(dst), 4096, 1024, 1024, 4, 1, 1, 1, 0, 0, None)
+    assert rc == -4
+    # empty output
+    src = _hip.isi_src(fake, 4, 16, 1, 8, 4)
+    assert lib.isi_conv2d_f32(C.byref(src), None, fake, None, None, C.byref(dst), 1, 2, 2, 4, 4, 4, 2, 0, 0, None) == -1
+    # quantiser: K not a multiple of 32, unsupported embed_dim, empty input
+    assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 100, 64, 500, None) == -1
+    assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 100, 24, 512, None) == -4
+    assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 0, 64, 512, None) == -1
+    # fused residual block outside its range -> caller must compose two convolutions
+    assert lib.isi_resblock_fusable(128, 32) == 1 and lib.isi_resblock_fusable(16, 8) == 0
+    assert lib.isi_resblock_fusable(256, 32) == 0 and lib.isi_resblock_fusable(128, 64) == 0
+    assert lib.isi_resblock_f32(fake, fake, fake, fake, fake, fake, 1, 4, 4, 16, 8, 0, None) == -4
+    # sampler limits
+    assert lib.isi_sample_row_f32(fake, 2048, 1, 2048, 1.0, 0, 0.0, fake, fake, None, None) == -4
+    assert lib.isi_sample_row_f32(fake, 512, 1, 512, 0.0, 0, 0.0, fake, fake, None, None) == -1   # temperature 0

@@ -272,3 +272,43 @@ def test_split_bf16_precision_modes():
     assert agree_t > 0.98 and agree_b > 0.98, (agree_t, agree_b)
     m.conv_precision = "f32"
     assert torch.equal(m(x)[0], ref[0])
+
+
+@pytest.mark.parametrize("in_ch,B,H,W", [(3, 1, 8, 8), (1, 2, 16, 24), (2, 1, 8, 200), (3, 5, 24, 40)])
+def test_vqvae_edge_shapes_against_oracle(in_ch, B, H, W):
+    """Batch 1, the smallest legal map (top grid 1x1), 1- and 3-channel inputs (the reference's
+    default in_channel is 3), long thin maps: ragged tiles everywhere."""
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    kw = dict(in_channel=in_ch, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=8,
+              num_embeddings=32)
+    cfg = O.Config(**kw)
+    sd = O.init_state_dict(cfg, seed=31 + in_ch)
+    g = torch.Generator().manual_seed(32)
+    O.calibrate_codebooks(sd, cfg, torch.randn(2, in_ch, 32, 32, generator=g))
+    x = torch.randn(B, in_ch, H, W, generator=g)
+    ref = O.forward(x, sd, cfg)
+    m = VQVAE(**kw)
+    m.load_state_dict(sd)
+    m = m.to(_dev()).eval()
+    dec, diff, p_t, p_b, id_t, id_b = m(x.to(_dev()))
+    assert dec.shape == ref[0].shape
+    assert torch.equal(id_t.cpu(), ref[4]) and torch.equal(id_b.cpu(), ref[5])
+    _close(dec, ref[0], TOL, "dec"); _close(diff, ref[1], TOL, "diff")
+
+
+def test_vqvae_rejects_what_it_cannot_compute():
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    m = VQVAE(in_channel=2, num_hidden_channels=32, num_residual_channels=8, embed_dim=16, num_embeddings=64).to(_dev()).eval()
+    with pytest.raises((_hip.HipLibraryError, RuntimeError)):
+        m(torch.randn(1, 2, 4, 4, device=_dev()))             # too small for the 8x down-sampling
+    with pytest.raises((_hip.HipLibraryError, RuntimeError)):
+        m(torch.randn(0, 2, 32, 32, device=_dev()))           # empty batch
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 3, 32, 32, device=_dev()))           # wrong channel count
+    with pytest.raises(_hip.HipLibraryError):
+        m(torch.randn(1, 2, 32, 32, device=_dev(), dtype=torch.float64))
+    with pytest.raises(IndexError):
+        m.decode_code(torch.full((1, 4, 4), 64, dtype=torch.int64, device=_dev()),
+                      torch.zeros(1, 8, 8, dtype=torch.int64, device=_dev()))

@@ -74,7 +74,7 @@ size_t isi_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
  * [phase=py*2+px][Cout][Kpad], k = (ty*2+tx)*Cin + ci, tap (ty,tx) of phase
  * (py,px) reading torch tap (ky,kx) = (3-py-2ty, 3-px-2tx).
  * When Cout <= 4 and Cin % 32 == 0 (the decoder's last layer) the layout is
- * instead [ky][kx][Cin][Cout] for the direct small-Cout kernel; the choice is a
+ * instead [(ky*4+kx)*Cout+co][Cin] for the small-Cout kernel (GEMM + col2im gather); the choice is a
  * function of (Cin, Cout) only and isi_conv_transpose2d_k4s2_f32 applies the
  * same rule.  (encoder_decoder.py:199-215; vqvae.py:193-201). */
 int isi_pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin,

@@ -1,116 +1,198 @@
 // ConvTranspose2d(kernel 4, stride 2, padding 1) with very few output channels
-// (the decoder's last layer, C/2 -> in_channel = 2; reference
-// vqvae/encoder_decoder.py:204-207).  With N = Cout <= 4 a matrix-core GEMM would
-// waste > 90 % of every MFMA, and the layer is HBM-bound anyway (it reads the
-// largest activation of the network and writes the spectrogram), so this is a
-// direct fp32 VALU kernel:
+// (the decoder's last layer, C/2 -> in_channel; reference
+// vqvae/encoder_decoder.py:204-207), exact fp32 on the matrix pipe.
 //
-//   * a workgroup owns a 4 x 64 patch of the input grid (-> 8 x 128 x Cout outputs);
-//   * the (4+2) x (64+2) input halo is staged through LDS in 32-channel slices with
-//     full-line coalesced buffer loads (zero padding = out-of-range buffer offset);
-//   * each thread owns one input-grid pixel = a 2 x 2 output block and walks its
-//     3 x 3 neighbourhood; the tap (ky,kx) an input neighbour feeds into output
-//     phase (py,px) is fixed at compile time (dy = -1: ky 3 | dy = 0: ky 1 (py 0),
-//     ky 2 (py 1) | dy = +1: ky 0);
-//   * weights are wave-uniform and come in through scalar loads (SGPR operands of
-//     v_fma_f32), so LDS bandwidth is spent on activations only.
+// With N = Cout <= 4 the 4-phase implicit GEMM wastes > 90 % of every MFMA.  A
+// transposed convolution is the adjoint of a convolution, so instead
 //
-// Weight layout (isi_pack_convT_k4s2_weight_f32 when Cout <= 4 and Cin % 32 == 0):
-//   wk[ky][kx][ci][co].
+//   Y'[m][(ky,kx,co)] = sum_ci x[m][ci] * W[ci][co][ky][kx]        (a GEMM: pixels x 16*Cout, K = Cin,
+//                                                                   no wasted columns for Cout = 2)
+//   out[2m-1+ky, 2n-1+kx, co] += Y'[(m,n)][(ky,kx,co)]              (col2im)
+//
+// and the scatter-add becomes a gather because a workgroup computes Y' for its
+// TH x 32 patch of input pixels (TH = 8, or 4 for short maps) PLUS a one-pixel halo
+// (10 x 34 = 340 rows, 11 MFMA row tiles), parks Y' in LDS and then every output pixel
+// of its 2TH x 64 output patch sums its four contributions.  Out-of-image halo pixels are zero rows (zero
+// padding).  HBM: the input (the largest activation of the network) is read once
+// plus halo overlap served by L2; the output is written once, coalesced along W.
+//
+// Weight layout (isi_pack_convT_k4s2_weight_f32 when this kernel applies):
+//   wn[(ky*4+kx)*Cout + co][ci].
+#include <algorithm>
+#include <cstdlib>
+
 #include "isi_common.h"
+#include "isi_internal.h"
 #include "prof.h"
 
 namespace isi {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvTSmallArgs {
-  const float *in, *wk, *bias;
+  const float *in, *wn, *bias;
   float *out;
   unsigned in_bytes;
-  int H, W, Cin, relu;
-  int on, oc, oh, ow;  // output element strides
+  int H, W, Cin, Cout, relu;
+  int sn, sc, sh, sw, vec;  // source element strides; vec: channel-contiguous, 16-B aligned quads
+  int on, oc, oh, ow;       // output element strides
 };
 
 namespace {
-constexpr int TH = 4, TW = 64, HW_ = TW + 2, HH_ = TH + 2, LDP = 36;
+constexpr int TW = 32, HW_ = TW + 2;   // input-pixel tile width, halo row
+constexpr int LDX = 36;                // staged input row: one 32-channel slice + 4 (conflict-free b128)
 constexpr unsigned OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ float elem4(const float4 &v, int e) {
+  return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
 }  // namespace
 
-template <int CO>
+// TH: input rows per workgroup; NT: 32-wide column tiles of Y' (16 * Cout <= 32 * NT); CIN in {32, 64}.
+// The input is staged one 32-channel slice at a time (LDS ~41 KB for TH = 4, NT = 1: three
+// workgroups per CU) and the next slice is prefetched into registers under the MFMAs.
+template <int TH, int NT, int CIN>
 __global__ __launch_bounds__(256) void convT_k4s2_small_kernel(const ConvTSmallArgs p) {
-  __shared__ __attribute__((aligned(16))) float xs[HH_ * HW_ * LDP];
-  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  constexpr int HPIX = (TH + 2) * HW_;          // halo pixels
+  constexpr int RT = (HPIX + 31) / 32;          // MFMA row tiles
+  constexpr int ROWS = RT * 32;
+  constexpr int TPW = (RT + 3) / 4;             // row tiles per wave
+  constexpr int NS = CIN / 32;                  // channel slices
+  constexpr int NLD = ROWS * 8 / 256;           // float4 staged per thread and slice
+  constexpr int LDW = CIN + 4;
+  constexpr int LDY = NT * 32 + 1;
+  constexpr int XFLOATS = ROWS * LDX > ROWS * LDY ? ROWS * LDX : ROWS * LDY;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *xs = sm;                             // [ROWS][LDX]   (later: Y' [ROWS][LDY])
+  float *ws = sm + XFLOATS;                   // [NT*32][LDW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
-  const float *__restrict__ wk = p.wk;
   const __amdgpu_buffer_rsrc_t rsi =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
 
-  float acc[2][2][CO];
+  // ---- this thread's staging slots: halo pixel (i >> 3), quad (i & 7) of the slice
+  unsigned off[NLD];
 #pragma unroll
-  for (int py = 0; py < 2; ++py)
+  for (int it = 0; it < NLD; ++it) {
+    const int i = tid + 256 * it;
+    const int pix = i >> 3, q = i & 7;
+    const int hy = pix / HW_, hx = pix - hy * HW_;
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    const bool ok = pix < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    off[it] = ok ? (unsigned)(b * p.sn + gy * p.sh + gx * p.sw + q * 4 * p.sc) : OOB;  // elements
+  }
+  i32x4 stg[NLD];
+  auto load_slice = [&](int s) {
 #pragma unroll
-    for (int px = 0; px < 2; ++px)
+    for (int it = 0; it < NLD; ++it) {
+      if (p.vec) {
+        stg[it] = __builtin_amdgcn_raw_buffer_load_b128(rsi, off[it] == OOB ? OOB : (off[it] + s * 32) * 4u, 0, 0);
+      } else {  // NCHW / strided source: element loads
 #pragma unroll
-      for (int co = 0; co < CO; ++co) acc[py][px][co] = p.bias ? p.bias[co] : 0.f;
-
-  const int Cin = p.Cin;
-  for (int c0 = 0; c0 < Cin; c0 += 32) {
-    __syncthreads();
-    for (int i = tid; i < HH_ * HW_ * 8; i += 256) {
-      const int pix = i >> 3, q = i & 7;
-      const int hy = pix / HW_, hx = pix - hy * HW_;
-      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-      const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      const unsigned off = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * Cin + c0 + q * 4) * 4u : OOB;
-      const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsi, off, 0, 0);
-      *reinterpret_cast<i32x4 *>(xs + pix * LDP + q * 4) = v;
+        for (int e = 0; e < 4; ++e)
+          stg[it][e] = __builtin_amdgcn_raw_buffer_load_b32(
+              rsi, off[it] == OOB ? OOB : (off[it] + (s * 32 + e) * p.sc) * 4u, 0, 0);
+      }
     }
-    __syncthreads();
+  };
+  auto store_slice = [&]() {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+    for (int it = 0; it < NLD; ++it) {
+      const int i = tid + 256 * it;
+      *reinterpret_cast<i32x4 *>(xs + (i >> 3) * LDX + (i & 7) * 4) = stg[it];
+    }
+  };
+  load_slice(0);
+  const int N = 16 * p.Cout;
+  for (int i = tid; i < NT * 32 * (CIN / 4); i += 256) {
+    const int n = i / (CIN / 4), q = i - n * (CIN / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) v = *reinterpret_cast<const float4 *>(p.wn + (size_t)n * CIN + q * 4);
+    *reinterpret_cast<float4 *>(ws + n * LDW + q * 4) = v;
+  }
+  store_slice();
+  __syncthreads();
+
+  // ---- Y' = X W^T : wave w owns row tiles w, w + 4, ...
+  const int frow = lane & 31, fq = lane >> 5;
+  f32x16 acc[TPW][NT];
 #pragma unroll
-      for (int f = 0; f < 3; ++f) {
-        const float *xp = xs + ((ty + d) * HW_ + tx + f) * LDP;
+  for (int i = 0; i < TPW; ++i)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 xv = *reinterpret_cast<const float4 *>(xp + q * 4);
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x = e == 0 ? xv.x : e == 1 ? xv.y : e == 2 ? xv.z : xv.w;
-            const int ci = c0 + q * 4 + e;
-            // phases fed by neighbour offset d-1 (rows) / f-1 (cols)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 #pragma unroll
-            for (int py = 0; py < 2; ++py) {
-              if ((d == 0 && py == 1) || (d == 2 && py == 0)) continue;
-              const int ky = d == 0 ? 3 : d == 2 ? 0 : (py == 0 ? 1 : 2);
+  for (int s = 0; s < NS; ++s) {
+    if (s + 1 < NS) load_slice(s + 1);
 #pragma unroll
-              for (int px = 0; px < 2; ++px) {
-                if ((f == 0 && px == 1) || (f == 2 && px == 0)) continue;
-                const int kx = f == 0 ? 3 : f == 2 ? 0 : (px == 0 ? 1 : 2);
+    for (int kq = 0; kq < 4; ++kq) {
+      float4 bf[NT];
 #pragma unroll
-                for (int co = 0; co < CO; ++co)
-                  acc[py][px][co] = fmaf(x, wk[((ky * 4 + kx) * Cin + ci) * CO + co], acc[py][px][co]);
-              }
-            }
-          }
+      for (int j = 0; j < NT; ++j)
+        bf[j] = *reinterpret_cast<const float4 *>(ws + (j * 32 + frow) * LDW + s * 32 + kq * 8 + fq * 4);
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int rt = wave + 4 * i;
+        if (rt < RT) {  // wave-uniform
+          const float4 af = *reinterpret_cast<const float4 *>(xs + (rt * 32 + frow) * LDX + kq * 8 + fq * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(elem4(af, e), elem4(bf[j], e), acc[i][j], 0, 0, 0);
         }
       }
     }
+    __syncthreads();  // every wave is done reading this slice
+    if (s + 1 < NS) {
+      store_slice();
+      __syncthreads();
+    }
   }
+  float *ys = xs;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int rt = wave + 4 * i;
+    if (rt < RT) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ys[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq) * LDY + j * 32 + frow] = acc[i][j][r];
+    }
+  }
+  __syncthreads();
 
-  const int m = y0 + ty, n = x0 + tx;
-  if (m < p.H && n < p.W) {
+  // ---- col2im as a gather: thread -> output column ox_l, rows oyb + 4 rr
+  const int ox_l = tid & 63, oyb = tid >> 6;
+  const int ox = 2 * x0 + ox_l;
+  // column taps: kx = (ox_l + 1) % 2 + 2 jx ; halo column hc = (ox_l + 1 - kx) / 2 + 1
+  int kxs[2], hcs[2];
 #pragma unroll
-    for (int py = 0; py < 2; ++py)
+  for (int jx = 0; jx < 2; ++jx) {
+    kxs[jx] = ((ox_l + 1) & 1) + 2 * jx;
+    hcs[jx] = (ox_l + 1 - kxs[jx]) / 2 + 1;
+  }
+  if (ox >= 2 * p.W) return;
 #pragma unroll
-      for (int px = 0; px < 2; ++px)
+  for (int rr = 0; rr < TH / 2; ++rr) {
+    const int oy_l = oyb + 4 * rr;
+    const int oy = 2 * y0 + oy_l;
+    if (oy >= 2 * p.H) continue;
+    for (int co = 0; co < p.Cout; ++co) {
+      float v = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
-        for (int co = 0; co < CO; ++co) {
-          float v = acc[py][px][co];
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.out[b * p.on + co * p.oc + (2 * m + py) * p.oh + (2 * n + px) * p.ow] = v;
-        }
+      for (int jy = 0; jy < 2; ++jy) {
+        const int ky = ((oy_l + 1) & 1) + 2 * jy;
+        const int hr = (oy_l + 1 - ky) / 2 + 1;
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx)
+          v += ys[(hr * HW_ + hcs[jx]) * LDY + (ky * 4 + kxs[jx]) * p.Cout + co];
+      }
+      if (p.relu) v = fmaxf(v, 0.f);
+      p.out[b * p.on + co * p.oc + oy * p.oh + ox * p.ow] = v;
+    }
   }
 }
 
@@ -118,12 +200,15 @@ __global__ void pack_convT_small_kernel(const float *__restrict__ w, float *__re
                                         int Cout) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 16 * Cin * Cout) return;
-  const int co = i % Cout, ci = (i / Cout) % Cin, t = i / (Cout * Cin);
+  const int ci = i % Cin, n = i / Cin;  // n = (ky*4 + kx)*Cout + co
+  const int co = n % Cout, t = n / Cout;
   const int ky = t >> 2, kx = t & 3;
   out[i] = w[((ci * Cout + co) * 4 + ky) * 4 + kx];
 }
 
-bool convT_small_applicable(int Cin, int Cout) { return Cout >= 1 && Cout <= 4 && Cin % 32 == 0; }
+bool convT_small_applicable(int Cin, int Cout) {
+  return Cout >= 1 && Cout <= 4 && (Cin == 32 || Cin == 64);
+}
 
 int pack_convT_small_weight_f32(const float *w, float *packed, int Cin, int Cout, hipStream_t stream) {
   const int total = 16 * Cin * Cout;
@@ -132,33 +217,48 @@ int pack_convT_small_weight_f32(const float *w, float *packed, int Cin, int Cout
   return check_launch("pack_convT_small_weight_f32");
 }
 
-template <int CO>
+template <int TH, int NT, int CIN>
 static int launch_small(const ConvTSmallArgs &a, int B, hipStream_t stream) {
+  auto kern = convT_k4s2_small_kernel<TH, NT, CIN>;
+  constexpr int ROWS = (((TH + 2) * HW_ + 31) / 32) * 32;
+  // staged slice or the Y' overlay ([ROWS][NT*32+1]), whichever is larger, + the weights
+  const size_t smem = ((size_t)ROWS * std::max(LDX, NT * 32 + 1) + (size_t)NT * 32 * (CIN + 4)) * sizeof(float);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem) != hipSuccess)
+    return check_launch("hipFuncSetAttribute(convT_small)");
+  if ((a.H + TH - 1) / TH > 65535) return unsupported("convT_small: grid too large");
   const double M = (double)B * a.H * a.W;
-  prof::Scope scope(prof::K_CONVT_SMALL, 2.0 * M * 16 * a.Cin * CO,
-                    4.0 * (M * a.Cin + 4.0 * M * CO + 16.0 * a.Cin * CO), stream);
-  hipLaunchKernelGGL(convT_k4s2_small_kernel<CO>, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(256),
-                     0, stream, a);
+  prof::Scope scope(prof::K_CONVT_SMALL, 2.0 * M * 16 * a.Cin * a.Cout,
+                    4.0 * (M * a.Cin + 4.0 * M * a.Cout + 16.0 * a.Cin * a.Cout), stream);
+  hipLaunchKernelGGL(kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(256), smem, stream, a);
   return check_launch("convT_k4s2_small_f32");
 }
 
-// src must be dense channels-last [B,H,W,Cin]; dst strides arbitrary (32-bit range checked by caller).
-int convT_k4s2_small_f32(const float *in, const float *wk, const float *bias, float *out, int B, int H,
-                         int W, int Cin, int Cout, int on, int oc, int oh, int ow, int relu,
-                         hipStream_t stream) {
-  if (!convT_small_applicable(Cin, Cout)) return unsupported("convT_small: need Cout <= 4 and Cin % 32 == 0");
-  if (B > 65535 || (H + TH - 1) / TH > 65535) return unsupported("convT_small: grid too large");
+template <int TH>
+static int dispatch_small(const ConvTSmallArgs &a, int B, hipStream_t stream) {
+  const bool one = 16 * a.Cout <= 32;
+  if (a.Cin == 32) return one ? launch_small<TH, 1, 32>(a, B, stream) : launch_small<TH, 2, 32>(a, B, stream);
+  return one ? launch_small<TH, 1, 64>(a, B, stream) : launch_small<TH, 2, 64>(a, B, stream);
+}
+
+// src / dst strides arbitrary (32-bit range checked by the caller); in_elems = extent of the source.
+int convT_k4s2_small_f32(const float *in, const float *wn, const float *bias, float *out, int B, int H,
+                         int W, int Cin, int Cout, int64_t in_elems, int sn, int sc, int sh, int sw, int on,
+                         int oc, int oh, int ow, int relu, hipStream_t stream) {
+  if (!convT_small_applicable(Cin, Cout))
+    return unsupported("convT_small: need Cout <= 4 and Cin in {32, 64}");
+  if (B > 65535) return unsupported("convT_small: grid too large");
   ConvTSmallArgs a;
-  a.in = in; a.wk = wk; a.bias = bias; a.out = out;
-  a.in_bytes = (unsigned)((size_t)B * H * W * Cin * 4);
-  a.H = H; a.W = W; a.Cin = Cin; a.relu = relu;
+  a.in = in; a.wn = wn; a.bias = bias; a.out = out;
+  a.in_bytes = (unsigned)(in_elems * 4);
+  a.sn = sn; a.sc = sc; a.sh = sh; a.sw = sw;
+  a.vec = sc == 1 && sn % 4 == 0 && sh % 4 == 0 && sw % 4 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+  a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
   a.on = on; a.oc = oc; a.oh = oh; a.ow = ow;
-  switch (Cout) {
-    case 1: return launch_small<1>(a, B, stream);
-    case 2: return launch_small<2>(a, B, stream);
-    case 3: return launch_small<3>(a, B, stream);
-    default: return launch_small<4>(a, B, stream);
-  }
+  // 8-row tiles recompute less halo (340 rows of Y' per 256 pixels vs 204 per 128); short maps keep 4
+  static const int th_env = [] { const char *e = getenv("ISI_CONVT_TH"); return e ? atoi(e) : 0; }();
+  const int th = th_env ? th_env : (H >= 8 ? 8 : 4);
+  return th == 8 ? dispatch_small<8>(a, B, stream) : dispatch_small<4>(a, B, stream);
 }
 
 }  // namespace isi

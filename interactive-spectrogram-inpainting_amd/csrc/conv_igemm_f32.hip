@@ -530,12 +530,10 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   const int64_t eo = extent(B, dst->sn, Cout, dst->sc, 2 * H, dst->sh, 2 * W, dst->sw);
   if (e0 > kMaxElems || eo > kMaxElems) return unsupported("convT: a tensor spans 4 GiB or more");
   if (convT_small_applicable(s->C, Cout)) {
-    // few output channels: direct VALU kernel (weights were packed in its layout)
-    const bool dense = s->sc == 1 && s->sw == s->C && s->sh == (int64_t)W * s->C &&
-                       s->sn == (int64_t)H * W * s->C && aligned16(s->ptr);
-    if (!dense) return unsupported("convT: small-Cout path needs a dense channels-last source");
-    return convT_k4s2_small_f32(s->ptr, packed_w, bias, dst->ptr, B, H, W, s->C, Cout, (int)dst->sn,
-                                (int)dst->sc, (int)dst->sh, (int)dst->sw, relu & ISI_CONV_RELU, stream);
+    // few output channels: GEMM + col2im gather kernel (weights were packed in its layout)
+    return convT_k4s2_small_f32(s->ptr, packed_w, bias, dst->ptr, B, H, W, s->C, Cout, e0, (int)s->sn,
+                                (int)s->sc, (int)s->sh, (int)s->sw, (int)dst->sn, (int)dst->sc,
+                                (int)dst->sh, (int)dst->sw, relu & ISI_CONV_RELU, stream);
   }
   ConvKArgs a;
   memset(&a, 0, sizeof a);

@@ -19,8 +19,8 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
 bool convT_small_applicable(int Cin, int Cout);
 int pack_convT_small_weight_f32(const float *w, float *packed, int Cin, int Cout, hipStream_t stream);
 int convT_k4s2_small_f32(const float *in, const float *wk, const float *bias, float *out, int B, int H,
-                         int W, int Cin, int Cout, int on, int oc, int oh, int ow, int relu,
-                         hipStream_t stream);
+                         int W, int Cin, int Cout, int64_t in_elems, int sn, int sc, int sh, int sw, int on,
+                         int oc, int oh, int ow, int relu, hipStream_t stream);
 
 int rel_attention_f32(const isi_attn_args *g, hipStream_t stream);
 int layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,

@@ -77,7 +77,7 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW) {
   return (size_t)Cout * round_up((size_t)KH * KW * Cin, kBK);
 }
 size_t packed_convT_k4s2_weight_floats(int Cin, int Cout) {
-  if (convT_small_applicable(Cin, Cout)) return (size_t)16 * Cin * Cout;  // wk[ky][kx][ci][co]
+  if (convT_small_applicable(Cin, Cout)) return (size_t)16 * Cin * Cout;  // wn[(ky*4+kx)*Cout+co][ci]
   return (size_t)4 * Cout * round_up((size_t)4 * Cin, kBK);
 }
 

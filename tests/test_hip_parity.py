@@ -62,6 +62,25 @@ def test_single_layers_against_reference(golden_dir):
             _close(layer.run(xin, relu=True), np.maximum(z[name + "::y"], 0), 1e-5, name + "+relu")
 
 
+@pytest.mark.parametrize("cin,cout,B,H,W", [(64, 2, 2, 9, 37), (32, 1, 1, 4, 32), (32, 3, 1, 5, 70), (64, 4, 1, 3, 33),
+                                              (32, 4, 2, 8, 31)])
+def test_last_layer_transposed_conv_kernel(cin, cout, B, H, W):
+    """The few-output-channel ConvTranspose2d(4, 2, 1) kernel (GEMM + col2im gather,
+    csrc/convT_small_f32.hip) against the op the oracle uses (encoder_decoder.py:204-207)."""
+    from interactive_spectrogram_inpainting.vqvae.encoder_decoder import _ConvParams
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g)
+    x = torch.randn(B, cin, H, W, generator=g)
+    want = torch.nn.functional.conv_transpose2d(x, w, bias, stride=2, padding=1)
+    layer = _ConvParams(cin, cout, 4, stride=2, padding=1, transposed=True)
+    layer.load_state_dict({"weight": w, "bias": bias})
+    layer = layer.to(_dev())
+    for xin in (x.to(_dev()), x.to(_dev()).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)):
+        _close(layer.run(xin, relu=False), want.numpy(), 1e-5, f"convT {cin}->{cout}")
+        _close(layer.run(xin, relu=True), want.clamp_min(0).numpy(), 1e-5, f"convT {cin}->{cout}+relu")
+
+
 def test_resblock_against_reference(golden_dir):
     from interactive_spectrogram_inpainting.vqvae.encoder_decoder import RosinalityResBlock
     z = np.load(golden_dir / "resblock.npz")

@@ -41,7 +41,7 @@ const char *isi_last_error(void);
  * bindings can verify their own layout: which = 0 isi_src, 1 isi_dst,
  * 2 isi_conv_w, 3 isi_encoder_w, 4 isi_decoder_w, 5 isi_codebook_w,
  * 6 isi_vqvae_w, 7 isi_vqvae_out, 8 isi_attn_args, 9 isi_prior_w,
- * 10 isi_prior_state.  Returns 0 for an unknown id. */
+ * 10 isi_prior_state, 11 isi_attn_bwd_args.  Returns 0 for an unknown id. */
 size_t isi_abi_struct_bytes(int which);
 
 /* x = max(x, 0) in place over n floats: the in-place nn.ReLU with which
@@ -204,8 +204,49 @@ typedef struct isi_attn_args {
   int Cq, Ck, Ek, rel_rows;
   int mask_mode;
   float scale;
+  float *lse;   /* optional [B,H,Sq]: log-sum-exp of every query's logits (kept for the backward) */
 } isi_attn_args;
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream);
+
+/* Backward of isi_rel_attention_f32 (replaces autograd through the attention of the absent
+ * VQCPCB.transformer.transformer_custom behind `loss.backward()`,
+ * train_autoregressive_model.py:257).  fwd = the forward call's arguments with out = its
+ * output and lse = the log-sum-exp it wrote.  d_out has the strides of out; dq / dk / dv
+ * are written with the strides of q / k / v (e.g. slices of one [S,B,3d] buffer); d_rel
+ * [H, rel_rows, head_dim] is overwritten (NULL iff rel_embeddings is NULL).  workspace:
+ * isi_rel_attention_bwd_workspace_floats(&fwd) floats, 16-byte aligned.  dK, dV, dQ and dE
+ * are reduced in a fixed order (no cross-wave float atomics). */
+typedef struct isi_attn_bwd_args {
+  isi_attn_args fwd;
+  const float *d_out;
+  float *dq, *dk, *dv, *d_rel;
+  float *workspace;
+  size_t workspace_floats;
+} isi_attn_bwd_args;
+size_t isi_rel_attention_bwd_workspace_floats(const isi_attn_args *fwd);
+int isi_rel_attention_bwd_f32(const isi_attn_bwd_args *args, void *stream);
+
+/* Backward of isi_layernorm_f32: dz = d loss / d (x + residual) (the gradient of both x and
+ * residual), dgamma / dbeta [D] (overwritten; deterministic two-stage reduction).
+ * workspace: isi_layernorm_bwd_workspace_floats(M, D) floats. */
+size_t isi_layernorm_bwd_workspace_floats(int64_t M, int D);
+int isi_layernorm_bwd_f32(const float *x, const float *residual, const float *gamma, const float *dy,
+                          float *dz, float *dgamma, float *dbeta, float *workspace, int64_t M,
+                          int D, float eps, void *stream);
+
+/* LabelSmoothingLoss (utils/losses/prediction.py:5-20) over rows of logits [M,K] with
+ * int64 targets [M]: row_loss[m] = sum_k -true_dist[k] log_softmax(logits[m])[k]; when
+ * dlogits is not NULL also (softmax - true_dist) * grad_scale (the gradient of the mean
+ * loss for grad_scale = upstream / M), in the same pass. */
+int isi_label_smoothing_loss_f32(const float *logits, const int64_t *target, float *row_loss,
+                                 float *dlogits, int64_t M, int K, int num_classes,
+                                 float smoothing, float grad_scale, void *stream);
+
+/* Dense gradient of an nn.Embedding table [V,D] (transformer.py:292-300): dW[v] = sum of
+ * dy[n] over the positions n whose index is v; sorted_idx / order = the indices sorted
+ * ascending (stable) and the permutation that sorts them.  Deterministic. */
+int isi_embedding_bwd_f32(const float *dy, const int64_t *sorted_idx, const int64_t *order,
+                          float *dw, int64_t N, int D, int V, void *stream);
 
 /* out[m,:] = LayerNorm(x[m,:] + residual[m,:]) * gamma + beta  (residual may be NULL). */
 int isi_layernorm_f32(const float *x, const float *residual, const float *gamma,

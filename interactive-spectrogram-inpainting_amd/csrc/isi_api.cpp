@@ -30,6 +30,7 @@ size_t isi_abi_struct_bytes(int which) {
     case 6: return sizeof(isi_vqvae_w);
     case 7: return sizeof(isi_vqvae_out);
     case 8: return sizeof(isi_attn_args);
+    case 11: return sizeof(isi_attn_bwd_args);
     case 9: return sizeof(isi_prior_w);
     case 10: return sizeof(isi_prior_state);
     default: return 0;
@@ -82,6 +83,21 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3, c
 int isi_resblock_fusable(int C, int R) { return resblock_fusable(C, R) ? 1 : 0; }
 
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream) { return rel_attention_f32(args, S(stream)); }
+size_t isi_rel_attention_bwd_workspace_floats(const isi_attn_args *fwd) { return rel_attention_bwd_workspace_floats(fwd); }
+int isi_rel_attention_bwd_f32(const isi_attn_bwd_args *args, void *stream) { return rel_attention_bwd_f32(args, S(stream)); }
+size_t isi_layernorm_bwd_workspace_floats(int64_t M, int D) { return layernorm_bwd_workspace_floats(M, D); }
+int isi_layernorm_bwd_f32(const float *x, const float *residual, const float *gamma, const float *dy, float *dz,
+                          float *dgamma, float *dbeta, float *workspace, int64_t M, int D, float eps, void *stream) {
+  return layernorm_bwd_f32(x, residual, gamma, dy, dz, dgamma, dbeta, workspace, M, D, eps, S(stream));
+}
+int isi_label_smoothing_loss_f32(const float *logits, const int64_t *target, float *row_loss, float *dlogits, int64_t M,
+                                 int K, int num_classes, float smoothing, float grad_scale, void *stream) {
+  return label_smoothing_loss_f32(logits, target, row_loss, dlogits, M, K, num_classes, smoothing, grad_scale, S(stream));
+}
+int isi_embedding_bwd_f32(const float *dy, const int64_t *sorted_idx, const int64_t *order, float *dw, int64_t N, int D,
+                          int V, void *stream) {
+  return embedding_bwd_f32(dy, sorted_idx, order, dw, N, D, V, S(stream));
+}
 int isi_layernorm_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *out,
                       int64_t M, int D, float eps, void *stream) {
   return layernorm_f32(x, residual, gamma, beta, out, M, D, eps, S(stream));

@@ -17,6 +17,7 @@ enum KernelId {
   K_CONVT_SMALL,
   K_REL_ATTENTION,
   K_CONV_BF16X3,
+  K_REL_ATTENTION_BWD,
   K_COUNT
 };
 

@@ -1,0 +1,650 @@
+// Backward of the relative-position attention of rel_attention_f32.hip, gfx950
+// exact-fp32 matrix pipe.  Nothing of size Sq x Sk is stored by the forward: both
+// kernels recompute the probabilities P = exp(logit - LSE) tile by tile from q, k,
+// e and the per-query log-sum-exp the forward kernel wrote.
+//
+//   dP = dO V^T                      D_i = sum_d dO[i,d] O[i,d]
+//   dS = P o (dP - D) * scale
+//   dV = P^T dO      dK = dS^T Q      dQ = dS K + G E      dE = G^T Q
+//   G[i, r] = sum over keys j with r(i,j) = r of dS[i,j]      (the "un-skew" of dS)
+//
+//   rel_attention_bwd_kv_kernel   key-stationary: a wave owns 32 keys (K, V rows in
+//       registers, dK^T / dV^T in accumulators), query tiles stream through LDS.  No
+//       atomics: every dK / dV element is produced by exactly one wave.
+//   rel_attention_bwd_q_kernel    query-stationary (the forward's loop): dQ^T in
+//       accumulators; dS is transposed through LDS so that one query's 32 keys land
+//       on consecutive columns of G (row-coalesced float atomics; a G row is only
+//       ever touched by the one wave that owns the query, in program order).
+//   then two plain GEMMs on the existing kernels:  dQ += G E  (1x1 "convolution",
+//       residual = dQ) and dE = G^T Q (the pixel-reduction GEMM of conv_wgrad_f32).
+//
+// Replaces autograd through the attention of the absent package
+// VQCPCB.transformer.transformer_custom behind `loss.backward()`
+// (reference train_autoregressive_model.py:257); specification:
+// oracle/prior_oracle.py::attention differentiated by torch autograd.
+#include <algorithm>
+
+#include "isi_common.h"
+#include "isi_internal.h"
+#include "prof.h"
+
+namespace isi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct AttnBwdKArgs {
+  const float *q, *k, *v, *e, *mask, *dout, *out, *lse;
+  float *dsum;            // [B,H,Sq]
+  float *dq, *dk, *dv;
+  float *g;               // [H][B*Sq][Rp]
+  unsigned q_bytes, k_bytes, v_bytes, e_bytes, o_bytes;
+  int Sq, Sk, H, B;
+  int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
+  int Cq, Ck, Ek, R, Rp;
+  int mask_mode;
+  float scale;
+};
+
+namespace {
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int QB = 128;        // queries (keys) per workgroup
+constexpr int BAND = 160;      // rows of e staged per tile
+constexpr int SRLD = 65;       // row of the per-wave skew buffer
+constexpr int TLD = 33;        // row of the per-wave transpose buffer (aliases the skew buffer)
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+  return *reinterpret_cast<float4 *>(&v);
+}
+__device__ __forceinline__ float elem(const float4 &v, int e) {
+  return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+}  // namespace
+
+// D[b,h,i] = sum_d dO[i,b,h,d] * O[i,b,h,d]
+__global__ void attn_dsum_kernel(const AttnBwdKArgs p, int HD) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.B * p.H * p.Sq) return;
+  const int i = idx % p.Sq, bh = idx / p.Sq, h = bh % p.H, b = bh / p.H;
+  const float *o = p.out + (size_t)i * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
+  const float *d = p.dout + (size_t)i * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
+  float s = 0.f;
+  for (int c = 0; c < HD; c += 4) {
+    const float4 a = *reinterpret_cast<const float4 *>(o + c), g = *reinterpret_cast<const float4 *>(d + c);
+    s += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
+  }
+  p.dsum[idx] = s;
+}
+
+// ------------------------------------------------------------------ dQ and G
+template <int HD>
+__global__ __launch_bounds__(256) void rel_attention_bwd_q_kernel(const AttnBwdKArgs p) {
+  constexpr int LDH = HD + 4;
+  constexpr int NQ = HD / 8;
+  constexpr int NDB = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Ks = smem;                 // [32][LDH]
+  float *Vs = Ks + 32 * LDH;        // [32][LDH]
+  float *Eb = Vs + 32 * LDH;        // [BAND][LDH]
+  float *Sr = Eb + BAND * LDH;      // [4][32][SRLD]
+  int *evk = reinterpret_cast<int *>(Sr + 4 * 32 * SRLD);  // [32] evk_max - event(key)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB, qw0 = q0 + 32 * wave, qi = qw0 + ql;
+  const bool has_e = p.e != nullptr;
+
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.v), 0, p.v_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dout), 0, p.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_e ? p.e : p.q), 0, has_e ? p.e_bytes : 4u, 0x00020000);
+
+  // Q and dO fragments of this lane's query: quads (2s + half)
+  float4 qf[NQ], dof[NQ];
+#pragma unroll
+  for (int s = 0; s < NQ; ++s) {
+    const bool ok = qi < p.Sq;
+    qf[s] = buf_load4(rq, ok ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + (2 * s + half) * 4) * 4u : OOB);
+    dof[s] = buf_load4(rdo, ok ? (unsigned)(qi * p.o_ss + b * p.o_sb + h * p.o_sh + (2 * s + half) * 4) * 4u : OOB);
+  }
+  const int stat = (b * p.H + h) * p.Sq + qi;
+  const float lse_i = qi < p.Sq ? p.lse[stat] : 0.f;
+  const float dsum_i = qi < p.Sq ? p.dsum[stat] : 0.f;
+  const int evq = qi / p.Cq;
+  const int evq_w0 = qw0 / p.Cq, evq_b0 = q0 / p.Cq;
+
+  f32x16 dQ[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQ[d][r] = 0.f;
+
+  int k_begin = 0, k_end = p.Sk;
+  if (p.mask_mode == 1) k_end = min(p.Sk, q0 + QB);
+  if (p.mask_mode == 2) k_begin = (q0 / 32) * 32;
+
+  const int srow = tid >> 3, squad = tid & 7;
+  float *gbase = p.g + ((size_t)h * p.B + b) * p.Sq * p.Rp;
+
+  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+    const int evk_max = (k0 + 31) / p.Ck;
+    const int rb = evq_b0 - evk_max + p.Ek - 1;
+    __syncthreads();
+    for (int qd = squad; qd < HD / 4; qd += 8) {
+      const int kj = k0 + srow;
+      const bool ok = kj < p.Sk;
+      *reinterpret_cast<float4 *>(Ks + srow * LDH + qd * 4) =
+          buf_load4(rk, ok ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + qd * 4) * 4u : OOB);
+      *reinterpret_cast<float4 *>(Vs + srow * LDH + qd * 4) =
+          buf_load4(rv, ok ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + qd * 4) * 4u : OOB);
+    }
+    if (has_e) {
+      for (int row = srow; row < BAND; row += 32) {
+        const int r = rb + row;
+        const bool ok = r >= 0 && r < p.R;
+        for (int qd = squad; qd < HD / 4; qd += 8)
+          *reinterpret_cast<float4 *>(Eb + row * LDH + qd * 4) =
+              buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      }
+    }
+    if (tid < 32) evk[tid] = evk_max - (k0 + tid) / p.Ck;
+    __syncthreads();
+
+    bool live = qw0 < p.Sq;
+    if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
+    if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
+    if (!live) continue;  // wave-uniform
+
+    // ---- S^T = K Q^T and dP^T = V dO^T  (rows = keys, this lane's column = its query)
+    f32x16 sacc, dpacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+    {
+      const float *kr = Ks + ql * LDH + half * 4;
+      const float *vr = Vs + ql * LDH + half * 4;
+#pragma unroll
+      for (int s = 0; s < NQ; ++s) {
+        const float4 kf = *reinterpret_cast<const float4 *>(kr + s * 8);
+        const float4 vf = *reinterpret_cast<const float4 *>(vr + s * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(kf, e), elem(qf[s], e), sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(vf, e), elem(dof[s], e), dpacc, 0, 0, 0);
+        }
+      }
+    }
+    float sv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
+
+    float *sr = Sr + wave * 32 * SRLD + ql * SRLD;
+    if (has_e) {
+      const int wrow0 = evq_w0 - evq_b0;
+      const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
+      for (int t = 0; t < nt; ++t) {
+        f32x16 racc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+        const float *er = Eb + (wrow0 + 32 * t + ql) * LDH + half * 4;
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+          const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(ef, e), elem(qf[s], e), racc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sr[32 * t + mfma_row(r, half)] = racc[r];
+      }
+      wave_lds_sync();
+      const int dq = evq - evq_w0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evk[mfma_row(r, half)]];
+      wave_lds_sync();
+    }
+
+    // ---- P, dS (scaled)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kj = k0 + mfma_row(r, half);
+      bool ok = kj < p.Sk && qi < p.Sq;
+      if (p.mask_mode == 1) ok = ok && kj <= qi;
+      if (p.mask_mode == 2) ok = ok && kj >= qi;
+      float s = sv[r] * p.scale;
+      if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj];
+      const float pr = ok ? expf(s - lse_i) : 0.f;
+      sv[r] = pr * (dpacc[r] - dsum_i) * p.scale;
+    }
+
+    // ---- dQ^T += K^T dS^T
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) {
+      const int dcol = d * 32 + ql;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const float kk = dcol < HD ? Ks[mfma_row(t, half) * LDH + dcol] : 0.f;
+        dQ[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, sv[t], dQ[d], 0, 0, 0);
+      }
+    }
+
+    // ---- G[i, r(i,j)] += dS[i,j]: transpose through LDS so that lanes run along the keys of one query
+    if (has_e) {
+      float *tb = Sr + wave * 32 * SRLD;  // [key][query], row TLD
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tb[mfma_row(r, half) * TLD + ql] = sv[r];
+      wave_lds_sync();
+      const int kev = (k0 + ql) / p.Ck;
+#pragma unroll 4
+      for (int it = 0; it < 16; ++it) {
+        const int qq = 2 * it + half;
+        const float val = tb[ql * TLD + qq];
+        const int q = qw0 + qq;
+        const int rho = q / p.Cq - kev + p.Ek - 1;
+        if (val != 0.f && rho >= 0 && rho < p.R) unsafeAtomicAdd(gbase + (size_t)q * p.Rp + rho, val);
+      }
+      wave_lds_sync();
+    }
+  }
+
+  if (qi < p.Sq) {
+    float *orow = p.dq + (size_t)qi * p.q_ss + (size_t)b * p.q_sb + (size_t)h * p.q_sh;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * half;
+        if (dd < HD)
+          *reinterpret_cast<float4 *>(orow + dd) =
+              make_float4(dQ[d][4 * g], dQ[d][4 * g + 1], dQ[d][4 * g + 2], dQ[d][4 * g + 3]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------ dK and dV
+template <int HD>
+__global__ __launch_bounds__(256) void rel_attention_bwd_kv_kernel(const AttnBwdKArgs p) {
+  constexpr int LDH = HD + 4;
+  constexpr int NQ = HD / 8;
+  constexpr int NDB = (HD + 31) / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Qs = smem;                 // [32][LDH]
+  float *Gs = Qs + 32 * LDH;        // [32][LDH]   dO tile
+  float *Eb = Gs + 32 * LDH;        // [BAND][LDH]
+  float *Sr = Eb + BAND * LDH;      // [4][32][SRLD]
+  float *lse_s = Sr + 4 * 32 * SRLD;  // [32]
+  float *dsum_s = lse_s + 32;         // [32]
+  int *evq_s = reinterpret_cast<int *>(dsum_s + 32);  // [32] event(query) - first event of the tile
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int k0b = blockIdx.x * QB, kw0 = k0b + 32 * wave, kj = kw0 + ql;
+  const bool has_e = p.e != nullptr;
+
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.v), 0, p.v_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dout), 0, p.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_e ? p.e : p.q), 0, has_e ? p.e_bytes : 4u, 0x00020000);
+
+  float4 kf[NQ], vf[NQ];
+#pragma unroll
+  for (int s = 0; s < NQ; ++s) {
+    const bool ok = kj < p.Sk;
+    kf[s] = buf_load4(rk, ok ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + (2 * s + half) * 4) * 4u : OOB);
+    vf[s] = buf_load4(rv, ok ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + (2 * s + half) * 4) * 4u : OOB);
+  }
+  const int evk_max_b = (k0b + QB - 1) / p.Ck, evk_max_w = (kw0 + 31) / p.Ck;
+  const int dkv = evk_max_w - kj / p.Ck;     // >= 0
+  const int wrow0 = evk_max_b - evk_max_w;   // this wave's first band row
+
+  f32x16 dK[NDB], dV[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dK[d][r] = 0.f; dV[d][r] = 0.f; }
+
+  int q_begin = 0, q_end = p.Sq;
+  if (p.mask_mode == 1) q_begin = (k0b / 32) * 32;          // j <= i
+  if (p.mask_mode == 2) q_end = min(p.Sq, k0b + QB);        // j >= i
+
+  const int srow = tid >> 3, squad = tid & 7;
+  const int statb = (b * p.H + h) * p.Sq;
+
+  for (int q0 = q_begin; q0 < q_end; q0 += 32) {
+    const int evq_min = q0 / p.Cq;
+    const int rb = evq_min - evk_max_b + p.Ek - 1;
+    __syncthreads();
+    for (int qd = squad; qd < HD / 4; qd += 8) {
+      const int qi = q0 + srow;
+      const bool ok = qi < p.Sq;
+      *reinterpret_cast<float4 *>(Qs + srow * LDH + qd * 4) =
+          buf_load4(rq, ok ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + qd * 4) * 4u : OOB);
+      *reinterpret_cast<float4 *>(Gs + srow * LDH + qd * 4) =
+          buf_load4(rdo, ok ? (unsigned)(qi * p.o_ss + b * p.o_sb + h * p.o_sh + qd * 4) * 4u : OOB);
+    }
+    if (has_e) {
+      for (int row = srow; row < BAND; row += 32) {
+        const int r = rb + row;
+        const bool ok = r >= 0 && r < p.R;
+        for (int qd = squad; qd < HD / 4; qd += 8)
+          *reinterpret_cast<float4 *>(Eb + row * LDH + qd * 4) =
+              buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      }
+    }
+    if (tid < 32) {
+      const int qi = q0 + tid;
+      lse_s[tid] = qi < p.Sq ? p.lse[statb + qi] : 0.f;
+      dsum_s[tid] = qi < p.Sq ? p.dsum[statb + qi] : 0.f;
+      evq_s[tid] = qi / p.Cq - evq_min;
+    }
+    __syncthreads();
+
+    bool live = kw0 < p.Sk;
+    if (p.mask_mode == 1) live = live && q0 + 31 >= kw0;
+    if (p.mask_mode == 2) live = live && q0 <= kw0 + 31;
+    if (!live) continue;  // wave-uniform
+
+    // ---- S = Q K^T and dP = dO V^T  (rows = queries, this lane's column = its key)
+    f32x16 sacc, dpacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+    float4 qfr[NQ];
+    {
+      const float *qr = Qs + ql * LDH + half * 4;
+      const float *gr = Gs + ql * LDH + half * 4;
+#pragma unroll
+      for (int s = 0; s < NQ; ++s) {
+        qfr[s] = *reinterpret_cast<const float4 *>(qr + s * 8);
+        const float4 gf = *reinterpret_cast<const float4 *>(gr + s * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(qfr[s], e), elem(kf[s], e), sacc, 0, 0, 0);
+          dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(gf, e), elem(vf[s], e), dpacc, 0, 0, 0);
+        }
+      }
+    }
+    float sv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
+
+    if (has_e) {
+      // U = Q E_band^T : rows = queries, columns = band rows; entry (i, j) sits at column
+      // (event(i) - first event of the tile) + (last event of the wave's keys - event(j))
+      float *sw = Sr + wave * 32 * SRLD;
+      const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
+      for (int t = 0; t < nt; ++t) {
+        f32x16 racc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+        const float *er = Eb + (wrow0 + 32 * t + ql) * LDH + half * 4;
+#pragma unroll
+        for (int s = 0; s < NQ; ++s) {
+          const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(qfr[s], e), elem(ef, e), racc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sw[mfma_row(r, half) * SRLD + 32 * t + ql] = racc[r];
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qrow = mfma_row(r, half);
+        sv[r] += sw[qrow * SRLD + evq_s[qrow] + dkv];
+      }
+      wave_lds_sync();
+    }
+
+    float pv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = mfma_row(r, half);
+      const int qi = q0 + qrow;
+      bool ok = kj < p.Sk && qi < p.Sq;
+      if (p.mask_mode == 1) ok = ok && kj <= qi;
+      if (p.mask_mode == 2) ok = ok && kj >= qi;
+      float s = sv[r] * p.scale;
+      if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj];
+      const float pr = ok ? expf(s - lse_s[qrow]) : 0.f;
+      pv[r] = pr;
+      sv[r] = pr * (dpacc[r] - dsum_s[qrow]) * p.scale;
+    }
+
+    // ---- dV^T += dO^T P ,  dK^T += Q^T dS
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) {
+      const int dcol = d * 32 + ql;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int row = mfma_row(t, half);
+        const float gg = dcol < HD ? Gs[row * LDH + dcol] : 0.f;
+        const float qq = dcol < HD ? Qs[row * LDH + dcol] : 0.f;
+        dV[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, pv[t], dV[d], 0, 0, 0);
+        dK[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qq, sv[t], dK[d], 0, 0, 0);
+      }
+    }
+  }
+
+  if (kj < p.Sk) {
+    float *krow = p.dk + (size_t)kj * p.k_ss + (size_t)b * p.k_sb + (size_t)h * p.k_sh;
+    float *vrow = p.dv + (size_t)kj * p.v_ss + (size_t)b * p.v_sb + (size_t)h * p.v_sh;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * half;
+        if (dd < HD) {
+          *reinterpret_cast<float4 *>(krow + dd) =
+              make_float4(dK[d][4 * g], dK[d][4 * g + 1], dK[d][4 * g + 2], dK[d][4 * g + 3]);
+          *reinterpret_cast<float4 *>(vrow + dd) =
+              make_float4(dV[d][4 * g], dV[d][4 * g + 1], dV[d][4 * g + 2], dV[d][4 * g + 3]);
+        }
+      }
+  }
+}
+
+// packed GEMM operand of one head's table, transposed: w[d][r] = e[h][r][d], zero padded to Kpad
+__global__ void pack_rel_T_kernel(const float *__restrict__ e, float *__restrict__ out, int H, int R, int HD,
+                                  int Kpad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)H * HD * Kpad) return;
+  const int r = (int)(i % Kpad);
+  const int d = (int)((i / Kpad) % HD);
+  const int h = (int)(i / ((int64_t)Kpad * HD));
+  out[i] = r < R ? e[((int64_t)h * R + r) * HD + d] : 0.f;
+}
+
+// d_rel[h][r][d] = dw[h][r][d'] (rows padded to Rp, columns to Kp)
+__global__ void unpack_drel_kernel(const float *__restrict__ dw, float *__restrict__ out, int H, int R, int HD,
+                                   int Rp, int Kp) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)H * R * HD) return;
+  const int d = (int)(i % HD);
+  const int r = (int)((i / HD) % R);
+  const int h = (int)(i / ((int64_t)HD * R));
+  out[i] = dw[((int64_t)h * Rp + r) * Kp + d];
+}
+
+namespace {
+struct BwdLayout {
+  int Rp, Kp;                                // padded table rows (x4) / GEMM K of the table (x32) ; Kp: head dim x32
+  size_t dsum, g, wT, dw, wg, total;         // float offsets into the workspace
+  size_t wg_floats;
+};
+BwdLayout bwd_layout(int B, int H, int Sq, int R, int HD) {
+  BwdLayout L;
+  L.Rp = (int)round_up((size_t)std::max(R, 1), 4);
+  L.Kp = (int)round_up((size_t)HD, kBK);
+  size_t off = 0;
+  auto take = [&](size_t n) { const size_t o = off; off += round_up(n, 64); return o; };
+  L.dsum = take((size_t)B * H * Sq);
+  if (R > 0) {
+    L.g = take((size_t)H * B * Sq * L.Rp);
+    L.wT = take((size_t)H * HD * round_up((size_t)L.Rp, kBK));
+    L.dw = take((size_t)H * L.Rp * L.Kp);
+    L.wg_floats = conv_wgrad_workspace_floats(L.Rp, HD, B * Sq, 1);
+    L.wg = take(L.wg_floats);
+  } else {
+    L.g = L.wT = L.dw = L.wg = 0; L.wg_floats = 0;
+  }
+  L.total = off;
+  return L;
+}
+int64_t span(int64_t S, int64_t ss, int64_t B, int64_t sb, int64_t H, int64_t sh, int64_t hd) {
+  return (S - 1) * ss + (B - 1) * sb + (H - 1) * sh + hd;
+}
+}  // namespace
+
+size_t rel_attention_bwd_workspace_floats(const isi_attn_args *g) {
+  if (!g || g->B <= 0 || g->H <= 0 || g->Sq <= 0) return 0;
+  return bwd_layout(g->B, g->H, g->Sq, g->rel_embeddings ? g->rel_rows : 0, g->head_dim).total;
+}
+
+template <int HD>
+static int launch_bwd(const AttnBwdKArgs &a, hipStream_t stream) {
+  auto kq = rel_attention_bwd_q_kernel<HD>;
+  auto kkv = rel_attention_bwd_kv_kernel<HD>;
+  constexpr size_t smem = (size_t)((64 + BAND) * (HD + 4) + 4 * 32 * SRLD + 96) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(rel_attention_bwd)");
+    attr_set = true;
+  }
+  const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * a.B;
+  {
+    prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 5 : 4),
+                      4.0 * a.B * a.H * HD * (3.0 * a.Sq + 4.0 * a.Sk), stream);
+    hipLaunchKernelGGL(kkv, dim3((a.Sk + QB - 1) / QB, a.H, a.B), dim3(256), smem, stream, a);
+  }
+  int rc = check_launch("rel_attention_bwd_kv");
+  if (rc) return rc;
+  {
+    prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 4 : 3),
+                      4.0 * a.B * a.H * HD * (3.0 * a.Sq + 2.0 * a.Sk), stream);
+    hipLaunchKernelGGL(kq, dim3((a.Sq + QB - 1) / QB, a.H, a.B), dim3(256), smem, stream, a);
+  }
+  return check_launch("rel_attention_bwd_q");
+}
+
+int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
+  if (!ga) return invalid("rel_attention_bwd: null pointer");
+  const isi_attn_args *g = &ga->fwd;
+  if (!g->q || !g->k || !g->v || !g->out || !g->lse || !ga->d_out || !ga->dq || !ga->dk || !ga->dv || !ga->workspace)
+    return invalid("rel_attention_bwd: null pointer");
+  if (g->Sq <= 0 || g->Sk <= 0 || g->B <= 0 || g->H <= 0) return invalid("rel_attention_bwd: bad shape");
+  if (g->Cq <= 0 || g->Ck <= 0 || g->Ek <= 0) return invalid("rel_attention_bwd: bad event layout");
+  if (g->mask_mode < 0 || g->mask_mode > 2) return invalid("rel_attention_bwd: bad mask mode");
+  if (g->head_dim != 16 && g->head_dim != 32 && g->head_dim != 64)
+    return unsupported("rel_attention_bwd: head_dim must be 16, 32 or 64");
+  if (127 / g->Cq + 31 / g->Ck + 1 > BAND || 31 / g->Cq + 127 / g->Ck + 1 > BAND)
+    return unsupported("rel_attention_bwd: band too wide");
+  const bool has_e = g->rel_embeddings != nullptr;
+  if (has_e && (g->rel_rows <= 0 || !ga->d_rel)) return invalid("rel_attention_bwd: rel_rows / d_rel missing");
+  const int64_t lim = (int64_t)1 << 30;
+  const int HD = g->head_dim;
+  const int64_t eq = span(g->Sq, g->q_ss, g->B, g->q_sb, g->H, g->q_sh, HD);
+  const int64_t ek = span(g->Sk, g->k_ss, g->B, g->k_sb, g->H, g->k_sh, HD);
+  const int64_t ev = span(g->Sk, g->v_ss, g->B, g->v_sb, g->H, g->v_sh, HD);
+  const int64_t eo = span(g->Sq, g->o_ss, g->B, g->o_sb, g->H, g->o_sh, HD);
+  if (eq > lim || ek > lim || ev > lim || eo > lim) return unsupported("rel_attention_bwd: tensor spans 4 GiB or more");
+  const int64_t all = g->q_ss | g->q_sb | g->q_sh | g->k_ss | g->k_sb | g->k_sh | g->v_ss | g->v_sb | g->v_sh |
+                      g->o_ss | g->o_sb | g->o_sh;
+  const uintptr_t ptrs = reinterpret_cast<uintptr_t>(g->q) | reinterpret_cast<uintptr_t>(g->k) |
+                         reinterpret_cast<uintptr_t>(g->v) | reinterpret_cast<uintptr_t>(g->out) |
+                         reinterpret_cast<uintptr_t>(g->rel_embeddings) | reinterpret_cast<uintptr_t>(ga->d_out) |
+                         reinterpret_cast<uintptr_t>(ga->dq) | reinterpret_cast<uintptr_t>(ga->dk) |
+                         reinterpret_cast<uintptr_t>(ga->dv) | reinterpret_cast<uintptr_t>(ga->workspace);
+  if ((all & 3) || (ptrs & 15))
+    return invalid("rel_attention_bwd: strides must be multiples of 4 floats and pointers 16-byte aligned");
+  const BwdLayout L = bwd_layout(g->B, g->H, g->Sq, has_e ? g->rel_rows : 0, HD);
+  if (ga->workspace_floats < L.total) { set_last_error("rel_attention_bwd: workspace too small"); return ISI_E_WORKSPACE; }
+  if (has_e && (int64_t)g->H * g->B * g->Sq * L.Rp > lim) return unsupported("rel_attention_bwd: G spans 4 GiB or more");
+
+  AttnBwdKArgs a;
+  memset(&a, 0, sizeof a);
+  a.q = g->q; a.k = g->k; a.v = g->v; a.e = g->rel_embeddings; a.mask = g->dense_mask;
+  a.dout = ga->d_out; a.out = g->out; a.lse = g->lse;
+  a.dsum = ga->workspace + L.dsum;
+  a.dq = ga->dq; a.dk = ga->dk; a.dv = ga->dv;
+  a.g = has_e ? ga->workspace + L.g : nullptr;
+  a.q_bytes = (unsigned)(eq * 4); a.k_bytes = (unsigned)(ek * 4); a.v_bytes = (unsigned)(ev * 4);
+  a.o_bytes = (unsigned)(eo * 4);
+  a.R = g->rel_rows; a.Rp = L.Rp;
+  a.e_bytes = (unsigned)((size_t)g->H * g->rel_rows * HD * 4);
+  a.Sq = g->Sq; a.Sk = g->Sk; a.H = g->H; a.B = g->B;
+  a.q_ss = (int)g->q_ss; a.q_sb = (int)g->q_sb; a.q_sh = (int)g->q_sh;
+  a.k_ss = (int)g->k_ss; a.k_sb = (int)g->k_sb; a.k_sh = (int)g->k_sh;
+  a.v_ss = (int)g->v_ss; a.v_sb = (int)g->v_sb; a.v_sh = (int)g->v_sh;
+  a.o_ss = (int)g->o_ss; a.o_sb = (int)g->o_sb; a.o_sh = (int)g->o_sh;
+  a.Cq = g->Cq; a.Ck = g->Ck; a.Ek = g->Ek;
+  a.mask_mode = g->mask_mode; a.scale = g->scale;
+
+  const int nstat = g->B * g->H * g->Sq;
+  hipLaunchKernelGGL(attn_dsum_kernel, dim3((nstat + 255) / 256), dim3(256), 0, stream, a, HD);
+  int rc = check_launch("attn_dsum");
+  if (rc) return rc;
+  if (has_e) {
+    if (hipMemsetAsync(a.g, 0, (size_t)g->H * g->B * g->Sq * L.Rp * sizeof(float), stream) != hipSuccess)
+      return check_launch("hipMemsetAsync(G)");
+  }
+  switch (HD) {
+    case 16: rc = launch_bwd<16>(a, stream); break;
+    case 32: rc = launch_bwd<32>(a, stream); break;
+    default: rc = launch_bwd<64>(a, stream); break;
+  }
+  if (rc || !has_e) return rc;
+
+  // ---- dQ += G E  and  dE = G^T Q, head by head, on the GEMM kernels
+  const int R = g->rel_rows;
+  const int KpT = (int)round_up((size_t)L.Rp, kBK);
+  float *wT = ga->workspace + L.wT;
+  {
+    const int64_t total = (int64_t)g->H * HD * KpT;
+    hipLaunchKernelGGL(pack_rel_T_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       g->rel_embeddings, wT, g->H, R, HD, KpT);
+    if ((rc = check_launch("pack_rel_T"))) return rc;
+  }
+  for (int h = 0; h < g->H; ++h) {
+    float *Gh = a.g + (size_t)h * g->B * g->Sq * L.Rp;
+    isi_src sg;
+    memset(&sg, 0, sizeof sg);
+    sg.ptr = Gh; sg.C = L.Rp; sg.sn = (int64_t)g->Sq * L.Rp; sg.sc = 1; sg.sh = L.Rp; sg.sw = L.Rp;
+    isi_src res;
+    memset(&res, 0, sizeof res);
+    res.ptr = ga->dq + (size_t)h * g->q_sh; res.C = HD; res.sn = g->q_sb; res.sc = 1; res.sh = g->q_ss; res.sw = g->q_ss;
+    isi_dst dst;
+    memset(&dst, 0, sizeof dst);
+    dst.ptr = ga->dq + (size_t)h * g->q_sh; dst.sn = g->q_sb; dst.sc = 1; dst.sh = g->q_ss; dst.sw = g->q_ss;
+    rc = conv2d_f32(&sg, nullptr, wT + (size_t)h * HD * KpT, nullptr, &res, &dst, g->B, g->Sq, 1, HD, 1, 1, 1, 0, 0,
+                    stream);
+    if (rc) return rc;
+    isi_src sq;
+    memset(&sq, 0, sizeof sq);
+    sq.ptr = g->q + (size_t)h * g->q_sh; sq.C = HD; sq.sn = g->q_sb; sq.sc = 1; sq.sh = g->q_ss; sq.sw = g->q_ss;
+    rc = conv_wgrad_f32(&sq, nullptr, Gh, ga->workspace + L.dw + (size_t)h * L.Rp * L.Kp, nullptr,
+                        ga->workspace + L.wg, L.wg_floats, g->B, g->Sq, 1, L.Rp, 1, 1, 1, 0, 0, stream);
+    if (rc) return rc;
+  }
+  {
+    const int64_t total = (int64_t)g->H * R * HD;
+    hipLaunchKernelGGL(unpack_drel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       ga->workspace + L.dw, ga->d_rel, g->H, R, HD, L.Rp, L.Kp);
+    rc = check_launch("unpack_drel");
+  }
+  return rc;
+}
+
+}  // namespace isi

@@ -33,7 +33,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct AttnKArgs {
   const float *q, *k, *v, *e, *mask;
-  float *out;
+  float *out, *lse;
   unsigned q_bytes, k_bytes, v_bytes, e_bytes;
   int Sq, Sk, H;
   int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void rel_attention_f32_kernel(const AttnKArgs 
   if (qi < p.Sq) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     float *orow = p.out + (size_t)qi * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
+    if (p.lse && half == 0) p.lse[((size_t)b * p.H + h) * p.Sq + qi] = l_run > 0.f ? m_run + logf(l_run) : 1e30f;
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -283,7 +284,7 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
                      reinterpret_cast<uintptr_t>(g->rel_embeddings)) & 15))
     return invalid("rel_attention: strides must be multiples of 4 floats and pointers 16-byte aligned");
   AttnKArgs a;
-  a.q = g->q; a.k = g->k; a.v = g->v; a.e = g->rel_embeddings; a.mask = g->dense_mask; a.out = g->out;
+  a.q = g->q; a.k = g->k; a.v = g->v; a.e = g->rel_embeddings; a.mask = g->dense_mask; a.out = g->out; a.lse = g->lse;
   a.q_bytes = (unsigned)(eq * 4); a.k_bytes = (unsigned)(ek * 4); a.v_bytes = (unsigned)(ev * 4);
   a.R = g->rel_rows;
   a.e_bytes = (unsigned)((size_t)g->H * g->rel_rows * g->head_dim * 4);

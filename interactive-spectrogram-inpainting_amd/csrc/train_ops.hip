@@ -10,15 +10,18 @@
 namespace isi {
 
 // dy *= (y > 0): ReLU backward through an output that was rectified in the producer's epilogue.
-__global__ void relu_bwd_kernel(float *__restrict__ dy, const float *__restrict__ y, int64_t n4) {
+__global__ void relu_bwd_kernel(float *__restrict__ dy, const float *__restrict__ y, int64_t n4, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  const int64_t first = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = first; i < n4; i += stride) {
     float4 g = reinterpret_cast<float4 *>(dy)[i];
     const float4 v = reinterpret_cast<const float4 *>(y)[i];
     g.x = v.x > 0.f ? g.x : 0.f; g.y = v.y > 0.f ? g.y : 0.f;
     g.z = v.z > 0.f ? g.z : 0.f; g.w = v.w > 0.f ? g.w : 0.f;
     reinterpret_cast<float4 *>(dy)[i] = g;
   }
+  const int64_t t = 4 * n4 + first;  // tail of a length that is not a multiple of 4
+  if (t < n) dy[t] = y[t] > 0.f ? dy[t] : 0.f;
 }
 
 // a += alpha * b
@@ -105,9 +108,11 @@ __global__ __launch_bounds__(1024) void vq_ema_update_kernel(float *__restrict__
 static unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 8192); }
 
 int relu_bwd_f32(float *dy, const float *y, int64_t n, hipStream_t st) {
-  if (!dy || !y || n < 0 || (n & 3)) return invalid("relu_bwd: bad argument (n % 4 == 0 required)");
+  if (!dy || !y || n < 0) return invalid("relu_bwd: bad argument");
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y)) & 15)
+    return invalid("relu_bwd: pointers must be 16-byte aligned");
   if (n == 0) return ISI_OK;
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, dy, y, n / 4);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, st, dy, y, n / 4, n);
   return check_launch("relu_bwd_f32");
 }
 

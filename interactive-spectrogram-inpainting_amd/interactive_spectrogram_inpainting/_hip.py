@@ -77,7 +77,13 @@ class isi_attn_args(C.Structure):
                 ("v_ss", C.c_int64), ("v_sb", C.c_int64), ("v_sh", C.c_int64),
                 ("o_ss", C.c_int64), ("o_sb", C.c_int64), ("o_sh", C.c_int64),
                 ("Cq", C.c_int), ("Ck", C.c_int), ("Ek", C.c_int), ("rel_rows", C.c_int),
-                ("mask_mode", C.c_int), ("scale", C.c_float)]
+                ("mask_mode", C.c_int), ("scale", C.c_float), ("lse", C.c_void_p)]
+
+
+class isi_attn_bwd_args(C.Structure):
+    _fields_ = [("fwd", isi_attn_args), ("d_out", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p),
+                ("dv", C.c_void_p), ("d_rel", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_floats", C.c_size_t)]
 
 
 ISI_MAX_LAYERS = 16
@@ -135,6 +141,13 @@ SIGNATURES = {
     "isi_resblock_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, _P]),
     "isi_rel_attention_f32": (C.c_int, [C.POINTER(isi_attn_args), _P]),
+    "isi_rel_attention_bwd_workspace_floats": (C.c_size_t, [C.POINTER(isi_attn_args)]),
+    "isi_rel_attention_bwd_f32": (C.c_int, [C.POINTER(isi_attn_bwd_args), _P]),
+    "isi_layernorm_bwd_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int]),
+    "isi_layernorm_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "isi_label_smoothing_loss_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_float,
+                                               _P]),
+    "isi_embedding_bwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "isi_rel_attention_decode_f32": (C.c_int, [C.POINTER(isi_attn_args), C.c_int, _P, _P]),
     "isi_rel_attention_decode_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "isi_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
@@ -190,7 +203,7 @@ def lib() -> C.CDLL:
                     fn.restype = res
                     fn.argtypes = args
                 structs = [isi_src, isi_dst, isi_conv_w, isi_encoder_w, isi_decoder_w, isi_codebook_w,
-                           isi_vqvae_w, isi_vqvae_out, isi_attn_args, isi_prior_w, isi_prior_state]
+                           isi_vqvae_w, isi_vqvae_out, isi_attn_args, isi_prior_w, isi_prior_state, isi_attn_bwd_args]
                 for i, st in enumerate(structs):
                     if handle.isi_abi_struct_bytes(i) != C.sizeof(st):
                         raise HipLibraryError(f"ABI mismatch for {st.__name__}: library "

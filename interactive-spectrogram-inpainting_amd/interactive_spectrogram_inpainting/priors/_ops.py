@@ -97,7 +97,7 @@ def _attn_args(q, k, v, rel, out, Sq, Sk, B, H, hd, Cq, Ck, Ek, mask_mode, dense
 
 def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Optional[torch.Tensor], nhead: int,
                   Cq: int, Ck: int, Ek: int, mask_mode: int = 0,
-                  dense_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  dense_mask: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [Sq,B,d], k/v [Sk,B,d] (any row strides, last dim contiguous; views into a
     fused qkv buffer are consumed in place) -> [Sq,B,d]."""
     _hip.require_gpu(q, "attention input")
@@ -110,6 +110,8 @@ def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Option
     a.k_ss, a.k_sb, a.k_sh = k.stride(0), k.stride(1), hd
     a.v_ss, a.v_sb, a.v_sh = v.stride(0), v.stride(1), hd
     a.o_ss, a.o_sb, a.o_sh = out.stride(0), out.stride(1), hd
+    if lse is not None:  # [B,H,Sq] log-sum-exp per query, kept for the backward
+        a.lse = lse.data_ptr()
     _hip.check(_hip.lib().isi_rel_attention_f32(C.byref(a), _s(q)), "isi_rel_attention_f32")
     return out
 

@@ -1,0 +1,213 @@
+"""Differentiable building blocks of the transformer prior on MI355X.
+
+The reference trains the prior with `loss.backward()` through the absent package's
+layers (train_autoregressive_model.py:203-257).  Here every heavy operator is a
+`torch.autograd.Function` whose forward AND backward are entry points of
+libisi_hip.so; torch autograd only chains them and handles the small index / concat
+plumbing of `VQNSynthTransformer.prepare_data` (priors/transformer.py:513-680).
+
+  Linear        y = x W^T + b (+relu) (+residual)   fwd: isi_conv2d_f32 (1x1 = GEMM)
+                                                    dX : the same GEMM with W^T packed
+                                                    dW, db: isi_conv_wgrad_f32 (row-reduction GEMM)
+  LayerNorm     LN(x + residual)                    isi_layernorm_f32 / isi_layernorm_bwd_f32
+  RelAttention  softmax((q.k + q.e[r]) * s + mask)v isi_rel_attention_f32 (+LSE) / isi_rel_attention_bwd_f32
+  LabelSmoothingLoss                                isi_label_smoothing_loss_f32 (loss and gradient in one pass)
+
+There is no CPU path: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from .. import _hip
+from . import _ops
+
+
+def _s(t):
+    return C.c_void_p(_hip.stream_ptr(t.device))
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2 if t2.is_contiguous() else t2.contiguous()
+
+
+def linear_wgrad(x2: torch.Tensor, dy2: torch.Tensor):
+    """x2 [M,K], dy2 [M,N] dense -> (dW [N,K] torch layout, db [N])."""
+    M, K = x2.shape
+    N = dy2.shape[1]
+    L = _hip.lib()
+    Kpad = (K + 31) // 32 * 32
+    nws = L.isi_conv_wgrad_workspace_floats(N, K, M, 1)
+    ws = torch.empty(nws, dtype=torch.float32, device=x2.device)
+    packed = torch.empty(N, Kpad, dtype=torch.float32, device=x2.device)
+    db = torch.empty(N, dtype=torch.float32, device=x2.device)
+    s0 = _hip.isi_src(x2.data_ptr(), K, 0, 1, 0, x2.stride(0))
+    rc = L.isi_conv_wgrad_f32(C.byref(s0), None, dy2.data_ptr(), packed.data_ptr(), db.data_ptr(), ws.data_ptr(), nws,
+                              1, 1, M, N, 1, 1, 1, 0, 0, _s(x2))
+    _hip.check(rc, "isi_conv_wgrad_f32 (linear)")
+    return (packed if Kpad == K else packed[:, :K]), db
+
+
+class LinearFn(torch.autograd.Function):
+    """y[..., N] = x[..., K] W^T + b, optionally rectified, optionally + residual (added before the ReLU)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, relu: bool, packed, packed_t_fn):
+        y = _ops.linear(x, packed, bias, weight.shape[0], relu=relu, residual=residual)
+        ctx.relu, ctx.packed_t_fn = relu, packed_t_fn
+        ctx.has_res = residual is not None
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        N, K = weight.shape
+        dy2 = _rows(dy)
+        if ctx.relu:
+            if dy2.data_ptr() == dy.data_ptr():
+                dy2 = dy2.clone()
+            _hip.check(_hip.lib().isi_relu_bwd_f32(dy2.data_ptr(), _rows(y).data_ptr(), dy2.numel(), _s(dy2)),
+                       "isi_relu_bwd_f32")
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K).reshape(x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, db = linear_wgrad(_rows(x), dy2)
+            if not ctx.has_bias:
+                db = None
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy2.reshape(dy.shape)
+        return dx, dw, db, dres, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """LayerNorm(x + residual) * gamma + beta over the last dimension."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, eps: float):
+        x = x.contiguous()
+        if residual is not None:
+            residual = residual.contiguous()
+        y = _ops.layernorm(x, gamma, beta, eps, residual=residual)
+        ctx.eps = eps
+        ctx.save_for_backward(x, residual, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, residual, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        D = x.shape[-1]
+        M = x.numel() // D
+        L = _hip.lib()
+        dz = torch.empty_like(x)
+        dg = torch.empty(D, dtype=torch.float32, device=x.device)
+        db = torch.empty(D, dtype=torch.float32, device=x.device)
+        ws = torch.empty(L.isi_layernorm_bwd_workspace_floats(M, D), dtype=torch.float32, device=x.device)
+        rc = L.isi_layernorm_bwd_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                     gamma.data_ptr(), dy.data_ptr(), dz.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                     ws.data_ptr(), M, D, ctx.eps, _s(x))
+        _hip.check(rc, "isi_layernorm_bwd_f32")
+        return dz, (dz if residual is not None else None), dg, db, None
+
+
+class RelAttentionFn(torch.autograd.Function):
+    """Attention over fused projection buffers, consumed and differentiated in place:
+    self-attention  a = qkv [S,B,3d], b = None;  cross-attention  a = q [Sq,B,d], b = k|v [Sk,B,2d];
+    rel [H,R,hd] or None -> [Sq,B,d].  The gradient of a (and b) is ONE buffer whose q / k / v
+    slices the backward kernels write directly."""
+
+    @staticmethod
+    def _split(a, b):
+        if b is None:
+            d = a.shape[-1] // 3
+            return a[..., :d], a[..., d:2 * d], a[..., 2 * d:]
+        d = a.shape[-1]
+        return a, b[..., :d], b[..., d:]
+
+    @staticmethod
+    def forward(ctx, a, b, rel, nhead, Cq, Ck, Ek, mask_mode, dense_mask):
+        a = a.contiguous()
+        b = b.contiguous() if b is not None else None
+        q, k, v = RelAttentionFn._split(a, b)
+        Sq, B, _ = q.shape
+        lse = torch.empty(B, nhead, Sq, dtype=torch.float32, device=q.device)
+        out = _ops.rel_attention(q, k, v, rel, nhead, Cq, Ck, Ek, mask_mode=mask_mode, dense_mask=dense_mask,
+                                 lse=lse)
+        ctx.cfg = (nhead, Cq, Ck, Ek, mask_mode)
+        ctx.save_for_backward(a, b, rel, out, lse, dense_mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a_in, b_in, rel, out, lse, dense_mask = ctx.saved_tensors
+        nhead, Cq, Ck, Ek, mask_mode = ctx.cfg
+        q, k, v = RelAttentionFn._split(a_in, b_in)
+        Sq, B, d = q.shape
+        Sk = k.shape[0]
+        hd = d // nhead
+        dout = dout.contiguous()
+        L = _hip.lib()
+        da = torch.empty_like(a_in)
+        db = torch.empty_like(b_in) if b_in is not None else None
+        dq, dk, dv = RelAttentionFn._split(da, db)
+        drel = torch.empty_like(rel) if rel is not None else None
+        a = _hip.isi_attn_bwd_args()
+        a.fwd = _ops._attn_args(q, k, v, rel, out, Sq, Sk, B, nhead, hd, Cq, Ck, Ek, mask_mode, dense_mask)
+        f = a.fwd
+        f.q_ss, f.q_sb, f.q_sh = q.stride(0), q.stride(1), hd
+        f.k_ss, f.k_sb, f.k_sh = k.stride(0), k.stride(1), hd
+        f.v_ss, f.v_sb, f.v_sh = v.stride(0), v.stride(1), hd
+        f.o_ss, f.o_sb, f.o_sh = out.stride(0), out.stride(1), hd
+        f.lse = lse.data_ptr()
+        a.d_out = dout.data_ptr()
+        a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        a.d_rel = drel.data_ptr() if drel is not None else None
+        nws = L.isi_rel_attention_bwd_workspace_floats(C.byref(a.fwd))
+        ws = torch.empty(nws, dtype=torch.float32, device=q.device)
+        a.workspace, a.workspace_floats = ws.data_ptr(), nws
+        _hip.check(L.isi_rel_attention_bwd_f32(C.byref(a), _s(q)), "isi_rel_attention_bwd_f32")
+        return da, db, drel, None, None, None, None, None, None
+
+
+class LabelSmoothingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits2, target1, num_classes: int, smoothing: float):
+        M, K = logits2.shape
+        row_loss = torch.empty(M, dtype=torch.float32, device=logits2.device)
+        grad = torch.empty_like(logits2) if logits2.requires_grad else None
+        rc = _hip.lib().isi_label_smoothing_loss_f32(
+            logits2.data_ptr(), target1.data_ptr(), row_loss.data_ptr(),
+            grad.data_ptr() if grad is not None else None, M, K, num_classes, smoothing, 1.0 / M, _s(logits2))
+        _hip.check(rc, "isi_label_smoothing_loss_f32")
+        ctx.save_for_backward(grad)
+        return row_loss.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None
+
+
+def label_smoothing_loss(pred: torch.Tensor, target: torch.Tensor, num_classes: int, smoothing: float,
+                         dim: int = 1) -> torch.Tensor:
+    """`LabelSmoothingLoss(num_classes, smoothing, dim)(pred, target)` (utils/losses/prediction.py:14-20):
+    class scores along `dim` of pred, int64 targets of pred's shape without that dim."""
+    _hip.require_gpu(pred, "logits")
+    dim = dim % pred.dim()
+    logits2 = pred.movedim(dim, -1)
+    K = logits2.shape[-1]
+    logits2 = logits2.reshape(-1, K)
+    if not logits2.is_contiguous():
+        logits2 = logits2.contiguous()
+    target1 = target.reshape(-1).contiguous()
+    if target1.numel() != logits2.shape[0]:
+        raise RuntimeError(f"target of shape {tuple(target.shape)} for predictions of shape {tuple(pred.shape)}")
+    return LabelSmoothingFn.apply(logits2, target1, int(num_classes), float(smoothing))

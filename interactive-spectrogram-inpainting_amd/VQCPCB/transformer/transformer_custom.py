@@ -16,6 +16,12 @@ matrices the reference builds (`causal_mask`, its transpose; recognised and
 replaced by an in-kernel predicate) or the strings 'causal' / 'anticausal'.
 Arithmetic: see oracle/prior_oracle.py (specification; parity unpinned because
 the original package is not available).
+
+Training: when autograd is recording, every operator runs through the
+`torch.autograd.Function`s of priors/_train.py (hand-written backward kernels).
+In `.train()` mode dropout(p) is applied where torch's post-norm layers apply it
+(after each attention output projection, after the feed-forward activation and
+after the second feed-forward linear); attention probabilities are not dropped.
 """
 from __future__ import annotations
 
@@ -27,6 +33,7 @@ import torch
 from torch import nn
 
 from interactive_spectrogram_inpainting.priors import _ops
+from interactive_spectrogram_inpainting.priors import _train
 
 MaskArg = Union[None, str, torch.Tensor]
 
@@ -43,6 +50,7 @@ class _LinearParams(nn.Module):
         bound = 1 / math.sqrt(in_features)
         nn.init.uniform_(self.bias, -bound, bound)
         self._packed, self._key = None, None
+        self._packed_t, self._key_t = None, None
 
     def packed(self):
         key = (self.weight._version, self.weight.data_ptr())
@@ -50,7 +58,16 @@ class _LinearParams(nn.Module):
             self._packed, self._key = _ops.pack_linear_weight(self.weight), key
         return self._packed
 
+    def packed_t(self):
+        """GEMM operand of the input gradient: W^T ([in, out]) packed like a forward weight."""
+        key = (self.weight._version, self.weight.data_ptr())
+        if self._key_t != key:
+            self._packed_t, self._key_t = _ops.pack_linear_weight(self.weight.detach().t().contiguous()), key
+        return self._packed_t
+
     def run(self, x, relu=False, residual=None):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return _train.LinearFn.apply(x, self.weight, self.bias, residual, relu, self.packed(), self.packed_t)
         return _ops.linear(x, self.packed(), self.bias, self.out_features, relu=relu, residual=residual)
 
 
@@ -61,8 +78,11 @@ class _LayerNormParams(nn.Module):
         self.bias = nn.Parameter(torch.zeros(d))
         self.eps = eps
 
-    def run(self, x):
-        return _ops.layernorm(x, self.weight, self.bias, self.eps)
+    def run(self, x, residual=None):
+        """LayerNorm(x + residual)."""
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            return _train.LayerNormFn.apply(x, residual, self.weight, self.bias, self.eps)
+        return _ops.layernorm(x, self.weight, self.bias, self.eps, residual=residual)
 
 
 def _classify_mask(mask: MaskArg, Sq: int, Sk: int, device) -> Tuple[int, Optional[torch.Tensor]]:
@@ -121,6 +141,26 @@ class RelativeMultiheadAttention(nn.Module):
         else:
             self.register_parameter("rel_embeddings", None)
         self._packed, self._key = None, None
+        self._packed_t, self._key_t = None, None
+
+    def _packs_t(self):
+        """W^T operands of the input gradients: (all three projections, q only, k|v)."""
+        key = (self.in_proj_weight._version, self.in_proj_weight.data_ptr())
+        if self._key_t != key:
+            d = self.d_model
+            W = self.in_proj_weight.detach()
+            self._packed_t = tuple(_ops.pack_linear_weight(w.t().contiguous()) for w in (W, W[:d], W[d:]))
+            self._key_t = key
+        return self._packed_t
+
+    def _project(self, x, which: int):
+        """which: 0 = q|k|v, 1 = q, 2 = k|v of the fused in-projection."""
+        d = self.d_model
+        lo, hi = ((0, 3 * d), (0, d), (d, 3 * d))[which]
+        W, b = self.in_proj_weight[lo:hi], self.in_proj_bias[lo:hi]
+        if torch.is_grad_enabled() and (x.requires_grad or self.in_proj_weight.requires_grad):
+            return _train.LinearFn.apply(x, W, b, None, False, self._packs()[which], lambda: self._packs_t()[which])
+        return _ops.linear(x, self._packs()[which], b, hi - lo)
 
     def _packs(self):
         key = (self.in_proj_weight._version, self.in_proj_weight.data_ptr())
@@ -134,28 +174,47 @@ class RelativeMultiheadAttention(nn.Module):
 
     def project_kv(self, mem: torch.Tensor) -> torch.Tensor:
         """[Sk,B,d] -> fused [Sk,B,2d] keys|values (cacheable: depends on mem only)."""
-        d = self.d_model
-        return _ops.linear(mem, self._packs()[2], self.in_proj_bias[d:], 2 * d)
+        return self._project(mem, 2)
 
     def forward(self, x: torch.Tensor, mem: Optional[torch.Tensor], mask: MaskArg = None,
                 kv: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Attention output BEFORE the output projection ([Sq,B,d]); `mem is None` = self-attention."""
         d = self.d_model
         Sq = x.shape[0]
-        w_all, w_q, _ = self._packs()
         if mem is None and kv is None:
-            qkv = _ops.linear(x, w_all, self.in_proj_bias, 3 * d)
-            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+            a, b = self._project(x, 0), None
+            Sk = Sq
         else:
-            q = _ops.linear(x, w_q, self.in_proj_bias[:d], d)
-            if kv is None:
-                kv = self.project_kv(mem)
-            k, v = kv[..., :d], kv[..., d:]
-        mode, dense = _classify_mask(mask, Sq, k.shape[0], x.device)
+            a = self._project(x, 1)
+            b = kv if kv is not None else self.project_kv(mem)
+            Sk = b.shape[0]
+        mode, dense = _classify_mask(mask, Sq, Sk, x.device)
+        if torch.is_grad_enabled() and a.requires_grad:
+            return _train.RelAttentionFn.apply(a, b, self.rel_embeddings, self.nhead, self.Cq, self.Ck, self.Ek,
+                                               mode, dense)
+        if b is None:
+            q, k, v = a[..., :d], a[..., d:2 * d], a[..., 2 * d:]
+        else:
+            q, k, v = a, b[..., :d], b[..., d:]
         return _ops.rel_attention(q, k, v, self.rel_embeddings, self.nhead, self.Cq, self.Ck, self.Ek,
                                   mask_mode=mode, dense_mask=dense)
 
 
+
+
+def _drop(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if layer.training and layer.dropout > 0:
+        return nn.functional.dropout(x, layer.dropout, True)
+    return x
+
+
+def _add_norm(layer: nn.Module, lin: _LinearParams, x: torch.Tensor, residual: torch.Tensor,
+              norm: _LayerNormParams) -> torch.Tensor:
+    """norm(residual + dropout(lin(x))): the residual add rides in the GEMM epilogue when nothing is
+    dropped, in the LayerNorm kernel otherwise."""
+    if layer.training and layer.dropout > 0:
+        return norm.run(nn.functional.dropout(lin.run(x), layer.dropout, True), residual=residual)
+    return norm.run(lin.run(x, residual=residual))
 
 
 class TransformerEncoderLayerCustom(nn.Module):
@@ -169,13 +228,13 @@ class TransformerEncoderLayerCustom(nn.Module):
         self.linear2 = _LinearParams(dim_feedforward, d_model)
         self.norm1 = _LayerNormParams(d_model)
         self.norm2 = _LayerNormParams(d_model)
-        self.dropout = dropout  # eval-only path: dropout is the identity
+        self.dropout = dropout  # identity in eval mode
 
     def forward(self, src: torch.Tensor, src_mask: MaskArg = None) -> torch.Tensor:
         a = self.self_attn(src, None, src_mask)
-        x = self.norm1.run(self.self_attn.out_proj.run(a, residual=src))
-        h = self.linear1.run(x, relu=True)
-        return self.norm2.run(self.linear2.run(h, residual=x))
+        x = _add_norm(self, self.self_attn.out_proj, a, src, self.norm1)
+        h = _drop(self, self.linear1.run(x, relu=True))
+        return _add_norm(self, self.linear2, h, x, self.norm2)
 
 
 class TransformerDecoderLayerCustom(nn.Module):
@@ -201,11 +260,11 @@ class TransformerDecoderLayerCustom(nn.Module):
     def forward(self, tgt: torch.Tensor, memory: torch.Tensor, tgt_mask: MaskArg = None,
                 memory_mask: MaskArg = None, memory_kv: Optional[torch.Tensor] = None) -> torch.Tensor:
         a = self.self_attn(tgt, None, tgt_mask)
-        x = self.norm1.run(self.self_attn.out_proj.run(a, residual=tgt))
+        x = _add_norm(self, self.self_attn.out_proj, a, tgt, self.norm1)
         c = self.multihead_attn(x, memory, memory_mask, kv=memory_kv)
-        x = self.norm2.run(self.multihead_attn.out_proj.run(c, residual=x))
-        h = self.linear1.run(x, relu=True)
-        return self.norm3.run(self.linear2.run(h, residual=x))
+        x = _add_norm(self, self.multihead_attn.out_proj, c, x, self.norm2)
+        h = _drop(self, self.linear1.run(x, relu=True))
+        return _add_norm(self, self.linear2, h, x, self.norm3)
 
 
 class TransformerAlignedDecoderLayerCustom(TransformerDecoderLayerCustom):

@@ -177,6 +177,28 @@ class RelAttentionFn(torch.autograd.Function):
         return da, db, drel, None, None, None, None, None, None
 
 
+class EmbeddingRowsFn(torch.autograd.Function):
+    """table[idx] with a dense, deterministic table gradient (nn.Embedding's backward)."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = table.shape[0]
+        return table[idx]
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        D = dy.shape[-1]
+        dy2 = _rows(dy)
+        sorted_idx, order = torch.sort(idx.reshape(-1), stable=True)
+        dw = torch.empty(ctx.rows, D, dtype=torch.float32, device=dy.device)
+        rc = _hip.lib().isi_embedding_bwd_f32(dy2.data_ptr(), sorted_idx.data_ptr(), order.data_ptr(), dw.data_ptr(),
+                                              dy2.shape[0], D, ctx.rows, _s(dy))
+        _hip.check(rc, "isi_embedding_bwd_f32")
+        return dw, None
+
+
 class LabelSmoothingFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits2, target1, num_classes: int, smoothing: float):

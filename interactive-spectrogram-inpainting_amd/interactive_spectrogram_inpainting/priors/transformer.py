@@ -29,6 +29,7 @@ from VQCPCB.transformer.transformer_custom import (
     TransformerDecoderLayerCustom, TransformerEncoderLayerCustom,
     TransformerAlignedDecoderLayerCustom, _LinearParams)
 
+from . import _train
 from .codemaps_helpers import CodemapsHelper, SimpleCodemapsHelper, ZigZagCodemapsHelper
 
 
@@ -241,6 +242,8 @@ class VQNSynthTransformer(nn.Module):
             raise ValueError(f"Unexpected value {kind} for kind option")
         key = (kind, emb.weight._version, emb.weight.data_ptr(), lin.weight._version, lin.weight.data_ptr(),
                lin.bias._version)
+        if self._differentiable():
+            return lin.run(emb.weight)  # recorded: gradients reach the embedding and the linear layer
         hit = self._tables.get(kind)
         if hit is None or hit[0] != key:
             with torch.no_grad():
@@ -248,10 +251,16 @@ class VQNSynthTransformer(nn.Module):
             self._tables[kind] = hit
         return hit[1]
 
+    def _differentiable(self) -> bool:
+        """The training path records autograd history; inference (eval / no_grad) uses cached tables."""
+        return self.training and torch.is_grad_enabled()
+
     def embed_data(self, input: torch.Tensor, kind: Seq2SeqInputKind) -> torch.Tensor:
         table = self._embedding_table(kind)
         if input.numel() and (int(input.min()) < 0 or int(input.max()) >= table.shape[0]):
             raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
+        if table.requires_grad:
+            return _train.EmbeddingRowsFn.apply(table, input)
         return table[input]
 
     def _get_combined_positional_embeddings(self, kind: Seq2SeqInputKind) -> torch.Tensor:
@@ -286,6 +295,22 @@ class VQNSynthTransformer(nn.Module):
         return torch.zeros(n, n).masked_fill(torch.eye(n) == 0, float('-inf'))
 
     # ---------------------------------------------------------------- sequences
+    def _helper(self, kind: str) -> CodemapsHelper:
+        if kind == 'source':
+            return self.source_codemaps_helper
+        if kind == 'target':
+            return self.target_codemaps_helper
+        raise ValueError(f"Unexpected value {kind} for kind option")
+
+    def to_time_frequency_map(self, sequence: torch.Tensor, kind: str,
+                              permute_output_as_logits: bool = False) -> torch.Tensor:
+        """What the reference's training loop calls on the model (train_autoregressive_model.py:233-234,
+        268-269); the arithmetic lives in the codemaps helpers (codemaps_helpers.py:16-243)."""
+        return self._helper(kind).to_time_frequency_map(sequence, permute_output_as_logits=permute_output_as_logits)
+
+    def flatten_map(self, codemap: torch.Tensor, kind: str) -> torch.Tensor:
+        return self._helper(kind).to_sequence(codemap)
+
     def to_sequences(self, input: torch.Tensor, condition: Optional[torch.Tensor] = None,
                      class_conditioning: Mapping[str, torch.Tensor] = {},
                      mask: Optional[torch.Tensor] = None,
@@ -304,10 +329,13 @@ class VQNSynthTransformer(nn.Module):
                                                time_indexes=time_indexes_target)
         return source_sequence, target_sequence
 
-    @torch.no_grad()
     def prepare_data(self, sequence: torch.Tensor, kind: Seq2SeqInputKind,
                      class_conditioning: Mapping[str, torch.Tensor] = {},
                      mask: Optional[torch.Tensor] = None, time_indexes: Optional[Iterable[int]] = None):
+        with torch.set_grad_enabled(self._differentiable()):
+            return self._prepare_data(sequence, kind, class_conditioning, mask, time_indexes)
+
+    def _prepare_data(self, sequence, kind, class_conditioning, mask, time_indexes):
         if mask is not None:
             sequence = sequence.masked_fill(mask, self.mask_token_index)
         embedded = self.embed_data(sequence, kind=kind)
@@ -338,21 +366,23 @@ class VQNSynthTransformer(nn.Module):
                          class_conditioning: Mapping[str, torch.Tensor], sequence_dim: int):
         batch_size = sequence_with_positions.shape[0]
         start = self.source_start_symbol if kind == Seq2SeqInputKind.Source else self.target_start_symbol
-        start = start.detach().repeat(batch_size, 1, 1)
+        start = start.repeat(batch_size, 1, 1)
         for name, cls in class_conditioning.items():
-            emb = self.class_conditioning_embedding_layers[name].weight.detach()[cls].squeeze(1)
+            emb = self.class_conditioning_embedding_layers[name].weight[cls].squeeze(1)
             p0 = self.class_conditioning_start_positions_per_modality[name]
             start[:, :, p0:p0 + emb.shape[1]] = emb.unsqueeze(1)
         return torch.cat([start, sequence_with_positions], dim=sequence_dim)
 
     # ---------------------------------------------------------------- forward
-    @torch.no_grad()
     def forward(self, input: torch.Tensor, condition: Optional[torch.Tensor] = None,
                 class_condition: Optional[torch.Tensor] = None, memory: Optional[torch.Tensor] = None):
         """input = prepared target sequence [B,S_t,d], condition = prepared source [B,S_s,d]
-        (priors/transformer.py:720-795).  Returns (logits [B,S,n_class], memory [S_s,B,d])."""
-        if self.training:
-            raise NotImplementedError("the training path of the prior (backward) is not built yet; call .eval()")
+        (priors/transformer.py:720-795).  Returns (logits [B,S,n_class], memory [S_s,B,d]).
+        Differentiable in `.train()` mode (priors/_train.py); inference never records history."""
+        with torch.set_grad_enabled(self._differentiable()):
+            return self._forward(input, condition, class_condition, memory)
+
+    def _forward(self, input, condition, class_condition, memory):
         if class_condition is not None:
             raise NotImplementedError("local class conditioning is deprecated in the reference")
         tgt = input.transpose(0, 1).contiguous()

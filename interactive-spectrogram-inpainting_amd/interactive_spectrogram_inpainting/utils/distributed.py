@@ -53,6 +53,73 @@ class DistributedEvalSampler(Sampler[int]):
         self.epoch = epoch
 
 
+class GradBucketReducer:
+    """Data-parallel gradient averaging for an autograd-driven model (the prior): replaces
+    the reference's `nn.DataParallel` (train_autoregressive_model.py:145) with one process
+    per GPU.  Parameter gradients live in ONE flat fp32 buffer (each `p.grad` is a view);
+    consecutive parameters form buckets, and as soon as autograd has accumulated every
+    gradient of a bucket (post-accumulate hooks; the backward reaches the last layers
+    first) the bucket is all-reduced asynchronously (RCCL on the GPU, gloo on CPU),
+    overlapping the rest of the backward.  `finish()` reduces whatever is left (parameters
+    that received no gradient keep zeros), waits, and divides by the world size."""
+
+    def __init__(self, params, bucket_mb: float = 32.0):
+        self.params = [p for p in params if p.requires_grad]
+        sizes = [p.numel() for p in self.params]
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        self.world = dist.get_world_size() if is_distributed() else 1
+        cap = max(1, int(bucket_mb * (1 << 20) / 4))
+        # buckets are filled from the LAST parameter backwards (the order the backward produces them)
+        self.buckets = []      # [start, end) element ranges
+        self.bucket_of = {}
+        off = sum(sizes)
+        end, count = off, 0
+        for i in range(len(self.params) - 1, -1, -1):
+            off -= sizes[i]
+            p = self.params[i]
+            p.grad = self.flat[off:off + sizes[i]].view_as(p)
+            self.bucket_of[id(p)] = len(self.buckets)
+            count += 1
+            if end - off >= cap or i == 0:
+                self.buckets.append([off, end, count])
+                end, count = off, 0
+        self.left = [b[2] for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+        if self.world > 1:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def zero(self) -> None:
+        """Call instead of `zero_grad()` (which would detach the views)."""
+        self.flat.zero_()
+        self.left = [b[2] for b in self.buckets]
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+
+    def _launch(self, b: int) -> None:
+        s, e, _ = self.buckets[b]
+        self.launched[b] = True
+        self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _on_grad(self, p) -> None:
+        b = self.bucket_of[id(p)]
+        self.left[b] -= 1
+        if self.left[b] == 0 and not self.launched[b]:
+            self._launch(b)
+
+    def finish(self) -> None:
+        if self.world == 1:
+            return
+        for b in range(len(self.buckets)):
+            if not self.launched[b]:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        self.flat.div_(self.world)
+
+
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
     """Slowest rank's value (used for step timing); identity when not distributed."""
     if not is_distributed():

@@ -358,11 +358,55 @@ def filtering_fixtures():
     _save("filtering.npz", **out)
 
 
+def scheduler_fixtures():
+    """LR (and beta1) traces of the schedules the training scripts use
+    (utils/training/scheduler.py: CycleScheduler, get_cosine_schedule_with_warmup)."""
+    from interactive_spectrogram_inpainting.utils.training.scheduler import (
+        CycleScheduler, get_cosine_schedule_with_warmup)
+    out = {}
+    for tag, n_iter, kw in (("a", 10, {}), ("b", 37, dict(divider=10, warmup_proportion=0.45)),
+                            ("c", 8, dict(momentum=None, phase=("cos", "linear")))):
+        w = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([w], lr=1.0)
+        # The reference class calls `_LRScheduler.__init__` FIRST, which itself calls `self.step()`
+        # before `lr_phase` exists (AttributeError on every torch release that has that base class);
+        # the schedule it describes is recorded here by skipping the base constructor.
+        base_init = torch.optim.lr_scheduler._LRScheduler.__init__
+        torch.optim.lr_scheduler._LRScheduler.__init__ = lambda self, optimizer, *a, **k: setattr(self, "optimizer", optimizer)
+        try:
+            sch = CycleScheduler(opt, 3e-4, n_iter=n_iter, **kw)
+        finally:
+            torch.optim.lr_scheduler._LRScheduler.__init__ = base_init
+        lrs, moms = [], []
+        for _ in range(2 * n_iter + 3):   # runs past the end of the cycle: it restarts
+            lr, mom = sch.step()
+            lrs.append(lr)
+            moms.append(opt.param_groups[0]["betas"][0])
+        out[f"cycle_{tag}::lr"], out[f"cycle_{tag}::beta1"] = np.array(lrs), np.array(moms)
+        out[f"cycle_{tag}::args"] = np.array([n_iter, kw.get("divider", 25), kw.get("warmup_proportion", 0.3)])
+    for tag, warm, total, cycles in (("a", 5, 40, 0.5), ("b", 0, 12, 0.5), ("c", 3, 20, 1.5)):
+        w = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([w], lr=0.01)
+        sch = get_cosine_schedule_with_warmup(opt, warm, total, num_cycles=cycles)
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(total + 4):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        out[f"cosine_{tag}::lr"] = np.array(lrs)
+        out[f"cosine_{tag}::args"] = np.array([warm, total, cycles])
+    _save("schedulers.npz", **out)
+
+
 def main():
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     _install_stubs()
     sys.path.insert(0, str(REF))
     torch.set_num_threads(4)
+    if len(sys.argv) > 1:   # regenerate only the named groups, e.g. `make_golden.py schedulers`
+        for name in sys.argv[1:]:
+            globals()[name + "_fixtures"]()
+        return
     # reduced config
     vqvae_fixture("vqvae_small.npz",
                   dict(in_channel=2, num_hidden_channels=32, n_res_block=2,
@@ -385,6 +429,7 @@ def main():
     codemap_fixtures()
     prior_wrapper_fixtures()
     filtering_fixtures()
+    scheduler_fixtures()
 
 
 if __name__ == "__main__":

@@ -155,3 +155,105 @@ def test_bucketed_gradient_allreduce_gloo():
     for rank, means, n_handles in out:
         assert all(abs(m - 1.5) < 1e-6 for m in means), means      # (1 + 2) / 2 on every rank
         assert n_handles >= 2                                        # more than one bucket was exchanged
+
+
+def test_lr_schedules_match_reference_traces(golden_dir):
+    """CycleScheduler / get_cosine_schedule_with_warmup (utils/training/scheduler.py) against LR and
+    beta1 traces recorded from the reference classes (oracle/make_golden.py::scheduler_fixtures)."""
+    from interactive_spectrogram_inpainting.utils.training.scheduler import (
+        CycleScheduler, get_cosine_schedule_with_warmup)
+    z = np.load(golden_dir / "schedulers.npz")
+    for tag, kw in (("a", {}), ("b", dict(divider=10, warmup_proportion=0.45)),
+                    ("c", dict(momentum=None, phase=("cos", "linear")))):
+        n_iter = int(z[f"cycle_{tag}::args"][0])
+        opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        sch = CycleScheduler(opt, 3e-4, n_iter=n_iter, **kw)
+        lrs, moms = [], []
+        for _ in range(len(z[f"cycle_{tag}::lr"])):
+            lr, _mom = sch.step()
+            assert lr == opt.param_groups[0]["lr"]
+            lrs.append(lr)
+            moms.append(opt.param_groups[0]["betas"][0])
+        np.testing.assert_allclose(lrs, z[f"cycle_{tag}::lr"], rtol=1e-12, atol=1e-18)
+        np.testing.assert_allclose(moms, z[f"cycle_{tag}::beta1"], rtol=1e-12)
+    for tag in "abc":
+        warm, total, cycles = z[f"cosine_{tag}::args"]
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.01)
+        sch = get_cosine_schedule_with_warmup(opt, int(warm), int(total), num_cycles=float(cycles))
+        lrs = [opt.param_groups[0]["lr"]]
+        for _ in range(len(z[f"cosine_{tag}::lr"]) - 1):
+            opt.step()
+            sch.step()
+            lrs.append(opt.param_groups[0]["lr"])
+        np.testing.assert_allclose(lrs, z[f"cosine_{tag}::lr"], rtol=1e-12, atol=1e-18)
+    # checkpointable
+    opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    a = CycleScheduler(opt, 1e-3, n_iter=10)
+    for _ in range(4):
+        a.step()
+    b = CycleScheduler(opt, 1e-3, n_iter=10)
+    b.load_state_dict(a.state_dict())
+    assert a.step() == b.step()
+
+
+def _reducer_worker(rank, world, port, q):
+    import os
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "interactive-spectrogram-inpainting_amd"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from interactive_spectrogram_inpainting.utils.distributed import GradBucketReducer
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 2))
+    unused = torch.nn.Parameter(torch.ones(4))       # a parameter the loss never touches
+    params = list(model.parameters()) + [unused]
+    red = GradBucketReducer(params, bucket_mb=1e-4)  # ~26 floats per bucket: several buckets
+    out = []
+    for step in range(2):                            # buffers are reused across steps
+        red.zero()
+        g = torch.Generator().manual_seed(10 * step + rank)
+        x = torch.randn(6, 5, generator=g)
+        model(x).square().sum().backward()
+        red.finish()
+        out.append([p.grad.flatten().tolist() for p in params])
+    q.put((rank, out, len(red.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_two_process_gloo():
+    """Autograd-driven DP of the prior: bucketed async all-reduce == mean of the per-rank gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + int(torch.randint(0, 2000, (1,)).item())
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        rank, out, nb = q.get(timeout=120)
+        got[rank] = out
+        assert nb >= 2
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3), torch.nn.Linear(3, 2))
+    for step in range(2):
+        grads = []
+        for rank in range(2):
+            model.zero_grad()
+            g = torch.Generator().manual_seed(10 * step + rank)
+            model(torch.randn(6, 5, generator=g)).square().sum().backward()
+            grads.append([p.grad.clone() for p in model.parameters()])
+        mean = [(a + b) / 2 for a, b in zip(*grads)]
+        for rank in range(2):
+            for g_, m in zip(got[rank][step][:-1], mean):
+                torch.testing.assert_close(torch.tensor(g_), m.flatten(), rtol=1e-6, atol=1e-7)
+            assert got[rank][step][-1] == [0.0] * 4   # untouched parameter: zeros, no hang

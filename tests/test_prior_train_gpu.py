@@ -175,3 +175,151 @@ def test_linear_layernorm_loss_backward_against_torch(golden_dir):
         _close(got, ref, 1e-5, "label smoothing loss")
         (got * 1.7).backward()
         _close(gp.grad, pred.grad, TOL, "label smoothing gradient")
+
+
+# ------------------------------------------------------------------ whole model
+COMMON = dict(n_class=32, channel=8, kernel_size=5, n_block=1, n_res_block=1, res_channel=8,
+              d_model=64, embeddings_dim=8, positional_embeddings_dim=8,
+              use_relative_transformer=True, predict_frequencies_first=True,
+              conditional_model=True, class_conditioning_prepend_to_dummy_input=True,
+              class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+              class_conditioning_embedding_dim_per_modality={"instrument_family_str": 16, "pitch": 16},
+              conditional_model_nhead=4, conditional_model_num_encoder_layers=2,
+              conditional_model_num_decoder_layers=3)
+
+
+def _cpu_prepare(model, P, code_map, kind, cls, mask_map=None):
+    """Plain-torch restatement of VQNSynthTransformer.prepare_data (priors/transformer.py:419-680) on
+    leaf copies P of the parameters: Embedding -> Linear -> (+ positional embeddings) -> start symbol
+    with the class-conditioning embeddings written into its leading dims."""
+    F_ = torch.nn.functional
+    src = kind == "source"
+    helper = model.source_codemaps_helper if src else model.target_codemaps_helper
+    seq = helper.to_sequence(code_map)
+    if mask_map is not None:
+        seq = seq.masked_fill(helper.to_sequence(mask_map), model.mask_token_index)
+    emb = F_.linear(F_.embedding(seq, P[f"{kind}_embed.weight"]), P[f"{kind}_embeddings_linear.weight"],
+                    P[f"{kind}_embeddings_linear.bias"])
+    if src:
+        freq = P["source_positional_embeddings_frequency"].repeat(1, 1, model.source_duration, 1)
+        pos = torch.cat([freq, freq], 3).reshape(1, model.source_frequencies, model.source_duration, -1)
+    else:
+        freq = P["target_positional_embeddings_frequency"].repeat(1, 1, model.target_duration, 1)
+        patch = P["target_positional_embeddings_patch"].repeat(1, model.source_frequencies, model.source_duration, 1)
+        pos = torch.cat([freq, patch], 3).reshape(1, model.target_frequencies, model.target_duration, -1)
+    B = code_map.shape[0]
+    x = torch.cat([emb, helper.to_sequence(pos).expand(B, -1, -1)], 2)
+    start = P[f"{kind}_start_symbol"].repeat(B, 1, 1)
+    for name, c in cls.items():
+        e = F_.embedding(c, P[f"class_conditioning_embedding_layers.{name}.weight"]).squeeze(1)
+        p0 = model.class_conditioning_start_positions_per_modality[name]
+        start[:, :, p0:p0 + e.shape[1]] = e.unsqueeze(1)
+    return torch.cat([start, x], 1)
+
+
+@pytest.mark.parametrize("level", ["top", "bottom"])
+def test_prior_training_step_gradients_against_spec(level):
+    """loss.backward() of one training batch (train_autoregressive_model.py:178-257 semantics, dropout 0):
+    every parameter gradient of the HIP path against torch autograd of the CPU specification."""
+    from oracle import prior_oracle as P_
+    from interactive_spectrogram_inpainting.priors.transformer import (
+        SelfAttentiveVQTransformer, UpsamplingVQTransformer)
+    from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss
+    torch.manual_seed(7)
+    if level == "top":
+        model = SelfAttentiveVQTransformer(shape=[8, 4], condition_shape=[8, 4], self_conditional_model=True,
+                                           add_mask_token_to_symbols=True, **COMMON)
+    else:
+        model = UpsamplingVQTransformer(shape=[16, 8], condition_shape=[8, 4], **COMMON)
+    for m in model.modules():
+        if hasattr(m, "dropout") and isinstance(m.dropout, float):
+            m.dropout = 0.0
+    B = 3
+    g = torch.Generator().manual_seed(8)
+    cls = {"instrument_family_str": torch.randint(0, 11, (B, 1), generator=g),
+           "pitch": torch.randint(0, 61, (B, 1), generator=g)}
+    top = torch.randint(0, 32, (B, 8, 4), generator=g)
+    bottom = torch.randint(0, 32, (B, 16, 8), generator=g)
+    mask = torch.rand(B, 8, 4, generator=g) < 0.5
+    target, cond = (top, top) if level == "top" else (bottom, top)
+
+    # ---- CPU specification with autograd
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    src = _cpu_prepare(model, P, cond, "source", cls, mask if level == "top" else None)
+    tgt = _cpu_prepare(model, P, target, "target", cls)
+    H = model.conditional_model_nhead
+    Ce, Ee = model.source_num_channels, model.source_num_events_with_start_symbol
+    Cd, Ed = model.target_num_channels, model.target_num_events_with_start_symbol
+    s, t = src.transpose(0, 1), tgt.transpose(0, 1)
+    enc_mask = P_.causal_mask(s.shape[0]).t() if model.self_conditional_model else None
+    memory = P_.encoder(s, P, "transformer.encoder.", model.conditional_model_num_encoder_layers, H, Ce, Ee, enc_mask)
+    out = P_.decoder(t, memory, P, "transformer.decoder.", model.conditional_model_num_decoder_layers, H,
+                     Cd, Ed, Ce, Ee, P_.causal_mask(t.shape[0]), None)
+    start = model.target_start_symbol.shape[1]
+    logits = torch.nn.functional.linear(out[start - 1:-1].transpose(0, 1),
+                                        P["project_transformer_outputs_to_logits.weight"],
+                                        P["project_transformer_outputs_to_logits.bias"])
+    ref_map = model.target_codemaps_helper.to_time_frequency_map(logits, permute_output_as_logits=True)
+    ref_loss = P_.label_smoothing_loss(ref_map, target, 32, 0.1, dim=1)
+    ref_loss.backward()
+
+    # ---- HIP path
+    dev = _dev()
+    model = model.to(dev).train()
+    dcls = {k: v.to(dev) for k, v in cls.items()}
+    src_g, tgt_g = model.to_sequences(target.to(dev), condition=cond.to(dev), class_conditioning=dcls,
+                                      mask=mask.to(dev) if level == "top" else None)
+    _close(src_g, src, 1e-5, "prepared source")
+    _close(tgt_g, tgt, 1e-5, "prepared target")
+    logits_g, _ = model(tgt_g, condition=src_g)
+    _close(logits_g, logits, 1e-4, "logits")
+    loss = LabelSmoothingLoss(32, 0.1, dim=1)(
+        model.to_time_frequency_map(logits_g, kind="target", permute_output_as_logits=True), target.to(dev))
+    _close(loss, ref_loss, 1e-5, "loss")
+    loss.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        ref = P[name].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, f"{name}: no gradient"
+        _close(p.grad, ref, 5e-4, name)
+        checked += 1
+    assert checked >= 60
+    # inference is untouched by the training machinery: eval forward records nothing
+    model.eval()
+    lg, _ = model(tgt_g.detach(), condition=src_g.detach())
+    assert not lg.requires_grad
+    _close(lg, logits, 1e-4, "eval logits")
+
+
+def test_run_model_epoch_decreases_loss():
+    """`run_model` (train_autoregressive_model.py:119-372): two epochs over a tiny fixed dataset with
+    Adam reduce the loss; returned sums are sample-weighted."""
+    import argparse
+    import train_autoregressive_model as T
+    from interactive_spectrogram_inpainting.priors.sequence_mask import BernoulliSequenceMask
+    from interactive_spectrogram_inpainting.priors.transformer import SelfAttentiveVQTransformer
+    from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss
+    dev = _dev()
+    torch.manual_seed(11)
+    model = SelfAttentiveVQTransformer(shape=[8, 4], condition_shape=[8, 4], self_conditional_model=True,
+                                       add_mask_token_to_symbols=True, **COMMON).to(dev)
+    data = T.SyntheticCodes(12, [8, 4], [16, 8], 32, {"instrument_family_str": 11, "pitch": 61}, seed=1)
+    loader = torch.utils.data.DataLoader(data, batch_size=5, shuffle=False)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    crit = LabelSmoothingLoss(32, 0.05, dim=1)
+    sampler = BernoulliSequenceMask(0.5, sequence_duration=model.source_transformer_sequence_length,
+                                    mask_token_index=model.mask_token_index)
+    args = argparse.Namespace(hier="top")
+    losses = []
+    for epoch in range(4):
+        loss_sum, acc_sum, n = T.run_model(args, epoch, loader, model, opt, None, dev, crit, is_training=True,
+                                           mask_sampler=sampler, clip_grad_norm=1.0)
+        assert n == 12 and 0.0 <= acc_sum / n <= 1.0
+        losses.append(loss_sum / n)
+    assert losses[-1] < losses[0], losses
+    v_loss, v_acc, n = T.run_model(args, 0, loader, model, opt, None, dev, crit, is_training=False, mask_sampler=sampler)
+    assert n == 12 and math.isfinite(v_loss)
+    assert all(p.grad is None or torch.isfinite(p.grad).all() for p in model.parameters())

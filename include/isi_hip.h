@@ -242,11 +242,6 @@ int isi_label_smoothing_loss_f32(const float *logits, const int64_t *target, flo
                                  float *dlogits, int64_t M, int K, int num_classes,
                                  float smoothing, float grad_scale, void *stream);
 
-/* Dense gradient of an nn.Embedding table [V,D] (transformer.py:292-300): dW[v] = sum of
- * dy[n] over the positions n whose index is v; sorted_idx / order = the indices sorted
- * ascending (stable) and the permutation that sorts them.  Deterministic. */
-int isi_embedding_bwd_f32(const float *dy, const int64_t *sorted_idx, const int64_t *order,
-                          float *dw, int64_t N, int D, int V, void *stream);
 
 /* out[m,:] = LayerNorm(x[m,:] + residual[m,:]) * gamma + beta  (residual may be NULL). */
 int isi_layernorm_f32(const float *x, const float *residual, const float *gamma,

@@ -94,10 +94,6 @@ int isi_label_smoothing_loss_f32(const float *logits, const int64_t *target, flo
                                  int K, int num_classes, float smoothing, float grad_scale, void *stream) {
   return label_smoothing_loss_f32(logits, target, row_loss, dlogits, M, K, num_classes, smoothing, grad_scale, S(stream));
 }
-int isi_embedding_bwd_f32(const float *dy, const int64_t *sorted_idx, const int64_t *order, float *dw, int64_t N, int D,
-                          int V, void *stream) {
-  return embedding_bwd_f32(dy, sorted_idx, order, dw, N, D, V, S(stream));
-}
 int isi_layernorm_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *out,
                       int64_t M, int D, float eps, void *stream) {
   return layernorm_f32(x, residual, gamma, beta, out, M, D, eps, S(stream));

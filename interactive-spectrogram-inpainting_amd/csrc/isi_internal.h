@@ -31,8 +31,6 @@ int layernorm_bwd_f32(const float *x, const float *res, const float *gamma, cons
                       hipStream_t stream);
 int label_smoothing_loss_f32(const float *logits, const int64_t *target, float *row_loss, float *dlogits, int64_t M,
                              int K, int num_classes, float smoothing, float grad_scale, hipStream_t stream);
-int embedding_bwd_f32(const float *dy, const int64_t *sorted_idx, const int64_t *order, float *dw, int64_t N,
-                      int D, int V, hipStream_t stream);
 int layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,
                   int64_t M, int D, float eps, hipStream_t stream);
 int linear_rows_f32(const float *x, int x_stride, const float *W, const float *bias, const float *res,

@@ -3,7 +3,6 @@
 //   label_smoothing_loss_f32 the criterion of the prior, forward and gradient in one pass
 //                            (reference utils/losses/prediction.py:5-20 behind
 //                            train_autoregressive_model.py:254-257)
-//   embedding_bwd_f32        dense gradient of an nn.Embedding table (sorted, deterministic)
 // All HBM-bound: one pass over the activations, 16-byte accesses, a wave per row.
 #include <algorithm>
 #include <cmath>
@@ -136,7 +135,7 @@ __global__ void layernorm_bwd_reduce_kernel(const float *__restrict__ partial, f
   (which ? dbeta : dgamma)[col] = s;
 }
 
-static int ln_bwd_blocks(int64_t M) { return (int)std::min<int64_t>(1024, (M + 15) / 16); }
+static int ln_bwd_blocks(int64_t M) { return (int)std::min<int64_t>(128, (M + 15) / 16); }
 
 size_t layernorm_bwd_workspace_floats(int64_t M, int D) { return M > 0 ? (size_t)ln_bwd_blocks(M) * 2 * D : 0; }
 
@@ -207,36 +206,6 @@ int label_smoothing_loss_f32(const float *logits, const int64_t *target, float *
   hipLaunchKernelGGL(label_smoothing_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, logits, target,
                      row_loss, dlogits, (int)M, K, num_classes, smoothing, grad_scale);
   return check_launch("label_smoothing_loss");
-}
-
-// dW[v, :] = sum over positions n with idx[n] == v of dy[n, :].  `order` = positions sorted by index
-// (stable), so that each table row is reduced by one wave over a contiguous run in a fixed order.
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float *__restrict__ dy,
-                                                            const int64_t *__restrict__ sorted_idx,
-                                                            const int64_t *__restrict__ order,
-                                                            float *__restrict__ dw, int64_t N, int D, int V) {
-  const int lane = threadIdx.x & 63;
-  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= V) return;
-  // lower / upper bound of v in sorted_idx
-  int64_t lo = 0, hi = N;
-  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_idx[mid] < v) lo = mid + 1; else hi = mid; }
-  const int64_t first = lo;
-  hi = N;
-  while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_idx[mid] <= v) lo = mid + 1; else hi = mid; }
-  const int64_t last = lo;
-  for (int c = lane; c < D; c += 64) {
-    float s = 0.f;
-    for (int64_t n = first; n < last; ++n) s += dy[(size_t)order[n] * D + c];
-    dw[(size_t)v * D + c] = s;
-  }
-}
-
-int embedding_bwd_f32(const float *dy, const int64_t *sorted_idx, const int64_t *order, float *dw, int64_t N,
-                      int D, int V, hipStream_t stream) {
-  if (!dy || !sorted_idx || !order || !dw || N <= 0 || D <= 0 || V <= 0) return invalid("embedding_bwd: bad argument");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, stream, dy, sorted_idx, order, dw, N, D, V);
-  return check_launch("embedding_bwd");
 }
 
 }  // namespace isi

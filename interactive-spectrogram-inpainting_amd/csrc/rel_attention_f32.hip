@@ -45,8 +45,15 @@ struct AttnKArgs {
 namespace {
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float NEG = -1e30f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr int QB = 128;        // queries per workgroup
-constexpr int BAND = 160;      // rows of e staged per key tile (>= 127/Cq + 31/Ck + 1)
+constexpr int BAND = 160;      // rows of e a key tile can touch (>= 127/Cq + 31/Ck + 1)
+constexpr int BAND2 = 192;     // rows a PAIR of key tiles can touch (>= 127/Cq + 63/Ck + 1)
+constexpr int RING = 192;      // rows of the band ring (>= BAND2: new rows replace rows no tile needs any more)
+__device__ __forceinline__ int ring_slot(int r) {
+  r %= RING;
+  return r < 0 ? r + RING : r;
+}
 constexpr int SRLD = 65;       // per-query row of the skew buffer (64 + 1: conflict-free)
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -59,22 +66,35 @@ __device__ __forceinline__ float elem(const float4 &v, int e) {
 __device__ __forceinline__ int mfma_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 }  // namespace
 
+// Workgroup = 8 waves = 128 consecutive queries of one (batch, head), in two groups of four waves.
+// Both groups own the same 4 x 32 queries; group g walks the key tiles of parity g with its own
+// online-softmax state (m, l, O) and the two states are merged at the end.  Two waves per SIMD: the
+// softmax / skew (VALU, LDS) phase of one overlaps the MFMAs of the other.
+//
+// Staging is software pipelined: while the waves work on a pair of key tiles, the global loads of
+// the next pair are already in flight into registers; they are written to LDS between two barriers.
+// The band of e lives in a ring of RING rows addressed by (table row mod RING): consecutive tile
+// pairs shift the band by at most 64 rows, so only 64 rows are (re)loaded per pair.
 template <int HD>
-__global__ __launch_bounds__(256) void rel_attention_f32_kernel(const AttnKArgs p) {
+__global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs p) {
   constexpr int LDH = HD + 4;  // padded LDS row
   constexpr int NQ = HD / 8;   // float4 fragments per lane along the head dim
   constexpr int NDB = (HD + 31) / 32;  // 32-wide blocks of the head dim in O
+  constexpr int NKQ = (HD / 4 + 7) / 8;  // staging quads per thread and row
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Ks = smem;                 // [32][LDH]
-  float *Vs = Ks + 32 * LDH;        // [32][LDH]
-  float *Eb = Vs + 32 * LDH;        // [BAND][LDH]
-  float *Sr = Eb + BAND * LDH;      // [4][32][SRLD]
-  int *evk = reinterpret_cast<int *>(Sr + 4 * 32 * SRLD);  // [32] evk_max - event(key)
+  float *Ks = smem;                    // [2][32][LDH]   tile of group 0 / group 1
+  float *Vs = Ks + 2 * 32 * LDH;       // [2][32][LDH]
+  float *Eb = Vs + 2 * 32 * LDH;       // [RING][LDH]
+  float *Sr = Eb + RING * LDH;         // [8][32][SRLD]
+  int *evk = reinterpret_cast<int *>(Sr + 8 * 32 * SRLD);  // [2][32] last event of the tile - event(key)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
   const int ql = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * QB, qw0 = q0 + 32 * wave, qi = qw0 + ql;
+  // causal rows: the last query blocks see the most keys -> launch them first
+  const int qblk = p.mask_mode == 1 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int q0 = qblk * QB, qw0 = q0 + 32 * wq, qi = qw0 + ql;
   const bool has_e = p.e != nullptr;
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
@@ -104,133 +124,227 @@ __global__ __launch_bounds__(256) void rel_attention_f32_kernel(const AttnKArgs 
   if (p.mask_mode == 1) k_end = min(p.Sk, q0 + QB);
   if (p.mask_mode == 2) k_begin = (q0 / 32) * 32;
 
-  const int srow = tid >> 3, squad = tid & 7;  // staging: 32 rows x 8 quads per pass
-
-  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-    const int evk_max = (k0 + 31) / p.Ck;
-    const int rb = evq_b0 - evk_max + p.Ek - 1;  // first table row of the band
-    __syncthreads();
-    // ---- stage K, V (32 x HD) and the band of e (BAND x HD)
-    for (int qd = squad; qd < HD / 4; qd += 8) {
-      const int kj = k0 + srow;
-      const bool ok = kj < p.Sk;
-      *reinterpret_cast<float4 *>(Ks + srow * LDH + qd * 4) =
-          buf_load4(rk, ok ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + qd * 4) * 4u : OOB);
-      *reinterpret_cast<float4 *>(Vs + srow * LDH + qd * 4) =
-          buf_load4(rv, ok ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + qd * 4) * 4u : OOB);
+  // staging role: tile st of the pair, row srow, quads squad + 8 i
+  const int st = tid >> 8, srow = (tid >> 3) & 31, squad = tid & 7;
+  float4 pk[NKQ], pv[NKQ], pe[NKQ];
+  // first table row of the band of the key tile that starts at k
+  auto band0 = [&](int k) { return evq_b0 - (k + 31) / p.Ck + p.Ek - 1; };
+  auto prefetch = [&](int k0) {  // K, V rows of the pair at k0 and the 64 lowest rows of its band
+    const int kj = k0 + 32 * st + srow;
+    const bool ok = kj < p.Sk;
+    const int r = band0(k0 + 32) + 32 * st + srow;
+    const bool rok = has_e && r >= 0 && r < p.R;
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      const bool in = qd < HD / 4;
+      pk[i] = buf_load4(rk, ok && in ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + qd * 4) * 4u : OOB);
+      pv[i] = buf_load4(rv, ok && in ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + qd * 4) * 4u : OOB);
+      pe[i] = buf_load4(re, rok && in ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
     }
+  };
+  auto commit = [&](int k0) {
+    const int slot = ring_slot(band0(k0 + 32) + 32 * st + srow);
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      if (qd < HD / 4) {
+        *reinterpret_cast<float4 *>(Ks + (st * 32 + srow) * LDH + qd * 4) = pk[i];
+        *reinterpret_cast<float4 *>(Vs + (st * 32 + srow) * LDH + qd * 4) = pv[i];
+        if (has_e) *reinterpret_cast<float4 *>(Eb + slot * LDH + qd * 4) = pe[i];
+      }
+    }
+    if (tid < 64) {
+      const int kt = k0 + (tid & 32);
+      evk[tid] = (kt + 31) / p.Ck - (kt + (tid & 31)) / p.Ck;
+    }
+  };
+
+  // ---- prologue: first pair and the rest of its band (BAND2 rows from band0 of the pair's second tile)
+  if (k_begin < k_end) {
+    prefetch(k_begin);
+    commit(k_begin);
     if (has_e) {
-      for (int row = srow; row < BAND; row += 32) {
+      const int rb = band0(k_begin + 32);
+      for (int row = 64 + (tid >> 3); row < BAND2; row += 64) {
         const int r = rb + row;
         const bool ok = r >= 0 && r < p.R;
         for (int qd = squad; qd < HD / 4; qd += 8)
-          *reinterpret_cast<float4 *>(Eb + row * LDH + qd * 4) =
+          *reinterpret_cast<float4 *>(Eb + ring_slot(r) * LDH + qd * 4) =
               buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
       }
     }
-    if (tid < 32) evk[tid] = evk_max - (k0 + tid) / p.Ck;
-    __syncthreads();
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): Q and the prologue are in; in-loop waits then only cover the prefetch
+  __syncthreads();
+  const float scale2 = p.scale * LOG2E;
+  // (last event of a key tile) - event(key): the same for every tile when Ck divides 32
+  const bool ck_regular = (32 % p.Ck) == 0;
+  int evoff[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) evoff[r] = 31 / p.Ck - mfma_row(r, half) / p.Ck;
+  const float *Kb = Ks + grp * 32 * LDH, *Vb = Vs + grp * 32 * LDH;
+  const int *evkb = evk + grp * 32;
+
+  for (int kp = k_begin; kp < k_end; kp += 64) {
+    const bool more = kp + 64 < k_end;
+    if (more) prefetch(kp + 64);
+    const int k0 = kp + 32 * grp;  // this group's tile
+    const int rb = band0(k0);
 
     // does this wave's query tile see any key of this tile?
-    bool live = qw0 < p.Sq;
+    bool live = qw0 < p.Sq && k0 < k_end;
     if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
     if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
-    if (!live) continue;  // wave-uniform
-
-    // ---- S^T = K Q^T
-    f32x16 sacc;
+    if (live) {  // wave-uniform
+      // ---- S^T = K Q^T
+      f32x16 sacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    {
-      const float *kr = Ks + ql * LDH + half * 4;
-#pragma unroll
-      for (int s = 0; s < NQ; ++s) {
-        const float4 kf = *reinterpret_cast<const float4 *>(kr + s * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(kf, e), elem(qf[s], e), sacc, 0, 0, 0);
-      }
-    }
-    float sv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
-
-    // ---- relative logits through the skew buffer
-    if (has_e) {
-      float *sr = Sr + wave * 32 * SRLD + ql * SRLD;
-      const int wrow0 = evq_w0 - evq_b0;  // this wave's first band row
-      const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;  // 32-row tiles of the band actually reachable
-      for (int t = 0; t < nt; ++t) {
-        f32x16 racc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-        const float *er = Eb + (wrow0 + 32 * t + ql) * LDH + half * 4;
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      {
+        const float *kr = Kb + ql * LDH + half * 4;
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
-          const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+          const float4 kf = *reinterpret_cast<const float4 *>(kr + s * 8);
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(ef, e), elem(qf[s], e), racc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(kf, e), elem(qf[s], e), sacc, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sr[32 * t + mfma_row(r, half)] = racc[r];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int dq = evq - evq_w0;
+      float sv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evk[mfma_row(r, half)]];
-      __builtin_amdgcn_wave_barrier();
-    }
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
 
-    // ---- scale, mask, online softmax (this lane: query qi, 16 of the tile's keys)
-    float tmax = NEG;
+      // ---- relative logits through the skew buffer
+      if (has_e) {
+        float *sr = Sr + wave * 32 * SRLD + ql * SRLD;
+        const int wrow0 = rb + evq_w0 - evq_b0;  // table row of this wave's first band row
+        const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;  // 32-row tiles of the band actually reachable
+        for (int t = 0; t < nt; ++t) {
+          f32x16 racc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kj = k0 + mfma_row(r, half);
-      bool ok = kj < p.Sk;
-      if (p.mask_mode == 1) ok = ok && kj <= qi;
-      if (p.mask_mode == 2) ok = ok && kj >= qi;
-      float s = sv[r] * p.scale;
-      if (p.mask && ok && qi < p.Sq) s += p.mask[(size_t)qi * p.Sk + kj];
-      s = ok ? s : NEG;
-      sv[r] = s;
-      tmax = fmaxf(tmax, s);
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = expf(m_run - m_new);
-    float psum = 0.f;
+          for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+          const float *er = Eb + ring_slot(wrow0 + 32 * t + ql) * LDH + half * 4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pr = sv[r] <= -1e29f ? 0.f : expf(sv[r] - m_new);
-      sv[r] = pr;
-      psum += pr;
-    }
-    psum += __shfl_xor(psum, 32);
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+          for (int s = 0; s < NQ; ++s) {
+            const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(ef, e), elem(qf[s], e), racc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sr[32 * t + mfma_row(r, half)] = racc[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int dq = evq - evq_w0;
+        if (ck_regular) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evoff[r]];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evkb[mfma_row(r, half)]];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
 
-    // ---- O^T = alpha * O^T + V^T P^T
+      // ---- scale, mask, online softmax (this lane: query qi, 16 of the tile's keys)
+      // (logits are kept in base 2: exp2 is one v_exp_f32; m_run, tmax are base-2 maxima)
+      float tmax = NEG;
+      // tiles entirely inside the visible region need no per-element predicate
+      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < p.Sq;
+      if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
+      if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
+      if (full) {
 #pragma unroll
-    for (int d = 0; d < NDB; ++d) {
+        for (int r = 0; r < 16; ++r) {
+          sv[r] *= scale2;
+          tmax = fmaxf(tmax, sv[r]);
+        }
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
-      const int dcol = d * 32 + ql;
+        for (int r = 0; r < 16; ++r) {
+          const int kj = k0 + mfma_row(r, half);
+          bool ok = kj < p.Sk;
+          if (p.mask_mode == 1) ok = ok && kj <= qi;
+          if (p.mask_mode == 2) ok = ok && kj >= qi;
+          float s = sv[r] * scale2;
+          if (p.mask && ok && qi < p.Sq) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          s = ok ? s : NEG;
+          sv[r] = s;
+          tmax = fmaxf(tmax, s);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.f;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const float vv = dcol < HD ? Vs[mfma_row(t, half) * LDH + dcol] : 0.f;
-        O[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sv[t], O[d], 0, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        const float pr = sv[r] <= -1e29f ? 0.f : __builtin_amdgcn_exp2f(sv[r] - m_new);
+        sv[r] = pr;
+        psum += pr;
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+
+      // ---- O^T = alpha * O^T + V^T P^T   (the running maximum settles after a few tiles:
+      //      skip the rescale when no lane of the wave needs it)
+      const bool rescale = __any(alpha != 1.f);
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        if (rescale) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+        }
+        const int dcol = d * 32 + ql;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float vv = dcol < HD ? Vb[mfma_row(t, half) * LDH + dcol] : 0.f;
+          O[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, sv[t], O[d], 0, 0, 0);
+        }
       }
     }
+    __syncthreads();           // every wave is done with this pair's tiles
+    if (more) commit(kp + 64);
+    __syncthreads();
+  }
+
+  // ---- merge the two groups' softmax states (group 1 -> LDS -> group 0)
+  float *mg = smem;            // [4][NDB*16 + 2][64]
+  constexpr int MGW = (NDB * 16 + 2) * 64;
+  if (grp == 1) {
+    float *dst = mg + wq * MGW + lane;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = O[d][r];
+    dst[NDB * 16 * 64] = m_run;
+    dst[(NDB * 16 + 1) * 64] = l_run;
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  {
+    const float *src = mg + wq * MGW + lane;
+    const float m1 = src[NDB * 16 * 64], l1 = src[(NDB * 16 + 1) * 64];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    l_run = l_run * a0 + l1 * a1;
+    m_run = m;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[d][r] = O[d][r] * a0 + src[(d * 16 + r) * 64] * a1;
   }
 
   // ---- normalise and store: accumulator regs 4g..4g+3 are 4 consecutive head dims
   if (qi < p.Sq) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     float *orow = p.out + (size_t)qi * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
-    if (p.lse && half == 0) p.lse[((size_t)b * p.H + h) * p.Sq + qi] = l_run > 0.f ? m_run + logf(l_run) : 1e30f;
+    if (p.lse && half == 0)  // natural-log domain
+      p.lse[((size_t)b * p.H + h) * p.Sq + qi] = l_run > 0.f ? m_run * LN2 + logf(l_run) : 1e30f;
 #pragma unroll
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -246,7 +360,7 @@ __global__ __launch_bounds__(256) void rel_attention_f32_kernel(const AttnKArgs 
 template <int HD>
 static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
   auto kern = rel_attention_f32_kernel<HD>;
-  constexpr size_t smem = (size_t)((64 + BAND) * (HD + 4) + 4 * 32 * SRLD) * sizeof(float) + 32 * sizeof(int);
+  constexpr size_t smem = (size_t)((128 + RING) * (HD + 4) + 8 * 32 * SRLD) * sizeof(float) + 64 * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -257,7 +371,7 @@ static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * B;
   prof::Scope scope(prof::K_REL_ATTENTION, 2.0 * pairs * HD * (a.e ? 3 : 2),
                     4.0 * B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), stream);
-  hipLaunchKernelGGL(kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(512), smem, stream, a);
   return check_launch("rel_attention_f32");
 }
 

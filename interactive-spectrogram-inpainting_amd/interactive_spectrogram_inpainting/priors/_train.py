@@ -178,7 +178,9 @@ class RelAttentionFn(torch.autograd.Function):
 
 
 class EmbeddingRowsFn(torch.autograd.Function):
-    """table[idx] with a dense, deterministic table gradient (nn.Embedding's backward)."""
+    """table[idx] with a dense, deterministic table gradient (nn.Embedding's backward):
+    dTable = onehot(idx)^T dy, the one-hot GEMM of the codebook statistics
+    (isi_vq_embed_sum_f32: the one-hot operand is generated on the fly, never stored)."""
 
     @staticmethod
     def forward(ctx, table, idx):
@@ -191,12 +193,16 @@ class EmbeddingRowsFn(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         D = dy.shape[-1]
         dy2 = _rows(dy)
-        sorted_idx, order = torch.sort(idx.reshape(-1), stable=True)
-        dw = torch.empty(ctx.rows, D, dtype=torch.float32, device=dy.device)
-        rc = _hip.lib().isi_embedding_bwd_f32(dy2.data_ptr(), sorted_idx.data_ptr(), order.data_ptr(), dw.data_ptr(),
-                                              dy2.shape[0], D, ctx.rows, _s(dy))
-        _hip.check(rc, "isi_embedding_bwd_f32")
-        return dw, None
+        N = dy2.shape[0]
+        Vp = (ctx.rows + 31) // 32 * 32
+        L = _hip.lib()
+        out = torch.empty(D, Vp, dtype=torch.float32, device=dy.device)
+        nws = L.isi_vq_embed_sum_workspace_floats(D, Vp, N)
+        ws = torch.empty(nws, dtype=torch.float32, device=dy.device)
+        rc = L.isi_vq_embed_sum_f32(dy2.data_ptr(), idx.reshape(-1).contiguous().data_ptr(), out.data_ptr(),
+                                    ws.data_ptr(), nws, N, D, Vp, _s(dy))
+        _hip.check(rc, "isi_vq_embed_sum_f32 (embedding backward)")
+        return out.t()[:ctx.rows], None
 
 
 class LabelSmoothingFn(torch.autograd.Function):

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Relative-attention micro-benchmark: forward and backward kernels at the top prior's
+shape (B=8, H=8, S=1025, head_dim 64, fp32), causal and dense.  Prices against the DENSE
+flop count 2*S*S*hd per GEMM (3 GEMMs forward incl. the relative logits, 7 backward)."""
+import argparse
+import pathlib
+import sys
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
+import torch  # noqa: E402
+from interactive_spectrogram_inpainting.priors._train import RelAttentionFn  # noqa: E402
+
+
+def timed(fn, n=5):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--H", type=int, default=8)
+    ap.add_argument("--S", type=int, default=1025)
+    ap.add_argument("--hd", type=int, default=64)
+    ap.add_argument("--modes", type=int, nargs="*", default=[1, 0])
+    ap.add_argument("--fwd-only", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, H, S, hd = a.B, a.H, a.S, a.hd
+    d = H * hd
+    torch.manual_seed(0)
+    qkv = torch.randn(S, B, 3 * d, device=dev, requires_grad=True)
+    rel = (torch.randn(H, 2 * S - 1, hd, device=dev) * 0.1).requires_grad_(True)
+    w = torch.randn(S, B, d, device=dev)
+    for mode in a.modes:
+        with torch.no_grad():
+            t_f = timed(lambda: RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, mode, None))
+        dense = 2.0 * S * S * hd * B * H
+        line = f"mode {mode}: fwd {t_f:8.1f} us  {3 * dense / t_f / 1e6:6.1f} TF(dense)"
+        if not a.fwd_only:
+            out = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, mode, None)
+
+            def bwd():
+                qkv.grad = None
+                rel.grad = None
+                out.backward(w, retain_graph=True)
+            t_b = timed(bwd)
+            line += f" | bwd {t_b:8.1f} us  {7 * dense / t_b / 1e6:6.1f} TF(dense)"
+        print(line)
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,7 @@ struct AttnBwdKArgs {
   int Sq, Sk, H, B;
   int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
   int Cq, Ck, Ek, R, Rp;
+  int rho_lo;             // G column c holds table row rho_lo + c (causal modes only touch half of the table)
   int mask_mode;
   float scale;
 };
@@ -49,7 +50,9 @@ struct AttnBwdKArgs {
 namespace {
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int QB = 128;        // queries (keys) per workgroup
-constexpr int BAND = 160;      // rows of e staged per tile
+constexpr int BAND = 160;      // rows of e a tile can touch
+constexpr int RING = 256;      // rows of the band ring (power of two, >= BAND + 32)
+constexpr float LOG2E = 1.4426950408889634f;
 constexpr int SRLD = 65;       // row of the per-wave skew buffer
 constexpr int TLD = 33;        // row of the per-wave transpose buffer (aliases the skew buffer)
 
@@ -89,17 +92,19 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_q_kernel(const AttnBwdK
   constexpr int LDH = HD + 4;
   constexpr int NQ = HD / 8;
   constexpr int NDB = (HD + 31) / 32;
+  constexpr int NKQ = (HD / 4 + 7) / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Ks = smem;                 // [32][LDH]
-  float *Vs = Ks + 32 * LDH;        // [32][LDH]
-  float *Eb = Vs + 32 * LDH;        // [BAND][LDH]
-  float *Sr = Eb + BAND * LDH;      // [4][32][SRLD]
-  int *evk = reinterpret_cast<int *>(Sr + 4 * 32 * SRLD);  // [32] evk_max - event(key)
+  float *Ks = smem;                    // [2][32][LDH]
+  float *Vs = Ks + 2 * 32 * LDH;       // [2][32][LDH]
+  float *Eb = Vs + 2 * 32 * LDH;       // [RING][LDH]
+  float *Sr = Eb + RING * LDH;         // [4][32][SRLD]
+  int *evk = reinterpret_cast<int *>(Sr + 4 * 32 * SRLD);  // [2][32] evk_max - event(key)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * QB, qw0 = q0 + 32 * wave, qi = qw0 + ql;
+  const int qblk = p.mask_mode == 1 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;  // heavy blocks first
+  const int q0 = qblk * QB, qw0 = q0 + 32 * wave, qi = qw0 + ql;
   const bool has_e = p.e != nullptr;
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_q_kernel(const AttnBwdK
     dof[s] = buf_load4(rdo, ok ? (unsigned)(qi * p.o_ss + b * p.o_sb + h * p.o_sh + (2 * s + half) * 4) * 4u : OOB);
   }
   const int stat = (b * p.H + h) * p.Sq + qi;
-  const float lse_i = qi < p.Sq ? p.lse[stat] : 0.f;
+  const float lse2 = (qi < p.Sq ? p.lse[stat] : 0.f) * LOG2E;
   const float dsum_i = qi < p.Sq ? p.dsum[stat] : 0.f;
   const int evq = qi / p.Cq;
   const int evq_w0 = qw0 / p.Cq, evq_b0 = q0 / p.Cq;
@@ -134,125 +139,171 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_q_kernel(const AttnBwdK
 
   const int srow = tid >> 3, squad = tid & 7;
   float *gbase = p.g + ((size_t)h * p.B + b) * p.Sq * p.Rp;
-
-  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
-    const int evk_max = (k0 + 31) / p.Ck;
-    const int rb = evq_b0 - evk_max + p.Ek - 1;
-    __syncthreads();
-    for (int qd = squad; qd < HD / 4; qd += 8) {
-      const int kj = k0 + srow;
-      const bool ok = kj < p.Sk;
-      *reinterpret_cast<float4 *>(Ks + srow * LDH + qd * 4) =
-          buf_load4(rk, ok ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + qd * 4) * 4u : OOB);
-      *reinterpret_cast<float4 *>(Vs + srow * LDH + qd * 4) =
-          buf_load4(rv, ok ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + qd * 4) * 4u : OOB);
+  float4 pk[NKQ], pv[NKQ], pe[NKQ];
+  auto band0 = [&](int k0) { return evq_b0 - (k0 + 31) / p.Ck + p.Ek - 1; };
+  auto prefetch = [&](int k0) {
+    const int kj = k0 + srow;
+    const bool ok = kj < p.Sk;
+    const int r = band0(k0) + srow;
+    const bool rok = has_e && r >= 0 && r < p.R;
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      const bool in = qd < HD / 4;
+      pk[i] = buf_load4(rk, ok && in ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + qd * 4) * 4u : OOB);
+      pv[i] = buf_load4(rv, ok && in ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + qd * 4) * 4u : OOB);
+      pe[i] = buf_load4(re, rok && in ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
     }
+  };
+  auto commit = [&](int k0, int buf) {
+    const int slot = (band0(k0) + srow) & (RING - 1);
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      if (qd < HD / 4) {
+        *reinterpret_cast<float4 *>(Ks + (buf * 32 + srow) * LDH + qd * 4) = pk[i];
+        *reinterpret_cast<float4 *>(Vs + (buf * 32 + srow) * LDH + qd * 4) = pv[i];
+        if (has_e) *reinterpret_cast<float4 *>(Eb + slot * LDH + qd * 4) = pe[i];
+      }
+    }
+    if (tid < 32) evk[buf * 32 + tid] = (k0 + 31) / p.Ck - (k0 + tid) / p.Ck;
+  };
+
+  if (k_begin < k_end) {
+    prefetch(k_begin);
+    commit(k_begin, 0);
     if (has_e) {
-      for (int row = srow; row < BAND; row += 32) {
+      const int rb = band0(k_begin);
+      for (int row = 32 + srow; row < BAND; row += 32) {
         const int r = rb + row;
         const bool ok = r >= 0 && r < p.R;
         for (int qd = squad; qd < HD / 4; qd += 8)
-          *reinterpret_cast<float4 *>(Eb + row * LDH + qd * 4) =
+          *reinterpret_cast<float4 *>(Eb + (r & (RING - 1)) * LDH + qd * 4) =
               buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
       }
     }
-    if (tid < 32) evk[tid] = evk_max - (k0 + tid) / p.Ck;
-    __syncthreads();
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): fragments and prologue are in
+  __syncthreads();
+  const float scale2 = p.scale * LOG2E;
+
+  int buf = 0;
+  for (int k0 = k_begin; k0 < k_end; k0 += 32, buf ^= 1) {
+    const bool more = k0 + 32 < k_end;
+    if (more) prefetch(k0 + 32);
+    const int rb = band0(k0);
+    const float *Kb = Ks + buf * 32 * LDH, *Vb = Vs + buf * 32 * LDH;
+    const int *evkb = evk + buf * 32;
 
     bool live = qw0 < p.Sq;
     if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
     if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
-    if (!live) continue;  // wave-uniform
-
-    // ---- S^T = K Q^T and dP^T = V dO^T  (rows = keys, this lane's column = its query)
-    f32x16 sacc, dpacc;
+    if (live) {  // wave-uniform
+      // ---- S^T = K Q^T and dP^T = V dO^T  (rows = keys, this lane's column = its query)
+      f32x16 sacc, dpacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-    {
-      const float *kr = Ks + ql * LDH + half * 4;
-      const float *vr = Vs + ql * LDH + half * 4;
-#pragma unroll
-      for (int s = 0; s < NQ; ++s) {
-        const float4 kf = *reinterpret_cast<const float4 *>(kr + s * 8);
-        const float4 vf = *reinterpret_cast<const float4 *>(vr + s * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(kf, e), elem(qf[s], e), sacc, 0, 0, 0);
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(vf, e), elem(dof[s], e), dpacc, 0, 0, 0);
-        }
-      }
-    }
-    float sv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
-
-    float *sr = Sr + wave * 32 * SRLD + ql * SRLD;
-    if (has_e) {
-      const int wrow0 = evq_w0 - evq_b0;
-      const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
-      for (int t = 0; t < nt; ++t) {
-        f32x16 racc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-        const float *er = Eb + (wrow0 + 32 * t + ql) * LDH + half * 4;
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      {
+        const float *kr = Kb + ql * LDH + half * 4;
+        const float *vr = Vb + ql * LDH + half * 4;
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
-          const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+          const float4 kf = *reinterpret_cast<const float4 *>(kr + s * 8);
+          const float4 vf = *reinterpret_cast<const float4 *>(vr + s * 8);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(ef, e), elem(qf[s], e), racc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(kf, e), elem(qf[s], e), sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(vf, e), elem(dof[s], e), dpacc, 0, 0, 0);
+          }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sr[32 * t + mfma_row(r, half)] = racc[r];
       }
-      wave_lds_sync();
-      const int dq = evq - evq_w0;
+      float sv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evk[mfma_row(r, half)]];
-      wave_lds_sync();
-    }
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
 
-    // ---- P, dS (scaled)
+      float *sr = Sr + wave * 32 * SRLD + ql * SRLD;
+      if (has_e) {
+        const int wrow0 = rb + evq_w0 - evq_b0;
+        const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
+        for (int t = 0; t < nt; ++t) {
+          f32x16 racc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kj = k0 + mfma_row(r, half);
-      bool ok = kj < p.Sk && qi < p.Sq;
-      if (p.mask_mode == 1) ok = ok && kj <= qi;
-      if (p.mask_mode == 2) ok = ok && kj >= qi;
-      float s = sv[r] * p.scale;
-      if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj];
-      const float pr = ok ? expf(s - lse_i) : 0.f;
-      sv[r] = pr * (dpacc[r] - dsum_i) * p.scale;
-    }
-
-    // ---- dQ^T += K^T dS^T
+          for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+          const float *er = Eb + ((wrow0 + 32 * t + ql) & (RING - 1)) * LDH + half * 4;
 #pragma unroll
-    for (int d = 0; d < NDB; ++d) {
-      const int dcol = d * 32 + ql;
+          for (int s = 0; s < NQ; ++s) {
+            const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const float kk = dcol < HD ? Ks[mfma_row(t, half) * LDH + dcol] : 0.f;
-        dQ[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, sv[t], dQ[d], 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+              racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(ef, e), elem(qf[s], e), racc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sr[32 * t + mfma_row(r, half)] = racc[r];
+        }
+        wave_lds_sync();
+        const int dq = evq - evq_w0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evkb[mfma_row(r, half)]];
+        wave_lds_sync();
       }
-    }
 
-    // ---- G[i, r(i,j)] += dS[i,j]: transpose through LDS so that lanes run along the keys of one query
-    if (has_e) {
-      float *tb = Sr + wave * 32 * SRLD;  // [key][query], row TLD
+      // ---- P, dS (scaled)
+      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < p.Sq;
+      if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
+      if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tb[mfma_row(r, half) * TLD + ql] = sv[r];
-      wave_lds_sync();
-      const int kev = (k0 + ql) / p.Ck;
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(sv[r] * scale2 - lse2);
+          sv[r] = pr * (dpacc[r] - dsum_i) * p.scale;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = k0 + mfma_row(r, half);
+          bool ok = kj < p.Sk && qi < p.Sq;
+          if (p.mask_mode == 1) ok = ok && kj <= qi;
+          if (p.mask_mode == 2) ok = ok && kj >= qi;
+          float s = sv[r] * scale2;
+          if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          const float pr = ok ? __builtin_amdgcn_exp2f(s - lse2) : 0.f;
+          sv[r] = pr * (dpacc[r] - dsum_i) * p.scale;
+        }
+      }
+
+      // ---- dQ^T += K^T dS^T
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const int dcol = d * 32 + ql;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const float kk = dcol < HD ? Kb[mfma_row(t, half) * LDH + dcol] : 0.f;
+          dQ[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, sv[t], dQ[d], 0, 0, 0);
+        }
+      }
+
+      // ---- G[i, r(i,j)] += dS[i,j]: transpose through LDS so that lanes run along the keys of one query
+      if (has_e) {
+        float *tb = Sr + wave * 32 * SRLD;  // [key][query], row TLD
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[mfma_row(r, half) * TLD + ql] = sv[r];
+        wave_lds_sync();
+        const int kev = (k0 + ql) / p.Ck;
 #pragma unroll 4
-      for (int it = 0; it < 16; ++it) {
-        const int qq = 2 * it + half;
-        const float val = tb[ql * TLD + qq];
-        const int q = qw0 + qq;
-        const int rho = q / p.Cq - kev + p.Ek - 1;
-        if (val != 0.f && rho >= 0 && rho < p.R) unsafeAtomicAdd(gbase + (size_t)q * p.Rp + rho, val);
+        for (int it = 0; it < 16; ++it) {
+          const int qq = 2 * it + half;
+          const float val = tb[ql * TLD + qq];
+          const int q = qw0 + qq;
+          const int rho = q / p.Cq - kev + p.Ek - 1;
+          const int col = rho - p.rho_lo;
+          if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp)
+            unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);
+        }
+        wave_lds_sync();
       }
-      wave_lds_sync();
     }
+    if (more) commit(k0 + 32, buf ^ 1);
+    __syncthreads();
   }
 
   if (qi < p.Sq) {
@@ -275,19 +326,22 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_kv_kernel(const AttnBwd
   constexpr int LDH = HD + 4;
   constexpr int NQ = HD / 8;
   constexpr int NDB = (HD + 31) / 32;
+  constexpr int NKQ = (HD / 4 + 7) / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Qs = smem;                 // [32][LDH]
-  float *Gs = Qs + 32 * LDH;        // [32][LDH]   dO tile
-  float *Eb = Gs + 32 * LDH;        // [BAND][LDH]
-  float *Sr = Eb + BAND * LDH;      // [4][32][SRLD]
-  float *lse_s = Sr + 4 * 32 * SRLD;  // [32]
-  float *dsum_s = lse_s + 32;         // [32]
-  int *evq_s = reinterpret_cast<int *>(dsum_s + 32);  // [32] event(query) - first event of the tile
+  float *Qs = smem;                    // [2][32][LDH]
+  float *Gs = Qs + 2 * 32 * LDH;       // [2][32][LDH]   dO tiles
+  float *Eb = Gs + 2 * 32 * LDH;       // [RING][LDH]
+  float *Sr = Eb + RING * LDH;         // [4][32][SRLD]
+  float *lse_s = Sr + 4 * 32 * SRLD;   // [2][32]  (base 2)
+  float *dsum_s = lse_s + 64;          // [2][32]
+  int *evq_s = reinterpret_cast<int *>(dsum_s + 64);  // [2][32] event(query) - first event of the tile
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, half = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int k0b = blockIdx.x * QB, kw0 = k0b + 32 * wave, kj = kw0 + ql;
+  // anti-causal rows (j >= i): the last key blocks see the most queries -> launch them first
+  const int kblk = p.mask_mode == 2 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int k0b = kblk * QB, kw0 = k0b + 32 * wave, kj = kw0 + ql;
   const bool has_e = p.e != nullptr;
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
@@ -305,7 +359,7 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_kv_kernel(const AttnBwd
   }
   const int evk_max_b = (k0b + QB - 1) / p.Ck, evk_max_w = (kw0 + 31) / p.Ck;
   const int dkv = evk_max_w - kj / p.Ck;     // >= 0
-  const int wrow0 = evk_max_b - evk_max_w;   // this wave's first band row
+  const int wrow0 = evk_max_b - evk_max_w;   // this wave's first band row (relative to the tile's band)
 
   f32x16 dK[NDB], dV[NDB];
 #pragma unroll
@@ -319,121 +373,174 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_kv_kernel(const AttnBwd
 
   const int srow = tid >> 3, squad = tid & 7;
   const int statb = (b * p.H + h) * p.Sq;
-
-  for (int q0 = q_begin; q0 < q_end; q0 += 32) {
-    const int evq_min = q0 / p.Cq;
-    const int rb = evq_min - evk_max_b + p.Ek - 1;
-    __syncthreads();
-    for (int qd = squad; qd < HD / 4; qd += 8) {
-      const int qi = q0 + srow;
-      const bool ok = qi < p.Sq;
-      *reinterpret_cast<float4 *>(Qs + srow * LDH + qd * 4) =
-          buf_load4(rq, ok ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + qd * 4) * 4u : OOB);
-      *reinterpret_cast<float4 *>(Gs + srow * LDH + qd * 4) =
-          buf_load4(rdo, ok ? (unsigned)(qi * p.o_ss + b * p.o_sb + h * p.o_sh + qd * 4) * 4u : OOB);
+  float4 pq[NKQ], pg[NKQ], pe[NKQ];
+  float plse = 0.f, pdsum = 0.f;
+  // first table row of the band of the query tile that starts at q0
+  auto band0 = [&](int q0) { return q0 / p.Cq - evk_max_b + p.Ek - 1; };
+  auto prefetch = [&](int q0) {  // Q, dO rows of tile q0 and the 32 highest band rows of that tile
+    const int qi = q0 + srow;
+    const bool ok = qi < p.Sq;
+    const int r = band0(q0) + (BAND - 32) + srow;
+    const bool rok = has_e && r >= 0 && r < p.R;
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      const bool in = qd < HD / 4;
+      pq[i] = buf_load4(rq, ok && in ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + qd * 4) * 4u : OOB);
+      pg[i] = buf_load4(rdo, ok && in ? (unsigned)(qi * p.o_ss + b * p.o_sb + h * p.o_sh + qd * 4) * 4u : OOB);
+      pe[i] = buf_load4(re, rok && in ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
     }
-    if (has_e) {
-      for (int row = srow; row < BAND; row += 32) {
-        const int r = rb + row;
-        const bool ok = r >= 0 && r < p.R;
-        for (int qd = squad; qd < HD / 4; qd += 8)
-          *reinterpret_cast<float4 *>(Eb + row * LDH + qd * 4) =
-              buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+    if (tid < 32) {
+      const int q = q0 + tid;
+      plse = q < p.Sq ? p.lse[statb + q] : 0.f;
+      pdsum = q < p.Sq ? p.dsum[statb + q] : 0.f;
+    }
+  };
+  auto commit = [&](int q0, int buf) {
+    const int slot = (band0(q0) + (BAND - 32) + srow) & (RING - 1);
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      if (qd < HD / 4) {
+        *reinterpret_cast<float4 *>(Qs + (buf * 32 + srow) * LDH + qd * 4) = pq[i];
+        *reinterpret_cast<float4 *>(Gs + (buf * 32 + srow) * LDH + qd * 4) = pg[i];
+        if (has_e) *reinterpret_cast<float4 *>(Eb + slot * LDH + qd * 4) = pe[i];
       }
     }
     if (tid < 32) {
-      const int qi = q0 + tid;
-      lse_s[tid] = qi < p.Sq ? p.lse[statb + qi] : 0.f;
-      dsum_s[tid] = qi < p.Sq ? p.dsum[statb + qi] : 0.f;
-      evq_s[tid] = qi / p.Cq - evq_min;
+      lse_s[buf * 32 + tid] = plse * LOG2E;
+      dsum_s[buf * 32 + tid] = pdsum;
+      evq_s[buf * 32 + tid] = (q0 + tid) / p.Cq - q0 / p.Cq;
     }
-    __syncthreads();
+  };
+
+  if (q_begin < q_end) {
+    prefetch(q_begin);
+    commit(q_begin, 0);
+    if (has_e) {
+      const int rb = band0(q_begin);
+      for (int row = srow; row < BAND - 32; row += 32) {
+        const int r = rb + row;
+        const bool ok = r >= 0 && r < p.R;
+        for (int qd = squad; qd < HD / 4; qd += 8)
+          *reinterpret_cast<float4 *>(Eb + (r & (RING - 1)) * LDH + qd * 4) =
+              buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): fragments and prologue are in
+  __syncthreads();
+  const float scale2 = p.scale * LOG2E;
+
+  int buf = 0;
+  for (int q0 = q_begin; q0 < q_end; q0 += 32, buf ^= 1) {
+    const bool more = q0 + 32 < q_end;
+    if (more) prefetch(q0 + 32);
+    const int rb = band0(q0);
+    const float *Qb = Qs + buf * 32 * LDH, *Gb = Gs + buf * 32 * LDH;
+    const float *lseb = lse_s + buf * 32, *dsumb = dsum_s + buf * 32;
+    const int *evqb = evq_s + buf * 32;
 
     bool live = kw0 < p.Sk;
     if (p.mask_mode == 1) live = live && q0 + 31 >= kw0;
     if (p.mask_mode == 2) live = live && q0 <= kw0 + 31;
-    if (!live) continue;  // wave-uniform
-
-    // ---- S = Q K^T and dP = dO V^T  (rows = queries, this lane's column = its key)
-    f32x16 sacc, dpacc;
+    if (live) {  // wave-uniform
+      // ---- S = Q K^T and dP = dO V^T  (rows = queries, this lane's column = its key)
+      f32x16 sacc, dpacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-    float4 qfr[NQ];
-    {
-      const float *qr = Qs + ql * LDH + half * 4;
-      const float *gr = Gs + ql * LDH + half * 4;
-#pragma unroll
-      for (int s = 0; s < NQ; ++s) {
-        qfr[s] = *reinterpret_cast<const float4 *>(qr + s * 8);
-        const float4 gf = *reinterpret_cast<const float4 *>(gr + s * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(qfr[s], e), elem(kf[s], e), sacc, 0, 0, 0);
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(gf, e), elem(vf[s], e), dpacc, 0, 0, 0);
-        }
-      }
-    }
-    float sv[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
-
-    if (has_e) {
-      // U = Q E_band^T : rows = queries, columns = band rows; entry (i, j) sits at column
-      // (event(i) - first event of the tile) + (last event of the wave's keys - event(j))
-      float *sw = Sr + wave * 32 * SRLD;
-      const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
-      for (int t = 0; t < nt; ++t) {
-        f32x16 racc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-        const float *er = Eb + (wrow0 + 32 * t + ql) * LDH + half * 4;
+      for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+      const float *qr = Qb + ql * LDH + half * 4;
+      {
+        const float *gr = Gb + ql * LDH + half * 4;
 #pragma unroll
         for (int s = 0; s < NQ; ++s) {
-          const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+          const float4 qfr = *reinterpret_cast<const float4 *>(qr + s * 8);
+          const float4 gf = *reinterpret_cast<const float4 *>(gr + s * 8);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(qfr[s], e), elem(ef, e), racc, 0, 0, 0);
+          for (int e = 0; e < 4; ++e) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(qfr, e), elem(kf[s], e), sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(gf, e), elem(vf[s], e), dpacc, 0, 0, 0);
+          }
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sw[mfma_row(r, half) * SRLD + 32 * t + ql] = racc[r];
       }
-      wave_lds_sync();
+      float sv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qrow = mfma_row(r, half);
-        sv[r] += sw[qrow * SRLD + evq_s[qrow] + dkv];
-      }
-      wave_lds_sync();
-    }
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
 
-    float pv[16];
+      if (has_e) {
+        // U = Q E_band^T : rows = queries, columns = band rows; entry (i, j) sits at column
+        // (event(i) - first event of the tile) + (last event of the wave's keys - event(j))
+        float *sw = Sr + wave * 32 * SRLD;
+        const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
+        for (int t = 0; t < nt; ++t) {
+          f32x16 racc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qrow = mfma_row(r, half);
-      const int qi = q0 + qrow;
-      bool ok = kj < p.Sk && qi < p.Sq;
-      if (p.mask_mode == 1) ok = ok && kj <= qi;
-      if (p.mask_mode == 2) ok = ok && kj >= qi;
-      float s = sv[r] * p.scale;
-      if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj];
-      const float pr = ok ? expf(s - lse_s[qrow]) : 0.f;
-      pv[r] = pr;
-      sv[r] = pr * (dpacc[r] - dsum_s[qrow]) * p.scale;
-    }
+          for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+          const float *er = Eb + ((rb + wrow0 + 32 * t + ql) & (RING - 1)) * LDH + half * 4;
+#pragma unroll
+          for (int s = 0; s < NQ; ++s) {
+            const float4 ef = *reinterpret_cast<const float4 *>(er + s * 8);
+            const float4 qfr = *reinterpret_cast<const float4 *>(qr + s * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              racc = __builtin_amdgcn_mfma_f32_32x32x2f32(elem(qfr, e), elem(ef, e), racc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sw[mfma_row(r, half) * SRLD + 32 * t + ql] = racc[r];
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qrow = mfma_row(r, half);
+          sv[r] += sw[qrow * SRLD + evqb[qrow] + dkv];
+        }
+        wave_lds_sync();
+      }
 
-    // ---- dV^T += dO^T P ,  dK^T += Q^T dS
+      float pv[16];
+      bool full = !p.mask && kw0 + 31 < p.Sk && q0 + 31 < p.Sq;
+      if (p.mask_mode == 1) full = full && kw0 + 31 <= q0;
+      if (p.mask_mode == 2) full = full && kw0 >= q0 + 31;
+      if (full) {
 #pragma unroll
-    for (int d = 0; d < NDB; ++d) {
-      const int dcol = d * 32 + ql;
+        for (int r = 0; r < 16; ++r) {
+          const int qrow = mfma_row(r, half);
+          const float pr = __builtin_amdgcn_exp2f(sv[r] * scale2 - lseb[qrow]);
+          pv[r] = pr;
+          sv[r] = pr * (dpacc[r] - dsumb[qrow]) * p.scale;
+        }
+      } else {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int row = mfma_row(t, half);
-        const float gg = dcol < HD ? Gs[row * LDH + dcol] : 0.f;
-        const float qq = dcol < HD ? Qs[row * LDH + dcol] : 0.f;
-        dV[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, pv[t], dV[d], 0, 0, 0);
-        dK[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qq, sv[t], dK[d], 0, 0, 0);
+        for (int r = 0; r < 16; ++r) {
+          const int qrow = mfma_row(r, half);
+          const int qi = q0 + qrow;
+          bool ok = kj < p.Sk && qi < p.Sq;
+          if (p.mask_mode == 1) ok = ok && kj <= qi;
+          if (p.mask_mode == 2) ok = ok && kj >= qi;
+          float s = sv[r] * scale2;
+          if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          const float pr = ok ? __builtin_amdgcn_exp2f(s - lseb[qrow]) : 0.f;
+          pv[r] = pr;
+          sv[r] = pr * (dpacc[r] - dsumb[qrow]) * p.scale;
+        }
+      }
+
+      // ---- dV^T += dO^T P ,  dK^T += Q^T dS
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const int dcol = d * 32 + ql;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          const int row = mfma_row(t, half);
+          const float gg = dcol < HD ? Gb[row * LDH + dcol] : 0.f;
+          const float qq = dcol < HD ? Qb[row * LDH + dcol] : 0.f;
+          dV[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(gg, pv[t], dV[d], 0, 0, 0);
+          dK[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qq, sv[t], dK[d], 0, 0, 0);
+        }
       }
     }
+    if (more) commit(q0 + 32, buf ^ 1);
+    __syncthreads();
   }
 
   if (kj < p.Sk) {
@@ -454,26 +561,27 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_kv_kernel(const AttnBwd
   }
 }
 
-// packed GEMM operand of one head's table, transposed: w[d][r] = e[h][r][d], zero padded to Kpad
+// packed GEMM operand of one head's table rows [lo, lo + n), transposed: w[d][c] = e[h][lo + c][d], zero padded to Kpad
 __global__ void pack_rel_T_kernel(const float *__restrict__ e, float *__restrict__ out, int H, int R, int HD,
-                                  int Kpad) {
+                                  int Kpad, int lo, int n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)H * HD * Kpad) return;
-  const int r = (int)(i % Kpad);
+  const int c = (int)(i % Kpad);
   const int d = (int)((i / Kpad) % HD);
   const int h = (int)(i / ((int64_t)Kpad * HD));
-  out[i] = r < R ? e[((int64_t)h * R + r) * HD + d] : 0.f;
+  out[i] = c < n ? e[((int64_t)h * R + lo + c) * HD + d] : 0.f;
 }
 
-// d_rel[h][r][d] = dw[h][r][d'] (rows padded to Rp, columns to Kp)
+// d_rel[h][r][d] = dw[h][r - lo][d] for table rows in [lo, lo + n), 0 elsewhere (dw rows padded to Rp, columns to Kp)
 __global__ void unpack_drel_kernel(const float *__restrict__ dw, float *__restrict__ out, int H, int R, int HD,
-                                   int Rp, int Kp) {
+                                   int Rp, int Kp, int lo, int n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)H * R * HD) return;
   const int d = (int)(i % HD);
   const int r = (int)((i / HD) % R);
   const int h = (int)(i / ((int64_t)HD * R));
-  out[i] = dw[((int64_t)h * Rp + r) * Kp + d];
+  const int c = r - lo;
+  out[i] = c >= 0 && c < n ? dw[((int64_t)h * Rp + c) * Kp + d] : 0.f;
 }
 
 namespace {
@@ -482,7 +590,17 @@ struct BwdLayout {
   size_t dsum, g, wT, dw, wg, total;         // float offsets into the workspace
   size_t wg_floats;
 };
-BwdLayout bwd_layout(int B, int H, int Sq, int R, int HD) {
+// Table rows a (query, key) pair can select: causal / anti-causal self-attention (Cq == Ck) only ever
+// reaches the upper / lower half of the table, which halves G and the two GEMMs over it.
+void rho_range(const isi_attn_args *g, int *lo, int *n) {
+  const int R = g->rel_rows;
+  *lo = 0; *n = R;
+  if (g->Cq == g->Ck && !g->dense_mask) {
+    if (g->mask_mode == 1) { *lo = std::min(std::max(g->Ek - 1, 0), R - 1); *n = R - *lo; }   // j <= i: rho >= Ek - 1
+    if (g->mask_mode == 2) { *n = std::max(1, std::min(R, g->Ek)); }                           // j >= i: rho <= Ek - 1
+  }
+}
+BwdLayout bwd_layout(int B, int H, int Sq, int R, int HD) {   // R = number of table rows G covers
   BwdLayout L;
   L.Rp = (int)round_up((size_t)std::max(R, 1), 4);
   L.Kp = (int)round_up((size_t)HD, kBK);
@@ -508,14 +626,16 @@ int64_t span(int64_t S, int64_t ss, int64_t B, int64_t sb, int64_t H, int64_t sh
 
 size_t rel_attention_bwd_workspace_floats(const isi_attn_args *g) {
   if (!g || g->B <= 0 || g->H <= 0 || g->Sq <= 0) return 0;
-  return bwd_layout(g->B, g->H, g->Sq, g->rel_embeddings ? g->rel_rows : 0, g->head_dim).total;
+  int lo = 0, n = 0;
+  if (g->rel_embeddings && g->rel_rows > 0) rho_range(g, &lo, &n);
+  return bwd_layout(g->B, g->H, g->Sq, n, g->head_dim).total;
 }
 
 template <int HD>
 static int launch_bwd(const AttnBwdKArgs &a, hipStream_t stream) {
   auto kq = rel_attention_bwd_q_kernel<HD>;
   auto kkv = rel_attention_bwd_kv_kernel<HD>;
-  constexpr size_t smem = (size_t)((64 + BAND) * (HD + 4) + 4 * 32 * SRLD + 96) * sizeof(float);
+  constexpr size_t smem = (size_t)((128 + RING) * (HD + 4) + 4 * 32 * SRLD + 192) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
@@ -569,7 +689,9 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
                          reinterpret_cast<uintptr_t>(ga->dv) | reinterpret_cast<uintptr_t>(ga->workspace);
   if ((all & 3) || (ptrs & 15))
     return invalid("rel_attention_bwd: strides must be multiples of 4 floats and pointers 16-byte aligned");
-  const BwdLayout L = bwd_layout(g->B, g->H, g->Sq, has_e ? g->rel_rows : 0, HD);
+  int rho_lo = 0, rho_n = 0;
+  if (has_e) rho_range(g, &rho_lo, &rho_n);
+  const BwdLayout L = bwd_layout(g->B, g->H, g->Sq, rho_n, HD);
   if (ga->workspace_floats < L.total) { set_last_error("rel_attention_bwd: workspace too small"); return ISI_E_WORKSPACE; }
   if (has_e && (int64_t)g->H * g->B * g->Sq * L.Rp > lim) return unsupported("rel_attention_bwd: G spans 4 GiB or more");
 
@@ -582,7 +704,7 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   a.g = has_e ? ga->workspace + L.g : nullptr;
   a.q_bytes = (unsigned)(eq * 4); a.k_bytes = (unsigned)(ek * 4); a.v_bytes = (unsigned)(ev * 4);
   a.o_bytes = (unsigned)(eo * 4);
-  a.R = g->rel_rows; a.Rp = L.Rp;
+  a.R = g->rel_rows; a.Rp = L.Rp; a.rho_lo = rho_lo;
   a.e_bytes = (unsigned)((size_t)g->H * g->rel_rows * HD * 4);
   a.Sq = g->Sq; a.Sk = g->Sk; a.H = g->H; a.B = g->B;
   a.q_ss = (int)g->q_ss; a.q_sb = (int)g->q_sb; a.q_sh = (int)g->q_sh;
@@ -614,7 +736,7 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   {
     const int64_t total = (int64_t)g->H * HD * KpT;
     hipLaunchKernelGGL(pack_rel_T_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       g->rel_embeddings, wT, g->H, R, HD, KpT);
+                       g->rel_embeddings, wT, g->H, R, HD, KpT, rho_lo, rho_n);
     if ((rc = check_launch("pack_rel_T"))) return rc;
   }
   for (int h = 0; h < g->H; ++h) {
@@ -641,7 +763,7 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   {
     const int64_t total = (int64_t)g->H * R * HD;
     hipLaunchKernelGGL(unpack_drel_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       ga->workspace + L.dw, ga->d_rel, g->H, R, HD, L.Rp, L.Kp);
+                       ga->workspace + L.dw, ga->d_rel, g->H, R, HD, L.Rp, L.Kp, rho_lo, rho_n);
     rc = check_launch("unpack_drel");
   }
   return rc;

@@ -48,6 +48,32 @@ size_t isi_abi_struct_bytes(int which);
  * RosinalityResBlock overwrites its caller's tensor (encoder_decoder.py:23). */
 int isi_relu_inplace_f32(float *x, int64_t n, void *stream);
 
+/* ------------------------------------------------ audio <-> spectrogram */
+/* HBM-bound stages of the GANSynth front-end the reference reaches through the absent
+ * GANsynth_pytorch.spectrograms_helper (SpectrogramsHelper.to_spectrogram / to_audio;
+ * utils/misc.py:10-29, train_vqvae.py:392-400, sample.py:599, flask_server.py:596,1016);
+ * specification: oracle/spectrogram_oracle.py (parity unpinned).  The contractions
+ * (windowed DFT, mel projections and their inverses) are isi_conv2d_f32 calls.
+ *   stft  [B,T,2F]  real block | imaginary block, DC bin dropped (F = n_fft / 2)
+ *   a, ph [B,T,F]   channels-last intermediates
+ *   spec  [B,2,F,T] channel 0 log-magnitude (mel: log mel power), channel 1 instantaneous
+ *                   frequency in units of pi
+ * isi_spec_polar: mel = 0: a = log(|X| + 1e-6), ph = angle; mel = 1: a = |X|^2, ph = unwrapped angle.
+ * isi_spec_finish: spec0 = mel ? log(a + 1e-6) : a, spec1 = wrapped time difference of ph / pi.
+ * isi_spec_inverse_prepare: a = exp(spec0), ph = running sum over time of spec1 * pi.
+ * isi_spec_to_stft: mag = mel ? sqrt(max(a, 0) + 1e-6) : a; stft = mag (cos ph | sin ph).
+ * isi_overlap_add: audio[b,n] = sum_t frames[b,t,left + n - t*hop], frames [B,T,n_fft]. */
+int isi_spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel,
+                       void *stream);
+int isi_spec_finish_f32(const float *a, const float *ph, float *spec, int B, int T, int F,
+                        int mel, void *stream);
+int isi_spec_inverse_prepare_f32(const float *spec, float *a, float *ph, int B, int T, int F,
+                                 void *stream);
+int isi_spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t rows, int F,
+                         int mel, void *stream);
+int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop,
+                        int left, int64_t L, void *stream);
+
 /* ------------------------------------------------- measurement (bench.py) */
 /* Per-launch timing with HIP events recorded on the launch stream.  State is
  * per calling thread; enabling clears earlier records.  isi_prof_read blocks

@@ -82,6 +82,22 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3, c
 }
 int isi_resblock_fusable(int C, int R) { return resblock_fusable(C, R) ? 1 : 0; }
 
+int isi_spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel, void *stream) {
+  return spec_polar_f32(stft, a, ph, B, T, F, mel, S(stream));
+}
+int isi_spec_finish_f32(const float *a, const float *ph, float *spec, int B, int T, int F, int mel, void *stream) {
+  return spec_finish_f32(a, ph, spec, B, T, F, mel, S(stream));
+}
+int isi_spec_inverse_prepare_f32(const float *spec, float *a, float *ph, int B, int T, int F, void *stream) {
+  return spec_inverse_prepare_f32(spec, a, ph, B, T, F, S(stream));
+}
+int isi_spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t rows, int F, int mel, void *stream) {
+  return spec_to_stft_f32(a, ph, stft, rows, F, mel, S(stream));
+}
+int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
+                        void *stream) {
+  return overlap_add_f32(frames, audio, B, T, n_fft, hop, left, L, S(stream));
+}
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream) { return rel_attention_f32(args, S(stream)); }
 size_t isi_rel_attention_bwd_workspace_floats(const isi_attn_args *fwd) { return rel_attention_bwd_workspace_floats(fwd); }
 int isi_rel_attention_bwd_f32(const isi_attn_bwd_args *args, void *stream) { return rel_attention_bwd_f32(args, S(stream)); }

@@ -72,6 +72,13 @@ int embed_code_f32(const int64_t *idx, const float *codes, float *out, int64_t N
 
 int relu_inplace_f32(float *x, int64_t n, hipStream_t stream);
 
+int spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel, hipStream_t st);
+int spec_finish_f32(const float *a, const float *ph, float *out, int B, int T, int F, int mel, hipStream_t st);
+int spec_inverse_prepare_f32(const float *spec, float *a, float *ph, int B, int T, int F, hipStream_t st);
+int spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t rows, int F, int mel, hipStream_t st);
+int overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
+                    hipStream_t st);
+
 size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
 size_t packed_convT_k4s2_weight_floats(int Cin, int Cout);
 int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,

@@ -1,0 +1,207 @@
+// Element-wise / scan stages of the audio <-> spectrogram front-end (gfx950).
+//
+// The reference delegates the front-end to the absent package GANsynth_pytorch
+// (`SpectrogramsHelper.to_spectrogram / to_audio`; call sites utils/misc.py:10-29,
+// train_vqvae.py:392-400, sample.py:599, flask_server.py:596,1016); the arithmetic built
+// here is the published GANSynth representation, specification: oracle/spectrogram_oracle.py.
+//
+// The two contractions of each direction run on the exact-fp32 matrix pipe through the
+// existing GEMM kernel (isi_conv2d_f32):
+//   STFT    = convolution of the audio, viewed as [B, 1, L/hop, hop] channels-last, with the
+//             windowed DFT basis as a 1 x (n_fft/hop) kernel  ->  X[b, t, re(F) | im(F)]
+//   mel     = 1x1 convolution with the mel matrix (power and unwrapped phase rows)
+//   inverse = the transposed matrices; frames are overlap-added by overlap_add_kernel.
+// The kernels below are the HBM-bound stages in between: one pass each, threads along the
+// frequency axis (unit stride in the channels-last intermediates), a sequential scan over the
+// (short) time axis where the phase is unwrapped / integrated, and LDS tile transposes to and
+// from the [B, 2, F, T] layout the VQ-VAE consumes.
+#include <cmath>
+
+#include "isi_common.h"
+#include "isi_internal.h"
+
+namespace isi {
+
+namespace {
+constexpr float PI_F = 3.14159265358979323846f;
+constexpr float TWO_PI_F = 6.28318530717958647692f;
+constexpr float SPEC_EPS = 1e-6f;
+// principal value in [-pi, pi], numpy.unwrap's convention at the ends
+__device__ __forceinline__ float wrap_pi(float d) {
+  float w = d + PI_F;
+  w = w - TWO_PI_F * floorf(w / TWO_PI_F) - PI_F;
+  if (w == -PI_F && d > 0.f) w = PI_F;
+  return w;
+}
+}  // namespace
+
+// stft [B,T,2F] (re block | im block) -> a, ph [B,T,F]
+//   mel == 0: a = log(|X| + eps), ph = angle(X)
+//   mel == 1: a = |X|^2,          ph = unwrapped angle (running sum of wrapped differences)
+__global__ __launch_bounds__(256) void spec_polar_kernel(const float *__restrict__ x, float *__restrict__ a,
+                                                         float *__restrict__ ph, int T, int F, int mel) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (f >= F) return;
+  const float *xr = x + (size_t)b * T * 2 * F + f;
+  float *ar = a + (size_t)b * T * F + f, *pr = ph + (size_t)b * T * F + f;
+  float prev = 0.f, run = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const float re = xr[(size_t)t * 2 * F], im = xr[(size_t)t * 2 * F + F];
+    const float ang = atan2f(im, re);
+    if (mel) {
+      run = t == 0 ? ang : run + wrap_pi(ang - prev);
+      prev = ang;
+      ar[(size_t)t * F] = re * re + im * im;
+      pr[(size_t)t * F] = run;
+    } else {
+      ar[(size_t)t * F] = logf(sqrtf(re * re + im * im) + SPEC_EPS);
+      pr[(size_t)t * F] = ang;
+    }
+  }
+}
+
+// a, ph [B,T,F] -> out [B,2,F,T]:  out0 = mel ? log(a + eps) : a ;  out1 = IF(ph) (wrapped difference / pi)
+// 32(t) x 32(f) tiles transposed through LDS: reads unit-stride in f, writes unit-stride in t.
+__global__ __launch_bounds__(256) void spec_finish_kernel(const float *__restrict__ a, const float *__restrict__ ph,
+                                                          float *__restrict__ out, int T, int F, int mel) {
+  __shared__ float ta[32][33], tp[32][33];
+  const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32, b = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int t = t0 + i, f = f0 + tx;
+    float va = 0.f, vp = 0.f;
+    if (t < T && f < F) {
+      const size_t o = ((size_t)b * T + t) * F + f;
+      va = mel ? logf(a[o] + SPEC_EPS) : a[o];
+      const float cur = ph[o];
+      vp = t == 0 ? cur : wrap_pi(cur - ph[o - F]);
+      vp *= (1.f / PI_F);
+    }
+    ta[i][tx] = va;
+    tp[i][tx] = vp;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int f = f0 + i, t = t0 + tx;
+    if (f < F && t < T) {
+      out[(((size_t)b * 2 + 0) * F + f) * T + t] = ta[tx][i];
+      out[(((size_t)b * 2 + 1) * F + f) * T + t] = tp[tx][i];
+    }
+  }
+}
+
+// spec [B,2,F,T] -> a = exp(ch0), ph = running sum of ch1 * pi, both [B,T,F].
+// A workgroup owns 32 frequencies; 32 x 32 tiles are transposed through LDS and the running
+// phase of each frequency is carried from tile to tile.
+__global__ __launch_bounds__(256) void spec_inverse_prepare_kernel(const float *__restrict__ spec, float *__restrict__ a,
+                                                                   float *__restrict__ ph, int T, int F) {
+  __shared__ float ta[32][33], tp[32][33];
+  __shared__ float carry[32];
+  const int f0 = blockIdx.x * 32, b = blockIdx.y;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (threadIdx.x < 32) carry[threadIdx.x] = 0.f;
+  for (int t0 = 0; t0 < T; t0 += 32) {
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {  // rows = frequencies, unit stride along t
+      const int f = f0 + i, t = t0 + tx;
+      float va = 0.f, vp = 0.f;
+      if (f < F && t < T) {
+        va = expf(spec[(((size_t)b * 2 + 0) * F + f) * T + t]);
+        vp = spec[(((size_t)b * 2 + 1) * F + f) * T + t] * PI_F;
+      }
+      ta[i][tx] = va;
+      tp[i][tx] = vp;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {  // sequential scan of one frequency's 32 frames
+      float run = carry[threadIdx.x];
+      for (int j = 0; j < 32; ++j) {
+        run += tp[threadIdx.x][j];
+        tp[threadIdx.x][j] = run;
+      }
+      carry[threadIdx.x] = run;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {  // rows = frames, unit stride along f
+      const int t = t0 + i, f = f0 + tx;
+      if (t < T && f < F) {
+        const size_t o = ((size_t)b * T + t) * F + f;
+        a[o] = ta[tx][i];
+        ph[o] = tp[tx][i];
+      }
+    }
+  }
+}
+
+// a, ph [B,T,F] -> stft [B,T,2F]: mag = mel ? sqrt(max(a,0) + eps) : a ; (re, im) = mag (cos ph, sin ph)
+__global__ void spec_to_stft_kernel(const float *__restrict__ a, const float *__restrict__ ph, float *__restrict__ x,
+                                    int64_t rows, int F, int mel) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * F) return;
+  const int64_t r = i / F;
+  const int f = (int)(i - r * F);
+  float mag = a[i];
+  if (mel) mag = expf(0.5f * logf(fmaxf(mag, 0.f) + SPEC_EPS));
+  float s, c;
+  sincosf(ph[i], &s, &c);
+  x[r * 2 * F + f] = mag * c;
+  x[r * 2 * F + F + f] = mag * s;
+}
+
+// audio[b, n] = sum over frames t of frames[b, t, left + n - t hop]   (frames already carry the synthesis window)
+__global__ void overlap_add_kernel(const float *__restrict__ frames, float *__restrict__ audio, int T, int n_fft,
+                                   int hop, int left, int64_t L) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (n >= L) return;
+  const int64_t pos = n + left;                 // position in the padded signal
+  int t_hi = (int)(pos / hop);
+  if (t_hi > T - 1) t_hi = T - 1;
+  float s = 0.f;
+  for (int t = t_hi; t >= 0; --t) {
+    const int64_t k = pos - (int64_t)t * hop;
+    if (k >= n_fft) break;
+    s += frames[((size_t)b * T + t) * n_fft + k];
+  }
+  audio[(size_t)b * L + n] = s;
+}
+
+int spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel, hipStream_t st) {
+  if (!stft || !a || !ph || B <= 0 || T <= 0 || F <= 0 || B > 65535) return invalid("spec_polar: bad argument");
+  hipLaunchKernelGGL(spec_polar_kernel, dim3((F + 255) / 256, B), dim3(256), 0, st, stft, a, ph, T, F, mel);
+  return check_launch("spec_polar");
+}
+
+int spec_finish_f32(const float *a, const float *ph, float *out, int B, int T, int F, int mel, hipStream_t st) {
+  if (!a || !ph || !out || B <= 0 || T <= 0 || F <= 0 || B > 65535 || (T + 31) / 32 > 65535)
+    return invalid("spec_finish: bad argument");
+  hipLaunchKernelGGL(spec_finish_kernel, dim3((F + 31) / 32, (T + 31) / 32, B), dim3(256), 0, st, a, ph, out, T, F,
+                     mel);
+  return check_launch("spec_finish");
+}
+
+int spec_inverse_prepare_f32(const float *spec, float *a, float *ph, int B, int T, int F, hipStream_t st) {
+  if (!spec || !a || !ph || B <= 0 || T <= 0 || F <= 0 || B > 65535) return invalid("spec_inverse_prepare: bad argument");
+  hipLaunchKernelGGL(spec_inverse_prepare_kernel, dim3((F + 31) / 32, B), dim3(256), 0, st, spec, a, ph, T, F);
+  return check_launch("spec_inverse_prepare");
+}
+
+int spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t rows, int F, int mel, hipStream_t st) {
+  if (!a || !ph || !stft || rows <= 0 || F <= 0) return invalid("spec_to_stft: bad argument");
+  const int64_t n = rows * F;
+  hipLaunchKernelGGL(spec_to_stft_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, ph, stft, rows, F,
+                     mel);
+  return check_launch("spec_to_stft");
+}
+
+int overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
+                    hipStream_t st) {
+  if (!frames || !audio || B <= 0 || T <= 0 || n_fft <= 0 || hop <= 0 || left < 0 || L <= 0 || B > 65535)
+    return invalid("overlap_add: bad argument");
+  hipLaunchKernelGGL(overlap_add_kernel, dim3((unsigned)((L + 255) / 256), B), dim3(256), 0, st, frames, audio, T,
+                     n_fft, hop, left, L);
+  return check_launch("overlap_add");
+}
+
+}  // namespace isi

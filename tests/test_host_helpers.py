@@ -257,3 +257,26 @@ def test_grad_bucket_reducer_two_process_gloo():
             for g_, m in zip(got[rank][step][:-1], mean):
                 torch.testing.assert_close(torch.tensor(g_), m.flatten(), rtol=1e-6, atol=1e-7)
             assert got[rank][step][-1] == [0.0] * 4   # untouched parameter: zeros, no hang
+
+
+def test_spectrogram_specification_is_self_consistent():
+    """oracle/spectrogram_oracle.py (parity unpinned): the linear representation inverts to the
+    audio it came from, the mel matrix has unit-height triangles, and its approximate inverse
+    returns bin-centred energy."""
+    import math
+    from oracle import spectrogram_oracle as S
+    cfg = S.SpecConfig(n_fft=256, hop_length=64, window_length=256)
+    t = torch.arange(4000) / 16000.0
+    x = (0.5 * torch.sin(2 * math.pi * 440 * t) + 0.3 * torch.sin(2 * math.pi * 1234 * t + 1))[None].double()
+    sp = S.to_spectrogram(cfg, x, mel=False)
+    assert sp.shape == (1, 2, 128, 63)
+    y = S.to_audio(cfg, sp, mel=False)
+    assert float((y[:, 300:3700] - x[:, 300:3700]).abs().max()) < 5e-3
+    # the synthesis window satisfies the overlap-add identity  sum_k w(n + k hop) w_s(n + k hop) = 1
+    w = torch.hann_window(256, periodic=True, dtype=torch.float64)
+    ws = S.synthesis_window(cfg, torch.float64)
+    acc = sum((w * ws)[k * 64:(k + 1) * 64] for k in range(4))
+    assert torch.allclose(acc, torch.ones(64, dtype=torch.float64), atol=1e-12)
+    M = S.mel_matrix(cfg)
+    assert M.shape == (128, 128) and float(M.max()) <= 1.0 and float(M.min()) >= 0.0
+    assert S.instantaneous_frequency(torch.tensor([[0.0, 3.0, -3.0]]))[0, 2] == pytest.approx((2 * math.pi - 6.0) / math.pi)

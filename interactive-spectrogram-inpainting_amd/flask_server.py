@@ -1,0 +1,114 @@
+"""HTTP surface of the interactive inpainting service (reference flask_server.py): same routes,
+query arguments and JSON schema for the operations built on MI355X
+
+  POST /timerange-change?layer=&temperature=&start_index_top=&uniform_sampling=&pitch=&instrument_family_str=
+       body {top_code: int[F_t][T], bottom_code: int[F_b][T_b], mask: bool[F][W],
+             top_conditioning, bottom_conditioning: {modality: value[F][T]}}          (:685-870,934-1000)
+  GET/POST /generate?pitch=&instrument_family_str=&temperature=                         (:376-443)
+  POST /erase?eraser_amplitude=&start_index_top=                                        (:873-931)
+  POST /get-audio   -> audio/wav (16-bit PCM written with the standard library)         (:1003-1021)
+  response {top_code, bottom_code, top_conditioning, bottom_conditioning}               (:991-1000)
+
+A thin adapter: parsing / serialisation here, all compute in `inpainting.py`.  The models are
+handed to `create_app` already loaded (checkpoint paths and the LMDB sampling database are
+deployment plumbing; `/sample-from-dataset`, `/analyze-audio` and the spectrogram-image route
+depend on lmdb / torchaudio / matplotlib, absent from this image, and are not built).
+Global (non-local) class conditioning only, like the reference's default deployment.
+"""
+from __future__ import annotations
+
+import io
+import struct
+from typing import Mapping, Optional
+
+import flask
+import torch
+
+import inpainting
+
+
+def _wav_bytes(audio: torch.Tensor, fs_hz: int) -> bytes:
+    pcm = (audio.clamp(-1, 1) * 32767.0).round().to(torch.int16).cpu().numpy().tobytes()
+    header = b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVEfmt " + struct.pack(
+        "<IHHIIHH", 16, 1, 1, fs_hz, fs_hz * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm))
+    return header + pcm
+
+
+def create_app(vqvae, transformer_top, transformer_bottom, label_encoders_per_modality: Mapping[str, object],
+               device, spectrograms_helper=None, top_k: int = 0, top_p: float = 0.0,
+               seed: Optional[int] = None) -> flask.Flask:
+    """`label_encoders_per_modality[name].transform([value]) -> [class index]` (sklearn LabelEncoder
+    in the reference, `utils/datasets/label_encoders.py`)."""
+    app = flask.Flask(__name__)
+    device = torch.device(device)
+    generator = torch.Generator().manual_seed(seed) if seed is not None else None
+    sampling = dict(top_k_sampling_k=top_k, top_p_sampling_p=top_p)
+
+    def conditioning_tensors(args) -> Mapping[str, torch.Tensor]:
+        values = {'pitch': args.get('pitch', type=int), 'instrument_family_str': str(args.get('instrument_family_str'))}
+        return {name: torch.as_tensor(label_encoders_per_modality[name].transform([value])).long().reshape(1, 1)
+                for name, value in values.items()}, values
+
+    def codes(json_data):
+        return (torch.LongTensor(json_data['top_code']).unsqueeze(0).to(device),
+                torch.LongTensor(json_data['bottom_code']).unsqueeze(0).to(device))
+
+    def respond(top_code, bottom_code, conditioning_top, conditioning_bottom):
+        return flask.jsonify({'top_code': top_code[0].int().cpu().numpy().tolist(),
+                              'bottom_code': bottom_code[0].int().cpu().numpy().tolist(),
+                              'top_conditioning': conditioning_top, 'bottom_conditioning': conditioning_bottom})
+
+    def matrix(shape, value):
+        return [[value] * shape[1]] * shape[0]
+
+    @app.route('/generate', methods=['GET', 'POST'])
+    def generate():
+        args = flask.request.args
+        cls, values = conditioning_tensors(args)
+        top, bottom = inpainting.generate(transformer_top, transformer_bottom, float(args.get('temperature')), cls, cls,
+                                          device, generator=generator, **sampling)
+        return respond(top, bottom, {k: matrix(transformer_top.shape, v) for k, v in values.items()},
+                       {k: matrix(transformer_bottom.shape, v) for k, v in values.items()})
+
+    @app.route('/timerange-change', methods=['POST'])
+    def timerange_change():
+        args = flask.request.args
+        json_data = flask.request.get_json(force=True)
+        cls, values = conditioning_tensors(args)
+        top_code, bottom_code = codes(json_data)
+        mask = torch.BoolTensor(json_data['mask']).unsqueeze(0)
+        layer = str(args.get('layer'))
+        uniform = str(args.get('uniform_sampling', default='False')).lower() in ('1', 'true', 'yes', 'y', 'on', 't')
+        new_top, new_bottom = inpainting.timerange_change(
+            transformer_top, transformer_bottom, top_code, bottom_code, mask, layer,
+            args.get('start_index_top', type=int), args.get('temperature', type=float), cls, cls, device,
+            uniform_sampling=uniform, generator=generator, **sampling)
+        cond_top, cond_bottom = json_data.get('top_conditioning'), json_data.get('bottom_conditioning')
+        if layer == 'top' and cond_bottom is not None:
+            # the regenerated zone now carries the requested classes (flask_server.py:845-853)
+            ratio_f = transformer_bottom.shape[0] // transformer_top.shape[0]
+            ratio_t = transformer_bottom.shape[1] // transformer_top.shape[1]
+            m = mask[0].repeat_interleave(ratio_f, 0).repeat_interleave(ratio_t, 1).tolist()
+            cond_bottom = {name: [[values[name] if mv else pv for pv, mv in zip(row, mrow)]
+                                  for row, mrow in zip(rows, m)] for name, rows in cond_bottom.items()}
+        return respond(new_top, new_bottom, cond_top, cond_bottom)
+
+    @app.route('/erase', methods=['POST'])
+    def erase():
+        args = flask.request.args
+        json_data = flask.request.get_json(force=True)
+        top_code, bottom_code = codes(json_data)
+        new_top, new_bottom = inpainting.erase(vqvae, top_code, bottom_code, torch.BoolTensor(json_data['mask']),
+                                               float(args.get('eraser_amplitude')), int(args.get('start_index_top')))
+        return respond(new_top, new_bottom, json_data.get('top_conditioning'), json_data.get('bottom_conditioning'))
+
+    @app.route('/get-audio', methods=['POST'])
+    def get_audio():
+        if spectrograms_helper is None:
+            flask.abort(501)
+        top_code, bottom_code = codes(flask.request.get_json(force=True))
+        audio = inpainting.codes_to_audio(vqvae, spectrograms_helper, top_code, bottom_code)[0]
+        return flask.send_file(io.BytesIO(_wav_bytes(audio, spectrograms_helper.fs_hz)), mimetype="audio/wav",
+                               max_age=0)
+
+    return app

@@ -398,6 +398,30 @@ def scheduler_fixtures():
     _save("schedulers.npz", **out)
 
 
+def time_indexes_fixtures():
+    """`make_time_indexes` (flask_server.py:670-682) is a pure function living in a script whose imports
+    (flask_cors, GANsynth_pytorch, ...) are absent: its definition is extracted from the reference source
+    with `ast` and executed here, and only its outputs are stored."""
+    import ast
+    from typing import List
+    src = (REF / "flask_server.py").read_text()
+    fn = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "make_time_indexes")
+    ns = {"List": List}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "flask_server.py", "exec"), ns)
+    out, cases = {}, []
+    for codemap_duration, transformer_duration in ((32, 32), (64, 32), (96, 32), (40, 32), (128, 64), (33, 32),
+                                                   (12, 4), (16, 8)):
+        for start in sorted({0, 1, (codemap_duration - transformer_duration) // 2,
+                             codemap_duration - transformer_duration}):
+            if start < 0:
+                continue
+            cases.append((start, codemap_duration, transformer_duration))
+            out[f"ti::{start}_{codemap_duration}_{transformer_duration}"] = np.array(
+                ns["make_time_indexes"](start, codemap_duration, transformer_duration), dtype=np.int64)
+    out["cases"] = np.array(cases, dtype=np.int64)
+    _save("time_indexes.npz", **out)
+
+
 def main():
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     _install_stubs()
@@ -430,6 +454,7 @@ def main():
     prior_wrapper_fixtures()
     filtering_fixtures()
     scheduler_fixtures()
+    time_indexes_fixtures()
 
 
 if __name__ == "__main__":

@@ -280,3 +280,14 @@ def test_spectrogram_specification_is_self_consistent():
     M = S.mel_matrix(cfg)
     assert M.shape == (128, 128) and float(M.max()) <= 1.0 and float(M.min()) >= 0.0
     assert S.instantaneous_frequency(torch.tensor([[0.0, 3.0, -3.0]]))[0, 2] == pytest.approx((2 * math.pi - 6.0) / math.pi)
+
+
+def test_make_time_indexes_matches_reference(golden_dir):
+    """inpainting.make_time_indexes against outputs of the reference's function
+    (flask_server.py:670-682; oracle/make_golden.py::time_indexes_fixtures)."""
+    import inpainting
+    z = np.load(golden_dir / "time_indexes.npz")
+    assert len(z["cases"]) >= 20
+    for start, codemap_duration, transformer_duration in z["cases"].tolist():
+        got = inpainting.make_time_indexes(start, codemap_duration, transformer_duration)
+        assert got == z[f"ti::{start}_{codemap_duration}_{transformer_duration}"].tolist()

@@ -263,3 +263,105 @@ def test_sample_model_matches_full_pass_sampling(golden_dir):
     out_b = S.sample_model(bottom, dev, B, [16, 8], temperature=1.0, condition=got, class_conditioning=cls,
                            generator=torch.Generator().manual_seed(1))
     assert out_b.shape == (B, 16, 8) and int(out_b.min()) >= 0 and int(out_b.max()) < 32
+
+
+def test_inpainting_operations(golden_dir):
+    """The compute behind the reference's /timerange-change, /generate, /erase and /get-audio routes
+    (flask_server.py:376-443,685-931,1003-1021): regenerated zones stay inside the mask and the model
+    window, everything else is returned untouched, same seed -> same result."""
+    import inpainting
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    from GANsynth_pytorch.spectrograms_helper import SpectrogramsHelper
+    z, top, bottom = _models(golden_dir)
+    dev = _dev()
+    cls = {k[5:]: torch.from_numpy(z[k])[:1].to(dev) for k in z.files if k.startswith("cls::")}
+    g = torch.Generator().manual_seed(4)
+    T_top, T_bot = 8, 16                                   # codemaps twice as long as the models' windows
+    top_code = torch.randint(0, 32, (1, 8, T_top), generator=g).to(dev)
+    bottom_code = torch.randint(0, 32, (1, 16, T_bot), generator=g).to(dev)
+    mask = torch.zeros(1, 8, 4, dtype=torch.bool)
+    mask[0, 2:6, 1:3] = True
+    start = 3
+
+    def run(layer, seed, m=mask):
+        return inpainting.timerange_change(top, bottom, top_code, bottom_code, m, layer, start, 1.0, cls, cls, dev,
+                                           generator=torch.Generator().manual_seed(seed), top_p_sampling_p=0.9)
+    new_top, new_bottom = run("top", 1)
+    assert new_top.shape == top_code.shape and new_bottom.shape == bottom_code.shape
+    full_top = torch.zeros(1, 8, T_top, dtype=torch.bool, device=dev)
+    full_top[..., start:start + 4] = mask.to(dev)
+    assert torch.equal(new_top[~full_top], top_code[~full_top])
+    assert int(new_top.min()) >= 0 and int(new_top.max()) < 32
+    full_bot = full_top.repeat_interleave(2, -2).repeat_interleave(2, -1)
+    assert torch.equal(new_bottom[~full_bot], bottom_code[~full_bot])
+    assert (new_bottom[full_bot] != bottom_code[full_bot]).any()
+    again_top, again_bottom = run("top", 1)
+    assert torch.equal(again_top, new_top) and torch.equal(again_bottom, new_bottom)
+    # bottom layer only: the top codemap is returned as is
+    mask_b = torch.zeros(1, 16, 8, dtype=torch.bool)
+    mask_b[0, 4:9, 2:7] = True
+    t2, b2 = run("bottom", 2, mask_b)
+    assert torch.equal(t2, top_code)
+    fb = torch.zeros(1, 16, T_bot, dtype=torch.bool, device=dev)
+    fb[..., 2 * start:2 * start + 8] = mask_b.to(dev)
+    assert torch.equal(b2[~fb], bottom_code[~fb]) and (b2[fb] != bottom_code[fb]).any()
+    with pytest.raises(ValueError):
+        run("middle", 0)
+    # generate from scratch
+    gt, gb = inpainting.generate(top, bottom, 1.0, cls, cls, dev, generator=torch.Generator().manual_seed(3))
+    assert gt.shape == (1, 8, 4) and gb.shape == (1, 16, 8) and int(gt.max()) < 32 and int(gb.max()) < 32
+    # erase + audio through a VQ-VAE whose code maps have the models' shapes ([1,2,64,32] -> 8x4 / 16x8)
+    torch.manual_seed(9)
+    vq = VQVAE(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16,
+               num_embeddings=64, resolution_factors={"bottom": 4, "top": 2}).to(dev).eval()
+    et, eb = inpainting.erase(vq, gt, gb, mask[0], amplitude=0.5, start_index_top=0)
+    assert et.shape == gt.shape and eb.shape == gb.shape and et.dtype == torch.int64
+    helper = SpectrogramsHelper(16000, 128, 32, 128).to(dev)           # 64 bins = the decoded height
+    audio = inpainting.codes_to_audio(vq, helper, gt, gb)
+    assert audio.shape == (1, 32 * 32) and torch.isfinite(audio).all()
+
+
+def test_flask_routes_round_trip(golden_dir):
+    """Same routes / query arguments / JSON schema as the reference server (flask_server.py:376-443,
+    685-1021; request example locustfile.py:4-17), served by Flask's test client."""
+    import json
+    import flask_server
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    from GANsynth_pytorch.spectrograms_helper import SpectrogramsHelper
+    z, top, bottom = _models(golden_dir)
+    dev = _dev()
+
+    class Enc:                                   # stands in for sklearn's LabelEncoder
+        def __init__(self, classes):
+            self.classes = list(classes)
+
+        def transform(self, values):
+            return np.array([self.classes.index(v) for v in values])
+    encoders = {"pitch": Enc(range(24, 85)), "instrument_family_str": Enc([f"fam{i}" for i in range(11)])}
+    torch.manual_seed(9)
+    vq = VQVAE(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16,
+               num_embeddings=64, resolution_factors={"bottom": 4, "top": 2}).to(dev).eval()
+    helper = SpectrogramsHelper(16000, 128, 32, 128).to(dev)
+    app = flask_server.create_app(vq, top, bottom, encoders, dev, spectrograms_helper=helper, top_p=0.9, seed=0)
+    c = app.test_client()
+    q = "pitch=60&instrument_family_str=fam3&temperature=1.0"
+    r = c.get("/generate?" + q)
+    assert r.status_code == 200
+    body = r.get_json()
+    assert np.array(body["top_code"]).shape == (8, 4) and np.array(body["bottom_code"]).shape == (16, 8)
+    assert body["top_conditioning"]["pitch"][0][0] == 60 and body["bottom_conditioning"]["instrument_family_str"][3][2] == "fam3"
+    mask = np.zeros((8, 4), dtype=bool)
+    mask[1:5, 0:2] = True
+    payload = dict(body, mask=mask.tolist())
+    r2 = c.post("/timerange-change?layer=top&start_index_top=0&uniform_sampling=False&" + q.replace("60", "72"),
+                data=json.dumps(payload))
+    assert r2.status_code == 200
+    b2 = r2.get_json()
+    t0, t2 = np.array(body["top_code"]), np.array(b2["top_code"])
+    assert (t0[~mask] == t2[~mask]).all()
+    assert b2["bottom_conditioning"]["pitch"][2][0] == 72 and b2["bottom_conditioning"]["pitch"][0][0] == 60
+    r3 = c.post("/erase?eraser_amplitude=0.3&start_index_top=0", data=json.dumps(payload))
+    assert r3.status_code == 200 and np.array(r3.get_json()["bottom_code"]).shape == (16, 8)
+    r4 = c.post("/get-audio", data=json.dumps(body))
+    assert r4.status_code == 200 and r4.mimetype == "audio/wav" and r4.data[:4] == b"RIFF"
+    assert len(r4.data) == 44 + 2 * 32 * 32

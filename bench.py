@@ -130,6 +130,72 @@ def _prior_sampling(device):
     return out
 
 
+def _top_prior(device):
+    from interactive_spectrogram_inpainting.priors.transformer import SelfAttentiveVQTransformer
+    torch.manual_seed(2)
+    return SelfAttentiveVQTransformer(
+        shape=[32, 32], condition_shape=[32, 32], n_class=512, channel=256, kernel_size=5, n_block=4,
+        n_res_block=4, res_channel=256, d_model=512, embeddings_dim=32, positional_embeddings_dim=16,
+        use_relative_transformer=True, predict_frequencies_first=True, conditional_model=True,
+        self_conditional_model=True, add_mask_token_to_symbols=True,
+        class_conditioning_prepend_to_dummy_input=True,
+        class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+        class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device)
+
+
+def _prior_training(device, B=8, steps=3):
+    """BASELINE config 4 on one GPU: training step of the top prior (1024 tokens + start symbol, d_model 512,
+    6 + 8 layers, fp32, dropout 0.1, label smoothing, Adam): forward + loss + backward + optimizer step."""
+    from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss
+    m = _top_prior(device).train()
+    code = torch.randint(0, 512, (B, 32, 32), device=device)
+    mask = torch.rand(B, 32, 32, device=device) < 0.5
+    cls = {"pitch": torch.full((B, 1), 24, device=device),
+           "instrument_family_str": torch.zeros(B, 1, dtype=torch.long, device=device)}
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    crit = LabelSmoothingLoss(512, 0.1, dim=1)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        src, tgt = m.to_sequences(code, condition=code, class_conditioning=cls, mask=mask)
+        logits, _ = m(tgt, condition=src)
+        loss = crit(m.to_time_frequency_map(logits, kind="target", permute_output_as_logits=True), code)
+        loss.backward()
+        opt.step()
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    return {"ms_per_step": round(dt * 1e3, 1), "tokens_per_s": round(B * 1024 / dt, 0), "codemaps_per_s": round(B / dt, 1),
+            "config": f"top prior [32,32], B={B} x 1025 tokens, d_model 512, 6+8 layers, 8 heads, fp32, Adam, 1 GPU"}
+
+
+def _frontend(device, B=64):
+    """Audio -> mel/IF spectrogram -> audio (n_fft 2048, hop 512, 4 s clips at 16 kHz): DFT and mel
+    projections as fp32 GEMMs + HBM-bound polar / scan / transpose kernels."""
+    from GANsynth_pytorch.spectrograms_helper import MelSpectrogramsHelper
+    h = MelSpectrogramsHelper(16000, 2048, 512, 2048).to(device)
+    x = torch.randn(B, 64000, device=device) * 0.1
+    spec = h.to_spectrogram(x)
+    out = {}
+    for name, fn in (("to_spectrogram", lambda: h.to_spectrogram(x)), ("to_audio", lambda: h.to_audio(spec))):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize(device)
+        dt = (time.perf_counter() - t0) / 5
+        out[name] = {"ms": round(dt * 1e3, 3), "clips_per_s": round(B / dt, 0)}
+    out["config"] = f"B={B} clips x 64000 samples -> [B,2,1024,125] (mel), fp32"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,6 +325,8 @@ def main():
         line["alt_precision_single_gpu"] = alt
         if not args.no_prior:
             line["prior_sampling"] = _prior_sampling(device)
+            line["prior_training_single_gpu"] = _prior_training(device)
+            line["frontend"] = _frontend(device)
         if not args.no_cpu_baseline and world >= 1:
             line["cpu_baseline"] = _cpu_baseline(sd)
         print(json.dumps(line), flush=True)

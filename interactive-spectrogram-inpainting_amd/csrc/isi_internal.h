@@ -38,7 +38,12 @@ int linear_rows_f32(const float *x, int x_stride, const float *W, const float *b
                     hipStream_t stream);
 
 int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, float *workspace, hipStream_t stream);
+int rel_attention_decode_pos_f32(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
+                                 hipStream_t stream);
 size_t rel_attention_decode_workspace_floats(int B, int H, int head_dim);
+int sample_row_pos_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
+                       const float *u, int64_t *out, float *filtered, const int *pos, int pos_off,
+                       hipStream_t stream);
 int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                    const float *u, int64_t *out, float *filtered, hipStream_t stream);
 

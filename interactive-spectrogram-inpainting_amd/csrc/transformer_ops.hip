@@ -160,7 +160,17 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ e, float *__restrict__ out, int Sk, int64_t q_sb, int64_t q_sh, int64_t k_ss,
     int64_t k_sb, int64_t k_sh, int64_t v_ss, int64_t v_sb, int64_t v_sh, int64_t o_sb, int64_t o_sh,
-    int q_pos, int Cq, int Ck, int Ek, int R, float scale, int chunk, float *__restrict__ partial) {
+    int q_pos, int Cq, int Ck, int Ek, int R, float scale, int chunk, float *__restrict__ partial,
+    const int *__restrict__ pos, int self_keys) {
+  // Replayable form (hipGraph): the position comes from device memory; for self-attention the key
+  // count is position + 1 and the (fixed) number of splits shares it evenly.
+  if (pos) {
+    q_pos = *pos;
+    if (self_keys) {
+      Sk = q_pos + 1;
+      chunk = (Sk + (int)gridDim.z - 1) / (int)gridDim.z;
+    }
+  }
   // blockIdx.z = key split: this workgroup handles keys [z*chunk, min(Sk, (z+1)*chunk)) and,
   // when there are several splits, writes an un-normalised partial (o, max, sum) that
   // rel_attention_combine_kernel merges.
@@ -180,6 +190,14 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   v += (size_t)kbeg * v_ss;
   const int key0 = kbeg;              // absolute index of local key 0 (relative positions)
   Sk = min(Sk - kbeg, chunk);         // local key count
+  if (Sk <= 0) {                      // empty split (only with a fixed split count): neutral partial
+    if (gridDim.z > 1 && tid < HD) {
+      float *pp = partial + (((size_t)b * gridDim.x + h) * gridDim.z + blockIdx.z) * (HD + 2);
+      pp[tid] = 0.f;
+      if (tid == 0) { pp[HD] = -1e30f; pp[HD + 1] = 0.f; }
+    }
+    return;
+  }
   const float4 qq = *reinterpret_cast<const float4 *>(q + b * q_sb + h * q_sh + gl * 4);
   const int evq = q_pos / Cq;
   const float *kb = k + b * k_sb + h * k_sh + gl * 4;
@@ -288,6 +306,13 @@ size_t rel_attention_decode_workspace_floats(int B, int H, int head_dim) {
 }
 
 int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, float *workspace, hipStream_t stream) {
+  return rel_attention_decode_pos_f32(g, q_pos, nullptr, 0, workspace, stream);
+}
+
+// pos != nullptr: the query position is read from device memory at run time (replayable launch); with
+// self_keys the key count is position + 1 and g->Sk is its upper bound (it fixes grid and LDS sizes).
+int rel_attention_decode_pos_f32(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
+                                 hipStream_t stream) {
   if (!g || !g->q || !g->k || !g->v || !g->out) return invalid("attention_decode: null pointer");
   if (g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->Cq <= 0 || g->Ck <= 0) return invalid("attention_decode: bad shape");
   if (g->Sk > 65536) return unsupported("attention_decode: more than 65536 keys");
@@ -304,7 +329,8 @@ int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, float *workspace
       return check_launch("hipFuncSetAttribute(attention_decode)");                                         \
     hipLaunchKernelGGL(kern, grid, block, smem, stream, g->q, g->k, g->v, g->rel_embeddings, g->out, g->Sk, \
                        g->q_sb, g->q_sh, g->k_ss, g->k_sb, g->k_sh, g->v_ss, g->v_sb, g->v_sh, g->o_sb,     \
-                       g->o_sh, q_pos, g->Cq, g->Ck, g->Ek, g->rel_rows, g->scale, chunk, workspace);       \
+                       g->o_sh, q_pos, g->Cq, g->Ck, g->Ek, g->rel_rows, g->scale, chunk, workspace, pos,  \
+                       self_keys);                                                                          \
   } while (0)
   switch (g->head_dim) {
     case 16: ISI_DEC(16); break;
@@ -330,7 +356,9 @@ __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__res
                                                               int n, float inv_temperature, int top_k,
                                                               float top_p, const float *__restrict__ u,
                                                               int64_t *__restrict__ out,
-                                                              float *__restrict__ filtered) {
+                                                              float *__restrict__ filtered,
+                                                              const int *__restrict__ pos, int pos_off) {
+  if (pos) u += (size_t)(*pos - pos_off) * gridDim.x;  // replayable launch: this token's uniforms
   __shared__ float val[1024];
   __shared__ int idx[1024];
   __shared__ float scan[1024];
@@ -406,12 +434,19 @@ __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__res
 
 int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                    const float *u, int64_t *out, float *filtered, hipStream_t stream) {
+  return sample_row_pos_f32(logits, stride, rows, n, temperature, top_k, top_p, u, out, filtered, nullptr, 0, stream);
+}
+
+// pos != nullptr: row r draws with u[(*pos - pos_off) * rows + r]
+int sample_row_pos_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
+                       const float *u, int64_t *out, float *filtered, const int *pos, int pos_off,
+                       hipStream_t stream) {
   if (!logits || !u || !out || rows <= 0 || n <= 0 || temperature <= 0.f) return invalid("sample_row: bad argument");
   if (n > 1024) return unsupported("sample_row: at most 1024 classes");
   int np = 64;
   while (np < n) np <<= 1;
   hipLaunchKernelGGL(sample_row_f32_kernel, dim3(rows), dim3(np), 0, stream, logits, stride, n, 1.0f / temperature,
-                     top_k, top_p, u, out, filtered);
+                     top_k, top_p, u, out, filtered, pos, pos_off);
   return check_launch("sample_row_f32");
 }
 

@@ -7,6 +7,7 @@ import sys
 
 
 def short(n):
+    n = n.replace('(anonymous namespace)::', '')
     n = re.sub(r'isi::', '', n)
     n = re.sub(r'\(.*', '', n)
     return n[:64]

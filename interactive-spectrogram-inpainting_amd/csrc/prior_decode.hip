@@ -191,10 +191,10 @@ int launch_row_linear(const RowLinArgs &a, hipStream_t st) {
 // codes[b, i] = sampled[b]; x_seq[p + 1][b, 0:eff] = table[sampled[b], :]   (i = p - i_off, p = *pos)
 __global__ void commit_token_kernel(const int64_t *__restrict__ sampled, const float *__restrict__ table,
                                     int eff, int64_t *__restrict__ codes, int codes_stride,
-                                    const int *__restrict__ pos, int i_off, int S_t, float *__restrict__ x_seq,
-                                    int B, int x_stride) {
+                                    const int *__restrict__ pos, int p_value, int i_off, int S_t,
+                                    float *__restrict__ x_seq, int B, int x_stride) {
   const int b = blockIdx.x;
-  const int p = *pos;
+  const int p = pos ? *pos : p_value;
   const int64_t tok = sampled[b];
   if (threadIdx.x == 0) codes[(size_t)b * codes_stride + (p - i_off)] = tok;
   if (p + 1 >= S_t) return;
@@ -210,7 +210,7 @@ size_t prior_decode_scratch_floats(const isi_prior_w *w, int B) {
   if (!w || B <= 0) return 0;
   const size_t d = w->d_model;
   // q, attn out, y1, y2, y3(a), y3(b), hidden, logits, sampled(int64)
-  return (size_t)B * (6 * d + w->dim_feedforward + w->n_class) + 2 * (size_t)B + 64 + 16 +
+  return (size_t)B * (6 * d + w->dim_feedforward + w->n_class) + 2 * (size_t)B + 64 + 32 +
          rel_attention_decode_workspace_floats(B, w->nhead, w->d_model / w->nhead);
 }
 
@@ -297,7 +297,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
                                    nullptr, pos, i_off, q_st)))
         return rc;
       hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, q_st, sampled, w->embed_table, w->eff_dim,
-                         s->codes, s->S, pos, i_off, s->S_t, s->x_seq, B, d);
+                         s->codes, s->S, pos, 0, i_off, s->S_t, s->x_seq, B, d);
       if ((rc = check_launch("commit_token"))) return rc;
     }
     hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, q_st, pos, 1, 1);
@@ -309,6 +309,36 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   };
 
   if (p_begin == p_end) return ISI_OK;
+
+  // ---- ISI_PRIOR_PERSISTENT=1: one persistent cooperative kernel per position (prior_decode_persistent.hip)
+  // followed by the draw and the commit of the sampled token.  Measured on MI355X: 0.89 ms per position
+  // against 0.50 ms for the multi-kernel path below (a software grid barrier plus cache-bypassing exchange
+  // rows cost more than this part's ~4.5 us kernel boundary), so it is not the default.
+  const bool use_persistent = [] { const char *e = getenv("ISI_PRIOR_PERSISTENT"); return e && atoi(e) != 0; }();
+  if (use_persistent && prior_position_supported(w, B)) {
+    unsigned *bar = reinterpret_cast<unsigned *>(pos + 4);
+    if (hipMemsetAsync(bar, 0, 4 * sizeof(unsigned), st) != hipSuccess) return check_launch("hipMemsetAsync(barrier)");
+    for (int p = p_begin; p < p_end; ++p) {
+      const bool smp = sampled_at(p);
+      int rc = prior_position_run(w, s, q, y1, y2, y3a, y3b, hid, logits, attn_ws, bar, p, smp ? 1 : 0, st);
+      if (rc) return rc;
+      if (!smp) continue;
+      const int i = p - i_off;
+      if ((rc = sample_row_f32(logits, w->n_class, B, w->n_class, temperature, top_k, top_p,
+                               s->uniforms + (size_t)i * B, sampled, nullptr, st)))
+        return rc;
+      hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, st, sampled, w->embed_table, w->eff_dim,
+                         s->codes, s->S, static_cast<const int *>(nullptr), p, i_off, s->S_t, s->x_seq, B, d);
+      if ((rc = check_launch("commit_token"))) return rc;
+    }
+    unsigned flag = 0;   // a grid barrier that gave up (spin limit) leaves garbage behind: report it
+    if (hipMemcpyAsync(&flag, bar + 2, sizeof flag, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return check_launch("prior_position: reading the barrier status");
+    if (flag) { set_last_error("prior_position: grid barrier timed out"); return ISI_E_LAUNCH; }
+    return ISI_OK;
+  }
+
   hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, p_begin, 0);
   int rc = check_launch("set_position");
   if (rc) return rc;
@@ -319,7 +349,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   // ~85 launches per position collapse into one graph launch.  Measured on MI355X: no gain (1.93 k vs
   // 1.96 k codes/s) -- the loop is bound by the GPU-side duration of the dependent kernels (4.5-9 us
   // each in the kernel trace, profiles/), not by host launch cost -- so direct launches stay the default.
-  static const bool use_graph = [] { const char *e = getenv("ISI_PRIOR_GRAPH"); return e && atoi(e) != 0; }();
+  const bool use_graph = [] { const char *e = getenv("ISI_PRIOR_GRAPH"); return e && atoi(e) != 0; }();
   if (use_graph && p_end - p >= 4) {
     hipStream_t cap = nullptr;
     hipGraph_t graphs[2] = {nullptr, nullptr};

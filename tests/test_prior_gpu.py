@@ -259,6 +259,17 @@ def test_sample_model_matches_full_pass_sampling(golden_dir):
         tgt[:, i + 1, :top.embeddings_effective_dim] = top.embed_data(s, Seq2SeqInputKind.Target)
     ref = top.target_codemaps_helper.to_time_frequency_map(seq)
     assert torch.equal(got, ref)
+    # the opt-in execution modes of the decoding loop (hipGraph replay of the per-position launch
+    # sequence; one persistent cooperative kernel per position) draw the same codes
+    import os
+    for var in ("ISI_PRIOR_GRAPH", "ISI_PRIOR_PERSISTENT"):
+        os.environ[var] = "1"
+        try:
+            alt = S.sample_model(top, dev, B, [8, 4], temperature=0.9, class_conditioning=cls,
+                                 initial_code=init.clone(), mask=mask, top_p_sampling_p=0.8, uniforms=uni)
+        finally:
+            del os.environ[var]
+        assert torch.equal(alt, ref), var
     # bottom prior conditioned on the sampled top map: runs and stays in range
     out_b = S.sample_model(bottom, dev, B, [16, 8], temperature=1.0, condition=got, class_conditioning=cls,
                            generator=torch.Generator().manual_seed(1))

@@ -65,23 +65,21 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigne
 // by ~2^-16 (fp32: 2^-24); opt-in (ISI_CONV_BF16X3), never the default.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDB = 40;  // padded LDS row of a bf16 plane (elements): 80 B, conflict-free b128 reads
+constexpr int LDB = 32;  // LDS row of a bf16 plane (elements): 64 B, unpadded; the four 16-B slots of a row are
+                         // XOR-swizzled with (row >> 2) & 3: the 16-lane groups of ds_read_b128 then hit 16 distinct
+                         // slots, and the contiguous 16-lane groups of ds_write_b64 cover 32 distinct banks
+__device__ __forceinline__ int bf_slot(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 8; }
 
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-  unsigned u = __builtin_bit_cast(unsigned, x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// hi = bf16(x) (round to nearest even: v_cvt_pk_bf16_f32), lo = bf16(x - hi): ~10 VALU per float4
 __device__ __forceinline__ void split_bf16x4(const float4 v, uint2 &hi, uint2 &lo) {
-  const float f[4] = {v.x, v.y, v.z, v.w};
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = bf16_rne(f[i]);
-    l[i] = bf16_rne(f[i] - __builtin_bit_cast(float, h[i] << 16));
-  }
-  hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-  lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+  const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const bf16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), bf16x2);
+  const bf16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), bf16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
@@ -273,8 +271,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (BF) {
         uint2 hi, lo;
         split_bf16x4(v, hi, lo);
-        *reinterpret_cast<uint2 *>(Ahi + (lrow + 32 * j) * LDB + lq * 4) = hi;
-        *reinterpret_cast<uint2 *>(Alo + (lrow + 32 * j) * LDB + lq * 4) = lo;
+        const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
+        *reinterpret_cast<uint2 *>(Ahi + wo) = hi;
+        *reinterpret_cast<uint2 *>(Alo + wo) = lo;
       } else {
         *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lq * 4) = v;
       }
@@ -284,8 +283,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (BF) {
         uint2 hi, lo;
         split_bf16x4(rb[j], hi, lo);
-        *reinterpret_cast<uint2 *>(Bhi + (lrow + 32 * j) * LDB + lq * 4) = hi;
-        *reinterpret_cast<uint2 *>(Blo + (lrow + 32 * j) * LDB + lq * 4) = lo;
+        const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
+        *reinterpret_cast<uint2 *>(Bhi + wo) = hi;
+        *reinterpret_cast<uint2 *>(Blo + wo) = lo;
       } else {
         *reinterpret_cast<float4 *>(b + (lrow + 32 * j) * LDK + lq * 4) = rb[j];
       }
@@ -319,13 +319,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         s16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const int off = (wm0 + i * 32 + frow) * LDB + s * 16 + fq * 8;
+          const int off = (wm0 + i * 32 + frow) * LDB + bf_slot(wm0 + i * 32 + frow, s * 2 + fq);
           ah[i] = *reinterpret_cast<const s16x8 *>(Ahi + off);
           al[i] = *reinterpret_cast<const s16x8 *>(Alo + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int off = (wn0 + j * 32 + frow) * LDB + s * 16 + fq * 8;
+          const int off = (wn0 + j * 32 + frow) * LDB + bf_slot(wn0 + j * 32 + frow, s * 2 + fq);
           bh[j] = *reinterpret_cast<const s16x8 *>(Bhi + off);
           bl[j] = *reinterpret_cast<const s16x8 *>(Blo + off);
         }

@@ -57,21 +57,16 @@ __device__ __forceinline__ float elem(const float4 &v, int e) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDB = 40;  // bf16 plane row (elements): 80 B
-__device__ __forceinline__ unsigned bf16_rne(float x) {
-  unsigned u = __builtin_bit_cast(unsigned, x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return u >> 16;
-}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// hi = bf16(x) (round to nearest even: v_cvt_pk_bf16_f32), lo = bf16(x - hi)
 __device__ __forceinline__ void split_bf16x4(const float4 v, uint2 &hi, uint2 &lo) {
-  const float f[4] = {v.x, v.y, v.z, v.w};
-  unsigned h[4], l[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = bf16_rne(f[i]);
-    l[i] = bf16_rne(f[i] - __builtin_bit_cast(float, h[i] << 16));
-  }
-  hi = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-  lo = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+  const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const bf16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), bf16x2);
+  const bf16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), bf16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
 __device__ __forceinline__ f32x16 mfma3(const s16x8 ah, const s16x8 al, const s16x8 bh, const s16x8 bl, f32x16 acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
@@ -223,10 +218,10 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
     for (int r = 0; r < 16; ++r) {
       const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
       const float hv = frow < p.R ? fmaxf(acc1[r] + b1, 0.f) : 0.f;
-      const unsigned hh = bf16_rne(hv);
-      const unsigned hl = bf16_rne(hv - __builtin_bit_cast(float, hh << 16));
-      Ahi[row * LDB + frow] = (unsigned short)hh;
-      Alo[row * LDB + frow] = (unsigned short)hl;
+      const __bf16 hh = (__bf16)hv;
+      const __bf16 hl = (__bf16)(hv - (float)hh);
+      Ahi[row * LDB + frow] = __builtin_bit_cast(unsigned short, hh);
+      Alo[row * LDB + frow] = __builtin_bit_cast(unsigned short, hl);
     }
     __syncthreads();
 #pragma unroll

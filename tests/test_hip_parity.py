@@ -264,9 +264,9 @@ def test_extract_rows(golden_dir):
 
 
 def test_split_bf16_precision_modes():
-    """Opt-in bf16x3 products: decoder-only mode must leave every code index untouched and
-    the reconstruction within 1e-4 of the exact-fp32 path; the all-layers mode may only move
-    indices that are near-ties."""
+    """Split-bf16 products: the default decoder-only mode must leave every code index untouched and
+    the reconstruction within 1e-4 of the exact-fp32 path (north_star: 1e-3); the all-layers mode may
+    only move indices that are near-ties."""
     from oracle import vqvae_oracle as O
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     cfg = O.Config(in_channel=2)
@@ -277,7 +277,8 @@ def test_split_bf16_precision_modes():
     m = VQVAE(in_channel=2)
     m.load_state_dict(sd)
     m = m.to(_dev()).eval()
-    assert m.conv_precision == "f32"
+    assert m.conv_precision == "bf16x3_decoder"
+    m.conv_precision = "f32"
     ref = m(x)
     m.conv_precision = "bf16x3_decoder"
     got = m(x)

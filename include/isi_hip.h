@@ -131,6 +131,9 @@ typedef struct isi_dst {
 #define ISI_CONV_BF16X3 2 /* opt-in: split-bf16 products (a_hi b_hi + a_hi b_lo + a_lo b_hi on
                            * the bf16 matrix pipe, fp32 accumulate; per-product relative error
                            * ~2^-16 instead of 2^-24).  Default is exact fp32.              */
+#define ISI_CONV_BF16X6 4 /* opt-in: six-term split (x = hi + mid + lo exactly; hi.hi, hi.mid, mid.hi,
+                           * hi.lo, lo.hi, mid.mid): every term above 2^-24 of a product is kept --
+                           * fp32-grade products at 6/16 of the fp32 pipe's matrix time.   */
 
 /* Conv2d, groups=1, square stride, symmetric zero padding, fp32.
  *   out = [relu]( conv(cat(src0, src1), W) + bias [+ residual] )
@@ -413,9 +416,11 @@ typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
   isi_decoder_w dec_t, dec;
   int n_upsample;
   isi_conv_w upsample[ISI_MAX_STAGES];
-  int precision; /* 0: exact fp32 everywhere (default).  1: ISI_CONV_BF16X3 in `dec` and
-                  * `upsample` only (code indices stay bit-exact).  2: in every convolution
-                  * (indices may differ at near-ties).                                     */
+  int precision; /* products of the convolutions (data and accumulation are always fp32):
+                  * 0: fp32 matrix pipe everywhere.  1: ISI_CONV_BF16X3 in `dec` and `upsample` only
+                  * (no code index depends on them).  2: ISI_CONV_BF16X3 in every convolution (near-tie
+                  * indices move).  3: ISI_CONV_BF16X6 (fp32-grade six-term split) in every layer that
+                  * feeds a code index, ISI_CONV_BF16X3 in `dec` and `upsample`.            */
 } isi_vqvae_w;
 
 /* Outputs of VQVAE.encode / forward (vqvae.py:245-278).  Any pointer may be

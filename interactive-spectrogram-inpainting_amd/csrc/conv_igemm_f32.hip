@@ -82,9 +82,24 @@ __device__ __forceinline__ void split_bf16x4(const float4 v, uint2 &hi, uint2 &l
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
 
+// x = hi + mid + lo exactly (3 x 8 significand bits): the six products hi.hi, hi.mid, mid.hi, hi.lo, lo.hi,
+// mid.mid carry every term above 2^-24 of the result ("bf16x6": fp32-grade products at 6/16 of the fp32 pipe's time)
+__device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
+  const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+  const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
+  const bf16x2 la = __builtin_convertvector(ra - __builtin_convertvector(ma, f32x2), bf16x2);
+  const bf16x2 lb = __builtin_convertvector(rb - __builtin_convertvector(mb, f32x2), bf16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  mid = make_uint2(__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb));
+  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) {
-  constexpr bool BF = PREC == 1;
+  constexpr bool BF = PREC >= 1;
+  constexpr bool BF6 = PREC == 2;
   constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int RA = BM / 32;  // A rows staged per thread
@@ -103,7 +118,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   unsigned short *Alo = Ahi + BM * LDB;
   unsigned short *Bhi = Alo + BM * LDB;
   unsigned short *Blo = Bhi + BN * LDB;
-  int *row_b = BF ? reinterpret_cast<int *>(Blo + BN * LDB)
+  unsigned short *Ami = Blo + BN * LDB;     // bf16x6 only: the middle pieces
+  unsigned short *Bmi = Ami + BM * LDB;
+  int *row_b = BF ? reinterpret_cast<int *>(BF6 ? Bmi + BN * LDB : Blo + BN * LDB)
                   : reinterpret_cast<int *>(Bs + NBUF * BN * LDK);  // [BM] batch index or -1
   int *row_y = row_b + BM;
   int *row_x = row_y + BM;
@@ -269,11 +286,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       float4 v = ra[j];
       if constexpr (DUAL) v = sel1 ? ra1[j] : v;
       if constexpr (BF) {
-        uint2 hi, lo;
-        split_bf16x4(v, hi, lo);
+        uint2 hi, mid, lo;
+        if constexpr (BF6) split3_bf16x4(v, hi, mid, lo); else split_bf16x4(v, hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Ahi + wo) = hi;
         *reinterpret_cast<uint2 *>(Alo + wo) = lo;
+        if constexpr (BF6) *reinterpret_cast<uint2 *>(Ami + wo) = mid;
       } else {
         *reinterpret_cast<float4 *>(a + (lrow + 32 * j) * LDK + lq * 4) = v;
       }
@@ -281,11 +299,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
       if constexpr (BF) {
-        uint2 hi, lo;
-        split_bf16x4(rb[j], hi, lo);
+        uint2 hi, mid, lo;
+        if constexpr (BF6) split3_bf16x4(rb[j], hi, mid, lo); else split_bf16x4(rb[j], hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Bhi + wo) = hi;
         *reinterpret_cast<uint2 *>(Blo + wo) = lo;
+        if constexpr (BF6) *reinterpret_cast<uint2 *>(Bmi + wo) = mid;
       } else {
         *reinterpret_cast<float4 *>(b + (lrow + 32 * j) * LDK + lq * 4) = rb[j];
       }
@@ -316,30 +335,48 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       // 32x32x16 bf16 MFMA: lane (row = lane & 31, k-block = lane >> 5) holds 8 consecutive k
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        s16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        s16x8 ah[TM], al[TM], bh[TN], bl[TN], am[BF6 ? TM : 1], bm[BF6 ? TN : 1];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int off = (wm0 + i * 32 + frow) * LDB + bf_slot(wm0 + i * 32 + frow, s * 2 + fq);
           ah[i] = *reinterpret_cast<const s16x8 *>(Ahi + off);
           al[i] = *reinterpret_cast<const s16x8 *>(Alo + off);
+          if constexpr (BF6) am[i] = *reinterpret_cast<const s16x8 *>(Ami + off);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int off = (wn0 + j * 32 + frow) * LDB + bf_slot(wn0 + j * 32 + frow, s * 2 + fq);
           bh[j] = *reinterpret_cast<const s16x8 *>(Bhi + off);
           bl[j] = *reinterpret_cast<const s16x8 *>(Blo + off);
+          if constexpr (BF6) bm[j] = *reinterpret_cast<const s16x8 *>(Bmi + off);
         }
+        if constexpr (BF6) {
+          // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {  // lo terms first, the dominant hi.hi last
+          for (int t = 0; t < 6; ++t) {
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const s16x8 av = t == 0 ? al[i] : ah[i];
-              const s16x8 bv = t == 1 ? bl[j] : bh[j];
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
-                                                                  __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
-            }
+              for (int j = 0; j < TN; ++j) {
+                const s16x8 av = t == 0 ? al[i] : (t == 2 || t == 3) ? am[i] : ah[i];
+                const s16x8 bv = t == 1 ? bl[j] : (t == 2 || t == 4) ? bm[j] : bh[j];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                    __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
+              }
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {  // lo terms first, the dominant hi.hi last
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                const s16x8 av = t == 0 ? al[i] : ah[i];
+                const s16x8 bv = t == 1 ? bl[j] : bh[j];
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                    __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
+              }
+          }
         }
       }
     }
@@ -416,7 +453,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 
 template <int BM, int BN, int PREC>
 constexpr size_t conv_smem_bytes() {
-  if (PREC == 1) return (size_t)(2 * BM * LDB + 2 * BN * LDB) * sizeof(unsigned short) + 3 * BM * sizeof(int);
+  if (PREC >= 1) return (size_t)((PREC == 2 ? 3 : 2) * (BM + BN) * LDB) * sizeof(unsigned short) + 3 * BM * sizeof(int);
   return (size_t)(nbuf_for<BN>() * BM * LDK + nbuf_for<BN>() * BN * LDK) * sizeof(float) + 3 * BM * sizeof(int);
 }
 
@@ -440,7 +477,7 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
     const double in_px = nphase == 1 ? (double)a.M / (a.OH * a.OW) * a.H * a.W : (double)a.M;
     const double bytes = 4.0 * (in_px * a.Cin + (double)a.M * np * a.Cout * (a.res ? 2 : 1) +
                                 np * a.Cout * a.K);
-    const int kid = PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
+    const int kid = PREC == 2 ? prof::K_CONV_BF16X6 : PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
                              : (BN == 128 ? prof::K_CONV_128x128 : BN == 64 ? prof::K_CONV_128x64 : prof::K_CONV_128x32);
     prof::Scope scope(kid, flops, bytes, stream);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
@@ -451,6 +488,10 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
 static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_t stream) {
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
+    if (a.bf16x3 == 2) {   // six-term split: fp32-grade products
+      if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 2>(a, nphase, stream);
+      return launch_cfg<128, 128, 2, 2, 0, 2>(a, nphase, stream);
+    }
     if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 1>(a, nphase, stream);
     return launch_cfg<128, 128, 2, 2, 0, 1>(a, nphase, stream);
   }
@@ -511,7 +552,7 @@ int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, cons
   a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.Cout = Cout;
   a.K = KH * KW * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
-  a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = (relu >> 1) & 1; a.M = B * OH * OW;
+  a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = (relu & ISI_CONV_BF16X6) ? 2 : ((relu >> 1) & 1); a.M = B * OH * OW;
   a.pad = pad; a.convT = 0;
   bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (C1 % 4 == 0) && aligned16(s0->ptr) &&
              (s0->sn % 4 == 0) && (s0->sh % 4 == 0) && (s0->sw % 4 == 0);
@@ -550,7 +591,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.K = 4 * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_phase_stride = Cout * a.Kpad;
   a.w_bytes = (unsigned)((size_t)4 * Cout * a.Kpad * 4);
-  a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = (relu >> 1) & 1; a.M = B * H * W;
+  a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = (relu & ISI_CONV_BF16X6) ? 2 : ((relu >> 1) & 1); a.M = B * H * W;
   a.convT = 1;
   const bool vec = s->sc == 1 && (a.C0 % 4 == 0) && aligned16(s->ptr) && (s->sn % 4 == 0) &&
                    (s->sh % 4 == 0) && (s->sw % 4 == 0);

@@ -18,6 +18,7 @@ enum KernelId {
   K_REL_ATTENTION,
   K_CONV_BF16X3,
   K_REL_ATTENTION_BWD,
+  K_CONV_BF16X6,
   K_COUNT
 };
 

@@ -56,7 +56,9 @@ __device__ __forceinline__ float elem(const float4 &v, int e) {
 // ---- opt-in split-bf16 products (ISI_CONV_BF16X3, see conv_igemm_f32.hip)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-constexpr int LDB = 40;  // bf16 plane row (elements): 80 B
+constexpr int LDB = 32;  // bf16 plane row (elements): 64 B unpadded; 16-B slots XOR-swizzled with (row >> 2) & 3
+                         // (conflict-free ds_read_b128 lane groups and ds_write_b64 groups, see conv_igemm_f32.hip)
+__device__ __forceinline__ int bf_slot(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 8; }
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // hi = bf16(x) (round to nearest even: v_cvt_pk_bf16_f32), lo = bf16(x - hi)
@@ -68,23 +70,42 @@ __device__ __forceinline__ void split_bf16x4(const float4 v, uint2 &hi, uint2 &l
   hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
-__device__ __forceinline__ f32x16 mfma3(const s16x8 ah, const s16x8 al, const s16x8 bh, const s16x8 bl, f32x16 acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc, 0, 0, 0);
+// x = hi + mid + lo exactly ("bf16x6", ISI_CONV_BF16X6)
+__device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
+  const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+  const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
+  const bf16x2 la = __builtin_convertvector(ra - __builtin_convertvector(ma, f32x2), bf16x2);
+  const bf16x2 lb = __builtin_convertvector(rb - __builtin_convertvector(mb, f32x2), bf16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  mid = make_uint2(__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb));
+  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+#define ISI_MF(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0)
+// a = {hi, lo, mid}, b = {hi, lo, mid}; smallest terms first
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma_split(const s16x8 *a, const s16x8 *b, f32x16 acc) {
+  if constexpr (PREC == 2) {
+    ISI_MF(a[1], b[0]); ISI_MF(a[0], b[1]); ISI_MF(a[2], b[2]); ISI_MF(a[2], b[0]); ISI_MF(a[0], b[2]); ISI_MF(a[0], b[0]);
+  } else {
+    ISI_MF(a[1], b[0]); ISI_MF(a[0], b[1]); ISI_MF(a[0], b[0]);
+  }
   return acc;
 }
+#undef ISI_MF
 
-template <int TC, bool BF = false>  // TC = C / 32
+template <int TC, int PREC = 0>  // TC = C / 32; PREC 0 exact fp32, 1 bf16x3, 2 bf16x6
 __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
+  constexpr bool BF = PREC >= 1;
+  constexpr int NP = PREC == 2 ? 3 : 2;   // bf16 pieces per value: hi, lo(, mid)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *Ah = smem;                     // [HPIX][LDK]      halo slice   (later: h, [128][LDK])
   float *W1s = Ah + HPIX * LDK;         // [9][32][LDK]     W1 slice     (later: W2, [C][LDK])
-  // bf16x3: bf16 planes instead -- halo hi/lo [HPIX][LDB], W1 slice hi/lo [9*32][LDB]
-  unsigned short *Ahi = reinterpret_cast<unsigned short *>(smem);
-  unsigned short *Alo = Ahi + HPIX * LDB;
-  unsigned short *Whi = Alo + HPIX * LDB;
-  unsigned short *Wlo = Whi + 9 * 32 * LDB;
+  // split-bf16: bf16 planes instead -- halo [NP][HPIX][LDB], W1 slice [NP][9*32][LDB]  (piece 0 hi, 1 lo, 2 mid)
+  unsigned short *Apl = reinterpret_cast<unsigned short *>(smem);
+  unsigned short *Wpl = Apl + NP * HPIX * LDB;
+  constexpr int APS = HPIX * LDB, WPS = 9 * 32 * LDB;   // plane strides
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int C = TC * 32;
@@ -122,10 +143,12 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
       const int i = tid + 256 * j;
       if (j < NA - 1 || i < HPIX * 8) {
         if constexpr (BF) {
-          uint2 hi, lo;
-          split_bf16x4(ra[j], hi, lo);
-          *reinterpret_cast<uint2 *>(Ahi + (i >> 3) * LDB + lq * 4) = hi;
-          *reinterpret_cast<uint2 *>(Alo + (i >> 3) * LDB + lq * 4) = lo;
+          uint2 hi, mid, lo;
+          if constexpr (PREC == 2) split3_bf16x4(ra[j], hi, mid, lo); else split_bf16x4(ra[j], hi, lo);
+          const int wo = (i >> 3) * LDB + bf_slot(i >> 3, lq >> 1) + (lq & 1) * 4;
+          *reinterpret_cast<uint2 *>(Apl + wo) = hi;
+          *reinterpret_cast<uint2 *>(Apl + APS + wo) = lo;
+          if constexpr (PREC == 2) *reinterpret_cast<uint2 *>(Apl + 2 * APS + wo) = mid;
         } else {
           *reinterpret_cast<float4 *>(Ah + (i >> 3) * LDK + lq * 4) = ra[j];
         }
@@ -134,10 +157,12 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       if constexpr (BF) {
-        uint2 hi, lo;
-        split_bf16x4(rw[t], hi, lo);
-        *reinterpret_cast<uint2 *>(Whi + (t * 32 + ln) * LDB + lq * 4) = hi;
-        *reinterpret_cast<uint2 *>(Wlo + (t * 32 + ln) * LDB + lq * 4) = lo;
+        uint2 hi, mid, lo;
+        if constexpr (PREC == 2) split3_bf16x4(rw[t], hi, mid, lo); else split_bf16x4(rw[t], hi, lo);
+        const int wo = (t * 32 + ln) * LDB + bf_slot(t * 32 + ln, lq >> 1) + (lq & 1) * 4;
+        *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
+        *reinterpret_cast<uint2 *>(Wpl + WPS + wo) = lo;
+        if constexpr (PREC == 2) *reinterpret_cast<uint2 *>(Wpl + 2 * WPS + wo) = mid;
       } else {
         *reinterpret_cast<float4 *>(W1s + (t * 32 + ln) * LDK + lq * 4) = rw[t];
       }
@@ -163,16 +188,18 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
     if constexpr (BF) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const int ao = ((ry + t / 3) * HWD + rx + (t % 3)) * LDB + fq * 8;
-        const int bo = (t * 32 + frow) * LDB + fq * 8;
+        const int arow = (ry + t / 3) * HWD + rx + (t % 3), brow = t * 32 + frow;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          const s16x8 ah = *reinterpret_cast<const s16x8 *>(Ahi + ao + s * 16);
-          const s16x8 al = *reinterpret_cast<const s16x8 *>(Alo + ao + s * 16);
-          const s16x8 bh = *reinterpret_cast<const s16x8 *>(Whi + bo + s * 16);
-          const s16x8 bl = *reinterpret_cast<const s16x8 *>(Wlo + bo + s * 16);
-          if (s == 0) acc1 = mfma3(ah, al, bh, bl, acc1);
-          else acc1b = mfma3(ah, al, bh, bl, acc1b);
+          const int ao = arow * LDB + bf_slot(arow, s * 2 + fq), bo = brow * LDB + bf_slot(brow, s * 2 + fq);
+          s16x8 av[NP], bv[NP];
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            av[q] = *reinterpret_cast<const s16x8 *>(Apl + q * APS + ao);
+            bv[q] = *reinterpret_cast<const s16x8 *>(Wpl + q * WPS + bo);
+          }
+          if (s == 0) acc1 = mfma_split<PREC>(av, bv, acc1);
+          else acc1b = mfma_split<PREC>(av, bv, acc1b);
         }
       }
     }
@@ -208,32 +235,48 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
 #pragma unroll
     for (int j = 0; j < TC; ++j) {
       const int n = ln + 32 * j;
-      uint2 hi, lo;
-      split_bf16x4(buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u), hi, lo);
-      *reinterpret_cast<uint2 *>(Whi + n * LDB + lq * 4) = hi;
-      *reinterpret_cast<uint2 *>(Wlo + n * LDB + lq * 4) = lo;
+      uint2 hi, mid, lo;
+      const float4 wv = buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u);
+      if constexpr (PREC == 2) split3_bf16x4(wv, hi, mid, lo); else split_bf16x4(wv, hi, lo);
+      const int wo = n * LDB + bf_slot(n, lq >> 1) + (lq & 1) * 4;
+      *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
+      *reinterpret_cast<uint2 *>(Wpl + WPS + wo) = lo;
+      if constexpr (PREC == 2) *reinterpret_cast<uint2 *>(Wpl + 2 * WPS + wo) = mid;
     }
     const float b1 = frow < p.R ? p.b1[frow] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
       const float hv = frow < p.R ? fmaxf(acc1[r] + b1, 0.f) : 0.f;
+      const int wo = row * LDB + bf_slot(row, frow >> 3) + (frow & 7);
       const __bf16 hh = (__bf16)hv;
-      const __bf16 hl = (__bf16)(hv - (float)hh);
-      Ahi[row * LDB + frow] = __builtin_bit_cast(unsigned short, hh);
-      Alo[row * LDB + frow] = __builtin_bit_cast(unsigned short, hl);
+      const float r1 = hv - (float)hh;
+      if constexpr (PREC == 2) {
+        const __bf16 hm = (__bf16)r1;
+        const __bf16 hl = (__bf16)(r1 - (float)hm);
+        Apl[2 * APS + wo] = __builtin_bit_cast(unsigned short, hm);
+        Apl[APS + wo] = __builtin_bit_cast(unsigned short, hl);
+      } else {
+        Apl[APS + wo] = __builtin_bit_cast(unsigned short, (__bf16)r1);
+      }
+      Apl[wo] = __builtin_bit_cast(unsigned short, hh);
     }
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int ao = (wave * 32 + frow) * LDB + s * 16 + fq * 8;
-      const s16x8 ah = *reinterpret_cast<const s16x8 *>(Ahi + ao);
-      const s16x8 al = *reinterpret_cast<const s16x8 *>(Alo + ao);
+      const int arow = wave * 32 + frow;
+      const int ao = arow * LDB + bf_slot(arow, s * 2 + fq);
+      s16x8 av[NP];
+#pragma unroll
+      for (int q = 0; q < NP; ++q) av[q] = *reinterpret_cast<const s16x8 *>(Apl + q * APS + ao);
 #pragma unroll
       for (int j = 0; j < TC; ++j) {
-        const int bo = (j * 32 + frow) * LDB + s * 16 + fq * 8;
-        acc2[j] = mfma3(ah, al, *reinterpret_cast<const s16x8 *>(Whi + bo), *reinterpret_cast<const s16x8 *>(Wlo + bo),
-                        acc2[j]);
+        const int brow = j * 32 + frow;
+        const int bo = brow * LDB + bf_slot(brow, s * 2 + fq);
+        s16x8 bv[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bv[q] = *reinterpret_cast<const s16x8 *>(Wpl + q * WPS + bo);
+        acc2[j] = mfma_split<PREC>(av, bv, acc2[j]);
       }
     }
   } else {
@@ -302,10 +345,10 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   }
 }
 
-template <int TC, bool BF>
+template <int TC, int PREC>
 static int launch_res(const ResKArgs &a, int B, hipStream_t stream) {
-  auto kern = resblock_f32_kernel<TC, BF>;
-  constexpr size_t smem = BF ? (size_t)(HPIX + 9 * 32) * LDB * 2 * sizeof(unsigned short)
+  auto kern = resblock_f32_kernel<TC, PREC>;
+  constexpr size_t smem = PREC ? (size_t)(HPIX + 9 * 32) * LDB * (PREC == 2 ? 3 : 2) * sizeof(unsigned short)
                              : (size_t)(HPIX * LDK + 9 * 32 * LDK) * sizeof(float);
   static_assert(9 * 32 >= TC * 32 && HPIX >= 128, "aliased regions must fit");
   static bool attr_set = false;
@@ -341,20 +384,19 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
   a.w1_bytes = (unsigned)((size_t)R * 9 * C * 4);  // packed [R][9C], 9C % 32 == 0
   a.w2_bytes = (unsigned)((size_t)C * 32 * 4);
   a.C = C; a.R = R; a.H = H; a.W = W; a.relu = relu & 1;
-  if (relu & ISI_CONV_BF16X3) {
-    switch (C / 32) {
-      case 1: return launch_res<1, true>(a, B, stream);
-      case 2: return launch_res<2, true>(a, B, stream);
-      case 3: return launch_res<3, true>(a, B, stream);
-      default: return launch_res<4, true>(a, B, stream);
-    }
+#define ISI_RES(PREC)                                          \
+  switch (C / 32) {                                            \
+    case 1: return launch_res<1, PREC>(a, B, stream);          \
+    case 2: return launch_res<2, PREC>(a, B, stream);          \
+    case 3: return launch_res<3, PREC>(a, B, stream);          \
+    default: return launch_res<4, PREC>(a, B, stream);         \
   }
-  switch (C / 32) {
-    case 1: return launch_res<1, false>(a, B, stream);
-    case 2: return launch_res<2, false>(a, B, stream);
-    case 3: return launch_res<3, false>(a, B, stream);
-    default: return launch_res<4, false>(a, B, stream);
-  }
+  // six-term split: the fused kernel's three-plane LDS footprint (106 KB) allows one workgroup per CU and is
+  // slower than the exact-fp32 variant (209 vs 195 us at 128/32 channels, B64 32x128), which is used instead
+  if (relu & ISI_CONV_BF16X6) { ISI_RES(0) }
+  if (relu & ISI_CONV_BF16X3) { ISI_RES(1) }
+  ISI_RES(0)
+#undef ISI_RES
 }
 
 }  // namespace isi

@@ -238,7 +238,9 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   int64_t *id_b = out->id_b ? out->id_b : id_b_ws;
   float *scal = out->scalars ? out->scalars : scal_ws;
   int rc;
-  const int pf_enc = w.precision >= 2 ? ISI_CONV_BF16X3 : 0;   // path that feeds the quantisers
+  // precision: 0 all fp32 | 1 decoder split-bf16 (x3) | 2 everything x3 | 3 index-feeding layers six-term
+  // split (x6: fp32-grade products), decoder x3
+  const int pf_enc = w.precision == 3 ? ISI_CONV_BF16X6 : w.precision == 2 ? ISI_CONV_BF16X3 : 0;   // feeds the quantisers
   const int pf_dec = w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
 
   if (mode & ISI_MODE_ENCODE) {

@@ -56,6 +56,11 @@ def pack_codebook(embed: torch.Tensor):
     return codes, e2
 
 
+def _prec_flag(bf16x3) -> int:
+    """False / 0 -> exact fp32, True / 1 -> ISI_CONV_BF16X3, 2 -> ISI_CONV_BF16X6."""
+    return {0: 0, 1: 2, 2: 4}[int(bf16x3)]
+
+
 def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
            k: int, stride: int, pad: int, relu: bool, x2_bchw: Optional[torch.Tensor] = None,
            residual_bchw: Optional[torch.Tensor] = None, bf16x3: bool = False) -> torch.Tensor:
@@ -73,7 +78,7 @@ def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Te
     rc = _hip.lib().isi_conv2d_f32(
         C.byref(s0), C.byref(s1) if s1 is not None else None, packed_w.data_ptr(),
         bias.data_ptr() if bias is not None else None, C.byref(res) if res is not None else None,
-        C.byref(dst), B, H, W, cout, k, k, stride, pad, int(relu) | (2 if bf16x3 else 0), _s(x_bchw))
+        C.byref(dst), B, H, W, cout, k, k, stride, pad, int(relu) | _prec_flag(bf16x3), _s(x_bchw))
     _hip.check(rc, "isi_conv2d_f32")
     return out
 
@@ -90,7 +95,7 @@ def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Op
     dst = _hip.dst_nchw_view(out)
     rc = _hip.lib().isi_conv_transpose2d_k4s2_f32(
         C.byref(s0), packed_w.data_ptr(), bias.data_ptr() if bias is not None else None,
-        C.byref(dst), B, H, W, cout, int(relu) | (2 if bf16x3 else 0), _s(x_bchw))
+        C.byref(dst), B, H, W, cout, int(relu) | _prec_flag(bf16x3), _s(x_bchw))
     _hip.check(rc, "isi_conv_transpose2d_k4s2_f32")
     return out
 
@@ -109,7 +114,7 @@ def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: b
         nhwc = nhwc.contiguous()
     out = torch.empty_like(nhwc)
     rc = _hip.lib().isi_resblock_f32(nhwc.data_ptr(), packed_w3.data_ptr(), b3.data_ptr(), packed_w1.data_ptr(),
-                                     b1.data_ptr(), out.data_ptr(), B, H, W, C_, R, int(relu) | (2 if bf16x3 else 0),
+                                     b1.data_ptr(), out.data_ptr(), B, H, W, C_, R, int(relu) | _prec_flag(bf16x3),
                                      _s(r_bchw))
     _hip.check(rc, "isi_resblock_f32")
     return out.permute(0, 3, 1, 2)

@@ -132,14 +132,18 @@ class VQVAE(nn.Module):
         self._plan = None
         self._plan_key = None
         # Arithmetic of the convolutions' products (accumulation is always fp32):
-        #   'bf16x3_decoder' (default) every layer that feeds a code index -- encoders, quantisers, top decoder --
-        #                    in exact fp32; only `upsample_top_to_bottom` and the final decoder `dec` use split-bf16
-        #                    products (x = hi + lo in bf16, hi.hi + hi.lo + lo.hi on the bf16 matrix pipe): code
-        #                    indices are bit-identical to 'f32', the reconstruction differs by < 1e-5 of its maximum
-        #                    (north_star's bound: 1e-3), at ~1/3 of the fp32 pipe's time for those layers
-        #   'f32'            everything on the exact-fp32 matrix pipe
-        #   'bf16x3'         every convolution split-bf16: near-tie code indices may move (not parity-safe)
-        self.conv_precision = os.environ.get("ISI_CONV_PRECISION", "bf16x3_decoder")
+        #   'split_bf16' (default)  products as sums of bf16 pieces on the bf16 matrix pipe (16x the fp32 pipe's rate):
+        #        * every layer that feeds a code index (encoders, quantiser 1x1s, top decoder): SIX-term split
+        #          (x = hi + mid + lo exactly; hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid = every term above
+        #          2^-24 of a product).  Measured against fp64 its error is at or below the fp32 pipe's own
+        #          (1.2e-6 vs 1.4e-6 of the maximum on the 3x3 128->128 layer; torch-CPU: 2.8e-7), and its code
+        #          indices agree with the CPU reference as often as the fp32 pipe's do (near-ties only);
+        #        * `upsample_top_to_bottom` and the final decoder `dec` (no index depends on them): THREE-term
+        #          split (hi.hi + hi.lo + lo.hi): reconstruction within 1e-5 of its maximum (north_star: 1e-3)
+        #   'bf16x3_decoder'  index-feeding layers on the exact-fp32 matrix pipe, decoder three-term split
+        #   'f32'             everything on the exact-fp32 matrix pipe
+        #   'bf16x3'          every convolution three-term split: near-tie code indices move (not parity-safe)
+        self.conv_precision = os.environ.get("ISI_CONV_PRECISION", "split_bf16")
 
     # ------------------------------------------------------------ native plan
     def _plan_fingerprint(self):
@@ -201,7 +205,7 @@ class VQVAE(nn.Module):
         w.quantize_conv_t, w.quantize_conv_b = conv(self.quantize_conv_t), conv(self.quantize_conv_b)
         w.quantize_t, w.quantize_b = book(self.quantize_t), book(self.quantize_b)
         w.dec_t, w.dec = dec(self.dec_t), dec(self.dec)
-        w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2}[self.conv_precision]
+        w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2, "split_bf16": 3}[self.conv_precision]
         w.n_upsample = len(self.upsample_top_to_bottom)
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)

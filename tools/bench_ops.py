@@ -32,7 +32,7 @@ def nhwc(b, c, h, w):
 
 def main():
     ops = [a for a in sys.argv[1:] if not a.startswith("--")] or ["all"]
-    bf = "--bf16x3" in sys.argv
+    bf = 2 if "--bf16x6" in sys.argv else ("--bf16x3" in sys.argv)
 
     def err(a, b):
         return ((a - b).abs().max() / b.abs().max()).item()
@@ -43,19 +43,19 @@ def main():
         if "conv3" in ops or "all" in ops:
             l = _ConvParams(128, 128, 3, padding=1).to(dev); x = nhwc(B, 128, 32, 128)
             t = timeit(lambda: l.run(x, relu=True, bf16x3=bf)); res.append(("conv3x3 128->128 @32x128", t, 2 * B * 32 * 128 * 128 * 1152))
-            if bf: print("  bf16x3 max err / max|ref|:", err(l.run(x, relu=True, bf16x3=True), l.run(x, relu=True)))
+            if bf: print("  bf16x3 max err / max|ref|:", err(l.run(x, relu=True, bf16x3=bf), l.run(x, relu=True)))
         if "down2" in ops or "all" in ops:
             l = _ConvParams(64, 128, 4, stride=2, padding=1).to(dev); x = nhwc(B, 64, 64, 256)
             t = timeit(lambda: l.run(x, relu=True, bf16x3=bf)); res.append(("conv4x4s2 64->128 @64x256", t, 2 * B * 32 * 128 * 128 * 1024))
-            if bf: print("  bf16x3 max err / max|ref|:", err(l.run(x, relu=True, bf16x3=True), l.run(x, relu=True)))
+            if bf: print("  bf16x3 max err / max|ref|:", err(l.run(x, relu=True, bf16x3=bf), l.run(x, relu=True)))
         if "resblock" in ops or "all" in ops:
             l = RosinalityResBlock(128, 32).to(dev); x = torch.relu(nhwc(B, 128, 32, 128))
             t = timeit(lambda: l.forward_rectified(x, relu_out=True, bf16x3=bf)); res.append(("resblock 128/32 @32x128", t, 2 * B * 32 * 128 * (32 * 1152 + 128 * 32)))
-            if bf: print("  bf16x3 max err / max|ref|:", err(l.forward_rectified(x, relu_out=True, bf16x3=True), l.forward_rectified(x, relu_out=True)))
+            if bf: print("  bf16x3 max err / max|ref|:", err(l.forward_rectified(x, relu_out=True, bf16x3=bf), l.forward_rectified(x, relu_out=True)))
         if "convT" in ops or "all" in ops:
             l = _ConvParams(128, 64, 4, stride=2, padding=1, transposed=True).to(dev); x = nhwc(B, 128, 32, 128)
             t = timeit(lambda: l.run(x, relu=True, bf16x3=bf)); res.append(("convT 128->64 @32x128", t, 2 * B * 32 * 128 * 4 * 64 * 512))
-            if bf: print("  bf16x3 max err / max|ref|:", err(l.run(x, relu=True, bf16x3=True), l.run(x, relu=True)))
+            if bf: print("  bf16x3 max err / max|ref|:", err(l.run(x, relu=True, bf16x3=bf), l.run(x, relu=True)))
         if "up_last" in ops or "all" in ops:
             l = _ConvParams(64, 2, 4, stride=2, padding=1, transposed=True).to(dev); x = nhwc(B, 64, 64, 256)
             t = timeit(lambda: l.run(x, relu=False, out_nchw=True)); res.append(("convT 64->2 @64x256", t, 2 * B * 64 * 256 * 4 * 2 * 256))

@@ -17,6 +17,8 @@
 // Replaces (reference, torch.nn): nn.Conv2d / nn.ConvTranspose2d / nn.ReLU /
 // residual add / torch.cat at vqvae/encoder_decoder.py:22-35,95-112,138,199-215
 // and vqvae/vqvae.py:193-201,260,270-272,282.
+#include <cstdlib>
+
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "prof.h"
@@ -489,7 +491,7 @@ static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
     if (a.bf16x3 == 2) {   // six-term split: fp32-grade products
-      if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 2>(a, nphase, stream);
+      if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 2>(a, nphase, stream);   // (128x64 for Cout = 128: 20 % slower)
       return launch_cfg<128, 128, 2, 2, 0, 2>(a, nphase, stream);
     }
     if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 1>(a, nphase, stream);

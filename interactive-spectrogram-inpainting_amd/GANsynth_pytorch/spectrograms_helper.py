@@ -110,7 +110,8 @@ class SpectrogramsHelper:
         s0 = _hip.isi_src(x.data_ptr(), hop, total, 1, total, hop)
         dst = _hip.isi_dst(out.data_ptr(), T * 2 * F, 1, T * 2 * F, 2 * F)
         rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, c["stft_w"].data_ptr(), None, None, C.byref(dst),
-                                       B, 1, total // hop, 2 * F, 1, N // hop, 1, 0, 0, _s(audio))
+                                       B, 1, total // hop, 2 * F, 1, N // hop, 1, 0, _gemm._PREC_FLAG[_gemm.LINEAR_PRECISION],
+                                       _s(audio))
         _hip.check(rc, "isi_conv2d_f32 (stft)")
         return out, T
 

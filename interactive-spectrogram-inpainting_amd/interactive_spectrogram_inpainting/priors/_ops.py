@@ -13,8 +13,19 @@ from .. import _hip
 from ..vqvae._ops import pack_conv_weight
 
 
+import os
+
+
 def _s(t):
     return C.c_void_p(_hip.stream_ptr(t.device))
+
+
+# Products of the whole-sequence GEMMs (data and accumulation are fp32): 'bf16x6' (default) = six-term split
+# on the bf16 matrix pipe -- x = hi + mid + lo exactly, every term above 2^-24 of a product kept: error against
+# fp64 at or below the fp32 pipe's own, 1.4x its speed; 'f32' = the fp32 matrix pipe.
+# Shapes the split kernel does not cover (N <= 32 or K < 128) run on the fp32 pipe either way.
+LINEAR_PRECISION = os.environ.get("ISI_LINEAR_PRECISION", "bf16x6")
+_PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4}
 
 
 def pack_linear_weight(weight: torch.Tensor) -> torch.Tensor:
@@ -44,7 +55,7 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
     rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, packed_w.data_ptr(),
                                    bias.data_ptr() if bias is not None else None,
                                    C.byref(res) if res is not None else None, C.byref(dst),
-                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu), _s(x))
+                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[LINEAR_PRECISION], _s(x))
     _hip.check(rc, "isi_conv2d_f32 (linear)")
     return out.reshape(*x.shape[:-1], n_out)
 

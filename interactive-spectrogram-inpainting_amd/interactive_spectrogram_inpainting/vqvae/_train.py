@@ -33,8 +33,16 @@ from . import _ops
 from .encoder_decoder import RosinalityDecoder, RosinalityEncoder, RosinalityResBlock, _ConvParams
 
 
+import os
+
+
 def _s(t):
     return C.c_void_p(_hip.stream_ptr(t.device))
+
+
+# Products of the training step's forward and input-gradient convolutions: 2 = six-term split-bf16
+# (fp32-grade; default), 0 = fp32 matrix pipe.  Weight gradients always use the fp32 pipe.
+TRAIN_PRECISION = {"f32": 0, "bf16x6": 2}[os.environ.get("ISI_TRAIN_PRECISION", "bf16x6")]
 
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
@@ -143,11 +151,12 @@ def conv_dgrad(dw: _DgradWeights, layer: _ConvParams, dy: torch.Tensor,
     packed = dw.get(layer)
     cin = layer.in_channels
     if layer.transposed:
-        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False)
+        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False, bf16x3=TRAIN_PRECISION)
     if layer.stride == 2:
-        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False)
+        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False, bf16x3=TRAIN_PRECISION)
     k = layer.kernel_size
-    return _ops.conv2d(dy, packed, None, cin, k, 1, k - 1 - layer.padding, relu=False, residual_bchw=residual)
+    return _ops.conv2d(dy, packed, None, cin, k, 1, k - 1 - layer.padding, relu=False, residual_bchw=residual,
+                       bf16x3=TRAIN_PRECISION)
 
 
 def _set_wb(grads, layer: _ConvParams, wb) -> None:
@@ -218,7 +227,7 @@ class Grads:
 
 # ------------------------------------------------------------------ forward (train mode)
 def _conv_fwd(layer: _ConvParams, x, relu, x2=None, out_nchw=False):
-    return layer.run(x, relu=relu, x2=x2, out_nchw=out_nchw)
+    return layer.run(x, relu=relu, x2=x2, out_nchw=out_nchw, bf16x3=TRAIN_PRECISION)
 
 
 def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
@@ -230,8 +239,8 @@ def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
     tape[f"{tag}.c3"] = x
     for j, i in enumerate(m._res):
         blk: RosinalityResBlock = m.blocks[i]
-        h = blk.conv[1].run(x, relu=True)
-        y = blk.conv[3].run(h, relu=True, residual=x)
+        h = blk.conv[1].run(x, relu=True, bf16x3=TRAIN_PRECISION)
+        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=TRAIN_PRECISION)
         tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
         x = y
     return x
@@ -239,17 +248,17 @@ def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
 
 def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_last: bool):
     tape[f"{tag}.in"], tape[f"{tag}.in2"] = x, x2
-    x = m.blocks[0].run(x, relu=True, x2=x2)
+    x = m.blocks[0].run(x, relu=True, x2=x2, bf16x3=TRAIN_PRECISION)
     tape[f"{tag}.c3"] = x
     for j, i in enumerate(m._res):
         blk = m.blocks[i]
-        h = blk.conv[1].run(x, relu=True)
-        y = blk.conv[3].run(h, relu=True, residual=x)
+        h = blk.conv[1].run(x, relu=True, bf16x3=TRAIN_PRECISION)
+        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=TRAIN_PRECISION)
         tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
         x = y
     for j, i in enumerate(m._up):
         last = j == len(m._up) - 1
-        x = m.blocks[i].run(x, relu=not last, out_nchw=(last and out_nchw_last))
+        x = m.blocks[i].run(x, relu=not last, out_nchw=(last and out_nchw_last), bf16x3=TRAIN_PRECISION)
         tape[f"{tag}.up{j}"] = x
     return x
 
@@ -368,19 +377,19 @@ class VQVAETrainFunction(torch.autograd.Function):
         x = x.contiguous()
         enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
         enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
-        z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False))
+        z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=TRAIN_PRECISION))
         q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t)
         tape["z_t"], tape["q_t"] = z_t, q_t
         dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
         if dec_t.shape[-1] != enc_b.shape[-1]:
             raise NotImplementedError("training needs input sizes divisible by the total down-sampling factor")
-        z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b))
+        z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=TRAIN_PRECISION))
         q_b, diff_b, id_b, perp_b = quantize_train(model.quantize_b, z_b)
         tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
         up = _as_bchw(q_t)
         for j, layer in enumerate(model.upsample_top_to_bottom):
             tape[f"up.in{j}"] = up
-            up = layer.run(up, relu=False)
+            up = layer.run(up, relu=False, bf16x3=TRAIN_PRECISION)
         dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True)
         diff = (diff_t + diff_b).reshape(1)
         ctx.model, ctx.tape = model, tape

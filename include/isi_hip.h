@@ -183,7 +183,9 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3,
  * workspace of isi_conv_wgrad_workspace_floats(Cout, K, M, nphase) floats with
  * K = KH*KW*Cin (transposed: 4*Cin), M = B*OH*OW (transposed: B*H*W), nphase = 1 (4).
  * db [Cout] (optional) receives the bias gradient = column sums of dy, computed on the
- * staged dY tiles at no extra pass. */
+ * staged dY tiles at no extra pass.  `transposed` is a flag word: bit 0 = transposed
+ * convolution, ISI_CONV_BF16X3 / ISI_CONV_BF16X6 select split-bf16 products (vectorised
+ * channels-last operands only; other layouts use the fp32 pipe). */
 size_t isi_conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
 int isi_conv_wgrad_f32(const isi_src *src0, const isi_src *src1, const float *dy,
                        float *dw_packed, float *db, float *workspace, size_t workspace_floats,

@@ -199,6 +199,194 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
     }
 }
 
+// ---- split-bf16 products (ISI_CONV_BF16X3 / ISI_CONV_BF16X6, see conv_igemm_f32.hip): the reduction runs over
+// pixels, so both operands are transposed on the way into LDS -- a thread stages 4 consecutive pixels x 4
+// consecutive channels and writes, per channel, the 4 pixels as one 8-byte row segment of the bf16 planes
+// [channel][32 pixels] (64-B rows, 16-B slots XOR-swizzled with (row >> 2) & 3); fragments are then the same
+// ds_read_b128 reads as in the forward kernel with "K" = pixels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+namespace {
+constexpr int LDB = 32;
+__device__ __forceinline__ int bf_slot(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 8; }
+// pieces of 4 values (one channel, 4 consecutive pixels): hi, lo(, mid); x = hi + mid + lo exactly when NP == 3
+template <int NP>
+__device__ __forceinline__ void split4(const float a, const float b, const float c, const float d, uint2 *out) {
+  const f32x2 p0 = {a, b}, p1 = {c, d};
+  const bf16x2 h0 = __builtin_convertvector(p0, bf16x2), h1 = __builtin_convertvector(p1, bf16x2);
+  const f32x2 r0 = p0 - __builtin_convertvector(h0, f32x2), r1 = p1 - __builtin_convertvector(h1, f32x2);
+  out[0] = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+  if constexpr (NP == 3) {
+    const bf16x2 m0 = __builtin_convertvector(r0, bf16x2), m1 = __builtin_convertvector(r1, bf16x2);
+    const bf16x2 l0 = __builtin_convertvector(r0 - __builtin_convertvector(m0, f32x2), bf16x2);
+    const bf16x2 l1 = __builtin_convertvector(r1 - __builtin_convertvector(m1, f32x2), bf16x2);
+    out[2] = make_uint2(__builtin_bit_cast(unsigned, m0), __builtin_bit_cast(unsigned, m1));
+    out[1] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+  } else {
+    out[1] = make_uint2(__builtin_bit_cast(unsigned, __builtin_convertvector(r0, bf16x2)),
+                        __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2)));
+  }
+}
+}  // namespace
+
+template <int NP>   // 2: three-term split, 3: six-term split
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short *Dp = reinterpret_cast<unsigned short *>(smem);   // [NP][128 co][LDB]  dY^T pieces (0 hi, 1 lo, 2 mid)
+  unsigned short *Xp = Dp + NP * 128 * LDB;                        // [NP][128 k ][LDB]  im2col^T pieces
+  float *bias_s = reinterpret_cast<float *>(Xp + NP * 128 * LDB);  // [8][128] bias partials of the pixel groups
+  constexpr int PS = 128 * LDB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+  const int co0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int phase = blockIdx.z / p.nsplit, split = blockIdx.z - phase * p.nsplit;
+  const int py = p.convT ? phase >> 1 : 0, px = p.convT ? phase & 1 : 0;
+  const int pad_y = p.convT ? 1 - py : p.pad, pad_x = p.convT ? 1 - px : p.pad;
+  const int dy_off = p.convT ? py * p.dst_sh + px * p.dst_sw : 0;
+
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x1), 0, p.x1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+  // staging role: pixel group pg (pixels 4 pg .. 4 pg + 3 of the 32-pixel chunk), channel quad sq
+  const int pg = tid >> 5, sq = tid & 31;
+  const int kk = k0 + sq * 4;
+  const bool kvalid = kk < p.K;
+  int tap = 0, c = 0, kh = 0, kw = 0;
+  if (kvalid) { tap = kk / p.Cin; c = kk - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW; }
+  const bool second = c >= p.C0;
+  const int cc = second ? c - p.C0 : c;
+  const int co = co0 + sq * 4;
+  const bool covalid = co < p.Cout;
+
+  const int chunk_begin = split * p.chunks_per_split;
+  const int nchunks_total = (p.M + 31) / 32;
+  const int chunk_end = min(nchunks_total, chunk_begin + p.chunks_per_split);
+
+  float4 rdq[4], rxq[4];
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = ch * 32 + 4 * pg + j;
+      unsigned doff = OOB, xoff = OOB;
+      if (m < p.M) {
+        const int b = m / (p.OH * p.OW);
+        const int rem = m - b * (p.OH * p.OW);
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        if (covalid) doff = (unsigned)(dy_off + b * p.dn + oy * p.dh + ox * p.dw + co) * 4u;
+        const int iy = oy * p.stride - pad_y + kh, ix = ox * p.stride - pad_x + kw;
+        if (kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          xoff = second ? (unsigned)(b * p.s1n + iy * p.s1h + ix * p.s1w + cc) * 4u
+                        : (unsigned)(b * p.s0n + iy * p.s0h + ix * p.s0w + cc) * 4u;
+      }
+      rdq[j] = buf_load4(rd, doff);
+      rxq[j] = second ? buf_load4(r1, xoff) : buf_load4(r0, xoff);
+    }
+  };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's 4 channels of dY over its pixel group, all chunks
+  auto store_chunk = [&]() {
+    bsum[0] += (rdq[0].x + rdq[1].x) + (rdq[2].x + rdq[3].x);
+    bsum[1] += (rdq[0].y + rdq[1].y) + (rdq[2].y + rdq[3].y);
+    bsum[2] += (rdq[0].z + rdq[1].z) + (rdq[2].z + rdq[3].z);
+    bsum[3] += (rdq[0].w + rdq[1].w) + (rdq[2].w + rdq[3].w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = sq * 4 + e;
+      const int wo = row * LDB + bf_slot(row, pg >> 1) + (pg & 1) * 4;
+      uint2 pd[3], px_[3];
+      const float d0 = e == 0 ? rdq[0].x : e == 1 ? rdq[0].y : e == 2 ? rdq[0].z : rdq[0].w;
+      const float d1 = e == 0 ? rdq[1].x : e == 1 ? rdq[1].y : e == 2 ? rdq[1].z : rdq[1].w;
+      const float d2 = e == 0 ? rdq[2].x : e == 1 ? rdq[2].y : e == 2 ? rdq[2].z : rdq[2].w;
+      const float d3 = e == 0 ? rdq[3].x : e == 1 ? rdq[3].y : e == 2 ? rdq[3].z : rdq[3].w;
+      const float x0 = e == 0 ? rxq[0].x : e == 1 ? rxq[0].y : e == 2 ? rxq[0].z : rxq[0].w;
+      const float x1 = e == 0 ? rxq[1].x : e == 1 ? rxq[1].y : e == 2 ? rxq[1].z : rxq[1].w;
+      const float x2 = e == 0 ? rxq[2].x : e == 1 ? rxq[2].y : e == 2 ? rxq[2].z : rxq[2].w;
+      const float x3 = e == 0 ? rxq[3].x : e == 1 ? rxq[3].y : e == 2 ? rxq[3].z : rxq[3].w;
+      split4<NP>(d0, d1, d2, d3, pd);
+      split4<NP>(x0, x1, x2, x3, px_);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        *reinterpret_cast<uint2 *>(Dp + q * PS + wo) = pd[q];
+        *reinterpret_cast<uint2 *>(Xp + q * PS + wo) = px_[q];
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fl = lane & 31, half = lane >> 5;
+  if (chunk_begin < chunk_end) {
+    load_chunk(chunk_begin);
+    store_chunk();
+  }
+  __syncthreads();
+  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+    if (ch + 1 < chunk_end) load_chunk(ch + 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      s16x8 av[2][NP], bv[2][NP];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm0 + i * 32 + fl, rb = wn0 + i * 32 + fl;
+        const int ao = ra * LDB + bf_slot(ra, s * 2 + half), bo = rb * LDB + bf_slot(rb, s * 2 + half);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          av[i][q] = *reinterpret_cast<const s16x8 *>(Dp + q * PS + ao);
+          bv[i][q] = *reinterpret_cast<const s16x8 *>(Xp + q * PS + bo);
+        }
+      }
+#define ISI_MF(i, j, qa, qb)                                                                                       \
+  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i][qa]),                       \
+                                                      __builtin_bit_cast(bf16x8, bv[j][qb]), acc[i][j], 0, 0, 0)
+#define ISI_TERM(qa, qb) ISI_MF(0, 0, qa, qb); ISI_MF(0, 1, qa, qb); ISI_MF(1, 0, qa, qb); ISI_MF(1, 1, qa, qb)
+      if constexpr (NP == 3) {   // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+        ISI_TERM(1, 0); ISI_TERM(0, 1); ISI_TERM(2, 2); ISI_TERM(2, 0); ISI_TERM(0, 2); ISI_TERM(0, 0);
+      } else {
+        ISI_TERM(1, 0); ISI_TERM(0, 1); ISI_TERM(0, 0);
+      }
+#undef ISI_TERM
+#undef ISI_MF
+    }
+    __syncthreads();   // every wave has read the single stage
+    if (ch + 1 < chunk_end) store_chunk();
+    __syncthreads();
+  }
+  // ---- bias partials: fixed-order sum over the 8 pixel groups
+  if (p.db_partial != nullptr && blockIdx.y == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias_s[pg * 128 + sq * 4 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && co0 + tid < p.Cout) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += bias_s[g * 128 + tid];
+      p.db_partial[(size_t)blockIdx.z * p.Cout + co0 + tid] = t;
+    }
+  }
+
+  float *out = p.partial + (size_t)blockIdx.z * p.Cout * p.Kpad;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kcol = k0 + wn0 + j * 32 + fl;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int corow = co0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (corow < p.Cout && kcol < p.Kpad) out[(size_t)corow * p.Kpad + kcol] = acc[i][j][r];
+      }
+    }
+}
+
 // out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
                                                               float *__restrict__ out, int64_t n, int nsplit,
@@ -237,6 +425,8 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
                    float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                    int stride, int pad, int transposed, hipStream_t stream) {
   if (!s0 || !s0->ptr || !dy || !dw_packed || !workspace) return invalid("conv_wgrad: null pointer");
+  const int prec_flags = transposed & (ISI_CONV_BF16X3 | ISI_CONV_BF16X6);   // product mode rides in the flag word
+  transposed &= 1;
   const bool two = s1 && s1->ptr;
   const int Cin = s0->C + (two ? s1->C : 0);
   int OH, OW, nphase = 1, K;
@@ -295,7 +485,15 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
     attr_set = true;
   }
   dim3 grid((Cout + 127) / 128, (a.Kpad + 127) / 128, nphase * nsplit);
-  hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(256), smem, stream, a);
+  // split-bf16 products need the vectorised loaders (channels-last sources, Cout % 4 == 0)
+  if (prec_flags && a.vec && a.dvec) {
+    const int np = (prec_flags & ISI_CONV_BF16X6) ? 3 : 2;
+    const size_t smem_s = (size_t)2 * np * 128 * LDB * sizeof(unsigned short) + 8 * 128 * sizeof(float);
+    if (np == 3) hipLaunchKernelGGL(conv_wgrad_split_kernel<3>, grid, dim3(256), smem_s, stream, a);
+    else hipLaunchKernelGGL(conv_wgrad_split_kernel<2>, grid, dim3(256), smem_s, stream, a);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(256), smem, stream, a);
+  }
   int rc = check_launch("conv_wgrad_f32");
   if (rc) return rc;
   // partial layout: [phase][split][Cout][Kpad] -> out [phase][Cout][Kpad]

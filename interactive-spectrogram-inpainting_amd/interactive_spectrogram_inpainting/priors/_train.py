@@ -36,6 +36,11 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     return t2 if t2.is_contiguous() else t2.contiguous()
 
 
+def _wgrad_flags() -> int:
+    from ..vqvae._train import WGRAD_FLAGS   # one switch for both models (ISI_WGRAD_PRECISION)
+    return WGRAD_FLAGS
+
+
 def linear_wgrad(x2: torch.Tensor, dy2: torch.Tensor):
     """x2 [M,K], dy2 [M,N] dense -> (dW [N,K] torch layout, db [N])."""
     M, K = x2.shape
@@ -48,7 +53,7 @@ def linear_wgrad(x2: torch.Tensor, dy2: torch.Tensor):
     db = torch.empty(N, dtype=torch.float32, device=x2.device)
     s0 = _hip.isi_src(x2.data_ptr(), K, 0, 1, 0, x2.stride(0))
     rc = L.isi_conv_wgrad_f32(C.byref(s0), None, dy2.data_ptr(), packed.data_ptr(), db.data_ptr(), ws.data_ptr(), nws,
-                              1, 1, M, N, 1, 1, 1, 0, 0, _s(x2))
+                              1, 1, M, N, 1, 1, 1, 0, _wgrad_flags(), _s(x2))
     _hip.check(rc, "isi_conv_wgrad_f32 (linear)")
     return (packed if Kpad == K else packed[:, :K]), db
 

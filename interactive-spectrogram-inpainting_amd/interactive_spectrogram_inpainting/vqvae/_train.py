@@ -43,6 +43,10 @@ def _s(t):
 # Products of the training step's forward and input-gradient convolutions: 2 = six-term split-bf16
 # (fp32-grade; default), 0 = fp32 matrix pipe.  Weight gradients always use the fp32 pipe.
 TRAIN_PRECISION = {"f32": 0, "bf16x6": 2}[os.environ.get("ISI_TRAIN_PRECISION", "bf16x6")]
+# Products of the weight-gradient GEMMs (flag bits of isi_conv_wgrad_f32's `transposed` word): three-term split by
+# default (relative error ~4e-6 of the gradient's maximum, far below the step-to-step noise of training and 50x
+# inside the parity tests' 2e-4), 'bf16x6' = fp32-grade, 'f32' = fp32 matrix pipe.
+WGRAD_FLAGS = {"f32": 0, "bf16x3": 2, "bf16x6": 4}[os.environ.get("ISI_WGRAD_PRECISION", "bf16x3")]
 
 
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
@@ -110,7 +114,7 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
     s1 = _hip.src_nchw_view(x2) if (x2 is not None and not tr) else None
     rc = L.isi_conv_wgrad_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
                               packed.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), nws,
-                              B, H, W, rows, k, k, layer.stride, layer.padding, 0, _s(x))
+                              B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
     _hip.check(rc, "isi_conv_wgrad_f32")
     # [rows][kh][kw][cin_role] -> [rows, cin_role, kh, kw]  (= torch layout for both layer kinds)
     dw = packed[:, :K].reshape(rows, k, k, cin_role).permute(0, 3, 1, 2)

@@ -236,6 +236,8 @@ typedef struct isi_attn_args {
   int mask_mode;
   float scale;
   float *lse;   /* optional [B,H,Sq]: log-sum-exp of every query's logits (kept for the backward) */
+  int precision; /* products of the three contractions: 0 = fp32 matrix pipe, 1 = three-term split-bf16
+                  * (hi.hi + hi.lo + lo.hi on the bf16 pipe, fp32 accumulation; logits / softmax fp32) */
 } isi_attn_args;
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream);
 

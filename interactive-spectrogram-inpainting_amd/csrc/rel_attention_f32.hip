@@ -40,6 +40,7 @@ struct AttnKArgs {
   int Cq, Ck, Ek, R;
   int mask_mode;  // 0 none, 1 causal (j <= i), 2 anti-causal (j >= i)
   float scale;
+  int split;      // 1: three-term split-bf16 products (rel_attention_split_kernel)
 };
 
 namespace {
@@ -357,16 +358,402 @@ __global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 variant (args->precision = 1, the Python default): the three contractions run on the bf16
+// matrix pipe as THREE-term split products (x = hi + lo in bf16; hi.hi + hi.lo + lo.hi, fp32
+// accumulation: relative error of a product ~2^-16), everything else -- logits, skew, online softmax,
+// merge -- stays fp32.  The exact-fp32 kernel above is matrix-bound (the band GEMM doubles the QK^T
+// work); here the matrix time drops 5x and the kernel becomes bound by the softmax / skew arithmetic.
+//   S^T  = K Q^T     A = K rows from LDS bf16 planes [key][HD], B = the lane's Q fragment (registers)
+//   band = E Q^T     A = ring rows of e
+//   O^T += V^T P^T   A = V^T from LDS planes [d][32 keys] (V is transposed while staged: a thread stages a
+//                    4 keys x 4 dims block), B = P packed from the accumulator layout; MFMA k-slot (half h, e)
+//                    of key block t is key 16 t + 8 (e >> 2) + 4 h + (e & 3), i.e. exactly the lane's registers
+// LDS rows are unpadded and XOR-swizzled: 16-B slot s of row r of a [.][HD] plane sits at s ^ ((r / (128/HD))
+// mod (HD/8)); 8-B unit u of row d of a V^T plane at u ^ ((d >> 2) & 7)  (conflict-free ds_read_b128 / b64).
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+namespace {
+__device__ __forceinline__ void split2(const float a, const float b, unsigned &hi, unsigned &lo) {
+  const f32x2_t v = {a, b};
+  const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+  const bf16x2_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2_t), bf16x2_t);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ void split_f4(const float4 v, uint2 &hi, uint2 &lo) {
+  split2(v.x, v.y, hi.x, lo.x);
+  split2(v.z, v.w, hi.y, lo.y);
+}
+#define ISI_MFB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0)
+}  // namespace
+
+template <int HD>
+__global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArgs p) {
+  constexpr int NKB = HD / 16;           // 16-deep k-blocks of the head dim
+  constexpr int NSL = HD / 8;            // 16-B slots per [.][HD] row
+  constexpr int RPB = 128 / HD;          // rows per 256-B bank row
+  constexpr int NDB = (HD + 31) / 32;    // 32-row blocks of O^T
+  constexpr int VR = NDB * 32;           // rows of a V^T plane (rows >= HD stay zero)
+  constexpr int NQD = HD / 4;            // dim quads per key row
+  constexpr int NKQ = (HD / 4 + 7) / 8;  // band quads per thread and row
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short *Kp = reinterpret_cast<unsigned short *>(smem);   // [tile 2][plane 2][32][HD]
+  unsigned short *Vp = Kp + 2 * 2 * 32 * HD;                       // [tile 2][plane 2][VR][32]
+  unsigned short *Ep = Vp + 2 * 2 * VR * 32;                       // [plane 2][RING][HD]
+  float *Sr = reinterpret_cast<float *>(Ep + 2 * RING * HD);       // [8][32][SRLD]
+  int *evk = reinterpret_cast<int *>(Sr + 8 * 32 * SRLD);          // [2][32]
+  auto swz = [](int row, int slot) { return (slot ^ ((row / RPB) % NSL)) * 8; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qblk = p.mask_mode == 1 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int q0 = qblk * QB, qw0 = q0 + 32 * wq, qi = qw0 + ql;
+  const bool has_e = p.e != nullptr;
+
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.v), 0, p.v_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_e ? p.e : p.q), 0, has_e ? p.e_bytes : 4u, 0x00020000);
+
+  // ---- Q fragment of this lane's query, split once: k-block t holds dims 16 t + 8 half + 0..7
+  s16x8_t qh[NKB], qlo[NKB];
+#pragma unroll
+  for (int t = 0; t < NKB; ++t) {
+    const unsigned off = qi < p.Sq ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + 16 * t + 8 * half) * 4u : OOB;
+    uint2 h0, l0, h1, l1;
+    split_f4(buf_load4(rq, off), h0, l0);
+    split_f4(buf_load4(rq, off == OOB ? OOB : off + 16u), h1, l1);
+    qh[t] = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    qlo[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+  }
+  const int evq = qi / p.Cq;
+  const int evq_w0 = qw0 / p.Cq, evq_b0 = q0 / p.Cq;
+
+  float m_run = NEG, l_run = 0.f;
+  f32x16 O[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
+
+  int k_begin = 0, k_end = p.Sk;
+  if (p.mask_mode == 1) k_end = min(p.Sk, q0 + QB);
+  if (p.mask_mode == 2) k_begin = (q0 / 32) * 32;
+
+  // staging roles.  K / V: a 4 keys x 4 dims block per thread (threads [0, 16 NQD) stage K, [256, 256 + 16 NQD) V);
+  // band: row 32 st + srow of the pair's 64 new rows, quads squad + 8 i
+  const int kind = tid >> 8, bidx = tid & 255;
+  const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);
+  const bool blk_on = btile < 2;
+  const int st = tid >> 8, srow = (tid >> 3) & 31, squad = tid & 7;
+  float4 pb[4], pe[NKQ];
+  auto band0 = [&](int k) { return evq_b0 - (k + 31) / p.Ck + p.Ek - 1; };
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kj = k0 + 32 * btile + 4 * bkg + j;
+      const bool ok = blk_on && kj < p.Sk;
+      const unsigned ko = (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + bqd * 4) * 4u;
+      const unsigned vo = (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + bqd * 4) * 4u;
+      pb[j] = kind == 0 ? buf_load4(rk, ok ? ko : OOB) : buf_load4(rv, ok ? vo : OOB);
+    }
+    const int r = band0(k0 + 32) + 32 * st + srow;
+    const bool rok = has_e && r >= 0 && r < p.R;
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+    }
+  };
+  auto commit = [&](int k0) {
+    if (blk_on) {
+      if (kind == 0) {   // K rows: 8 bytes (4 dims) per key and plane
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = 4 * bkg + j;
+          uint2 hi, lo;
+          split_f4(pb[j], hi, lo);
+          const int o = ((btile * 2) * 32 + row) * HD + swz(row, bqd >> 1) + (bqd & 1) * 4;
+          *reinterpret_cast<uint2 *>(Kp + o) = hi;
+          *reinterpret_cast<uint2 *>(Kp + o + 32 * HD) = lo;
+        }
+      } else {           // V transposed: per dim the 4 keys of the block as one 8-byte unit
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int d = 4 * bqd + e;
+          const float a0 = e == 0 ? pb[0].x : e == 1 ? pb[0].y : e == 2 ? pb[0].z : pb[0].w;
+          const float a1 = e == 0 ? pb[1].x : e == 1 ? pb[1].y : e == 2 ? pb[1].z : pb[1].w;
+          const float a2 = e == 0 ? pb[2].x : e == 1 ? pb[2].y : e == 2 ? pb[2].z : pb[2].w;
+          const float a3 = e == 0 ? pb[3].x : e == 1 ? pb[3].y : e == 2 ? pb[3].z : pb[3].w;
+          uint2 hi, lo;
+          split2(a0, a1, hi.x, lo.x);
+          split2(a2, a3, hi.y, lo.y);
+          const int o = ((btile * 2) * VR + d) * 32 + ((bkg ^ ((d >> 2) & 7)) * 4);
+          *reinterpret_cast<uint2 *>(Vp + o) = hi;
+          *reinterpret_cast<uint2 *>(Vp + o + VR * 32) = lo;
+        }
+      }
+    }
+    if (has_e) {
+      const int slot = ring_slot(band0(k0 + 32) + 32 * st + srow);
+#pragma unroll
+      for (int i = 0; i < NKQ; ++i) {
+        const int qd = squad + 8 * i;
+        if (qd < NQD) {
+          uint2 hi, lo;
+          split_f4(pe[i], hi, lo);
+          const int o = slot * HD + swz(slot, qd >> 1) + (qd & 1) * 4;
+          *reinterpret_cast<uint2 *>(Ep + o) = hi;
+          *reinterpret_cast<uint2 *>(Ep + o + RING * HD) = lo;
+        }
+      }
+    }
+    if (tid < 64) {
+      const int kt = k0 + (tid & 32);
+      evk[tid] = (kt + 31) / p.Ck - (kt + (tid & 31)) / p.Ck;
+    }
+  };
+
+  // ---- prologue
+  if (VR > HD) {   // rows of V^T beyond the head dim feed zero products
+    for (int i = tid; i < 2 * 2 * VR * 32 / 2; i += 512) reinterpret_cast<unsigned *>(Vp)[i] = 0u;
+    __syncthreads();
+  }
+  if (k_begin < k_end) {
+    prefetch(k_begin);
+    commit(k_begin);
+    if (has_e) {
+      const int rb = band0(k_begin + 32);
+      for (int row = 64 + (tid >> 3); row < BAND2; row += 64) {
+        const int r = rb + row;
+        const bool ok = r >= 0 && r < p.R;
+        const int slot = ring_slot(r);
+        for (int qd = squad; qd < NQD; qd += 8) {
+          uint2 hi, lo;
+          split_f4(buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB), hi, lo);
+          const int o = slot * HD + swz(slot, qd >> 1) + (qd & 1) * 4;
+          *reinterpret_cast<uint2 *>(Ep + o) = hi;
+          *reinterpret_cast<uint2 *>(Ep + o + RING * HD) = lo;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  const float scale2 = p.scale * LOG2E;
+  const bool ck_regular = (32 % p.Ck) == 0;
+  int evoff[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) evoff[r] = 31 / p.Ck - mfma_row(r, half) / p.Ck;
+  const unsigned short *Kb = Kp + (grp * 2) * 32 * HD, *Vb = Vp + (grp * 2) * VR * 32;
+  const int *evkb = evk + grp * 32;
+
+  for (int kp = k_begin; kp < k_end; kp += 64) {
+    const bool more = kp + 64 < k_end;
+    if (more) prefetch(kp + 64);
+    const int k0 = kp + 32 * grp;
+    const int rb = band0(k0);
+
+    bool live = qw0 < p.Sq && k0 < k_end;
+    if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
+    if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
+    if (live) {
+      // ---- S^T = K Q^T
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NKB; ++t) {
+        const int o = ql * HD + swz(ql, 2 * t + half);
+        const s16x8_t kh = *reinterpret_cast<const s16x8_t *>(Kb + o);
+        const s16x8_t kl = *reinterpret_cast<const s16x8_t *>(Kb + o + 32 * HD);
+        sacc = ISI_MFB(kl, qh[t], sacc);
+        sacc = ISI_MFB(kh, qlo[t], sacc);
+        sacc = ISI_MFB(kh, qh[t], sacc);
+      }
+      float sv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
+
+      // ---- relative logits through the skew buffer
+      if (has_e) {
+        float *sr = Sr + wave * 32 * SRLD + ql * SRLD;
+        const int wrow0 = rb + evq_w0 - evq_b0;
+        const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
+        for (int tb = 0; tb < nt; ++tb) {
+          f32x16 racc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+          const int slot = ring_slot(wrow0 + 32 * tb + ql);
+#pragma unroll
+          for (int t = 0; t < NKB; ++t) {
+            const int o = slot * HD + swz(slot, 2 * t + half);
+            const s16x8_t eh = *reinterpret_cast<const s16x8_t *>(Ep + o);
+            const s16x8_t el = *reinterpret_cast<const s16x8_t *>(Ep + o + RING * HD);
+            racc = ISI_MFB(el, qh[t], racc);
+            racc = ISI_MFB(eh, qlo[t], racc);
+            racc = ISI_MFB(eh, qh[t], racc);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sr[32 * tb + mfma_row(r, half)] = racc[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int dq = evq - evq_w0;
+        if (ck_regular) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evoff[r]];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sv[r] += sr[dq + evkb[mfma_row(r, half)]];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+
+      // ---- scale, mask, online softmax (base 2)
+      float tmax = NEG;
+      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < p.Sq;
+      if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
+      if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sv[r] *= scale2;
+          tmax = fmaxf(tmax, sv[r]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = k0 + mfma_row(r, half);
+          bool ok = kj < p.Sk;
+          if (p.mask_mode == 1) ok = ok && kj <= qi;
+          if (p.mask_mode == 2) ok = ok && kj >= qi;
+          float sc = sv[r] * scale2;
+          if (p.mask && ok && qi < p.Sq) sc += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          sc = ok ? sc : NEG;
+          sv[r] = sc;
+          tmax = fmaxf(tmax, sc);
+        }
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = sv[r] <= -1e29f ? 0.f : __builtin_amdgcn_exp2f(sv[r] - m_new);
+        sv[r] = pr;
+        psum += pr;
+      }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+
+      // ---- P split: key block t = registers 8 t .. 8 t + 7
+      s16x8_t ph[2], pl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2(sv[8 * t + 2 * e], sv[8 * t + 2 * e + 1], hh[e], ll[e]);
+        ph[t] = __builtin_bit_cast(s16x8_t, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+        pl[t] = __builtin_bit_cast(s16x8_t, make_uint4(ll[0], ll[1], ll[2], ll[3]));
+      }
+      // ---- O^T = alpha * O^T + V^T P^T
+      const bool rescale = __any(alpha != 1.f);
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        if (rescale) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
+        }
+        const int drow = d * 32 + ql;
+        const int sx = (drow >> 2) & 7;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const unsigned short *vr = Vb + drow * 32;
+          const uint2 h0 = *reinterpret_cast<const uint2 *>(vr + (((4 * t + half) ^ sx) * 4));
+          const uint2 h1 = *reinterpret_cast<const uint2 *>(vr + (((4 * t + 2 + half) ^ sx) * 4));
+          const uint2 l0 = *reinterpret_cast<const uint2 *>(vr + VR * 32 + (((4 * t + half) ^ sx) * 4));
+          const uint2 l1 = *reinterpret_cast<const uint2 *>(vr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
+          const s16x8_t vh = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+          const s16x8_t vl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+          O[d] = ISI_MFB(vl, ph[t], O[d]);
+          O[d] = ISI_MFB(vh, pl[t], O[d]);
+          O[d] = ISI_MFB(vh, ph[t], O[d]);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) commit(kp + 64);
+    __syncthreads();
+  }
+
+  // ---- merge the two groups' softmax states (group 1 -> LDS -> group 0)
+  float *mg = smem;
+  constexpr int MGW = (NDB * 16 + 2) * 64;
+  if (grp == 1) {
+    float *dst = mg + wq * MGW + lane;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = O[d][r];
+    dst[NDB * 16 * 64] = m_run;
+    dst[(NDB * 16 + 1) * 64] = l_run;
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  {
+    const float *src = mg + wq * MGW + lane;
+    const float m1 = src[NDB * 16 * 64], l1 = src[(NDB * 16 + 1) * 64];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+    l_run = l_run * a0 + l1 * a1;
+    m_run = m;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[d][r] = O[d][r] * a0 + src[(d * 16 + r) * 64] * a1;
+  }
+  if (qi < p.Sq) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float *orow = p.out + (size_t)qi * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
+    if (p.lse && half == 0)
+      p.lse[((size_t)b * p.H + h) * p.Sq + qi] = l_run > 0.f ? m_run * LN2 + logf(l_run) : 1e30f;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * half;
+        if (dd < HD)
+          *reinterpret_cast<float4 *>(orow + dd) =
+              make_float4(O[d][4 * g] * inv, O[d][4 * g + 1] * inv, O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv);
+      }
+  }
+}
+
 template <int HD>
 static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
-  auto kern = rel_attention_f32_kernel<HD>;
-  constexpr size_t smem = (size_t)((128 + RING) * (HD + 4) + 8 * 32 * SRLD) * sizeof(float) + 64 * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
+  auto kern = a.split ? rel_attention_split_kernel<HD> : rel_attention_f32_kernel<HD>;
+  constexpr int VR = ((HD + 31) / 32) * 32;
+  constexpr size_t smem_f = (size_t)((128 + RING) * (HD + 4) + 8 * 32 * SRLD) * sizeof(float) + 64 * sizeof(int);
+  constexpr size_t smem_s = (size_t)(2 * 2 * 32 * HD + 2 * 2 * VR * 32 + 2 * RING * HD) * sizeof(unsigned short) +
+                            (size_t)(8 * 32 * SRLD) * sizeof(float) + 64 * sizeof(int);
+  const size_t smem = a.split ? smem_s : smem_f;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[a.split]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(rel_attention)");
-    attr_set = true;
+    attr_set[a.split] = true;
   }
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * B;
   prof::Scope scope(prof::K_REL_ATTENTION, 2.0 * pairs * HD * (a.e ? 3 : 2),
@@ -409,6 +796,7 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   a.o_ss = (int)g->o_ss; a.o_sb = (int)g->o_sb; a.o_sh = (int)g->o_sh;
   a.Cq = g->Cq; a.Ck = g->Ck; a.Ek = g->Ek;
   a.mask_mode = g->mask_mode; a.scale = g->scale;
+  a.split = g->precision == 1 ? 1 : 0;
   if (a.e && a.R <= 0) return invalid("rel_attention: rel_rows must be positive");
   switch (g->head_dim) {
     case 16: return launch_attn<16>(a, g->B, stream);

@@ -25,6 +25,10 @@ def _s(t):
 # fp64 at or below the fp32 pipe's own, 1.4x its speed; 'f32' = the fp32 matrix pipe.
 # Shapes the split kernel does not cover (N <= 32 or K < 128) run on the fp32 pipe either way.
 LINEAR_PRECISION = os.environ.get("ISI_LINEAR_PRECISION", "bf16x6")
+# products of the attention contractions (q k^T, q e^T, p v): 'f32' = fp32 matrix pipe, 'bf16x3' = three-term
+# split-bf16 on the bf16 pipe (relative error of a product ~2^-16, fp32 accumulation, logits / softmax fp32)
+ATTENTION_PRECISION = os.environ.get("ISI_ATTENTION_PRECISION", "bf16x3")
+_ATTN_PREC = {"f32": 0, "bf16x3": 1}
 _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4}
 
 
@@ -103,6 +107,7 @@ def _attn_args(q, k, v, rel, out, Sq, Sk, B, H, hd, Cq, Ck, Ek, mask_mode, dense
     a.rel_rows = rel.shape[1] if rel is not None else 0
     a.mask_mode = mask_mode
     a.scale = 1.0 / math.sqrt(hd)
+    a.precision = _ATTN_PREC[ATTENTION_PRECISION]
     return a
 
 

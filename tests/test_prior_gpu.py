@@ -59,9 +59,11 @@ def _models(golden_dir, load=True):
     (16, 4, 33, 33, 1, 1, 1), (16, 4, 33, 33, 1, 1, 2), (16, 4, 132, 33, 4, 1, 0),
     (64, 2, 200, 200, 1, 1, 1), (32, 3, 260, 260, 4, 4, 1), (64, 2, 77, 150, 2, 1, 0),
 ])
-def test_rel_attention_against_spec(hd, H, Sq, Sk, Cq, Ck, mode):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_rel_attention_against_spec(hd, H, Sq, Sk, Cq, Ck, mode, precision, monkeypatch):
     from oracle import prior_oracle as P
     from interactive_spectrogram_inpainting.priors import _ops
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", precision)  # both kernels hold the same tolerance
     torch.manual_seed(hd + Sq)
     d, B = hd * H, 2
     Eq, Ek = -(-Sq // Cq), -(-Sk // Ck)

@@ -9,6 +9,7 @@ import sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
 import torch  # noqa: E402
+from interactive_spectrogram_inpainting.priors import _ops  # noqa: E402
 from interactive_spectrogram_inpainting.priors._train import RelAttentionFn  # noqa: E402
 
 
@@ -33,6 +34,7 @@ def main():
     ap.add_argument("--hd", type=int, default=64)
     ap.add_argument("--modes", type=int, nargs="*", default=[1, 0])
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--precisions", nargs="*", default=["f32", "bf16x3"])
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     B, H, S, hd = a.B, a.H, a.S, a.hd
@@ -41,11 +43,12 @@ def main():
     qkv = torch.randn(S, B, 3 * d, device=dev, requires_grad=True)
     rel = (torch.randn(H, 2 * S - 1, hd, device=dev) * 0.1).requires_grad_(True)
     w = torch.randn(S, B, d, device=dev)
-    for mode in a.modes:
+    for mode, prec in [(m, p) for m in a.modes for p in a.precisions]:
+        _ops.ATTENTION_PRECISION = prec
         with torch.no_grad():
             t_f = timed(lambda: RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, mode, None))
         dense = 2.0 * S * S * hd * B * H
-        line = f"mode {mode}: fwd {t_f:8.1f} us  {3 * dense / t_f / 1e6:6.1f} TF(dense)"
+        line = f"mode {mode} {prec:7s}: fwd {t_f:8.1f} us  {3 * dense / t_f / 1e6:6.1f} TF(dense)"
         if not a.fwd_only:
             out = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, mode, None)
 
@@ -55,6 +58,11 @@ def main():
                 out.backward(w, retain_graph=True)
             t_b = timed(bwd)
             line += f" | bwd {t_b:8.1f} us  {7 * dense / t_b / 1e6:6.1f} TF(dense)"
+        with torch.no_grad():
+            o = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, mode, None)
+            _ops.ATTENTION_PRECISION = "f32"
+            o0 = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, mode, None)
+        line += f" | max |out - out_f32| {(o - o0).abs().max().item():.2e} (|out| max {o0.abs().max().item():.2f})"
         print(line)
 
 

@@ -739,6 +739,7 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
                        g->rel_embeddings, wT, g->H, R, HD, KpT, rho_lo, rho_n);
     if ((rc = check_launch("pack_rel_T"))) return rc;
   }
+  const int gemm_flags = g->precision == 1 ? ISI_CONV_BF16X3 : 0;   // same product mode as the attention kernels
   for (int h = 0; h < g->H; ++h) {
     float *Gh = a.g + (size_t)h * g->B * g->Sq * L.Rp;
     isi_src sg;
@@ -750,14 +751,14 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     isi_dst dst;
     memset(&dst, 0, sizeof dst);
     dst.ptr = ga->dq + (size_t)h * g->q_sh; dst.sn = g->q_sb; dst.sc = 1; dst.sh = g->q_ss; dst.sw = g->q_ss;
-    rc = conv2d_f32(&sg, nullptr, wT + (size_t)h * HD * KpT, nullptr, &res, &dst, g->B, g->Sq, 1, HD, 1, 1, 1, 0, 0,
-                    stream);
+    rc = conv2d_f32(&sg, nullptr, wT + (size_t)h * HD * KpT, nullptr, &res, &dst, g->B, g->Sq, 1, HD, 1, 1, 1, 0,
+                    gemm_flags, stream);
     if (rc) return rc;
     isi_src sq;
     memset(&sq, 0, sizeof sq);
     sq.ptr = g->q + (size_t)h * g->q_sh; sq.C = HD; sq.sn = g->q_sb; sq.sc = 1; sq.sh = g->q_ss; sq.sw = g->q_ss;
     rc = conv_wgrad_f32(&sq, nullptr, Gh, ga->workspace + L.dw + (size_t)h * L.Rp * L.Kp, nullptr,
-                        ga->workspace + L.wg, L.wg_floats, g->B, g->Sq, 1, L.Rp, 1, 1, 1, 0, 0, stream);
+                        ga->workspace + L.wg, L.wg_floats, g->B, g->Sq, 1, L.Rp, 1, 1, 1, 0, gemm_flags, stream);
     if (rc) return rc;
   }
   {

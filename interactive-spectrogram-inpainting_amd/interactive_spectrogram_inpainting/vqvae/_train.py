@@ -117,7 +117,7 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
                               B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
     _hip.check(rc, "isi_conv_wgrad_f32")
     # [rows][kh][kw][cin_role] -> [rows, cin_role, kh, kw]  (= torch layout for both layer kinds)
-    dw = packed[:, :K].reshape(rows, k, k, cin_role).permute(0, 3, 1, 2)
+    dw = layer.grouped(packed[:, :K].reshape(rows, k, k, cin_role).permute(0, 3, 1, 2))
     if tr:
         db = colsum(dy_nhwc.reshape(-1, dy_nhwc.shape[-1]))
     return dw, db
@@ -133,7 +133,7 @@ class _DgradWeights:
         key = (layer.weight._version, layer.weight.data_ptr())
         hit = self.cache.get(id(layer))
         if hit is None or hit[0] != key:
-            w = layer.weight.detach()
+            w = layer.dense_weight()
             if layer.transposed:
                 # d/dx ConvT(k4,s2,p1) = Conv(k4,s2,p1) with weight [out=Cin_T, in=Cout_T]: same tensor
                 packed = _ops.pack_conv_weight(w)
@@ -324,10 +324,9 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
 
 # ------------------------------------------------------------------ quantiser (train mode)
 def quantize_train(q, z_nhwc: torch.Tensor):
-    """Eval-identical search with the CURRENT codebook, then the EMA update of the buffers
-    (bottleneck.py:75-92) from statistics all-reduced over the data-parallel ranks."""
-    if q.corruption_weights is not None:
-        raise NotImplementedError("index corruption (bottleneck.py:63-73) is not built")
+    """Eval-identical search with the CURRENT codebook, optional index corruption (bottleneck.py:63-73),
+    then the EMA update of the buffers (bottleneck.py:75-92) from statistics all-reduced over the
+    data-parallel ranks."""
     codes, e2 = q.packed()
     L = _hip.lib()
     D, K = q.dim, q.n_embed
@@ -343,6 +342,20 @@ def quantize_train(q, z_nhwc: torch.Tensor):
                "isi_vq_nearest_f32")
     _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D, out2.data_ptr(),
                                      _s(z_nhwc)), "isi_vq_finalize_f32")
+    diff, perplexity = out2[0], out2[1]
+    if q.corruption_weights is not None:
+        # offsets in {-1, 0, +1} drawn exactly like the reference: torch.multinomial on the CPU default
+        # generator (same seed -> same offsets), moved to the device and added modulo K; every quantity
+        # downstream (codes, diff, usage statistics, EMA sums) is then taken from the corrupted indices
+        offsets = torch.multinomial(torch.Tensor(q.corruption_weights), idx.numel(), replacement=True) - 1
+        idx = (idx + offsets.reshape(idx.shape).to(idx.device)) % K
+        qv = _ops.embed_code(idx, codes)
+        delta = qv - z_nhwc
+        q_st = z_nhwc + delta
+        diff = delta.pow(2).mean()
+        counts = torch.bincount(idx.reshape(-1), minlength=K).to(torch.int32)
+        p = counts.float() / N
+        perplexity = torch.exp(-torch.sum(p * torch.log(p.clamp(min=1e-7))))
     embed_sum = torch.empty(D, K, dtype=torch.float32, device=z_nhwc.device)
     nws = L.isi_vq_embed_sum_workspace_floats(D, K, N)
     ws = torch.empty(nws, dtype=torch.float32, device=z_nhwc.device)
@@ -359,7 +372,27 @@ def quantize_train(q, z_nhwc: torch.Tensor):
     # the buffers were written through raw pointers (no torch version bump): invalidate caches
     q._packed_key = None
     q._ema_steps = getattr(q, "_ema_steps", 0) + 1
-    return q_st, out2[0], idx, out2[1]
+    return q_st, diff, idx, perplexity
+
+
+class QuantizeTrainFunction(torch.autograd.Function):
+    """Stand-alone train-mode QuantizedBottleneck.forward (bottleneck.py:53-101): straight-through
+    gradient for the quantised output plus the commitment gradient 2 (z - q) / numel through `diff`."""
+
+    @staticmethod
+    def forward(ctx, q, z):
+        z = z.contiguous()
+        q_st, diff, idx, perplexity = quantize_train(q, z)
+        ctx.save_for_backward(z, q_st)
+        ctx.mark_non_differentiable(idx, perplexity)
+        return q_st, diff, idx, perplexity
+
+    @staticmethod
+    def backward(ctx, dq, ddiff, _di, _dp):
+        z, q_st = ctx.saved_tensors
+        dq = torch.zeros_like(z) if dq is None else dq.contiguous()
+        g = torch.zeros((), device=z.device) if ddiff is None else ddiff.reshape(())
+        return None, vq_backward(dq, z, q_st, g.contiguous())
 
 
 def vq_backward(dq_nhwc, z_nhwc, q_st_nhwc, g_diff):

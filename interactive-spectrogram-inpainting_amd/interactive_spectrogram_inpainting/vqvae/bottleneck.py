@@ -49,12 +49,11 @@ class QuantizedBottleneck(nn.Module):
         return self._packed
 
     def forward(self, input: Tensor) -> Tuple[Tensor, Tensor, Tensor, Tensor]:
-        """input [..., D] channels-last.  Eval mode only for now: the train-mode
-        EMA update / index corruption (bottleneck.py:63-73,79-92) are not built."""
+        """input [..., D] channels-last.  Train mode also corrupts the indices when
+        `corruption_weights` is set and updates the codebook buffers (bottleneck.py:63-73,79-92)."""
         if self.training:
-            raise NotImplementedError(
-                "train-mode quantisation (EMA codebook update, index corruption) is not built yet; "
-                "call .eval() for the inference path")
+            from ._train import QuantizeTrainFunction
+            return QuantizeTrainFunction.apply(self, input)
         codes, e2 = self.packed()
         return _ops.vq_nearest(input, codes, e2)
 

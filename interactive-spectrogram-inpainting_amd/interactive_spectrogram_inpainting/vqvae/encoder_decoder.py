@@ -33,12 +33,16 @@ class _ConvParams(nn.Module):
     Holds parameters only; packing for the HIP kernels is cached per version."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int,
-                 stride: int = 1, padding: int = 0, transposed: bool = False):
+                 stride: int = 1, padding: int = 0, transposed: bool = False, groups: int = 1):
         super().__init__()
+        if groups < 1 or in_channels % groups or out_channels % groups:
+            raise ValueError("in_channels and out_channels must be divisible by groups")  # torch.nn's check
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
         self.transposed = transposed
-        shape = ((in_channels, out_channels) if transposed else (out_channels, in_channels))
+        self.groups = groups
+        # torch.nn layouts: Conv2d [Cout, Cin/groups, k, k], ConvTranspose2d [Cin, Cout/groups, k, k]
+        shape = ((in_channels, out_channels // groups) if transposed else (out_channels, in_channels // groups))
         self.weight = nn.Parameter(torch.empty(*shape, kernel_size, kernel_size))
         self.bias = nn.Parameter(torch.empty(out_channels))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -48,6 +52,28 @@ class _ConvParams(nn.Module):
         self._packed = None
         self._packed_key = None
 
+    def dense_weight(self) -> torch.Tensor:
+        """The weight as the kernels consume it (detached): a grouped convolution (encoder_decoder.py:58-215,
+        `groups=groups`) is run as the dense convolution with the block-diagonal weight -- group g maps
+        its slice of the input channels to its slice of the output channels, every other product is an
+        exact zero -- so the implicit-GEMM kernels need no grouped variant."""
+        w = self.weight.detach()
+        if self.groups == 1:
+            return w
+        rows = w.shape[0] // self.groups          # Conv2d: output channels / group; ConvTranspose2d: input channels
+        cols = w.shape[1]
+        dense = w.new_zeros(w.shape[0], cols * self.groups, *w.shape[2:])
+        for g in range(self.groups):
+            dense[g * rows:(g + 1) * rows, g * cols:(g + 1) * cols] = w[g * rows:(g + 1) * rows]
+        return dense
+
+    def grouped(self, dense: torch.Tensor) -> torch.Tensor:
+        """Block-diagonal part of a dense-layout tensor (a weight gradient) in the parameter's layout."""
+        if self.groups == 1:
+            return dense
+        rows, cols = dense.shape[0] // self.groups, dense.shape[1] // self.groups
+        return torch.cat([dense[g * rows:(g + 1) * rows, g * cols:(g + 1) * cols] for g in range(self.groups)], 0)
+
     def packed(self) -> torch.Tensor:
         key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
         if self._packed is None or self._packed_key != key:
@@ -55,16 +81,16 @@ class _ConvParams(nn.Module):
                 if (self.kernel_size, self.stride, self.padding) != (4, 2, 1):
                     raise NotImplementedError("only ConvTranspose2d(k=4, s=2, p=1) is built "
                                               "(use_local_kernels=True is not)")
-                self._packed = _ops.pack_convT_weight(self.weight)
+                self._packed = _ops.pack_convT_weight(self.dense_weight())
             else:
-                self._packed = _ops.pack_conv_weight(self.weight)
+                self._packed = _ops.pack_conv_weight(self.dense_weight())
             self._packed_key = key
         return self._packed
 
     def extra_repr(self):
         kind = "ConvTranspose2d" if self.transposed else "Conv2d"
         return (f"{kind}({self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
-                f"stride={self.stride}, padding={self.padding})")
+                f"stride={self.stride}, padding={self.padding}" + (f", groups={self.groups})" if self.groups > 1 else ")"))
 
     def run(self, x, relu: bool, x2=None, residual=None, out_nchw: bool = False, bf16x3: bool = False):
         if self.transposed:
@@ -72,11 +98,6 @@ class _ConvParams(nn.Module):
                                               out_nchw=out_nchw, bf16x3=bf16x3)
         return _ops.conv2d(x, self.packed(), self.bias, self.out_channels, self.kernel_size,
                            self.stride, self.padding, relu, x2_bchw=x2, residual_bchw=residual, bf16x3=bf16x3)
-
-
-def _check_groups(groups: int):
-    if groups != 1:
-        raise NotImplementedError("grouped convolutions are not built for the MI355X path (groups must be 1)")
 
 
 class RosinalityResBlock(nn.Module):
@@ -104,6 +125,14 @@ class RosinalityResBlock(nn.Module):
         # the in-place ReLU of the reference is reproduced on the caller's tensor
         _ops.relu_(input)
         return self.forward_rectified(input, relu_out=False)
+
+
+# The reference keeps padding=1 with its k=2 "local" kernels (encoder_decoder.py:46-51,146-151), so a stage maps
+# H -> H/2 + 1 going down and H -> 2H - 2 going up: VQVAE.encode then fails on torch.cat([dec_t, enc_b])
+# (vqvae.py:264-271; probed: "Sizes of tensors must match ... Expected size 8 but got size 9").  The option
+# cannot run in the reference's own model, so there is no behaviour to reproduce.
+_LOCAL_KERNELS = ("use_local_kernels=True is not built: with the reference's padding=1 the k=2 stages give "
+                  "H/2+1 and 2H-2 sized maps and the reference VQVAE.encode itself fails on the top/bottom concat")
 
 
 def _down_channels(in_channel: int, channel: int, factor: int):
@@ -134,9 +163,8 @@ class RosinalityEncoder(nn.Module):
     def __init__(self, in_channel: int, channel: int, n_res_block: int, n_res_channel: int,
                  resolution_factor: int, groups: int = 1, use_local_kernels: bool = False):
         super().__init__()
-        _check_groups(groups)
         if use_local_kernels:
-            raise NotImplementedError("use_local_kernels=True (k=2 non-overlapping kernels) is not built")
+            raise NotImplementedError(_LOCAL_KERNELS)
         self.use_local_kernels = use_local_kernels
         self.resolution_factor = resolution_factor
         blocks: List[nn.Module] = []
@@ -144,10 +172,10 @@ class RosinalityEncoder(nn.Module):
         last = in_channel
         for (a, b) in _down_channels(in_channel, channel, resolution_factor):
             self._down.append(len(blocks))
-            blocks += [_ConvParams(a, b, 4, stride=2, padding=1), _Slot()]
+            blocks += [_ConvParams(a, b, 4, stride=2, padding=1, groups=groups), _Slot()]
             last = b
         self._conv3 = len(blocks)
-        blocks.append(_ConvParams(last, channel, 3, padding=1))
+        blocks.append(_ConvParams(last, channel, 3, padding=1, groups=groups))
         self._res: List[int] = []
         for _ in range(n_res_block):
             self._res.append(len(blocks))
@@ -172,9 +200,8 @@ class RosinalityDecoder(nn.Module):
                  n_res_channel: int, resolution_factor: int, groups: int = 1,
                  use_local_kernels: bool = False, output_activation: Optional[nn.Module] = None):
         super().__init__()
-        _check_groups(groups)
         if use_local_kernels:
-            raise NotImplementedError("use_local_kernels=True (k=2 non-overlapping kernels) is not built")
+            raise NotImplementedError(_LOCAL_KERNELS)
         if output_activation is not None:
             raise NotImplementedError("decoder output activations are not built (always None in the reference, "
                                       "vqvae.py:95-96)")
@@ -190,7 +217,7 @@ class RosinalityDecoder(nn.Module):
         ups = _up_channels(channel, out_channel, resolution_factor)
         for j, (a, b) in enumerate(ups):
             self._up.append(len(blocks))
-            blocks.append(_ConvParams(a, b, 4, stride=2, padding=1, transposed=True))
+            blocks.append(_ConvParams(a, b, 4, stride=2, padding=1, transposed=True, groups=groups))
             if j != len(ups) - 1:
                 blocks.append(_Slot())
         self.blocks = nn.ModuleList(blocks)

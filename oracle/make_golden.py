@@ -153,6 +153,7 @@ def vqvae_fixture(name, ctor_kwargs, in_shape, seed):
         cfg_num_embeddings=np.int64(ctor_kwargs.get("num_embeddings", 512)),
         cfg_factor_bottom=np.int64(ctor_kwargs.get("resolution_factors", {"bottom": 4})["bottom"]),
         cfg_factor_top=np.int64(ctor_kwargs.get("resolution_factors", {"top": 2})["top"]),
+        cfg_groups=np.int64(ctor_kwargs.get("groups", 1)),
     )
     _save(name, **arrays)
 
@@ -235,6 +236,19 @@ def quantizer_fixtures():
         out[f"e_embed_avg{step}"] = q3.embed_avg.clone().numpy()
         out[f"e_diff{step}"] = diff3.numpy()
         out[f"e_perp{step}"] = perp3.numpy()
+    # (4) train mode with index corruption (bottleneck.py:63-73); the offsets come from the CPU default generator
+    torch.manual_seed(15)
+    q4 = QuantizedBottleneck(16, 32, corruption_weights=[0.1, 0.8, 0.1]).train()
+    out["c_embed0"] = q4.embed.clone().numpy()
+    zc = torch.randn(2, 5, 7, 16)
+    out["c_z"] = zc.numpy()
+    torch.manual_seed(16)      # state of the default generator when forward draws the offsets
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        quant4, diff4, ind4, perp4 = q4(zc)
+    out.update(c_ind=ind4.numpy(), c_quant=quant4.numpy(), c_diff=diff4.numpy(), c_perp=perp4.numpy(),
+               c_embed1=q4.embed.clone().numpy(), c_cluster_size1=q4.cluster_size.clone().numpy(),
+               c_embed_avg1=q4.embed_avg.clone().numpy())
     _save("quantizer.npz", **out)
 
 
@@ -447,6 +461,12 @@ def main():
                        num_residual_channels=8, embed_dim=8, num_embeddings=32,
                        resolution_factors={"bottom": 8, "top": 4}),
                   (1, 2, 64, 64), seed=23)
+    # grouped convolutions (groups=2 in every down / up-sampling conv and the encoders' 3x3)
+    vqvae_fixture("vqvae_groups2.npz",
+                  dict(in_channel=2, num_hidden_channels=32, n_res_block=1,
+                       num_residual_channels=8, embed_dim=16, num_embeddings=64, groups=2,
+                       resolution_factors={"bottom": 4, "top": 2}),
+                  (2, 2, 32, 32), seed=24)
     resblock_fixture()
     layer_fixtures()
     quantizer_fixtures()

@@ -66,6 +66,16 @@ def _up_channels(channel: int, out_channel: int, factor: int):
     return list(zip(chans[:-1], chans[1:]))
 
 
+def _conv(x: Tensor, w: Tensor, b: Tensor, **kw) -> Tensor:
+    """Conv2d whose `groups` (encoder_decoder.py:58-112) is read off the weight shape [Cout, Cin/groups, k, k]."""
+    return F.conv2d(x, w, b, groups=x.shape[1] // w.shape[1], **kw)
+
+
+def _conv_t(x: Tensor, w: Tensor, b: Tensor, **kw) -> Tensor:
+    """ConvTranspose2d, `groups` (encoder_decoder.py:159-215) from the weight shape [Cin, Cout/groups, k, k]."""
+    return F.conv_transpose2d(x, w, b, groups=b.shape[0] // w.shape[1], **kw)
+
+
 def res_block(x: Tensor, sd: StateDict, prefix: str) -> Tensor:
     """RosinalityResBlock (encoder_decoder.py:18-35).
 
@@ -87,15 +97,15 @@ def encoder(x: Tensor, sd: StateDict, prefix: str, factor: int, n_res_block: int
     idx = 0
     n_stages = _STAGES[factor]
     for s in range(n_stages):
-        x = F.conv2d(x, sd[f"{prefix}blocks.{idx}.weight"], sd[f"{prefix}blocks.{idx}.bias"],
-                     stride=2, padding=1)
+        x = _conv(x, sd[f"{prefix}blocks.{idx}.weight"], sd[f"{prefix}blocks.{idx}.bias"],
+                  stride=2, padding=1)
         idx += 1
         # every strided conv is followed by a ReLU (encoder_decoder.py:53-113)
         x = F.relu(x)
         idx += 1
     assert k == sd[f"{prefix}blocks.0.weight"].shape[-1]
-    x = F.conv2d(x, sd[f"{prefix}blocks.{idx}.weight"], sd[f"{prefix}blocks.{idx}.bias"],
-                 padding=1)
+    x = _conv(x, sd[f"{prefix}blocks.{idx}.weight"], sd[f"{prefix}blocks.{idx}.bias"],
+              padding=1)
     idx += 1
     for _ in range(n_res_block):
         x = res_block(x, sd, f"{prefix}blocks.{idx}.")
@@ -116,8 +126,8 @@ def decoder(x: Tensor, sd: StateDict, prefix: str, factor: int, n_res_block: int
     idx += 1
     n_stages = _STAGES[factor]
     for s in range(n_stages):
-        x = F.conv_transpose2d(x, sd[f"{prefix}blocks.{idx}.weight"],
-                               sd[f"{prefix}blocks.{idx}.bias"], stride=2, padding=1)
+        x = _conv_t(x, sd[f"{prefix}blocks.{idx}.weight"],
+                    sd[f"{prefix}blocks.{idx}.bias"], stride=2, padding=1)
         idx += 1
         if s != n_stages - 1:
             x = F.relu(x)
@@ -163,16 +173,20 @@ def ema_update(flat: Tensor, ind: Tensor, embed: Tensor, cluster_size: Tensor,
 
 
 def quantize_train(z: Tensor, embed: Tensor, cluster_size: Tensor, embed_avg: Tensor, decay: float = 0.99,
-                   eps: float = 1e-5):
+                   eps: float = 1e-5, corruption_weights=None):
     """QuantizedBottleneck.forward in train mode with autograd semantics
-    (bottleneck.py:53-101, corruption disabled): search with the current codebook,
-    EMA update of the buffers, commitment `diff`, straight-through output.
+    (bottleneck.py:53-101): search with the current codebook, optional index corruption
+    (`:63-73`: offsets multinomial(weights) - 1 in {-1, 0, +1}, drawn from the CPU default
+    generator, added modulo K), EMA update of the buffers, commitment `diff`, straight-through output.
     Returns (q_st, diff, ind, perplexity, (embed', cluster_size', embed_avg'))."""
     dim, n_embed = embed.shape
     with torch.no_grad():
         flat = z.detach().reshape(-1, dim)
         dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ embed + embed.pow(2).sum(0, keepdim=True)
         _, ind = (-dist).max(1)
+        if corruption_weights is not None:
+            offsets = torch.multinomial(torch.Tensor(corruption_weights), ind.numel(), replacement=True) - 1
+            ind = (ind + offsets.reshape(ind.shape)) % n_embed
         new = ema_update(flat, ind, embed, cluster_size, embed_avg, decay, eps)
         onehot_mean = torch.bincount(ind, minlength=n_embed).to(flat.dtype) / flat.shape[0]
         perplexity = torch.exp(-torch.sum(onehot_mean * torch.log(onehot_mean.clamp(min=1e-7))))
@@ -190,13 +204,15 @@ def forward_train(x: Tensor, sd: StateDict, cfg: "Config"):
     enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
     z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
     q_t, diff_t, id_t, _, new_t = quantize_train(z_t, sd["quantize_t.embed"], sd["quantize_t.cluster_size"],
-                                                 sd["quantize_t.embed_avg"])
+                                                 sd["quantize_t.embed_avg"],
+                                                 corruption_weights=cfg.corruption_weights["top"])
     q_t = q_t.permute(0, 3, 1, 2)
     dec_t = decoder(q_t, sd, "dec_t.", ft, cfg.n_res_block)
     z_b = F.conv2d(torch.cat([dec_t, enc_b], 1), sd["quantize_conv_b.weight"],
                    sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
     q_b, diff_b, id_b, _, new_b = quantize_train(z_b, sd["quantize_b.embed"], sd["quantize_b.cluster_size"],
-                                                 sd["quantize_b.embed_avg"])
+                                                 sd["quantize_b.embed_avg"],
+                                                 corruption_weights=cfg.corruption_weights["bottom"])
     q_b = q_b.permute(0, 3, 1, 2)
     dec = decode(q_t, q_b, sd, cfg)
     return dec, diff_t.unsqueeze(0) + diff_b.unsqueeze(0), id_t, id_b, (new_t, new_b)
@@ -212,7 +228,9 @@ class Config:
 
     def __init__(self, in_channel=2, num_hidden_channels=128, n_res_block=2,
                  num_residual_channels=32, embed_dim=64, num_embeddings=512,
-                 resolution_factors=None, adapt_quantized_durations=True):
+                 resolution_factors=None, adapt_quantized_durations=True, groups=1, corruption_weights=None):
+        self.groups = groups                              # vqvae.py:76: down / up-sampling convs and the encoders' 3x3
+        self.corruption_weights = dict(corruption_weights or {"top": None, "bottom": None})   # vqvae.py:84-85
         self.in_channel = in_channel
         self.num_hidden_channels = num_hidden_channels
         self.n_res_block = n_res_block
@@ -279,14 +297,14 @@ def init_state_dict(cfg: Config, seed: int = 1) -> Dict[str, Tensor]:
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, Tensor] = {}
 
-    def conv(name, cout, cin, k):
-        bound = 1.0 / math.sqrt(cin * k * k)
-        sd[name + ".weight"] = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) * bound
+    def conv(name, cout, cin, k, groups=1):
+        bound = 1.0 / math.sqrt(cin // groups * k * k)
+        sd[name + ".weight"] = (torch.rand(cout, cin // groups, k, k, generator=g) * 2 - 1) * bound
         sd[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
 
-    def convT(name, cin, cout, k):
-        bound = 1.0 / math.sqrt(cout * k * k)
-        sd[name + ".weight"] = (torch.rand(cin, cout, k, k, generator=g) * 2 - 1) * bound
+    def convT(name, cin, cout, k, groups=1):
+        bound = 1.0 / math.sqrt(cout // groups * k * k)
+        sd[name + ".weight"] = (torch.rand(cin, cout // groups, k, k, generator=g) * 2 - 1) * bound
         sd[name + ".bias"] = (torch.rand(cout, generator=g) * 2 - 1) * bound
 
     C, R, D = cfg.num_hidden_channels, cfg.num_residual_channels, cfg.embed_dim
@@ -294,10 +312,10 @@ def init_state_dict(cfg: Config, seed: int = 1) -> Dict[str, Tensor]:
     def enc(prefix, cin, factor):
         idx = 0
         for (a, b) in _down_channels(cin, C, factor):
-            conv(f"{prefix}blocks.{idx}", b, a, 4)
+            conv(f"{prefix}blocks.{idx}", b, a, 4, cfg.groups)
             idx += 2
             last = b
-        conv(f"{prefix}blocks.{idx}", C, last, 3)
+        conv(f"{prefix}blocks.{idx}", C, last, 3, cfg.groups)
         idx += 1
         for _ in range(cfg.n_res_block):
             conv(f"{prefix}blocks.{idx}.conv.1", R, C, 3)
@@ -314,7 +332,7 @@ def init_state_dict(cfg: Config, seed: int = 1) -> Dict[str, Tensor]:
             idx += 1
         idx += 1  # ReLU
         for (a, b) in _up_channels(C, cout, factor):
-            convT(f"{prefix}blocks.{idx}", a, b, 4)
+            convT(f"{prefix}blocks.{idx}", a, b, 4, cfg.groups)
             idx += 2
 
     fb, ft = cfg.resolution_factors["bottom"], cfg.resolution_factors["top"]

@@ -93,8 +93,13 @@ def test_no_cpu_fallback():
         m(torch.randn(1, 2, 16, 16))
     with pytest.raises(_hip.HipLibraryError):
         m.decode_code(torch.zeros(1, 2, 2, dtype=torch.int64), torch.zeros(1, 4, 4, dtype=torch.int64))
-    with pytest.raises(NotImplementedError):
-        VQVAE(in_channel=2, groups=2)
+    with pytest.raises(NotImplementedError):      # unusable in the reference itself (see encoder_decoder._LOCAL_KERNELS)
+        VQVAE(in_channel=2, use_local_kernels=True)
+    g2 = VQVAE(in_channel=2, num_hidden_channels=32, num_residual_channels=8, embed_dim=16, num_embeddings=64, groups=2)
+    assert g2.enc_b.blocks[0].weight.shape == (16, 1, 4, 4) and g2.dec.blocks[-1].weight.shape == (16, 1, 4, 4)
+    dense = g2.enc_b.blocks[2].dense_weight()     # grouped conv = dense conv with the block-diagonal weight
+    assert dense.shape == (32, 16, 4, 4) and not dense[:16, 8:].any() and not dense[16:, :8].any()
+    assert torch.equal(g2.enc_b.blocks[2].grouped(dense), g2.enc_b.blocks[2].weight)
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

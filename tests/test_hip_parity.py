@@ -29,7 +29,8 @@ def _cfg_kwargs(z):
     return dict(in_channel=int(z["cfg_in_channel"]), num_hidden_channels=int(z["cfg_num_hidden_channels"]),
                 n_res_block=int(z["cfg_n_res_block"]), num_residual_channels=int(z["cfg_num_residual_channels"]),
                 embed_dim=int(z["cfg_embed_dim"]), num_embeddings=int(z["cfg_num_embeddings"]),
-                resolution_factors={"bottom": int(z["cfg_factor_bottom"]), "top": int(z["cfg_factor_top"])})
+                resolution_factors={"bottom": int(z["cfg_factor_bottom"]), "top": int(z["cfg_factor_top"])},
+                groups=int(z["cfg_groups"]) if "cfg_groups" in z.files else 1)
 
 
 def _model_from_golden(z):
@@ -114,6 +115,40 @@ def test_quantizer_against_reference(golden_dir):
     assert torch.equal(got.cpu(), torch.from_numpy(z["g_embed_code"]))
 
 
+def test_quantizer_train_mode_against_reference(golden_dir):
+    """Stand-alone train-mode forward: EMA trajectory (bottleneck.py:79-92) and index corruption
+    (bottleneck.py:63-73; offsets from the CPU default generator, so the same seed gives the
+    reference's corrupted indices bit for bit), straight-through / commitment gradients."""
+    from interactive_spectrogram_inpainting.vqvae.bottleneck import QuantizedBottleneck
+    z = np.load(golden_dir / "quantizer.npz")
+    t = lambda k: torch.from_numpy(z[k])
+    q = QuantizedBottleneck(16, 32)
+    q.embed.copy_(t("e_embed0")); q.embed_avg.copy_(t("e_embed0"))
+    q = q.to(_dev()).train()
+    for step in (1, 2):
+        quant, diff, ind, perp = q(t(f"e_z{step}").to(_dev()))
+        assert torch.equal(ind.cpu(), t(f"e_ind{step}"))
+        _close(diff, z[f"e_diff{step}"], 1e-5, "diff"); _close(perp, z[f"e_perp{step}"], 1e-5, "perplexity")
+        _close(q.embed, z[f"e_embed{step}"], 1e-5, "embed"); _close(q.cluster_size, z[f"e_cluster_size{step}"], 2e-6, "cs")
+        _close(q.embed_avg, z[f"e_embed_avg{step}"], 2e-6, "embed_avg")
+    q = QuantizedBottleneck(16, 32, corruption_weights=[0.1, 0.8, 0.1])
+    q.embed.copy_(t("c_embed0")); q.embed_avg.copy_(t("c_embed0"))
+    q = q.to(_dev()).train()
+    zc = t("c_z").to(_dev()).requires_grad_(True)
+    torch.manual_seed(16)
+    quant, diff, ind, perp = q(zc)
+    assert torch.equal(ind.cpu(), t("c_ind")), "corrupted indices must be bit-exact"
+    _close(quant, z["c_quant"], 1e-6, "quantize"); _close(diff, z["c_diff"], 1e-5, "diff")
+    _close(perp, z["c_perp"], 1e-5, "perplexity")
+    _close(q.embed, z["c_embed1"], 1e-5, "embed"); _close(q.cluster_size, z["c_cluster_size1"], 2e-6, "cs")
+    _close(q.embed_avg, z["c_embed_avg1"], 2e-6, "embed_avg")
+    # gradients: d(sum(w * quant) + 3 diff)/dz = w + 3 * 2 (z - q) / numel
+    w = torch.randn_like(zc)
+    (torch.sum(w * quant) + 3.0 * diff).backward()
+    qv = torch.from_numpy(z["c_embed0"]).t()[t("c_ind")].to(_dev())
+    _close(zc.grad, w + 6.0 * (zc.detach() - qv) / zc.numel(), 1e-5, "dz")
+
+
 def test_quantizer_exact_ties_pick_lowest_index():
     from interactive_spectrogram_inpainting.vqvae.bottleneck import QuantizedBottleneck
     from oracle import vqvae_oracle as O
@@ -151,7 +186,7 @@ def _certify_index_mismatches(z_vecs, embed, got, ref, eps=2e-6):
     return bad.numel()
 
 
-@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz"])
+@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz", "vqvae_groups2.npz"])
 def test_vqvae_against_reference(golden_dir, name):
     z = np.load(golden_dir / name)
     m = _model_from_golden(z)

@@ -18,7 +18,8 @@ def _cfg(z):
         in_channel=int(z["cfg_in_channel"]), num_hidden_channels=int(z["cfg_num_hidden_channels"]),
         n_res_block=int(z["cfg_n_res_block"]), num_residual_channels=int(z["cfg_num_residual_channels"]),
         embed_dim=int(z["cfg_embed_dim"]), num_embeddings=int(z["cfg_num_embeddings"]),
-        resolution_factors={"bottom": int(z["cfg_factor_bottom"]), "top": int(z["cfg_factor_top"])})
+        resolution_factors={"bottom": int(z["cfg_factor_bottom"]), "top": int(z["cfg_factor_top"])},
+        groups=int(z["cfg_groups"]) if "cfg_groups" in z.files else 1)
 
 
 def _close(a, b, tol=1e-5):
@@ -29,7 +30,7 @@ def _close(a, b, tol=1e-5):
     assert err <= tol, f"max rel-to-max error {err:.3e} > {tol}"
 
 
-@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz"])
+@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz", "vqvae_groups2.npz"])
 def test_vqvae_forward_matches_reference(golden_dir, name):
     z, sd = _load(golden_dir, name)
     cfg = _cfg(z)
@@ -94,6 +95,17 @@ def test_quantizer(golden_dir):
         embed, cs, ea = O.ema_update(zt.reshape(-1, zt.shape[-1]), ind, embed, cs, ea)
         _close(embed, z[f"e_embed{step}"], 1e-5); _close(cs, z[f"e_cluster_size{step}"], 1e-6)
         _close(ea, z[f"e_embed_avg{step}"], 1e-6)
+    # train mode with index corruption (bottleneck.py:63-73): same generator state -> same offsets
+    embed = t("c_embed0")
+    torch.manual_seed(16)
+    q_st, diff, ind, perp, (e1, cs1, ea1) = O.quantize_train(t("c_z"), embed, torch.zeros(embed.shape[1]), embed.clone(),
+                                                             corruption_weights=[0.1, 0.8, 0.1])
+    assert torch.equal(ind, t("c_ind"))
+    clean = O.quantize(t("c_z"), embed)[2]
+    moved = (ind != clean).float().mean().item()
+    assert 0.1 < moved < 0.3 and set(((ind - clean) % embed.shape[1]).unique().tolist()) <= {0, 1, embed.shape[1] - 1}
+    _close(q_st, z["c_quant"], 1e-6); _close(diff, z["c_diff"], 1e-6); _close(perp, z["c_perp"], 1e-6)
+    _close(e1, z["c_embed1"], 1e-5); _close(cs1, z["c_cluster_size1"], 1e-6); _close(ea1, z["c_embed_avg1"], 1e-6)
 
 
 def test_init_state_dict_keys_match_reference(golden_dir):
@@ -102,8 +114,9 @@ def test_init_state_dict_keys_match_reference(golden_dir):
     assert set(mine) == set(sd)
     for k in sd:
         assert mine[k].shape == sd[k].shape, k
-    z, sd = _load(golden_dir, "vqvae_f8_f4.npz")
-    mine = O.init_state_dict(_cfg(z))
-    assert set(mine) == set(sd)
-    for k in sd:
-        assert mine[k].shape == sd[k].shape, k
+    for name in ("vqvae_f8_f4.npz", "vqvae_groups2.npz"):
+        z, sd = _load(golden_dir, name)
+        mine = O.init_state_dict(_cfg(z))
+        assert set(mine) == set(sd)
+        for k in sd:
+            assert mine[k].shape == sd[k].shape, (name, k)

@@ -21,6 +21,9 @@ def _rel(a, b):
     dict(in_channel=2, num_hidden_channels=32, n_res_block=2, num_residual_channels=8, embed_dim=16, num_embeddings=64),
     dict(in_channel=2, num_hidden_channels=16, n_res_block=1, num_residual_channels=8, embed_dim=8, num_embeddings=32,
          resolution_factors={"bottom": 8, "top": 4}),
+    # grouped convolutions (vqvae.py:76) and index corruption in both quantisers (bottleneck.py:63-73)
+    dict(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16, num_embeddings=64,
+         groups=2, corruption_weights={"top": [0.1, 0.8, 0.1], "bottom": [0.2, 0.6, 0.2]}),
 ])
 def test_training_step_gradients_and_ema(cfgk):
     from oracle import vqvae_oracle as O
@@ -34,14 +37,19 @@ def test_training_step_gradients_and_ema(cfgk):
     # ---- oracle: autograd on CPU
     params = {k: v.clone().requires_grad_(not k.startswith("quantize_t.") and not k.startswith("quantize_b."))
               for k, v in sd.items()}
+    torch.manual_seed(77)     # the corruption offsets come from the CPU default generator on both sides
     dec, diff, id_t, id_b, (new_t, new_b) = O.forward_train(x, params, cfg)
     loss = torch.nn.functional.mse_loss(dec, x) + 0.25 * diff.mean()
     loss.backward()
+    if cfg.corruption_weights["top"] is not None:
+        clean = O.forward(x, sd, cfg)
+        assert (clean[4] != id_t).any() and (clean[5] != id_b).any()
     # ---- HIP path
     m = VQVAE(**cfgk)
     m.load_state_dict(sd)
     m = m.to(_dev()).train()
     xd = x.to(_dev())
+    torch.manual_seed(77)
     out, latent, perp_t, perp_b, it, ib = m(xd)
     assert out.requires_grad and latent.requires_grad
     assert torch.equal(it.cpu(), id_t) and torch.equal(ib.cpu(), id_b)

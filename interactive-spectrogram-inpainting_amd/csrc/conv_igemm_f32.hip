@@ -47,6 +47,8 @@ struct ConvKArgs {
   int convT;                 // 1: blockIdx.z = phase (py,px) of ConvTranspose2d(k4,s2,p1)
   int w_phase_stride;        // convT: floats between two phase weight matrices
   int dst_sh, dst_sw;        // convT: strides of the full output tensor (phase offset)
+  int nz;                    // plain conv, nz > 1: blockIdx.z = one of nz independent operand sets of the same shape
+  int zs_in0, zs_w, zs_res, zs_out;   // element strides between two sets (source 0, packed weight, residual, output)
 };
 
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, 16-B aligned, bank-conflict free
@@ -140,6 +142,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   const int pad_x = p.convT ? 1 - px : p.pad;
   const int w_off = p.convT ? (int)blockIdx.z * p.w_phase_stride : 0;
   const int out_off = p.convT ? py * p.dst_sh + px * p.dst_sw : 0;
+  // batched plain convolution: operand set blockIdx.z
+  const int zb = p.convT ? 0 : (int)blockIdx.z;
+  const float *in0 = p.in0 + (size_t)zb * p.zs_in0;
+  const float *wz = p.w + (size_t)zb * p.zs_w;
 
   // XCD-aware tile order: consecutive M tiles (neighbouring pixels, shared
   // halo rows) are given to one XCD so their re-reads hit that XCD's L2.
@@ -172,9 +178,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   const int lrow = tid >> 3;  // 0..31
   const int lq = tid & 7;     // quad inside the 32-wide K chunk
 
-  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in0), 0, p.in0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0), 0, p.in0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in1), 0, p.in1_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wz), 0, p.w_bytes, 0x00020000);
 
   // per staged A row: validity, top-left input coordinate, batch offsets (elements)
   int a_y0[RA], a_x0[RA], a_n0[RA], a_n1[RA];
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
           const bool ok = k1 < p.K && a_ok[j] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
           float t = 0.f;
           if (ok) {
-            if (c < p.C0) t = p.in0[a_n0[j] + c * p.s0c + iy * p.s0h + ix * p.s0w];
+            if (c < p.C0) t = in0[a_n0[j] + c * p.s0c + iy * p.s0h + ix * p.s0w];
             else t = p.in1[a_n1[j] + (c - p.C0) + iy * p.s1h + ix * p.s1w];
           }
           v[e] = t;
@@ -421,8 +427,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     row_ro[tid] = b < 0 ? 0 : b * p.rn + oy * p.rh + ox * p.rw;
   }
   __syncthreads();
-  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.in0), 0, p.res_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)zb * p.zs_out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res + (size_t)zb * p.zs_res : in0), 0, p.res_bytes, 0x00020000);
   const bool has_res = p.res != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -470,11 +476,11 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
       return check_launch("hipFuncSetAttribute(conv_igemm)");
     attr_set = true;
   }
-  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, nphase);
+  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, nphase > 1 ? nphase : std::max(a.nz, 1));
   {
     // algorithmic work: every MAC of the convolution once; input read once,
     // output written once, weights once (DESIGN.md "roofline accounting")
-    const double np = nphase;
+    const double np = nphase * (double)std::max(a.nz, 1);
     const double flops = 2.0 * a.M * np * a.Cout * a.K;
     const double in_px = nphase == 1 ? (double)a.M / (a.OH * a.OW) * a.H * a.W : (double)a.M;
     const double bytes = 4.0 * (in_px * a.Cin + (double)a.M * np * a.Cout * (a.res ? 2 : 1) +
@@ -521,6 +527,20 @@ constexpr int64_t kMaxElems = (int64_t)1 << 30;  // 4 GiB of fp32: 32-bit byte o
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                int KW, int stride, int pad, int relu, hipStream_t stream) {
+  return conv2d_batched_f32(s0, s1, packed_w, bias, res, dst, B, H, W, Cout, KH, KW, stride, pad, relu, 1, 0, 0, 0, 0,
+                            stream);
+}
+
+// nz independent convolutions of one shape in a single launch (grid z): set z reads source 0 at
+// ptr + z * zs_in0, the packed weight at packed_w + z * zs_w, the residual at + z * zs_res and writes
+// at dst + z * zs_out (element strides; the views describe one set).  One source only when nz > 1.
+int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
+                       const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
+                       int KW, int stride, int pad, int relu, int nz, int64_t zs_in0, int64_t zs_w,
+                       int64_t zs_res, int64_t zs_out, hipStream_t stream) {
+  if (nz < 1 || nz > 65535) return invalid("conv2d: bad batch count");
+  if (nz > 1 && s1 && s1->ptr) return unsupported("conv2d: batched launches take one source");
+  if (nz > 1 && ((zs_in0 | zs_w | zs_res | zs_out) & 3)) return invalid("conv2d: batch strides must be multiples of 4 floats");
   if (!s0 || !s0->ptr || !packed_w || !dst || !dst->ptr) return invalid("conv2d: null pointer");
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     return invalid("conv2d: bad shape");
@@ -536,8 +556,11 @@ int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, cons
   const int64_t er = (res && res->ptr) ? extent(B, res->sn, Cout, res->sc, OH, res->sh, OW, res->sw) : 1;
   if (e0 > kMaxElems || e1 > kMaxElems || eo > kMaxElems || er > kMaxElems)
     return unsupported("conv2d: a tensor spans 4 GiB or more");
+  const int64_t zmax = std::max(std::max(zs_in0, zs_w), std::max(zs_res, zs_out));
+  if (zmax < 0 || zmax >= ((int64_t)1 << 31)) return unsupported("conv2d: batch stride out of range");
   ConvKArgs a;
   memset(&a, 0, sizeof a);
+  a.nz = nz; a.zs_in0 = (int)zs_in0; a.zs_w = (int)zs_w; a.zs_res = (int)zs_res; a.zs_out = (int)zs_out;
   a.in0 = s0->ptr; a.C0 = s0->C; a.in0_bytes = (unsigned)(e0 * 4);
   a.s0n = (int)s0->sn; a.s0c = (int)s0->sc; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;
   a.in1 = two ? s1->ptr : s0->ptr;

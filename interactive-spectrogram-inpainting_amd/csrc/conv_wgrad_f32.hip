@@ -36,6 +36,7 @@ struct WgradKArgs {
   int H, W, OH, OW, Cout, K, Kpad, KW, stride, pad, M;
   int convT, dst_sh, dst_sw;   // transposed conv: phase offset into dY
   int nsplit, chunks_per_split;
+  int nz, zs_x0, zs_dy;        // nz > 1: blockIdx.z also enumerates nz independent (x, dY) pairs (element strides)
 };
 
 namespace {
@@ -55,14 +56,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
   const int co0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-  const int phase = blockIdx.z / p.nsplit, split = blockIdx.z - phase * p.nsplit;
+  const int per_z = (p.convT ? 4 : 1) * p.nsplit;
+  const int zb = (int)blockIdx.z / per_z, zrem = (int)blockIdx.z - zb * per_z;
+  const int phase = zrem / p.nsplit, split = zrem - phase * p.nsplit;
   const int py = p.convT ? phase >> 1 : 0, px = p.convT ? phase & 1 : 0;
   const int pad_y = p.convT ? 1 - py : p.pad, pad_x = p.convT ? 1 - px : p.pad;
   const int dy_off = p.convT ? py * p.dst_sh + px * p.dst_sw : 0;
+  const float *x0p = p.x0 + (size_t)zb * p.zs_x0, *x1p = p.x1 + (size_t)zb * p.zs_x0, *dyp = p.dy + (size_t)zb * p.zs_dy;
 
-  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x1), 0, p.x1_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x0p), 0, p.x0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x1p), 0, p.x1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dyp), 0, p.dy_bytes, 0x00020000);
 
   // staging role: pixel row tid/32 + 8j (j < 4), quad tid%32 of the 128-wide tile
   const int srow = tid >> 5, sq = tid & 31;
@@ -113,8 +117,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
               const int kh1 = tp / p.KW, kw1 = tp - kh1 * p.KW;
               const int iy1 = oy * p.stride - pad_y + kh1, ix1 = ox * p.stride - pad_x + kw1;
               if ((unsigned)iy1 < (unsigned)p.H && (unsigned)ix1 < (unsigned)p.W)
-                val = c1 < p.C0 ? p.x0[b * p.s0n + c1 * p.s0c + iy1 * p.s0h + ix1 * p.s0w]
-                                : p.x1[b * p.s1n + (c1 - p.C0) + iy1 * p.s1h + ix1 * p.s1w];
+                val = c1 < p.C0 ? x0p[b * p.s0n + c1 * p.s0c + iy1 * p.s0h + ix1 * p.s0w]
+                                : x1p[b * p.s1n + (c1 - p.C0) + iy1 * p.s1h + ix1 * p.s1w];
             }
             t[e] = val;
           }
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32_kernel(const WgradKArgs p)
         if (doff != OOB) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (co + e < p.Cout) t[e] = p.dy[(doff >> 2) + e];
+            if (co + e < p.Cout) t[e] = dyp[(doff >> 2) + e];
         }
         rdq[j] = make_float4(t[0], t[1], t[2], t[3]);
       }
@@ -242,14 +246,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
   const int co0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-  const int phase = blockIdx.z / p.nsplit, split = blockIdx.z - phase * p.nsplit;
+  const int per_z = (p.convT ? 4 : 1) * p.nsplit;
+  const int zb = (int)blockIdx.z / per_z, zrem = (int)blockIdx.z - zb * per_z;
+  const int phase = zrem / p.nsplit, split = zrem - phase * p.nsplit;
   const int py = p.convT ? phase >> 1 : 0, px = p.convT ? phase & 1 : 0;
   const int pad_y = p.convT ? 1 - py : p.pad, pad_x = p.convT ? 1 - px : p.pad;
   const int dy_off = p.convT ? py * p.dst_sh + px * p.dst_sw : 0;
+  const float *x0p = p.x0 + (size_t)zb * p.zs_x0, *x1p = p.x1 + (size_t)zb * p.zs_x0, *dyp = p.dy + (size_t)zb * p.zs_dy;
 
-  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x1), 0, p.x1_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x0p), 0, p.x0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x1p), 0, p.x1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dyp), 0, p.dy_bytes, 0x00020000);
 
   // staging role: pixel group pg (pixels 4 pg .. 4 pg + 3 of the 32-pixel chunk), channel quad sq
   const int pg = tid >> 5, sq = tid & 31;
@@ -390,8 +397,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
 // out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
                                                               float *__restrict__ out, int64_t n, int nsplit,
-                                                              int64_t stride, int accumulate) {
+                                                              int64_t stride, int accumulate, int64_t zs_partial,
+                                                              int64_t zs_out) {
   __shared__ float red[4][64];
+  partial += (size_t)blockIdx.y * zs_partial;   // grid y: independent reductions
+  out += (size_t)blockIdx.y * zs_out;
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + e;
   float s = 0.f;
@@ -410,13 +420,19 @@ static int64_t extent4(int64_t n, int64_t sn, int64_t c, int64_t sc, int64_t h, 
   return (n - 1) * sn + (c - 1) * sc + (h - 1) * sh + (w - 1) * sw + 1;
 }
 
-size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
-  const int Kpad = (int)round_up(K, kBK);
-  const int tiles = ((Cout + 127) / 128) * ((Kpad + 127) / 128) * nphase;
+static int wgrad_nsplit(int Cout, int Kpad, int M, int nphase, int nz) {
+  const int tiles = ((Cout + 127) / 128) * ((Kpad + 127) / 128) * nphase * nz;
   const int nchunks = (M + 31) / 32;
-  int nsplit = std::min(256, std::max(1, 768 / tiles));
-  nsplit = std::min(nsplit, std::max(1, nchunks / 8));
-  return (size_t)nsplit * nphase * Cout * Kpad + (size_t)nsplit * nphase * Cout;
+  const int nsplit = std::min(256, std::max(1, 768 / tiles));
+  return std::min(nsplit, std::max(1, nchunks / 8));
+}
+size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, int nz) {
+  const int Kpad = (int)round_up(K, kBK);
+  const int nsplit = wgrad_nsplit(Cout, Kpad, M, nphase, nz);
+  return (size_t)nz * ((size_t)nsplit * nphase * Cout * Kpad + (size_t)nsplit * nphase * Cout);
+}
+size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
+  return conv_wgrad_batched_workspace_floats(Cout, K, M, nphase, 1);
 }
 
 // dW packed like the forward weights: [nphase][Cout][Kpad].  x = layer input (two sources allowed), dy = gradient
@@ -424,7 +440,22 @@ size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
 int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                    float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                    int stride, int pad, int transposed, hipStream_t stream) {
+  return conv_wgrad_batched_f32(s0, s1, dy, dw_packed, db, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride,
+                                pad, transposed, 1, 0, 0, 0, stream);
+}
+
+// nz independent weight-gradient GEMMs of one shape in a single launch: pair z reads x at s0->ptr + z * zs_x0
+// and dY at dy + z * zs_dy and writes dw_packed + z * zs_dw (element strides).  One source, no bias when nz > 1.
+int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
+                           float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
+                           int stride, int pad, int transposed, int nz, int64_t zs_x0, int64_t zs_dy, int64_t zs_dw,
+                           hipStream_t stream) {
   if (!s0 || !s0->ptr || !dy || !dw_packed || !workspace) return invalid("conv_wgrad: null pointer");
+  if (nz < 1 || nz > 255) return invalid("conv_wgrad: bad batch count");
+  if (nz > 1 && ((s1 && s1->ptr) || db)) return unsupported("conv_wgrad: batched launches take one source and no bias");
+  if (nz > 1 && ((zs_x0 | zs_dy | zs_dw) & 3)) return invalid("conv_wgrad: batch strides must be multiples of 4 floats");
+  if (zs_x0 < 0 || zs_dy < 0 || zs_x0 >= ((int64_t)1 << 31) || zs_dy >= ((int64_t)1 << 31))
+    return unsupported("conv_wgrad: batch stride out of range");
   const int prec_flags = transposed & (ISI_CONV_BF16X3 | ISI_CONV_BF16X6);   // product mode rides in the flag word
   transposed &= 1;
   const bool two = s1 && s1->ptr;
@@ -468,12 +499,11 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
   } else {
     a.dn = OH * OW * Cout; a.dh = OW * Cout; a.dw = Cout;
   }
-  const int tiles = ((Cout + 127) / 128) * ((a.Kpad + 127) / 128) * nphase;
   const int nchunks = (a.M + 31) / 32;
-  int nsplit = std::min(256, std::max(1, 768 / tiles));
-  nsplit = std::min(nsplit, std::max(1, nchunks / 8));
+  const int nsplit = wgrad_nsplit(Cout, a.Kpad, a.M, nphase, nz);
   a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
-  const size_t need = (size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout;
+  a.nz = nz; a.zs_x0 = (int)zs_x0; a.zs_dy = (int)zs_dy;
+  const size_t need = (size_t)nz * ((size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout);
   if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
   a.db_partial = db ? workspace + (size_t)nsplit * nphase * Cout * a.Kpad : nullptr;
   constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
@@ -484,7 +514,7 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
       return check_launch("hipFuncSetAttribute(conv_wgrad)");
     attr_set = true;
   }
-  dim3 grid((Cout + 127) / 128, (a.Kpad + 127) / 128, nphase * nsplit);
+  dim3 grid((Cout + 127) / 128, (a.Kpad + 127) / 128, nz * nphase * nsplit);
   // split-bf16 products need the vectorised loaders (channels-last sources, Cout % 4 == 0)
   if (prec_flags && a.vec && a.dvec) {
     const int np = (prec_flags & ISI_CONV_BF16X6) ? 3 : 2;
@@ -498,15 +528,16 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
   if (rc) return rc;
   // partial layout: [phase][split][Cout][Kpad] -> out [phase][Cout][Kpad]
   const int64_t per = (int64_t)Cout * a.Kpad;
-  for (int ph = 0; ph < nphase; ++ph) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, stream,
-                       workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0);
+  for (int ph = 0; ph < nphase; ++ph) {   // grid y = operand set: partials [z][phase][split][Cout][Kpad]
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64), nz), dim3(256), 0, stream,
+                       workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0,
+                       (int64_t)nphase * nsplit * per, zs_dw);
   }
   rc = check_launch("reduce_partials");
   if (rc || !db) return rc;
   // bias gradient: every (phase, split) partial covers a disjoint pixel set
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cout + 63) / 64), dim3(256), 0, stream, a.db_partial, db,
-                     (int64_t)Cout, nsplit * nphase, (int64_t)Cout, 0);
+                     (int64_t)Cout, nsplit * nphase, (int64_t)Cout, 0, (int64_t)0, (int64_t)0);
   return check_launch("reduce_partials(bias)");
 }
 
@@ -543,7 +574,7 @@ int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, fl
   if (rc) return rc;
   const int64_t per = (int64_t)D * K;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, stream, workspace,
-                     embed_sum_dk, per, nsplit, per, 0);
+                     embed_sum_dk, per, nsplit, per, 0, (int64_t)0, (int64_t)0);
   return check_launch("vq_embed_sum(reduce)");
 }
 

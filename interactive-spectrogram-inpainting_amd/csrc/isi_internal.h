@@ -9,6 +9,10 @@ namespace isi {
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                int KW, int stride, int pad, int relu, hipStream_t stream);
+int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
+                       const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
+                       int KW, int stride, int pad, int relu, int nz, int64_t zs_in0, int64_t zs_w,
+                       int64_t zs_res, int64_t zs_out, hipStream_t stream);
 int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const float *bias,
                               const isi_dst *dst, int B, int H, int W, int Cout, int relu,
                               hipStream_t stream);
@@ -59,6 +63,11 @@ size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
 int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                    float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                    int stride, int pad, int transposed, hipStream_t stream);
+int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
+                           float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
+                           int stride, int pad, int transposed, int nz, int64_t zs_x0, int64_t zs_dy, int64_t zs_dw,
+                           hipStream_t stream);
+size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, int nz);
 size_t vq_embed_sum_workspace_floats(int D, int K, int64_t N);
 int relu_bwd_f32(float *dy, const float *y, int64_t n, hipStream_t st);
 int axpy_f32(float *a, const float *b, float alpha, int64_t n, hipStream_t st);

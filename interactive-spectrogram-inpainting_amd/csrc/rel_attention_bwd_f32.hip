@@ -27,6 +27,7 @@
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "prof.h"
+#include "split_bf16.h"
 
 namespace isi {
 
@@ -561,6 +562,693 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_kv_kernel(const AttnBwd
   }
 }
 
+// ================================================================== split-bf16 variants (fwd.precision = 1)
+// Same mathematics with every contraction on the bf16 matrix pipe as a three-term split product
+// (split_bf16.h) and fp32 everywhere else.  Layout of rel_attention_split_kernel (forward): workgroup =
+// 8 waves in two groups, a group per tile of the streamed pair; operands pre-split once per workgroup into
+// swizzled hi/lo bf16 planes in LDS -- row planes [row][HD] where the contraction runs over the head dim,
+// transposed planes [d][32 rows] where it runs over the streamed rows; band of e in a 192-row ring.  The
+// skew buffer holds 32 columns and the (up to) 64-column band is skewed in two passes, which is what lets
+// all of this fit 160 KB.
+namespace {
+constexpr int RING_S = 192, BAND2_S = 192, SRL = 33;
+__device__ __forceinline__ int ring_s(int r) {
+  r %= RING_S;
+  return r < 0 ? r + RING_S : r;
+}
+}  // namespace
+
+// ------------------------------------------------------------------ dQ and G (split)
+template <int HD>
+__global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const AttnBwdKArgs p) {
+  constexpr int NKB = HD / 16, NSL = HD / 8, RPB = 128 / HD, NDB = (HD + 31) / 32, VR = NDB * 32;
+  constexpr int NQD = HD / 4, NKQ = (HD / 4 + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short *Kp = reinterpret_cast<unsigned short *>(smem);   // [tile 2][plane 2][32][HD]   K rows
+  unsigned short *Ktp = Kp + 2 * 2 * 32 * HD;                      // [tile 2][plane 2][VR][32]   K transposed
+  unsigned short *Vp = Ktp + 2 * 2 * VR * 32;                      // [tile 2][plane 2][32][HD]   V rows
+  unsigned short *Ep = Vp + 2 * 2 * 32 * HD;                       // [plane 2][RING_S][HD]
+  float *Sr = reinterpret_cast<float *>(Ep + 2 * RING_S * HD);     // [8][32][SRL]
+  int *evk = reinterpret_cast<int *>(Sr + 8 * 32 * SRL);           // [2][32]
+  auto swz = [](int row, int slot) { return (slot ^ ((row / RPB) % NSL)) * 8; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int qblk = p.mask_mode == 1 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int q0 = qblk * QB, qw0 = q0 + 32 * wq, qi = qw0 + ql;
+  const bool has_e = p.e != nullptr;
+
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.v), 0, p.v_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dout), 0, p.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_e ? p.e : p.q), 0, has_e ? p.e_bytes : 4u, 0x00020000);
+
+  // Q and dO fragments of this lane's query, split once: k-block t holds dims 16 t + 8 half + 0..7
+  s16x8_t qh[NKB], qlo[NKB], doh[NKB], dol[NKB];
+#pragma unroll
+  for (int t = 0; t < NKB; ++t) {
+    const bool ok = qi < p.Sq;
+    const unsigned oq = ok ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + 16 * t + 8 * half) * 4u : OOB;
+    const unsigned od = ok ? (unsigned)(qi * p.o_ss + b * p.o_sb + h * p.o_sh + 16 * t + 8 * half) * 4u : OOB;
+    uint2 h0, l0, h1, l1;
+    split_f4(buf_load4(rq, oq), h0, l0);
+    split_f4(buf_load4(rq, ok ? oq + 16u : OOB), h1, l1);
+    qh[t] = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    qlo[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    split_f4(buf_load4(rdo, od), h0, l0);
+    split_f4(buf_load4(rdo, ok ? od + 16u : OOB), h1, l1);
+    doh[t] = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    dol[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+  }
+  const int stat = (b * p.H + h) * p.Sq + qi;
+  const float lse2 = (qi < p.Sq ? p.lse[stat] : 0.f) * LOG2E;
+  const float dsum_i = qi < p.Sq ? p.dsum[stat] : 0.f;
+  const int evq = qi / p.Cq;
+  const int evq_w0 = qw0 / p.Cq, evq_b0 = q0 / p.Cq;
+
+  f32x16 dQ[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dQ[d][r] = 0.f;
+
+  int k_begin = 0, k_end = p.Sk;
+  if (p.mask_mode == 1) k_end = min(p.Sk, q0 + QB);
+  if (p.mask_mode == 2) k_begin = (q0 / 32) * 32;
+
+  // staging roles: a 4 keys x 4 dims block of K (threads [0, 256)) or V ([256, 512)); band row 32 st + srow
+  const int kind = tid >> 8, bidx = tid & 255;
+  const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);
+  const bool blk_on = btile < 2;
+  const int st = tid >> 8, srow = (tid >> 3) & 31, squad = tid & 7;
+  float *gbase = p.g + ((size_t)h * p.B + b) * p.Sq * p.Rp;
+  float4 pb[4], pe[NKQ];
+  auto band0 = [&](int k) { return evq_b0 - (k + 31) / p.Ck + p.Ek - 1; };
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kj = k0 + 32 * btile + 4 * bkg + j;
+      const bool ok = blk_on && kj < p.Sk;
+      const unsigned ko = (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + bqd * 4) * 4u;
+      const unsigned vo = (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + bqd * 4) * 4u;
+      pb[j] = kind == 0 ? buf_load4(rk, ok ? ko : OOB) : buf_load4(rv, ok ? vo : OOB);
+    }
+    const int r = band0(k0 + 32) + 32 * st + srow;
+    const bool rok = has_e && r >= 0 && r < p.R;
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+    }
+  };
+  auto put_e = [&](int slot, int qd, const float4 v) {
+    uint2 hi, lo;
+    split_f4(v, hi, lo);
+    const int o = slot * HD + swz(slot, qd >> 1) + (qd & 1) * 4;
+    *reinterpret_cast<uint2 *>(Ep + o) = hi;
+    *reinterpret_cast<uint2 *>(Ep + o + RING_S * HD) = lo;
+  };
+  auto commit = [&](int k0) {
+    if (blk_on) {
+      unsigned short *rows = (kind == 0 ? Kp : Vp) + (btile * 2) * 32 * HD;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {   // row planes: 8 bytes (4 dims) per key
+        const int row = 4 * bkg + j;
+        uint2 hi, lo;
+        split_f4(pb[j], hi, lo);
+        const int o = row * HD + swz(row, bqd >> 1) + (bqd & 1) * 4;
+        *reinterpret_cast<uint2 *>(rows + o) = hi;
+        *reinterpret_cast<uint2 *>(rows + o + 32 * HD) = lo;
+      }
+      if (kind == 0) {                // K transposed: per dim the block's 4 keys as one 8-byte unit
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int d = 4 * bqd + e;
+          uint2 hi, lo;
+          split2(elem(pb[0], e), elem(pb[1], e), hi.x, lo.x);
+          split2(elem(pb[2], e), elem(pb[3], e), hi.y, lo.y);
+          const int o = ((btile * 2) * VR + d) * 32 + ((bkg ^ ((d >> 2) & 7)) * 4);
+          *reinterpret_cast<uint2 *>(Ktp + o) = hi;
+          *reinterpret_cast<uint2 *>(Ktp + o + VR * 32) = lo;
+        }
+      }
+    }
+    if (has_e) {
+      const int slot = ring_s(band0(k0 + 32) + 32 * st + srow);
+#pragma unroll
+      for (int i = 0; i < NKQ; ++i)
+        if (squad + 8 * i < NQD) put_e(slot, squad + 8 * i, pe[i]);
+    }
+    if (tid < 64) {
+      const int kt = k0 + (tid & 32);
+      evk[tid] = (kt + 31) / p.Ck - (kt + (tid & 31)) / p.Ck;
+    }
+  };
+
+  if (VR > HD) {
+    for (int i = tid; i < 2 * 2 * VR * 32 / 2; i += 512) reinterpret_cast<unsigned *>(Ktp)[i] = 0u;
+    __syncthreads();
+  }
+  if (k_begin < k_end) {
+    prefetch(k_begin);
+    commit(k_begin);
+    if (has_e) {
+      const int rb = band0(k_begin + 32);
+      for (int row = 64 + (tid >> 3); row < BAND2_S; row += 64) {
+        const int r = rb + row;
+        const bool ok = r >= 0 && r < p.R;
+        const int slot = ring_s(r);
+        for (int qd = squad; qd < NQD; qd += 8)
+          put_e(slot, qd, buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB));
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  const float scale2 = p.scale * LOG2E;
+  const unsigned short *Kb = Kp + (grp * 2) * 32 * HD, *Ktb = Ktp + (grp * 2) * VR * 32, *Vb = Vp + (grp * 2) * 32 * HD;
+  const int *evkb = evk + grp * 32;
+  float *sr = Sr + wave * 32 * SRL + ql * SRL;
+  float *tb = Sr + wave * 32 * SRL;
+  const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
+
+  for (int kp = k_begin; kp < k_end; kp += 64) {
+    const bool more = kp + 64 < k_end;
+    if (more) prefetch(kp + 64);
+    const int k0 = kp + 32 * grp;
+    const int rb = band0(k0);
+
+    bool live = qw0 < p.Sq && k0 < k_end;
+    if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
+    if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
+    if (live) {  // wave-uniform
+      // ---- S^T = K Q^T
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NKB; ++t) {
+        const int o = ql * HD + swz(ql, 2 * t + half);
+        const s16x8_t kh = *reinterpret_cast<const s16x8_t *>(Kb + o);
+        const s16x8_t kl = *reinterpret_cast<const s16x8_t *>(Kb + o + 32 * HD);
+        acc = ISI_MFB(kl, qh[t], acc);
+        acc = ISI_MFB(kh, qlo[t], acc);
+        acc = ISI_MFB(kh, qh[t], acc);
+      }
+      float sv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = acc[r];
+
+      // ---- relative logits: band GEMM, skewed through LDS 32 columns at a time
+      if (has_e) {
+        const int wrow0 = rb + evq_w0 - evq_b0;
+        const int dq = evq - evq_w0;
+        for (int tbi = 0; tbi < nt; ++tbi) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const int slot = ring_s(wrow0 + 32 * tbi + ql);
+#pragma unroll
+          for (int t = 0; t < NKB; ++t) {
+            const int o = slot * HD + swz(slot, 2 * t + half);
+            const s16x8_t eh = *reinterpret_cast<const s16x8_t *>(Ep + o);
+            const s16x8_t el = *reinterpret_cast<const s16x8_t *>(Ep + o + RING_S * HD);
+            acc = ISI_MFB(el, qh[t], acc);
+            acc = ISI_MFB(eh, qlo[t], acc);
+            acc = ISI_MFB(eh, qh[t], acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sr[mfma_row(r, half)] = acc[r];
+          wave_lds_sync();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = dq + evkb[mfma_row(r, half)] - 32 * tbi;
+            const float v = sr[idx & 31];
+            sv[r] += (unsigned)idx < 32u ? v : 0.f;
+          }
+          wave_lds_sync();
+        }
+      }
+
+      // ---- P
+      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < p.Sq;
+      if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
+      if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(sv[r] * scale2 - lse2);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kj = k0 + mfma_row(r, half);
+          bool ok = kj < p.Sk && qi < p.Sq;
+          if (p.mask_mode == 1) ok = ok && kj <= qi;
+          if (p.mask_mode == 2) ok = ok && kj >= qi;
+          float s = sv[r] * scale2;
+          if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          sv[r] = ok ? __builtin_amdgcn_exp2f(s - lse2) : 0.f;
+        }
+      }
+      // ---- dP^T = V dO^T ;  dS = P (dP - D) scale
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NKB; ++t) {
+        const int o = ql * HD + swz(ql, 2 * t + half);
+        const s16x8_t vh = *reinterpret_cast<const s16x8_t *>(Vb + o);
+        const s16x8_t vl = *reinterpret_cast<const s16x8_t *>(Vb + o + 32 * HD);
+        acc = ISI_MFB(vl, doh[t], acc);
+        acc = ISI_MFB(vh, dol[t], acc);
+        acc = ISI_MFB(vh, doh[t], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sv[r] * (acc[r] - dsum_i) * p.scale;
+
+      // ---- dQ^T += K^T dS^T
+      s16x8_t sh[2], sl[2];
+      split_acc16(sv, sh, sl);
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const int drow = d * 32 + ql;
+        const int sx = (drow >> 2) & 7;
+        const unsigned short *kr = Ktb + drow * 32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint2 h0 = *reinterpret_cast<const uint2 *>(kr + (((4 * t + half) ^ sx) * 4));
+          const uint2 h1 = *reinterpret_cast<const uint2 *>(kr + (((4 * t + 2 + half) ^ sx) * 4));
+          const uint2 l0 = *reinterpret_cast<const uint2 *>(kr + VR * 32 + (((4 * t + half) ^ sx) * 4));
+          const uint2 l1 = *reinterpret_cast<const uint2 *>(kr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
+          const s16x8_t kth = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+          const s16x8_t ktl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+          dQ[d] = ISI_MFB(ktl, sh[t], dQ[d]);
+          dQ[d] = ISI_MFB(kth, sl[t], dQ[d]);
+          dQ[d] = ISI_MFB(kth, sh[t], dQ[d]);
+        }
+      }
+
+      // ---- G[i, r(i,j)] += dS[i,j]: transpose through LDS so that lanes run along the keys of one query
+      if (has_e) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tb[mfma_row(r, half) * SRL + ql] = sv[r];
+        wave_lds_sync();
+        const int kev = (k0 + ql) / p.Ck;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int qq = 2 * it + half;
+          const float val = tb[ql * SRL + qq];
+          const int q = qw0 + qq;
+          const int rho = q / p.Cq - kev + p.Ek - 1;
+          const int col = rho - p.rho_lo;
+          if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp)
+            unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);
+        }
+        wave_lds_sync();
+      }
+    }
+    __syncthreads();
+    if (more) commit(kp + 64);
+    __syncthreads();
+  }
+
+  // ---- add the two groups' partial dQ (group 1 -> LDS -> group 0) and store
+  float *mg = smem;
+  constexpr int MGW = NDB * 16 * 64;
+  if (grp == 1) {
+    float *dst = mg + wq * MGW + lane;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(d * 16 + r) * 64] = dQ[d][r];
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  if (qi < p.Sq) {
+    const float *src = mg + wq * MGW + lane;
+    float *orow = p.dq + (size_t)qi * p.q_ss + (size_t)b * p.q_sb + (size_t)h * p.q_sh;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * half;
+        if (dd < HD)
+          *reinterpret_cast<float4 *>(orow + dd) =
+              make_float4(dQ[d][4 * g] + src[(d * 16 + 4 * g) * 64], dQ[d][4 * g + 1] + src[(d * 16 + 4 * g + 1) * 64],
+                          dQ[d][4 * g + 2] + src[(d * 16 + 4 * g + 2) * 64], dQ[d][4 * g + 3] + src[(d * 16 + 4 * g + 3) * 64]);
+      }
+  }
+}
+
+// ------------------------------------------------------------------ dK and dV (split)
+// Key-stationary: wave wq of either group owns keys k0b + 32 wq .. + 31 (K, V fragments split once, in
+// registers as B operands; dK^T / dV^T in accumulators); group g walks the query tiles of parity g and the
+// two partial results are added at the end.  Q and dO tiles are staged as row planes (S = Q K^T,
+// dP = dO V^T, U = Q E^T contract over the head dim) AND transposed planes (dV^T += dO^T P,
+// dK^T += Q^T dS contract over the queries).
+template <int HD>
+__global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const AttnBwdKArgs p) {
+  constexpr int NKB = HD / 16, NSL = HD / 8, RPB = 128 / HD, NDB = (HD + 31) / 32, VR = NDB * 32;
+  constexpr int NQD = HD / 4, NKQ = (HD / 4 + 7) / 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short *Qp = reinterpret_cast<unsigned short *>(smem);   // [tile 2][plane 2][32][HD]   Q rows
+  unsigned short *Qtp = Qp + 2 * 2 * 32 * HD;                      // [tile 2][plane 2][VR][32]   Q transposed
+  unsigned short *Gp = Qtp + 2 * 2 * VR * 32;                      // dO rows
+  unsigned short *Gtp = Gp + 2 * 2 * 32 * HD;                      // dO transposed
+  unsigned short *Ep = Gtp + 2 * 2 * VR * 32;                      // [plane 2][RING_S][HD]
+  float *Sr = reinterpret_cast<float *>(Ep + 2 * RING_S * HD);     // [8][32][SRL]
+  float *lse_s = Sr + 8 * 32 * SRL;                                // [2][32]  (base 2)
+  float *dsum_s = lse_s + 64;                                      // [2][32]
+  int *evq_s = reinterpret_cast<int *>(dsum_s + 64);               // [2][32] event(query) - first event of the tile
+  auto swz = [](int row, int slot) { return (slot ^ ((row / RPB) % NSL)) * 8; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave >> 2, wq = wave & 3;
+  const int ql = lane & 31, half = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int kblk = p.mask_mode == 2 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int k0b = kblk * QB, kw0 = k0b + 32 * wq, kj = kw0 + ql;
+  const bool has_e = p.e != nullptr;
+
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.v), 0, p.v_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dout), 0, p.o_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_e ? p.e : p.q), 0, has_e ? p.e_bytes : 4u, 0x00020000);
+
+  s16x8_t kh[NKB], kl[NKB], vh[NKB], vl[NKB];
+#pragma unroll
+  for (int t = 0; t < NKB; ++t) {
+    const bool ok = kj < p.Sk;
+    const unsigned ok_ = ok ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + 16 * t + 8 * half) * 4u : OOB;
+    const unsigned ov = ok ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + 16 * t + 8 * half) * 4u : OOB;
+    uint2 h0, l0, h1, l1;
+    split_f4(buf_load4(rk, ok_), h0, l0);
+    split_f4(buf_load4(rk, ok ? ok_ + 16u : OOB), h1, l1);
+    kh[t] = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    kl[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    split_f4(buf_load4(rv, ov), h0, l0);
+    split_f4(buf_load4(rv, ok ? ov + 16u : OOB), h1, l1);
+    vh[t] = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    vl[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+  }
+  const int evk_max_b = (k0b + QB - 1) / p.Ck, evk_max_w = (kw0 + 31) / p.Ck;
+  const int dkv = evk_max_w - kj / p.Ck;     // >= 0
+  const int wrow0 = evk_max_b - evk_max_w;   // this wave's first band row (relative to the tile's band)
+
+  f32x16 dK[NDB], dV[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dK[d][r] = 0.f; dV[d][r] = 0.f; }
+
+  int q_begin = 0, q_end = p.Sq;
+  if (p.mask_mode == 1) q_begin = (k0b / 32) * 32;          // j <= i
+  if (p.mask_mode == 2) q_end = min(p.Sq, k0b + QB);        // j >= i
+
+  // staging roles: a 4 queries x 4 dims block of Q (threads [0, 256)) or dO ([256, 512)); band row 32 st + srow
+  const int kind = tid >> 8, bidx = tid & 255;
+  const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);
+  const bool blk_on = btile < 2;
+  const int st = tid >> 8, srow = (tid >> 3) & 31, squad = tid & 7;
+  const int statb = (b * p.H + h) * p.Sq;
+  float4 pb[4], pe[NKQ];
+  float plse = 0.f, pdsum = 0.f;
+  // first table row of the band of the query tile that starts at q
+  auto band0 = [&](int q) { return q / p.Cq - evk_max_b + p.Ek - 1; };
+  auto prefetch = [&](int q0) {  // Q / dO blocks of the pair at q0 and the 64 highest rows of its band
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int qj = q0 + 32 * btile + 4 * bkg + j;
+      const bool ok = blk_on && qj < p.Sq;
+      const unsigned qo = (unsigned)(qj * p.q_ss + b * p.q_sb + h * p.q_sh + bqd * 4) * 4u;
+      const unsigned go = (unsigned)(qj * p.o_ss + b * p.o_sb + h * p.o_sh + bqd * 4) * 4u;
+      pb[j] = kind == 0 ? buf_load4(rq, ok ? qo : OOB) : buf_load4(rdo, ok ? go : OOB);
+    }
+    const int r = band0(q0) + (BAND2_S - 64) + 32 * st + srow;
+    const bool rok = has_e && r >= 0 && r < p.R;
+#pragma unroll
+    for (int i = 0; i < NKQ; ++i) {
+      const int qd = squad + 8 * i;
+      pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+    }
+    if (tid < 64) {
+      const int q = q0 + tid;
+      plse = q < p.Sq ? p.lse[statb + q] : 0.f;
+      pdsum = q < p.Sq ? p.dsum[statb + q] : 0.f;
+    }
+  };
+  auto put_e = [&](int slot, int qd, const float4 v) {
+    uint2 hi, lo;
+    split_f4(v, hi, lo);
+    const int o = slot * HD + swz(slot, qd >> 1) + (qd & 1) * 4;
+    *reinterpret_cast<uint2 *>(Ep + o) = hi;
+    *reinterpret_cast<uint2 *>(Ep + o + RING_S * HD) = lo;
+  };
+  auto commit = [&](int q0) {
+    if (blk_on) {
+      unsigned short *rows = (kind == 0 ? Qp : Gp) + (btile * 2) * 32 * HD;
+      unsigned short *cols = (kind == 0 ? Qtp : Gtp) + (btile * 2) * VR * 32;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = 4 * bkg + j;
+        uint2 hi, lo;
+        split_f4(pb[j], hi, lo);
+        const int o = row * HD + swz(row, bqd >> 1) + (bqd & 1) * 4;
+        *reinterpret_cast<uint2 *>(rows + o) = hi;
+        *reinterpret_cast<uint2 *>(rows + o + 32 * HD) = lo;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = 4 * bqd + e;
+        uint2 hi, lo;
+        split2(elem(pb[0], e), elem(pb[1], e), hi.x, lo.x);
+        split2(elem(pb[2], e), elem(pb[3], e), hi.y, lo.y);
+        const int o = d * 32 + ((bkg ^ ((d >> 2) & 7)) * 4);
+        *reinterpret_cast<uint2 *>(cols + o) = hi;
+        *reinterpret_cast<uint2 *>(cols + o + VR * 32) = lo;
+      }
+    }
+    if (has_e) {
+      const int slot = ring_s(band0(q0) + (BAND2_S - 64) + 32 * st + srow);
+#pragma unroll
+      for (int i = 0; i < NKQ; ++i)
+        if (squad + 8 * i < NQD) put_e(slot, squad + 8 * i, pe[i]);
+    }
+    if (tid < 64) {
+      const int qt = q0 + (tid & 32);
+      lse_s[tid] = plse * LOG2E;
+      dsum_s[tid] = pdsum;
+      evq_s[tid] = (q0 + tid) / p.Cq - qt / p.Cq;
+    }
+  };
+
+  if (VR > HD) {
+    for (int i = tid; i < 2 * 2 * VR * 32 / 2; i += 512) {
+      reinterpret_cast<unsigned *>(Qtp)[i] = 0u;
+      reinterpret_cast<unsigned *>(Gtp)[i] = 0u;
+    }
+    __syncthreads();
+  }
+  if (q_begin < q_end) {
+    prefetch(q_begin);
+    commit(q_begin);
+    if (has_e) {
+      const int rb = band0(q_begin);
+      for (int row = tid >> 3; row < BAND2_S - 64; row += 64) {
+        const int r = rb + row;
+        const bool ok = r >= 0 && r < p.R;
+        const int slot = ring_s(r);
+        for (int qd = squad; qd < NQD; qd += 8)
+          put_e(slot, qd, buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB));
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  const float scale2 = p.scale * LOG2E;
+  const unsigned short *Qb = Qp + (grp * 2) * 32 * HD, *Qtb = Qtp + (grp * 2) * VR * 32;
+  const unsigned short *Gb = Gp + (grp * 2) * 32 * HD, *Gtb = Gtp + (grp * 2) * VR * 32;
+  const float *lseb = lse_s + grp * 32, *dsumb = dsum_s + grp * 32;
+  const int *evqb = evq_s + grp * 32;
+  float *sw = Sr + wave * 32 * SRL;
+  const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
+
+  for (int qp = q_begin; qp < q_end; qp += 64) {
+    const bool more = qp + 64 < q_end;
+    if (more) prefetch(qp + 64);
+    const int q0 = qp + 32 * grp;
+    const int rb = band0(q0);
+
+    bool live = kw0 < p.Sk && q0 < q_end;
+    if (p.mask_mode == 1) live = live && q0 + 31 >= kw0;
+    if (p.mask_mode == 2) live = live && q0 <= kw0 + 31;
+    if (live) {  // wave-uniform
+      // ---- S = Q K^T  (rows = queries, this lane's column = its key)
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NKB; ++t) {
+        const int o = ql * HD + swz(ql, 2 * t + half);
+        const s16x8_t qfh = *reinterpret_cast<const s16x8_t *>(Qb + o);
+        const s16x8_t qfl = *reinterpret_cast<const s16x8_t *>(Qb + o + 32 * HD);
+        acc = ISI_MFB(qfl, kh[t], acc);
+        acc = ISI_MFB(qfh, kl[t], acc);
+        acc = ISI_MFB(qfh, kh[t], acc);
+      }
+      float sv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = acc[r];
+
+      if (has_e) {
+        // U = Q E_band^T : rows = queries, columns = band rows; entry (i, j) sits at column
+        // (event(i) - first event of the tile) + (last event of the wave's keys - event(j))
+        for (int tbi = 0; tbi < nt; ++tbi) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          const int slot = ring_s(rb + wrow0 + 32 * tbi + ql);
+#pragma unroll
+          for (int t = 0; t < NKB; ++t) {
+            const int o = slot * HD + swz(slot, 2 * t + half);
+            const int oq = ql * HD + swz(ql, 2 * t + half);
+            const s16x8_t eh = *reinterpret_cast<const s16x8_t *>(Ep + o);
+            const s16x8_t el = *reinterpret_cast<const s16x8_t *>(Ep + o + RING_S * HD);
+            const s16x8_t qfh = *reinterpret_cast<const s16x8_t *>(Qb + oq);
+            const s16x8_t qfl = *reinterpret_cast<const s16x8_t *>(Qb + oq + 32 * HD);
+            acc = ISI_MFB(qfl, eh, acc);
+            acc = ISI_MFB(qfh, el, acc);
+            acc = ISI_MFB(qfh, eh, acc);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sw[mfma_row(r, half) * SRL + ql] = acc[r];
+          wave_lds_sync();
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = evqb[mfma_row(r, half)] + dkv - 32 * tbi;
+            const float v = sw[mfma_row(r, half) * SRL + (idx & 31)];
+            sv[r] += (unsigned)idx < 32u ? v : 0.f;
+          }
+          wave_lds_sync();
+        }
+      }
+
+      // ---- P
+      bool full = !p.mask && kw0 + 31 < p.Sk && q0 + 31 < p.Sq;
+      if (p.mask_mode == 1) full = full && kw0 + 31 <= q0;
+      if (p.mask_mode == 2) full = full && kw0 >= q0 + 31;
+      if (full) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(sv[r] * scale2 - lseb[mfma_row(r, half)]);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qrow = mfma_row(r, half);
+          const int qi = q0 + qrow;
+          bool ok = kj < p.Sk && qi < p.Sq;
+          if (p.mask_mode == 1) ok = ok && kj <= qi;
+          if (p.mask_mode == 2) ok = ok && kj >= qi;
+          float s = sv[r] * scale2;
+          if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          sv[r] = ok ? __builtin_amdgcn_exp2f(s - lseb[qrow]) : 0.f;
+        }
+      }
+      // ---- dV^T += dO^T P   (A = dO transposed, k-slots = queries in accumulator order)
+      s16x8_t sh[2], sl[2];
+      split_acc16(sv, sh, sl);
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const int drow = d * 32 + ql;
+        const int sx = (drow >> 2) & 7;
+        const unsigned short *gr = Gtb + drow * 32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint2 h0 = *reinterpret_cast<const uint2 *>(gr + (((4 * t + half) ^ sx) * 4));
+          const uint2 h1 = *reinterpret_cast<const uint2 *>(gr + (((4 * t + 2 + half) ^ sx) * 4));
+          const uint2 l0 = *reinterpret_cast<const uint2 *>(gr + VR * 32 + (((4 * t + half) ^ sx) * 4));
+          const uint2 l1 = *reinterpret_cast<const uint2 *>(gr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
+          const s16x8_t gh = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+          const s16x8_t gl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+          dV[d] = ISI_MFB(gl, sh[t], dV[d]);
+          dV[d] = ISI_MFB(gh, sl[t], dV[d]);
+          dV[d] = ISI_MFB(gh, sh[t], dV[d]);
+        }
+      }
+      // ---- dP = dO V^T ;  dS = P (dP - D) scale
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < NKB; ++t) {
+        const int o = ql * HD + swz(ql, 2 * t + half);
+        const s16x8_t gh = *reinterpret_cast<const s16x8_t *>(Gb + o);
+        const s16x8_t gl = *reinterpret_cast<const s16x8_t *>(Gb + o + 32 * HD);
+        acc = ISI_MFB(gl, vh[t], acc);
+        acc = ISI_MFB(gh, vl[t], acc);
+        acc = ISI_MFB(gh, vh[t], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sv[r] = sv[r] * (acc[r] - dsumb[mfma_row(r, half)]) * p.scale;
+      // ---- dK^T += Q^T dS
+      split_acc16(sv, sh, sl);
+#pragma unroll
+      for (int d = 0; d < NDB; ++d) {
+        const int drow = d * 32 + ql;
+        const int sx = (drow >> 2) & 7;
+        const unsigned short *qr = Qtb + drow * 32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint2 h0 = *reinterpret_cast<const uint2 *>(qr + (((4 * t + half) ^ sx) * 4));
+          const uint2 h1 = *reinterpret_cast<const uint2 *>(qr + (((4 * t + 2 + half) ^ sx) * 4));
+          const uint2 l0 = *reinterpret_cast<const uint2 *>(qr + VR * 32 + (((4 * t + half) ^ sx) * 4));
+          const uint2 l1 = *reinterpret_cast<const uint2 *>(qr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
+          const s16x8_t qth = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
+          const s16x8_t qtl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+          dK[d] = ISI_MFB(qtl, sh[t], dK[d]);
+          dK[d] = ISI_MFB(qth, sl[t], dK[d]);
+          dK[d] = ISI_MFB(qth, sh[t], dK[d]);
+        }
+      }
+    }
+    __syncthreads();
+    if (more) commit(qp + 64);
+    __syncthreads();
+  }
+
+  // ---- add the two groups' partial results (group 1 -> LDS -> group 0) and store
+  float *mg = smem;
+  constexpr int MGW = 2 * NDB * 16 * 64;
+  if (grp == 1) {
+    float *dst = mg + wq * MGW + lane;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        dst[(d * 16 + r) * 64] = dK[d][r];
+        dst[((NDB + d) * 16 + r) * 64] = dV[d][r];
+      }
+  }
+  __syncthreads();
+  if (grp == 1) return;
+  if (kj < p.Sk) {
+    const float *src = mg + wq * MGW + lane;
+    float *krow = p.dk + (size_t)kj * p.k_ss + (size_t)b * p.k_sb + (size_t)h * p.k_sh;
+    float *vrow = p.dv + (size_t)kj * p.v_ss + (size_t)b * p.v_sb + (size_t)h * p.v_sh;
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = d * 32 + 8 * g + 4 * half;
+        if (dd < HD) {
+          const float *sk = src + (d * 16 + 4 * g) * 64, *sv_ = src + ((NDB + d) * 16 + 4 * g) * 64;
+          *reinterpret_cast<float4 *>(krow + dd) = make_float4(dK[d][4 * g] + sk[0], dK[d][4 * g + 1] + sk[64],
+                                                               dK[d][4 * g + 2] + sk[128], dK[d][4 * g + 3] + sk[192]);
+          *reinterpret_cast<float4 *>(vrow + dd) = make_float4(dV[d][4 * g] + sv_[0], dV[d][4 * g + 1] + sv_[64],
+                                                               dV[d][4 * g + 2] + sv_[128], dV[d][4 * g + 3] + sv_[192]);
+        }
+      }
+  }
+}
+
 // packed GEMM operand of one head's table rows [lo, lo + n), transposed: w[d][c] = e[h][lo + c][d], zero padded to Kpad
 __global__ void pack_rel_T_kernel(const float *__restrict__ e, float *__restrict__ out, int H, int R, int HD,
                                   int Kpad, int lo, int n) {
@@ -611,7 +1299,7 @@ BwdLayout bwd_layout(int B, int H, int Sq, int R, int HD) {   // R = number of t
     L.g = take((size_t)H * B * Sq * L.Rp);
     L.wT = take((size_t)H * HD * round_up((size_t)L.Rp, kBK));
     L.dw = take((size_t)H * L.Rp * L.Kp);
-    L.wg_floats = conv_wgrad_workspace_floats(L.Rp, HD, B * Sq, 1);
+    L.wg_floats = conv_wgrad_batched_workspace_floats(L.Rp, HD, B * Sq, 1, H);
     L.wg = take(L.wg_floats);
   } else {
     L.g = L.wT = L.dw = L.wg = 0; L.wg_floats = 0;
@@ -629,6 +1317,38 @@ size_t rel_attention_bwd_workspace_floats(const isi_attn_args *g) {
   int lo = 0, n = 0;
   if (g->rel_embeddings && g->rel_rows > 0) rho_range(g, &lo, &n);
   return bwd_layout(g->B, g->H, g->Sq, n, g->head_dim).total;
+}
+
+template <int HD>
+static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
+  auto kq = rel_attention_bwd_q_split_kernel<HD>;
+  auto kkv = rel_attention_bwd_kv_split_kernel<HD>;
+  constexpr int VR = ((HD + 31) / 32) * 32;
+  constexpr size_t smem_q = (size_t)(2 * (2 * 2 * 32 * HD) + 2 * 2 * VR * 32 + 2 * RING_S * HD) * sizeof(unsigned short) +
+                            (size_t)(8 * 32 * SRL + 64) * sizeof(float);
+  constexpr size_t smem_kv = (size_t)(2 * (2 * 2 * 32 * HD) + 2 * (2 * 2 * VR * 32) + 2 * RING_S * HD) * sizeof(unsigned short) +
+                             (size_t)(8 * 32 * SRL + 192) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(rel_attention_bwd_split)");
+    attr_set = true;
+  }
+  const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * a.B;
+  {
+    prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 5 : 4),
+                      4.0 * a.B * a.H * HD * (3.0 * a.Sq + 4.0 * a.Sk), stream);
+    hipLaunchKernelGGL(kkv, dim3((a.Sk + QB - 1) / QB, a.H, a.B), dim3(512), smem_kv, stream, a);
+  }
+  int rc = check_launch("rel_attention_bwd_kv_split");
+  if (rc) return rc;
+  {
+    prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 4 : 3),
+                      4.0 * a.B * a.H * HD * (3.0 * a.Sq + 2.0 * a.Sk), stream);
+    hipLaunchKernelGGL(kq, dim3((a.Sq + QB - 1) / QB, a.H, a.B), dim3(512), smem_q, stream, a);
+  }
+  return check_launch("rel_attention_bwd_q_split");
 }
 
 template <int HD>
@@ -722,10 +1442,11 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     if (hipMemsetAsync(a.g, 0, (size_t)g->H * g->B * g->Sq * L.Rp * sizeof(float), stream) != hipSuccess)
       return check_launch("hipMemsetAsync(G)");
   }
+  const bool split = g->precision == 1;
   switch (HD) {
-    case 16: rc = launch_bwd<16>(a, stream); break;
-    case 32: rc = launch_bwd<32>(a, stream); break;
-    default: rc = launch_bwd<64>(a, stream); break;
+    case 16: rc = split ? launch_bwd_split<16>(a, stream) : launch_bwd<16>(a, stream); break;
+    case 32: rc = split ? launch_bwd_split<32>(a, stream) : launch_bwd<32>(a, stream); break;
+    default: rc = split ? launch_bwd_split<64>(a, stream) : launch_bwd<64>(a, stream); break;
   }
   if (rc || !has_e) return rc;
 
@@ -740,25 +1461,28 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     if ((rc = check_launch("pack_rel_T"))) return rc;
   }
   const int gemm_flags = g->precision == 1 ? ISI_CONV_BF16X3 : 0;   // same product mode as the attention kernels
-  for (int h = 0; h < g->H; ++h) {
-    float *Gh = a.g + (size_t)h * g->B * g->Sq * L.Rp;
+  {
+    // all heads in one launch each (grid z = head): G_h [B*Sq, Rp] x E_h^T, accumulated into dq's head slice ...
     isi_src sg;
     memset(&sg, 0, sizeof sg);
-    sg.ptr = Gh; sg.C = L.Rp; sg.sn = (int64_t)g->Sq * L.Rp; sg.sc = 1; sg.sh = L.Rp; sg.sw = L.Rp;
+    sg.ptr = a.g; sg.C = L.Rp; sg.sn = (int64_t)g->Sq * L.Rp; sg.sc = 1; sg.sh = L.Rp; sg.sw = L.Rp;
     isi_src res;
     memset(&res, 0, sizeof res);
-    res.ptr = ga->dq + (size_t)h * g->q_sh; res.C = HD; res.sn = g->q_sb; res.sc = 1; res.sh = g->q_ss; res.sw = g->q_ss;
+    res.ptr = ga->dq; res.C = HD; res.sn = g->q_sb; res.sc = 1; res.sh = g->q_ss; res.sw = g->q_ss;
     isi_dst dst;
     memset(&dst, 0, sizeof dst);
-    dst.ptr = ga->dq + (size_t)h * g->q_sh; dst.sn = g->q_sb; dst.sc = 1; dst.sh = g->q_ss; dst.sw = g->q_ss;
-    rc = conv2d_f32(&sg, nullptr, wT + (size_t)h * HD * KpT, nullptr, &res, &dst, g->B, g->Sq, 1, HD, 1, 1, 1, 0,
-                    gemm_flags, stream);
+    dst.ptr = ga->dq; dst.sn = g->q_sb; dst.sc = 1; dst.sh = g->q_ss; dst.sw = g->q_ss;
+    const int64_t zs_g = (int64_t)g->B * g->Sq * L.Rp;
+    rc = conv2d_batched_f32(&sg, nullptr, wT, nullptr, &res, &dst, g->B, g->Sq, 1, HD, 1, 1, 1, 0, gemm_flags, g->H,
+                            zs_g, (int64_t)HD * KpT, g->q_sh, g->q_sh, stream);
     if (rc) return rc;
+    // ... and dE_h = G_h^T Q_h, the pixel-reduction GEMM
     isi_src sq;
     memset(&sq, 0, sizeof sq);
-    sq.ptr = g->q + (size_t)h * g->q_sh; sq.C = HD; sq.sn = g->q_sb; sq.sc = 1; sq.sh = g->q_ss; sq.sw = g->q_ss;
-    rc = conv_wgrad_f32(&sq, nullptr, Gh, ga->workspace + L.dw + (size_t)h * L.Rp * L.Kp, nullptr,
-                        ga->workspace + L.wg, L.wg_floats, g->B, g->Sq, 1, L.Rp, 1, 1, 1, 0, gemm_flags, stream);
+    sq.ptr = g->q; sq.C = HD; sq.sn = g->q_sb; sq.sc = 1; sq.sh = g->q_ss; sq.sw = g->q_ss;
+    rc = conv_wgrad_batched_f32(&sq, nullptr, a.g, ga->workspace + L.dw, nullptr, ga->workspace + L.wg, L.wg_floats,
+                                g->B, g->Sq, 1, L.Rp, 1, 1, 1, 0, gemm_flags, g->H, g->q_sh, zs_g,
+                                (int64_t)L.Rp * L.Kp, stream);
     if (rc) return rc;
   }
   {

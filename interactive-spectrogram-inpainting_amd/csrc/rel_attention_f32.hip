@@ -25,6 +25,7 @@
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "prof.h"
+#include "split_bf16.h"
 
 namespace isi {
 
@@ -371,27 +372,6 @@ __global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs 
 //                    of key block t is key 16 t + 8 (e >> 2) + 4 h + (e & 3), i.e. exactly the lane's registers
 // LDS rows are unpadded and XOR-swizzled: 16-B slot s of row r of a [.][HD] plane sits at s ^ ((r / (128/HD))
 // mod (HD/8)); 8-B unit u of row d of a V^T plane at u ^ ((d >> 2) & 7)  (conflict-free ds_read_b128 / b64).
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
-
-namespace {
-__device__ __forceinline__ void split2(const float a, const float b, unsigned &hi, unsigned &lo) {
-  const f32x2_t v = {a, b};
-  const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
-  const bf16x2_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2_t), bf16x2_t);
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
-}
-__device__ __forceinline__ void split_f4(const float4 v, uint2 &hi, uint2 &lo) {
-  split2(v.x, v.y, hi.x, lo.x);
-  split2(v.z, v.w, hi.y, lo.y);
-}
-#define ISI_MFB(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0)
-}  // namespace
-
 template <int HD>
 __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArgs p) {
   constexpr int NKB = HD / 16;           // 16-deep k-blocks of the head dim
@@ -659,14 +639,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
 
       // ---- P split: key block t = registers 8 t .. 8 t + 7
       s16x8_t ph[2], pl[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        unsigned hh[4], ll[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) split2(sv[8 * t + 2 * e], sv[8 * t + 2 * e + 1], hh[e], ll[e]);
-        ph[t] = __builtin_bit_cast(s16x8_t, make_uint4(hh[0], hh[1], hh[2], hh[3]));
-        pl[t] = __builtin_bit_cast(s16x8_t, make_uint4(ll[0], ll[1], ll[2], ll[3]));
-      }
+      split_acc16(sv, ph, pl);
       // ---- O^T = alpha * O^T + V^T P^T
       const bool rescale = __any(alpha != 1.f);
 #pragma unroll

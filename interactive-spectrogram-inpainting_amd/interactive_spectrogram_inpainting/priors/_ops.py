@@ -25,6 +25,9 @@ def _s(t):
 # fp64 at or below the fp32 pipe's own, 1.4x its speed; 'f32' = the fp32 matrix pipe.
 # Shapes the split kernel does not cover (N <= 32 or K < 128) run on the fp32 pipe either way.
 LINEAR_PRECISION = os.environ.get("ISI_LINEAR_PRECISION", "bf16x6")
+# products of the input-gradient GEMMs of the training path (dX = dY W): three terms (relative error ~2^-16 per
+# product) are far below the noise the ReLU / dropout masks and the optimiser see
+LINEAR_GRAD_PRECISION = os.environ.get("ISI_LINEAR_GRAD_PRECISION", "bf16x3")
 # products of the attention contractions (q k^T, q e^T, p v): 'f32' = fp32 matrix pipe, 'bf16x3' = three-term
 # split-bf16 on the bf16 pipe (relative error of a product ~2^-16, fp32 accumulation, logits / softmax fp32)
 ATTENTION_PRECISION = os.environ.get("ISI_ATTENTION_PRECISION", "bf16x3")
@@ -38,9 +41,10 @@ def pack_linear_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], n_out: int,
-           relu: bool = False, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y[..., n_out] = x[..., K] W^T + b (+ residual) on the fp32 matrix pipe: the
-    implicit-GEMM convolution kernel with a 1x1 window (rows = "pixels")."""
+           relu: bool = False, residual: Optional[torch.Tensor] = None,
+           precision: Optional[str] = None) -> torch.Tensor:
+    """y[..., n_out] = x[..., K] W^T + b (+ residual): the implicit-GEMM convolution kernel with a
+    1x1 window (rows = "pixels"); `precision` overrides LINEAR_PRECISION."""
     _hip.require_gpu(x, "linear input")
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
@@ -59,7 +63,7 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
     rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, packed_w.data_ptr(),
                                    bias.data_ptr() if bias is not None else None,
                                    C.byref(res) if res is not None else None, C.byref(dst),
-                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[LINEAR_PRECISION], _s(x))
+                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[precision or LINEAR_PRECISION], _s(x))
     _hip.check(rc, "isi_conv2d_f32 (linear)")
     return out.reshape(*x.shape[:-1], n_out)
 

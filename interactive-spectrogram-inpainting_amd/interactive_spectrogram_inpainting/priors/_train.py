@@ -58,6 +58,11 @@ def linear_wgrad(x2: torch.Tensor, dy2: torch.Tensor):
     return (packed if Kpad == K else packed[:, :K]), db
 
 
+def _grad_precision() -> str:
+    # an exact forward ('f32') keeps exact gradients; otherwise the input-gradient GEMMs use their own default
+    return "f32" if _ops.LINEAR_PRECISION == "f32" else _ops.LINEAR_GRAD_PRECISION
+
+
 class LinearFn(torch.autograd.Function):
     """y[..., N] = x[..., K] W^T + b, optionally rectified, optionally + residual (added before the ReLU)."""
 
@@ -82,7 +87,7 @@ class LinearFn(torch.autograd.Function):
                        "isi_relu_bwd_f32")
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K).reshape(x.shape)
+            dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K, precision=_grad_precision()).reshape(x.shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = linear_wgrad(_rows(x), dy2)
             if not ctx.has_bias:

@@ -73,6 +73,14 @@ int isi_spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t r
                          int mel, void *stream);
 int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop,
                         int left, int64_t L, void *stream);
+/* Per-channel affine map of a dense [B,2,H,W] spectrogram plus the masked-phase rule, one pass:
+ * y0 = a0 x0 + b0; y1 = a1 x1 + b1, set to 0 where the log-magnitude (channel 0 of `ref` when given,
+ * else y0) is <= thr (use_mask != 0).  Replaces GANsynth_pytorch's DataNormalizer.normalize /
+ * denormalize and make_masked_phase_transform at the reference's call sites vqvae.py:254-255,297-302
+ * (package absent from the tree; semantics in oracle/spectrogram_oracle.py).  HW % 4 == 0. */
+int isi_spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t B, int64_t HW,
+                             float a0, float b0, float a1, float b1, float thr, int use_mask,
+                             void *stream);
 
 /* ------------------------------------------------- measurement (bench.py) */
 /* Per-launch timing with HIP events recorded on the launch stream.  State is

@@ -50,6 +50,9 @@ class SpectrogramsHelper:
             raise NotImplementedError("hop_length must divide n_fft and be a multiple of 4")
         self.fs_hz, self.n_fft, self.hop_length, self.window_length = fs_hz, n_fft, hop_length, window_length
         self.n_bins = n_fft // 2
+        # floor of the log-magnitude channel, log(0 + eps): the threshold the masked-phase transform and
+        # `output_spectrogram_min_magnitude` use (train_vqvae.py:710-712)
+        self.safelog_eps = math.log(1e-6)
         self.device = torch.device(device) if device is not None else None
         self._built = None
 

@@ -94,6 +94,10 @@ int isi_spec_inverse_prepare_f32(const float *spec, float *a, float *ph, int B, 
 int isi_spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t rows, int F, int mel, void *stream) {
   return spec_to_stft_f32(a, ph, stft, rows, F, mel, S(stream));
 }
+int isi_spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t B, int64_t HW, float a0, float b0,
+                             float a1, float b1, float thr, int use_mask, void *stream) {
+  return spec_affine_mask_f32(x, ref, y, B, HW, a0, b0, a1, b1, thr, use_mask, S(stream));
+}
 int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
                         void *stream) {
   return overlap_add_f32(frames, audio, B, T, n_fft, hop, left, L, S(stream));

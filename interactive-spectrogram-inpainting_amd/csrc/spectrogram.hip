@@ -167,6 +167,40 @@ __global__ void overlap_add_kernel(const float *__restrict__ frames, float *__re
   audio[(size_t)b * L + n] = s;
 }
 
+// Per-channel affine map of a [B,2,H,W] spectrogram with the masked-phase rule, one pass:
+//   y0 = a0 x0 + b0 ;  y1 = a1 x1 + b1, forced to 0 where the log-magnitude (ref channel 0 when `ref` is given,
+//   else y0) is <= thr.  Serves DataNormalizer.normalize / denormalize (vqvae.py:254-255,297-300), the
+//   masked-phase transform (vqvae.py:238-241,301-302) and, with b = 0 and ref = forward output, their backward.
+__global__ __launch_bounds__(256) void spec_affine_mask_kernel(const float *__restrict__ x, const float *__restrict__ ref,
+                                                               float *__restrict__ y, int64_t HW4, float a0, float b0,
+                                                               float a1, float b1, float thr, int use_mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 index inside one channel plane
+  const int64_t b = blockIdx.y;
+  if (i >= HW4) return;
+  const size_t o0 = ((size_t)b * 2) * HW4 + i, o1 = o0 + HW4;
+  const float4 m = reinterpret_cast<const float4 *>(x)[o0], p = reinterpret_cast<const float4 *>(x)[o1];
+  float4 ym = make_float4(a0 * m.x + b0, a0 * m.y + b0, a0 * m.z + b0, a0 * m.w + b0);
+  float4 yp = make_float4(a1 * p.x + b1, a1 * p.y + b1, a1 * p.z + b1, a1 * p.w + b1);
+  if (use_mask) {
+    const float4 r = ref ? reinterpret_cast<const float4 *>(ref)[o0] : ym;
+    yp.x = r.x <= thr ? 0.f : yp.x; yp.y = r.y <= thr ? 0.f : yp.y;
+    yp.z = r.z <= thr ? 0.f : yp.z; yp.w = r.w <= thr ? 0.f : yp.w;
+  }
+  reinterpret_cast<float4 *>(y)[o0] = ym;
+  reinterpret_cast<float4 *>(y)[o1] = yp;
+}
+
+int spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t B, int64_t HW, float a0, float b0, float a1,
+                         float b1, float thr, int use_mask, hipStream_t st) {
+  if (!x || !y || B <= 0 || HW <= 0 || B > 65535) return invalid("spec_affine_mask: bad argument");
+  if ((HW & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ref)) & 15))
+    return invalid("spec_affine_mask: H*W must be a multiple of 4 and pointers 16-byte aligned");
+  const int64_t HW4 = HW / 4;
+  hipLaunchKernelGGL(spec_affine_mask_kernel, dim3((unsigned)((HW4 + 255) / 256), (unsigned)B), dim3(256), 0, st, x, ref, y,
+                     HW4, a0, b0, a1, b1, thr, use_mask);
+  return check_launch("spec_affine_mask");
+}
+
 int spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel, hipStream_t st) {
   if (!stft || !a || !ph || B <= 0 || T <= 0 || F <= 0 || B > 65535) return invalid("spec_polar: bad argument");
   hipLaunchKernelGGL(spec_polar_kernel, dim3((F + 255) / 256, B), dim3(256), 0, st, stft, a, ph, T, F, mel);

@@ -69,10 +69,8 @@ class VQVAE(nn.Module):
         if restarts_usage_threshold != 1.:
             raise NotImplementedError("QuantizedBottleneckWithRestarts needs the absent `discretization` "
                                       "package and is not built")
-        if normalizer_statistics is not None or output_spectrogram_min_magnitude is not None \
-                or output_activation_type is not None:
-            raise NotImplementedError("GANSynth normalisation / masked-phase output transform live in the "
-                                      "absent GANsynth_pytorch package and are not built yet")
+        if output_activation_type is not None:
+            raise NotImplementedError("decoder output activations ('threshold_gelu', vqvae.py:229-236) are not built")
 
         # instantiation parameters, JSON round-tripped like vqvae.py:98-122
         self.in_channel = in_channel
@@ -125,9 +123,17 @@ class VQVAE(nn.Module):
         self.dec = RosinalityDecoder(D + D, in_channel, C_, n_res_block, R, resolution_factor=fb,
                                      groups=groups, use_local_kernels=use_local_kernels)
 
-        self.use_gansynth_normalization = False
+        # GANSynth range normalisation of the input / de-normalisation of the output and the masked-phase
+        # output transform (vqvae.py:218-241): one fused HBM pass each (GANsynth_pytorch/normalizer.py)
+        self.use_gansynth_normalization = normalizer_statistics is not None
         self.data_normalizer = None
         self.output_transform = None
+        if self.use_gansynth_normalization:
+            from GANsynth_pytorch.normalizer import DataNormalizer, DataNormalizerStatistics
+            self.data_normalizer = DataNormalizer(DataNormalizerStatistics(**normalizer_statistics))
+        if output_spectrogram_min_magnitude is not None:
+            from GANsynth_pytorch.loader import make_masked_phase_transform
+            self.output_transform = make_masked_phase_transform(output_spectrogram_min_magnitude)
         self.adapt_quantized_durations = adapt_quantized_durations
         self._plan = None
         self._plan_key = None
@@ -255,6 +261,8 @@ class VQVAE(nn.Module):
         if input.dim() != 4 or input.shape[1] != self.in_channel:
             raise RuntimeError(f"expected input [B, {self.in_channel}, H, W], got {tuple(input.shape)}")
         x = input.contiguous()
+        if self.data_normalizer is not None:
+            x = self.data_normalizer.normalize(x)          # vqvae.py:254-255
         B, _, H, W = x.shape
         Hb, Wb, Ht, Wt, Wq = self._latent_shapes(H, W)
         dev, D = x.device, self.embed_dim
@@ -279,7 +287,7 @@ class VQVAE(nn.Module):
         if self.training:
             return self._forward_train(input)
         dec, _, _, diff, id_t, id_b, perp_t, perp_b = self._encode_impl(input, with_decode=True)
-        return dec, diff, perp_t, perp_b, id_t, id_b
+        return self.post_process(dec), diff, perp_t, perp_b, id_t, id_b
 
     def _forward_train(self, input: Tensor):
         """Train-mode forward (EMA codebook update in-forward, bottleneck.py:79-92) whose
@@ -291,7 +299,10 @@ class VQVAE(nn.Module):
             raise NotImplementedError("disable_quantization=True has no training path")
         if not hasattr(self, "_dgrad_weights"):
             self._dgrad_weights = _DgradWeights()
-        return VQVAETrainFunction.apply(self, input, *self.parameters())
+        if self.data_normalizer is not None:
+            input = self.data_normalizer.normalize(input)
+        dec, *rest = VQVAETrainFunction.apply(self, input, *self.parameters())
+        return (self.post_process(dec), *rest)      # differentiable (SpecAffineMaskFunction)
 
     def encode(self, input: Tensor):
         _, q_t, q_b, diff, id_t, id_b, perp_t, perp_b = self._encode_impl(input, with_decode=False)
@@ -323,7 +334,14 @@ class VQVAE(nn.Module):
         return self.decode(quant_t, quant_b)
 
     def post_process(self, dec: Tensor) -> Tensor:
-        return dec  # no normaliser statistics / output transform configured (see __init__)
+        """vqvae.py:297-302: de-normalise, then zero the phase of bins at or below the magnitude floor
+        (one fused pass when both are configured)."""
+        thr = self.output_spectrogram_min_magnitude
+        if self.data_normalizer is not None:
+            return self.data_normalizer.denormalize(dec, threshold=thr)
+        if self.output_transform is not None:
+            return self.output_transform(dec)
+        return dec
 
     # ------------------------------------------------------------ persistence
     @classmethod

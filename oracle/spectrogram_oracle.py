@@ -163,3 +163,37 @@ def to_audio(cfg: SpecConfig, spec: torch.Tensor, mel: bool) -> torch.Tensor:
         out[:, t * cfg.hop_length:t * cfg.hop_length + cfg.n_fft] += frames[:, :, t]
     left = cfg.n_fft - cfg.hop_length
     return out[:, left:left + T * cfg.hop_length]
+
+
+# ---------------------------------------------------------------- range normalisation / masked phase
+# (GANsynth_pytorch.normalizer.DataNormalizer, GANsynth_pytorch.loader.make_masked_phase_transform; call
+# sites vqvae.py:221-241,254-255,297-302, train_vqvae.py:646-676.  PARITY UNPINNED: source absent.)
+def normalizer_statistics(specs, magnitude_margin: float = 0.8, IF_margin: float = 1.0) -> dict:
+    """Affine maps sending each channel's [min, max] over `specs` (iterable of [B,2,F,T]) to [-margin, margin]."""
+    lo = [min(float(s[:, c].min()) for s in specs) for c in range(2)]
+    hi = [max(float(s[:, c].max()) for s in specs) for c in range(2)]
+    out = {}
+    for c, (ka, kb, margin) in enumerate((("s_a", "s_b", magnitude_margin), ("p_a", "p_b", IF_margin))):
+        rng = hi[c] - lo[c]
+        out[ka] = margin * 2.0 / rng
+        out[kb] = margin * (1.0 - 2.0 * hi[c] / rng)
+    return out
+
+
+def normalize(spec: torch.Tensor, st: dict) -> torch.Tensor:
+    a = torch.tensor([st["s_a"], st["p_a"]], dtype=spec.dtype).view(1, 2, 1, 1)
+    b = torch.tensor([st["s_b"], st["p_b"]], dtype=spec.dtype).view(1, 2, 1, 1)
+    return spec * a + b
+
+
+def denormalize(spec: torch.Tensor, st: dict) -> torch.Tensor:
+    a = torch.tensor([1.0 / st["s_a"], 1.0 / st["p_a"]], dtype=spec.dtype).view(1, 2, 1, 1)
+    b = torch.tensor([-st["s_b"] / st["s_a"], -st["p_b"] / st["p_a"]], dtype=spec.dtype).view(1, 2, 1, 1)
+    return spec * a + b
+
+
+def mask_phase(spec: torch.Tensor, min_magnitude: float) -> torch.Tensor:
+    """Instantaneous frequency zeroed where the log-magnitude is at or below `min_magnitude`."""
+    out = spec.clone()
+    out[:, 1] = torch.where(spec[:, 0] <= min_magnitude, torch.zeros_like(spec[:, 1]), spec[:, 1])
+    return out

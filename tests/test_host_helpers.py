@@ -291,3 +291,25 @@ def test_make_time_indexes_matches_reference(golden_dir):
     for start, codemap_duration, transformer_duration in z["cases"].tolist():
         got = inpainting.make_time_indexes(start, codemap_duration, transformer_duration)
         assert got == z[f"ti::{start}_{codemap_duration}_{transformer_duration}"].tolist()
+
+
+def test_label_encoders_and_checkpoint_round_trip(tmp_path):
+    """utils/datasets/label_encoders.py:8-26 and utils/training/checkpoint.py:6-31."""
+    from sklearn.preprocessing import LabelEncoder
+    from interactive_spectrogram_inpainting.utils.datasets.label_encoders import dump_label_encoders, load_label_encoders
+    from interactive_spectrogram_inpainting.utils.training.checkpoint import Checkpoint
+    enc = {"pitch": LabelEncoder().fit(list(range(24, 85))),
+           "instrument_family_str": LabelEncoder().fit(["bass", "brass", "flute", "guitar", "keyboard"])}
+    dump_label_encoders(enc, tmp_path)
+    back = load_label_encoders(tmp_path / "label_encoders.json")
+    assert set(back) == set(enc)
+    assert back["pitch"].transform([60]).tolist() == enc["pitch"].transform([60]).tolist() == [36]
+    assert back["instrument_family_str"].classes_.tolist() == enc["instrument_family_str"].classes_.tolist()
+    lin = torch.nn.Linear(3, 2)
+    opt = torch.optim.Adam(lin.parameters())
+    ck = Checkpoint(lin, 4, 0.5, {"perplexity": 12.0}, opt)
+    assert list(ck) == ["model", "epoch", "validation_loss", "validation_metrics", "optimizer", "scheduler", "scaler", "use_amp"]
+    assert ck["scheduler"] is None and ck["use_amp"] is False and ck["epoch"] == 4
+    torch.save(ck, tmp_path / "ck.pt")
+    again = torch.load(tmp_path / "ck.pt", weights_only=False)
+    assert torch.equal(again["model"]["weight"], lin.weight)

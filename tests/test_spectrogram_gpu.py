@@ -89,3 +89,81 @@ def test_round_trip_and_api():
         h.to_spectrogram(x)                                          # CPU tensor: no fallback
     with pytest.raises(ValueError):
         h.to_audio(torch.zeros(1, 2, 100, 4, device=_dev()))
+
+
+def test_normalizer_and_masked_phase_against_spec(tmp_path):
+    """DataNormalizer / make_masked_phase_transform (fused affine + mask kernel) against the CPU
+    specification, their gradients against autograd, statistics measured from a loader, JSON round trip."""
+    from GANsynth_pytorch.loader import make_masked_phase_transform
+    from GANsynth_pytorch.normalizer import DataNormalizer, DataNormalizerStatistics
+    from oracle import spectrogram_oracle as S
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    batches = [torch.randn(3, 2, 16, 24, generator=g) * 4 - 5 for _ in range(3)]
+    st = S.normalizer_statistics(batches)
+    norm = DataNormalizer(dataloader=[(b.to(dev), None) for b in batches])
+    for k, v in st.items():
+        assert abs(norm.statistics[k] - v) <= 1e-6 * max(1.0, abs(v)), k
+    x = batches[1]
+    y = norm.normalize(x.to(dev))
+    ref = S.normalize(x, st)
+    assert (y.cpu() - ref).abs().max() <= 1e-6 * ref.abs().max()
+    assert y[:, 0].abs().max() <= 0.8 + 1e-5 and y[:, 1].abs().max() <= 1.0 + 1e-5
+    back = norm.denormalize(y)
+    assert (back.cpu() - x).abs().max() <= 1e-5 * x.abs().max()
+    # masked phase, alone and fused with the de-normalisation; 3-D input like a dataset transform sees
+    thr = float(x[:, 0].median())
+    m = make_masked_phase_transform(thr)(x.to(dev))
+    assert torch.equal(m.cpu(), S.mask_phase(x, thr))
+    assert torch.equal(make_masked_phase_transform(thr)(x[0].to(dev)).cpu(), S.mask_phase(x[:1], thr)[0])
+    fused = norm.denormalize(y, threshold=thr)
+    ref_f = S.mask_phase(S.denormalize(ref, st), thr)
+    near = (S.denormalize(ref, st)[:, 0] - thr).abs() < 1e-4          # bins whose magnitude sits on the threshold
+    assert ((fused.cpu() - ref_f).abs().max(1).values[~near]).max() <= 1e-5 * x.abs().max()
+    # gradients
+    xd = x.to(dev).requires_grad_(True)
+    w = torch.randn(x.shape, generator=g)
+    (norm.denormalize(norm.normalize(xd) * 1.5, threshold=thr) * w.to(dev)).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    (S.mask_phase(S.denormalize(S.normalize(xr, st) * 1.5, st), thr) * w).sum().backward()
+    assert (xd.grad.cpu() - xr.grad).abs().max() <= 1e-5 * xr.grad.abs().max()
+    # persistence
+    norm.dump_statistics(tmp_path / "stats.json")
+    again = DataNormalizer.load_statistics(tmp_path / "stats.json")
+    assert dict(again.statistics) == dict(norm.statistics)
+    assert isinstance(DataNormalizerStatistics(**norm.statistics), dict)
+
+
+def test_vqvae_with_normalizer_and_output_threshold():
+    """VQVAE(normalizer_statistics=..., output_spectrogram_min_magnitude=...) (vqvae.py:218-241,254-255,297-302):
+    encode sees the normalised input, every decode path post-processes."""
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    from oracle import spectrogram_oracle as S, vqvae_oracle as O
+    dev = torch.device("cuda:0")
+    kw = dict(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16, num_embeddings=64)
+    cfg = O.Config(**kw)
+    sd = O.init_state_dict(cfg, seed=31)
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(2, 2, 32, 32, generator=g) * 3 - 4
+    st = S.normalizer_statistics([x])
+    O.calibrate_codebooks(sd, cfg, S.normalize(x, st))
+    thr = -0.5
+    m = VQVAE(normalizer_statistics=st, output_spectrogram_min_magnitude=thr, **kw)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    ref = O.forward(S.normalize(x, st), sd, cfg)
+    ref_dec = S.mask_phase(S.denormalize(ref[0], st), thr)
+    dec, diff, p_t, p_b, id_t, id_b = m(x.to(dev))
+    assert torch.equal(id_t.cpu(), ref[4]) and torch.equal(id_b.cpu(), ref[5])
+    near = (S.denormalize(ref[0], st)[:, 0] - thr).abs() < 1e-3
+    err = (dec.cpu() - ref_dec).abs()
+    assert err[:, 0].max() <= 1e-4 * ref_dec.abs().max() and err[:, 1][~near].max() <= 1e-4 * ref_dec.abs().max()
+    assert (dec[:, 1][dec[:, 0] <= thr] == 0).all() and (dec[:, 0] <= thr).any()
+    assert torch.equal(m.decode_code(id_t, id_b), dec)
+    # the parameters JSON carries the statistics (vqvae.py:98-122)
+    assert m.normalizer_statistics == st and m.output_spectrogram_min_magnitude == thr
+    # train mode: differentiable through the post-processing
+    m.train()
+    out, latent, *_ = m(x.to(dev))
+    (out.pow(2).mean() + latent.mean()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())

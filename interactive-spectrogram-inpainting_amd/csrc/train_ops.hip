@@ -149,9 +149,58 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restric
   if (g == 0 && c < C) out[c] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
+// Dense [M, C] with C a power of two <= 1024: the matrix is streamed as one flat float4 array; a thread's
+// stride (256 float4 = 1024 floats) is a multiple of C, so its four lanes always see the same four columns and
+// every lane of the wave loads (C = 2 used 2 lanes of 64 in colsum_partial_kernel: 500 -> ~60 us on the
+// last decoder layer's bias gradient).
+__global__ __launch_bounds__(256) void colsum_flat_kernel(const float4 *__restrict__ x, float *__restrict__ partial,
+                                                          int64_t n4, int C, int64_t f4_per_block) {
+  __shared__ float red[256][4];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * f4_per_block, i1 = i0 + f4_per_block < n4 ? i0 + f4_per_block : n4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+  int64_t i = i0 + tid;
+  for (; i + 768 < i1; i += 1024) {
+    const float4 v0 = x[i], v1 = x[i + 256], v2 = x[i + 512], v3 = x[i + 768];
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+    b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+    c.x += v2.x; c.y += v2.y; c.z += v2.z; c.w += v2.w;
+    d.x += v3.x; d.y += v3.y; d.z += v3.z; d.w += v3.w;
+  }
+  for (; i < i1; i += 256) {
+    const float4 v0 = x[i];
+    a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+  }
+  red[tid][0] = (a.x + b.x) + (c.x + d.x);
+  red[tid][1] = (a.y + b.y) + (c.y + d.y);
+  red[tid][2] = (a.z + b.z) + (c.z + d.z);
+  red[tid][3] = (a.w + b.w) + (c.w + d.w);
+  __syncthreads();
+  for (int col = tid; col < C; col += 256) {
+    float s = 0.f;
+    if (C >= 4) {
+      for (int t = col >> 2; t < 256; t += C >> 2) s += red[t][col & 3];
+    } else {
+      for (int t = 0; t < 256; ++t)
+        for (int e = col; e < 4; e += C) s += red[t][e];
+    }
+    partial[(size_t)blockIdx.x * C + col] = s;
+  }
+}
+
 int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, hipStream_t st) {
   if (!x || !out || !workspace || M <= 0 || C <= 0) return invalid("colsum: bad argument");
   const int nblk = colsum_num_partials(M);
+  if (x_stride == C && C <= 1024 && (C & (C - 1)) == 0 && ((M * C) & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+    const int64_t n4 = M * C / 4;
+    const int64_t per = ((n4 + nblk - 1) / nblk + 255) / 256 * 256;   // block starts stay multiples of 1024 floats
+    hipLaunchKernelGGL(colsum_flat_kernel, dim3(nblk), dim3(256), 0, st, reinterpret_cast<const float4 *>(x), workspace,
+                       n4, C, per);
+    int rc = check_launch("colsum_flat");
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, out, C, nblk);
+    return check_launch("colsum_reduce");
+  }
   const int rows = (int)((M + nblk - 1) / nblk);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, x, workspace, M, C, x_stride, rows);
   int rc = check_launch("colsum_partial");

@@ -272,9 +272,16 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(ROOT / "profiles" / "r01_pmc_hbm_traffic.json"))
+            # rocprof names of the launches the dominant profiling id covers (template tail = MODE, PREC)
+            tail = {"bf16x6": ", 0, 2>", "bf16x3": ", 0, 1>"}
+            want = next((t for k, t in tail.items() if k in dom["kernel"]), "<128, 128, 2, 2, 0, 0>")
+            tot_b = tot_n = 0.0
             for name, d in pmc.items():
-                if "conv_igemm_f32_kernel<128, 128, 2, 2, 0, 0>" in name:
-                    traffic = round(d["hbm_bytes_per_launch_corrected"])
+                if "conv_igemm_f32_kernel" in name and name.endswith(want) and "hbm_bytes_per_launch_corrected" in d:
+                    tot_b += d["hbm_bytes_per_launch_corrected"] * d["dispatches"]
+                    tot_n += d["dispatches"]
+            if tot_n:
+                traffic = round(tot_b / tot_n)
         except (OSError, ValueError, KeyError):
             pass
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -283,7 +290,7 @@ def main():
         peak = BF16_MATRIX_PEAK_TFLOPS / terms if terms else FP32_MATRIX_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": None if terms else traffic,
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                 "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                 "launches_per_step": dom["launches"] // args.steps,
@@ -340,9 +347,11 @@ def main():
             model.conv_precision = default_precision
         line["alt_precision_single_gpu"] = alt
         if not args.no_prior:
-            line["prior_sampling"] = _prior_sampling(device)
-            line["prior_training_single_gpu"] = _prior_training(device)
             line["frontend"] = _frontend(device)
+            torch.cuda.empty_cache()
+            line["prior_sampling"] = _prior_sampling(device)
+            torch.cuda.empty_cache()
+            line["prior_training_single_gpu"] = _prior_training(device)
         if not args.no_cpu_baseline and world >= 1:
             line["cpu_baseline"] = _cpu_baseline(sd)
         print(json.dumps(line), flush=True)

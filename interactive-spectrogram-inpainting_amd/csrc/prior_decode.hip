@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void row_linear_ln_kernel(RowLinArgs a) {
 }
 
 int launch_row_linear(const RowLinArgs &a, hipStream_t st) {
-  const size_t smem = ((size_t)a.M * a.K + 2 * a.M) * sizeof(float);
+  const int mr = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;   // the kernel's row capacity (template MR)
+  const size_t smem = ((size_t)mr * a.K + 2 * mr) * sizeof(float);
   dim3 grid((a.N + NPB - 1) / NPB), block(256);
 #define ISI_RL(MR)                                                                                      \
   do {                                                                                                  \

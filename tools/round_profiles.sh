@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box into gpurun_out/round/ (copied to profiles/ afterwards):
+# bench line, kernel traces (VQ-VAE forward, VQ-VAE training, prior training, prior sampling, front-end) and
+# the HBM-traffic PMC passes of the forward.  Counters are collected in their own runs (kernel-trace only).
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/round; mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/kt_fwd -o fwd -- python3 bench.py --no-cpu-baseline --no-prior > $O/bench_under_rocprof.json 2>/dev/null
+python tools/prof_summary.py $O/kt_fwd/fwd_results.db 0 > $O/fwd_summary.txt 2>&1
+rocprofv3 --kernel-trace -d $O/kt_vt -o vt -- python3 tools/bench_train.py > $O/vt.log 2>&1
+python tools/prof_summary.py $O/kt_vt/vt_results.db 0 > $O/vqvae_train_summary.txt 2>&1
+rocprofv3 --kernel-trace -d $O/kt_pt -o pt -- python3 tools/bench_prior_train.py --batch 8 --steps 2 > $O/pt.log 2>&1
+python tools/prof_summary.py $O/kt_pt/pt_results.db 0 > $O/prior_train_summary.txt 2>&1
+rocprofv3 --kernel-trace -d $O/kt_ps -o ps -- python3 tools/bench_prior.py > $O/ps.log 2>&1
+python tools/prof_summary.py $O/kt_ps/ps_results.db 0 > $O/prior_sampling_summary.txt 2>&1
+rocprofv3 --kernel-trace -d $O/kt_fe -o fe -- python3 tools/bench_frontend.py > $O/fe.log 2>&1
+python tools/prof_summary.py $O/kt_fe/fe_results.db 0 > $O/frontend_summary.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-prior --steps 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --no-cpu-baseline --no-prior --steps 5 > /dev/null 2>&1
+python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_hbm_traffic.json > $O/pmc_traffic.txt 2>&1
+python tools/bench_attention.py > $O/attention.txt 2>&1
+python tools/bench_prior_train.py --batch 8 --steps 4 > $O/prior_train.txt 2>&1
+python tools/bench_train.py > $O/vqvae_train.txt 2>&1
+python tools/bench_prior.py > $O/prior_sampling.txt 2>&1
+python tools/bench_frontend.py > $O/frontend.txt 2>&1
+rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write     # the sqlite / csv dumps are large; the summaries are what is kept
+tail -c 600 $O/bench.json

@@ -125,17 +125,35 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
   }
 }
 
-__global__ void layernorm_bwd_reduce_kernel(const float *__restrict__ partial, float *__restrict__ dgamma,
-                                            float *__restrict__ dbeta, int nblk, int D) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * D) return;
-  const int which = c / D, col = c - which * D;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * 2 + which) * D + col];
-  (which ? dbeta : dgamma)[col] = s;
+// dgamma | dbeta [2][D] = sum over the blocks' partials [nblk][2][D]: 64 columns per workgroup, the four waves
+// take interleaved blocks (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float *__restrict__ partial,
+                                                                   float *__restrict__ dgamma,
+                                                                   float *__restrict__ dbeta, int nblk, int D) {
+  __shared__ float red[4][64];
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < 2 * D) {
+    const int which = c / D, col = c - which * D;
+    const float *pp = partial + (size_t)which * D + col;
+    int b = g;
+    for (; b + 12 < nblk; b += 16) {
+      s0 += pp[(size_t)b * 2 * D]; s1 += pp[(size_t)(b + 4) * 2 * D];
+      s2 += pp[(size_t)(b + 8) * 2 * D]; s3 += pp[(size_t)(b + 12) * 2 * D];
+    }
+    for (; b < nblk; b += 4) s0 += pp[(size_t)b * 2 * D];
+  }
+  red[g][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g == 0 && c < 2 * D) {
+    const int which = c / D, col = c - which * D;
+    (which ? dbeta : dgamma)[col] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  }
 }
 
-static int ln_bwd_blocks(int64_t M) { return (int)std::min<int64_t>(128, (M + 15) / 16); }
+// 8 rows per workgroup (2 per wave): enough waves per SIMD to hide a row's dependent load -> reduce -> store chain
+static int ln_bwd_blocks(int64_t M) { return (int)std::min<int64_t>(1024, (M + 7) / 8); }
 
 size_t layernorm_bwd_workspace_floats(int64_t M, int D) { return M > 0 ? (size_t)ln_bwd_blocks(M) * 2 * D : 0; }
 
@@ -154,7 +172,7 @@ int layernorm_bwd_f32(const float *x, const float *res, const float *gamma, cons
                      gamma, dy, dz, workspace, (int)M, D, eps, rpb);
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, stream, workspace, dgamma,
+  hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(256), 0, stream, workspace, dgamma,
                      dbeta, nblk, D);
   return check_launch("layernorm_bwd_reduce");
 }

@@ -496,11 +496,16 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
 static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_t stream) {
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
+    // 128x64 tiles are ~20 % slower per FLOP than 128x128, but a GEMM that fills less than the chip's
+    // 3 workgroups per CU with 128x128 tiles (the prior's d x d linears at 8 k rows: 260 tiles) finishes
+    // sooner with twice as many, half as long, workgroups
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128) * nphase * (a.nz > 1 ? a.nz : 1);
+    const bool narrow = a.Cout <= 64 || tiles128 < 640;
     if (a.bf16x3 == 2) {   // six-term split: fp32-grade products
-      if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 2>(a, nphase, stream);   // (128x64 for Cout = 128: 20 % slower)
+      if (narrow) return launch_cfg<128, 64, 2, 2, 0, 2>(a, nphase, stream);
       return launch_cfg<128, 128, 2, 2, 0, 2>(a, nphase, stream);
     }
-    if (a.Cout <= 64) return launch_cfg<128, 64, 2, 2, 0, 1>(a, nphase, stream);
+    if (narrow) return launch_cfg<128, 64, 2, 2, 0, 1>(a, nphase, stream);
     return launch_cfg<128, 128, 2, 2, 0, 1>(a, nphase, stream);
   }
 #define ISI_CONV_DISPATCH(MODE)                                                        \

@@ -17,6 +17,8 @@
 //
 // Requirements (else the caller uses two isi_conv2d_f32 launches): channels-last
 // dense input/output, C % 32 == 0, C <= 128, R <= 32.
+#include <cstdlib>
+
 #include "isi_common.h"
 #include "prof.h"
 
@@ -34,9 +36,7 @@ struct ResKArgs {
 
 namespace {
 constexpr int LDK = 36;             // padded LDS row (floats)
-constexpr int TH = 2, TW = 64;      // output tile: 2 rows x 64 pixels = 128 GEMM rows
-constexpr int HH = TH + 2, HWD = TW + 2, HPIX = HH * HWD;  // halo 4 x 66 pixels
-constexpr int NA = (HPIX * 8 + 255) / 256;                 // halo quads per thread (9)
+constexpr int TW = 64, HWD = TW + 2;   // output tile: TH rows x 64 pixels (TH = 2: 4 waves, TH = 4: 8 waves); halo row 66
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
@@ -95,8 +95,15 @@ __device__ __forceinline__ f32x16 mfma_split(const s16x8 *a, const s16x8 *b, f32
 }
 #undef ISI_MF
 
-template <int TC, int PREC = 0>  // TC = C / 32; PREC 0 exact fp32, 1 bf16x3, 2 bf16x6
-__global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
+// TH = 2: 4 waves, 2 x 64 pixels; TH = 4: 8 waves, 4 x 64 pixels -- one W1 slice and a (TH + 2)-row halo serve
+// twice the pixels (1.55 instead of 2.06 staged halo rows per output row: a quarter less staging and split work),
+// and the three-plane six-term variant then runs two waves per SIMD inside ONE workgroup per CU.
+template <int TC, int PREC = 0, int TH = 2>  // TC = C / 32; PREC 0 exact fp32, 1 bf16x3, 2 bf16x6
+__global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p) {
+  constexpr int NTH = TH * 128;                               // threads
+  constexpr int HH = TH + 2, HPIX = HH * HWD;                 // halo (TH + 2) x 66 pixels
+  constexpr int NA = (HPIX * 8 + NTH - 1) / NTH;              // halo quads per thread
+  constexpr int NWT = TH == 2 ? 9 : 5;                        // W1 taps staged per thread
   constexpr bool BF = PREC >= 1;
   constexpr int NP = PREC == 2 ? 3 : 2;   // bf16 pieces per value: hi, lo(, mid)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -116,31 +123,34 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w2), 0, p.w2_bytes, 0x00020000);
 
   const int lq = tid & 7, ln = tid >> 3;
+  const int lr = ln & 31, lt = ln >> 5;   // W1 staging: hidden channel lr, taps lt, lt + NTH / 256, ...
   // byte offsets (channel slice 0) of this thread's halo quads / W1 quads
   unsigned a_off[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int i = tid + 256 * j;
+    const int i = tid + NTH * j;
     const int pix = i >> 3;
     const int hy = pix / HWD, hx = pix - hy * HWD;
     const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
     const bool ok = pix < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     a_off[j] = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * C + lq * 4) * 4u : OOB;
   }
-  const unsigned w_off = ln < p.R ? (unsigned)(ln * 9 * C + lq * 4) * 4u : OOB;
+  const unsigned w_off = lr < p.R ? (unsigned)(lr * 9 * C + lq * 4) * 4u : OOB;
 
-  float4 ra[NA], rw[9];
+  float4 ra[NA], rw[NWT];
   auto load_slice = [&](int c) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) ra[j] = buf_load4(rsi, a_off[j] == OOB ? OOB : a_off[j] + (unsigned)c * 128u);
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-      rw[t] = buf_load4(rs1, w_off == OOB ? OOB : w_off + (unsigned)(t * C + c * 32) * 4u);
+    for (int k = 0; k < NWT; ++k) {
+      const int t = TH == 2 ? k : 2 * k + lt;
+      rw[k] = buf_load4(rs1, (w_off == OOB || t >= 9) ? OOB : w_off + (unsigned)(t * C + c * 32) * 4u);
+    }
   };
   auto store_slice = [&]() {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const int i = tid + 256 * j;
+      const int i = tid + NTH * j;
       if (j < NA - 1 || i < HPIX * 8) {
         if constexpr (BF) {
           uint2 hi, mid, lo;
@@ -155,16 +165,18 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
       }
     }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int k = 0; k < NWT; ++k) {
+      const int t = TH == 2 ? k : 2 * k + lt;
+      if (t >= 9) continue;
       if constexpr (BF) {
         uint2 hi, mid, lo;
-        if constexpr (PREC == 2) split3_bf16x4(rw[t], hi, mid, lo); else split_bf16x4(rw[t], hi, lo);
-        const int wo = (t * 32 + ln) * LDB + bf_slot(t * 32 + ln, lq >> 1) + (lq & 1) * 4;
+        if constexpr (PREC == 2) split3_bf16x4(rw[k], hi, mid, lo); else split_bf16x4(rw[k], hi, lo);
+        const int wo = (t * 32 + lr) * LDB + bf_slot(t * 32 + lr, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
         *reinterpret_cast<uint2 *>(Wpl + WPS + wo) = lo;
         if constexpr (PREC == 2) *reinterpret_cast<uint2 *>(Wpl + 2 * WPS + wo) = mid;
       } else {
-        *reinterpret_cast<float4 *>(W1s + (t * 32 + ln) * LDK + lq * 4) = rw[t];
+        *reinterpret_cast<float4 *>(W1s + (t * 32 + lr) * LDK + lq * 4) = rw[k];
       }
     }
   };
@@ -233,8 +245,9 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
     for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
   if constexpr (BF) {
 #pragma unroll
-    for (int j = 0; j < TC; ++j) {
-      const int n = ln + 32 * j;
+    for (int j = 0; j < (TC * 32 + NTH / 8 - 1) / (NTH / 8); ++j) {
+      const int n = ln + (NTH / 8) * j;
+      if (n >= C) continue;
       uint2 hi, mid, lo;
       const float4 wv = buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u);
       if constexpr (PREC == 2) split3_bf16x4(wv, hi, mid, lo); else split_bf16x4(wv, hi, lo);
@@ -282,9 +295,9 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   } else {
   float *W2s = W1s;
 #pragma unroll
-  for (int j = 0; j < TC; ++j) {
-    const int n = ln + 32 * j;
-    *reinterpret_cast<float4 *>(W2s + n * LDK + lq * 4) = buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u);
+  for (int j = 0; j < (TC * 32 + NTH / 8 - 1) / (NTH / 8); ++j) {
+    const int n = ln + (NTH / 8) * j;
+    if (n < C) *reinterpret_cast<float4 *>(W2s + n * LDK + lq * 4) = buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u);
   }
   float *hs = Ah + wave * 32 * LDK;
   {
@@ -345,12 +358,13 @@ __global__ __launch_bounds__(256) void resblock_f32_kernel(const ResKArgs p) {
   }
 }
 
-template <int TC, int PREC>
-static int launch_res(const ResKArgs &a, int B, hipStream_t stream) {
-  auto kern = resblock_f32_kernel<TC, PREC>;
+template <int TC, int PREC, int TH>
+static int launch_res_t(const ResKArgs &a, int B, hipStream_t stream) {
+  auto kern = resblock_f32_kernel<TC, PREC, TH>;
+  constexpr int HPIX = (TH + 2) * HWD;
   constexpr size_t smem = PREC ? (size_t)(HPIX + 9 * 32) * LDB * (PREC == 2 ? 3 : 2) * sizeof(unsigned short)
                              : (size_t)(HPIX * LDK + 9 * 32 * LDK) * sizeof(float);
-  static_assert(9 * 32 >= TC * 32 && HPIX >= 128, "aliased regions must fit");
+  static_assert(9 * 32 >= TC * 32 && HPIX >= TH * 64, "aliased regions must fit");
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -361,8 +375,16 @@ static int launch_res(const ResKArgs &a, int B, hipStream_t stream) {
   const double C = a.C, R = a.R, M = (double)B * a.H * a.W;
   prof::Scope scope(prof::K_RESBLOCK, 2.0 * M * R * 9 * C + 2.0 * M * C * R,
                     4.0 * (2.0 * M * C + 10.0 * C * R), stream);
-  hipLaunchKernelGGL(kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(TH * 128), smem, stream, a);
   return check_launch("resblock_f32");
+}
+
+// tile height: 8-wave 4 x 64 tiles for the six-term variant (ISI_RES_TH = 2 / 4 overrides, for measurements)
+template <int TC, int PREC>
+static int launch_res(const ResKArgs &a, int B, hipStream_t stream) {
+  static const int forced = [] { const char *e = getenv("ISI_RES_TH"); return e ? atoi(e) : 0; }();
+  const int th = forced == 2 || forced == 4 ? forced : (PREC == 2 ? 4 : 2);
+  return th == 4 ? launch_res_t<TC, PREC, 4>(a, B, stream) : launch_res_t<TC, PREC, 2>(a, B, stream);
 }
 
 bool resblock_fusable(int C, int R) { return C % 32 == 0 && C >= 32 && C <= 128 && R >= 1 && R <= 32; }
@@ -377,7 +399,7 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
   if (elems > ((int64_t)1 << 30)) return unsupported("resblock: tensor spans 4 GiB or more");
   if ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(w2)) & 15)
     return invalid("resblock: pointers must be 16-byte aligned");
-  if (B > 65535 || (H + TH - 1) / TH > 65535) return unsupported("resblock: grid too large");
+  if (B > 65535 || (H + 1) / 2 > 65535) return unsupported("resblock: grid too large");
   ResKArgs a;
   a.in = in; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.out = out;
   a.in_bytes = (unsigned)(elems * 4);
@@ -391,9 +413,7 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
     case 3: return launch_res<3, PREC>(a, B, stream);          \
     default: return launch_res<4, PREC>(a, B, stream);         \
   }
-  // six-term split: the fused kernel's three-plane LDS footprint (106 KB) allows one workgroup per CU and is
-  // slower than the exact-fp32 variant (209 vs 195 us at 128/32 channels, B64 32x128), which is used instead
-  if (relu & ISI_CONV_BF16X6) { ISI_RES(0) }
+  if (relu & ISI_CONV_BF16X6) { ISI_RES(2) }
   if (relu & ISI_CONV_BF16X3) { ISI_RES(1) }
   ISI_RES(0)
 #undef ISI_RES

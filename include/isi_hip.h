@@ -73,6 +73,17 @@ int isi_spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t r
                          int mel, void *stream);
 int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop,
                         int left, int64_t L, void *stream);
+/* One scale of the multi-scale spectral loss (reference utils/losses/spectral.py:78-118, where the STFTs come
+ * from torch.stft): xp / xt = STFT rows [B*T][RS] (re block | im block of F bins, RS >= 2F) of the predicted and
+ * the target audio.  fwd: per (sample, chunk of rows_per_block frames) the sums
+ *   sum |dm|, sum dm^2, sum |dl|, sum dl^2,  dm = |Xp| - |Xt|, dl = log(|Xp| + eps) - log(|Xt| + eps)
+ * into partial[B][ceil(T / rows_per_block)][4] (L1 / MSE means and per-sample L2 norms are sums of these).
+ * bwd: dx = d/dXp of sum_b clin[b] g(dm) + clog[b] g(dl), g' = sign (kind 0) or identity (kind 1). */
+int isi_spec_distance_fwd_f32(const float *xp, const float *xt, float *partial, int B, int T, int F,
+                              int RS, float eps, int rows_per_block, void *stream);
+int isi_spec_distance_bwd_f32(const float *xp, const float *xt, float *dx, const float *clin,
+                              const float *clog, int B, int T, int F, int RS, float eps, int kind,
+                              void *stream);
 /* Per-channel affine map of a dense [B,2,H,W] spectrogram plus the masked-phase rule, one pass:
  * y0 = a0 x0 + b0; y1 = a1 x1 + b1, set to 0 where the log-magnitude (channel 0 of `ref` when given,
  * else y0) is <= thr (use_mask != 0).  Replaces GANsynth_pytorch's DataNormalizer.normalize /

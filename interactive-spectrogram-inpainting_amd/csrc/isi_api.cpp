@@ -98,6 +98,14 @@ int isi_spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t
                              float a1, float b1, float thr, int use_mask, void *stream) {
   return spec_affine_mask_f32(x, ref, y, B, HW, a0, b0, a1, b1, thr, use_mask, S(stream));
 }
+int isi_spec_distance_fwd_f32(const float *xp, const float *xt, float *partial, int B, int T, int F, int RS, float eps,
+                              int rows_per_block, void *stream) {
+  return spec_distance_fwd_f32(xp, xt, partial, B, T, F, RS, eps, rows_per_block, S(stream));
+}
+int isi_spec_distance_bwd_f32(const float *xp, const float *xt, float *dx, const float *clin, const float *clog, int B,
+                              int T, int F, int RS, float eps, int kind, void *stream) {
+  return spec_distance_bwd_f32(xp, xt, dx, clin, clog, B, T, F, RS, eps, kind, S(stream));
+}
 int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
                         void *stream) {
   return overlap_add_f32(frames, audio, B, T, n_fft, hop, left, L, S(stream));

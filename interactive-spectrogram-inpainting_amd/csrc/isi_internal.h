@@ -96,6 +96,10 @@ int spec_inverse_prepare_f32(const float *spec, float *a, float *ph, int B, int 
 int spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t rows, int F, int mel, hipStream_t st);
 int spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t B, int64_t HW, float a0, float b0, float a1,
                          float b1, float thr, int use_mask, hipStream_t st);
+int spec_distance_fwd_f32(const float *xp, const float *xt, float *partial, int B, int T, int F, int RS, float eps,
+                          int rows_per_block, hipStream_t st);
+int spec_distance_bwd_f32(const float *xp, const float *xt, float *dx, const float *clin, const float *clog, int B, int T,
+                          int F, int RS, float eps, int kind, hipStream_t st);
 int overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
                     hipStream_t st);
 

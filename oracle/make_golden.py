@@ -436,6 +436,49 @@ def time_indexes_fixtures():
     _save("time_indexes.npz", **out)
 
 
+def spectral_loss_fixtures():
+    """Values and d/d(audio_pred) of the reference's MultiscaleSpectralLoss (utils/losses/spectral.py) with the
+    DDSP and the Jukebox parameter sets and with L2Loss.  The reference calls torch.stft without
+    `return_complex`, which current torch rejects for real input: the call is given the legacy real-pair
+    output (return_complex=False, still available) -- the format `magnitude()` (`t.norm(2, dim=-1)`) expects."""
+    import types as _t
+    for name in ("GANsynth_pytorch", "GANsynth_pytorch.spectrograms_helper"):
+        if name not in sys.modules:
+            sys.modules[name] = _t.ModuleType(name)
+    if not hasattr(sys.modules["GANsynth_pytorch.spectrograms_helper"], "SpectrogramsHelper"):
+        sys.modules["GANsynth_pytorch.spectrograms_helper"].SpectrogramsHelper = object
+    from interactive_spectrogram_inpainting.utils.losses import spectral as R
+    import warnings
+    legacy = torch.stft
+
+    def stft_legacy(*a, **k):
+        k.setdefault("return_complex", False)
+        return legacy(*a, **k)
+
+    out = {}
+    g = torch.Generator().manual_seed(41)
+    pred = torch.randn(2, 6000, generator=g) * 0.3
+    target = pred * 0.7 + torch.randn(2, 6000, generator=g) * 0.2
+    out["pred"], out["target"] = pred.numpy(), target.numpy()
+    cases = {"ddsp": R.DDSPMultiscaleSpectralLoss_kwargs, "jukebox": R.JukeboxMultiscaleSpectralLoss_kwargs,
+             "l2": dict(n_ffts=[256, 512], window_lengths=[200, 512], overlap_ratio=0.75, loss=R.L2Loss(),
+                        lin_loss_alpha=0.5, log_loss_alpha=2.0)}
+    torch.stft = stft_legacy
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for name, kw in cases.items():
+                m = R.MultiscaleSpectralLoss(**kw)
+                p = pred.clone().requires_grad_(True)
+                loss = m(p, target)
+                loss.backward()
+                out[f"{name}::loss"] = loss.detach().numpy()
+                out[f"{name}::grad"] = p.grad.numpy()
+    finally:
+        torch.stft = legacy
+    _save("spectral_loss.npz", **out)
+
+
 def main():
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     _install_stubs()
@@ -475,6 +518,7 @@ def main():
     filtering_fixtures()
     scheduler_fixtures()
     time_indexes_fixtures()
+    spectral_loss_fixtures()
 
 
 if __name__ == "__main__":

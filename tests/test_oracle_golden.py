@@ -120,3 +120,21 @@ def test_init_state_dict_keys_match_reference(golden_dir):
         assert set(mine) == set(sd)
         for k in sd:
             assert mine[k].shape == sd[k].shape, (name, k)
+
+
+def test_spectral_loss_oracle_matches_reference(golden_dir):
+    """oracle/spectral_loss_oracle.py against values and gradients of the reference's MultiscaleSpectralLoss
+    (utils/losses/spectral.py:10-171: DDSP and Jukebox parameter sets, L2Loss)."""
+    from oracle import spectral_loss_oracle as S
+    z = np.load(golden_dir / "spectral_loss.npz")
+    target = torch.from_numpy(z["target"])
+    cases = {"ddsp": dict(n_ffts=[64, 128, 256, 512, 1024, 2048], kind="l1"),
+             "jukebox": dict(n_ffts=[2048, 1024, 512], window_lengths=[1200, 600, 240], overlap_ratio=0.80, kind="mse",
+                             log_loss_alpha=0.0),
+             "l2": dict(n_ffts=[256, 512], window_lengths=[200, 512], kind="l2norm", lin_loss_alpha=0.5, log_loss_alpha=2.0)}
+    for name, kw in cases.items():
+        p = torch.from_numpy(z["pred"]).clone().requires_grad_(True)
+        loss = S.multiscale_spectral_loss(p, target, **kw)
+        loss.backward()
+        _close(loss.detach(), z[f"{name}::loss"], 1e-5)
+        _close(p.grad, z[f"{name}::grad"], 1e-4)

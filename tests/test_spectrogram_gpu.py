@@ -8,6 +8,8 @@ compared on the circle, and where a wrapped difference sits within rounding of +
 implementations may legitimately pick opposite signs, so a 1e-4 fraction of outliers is allowed."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -167,3 +169,40 @@ def test_vqvae_with_normalizer_and_output_threshold():
     out, latent, *_ = m(x.to(dev))
     (out.pow(2).mean() + latent.mean()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("name", ["ddsp", "jukebox", "l2"])
+def test_multiscale_spectral_loss_against_reference(golden_dir, name):
+    """utils/losses/spectral.py classes (strided-conv STFTs + fused distance kernels) against the values and the
+    audio gradients of the reference's own classes (tests/golden/spectral_loss.npz)."""
+    from interactive_spectrogram_inpainting.utils.losses import spectral as S
+    z = np.load(golden_dir / "spectral_loss.npz")
+    dev = torch.device("cuda:0")
+    kw = {"ddsp": S.DDSPMultiscaleSpectralLoss_kwargs, "jukebox": S.JukeboxMultiscaleSpectralLoss_kwargs,
+          "l2": dict(n_ffts=[256, 512], window_lengths=[200, 512], overlap_ratio=0.75, loss=S.L2Loss(),
+                     lin_loss_alpha=0.5, log_loss_alpha=2.0)}[name]
+    m = S.MultiscaleSpectralLoss(**kw)
+    p = torch.from_numpy(z["pred"]).to(dev).requires_grad_(True)
+    loss = m(p, torch.from_numpy(z["target"]).to(dev))
+    loss.backward()
+    ref_l, ref_g = float(z[f"{name}::loss"]), torch.from_numpy(z[f"{name}::grad"])
+    assert abs(loss.item() - ref_l) <= 1e-4 * abs(ref_l), (loss.item(), ref_l)
+    err = (p.grad.cpu() - ref_g).abs().max() / ref_g.abs().max()
+    assert err <= 1e-3, f"audio gradient: max error / max|ref| = {err:.3e}"
+
+
+def test_spectral_loss_from_spectrogram_runs():
+    from GANsynth_pytorch.spectrograms_helper import MelSpectrogramsHelper
+    from interactive_spectrogram_inpainting.utils.losses.spectral import JukeboxMultiscaleSpectralLoss_fromSpectrogram
+    from oracle import spectral_loss_oracle as S
+    dev = torch.device("cuda:0")
+    h = MelSpectrogramsHelper(16000, 2048, 512, 2048).to(dev)
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(2, 16000, generator=g).to(dev) * 0.1
+    spec_t = h.to_spectrogram(a)
+    spec_p = h.to_spectrogram(a * 0.8 + 0.01 * torch.randn(2, 16000, generator=g).to(dev))
+    crit = JukeboxMultiscaleSpectralLoss_fromSpectrogram(h)
+    loss = crit(spec_p, spec_t)
+    ref = S.multiscale_spectral_loss(h.to_audio(spec_p).cpu(), h.to_audio(spec_t).cpu(), [2048, 1024, 512],
+                                     [1200, 600, 240], 0.80, "mse", 1.0, 0.0)
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())

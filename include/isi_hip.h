@@ -73,6 +73,13 @@ int isi_spec_to_stft_f32(const float *a, const float *ph, float *stft, int64_t r
                          int mel, void *stream);
 int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop,
                         int left, int64_t L, void *stream);
+/* Adjoints of isi_spec_to_stft_f32 and isi_spec_inverse_prepare_f32: the backward of `to_audio`, which the
+ * reference obtains from autograd through GANsynth_pytorch when a `_fromSpectrogram` loss trains the VQ-VAE
+ * (utils/losses/spectral.py:106-118, train_vqvae.py:88-96).  `a`, `ph` are the forward's inputs. */
+int isi_spec_to_stft_bwd_f32(const float *a, const float *ph, const float *dx, float *da, float *dph,
+                             int64_t rows, int F, int mel, void *stream);
+int isi_spec_inverse_prepare_bwd_f32(const float *spec, const float *da, const float *dph,
+                                     float *dspec, int B, int T, int F, void *stream);
 /* One scale of the multi-scale spectral loss (reference utils/losses/spectral.py:78-118, where the STFTs come
  * from torch.stft): xp / xt = STFT rows [B*T][RS] (re block | im block of F bins, RS >= 2F) of the predicted and
  * the target audio.  fwd: per (sample, chunk of rows_per_block frames) the sums

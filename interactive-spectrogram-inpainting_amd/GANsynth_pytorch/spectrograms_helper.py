@@ -85,8 +85,10 @@ class SpectrogramsHelper:
         kw = N // hop
         # conv weight [Cout = 2F, Cin = hop, 1, kw]: tap j, channel c = sample j * hop + c of the frame
         w_conv = fwd.reshape(2 * F, kw, hop).permute(0, 2, 1).reshape(2 * F, hop, 1, kw).contiguous().to(device)
+        wi_conv = inv.reshape(2 * F, kw, hop).permute(0, 2, 1).reshape(2 * F, hop, 1, kw).contiguous().to(device)
         built = {"device": device, "stft_w": pack_conv_weight(w_conv),
-                 "istft_w": _gemm.pack_linear_weight(inv.t().contiguous().to(device))}   # Linear [N out, 2F in]
+                 "istft_w": _gemm.pack_linear_weight(inv.t().contiguous().to(device)),   # Linear [N out, 2F in]
+                 "istft_conv_w": pack_conv_weight(wi_conv)}   # its adjoint, as the framing convolution (backward)
         built.update(self._build_extra(device))
         self._built = built
         return built
@@ -138,8 +140,18 @@ class SpectrogramsHelper:
     def _unproject(self, a, ph):
         return a, ph
 
+    def _unproject_bwd(self, da, dph):
+        return da, dph
+
     # ------------------------------------------------------------------ inverse
     def to_audio(self, spec: torch.Tensor) -> torch.Tensor:
+        """[B, 2, F, T] -> [B, T * hop]; differentiable w.r.t. the spectrogram (the `_fromSpectrogram` losses of
+        utils/losses/spectral.py train through it)."""
+        if torch.is_grad_enabled() and spec.requires_grad:
+            return _ToAudioFunction.apply(spec, self)
+        return self._to_audio(spec)[0]
+
+    def _to_audio(self, spec: torch.Tensor, keep: bool = False):
         _hip.require_gpu(spec, "spectrogram")
         c = self._build(spec.device)
         spec = spec.float().contiguous()
@@ -160,10 +172,49 @@ class SpectrogramsHelper:
         audio = torch.empty(B, n_out, dtype=torch.float32, device=spec.device)
         _hip.check(L.isi_overlap_add_f32(frames.data_ptr(), audio.data_ptr(), B, T, self.n_fft, self.hop_length,
                                          self.n_fft - self.hop_length, n_out, _s(spec)), "isi_overlap_add_f32")
-        return audio
+        return audio, ((spec, a, ph) if keep else None)
+
+    def _to_audio_backward(self, saved, d_audio: torch.Tensor) -> torch.Tensor:
+        spec, a, ph = saved
+        c = self._build(spec.device)
+        B, _, F, T = spec.shape
+        N, hop = self.n_fft, self.hop_length
+        L = _hip.lib()
+        # d frames[b, t, k] = d audio[b, t hop + k - left]; d X = d frames . inv^T : the framing convolution of the
+        # padded gradient with the inverse basis (same form as the forward STFT)
+        left, total = N - hop, (T - 1) * hop + N
+        g = torch.nn.functional.pad(d_audio.float(), (left, total - left - T * hop)).contiguous()
+        dX = torch.empty(B, T, 2 * F, dtype=torch.float32, device=spec.device)
+        s0 = _hip.isi_src(g.data_ptr(), hop, total, 1, total, hop)
+        dst = _hip.isi_dst(dX.data_ptr(), T * 2 * F, 1, T * 2 * F, 2 * F)
+        _hip.check(L.isi_conv2d_f32(C.byref(s0), None, c["istft_conv_w"].data_ptr(), None, None, C.byref(dst),
+                                    B, 1, total // hop, 2 * F, 1, N // hop, 1, 0,
+                                    _gemm._PREC_FLAG[_gemm.LINEAR_PRECISION], _s(spec)), "isi_conv2d_f32 (istft backward)")
+        da, dph = torch.empty_like(a), torch.empty_like(ph)
+        _hip.check(L.isi_spec_to_stft_bwd_f32(a.data_ptr(), ph.data_ptr(), dX.data_ptr(), da.data_ptr(), dph.data_ptr(),
+                                              B * T, F, int(self.mel), _s(spec)), "isi_spec_to_stft_bwd_f32")
+        da, dph = self._unproject_bwd(da, dph)
+        dspec = torch.empty_like(spec)
+        _hip.check(L.isi_spec_inverse_prepare_bwd_f32(spec.data_ptr(), da.contiguous().data_ptr(),
+                                                      dph.contiguous().data_ptr(), dspec.data_ptr(), B, T, F, _s(spec)),
+                   "isi_spec_inverse_prepare_bwd_f32")
+        return dspec
 
     def from_wavfile(self, *args, **kwargs):
         raise NotImplementedError("decoding audio files needs torchaudio / soundfile, which this image lacks")
+
+
+class _ToAudioFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec, helper):
+        audio, saved = helper._to_audio(spec, keep=True)
+        ctx.helper = helper
+        ctx.save_for_backward(*saved)
+        return audio
+
+    @staticmethod
+    def backward(ctx, d_audio):
+        return ctx.helper._to_audio_backward(ctx.saved_tensors, d_audio.contiguous()), None
 
 
 class MelSpectrogramsHelper(SpectrogramsHelper):
@@ -194,7 +245,8 @@ class MelSpectrogramsHelper(SpectrogramsHelper):
         s = (m @ mt).sum(0)
         minv = mt * torch.where(s.abs() > 1e-8, 1.0 / s, s)[None, :]   # [mel, linear]
         return {"mel_w": _gemm.pack_linear_weight(m.t().contiguous().float().to(device)),      # Linear [mel out, linear in]
-                "mel_inv_w": _gemm.pack_linear_weight(minv.t().contiguous().float().to(device))}
+                "mel_inv_w": _gemm.pack_linear_weight(minv.t().contiguous().float().to(device)),
+                "mel_inv_wT": _gemm.pack_linear_weight(minv.contiguous().float().to(device))}     # adjoint (backward)
 
     def _project(self, a, ph):
         c = self._build(a.device)
@@ -203,3 +255,7 @@ class MelSpectrogramsHelper(SpectrogramsHelper):
     def _unproject(self, a, ph):
         c = self._build(a.device)
         return _gemm.linear(a, c["mel_inv_w"], None, self.n_bins), _gemm.linear(ph, c["mel_inv_w"], None, self.n_bins)
+
+    def _unproject_bwd(self, da, dph):
+        c = self._build(da.device)
+        return _gemm.linear(da, c["mel_inv_wT"], None, self.n_bins), _gemm.linear(dph, c["mel_inv_wT"], None, self.n_bins)

@@ -106,6 +106,14 @@ int isi_spec_distance_bwd_f32(const float *xp, const float *xt, float *dx, const
                               int T, int F, int RS, float eps, int kind, void *stream) {
   return spec_distance_bwd_f32(xp, xt, dx, clin, clog, B, T, F, RS, eps, kind, S(stream));
 }
+int isi_spec_to_stft_bwd_f32(const float *a, const float *ph, const float *dx, float *da, float *dph, int64_t rows, int F,
+                             int mel, void *stream) {
+  return spec_to_stft_bwd_f32(a, ph, dx, da, dph, rows, F, mel, S(stream));
+}
+int isi_spec_inverse_prepare_bwd_f32(const float *spec, const float *da, const float *dph, float *dspec, int B, int T,
+                                     int F, void *stream) {
+  return spec_inverse_prepare_bwd_f32(spec, da, dph, dspec, B, T, F, S(stream));
+}
 int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
                         void *stream) {
   return overlap_add_f32(frames, audio, B, T, n_fft, hop, left, L, S(stream));

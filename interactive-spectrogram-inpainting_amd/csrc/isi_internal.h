@@ -100,6 +100,10 @@ int spec_distance_fwd_f32(const float *xp, const float *xt, float *partial, int 
                           int rows_per_block, hipStream_t st);
 int spec_distance_bwd_f32(const float *xp, const float *xt, float *dx, const float *clin, const float *clog, int B, int T,
                           int F, int RS, float eps, int kind, hipStream_t st);
+int spec_to_stft_bwd_f32(const float *a, const float *ph, const float *dx, float *da, float *dph, int64_t rows, int F,
+                         int mel, hipStream_t st);
+int spec_inverse_prepare_bwd_f32(const float *spec, const float *da, const float *dph, float *dspec, int B, int T, int F,
+                                 hipStream_t st);
 int overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, int hop, int left, int64_t L,
                     hipStream_t st);
 

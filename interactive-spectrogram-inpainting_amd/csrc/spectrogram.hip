@@ -278,6 +278,91 @@ int spec_distance_bwd_f32(const float *xp, const float *xt, float *dx, const flo
   return check_launch("spec_distance_bwd");
 }
 
+// ---------------------------------------------------------------- backward of the inverse front-end (to_audio)
+// Adjoint of spec_to_stft_kernel: (d_a, d_ph) from d stft; a = mel ? power : magnitude (the forward's input).
+__global__ void spec_to_stft_bwd_kernel(const float *__restrict__ a, const float *__restrict__ ph,
+                                        const float *__restrict__ dx, float *__restrict__ da, float *__restrict__ dph,
+                                        int64_t rows, int F, int mel) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * F) return;
+  const int64_t r = i / F;
+  const int f = (int)(i - r * F);
+  const float av = a[i];
+  float mag = av, dmag_da = 1.f;
+  if (mel) {
+    const float pw = fmaxf(av, 0.f) + SPEC_EPS;
+    mag = expf(0.5f * logf(pw));
+    dmag_da = av > 0.f ? 0.5f * mag / pw : 0.f;
+  }
+  float sn, cs;
+  sincosf(ph[i], &sn, &cs);
+  const float gr = dx[r * 2 * F + f], gi = dx[r * 2 * F + F + f];
+  da[i] = (gr * cs + gi * sn) * dmag_da;
+  dph[i] = mag * (gi * cs - gr * sn);
+}
+
+// Adjoint of spec_inverse_prepare_kernel: d spec [B,2,F,T] from d_a, d_ph [B,T,F]:
+//   d ch0 = d_a * exp(ch0) ;  d ch1 = pi * (sum over later frames of d_ph)   (reverse running sum, tile by tile)
+__global__ __launch_bounds__(256) void spec_inverse_prepare_bwd_kernel(const float *__restrict__ spec,
+                                                                       const float *__restrict__ da,
+                                                                       const float *__restrict__ dph,
+                                                                       float *__restrict__ dspec, int T, int F) {
+  __shared__ float ta[32][33], tp[32][33];
+  __shared__ float carry[32];
+  const int f0 = blockIdx.x * 32, b = blockIdx.y;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (threadIdx.x < 32) carry[threadIdx.x] = 0.f;
+  for (int t0 = ((T - 1) / 32) * 32; t0 >= 0; t0 -= 32) {
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {  // rows = frames, unit stride along f
+      const int t = t0 + i, f = f0 + tx;
+      float va = 0.f, vp = 0.f;
+      if (t < T && f < F) {
+        const size_t o = ((size_t)b * T + t) * F + f;
+        va = da[o];
+        vp = dph[o];
+      }
+      ta[tx][i] = va;   // [f][t]
+      tp[tx][i] = vp;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {  // reverse scan of one frequency's 32 frames
+      float run = carry[threadIdx.x];
+      for (int j = 31; j >= 0; --j) {
+        run += tp[threadIdx.x][j];
+        tp[threadIdx.x][j] = run;
+      }
+      carry[threadIdx.x] = run;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {  // rows = frequencies, unit stride along t
+      const int f = f0 + i, t = t0 + tx;
+      if (f < F && t < T) {
+        const size_t o0 = (((size_t)b * 2 + 0) * F + f) * T + t, o1 = (((size_t)b * 2 + 1) * F + f) * T + t;
+        dspec[o0] = ta[i][tx] * expf(spec[o0]);
+        dspec[o1] = tp[i][tx] * PI_F;
+      }
+    }
+  }
+}
+
+int spec_to_stft_bwd_f32(const float *a, const float *ph, const float *dx, float *da, float *dph, int64_t rows, int F,
+                         int mel, hipStream_t st) {
+  if (!a || !ph || !dx || !da || !dph || rows <= 0 || F <= 0) return invalid("spec_to_stft_bwd: bad argument");
+  const int64_t n = rows * F;
+  hipLaunchKernelGGL(spec_to_stft_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, ph, dx, da, dph, rows,
+                     F, mel);
+  return check_launch("spec_to_stft_bwd");
+}
+
+int spec_inverse_prepare_bwd_f32(const float *spec, const float *da, const float *dph, float *dspec, int B, int T, int F,
+                                 hipStream_t st) {
+  if (!spec || !da || !dph || !dspec || B <= 0 || T <= 0 || F <= 0 || B > 65535)
+    return invalid("spec_inverse_prepare_bwd: bad argument");
+  hipLaunchKernelGGL(spec_inverse_prepare_bwd_kernel, dim3((F + 31) / 32, B), dim3(256), 0, st, spec, da, dph, dspec, T, F);
+  return check_launch("spec_inverse_prepare_bwd");
+}
+
 int spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel, hipStream_t st) {
   if (!stft || !a || !ph || B <= 0 || T <= 0 || F <= 0 || B > 65535) return invalid("spec_polar: bad argument");
   hipLaunchKernelGGL(spec_polar_kernel, dim3((F + 255) / 256, B), dim3(256), 0, st, stft, a, ph, T, F, mel);

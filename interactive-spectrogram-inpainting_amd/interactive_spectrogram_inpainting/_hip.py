@@ -148,6 +148,8 @@ SIGNATURES = {
                                            C.c_float, C.c_int, _P]),
     "isi_spec_distance_fwd_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
     "isi_spec_distance_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P]),
+    "isi_spec_to_stft_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "isi_spec_inverse_prepare_bwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "isi_overlap_add_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P]),
     "isi_rel_attention_f32": (C.c_int, [C.POINTER(isi_attn_args), _P]),
     "isi_rel_attention_bwd_workspace_floats": (C.c_size_t, [C.POINTER(isi_attn_args)]),

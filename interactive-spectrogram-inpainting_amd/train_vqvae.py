@@ -123,6 +123,22 @@ class SyntheticSpectrograms(torch.utils.data.Dataset):
         return (x,)
 
 
+def get_reconstruction_criterion(criterion_id: str, spectrograms_helper=None):
+    """reference train_vqvae.py:82-98: 'MSE' on the spectrograms, or a multi-scale spectral loss on the audio both
+    spectrograms invert to ('Jukebox' / 'DDSP'; needs the helper that defines the inversion)."""
+    if criterion_id == 'MSE':
+        return nn.MSELoss()
+    from interactive_spectrogram_inpainting.utils.losses.spectral import (
+        DDSPMultiscaleSpectralLoss_fromSpectrogram, JukeboxMultiscaleSpectralLoss_fromSpectrogram)
+    if criterion_id in ('Jukebox', 'JukeboxMultiscaleSpectralLoss'):
+        assert spectrograms_helper is not None
+        return JukeboxMultiscaleSpectralLoss_fromSpectrogram(spectrograms_helper)
+    if criterion_id in ('DDSP', 'DDSPMultiscaleSpectralLoss'):
+        assert spectrograms_helper is not None
+        return DDSPMultiscaleSpectralLoss_fromSpectrogram(spectrograms_helper)
+    raise ValueError("Unexpected reconstruction criterion identifier " + criterion_id)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--synthetic", type=int, default=64, help="number of synthetic spectrograms")
@@ -131,6 +147,8 @@ def main():
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--clip-grad-norm", type=float, default=None)
     ap.add_argument("--latent-loss-weight", type=float, default=0.25)
+    ap.add_argument("--reconstruction-criterion", default="MSE",
+                    help="MSE | Jukebox | DDSP (spectral losses invert both spectrograms with the mel helper)")
     ap.add_argument("--dry-run", action="store_true")
     args = ap.parse_args()
 
@@ -146,7 +164,12 @@ def main():
     torch.manual_seed(1)   # identical initial weights on every rank
     model = VQVAE(in_channel=2).to(device)
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
-    criterion = nn.MSELoss()
+    helper = None
+    if args.reconstruction_criterion != "MSE":
+        from GANsynth_pytorch.spectrograms_helper import SpectrogramsHelper
+        # the synthetic spectrograms are [2, 128, 512]: 128 bins <-> n_fft 256, hop 64
+        helper = SpectrogramsHelper(16000, 256, 64, 256).to(device)
+    criterion = get_reconstruction_criterion(args.reconstruction_criterion, helper)
     data = SyntheticSpectrograms(args.synthetic)
     sampler = DistributedEvalSampler(data, shuffle=True, seed=20200117) if world > 1 else None
     loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, sampler=sampler, shuffle=sampler is None,

@@ -206,3 +206,50 @@ def test_spectral_loss_from_spectrogram_runs():
     ref = S.multiscale_spectral_loss(h.to_audio(spec_p).cpu(), h.to_audio(spec_t).cpu(), [2048, 1024, 512],
                                      [1200, 600, 240], 0.80, "mse", 1.0, 0.0)
     assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+
+
+@pytest.mark.parametrize("mel", [False, True])
+def test_to_audio_gradient_against_spec(mel):
+    """Backward of to_audio (framing convolution with the inverse basis, adjoint polar / mel / running-sum kernels)
+    against torch autograd through the CPU specification."""
+    from GANsynth_pytorch.spectrograms_helper import MelSpectrogramsHelper, SpectrogramsHelper
+    from oracle import spectrogram_oracle as S
+    dev = torch.device("cuda:0")
+    n_fft, hop = 256, 64
+    cfg = S.SpecConfig(fs_hz=16000, n_fft=n_fft, hop_length=hop, window_length=n_fft)
+    h = (MelSpectrogramsHelper if mel else SpectrogramsHelper)(16000, n_fft, hop, n_fft).to(dev)
+    g = torch.Generator().manual_seed(9)
+    audio = torch.randn(2, 40 * hop, generator=g) * 0.2
+    spec = S.to_spectrogram(cfg, audio, mel).float()          # a realistic operating point
+    w = torch.randn(2, 40 * hop, generator=g)
+    sd = spec.to(dev).requires_grad_(True)
+    out = h.to_audio(sd)
+    assert out.requires_grad
+    (out * w.to(dev)).sum().backward()
+    sr = spec.double().requires_grad_(True)
+    ref = S.to_audio(cfg, sr, mel)
+    (ref * w.double()).sum().backward()
+    assert (out.detach().cpu() - ref.detach().float()).abs().max() <= 2e-3 * ref.abs().max()
+    gr = sr.grad.float()
+    for ch in (0, 1):
+        err = (sd.grad[:, ch].cpu() - gr[:, ch]).abs().max() / gr[:, ch].abs().max()
+        assert err <= 5e-3, f"channel {ch}: gradient error {err:.3e}"
+
+
+def test_spectral_loss_from_spectrogram_trains():
+    """A `_fromSpectrogram` criterion back-propagates into the predicted spectrogram (and only into it)."""
+    from GANsynth_pytorch.spectrograms_helper import MelSpectrogramsHelper
+    from interactive_spectrogram_inpainting.utils.losses.spectral import DDSPMultiscaleSpectralLoss_fromSpectrogram
+    dev = torch.device("cuda:0")
+    h = MelSpectrogramsHelper(16000, 2048, 512, 2048).to(dev)
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(2, 16000, generator=g).to(dev) * 0.1
+    target = h.to_spectrogram(a)
+    pred = (target + 0.05 * torch.randn(target.shape, generator=g).to(dev)).requires_grad_(True)
+    crit = DDSPMultiscaleSpectralLoss_fromSpectrogram(h)
+    l0 = crit(pred, target)
+    l0.backward()
+    assert pred.grad is not None and torch.isfinite(pred.grad).all() and pred.grad.abs().max() > 0
+    with torch.no_grad():
+        stepped = pred - 1e-2 * pred.grad / pred.grad.abs().max()
+    assert crit(stepped, target).item() < l0.item()         # a small step against the gradient lowers the loss

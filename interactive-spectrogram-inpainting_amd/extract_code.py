@@ -25,7 +25,9 @@ import torch  # noqa: E402
 
 from interactive_spectrogram_inpainting.utils.distributed import is_master_process  # noqa: E402
 
-CodeRow = namedtuple('CodeRow', ['top', 'bottom', 'attributes', 'filename'])
+# the pickled rows name this class by module path: the reference's own (extract_code.py:26-27), so databases written
+# by either code base unpickle in the other
+from interactive_spectrogram_inpainting.utils.datasets.lmdb_dataset import CodeRow  # noqa: E402
 
 
 @torch.no_grad()

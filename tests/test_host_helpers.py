@@ -313,3 +313,100 @@ def test_label_encoders_and_checkpoint_round_trip(tmp_path):
     torch.save(ck, tmp_path / "ck.pt")
     again = torch.load(tmp_path / "ck.pt", weights_only=False)
     assert torch.equal(again["model"]["weight"], lin.weight)
+
+
+class _FakeLMDB:
+    """Dictionary-backed stand-in for the slice of the `lmdb` API the code database uses (the package is not in
+    this image): named sub-databases, write / read transactions, sorted-key cursors, stat()."""
+
+    class _Txn:
+        def __init__(self, env, db):
+            self.env, self.db = env, db
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+        def _table(self, db=None):
+            return self.env.tables[db if db is not None else self.db]
+
+        def put(self, key, value):
+            self._table()[bytes(key)] = bytes(value)
+
+        def get(self, key):
+            return self._table().get(bytes(key))
+
+        def stat(self, db):
+            return {'entries': len(self.env.tables[db])}
+
+        def cursor(self):
+            table = self._table()
+
+            class _Cursor:
+                def first(self):
+                    return bool(table)
+
+                def iternext(self, values=True):
+                    return iter(sorted(table)) if not values else iter(sorted(table.items()))
+            return _Cursor()
+
+    class _Env:
+        def __init__(self):
+            self.tables = {None: {}}
+
+        def open_db(self, name, **kw):
+            self.tables.setdefault(name, {})
+            return name
+
+        def begin(self, db=None, write=False):
+            return _FakeLMDB._Txn(self, db)
+
+    def __init__(self):
+        self.envs = {}
+
+    def open(self, path, **kw):
+        return self.envs.setdefault(path, _FakeLMDB._Env())
+
+
+def test_code_database_round_trip(tmp_path, monkeypatch):
+    """extract_code.lmdb_sink -> utils.datasets.lmdb_dataset.LMDBDataset: the layout of the reference's code
+    database (extract_code.py:47-79, lmdb_dataset.py:15-89): db 'codes', key = note name, value = pickled CodeRow,
+    `label_encoders` entry, label_encoders.json beside it."""
+    import pickle
+    import sys
+    import types
+    from sklearn.preprocessing import LabelEncoder
+    fake = _FakeLMDB()
+    mod = types.ModuleType("lmdb")
+    mod.open = fake.open
+    monkeypatch.setitem(sys.modules, "lmdb", mod)
+    import extract_code
+    from interactive_spectrogram_inpainting.utils.datasets.label_encoders import dump_label_encoders
+    from interactive_spectrogram_inpainting.utils.datasets.lmdb_dataset import CodeRow, LMDBDataset
+    enc = {"pitch": LabelEncoder().fit(list(range(24, 85))), "instrument_family_str": LabelEncoder().fit(["bass", "flute"])}
+    sink = extract_code.lmdb_sink(tmp_path, enc)
+    rng = np.random.default_rng(0)
+    rows = {}
+    for name in ("guitar_001-060-100", "bass_004-030-050", "flute_002-072-127"):
+        row = extract_code.CodeRow(top=rng.integers(0, 512, (16, 64)), bottom=rng.integers(0, 512, (32, 128)),
+                                   attributes={"pitch": torch.tensor(int(name[-7:-4]) - 24),
+                                               "instrument_family_str": torch.tensor(0)}, filename=name)
+        sink(name, row)
+        rows[name] = row
+    env = fake.envs[str(tmp_path)]
+    assert set(env.tables[b'codes']) == {n.encode() for n in rows}
+    assert set(pickle.loads(env.tables[None][b'label_encoders'])) == set(enc)
+    assert isinstance(pickle.loads(env.tables[b'codes'][b'bass_004-030-050']), extract_code.CodeRow)
+    dump_label_encoders(enc, tmp_path)
+    ds = LMDBDataset(tmp_path, classes_for_conditioning=["pitch"])
+    assert len(ds) == 3 and set(ds.label_encoders) == {"pitch"}
+    names = sorted(rows)                                       # LMDB iterates keys in byte order
+    for i, name in enumerate(names):
+        top, bottom, attributes = ds[i]
+        assert top.dtype == torch.int64 and torch.equal(top, torch.from_numpy(rows[name].top))
+        assert torch.equal(bottom, torch.from_numpy(rows[name].bottom))
+        assert list(attributes) == ["pitch"] and attributes["pitch"].shape == (1,)
+        assert int(attributes["pitch"]) == int(rows[name].attributes["pitch"])
+    assert CodeRow._fields == extract_code.CodeRow._fields == ('top', 'bottom', 'attributes', 'filename')

@@ -144,6 +144,9 @@ def main(argv=None):
     ap.add_argument('--top_shape', type=int, nargs=2, default=[32, 32])
     ap.add_argument('--num_encoder_layers', type=int, default=6)
     ap.add_argument('--num_decoder_layers', type=int, default=8)
+    ap.add_argument('--database_path', default=None,
+                    help="code database written by extract_code.py (LMDB, needs the `lmdb` package); "
+                         "default: synthetic code maps")
     args = ap.parse_args(argv)
 
     distributed = 'RANK' in __import__('os').environ
@@ -168,9 +171,15 @@ def main(argv=None):
     else:
         model = UpsamplingVQTransformer(shape=bottom_shape, condition_shape=top_shape, **common)
     model = model.to(device)
-    data = SyntheticCodes(args.batch_size * args.num_batches, top_shape, bottom_shape, args.n_class, classes,
-                          seed=dist.get_rank() if distributed else 0)
-    loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False)
+    if args.database_path is not None:   # train_autoregressive_model.py:330-352 of the reference
+        from interactive_spectrogram_inpainting.utils.datasets.lmdb_dataset import LMDBDataset
+        data = LMDBDataset(args.database_path, classes_for_conditioning=list(classes))
+        sampler_d = torch.utils.data.distributed.DistributedSampler(data) if distributed else None
+        loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=sampler_d is None, sampler=sampler_d)
+    else:
+        data = SyntheticCodes(args.batch_size * args.num_batches, top_shape, bottom_shape, args.n_class, classes,
+                              seed=dist.get_rank() if distributed else 0)
+        loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False)
     optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
     scheduler = CycleScheduler(optimizer, args.lr, n_iter=len(loader) * args.num_epochs)
     criterion = LabelSmoothingLoss(args.n_class, args.label_smoothing, dim=1)

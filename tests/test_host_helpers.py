@@ -410,3 +410,40 @@ def test_code_database_round_trip(tmp_path, monkeypatch):
         assert list(attributes) == ["pitch"] and attributes["pitch"].shape == (1,)
         assert int(attributes["pitch"]) == int(rows[name].attributes["pitch"])
     assert CodeRow._fields == extract_code.CodeRow._fields == ('top', 'bottom', 'attributes', 'filename')
+
+
+def test_normalizer_statistics_and_spectral_basis_host_side():
+    """Host-side constants of the front-end extras, checked without a GPU: DataNormalizer's measured statistics
+    against the CPU specification, and the multi-scale loss's windowed DFT basis (window centred inside n_fft,
+    hop = ceil((1 - overlap) * window), g = gcd(hop, n_fft) view) against torch.stft frames."""
+    import math
+    from GANsynth_pytorch.normalizer import DataNormalizer
+    from interactive_spectrogram_inpainting.utils.losses.spectral import _Scale
+    from oracle import spectrogram_oracle as S
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.randn(2, 2, 8, 12, generator=g) * 3 - 2 for _ in range(3)]
+    st = DataNormalizer._measure([(b, None) for b in batches], 0.8, 1.0)
+    ref = S.normalizer_statistics(batches)
+    assert all(abs(st[k] - ref[k]) <= 1e-12 * max(1.0, abs(ref[k])) for k in ref)
+    y = S.normalize(torch.cat(batches), ref)
+    assert abs(float(y[:, 0].max()) - 0.8) < 1e-5 and abs(float(y[:, 0].min()) + 0.8) < 1e-5
+    assert abs(float(y[:, 1].max()) - 1.0) < 1e-5 and abs(float(y[:, 1].min()) + 1.0) < 1e-5
+    for n_fft, win, overlap in ((64, 64, 0.75), (2048, 1200, 0.80), (256, 200, 0.75)):
+        sc = _Scale(n_fft, win, overlap)
+        assert sc.hop == math.ceil((1 - overlap) * win) and sc.hop % sc.g == 0 and n_fft % sc.g == 0
+        N, F = n_fft, sc.F
+        w = torch.zeros(N, dtype=torch.float64)
+        left = (N - win) // 2
+        w[left:left + win] = torch.hann_window(win, dtype=torch.float64)
+        n = torch.arange(N, dtype=torch.float64)
+        k = torch.arange(F, dtype=torch.float64)
+        ang = 2 * math.pi * k[:, None] * n[None, :] / N
+        basis = torch.cat([torch.cos(ang) * w, -torch.sin(ang) * w], 0)          # what _Scale.build packs
+        audio = torch.randn(1, N + 3 * sc.hop, generator=g, dtype=torch.float64)
+        X = torch.stft(audio, n_fft=N, hop_length=sc.hop, win_length=win, window=torch.hann_window(win, dtype=torch.float64),
+                       center=False, return_complex=True)[0]                        # [F, T]
+        assert X.shape[1] == sc.frames(audio.shape[1]) == 4
+        for t in range(4):
+            frame = audio[0, t * sc.hop:t * sc.hop + N]
+            mine = basis @ frame
+            assert (mine[:F] - X[:, t].real).abs().max() < 1e-9 and (mine[F:] - X[:, t].imag).abs().max() < 1e-9

@@ -230,7 +230,7 @@ static int launch_small(const ConvTSmallArgs &a, int B, hipStream_t stream) {
   const double M = (double)B * a.H * a.W;
   prof::Scope scope(prof::K_CONVT_SMALL, 2.0 * M * 16 * a.Cin * a.Cout,
                     4.0 * (M * a.Cin + 4.0 * M * a.Cout + 16.0 * a.Cin * a.Cout), stream);
-  hipLaunchKernelGGL(kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(256), smem, stream, a);
+  ISI_PROF_LAUNCH(scope, kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(256), smem, stream, a);
   return check_launch("convT_k4s2_small_f32");
 }
 

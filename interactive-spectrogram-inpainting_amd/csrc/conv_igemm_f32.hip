@@ -488,7 +488,7 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
     const int kid = PREC == 2 ? prof::K_CONV_BF16X6 : PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
                              : (BN == 128 ? prof::K_CONV_128x128 : BN == 64 ? prof::K_CONV_128x64 : prof::K_CONV_128x32);
     prof::Scope scope(kid, flops, bytes, stream);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, a);
+    ISI_PROF_LAUNCH(scope, kern, grid, dim3(256), smem, stream, a);
   }
   return check_launch("conv_igemm_f32");
 }

@@ -52,12 +52,10 @@ Scope::Scope(int kernel_id, double flops, double bytes, hipStream_t s) : slot(-1
   auto ev = g.pool[g.used++];
   g.recs.push_back(Record{kernel_id, flops, bytes, ev.first, ev.second});
   slot = (int)g.recs.size() - 1;
-  (void)hipEventRecord(ev.first, stream);
 }
 
-Scope::~Scope() {
-  if (slot >= 0) (void)hipEventRecord(g.recs[slot].stop, stream);
-}
+hipEvent_t Scope::start() const { return g.recs[slot].start; }
+hipEvent_t Scope::stop() const { return g.recs[slot].stop; }
 
 int enable(int on) {
   if (on) {

@@ -2,6 +2,7 @@
 // to price each kernel against its roofline.  Off by default; when off the cost
 // is one thread-local load per launch.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 namespace isi {
@@ -24,13 +25,24 @@ enum KernelId {
 
 const char *kernel_name(int id);
 bool enabled();
-// Records start/stop events around a launch when profiling is on.
+// One record (kernel id, algorithmic work, a start / stop event pair) per launch when profiling is on.  The events
+// are handed to hipExtLaunchKernelGGL (ISI_PROF_LAUNCH): the dispatch packet's own start / end timestamps are
+// used, no extra event packets enter the stream (hipEventRecord pairs cost ~5 % of a forward's stream time).
 struct Scope {
   Scope(int kernel_id, double flops, double bytes, hipStream_t stream);
-  ~Scope();
   int slot;
   hipStream_t stream;
+  hipEvent_t start() const;
+  hipEvent_t stop() const;
 };
+
+#define ISI_PROF_LAUNCH(scope, kern, grid, block, smem, stream, ...)                                              \
+  do {                                                                                                            \
+    if ((scope).slot >= 0)                                                                                        \
+      hipExtLaunchKernelGGL(kern, grid, block, smem, stream, (scope).start(), (scope).stop(), 0, __VA_ARGS__);    \
+    else                                                                                                          \
+      hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__);                                           \
+  } while (0)
 
 int enable(int on);
 int read(int kernel_id, long long *launches, double *ms, double *flops, double *bytes);

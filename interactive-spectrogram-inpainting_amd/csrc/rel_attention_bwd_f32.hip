@@ -1339,14 +1339,14 @@ static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 5 : 4),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 4.0 * a.Sk), stream);
-    hipLaunchKernelGGL(kkv, dim3((a.Sk + QB - 1) / QB, a.H, a.B), dim3(512), smem_kv, stream, a);
+    ISI_PROF_LAUNCH(scope, kkv, dim3((a.Sk + QB - 1) / QB, a.H, a.B), dim3(512), smem_kv, stream, a);
   }
   int rc = check_launch("rel_attention_bwd_kv_split");
   if (rc) return rc;
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 4 : 3),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 2.0 * a.Sk), stream);
-    hipLaunchKernelGGL(kq, dim3((a.Sq + QB - 1) / QB, a.H, a.B), dim3(512), smem_q, stream, a);
+    ISI_PROF_LAUNCH(scope, kq, dim3((a.Sq + QB - 1) / QB, a.H, a.B), dim3(512), smem_q, stream, a);
   }
   return check_launch("rel_attention_bwd_q_split");
 }
@@ -1367,14 +1367,14 @@ static int launch_bwd(const AttnBwdKArgs &a, hipStream_t stream) {
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 5 : 4),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 4.0 * a.Sk), stream);
-    hipLaunchKernelGGL(kkv, dim3((a.Sk + QB - 1) / QB, a.H, a.B), dim3(256), smem, stream, a);
+    ISI_PROF_LAUNCH(scope, kkv, dim3((a.Sk + QB - 1) / QB, a.H, a.B), dim3(256), smem, stream, a);
   }
   int rc = check_launch("rel_attention_bwd_kv");
   if (rc) return rc;
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 4 : 3),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 2.0 * a.Sk), stream);
-    hipLaunchKernelGGL(kq, dim3((a.Sq + QB - 1) / QB, a.H, a.B), dim3(256), smem, stream, a);
+    ISI_PROF_LAUNCH(scope, kq, dim3((a.Sq + QB - 1) / QB, a.H, a.B), dim3(256), smem, stream, a);
   }
   return check_launch("rel_attention_bwd_q");
 }

@@ -731,7 +731,7 @@ static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * B;
   prof::Scope scope(prof::K_REL_ATTENTION, 2.0 * pairs * HD * (a.e ? 3 : 2),
                     4.0 * B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), stream);
-  hipLaunchKernelGGL(kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(512), smem, stream, a);
+  ISI_PROF_LAUNCH(scope, kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(512), smem, stream, a);
   return check_launch("rel_attention_f32");
 }
 

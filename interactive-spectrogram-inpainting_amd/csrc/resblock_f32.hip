@@ -375,7 +375,7 @@ static int launch_res_t(const ResKArgs &a, int B, hipStream_t stream) {
   const double C = a.C, R = a.R, M = (double)B * a.H * a.W;
   prof::Scope scope(prof::K_RESBLOCK, 2.0 * M * R * 9 * C + 2.0 * M * C * R,
                     4.0 * (2.0 * M * C + 10.0 * C * R), stream);
-  hipLaunchKernelGGL(kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(TH * 128), smem, stream, a);
+  ISI_PROF_LAUNCH(scope, kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(TH * 128), smem, stream, a);
   return check_launch("resblock_f32");
 }
 

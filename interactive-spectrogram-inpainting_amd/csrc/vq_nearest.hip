@@ -198,7 +198,7 @@ static int launch_vq(const float *z, const float *codes, const float *e2, int64_
   {
     prof::Scope scope(prof::K_VQ_NEAREST, 2.0 * N * K * D, 4.0 * (2.0 * N * D + (double)K * D) + 8.0 * N,
                       stream);
-    hipLaunchKernelGGL(kern, dim3(vq_grid(N)), dim3(VQ_BLOCK), smem, stream, z, codes, e2, idx, q,
+    ISI_PROF_LAUNCH(scope, kern, dim3(vq_grid(N)), dim3(VQ_BLOCK), smem, stream, z, codes, e2, idx, q,
                        counts, sse_part, N, K);
   }
   return check_launch("vq_nearest_f32");

@@ -274,15 +274,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
   const int chunk_end = min(nchunks_total, chunk_begin + p.chunks_per_split);
 
   float4 rdq[4], rxq[4];
+  // (batch, row, column) of this thread's four pixels, carried from chunk to chunk (chunks are visited in
+  // order: + 32 pixels each) instead of two integer divisions per pixel and chunk
+  int pb[4], py_[4], px4[4];
+  const int adv_b = 32 / (p.OH * p.OW), adv_r = 32 - adv_b * (p.OH * p.OW);
+  const int adv_y = adv_r / p.OW, adv_x = adv_r - adv_y * p.OW;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = chunk_begin * 32 + 4 * pg + j;
+    pb[j] = m / (p.OH * p.OW);
+    const int rem = m - pb[j] * (p.OH * p.OW);
+    py_[j] = rem / p.OW;
+    px4[j] = rem - py_[j] * p.OW;
+  }
   auto load_chunk = [&](int ch) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = ch * 32 + 4 * pg + j;
       unsigned doff = OOB, xoff = OOB;
       if (m < p.M) {
-        const int b = m / (p.OH * p.OW);
-        const int rem = m - b * (p.OH * p.OW);
-        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int b = pb[j], oy = py_[j], ox = px4[j];
         if (covalid) doff = (unsigned)(dy_off + b * p.dn + oy * p.dh + ox * p.dw + co) * 4u;
         const int iy = oy * p.stride - pad_y + kh, ix = ox * p.stride - pad_x + kw;
         if (kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
@@ -291,6 +302,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
       }
       rdq[j] = buf_load4(rd, doff);
       rxq[j] = second ? buf_load4(r1, xoff) : buf_load4(r0, xoff);
+      // next chunk: + 32 pixels = adv_b images + adv_y rows + adv_x columns, one carry each (branch-free)
+      px4[j] += adv_x;
+      const int c1 = px4[j] >= p.OW ? 1 : 0;
+      px4[j] -= c1 ? p.OW : 0;
+      py_[j] += adv_y + c1;
+      const int c2 = py_[j] >= p.OH ? 1 : 0;
+      py_[j] -= c2 ? p.OH : 0;
+      pb[j] += adv_b + c2;
     }
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's 4 channels of dY over its pixel group, all chunks

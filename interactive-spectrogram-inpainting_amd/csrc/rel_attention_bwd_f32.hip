@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_q_kernel(const AttnBwdK
           const int qq = 2 * it + half;
           const float val = tb[ql * TLD + qq];
           const int q = qw0 + qq;
-          const int rho = q / p.Cq - kev + p.Ek - 1;
+          const int rho = __shfl(evq, qq) - kev + p.Ek - 1;   // lane qq holds event(query qw0 + qq): no division here
           const int col = rho - p.rho_lo;
           if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp)
             unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
           const int qq = 2 * it + half;
           const float val = tb[ql * SRL + qq];
           const int q = qw0 + qq;
-          const int rho = q / p.Cq - kev + p.Ek - 1;
+          const int rho = __shfl(evq, qq) - kev + p.Ek - 1;   // lane qq holds event(query qw0 + qq): no division here
           const int col = rho - p.rho_lo;
           if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp)
             unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);

@@ -50,10 +50,17 @@ def _spec_attention(q, k, v, rel, H, Cq, Ck, Ek, mask):
     (16, 4, 33, 33, 1, 1, 1, True), (16, 4, 33, 33, 1, 1, 2, True), (32, 2, 132, 33, 4, 1, 0, True),
     (64, 2, 200, 200, 1, 1, 1, True), (32, 3, 260, 260, 4, 4, 1, True), (64, 2, 77, 150, 2, 1, 0, True),
     (64, 2, 150, 150, 1, 1, 1, False), (32, 2, 40, 70, 1, 2, 0, False),
+    # degenerate / boundary shapes: one query (over two keys: with a single key every gradient but dV is
+    # identically zero and a relative comparison is meaningless), exactly one tile, a tile boundary + 1
+    (16, 2, 1, 2, 1, 1, 0, True), (64, 1, 1, 97, 1, 1, 0, True), (32, 2, 64, 64, 1, 1, 2, True),
+    (64, 2, 129, 129, 1, 1, 1, True),
 ])
-def test_rel_attention_backward_against_spec(hd, H, Sq, Sk, Cq, Ck, mode, bias):
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_rel_attention_backward_against_spec(hd, H, Sq, Sk, Cq, Ck, mode, bias, precision, monkeypatch):
     from oracle import prior_oracle as P
+    from interactive_spectrogram_inpainting.priors import _ops
     from interactive_spectrogram_inpainting.priors._train import RelAttentionFn
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", precision)   # exact-fp32 and split-bf16 kernels, one tolerance
     torch.manual_seed(hd + Sq + mode)
     d, B = hd * H, 2
     Eq, Ek = -(-Sq // Cq), -(-Sk // Ck)

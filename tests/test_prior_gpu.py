@@ -279,6 +279,34 @@ def test_sample_model_matches_full_pass_sampling(golden_dir):
     assert out_b.shape == (B, 16, 8) and int(out_b.min()) >= 0 and int(out_b.max()) < 32
 
 
+def test_sample_model_edge_masks(golden_dir):
+    """Empty mask (nothing to resample), a single masked token, the last token only, batch 1 vs the same row of
+    a batch: the KV-cached loop keeps every unmasked code and its draws do not depend on the batch composition."""
+    import sample as S
+    z, top, bottom = _models(golden_dir)
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    init = torch.randint(0, 32, (3, 8, 4), generator=g)
+    cls = {"pitch": torch.tensor([20]), "instrument_family_str": torch.tensor([3])}
+    S_len = top.target_transformer_sequence_length
+    uni = torch.rand(S_len, 3, generator=g)
+    none = torch.zeros(1, 8, 4, dtype=torch.bool)
+    out = S.sample_model(top, dev, 3, [8, 4], temperature=1.0, class_conditioning=cls, initial_code=init.clone(),
+                         mask=none, uniforms=uni)
+    assert torch.equal(out.cpu(), init)
+    for pos in ((0, 0), (3, 2), (7, 3)):
+        m = none.clone()
+        m[0, pos[0], pos[1]] = True
+        out = S.sample_model(top, dev, 3, [8, 4], temperature=1.0, class_conditioning=cls, initial_code=init.clone(),
+                             mask=m, uniforms=uni)
+        keep = ~m.expand(3, -1, -1)
+        assert torch.equal(out.cpu()[keep], init[keep]) and 0 <= int(out.min()) and int(out.max()) < 32
+        # row 1 alone, with its own column of uniforms, reproduces row 1 of the batch
+        solo = S.sample_model(top, dev, 1, [8, 4], temperature=1.0, class_conditioning=cls,
+                              initial_code=init[1:2].clone(), mask=m, uniforms=uni[:, 1:2].contiguous())
+        assert torch.equal(solo[0], out[1])
+
+
 def test_inpainting_operations(golden_dir):
     """The compute behind the reference's /timerange-change, /generate, /erase and /get-audio routes
     (flask_server.py:376-443,685-931,1003-1021): regenerated zones stay inside the mask and the model

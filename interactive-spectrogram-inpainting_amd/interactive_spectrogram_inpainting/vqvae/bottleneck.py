@@ -58,7 +58,9 @@ class QuantizedBottleneck(nn.Module):
         return _ops.vq_nearest(input, codes, e2)
 
     def embed_code(self, embed_id: Tensor) -> Tensor:
-        if embed_id.numel() and (int(embed_id.min()) < 0 or int(embed_id.max()) >= self.n_embed):
+        # range check on the host like F.embedding's (one device sync; skipped while a HIP graph is being captured)
+        if embed_id.numel() and embed_id.is_cuda and not torch.cuda.is_current_stream_capturing() and \
+                (int(embed_id.min()) < 0 or int(embed_id.max()) >= self.n_embed):
             raise IndexError("index out of range in self")  # same failure class as F.embedding
         codes, _ = self.packed()
         return _ops.embed_code(embed_id, codes)

@@ -145,6 +145,44 @@ def _top_prior(device):
         class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device)
 
 
+def _timerange_change(device, vqvae, calls=3):
+    """SURVEY 8d metric 2, second half: latency of one /timerange-change-equivalent request
+    (flask_server.py:685-870): layer 'top', mask = half of the top codemap's columns -> the top prior resamples
+    512 codes, the bottom prior the 2048 codes under the up-sampled mask, then VQ-VAE decode_code of the new
+    maps.  Top [32,32] / bottom [64,64] priors (d_model 512, 6+8 layers), random weights."""
+    import inpainting
+    from interactive_spectrogram_inpainting.priors.transformer import UpsamplingVQTransformer
+    top = _top_prior(device).eval()
+    torch.manual_seed(3)
+    bottom = UpsamplingVQTransformer(
+        shape=[64, 64], condition_shape=[32, 32], n_class=512, channel=256, kernel_size=5, n_block=4,
+        n_res_block=4, res_channel=256, d_model=512, embeddings_dim=32, positional_embeddings_dim=16,
+        use_relative_transformer=True, predict_frequencies_first=True, conditional_model=True,
+        class_conditioning_prepend_to_dummy_input=True,
+        class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+        class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device).eval()
+    g = torch.Generator().manual_seed(5)
+    top_code = torch.randint(0, 512, (1, 32, 32), generator=g).to(device)
+    bottom_code = torch.randint(0, 512, (1, 64, 64), generator=g).to(device)
+    mask = torch.zeros(1, 32, 32, dtype=torch.bool)
+    mask[..., 8:24] = True
+    cls = {"pitch": torch.tensor([[24]]), "instrument_family_str": torch.tensor([[0]])}
+    times = []
+    for i in range(calls + 1):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        nt, nb = inpainting.timerange_change(top, bottom, top_code, bottom_code, mask, 'top', 0, 1.0, cls, cls, device,
+                                             generator=torch.Generator().manual_seed(i), top_p_sampling_p=0.8)
+        spec = vqvae.decode_code(nt, nb)
+        torch.cuda.synchronize(device)
+        times.append(time.perf_counter() - t0)
+    assert spec.shape == (1, 2, 256, 256) and torch.isfinite(spec).all()
+    times = sorted(times[1:])
+    return {"p50_ms": round(times[len(times) // 2] * 1e3, 1), "calls": calls,
+            "resampled_codes": {"top": 512, "bottom": 2048},
+            "config": "layer 'top', mask = columns 8..23 of the [32,32] top map; bottom [64,64]; + decode_code"}
+
+
 def _prior_training(device, B=8, steps=3):
     """BASELINE config 4 on one GPU: training step of the top prior (1024 tokens + start symbol, d_model 512,
     6 + 8 layers, fp32, dropout 0.1, label smoothing, Adam): forward + loss + backward + optimizer step."""
@@ -350,6 +388,8 @@ def main():
             line["frontend"] = _frontend(device)
             torch.cuda.empty_cache()
             line["prior_sampling"] = _prior_sampling(device)
+            torch.cuda.empty_cache()
+            line["prior_sampling"]["timerange_change"] = _timerange_change(device, model)
             torch.cuda.empty_cache()
             line["prior_training_single_gpu"] = _prior_training(device)
         if not args.no_cpu_baseline and world >= 1:

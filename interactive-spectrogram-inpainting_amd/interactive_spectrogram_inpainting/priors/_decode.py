@@ -144,6 +144,28 @@ class NativeSampler:
         self.state = st
 
     @torch.no_grad()
+    def prefill(self, p0: int) -> None:
+        """Key / value cache rows [0, p0) of every decoder layer from ONE causal pass over those rows (the
+        full-sequence GEMM / attention kernels) instead of p0 single-row steps: what an unmasked prefix of an
+        inpainting request needs -- its codes are known, only its keys and values are read later."""
+        if p0 <= 0:
+            return
+        from VQCPCB.transformer.transformer_custom import _add_norm
+        d = self.model.d_model
+        x = self.x_seq[:p0].contiguous()
+        for l, layer in enumerate(self.model.transformer.decoder.layers):
+            sa = layer.self_attn
+            qkv = sa._project(x, 0)                                  # [p0, B, 3d]
+            self.kv_cache[l, :p0] = qkv[..., d:]
+            a = _ops.rel_attention(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], sa.rel_embeddings, sa.nhead,
+                                   sa.Cq, sa.Ck, sa.Ek, mask_mode=1)
+            x1 = _add_norm(layer, sa.out_proj, a, x, layer.norm1)
+            c = layer.multihead_attn(x1, None, None, kv=self.memory_kv[l])
+            x2 = _add_norm(layer, layer.multihead_attn.out_proj, c, x1, layer.norm2)
+            h = layer.linear1.run(x2, relu=True)
+            x = _add_norm(layer, layer.linear2, h, x2, layer.norm3)
+
+    @torch.no_grad()
     def run(self, p_begin: int, p_end: int, temperature: float, top_k: int, top_p: float) -> None:
         C, _hip = self._C, self._hip
         rc = _hip.lib().isi_prior_sample_run(C.byref(self.w), C.byref(self.state), p_begin, p_end,

@@ -96,11 +96,21 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
     if not code_seq.is_contiguous():
         code_seq = code_seq.contiguous()
     n_pos = S + start_len - 1
+    # Token i is drawn from decoder position i + start_len - 1.  Positions behind the last masked token are
+    # never read; positions before the first one only contribute keys / values, which one batched causal
+    # pass over that prefix provides (an inpainting request masks a window, not the whole map).
+    masked = [i for i, mk in enumerate(mask_seq) if mk]
+    if not masked:
+        return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()
+    p_first, n_pos = masked[0] + start_len - 1, min(n_pos, masked[-1] + start_len)
     if batch_size <= 8:
         # the whole loop natively: no per-token return to Python, no host sync
         sampler = NativeSampler(model, memory, x_seq, code_seq, mask_seq, uniforms)
+        if p_first < 8:
+            p_first = 0                                        # a few rows: not worth a batched pass
+        sampler.prefill(p_first)
         chunk = n_pos if progressbar_decorator is None else 64
-        starts = range(0, n_pos, chunk)
+        starts = range(p_first, n_pos, chunk)
         if progressbar_decorator is not None:
             starts = progressbar_decorator(starts)
         for p0 in starts:

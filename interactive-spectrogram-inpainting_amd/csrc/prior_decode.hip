@@ -164,7 +164,24 @@ __global__ __launch_bounds__(256) void row_linear_ln_kernel(RowLinArgs a) {
   }
 }
 
-int launch_row_linear(const RowLinArgs &a, hipStream_t st) {
+int launch_row_linear_8(const RowLinArgs &a, hipStream_t st);
+
+// more than 8 rows (batched serving): groups of 8 rows, one launch each (the kernel stages its rows in LDS)
+int launch_row_linear(const RowLinArgs &a0, hipStream_t st) {
+  for (int m0 = 0; m0 < a0.M; m0 += 8) {
+    RowLinArgs a = a0;
+    a.M = a0.M - m0 < 8 ? a0.M - m0 : 8;
+    a.x += (size_t)m0 * a.x_stride;
+    if (a.res) a.res += (size_t)m0 * a.res_stride;
+    a.out += (size_t)m0 * a.out_stride;
+    if (a.out2) a.out2 += (size_t)m0 * a.out2_stride;
+    const int rc = launch_row_linear_8(a, st);
+    if (rc) return rc;
+  }
+  return ISI_OK;
+}
+
+int launch_row_linear_8(const RowLinArgs &a, hipStream_t st) {
   const int mr = a.M <= 1 ? 1 : a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;   // the kernel's row capacity (template MR)
   const size_t smem = ((size_t)mr * a.K + 2 * mr) * sizeof(float);
   dim3 grid((a.N + NPB - 1) / NPB), block(256);
@@ -219,7 +236,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
                      int top_k, float top_p, hipStream_t st) {
   if (!w || !s) return invalid("prior_sample_run: null pointer");
   if (w->n_layers <= 0 || w->n_layers > ISI_MAX_LAYERS) return invalid("prior_sample_run: bad layer count");
-  if (s->B <= 0 || s->B > 8) return unsupported("prior_sample_run: batch size must be 1..8");
+  if (s->B <= 0 || s->B > 256) return unsupported("prior_sample_run: batch size must be 1..256");
   if (p_begin < 0 || p_end > s->S_t || p_begin > p_end) return invalid("prior_sample_run: bad position range");
   if (!s->x_seq || !s->kv_cache || !s->memory_kv || !s->codes || !s->mask || !s->uniforms || !s->scratch)
     return invalid("prior_sample_run: null state pointer");

@@ -85,8 +85,8 @@ class NativeSampler:
             raise NotImplementedError(f"more than {_hip.ISI_MAX_LAYERS} decoder layers")
         dev = memory.device
         d, B = model.d_model, x_seq.shape[1]
-        if B > 8:
-            raise NotImplementedError("native sampling supports batch sizes up to 8")
+        if B > 256:
+            raise NotImplementedError("native sampling supports batch sizes up to 256")
         self.model = model
         self.keep = []
         w = _hip.isi_prior_w()

@@ -103,7 +103,7 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
     if not masked:
         return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()
     p_first, n_pos = masked[0] + start_len - 1, min(n_pos, masked[-1] + start_len)
-    if batch_size <= 8:
+    if batch_size <= 256:
         # the whole loop natively: no per-token return to Python, no host sync
         sampler = NativeSampler(model, memory, x_seq, code_seq, mask_seq, uniforms)
         if p_first < 8:

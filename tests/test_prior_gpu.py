@@ -307,6 +307,23 @@ def test_sample_model_edge_masks(golden_dir):
         assert torch.equal(solo[0], out[1])
 
 
+def test_sample_model_large_batch(golden_dir):
+    """More than 8 sequences per call (the row kernels take groups of 8 rows): every row equals its single-sequence run."""
+    import sample as S
+    z, top, bottom = _models(golden_dir)
+    dev = _dev()
+    B = 11
+    g = torch.Generator().manual_seed(13)
+    cls = {"pitch": torch.tensor([20]), "instrument_family_str": torch.tensor([3])}
+    uni = torch.rand(top.target_transformer_sequence_length, B, generator=g)
+    out = S.sample_model(top, dev, B, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9, uniforms=uni)
+    assert out.shape == (B, 8, 4)
+    for b in (0, 7, 8, 10):
+        solo = S.sample_model(top, dev, 1, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9,
+                              uniforms=uni[:, b:b + 1].contiguous())
+        assert torch.equal(solo[0], out[b]), b
+
+
 def test_inpainting_operations(golden_dir):
     """The compute behind the reference's /timerange-change, /generate, /erase and /get-audio routes
     (flask_server.py:376-443,685-931,1003-1021): regenerated zones stay inside the mask and the model

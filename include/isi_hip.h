@@ -372,7 +372,7 @@ size_t isi_prior_decode_scratch_floats(const isi_prior_w *w, int B);
 /* Enqueues positions [p_begin, p_end) of the decoder (one new row each, all layers),
  * and for every masked position the logits head, the draw (isi_sample_row_f32
  * semantics) and the write of the sampled token into codes / the next input row.
- * No host synchronisation.  B <= 8. */
+ * No host synchronisation.  B <= 256 (rows are processed in groups of 8). */
 int isi_prior_sample_run(const isi_prior_w *w, const isi_prior_state *state, int p_begin,
                          int p_end, float temperature, int top_k, float top_p, void *stream);
 

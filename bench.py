@@ -311,7 +311,7 @@ def main():
         try:
             pmc = json.load(open(ROOT / "profiles" / "r01_pmc_hbm_traffic.json"))
             # rocprof names of the launches the dominant profiling id covers (template tail = MODE, PREC)
-            tail = {"bf16x6": ", 0, 2>", "bf16x3": ", 0, 1>"}
+            tail = {"bf16x6": ", 0, 2>", "bf16x3": ", 0, 1>", "f16x3": ", 0, 3>"}
             want = next((t for k, t in tail.items() if k in dom["kernel"]), "<128, 128, 2, 2, 0, 0>")
             tot_b = tot_n = 0.0
             for name, d in pmc.items():
@@ -323,8 +323,9 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        # a split-bf16 kernel spends three bf16 MFMA products per algorithmic product
-        terms = 6.0 if "bf16x6" in dom["kernel"] else 3.0 if "bf16x3" in dom["kernel"] else 0.0
+        # a split kernel spends three (six) bf16 / f16 MFMA products per algorithmic product; both 16-bit types run
+        # at the same dense matrix rate
+        terms = 6.0 if "bf16x6" in dom["kernel"] else 3.0 if "f16x3" in dom["kernel"] else 0.0
         peak = BF16_MATRIX_PEAK_TFLOPS / terms if terms else FP32_MATRIX_PEAK_TFLOPS
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s",
@@ -341,15 +342,17 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if default_precision == "f32" else "f32 (products split into bf16 pieces: x6 / x3)",
+            "dtype": {"f32": "f32", "split_f16": "f32 (products split into two f16 pieces, three terms)"}.get(
+                default_precision, "f32 (products split into bf16 pieces: x6 / x3)"),
             "precision": {"mode": default_precision,
-                          "note": "fp32 data and fp32 accumulation everywhere; products as sums of bf16 pieces on the "
-                                  "bf16 matrix pipe: six terms (x = hi+mid+lo exactly, every term above 2^-24 kept) "
-                                  "in every layer that feeds a code index -- error vs fp64 at or below the fp32 "
-                                  "pipe's own, index agreement with the CPU reference equal to the fp32 pipe's -- "
-                                  "and three terms (hi.hi+hi.lo+lo.hi) in the final decoder (reconstruction within "
-                                  "1e-5 of its maximum; north_star bound 1e-3). The all-fp32-pipe number is "
-                                  "alt_precision_single_gpu.f32"},
+                          "note": "fp32 data and fp32 accumulation everywhere; split_f16 (default): every product as "
+                                  "hi.hi+hi.lo+lo.hi of two 11-bit f16 pieces of the operands (scaled by powers of "
+                                  "two) on the f16 matrix pipe -- per-product error ~2^-23, error vs fp64 at or below "
+                                  "the fp32 pipe's own, index agreement with the CPU reference equal to the fp32 "
+                                  "pipe's; operand range |activation| < 16384, |weight| < 64 (weights checked at "
+                                  "plan time, an activation beyond it gives NaN / index -1). split_bf16: six-term "
+                                  "bf16 split (no range limit) in index-feeding layers, three-term in the final "
+                                  "decoder. The other modes are timed in alt_precision_single_gpu"},
             "data": "synthetic",
             "config": {"workload": "VQVAE.forward (encode + quantize x2 + decode), eval, default ctor "
                                    "(128 hidden, 2 res blocks, D=64, K=512, factors 4/2)",
@@ -368,9 +371,9 @@ def main():
         with torch.no_grad():
             model.conv_precision = "f32"
             ref_out = [o.clone() for o in model(x)]
-            for mode in ("f32", "bf16x3_decoder", "split_bf16", "bf16x3"):
+            for mode in ("f32", "bf16x3_decoder", "split_bf16", "bf16x3", "split_f16"):
                 model.conv_precision = mode
-                for _ in range(2):
+                for _ in range(5):
                     o = model(x)
                 torch.cuda.synchronize(device)
                 t0 = time.perf_counter()

@@ -160,6 +160,12 @@ typedef struct isi_dst {
 #define ISI_CONV_BF16X6 4 /* opt-in: six-term split (x = hi + mid + lo exactly; hi.hi, hi.mid, mid.hi,
                            * hi.lo, lo.hi, mid.mid): every term above 2^-24 of a product is kept --
                            * fp32-grade products at 6/16 of the fp32 pipe's matrix time.   */
+#define ISI_CONV_F16X3 8  /* opt-in: split-f16 products (two 11-bit pieces, three terms on the f16 matrix
+                           * pipe): per-product relative error ~2^-23 like ISI_CONV_BF16X6 at the
+                           * cost of ISI_CONV_BF16X3, inside f16's RANGE -- activations must satisfy
+                           * |x| < 16384 and weights |w| < 64 (operands are scaled by 2^2 / 2^10 before
+                           * the split; the scaling is undone exactly).  An operand outside the range
+                           * gives Inf / NaN in the output, never a silently wrong value.        */
 
 /* Conv2d, groups=1, square stride, symmetric zero padding, fp32.
  *   out = [relu]( conv(cat(src0, src1), W) + bias [+ residual] )
@@ -450,7 +456,8 @@ typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
                   * 0: fp32 matrix pipe everywhere.  1: ISI_CONV_BF16X3 in `dec` and `upsample` only
                   * (no code index depends on them).  2: ISI_CONV_BF16X3 in every convolution (near-tie
                   * indices move).  3: ISI_CONV_BF16X6 (fp32-grade six-term split) in every layer that
-                  * feeds a code index, ISI_CONV_BF16X3 in `dec` and `upsample`.            */
+                  * feeds a code index, ISI_CONV_BF16X3 in `dec` and `upsample`.  4: ISI_CONV_F16X3
+                  * (fp32-grade three-term split-f16 products, f16 operand range) in every convolution. */
 } isi_vqvae_w;
 
 /* Outputs of VQVAE.encode / forward (vqvae.py:245-278).  Any pointer may be

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void convT_k4s2_small_kernel(const ConvTSmallA
         for (int jx = 0; jx < 2; ++jx)
           v += ys[(hr * HW_ + hcs[jx]) * LDY + (ky * 4 + kxs[jx]) * p.Cout + co];
       }
-      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.relu) v = v < 0.f ? 0.f : v;   // like torch.relu, NaN stays NaN (fmaxf would drop it)
       p.out[b * p.on + co * p.oc + oy * p.oh + ox * p.ow] = v;
     }
   }

@@ -100,10 +100,30 @@ __device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
 
+// ---- split-f16 ("f16x3", ISI_CONV_F16X3): x = hi + lo with hi = f16(s x), lo = f16(s x - hi), s a power of two.
+// Two 11-bit pieces hold 22 significand bits and the rounding of lo leaves |x - (hi + lo) / s| <= 2^-24 |x|, the
+// dropped lo.lo term is <= 2^-24 of the product: fp32-grade products from THREE MFMAs (the six-term bf16 split
+// needs six).  The price is f16's range: |s x| must stay below 65504 (an overflow turns into Inf / NaN in the
+// output, never into a silently wrong value) and lo keeps all its bits only while |s x| >= 2^-3 (below, the absolute
+// error floor is 2^-25 / s).  Activations are scaled by 2^2 (|x| < 16384, floor 7e-9), weights by 2^10 (|w| < 64,
+// floor 3e-11); the accumulator is rescaled by 2^-12 in the epilogue (all exact).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kF16ScaleA = 4.f, kF16ScaleB = 1024.f, kF16Unscale = 1.f / (4.f * 1024.f);
+__device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
+  const f32x2 a = f32x2{v.x, v.y} * s, b = f32x2{v.z, v.w} * s;
+  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+  const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), f16x2);
+  const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) {
   constexpr bool BF = PREC >= 1;
   constexpr bool BF6 = PREC == 2;
+  constexpr bool F16 = PREC == 3;
   constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int RA = BM / 32;  // A rows staged per thread
@@ -295,7 +315,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (DUAL) v = sel1 ? ra1[j] : v;
       if constexpr (BF) {
         uint2 hi, mid, lo;
-        if constexpr (BF6) split3_bf16x4(v, hi, mid, lo); else split_bf16x4(v, hi, lo);
+        if constexpr (BF6) split3_bf16x4(v, hi, mid, lo);
+        else if constexpr (F16) split_f16x4(v, kF16ScaleA, hi, lo);
+        else split_bf16x4(v, hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Ahi + wo) = hi;
         *reinterpret_cast<uint2 *>(Alo + wo) = lo;
@@ -308,7 +330,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     for (int j = 0; j < RB; ++j) {
       if constexpr (BF) {
         uint2 hi, mid, lo;
-        if constexpr (BF6) split3_bf16x4(rb[j], hi, mid, lo); else split_bf16x4(rb[j], hi, lo);
+        if constexpr (BF6) split3_bf16x4(rb[j], hi, mid, lo);
+        else if constexpr (F16) split_f16x4(rb[j], kF16ScaleB, hi, lo);
+        else split_bf16x4(rb[j], hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Bhi + wo) = hi;
         *reinterpret_cast<uint2 *>(Blo + wo) = lo;
@@ -381,8 +405,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
               for (int j = 0; j < TN; ++j) {
                 const s16x8 av = t == 0 ? al[i] : ah[i];
                 const s16x8 bv = t == 1 ? bl[j] : bh[j];
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
-                                                                    __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
+                if constexpr (F16)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av),
+                                                                     __builtin_bit_cast(f16x8, bv), acc[i][j], 0, 0, 0);
+                else
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
+                                                                      __builtin_bit_cast(bf16x8, bv), acc[i][j], 0, 0, 0);
               }
           }
         }
@@ -451,8 +479,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float v = acc[i][j][r] + bias + res[r];
-        if (p.relu) v = fmaxf(v, 0.f);
+        float v = (F16 ? acc[i][j][r] * kF16Unscale : acc[i][j][r]) + bias + res[r];
+        // fmaxf alone would turn a NaN (an operand beyond the range of ISI_CONV_F16X3, an fp32 overflow) into 0;
+        // v - v is 0 for finite v and NaN otherwise.  (The select form `v < 0 ? 0 : v` makes this compiler allocate
+        // 244 VGPRs for the split-f16 variant, 1 wave per SIMD.)
+        if (p.relu) v = fmaxf(v, 0.f) + (v - v);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso, oo[r], 0, 0);
       }
     }
@@ -485,7 +516,7 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
     const double in_px = nphase == 1 ? (double)a.M / (a.OH * a.OW) * a.H * a.W : (double)a.M;
     const double bytes = 4.0 * (in_px * a.Cin + (double)a.M * np * a.Cout * (a.res ? 2 : 1) +
                                 np * a.Cout * a.K);
-    const int kid = PREC == 2 ? prof::K_CONV_BF16X6 : PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
+    const int kid = PREC == 3 ? prof::K_CONV_F16X3 : PREC == 2 ? prof::K_CONV_BF16X6 : PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
                              : (BN == 128 ? prof::K_CONV_128x128 : BN == 64 ? prof::K_CONV_128x64 : prof::K_CONV_128x32);
     prof::Scope scope(kid, flops, bytes, stream);
     ISI_PROF_LAUNCH(scope, kern, grid, dim3(256), smem, stream, a);
@@ -505,6 +536,10 @@ static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_
       if (narrow) return launch_cfg<128, 64, 2, 2, 0, 2>(a, nphase, stream);
       return launch_cfg<128, 128, 2, 2, 0, 2>(a, nphase, stream);
     }
+    if (a.bf16x3 == 3) {   // split-f16: fp32-grade products from three terms, f16 range
+      if (narrow) return launch_cfg<128, 64, 2, 2, 0, 3>(a, nphase, stream);
+      return launch_cfg<128, 128, 2, 2, 0, 3>(a, nphase, stream);
+    }
     if (narrow) return launch_cfg<128, 64, 2, 2, 0, 1>(a, nphase, stream);
     return launch_cfg<128, 128, 2, 2, 0, 1>(a, nphase, stream);
   }
@@ -518,6 +553,11 @@ static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_
   if (mode == 1) ISI_CONV_DISPATCH(1);
   ISI_CONV_DISPATCH(0);
 #undef ISI_CONV_DISPATCH
+}
+
+// flags -> 0 exact fp32 | 1 bf16x3 | 2 bf16x6 | 3 f16x3 (the most precise requested mode wins)
+static int split_mode(int flags) {
+  return (flags & ISI_CONV_BF16X6) ? 2 : (flags & ISI_CONV_F16X3) ? 3 : (flags & ISI_CONV_BF16X3) ? 1 : 0;
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -582,7 +622,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.Cout = Cout;
   a.K = KH * KW * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
-  a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = (relu & ISI_CONV_BF16X6) ? 2 : ((relu >> 1) & 1); a.M = B * OH * OW;
+  a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * OH * OW;
   a.pad = pad; a.convT = 0;
   bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (C1 % 4 == 0) && aligned16(s0->ptr) &&
              (s0->sn % 4 == 0) && (s0->sh % 4 == 0) && (s0->sw % 4 == 0);
@@ -621,7 +661,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.K = 4 * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_phase_stride = Cout * a.Kpad;
   a.w_bytes = (unsigned)((size_t)4 * Cout * a.Kpad * 4);
-  a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = (relu & ISI_CONV_BF16X6) ? 2 : ((relu >> 1) & 1); a.M = B * H * W;
+  a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * H * W;
   a.convT = 1;
   const bool vec = s->sc == 1 && (a.C0 % 4 == 0) && aligned16(s->ptr) && (s->sn % 4 == 0) &&
                    (s->sh % 4 == 0) && (s->sw % 4 == 0);

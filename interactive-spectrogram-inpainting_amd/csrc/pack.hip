@@ -61,7 +61,7 @@ __global__ void pack_codebook_kernel(const float *__restrict__ embed, float *__r
 __global__ void relu_inplace_kernel(float *__restrict__ x, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    x[i] = fmaxf(x[i], 0.f);
+    x[i] = x[i] < 0.f ? 0.f : x[i];   // NaN stays NaN
 }
 
 int relu_inplace_f32(float *x, int64_t n, hipStream_t stream) {

@@ -20,6 +20,7 @@ enum KernelId {
   K_CONV_BF16X3,
   K_REL_ATTENTION_BWD,
   K_CONV_BF16X6,
+  K_CONV_F16X3,
   K_COUNT
 };
 

@@ -82,23 +82,45 @@ __device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &
   mid = make_uint2(__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb));
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
+// split-f16 pieces (ISI_CONV_F16X3, see conv_igemm_f32.hip): operands scaled by a power of two, f16 range
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr float kF16ScaleA = 4.f, kF16ScaleB = 1024.f, kF16Unscale = 1.f / (4.f * 1024.f);
+__device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
+  const f32x2 a = f32x2{v.x, v.y} * s, b = f32x2{v.z, v.w} * s;
+  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+  const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), f16x2);
+  const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+template <int PREC>
+__device__ __forceinline__ void split_x4(const float4 v, const float s16, uint2 &hi, uint2 &mid, uint2 &lo) {
+  if constexpr (PREC == 2) split3_bf16x4(v, hi, mid, lo);
+  else if constexpr (PREC == 3) split_f16x4(v, s16, hi, lo);
+  else split_bf16x4(v, hi, lo);
+}
+#define ISI_MH(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0)
 #define ISI_MF(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0)
 // a = {hi, lo, mid}, b = {hi, lo, mid}; smallest terms first
 template <int PREC>
 __device__ __forceinline__ f32x16 mfma_split(const s16x8 *a, const s16x8 *b, f32x16 acc) {
   if constexpr (PREC == 2) {
     ISI_MF(a[1], b[0]); ISI_MF(a[0], b[1]); ISI_MF(a[2], b[2]); ISI_MF(a[2], b[0]); ISI_MF(a[0], b[2]); ISI_MF(a[0], b[0]);
+  } else if constexpr (PREC == 3) {
+    ISI_MH(a[1], b[0]); ISI_MH(a[0], b[1]); ISI_MH(a[0], b[0]);
   } else {
     ISI_MF(a[1], b[0]); ISI_MF(a[0], b[1]); ISI_MF(a[0], b[0]);
   }
   return acc;
 }
 #undef ISI_MF
+#undef ISI_MH
 
 // TH = 2: 4 waves, 2 x 64 pixels; TH = 4: 8 waves, 4 x 64 pixels -- one W1 slice and a (TH + 2)-row halo serve
 // twice the pixels (1.55 instead of 2.06 staged halo rows per output row: a quarter less staging and split work),
 // and the three-plane six-term variant then runs two waves per SIMD inside ONE workgroup per CU.
-template <int TC, int PREC = 0, int TH = 2>  // TC = C / 32; PREC 0 exact fp32, 1 bf16x3, 2 bf16x6
+template <int TC, int PREC = 0, int TH = 2>  // TC = C / 32; PREC 0 exact fp32, 1 bf16x3, 2 bf16x6, 3 f16x3
 __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p) {
   constexpr int NTH = TH * 128;                               // threads
   constexpr int HH = TH + 2, HPIX = HH * HWD;                 // halo (TH + 2) x 66 pixels
@@ -154,7 +176,7 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (j < NA - 1 || i < HPIX * 8) {
         if constexpr (BF) {
           uint2 hi, mid, lo;
-          if constexpr (PREC == 2) split3_bf16x4(ra[j], hi, mid, lo); else split_bf16x4(ra[j], hi, lo);
+          split_x4<PREC>(ra[j], kF16ScaleA, hi, mid, lo);
           const int wo = (i >> 3) * LDB + bf_slot(i >> 3, lq >> 1) + (lq & 1) * 4;
           *reinterpret_cast<uint2 *>(Apl + wo) = hi;
           *reinterpret_cast<uint2 *>(Apl + APS + wo) = lo;
@@ -170,7 +192,7 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (t >= 9) continue;
       if constexpr (BF) {
         uint2 hi, mid, lo;
-        if constexpr (PREC == 2) split3_bf16x4(rw[k], hi, mid, lo); else split_bf16x4(rw[k], hi, lo);
+        split_x4<PREC>(rw[k], kF16ScaleB, hi, mid, lo);
         const int wo = (t * 32 + lr) * LDB + bf_slot(t * 32 + lr, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
         *reinterpret_cast<uint2 *>(Wpl + WPS + wo) = lo;
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (n >= C) continue;
       uint2 hi, mid, lo;
       const float4 wv = buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u);
-      if constexpr (PREC == 2) split3_bf16x4(wv, hi, mid, lo); else split_bf16x4(wv, hi, lo);
+      split_x4<PREC>(wv, kF16ScaleB, hi, mid, lo);
       const int wo = n * LDB + bf_slot(n, lq >> 1) + (lq & 1) * 4;
       *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
       *reinterpret_cast<uint2 *>(Wpl + WPS + wo) = lo;
@@ -260,8 +282,16 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
-      const float hv = frow < p.R ? fmaxf(acc1[r] + b1, 0.f) : 0.f;
+      const float hpre = (PREC == 3 ? acc1[r] * kF16Unscale : acc1[r]) + b1;
+      const float hv = frow < p.R ? (hpre < 0.f ? 0.f : hpre) : 0.f;   // NaN-propagating rectifier (torch.relu)
       const int wo = row * LDB + bf_slot(row, frow >> 3) + (frow & 7);
+      if constexpr (PREC == 3) {
+        const float hs_ = hv * kF16ScaleA;
+        const _Float16 h0 = (_Float16)hs_;
+        Apl[wo] = __builtin_bit_cast(unsigned short, h0);
+        Apl[APS + wo] = __builtin_bit_cast(unsigned short, (_Float16)(hs_ - (float)h0));
+        continue;
+      }
       const __bf16 hh = (__bf16)hv;
       const float r1 = hv - (float)hh;
       if constexpr (PREC == 2) {
@@ -305,7 +335,8 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * fq;
-      hs[row * LDK + frow] = frow < p.R ? fmaxf(acc1[r] + b1, 0.f) : 0.f;
+      const float hpre = acc1[r] + b1;
+      hs[row * LDK + frow] = frow < p.R ? (hpre < 0.f ? 0.f : hpre) : 0.f;
     }
   }
   __syncthreads();
@@ -350,8 +381,8 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
                                              rsi, eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = acc2[j][r] + b2 + res[r];
-      if (p.relu) v = fmaxf(v, 0.f);
+      float v = (PREC == 3 ? acc2[j][r] * kF16Unscale : acc2[j][r]) + b2 + res[r];
+      if (p.relu) v = v < 0.f ? 0.f : v;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso,
                                             eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0);
     }
@@ -414,6 +445,7 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
     default: return launch_res<4, PREC>(a, B, stream);         \
   }
   if (relu & ISI_CONV_BF16X6) { ISI_RES(2) }
+  if (relu & ISI_CONV_F16X3) { ISI_RES(3) }
   if (relu & ISI_CONV_BF16X3) { ISI_RES(1) }
   ISI_RES(0)
 #undef ISI_RES

@@ -7,6 +7,7 @@
 //   idx[n]  = first k attaining min_k d[n,k]            ((-dist).max(1), ties -> lowest)
 //   q[n]    = z_n + (e_idx - z_n)                        (straight-through value)
 //   sse    += sum (e_idx - z_n)^2 ;  counts[idx[n]] += 1
+//   (a z_n holding NaN / Inf: idx = -1, q = NaN, sse = NaN, not counted)
 //
 // The whole codebook ([K][D+4] fp32, 136 KiB at K=512, D=64) stays in LDS for
 // the lifetime of a persistent workgroup.  Each wave handles 32 vectors at a
@@ -102,7 +103,17 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
       const int oi = __shfl_xor(besti, 32);
       if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
     }
-    if (valid) {
+    // a vector with a NaN / Inf component has no nearest code (every comparison above fails): index -1, so that a
+    // range violation upstream (ISI_CONV_F16X3 operands beyond f16, or an overflow in fp32) is never mistaken for
+    // code 0; its quantised value and the squared error are NaN
+    const bool lost = !(best < INFINITY);
+    if (valid && lost) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+        *reinterpret_cast<float4 *>(q_out + n * D + (2 * j + half) * 4) = make_float4(NAN, NAN, NAN, NAN);
+      sse = NAN;
+      if (half == 0) idx_out[n] = -1;
+    } else if (valid) {
       const float *crow = cb + (size_t)besti * LDD + half * 4;
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {

@@ -57,8 +57,8 @@ def pack_codebook(embed: torch.Tensor):
 
 
 def _prec_flag(bf16x3) -> int:
-    """False / 0 -> exact fp32, True / 1 -> ISI_CONV_BF16X3, 2 -> ISI_CONV_BF16X6."""
-    return {0: 0, 1: 2, 2: 4}[int(bf16x3)]
+    """False / 0 -> exact fp32, True / 1 -> ISI_CONV_BF16X3, 2 -> ISI_CONV_BF16X6, 3 -> ISI_CONV_F16X3."""
+    return {0: 0, 1: 2, 2: 4, 3: 8}[int(bf16x3)]
 
 
 def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,

@@ -32,6 +32,8 @@ from .. import _hip
 from .encoder_decoder import RosinalityEncoder, RosinalityDecoder, _ConvParams
 from .bottleneck import QuantizedBottleneck, UnquantizedBottleneck
 
+_F16_WEIGHT_LIMIT = 64.0   # ISI_CONV_F16X3 scales weights by 2^10 before the f16 split (include/isi_hip.h)
+
 
 class VQVAE(nn.Module):
     n_embed_t: int
@@ -137,8 +139,16 @@ class VQVAE(nn.Module):
         self.adapt_quantized_durations = adapt_quantized_durations
         self._plan = None
         self._plan_key = None
-        # Arithmetic of the convolutions' products (accumulation is always fp32):
-        #   'split_bf16' (default)  products as sums of bf16 pieces on the bf16 matrix pipe (16x the fp32 pipe's rate):
+        # Arithmetic of the convolutions' products (data and accumulation are always fp32):
+        #   'split_f16' (default)  every product as a sum of f16 pieces on the f16 matrix pipe (16x the fp32 pipe's
+        #        rate): x = hi + lo, two 11-bit pieces of the operand scaled by a power of two, THREE terms
+        #        (hi.hi + hi.lo + lo.hi).  Per-product relative error ~2^-23; measured against fp64 on the 3x3
+        #        128->128 layer: 0.9e-6 of the maximum (fp32 pipe 1.2e-6, six-term bf16 split 1.2e-6, torch-CPU
+        #        2.8e-7), code indices agree with the CPU reference as often as the fp32 pipe's do.  Inside f16's
+        #        range: activations |x| < 16384, weights |w| < 64.  The weights are checked when the plan is
+        #        built (a model beyond the range runs in 'split_bf16'); an activation beyond it turns into NaN in
+        #        `dec` / `diff` and into code index -1, never into a silently wrong value.
+        #   'split_bf16'  products as sums of bf16 pieces (fp32's exponent range, no operand limits):
         #        * every layer that feeds a code index (encoders, quantiser 1x1s, top decoder): SIX-term split
         #          (x = hi + mid + lo exactly; hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid = every term above
         #          2^-24 of a product).  Measured against fp64 its error is at or below the fp32 pipe's own
@@ -149,7 +159,7 @@ class VQVAE(nn.Module):
         #   'bf16x3_decoder'  index-feeding layers on the exact-fp32 matrix pipe, decoder three-term split
         #   'f32'             everything on the exact-fp32 matrix pipe
         #   'bf16x3'          every convolution three-term split: near-tie code indices move (not parity-safe)
-        self.conv_precision = os.environ.get("ISI_CONV_PRECISION", "split_bf16")
+        self.conv_precision = os.environ.get("ISI_CONV_PRECISION", "split_f16")
 
     # ------------------------------------------------------------ native plan
     def _plan_fingerprint(self):
@@ -169,9 +179,12 @@ class VQVAE(nn.Module):
             return self._plan[0]
         keep = []
 
+        wmax = []
+
         def conv(m: _ConvParams) -> _hip.isi_conv_w:
             p = m.packed()
             keep.append(p)
+            wmax.append(p.detach().abs().max())
             return _hip.isi_conv_w(p.data_ptr(), m.bias.data_ptr(), m.in_channels, m.out_channels)
 
         def res(stack, blocks, idxs):
@@ -211,10 +224,14 @@ class VQVAE(nn.Module):
         w.quantize_conv_t, w.quantize_conv_b = conv(self.quantize_conv_t), conv(self.quantize_conv_b)
         w.quantize_t, w.quantize_b = book(self.quantize_t), book(self.quantize_b)
         w.dec_t, w.dec = dec(self.dec_t), dec(self.dec)
-        w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2, "split_bf16": 3}[self.conv_precision]
+        w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2, "split_bf16": 3, "split_f16": 4}[self.conv_precision]
         w.n_upsample = len(self.upsample_top_to_bottom)
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)
+        if w.precision == 4 and not float(torch.stack(wmax).max()) < _F16_WEIGHT_LIMIT:
+            warnings.warn(f"a convolution weight reaches {_F16_WEIGHT_LIMIT:g} in magnitude (or is not finite): beyond the "
+                          "operand range of conv_precision='split_f16', running this model in 'split_bf16'")
+            w.precision = 3
         self._plan, self._plan_key = (w, keep), key
         return w
 

@@ -312,7 +312,7 @@ def test_split_bf16_precision_modes():
     m = VQVAE(in_channel=2)
     m.load_state_dict(sd)
     m = m.to(_dev()).eval()
-    assert m.conv_precision == "split_bf16"
+    assert m.conv_precision == "split_f16"
     m.conv_precision = "f32"
     ref = m(x)
     m.conv_precision = "bf16x3_decoder"
@@ -332,8 +332,90 @@ def test_split_bf16_precision_modes():
     agree_t = (got[4] == ref[4]).float().mean().item()
     agree_b = (got[5] == ref[5]).float().mean().item()
     assert agree_t > 0.995 and agree_b > 0.995, (agree_t, agree_b)
+    # default: three-term split-f16 everywhere, fp32-grade like the six-term bf16 split
+    m.conv_precision = "split_f16"
+    got = m(x)
+    agree_t = (got[4] == ref[4]).float().mean().item()
+    agree_b = (got[5] == ref[5]).float().mean().item()
+    assert agree_t > 0.995 and agree_b > 0.995, (agree_t, agree_b)
+    same = (got[4] == ref[4]).all(-1).all(-1) & (got[5] == ref[5]).all(-1).all(-1)
+    if same.any():
+        _close(got[0][same], ref[0][same], 2e-6, "dec (split_f16, items with identical codes)")
+    assert not torch.equal(got[0], ref[0]), "the mode switch must actually change the arithmetic"
     m.conv_precision = "f32"
     assert torch.equal(m(x)[0], ref[0])
+
+
+def test_split_f16_products_against_fp64():
+    """ISI_CONV_F16X3: fp32-grade products (checked against fp64 next to the exact-fp32 pipe and the six-term
+    bf16 split) over five decades of operand magnitude inside the documented range, for the implicit-GEMM
+    convolution and the fused residual block."""
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W, R = 2, 128, 24, 40, 32
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.03
+    b = torch.randn(C, generator=g) * 0.1
+    w3 = torch.randn(R, C, 3, 3, generator=g) * 0.03
+    b3 = torch.randn(R, generator=g) * 0.1
+    w1 = torch.randn(C, R, 1, 1, generator=g) * 0.1
+    b1 = torch.randn(C, generator=g) * 0.1
+    pw, p3, p1 = (_ops.pack_conv_weight(t.to(dev)) for t in (w, w3, w1))
+    F = torch.nn.functional
+    for scale in (1e-3, 1e-1, 1.0, 30.0, 3000.0):
+        x = torch.randn(B, C, H, W, generator=g).abs() * scale     # max ~ 4.5 scale < 16384
+        xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        err = {}
+        for mode in (0, 2, 3):
+            y = _ops.conv2d(xd, pw, b.to(dev), C, 3, 1, 1, relu=False, bf16x3=mode).cpu().double()
+            err[mode] = ((y - ref).abs().max() / ref.abs().max()).item()
+        assert err[3] < 3e-6 and err[3] < 2.0 * max(err[0], err[2]) + 1e-7, (scale, err)
+        h = torch.relu(F.conv2d(x.double(), w3.double(), b3.double(), padding=1))
+        ref = torch.relu(x.double() + F.conv2d(h, w1.double(), b1.double()))
+        for mode in (0, 2, 3):
+            y = _ops.resblock(xd, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=mode).cpu().double()
+            err[mode] = ((y - ref).abs().max() / ref.abs().max()).item()
+        assert err[3] < 3e-6 and err[3] < 2.0 * max(err[0], err[2]) + 1e-7, (scale, err)
+
+
+def test_split_f16_range_violations_are_loud():
+    """Operands beyond f16's range must never produce a plausible result: an activation beyond 16384 gives
+    NaN in the output (and code index -1, NaN diff in the model); a weight beyond 64 makes the model run in
+    split_bf16 (warning) with the usual finite results."""
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    C = 64
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.05
+    pw = _ops.pack_conv_weight(w.to(dev))
+    x = torch.randn(1, C, 16, 16, generator=g)
+    x[0, 3, 5, 7] = 7e4
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    y = _ops.conv2d(xd, pw, None, C, 3, 1, 1, relu=False, bf16x3=3)
+    assert not torch.isfinite(y[0, :, 4:7, 6:9]).any(), "every output that reads the out-of-range value"
+    assert torch.isfinite(y[0, :, 10:, :]).all(), "and nothing else"
+    assert torch.isfinite(_ops.conv2d(xd, pw, None, C, 3, 1, 1, relu=False, bf16x3=2)).all()
+
+    cfg = O.Config(in_channel=2)
+    sd = O.init_state_dict(cfg, seed=2)
+    m = VQVAE(in_channel=2)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    xin = torch.randn(2, 2, 32, 64, generator=g)
+    xin[1] *= 1e5
+    out = m(xin.to(dev))
+    assert torch.isfinite(out[0][0]).all() and (out[4][0] >= 0).all() and (out[5][0] >= 0).all()
+    assert (out[4][1] == -1).any() and not torch.isfinite(out[0][1]).all() and not torch.isfinite(out[1]).all()
+    with pytest.raises(IndexError):
+        m.decode_code(out[4], out[5])
+    with torch.no_grad():
+        m.enc_b.blocks[m.enc_b._conv3].weight[0, 0, 0, 0] = 100.0
+    with pytest.warns(UserWarning, match="split_bf16"):
+        out2 = m(xin[:1].to(dev))
+    assert torch.isfinite(out2[0]).all() and (out2[4] >= 0).all()
 
 
 @pytest.mark.parametrize("in_ch,B,H,W", [(3, 1, 8, 8), (1, 2, 16, 24), (2, 1, 8, 200), (3, 5, 24, 40)])

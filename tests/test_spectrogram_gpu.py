@@ -161,7 +161,12 @@ def test_vqvae_with_normalizer_and_output_threshold():
     err = (dec.cpu() - ref_dec).abs()
     assert err[:, 0].max() <= 1e-4 * ref_dec.abs().max() and err[:, 1][~near].max() <= 1e-4 * ref_dec.abs().max()
     assert (dec[:, 1][dec[:, 0] <= thr] == 0).all() and (dec[:, 0] <= thr).any()
-    assert torch.equal(m.decode_code(id_t, id_b), dec)
+    # forward decodes the straight-through value z + (e - z), decode_code the code vector e: equal up to the rounding
+    # of that sum (bottleneck.py:94-101), as in the reference
+    again = m.decode_code(id_t, id_b)
+    keep = (S.denormalize(ref[0], st)[:, 0] - thr).abs() >= 1e-3
+    assert (again[:, 0] - dec[:, 0]).abs().max() <= 2e-6 * dec.abs().max()
+    assert (again[:, 1] - dec[:, 1]).abs().cpu()[keep].max() <= 2e-6 * dec.abs().max()
     # the parameters JSON carries the statistics (vqvae.py:98-122)
     assert m.normalizer_statistics == st and m.output_spectrogram_min_magnitude == thr
     # train mode: differentiable through the post-processing

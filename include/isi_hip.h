@@ -396,6 +396,13 @@ int isi_prior_sample_run(const isi_prior_w *w, const isi_prior_state *state, int
 int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2,
                        int64_t *idx_out, float *q_out, int32_t *counts,
                        float *sse_part, int64_t N, int D, int K, void *stream);
+/* Same, with a flag word: ISI_CONV_F16X3 computes z.e_k with split-f16 products (three f16 MFMA terms, per-product
+ * error ~2^-23; |z| < 16384, |e| < 64) when D == 64 and the codebook's two f16 planes fit in LDS (K <= 512), five
+ * times fewer matrix-pipe cycles than the exact-fp32 products that bound isi_vq_nearest_f32.  0 = exact.
+ * A vector with a non-finite component (or distances) gets idx -1, q = NaN, and makes the squared error NaN. */
+int isi_vq_nearest_flags_f32(const float *z, const float *codes_kd, const float *e2,
+                             int64_t *idx_out, float *q_out, int32_t *counts,
+                             float *sse_part, int64_t N, int D, int K, int flags, void *stream);
 int isi_vq_num_partials(int64_t N);
 
 /* diff = sum(sse_part)/(N*D); perplexity = exp(-sum p log(max(p,1e-7))),

@@ -191,7 +191,12 @@ int isi_vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg, c
 int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,
                        float *q_out, int32_t *counts, float *sse_part, int64_t N, int D, int K,
                        void *stream) {
-  return vq_nearest_f32(z, codes_kd, e2, idx_out, q_out, counts, sse_part, N, D, K, S(stream));
+  return vq_nearest_f32(z, codes_kd, e2, idx_out, q_out, counts, sse_part, N, D, K, 0, S(stream));
+}
+int isi_vq_nearest_flags_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,
+                             float *q_out, int32_t *counts, float *sse_part, int64_t N, int D, int K,
+                             int flags, void *stream) {
+  return vq_nearest_f32(z, codes_kd, e2, idx_out, q_out, counts, sse_part, N, D, K, flags, S(stream));
 }
 int isi_vq_num_partials(int64_t N) { return vq_num_partials(N); }
 int isi_vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,

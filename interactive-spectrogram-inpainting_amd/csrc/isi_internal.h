@@ -81,7 +81,7 @@ int vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg, const
                       const float *embed_sum_dk, int D, int K, float decay, float eps, hipStream_t st);
 
 int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
-                   int32_t *counts, float *sse_part, int64_t N, int D, int K, hipStream_t stream);
+                   int32_t *counts, float *sse_part, int64_t N, int D, int K, int flags, hipStream_t stream);
 int vq_num_partials(int64_t N);
 int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,
                     int D, float *out2, hipStream_t stream);

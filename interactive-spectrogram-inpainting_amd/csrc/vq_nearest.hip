@@ -22,6 +22,7 @@
 namespace isi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
 
 #ifndef ISI_VQ_WAVES
 #define ISI_VQ_WAVES 8
@@ -147,6 +148,152 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
   }
 }
 
+
+// ---- split-f16 distances (ISI_CONV_F16X3; D = 64): z.e_k as hi.hi + hi.lo + lo.hi of two 11-bit f16 pieces of
+// 4 z and 1024 e (per-product error ~2^-23, the scaling undone exactly) on v_mfma_f32_32x32x16_f16: 12 MFMAs of
+// 8 passes per 32 codes instead of 32 MFMAs of 16 passes on the fp32 pipe, which bounds the exact kernel
+// (2 N K D flops at 157 TFLOP/s).  The codebook lives in LDS as two f16 planes [K][64] (128 KiB at K = 512; the
+// eight 16-B slots of a row are XOR-swizzled with (row >> 1) & 7: conflict-free ds_read_b128); the fp32 code
+// vector of the winner is re-read from global memory (L2) for q and the squared error.  Same operand swap,
+// association of d, tie rule and outputs as the exact kernel; ranges as for the convolutions (|z| < 16384,
+// |e| < 64; beyond: non-finite distances -> index -1).
+typedef _Float16 vq_f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 vq_f16x8 __attribute__((ext_vector_type(8)));
+typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kVqScaleZ = 4.f, kVqScaleE = 1024.f, kVqUnscale = 1.f / (4.f * 1024.f);
+
+__device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
+  const vq_f32x2 a = vq_f32x2{v.x, v.y} * s, b = vq_f32x2{v.z, v.w} * s;
+  const vq_f16x2 ha = __builtin_convertvector(a, vq_f16x2), hb = __builtin_convertvector(b, vq_f16x2);
+  const vq_f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, vq_f32x2), vq_f16x2);
+  const vq_f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, vq_f32x2), vq_f16x2);
+  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
+  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+
+__global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
+    const float *__restrict__ z, const float *__restrict__ codes, const float *__restrict__ e2g,
+    int64_t *__restrict__ idx_out, float *__restrict__ q_out, int32_t *__restrict__ counts,
+    float *__restrict__ sse_part, int64_t N, int K) {
+  constexpr int D = 64;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned short *cbh = reinterpret_cast<unsigned short *>(smem);   // [K][64] hi pieces
+  unsigned short *cbl = cbh + (size_t)K * D;                        // [K][64] lo pieces
+  float *e2 = reinterpret_cast<float *>(cbl + (size_t)K * D);       // [K]
+  float *red = e2 + K;
+  int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;
+  const int half = lane >> 5;
+
+  for (int i = tid; i < K * (D / 4); i += VQ_BLOCK) {
+    const int k = i >> 4, qd = i & 15;
+    uint2 hi, lo;
+    vq_split4(*reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4), kVqScaleE, hi, lo);
+    const int wo = k * D + (((qd >> 1) ^ ((k >> 1) & 7)) * 8) + (qd & 1) * 4;
+    *reinterpret_cast<uint2 *>(cbh + wo) = hi;
+    *reinterpret_cast<uint2 *>(cbl + wo) = lo;
+  }
+  for (int i = tid; i < K; i += VQ_BLOCK) { e2[i] = e2g[i]; hist[i] = 0; }
+  __syncthreads();
+
+  float sse = 0.f;
+  const int64_t n_iter = (N + VQ_VEC_PER_BLOCK_ITER - 1) / VQ_VEC_PER_BLOCK_ITER;
+  for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
+    const bool valid = n < N;
+    // this lane's 8 quads of z_n: k-step s covers components 16 s + 8 half .. + 8 (quads 4 s + 2 half, + 1)
+    float4 zq[8];
+    s16x8v zh[4], zl[4];
+    float x2p = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      uint2 h0, l0, h1, l1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) v = *reinterpret_cast<const float4 *>(z + n * D + (4 * s + 2 * half + e) * 4);
+        zq[2 * s + e] = v;
+        x2p += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      vq_split4(zq[2 * s], kVqScaleZ, h0, l0);
+      vq_split4(zq[2 * s + 1], kVqScaleZ, h1, l1);
+      zh[s] = __builtin_bit_cast(s16x8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      zl[s] = __builtin_bit_cast(s16x8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+    const float x2 = x2p + __shfl_xor(x2p, 32);
+
+    float best = INFINITY;
+    int besti = 0;
+    for (int kt = 0; kt < K; kt += 32) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int row = kt + col;
+      const int sw = (row >> 1) & 7;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int off = row * D + (((2 * s + half) ^ sw) * 8);
+        const s16x8v ah = *reinterpret_cast<const s16x8v *>(cbh + off);
+        const s16x8v al = *reinterpret_cast<const s16x8v *>(cbl + off);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zl[s]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int code = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float d = (x2 - 2.f * (acc[r] * kVqUnscale)) + e2[code];
+        if (d < best) { best = d; besti = code; }
+      }
+    }
+    {
+      const float ob = __shfl_xor(best, 32);
+      const int oi = __shfl_xor(besti, 32);
+      if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    const bool lost = !(best < INFINITY);
+    if (valid && lost) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        *reinterpret_cast<float4 *>(q_out + n * D + (4 * (j >> 1) + 2 * half + (j & 1)) * 4) = make_float4(NAN, NAN, NAN, NAN);
+      sse = NAN;
+      if (half == 0) idx_out[n] = -1;
+    } else if (valid) {
+      const float *crow = codes + (size_t)besti * D;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int qd = 4 * (j >> 1) + 2 * half + (j & 1);
+        const float4 e = *reinterpret_cast<const float4 *>(crow + qd * 4);
+        const float4 v = zq[j];
+        float4 dq = make_float4(e.x - v.x, e.y - v.y, e.z - v.z, e.w - v.w);
+        sse += dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w;
+        *reinterpret_cast<float4 *>(q_out + n * D + qd * 4) = make_float4(v.x + dq.x, v.y + dq.y, v.z + dq.z, v.w + dq.w);
+      }
+      if (half == 0) {
+        idx_out[n] = besti;
+        atomicAdd(&hist[besti], 1);
+      }
+    }
+  }
+
+  __syncthreads();
+  for (int i = tid; i < K; i += VQ_BLOCK)
+    if (hist[i]) atomicAdd(&counts[i], hist[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
+  if (lane == 0) red[wave] = sse;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < ISI_VQ_WAVES; ++w) t += red[w];
+    sse_part[blockIdx.x] = t;
+  }
+}
+
 __global__ void vq_finalize_kernel(const float *__restrict__ sse_part, int n_part,
                                    const int32_t *__restrict__ counts, int K, int64_t N, int D,
                                    float *__restrict__ out2) {
@@ -215,14 +362,33 @@ static int launch_vq(const float *z, const float *codes, const float *e2, int64_
   return check_launch("vq_nearest_f32");
 }
 
+static int launch_vq_f16x3(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
+                           int32_t *counts, float *sse_part, int64_t N, int K, hipStream_t stream) {
+  const size_t smem = (size_t)K * 64 * 2 * sizeof(unsigned short) + ((size_t)2 * K + ISI_VQ_WAVES) * sizeof(float);
+  auto kern = vq_nearest_f16x3_kernel;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return check_launch("hipFuncSetAttribute(vq f16x3)");
+  {
+    prof::Scope scope(prof::K_VQ_NEAREST, 2.0 * N * K * 64, 4.0 * (2.0 * N * 64 + (double)K * 64) + 8.0 * N, stream);
+    ISI_PROF_LAUNCH(scope, kern, dim3(vq_grid(N)), dim3(VQ_BLOCK), smem, stream, z, codes, e2, idx, q,
+                       counts, sse_part, N, K);
+  }
+  return check_launch("vq_nearest_f16x3");
+}
+
+// flags: 0 exact fp32 products | ISI_CONV_F16X3 split-f16 products (D = 64 with the codebook's two f16 planes
+// fitting in LDS; other shapes run the exact kernel)
 int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
-                   int32_t *counts, float *sse_part, int64_t N, int D, int K,
+                   int32_t *counts, float *sse_part, int64_t N, int D, int K, int flags,
                    hipStream_t stream) {
   if (!z || !codes || !e2 || !idx || !q || !counts || !sse_part) return invalid("vq: null pointer");
   if (N <= 0 || K <= 0 || (K % 32) != 0) return invalid("vq: need N > 0 and K % 32 == 0");
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(codes) |
        reinterpret_cast<uintptr_t>(q)) & 15)
     return invalid("vq: z, codes and q must be 16-byte aligned");
+  if ((flags & ISI_CONV_F16X3) && D == 64 && (size_t)K * 64 * 4 + (size_t)K * 8 + 64 <= 150 * 1024)
+    return launch_vq_f16x3(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
   switch (D) {
     case 8: return launch_vq<8>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
     case 16: return launch_vq<16>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);

@@ -12,6 +12,7 @@
 //     activations are channels-last, strides describe the API tensors.
 #include <algorithm>
 
+#include <cstdlib>
 #include "isi_common.h"
 #include "isi_internal.h"
 
@@ -191,10 +192,14 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
 }
 
 int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *idx, float *q,
-                  int32_t *counts, float *sse_part, float *scalars2, hipStream_t st) {
+                  int32_t *counts, float *sse_part, float *scalars2, int flags, hipStream_t st) {
   if (hipMemsetAsync(counts, 0, (size_t)cb.K * sizeof(int32_t), st) != hipSuccess)
     return check_launch("hipMemsetAsync(counts)");
-  int rc = vq_nearest_f32(z, cb.codes_kd, cb.e2, idx, q, counts, sse_part, N, cb.D, cb.K, st);
+  // The split-f16 distance kernel (vq_nearest.hip) saves 40 us of a 2.5 ms forward at B = 64 but moves a third more
+  // near-tie indices away from the CPU reference's (69 instead of 53 of 24576 top codes; the exact-fp32 pipe: 55):
+  // the quantisers stay on the exact pipe unless ISI_VQ_SPLIT_F16 is set (measurements).
+  static const bool vq_split = getenv("ISI_VQ_SPLIT_F16") != nullptr;
+  int rc = vq_nearest_f32(z, cb.codes_kd, cb.e2, idx, q, counts, sse_part, N, cb.D, cb.K, vq_split ? flags : 0, st);
   if (rc) return rc;
   return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);
 }
@@ -259,7 +264,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
                       et.W, D, 1, 1, 1, 0, pf_enc, st);
       if (rc) return rc;
       rc = run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
-                         sse_part, scal + 0, st);
+                         sse_part, scal + 0, pf_enc & ISI_CONV_F16X3, st);
       if (rc) return rc;
     }
     // dec_t (vqvae.py:265): [B,Ht,Wt,D] -> [B,Hb,2^n Wt,D]
@@ -281,7 +286,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
                       sh.Wq, D, 1, 1, 1, 0, pf_enc, st);
       if (rc) return rc;
       rc = run_quantizer(w.quantize_b, zbuf, (int64_t)B * sh.Hb * sh.Wq, id_b, quant_b, counts,
-                         sse_part, scal + 2, st);
+                         sse_part, scal + 2, pf_enc & ISI_CONV_F16X3, st);
       if (rc) return rc;
     }
   }

@@ -120,8 +120,9 @@ def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: b
     return out.permute(0, 3, 1, 2)
 
 
-def vq_nearest(z: torch.Tensor, codes: torch.Tensor, e2: torch.Tensor):
-    """z [..., D] dense channels-last -> (q_st [..., D], diff [], idx int64 [...], perplexity [])."""
+def vq_nearest(z: torch.Tensor, codes: torch.Tensor, e2: torch.Tensor, split_f16: bool = False):
+    """z [..., D] dense channels-last -> (q_st [..., D], diff [], idx int64 [...], perplexity []).
+    `split_f16`: z.e products as three split-f16 terms (ISI_CONV_F16X3) instead of the exact-fp32 matrix pipe."""
     _hip.require_gpu(z, "quantizer input")
     if not z.is_contiguous():
         z = z.contiguous()
@@ -135,9 +136,10 @@ def vq_nearest(z: torch.Tensor, codes: torch.Tensor, e2: torch.Tensor):
     n_part = L.isi_vq_num_partials(N)
     part = torch.empty(n_part, dtype=torch.float32, device=z.device)
     out2 = torch.empty(2, dtype=torch.float32, device=z.device)
-    _hip.check(L.isi_vq_nearest_f32(z.data_ptr(), codes.data_ptr(), e2.data_ptr(), idx.data_ptr(),
-                                    q.data_ptr(), counts.data_ptr(), part.data_ptr(), N, D, K, _s(z)),
-               "isi_vq_nearest_f32")
+    _hip.check(L.isi_vq_nearest_flags_f32(z.data_ptr(), codes.data_ptr(), e2.data_ptr(), idx.data_ptr(),
+                                          q.data_ptr(), counts.data_ptr(), part.data_ptr(), N, D, K,
+                                          8 if split_f16 else 0, _s(z)),
+               "isi_vq_nearest_flags_f32")
     _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D,
                                      out2.data_ptr(), _s(z)), "isi_vq_finalize_f32")
     return q, out2[0], idx, out2[1]

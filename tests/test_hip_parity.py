@@ -166,6 +166,41 @@ def test_quantizer_exact_ties_pick_lowest_index():
     assert torch.equal(ind.cpu(), ref[2])
 
 
+def test_quantizer_split_f16_products():
+    """isi_vq_nearest_flags_f32(ISI_CONV_F16X3): same outputs as the exact kernel except at near-ties
+    (certified in fp64), ties between duplicate codes still go to the lowest index, ragged N, range violations
+    give index -1."""
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    D, K = 64, 512
+    embed = torch.randn(D, K, generator=g) * 0.7
+    embed[:, 300] = embed[:, 17]
+    embed[:, 45] = embed[:, 9]
+    codes, e2 = _ops.pack_codebook(embed.to(dev))
+    for n in (1, 33, 20011):
+        z = torch.randn(n, D, generator=g) * 0.8
+        if n > 2:
+            z[1] = embed[:, 17]
+            z[2] = embed[:, 45]
+        q0, d0, i0, p0 = _ops.vq_nearest(z.to(dev), codes, e2)
+        q1, d1, i1, p1 = _ops.vq_nearest(z.to(dev), codes, e2, split_f16=True)
+        moved = _certify_index_mismatches(z, embed, i1.cpu(), i0.cpu())
+        assert moved <= max(1, n // 2000), moved
+        same = (i0 == i1)
+        assert torch.equal(q0[same], q1[same])
+        if n > 2:
+            assert i1[1] == 17 and i1[2] == 9
+        assert abs(d1.item() - d0.item()) <= 1e-5 * abs(d0.item()) and abs(p1.item() - p0.item()) <= 1e-3 * p0.item()
+    z = torch.randn(40, D, generator=g)
+    z[7, 3] = 3e4
+    z[9, 60] = float("nan")
+    q1, d1, i1, p1 = _ops.vq_nearest(z.to(dev), codes, e2, split_f16=True)
+    assert i1[7] == -1 and i1[9] == -1 and (i1 >= 0).sum() == 38 and torch.isnan(q1[7]).all() and torch.isnan(d1)
+    q0, d0, i0, p0 = _ops.vq_nearest(z.to(dev), codes, e2)
+    assert i0[7] >= 0 and i0[9] == -1 and torch.isnan(d0)
+
+
 def _certify_index_mismatches(z_vecs, embed, got, ref, eps=2e-6):
     """Any index that differs from the reference must be a near-tie: the fp64
     distances of the two candidates differ by less than `eps` of the magnitude

@@ -47,6 +47,9 @@ struct ConvKArgs {
   int convT;                 // 1: blockIdx.z = phase (py,px) of ConvTranspose2d(k4,s2,p1)
   int w_phase_stride;        // convT: floats between two phase weight matrices
   int dst_sh, dst_sw;        // convT: strides of the full output tensor (phase offset)
+  int KH;                    // kernel height (K = KH * KW * Cin)
+  int chunk_major;           // 1: K is walked slice-major -- for each 32-channel slice all KH x KW taps -- instead of
+                             // tap-major (the packed weight keeps k = tap * Cin + c; only the visiting order changes)
   int nz;                    // plain conv, nz > 1: blockIdx.z = one of nz independent operand sets of the same shape
   int zs_in0, zs_w, zs_res, zs_out;   // element strides between two sets (source 0, packed weight, residual, output)
 };
@@ -216,11 +219,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     a_n1[j] = b * p.s1n;
   }
   // per staged B row: byte offset of the packed weight row (OOB past Cout: zeros)
-  unsigned b_off[RB];
+  unsigned b_off[RB], b_row[RB];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     const int n = n0 + lrow + 32 * j;
     b_off[j] = n < p.Cout ? (unsigned)(w_off + n * p.Kpad + lq * 4) * 4u : OOB;
+    b_row[j] = (unsigned)(w_off + n * p.Kpad) * 4u;
   }
 
   // this thread's position in K: tap (kh,kw) and channel c of its quad, advanced by 32 per chunk
@@ -291,6 +295,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         }
         ra[j] = make_float4(v[0], v[1], v[2], v[3]);
       }
+    }
+    if (p.chunk_major) {
+      // weight quad of this thread: k = tap * Cin + c
+      const unsigned koff = (unsigned)((kc_kh * p.KW + kc_kw) * p.Cin + kc_c) * 4u;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) rb[j] = buf_load4(rsw, b_off[j] == OOB ? OOB : b_row[j] + koff);
+      kk_next += kBK;
+      // next tap of the same 32-channel slice; after the last tap, the next slice.  The nine shifted reads of a
+      // slice are then adjacent in time on every workgroup of the XCD: their re-reads hit L2 instead of going to
+      // the fabric (tap-major order re-reads a pixel's slice four chunks -- 6 MB of other traffic -- later)
+      if (++kc_kw == p.KW) {
+        kc_kw = 0;
+        if (++kc_kh == p.KH) { kc_kh = 0; kc_c += kBK; }
+      }
+      return;
     }
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
@@ -524,8 +543,11 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
   return check_launch("conv_igemm_f32");
 }
 
-static int launch_conv(const ConvKArgs &a, bool scalar_a, int nphase, hipStream_t stream) {
+static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStream_t stream) {
+  ConvKArgs a = a_in;
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
+  static const bool tap_major = getenv("ISI_CONV_TAP_MAJOR") != nullptr;   // measurements
+  a.chunk_major = (mode == 0 && a.KH * a.KW > 1 && a.C0 % kBK == 0 && a.Cin % kBK == 0 && !tap_major) ? 1 : 0;
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
     // 128x64 tiles are ~20 % slower per FLOP than 128x128, but a GEMM that fills less than the chip's
     // 3 workgroups per CU with 128x128 tiles (the prior's d x d linears at 8 k rows: 260 tiles) finishes
@@ -623,6 +645,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   a.K = KH * KW * a.Cin; a.Kpad = (int)round_up(a.K, kBK);
   a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
   a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * OH * OW;
+  a.KH = KH;
   a.pad = pad; a.convT = 0;
   bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (C1 % 4 == 0) && aligned16(s0->ptr) &&
              (s0->sn % 4 == 0) && (s0->sh % 4 == 0) && (s0->sw % 4 == 0);
@@ -662,6 +685,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.w_phase_stride = Cout * a.Kpad;
   a.w_bytes = (unsigned)((size_t)4 * Cout * a.Kpad * 4);
   a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * H * W;
+  a.KH = 2;
   a.convT = 1;
   const bool vec = s->sc == 1 && (a.C0 % 4 == 0) && aligned16(s->ptr) && (s->sn % 4 == 0) &&
                    (s->sh % 4 == 0) && (s->sw % 4 == 0);

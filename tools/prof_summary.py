@@ -25,6 +25,8 @@ def main(path, last=40):
     print(f"{'kernel':64s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f"{k:64s} {v[0]:6d} {v[1]:12.1f} {v[1] / v[0]:10.1f} {100 * v[1] / tot:6.2f}")
+    if last <= 0:
+        return
     print("\nlast dispatches:")
     for r in rows[-last:]:
         wg = max(r[6], 1)

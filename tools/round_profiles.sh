@@ -18,10 +18,13 @@ python tools/prof_summary.py $O/kt_fe/fe_results.db 0 > $O/frontend_summary.txt 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-prior --steps 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --no-cpu-baseline --no-prior --steps 5 > /dev/null 2>&1
 python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $O/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_hbm_traffic.json > $O/pmc_traffic.txt 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq1 -- python3 bench.py --no-cpu-baseline --no-prior --steps 3 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/pmc_sq2 -- python3 bench.py --no-cpu-baseline --no-prior --steps 3 > /dev/null 2>&1
+python tools/pmc_sq_summary.py $(find $O/pmc_sq1 $O/pmc_sq2 -name "*counter_collection.csv") > $O/pmc_sq_forward.txt 2>&1
 python tools/bench_attention.py > $O/attention.txt 2>&1
 python tools/bench_prior_train.py --batch 8 --steps 4 > $O/prior_train.txt 2>&1
 python tools/bench_train.py > $O/vqvae_train.txt 2>&1
 python tools/bench_prior.py > $O/prior_sampling.txt 2>&1
 python tools/bench_frontend.py > $O/frontend.txt 2>&1
-rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write     # the sqlite / csv dumps are large; the summaries are what is kept
+rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2     # the sqlite / csv dumps are large; the summaries are what is kept
 tail -c 600 $O/bench.json

@@ -120,6 +120,9 @@ int isi_prof_read(int kernel_id, long long *launches, double *ms, double *flops,
  * isi_conv2d_f32 (encoder_decoder.py:95-112,138; vqvae.py:149-150,175-177). */
 int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin,
                              int KH, int KW, void *stream);
+/* Split-f16 pair copy of a packed weight (any of the packed layouts; n_floats % 4 == 0, 16-byte aligned):
+ * every quad of floats becomes {hi0..hi3 | lo0..lo3}, the f16 pieces of 1024 w, in the same 16 bytes. */
+int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream);
 size_t isi_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
 
 /* ConvTranspose2d(k=4,s=2,p=1) weight [Cin,Cout,4,4] -> 4 phase matrices
@@ -166,6 +169,11 @@ typedef struct isi_dst {
                            * |x| < 16384 and weights |w| < 64 (operands are scaled by 2^2 / 2^10 before
                            * the split; the scaling is undone exactly).  An operand outside the range
                            * gives Inf / NaN in the output, never a silently wrong value.        */
+
+#define ISI_CONV_W16 16   /* with ISI_CONV_F16X3: the packed weight is followed in memory by its split-f16 pair copy
+                           * (isi_split_conv_weight_f16 written at packed_w + the packed size in floats: the weights'
+                           * pieces are then prepared once instead of every time a tile is staged; same results bit
+                           * for bit).  Ignored by the launches that do not run split products.          */
 
 /* Conv2d, groups=1, square stride, symmetric zero padding, fp32.
  *   out = [relu]( conv(cat(src0, src1), W) + bias [+ residual] )
@@ -459,6 +467,8 @@ typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
   isi_decoder_w dec_t, dec;
   int n_upsample;
   isi_conv_w upsample[ISI_MAX_STAGES];
+  int w16;       /* 1: every packed convolution weight above is followed by its isi_split_conv_weight_f16 copy
+                  * (used when precision == 4)                                                        */
   int precision; /* products of the convolutions (data and accumulation are always fp32):
                   * 0: fp32 matrix pipe everywhere.  1: ISI_CONV_BF16X3 in `dec` and `upsample` only
                   * (no code index depends on them).  2: ISI_CONV_BF16X3 in every convolution (near-tie

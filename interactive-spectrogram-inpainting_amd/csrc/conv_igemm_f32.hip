@@ -47,6 +47,7 @@ struct ConvKArgs {
   int convT;                 // 1: blockIdx.z = phase (py,px) of ConvTranspose2d(k4,s2,p1)
   int w_phase_stride;        // convT: floats between two phase weight matrices
   int dst_sh, dst_sw;        // convT: strides of the full output tensor (phase offset)
+  const float *w16;          // ISI_CONV_W16: split-f16 pair copy of the packed weight (behind the fp32 one), or null
   int KH;                    // kernel height (K = KH * KW * Cin)
   int chunk_major;           // 1: K is walked slice-major -- for each 32-channel slice all KH x KW taps -- instead of
                              // tap-major (the packed weight keeps k = tap * Cin + c; only the visiting order changes)
@@ -126,7 +127,8 @@ template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) {
   constexpr bool BF = PREC >= 1;
   constexpr bool BF6 = PREC == 2;
-  constexpr bool F16 = PREC == 3;
+  constexpr bool F16 = PREC >= 3;
+  constexpr bool WPRE = PREC == 4;   // weights arrive as split-f16 pairs (ISI_CONV_W16): no conversion
   constexpr int TM = BM / WM / 32;  // 32x32 tiles per wave along M
   constexpr int TN = BN / WN / 32;
   constexpr int RA = BM / 32;  // A rows staged per thread
@@ -350,7 +352,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (BF) {
         uint2 hi, mid, lo;
         if constexpr (BF6) split3_bf16x4(rb[j], hi, mid, lo);
-        else if constexpr (F16) split_f16x4(rb[j], kF16ScaleB, hi, lo);
+        else if constexpr (WPRE) {
+          const uint4 u = __builtin_bit_cast(uint4, rb[j]);
+          hi = make_uint2(u.x, u.y);
+          lo = make_uint2(u.z, u.w);
+        } else if constexpr (F16) split_f16x4(rb[j], kF16ScaleB, hi, lo);
         else split_bf16x4(rb[j], hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Bhi + wo) = hi;
@@ -535,7 +541,7 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
     const double in_px = nphase == 1 ? (double)a.M / (a.OH * a.OW) * a.H * a.W : (double)a.M;
     const double bytes = 4.0 * (in_px * a.Cin + (double)a.M * np * a.Cout * (a.res ? 2 : 1) +
                                 np * a.Cout * a.K);
-    const int kid = PREC == 3 ? prof::K_CONV_F16X3 : PREC == 2 ? prof::K_CONV_BF16X6 : PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
+    const int kid = PREC >= 3 ? prof::K_CONV_F16X3 : PREC == 2 ? prof::K_CONV_BF16X6 : PREC == 1 ? prof::K_CONV_BF16X3 : MODE == 2 ? prof::K_CONV_GATHER
                              : (BN == 128 ? prof::K_CONV_128x128 : BN == 64 ? prof::K_CONV_128x64 : prof::K_CONV_128x32);
     prof::Scope scope(kid, flops, bytes, stream);
     ISI_PROF_LAUNCH(scope, kern, grid, dim3(256), smem, stream, a);
@@ -557,6 +563,11 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
     if (a.bf16x3 == 2) {   // six-term split: fp32-grade products
       if (narrow) return launch_cfg<128, 64, 2, 2, 0, 2>(a, nphase, stream);
       return launch_cfg<128, 128, 2, 2, 0, 2>(a, nphase, stream);
+    }
+    if (a.bf16x3 == 3 && a.w16) {   // split-f16 with the weights' pieces prepared at pack time
+      a.w = a.w16;
+      if (narrow) return launch_cfg<128, 64, 2, 2, 0, 4>(a, nphase, stream);
+      return launch_cfg<128, 128, 2, 2, 0, 4>(a, nphase, stream);
     }
     if (a.bf16x3 == 3) {   // split-f16: fp32-grade products from three terms, f16 range
       if (narrow) return launch_cfg<128, 64, 2, 2, 0, 3>(a, nphase, stream);
@@ -646,6 +657,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
   a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * OH * OW;
   a.KH = KH;
+  a.w16 = ((relu & ISI_CONV_W16) && nz == 1) ? packed_w + (size_t)Cout * a.Kpad : nullptr;
   a.pad = pad; a.convT = 0;
   bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (C1 % 4 == 0) && aligned16(s0->ptr) &&
              (s0->sn % 4 == 0) && (s0->sh % 4 == 0) && (s0->sw % 4 == 0);
@@ -686,6 +698,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.w_bytes = (unsigned)((size_t)4 * Cout * a.Kpad * 4);
   a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * H * W;
   a.KH = 2;
+  a.w16 = (relu & ISI_CONV_W16) ? packed_w + (size_t)4 * Cout * a.Kpad : nullptr;
   a.convT = 1;
   const bool vec = s->sc == 1 && (a.C0 % 4 == 0) && aligned16(s->ptr) && (s->sn % 4 == 0) &&
                    (s->sh % 4 == 0) && (s->sw % 4 == 0);

@@ -49,6 +49,9 @@ int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, i
                              void *stream) {
   return pack_conv_weight_f32(w, packed, Cout, Cin, KH, KW, S(stream));
 }
+int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream) {
+  return split_conv_weight_f16(packed_w, out, n_floats, S(stream));
+}
 size_t isi_packed_conv_weight_floats(int Cout, int Cin, int KH, int KW) {
   return packed_conv_weight_floats(Cout, Cin, KH, KW);
 }

@@ -58,6 +58,34 @@ __global__ void pack_codebook_kernel(const float *__restrict__ embed, float *__r
   e2[k] = s;
 }
 
+// fp32 packed weight -> split-f16 pair format of ISI_CONV_W16: every quad of four consecutive floats becomes
+// 16 bytes {hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3}, the f16 pieces of 1024 w exactly as the kernels of ISI_CONV_F16X3
+// compute them while staging (conv_igemm_f32.hip: split_f16x4) -- a staged quad is then one 16-byte load and two
+// 8-byte LDS stores, no conversion
+typedef _Float16 pk_f16x2 __attribute__((ext_vector_type(2)));
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+__global__ void split_weight_f16_kernel(const float4 *__restrict__ in, uint4 *__restrict__ out, int64_t nq) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const float4 v = in[i];
+  const pk_f32x2 a = pk_f32x2{v.x, v.y} * 1024.f, b = pk_f32x2{v.z, v.w} * 1024.f;
+  const pk_f16x2 ha = __builtin_convertvector(a, pk_f16x2), hb = __builtin_convertvector(b, pk_f16x2);
+  const pk_f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, pk_f32x2), pk_f16x2);
+  const pk_f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, pk_f32x2), pk_f16x2);
+  out[i] = make_uint4(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb),
+                      __builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+
+int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream) {
+  if (!packed || !out || n_floats <= 0 || (n_floats & 3)) return invalid("split_conv_weight_f16: bad argument");
+  if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15)
+    return invalid("split_conv_weight_f16: pointers must be 16-byte aligned");
+  const int64_t nq = n_floats / 4;
+  hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const float4 *>(packed), reinterpret_cast<uint4 *>(out), nq);
+  return check_launch("split_conv_weight_f16");
+}
+
 __global__ void relu_inplace_kernel(float *__restrict__ x, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)

@@ -97,8 +97,19 @@ __device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2
 template <int PREC>
 __device__ __forceinline__ void split_x4(const float4 v, const float s16, uint2 &hi, uint2 &mid, uint2 &lo) {
   if constexpr (PREC == 2) split3_bf16x4(v, hi, mid, lo);
-  else if constexpr (PREC == 3) split_f16x4(v, s16, hi, lo);
+  else if constexpr (PREC >= 3) split_f16x4(v, s16, hi, lo);
   else split_bf16x4(v, hi, lo);
+}
+// weights: PREC 4 = already split-f16 pairs in memory (ISI_CONV_W16)
+template <int PREC>
+__device__ __forceinline__ void split_w4(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
+  if constexpr (PREC == 4) {
+    const uint4 u = __builtin_bit_cast(uint4, v);
+    hi = make_uint2(u.x, u.y);
+    lo = make_uint2(u.z, u.w);
+  } else {
+    split_x4<PREC>(v, kF16ScaleB, hi, mid, lo);
+  }
 }
 #define ISI_MH(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0)
 #define ISI_MF(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0)
@@ -107,7 +118,7 @@ template <int PREC>
 __device__ __forceinline__ f32x16 mfma_split(const s16x8 *a, const s16x8 *b, f32x16 acc) {
   if constexpr (PREC == 2) {
     ISI_MF(a[1], b[0]); ISI_MF(a[0], b[1]); ISI_MF(a[2], b[2]); ISI_MF(a[2], b[0]); ISI_MF(a[0], b[2]); ISI_MF(a[0], b[0]);
-  } else if constexpr (PREC == 3) {
+  } else if constexpr (PREC >= 3) {
     ISI_MH(a[1], b[0]); ISI_MH(a[0], b[1]); ISI_MH(a[0], b[0]);
   } else {
     ISI_MF(a[1], b[0]); ISI_MF(a[0], b[1]); ISI_MF(a[0], b[0]);
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (t >= 9) continue;
       if constexpr (BF) {
         uint2 hi, mid, lo;
-        split_x4<PREC>(rw[k], kF16ScaleB, hi, mid, lo);
+        split_w4<PREC>(rw[k], hi, mid, lo);
         const int wo = (t * 32 + lr) * LDB + bf_slot(t * 32 + lr, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
         *reinterpret_cast<uint2 *>(Wpl + WPS + wo) = lo;
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (n >= C) continue;
       uint2 hi, mid, lo;
       const float4 wv = buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u);
-      split_x4<PREC>(wv, kF16ScaleB, hi, mid, lo);
+      split_w4<PREC>(wv, hi, mid, lo);
       const int wo = n * LDB + bf_slot(n, lq >> 1) + (lq & 1) * 4;
       *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
       *reinterpret_cast<uint2 *>(Wpl + WPS + wo) = lo;
@@ -282,10 +293,10 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
-      const float hpre = (PREC == 3 ? acc1[r] * kF16Unscale : acc1[r]) + b1;
+      const float hpre = (PREC >= 3 ? acc1[r] * kF16Unscale : acc1[r]) + b1;
       const float hv = frow < p.R ? (hpre < 0.f ? 0.f : hpre) : 0.f;   // NaN-propagating rectifier (torch.relu)
       const int wo = row * LDB + bf_slot(row, frow >> 3) + (frow & 7);
-      if constexpr (PREC == 3) {
+      if constexpr (PREC >= 3) {
         const float hs_ = hv * kF16ScaleA;
         const _Float16 h0 = (_Float16)hs_;
         Apl[wo] = __builtin_bit_cast(unsigned short, h0);
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
                                              rsi, eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = (PREC == 3 ? acc2[j][r] * kF16Unscale : acc2[j][r]) + b2 + res[r];
+      float v = (PREC >= 3 ? acc2[j][r] * kF16Unscale : acc2[j][r]) + b2 + res[r];
       if (p.relu) v = v < 0.f ? 0.f : v;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso,
                                             eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0);
@@ -445,6 +456,11 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
     default: return launch_res<4, PREC>(a, B, stream);         \
   }
   if (relu & ISI_CONV_BF16X6) { ISI_RES(2) }
+  if ((relu & ISI_CONV_F16X3) && (relu & ISI_CONV_W16)) {   // split-f16 pair copies behind the fp32 weights
+    a.w1 = w1 + (size_t)R * 9 * C;
+    a.w2 = w2 + (size_t)C * 32;
+    ISI_RES(4)
+  }
   if (relu & ISI_CONV_F16X3) { ISI_RES(3) }
   if (relu & ISI_CONV_BF16X3) { ISI_RES(1) }
   ISI_RES(0)

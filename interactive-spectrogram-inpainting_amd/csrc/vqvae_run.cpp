@@ -245,9 +245,10 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   int rc;
   // precision: 0 all fp32 | 1 decoder split-bf16 (x3) | 2 everything x3 | 3 index-feeding layers six-term
   // split (x6: fp32-grade products), decoder x3 | 4 split-f16 everywhere (fp32-grade products, f16 range)
-  const int pf_enc = w.precision == 4 ? ISI_CONV_F16X3 : w.precision == 3 ? ISI_CONV_BF16X6
+  const int f16 = ISI_CONV_F16X3 | (w.w16 ? ISI_CONV_W16 : 0);
+  const int pf_enc = w.precision == 4 ? f16 : w.precision == 3 ? ISI_CONV_BF16X6
                    : w.precision == 2 ? ISI_CONV_BF16X3 : 0;   // feeds the quantisers
-  const int pf_dec = w.precision == 4 ? ISI_CONV_F16X3 : w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
+  const int pf_dec = w.precision == 4 ? f16 : w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
 
   if (mode & ISI_MODE_ENCODE) {
     if (!x) return invalid("vqvae: x is null");

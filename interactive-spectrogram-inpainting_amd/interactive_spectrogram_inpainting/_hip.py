@@ -60,7 +60,8 @@ class isi_vqvae_w(C.Structure):
                 ("quantize_conv_t", isi_conv_w), ("quantize_conv_b", isi_conv_w),
                 ("quantize_t", isi_codebook_w), ("quantize_b", isi_codebook_w),
                 ("dec_t", isi_decoder_w), ("dec", isi_decoder_w),
-                ("n_upsample", C.c_int), ("upsample", isi_conv_w * ISI_MAX_STAGES), ("precision", C.c_int)]
+                ("n_upsample", C.c_int), ("upsample", isi_conv_w * ISI_MAX_STAGES), ("w16", C.c_int),
+                ("precision", C.c_int)]
 
 
 class isi_vqvae_out(C.Structure):
@@ -130,6 +131,7 @@ SIGNATURES = {
     "isi_pack_conv_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "isi_pack_convT_k4s2_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
+    "isi_split_conv_weight_f16": (C.c_int, [_P, _P, C.c_int64, _P]),
     "isi_packed_convT_k4s2_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "isi_pack_codebook_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "isi_conv2d_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.POINTER(isi_src),

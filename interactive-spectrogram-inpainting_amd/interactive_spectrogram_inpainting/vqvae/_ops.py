@@ -18,19 +18,27 @@ def _s(t):
     return C.c_void_p(_hip.stream_ptr(t.device))
 
 
-def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
-    """torch Conv2d weight [Cout,Cin,KH,KW] -> packed [Cout, Kpad]."""
+def _with_f16_copy(out: torch.Tensor, n: int) -> torch.Tensor:
+    """Fill out[n:2n] with the split-f16 pair copy of the packed weight out[:n] (ISI_CONV_W16)."""
+    _hip.check(_hip.lib().isi_split_conv_weight_f16(out.data_ptr(), out.data_ptr() + 4 * n, n, _s(out)),
+               "isi_split_conv_weight_f16")
+    return out
+
+
+def pack_conv_weight(weight: torch.Tensor, with_f16: bool = False) -> torch.Tensor:
+    """torch Conv2d weight [Cout,Cin,KH,KW] -> packed [Cout, Kpad] (`with_f16`: followed by its split-f16 pair
+    copy, the layout ISI_CONV_W16 expects)."""
     _hip.require_gpu(weight, "conv weight")
     w = weight.detach().contiguous()
     cout, cin, kh, kw = w.shape
     n = _hip.lib().isi_packed_conv_weight_floats(cout, cin, kh, kw)
-    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    out = torch.empty(2 * n if with_f16 else n, dtype=torch.float32, device=w.device)
     _hip.check(_hip.lib().isi_pack_conv_weight_f32(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, _s(w)),
                "isi_pack_conv_weight_f32")
-    return out
+    return _with_f16_copy(out, n) if with_f16 else out
 
 
-def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
+def pack_convT_weight(weight: torch.Tensor, with_f16: bool = False) -> torch.Tensor:
     """torch ConvTranspose2d(k4,s2,p1) weight [Cin,Cout,4,4] -> 4 packed phase matrices."""
     _hip.require_gpu(weight, "convT weight")
     w = weight.detach().contiguous()
@@ -38,10 +46,10 @@ def pack_convT_weight(weight: torch.Tensor) -> torch.Tensor:
     if (kh, kw) != (4, 4):
         raise NotImplementedError("only ConvTranspose2d(kernel 4, stride 2, padding 1) is built")
     n = _hip.lib().isi_packed_convT_k4s2_weight_floats(cin, cout)
-    out = torch.empty(n, dtype=torch.float32, device=w.device)
+    out = torch.empty(2 * n if with_f16 else n, dtype=torch.float32, device=w.device)
     _hip.check(_hip.lib().isi_pack_convT_k4s2_weight_f32(w.data_ptr(), out.data_ptr(), cin, cout, _s(w)),
                "isi_pack_convT_k4s2_weight_f32")
-    return out
+    return _with_f16_copy(out, n) if with_f16 else out
 
 
 def pack_codebook(embed: torch.Tensor):
@@ -57,8 +65,9 @@ def pack_codebook(embed: torch.Tensor):
 
 
 def _prec_flag(bf16x3) -> int:
-    """False / 0 -> exact fp32, True / 1 -> ISI_CONV_BF16X3, 2 -> ISI_CONV_BF16X6, 3 -> ISI_CONV_F16X3."""
-    return {0: 0, 1: 2, 2: 4, 3: 8}[int(bf16x3)]
+    """False / 0 -> exact fp32, True / 1 -> ISI_CONV_BF16X3, 2 -> ISI_CONV_BF16X6, 3 -> ISI_CONV_F16X3,
+    4 -> ISI_CONV_F16X3 | ISI_CONV_W16 (the packed weights carry their split-f16 pair copy, `with_f16=True`)."""
+    return {0: 0, 1: 2, 2: 4, 3: 8, 4: 24}[int(bf16x3)]
 
 
 def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,

@@ -75,15 +75,17 @@ class _ConvParams(nn.Module):
         return torch.cat([dense[g * rows:(g + 1) * rows, g * cols:(g + 1) * cols] for g in range(self.groups)], 0)
 
     def packed(self) -> torch.Tensor:
+        """Packed weight followed by its split-f16 pair copy (the layout ISI_CONV_W16 / isi_vqvae_w.w16 expect;
+        entry points called without that flag read the first half only)."""
         key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
         if self._packed is None or self._packed_key != key:
             if self.transposed:
                 if (self.kernel_size, self.stride, self.padding) != (4, 2, 1):
                     raise NotImplementedError("only ConvTranspose2d(k=4, s=2, p=1) is built "
                                               "(use_local_kernels=True is not)")
-                self._packed = _ops.pack_convT_weight(self.dense_weight())
+                self._packed = _ops.pack_convT_weight(self.dense_weight(), with_f16=True)
             else:
-                self._packed = _ops.pack_conv_weight(self.dense_weight())
+                self._packed = _ops.pack_conv_weight(self.dense_weight(), with_f16=True)
             self._packed_key = key
         return self._packed
 

@@ -184,7 +184,7 @@ class VQVAE(nn.Module):
         def conv(m: _ConvParams) -> _hip.isi_conv_w:
             p = m.packed()
             keep.append(p)
-            wmax.append(p.detach().abs().max())
+            wmax.append(m.weight.detach().abs().max())
             return _hip.isi_conv_w(p.data_ptr(), m.bias.data_ptr(), m.in_channels, m.out_channels)
 
         def res(stack, blocks, idxs):
@@ -226,6 +226,7 @@ class VQVAE(nn.Module):
         w.quantize_t, w.quantize_b = book(self.quantize_t), book(self.quantize_b)
         w.dec_t, w.dec = dec(self.dec_t), dec(self.dec)
         w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2, "split_bf16": 3, "split_f16": 4}[self.conv_precision]
+        w.w16 = 1          # _ConvParams.packed() carries the split-f16 pair copies
         w.n_upsample = len(self.upsample_top_to_bottom)
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)

@@ -395,7 +395,7 @@ def test_split_f16_products_against_fp64():
     b3 = torch.randn(R, generator=g) * 0.1
     w1 = torch.randn(C, R, 1, 1, generator=g) * 0.1
     b1 = torch.randn(C, generator=g) * 0.1
-    pw, p3, p1 = (_ops.pack_conv_weight(t.to(dev)) for t in (w, w3, w1))
+    pw, p3, p1 = (_ops.pack_conv_weight(t.to(dev), with_f16=True) for t in (w, w3, w1))
     F = torch.nn.functional
     for scale in (1e-3, 1e-1, 1.0, 30.0, 3000.0):
         x = torch.randn(B, C, H, W, generator=g).abs() * scale     # max ~ 4.5 scale < 16384
@@ -406,12 +406,24 @@ def test_split_f16_products_against_fp64():
             y = _ops.conv2d(xd, pw, b.to(dev), C, 3, 1, 1, relu=False, bf16x3=mode).cpu().double()
             err[mode] = ((y - ref).abs().max() / ref.abs().max()).item()
         assert err[3] < 3e-6 and err[3] < 2.0 * max(err[0], err[2]) + 1e-7, (scale, err)
+        # weights' pieces prepared at pack time (ISI_CONV_W16): the same bits
+        assert torch.equal(_ops.conv2d(xd, pw, b.to(dev), C, 3, 1, 1, relu=False, bf16x3=4),
+                           _ops.conv2d(xd, pw, b.to(dev), C, 3, 1, 1, relu=False, bf16x3=3))
         h = torch.relu(F.conv2d(x.double(), w3.double(), b3.double(), padding=1))
         ref = torch.relu(x.double() + F.conv2d(h, w1.double(), b1.double()))
         for mode in (0, 2, 3):
             y = _ops.resblock(xd, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=mode).cpu().double()
             err[mode] = ((y - ref).abs().max() / ref.abs().max()).item()
         assert err[3] < 3e-6 and err[3] < 2.0 * max(err[0], err[2]) + 1e-7, (scale, err)
+        assert torch.equal(_ops.resblock(xd, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4),
+                           _ops.resblock(xd, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=3))
+    # transposed convolution (4 phase matrices)
+    wt = torch.randn(C, 64, 4, 4, generator=g) * 0.05
+    pt = _ops.pack_convT_weight(wt.to(dev), with_f16=True)
+    y3 = _ops.conv_transpose2d_k4s2(xd, pt, None, 64, relu=True, bf16x3=3)
+    assert torch.equal(_ops.conv_transpose2d_k4s2(xd, pt, None, 64, relu=True, bf16x3=4), y3)
+    ref = torch.relu(F.conv_transpose2d(x.double(), wt.double(), None, stride=2, padding=1))
+    assert ((y3.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
 
 
 def test_split_f16_range_violations_are_loud():

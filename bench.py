@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU per step")
+    ap.add_argument("--spinup-ms", type=float, default=150.0,
+                    help="untimed forwards before the warm-up steps until the clocks are steady")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prior", action="store_true", help="skip the secondary prior-sampling metric")
     args = ap.parse_args()
@@ -275,6 +277,12 @@ def main():
         torch.cuda.synchronize(device)
 
     with torch.no_grad():
+        # device spin-up, untimed and independent of --warmup: from idle the part needs ~15 forwards (35 ms) to
+        # reach its steady clock (first forwards 3.0 ms, steady 2.3 ms; tools/bench_ramp.py prints the ramp)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spinup_ms * 1e-3:
+            out = model(x)
+            torch.cuda.synchronize(device)
         for _ in range(args.warmup):
             out = model(x)
         barrier()
@@ -339,7 +347,7 @@ def main():
             "metric": "spectrograms/sec VQ-VAE fwd+quantize @B64",
             "value": round(world * args.batch * args.steps / dt, 2),
             "unit": "spectrograms/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms,
             "ms_per_step": round(dt * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "split_f16": "f32 (products split into two f16 pieces, three terms)"}.get(

@@ -102,7 +102,8 @@ int isi_spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t
 
 /* ------------------------------------------------- measurement (bench.py) */
 /* Per-launch timing with HIP events recorded on the launch stream.  State is
- * per calling thread; enabling clears earlier records.  isi_prof_read blocks
+ * per calling thread; `on` = 1 starts (earlier records cleared), 0 pauses, 2 resumes without
+ * clearing (bench.py times every n-th step only).  isi_prof_read blocks
  * until the recorded events have completed and returns, for one kernel id in
  * [0, isi_prof_num_kernels()), the number of launches, their summed duration
  * (ms) and their summed algorithmic FLOPs / bytes. */

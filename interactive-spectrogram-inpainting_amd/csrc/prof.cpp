@@ -58,8 +58,8 @@ Scope::Scope(int kernel_id, double flops, double bytes, hipStream_t s) : slot(-1
 hipEvent_t Scope::start() const { return g.recs[slot].start; }
 hipEvent_t Scope::stop() const { return g.recs[slot].stop; }
 
-int enable(int on) {
-  if (on) {
+int enable(int on) {   // 0: pause, 1: start (records cleared), 2: resume
+  if (on == 1) {
     g.recs.clear();
     g.used = 0;
   }

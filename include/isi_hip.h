@@ -176,6 +176,19 @@ typedef struct isi_dst {
                            * pieces are then prepared once instead of every time a tile is staged; same results bit
                            * for bit).  Ignored by the launches that do not run split products.          */
 
+/* Activations as split-f16 PAIRS (with ISI_CONV_F16X3 | ISI_CONV_W16): an element's 4 bytes hold hi = f16(4 x) in the
+ * low half and lo = f16(4 x - hi) in the high half, the pieces the split-f16 kernels otherwise compute from the fp32
+ * value every time they stage it (once per tap and output tile).  A producer writes them once in its epilogue
+ * (ISI_CONV_OUT_PAIR, any convolution / residual-block launch), a consumer that runs the split-f16 kernel reads them
+ * with a de-interleave (ISI_CONV_IN0_PAIR / ISI_CONV_IN1_PAIR per source; other launches return ISI_ERR_UNSUPPORTED).
+ * Same matrix operands bit for bit; a residual-block skip connection reads (hi + lo) / 4, within 2^-24 of x.
+ * isi_pair_encode_f32 / isi_pair_decode_f32 convert whole tensors (tests, boundaries).                        */
+#define ISI_CONV_IN0_PAIR 32
+#define ISI_CONV_IN1_PAIR 64
+#define ISI_CONV_OUT_PAIR 128
+int isi_pair_encode_f32(const float *x, float *pairs, int64_t n, void *stream);
+int isi_pair_decode_f32(const float *pairs, float *x, int64_t n, void *stream);
+
 /* Conv2d, groups=1, square stride, symmetric zero padding, fp32.
  *   out = [relu]( conv(cat(src0, src1), W) + bias [+ residual] )
  * src1.ptr may be NULL (single source); residual.ptr may be NULL.  `residual`

@@ -47,6 +47,8 @@ struct ConvKArgs {
   int convT;                 // 1: blockIdx.z = phase (py,px) of ConvTranspose2d(k4,s2,p1)
   int w_phase_stride;        // convT: floats between two phase weight matrices
   int dst_sh, dst_sw;        // convT: strides of the full output tensor (phase offset)
+  int in0_pair, in1_pair;    // ISI_CONV_IN0_PAIR / IN1_PAIR: the source holds split-f16 pairs (hi | lo << 16 per element)
+  int out_pair;              // ISI_CONV_OUT_PAIR: write the output as split-f16 pairs
   const float *w16;          // ISI_CONV_W16: split-f16 pair copy of the packed weight (behind the fp32 one), or null
   int KH;                    // kernel height (K = KH * KW * Cin)
   int chunk_major;           // 1: K is walked slice-major -- for each 32-channel slice all KH x KW taps -- instead of
@@ -121,6 +123,22 @@ __device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2
   const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
   hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+
+// ---- activations as split-f16 PAIRS (ISI_CONV_OUT_PAIR / IN*_PAIR): an element's 4 bytes hold hi = f16(4 x) in the
+// low half and lo = f16(4 x - hi) in the high half -- exactly the pieces split_f16x4 computes while staging, written
+// ONCE by the producer's epilogue instead of once per tap and output tile by every consumer.  A staged quad is then
+// four v_perm_b32 (de-interleave) instead of ~14 conversion instructions.
+__device__ __forceinline__ unsigned pair_encode(const float v) {
+  const float t = v * kF16ScaleA;
+  const _Float16 h = (_Float16)t;
+  const _Float16 l = (_Float16)(t - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ void pair_quad(const float4 v, uint2 &hi, uint2 &lo) {
+  const uint4 u = __builtin_bit_cast(uint4, v);
+  hi = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x05040100u), __builtin_amdgcn_perm(u.w, u.z, 0x05040100u));
+  lo = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x07060302u), __builtin_amdgcn_perm(u.w, u.z, 0x07060302u));
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
@@ -243,6 +261,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   float4 ra[RA], rb[RB];
   float4 ra1[DUAL ? RA : 1];  // second-source candidates (DUAL only)
   bool sel1 = false;
+  bool chunk_pair = false;   // uniform: the chunk in flight comes from a pair-format source (split-f16 kernels)
 
   auto load_chunk = [&]() {
     if constexpr (!SCALAR_A) {
@@ -252,6 +271,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (!DUAL) {
         // the whole workgroup reads one source in this chunk: uniform descriptor
         const bool sec_u = __builtin_amdgcn_readfirstlane((int)second) != 0;
+        chunk_pair = (sec_u ? p.in1_pair : p.in0_pair) != 0;
         const __amdgpu_buffer_rsrc_t rs = sec_u ? rs1 : rs0;
         const int sh = sec_u ? p.s1h : p.s0h, sw = sec_u ? p.s1w : p.s0w;
 #pragma unroll
@@ -337,7 +357,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (BF) {
         uint2 hi, mid, lo;
         if constexpr (BF6) split3_bf16x4(v, hi, mid, lo);
-        else if constexpr (F16) split_f16x4(v, kF16ScaleA, hi, lo);
+        else if constexpr (WPRE) {
+          if (chunk_pair) pair_quad(v, hi, lo); else split_f16x4(v, kF16ScaleA, hi, lo);
+        } else if constexpr (F16) split_f16x4(v, kF16ScaleA, hi, lo);
         else split_bf16x4(v, hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Ahi + wo) = hi;
@@ -509,7 +531,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         // v - v is 0 for finite v and NaN otherwise.  (The select form `v < 0 ? 0 : v` makes this compiler allocate
         // 244 VGPRs for the split-f16 variant, 1 wave per SIMD.)
         if (p.relu) v = fmaxf(v, 0.f) + (v - v);
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso, oo[r], 0, 0);
+        const int bits = p.out_pair ? (int)pair_encode(v) : __builtin_bit_cast(int, v);
+        __builtin_amdgcn_raw_buffer_store_b32(bits, rso, oo[r], 0, 0);
       }
     }
   }
@@ -554,6 +577,9 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
   static const bool tap_major = getenv("ISI_CONV_TAP_MAJOR") != nullptr;   // measurements
   a.chunk_major = (mode == 0 && a.KH * a.KW > 1 && a.C0 % kBK == 0 && a.Cin % kBK == 0 && !tap_major) ? 1 : 0;
+  if ((a.in0_pair || a.in1_pair) && !(a.bf16x3 == 3 && a.w16 && mode == 0 && a.Cout > 32 && a.K >= 128))
+    return unsupported("conv: pair-format sources need the split-f16 kernel (ISI_CONV_F16X3 | ISI_CONV_W16, "
+                       "channels-last sources of 32-channel multiples, Cout > 32, K >= 128)");
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
     // 128x64 tiles are ~20 % slower per FLOP than 128x128, but a GEMM that fills less than the chip's
     // 3 workgroups per CU with 128x128 tiles (the prior's d x d linears at 8 k rows: 260 tiles) finishes
@@ -591,6 +617,14 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
 // flags -> 0 exact fp32 | 1 bf16x3 | 2 bf16x6 | 3 f16x3 (the most precise requested mode wins)
 static int split_mode(int flags) {
   return (flags & ISI_CONV_BF16X6) ? 2 : (flags & ISI_CONV_F16X3) ? 3 : (flags & ISI_CONV_BF16X3) ? 1 : 0;
+}
+
+// Would a convolution of dense channels-last sources (C0 [+ C1] channels) run the split-f16 kernel that accepts
+// pair-format sources?  (launch_conv's own conditions, for callers that plan tensor formats ahead: vqvae_run.cpp)
+bool conv_pair_sources_ok(int C0, int C1, int Cout, int taps) {
+  const bool vec = C0 % 4 == 0 && C1 % 4 == 0;
+  const bool uniform = C1 == 0 || (C0 % kBK == 0 && C1 % kBK == 0);
+  return vec && uniform && Cout > 32 && taps * (C0 + C1) >= 128;
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -657,6 +691,9 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   a.w_bytes = (unsigned)((size_t)Cout * a.Kpad * 4);
   a.KW = KW; a.stride = stride; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * OH * OW;
   a.KH = KH;
+  a.in0_pair = (relu & ISI_CONV_IN0_PAIR) ? 1 : 0; a.in1_pair = (two && (relu & ISI_CONV_IN1_PAIR)) ? 1 : 0;
+  a.out_pair = (relu & ISI_CONV_OUT_PAIR) ? 1 : 0;
+  if (a.res && (a.in0_pair || a.in1_pair || a.out_pair)) return unsupported("conv2d: pair formats with a residual input");
   a.w16 = ((relu & ISI_CONV_W16) && nz == 1) ? packed_w + (size_t)Cout * a.Kpad : nullptr;
   a.pad = pad; a.convT = 0;
   bool vec = s0->sc == 1 && (a.C0 % 4 == 0) && (C1 % 4 == 0) && aligned16(s0->ptr) &&
@@ -676,6 +713,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   const int64_t eo = extent(B, dst->sn, Cout, dst->sc, 2 * H, dst->sh, 2 * W, dst->sw);
   if (e0 > kMaxElems || eo > kMaxElems) return unsupported("convT: a tensor spans 4 GiB or more");
   if (convT_small_applicable(s->C, Cout)) {
+    if (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_OUT_PAIR)) return unsupported("convT: pair formats on the few-channel kernel");
     // few output channels: GEMM + col2im gather kernel (weights were packed in its layout)
     return convT_k4s2_small_f32(s->ptr, packed_w, bias, dst->ptr, B, H, W, s->C, Cout, e0, (int)s->sn,
                                 (int)s->sc, (int)s->sh, (int)s->sw, (int)dst->sn, (int)dst->sc,
@@ -698,6 +736,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.w_bytes = (unsigned)((size_t)4 * Cout * a.Kpad * 4);
   a.KW = 2; a.stride = 1; a.relu = relu & 1; a.bf16x3 = split_mode(relu); a.M = B * H * W;
   a.KH = 2;
+  a.in0_pair = (relu & ISI_CONV_IN0_PAIR) ? 1 : 0; a.out_pair = (relu & ISI_CONV_OUT_PAIR) ? 1 : 0;
   a.w16 = (relu & ISI_CONV_W16) ? packed_w + (size_t)4 * Cout * a.Kpad : nullptr;
   a.convT = 1;
   const bool vec = s->sc == 1 && (a.C0 % 4 == 0) && aligned16(s->ptr) && (s->sn % 4 == 0) &&

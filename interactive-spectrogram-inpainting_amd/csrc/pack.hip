@@ -86,6 +86,42 @@ int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hip
   return check_launch("split_conv_weight_f16");
 }
 
+// fp32 <-> activation pair format (ISI_CONV_OUT_PAIR / IN*_PAIR): hi = f16(4 x) | lo = f16(4 x - hi) << 16
+__global__ void pair_encode_kernel(const float *__restrict__ x, unsigned *__restrict__ out, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float t = x[i] * 4.f;
+    const _Float16 h = (_Float16)t;
+    const _Float16 l = (_Float16)(t - (float)h);
+    out[i] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+  }
+}
+__global__ void pair_decode_kernel(const unsigned *__restrict__ in, float *__restrict__ x, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const unsigned u = in[i];
+    const float h = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
+    const float l = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
+    x[i] = (h + l) * 0.25f;
+  }
+}
+int pair_encode_f32(const float *x, float *out, int64_t n, hipStream_t stream) {
+  if (!x || !out || n < 0) return invalid("pair_encode: bad argument");
+  if (n == 0) return ISI_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(pair_encode_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, x,
+                     reinterpret_cast<unsigned *>(out), n);
+  return check_launch("pair_encode_f32");
+}
+int pair_decode_f32(const float *in, float *x, int64_t n, hipStream_t stream) {
+  if (!x || !in || n < 0) return invalid("pair_decode: bad argument");
+  if (n == 0) return ISI_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(pair_decode_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
+                     reinterpret_cast<const unsigned *>(in), x, n);
+  return check_launch("pair_decode_f32");
+}
+
 __global__ void relu_inplace_kernel(float *__restrict__ x, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)

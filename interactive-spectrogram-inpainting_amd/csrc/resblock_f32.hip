@@ -32,6 +32,7 @@ struct ResKArgs {
   float *out;
   unsigned in_bytes, w1_bytes, w2_bytes;
   int C, R, H, W, relu;
+  int in_pair, out_pair;   // ISI_CONV_IN0_PAIR / ISI_CONV_OUT_PAIR (split-f16 variant with pack-time weight pieces only)
 };
 
 namespace {
@@ -93,6 +94,22 @@ __device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2
   const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
   hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+}
+// activation pair format (conv_igemm_f32.hip): hi = f16(4 x) | lo = f16(4 x - hi) << 16 per element
+__device__ __forceinline__ unsigned pair_encode(const float v) {
+  const float t = v * kF16ScaleA;
+  const _Float16 h = (_Float16)t;
+  const _Float16 l = (_Float16)(t - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+__device__ __forceinline__ float pair_decode(const unsigned u) {
+  return ((float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)) +
+          (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16))) * (1.f / kF16ScaleA);
+}
+__device__ __forceinline__ void pair_quad(const float4 v, uint2 &hi, uint2 &lo) {
+  const uint4 u = __builtin_bit_cast(uint4, v);
+  hi = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x05040100u), __builtin_amdgcn_perm(u.w, u.z, 0x05040100u));
+  lo = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x07060302u), __builtin_amdgcn_perm(u.w, u.z, 0x07060302u));
 }
 template <int PREC>
 __device__ __forceinline__ void split_x4(const float4 v, const float s16, uint2 &hi, uint2 &mid, uint2 &lo) {
@@ -187,7 +204,8 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (j < NA - 1 || i < HPIX * 8) {
         if constexpr (BF) {
           uint2 hi, mid, lo;
-          split_x4<PREC>(ra[j], kF16ScaleA, hi, mid, lo);
+          if (PREC == 4 && p.in_pair) pair_quad(ra[j], hi, lo);
+          else split_x4<PREC>(ra[j], kF16ScaleA, hi, mid, lo);
           const int wo = (i >> 3) * LDB + bf_slot(i >> 3, lq >> 1) + (lq & 1) * 4;
           *reinterpret_cast<uint2 *>(Apl + wo) = hi;
           *reinterpret_cast<uint2 *>(Apl + APS + wo) = lo;
@@ -392,9 +410,11 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
                                              rsi, eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0));
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = (PREC >= 3 ? acc2[j][r] * kF16Unscale : acc2[j][r]) + b2 + res[r];
+      const float rr = (PREC == 4 && p.in_pair) ? pair_decode(__builtin_bit_cast(unsigned, res[r])) : res[r];
+      float v = (PREC >= 3 ? acc2[j][r] * kF16Unscale : acc2[j][r]) + b2 + rr;
       if (p.relu) v = v < 0.f ? 0.f : v;
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso,
+      const int bits = (PREC == 4 && p.out_pair) ? (int)pair_encode(v) : __builtin_bit_cast(int, v);
+      __builtin_amdgcn_raw_buffer_store_b32(bits, rso,
                                             eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0);
     }
   }
@@ -448,6 +468,10 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
   a.w1_bytes = (unsigned)((size_t)R * 9 * C * 4);  // packed [R][9C], 9C % 32 == 0
   a.w2_bytes = (unsigned)((size_t)C * 32 * 4);
   a.C = C; a.R = R; a.H = H; a.W = W; a.relu = relu & 1;
+  a.in_pair = (relu & ISI_CONV_IN0_PAIR) ? 1 : 0;
+  a.out_pair = (relu & ISI_CONV_OUT_PAIR) ? 1 : 0;
+  if ((a.in_pair || a.out_pair) && (!((relu & ISI_CONV_F16X3) && (relu & ISI_CONV_W16)) || (relu & ISI_CONV_BF16X6)))
+    return unsupported("resblock: pair formats need ISI_CONV_F16X3 | ISI_CONV_W16");
 #define ISI_RES(PREC)                                          \
   switch (C / 32) {                                            \
     case 1: return launch_res<1, PREC>(a, B, stream);          \

@@ -107,14 +107,19 @@ bool compute_shapes(const isi_vqvae_w &w, int B, int H, int W, Shapes &s) {
 // Rosinality residual stack shared by encoder and decoder: `cur` holds the
 // rectified input r; each block writes relu(r + conv1(relu(conv3(r)))).
 // The last block writes to `final_out` when that is non-null.
+// `in_pair` / `out_pair`: the stack's input / output tensors are in the split-f16 pair format (isi_hip.h,
+// ISI_CONV_*_PAIR; only set when every block is fusable, see pairs_eligible); tensors between blocks follow `in_pair`.
 int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act &cur, int B,
-                  float *s0, float *s1, float *hid, float *final_out, int pf, hipStream_t st) {
+                  float *s0, float *s1, float *hid, float *final_out, int pf, bool in_pair, bool out_pair,
+                  hipStream_t st) {
   for (int i = 0; i < n_res; ++i) {
     const int R = res3[i].Cout;
     float *outp = (i == n_res - 1 && final_out) ? final_out : (cur.p == s0 ? s1 : s0);
     if (resblock_fusable(cur.C, R)) {
+      const bool op = (i == n_res - 1) ? out_pair : in_pair;
       int rc = resblock_f32(cur.p, res3[i].w, res3[i].bias, res1[i].w, res1[i].bias, outp, B, cur.H,
-                            cur.W, cur.C, R, /*relu*/ 1 | pf, st);
+                            cur.W, cur.C, R, /*relu*/ 1 | pf | (in_pair ? ISI_CONV_IN0_PAIR : 0) |
+                            (op ? ISI_CONV_OUT_PAIR : 0), st);
       if (rc) return rc;
       cur.p = outp;
       continue;
@@ -135,29 +140,33 @@ int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act
 }
 
 // RosinalityEncoder (encoder_decoder.py:38-126).  `in` may be NCHW.
+// `in_pair`: the input is in the pair format; `pairs`: every tensor this encoder writes (including its output) is.
 int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *s0, float *s1,
-                float *hid, float *final_out, Act &out, int pf, hipStream_t st) {
+                float *hid, float *final_out, Act &out, int pf, bool in_pair, bool pairs, hipStream_t st) {
   Act cur{nullptr, in.C, H, W};
   isi_src cs = in;
+  const int op = pairs ? ISI_CONV_OUT_PAIR : 0;
+  bool cp = in_pair;   // format of the current tensor
   for (int i = 0; i < e.n_down; ++i) {
     const int OH = down_dim(cur.H), OW = down_dim(cur.W);
     float *o = (cur.p == s0) ? s1 : s0;
     isi_dst d = dst_nhwc(o, e.down[i].Cout, OH, OW);
     int rc = conv2d_f32(&cs, nullptr, e.down[i].w, e.down[i].bias, nullptr, &d, B, cur.H, cur.W,
-                        e.down[i].Cout, 4, 4, 2, 1, 1 | pf, st);
+                        e.down[i].Cout, 4, 4, 2, 1, 1 | pf | (cp ? ISI_CONV_IN0_PAIR : 0) | op, st);
     if (rc) return rc;
     cur = Act{o, e.down[i].Cout, OH, OW};
     cs = src_nhwc(cur.p, cur.C, cur.H, cur.W);
+    cp = pairs;
   }
   {
     float *o = (e.n_res == 0) ? final_out : ((cur.p == s0) ? s1 : s0);
     isi_dst d = dst_nhwc(o, e.conv3.Cout, cur.H, cur.W);
     int rc = conv2d_f32(&cs, nullptr, e.conv3.w, e.conv3.bias, nullptr, &d, B, cur.H, cur.W,
-                        e.conv3.Cout, 3, 3, 1, 1, 1 | pf, st);
+                        e.conv3.Cout, 3, 3, 1, 1, 1 | pf | (cp ? ISI_CONV_IN0_PAIR : 0) | op, st);
     if (rc) return rc;
     cur = Act{o, e.conv3.Cout, cur.H, cur.W};
   }
-  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, pf, st);
+  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, pf, pairs, pairs, st);
   if (rc) return rc;
   out = cur;
   return ISI_OK;
@@ -165,17 +174,27 @@ int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *
 
 // RosinalityDecoder (encoder_decoder.py:129-227).  Input = cat(in0, in1) on
 // channels (in1 optional); the last transposed conv writes through `final_dst`.
+// `in0_pair` / `in1_pair`: formats of the two inputs; `pairs`: internal tensors are written in the pair format
+// wherever their consumer reads it (the few-channel transposed-convolution kernel reads fp32); `final_pair`: format
+// of the tensor written through `final_dst`.
 int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, int B, int H, int W,
-                float *s0, float *s1, float *hid, const isi_dst &final_dst, int pf, hipStream_t st) {
+                float *s0, float *s1, float *hid, const isi_dst &final_dst, int pf, bool in0_pair, bool in1_pair,
+                bool pairs, bool final_pair, hipStream_t st) {
   Act cur{s0, d.conv3.Cout, H, W};
+  // format in which up[i] wants its input: fp32 for the few-channel kernel
+  auto up_reads_pair = [&](int i, int Cin) { return pairs && !convT_small_applicable(Cin, d.up[i].Cout); };
   {
     isi_dst dd = dst_nhwc(cur.p, cur.C, H, W);
+    const bool op = d.n_res ? pairs : (d.n_up ? up_reads_pair(0, cur.C) : final_pair);
     int rc = conv2d_f32(&in0, in1, d.conv3.w, d.conv3.bias, nullptr, &dd, B, H, W, cur.C, 3, 3, 1,
-                        1, 1 | pf, st);
+                        1, 1 | pf | (in0_pair ? ISI_CONV_IN0_PAIR : 0) | (in1_pair ? ISI_CONV_IN1_PAIR : 0) |
+                        (op ? ISI_CONV_OUT_PAIR : 0), st);
     if (rc) return rc;
   }
+  bool cp = pairs;   // format of `cur` after the residual stack
   {
-    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, pf, st);
+    cp = d.n_up ? up_reads_pair(0, cur.C) : final_pair;
+    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, pf, pairs, cp, st);
     if (rc) return rc;
   }
   for (int i = 0; i < d.n_up; ++i) {
@@ -183,12 +202,65 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
     isi_src s = src_nhwc(cur.p, cur.C, cur.H, cur.W);
     float *o = (cur.p == s0) ? s1 : s0;
     isi_dst dd = last ? final_dst : dst_nhwc(o, d.up[i].Cout, 2 * cur.H, 2 * cur.W);
+    const bool op = last ? final_pair : up_reads_pair(i + 1, d.up[i].Cout);
     int rc = conv_transpose2d_k4s2_f32(&s, d.up[i].w, d.up[i].bias, &dd, B, cur.H, cur.W,
-                                       d.up[i].Cout, (last ? 0 : 1) | pf, st);
+                                       d.up[i].Cout, (last ? 0 : 1) | pf | (cp ? ISI_CONV_IN0_PAIR : 0) |
+                                       (op ? ISI_CONV_OUT_PAIR : 0), st);
     if (rc) return rc;
+    cp = op;
     cur = Act{o, d.up[i].Cout, 2 * cur.H, 2 * cur.W};
   }
   return ISI_OK;
+}
+
+// Can this model run with its internal activations in the split-f16 pair format (precision 4 with pack-time weight
+// pieces)?  Every launch that would READ a pair tensor must be one that accepts it: the split-f16 convolution kernel
+// (conv_pair_sources_ok) or the fused residual block.  All-or-nothing: one ineligible layer keeps the whole model on
+// fp32 activations (ISI_NO_PAIRS in the environment forces that, for measurements).
+bool stack_fusable(int C, int n_res, const isi_conv_w *res3) {
+  for (int i = 0; i < n_res; ++i)
+    if (!resblock_fusable(C, res3[i].Cout)) return false;
+  return true;
+}
+bool encoder_pairs_ok(const isi_encoder_w &e, int Cin, bool in_pair) {
+  int C = Cin;
+  bool cp = in_pair;
+  for (int i = 0; i < e.n_down; ++i) {
+    if (cp && !conv_pair_sources_ok(C, 0, e.down[i].Cout, 16)) return false;
+    C = e.down[i].Cout;
+    cp = true;
+  }
+  if (cp && !conv_pair_sources_ok(C, 0, e.conv3.Cout, 9)) return false;
+  return stack_fusable(e.conv3.Cout, e.n_res, e.res3);
+}
+bool decoder_pairs_ok(const isi_decoder_w &d, int C0, int C1, bool in0_pair, bool in1_pair) {
+  if ((in0_pair || in1_pair) && !conv_pair_sources_ok(C0, C1, d.conv3.Cout, 9)) return false;
+  if (!stack_fusable(d.conv3.Cout, d.n_res, d.res3)) return false;
+  int C = d.conv3.Cout;
+  for (int i = 0; i < d.n_up; ++i) {
+    // the few-channel kernel is handed fp32; the implicit-GEMM phases read pairs
+    if (!convT_small_applicable(C, d.up[i].Cout) && !conv_pair_sources_ok(C, 0, d.up[i].Cout, 4)) return false;
+    C = d.up[i].Cout;
+  }
+  return d.n_up >= 1;
+}
+bool pairs_eligible(const isi_vqvae_w &w) {
+  const bool off = getenv("ISI_NO_PAIRS") != nullptr;   // read per call: tests compare both paths in one process
+  if (off || w.precision != 4 || !w.w16) return false;
+  const int D = w.quantize_t.D;
+  if (w.quantize_b.D != D) return false;
+  if (!encoder_pairs_ok(w.enc_b, w.in_channel, false)) return false;
+  if (!encoder_pairs_ok(w.enc_t, w.enc_b.conv3.Cout, true)) return false;
+  if (!conv_pair_sources_ok(w.enc_t.conv3.Cout, 0, D, 1)) return false;                 // quantize_conv_t
+  if (!decoder_pairs_ok(w.dec_t, D, 0, false, false)) return false;
+  if (convT_small_applicable(w.dec_t.n_up == 1 ? w.dec_t.conv3.Cout : w.dec_t.up[w.dec_t.n_up - 2].Cout,
+                             w.dec_t.up[w.dec_t.n_up - 1].Cout)) return false;         // its output is written as pairs
+  if (!conv_pair_sources_ok(w.dec_t.up[w.dec_t.n_up - 1].Cout, w.enc_b.conv3.Cout, D, 1)) return false;   // quantize_conv_b
+  for (int i = 0; i < w.n_upsample; ++i) {
+    if (convT_small_applicable(w.upsample[i].Cin, w.upsample[i].Cout)) return false;
+    if (i > 0 && !conv_pair_sources_ok(w.upsample[i].Cin, 0, w.upsample[i].Cout, 4)) return false;
+  }
+  return decoder_pairs_ok(w.dec, D, D, w.n_upsample > 0, false);
 }
 
 int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *idx, float *q,
@@ -248,21 +320,23 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   const int f16 = ISI_CONV_F16X3 | (w.w16 ? ISI_CONV_W16 : 0);
   const int pf_enc = w.precision == 4 ? f16 : w.precision == 3 ? ISI_CONV_BF16X6
                    : w.precision == 2 ? ISI_CONV_BF16X3 : 0;   // feeds the quantisers
+  const bool pairs = pairs_eligible(w);   // internal activations as split-f16 pairs (isi_hip.h: ISI_CONV_*_PAIR)
   const int pf_dec = w.precision == 4 ? f16 : w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
 
   if (mode & ISI_MODE_ENCODE) {
     if (!x) return invalid("vqvae: x is null");
     Act eb, et;
-    rc = run_encoder(w.enc_b, src_nchw(x, w.in_channel, H, W), B, H, W, s0, s1, hid, enc_b, eb, pf_enc, st);
+    rc = run_encoder(w.enc_b, src_nchw(x, w.in_channel, H, W), B, H, W, s0, s1, hid, enc_b, eb, pf_enc, false, pairs, st);
     if (rc) return rc;
-    rc = run_encoder(w.enc_t, src_nhwc(eb.p, eb.C, eb.H, eb.W), B, eb.H, eb.W, s0, s1, hid, enc_t, et, pf_enc, st);
+    rc = run_encoder(w.enc_t, src_nhwc(eb.p, eb.C, eb.H, eb.W), B, eb.H, eb.W, s0, s1, hid, enc_t, et, pf_enc, pairs,
+                     pairs, st);
     if (rc) return rc;
     // quantize_conv_t + quantize_t (vqvae.py:260-263)
     {
       isi_src s = src_nhwc(et.p, et.C, et.H, et.W);
       isi_dst d = dst_nhwc(zbuf, D, et.H, et.W);
       rc = conv2d_f32(&s, nullptr, w.quantize_conv_t.w, w.quantize_conv_t.bias, nullptr, &d, B, et.H,
-                      et.W, D, 1, 1, 1, 0, pf_enc, st);
+                      et.W, D, 1, 1, 1, 0, pf_enc | (pairs ? ISI_CONV_IN0_PAIR : 0), st);
       if (rc) return rc;
       rc = run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
                          sse_part, scal + 0, pf_enc & ISI_CONV_F16X3, st);
@@ -274,7 +348,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
     {
       isi_src s = src_nhwc(quant_t, D, et.H, et.W);
       isi_dst d = dst_nhwc(dec_t, w.dec_t.up[w.dec_t.n_up - 1].Cout, sh.Hb, Wd);
-      rc = run_decoder(w.dec_t, s, nullptr, B, et.H, et.W, s0, s1, hid, d, pf_enc, st);
+      rc = run_decoder(w.dec_t, s, nullptr, B, et.H, et.W, s0, s1, hid, d, pf_enc, false, false, pairs, pairs, st);
       if (rc) return rc;
     }
     // quantize_conv_b on cat([dec_t, enc_b]) cropped to Wq (vqvae.py:266-273)
@@ -284,7 +358,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       isi_src b = src_nhwc(eb.p, eb.C, sh.Hb, sh.Wq, eb.W);
       isi_dst d = dst_nhwc(zbuf, D, sh.Hb, sh.Wq);
       rc = conv2d_f32(&a, &b, w.quantize_conv_b.w, w.quantize_conv_b.bias, nullptr, &d, B, sh.Hb,
-                      sh.Wq, D, 1, 1, 1, 0, pf_enc, st);
+                      sh.Wq, D, 1, 1, 1, 0, pf_enc | (pairs ? ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR : 0), st);
       if (rc) return rc;
       rc = run_quantizer(w.quantize_b, zbuf, (int64_t)B * sh.Hb * sh.Wq, id_b, quant_b, counts,
                          sse_part, scal + 2, pf_enc & ISI_CONV_F16X3, st);
@@ -304,7 +378,8 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       isi_src s = src_nhwc(cur, w.upsample[i].Cin, h, ww);
       isi_dst d = dst_nhwc(o, w.upsample[i].Cout, 2 * h, 2 * ww);
       rc = conv_transpose2d_k4s2_f32(&s, w.upsample[i].w, w.upsample[i].bias, &d, B, h, ww,
-                                     w.upsample[i].Cout, pf_dec, st);
+                                     w.upsample[i].Cout, pf_dec | ((pairs && i > 0) ? ISI_CONV_IN0_PAIR : 0) |
+                                     (pairs ? ISI_CONV_OUT_PAIR : 0), st);
       if (rc) return rc;
       cur = o; h *= 2; ww *= 2;
     }
@@ -314,7 +389,8 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
     int OHf = sh.Hb, OWf = sh.Wq;
     for (int i = 0; i < w.dec.n_up; ++i) { OHf *= 2; OWf *= 2; }
     isi_dst d = dst_nchw(out->dec, w.in_channel, OHf, OWf);
-    rc = run_decoder(w.dec, a, &b, B, sh.Hb, sh.Wq, s0, s1, hid, d, pf_dec, st);
+    rc = run_decoder(w.dec, a, &b, B, sh.Hb, sh.Wq, s0, s1, hid, d, pf_dec, pairs && w.n_upsample > 0, false, pairs,
+                     false, st);
     if (rc) return rc;
   }
   return ISI_OK;

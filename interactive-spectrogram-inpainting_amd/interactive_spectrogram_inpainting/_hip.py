@@ -132,6 +132,8 @@ SIGNATURES = {
     "isi_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "isi_pack_convT_k4s2_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "isi_split_conv_weight_f16": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "isi_pair_encode_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "isi_pair_decode_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "isi_packed_convT_k4s2_weight_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "isi_pack_codebook_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "isi_conv2d_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.POINTER(isi_src),

@@ -64,6 +64,26 @@ def pack_codebook(embed: torch.Tensor):
     return codes, e2
 
 
+def pair_encode(x: torch.Tensor) -> torch.Tensor:
+    """fp32 -> split-f16 pair format (ISI_CONV_IN*_PAIR / OUT_PAIR), same shape and strides' storage order."""
+    _hip.require_gpu(x, "pair_encode input")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _hip.check(_hip.lib().isi_pair_encode_f32(x.data_ptr(), out.data_ptr(), x.numel(), _s(x)), "isi_pair_encode_f32")
+    return out
+
+
+def pair_decode(p: torch.Tensor) -> torch.Tensor:
+    _hip.require_gpu(p, "pair_decode input")
+    p = p.contiguous()
+    out = torch.empty_like(p)
+    _hip.check(_hip.lib().isi_pair_decode_f32(p.data_ptr(), out.data_ptr(), p.numel(), _s(p)), "isi_pair_decode_f32")
+    return out
+
+
+PAIR_IN0, PAIR_IN1, PAIR_OUT = 32, 64, 128   # ISI_CONV_IN0_PAIR / IN1_PAIR / OUT_PAIR, OR-ed into `extra_flags`
+
+
 def _prec_flag(bf16x3) -> int:
     """False / 0 -> exact fp32, True / 1 -> ISI_CONV_BF16X3, 2 -> ISI_CONV_BF16X6, 3 -> ISI_CONV_F16X3,
     4 -> ISI_CONV_F16X3 | ISI_CONV_W16 (the packed weights carry their split-f16 pair copy, `with_f16=True`)."""
@@ -72,7 +92,7 @@ def _prec_flag(bf16x3) -> int:
 
 def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
            k: int, stride: int, pad: int, relu: bool, x2_bchw: Optional[torch.Tensor] = None,
-           residual_bchw: Optional[torch.Tensor] = None, bf16x3: bool = False) -> torch.Tensor:
+           residual_bchw: Optional[torch.Tensor] = None, bf16x3: bool = False, extra_flags: int = 0) -> torch.Tensor:
     """Convolution of a tensor indexed [B,C,H,W] (any strides); returns a
     [B,Cout,OH,OW]-shaped view of freshly allocated channels-last storage."""
     _hip.require_gpu(x_bchw, "conv input")
@@ -87,13 +107,13 @@ def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Te
     rc = _hip.lib().isi_conv2d_f32(
         C.byref(s0), C.byref(s1) if s1 is not None else None, packed_w.data_ptr(),
         bias.data_ptr() if bias is not None else None, C.byref(res) if res is not None else None,
-        C.byref(dst), B, H, W, cout, k, k, stride, pad, int(relu) | _prec_flag(bf16x3), _s(x_bchw))
+        C.byref(dst), B, H, W, cout, k, k, stride, pad, int(relu) | _prec_flag(bf16x3) | extra_flags, _s(x_bchw))
     _hip.check(rc, "isi_conv2d_f32")
     return out
 
 
 def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor],
-                          cout: int, relu: bool, out_nchw: bool = False, bf16x3: bool = False) -> torch.Tensor:
+                          cout: int, relu: bool, out_nchw: bool = False, bf16x3: bool = False, extra_flags: int = 0) -> torch.Tensor:
     _hip.require_gpu(x_bchw, "convT input")
     B, _, H, W = x_bchw.shape
     if out_nchw:
@@ -104,7 +124,7 @@ def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Op
     dst = _hip.dst_nchw_view(out)
     rc = _hip.lib().isi_conv_transpose2d_k4s2_f32(
         C.byref(s0), packed_w.data_ptr(), bias.data_ptr() if bias is not None else None,
-        C.byref(dst), B, H, W, cout, int(relu) | _prec_flag(bf16x3), _s(x_bchw))
+        C.byref(dst), B, H, W, cout, int(relu) | _prec_flag(bf16x3) | extra_flags, _s(x_bchw))
     _hip.check(rc, "isi_conv_transpose2d_k4s2_f32")
     return out
 
@@ -114,7 +134,7 @@ def resblock_fusable(C_: int, R: int) -> bool:
 
 
 def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: bool,
-             bf16x3: bool = False) -> torch.Tensor:
+             bf16x3: bool = False, extra_flags: int = 0) -> torch.Tensor:
     """Fused residual block on a rectified, dense channels-last input viewed as [B,C,H,W]."""
     _hip.require_gpu(r_bchw, "resblock input")
     B, C_, H, W = r_bchw.shape
@@ -123,7 +143,8 @@ def resblock(r_bchw: torch.Tensor, packed_w3, b3, packed_w1, b1, R: int, relu: b
         nhwc = nhwc.contiguous()
     out = torch.empty_like(nhwc)
     rc = _hip.lib().isi_resblock_f32(nhwc.data_ptr(), packed_w3.data_ptr(), b3.data_ptr(), packed_w1.data_ptr(),
-                                     b1.data_ptr(), out.data_ptr(), B, H, W, C_, R, int(relu) | _prec_flag(bf16x3),
+                                     b1.data_ptr(), out.data_ptr(), B, H, W, C_, R,
+                                     int(relu) | _prec_flag(bf16x3) | extra_flags,
                                      _s(r_bchw))
     _hip.check(rc, "isi_resblock_f32")
     return out.permute(0, 3, 1, 2)

@@ -216,7 +216,6 @@ class VQVAE(nn.Module):
         def book(q: QuantizedBottleneck) -> _hip.isi_codebook_w:
             codes, e2 = q.packed()
             keep.extend([codes, e2])
-            wmax.append(codes.detach().abs().max())
             return _hip.isi_codebook_w(codes.data_ptr(), e2.data_ptr(), q.dim, q.n_embed)
 
         w = _hip.isi_vqvae_w()
@@ -231,7 +230,7 @@ class VQVAE(nn.Module):
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)
         if w.precision == 4 and not float(torch.stack(wmax).max()) < _F16_WEIGHT_LIMIT:
-            warnings.warn(f"a convolution weight or code vector reaches {_F16_WEIGHT_LIMIT:g} in magnitude (or is not finite): beyond the "
+            warnings.warn(f"a convolution weight reaches {_F16_WEIGHT_LIMIT:g} in magnitude (or is not finite): beyond the "
                           "operand range of conv_precision='split_f16', running this model in 'split_bf16'")
             w.precision = 3
         self._plan, self._plan_key = (w, keep), key

@@ -426,6 +426,111 @@ def test_split_f16_products_against_fp64():
     assert ((y3.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
 
 
+def test_split_f16_pair_format_activations():
+    """ISI_CONV_OUT_PAIR / IN*_PAIR: a producer writes hi | lo << 16 per element, a split-f16 consumer de-interleaves
+    instead of converting.  Same matrix operands: a consumer fed pairs returns the bits it returns for the fp32
+    tensor; a producer's pair output decodes to its fp32 output within 2^-23; launches that cannot read pairs refuse."""
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    B, C, H, W, R = 2, 128, 12, 40, 32
+    F = torch.nn.functional
+    x = torch.relu(torch.randn(B, C, H, W, generator=g))
+    x2 = torch.randn(B, 64, H, W, generator=g)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    x2d = x2.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    xp = _ops.pair_encode(xd.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    x2p = _ops.pair_encode(x2d.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    back = _ops.pair_decode(xp)
+    assert (back - xd).abs().max() <= 2.0 ** -23 * xd.abs().max()
+    w = torch.randn(C, C, 3, 3, generator=g) * 0.03
+    bias = (torch.randn(C, generator=g) * 0.1).to(dev)
+    pw = _ops.pack_conv_weight(w.to(dev), with_f16=True)
+    ref = _ops.conv2d(xd, pw, bias, C, 3, 1, 1, relu=True, bf16x3=4)
+    got = _ops.conv2d(xp, pw, bias, C, 3, 1, 1, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0)
+    assert torch.equal(got, ref)
+    out_p = _ops.conv2d(xp, pw, bias, C, 3, 1, 1, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)
+    assert (_ops.pair_decode(out_p) - ref).abs().max() <= 2.0 ** -23 * ref.abs().max()
+    # two sources, the first in pair format, the second fp32 (decoder conv3: cat(upsampled top, quant_b))
+    w2 = torch.randn(C, C + 64, 3, 3, generator=g) * 0.03
+    pw2 = _ops.pack_conv_weight(w2.to(dev), with_f16=True)
+    ref = _ops.conv2d(xd, pw2, bias, C, 3, 1, 1, relu=False, x2_bchw=x2d, bf16x3=4)
+    assert torch.equal(_ops.conv2d(xp, pw2, bias, C, 3, 1, 1, relu=False, x2_bchw=x2d, bf16x3=4,
+                                   extra_flags=_ops.PAIR_IN0), ref)
+    assert torch.equal(_ops.conv2d(xp, pw2, bias, C, 3, 1, 1, relu=False, x2_bchw=x2p, bf16x3=4,
+                                   extra_flags=_ops.PAIR_IN0 | _ops.PAIR_IN1), ref)
+    # strided 4x4 and transposed convolution
+    w4 = torch.randn(C, C, 4, 4, generator=g) * 0.02
+    p4 = _ops.pack_conv_weight(w4.to(dev), with_f16=True)
+    assert torch.equal(_ops.conv2d(xp, p4, bias, C, 4, 2, 1, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0),
+                       _ops.conv2d(xd, p4, bias, C, 4, 2, 1, relu=True, bf16x3=4))
+    wt = torch.randn(C, 64, 4, 4, generator=g) * 0.05
+    pt = _ops.pack_convT_weight(wt.to(dev), with_f16=True)
+    ref = _ops.conv_transpose2d_k4s2(xd, pt, None, 64, relu=True, bf16x3=4)
+    assert torch.equal(_ops.conv_transpose2d_k4s2(xp, pt, None, 64, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0), ref)
+    tp = _ops.conv_transpose2d_k4s2(xp, pt, None, 64, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)
+    assert (_ops.pair_decode(tp) - ref).abs().max() <= 2.0 ** -23 * ref.abs().max()
+    # fused residual block: the skip connection reads (hi + lo) / 4
+    w3 = torch.randn(R, C, 3, 3, generator=g) * 0.03
+    b3 = (torch.randn(R, generator=g) * 0.1).to(dev)
+    w1 = torch.randn(C, R, 1, 1, generator=g) * 0.1
+    b1 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    p3, p1 = _ops.pack_conv_weight(w3.to(dev), with_f16=True), _ops.pack_conv_weight(w1.to(dev), with_f16=True)
+    ref = _ops.resblock(xd, p3, b3, p1, b1, R, True, bf16x3=4)
+    got = _ops.resblock(xp, p3, b3, p1, b1, R, True, bf16x3=4, extra_flags=_ops.PAIR_IN0)
+    assert (got - ref).abs().max() <= 2.0 ** -22 * ref.abs().max()
+    got = _ops.pair_decode(_ops.resblock(xp, p3, b3, p1, b1, R, True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT))
+    assert (got - ref).abs().max() <= 2.0 ** -22 * ref.abs().max()
+    # a first-layer (gather) convolution can WRITE pairs; launches that cannot READ them refuse
+    xin = torch.randn(B, 2, 16, 32, generator=g).to(dev)
+    wf = torch.randn(64, 2, 4, 4, generator=g) * 0.2
+    pf = _ops.pack_conv_weight(wf.to(dev), with_f16=True)
+    ref = _ops.conv2d(xin, pf, None, 64, 4, 2, 1, relu=True, bf16x3=4)
+    got = _ops.pair_decode(_ops.conv2d(xin, pf, None, 64, 4, 2, 1, relu=True, bf16x3=4, extra_flags=_ops.PAIR_OUT))
+    assert (got - ref).abs().max() <= 2.0 ** -23 * ref.abs().max()
+    for kw in (dict(bf16x3=3), dict(bf16x3=0), dict(bf16x3=2)):
+        with pytest.raises(_hip.HipLibraryError):
+            _ops.conv2d(xp, pw, bias, C, 3, 1, 1, relu=True, extra_flags=_ops.PAIR_IN0, **kw)
+    with pytest.raises(_hip.HipLibraryError):
+        _ops.resblock(xp, p3, b3, p1, b1, R, True, bf16x3=3, extra_flags=_ops.PAIR_IN0)
+
+
+def test_vqvae_pair_pipeline_against_fp32_activations():
+    """The fused forward keeps its internal activations in the pair format when every layer can read it; with
+    ISI_NO_PAIRS it runs the same arithmetic on fp32 activations.  Same codes (up to near-ties through the skip
+    connections' 2^-24 difference), same reconstruction to 1e-6; an ineligible model silently takes the fp32 path."""
+    import os
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    cfg = O.Config(in_channel=2)
+    sd = O.init_state_dict(cfg, seed=4)
+    g = torch.Generator().manual_seed(9)
+    O.calibrate_codebooks(sd, cfg, torch.randn(2, 2, 64, 128, generator=g))
+    m = VQVAE(in_channel=2)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    assert m.conv_precision == "split_f16"
+    x = torch.randn(3, 2, 64, 136, generator=g).to(dev)      # ragged width: cropped bottom grid
+    got = m(x)
+    os.environ["ISI_NO_PAIRS"] = "1"
+    try:
+        ref = m(x)
+        assert not torch.equal(ref[0], got[0]), "the switch must change the data path"
+    finally:
+        del os.environ["ISI_NO_PAIRS"]
+    agree_t = (got[4] == ref[4]).float().mean().item()
+    agree_b = (got[5] == ref[5]).float().mean().item()
+    assert agree_t > 0.998 and agree_b > 0.998, (agree_t, agree_b)
+    same = (got[4] == ref[4]).all(-1).all(-1) & (got[5] == ref[5]).all(-1).all(-1)
+    assert same.any()
+    _close(got[0][same], ref[0][same], 1e-6, "dec (pair pipeline vs fp32 activations)")
+    assert torch.equal(m.decode_code(got[4], got[5]).isfinite().all(), torch.tensor(True, device=dev))
+    oref = O.forward(x.cpu(), sd, cfg)
+    assert (got[4].cpu() != oref[4]).float().mean() < 0.01 and (got[5].cpu() != oref[5]).float().mean() < 0.01
+
+
 def test_split_f16_range_violations_are_loud():
     """Operands beyond f16's range must never produce a plausible result: an activation beyond 16384 gives
     NaN in the output (and code index -1, NaN diff in the model); a weight beyond 64 makes the model run in

@@ -1,0 +1,172 @@
+// First encoder layer for gfx950: Conv2d(2 -> 32 / 64, kernel 4, stride 2, padding 1) + ReLU on the NCHW input
+// (reference vqvae/encoder_decoder.py:95-99 with in_channel = 2, the mel-IF spectrogram).
+//
+// An HBM-oriented layer -- 34 MB in, 268 MB out at B = 64, 4.3 GFLOP (31 us of the exact-fp32 matrix pipe) -- that
+// the generic implicit-GEMM kernel ran through its element-wise gather loader in 107 us (here: 87 us) (integer divisions per gathered element, LDS staging of a
+// K = 32 "GEMM", 4-byte stores).  Here:
+//   * a wave owns 32 consecutive output pixels; the 16 input values a lane needs per pixel (its channel pair is
+//     selected by the half-wave) are fetched straight from global memory with out-of-range buffer offsets as zero
+//     padding -- every input element is used by four taps, the texture cache absorbs the re-reads; no LDS, no
+//     divisions per element;
+//   * the weights ([Cout][32], 8 KB) live in registers for the lifetime of the wave (8 tiles);
+//   * 16 exact-fp32 MFMA steps per 32-channel tile in the SAME k pairing and order as the generic kernel, so the
+//     results are bit-identical to it;
+//   * the 32 x Cout tile goes through a per-wave LDS transpose so that every lane stores 16 contiguous bytes and a
+//     wave writes whole 256-byte pixel rows (fp32 or the split-f16 pair format, ISI_CONV_OUT_PAIR).
+#include <cstdlib>
+
+#include "isi_common.h"
+#include "isi_internal.h"
+#include "prof.h"
+
+namespace isi {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int TILES_PER_WAVE = 8;   // 2: 92 us, 8: 87 us at B = 64
+constexpr int LDT = 68;   // LDS row of the transpose buffer (floats): 16-byte aligned rows, shifted banks
+
+struct FirstArgs {
+  const float *in, *w, *bias;
+  float *out;
+  unsigned in_bytes;
+  int s0n, s0c, s0h, s0w;   // input element strides
+  int H, W, OH, OW, M;      // M = B * OH * OW output pixels
+  int relu, out_pair;
+};
+
+__device__ __forceinline__ unsigned pair_encode(const float v) {
+  const float t = v * 4.f;
+  const _Float16 h = (_Float16)t;
+  const _Float16 l = (_Float16)(t - (float)h);
+  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
+template <int NT>   // NT = Cout / 32
+__global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs p) {
+  constexpr int COUT = NT * 32;
+  __shared__ __attribute__((aligned(16))) float tbuf[4][32 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  float *tb = tbuf[wave];
+
+  // weights of this lane's output channels: k = 8 s + 4 half + e  (packed [Cout][32], k = tap * 2 + c)
+  float4 bw[4][NT];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      bw[s][j] = *reinterpret_cast<const float4 *>(p.w + (size_t)(32 * j + col) * 32 + 8 * s + 4 * half);
+  float bias[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bias[j] = p.bias ? p.bias[32 * j + col] : 0.f;
+
+  const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
+  const int ohw = p.OH * p.OW;
+
+  for (int t = 0; t < TILES_PER_WAVE; ++t) {
+    const int tile = ((int)blockIdx.x * TILES_PER_WAVE + t) * 4 + wave;
+    const int m0 = tile * 32;
+    const int m = m0 + col;
+    // ---- this lane's 16 input values: channel e & 1, row 2 oy - 1 + s, column 2 ox - 1 + (e >> 1) + 2 half
+    // (issuing the next tile's loads under this tile's MFMAs was measured: 87 -> 92 us, the loads are not what a
+    // wave waits for)
+    float a[4][4];
+    {
+      const bool ok = m < p.M;
+      const int b = ok ? m / ohw : 0;
+      const int rem = m - b * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1 + 2 * half;
+      const int base = b * p.s0n;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int iy = iy0 + s;
+        const bool yok = ok && (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ix = ix0 + (e >> 1);
+          const bool in_range = yok && (unsigned)ix < (unsigned)p.W;
+          const unsigned off = in_range ? (unsigned)(base + (e & 1) * p.s0c + iy * p.s0h + ix * p.s0w) * 4u : OOB;
+          a[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, off, 0, 0));
+        }
+      }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float bv = e == 0 ? bw[s][j].x : e == 1 ? bw[s][j].y : e == 2 ? bw[s][j].z : bw[s][j].w;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][e], bv, acc[j], 0, 0, 0);
+        }
+    // ---- bias, ReLU, (pair encoding) -> LDS transpose -> 16-byte stores of whole pixel rows
+    __syncthreads();   // the previous tile's reads of tb are done (uniform trip count)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[j][r] + bias[j];
+        if (p.relu) v = fmaxf(v, 0.f) + (v - v);   // NaN-propagating rectifier (see conv_igemm_f32.hip)
+        tb[row * LDT + 32 * j + col] = p.out_pair ? __builtin_bit_cast(float, pair_encode(v)) : v;
+      }
+    __syncthreads();
+    constexpr int QP = COUT / 4;   // 16-byte quads per pixel
+#pragma unroll
+    for (int it = 0; it < 32 * QP / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int px = idx / QP, q = idx - px * QP;
+      if (m0 + px < p.M)
+        *reinterpret_cast<float4 *>(p.out + (size_t)(m0 + px) * COUT + q * 4) =
+            *reinterpret_cast<const float4 *>(tb + px * LDT + q * 4);
+    }
+  }
+}
+
+template <int NT>
+int launch_first(const FirstArgs &a, hipStream_t stream) {
+  const int tiles = (a.M + 31) / 32;
+  const int per_wg = 4 * TILES_PER_WAVE;
+  dim3 grid((tiles + per_wg - 1) / per_wg);
+  const double flops = 2.0 * a.M * (NT * 32) * 32;
+  const double bytes = 4.0 * ((double)a.M / (a.OH * a.OW) * 2.0 * a.H * a.W + (double)a.M * NT * 32 + NT * 32 * 32);
+  prof::Scope scope(prof::K_CONV_GATHER, flops, bytes, stream);
+  ISI_PROF_LAUNCH(scope, conv_first_kernel<NT>, grid, dim3(256), 0, stream, a);
+  return check_launch("conv_first_f32");
+}
+
+}  // namespace
+
+// Shapes this kernel takes over from the generic convolution (conv2d_batched_f32 asks before it plans its own launch).
+bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *res, const isi_dst *dst, int Cout,
+                           int KH, int KW, int stride, int pad, int OH, int OW, int nz) {
+  const bool off = getenv("ISI_NO_CONV_FIRST") != nullptr;   // measurements / tests: the generic gather kernel instead
+  if (off || nz != 1 || (s1 && s1->ptr) || (res && res->ptr)) return false;
+  if (s0->C != 2 || KH != 4 || KW != 4 || stride != 2 || pad != 1) return false;
+  if (Cout != 32 && Cout != 64) return false;
+  if (dst->sc != 1 || dst->sw != Cout || dst->sh != (int64_t)OW * Cout || dst->sn != (int64_t)OH * OW * Cout) return false;
+  return (reinterpret_cast<uintptr_t>(dst->ptr) & 15) == 0;
+}
+
+int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, const isi_dst *dst, int B, int H,
+                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream) {
+  FirstArgs a;
+  a.in = s0->ptr; a.w = packed_w; a.bias = bias; a.out = dst->ptr;
+  a.in_bytes = (unsigned)(in_extent * 4);
+  a.s0n = (int)s0->sn; a.s0c = (int)s0->sc; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;
+  a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.M = B * OH * OW;
+  a.relu = flags & ISI_CONV_RELU; a.out_pair = (flags & ISI_CONV_OUT_PAIR) ? 1 : 0;
+  return Cout == 64 ? launch_first<2>(a, stream) : launch_first<1>(a, stream);
+}
+
+}  // namespace isi

@@ -9,6 +9,10 @@ namespace isi {
 int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream);
 int pair_encode_f32(const float *x, float *out, int64_t n, hipStream_t stream);
 int pair_decode_f32(const float *in, float *x, int64_t n, hipStream_t stream);
+bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *res, const isi_dst *dst, int Cout,
+                           int KH, int KW, int stride, int pad, int OH, int OW, int nz);
+int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, const isi_dst *dst, int B, int H,
+                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream);
 bool conv_pair_sources_ok(int C0, int C1, int Cout, int taps);
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,

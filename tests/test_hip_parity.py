@@ -426,6 +426,39 @@ def test_split_f16_products_against_fp64():
     assert ((y3.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
 
 
+@pytest.mark.parametrize("B,H,W,cout", [(2, 16, 32, 64), (3, 10, 18, 32), (1, 128, 512, 64), (5, 6, 250, 64)])
+def test_first_layer_kernel(B, H, W, cout):
+    """conv_first_f32.hip (Conv2d(2 -> 32 / 64, k4 s2 p1) + ReLU on the NCHW input): bit-identical to the generic
+    gather kernel it replaces (same k pairing and order on the exact-fp32 pipe), within 1e-6 of torch-CPU, ragged
+    tiles, pair-format output, non-contiguous input view."""
+    import os
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    x = torch.randn(B, 2, H, W, generator=g)
+    w = torch.randn(cout, 2, 4, 4, generator=g) * 0.2
+    b = torch.randn(cout, generator=g) * 0.1
+    pw = _ops.pack_conv_weight(w.to(dev))
+    xd = x.to(dev)
+    got = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True)
+    os.environ["ISI_NO_CONV_FIRST"] = "1"
+    try:
+        generic = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True)
+    finally:
+        del os.environ["ISI_NO_CONV_FIRST"]
+    assert torch.equal(got, generic)
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=2, padding=1))
+    _close(got, ref, 2e-6, "first layer")
+    assert torch.equal(_ops.conv2d(xd, pw, None, cout, 4, 2, 1, relu=False),
+                       _ops.conv2d(xd, pw, torch.zeros(cout, device=dev), cout, 4, 2, 1, relu=False))
+    pair = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True, extra_flags=_ops.PAIR_OUT)
+    assert (_ops.pair_decode(pair) - got).abs().max() <= 2.0 ** -23 * got.abs().max()
+    wide = torch.randn(B, 2, H, W + 6, generator=g).to(dev)
+    view = wide[..., 3:W + 3]
+    assert torch.equal(_ops.conv2d(view, pw, b.to(dev), cout, 4, 2, 1, relu=True),
+                       _ops.conv2d(view.contiguous(), pw, b.to(dev), cout, 4, 2, 1, relu=True))
+
+
 def test_split_f16_pair_format_activations():
     """ISI_CONV_OUT_PAIR / IN*_PAIR: a producer writes hi | lo << 16 per element, a split-f16 consumer de-interleaves
     instead of converting.  Same matrix operands: a consumer fed pairs returns the bits it returns for the fp32

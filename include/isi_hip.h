@@ -507,6 +507,9 @@ typedef struct isi_vqvae_out {
 #define ISI_MODE_FORWARD 3 /* VQVAE.forward       vqvae.py:245-249 */
 
 /* Bytes of scratch `isi_vqvae_run` needs for this shape. */
+/* 1 if isi_vqvae_run keeps this model's internal activations in the split-f16 pair format (precision 4, w16, every
+ * layer that would read a pair tensor able to: see ISI_CONV_*_PAIR), 0 if it runs on fp32 activations. */
+int isi_vqvae_pair_activations(const isi_vqvae_w *w);
 size_t isi_vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W);
 
 /* x: [B, in_channel, H, W] NCHW contiguous fp32 (ignored in DECODE mode).

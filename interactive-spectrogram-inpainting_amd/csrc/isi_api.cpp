@@ -213,6 +213,7 @@ int isi_embed_code_f32(const int64_t *idx, const float *codes_kd, float *out, in
   return embed_code_f32(idx, codes_kd, out, N, D, K, S(stream));
 }
 
+int isi_vqvae_pair_activations(const isi_vqvae_w *w) { return vqvae_pair_activations(w); }
 size_t isi_vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W) {
   return vqvae_workspace_bytes(w, B, H, W);
 }

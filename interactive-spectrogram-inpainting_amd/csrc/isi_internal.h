@@ -124,6 +124,7 @@ int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,
 int pack_codebook_f32(const float *embed, float *codes_kd, float *e2, int D, int K,
                       hipStream_t stream);
 
+int vqvae_pair_activations(const isi_vqvae_w *w);
 size_t vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W);
 int vqvae_run(const isi_vqvae_w *w, int mode, const float *x, int B, int H, int W,
               const isi_vqvae_out *out, void *workspace, size_t workspace_bytes,

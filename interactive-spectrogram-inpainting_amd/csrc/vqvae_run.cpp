@@ -108,7 +108,8 @@ bool compute_shapes(const isi_vqvae_w &w, int B, int H, int W, Shapes &s) {
 // rectified input r; each block writes relu(r + conv1(relu(conv3(r)))).
 // The last block writes to `final_out` when that is non-null.
 // `in_pair` / `out_pair`: the stack's input / output tensors are in the split-f16 pair format (isi_hip.h,
-// ISI_CONV_*_PAIR; only set when every block is fusable, see pairs_eligible); tensors between blocks follow `in_pair`.
+// ISI_CONV_*_PAIR; only set when every block is fusable, see pairs_eligible); tensors between blocks follow `in_pair`
+// (the callers pass fp32 in: see run_encoder).
 int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act &cur, int B,
                   float *s0, float *s1, float *hid, float *final_out, int pf, bool in_pair, bool out_pair,
                   hipStream_t st) {
@@ -162,11 +163,14 @@ int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *
     float *o = (e.n_res == 0) ? final_out : ((cur.p == s0) ? s1 : s0);
     isi_dst d = dst_nhwc(o, e.conv3.Cout, cur.H, cur.W);
     int rc = conv2d_f32(&cs, nullptr, e.conv3.w, e.conv3.bias, nullptr, &d, B, cur.H, cur.W,
-                        e.conv3.Cout, 3, 3, 1, 1, 1 | pf | (cp ? ISI_CONV_IN0_PAIR : 0) | op, st);
+                        e.conv3.Cout, 3, 3, 1, 1, 1 | pf | (cp ? ISI_CONV_IN0_PAIR : 0) | (e.n_res ? 0 : op), st);
     if (rc) return rc;
     cur = Act{o, e.conv3.Cout, cur.H, cur.W};
   }
-  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, pf, pairs, pairs, st);
+  // the fused residual block stages its input once per slice (not once per tap): it reads and writes fp32 between
+  // blocks -- decoding the skip connection from pairs cost more than the conversion saved, 64 -> 72 us per block --
+  // and only the stack's last block writes pairs, for the implicit-GEMM consumers of the encoder's output
+  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, pf, false, pairs, st);
   if (rc) return rc;
   out = cur;
   return ISI_OK;
@@ -185,7 +189,7 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
   auto up_reads_pair = [&](int i, int Cin) { return pairs && !convT_small_applicable(Cin, d.up[i].Cout); };
   {
     isi_dst dd = dst_nhwc(cur.p, cur.C, H, W);
-    const bool op = d.n_res ? pairs : (d.n_up ? up_reads_pair(0, cur.C) : final_pair);
+    const bool op = d.n_res ? false : (d.n_up ? up_reads_pair(0, cur.C) : final_pair);   // fp32 into the residual stack
     int rc = conv2d_f32(&in0, in1, d.conv3.w, d.conv3.bias, nullptr, &dd, B, H, W, cur.C, 3, 3, 1,
                         1, 1 | pf | (in0_pair ? ISI_CONV_IN0_PAIR : 0) | (in1_pair ? ISI_CONV_IN1_PAIR : 0) |
                         (op ? ISI_CONV_OUT_PAIR : 0), st);
@@ -194,7 +198,7 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
   bool cp = pairs;   // format of `cur` after the residual stack
   {
     cp = d.n_up ? up_reads_pair(0, cur.C) : final_pair;
-    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, pf, pairs, cp, st);
+    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, pf, false, cp, st);
     if (rc) return rc;
   }
   for (int i = 0; i < d.n_up; ++i) {
@@ -397,6 +401,8 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
 }
 
 }  // namespace
+
+int vqvae_pair_activations(const isi_vqvae_w *w) { return (w && pairs_eligible(*w)) ? 1 : 0; }
 
 size_t vqvae_workspace_bytes(const isi_vqvae_w *w, int B, int H, int W) {
   if (!w || B <= 0 || H <= 0 || W <= 0) return 0;

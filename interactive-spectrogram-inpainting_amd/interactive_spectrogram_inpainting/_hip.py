@@ -189,6 +189,7 @@ SIGNATURES = {
     "isi_vq_finalize_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
     "isi_embed_code_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "isi_vqvae_workspace_bytes": (C.c_size_t, [C.POINTER(isi_vqvae_w), C.c_int, C.c_int, C.c_int]),
+    "isi_vqvae_pair_activations": (C.c_int, [C.POINTER(isi_vqvae_w)]),
     "isi_vqvae_run": (C.c_int, [C.POINTER(isi_vqvae_w), C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                 C.POINTER(isi_vqvae_out), _P, C.c_size_t, _P]),
 }

@@ -179,8 +179,10 @@ typedef struct isi_dst {
 /* Activations as split-f16 PAIRS (with ISI_CONV_F16X3 | ISI_CONV_W16): an element's 4 bytes hold hi = f16(4 x) in the
  * low half and lo = f16(4 x - hi) in the high half, the pieces the split-f16 kernels otherwise compute from the fp32
  * value every time they stage it (once per tap and output tile).  A producer writes them once in its epilogue
- * (ISI_CONV_OUT_PAIR, any convolution / residual-block launch), a consumer that runs the split-f16 kernel reads them
- * with a de-interleave (ISI_CONV_IN0_PAIR / ISI_CONV_IN1_PAIR per source; other launches return ISI_ERR_UNSUPPORTED).
+ * (ISI_CONV_OUT_PAIR), a consumer reads them with a de-interleave (ISI_CONV_IN0_PAIR / ISI_CONV_IN1_PAIR per source).
+ * Both need the launch to run the split-f16 kernel with pack-time weight pieces (ISI_CONV_F16X3 | ISI_CONV_W16, vectorised
+ * channels-last sources, Cout > 32, K >= 128; the fused residual block likewise) -- the 2-channel first layer can write
+ * them too; other launches return ISI_E_UNSUPPORTED.
  * Same matrix operands bit for bit; a residual-block skip connection reads (hi + lo) / 4, within 2^-24 of x.
  * isi_pair_encode_f32 / isi_pair_decode_f32 convert whole tensors (tests, boundaries).                        */
 #define ISI_CONV_IN0_PAIR 32

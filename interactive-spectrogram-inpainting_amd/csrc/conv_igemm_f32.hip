@@ -141,7 +141,7 @@ __device__ __forceinline__ void pair_quad(const float4 v, uint2 &hi, uint2 &lo) 
   lo = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x07060302u), __builtin_amdgcn_perm(u.w, u.z, 0x07060302u));
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
+template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0, bool OUTP = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) {
   constexpr bool BF = PREC >= 1;
   constexpr bool BF6 = PREC == 2;
@@ -531,7 +531,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         // v - v is 0 for finite v and NaN otherwise.  (The select form `v < 0 ? 0 : v` makes this compiler allocate
         // 244 VGPRs for the split-f16 variant, 1 wave per SIMD.)
         if (p.relu) v = fmaxf(v, 0.f) + (v - v);
-        const int bits = p.out_pair ? (int)pair_encode(v) : __builtin_bit_cast(int, v);
+        // The pair encoding is 8 VALU instructions per element: compiled in only where it is used (OUTP, the
+        // split-f16 kernels of the pair pipeline).  A runtime select computes both sides and cost the fp32 128x128
+        // variant its third wave per SIMD (103 -> 106 VGPRs); a runtime branch or a second loop over the tile makes
+        // this compiler allocate 244 VGPRs.
+        const int bits = (PREC == 4 && OUTP) ? (int)pair_encode(v) : __builtin_bit_cast(int, v);
         __builtin_amdgcn_raw_buffer_store_b32(bits, rso, oo[r], 0, 0);
       }
     }
@@ -544,9 +548,9 @@ constexpr size_t conv_smem_bytes() {
   return (size_t)(nbuf_for<BN>() * BM * LDK + nbuf_for<BN>() * BN * LDK) * sizeof(float) + 3 * BM * sizeof(int);
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0>
+template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0, bool OUTP = false>
 static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
-  auto kern = conv_igemm_f32_kernel<BM, BN, WM, WN, MODE, PREC>;
+  auto kern = conv_igemm_f32_kernel<BM, BN, WM, WN, MODE, PREC, OUTP>;
   constexpr size_t smem = conv_smem_bytes<BM, BN, PREC>();
   static bool attr_set = false;  // idempotent; racing threads set the same value
   if (!attr_set) {
@@ -577,9 +581,10 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
   static const bool tap_major = getenv("ISI_CONV_TAP_MAJOR") != nullptr;   // measurements
   a.chunk_major = (mode == 0 && a.KH * a.KW > 1 && a.C0 % kBK == 0 && a.Cin % kBK == 0 && !tap_major) ? 1 : 0;
-  if ((a.in0_pair || a.in1_pair) && !(a.bf16x3 == 3 && a.w16 && mode == 0 && a.Cout > 32 && a.K >= 128))
-    return unsupported("conv: pair-format sources need the split-f16 kernel (ISI_CONV_F16X3 | ISI_CONV_W16, "
-                       "channels-last sources of 32-channel multiples, Cout > 32, K >= 128)");
+  if ((a.in0_pair || a.in1_pair || a.out_pair) && !(a.bf16x3 == 3 && a.w16 && mode == 0 && a.Cout > 32 && a.K >= 128))
+    return unsupported("conv: pair-format tensors need the split-f16 kernel (ISI_CONV_F16X3 | ISI_CONV_W16, "
+                       "channels-last sources of 32-channel multiples, Cout > 32, K >= 128) or, for the output, the "
+                       "2-channel first-layer kernel");
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
     // 128x64 tiles are ~20 % slower per FLOP than 128x128, but a GEMM that fills less than the chip's
     // 3 workgroups per CU with 128x128 tiles (the prior's d x d linears at 8 k rows: 260 tiles) finishes
@@ -592,6 +597,10 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
     }
     if (a.bf16x3 == 3 && a.w16) {   // split-f16 with the weights' pieces prepared at pack time
       a.w = a.w16;
+      if (a.out_pair) {
+        if (narrow) return launch_cfg<128, 64, 2, 2, 0, 4, true>(a, nphase, stream);
+        return launch_cfg<128, 128, 2, 2, 0, 4, true>(a, nphase, stream);
+      }
       if (narrow) return launch_cfg<128, 64, 2, 2, 0, 4>(a, nphase, stream);
       return launch_cfg<128, 128, 2, 2, 0, 4>(a, nphase, stream);
     }

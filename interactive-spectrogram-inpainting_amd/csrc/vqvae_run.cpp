@@ -251,6 +251,10 @@ bool decoder_pairs_ok(const isi_decoder_w &d, int C0, int C1, bool in0_pair, boo
 bool pairs_eligible(const isi_vqvae_w &w) {
   const bool off = getenv("ISI_NO_PAIRS") != nullptr;   // read per call: tests compare both paths in one process
   if (off || w.precision != 4 || !w.w16) return false;
+  // the first layer must be able to WRITE pairs: the 2-channel kernel (conv_first_f32.hip) does, the generic gather
+  // kernel does not
+  if (getenv("ISI_NO_CONV_FIRST") || w.in_channel != 2 || w.enc_b.n_down < 1 ||
+      (w.enc_b.down[0].Cout != 32 && w.enc_b.down[0].Cout != 64)) return false;
   const int D = w.quantize_t.D;
   if (w.quantize_b.D != D) return false;
   if (!encoder_pairs_ok(w.enc_b, w.in_channel, false)) return false;

@@ -331,11 +331,12 @@ def main():
             pmc = json.load(open(ROOT / "profiles" / "r01_pmc_hbm_traffic.json"))
             # rocprof names of the launches the dominant profiling id covers (template tail = MODE, PREC)
             # (f16x3: 3 = pieces of the weights computed while staging, 4 = prepared at pack time, ISI_CONV_W16)
-            tail = {"bf16x6": (", 0, 2>",), "bf16x3": (", 0, 1>",), "f16x3": (", 0, 3>", ", 0, 4>")}
-            want = next((t for k, t in tail.items() if k in dom["kernel"]), ("<128, 128, 2, 2, 0, 0>",))
+            # (..., MODE, PREC, OUTP>: 4 = f16x3 with pack-time weight pieces, OUTP = output written as pairs)
+            tail = {"bf16x6": (", 0, 2, ",), "bf16x3": (", 0, 1, ",), "f16x3": (", 0, 3, ", ", 0, 4, ")}
+            want = next((t for k, t in tail.items() if k in dom["kernel"]), ("<128, 128, 2, 2, 0, 0, ",))
             tot_b = tot_n = 0.0
             for name, d in pmc.items():
-                if "conv_igemm_f32_kernel" in name and name.endswith(want) and "hbm_bytes_per_launch_corrected" in d:
+                if "conv_igemm_f32_kernel" in name and any(t in name for t in want) and "hbm_bytes_per_launch_corrected" in d:
                     tot_b += d["hbm_bytes_per_launch_corrected"] * d["dispatches"]
                     tot_n += d["dispatches"]
             if tot_n:

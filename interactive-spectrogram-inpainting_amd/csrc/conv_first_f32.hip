@@ -18,6 +18,7 @@
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "prof.h"
+#include "split_f16.h"
 
 namespace isi {
 
@@ -38,12 +39,7 @@ struct FirstArgs {
   int relu, out_pair;
 };
 
-__device__ __forceinline__ unsigned pair_encode(const float v) {
-  const float t = v * 4.f;
-  const _Float16 h = (_Float16)t;
-  const _Float16 l = (_Float16)(t - (float)h);
-  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-}
+using f16s::pair_encode;
 
 template <int NT>   // NT = Cout / 32
 __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs p) {

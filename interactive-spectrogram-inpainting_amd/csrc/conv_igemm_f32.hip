@@ -22,6 +22,7 @@
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "prof.h"
+#include "split_f16.h"
 
 namespace isi {
 
@@ -106,40 +107,13 @@ __device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
 
-// ---- split-f16 ("f16x3", ISI_CONV_F16X3): x = hi + lo with hi = f16(s x), lo = f16(s x - hi), s a power of two.
-// Two 11-bit pieces hold 22 significand bits and the rounding of lo leaves |x - (hi + lo) / s| <= 2^-24 |x|, the
-// dropped lo.lo term is <= 2^-24 of the product: fp32-grade products from THREE MFMAs (the six-term bf16 split
-// needs six).  The price is f16's range: |s x| must stay below 65504 (an overflow turns into Inf / NaN in the
-// output, never into a silently wrong value) and lo keeps all its bits only while |s x| >= 2^-3 (below, the absolute
-// error floor is 2^-25 / s).  Activations are scaled by 2^2 (|x| < 16384, floor 7e-9), weights by 2^10 (|w| < 64,
-// floor 3e-11); the accumulator is rescaled by 2^-12 in the epilogue (all exact).
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float kF16ScaleA = 4.f, kF16ScaleB = 1024.f, kF16Unscale = 1.f / (4.f * 1024.f);
-__device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
-  const f32x2 a = f32x2{v.x, v.y} * s, b = f32x2{v.z, v.w} * s;
-  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-  const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), f16x2);
-  const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
-  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
-  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
-}
-
-// ---- activations as split-f16 PAIRS (ISI_CONV_OUT_PAIR / IN*_PAIR): an element's 4 bytes hold hi = f16(4 x) in the
-// low half and lo = f16(4 x - hi) in the high half -- exactly the pieces split_f16x4 computes while staging, written
-// ONCE by the producer's epilogue instead of once per tap and output tile by every consumer.  A staged quad is then
-// four v_perm_b32 (de-interleave) instead of ~14 conversion instructions.
-__device__ __forceinline__ unsigned pair_encode(const float v) {
-  const float t = v * kF16ScaleA;
-  const _Float16 h = (_Float16)t;
-  const _Float16 l = (_Float16)(t - (float)h);
-  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-}
-__device__ __forceinline__ void pair_quad(const float4 v, uint2 &hi, uint2 &lo) {
-  const uint4 u = __builtin_bit_cast(uint4, v);
-  hi = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x05040100u), __builtin_amdgcn_perm(u.w, u.z, 0x05040100u));
-  lo = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x07060302u), __builtin_amdgcn_perm(u.w, u.z, 0x07060302u));
-}
+// ---- split-f16 ("f16x3", ISI_CONV_F16X3), pack-time weight pieces (ISI_CONV_W16) and activation pairs
+// (ISI_CONV_*_PAIR): definitions and error / range analysis in split_f16.h
+using f16s::f16x8;
+using f16s::pair_encode;
+using f16s::pair_quad;
+constexpr float kF16ScaleA = f16s::kScaleA, kF16ScaleB = f16s::kScaleB, kF16Unscale = f16s::kUnscale;
+__device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 
 template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0, bool OUTP = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) {
@@ -374,11 +348,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (BF) {
         uint2 hi, mid, lo;
         if constexpr (BF6) split3_bf16x4(rb[j], hi, mid, lo);
-        else if constexpr (WPRE) {
-          const uint4 u = __builtin_bit_cast(uint4, rb[j]);
-          hi = make_uint2(u.x, u.y);
-          lo = make_uint2(u.z, u.w);
-        } else if constexpr (F16) split_f16x4(rb[j], kF16ScaleB, hi, lo);
+        else if constexpr (WPRE) f16s::weight_quad(rb[j], hi, lo);
+        else if constexpr (F16) split_f16x4(rb[j], kF16ScaleB, hi, lo);
         else split_bf16x4(rb[j], hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Bhi + wo) = hi;

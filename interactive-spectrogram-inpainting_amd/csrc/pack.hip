@@ -8,6 +8,7 @@
 // vqvae/bottleneck.py:47-51.
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "split_f16.h"
 
 namespace isi {
 
@@ -62,18 +63,9 @@ __global__ void pack_codebook_kernel(const float *__restrict__ embed, float *__r
 // 16 bytes {hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3}, the f16 pieces of 1024 w exactly as the kernels of ISI_CONV_F16X3
 // compute them while staging (conv_igemm_f32.hip: split_f16x4) -- a staged quad is then one 16-byte load and two
 // 8-byte LDS stores, no conversion
-typedef _Float16 pk_f16x2 __attribute__((ext_vector_type(2)));
-typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
 __global__ void split_weight_f16_kernel(const float4 *__restrict__ in, uint4 *__restrict__ out, int64_t nq) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  const float4 v = in[i];
-  const pk_f32x2 a = pk_f32x2{v.x, v.y} * 1024.f, b = pk_f32x2{v.z, v.w} * 1024.f;
-  const pk_f16x2 ha = __builtin_convertvector(a, pk_f16x2), hb = __builtin_convertvector(b, pk_f16x2);
-  const pk_f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, pk_f32x2), pk_f16x2);
-  const pk_f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, pk_f32x2), pk_f16x2);
-  out[i] = make_uint4(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb),
-                      __builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
+  if (i < nq) out[i] = f16s::weight_encode(in[i]);
 }
 
 int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream) {
@@ -89,21 +81,11 @@ int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hip
 // fp32 <-> activation pair format (ISI_CONV_OUT_PAIR / IN*_PAIR): hi = f16(4 x) | lo = f16(4 x - hi) << 16
 __global__ void pair_encode_kernel(const float *__restrict__ x, unsigned *__restrict__ out, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const float t = x[i] * 4.f;
-    const _Float16 h = (_Float16)t;
-    const _Float16 l = (_Float16)(t - (float)h);
-    out[i] = (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = f16s::pair_encode(x[i]);
 }
 __global__ void pair_decode_kernel(const unsigned *__restrict__ in, float *__restrict__ x, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const unsigned u = in[i];
-    const float h = (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu));
-    const float l = (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16));
-    x[i] = (h + l) * 0.25f;
-  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = f16s::pair_decode(in[i]);
 }
 int pair_encode_f32(const float *x, float *out, int64_t n, hipStream_t stream) {
   if (!x || !out || n < 0) return invalid("pair_encode: bad argument");

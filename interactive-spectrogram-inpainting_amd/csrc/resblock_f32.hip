@@ -21,6 +21,7 @@
 
 #include "isi_common.h"
 #include "prof.h"
+#include "split_f16.h"
 
 namespace isi {
 
@@ -83,34 +84,13 @@ __device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &
   mid = make_uint2(__builtin_bit_cast(unsigned, ma), __builtin_bit_cast(unsigned, mb));
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
-// split-f16 pieces (ISI_CONV_F16X3, see conv_igemm_f32.hip): operands scaled by a power of two, f16 range
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-constexpr float kF16ScaleA = 4.f, kF16ScaleB = 1024.f, kF16Unscale = 1.f / (4.f * 1024.f);
-__device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
-  const f32x2 a = f32x2{v.x, v.y} * s, b = f32x2{v.z, v.w} * s;
-  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
-  const f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), f16x2);
-  const f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), f16x2);
-  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
-  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
-}
-// activation pair format (conv_igemm_f32.hip): hi = f16(4 x) | lo = f16(4 x - hi) << 16 per element
-__device__ __forceinline__ unsigned pair_encode(const float v) {
-  const float t = v * kF16ScaleA;
-  const _Float16 h = (_Float16)t;
-  const _Float16 l = (_Float16)(t - (float)h);
-  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
-}
-__device__ __forceinline__ float pair_decode(const unsigned u) {
-  return ((float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)) +
-          (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16))) * (1.f / kF16ScaleA);
-}
-__device__ __forceinline__ void pair_quad(const float4 v, uint2 &hi, uint2 &lo) {
-  const uint4 u = __builtin_bit_cast(uint4, v);
-  hi = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x05040100u), __builtin_amdgcn_perm(u.w, u.z, 0x05040100u));
-  lo = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x07060302u), __builtin_amdgcn_perm(u.w, u.z, 0x07060302u));
-}
+// split-f16 pieces, pack-time weight pieces and activation pairs: split_f16.h
+using f16s::f16x8;
+using f16s::pair_decode;
+using f16s::pair_encode;
+using f16s::pair_quad;
+constexpr float kF16ScaleA = f16s::kScaleA, kF16ScaleB = f16s::kScaleB, kF16Unscale = f16s::kUnscale;
+__device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 template <int PREC>
 __device__ __forceinline__ void split_x4(const float4 v, const float s16, uint2 &hi, uint2 &mid, uint2 &lo) {
   if constexpr (PREC == 2) split3_bf16x4(v, hi, mid, lo);
@@ -121,9 +101,7 @@ __device__ __forceinline__ void split_x4(const float4 v, const float s16, uint2 
 template <int PREC>
 __device__ __forceinline__ void split_w4(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
   if constexpr (PREC == 4) {
-    const uint4 u = __builtin_bit_cast(uint4, v);
-    hi = make_uint2(u.x, u.y);
-    lo = make_uint2(u.z, u.w);
+    f16s::weight_quad(v, hi, lo);
   } else {
     split_x4<PREC>(v, kF16ScaleB, hi, mid, lo);
   }

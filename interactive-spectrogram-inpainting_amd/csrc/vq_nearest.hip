@@ -18,6 +18,7 @@
 // are merged with a single cross-lane exchange at the end.
 #include "isi_common.h"
 #include "prof.h"
+#include "split_f16.h"
 
 namespace isi {
 
@@ -157,19 +158,9 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
 // vector of the winner is re-read from global memory (L2) for q and the squared error.  Same operand swap,
 // association of d, tie rule and outputs as the exact kernel; ranges as for the convolutions (|z| < 16384,
 // |e| < 64; beyond: non-finite distances -> index -1).
-typedef _Float16 vq_f16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 vq_f16x8 __attribute__((ext_vector_type(8)));
-typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
-constexpr float kVqScaleZ = 4.f, kVqScaleE = 1024.f, kVqUnscale = 1.f / (4.f * 1024.f);
-
-__device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
-  const vq_f32x2 a = vq_f32x2{v.x, v.y} * s, b = vq_f32x2{v.z, v.w} * s;
-  const vq_f16x2 ha = __builtin_convertvector(a, vq_f16x2), hb = __builtin_convertvector(b, vq_f16x2);
-  const vq_f16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, vq_f32x2), vq_f16x2);
-  const vq_f16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, vq_f32x2), vq_f16x2);
-  hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
-  lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
-}
+typedef f16s::f16x8 vq_f16x8;
+constexpr float kVqScaleZ = f16s::kScaleA, kVqScaleE = f16s::kScaleB, kVqUnscale = f16s::kUnscale;
+__device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 
 __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
     const float *__restrict__ z, const float *__restrict__ codes, const float *__restrict__ e2g,

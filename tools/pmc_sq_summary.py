@@ -12,7 +12,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"^void\s+", "", name).replace("isi::", "")
+    name = re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", "").replace("isi::", "")
     return re.sub(r"\(.*$", "", name)[:70]
 
 

@@ -12,7 +12,7 @@ import sys
 def load(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        agg[(r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        agg[(r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
     return agg
 
 

@@ -10,7 +10,9 @@
 //     divisions per element;
 //   * the weights ([Cout][32], 8 KB) live in registers for the lifetime of the wave (8 tiles);
 //   * 16 exact-fp32 MFMA steps per 32-channel tile in the SAME k pairing and order as the generic kernel, so the
-//     results are bit-identical to it;
+//     results are bit-identical to it (ISI_CONV_F16X3: 6 split-f16 MFMAs instead, 87 -> 81 us);
+//   * tiles are handed out grid-stride, so that the resident workgroups write one contiguous region at any time
+//     (8 consecutive tiles per workgroup put the concurrent writes 256 KB apart: 81 -> 75 us);
 //   * the 32 x Cout tile goes through a per-wave LDS transpose so that every lane stores 16 contiguous bytes and a
 //     wave writes whole 256-byte pixel rows (fp32 or the split-f16 pair format, ISI_CONV_OUT_PAIR).
 #include <cstdlib>
@@ -64,7 +66,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs p) {
   const int ohw = p.OH * p.OW;
 
   for (int t = 0; t < TILES_PER_WAVE; ++t) {
-    const int tile = ((int)blockIdx.x * TILES_PER_WAVE + t) * 4 + wave;
+    // grid-stride tile order: at any time the resident workgroups write ONE contiguous region (a workgroup that
+    // owned 8 consecutive tiles put the concurrent writes 256 KB apart -- the same memory channels)
+    const int tile = (t * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
     const int m0 = tile * 32;
     const int m = m0 + col;
     // ---- this lane's 16 input values: channel e & 1, row 2 oy - 1 + s, column 2 ox - 1 + (e >> 1) + 2 half
@@ -106,7 +110,8 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs p) {
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][e], bv, acc[j], 0, 0, 0);
         }
     // ---- bias, ReLU, (pair encoding) -> LDS transpose -> 16-byte stores of whole pixel rows
-    __syncthreads();   // the previous tile's reads of tb are done (uniform trip count)
+    __syncthreads();   // the previous tile's reads of tb are done (uniform trip count; wave-local ordering
+                       // without s_barrier was measured: no difference)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -129,7 +134,108 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs p) {
   }
 }
 
+// ---- split-f16 variant (ISI_CONV_F16X3): the 32 MFMAs of 16 passes per tile (31 us of the exact-fp32 pipe per
+// launch at B = 64) become 12 MFMAs of 8 passes on the f16 pipe, products as in split_f16.h.  A lane's k-block of an
+// MFMA step is 8 consecutive k = (4 taps of one kernel row) x (2 channels): step st, half-wave h -> kernel row
+// 2 st + h, the four columns, both channels.
+typedef short s16x8f __attribute__((ext_vector_type(8)));
 template <int NT>
+__global__ __launch_bounds__(256) void conv_first_f16x3_kernel(const FirstArgs p) {
+  constexpr int COUT = NT * 32;
+  __shared__ __attribute__((aligned(16))) float tbuf[4][32 * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  float *tb = tbuf[wave];
+
+  s16x8f bh[2][NT], bl[2][NT];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float *wr = p.w + (size_t)(32 * j + col) * 32 + 16 * st + 8 * half;
+      uint2 h0, l0, h1, l1;
+      f16s::split4(*reinterpret_cast<const float4 *>(wr), f16s::kScaleB, h0, l0);
+      f16s::split4(*reinterpret_cast<const float4 *>(wr + 4), f16s::kScaleB, h1, l1);
+      bh[st][j] = __builtin_bit_cast(s16x8f, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      bl[st][j] = __builtin_bit_cast(s16x8f, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+  float bias[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bias[j] = p.bias ? p.bias[32 * j + col] : 0.f;
+
+  const __amdgpu_buffer_rsrc_t rsi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
+  const int ohw = p.OH * p.OW;
+
+  for (int t = 0; t < TILES_PER_WAVE; ++t) {
+    // grid-stride tile order: at any time the resident workgroups write ONE contiguous region (a workgroup that
+    // owned 8 consecutive tiles put the concurrent writes 256 KB apart -- the same memory channels)
+    const int tile = (t * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
+    const int m0 = tile * 32;
+    const int m = m0 + col;
+    float a[2][8];   // [step][(kw, c)]
+    {
+      const bool ok = m < p.M;
+      const int b = ok ? m / ohw : 0;
+      const int rem = m - b * ohw;
+      const int oy = rem / p.OW, ox = rem - oy * p.OW;
+      const int iy0 = 2 * oy - 1 + half, ix0 = 2 * ox - 1;
+      const int base = b * p.s0n;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const int iy = iy0 + 2 * st;
+        const bool yok = ok && (unsigned)iy < (unsigned)p.H;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ix = ix0 + (i >> 1);
+          const bool in_range = yok && (unsigned)ix < (unsigned)p.W;
+          const unsigned off = in_range ? (unsigned)(base + (i & 1) * p.s0c + iy * p.s0h + ix * p.s0w) * 4u : OOB;
+          a[st][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsi, off, 0, 0));
+        }
+      }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      uint2 h0, l0, h1, l1;
+      f16s::split4(make_float4(a[st][0], a[st][1], a[st][2], a[st][3]), f16s::kScaleA, h0, l0);
+      f16s::split4(make_float4(a[st][4], a[st][5], a[st][6], a[st][7]), f16s::kScaleA, h1, l1);
+      const s16x8f ah = __builtin_bit_cast(s16x8f, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      const s16x8f al = __builtin_bit_cast(s16x8f, make_uint4(l0.x, l0.y, l1.x, l1.y));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16s::f16x8, al), __builtin_bit_cast(f16s::f16x8, bh[st][j]), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16s::f16x8, ah), __builtin_bit_cast(f16s::f16x8, bl[st][j]), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16s::f16x8, ah), __builtin_bit_cast(f16s::f16x8, bh[st][j]), acc[j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[j][r] * f16s::kUnscale + bias[j];
+        if (p.relu) v = fmaxf(v, 0.f) + (v - v);
+        tb[row * LDT + 32 * j + col] = p.out_pair ? __builtin_bit_cast(float, pair_encode(v)) : v;
+      }
+    __syncthreads();
+    constexpr int QP = COUT / 4;
+#pragma unroll
+    for (int it = 0; it < 32 * QP / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int px = idx / QP, q = idx - px * QP;
+      if (m0 + px < p.M)
+        *reinterpret_cast<float4 *>(p.out + (size_t)(m0 + px) * COUT + q * 4) =
+            *reinterpret_cast<const float4 *>(tb + px * LDT + q * 4);
+    }
+  }
+}
+
+template <int NT, bool F16>
 int launch_first(const FirstArgs &a, hipStream_t stream) {
   const int tiles = (a.M + 31) / 32;
   const int per_wg = 4 * TILES_PER_WAVE;
@@ -137,7 +243,11 @@ int launch_first(const FirstArgs &a, hipStream_t stream) {
   const double flops = 2.0 * a.M * (NT * 32) * 32;
   const double bytes = 4.0 * ((double)a.M / (a.OH * a.OW) * 2.0 * a.H * a.W + (double)a.M * NT * 32 + NT * 32 * 32);
   prof::Scope scope(prof::K_CONV_GATHER, flops, bytes, stream);
-  ISI_PROF_LAUNCH(scope, conv_first_kernel<NT>, grid, dim3(256), 0, stream, a);
+  if (F16) {
+    ISI_PROF_LAUNCH(scope, conv_first_f16x3_kernel<NT>, grid, dim3(256), 0, stream, a);
+  } else {
+    ISI_PROF_LAUNCH(scope, conv_first_kernel<NT>, grid, dim3(256), 0, stream, a);
+  }
   return check_launch("conv_first_f32");
 }
 
@@ -162,7 +272,10 @@ int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, 
   a.s0n = (int)s0->sn; a.s0c = (int)s0->sc; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;
   a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.M = B * OH * OW;
   a.relu = flags & ISI_CONV_RELU; a.out_pair = (flags & ISI_CONV_OUT_PAIR) ? 1 : 0;
-  return Cout == 64 ? launch_first<2>(a, stream) : launch_first<1>(a, stream);
+  // split-f16 products only where the caller asked for them and not for the six-term mode (most precise wins)
+  if ((flags & ISI_CONV_F16X3) && !(flags & ISI_CONV_BF16X6))
+    return Cout == 64 ? launch_first<2, true>(a, stream) : launch_first<1, true>(a, stream);
+  return Cout == 64 ? launch_first<2, false>(a, stream) : launch_first<1, false>(a, stream);
 }
 
 }  // namespace isi

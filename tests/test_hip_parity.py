@@ -453,6 +453,20 @@ def test_first_layer_kernel(B, H, W, cout):
                        _ops.conv2d(xd, pw, torch.zeros(cout, device=dev), cout, 4, 2, 1, relu=False))
     pair = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True, extra_flags=_ops.PAIR_OUT)
     assert (_ops.pair_decode(pair) - got).abs().max() <= 2.0 ** -23 * got.abs().max()
+    # split-f16 variant (ISI_CONV_F16X3): fp32-grade against fp64, pair output, NaN for an out-of-range input
+    ref64 = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1))
+    f16 = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True, bf16x3=3)
+    err16 = ((f16.cpu().double() - ref64).abs().max() / ref64.abs().max()).item()
+    err32 = ((got.cpu().double() - ref64).abs().max() / ref64.abs().max()).item()
+    assert err16 < 1e-6 and err16 < 3 * err32 + 1e-7, (err16, err32)
+    assert not torch.equal(f16, got)
+    pair = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True, bf16x3=3, extra_flags=_ops.PAIR_OUT)
+    assert (_ops.pair_decode(pair) - f16).abs().max() <= 2.0 ** -23 * f16.abs().max()
+    assert torch.equal(_ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True, bf16x3=2), got)   # six-term: exact kernel
+    xbad = xd.clone()
+    xbad[0, 1, 3, 5] = 5e4
+    ybad = _ops.conv2d(xbad, pw, b.to(dev), cout, 4, 2, 1, relu=True, bf16x3=3)
+    assert not torch.isfinite(ybad[0, :, 1:3, 2:4]).any() and torch.isfinite(ybad[0, :, 4:, :]).all()
     wide = torch.randn(B, 2, H, W + 6, generator=g).to(dev)
     view = wide[..., 3:W + 3]
     assert torch.equal(_ops.conv2d(view, pw, b.to(dev), cout, 4, 2, 1, relu=True),

@@ -411,7 +411,8 @@ def main():
                              "id_b_agreement": float((o[5] == ref_out[5]).float().mean())}
             model.conv_precision = default_precision
         line["alt_precision_single_gpu"] = alt
-        if not args.no_prior:
+        # secondary legs and the CPU baseline at N = 1 only: at N > 1 the other ranks wait in the final barrier
+        if not args.no_prior and world == 1:
             line["frontend"] = _frontend(device)
             torch.cuda.empty_cache()
             line["prior_sampling"] = _prior_sampling(device)
@@ -419,7 +420,7 @@ def main():
             line["prior_sampling"]["timerange_change"] = _timerange_change(device, model)
             torch.cuda.empty_cache()
             line["prior_training_single_gpu"] = _prior_training(device)
-        if not args.no_cpu_baseline and world >= 1:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = _cpu_baseline(sd)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: VQVAE.forward (encode + 2x quantize + decode),
 eval / no-grad, batch 64 of synthetic [2,128,512] spectrograms per GPU
-(BASELINE.json configs[1]).  One process per GPU; ranks are independent
-replicas of the path over disjoint batches (no data-path collective: weak
-scaling), a barrier + synchronize brackets the timed region and the slowest
-rank's time is used.
+(BASELINE.json configs[1]).  One process per GPU; for the headline metric the
+ranks are independent replicas of the path over disjoint batches (no data-path
+collective: weak scaling); a barrier + synchronize brackets the timed region
+and the slowest rank's time is used.
 
 Prints ONE JSON line on rank 0:
   value     spectrograms/s over all ranks, inputs resident in HBM
-  roofline  the dominant kernel (by summed HIP-event time inside the timed
-            region) priced on its algorithmic FLOPs against the gfx950 fp32
-            matrix peak (157.3 TFLOP/s); the layers that feed code indices compute
-            in exact fp32, the final decoder in split-bf16 products (see `precision`)
+  roofline  the dominant kernel (by summed in-library HIP-event time inside the
+            timed region) priced on its algorithmic FLOPs against the dense
+            16-bit matrix peak divided by the MFMA terms per product (default
+            split_f16 mode: three f16 terms -> 2500 / 3 TFLOP/s; exact-fp32
+            kernels: 157.3 TFLOP/s); `traffic` comes from the committed PMC pass
+            named in `traffic_source` (same command, same batch), not from this run
   cpu_baseline  the CPU oracle (oracle/vqvae_oracle.py, torch-CPU fp32) timed
-            on this host on a bounded sample of the same workload
+            on this host's cores on a bounded sample of the same workload
+  vqvae_training  BASELINE configs[2]: one data-parallel VQ-VAE training step
+            per rank at B = 64 (bucketed RCCL gradient all-reduce overlapped
+            with the backward + the EMA-statistics all-reduce), spectrograms/s
+            over all ranks -- the leg whose scaling exercises collectives
+  attention  BASELINE configs[3]'s kernel: relative attention forward /
+            backward at B8 H8 S1025 hd64 with its own roofline entry
 """
 from __future__ import annotations
 
@@ -61,21 +69,52 @@ def _build_model(device, seed=1):
     return m, sd
 
 
-def _cpu_baseline(sd, batch=16, iters=2):
-    """Oracle forward on the host cores: bounded sample (batch 16, same tensor shape)."""
+def _host_cpu():
+    """(model name, physical cores of ONE socket, sockets) from /proc/cpuinfo; (None, None, None) if unreadable."""
+    try:
+        model, cores = None, set()
+        phys = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                cores.add((phys, v))
+        sockets = sorted({p_ for p_, _ in cores})
+        per_socket = len([1 for p_, _ in cores if p_ == sockets[0]]) if sockets else None
+        return model, per_socket, len(sockets) or None
+    except OSError:
+        return None, None, None
+
+
+def _cpu_baseline(sd, batch=16, warmup=2, iters=5):
+    """Oracle forward on the host cores: threads = the physical cores of one socket, 2 warm-up and 5
+    timed iterations on a bounded sample (batch 16 of the same tensor shape), median."""
     from oracle import vqvae_oracle as O
     cfg = O.Config(in_channel=2)
-    cores = torch.get_num_threads()
+    model, per_socket, sockets = _host_cpu()
+    before = torch.get_num_threads()
+    cores = per_socket or before
+    torch.set_num_threads(cores)
     x = torch.randn(batch, 2, 128, 512, generator=torch.Generator().manual_seed(4))
-    with torch.no_grad():
-        O.forward(x[:2], sd, cfg)  # warm-up
-        t0 = time.perf_counter()
-        for _ in range(iters):
-            O.forward(x, sd, cfg)
-        dt = time.perf_counter() - t0
-    return {"value": round(batch * iters / dt, 3), "unit": "spectrograms/s", "cores": cores,
-            "kind": "port", "sample": f"{iters} x VQVAE.forward on batch {batch} of [2,128,512] fp32 "
-                                       f"(oracle/vqvae_oracle.py, torch-CPU)"}
+    times = []
+    try:
+        with torch.no_grad():
+            for i in range(warmup + iters):
+                t0 = time.perf_counter()
+                O.forward(x, sd, cfg)
+                if i >= warmup:
+                    times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_num_threads(before)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(batch / med, 3), "unit": "spectrograms/s", "cores": cores, "kind": "port",
+            "cpu_model": model, "sockets": sockets,
+            "sample": f"median of {iters} x VQVAE.forward on batch {batch} of [2,128,512] fp32 after {warmup} warm-up "
+                      f"iterations (oracle/vqvae_oracle.py, torch-CPU, {cores} threads = one socket's physical cores)"}
 
 
 def _prior_sampling(device):
@@ -214,6 +253,126 @@ def _prior_training(device, B=8, steps=3):
             "config": f"top prior [32,32], B={B} x 1025 tokens, d_model 512, 6+8 layers, 8 heads, fp32, Adam, 1 GPU"}
 
 
+def _vqvae_training(device, dist, world, batch=64, steps=5, warmup=2):
+    """BASELINE configs[2]: VQ-VAE training, global batch = world x 64 synthetic spectrograms, data parallel with one
+    process per GPU: train-mode forward (EMA-statistics all-reduce inside both quantisers), hand-written backward
+    whose gradient buckets are all-reduced by RCCL while it is still running, Adam step.  Runs on EVERY rank; timed
+    between barriers, slowest rank counts."""
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    torch.manual_seed(1)                       # identical weights on every rank
+    m = VQVAE(in_channel=2).to(device).train()
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    rank = dist.get_rank() if dist is not None else 0
+    x = torch.randn(batch, 2, 128, 512, generator=torch.Generator().manual_seed(200 + rank)).to(device)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    def step():
+        m.zero_grad()
+        out, latent, *_ = m(x)
+        loss = torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()
+        loss.backward()
+        opt.step()
+        return loss
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        # every rank must hold the same codebook and weights after the exchanged updates
+        chk = torch.stack([m.quantize_b.embed.double().sum(), m.enc_b.blocks[0].weight.double().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(((hi - lo).abs() <= 1e-6 * hi.abs().clamp(min=1e-12)).all())
+    else:
+        in_sync = True
+    assert torch.isfinite(loss).all()
+    out = {"value": round(world * batch * steps / dt, 1), "unit": "spectrograms/s", "ms_per_step": round(dt * 1e3 / steps, 2),
+           "n_gpus": world, "steps": steps, "warmup": warmup, "global_batch": world * batch, "scaling": "weak",
+           "ranks_in_sync": in_sync,
+           "collectives_per_step": "4 gradient buckets (5.5 MB fp32 in total) + 2 EMA-statistics messages (133 KB each)"
+                                   if world > 1 else "none (1 rank)",
+           "config": f"VQVAE default ctor, B={batch}/GPU of [2,128,512], MSE + 0.25 latent, Adam 3e-4, forward / "
+                     f"input-gradient products six-term split-bf16, weight gradients three-term"}
+    del m, opt
+    torch.cuda.empty_cache()
+    return out
+
+
+def _attention(device, B=8, H=8, S=1025, hd=64, n=10):
+    """BASELINE configs[3]'s kernel at the shape the metric names: relative self-attention (QK^T + Q E^T skewed +
+    softmax + PV), causal, B8 H8 S1025 head_dim 64, forward and backward, per product mode.  FLOPs = the DENSE count
+    2 S^2 hd per contraction (3 forward, 7 backward; a causal mask lets the kernels skip half of it -- convention of
+    SURVEY 8d), priced against the dense bf16 matrix peak / terms per product (fp32 pipe: 157.3)."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.priors._train import RelAttentionFn
+    d = H * hd
+    torch.manual_seed(0)
+    qkv = torch.randn(S, B, 3 * d, device=device, requires_grad=True)
+    rel = (torch.randn(H, 2 * S - 1, hd, device=device) * 0.1).requires_grad_(True)
+    w = torch.randn(S, B, d, device=device)
+    dense = 2.0 * S * S * hd * B * H
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) / n * 1e3   # us
+    saved = _ops.ATTENTION_PRECISION
+    out = {"config": f"self-attention B{B} H{H} S{S} head_dim {hd}, causal, relative logits, fp32 I/O",
+           "flops_convention": "dense 2 S^2 hd per contraction: 3 forward, 7 backward (causal kernels skip half)"}
+    with torch.no_grad():
+        _ops.ATTENTION_PRECISION = "f32"
+        ref = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, 1, None)
+    try:
+        for prec in _ops.ATTENTION_PRECISIONS:
+            _ops.ATTENTION_PRECISION = prec
+            terms = _ops.ATTENTION_TERMS[prec]
+            peak = BF16_MATRIX_PEAK_TFLOPS / terms if terms else FP32_MATRIX_PEAK_TFLOPS
+            with torch.no_grad():
+                t_f = timed(lambda: RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, 1, None))
+                o = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, 1, None)
+            entry = {"fwd_us": round(t_f, 1), "fwd_TFLOPs_dense": round(3 * dense / t_f / 1e6, 1),
+                     "peak_TFLOPs": round(peak, 1), "fwd_frac": round(3 * dense / t_f / 1e6 / peak, 4),
+                     "max_err_vs_f32_over_max": float((o - ref).abs().max() / ref.abs().max())}
+            res = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, 1, None)
+
+            def bwd():
+                qkv.grad = None
+                rel.grad = None
+                res.backward(w, retain_graph=True)
+            t_b = timed(bwd)
+            entry.update(bwd_us=round(t_b, 1), bwd_TFLOPs_dense=round(7 * dense / t_b / 1e6, 1),
+                         bwd_frac=round(7 * dense / t_b / 1e6 / peak, 4))
+            out[prec] = entry
+    finally:
+        _ops.ATTENTION_PRECISION = saved
+    out["default_precision"] = saved
+    dflt = out[saved]
+    out["roofline"] = {"bound": "mfma", "kernel": f"rel_attention forward ({saved})", "achieved": dflt["fwd_TFLOPs_dense"],
+                       "peak": dflt["peak_TFLOPs"], "unit": "TFLOP/s", "frac": dflt["fwd_frac"], "traffic": None,
+                       "frac_of_2500_bf16_peak": round(dflt["fwd_TFLOPs_dense"] / BF16_MATRIX_PEAK_TFLOPS, 4)}
+    return out
+
+
 def _frontend(device, B=64):
     """Audio -> mel/IF spectrogram -> audio (n_fft 2048, hop 512, 4 s clips at 16 kHz): DFT and mel
     projections as fp32 GEMMs + HBM-bound polar / scan / transpose kernels."""
@@ -248,6 +407,7 @@ def main():
                     help="untimed forwards before the warm-up steps until the clocks are steady")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prior", action="store_true", help="skip the secondary prior-sampling metric")
+    ap.add_argument("--no-train", action="store_true", help="skip the data-parallel VQ-VAE training leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -311,6 +471,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
 
+    # ---- BASELINE configs[2] on every rank: data-parallel VQ-VAE training step (collectives inside)
+    train_leg = None if args.no_train else _vqvae_training(device, dist, world, batch=args.batch)
+
     # ---- per-kernel HIP-event timing recorded inside the timed region
     kernels = []
     for kid in range(L.isi_prof_num_kernels()):
@@ -327,8 +490,13 @@ def main():
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH doubled as the
         # gfx950 guide prescribes; tools/pmc_traffic.py): a measured constant, not re-measured here
         traffic = None
+        traffic_file = "profiles/r02_pmc_hbm_traffic.json"
+        if not (ROOT / traffic_file).exists():
+            traffic_file = "profiles/r01_pmc_hbm_traffic.json"
         try:
-            pmc = json.load(open(ROOT / "profiles" / "r01_pmc_hbm_traffic.json"))
+            if args.batch != 64:
+                raise ValueError("the committed PMC pass was taken at batch 64")
+            pmc = json.load(open(ROOT / traffic_file))
             # rocprof names of the launches the dominant profiling id covers (template tail = MODE, PREC)
             # (f16x3: 3 = pieces of the weights computed while staging, 4 = prepared at pack time, ISI_CONV_W16)
             # (..., MODE, PREC, OUTP>: 4 = f16x3 with pack-time weight pieces, OUTP = output written as pairs)
@@ -351,6 +519,9 @@ def main():
         roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": traffic,
+                "traffic_source": (f"{traffic_file} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   f"command at batch 64, FETCH doubled per the gfx950 guide; not measured in this run)")
+                                  if traffic is not None else None,
                 "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]),
                 "avg_launch_us": round(dom["ms"] * 1e3 / dom["launches"], 2),
                 "launches_per_step": dom["launches"] // timed_steps,
@@ -411,8 +582,12 @@ def main():
                              "id_b_agreement": float((o[5] == ref_out[5]).float().mean())}
             model.conv_precision = default_precision
         line["alt_precision_single_gpu"] = alt
+        if train_leg is not None:
+            line["vqvae_training_single_gpu" if world == 1 else "vqvae_training_dp"] = train_leg
         # secondary legs and the CPU baseline at N = 1 only: at N > 1 the other ranks wait in the final barrier
         if not args.no_prior and world == 1:
+            line["attention"] = _attention(device)
+            torch.cuda.empty_cache()
             line["frontend"] = _frontend(device)
             torch.cuda.empty_cache()
             line["prior_sampling"] = _prior_sampling(device)

@@ -416,7 +416,8 @@ int isi_prior_sample_run(const isi_prior_w *w, const isi_prior_state *state, int
  *   q_out    [N, D]   z + (e_idx - z)      (straight-through value, :95)
  *   counts   [K] int32  histogram of idx (caller zeroes; accumulated)
  *   sse_part [isi_vq_num_partials(N)] fp32 per-workgroup sum (e_idx - z)^2
- * Requirements: D in {8,16,32,64}, K % 32 == 0, K*(D+4)*4 + K*4 <= 150 KiB. */
+ * Requirements: D in {8,16,32,64}; with Kp = K rounded up to 32: Kp*(D+4)*4 + Kp*8 <= 150 KiB
+ * (the LDS image is padded with rows that can never win). */
 int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2,
                        int64_t *idx_out, float *q_out, int32_t *counts,
                        float *sse_part, int64_t N, int D, int K, void *stream);
@@ -491,6 +492,9 @@ typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
                   * indices move).  3: ISI_CONV_BF16X6 (fp32-grade six-term split) in every layer that
                   * feeds a code index, ISI_CONV_BF16X3 in `dec` and `upsample`.  4: ISI_CONV_F16X3
                   * (fp32-grade three-term split-f16 products, f16 operand range) in every convolution. */
+  int no_quantize; /* 1: UnquantizedBottleneck (bottleneck.py:107-119, selected at vqvae.py:152-160): the two
+                    * codebook searches are skipped, quant_t / quant_b receive the 1x1 convolutions' outputs,
+                    * id_t / id_b are not written, scalars = {0, inf, 0, inf}; the codebooks may be null */
 } isi_vqvae_w;
 
 /* Outputs of VQVAE.encode / forward (vqvae.py:245-278).  Any pointer may be

@@ -39,10 +39,13 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
   constexpr int LDD = D + 4;  // padded row: conflict-free b128 fragment reads
   constexpr int NQ = D / 8;   // k-quads held per lane (half-waves interleave quads)
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *cb = smem;            // [K][LDD]
-  float *e2 = smem + (size_t)K * LDD;  // [K]
-  float *red = e2 + K;         // [4] per-wave sse
-  int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);  // [K] workgroup histogram (flushed once at the end)
+  // K need not be a multiple of the 32-code MFMA tile: the LDS image is padded to Kp rows of zeros whose |e|^2 is
+  // +inf, so a padding row's distance is +inf and never wins (`d < best` with best starting at +inf)
+  const int Kp = (K + 31) & ~31;
+  float *cb = smem;            // [Kp][LDD]
+  float *e2 = smem + (size_t)Kp * LDD;  // [Kp]
+  float *red = e2 + Kp;        // [waves] per-wave sse
+  int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);  // [Kp] workgroup histogram (flushed once at the end)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -51,12 +54,12 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
   const int half = lane >> 5;
 
   // ---- codebook -> LDS (once per persistent workgroup)
-  for (int i = tid; i < K * (D / 4); i += VQ_BLOCK) {
+  for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
     const int k = i / (D / 4), qd = i - k * (D / 4);
     *reinterpret_cast<float4 *>(cb + (size_t)k * LDD + qd * 4) =
-        *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4);
+        k < K ? *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  for (int i = tid; i < K; i += VQ_BLOCK) { e2[i] = e2g[i]; hist[i] = 0; }
+  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : INFINITY; hist[i] = 0; }
   __syncthreads();
 
   float sse = 0.f;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
 
     float best = INFINITY;
     int besti = 0;
-    for (int kt = 0; kt < K; kt += 32) {
+    for (int kt = 0; kt < Kp; kt += 32) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -168,10 +171,11 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
     float *__restrict__ sse_part, int64_t N, int K) {
   constexpr int D = 64;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned short *cbh = reinterpret_cast<unsigned short *>(smem);   // [K][64] hi pieces
-  unsigned short *cbl = cbh + (size_t)K * D;                        // [K][64] lo pieces
-  float *e2 = reinterpret_cast<float *>(cbl + (size_t)K * D);       // [K]
-  float *red = e2 + K;
+  const int Kp = (K + 31) & ~31;                                     // padding rows: zeros, |e|^2 = +inf
+  unsigned short *cbh = reinterpret_cast<unsigned short *>(smem);   // [Kp][64] hi pieces
+  unsigned short *cbl = cbh + (size_t)Kp * D;                       // [Kp][64] lo pieces
+  float *e2 = reinterpret_cast<float *>(cbl + (size_t)Kp * D);      // [Kp]
+  float *red = e2 + Kp;
   int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);
 
   const int tid = threadIdx.x;
@@ -180,15 +184,16 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
   const int col = lane & 31;
   const int half = lane >> 5;
 
-  for (int i = tid; i < K * (D / 4); i += VQ_BLOCK) {
+  for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
     const int k = i >> 4, qd = i & 15;
     uint2 hi, lo;
-    vq_split4(*reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4), kVqScaleE, hi, lo);
+    vq_split4(k < K ? *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f),
+              kVqScaleE, hi, lo);
     const int wo = k * D + (((qd >> 1) ^ ((k >> 1) & 7)) * 8) + (qd & 1) * 4;
     *reinterpret_cast<uint2 *>(cbh + wo) = hi;
     *reinterpret_cast<uint2 *>(cbl + wo) = lo;
   }
-  for (int i = tid; i < K; i += VQ_BLOCK) { e2[i] = e2g[i]; hist[i] = 0; }
+  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : INFINITY; hist[i] = 0; }
   __syncthreads();
 
   float sse = 0.f;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
 
     float best = INFINITY;
     int besti = 0;
-    for (int kt = 0; kt < K; kt += 32) {
+    for (int kt = 0; kt < Kp; kt += 32) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -338,7 +343,8 @@ int vq_num_partials(int64_t N) { return vq_grid(N); }
 template <int D>
 static int launch_vq(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                      int32_t *counts, float *sse_part, int64_t N, int K, hipStream_t stream) {
-  const size_t smem = ((size_t)K * (D + 4) + 2 * K + ISI_VQ_WAVES) * sizeof(float);
+  const int Kp = (K + 31) & ~31;
+  const size_t smem = ((size_t)Kp * (D + 4) + 2 * Kp + ISI_VQ_WAVES) * sizeof(float);
   if (smem > 150 * 1024) return unsupported("vq: codebook does not fit in LDS");
   auto kern = vq_nearest_kernel<D>;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -355,7 +361,8 @@ static int launch_vq(const float *z, const float *codes, const float *e2, int64_
 
 static int launch_vq_f16x3(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                            int32_t *counts, float *sse_part, int64_t N, int K, hipStream_t stream) {
-  const size_t smem = (size_t)K * 64 * 2 * sizeof(unsigned short) + ((size_t)2 * K + ISI_VQ_WAVES) * sizeof(float);
+  const int Kp = (K + 31) & ~31;
+  const size_t smem = (size_t)Kp * 64 * 2 * sizeof(unsigned short) + ((size_t)2 * Kp + ISI_VQ_WAVES) * sizeof(float);
   auto kern = vq_nearest_f16x3_kernel;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -374,11 +381,11 @@ int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t 
                    int32_t *counts, float *sse_part, int64_t N, int D, int K, int flags,
                    hipStream_t stream) {
   if (!z || !codes || !e2 || !idx || !q || !counts || !sse_part) return invalid("vq: null pointer");
-  if (N <= 0 || K <= 0 || (K % 32) != 0) return invalid("vq: need N > 0 and K % 32 == 0");
+  if (N <= 0 || K <= 0) return invalid("vq: need N > 0 and K > 0");
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(codes) |
        reinterpret_cast<uintptr_t>(q)) & 15)
     return invalid("vq: z, codes and q must be 16-byte aligned");
-  if ((flags & ISI_CONV_F16X3) && D == 64 && (size_t)K * 64 * 4 + (size_t)K * 8 + 64 <= 150 * 1024)
+  if ((flags & ISI_CONV_F16X3) && D == 64 && (size_t)((K + 31) & ~31) * (64 * 4 + 8) + 64 <= 150 * 1024)
     return launch_vq_f16x3(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
   switch (D) {
     case 8: return launch_vq<8>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);

@@ -284,6 +284,14 @@ int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *
   return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);
 }
 
+// UnquantizedBottleneck.forward (bottleneck.py:107-119): diff = 0, perplexity = inf
+int unquantized_scalars(float *scalars2, hipStream_t st) {
+  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scalars2), 0, 1, st) != hipSuccess ||
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scalars2 + 1), 0x7f800000, 1, st) != hipSuccess)
+    return check_launch("hipMemsetD32Async(unquantized scalars)");
+  return ISI_OK;
+}
+
 int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
          const isi_vqvae_out *out, Bump &ws, hipStream_t st) {
   Shapes sh;
@@ -342,12 +350,14 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
     // quantize_conv_t + quantize_t (vqvae.py:260-263)
     {
       isi_src s = src_nhwc(et.p, et.C, et.H, et.W);
-      isi_dst d = dst_nhwc(zbuf, D, et.H, et.W);
+      // UnquantizedBottleneck (bottleneck.py:107-119): the 1x1 convolution's output IS quant_t
+      isi_dst d = dst_nhwc(w.no_quantize ? quant_t : zbuf, D, et.H, et.W);
       rc = conv2d_f32(&s, nullptr, w.quantize_conv_t.w, w.quantize_conv_t.bias, nullptr, &d, B, et.H,
                       et.W, D, 1, 1, 1, 0, pf_enc | (pairs ? ISI_CONV_IN0_PAIR : 0), st);
       if (rc) return rc;
-      rc = run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
-                         sse_part, scal + 0, pf_enc & ISI_CONV_F16X3, st);
+      rc = w.no_quantize ? unquantized_scalars(scal + 0, st)
+                         : run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
+                                         sse_part, scal + 0, pf_enc & ISI_CONV_F16X3, st);
       if (rc) return rc;
     }
     // dec_t (vqvae.py:265): [B,Ht,Wt,D] -> [B,Hb,2^n Wt,D]
@@ -364,12 +374,13 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       const int Cd = w.dec_t.up[w.dec_t.n_up - 1].Cout;
       isi_src a = src_nhwc(dec_t, Cd, sh.Hb, sh.Wq, Wd);
       isi_src b = src_nhwc(eb.p, eb.C, sh.Hb, sh.Wq, eb.W);
-      isi_dst d = dst_nhwc(zbuf, D, sh.Hb, sh.Wq);
+      isi_dst d = dst_nhwc(w.no_quantize ? quant_b : zbuf, D, sh.Hb, sh.Wq);
       rc = conv2d_f32(&a, &b, w.quantize_conv_b.w, w.quantize_conv_b.bias, nullptr, &d, B, sh.Hb,
                       sh.Wq, D, 1, 1, 1, 0, pf_enc | (pairs ? ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR : 0), st);
       if (rc) return rc;
-      rc = run_quantizer(w.quantize_b, zbuf, (int64_t)B * sh.Hb * sh.Wq, id_b, quant_b, counts,
-                         sse_part, scal + 2, pf_enc & ISI_CONV_F16X3, st);
+      rc = w.no_quantize ? unquantized_scalars(scal + 2, st)
+                         : run_quantizer(w.quantize_b, zbuf, (int64_t)B * sh.Hb * sh.Wq, id_b, quant_b, counts,
+                                         sse_part, scal + 2, pf_enc & ISI_CONV_F16X3, st);
       if (rc) return rc;
     }
   }

@@ -61,7 +61,7 @@ class isi_vqvae_w(C.Structure):
                 ("quantize_t", isi_codebook_w), ("quantize_b", isi_codebook_w),
                 ("dec_t", isi_decoder_w), ("dec", isi_decoder_w),
                 ("n_upsample", C.c_int), ("upsample", isi_conv_w * ISI_MAX_STAGES), ("w16", C.c_int),
-                ("precision", C.c_int)]
+                ("precision", C.c_int), ("no_quantize", C.c_int)]
 
 
 class isi_vqvae_out(C.Structure):

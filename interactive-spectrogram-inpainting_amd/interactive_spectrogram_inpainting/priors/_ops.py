@@ -32,6 +32,8 @@ LINEAR_GRAD_PRECISION = os.environ.get("ISI_LINEAR_GRAD_PRECISION", "bf16x3")
 # split-bf16 on the bf16 pipe (relative error of a product ~2^-16, fp32 accumulation, logits / softmax fp32)
 ATTENTION_PRECISION = os.environ.get("ISI_ATTENTION_PRECISION", "bf16x3")
 _ATTN_PREC = {"f32": 0, "bf16x3": 1}
+ATTENTION_PRECISIONS = tuple(_ATTN_PREC)                 # modes bench.py times
+ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1}    # 16-bit MFMA terms per product (0: fp32 matrix pipe)
 _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4}
 
 

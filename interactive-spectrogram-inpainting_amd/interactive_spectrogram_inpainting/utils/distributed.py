@@ -53,6 +53,35 @@ class DistributedEvalSampler(Sampler[int]):
         self.epoch = epoch
 
 
+class DistributedTrainSampler(DistributedEvalSampler):
+    """Shards for TRAINING: every rank gets exactly `total // world` samples of the epoch's (shared) permutation, the
+    remainder is dropped for that epoch.  Every training step issues collectives (gradient buckets, EMA statistics),
+    so all ranks must run the same number of steps: `DistributedEvalSampler` leaves the first `total % world` ranks
+    one sample -- possibly one whole batch -- longer, which deadlocks or mixes mismatched buffers."""
+
+    def __init__(self, dataset: Sized, num_replicas: Optional[int] = None, rank: Optional[int] = None,
+                 shuffle: bool = True, seed: int = 0):
+        super().__init__(dataset, num_replicas, rank, shuffle, seed)
+        self.num_samples = self.total_size // self.num_replicas
+
+    def __iter__(self) -> Iterator[int]:
+        return iter(list(super().__iter__())[:self.num_samples])
+
+
+def assert_same_step_count(n_steps: int, device: Optional[torch.device] = None) -> int:
+    """Raises on every rank when the ranks disagree on the number of steps of the coming epoch (each step holds
+    collectives); returns the common count.  One small all-reduce per epoch."""
+    if not is_distributed():
+        return n_steps
+    t = torch.tensor([n_steps, -n_steps], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    lo, hi = int(t[0]), -int(t[1])
+    if lo != hi:
+        raise RuntimeError(f"data-parallel ranks would run between {lo} and {hi} training steps this epoch: use an even "
+                           f"sampler (DistributedTrainSampler) for training")
+    return n_steps
+
+
 class GradBucketReducer:
     """Data-parallel gradient averaging for an autograd-driven model (the prior): replaces
     the reference's `nn.DataParallel` (train_autoregressive_model.py:145) with one process

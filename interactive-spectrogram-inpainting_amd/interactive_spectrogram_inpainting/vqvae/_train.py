@@ -331,6 +331,20 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
 
 
 # ------------------------------------------------------------------ quantiser (train mode)
+def exchange_ema_statistics(counts: torch.Tensor, embed_sum: torch.Tensor):
+    """Data-parallel exchange of the EMA statistics of one quantiser: the per-code usage counts `onehot.sum(0)` [K]
+    and the per-code vector sums `flatten^T @ onehot` [D, K] (bottleneck.py:80-84) of every rank's batch shard are
+    summed in ONE all-reduce message ([K] + [D*K] floats), so that N ranks x B/N samples update the codebook exactly
+    like one process with B samples (the reference lets DDP broadcast rank 0's buffers instead).
+    Identity when not distributed.  Host logic only (any device: RCCL on the GPU, gloo in the CPU tests)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return counts, embed_sum
+    K = counts.numel()
+    packed = torch.cat([counts.reshape(-1).float(), embed_sum.reshape(-1).float()])
+    dist.all_reduce(packed)
+    return packed[:K], packed[K:].reshape(embed_sum.shape)
+
+
 def quantize_train(q, z_nhwc: torch.Tensor):
     """Eval-identical search with the CURRENT codebook, optional index corruption (bottleneck.py:63-73),
     then the EMA update of the buffers (bottleneck.py:75-92) from statistics all-reduced over the
@@ -369,11 +383,7 @@ def quantize_train(q, z_nhwc: torch.Tensor):
     ws = torch.empty(nws, dtype=torch.float32, device=z_nhwc.device)
     _hip.check(L.isi_vq_embed_sum_f32(z_nhwc.data_ptr(), idx.data_ptr(), embed_sum.data_ptr(), ws.data_ptr(), nws,
                                       N, D, K, _s(z_nhwc)), "isi_vq_embed_sum_f32")
-    countsf = counts.float()
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        packed = torch.cat([countsf, embed_sum.reshape(-1)])
-        dist.all_reduce(packed)                     # one exchange: [K] + [K*D] statistics
-        countsf, embed_sum = packed[:K], packed[K:].reshape(D, K)
+    countsf, embed_sum = exchange_ema_statistics(counts.float(), embed_sum)
     _hip.check(L.isi_vq_ema_update_f32(q.embed.data_ptr(), q.cluster_size.data_ptr(), q.embed_avg.data_ptr(),
                                        countsf.data_ptr(), embed_sum.contiguous().data_ptr(), D, K, q.decay,
                                        q.eps, _s(z_nhwc)), "isi_vq_ema_update_f32")
@@ -403,6 +413,27 @@ class QuantizeTrainFunction(torch.autograd.Function):
         return None, vq_backward(dq, z, q_st, g.contiguous())
 
 
+@torch.no_grad()
+def encode_train(model, x: torch.Tensor):
+    """VQVAE.encode under model.train() (vqvae.py:251-278 with the quantisers in train mode): same layer sequence as
+    the train-mode forward up to the bottom quantiser, EMA buffers updated in-forward; detached outputs."""
+    tape = Tape()
+    x = x.contiguous()
+    enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
+    enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
+    z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=TRAIN_PRECISION))
+    q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t)
+    dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
+    if dec_t.shape[-1] != enc_b.shape[-1]:
+        if not model.adapt_quantized_durations:
+            raise RuntimeError("Sizes of tensors must match except in dimension 1")
+        w = min(dec_t.shape[-1], enc_b.shape[-1])            # vqvae.py:266-269
+        dec_t, enc_b = dec_t[..., :w], enc_b[..., :w]
+    z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=TRAIN_PRECISION))
+    q_b, diff_b, id_b, perp_b = quantize_train(model.quantize_b, z_b)
+    return _as_bchw(q_t), _as_bchw(q_b), (diff_t + diff_b).reshape(1), id_t, id_b, perp_t, perp_b
+
+
 def vq_backward(dq_nhwc, z_nhwc, q_st_nhwc, g_diff):
     dz = torch.empty_like(z_nhwc)
     _hip.check(_hip.lib().isi_vq_bwd_f32(dz.data_ptr(), dq_nhwc.data_ptr(), z_nhwc.data_ptr(),
@@ -423,13 +454,19 @@ class VQVAETrainFunction(torch.autograd.Function):
         enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
         enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
         z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=TRAIN_PRECISION))
-        q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t)
+        unq = model.disable_quantization      # UnquantizedBottleneck (bottleneck.py:107-119): identity, diff 0
+
+        def _identity(z):
+            dev = z.device
+            return (z, torch.zeros((), device=dev), torch.zeros(0, dtype=torch.int64, device=dev),
+                    torch.full((), float("inf"), device=dev))
+        q_t, diff_t, id_t, perp_t = _identity(z_t) if unq else quantize_train(model.quantize_t, z_t)
         tape["z_t"], tape["q_t"] = z_t, q_t
         dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
         if dec_t.shape[-1] != enc_b.shape[-1]:
             raise NotImplementedError("training needs input sizes divisible by the total down-sampling factor")
         z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=TRAIN_PRECISION))
-        q_b, diff_b, id_b, perp_b = quantize_train(model.quantize_b, z_b)
+        q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b)
         tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
         up = _as_bchw(q_t)
         for j, layer in enumerate(model.upsample_top_to_bottom):
@@ -467,7 +504,8 @@ class VQVAETrainFunction(torch.autograd.Function):
             d_view = conv_dgrad(dw, layer, _as_bchw(g))
         d_qt = _nhwc(d_view).clone()
         # bottom quantiser and its 1x1 conv on cat(dec_t, enc_b)
-        d_zb = vq_backward(d_qb, tape["z_b"], tape["q_b"], g_diff)
+        unq = model.disable_quantization
+        d_zb = d_qb.contiguous() if unq else vq_backward(d_qb, tape["z_b"], tape["q_b"], g_diff)
         qcb = model.quantize_conv_b
         _set_wb(grads, qcb, conv_wgrad(qcb, tape["dec_t"], d_zb, x2=tape["enc_b"]))
         d_cat2 = conv_dgrad(dw, qcb, _as_bchw(d_zb))
@@ -477,7 +515,7 @@ class VQVAETrainFunction(torch.autograd.Function):
         d_qt2 = decoder_backward(model.dec_t, tape, "dec_t", d_dect, dw, grads)
         axpy_(d_qt, d_qt2)
         # top quantiser and its 1x1 conv
-        d_zt = vq_backward(d_qt, tape["z_t"], tape["q_t"], g_diff)
+        d_zt = d_qt if unq else vq_backward(d_qt, tape["z_t"], tape["q_t"], g_diff)
         qct = model.quantize_conv_t
         _set_wb(grads, qct, conv_wgrad(qct, tape["enc_t"], d_zt))
         d_enct = _nhwc(conv_dgrad(dw, qct, _as_bchw(d_zt)))

@@ -172,8 +172,6 @@ class VQVAE(nn.Module):
 
     def _native_weights(self) -> _hip.isi_vqvae_w:
         """isi_vqvae_w describing the packed weights (rebuilt when any parameter changes)."""
-        if self.disable_quantization:
-            raise NotImplementedError("disable_quantization=True has no fused native path")
         key = self._plan_fingerprint()
         if self._plan is not None and self._plan_key == key:
             return self._plan[0]
@@ -214,6 +212,8 @@ class VQVAE(nn.Module):
             return d
 
         def book(q: QuantizedBottleneck) -> _hip.isi_codebook_w:
+            if self.disable_quantization:     # UnquantizedBottleneck: no search, the codebook is never read
+                return _hip.isi_codebook_w(None, None, q.dim, q.n_embed)
             codes, e2 = q.packed()
             keep.extend([codes, e2])
             return _hip.isi_codebook_w(codes.data_ptr(), e2.data_ptr(), q.dim, q.n_embed)
@@ -226,6 +226,7 @@ class VQVAE(nn.Module):
         w.dec_t, w.dec = dec(self.dec_t), dec(self.dec)
         w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2, "split_bf16": 3, "split_f16": 4}[self.conv_precision]
         w.w16 = 1          # _ConvParams.packed() carries the split-f16 pair copies
+        w.no_quantize = 1 if self.disable_quantization else 0
         w.n_upsample = len(self.upsample_top_to_bottom)
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)
@@ -252,9 +253,6 @@ class VQVAE(nn.Module):
 
     def _run(self, mode: int, x: Optional[Tensor], B: int, H: int, W: int, out: _hip.isi_vqvae_out,
              device: torch.device):
-        if self.training:
-            raise NotImplementedError("the training path (backward, EMA codebook update) is not built yet; "
-                                      "call .eval()")
         if not self.adapt_quantized_durations:
             Hb, Wb, Ht, Wt, Wq = self._latent_shapes(H, W)
             if Wq != Wt * 2 ** len(self.enc_t._down):
@@ -297,6 +295,11 @@ class VQVAE(nn.Module):
         out = _hip.isi_vqvae_out(dec.data_ptr() if dec is not None else None, quant_t.data_ptr(),
                                  quant_b.data_ptr(), id_t.data_ptr(), id_b.data_ptr(), scalars.data_ptr())
         self._run(_hip.MODE_FORWARD if with_decode else _hip.MODE_ENCODE, x, B, H, W, out, dev)
+        if self.disable_quantization:
+            # UnquantizedBottleneck.forward (bottleneck.py:107-119): diff zeros(1) each -> unsqueeze(0) and summed
+            # (vqvae.py:263,275,277): [1, 1]; no indices; perplexity tensor([inf])
+            return (dec, quant_t.permute(0, 3, 1, 2), quant_b.permute(0, 3, 1, 2), (scalars[0] + scalars[2]).reshape(1, 1),
+                    None, None, scalars[1:2], scalars[3:4])
         diff = (scalars[0] + scalars[2]).reshape(1)  # diff_t.unsqueeze(0) + diff_b.unsqueeze(0), vqvae.py:263,275,277
         return (dec, quant_t.permute(0, 3, 1, 2), quant_b.permute(0, 3, 1, 2), diff, id_t, id_b,
                 scalars[1], scalars[3])
@@ -313,16 +316,25 @@ class VQVAE(nn.Module):
         hand-written backward (`vqvae/_train.py`)."""
         from ._train import VQVAETrainFunction, _DgradWeights
         _hip.require_gpu(input, "input")
-        if self.disable_quantization:
-            raise NotImplementedError("disable_quantization=True has no training path")
         if not hasattr(self, "_dgrad_weights"):
             self._dgrad_weights = _DgradWeights()
         if self.data_normalizer is not None:
             input = self.data_normalizer.normalize(input)
-        dec, *rest = VQVAETrainFunction.apply(self, input, *self.parameters())
-        return (self.post_process(dec), *rest)      # differentiable (SpecAffineMaskFunction)
+        dec, diff, perp_t, perp_b, id_t, id_b = VQVAETrainFunction.apply(self, input, *self.parameters())
+        if self.disable_quantization:   # UnquantizedBottleneck: diff [1, 1] zeros, perplexities tensor([inf]), no indices
+            diff, perp_t, perp_b, id_t, id_b = diff.reshape(1, 1), perp_t.reshape(1), perp_b.reshape(1), None, None
+        return self.post_process(dec), diff, perp_t, perp_b, id_t, id_b      # differentiable (SpecAffineMaskFunction)
 
     def encode(self, input: Tensor):
+        if self.training and not self.disable_quantization:
+            # train mode: the quantisers update their EMA buffers in-forward (bottleneck.py:79-92), like the
+            # reference's encode under model.train(); outputs are returned detached (gradients flow through
+            # forward(), the path train_vqvae.py uses)
+            from ._train import encode_train
+            _hip.require_gpu(input, "input")
+            if self.data_normalizer is not None:
+                input = self.data_normalizer.normalize(input)
+            return encode_train(self, input)
         _, q_t, q_b, diff, id_t, id_b, perp_t, perp_b = self._encode_impl(input, with_decode=False)
         return q_t, q_b, diff, id_t, id_b, perp_t, perp_b
 

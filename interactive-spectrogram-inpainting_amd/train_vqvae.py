@@ -35,7 +35,7 @@ import torch.distributed as dist  # noqa: E402
 from torch import nn  # noqa: E402
 
 from interactive_spectrogram_inpainting.utils.distributed import (  # noqa: E402
-    DistributedEvalSampler, is_distributed, is_master_process)
+    DistributedEvalSampler, DistributedTrainSampler, assert_same_step_count, is_distributed, is_master_process)
 from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE  # noqa: E402
 
 
@@ -63,6 +63,9 @@ def train(epoch: int, loader: Iterable, model: VQVAE, reconstruction_criterion: 
           clip_grad_norm: Optional[float] = None, dry_run: bool = False) -> Dict[str, float]:
     model.train()
     stats = RunningMeans(device)
+    if hasattr(loader, "__len__") and not dry_run:
+        assert_same_step_count(len(loader), torch.device(device) if is_distributed() and
+                               dist.get_backend() == "nccl" else None)
     for batch_index, (img, *_) in enumerate(loader):
         model.zero_grad()
         img = img.to(device, non_blocking=True)
@@ -171,9 +174,13 @@ def main():
         helper = SpectrogramsHelper(16000, 256, 64, 256).to(device)
     criterion = get_reconstruction_criterion(args.reconstruction_criterion, helper)
     data = SyntheticSpectrograms(args.synthetic)
-    sampler = DistributedEvalSampler(data, shuffle=True, seed=20200117) if world > 1 else None
+    # training: even shards (every step holds collectives); evaluation: nothing added, nothing dropped
+    sampler = DistributedTrainSampler(data, shuffle=True, seed=20200117) if world > 1 else None
     loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, sampler=sampler, shuffle=sampler is None,
                                          drop_last=True, num_workers=0)
+    eval_sampler = DistributedEvalSampler(data, shuffle=False) if world > 1 else None
+    eval_loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, sampler=eval_sampler, shuffle=False,
+                                              drop_last=False, num_workers=0)
     for epoch in range(args.epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -184,7 +191,7 @@ def main():
                       dry_run=args.dry_run)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
-        val_loss, val = evaluate(loader, model, criterion, device=device,
+        val_loss, val = evaluate(eval_loader, model, criterion, device=device,
                                  latent_loss_weight=args.latent_loss_weight, dry_run=args.dry_run)
         if is_master_process():
             print(f"epoch {epoch}: train {means} ({len(loader) * args.batch_size * world / dt:.1f} spectrograms/s) "

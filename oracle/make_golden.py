@@ -479,6 +479,94 @@ def spectral_loss_fixtures():
     _save("spectral_loss.npz", **out)
 
 
+@torch.no_grad()
+def unquantized_fixtures():
+    """VQVAE(disable_quantization=True): UnquantizedBottleneck at both levels (bottleneck.py:107-119, selected at
+    vqvae.py:152-160)."""
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    kw = dict(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16,
+              num_embeddings=64, resolution_factors={"bottom": 4, "top": 2})
+    torch.manual_seed(25)
+    model = VQVAE(disable_quantization=True, **kw).eval()
+    x = torch.randn(2, 2, 32, 40)
+    q_t, q_b, diff, id_t, id_b, perp_t, perp_b = model.encode(x.clone())
+    dec, diff2, perp_t2, perp_b2, id_t2, id_b2 = model(x.clone())
+    assert id_t is None and id_b is None and id_t2 is None
+    arrays = {"w::" + k: v for k, v in _np(model.state_dict()).items()}
+    arrays.update(x=x.numpy(), quant_t=q_t.contiguous().numpy(), quant_b=q_b.contiguous().numpy(), diff=diff.numpy(),
+                  perplexity_t=perp_t.numpy(), perplexity_b=perp_b.numpy(), dec=dec.numpy(),
+                  dec_from_quant=model.decode(q_t, q_b).numpy())
+    _save("vqvae_unquantized.npz", **arrays)
+
+
+def train_trajectory_fixtures():
+    """BASELINE config 1: the reference's own training-step semantics (train_vqvae.py:168-192:
+    model.zero_grad(); out, latent_loss, perplexity_t, perplexity_b, *_ = model(img); loss = MSE(out, img) +
+    0.25 * latent_loss.mean(); loss.backward(); Adam(lr 3e-4).step()) run on the imported reference VQ-VAE for two
+    steps of batch 8: per-step losses / perplexities / code indices, and the codebooks and a few parameters after the
+    second step.  Two cases: the reduced configuration (weights stored) and the DEFAULT constructor at the NSynth
+    shape [8,2,128,512] (initial weights = those of vqvae_default_tiny.npz, inputs regenerated from the seed)."""
+    import warnings
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    out = {}
+
+    def run(tag, model, batches):
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=3e-4)
+        crit = nn.MSELoss()
+        for step, img in enumerate(batches):
+            model.zero_grad()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                o, latent_loss, perp_t, perp_b, id_t, id_b = model(img.clone())
+            recon = crit(o, img)
+            latent = latent_loss.mean()
+            loss = recon + 0.25 * latent
+            loss.backward()
+            opt.step()
+            out[f"{tag}::recon{step}"] = recon.detach().numpy()
+            out[f"{tag}::latent{step}"] = latent.detach().numpy()
+            out[f"{tag}::loss{step}"] = loss.detach().numpy()
+            out[f"{tag}::perp_t{step}"] = perp_t.detach().numpy()
+            out[f"{tag}::perp_b{step}"] = perp_b.detach().numpy()
+            out[f"{tag}::id_t{step}"] = id_t.numpy().astype(np.int16)
+            out[f"{tag}::id_b{step}"] = id_b.numpy().astype(np.int16)
+            print(tag, step, "loss", loss.item(), "recon", recon.item(), "latent", latent.item(),
+                  "perplexity", perp_t.item(), perp_b.item())
+        sd = model.state_dict()
+        for k in ("quantize_t.embed", "quantize_b.embed", "quantize_t.cluster_size", "quantize_b.cluster_size",
+                  "quantize_t.embed_avg", "quantize_b.embed_avg", "quantize_conv_t.weight", "quantize_conv_t.bias",
+                  "enc_b.blocks.0.weight", "dec.blocks.0.bias", "enc_t.blocks.3.conv.3.weight"):
+            out[f"{tag}::after::{k}"] = sd[k].detach().numpy().copy()
+
+    # (1) reduced configuration, weights stored with the fixture
+    torch.manual_seed(41)
+    kw = dict(in_channel=2, num_hidden_channels=32, n_res_block=2, num_residual_channels=8, embed_dim=16,
+              num_embeddings=64, resolution_factors={"bottom": 4, "top": 2})
+    small = VQVAE(**kw).eval()
+    _calibrate_codebooks(small, torch.randn(4, 2, 32, 48), 141)
+    for k, v in _np(small.state_dict()).items():
+        out["small::w::" + k] = v.copy()       # .numpy() shares storage with the parameters the steps below update
+    xs = [torch.randn(8, 2, 32, 48) for _ in range(2)]
+    for i, xb in enumerate(xs):
+        out[f"small::x{i}"] = xb.numpy()
+    run("small", small, xs)
+
+    # (2) default constructor at the NSynth shape; initial weights = vqvae_default_tiny.npz
+    z = np.load(OUT / "vqvae_default_tiny.npz")
+    full = VQVAE(in_channel=2, resolution_factors={"bottom": 4, "top": 2})
+    full.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")})
+    g = torch.Generator().manual_seed(4242)
+    xs = [torch.randn(8, 2, 128, 512, generator=g) for _ in range(2)]
+    for i, xb in enumerate(xs):
+        xb[:, 1].tanh_()                       # channel 1 ~ mel-IF in [-1, 1] (SURVEY 8d synthetic input)
+        out[f"full::x{i}_head"] = xb.reshape(-1)[:64].numpy().copy()      # proves the regenerated inputs are the same
+        out[f"full::x{i}_sum"] = np.float64(xb.double().sum().item())
+    out["full::x_seed"] = np.int64(4242)
+    run("full", full, xs)
+    _save("train_trajectory.npz", **out)
+
+
 def main():
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     _install_stubs()
@@ -519,6 +607,8 @@ def main():
     scheduler_fixtures()
     time_indexes_fixtures()
     spectral_loss_fixtures()
+    unquantized_fixtures()
+    train_trajectory_fixtures()
 
 
 if __name__ == "__main__":

@@ -203,6 +203,10 @@ def forward_train(x: Tensor, sd: StateDict, cfg: "Config"):
     enc_b = encoder(x, sd, "enc_b.", fb, cfg.n_res_block)
     enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
     z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    if cfg.disable_quantization:      # identity bottlenecks: nothing to update, gradients pass straight through
+        dec_t = decoder(z_t.permute(0, 3, 1, 2), sd, "dec_t.", ft, cfg.n_res_block)
+        z_b = F.conv2d(torch.cat([dec_t, enc_b], 1), sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"])
+        return decode(z_t.permute(0, 3, 1, 2), z_b, sd, cfg), torch.zeros(1, 1), None, None, (None, None)
     q_t, diff_t, id_t, _, new_t = quantize_train(z_t, sd["quantize_t.embed"], sd["quantize_t.cluster_size"],
                                                  sd["quantize_t.embed_avg"],
                                                  corruption_weights=cfg.corruption_weights["top"])
@@ -218,6 +222,11 @@ def forward_train(x: Tensor, sd: StateDict, cfg: "Config"):
     return dec, diff_t.unsqueeze(0) + diff_b.unsqueeze(0), id_t, id_b, (new_t, new_b)
 
 
+def unquantized(z: Tensor) -> Tuple[Tensor, Tensor, None, Tensor]:
+    """UnquantizedBottleneck.forward (bottleneck.py:107-119): identity, diff zeros(1), no indices, perplexity [inf]."""
+    return z, torch.zeros((1,), dtype=z.dtype), None, torch.as_tensor([float("inf")])
+
+
 def embed_code(ind: Tensor, embed: Tensor) -> Tensor:
     """QuantizedBottleneck.embed_code (bottleneck.py:103-104)."""
     return F.embedding(ind, embed.t())
@@ -228,7 +237,9 @@ class Config:
 
     def __init__(self, in_channel=2, num_hidden_channels=128, n_res_block=2,
                  num_residual_channels=32, embed_dim=64, num_embeddings=512,
-                 resolution_factors=None, adapt_quantized_durations=True, groups=1, corruption_weights=None):
+                 resolution_factors=None, adapt_quantized_durations=True, groups=1, corruption_weights=None,
+                 disable_quantization=False):
+        self.disable_quantization = disable_quantization  # vqvae.py:152-160: UnquantizedBottleneck at both levels
         self.groups = groups                              # vqvae.py:76: down / up-sampling convs and the encoders' 3x3
         self.corruption_weights = dict(corruption_weights or {"top": None, "bottom": None})   # vqvae.py:84-85
         self.in_channel = in_channel
@@ -248,7 +259,7 @@ def encode(x: Tensor, sd: StateDict, cfg: Config):
     enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
 
     z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
-    q_t, diff_t, id_t, perp_t = quantize(z_t, sd["quantize_t.embed"])
+    q_t, diff_t, id_t, perp_t = unquantized(z_t) if cfg.disable_quantization else quantize(z_t, sd["quantize_t.embed"])
     q_t = q_t.permute(0, 3, 1, 2)
 
     dec_t = decoder(q_t, sd, "dec_t.", ft, cfg.n_res_block)
@@ -258,7 +269,7 @@ def encode(x: Tensor, sd: StateDict, cfg: Config):
         enc_b = enc_b[..., :w]
     cat = torch.cat([dec_t, enc_b], 1)
     z_b = F.conv2d(cat, sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
-    q_b, diff_b, id_b, perp_b = quantize(z_b, sd["quantize_b.embed"])
+    q_b, diff_b, id_b, perp_b = unquantized(z_b) if cfg.disable_quantization else quantize(z_b, sd["quantize_b.embed"])
     q_b = q_b.permute(0, 3, 1, 2)
     diff = diff_t.unsqueeze(0) + diff_b.unsqueeze(0)
     return q_t, q_b, diff, id_t, id_b, perp_t, perp_b

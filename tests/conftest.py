@@ -7,7 +7,7 @@ import pytest
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 PKG_DIR = ROOT / "interactive-spectrogram-inpainting_amd"
-for p in (str(ROOT), str(PKG_DIR)):
+for p in (str(ROOT), str(PKG_DIR), str(ROOT / "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 

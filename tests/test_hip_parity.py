@@ -97,9 +97,9 @@ def test_resblock_against_reference(golden_dir):
 def test_quantizer_against_reference(golden_dir):
     from interactive_spectrogram_inpainting.vqvae.bottleneck import QuantizedBottleneck
     z = np.load(golden_dir / "quantizer.npz")
+    # "t": the reference's engineered exact ties (duplicate codes -> first index wins) at K = 16, a codebook
+    # smaller than the 32-code MFMA tile
     for p, (d, k) in {"g": (64, 512), "t": (8, 16)}.items():
-        if k % 32:
-            continue
         q = QuantizedBottleneck(d, k)
         q.embed.copy_(torch.from_numpy(z[p + "_embed"]))
         q = q.to(_dev()).eval()
@@ -266,9 +266,15 @@ def test_vqvae_against_oracle_seeded_odd_width():
     _close(p_t, ref[2], TOL, "perplexity_t"); _close(p_b, ref[3], TOL, "perplexity_b")
 
 
-def test_vqvae_full_size_properties():
-    """BASELINE config 2 (B=64, [2,128,512]): size-independent properties plus an
-    oracle check on a slice of the batch."""
+@pytest.mark.parametrize("precision", ["split_f16", "f32"])
+def test_vqvae_full_size_properties(precision):
+    """BASELINE config 2 (B=64, [2,128,512], default constructor): size-independent properties, and a TEACHER-FORCED
+    oracle comparison of every stage on 8 of the 64 samples, so that a moved near-tie index at one level never hides
+    the levels behind it:
+      top     oracle z_t from x            -> every GPU id_t that differs from the oracle's is a certified near-tie
+      bottom  oracle z_b from the GPU's id_t (embed_code -> dec_t -> cat(enc_b) -> 1x1) -> same for id_b
+      decoder oracle decode_code(GPU id_t, GPU id_b) against the GPU reconstruction, <= 1e-4 of the maximum
+    in the default split-f16 product mode and on the exact-fp32 matrix pipe."""
     from oracle import vqvae_oracle as O
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     cfg = O.Config(in_channel=2)
@@ -279,6 +285,7 @@ def test_vqvae_full_size_properties():
     m = VQVAE(in_channel=2)
     m.load_state_dict(sd)
     m = m.to(_dev()).eval()
+    m.conv_precision = precision
     xd = x.to(_dev())
     dec, diff, p_t, p_b, id_t, id_b = m(xd)
     assert dec.shape == (64, 2, 128, 512) and id_t.shape == (64, 16, 64) and id_b.shape == (64, 32, 128)
@@ -295,25 +302,26 @@ def test_vqvae_full_size_properties():
     q_t, q_b, *_ = m.encode(xd[:4])
     rows = m.quantize_b.embed.t()[id_b[:4]]
     _close(q_b.permute(0, 2, 3, 1), rows, 1e-6, "quant_b rows")
-    # oracle on a slice of the batch
-    ref = O.forward(x[:2], sd, cfg)
-    top_ok = torch.equal(id_t[:2].cpu(), ref[4])
-    if not top_ok:
-        enc_t = O.encoder(O.encoder(x[:2], sd, "enc_b.", 4, 2), sd, "enc_t.", 2, 2)
-        z_t = torch.nn.functional.conv2d(enc_t, sd["quantize_conv_t.weight"],
-                                         sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
-        n_bad = _certify_index_mismatches(z_t, sd["quantize_t.embed"], id_t[:2].cpu(), ref[4])
-        assert n_bad <= 0.005 * ref[4].numel(), f"{n_bad} top indices differ from the oracle"
-    else:
-        # same top codes => the bottom quantiser saw (numerically) the same input
-        q_t = O.embed_code(ref[4], sd["quantize_t.embed"]).permute(0, 3, 1, 2)
-        cat = torch.cat([O.decoder(q_t, sd, "dec_t.", 2, 2), O.encoder(x[:2], sd, "enc_b.", 4, 2)], 1)
-        z_b = torch.nn.functional.conv2d(cat, sd["quantize_conv_b.weight"],
-                                         sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
-        n_bad = _certify_index_mismatches(z_b, sd["quantize_b.embed"], id_b[:2].cpu(), ref[5])
-        assert n_bad <= 0.005 * ref[5].numel(), f"{n_bad} bottom indices differ from the oracle"
-        if n_bad == 0:
-            _close(dec[:2], ref[0], TOL, "dec vs oracle")
+    # ---- teacher-forced oracle comparison on samples spread over the batch
+    pick = torch.tensor([0, 1, 9, 18, 27, 36, 50, 63])
+    xs = x[pick]
+    gt, gb = id_t[pick.to(_dev())].cpu(), id_b[pick.to(_dev())].cpu()
+    F = torch.nn.functional
+    enc_b = O.encoder(xs, sd, "enc_b.", 4, 2)
+    enc_t = O.encoder(enc_b, sd, "enc_t.", 2, 2)
+    z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    ref_t = O.quantize(z_t, sd["quantize_t.embed"])[2]
+    n_t = _certify_index_mismatches(z_t, sd["quantize_t.embed"], gt, ref_t)
+    assert n_t <= 0.004 * ref_t.numel(), f"{n_t} of {ref_t.numel()} top indices differ from the oracle"
+    q_t_forced = O.embed_code(gt, sd["quantize_t.embed"]).permute(0, 3, 1, 2)
+    cat = torch.cat([O.decoder(q_t_forced, sd, "dec_t.", 2, 2), enc_b], 1)
+    z_b = F.conv2d(cat, sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+    ref_b = O.quantize(z_b, sd["quantize_b.embed"])[2]
+    n_b = _certify_index_mismatches(z_b, sd["quantize_b.embed"], gb, ref_b)
+    assert n_b <= 0.002 * ref_b.numel(), f"{n_b} of {ref_b.numel()} bottom indices differ from the oracle"
+    _close(dec[pick.to(_dev())], O.decode_code(gt, gb, sd, cfg), TOL, "dec vs oracle decode_code(GPU codes)")
+    print(f"[{precision}] indices differing from the torch-CPU oracle on 8 spectrograms: top {n_t}/{ref_t.numel()}, "
+          f"bottom (teacher-forced) {n_b}/{ref_b.numel()}")
 
 
 def test_extract_rows(golden_dir):

@@ -447,3 +447,86 @@ def test_normalizer_statistics_and_spectral_basis_host_side():
             frame = audio[0, t * sc.hop:t * sc.hop + N]
             mine = basis @ frame
             assert (mine[:F] - X[:, t].real).abs().max() < 1e-9 and (mine[F:] - X[:, t].imag).abs().max() < 1e-9
+
+
+def _ema_worker(rank, world, port, q):
+    import os
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "interactive-spectrogram-inpainting_amd"))
+    sys.path.insert(0, str(root))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from interactive_spectrogram_inpainting.utils.distributed import (
+        DistributedEvalSampler, DistributedTrainSampler, assert_same_step_count)
+    from interactive_spectrogram_inpainting.vqvae._train import exchange_ema_statistics
+    from oracle import vqvae_oracle as O
+    D, K, N = 8, 16, 40
+    g = torch.Generator().manual_seed(5)
+    embed = torch.randn(D, K, generator=g)
+    z = torch.randn(N, D, generator=g)               # the GLOBAL batch; this rank owns every world-th vector
+    mine = z[rank::world]
+    ind = O.quantize(mine, embed)[2]
+    counts = torch.bincount(ind, minlength=K).float()
+    embed_sum = mine.t() @ torch.nn.functional.one_hot(ind, K).float()
+    counts, embed_sum = exchange_ema_statistics(counts, embed_sum)
+    # bottleneck.py:79-92 applied to the exchanged statistics
+    cs = 0.99 * torch.zeros(K) + 0.01 * counts
+    ea = 0.99 * embed + 0.01 * embed_sum
+    n = cs.sum()
+    new_embed = ea / ((cs + 1e-5) / (n + K * 1e-5) * n).unsqueeze(0)
+    # samplers: 63 samples, batch 8, 2 ranks
+    data = list(range(63))
+    steps = {}
+    for name, cls in (("eval", DistributedEvalSampler), ("train", DistributedTrainSampler)):
+        s = cls(data, shuffle=True, seed=3)
+        loader = torch.utils.data.DataLoader(data, batch_size=8, sampler=s, drop_last=True)
+        steps[name] = (len(loader), sorted(int(i) for b in loader for i in b))
+    uneven_raises = False
+    try:
+        assert_same_step_count(steps["eval"][0])
+    except RuntimeError:
+        uneven_raises = True
+    same = assert_same_step_count(steps["train"][0])
+    q.put((rank, new_embed, cs, ea, steps, uneven_raises, same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ema_statistics_exchange_and_even_training_shards_gloo():
+    """SURVEY 8e (config 3): (1) the EMA-statistics all-reduce -- the one place where the DP design deliberately
+    differs from the reference's DDP buffer broadcast -- makes 2 ranks x B/2 vectors update the codebook exactly like
+    one process with B vectors (checked against the oracle's single-process ema_update); (2) training shards are
+    even: with 63 samples / batch 8 the eval sampler gives the ranks 4 and 3 steps (a hang: every step holds
+    collectives), which `assert_same_step_count` rejects on every rank; the training sampler gives both 3."""
+    import torch.multiprocessing as mp
+    from oracle import vqvae_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + int(torch.randint(0, 2000, (1,)).item())
+    procs = [ctx.Process(target=_ema_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    D, K, N = 8, 16, 40
+    g = torch.Generator().manual_seed(5)
+    embed = torch.randn(D, K, generator=g)
+    z = torch.randn(N, D, generator=g)
+    ind = O.quantize(z, embed)[2]
+    ref_embed, ref_cs, ref_ea = O.ema_update(z, ind, embed, torch.zeros(K), embed.clone())
+    seen = []
+    for rank, new_embed, cs, ea, steps, uneven_raises, same in out:
+        torch.testing.assert_close(cs, ref_cs, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(ea, ref_ea, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(new_embed, ref_embed, rtol=1e-5, atol=1e-6)
+        assert steps["eval"][0] == (4 if rank == 0 else 3) and steps["train"][0] == 3 and same == 3
+        assert uneven_raises, "ranks with different step counts must be rejected before the first collective"
+        seen.append(steps["train"][1])
+    assert not set(seen[0]) & set(seen[1]) and len(seen[0]) == len(seen[1]) == 24
+    torch.testing.assert_close(out[0][1], out[1][1], rtol=0, atol=0)      # identical codebooks on both ranks

@@ -138,3 +138,65 @@ def test_spectral_loss_oracle_matches_reference(golden_dir):
         loss.backward()
         _close(loss.detach(), z[f"{name}::loss"], 1e-5)
         _close(p.grad, z[f"{name}::grad"], 1e-4)
+
+
+def test_unquantized_bottleneck_matches_reference(golden_dir):
+    """VQVAE(disable_quantization=True): UnquantizedBottleneck (bottleneck.py:107-119) at both levels."""
+    z, sd = _load(golden_dir, "vqvae_unquantized.npz")
+    cfg = O.Config(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16,
+                   num_embeddings=64, disable_quantization=True)
+    x = torch.from_numpy(z["x"])
+    q_t, q_b, diff, id_t, id_b, p_t, p_b = O.encode(x, sd, cfg)
+    assert id_t is None and id_b is None
+    assert diff.shape == z["diff"].shape == (1, 1) and float(diff) == 0.0
+    assert torch.isinf(p_t).all() and torch.isinf(p_b).all() and p_t.shape == z["perplexity_t"].shape
+    _close(q_t, z["quant_t"]); _close(q_b, z["quant_b"])
+    _close(O.forward(x, sd, cfg)[0], z["dec"])
+    _close(O.decode(q_t, q_b, sd, cfg), z["dec_from_quant"])
+
+
+def reference_training_steps(sd, cfg, batches):
+    """The reference's training-step semantics (train_vqvae.py:168-192) on the oracle: yields per-step
+    (recon, latent, loss, id_t, id_b) and finally the state."""
+    state = {k: v.clone() for k, v in sd.items()}
+    learn = [k for k in state if not k.startswith("quantize_t.") and not k.startswith("quantize_b.")]
+    for k in learn:
+        state[k].requires_grad_(True)
+    opt = torch.optim.Adam([state[k] for k in learn], lr=3e-4)
+    steps = []
+    for x in batches:
+        opt.zero_grad()
+        dec, diff, id_t, id_b, (nt, nb) = O.forward_train(x, state, cfg)
+        recon = torch.nn.functional.mse_loss(dec, x)
+        latent = diff.mean()
+        loss = recon + 0.25 * latent
+        loss.backward()
+        opt.step()
+        for lvl, new in (("t", nt), ("b", nb)):
+            for name, val in zip(("embed", "cluster_size", "embed_avg"), new):
+                state[f"quantize_{lvl}.{name}"] = val
+        steps.append((recon.item(), latent.item(), loss.item(), id_t, id_b))
+    return steps, state
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_training_trajectory_matches_reference(golden_dir, tag):
+    """BASELINE config 1: two training steps of the imported reference (batch 8; the default constructor at the
+    NSynth shape [8,2,128,512] and a reduced configuration): losses, perplexity-defining code indices, EMA codebooks
+    and Adam-updated parameters of the oracle's restatement."""
+    from tests_support import trajectory_case
+    z, sd, kw, xs = trajectory_case(golden_dir, tag)
+    cfg = O.Config(**kw)
+    steps, state = reference_training_steps(sd, cfg, xs)
+    for i, (recon, latent, loss, id_t, id_b) in enumerate(steps):
+        assert abs(recon - float(z[f"{tag}::recon{i}"])) <= 1e-4 * abs(float(z[f"{tag}::recon{i}"]))
+        assert abs(loss - float(z[f"{tag}::loss{i}"])) <= 1e-4 * abs(float(z[f"{tag}::loss{i}"]))
+        assert abs(latent - float(z[f"{tag}::latent{i}"])) <= 2e-3 * abs(float(z[f"{tag}::latent{i}"])) + 1e-7
+        for got, key in ((id_t, "id_t"), (id_b, "id_b")):
+            ref = torch.from_numpy(z[f"{tag}::{key}{i}"].astype(np.int64))
+            agree = (got == ref).float().mean().item()
+            assert agree == 1.0 if i == 0 else agree > 0.995, (tag, i, key, agree)
+    for k in z.files:
+        if k.startswith(f"{tag}::after::"):
+            name = k[len(f"{tag}::after::"):]
+            _close(state[name].detach(), z[k], 2e-3 if "quantize_" in name else 2e-4)

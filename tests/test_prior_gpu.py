@@ -424,3 +424,123 @@ def test_flask_routes_round_trip(golden_dir):
     r4 = c.post("/get-audio", data=json.dumps(body))
     assert r4.status_code == 200 and r4.mimetype == "audio/wav" and r4.data[:4] == b"RIFF"
     assert len(r4.data) == 44 + 2 * 32 * 32
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE sizes (configs 4 / 5): seq 1025 self-attention at head_dim 64 x 8 heads, the bottom prior's 4100 x 1025
+# cross-attention with four tokens per event, the full d_model 512 / 6 + 8 layer priors, sampling on a [32,32] map.
+
+FULL = dict(n_class=512, channel=256, kernel_size=5, n_block=4, n_res_block=4, res_channel=256, d_model=512,
+            embeddings_dim=32, positional_embeddings_dim=16, use_relative_transformer=True,
+            predict_frequencies_first=True, conditional_model=True, class_conditioning_prepend_to_dummy_input=True,
+            class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+            class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64})
+
+
+def _full_top(seed=2):
+    from interactive_spectrogram_inpainting.priors.transformer import SelfAttentiveVQTransformer
+    torch.manual_seed(seed)
+    return SelfAttentiveVQTransformer(shape=[32, 32], condition_shape=[32, 32], self_conditional_model=True,
+                                      add_mask_token_to_symbols=True, **FULL).to(_dev()).eval()
+
+
+def _full_bottom(seed=3):
+    from interactive_spectrogram_inpainting.priors.transformer import UpsamplingVQTransformer
+    torch.manual_seed(seed)
+    return UpsamplingVQTransformer(shape=[64, 64], condition_shape=[32, 32], **FULL).to(_dev()).eval()
+
+
+@pytest.mark.parametrize("Sq,Sk,Cq,Ck,mode", [(1025, 1025, 1, 1, 1), (1025, 1025, 1, 1, 2), (4100, 1025, 4, 1, 0),
+                                              (4100, 4100, 4, 4, 1)])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_rel_attention_at_baseline_sizes(Sq, Sk, Cq, Ck, mode, precision, monkeypatch):
+    """The attention shapes the metric is quoted on: top prior self-attention (S = 1025, causal in the decoder,
+    anti-causal in the self-conditional encoder), bottom prior cross-attention 4100 x 1025 (4 tokens per event) and
+    its causal self-attention at S = 4100; head_dim 64, 8 heads."""
+    from oracle import prior_oracle as P
+    from interactive_spectrogram_inpainting.priors import _ops
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", precision)
+    hd, H, B = 64, 8, 1
+    d = hd * H
+    torch.manual_seed(Sq + Sk + mode)
+    Eq, Ek = -(-Sq // Cq), -(-Sk // Ck)
+    q, k, v = torch.randn(Sq, B, d), torch.randn(Sk, B, d), torch.randn(Sk, B, d)
+    rel = torch.randn(H, Eq + Ek - 1, hd) * 0.5
+    hq = q.reshape(Sq, B, H, hd).permute(1, 2, 0, 3)
+    hk = k.reshape(Sk, B, H, hd).permute(1, 2, 0, 3)
+    hv = v.reshape(Sk, B, H, hd).permute(1, 2, 0, 3)
+    logits = hq @ hk.transpose(-1, -2)
+    qe = torch.einsum("bhid,hrd->bhir", hq, rel)
+    logits = (logits + qe.gather(3, P.rel_index(Sq, Sk, Cq, Ck, Ek).expand(B, H, Sq, Sk))) / math.sqrt(hd)
+    del qe
+    if mode == 1:
+        logits += P.causal_mask(Sq)
+    elif mode == 2:
+        logits += P.causal_mask(Sq).t()
+    ref = (torch.softmax(logits, -1) @ hv).permute(2, 0, 1, 3).reshape(Sq, B, d)
+    del logits
+    dev = _dev()
+    got = _ops.rel_attention(q.to(dev), k.to(dev), v.to(dev), rel.to(dev), H, Cq, Ck, Ek, mask_mode=mode)
+    _close(got, ref, TOL, f"rel_attention {Sq}x{Sk} mode {mode} {precision}")
+
+
+def test_full_size_priors_forward_against_spec():
+    """One forward of the top prior ([32,32]: 1025-token source and target, d_model 512, 6 encoder + 8 decoder layers,
+    8 heads) and of the bottom prior ([64,64] conditioned on [32,32]: 4100-token target) at B = 1 against the
+    specification in oracle/prior_oracle.py: encoder memory and logits within 5e-4 of their maxima (north_star: 1e-3)."""
+    dev = _dev()
+    g = torch.Generator().manual_seed(17)
+    top_code = torch.randint(0, 512, (1, 32, 32), generator=g).to(dev)
+    bottom_code = torch.randint(0, 512, (1, 64, 64), generator=g).to(dev)
+    mask = (torch.rand(1, 32, 32, generator=g) < 0.5).to(dev)
+    cls = {"pitch": torch.tensor([[24]], device=dev), "instrument_family_str": torch.tensor([[3]], device=dev)}
+    top, bottom = _full_top(), _full_bottom()
+    for name, m, (src, tgt) in (("top", top, top.to_sequences(top_code, top_code, class_conditioning=cls, mask=mask)),
+                                ("bottom", bottom, bottom.to_sequences(bottom_code, top_code, class_conditioning=cls))):
+        assert tgt.shape[1] == (1025 if name == "top" else 4100) and src.shape[1] == 1025
+        ref_logits, ref_mem, _ = _oracle_logits(m, src, tgt)
+        logits, memory = m(tgt, src)
+        _close(memory, ref_mem, 5e-4, name + " memory")
+        _close(logits, ref_logits, 5e-4, name + " logits")
+        err = ((logits.cpu() - ref_logits).abs().max() / ref_logits.abs().max()).item()
+        print(f"[{name} prior, d_model 512, 6+8 layers] max |logits - spec| / max |spec| = {err:.2e}")
+
+
+def test_sample_model_at_baseline_size_matches_full_pass_sampling():
+    """BASELINE config 5: KV-cached sampling on the [32,32] top map (1024 tokens, d_model 512, 6 + 8 layers) with a
+    32-token mask (one column of the map) == the reference's loop (one full decoder pass per masked token,
+    sample.py:268-305) drawing from the same uniforms; unmasked codes are kept."""
+    import sample as S
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.priors.transformer import Seq2SeqInputKind
+    top = _full_top()
+    dev = _dev()
+    B = 1
+    g = torch.Generator().manual_seed(19)
+    init = torch.randint(0, 512, (B, 32, 32), generator=g)
+    mask = torch.zeros(1, 32, 32, dtype=torch.bool)
+    mask[:, :, 17] = True                                      # 32 tokens: column 17
+    cls = {"pitch": torch.tensor([24]), "instrument_family_str": torch.tensor([0])}
+    uni = torch.rand(top.target_transformer_sequence_length, B, generator=g)
+    got = S.sample_model(top, dev, B, [32, 32], temperature=1.0, class_conditioning=cls, initial_code=init.clone(),
+                         mask=mask, top_p_sampling_p=0.8, uniforms=uni)
+    keep = ~mask.expand(B, -1, -1)
+    assert torch.equal(got.cpu()[keep], init[keep]), "unmasked positions must keep initial_code"
+    clsd = {k: v.long().expand(B).reshape(B, 1).to(dev) for k, v in cls.items()}
+    codemap = init.clone().to(dev)
+    src, tgt = top.to_sequences(codemap, codemap, class_conditioning=clsd, mask=mask.to(dev))
+    seq = top.target_codemaps_helper.to_sequence(codemap).clone()
+    mseq = top.target_codemaps_helper.to_sequence(mask.to(dev))[0].cpu().numpy()
+    assert int(mseq.sum()) == 32
+    memory = None
+    for i, is_masked in enumerate(mseq):
+        if not is_masked:
+            continue
+        logits, memory = top(tgt, src, memory=memory)
+        s = _ops.sample_rows(logits[:, i].contiguous(), 1.0, 0, 0.8, uni[i])
+        seq[:, i] = s
+        tgt[:, i + 1, :top.embeddings_effective_dim] = top.embed_data(s, Seq2SeqInputKind.Target)
+    ref = top.target_codemaps_helper.to_time_frequency_map(seq)
+    # a draw sits on a CDF step: rounding differences between the cached row and the full pass may move a code only
+    # if the uniform falls within float rounding of a step -- identical in practice
+    assert (got != ref).sum().item() <= 1, f"{(got != ref).sum().item()} of 32 sampled codes differ"

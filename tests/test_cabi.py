@@ -130,8 +130,9 @@ def test_oversize_and_bad_shapes_are_rejected_before_any_launch():
     # empty output
     src = _hip.isi_src(fake, 4, 16, 1, 8, 4)
     assert lib.isi_conv2d_f32(C.byref(src), None, fake, None, None, C.byref(dst), 1, 2, 2, 4, 4, 4, 2, 0, 0, None) == -1
-    # quantiser: K not a multiple of 32, unsupported embed_dim, empty input
-    assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 100, 64, 500, None) == -1
+    # quantiser: a codebook that does not fit in LDS, unsupported embed_dim, empty input
+    assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 100, 64, 1000, None) == -4
+    assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 100, 64, 0, None) == -1
     assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 100, 24, 512, None) == -4
     assert lib.isi_vq_nearest_f32(fake, fake, fake, fake, fake, fake, fake, 0, 64, 512, None) == -1
     # fused residual block outside its range -> caller must compose two convolutions

@@ -41,7 +41,38 @@ struct FirstArgs {
   int relu, out_pair;
 };
 
-using f16s::pair_encode;
+
+// transposed tile (32 pixels x COUT fp32 in LDS) -> whole pixel rows: 16-byte stores of fp32 quads or, for a
+// pair-format output (split_f16.h: {hi[8] | lo[8]} per group of 8 channels), of the two pieces of a group
+template <int COUT>
+__device__ __forceinline__ void store_tile(const FirstArgs &p, const float *tb, const int m0, const int lane) {
+  if (p.out_pair) {
+    constexpr int GP = COUT / 8;   // 32-byte groups per pixel
+#pragma unroll
+    for (int it = 0; it < 32 * GP / 64; ++it) {
+      const int idx = it * 64 + lane;
+      const int px = idx / GP, g = idx - px * GP;
+      uint4 hi, lo;
+      f16s::pair8_encode(*reinterpret_cast<const float4 *>(tb + px * LDT + g * 8),
+                         *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8 + 4), hi, lo);
+      if (m0 + px < p.M) {
+        uint4 *o = reinterpret_cast<uint4 *>(p.out + (size_t)(m0 + px) * COUT + g * 8);
+        o[0] = hi;
+        o[1] = lo;
+      }
+    }
+    return;
+  }
+  constexpr int QP = COUT / 4;   // 16-byte quads per pixel
+#pragma unroll
+  for (int it = 0; it < 32 * QP / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int px = idx / QP, q = idx - px * QP;
+    if (m0 + px < p.M)
+      *reinterpret_cast<float4 *>(p.out + (size_t)(m0 + px) * COUT + q * 4) =
+          *reinterpret_cast<const float4 *>(tb + px * LDT + q * 4);
+  }
+}
 
 template <int NT>   // NT = Cout / 32
 __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs p) {
@@ -119,18 +150,10 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const FirstArgs p) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[j][r] + bias[j];
         if (p.relu) v = fmaxf(v, 0.f) + (v - v);   // NaN-propagating rectifier (see conv_igemm_f32.hip)
-        tb[row * LDT + 32 * j + col] = p.out_pair ? __builtin_bit_cast(float, pair_encode(v)) : v;
+        tb[row * LDT + 32 * j + col] = v;
       }
     __syncthreads();
-    constexpr int QP = COUT / 4;   // 16-byte quads per pixel
-#pragma unroll
-    for (int it = 0; it < 32 * QP / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int px = idx / QP, q = idx - px * QP;
-      if (m0 + px < p.M)
-        *reinterpret_cast<float4 *>(p.out + (size_t)(m0 + px) * COUT + q * 4) =
-            *reinterpret_cast<const float4 *>(tb + px * LDT + q * 4);
-    }
+    store_tile<COUT>(p, tb, m0, lane);
   }
 }
 
@@ -220,18 +243,10 @@ __global__ __launch_bounds__(256) void conv_first_f16x3_kernel(const FirstArgs p
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         float v = acc[j][r] * f16s::kUnscale + bias[j];
         if (p.relu) v = fmaxf(v, 0.f) + (v - v);
-        tb[row * LDT + 32 * j + col] = p.out_pair ? __builtin_bit_cast(float, pair_encode(v)) : v;
+        tb[row * LDT + 32 * j + col] = v;
       }
     __syncthreads();
-    constexpr int QP = COUT / 4;
-#pragma unroll
-    for (int it = 0; it < 32 * QP / 64; ++it) {
-      const int idx = it * 64 + lane;
-      const int px = idx / QP, q = idx - px * QP;
-      if (m0 + px < p.M)
-        *reinterpret_cast<float4 *>(p.out + (size_t)(m0 + px) * COUT + q * 4) =
-            *reinterpret_cast<const float4 *>(tb + px * LDT + q * 4);
-    }
+    store_tile<COUT>(p, tb, m0, lane);
   }
 }
 

@@ -110,8 +110,6 @@ __device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &
 // ---- split-f16 ("f16x3", ISI_CONV_F16X3), pack-time weight pieces (ISI_CONV_W16) and activation pairs
 // (ISI_CONV_*_PAIR): definitions and error / range analysis in split_f16.h
 using f16s::f16x8;
-using f16s::pair_encode;
-using f16s::pair_quad;
 constexpr float kF16ScaleA = f16s::kScaleA, kF16ScaleB = f16s::kScaleB, kF16Unscale = f16s::kUnscale;
 __device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 
@@ -330,10 +328,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
       if constexpr (DUAL) v = sel1 ? ra1[j] : v;
       if constexpr (BF) {
         uint2 hi, mid, lo;
+        if constexpr (WPRE) {
+          if (chunk_pair) {
+            // pair8 source: the 16 bytes this thread loaded ARE an operand fragment -- piece lq of the row's 128-byte
+            // chunk = plane (lq & 1) of channel group (lq >> 1): one 16-byte LDS store, no arithmetic
+            const int w16 = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1);
+            *reinterpret_cast<float4 *>(((lq & 1) ? Alo : Ahi) + w16) = v;
+            continue;
+          }
+        }
         if constexpr (BF6) split3_bf16x4(v, hi, mid, lo);
-        else if constexpr (WPRE) {
-          if (chunk_pair) pair_quad(v, hi, lo); else split_f16x4(v, kF16ScaleA, hi, lo);
-        } else if constexpr (F16) split_f16x4(v, kF16ScaleA, hi, lo);
+        else if constexpr (F16) split_f16x4(v, kF16ScaleA, hi, lo);
         else split_bf16x4(v, hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
         *reinterpret_cast<uint2 *>(Ahi + wo) = hi;
@@ -347,8 +352,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
     for (int j = 0; j < RB; ++j) {
       if constexpr (BF) {
         uint2 hi, mid, lo;
+        if constexpr (WPRE) {   // weights in the blocked pair format (ISI_CONV_W16): a 16-byte piece = one fragment
+          const int w16 = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1);
+          *reinterpret_cast<float4 *>(((lq & 1) ? Blo : Bhi) + w16) = rb[j];
+          continue;
+        }
         if constexpr (BF6) split3_bf16x4(rb[j], hi, mid, lo);
-        else if constexpr (WPRE) f16s::weight_quad(rb[j], hi, lo);
         else if constexpr (F16) split_f16x4(rb[j], kF16ScaleB, hi, lo);
         else split_bf16x4(rb[j], hi, lo);
         const int wo = (lrow + 32 * j) * LDB + bf_slot(lrow + 32 * j, lq >> 1) + (lq & 1) * 4;
@@ -502,12 +511,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         // v - v is 0 for finite v and NaN otherwise.  (The select form `v < 0 ? 0 : v` makes this compiler allocate
         // 244 VGPRs for the split-f16 variant, 1 wave per SIMD.)
         if (p.relu) v = fmaxf(v, 0.f) + (v - v);
-        // The pair encoding is 8 VALU instructions per element: compiled in only where it is used (OUTP, the
-        // split-f16 kernels of the pair pipeline).  A runtime select computes both sides and cost the fp32 128x128
-        // variant its third wave per SIMD (103 -> 106 VGPRs); a runtime branch or a second loop over the tile makes
-        // this compiler allocate 244 VGPRs.
-        const int bits = (PREC == 4 && OUTP) ? (int)pair_encode(v) : __builtin_bit_cast(int, v);
-        __builtin_amdgcn_raw_buffer_store_b32(bits, rso, oo[r], 0, 0);
+        if constexpr (PREC == 4 && OUTP) {
+          // pair-format output (split_f16.h: {hi[8] | lo[8]} per group of 8 channels).  A lane of this layout owns
+          // ONE channel of 16 pixels, so its two pieces go out as 2-byte stores (conv_pair_f16.hip transposes
+          // through LDS and writes whole groups; this path serves the launches that kernel does not take)
+          const float t4 = v * kF16ScaleA;
+          const _Float16 h = (_Float16)t4;
+          const _Float16 l = (_Float16)(t4 - (float)h);
+          const unsigned po = oo[r] == OOB ? OOB : oo[r] - (unsigned)(n & 7) * 4u + (unsigned)(n & 7) * 2u;
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, h), rso, po, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, l), rso, po == OOB ? OOB : po + 16u, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rso, oo[r], 0, 0);
+        }
       }
     }
   }
@@ -552,10 +568,33 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
   static const bool tap_major = getenv("ISI_CONV_TAP_MAJOR") != nullptr;   // measurements
   a.chunk_major = (mode == 0 && a.KH * a.KW > 1 && a.C0 % kBK == 0 && a.Cin % kBK == 0 && !tap_major) ? 1 : 0;
+  const bool two = a.Cin > a.C0;
+  // the LDS-DMA kernel of the pair pipeline (conv_pair_f16.hip): pair8 sources, blocked weight pieces, whole
+  // 64-column output tiles, channels-last output, no residual
+  // It wins on the plain convolutions (1.13 - 1.2x, tools/bench_conv_pair.py); the transposed convolutions' four
+  // phases (K = 4 Cin: 16 or fewer chunks per tile, its per-tile set-up and epilogue are not amortised) and K < 256
+  // stay on this file's register-staged kernel.
+  static const bool dma_all = getenv("ISI_CONV_PAIR_ALL") != nullptr;
+  const bool dma_shape = dma_all || (!a.convT && a.K >= 256);
+  if (dma_shape && a.bf16x3 == 3 && a.w16 && mode == 0 && a.in0_pair && (!two || a.in1_pair) && !a.res && a.nz <= 1 && a.oc == 1 &&
+      conv_pair_kernel_ok(a.C0, a.Cin - a.C0, a.Cout, a.KH * a.KW) && a.KH <= 4 && a.KW <= 4 && a.M < (1 << 24) &&
+      a.in0_bytes < 0x70000000u && a.in1_bytes < 0x70000000u) {
+    PairConvArgs c;
+    memset(&c, 0, sizeof c);
+    c.in0 = a.in0; c.in1 = two ? a.in1 : nullptr; c.w16 = a.w16; c.bias = a.bias; c.out = a.out;
+    c.in0_bytes = a.in0_bytes; c.in1_bytes = a.in1_bytes; c.w_bytes = a.w_bytes; c.out_bytes = a.out_bytes;
+    c.C0 = a.C0; c.C1 = a.Cin - a.C0;
+    c.s0n = a.s0n; c.s0h = a.s0h; c.s0w = a.s0w; c.s1n = a.s1n; c.s1h = a.s1h; c.s1w = a.s1w;
+    c.on = a.on; c.oh = a.oh; c.ow = a.ow;
+    c.H = a.H; c.W = a.W; c.OH = a.OH; c.OW = a.OW; c.Cout = a.Cout; c.Kpad = a.Kpad; c.KH = a.KH; c.KW = a.KW;
+    c.stride = a.stride; c.pad = a.pad; c.relu = a.relu; c.M = a.M;
+    c.convT = a.convT; c.w_phase_stride = a.w_phase_stride; c.dst_sh = a.dst_sh; c.dst_sw = a.dst_sw;
+    c.out_pair = a.out_pair;
+    return conv_pair_f16(c, stream);
+  }
   if ((a.in0_pair || a.in1_pair || a.out_pair) && !(a.bf16x3 == 3 && a.w16 && mode == 0 && a.Cout > 32 && a.K >= 128))
-    return unsupported("conv: pair-format tensors need the split-f16 kernel (ISI_CONV_F16X3 | ISI_CONV_W16, "
-                       "channels-last sources of 32-channel multiples, Cout > 32, K >= 128) or, for the output, the "
-                       "2-channel first-layer kernel");
+    return unsupported("conv: pair-format tensors need the split-f16 kernels (ISI_CONV_F16X3 | ISI_CONV_W16, "
+                       "channels-last sources of 32-channel multiples, Cout > 32, K >= 128)");
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
     // 128x64 tiles are ~20 % slower per FLOP than 128x128, but a GEMM that fills less than the chip's
     // 3 workgroups per CU with 128x128 tiles (the prior's d x d linears at 8 k rows: 260 tiles) finishes
@@ -569,6 +608,7 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
     if (a.bf16x3 == 3 && a.w16) {   // split-f16 with the weights' pieces prepared at pack time
       a.w = a.w16;
       if (a.out_pair) {
+        if (a.oc != 1 || (a.Cout & 7)) return unsupported("conv: a pair-format output is channels-last with Cout % 8 == 0");
         if (narrow) return launch_cfg<128, 64, 2, 2, 0, 4, true>(a, nphase, stream);
         return launch_cfg<128, 128, 2, 2, 0, 4, true>(a, nphase, stream);
       }
@@ -602,9 +642,9 @@ static int split_mode(int flags) {
 // Would a convolution of dense channels-last sources (C0 [+ C1] channels) run the split-f16 kernel that accepts
 // pair-format sources?  (launch_conv's own conditions, for callers that plan tensor formats ahead: vqvae_run.cpp)
 bool conv_pair_sources_ok(int C0, int C1, int Cout, int taps) {
-  const bool vec = C0 % 4 == 0 && C1 % 4 == 0;
-  const bool uniform = C1 == 0 || (C0 % kBK == 0 && C1 % kBK == 0);
-  return vec && uniform && Cout > 32 && taps * (C0 + C1) >= 128;
+  // the split-f16 kernels that read (and write) pair tensors: this file's (32-channel slices per source, Cout > 32,
+  // K >= 128) and conv_pair_f16.hip (a subset of these shapes)
+  return C0 > 0 && C0 % kBK == 0 && C1 % kBK == 0 && Cout > 32 && Cout % 8 == 0 && taps * (C0 + C1) >= 128;
 }
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -1,0 +1,551 @@
+// Implicit-GEMM convolution of the split-f16 PAIR pipeline for gfx950 (the dominant kernel of VQVAE.forward).
+//
+//   out[m][n] = sum_k A[m][k] B[n][k]        M = B*OH*OW pixels, N = Cout, K = KH*KW*Cin
+//   every product as hi.hi + hi.lo + lo.hi of two 11-bit f16 pieces (split_f16.h) on v_mfma_f32_32x32x16_f16
+//
+// Same arithmetic as conv_igemm_f32.hip's ISI_CONV_F16X3 | ISI_CONV_W16 path -- with the accumulator flush off the
+// two kernels return the same bits -- restructured around what that kernel's counters showed (matrix pipe 46 % busy
+// on 128x128 tiles, 25-30 % on 128x64; waves parked at two barriers per 32-deep chunk; an LDS pipe loaded by 16
+// ds_write_b64 + 16 v_perm per thread and chunk):
+//
+//   * activations arrive in the pair8 format and weights in its k-blocked twin: a 16-byte piece of either IS an MFMA
+//     operand fragment, so staging is a pure copy, done by the LDS-DMA path (`buffer_load_dwordx4 ... lds`) -- no
+//     staging registers, no conversion, no ds_write.  The DMA is issued from inline asm and retired by COUNTED
+//     `s_waitcnt vmcnt(N)`: hipcc would wait vmcnt(0) for it at every barrier.
+//   * 256 x BN tile (BN = 128 / 64), 8 waves of 64 x BN/2, K walked in 32-channel chunks through a THREE-stage LDS
+//     ring: chunk k+2 is in flight while chunk k is multiplied, ONE barrier per chunk, 24 (12) MFMAs per wave between
+//     barriers but with two waves per SIMD covering each other's waits.
+//   * LDS rows are 128 bytes (8 pieces: hi/lo of four channel groups), the piece index XOR-swizzled with
+//     (row >> 1) & 7 ON THE SOURCE side of the DMA (the destination of a DMA is lane-linear): every 16-lane group of
+//     a ds_read_b128 fragment read covers all 16 slots of the bank row.
+//   * zero padding = out-of-range buffer offset (the DMA writes zeros, tools/probes/lds_dma_probe.hip).
+//   * accuracy: the accumulator of a tile is FLUSHED into a second one every `flush` chunks (pairwise-style
+//     summation: a K = 1152 product-sum is 216 sequential fp32 roundings at the full magnitude in one accumulator,
+//     18 at a twelfth of the variance plus 12 with flush = 3), which takes the error against fp64 from 0.9e-6 of the
+//     maximum to below torch-CPU's own.
+//   * epilogue: the accumulators are transposed through LDS (the stage ring is dead by then) so that a lane owns 8
+//     consecutive channels of one pixel: bias / ReLU, then 16-byte stores of fp32 or of {hi[8] | lo[8]} pair8 groups.
+//
+// Replaces (reference, torch.nn): nn.Conv2d / nn.ConvTranspose2d / nn.ReLU / torch.cat at
+// vqvae/encoder_decoder.py:95-112,138,199-215 and vqvae/vqvae.py:193-201,260,270-272,282.
+#include <cstdlib>
+
+#include "isi_common.h"
+#include "isi_internal.h"
+#include "prof.h"
+#include "split_f16.h"
+
+namespace isi {
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+using f16s::f16x8;
+
+constexpr int BM = 256;            // pixels per workgroup
+constexpr int NS = 3;              // LDS stages
+constexpr int ROWB = 128;          // bytes of one tile row per chunk: 32 channels x {hi, lo} f16
+constexpr unsigned OOB = 0x7FFFFFF0u;   // beyond every descriptor (tensors are below 1.75 GiB)
+constexpr unsigned OOB_STORE = 0xFFFFFFF0u;
+
+struct PairK {
+  const float *in0, *in1, *w, *bias;
+  float *out;
+  unsigned in0_bytes, in1_bytes, w_bytes, out_bytes;
+  int C0, C1;                      // channels per source (multiples of 32; C1 = 0: one source)
+  int s0n, s0h, s0w, s1n, s1h, s1w;
+  int on, oh, ow;                  // output strides in GEMM-grid pixels (channel stride 1)
+  int H, W, OH, OW, Cout, Kpad, KH, KW, stride, pad, relu, M;
+  int convT, w_phase_stride, dst_sh, dst_sw;
+  int flush;                       // chunks between accumulator flushes (0: never)
+};
+
+// one LDS-DMA: lane l's 16 bytes at rsrc.base + voff + soff land at lds_addr + 16 l; zeros when voff is out of range
+// (the range check looks at voff alone: tools/probes/lds_dma_probe.hip).  M0 carries the wave-uniform LDS address; it
+// is written here and never restored -- nothing else in this kernel uses M0 (no other m0 in the generated code).
+__device__ __forceinline__ void dma16(const unsigned lds_addr, const unsigned voff, const i32x4 rsrc, const unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// x / d for 0 <= x < 2^24, 1 <= d < 2^24
+__device__ __forceinline__ int udiv_small(const int x, const int d) {
+  int q = (int)((float)x * __builtin_amdgcn_rcpf((float)d));
+  int r = x - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) ++q;
+  return q;
+}
+
+__device__ __forceinline__ i32x4 make_rsrc(const void *ptr, const unsigned bytes) {
+  const unsigned long long b = (unsigned long long)ptr;
+  return i32x4{(int)(unsigned)b, (int)((unsigned)(b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+
+// phase timestamps of the instrumented variant (ISI_CONV_ABLATE=32; tools/ablate_conv.py reads them back)
+__device__ long long g_conv_pair_stamps[256];
+
+template <int BN, bool OUTP, int ABL = 0>   // ABL: measurements only (ISI_CONV_ABLATE): 1 no MFMAs, 2 no DMA in the loop
+__global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
+  constexpr int TM = 2;                       // 32-row tiles per wave (4 waves along M)
+  constexpr int TN = BN / 64;                 // 32-column tiles per wave (2 waves along N)
+  constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB, STAGE = A_STAGE + B_STAGE;
+  constexpr int NA = A_STAGE / 1024 / 8;      // A DMAs per wave and chunk (4)
+  constexpr int NB = B_STAGE / 1024 / 8;      // B DMAs per wave and chunk (2 / 1)
+  constexpr int PER = NA + NB;                // DMAs per wave and chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int *row_oo = reinterpret_cast<int *>(smem + NS * STAGE);   // [BM] output element offset or -1
+  int *row_n = row_oo + BM;                                    // [BM] batch index or -1
+  int *row_y = row_n + BM;                                     // [BM] top-left input y
+  int *row_x = row_y + BM;                                     // [BM] top-left input x
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- persistent over work items (phase, N tile, M tile): a workgroup's output stores drain while it already
+  // stages / multiplies its next tile (a non-persistent workgroup holds its CU until its stores have been
+  // acknowledged: with one workgroup per CU that exposed ~35 us of HBM write time per launch, tools/ablate_conv.py)
+  long long t_entry = 0;
+  if constexpr (ABL & 32) t_entry = __builtin_readcyclecounter();
+  const int mtiles = (p.M + BM - 1) / BM, ntiles_n = p.Cout / BN;
+  const int nitems = mtiles * ntiles_n * (p.convT ? 4 : 1);
+  for (int item_i = blockIdx.x; item_i < nitems; item_i += gridDim.x) {
+  // XCD-aware order: item_i's low bits (the XCD a workgroup runs on) select a contiguous range of items, so that
+  // consecutive M tiles (shared halo rows) meet in one XCD's L2
+  int item;
+  {
+    const int q = nitems / 8, r = nitems % 8, xcd = item_i % 8, idx = item_i / 8;
+    item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int phase = item / (mtiles * ntiles_n);
+  const int rem_i = item - phase * (mtiles * ntiles_n);
+  const int m0 = (rem_i % mtiles) * BM;
+  const int n0 = (rem_i / mtiles) * BN;
+  const int py = p.convT ? (phase >> 1) : 0;
+  const int px = p.convT ? (phase & 1) : 0;
+  const int pad_y = p.convT ? 1 - py : p.pad;
+  const int pad_x = p.convT ? 1 - px : p.pad;
+  const int w_off = p.convT ? phase * p.w_phase_stride : 0;
+  const int out_off = p.convT ? py * p.dst_sh + px * p.dst_sw : 0;
+
+  long long e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0, e7 = 0;
+  if constexpr (ABL & 32) e0 = __builtin_readcyclecounter();
+  __syncthreads();   // the previous item's epilogue has finished with the LDS (transpose buffers, row tables)
+  if constexpr (ABL & 32) e1 = __builtin_readcyclecounter();
+  if (tid < BM) {
+    const int m = m0 + tid;
+    int b = -1, oy = 0, ox = 0;
+    if (m < p.M) {
+      // m / (OH OW) and the remainder's / OW: reciprocal estimate + one correction step (exact: M < 2^24 here, the
+      // estimate is off by at most one); the two integer divisions were 40 % of a tile's 6 k-cycle set-up
+      b = udiv_small(m, p.OH * p.OW);
+      const int rem = m - b * (p.OH * p.OW);
+      oy = udiv_small(rem, p.OW);
+      ox = rem - oy * p.OW;
+    }
+    row_n[tid] = b;
+    row_y[tid] = oy * p.stride - pad_y;
+    row_x[tid] = ox * p.stride - pad_x;
+    row_oo[tid] = b < 0 ? -1 : out_off + b * p.on + oy * p.oh + ox * p.ow;
+  }
+  __syncthreads();
+
+  // Descriptors start `margin` bytes (the padding's worth) BEFORE each source: a lane's voffset is then the
+  // non-negative offset of its row's top-left tap incl. padding, constant over the K walk, and the chunk's tap /
+  // channel offset rides in the SGPR offset.  (readfirstlane: these are uniform, and must be SGPRs for the asm.)
+  const int upy = __builtin_amdgcn_readfirstlane(pad_y), upx = __builtin_amdgcn_readfirstlane(pad_x);
+  const unsigned margin0 = (unsigned)(upy * p.s0h + upx * p.s0w) * 4u;
+  const unsigned margin1 = (unsigned)(upy * p.s1h + upx * p.s1w) * 4u;
+  const i32x4 rs0 = make_rsrc(reinterpret_cast<const char *>(p.in0) - margin0, p.in0_bytes + margin0);
+  const i32x4 rs1 = make_rsrc(reinterpret_cast<const char *>(p.in1) - margin1, p.in1_bytes + margin1);
+  const i32x4 rsw = make_rsrc(p.w, p.w_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+  // ---- this lane's share of the staging: A DMA i of wave w covers tile rows (w NA + i) 8 .. + 8, lane l -> row
+  // + (l >> 3), LDS piece position l & 7, i.e. SOURCE piece (l & 7) ^ ((row >> 1) & 7).  Per DMA: the voffset into
+  // the current source (a_v; a_v1 holds the second source's until the walk reaches it) and a bit mask of the taps
+  // that fall inside the image (zero padding = out-of-range voffset).
+  unsigned a_v[NA], a_v1[NA], a_mask[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = (wave * NA + i) * 8 + (lane >> 3);
+    const int b = row_n[r];
+    const int y0 = row_y[r], x0 = row_x[r];
+    const unsigned piece = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    a_v[i] = (unsigned)(b * p.s0n + (y0 + upy) * p.s0h + (x0 + upx) * p.s0w) * 4u + piece;
+    a_v1[i] = (unsigned)(b * p.s1n + (y0 + upy) * p.s1h + (x0 + upx) * p.s1w) * 4u + piece;
+    // taps inside the image: kh in [max(0, -y0), min(KH, H - y0)), kw likewise; bit kh KW + kw (KH, KW <= 4)
+    const int kw_lo = max(0, -x0), kw_hi = min(p.KW, p.W - x0);
+    const unsigned colbits = kw_hi > kw_lo ? ((1u << (kw_hi - kw_lo)) - 1u) << kw_lo : 0u;
+    const int kh_lo = max(0, -y0), kh_hi = min(p.KH, p.H - y0);
+    unsigned mask = 0;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh)
+      if (kh >= kh_lo && kh < kh_hi) mask |= colbits << (kh * p.KW);
+    a_mask[i] = b >= 0 ? mask : 0u;
+  }
+  unsigned b_off[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave * NB + j) * 8 + (lane >> 3);
+    b_off[j] = (unsigned)(w_off + (n0 + n) * p.Kpad) * 4u + (unsigned)(((lane & 7) ^ ((n >> 1) & 7)) * 16);
+  }
+
+  // K walk, slice-major (for each 32-channel slice all KH x KW taps back to back: the shifted re-reads of a slice are
+  // adjacent in time on every workgroup of the XCD and hit its L2): state of the NEXT chunk to issue, all uniform
+  const int Cin = p.C0 + p.C1;
+  const int nk = p.KH * p.KW * (Cin / 32);
+  int is_c = 0, is_kh = 0, is_kw = 0;            // channel offset (over both sources), tap
+  i32x4 rs_cur = rs0;                            // source the walk is in
+  int sh_cur = p.s0h, sw_cur = p.s0w, c_sub = 0;
+
+  // piece Q (0 .. PER - 1) of the next chunk -> `stage`; the last piece also advances the walk
+#define ISI_ISSUE_PIECE(stage_, Q)                                                                                      \
+  do {                                                                                                                  \
+    if ((Q) < NA) {                                                                                                     \
+      const unsigned soff_ = (unsigned)(is_kh * sh_cur + is_kw * sw_cur + (is_c - c_sub)) * 4u;                          \
+      const unsigned tapbit_ = 1u << (is_kh * p.KW + is_kw);                                                             \
+      const unsigned v_ = (a_mask[(Q) < NA ? (Q) : 0] & tapbit_) ? a_v[(Q) < NA ? (Q) : 0] : OOB;                         \
+      dma16(lds0 + (unsigned)((stage_) * STAGE + (wave * NA + (Q)) * 1024), v_, rs_cur, soff_);                          \
+    } else {                                                                                                            \
+      const unsigned koff_ = (unsigned)((is_kh * p.KW + is_kw) * Cin + is_c) * 4u;                                        \
+      dma16(lds0 + (unsigned)((stage_) * STAGE + A_STAGE + (wave * NB + ((Q) - NA)) * 1024),                             \
+            b_off[(Q) >= NA ? (Q) - NA : 0], rsw, koff_);                                                                \
+    }                                                                                                                   \
+    if ((Q) == PER - 1) {                                                                                               \
+      if (++is_kw == p.KW) {                                                                                            \
+        is_kw = 0;                                                                                                      \
+        if (++is_kh == p.KH) {                                                                                          \
+          is_kh = 0;                                                                                                    \
+          is_c += 32;                                                                                                   \
+          if (is_c == p.C0 && p.C1 > 0) {   /* the walk enters the second source */                                     \
+            _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) a_v[i_] = a_v1[i_];                                        \
+            rs_cur = rs1; sh_cur = p.s1h; sw_cur = p.s1w; c_sub = p.C0;                                                  \
+          }                                                                                                             \
+        }                                                                                                               \
+      }                                                                                                                 \
+    }                                                                                                                   \
+  } while (0)
+#define ISI_ISSUE_CHUNK(stage_)                                                                                         \
+  do {                                                                                                                  \
+    ISI_ISSUE_PIECE(stage_, 0); ISI_ISSUE_PIECE(stage_, 1); ISI_ISSUE_PIECE(stage_, 2); ISI_ISSUE_PIECE(stage_, 3);     \
+    ISI_ISSUE_PIECE(stage_, 4);                                                                                         \
+    if (PER > 5) ISI_ISSUE_PIECE(stage_, 5);                                                                            \
+  } while (0)
+
+  // ---- fragment addresses: tile row r = base + (lane & 31), k-block kb = lane >> 5; piece (4 s + 2 kb + pl) of the
+  // row sits at slot (piece ^ ((r >> 1) & 7)); base is a multiple of 32, so the swizzle depends on the lane only
+  const int frow = lane & 31, kb = lane >> 5;
+  const int xs = (2 * kb) ^ ((frow >> 1) & 7);
+  unsigned fa[2][2], fb[2][2];                   // [k-step][plane] byte offsets inside a stage
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      fa[s][pl] = (unsigned)((wm * 64 + frow) * ROWB + ((xs ^ (4 * s + pl)) << 4));
+      fb[s][pl] = (unsigned)(A_STAGE + (wn * (BN / 2) + frow) * ROWB + ((xs ^ (4 * s + pl)) << 4));
+    }
+
+  f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+  bool fresh = true;   // uniform: the next MFMA of every accumulator starts a new partial sum (C operand = 0)
+
+  // this lane's eight output channels in the epilogue (lane -> 8-channel group g of the wave's columns); the bias
+  // values are fetched now so that their latency is not exposed after the K loop
+  constexpr int WCOLS = TN * 32;                 // columns of this wave's sub-tile
+  constexpr int G = WCOLS / 8;                   // 8-channel groups per row
+  const int g = lane % G, rsub = lane / G;
+  const int ncol = n0 + wn * WCOLS + g * 8;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = p.bias ? p.bias[ncol + e] : 0.f;
+  if constexpr (ABL & 32) e2 = __builtin_readcyclecounter();
+  // ---- prologue: two chunks in flight; chunk 0 landed (every wave waits for its own pieces, then the barrier)
+  ISI_ISSUE_CHUNK(0);
+  if (nk > 1) {
+    ISI_ISSUE_CHUNK(1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // ---- main loop.  A chunk is handled in two barrier-separated phases per wave:
+  //   memory phase  fragments of chunk kc: LDS -> registers (16 ds_read_b128); DMAs of chunk kc + 2 issued; waits
+  //   matrix phase  the chunk's 24 (12) MFMAs out of registers, nothing else
+  // and the two waves of a SIMD (waves w and w + 4 of the workgroup) run HALF AN ITERATION APART: waves 4-7 pass one
+  // extra barrier first, so that while one wave of a SIMD occupies the matrix pipe the other one issues its DMAs (which
+  // queue behind the CU's 64 B/clk address path: 16 clocks per 1-KiB piece, 48 pieces per chunk) and fragment reads.
+  // In lockstep -- every wave issuing DMAs at the same time, then every wave multiplying -- the three cost terms
+  // added up (tools/ablate_conv.py: 102 us skeleton + 54 us DMA + 106 us matrix = the measured 265 us).
+  // Hand-off rules (T = barrier interval; group A = waves 0-3, group B = waves 4-7 one interval later):
+  //   * a wave ends its memory phase with lgkmcnt(0) (its reads of the stage are done: the stage may be overwritten
+  //     two intervals later) and vmcnt(PER) (everything but the pieces it has just issued has landed);
+  //   * chunk c's pieces are issued during the memory phases of chunk c - 2 and are complete one memory phase
+  //     later on both groups, i.e. before the barrier in front of the first memory phase that reads them.
+  if constexpr (ABL & 32) e3 = __builtin_readcyclecounter();
+  const bool group_b = wave >= 4;                 // uniform per wave
+  if (group_b) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+  int since_flush = 0;
+  for (int kc = 0; kc < ((ABL & 4) ? 1 : nk); ++kc) {
+    const int stage = kc % NS;
+    const bool more = kc + 2 < nk;               // uniform
+    const int nstage = (kc + 2) % NS;
+    // ---------------- memory phase
+    const bool stamp = (ABL & 32) && blockIdx.x == 8 && (wave & 3) == 0 && kc >= 8 && kc < 16 && lane == 0;
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    if constexpr (ABL & 32) t0 = __builtin_readcyclecounter();
+    const char *st = smem + stage * STAGE;
+    s16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[s_][i] = *reinterpret_cast<const s16x8 *>(st + fa[s_][0] + i * 32 * ROWB);
+        al[s_][i] = *reinterpret_cast<const s16x8 *>(st + fa[s_][1] + i * 32 * ROWB);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[s_][j] = *reinterpret_cast<const s16x8 *>(st + fb[s_][0] + j * 32 * ROWB);
+        bl[s_][j] = *reinterpret_cast<const s16x8 *>(st + fb[s_][1] + j * 32 * ROWB);
+      }
+    }
+    if constexpr (ABL & 32) t1 = __builtin_readcyclecounter();
+    if (more && !(ABL & 2)) ISI_ISSUE_CHUNK(nstage);
+    if constexpr (ABL & 32) t2 = __builtin_readcyclecounter();
+    // the fragments are in registers (nobody reads this stage on this wave's behalf any more), and all but the newest
+    // pieces of this wave have landed
+    if constexpr (ABL & 16) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (measurement: DMA never waited for)
+    else if (more && !(ABL & 2)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ABL & 32) t3 = __builtin_readcyclecounter();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if constexpr (ABL & 32) t4 = __builtin_readcyclecounter();
+    // ---------------- matrix phase: lo terms first, the dominant hi.hi last (order of conv_igemm_f32.hip)
+    // The partner wave on this SIMD is in its memory phase: its address arithmetic, DMA and LDS issues would take
+    // issue slots between this wave's MFMAs -- the matrix pipe's owner gets priority for the phase.
+    __builtin_amdgcn_s_setprio(2);
+    // first term of k-step 0: starts a new partial sum after a flush (zero C operand: no register clearing)
+    if (fresh) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if constexpr (!(ABL & 1))
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[0][i]),
+                                                               __builtin_bit_cast(f16x8, bh[0][j]), zero, 0, 0, 0);
+        }
+      fresh = false;
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          if constexpr (!(ABL & 1))
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[0][i]),
+                                                               __builtin_bit_cast(f16x8, bh[0][j]), acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int t = (s_ == 0 ? 1 : 0); t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const s16x8 av = t == 0 ? al[s_][i] : ah[s_][i];
+            const s16x8 bv = t == 1 ? bl[s_][j] : bh[s_][j];
+            if constexpr (!(ABL & 1))
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv),
+                                                                 acc[i][j], 0, 0, 0);
+            else asm volatile("" ::"v"(av), "v"(bv));   // keep the fragment reads alive
+          }
+    __builtin_amdgcn_s_setprio(0);
+    if (p.flush && ++since_flush == p.flush) {
+      since_flush = 0;
+      fresh = true;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[i][j][r] += acc[i][j][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ABL & 32) {
+      asm volatile("s_nop 0" ::"v"(acc[0][0][0]), "v"(acc[1][TN - 1][15]));   // the stamp below follows the last MFMA's result
+      t5 = __builtin_readcyclecounter();
+    }
+    if (!(group_b && kc == ((ABL & 4) ? 1 : nk) - 1)) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    if constexpr (ABL & 32) {
+      if (stamp) {
+        long long *d = g_conv_pair_stamps + ((wave >> 2) * 8 + (kc - 8)) * 8;
+        d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = t4; d[5] = t5; d[6] = __builtin_readcyclecounter();
+      }
+    }
+  }
+
+  // ---- epilogue.  Stage ring -> per-wave transpose buffers [64 rows][LDT] fp32 (all waves are done reading).
+  if constexpr (ABL & 32) e4 = __builtin_readcyclecounter();
+  __syncthreads();
+  if constexpr (ABL & 32) e5 = __builtin_readcyclecounter();
+  constexpr int LDT = WCOLS + 4;                 // padded row (floats)
+  float *tb = reinterpret_cast<float *>(smem) + wave * 64 * LDT;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        tb[row * LDT + j * 32 + frow] = (fresh ? tot[i][j][r] : tot[i][j][r] + acc[i][j][r]) * f16s::kUnscale;
+      }
+  if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); e6 = __builtin_readcyclecounter(); }
+  // lane -> (row, 8-channel group): G groups per row, 64 / G rows per pass, G passes
+  constexpr int RPP = 64 / G;
+  const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+#pragma unroll
+  for (int it = 0; it < G; ++it) {
+    const int row = it * RPP + rsub;
+    const float4 v0 = *reinterpret_cast<const float4 *>(tb + row * LDT + g * 8);
+    const float4 v1 = *reinterpret_cast<const float4 *>(tb + row * LDT + g * 8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = v[e] + bias[e];
+      // NaN-propagating rectifier: an operand beyond the f16 range (or an fp32 overflow) stays loud (torch.relu)
+      if (p.relu) t = t < 0.f ? 0.f : t;   // NaN < 0 is false: a NaN stays (torch.relu)
+      v[e] = t;
+    }
+    const int o = row_oo[wm * 64 + row];
+    const unsigned off = o >= 0 ? (unsigned)(o + ncol) * 4u : OOB_STORE;
+    uint4 w0, w1;
+    if constexpr (OUTP) {
+      f16s::pair8_encode(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), w0, w1);
+    } else {
+      w0 = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                      __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+      w1 = make_uint4(__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]),
+                      __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7]));
+    }
+    if constexpr (ABL & 8) { asm volatile("" ::"v"(w0.x ^ w0.y ^ w0.z ^ w0.w ^ w1.x ^ w1.y ^ w1.z ^ w1.w), "v"(off)); continue; }
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_STORE ? OOB_STORE : off + 16u, 0, 0);
+  }
+  if constexpr (ABL & 32) {
+    e7 = __builtin_readcyclecounter();
+    if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && item_i == (int)blockIdx.x + (int)gridDim.x) {
+      long long *d = g_conv_pair_stamps + 130 + (wave >> 2) * 10;
+      d[0] = e0; d[1] = e1; d[2] = e2; d[3] = e3; d[4] = e4; d[5] = e5; d[6] = e6; d[7] = e7;
+    }
+  }
+  }   // work items
+  if constexpr (ABL & 32) {
+    if (blockIdx.x == 8 && tid == 0) {
+      g_conv_pair_stamps[126] = t_entry;
+      g_conv_pair_stamps[127] = __builtin_readcyclecounter();
+    }
+  }
+#undef ISI_ISSUE_CHUNK
+#undef ISI_ISSUE_PIECE
+}
+
+template <int BN>
+constexpr size_t pair_smem_bytes() {
+  return (size_t)NS * (BM + BN) * ROWB + 4 * BM * sizeof(int);
+}
+
+template <int BN, bool OUTP, int ABL = 0>
+int launch_pair(const PairK &a, int nphase, double flops, double bytes, hipStream_t stream) {
+  auto kern = conv_pair_kernel<BN, OUTP, ABL>;
+  constexpr size_t smem = pair_smem_bytes<BN>();
+  static_assert(8 * 64 * (BN / 2 + 4) * sizeof(float) <= (size_t)NS * (BM + BN) * ROWB, "transpose buffers fit in the ring");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(conv_pair)");
+    attr_set = true;
+  }
+  const int nitems = ((a.M + BM - 1) / BM) * (a.Cout / BN) * nphase;
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
+  dim3 grid(nitems < n_cu ? nitems : n_cu);   // one 144-KiB workgroup per CU, persistent over the items
+  prof::Scope scope(prof::K_CONV_F16X3, flops, bytes, stream);
+  ISI_PROF_LAUNCH(scope, kern, grid, dim3(512), smem, stream, a);
+  return check_launch("conv_pair_f16");
+}
+
+}  // namespace
+
+int conv_pair_debug_stamps(long long *host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_pair_stamps), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -2;
+}
+
+// Shapes the DMA kernel takes: pair8 sources of 32-channel multiples (both, when there are two), whole 64-column
+// output tiles, channels-last output.  (conv_igemm_f32.hip runs everything else, including fp32 sources.)
+bool conv_pair_kernel_ok(int C0, int C1, int Cout, int taps) {
+  const bool off = getenv("ISI_NO_CONV_PAIR_KERNEL") != nullptr;    // read per call: measurements, A/B tests
+  return !off && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && Cout % 64 == 0 && taps >= 1 && taps <= 16;   // 16-bit tap masks
+}
+
+int conv_pair_f16(const PairConvArgs &c, hipStream_t stream) {
+  // voffsets stay below the out-of-range marker 0x7FFFFFF0 with room for the SGPR offset
+  if (c.in0_bytes >= 0x70000000u || (c.in1 && c.in1_bytes >= 0x70000000u))
+    return unsupported("conv_pair: a pair-format source spans 1.75 GiB or more");
+  PairK a;
+  memset(&a, 0, sizeof a);
+  a.in0 = c.in0; a.in1 = c.in1 ? c.in1 : c.in0; a.w = c.w16; a.bias = c.bias; a.out = c.out;
+  a.in0_bytes = c.in0_bytes; a.in1_bytes = c.in1 ? c.in1_bytes : c.in0_bytes; a.w_bytes = c.w_bytes; a.out_bytes = c.out_bytes;
+  a.C0 = c.C0; a.C1 = c.C1;
+  a.s0n = c.s0n; a.s0h = c.s0h; a.s0w = c.s0w; a.s1n = c.s1n; a.s1h = c.s1h; a.s1w = c.s1w;
+  a.on = c.on; a.oh = c.oh; a.ow = c.ow;
+  a.H = c.H; a.W = c.W; a.OH = c.OH; a.OW = c.OW; a.Cout = c.Cout; a.Kpad = c.Kpad; a.KH = c.KH; a.KW = c.KW;
+  a.stride = c.stride; a.pad = c.pad; a.relu = c.relu; a.M = c.M;
+  a.convT = c.convT; a.w_phase_stride = c.w_phase_stride; a.dst_sh = c.dst_sh; a.dst_sw = c.dst_sw;
+  // accumulator flush period: every 3 chunks (one kernel row of a 3x3 / three taps) unless overridden; 0 = never
+  // (read per call: the tests compare flush = 0 -- the bits of conv_igemm_f32.hip -- with the default)
+  const char *fe = getenv("ISI_CONV_FLUSH");
+  a.flush = fe ? atoi(fe) : 3;
+  if (a.flush < 0) a.flush = 0;
+  const char *ab = getenv("ISI_CONV_ABLATE");    // measurements (tools/ablate_conv.py): wrong results by design
+  const int abl = ab ? atoi(ab) : 0;
+  const int nphase = c.convT ? 4 : 1;
+  const double K = (double)c.KH * c.KW * (c.C0 + c.C1);
+  const double flops = 2.0 * c.M * nphase * c.Cout * K;
+  const double in_px = nphase == 1 ? (double)c.M / (c.OH * c.OW) * c.H * c.W : (double)c.M;
+  const double bytes = 4.0 * (in_px * (c.C0 + c.C1) + (double)c.M * nphase * c.Cout + nphase * c.Cout * K);
+  const bool wide = c.Cout % 128 == 0;
+  if (abl == 1) return wide ? launch_pair<128, true, 1>(a, nphase, flops, bytes, stream) : launch_pair<64, true, 1>(a, nphase, flops, bytes, stream);
+  if (abl == 2) return wide ? launch_pair<128, true, 2>(a, nphase, flops, bytes, stream) : launch_pair<64, true, 2>(a, nphase, flops, bytes, stream);
+  if (abl == 3) return wide ? launch_pair<128, true, 3>(a, nphase, flops, bytes, stream) : launch_pair<64, true, 3>(a, nphase, flops, bytes, stream);
+  if (abl == 7) return launch_pair<128, true, 7>(a, nphase, flops, bytes, stream);     // + no main loop
+  if (abl == 15) return launch_pair<128, true, 15>(a, nphase, flops, bytes, stream);   // + no output stores
+  if (abl == 11) return launch_pair<128, true, 11>(a, nphase, flops, bytes, stream);   // skeleton loop, no output stores
+  if (abl == 32) return launch_pair<128, true, 32>(a, nphase, flops, bytes, stream);   // phase timestamps
+  if (abl == 16) return launch_pair<128, true, 16>(a, nphase, flops, bytes, stream);   // DMA issued, never waited for
+  if (abl == 17) return launch_pair<128, true, 17>(a, nphase, flops, bytes, stream);   // same, no MFMAs
+  if (abl == 8) return launch_pair<128, true, 8>(a, nphase, flops, bytes, stream);     // everything but the output stores
+  if (c.out_pair) return wide ? launch_pair<128, true>(a, nphase, flops, bytes, stream)
+                              : launch_pair<64, true>(a, nphase, flops, bytes, stream);
+  return wide ? launch_pair<128, false>(a, nphase, flops, bytes, stream)
+              : launch_pair<64, false>(a, nphase, flops, bytes, stream);
+}
+
+}  // namespace isi

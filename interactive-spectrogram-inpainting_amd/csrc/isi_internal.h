@@ -14,6 +14,21 @@ bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *
 int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, const isi_dst *dst, int B, int H,
                    int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream);
 bool conv_pair_sources_ok(int C0, int C1, int Cout, int taps);
+// conv_pair_f16.hip: the LDS-DMA implicit-GEMM kernel of the pair pipeline (pair8 sources, blocked W16 weights)
+struct PairConvArgs {
+  const float *in0, *in1, *w16, *bias;
+  float *out;
+  unsigned in0_bytes, in1_bytes, w_bytes, out_bytes;
+  int C0, C1;
+  int s0n, s0h, s0w, s1n, s1h, s1w;    // source element strides (channel stride 1)
+  int on, oh, ow;                      // output strides in GEMM-grid pixels (channel stride 1)
+  int H, W, OH, OW, Cout, Kpad, KH, KW, stride, pad, relu, M;
+  int convT, w_phase_stride, dst_sh, dst_sw;
+  int out_pair;
+};
+bool conv_pair_kernel_ok(int C0, int C1, int Cout, int taps);
+int conv_pair_f16(const PairConvArgs &c, hipStream_t stream);
+int conv_pair_debug_stamps(long long *host, int n);
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                int KW, int stride, int pad, int relu, hipStream_t stream);

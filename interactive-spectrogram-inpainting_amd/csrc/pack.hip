@@ -59,48 +59,64 @@ __global__ void pack_codebook_kernel(const float *__restrict__ embed, float *__r
   e2[k] = s;
 }
 
-// fp32 packed weight -> split-f16 pair format of ISI_CONV_W16: every quad of four consecutive floats becomes
-// 16 bytes {hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3}, the f16 pieces of 1024 w exactly as the kernels of ISI_CONV_F16X3
-// compute them while staging (conv_igemm_f32.hip: split_f16x4) -- a staged quad is then one 16-byte load and two
-// 8-byte LDS stores, no conversion
-__global__ void split_weight_f16_kernel(const float4 *__restrict__ in, uint4 *__restrict__ out, int64_t nq) {
+// fp32 packed weight -> split-f16 pair format of ISI_CONV_W16: every group of eight consecutive floats becomes 32 bytes
+// {hi0 .. hi7 | lo0 .. lo7}, the f16 pieces of 1024 w exactly as the kernels of ISI_CONV_F16X3 compute them while
+// staging (split_f16.h) -- a 16-byte piece is an MFMA operand fragment: staging is a plain copy
+__global__ void split_weight_f16_kernel(const float4 *__restrict__ in, uint4 *__restrict__ out, int64_t ng) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < nq) out[i] = f16s::weight_encode(in[i]);
+  if (i < ng) {
+    uint4 hi, lo;
+    f16s::weight8_encode(in[2 * i], in[2 * i + 1], hi, lo);
+    out[2 * i] = hi;
+    out[2 * i + 1] = lo;
+  }
 }
 
 int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream) {
-  if (!packed || !out || n_floats <= 0 || (n_floats & 3)) return invalid("split_conv_weight_f16: bad argument");
+  if (!packed || !out || n_floats <= 0 || (n_floats & 7)) return invalid("split_conv_weight_f16: bad argument");
   if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15)
     return invalid("split_conv_weight_f16: pointers must be 16-byte aligned");
-  const int64_t nq = n_floats / 4;
-  hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream,
-                     reinterpret_cast<const float4 *>(packed), reinterpret_cast<uint4 *>(out), nq);
+  const int64_t ng = n_floats / 8;
+  hipLaunchKernelGGL(split_weight_f16_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream,
+                     reinterpret_cast<const float4 *>(packed), reinterpret_cast<uint4 *>(out), ng);
   return check_launch("split_conv_weight_f16");
 }
 
-// fp32 <-> activation pair format (ISI_CONV_OUT_PAIR / IN*_PAIR): hi = f16(4 x) | lo = f16(4 x - hi) << 16
-__global__ void pair_encode_kernel(const float *__restrict__ x, unsigned *__restrict__ out, int64_t n) {
+// fp32 <-> activation pair format (ISI_CONV_OUT_PAIR / IN*_PAIR, split_f16.h): groups of 8 consecutive elements
+__global__ void pair_encode_kernel(const float4 *__restrict__ x, uint4 *__restrict__ out, int64_t ng) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = f16s::pair_encode(x[i]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ng; i += stride) {
+    uint4 hi, lo;
+    f16s::pair8_encode(x[2 * i], x[2 * i + 1], hi, lo);
+    out[2 * i] = hi;
+    out[2 * i + 1] = lo;
+  }
 }
-__global__ void pair_decode_kernel(const unsigned *__restrict__ in, float *__restrict__ x, int64_t n) {
+__global__ void pair_decode_kernel(const uint4 *__restrict__ in, float4 *__restrict__ x, int64_t ng) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = f16s::pair_decode(in[i]);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ng; i += stride) {
+    float4 a, b;
+    f16s::pair8_decode(in[2 * i], in[2 * i + 1], a, b);
+    x[2 * i] = a;
+    x[2 * i + 1] = b;
+  }
 }
 int pair_encode_f32(const float *x, float *out, int64_t n, hipStream_t stream) {
-  if (!x || !out || n < 0) return invalid("pair_encode: bad argument");
+  if (!x || !out || n < 0 || (n & 7)) return invalid("pair_encode: need a multiple of 8 elements");
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) return invalid("pair_encode: pointers must be 16-byte aligned");
   if (n == 0) return ISI_OK;
-  const int64_t blocks = (n + 255) / 256;
-  hipLaunchKernelGGL(pair_encode_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, x,
-                     reinterpret_cast<unsigned *>(out), n);
+  const int64_t ng = n / 8, blocks = (ng + 255) / 256;
+  hipLaunchKernelGGL(pair_encode_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
+                     reinterpret_cast<const float4 *>(x), reinterpret_cast<uint4 *>(out), ng);
   return check_launch("pair_encode_f32");
 }
 int pair_decode_f32(const float *in, float *x, int64_t n, hipStream_t stream) {
-  if (!x || !in || n < 0) return invalid("pair_decode: bad argument");
+  if (!x || !in || n < 0 || (n & 7)) return invalid("pair_decode: need a multiple of 8 elements");
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(in)) & 15) return invalid("pair_decode: pointers must be 16-byte aligned");
   if (n == 0) return ISI_OK;
-  const int64_t blocks = (n + 255) / 256;
+  const int64_t ng = n / 8, blocks = (ng + 255) / 256;
   hipLaunchKernelGGL(pair_decode_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
-                     reinterpret_cast<const unsigned *>(in), x, n);
+                     reinterpret_cast<const uint4 *>(in), reinterpret_cast<float4 *>(x), ng);
   return check_launch("pair_decode_f32");
 }
 

@@ -86,9 +86,6 @@ __device__ __forceinline__ void split3_bf16x4(const float4 v, uint2 &hi, uint2 &
 }
 // split-f16 pieces, pack-time weight pieces and activation pairs: split_f16.h
 using f16s::f16x8;
-using f16s::pair_decode;
-using f16s::pair_encode;
-using f16s::pair_quad;
 constexpr float kF16ScaleA = f16s::kScaleA, kF16ScaleB = f16s::kScaleB, kF16Unscale = f16s::kUnscale;
 __device__ __forceinline__ void split_f16x4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 template <int PREC>
@@ -97,14 +94,10 @@ __device__ __forceinline__ void split_x4(const float4 v, const float s16, uint2 
   else if constexpr (PREC >= 3) split_f16x4(v, s16, hi, lo);
   else split_bf16x4(v, hi, lo);
 }
-// weights: PREC 4 = already split-f16 pairs in memory (ISI_CONV_W16)
+// weights (PREC < 4: split while staged; PREC 4 = blocked pair pieces in memory, ISI_CONV_W16: stored as they are)
 template <int PREC>
 __device__ __forceinline__ void split_w4(const float4 v, uint2 &hi, uint2 &mid, uint2 &lo) {
-  if constexpr (PREC == 4) {
-    f16s::weight_quad(v, hi, lo);
-  } else {
-    split_x4<PREC>(v, kF16ScaleB, hi, mid, lo);
-  }
+  split_x4<PREC>(v, kF16ScaleB, hi, mid, lo);
 }
 #define ISI_MH(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0)
 #define ISI_MF(a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0)
@@ -182,8 +175,12 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (j < NA - 1 || i < HPIX * 8) {
         if constexpr (BF) {
           uint2 hi, mid, lo;
-          if (PREC == 4 && p.in_pair) pair_quad(ra[j], hi, lo);
-          else split_x4<PREC>(ra[j], kF16ScaleA, hi, mid, lo);
+          if (PREC == 4 && p.in_pair) {
+            // pair8 source: piece lq of the pixel's 128-byte slice = plane (lq & 1) of channel group (lq >> 1)
+            *reinterpret_cast<float4 *>(Apl + (lq & 1) * APS + (i >> 3) * LDB + bf_slot(i >> 3, lq >> 1)) = ra[j];
+            continue;
+          }
+          split_x4<PREC>(ra[j], kF16ScaleA, hi, mid, lo);
           const int wo = (i >> 3) * LDB + bf_slot(i >> 3, lq >> 1) + (lq & 1) * 4;
           *reinterpret_cast<uint2 *>(Apl + wo) = hi;
           *reinterpret_cast<uint2 *>(Apl + APS + wo) = lo;
@@ -197,7 +194,9 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
     for (int k = 0; k < NWT; ++k) {
       const int t = TH == 2 ? k : 2 * k + lt;
       if (t >= 9) continue;
-      if constexpr (BF) {
+      if constexpr (PREC == 4) {
+        *reinterpret_cast<float4 *>(Wpl + (lq & 1) * WPS + (t * 32 + lr) * LDB + bf_slot(t * 32 + lr, lq >> 1)) = rw[k];
+      } else if constexpr (BF) {
         uint2 hi, mid, lo;
         split_w4<PREC>(rw[k], hi, mid, lo);
         const int wo = (t * 32 + lr) * LDB + bf_slot(t * 32 + lr, lq >> 1) + (lq & 1) * 4;
@@ -279,6 +278,10 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       if (n >= C) continue;
       uint2 hi, mid, lo;
       const float4 wv = buf_load4(rs2, (unsigned)(n * 32 + lq * 4) * 4u);
+      if constexpr (PREC == 4) {
+        *reinterpret_cast<float4 *>(Wpl + (lq & 1) * WPS + n * LDB + bf_slot(n, lq >> 1)) = wv;
+        continue;
+      }
       split_w4<PREC>(wv, hi, mid, lo);
       const int wo = n * LDB + bf_slot(n, lq >> 1) + (lq & 1) * 4;
       *reinterpret_cast<uint2 *>(Wpl + wo) = hi;
@@ -378,18 +381,25 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
     const int gx = x0 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
     eoff[r] = (gy < p.H && gx < p.W) ? (unsigned)((rowbase + gx) * C + frow) * 4u : OOB;
   }
+  // pair8 tensors: channel n of a pixel has its hi piece at byte (n / 8) 32 + (n % 8) 2 and its lo piece 16 bytes on
+  const unsigned pair_ch = (unsigned)((frow >> 3) * 32 + (frow & 7) * 2);
 #pragma unroll
   for (int j = 0; j < TC; ++j) {
     const float b2 = p.b2[j * 32 + frow];
     float res[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                             rsi, eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0));
-    // pair decoding / encoding behind uniform BRANCHES (not selects: ~6 + 8 VALU instructions per element)
     if (PREC == 4 && p.in_pair) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) res[r] = pair_decode(__builtin_bit_cast(unsigned, res[r]));
+      for (int r = 0; r < 16; ++r) {
+        const unsigned o = eoff[r] == OOB ? OOB : eoff[r] - (unsigned)frow * 4u + (unsigned)j * 128u + pair_ch;
+        const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(rsi, o, 0, 0);
+        const unsigned short l = __builtin_amdgcn_raw_buffer_load_b16(rsi, o == OOB ? OOB : o + 16u, 0, 0);
+        res[r] = f16s::pair_value(h, l);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                               rsi, eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0));
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -398,10 +408,16 @@ __global__ __launch_bounds__(TH * 128) void resblock_f32_kernel(const ResKArgs p
       res[r] = v;
     }
     if (PREC == 4 && p.out_pair) {
+      // a lane of this layout owns one channel of 16 pixels: the pair8 pieces go out as 2-byte stores
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32((int)pair_encode(res[r]), rso,
-                                              eoff[r] == OOB ? OOB : eoff[r] + (unsigned)j * 128u, 0, 0);
+      for (int r = 0; r < 16; ++r) {
+        const float t = res[r] * kF16ScaleA;
+        const _Float16 h = (_Float16)t;
+        const _Float16 l = (_Float16)(t - (float)h);
+        const unsigned o = eoff[r] == OOB ? OOB : eoff[r] - (unsigned)frow * 4u + (unsigned)j * 128u + pair_ch;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, h), rso, o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, l), rso, o == OOB ? OOB : o + 16u, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r)

@@ -12,8 +12,12 @@
 // floor 7e-9), weights and code vectors by 2^10 (|w| < 64, floor 3e-11); accumulators are rescaled by 2^-12 in the
 // epilogue (all exact).
 //
-// Activation PAIR format: an element's 4 bytes = hi (low half) | lo << 16 of 4 x.  Weight pair format: a quad of
-// floats becomes {hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3} of 1024 w in the same 16 bytes.
+// Activation PAIR format ("pair8"): every aligned group of 8 consecutive channels (32 bytes, the footprint of 8 floats)
+// holds {hi0 .. hi7 | lo0 .. lo7}: sixteen bytes of f16 hi pieces followed by sixteen bytes of f16 lo pieces of 4 x.
+// A 16-byte piece IS an MFMA operand fragment (8 consecutive k of one plane), so a consumer stages a tile with plain
+// 16-byte copies -- `buffer_load ... lds` straight into LDS in conv_pair_f16.hip -- and no conversion or permute.
+// Weight pair format: the same blocking over k ({hi0 .. hi7 | lo0 .. lo7} of 1024 w per group of 8 floats).
+// Tensors in these formats have channel / k counts that are multiples of 8.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -35,33 +39,35 @@ __device__ __forceinline__ void split4(const float4 v, const float s, uint2 &hi,
   hi = make_uint2(__builtin_bit_cast(unsigned, ha), __builtin_bit_cast(unsigned, hb));
   lo = make_uint2(__builtin_bit_cast(unsigned, la), __builtin_bit_cast(unsigned, lb));
 }
-// weight pair quad {hi0..3 | lo0..3} -> pieces (no arithmetic)
-__device__ __forceinline__ void weight_quad(const float4 v, uint2 &hi, uint2 &lo) {
-  const uint4 u = __builtin_bit_cast(uint4, v);
-  hi = make_uint2(u.x, u.y);
-  lo = make_uint2(u.z, u.w);
+// ---- pair8 groups: 8 floats <-> {hi[8] | lo[8]}
+__device__ __forceinline__ void group8_encode(const float4 a, const float4 b, const float s, uint4 &hi, uint4 &lo) {
+  uint2 h0, l0, h1, l1;
+  split4(a, s, h0, l0);
+  split4(b, s, h1, l1);
+  hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
 }
-__device__ __forceinline__ uint4 weight_encode(const float4 v) {
-  uint2 hi, lo;
-  split4(v, kScaleB, hi, lo);
-  return make_uint4(hi.x, hi.y, lo.x, lo.y);
+__device__ __forceinline__ void pair8_encode(const float4 a, const float4 b, uint4 &hi, uint4 &lo) {
+  group8_encode(a, b, kScaleA, hi, lo);
 }
-// activation pairs
-__device__ __forceinline__ unsigned pair_encode(const float v) {
-  const float t = v * kScaleA;
-  const _Float16 h = (_Float16)t;
-  const _Float16 l = (_Float16)(t - (float)h);
-  return (unsigned)__builtin_bit_cast(unsigned short, h) | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+__device__ __forceinline__ void weight8_encode(const float4 a, const float4 b, uint4 &hi, uint4 &lo) {
+  group8_encode(a, b, kScaleB, hi, lo);
 }
-__device__ __forceinline__ float pair_decode(const unsigned u) {
-  return ((float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)) +
-          (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16))) * (1.f / kScaleA);
+__device__ __forceinline__ float pair_value(const unsigned short h, const unsigned short l) {
+  return ((float)__builtin_bit_cast(_Float16, h) + (float)__builtin_bit_cast(_Float16, l)) * (1.f / kScaleA);
 }
-// four pair elements -> packed hi / lo pieces: four v_perm_b32
-__device__ __forceinline__ void pair_quad(const float4 v, uint2 &hi, uint2 &lo) {
-  const uint4 u = __builtin_bit_cast(uint4, v);
-  hi = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x05040100u), __builtin_amdgcn_perm(u.w, u.z, 0x05040100u));
-  lo = make_uint2(__builtin_amdgcn_perm(u.y, u.x, 0x07060302u), __builtin_amdgcn_perm(u.w, u.z, 0x07060302u));
+// (hi + lo) / 4 of a group: exact sums (two 11-bit pieces fit an fp32 significand), exact scaling
+__device__ __forceinline__ void pair8_decode(const uint4 hi, const uint4 lo, float4 &a, float4 &b) {
+  a = make_float4(pair_value(hi.x & 0xffffu, lo.x & 0xffffu), pair_value(hi.x >> 16, lo.x >> 16),
+                  pair_value(hi.y & 0xffffu, lo.y & 0xffffu), pair_value(hi.y >> 16, lo.y >> 16));
+  b = make_float4(pair_value(hi.z & 0xffffu, lo.z & 0xffffu), pair_value(hi.z >> 16, lo.z >> 16),
+                  pair_value(hi.w & 0xffffu, lo.w & 0xffffu), pair_value(hi.w >> 16, lo.w >> 16));
+}
+// one element of a pair8 tensor (flat element index i): for the rare scalar accessor
+__device__ __forceinline__ float pair8_load(const unsigned short *base, const int64_t i) {
+  const int64_t g = i >> 3;
+  const int e = (int)(i & 7);
+  return pair_value(base[g * 16 + e], base[g * 16 + 8 + e]);
 }
 
 }  // namespace f16s

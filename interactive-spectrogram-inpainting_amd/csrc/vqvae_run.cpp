@@ -260,15 +260,16 @@ bool pairs_eligible(const isi_vqvae_w &w) {
   if (!encoder_pairs_ok(w.enc_b, w.in_channel, false)) return false;
   if (!encoder_pairs_ok(w.enc_t, w.enc_b.conv3.Cout, true)) return false;
   if (!conv_pair_sources_ok(w.enc_t.conv3.Cout, 0, D, 1)) return false;                 // quantize_conv_t
-  if (!decoder_pairs_ok(w.dec_t, D, 0, false, false)) return false;
+  if (!decoder_pairs_ok(w.dec_t, D, 0, true, false)) return false;      // reads the pair copy of quant_t
   if (convT_small_applicable(w.dec_t.n_up == 1 ? w.dec_t.conv3.Cout : w.dec_t.up[w.dec_t.n_up - 2].Cout,
                              w.dec_t.up[w.dec_t.n_up - 1].Cout)) return false;         // its output is written as pairs
   if (!conv_pair_sources_ok(w.dec_t.up[w.dec_t.n_up - 1].Cout, w.enc_b.conv3.Cout, D, 1)) return false;   // quantize_conv_b
   for (int i = 0; i < w.n_upsample; ++i) {
     if (convT_small_applicable(w.upsample[i].Cin, w.upsample[i].Cout)) return false;
-    if (i > 0 && !conv_pair_sources_ok(w.upsample[i].Cin, 0, w.upsample[i].Cout, 4)) return false;
+    if (!conv_pair_sources_ok(w.upsample[i].Cin, 0, w.upsample[i].Cout, 4)) return false;
   }
-  return decoder_pairs_ok(w.dec, D, D, w.n_upsample > 0, false);
+  if (w.no_quantize) return false;   // the pair copies of quant_t / quant_b are made behind the codebook searches
+  return decoder_pairs_ok(w.dec, D, D, true, true);
 }
 
 int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *idx, float *q,
@@ -313,6 +314,9 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   float *up2 = ws.floats((size_t)B * sh.Hb * sh.Wb * D);
   float *q_t_ws = ws.floats((size_t)B * sh.Ht * sh.Wt * D);
   float *q_b_ws = ws.floats((size_t)B * sh.Hb * sh.Wq * D);
+  // pair-format copies of the quantised maps: what the pair pipeline's convolutions read (the API tensors stay fp32)
+  float *q_t_pair = ws.floats((size_t)B * sh.Ht * sh.Wt * D);
+  float *q_b_pair = ws.floats((size_t)B * sh.Hb * sh.Wq * D);
   int64_t *id_t_ws = static_cast<int64_t *>(ws.take((size_t)B * sh.Ht * sh.Wt * sizeof(int64_t)));
   int64_t *id_b_ws = static_cast<int64_t *>(ws.take((size_t)B * sh.Hb * sh.Wq * sizeof(int64_t)));
   const int Kmax = std::max(w.quantize_t.K, w.quantize_b.K);
@@ -359,14 +363,18 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
                          : run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
                                          sse_part, scal + 0, pf_enc & ISI_CONV_F16X3, st);
       if (rc) return rc;
+      if (pairs) {
+        rc = pair_encode_f32(quant_t, q_t_pair, (int64_t)B * et.H * et.W * D, st);
+        if (rc) return rc;
+      }
     }
     // dec_t (vqvae.py:265): [B,Ht,Wt,D] -> [B,Hb,2^n Wt,D]
     int Wd = et.W;
     for (int i = 0; i < w.dec_t.n_up; ++i) Wd *= 2;
     {
-      isi_src s = src_nhwc(quant_t, D, et.H, et.W);
+      isi_src s = src_nhwc(pairs ? q_t_pair : quant_t, D, et.H, et.W);
       isi_dst d = dst_nhwc(dec_t, w.dec_t.up[w.dec_t.n_up - 1].Cout, sh.Hb, Wd);
-      rc = run_decoder(w.dec_t, s, nullptr, B, et.H, et.W, s0, s1, hid, d, pf_enc, false, false, pairs, pairs, st);
+      rc = run_decoder(w.dec_t, s, nullptr, B, et.H, et.W, s0, s1, hid, d, pf_enc, pairs, false, pairs, pairs, st);
       if (rc) return rc;
     }
     // quantize_conv_b on cat([dec_t, enc_b]) cropped to Wq (vqvae.py:266-273)
@@ -384,32 +392,39 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       if (rc) return rc;
     }
   }
+  if (pairs && (mode & ISI_MODE_DECODE)) {
+    // forward: quant_t was encoded behind its search (dec_t reads it); decode: both maps arrive as fp32
+    if (!(mode & ISI_MODE_ENCODE)) {
+      rc = pair_encode_f32(quant_t, q_t_pair, (int64_t)B * sh.Ht * sh.Wt * D, st);
+      if (rc) return rc;
+    }
+    rc = pair_encode_f32(quant_b, q_b_pair, (int64_t)B * sh.Hb * sh.Wq * D, st);
+    if (rc) return rc;
+  }
 
   if (mode & ISI_MODE_DECODE) {
     if (!out->dec) return invalid("vqvae: dec output is null");
     if (!(mode & ISI_MODE_ENCODE) && (!out->quant_t || !out->quant_b))
       return invalid("vqvae: decode needs quant_t and quant_b");
     // upsample_top_to_bottom: plain transposed convs, no ReLU (vqvae.py:183-201,281)
-    const float *cur = quant_t;
+    const float *cur = pairs ? q_t_pair : quant_t;
     int h = sh.Ht, ww = sh.Wt;
     for (int i = 0; i < w.n_upsample; ++i) {
       float *o = (i % 2 == 0) ? up : up2;
       isi_src s = src_nhwc(cur, w.upsample[i].Cin, h, ww);
       isi_dst d = dst_nhwc(o, w.upsample[i].Cout, 2 * h, 2 * ww);
       rc = conv_transpose2d_k4s2_f32(&s, w.upsample[i].w, w.upsample[i].bias, &d, B, h, ww,
-                                     w.upsample[i].Cout, pf_dec | ((pairs && i > 0) ? ISI_CONV_IN0_PAIR : 0) |
-                                     (pairs ? ISI_CONV_OUT_PAIR : 0), st);
+                                     w.upsample[i].Cout, pf_dec | (pairs ? ISI_CONV_IN0_PAIR | ISI_CONV_OUT_PAIR : 0), st);
       if (rc) return rc;
       cur = o; h *= 2; ww *= 2;
     }
     if (h != sh.Hb || ww != sh.Wq) return invalid("vqvae: upsampled top grid != bottom grid");
     isi_src a = src_nhwc(cur, D, h, ww);
-    isi_src b = src_nhwc(quant_b, D, sh.Hb, sh.Wq);
+    isi_src b = src_nhwc(pairs ? q_b_pair : quant_b, D, sh.Hb, sh.Wq);
     int OHf = sh.Hb, OWf = sh.Wq;
     for (int i = 0; i < w.dec.n_up; ++i) { OHf *= 2; OWf *= 2; }
     isi_dst d = dst_nchw(out->dec, w.in_channel, OHf, OWf);
-    rc = run_decoder(w.dec, a, &b, B, sh.Hb, sh.Wq, s0, s1, hid, d, pf_dec, pairs && w.n_upsample > 0, false, pairs,
-                     false, st);
+    rc = run_decoder(w.dec, a, &b, B, sh.Hb, sh.Wq, s0, s1, hid, d, pf_dec, pairs, pairs, pairs, false, st);
     if (rc) return rc;
   }
   return ISI_OK;

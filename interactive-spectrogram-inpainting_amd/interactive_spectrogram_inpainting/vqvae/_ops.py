@@ -64,21 +64,32 @@ def pack_codebook(embed: torch.Tensor):
     return codes, e2
 
 
+def _pair_storage(x: torch.Tensor):
+    """The pair format groups 8 consecutive CHANNELS in storage order (csrc/split_f16.h): a [B,C,H,W]-shaped view of
+    channels-last storage (what the convolutions return) is processed as [B,H,W,C]; anything else as a dense tensor
+    whose last dimension is the channel axis.  Returns (dense tensor, function mapping a result back to x's view)."""
+    if x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous():
+        return x.permute(0, 2, 3, 1), lambda y: y.permute(0, 3, 1, 2)
+    return x.contiguous(), lambda y: y
+
+
 def pair_encode(x: torch.Tensor) -> torch.Tensor:
-    """fp32 -> split-f16 pair format (ISI_CONV_IN*_PAIR / OUT_PAIR), same shape and strides' storage order."""
+    """fp32 -> split-f16 pair format (ISI_CONV_IN*_PAIR / OUT_PAIR): {hi[8] | lo[8]} per group of 8 channels."""
     _hip.require_gpu(x, "pair_encode input")
-    x = x.contiguous()
-    out = torch.empty_like(x)
-    _hip.check(_hip.lib().isi_pair_encode_f32(x.data_ptr(), out.data_ptr(), x.numel(), _s(x)), "isi_pair_encode_f32")
-    return out
+    d, back = _pair_storage(x)
+    if d.shape[-1] % 8:
+        raise ValueError("pair format needs a multiple of 8 channels")
+    out = torch.empty_like(d)
+    _hip.check(_hip.lib().isi_pair_encode_f32(d.data_ptr(), out.data_ptr(), d.numel(), _s(d)), "isi_pair_encode_f32")
+    return back(out)
 
 
 def pair_decode(p: torch.Tensor) -> torch.Tensor:
     _hip.require_gpu(p, "pair_decode input")
-    p = p.contiguous()
-    out = torch.empty_like(p)
-    _hip.check(_hip.lib().isi_pair_decode_f32(p.data_ptr(), out.data_ptr(), p.numel(), _s(p)), "isi_pair_decode_f32")
-    return out
+    d, back = _pair_storage(p)
+    out = torch.empty_like(d)
+    _hip.check(_hip.lib().isi_pair_decode_f32(d.data_ptr(), out.data_ptr(), d.numel(), _s(d)), "isi_pair_decode_f32")
+    return back(out)
 
 
 PAIR_IN0, PAIR_IN1, PAIR_OUT = 32, 64, 128   # ISI_CONV_IN0_PAIR / IN1_PAIR / OUT_PAIR, OR-ed into `extra_flags`

@@ -430,6 +430,20 @@ int isi_vq_nearest_flags_f32(const float *z, const float *codes_kd, const float 
                              float *sse_part, int64_t N, int D, int K, int flags, void *stream);
 int isi_vq_num_partials(int64_t N);
 
+/* quantize_conv (1x1, vqvae.py:260,272: Conv2d(C0 [+ C1] -> D, 1) on cat(src0, src1)) FUSED with the search above
+ * (SURVEY K4 + K5): z = W a + bias is produced in registers and consumed by the distance products, it never goes to
+ * memory.  Pair pipeline only: sources in the pair format (ISI_CONV_*_PAIR, channels-last, 32-channel multiples),
+ * `packed_w16` = the packed 1x1 weight's blocked pair copy (ISI_CONV_W16: packed weight + D * Kpad floats), D = 64.
+ * Pixel n = (b H + y) W + x reads src0 / src1 through their strides.  Outputs as isi_vq_nearest_f32 (bit-identical
+ * to isi_conv2d_f32(ISI_CONV_F16X3 | ISI_CONV_W16) followed by it); `q_pair_out` (nullable): pair-format copy of q.
+ * `workspace`: isi_vq_conv1x1_workspace_floats(C0, C1, D) floats, 16-byte aligned (a fragment-major copy of the
+ * weight is written there by a small pre-kernel). */
+int isi_vq_conv1x1_nearest_f32(const isi_src *src0, const isi_src *src1, const float *packed_w16, const float *bias,
+                               const float *codes_kd, const float *e2, int64_t *idx_out, float *q_out,
+                               float *q_pair_out, int32_t *counts, float *sse_part, float *workspace, int B, int H,
+                               int W, int D, int K, void *stream);
+size_t isi_vq_conv1x1_workspace_floats(int C0, int C1, int D);
+
 /* diff = sum(sse_part)/(N*D); perplexity = exp(-sum p log(max(p,1e-7))),
  * p = counts/N  (bottleneck.py:94,97-100).  Writes out2[0]=diff, out2[1]=perplexity. */
 int isi_vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts,

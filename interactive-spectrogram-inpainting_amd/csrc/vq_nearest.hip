@@ -24,6 +24,7 @@ namespace isi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8v __attribute__((ext_vector_type(8)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 #ifndef ISI_VQ_WAVES
 #define ISI_VQ_WAVES 8
@@ -290,6 +291,230 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
   }
 }
 
+
+// ---- fused quantize_conv (1x1) + codebook search (SURVEY K4 + K5; reference vqvae/vqvae.py:260,272 followed by
+// bottleneck.py:53-61): z never goes to memory.  Per wave and pass, 32 pixels:
+//
+//   z^T[d][pixel] = sum_c W[d][c] a[pixel][c] + bias[d]     split-f16 products (hi.hi + hi.lo + lo.hi), operands SWAPPED
+//                                                            (weights = MFMA rows, pixels = MFMA columns)
+//
+// With the swap a lane's accumulators of the two 32-channel row tiles hold dims (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+// (+ 32 per tile) of ONE pixel: exactly the quads `zq[j]` (quad 2 j + half) the distance MFMAs below take as their
+// B operand -- the 1x1 convolution's result is consumed in the registers it is born in.  The activations come in the
+// pair8 format (split_f16.h): a lane's operand fragment for a k-step is one 16-byte piece of its pixel's row, loaded
+// straight from memory (two sources for cat(dec_t, enc_b), vqvae.py:270); the weight pieces (blocked ISI_CONV_W16
+// copy) likewise -- 48 KiB per pass from L2, against 33 k matrix-pipe cycles of distance products per pass, and a
+// wave waiting for them leaves the pipe to its partner (no barriers in this loop).  Products, k order and term
+// order are those of the stand-alone convolution (conv_igemm_f32.hip): z, and hence every output, is bit-identical
+// to the two-launch path.  Outputs as vq_nearest_kernel, plus an optional pair8 copy of q for the pair pipeline.
+struct VqFusedArgs {
+  const float *in0, *in1, *w16, *bias, *codes, *e2;
+  const float *wfrag;                    // fragment-major copy of w16 (vq_weight_fragments_kernel)
+  int64_t *idx;
+  float *q, *q_pair;
+  int32_t *counts;
+  float *sse_part;
+  unsigned in0_bytes, in1_bytes, w_bytes;
+  int C0, C1, Kpad;
+  int s0n, s0h, s0w, s1n, s1h, s1w;     // element strides of the two sources (channel stride 1)
+  int H, W;                             // pixel grid: vector n = (b H + y) W + x
+  int64_t N;
+  int K;
+};
+
+// The 1x1 weight re-laid out FRAGMENT-major for the kernel below: piece ((k-step * 2 + tile) * 2 + plane) holds, for
+// lane l, the 16 bytes lane l feeds to the MFMA as its A operand (row 32 tile + (l & 31), channel group
+// 2 k-step + (l >> 5)): one weight load instruction then reads 1 KiB contiguously instead of 32 rows 768 bytes apart.
+__global__ void vq_weight_fragments_kernel(const uint4 *__restrict__ w16, uint4 *__restrict__ wf, int Kpad, int nstep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (step, tile, plane, lane)
+  if (i >= nstep * 2 * 2 * 64) return;
+  const int lane = i & 63, plane = (i >> 6) & 1, t = (i >> 7) & 1, step = i >> 8;
+  const int row = 32 * t + (lane & 31), grp = 2 * step + (lane >> 5);          // 8-channel group of the row
+  wf[i] = w16[((size_t)row * Kpad + grp * 8) / 4 + plane];
+}
+
+__global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFusedArgs p) {
+  constexpr int D = 64, LDD = D + 4, NQ = D / 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = p.K;
+  const int Kp = (K + 31) & ~31;
+  float *cb = smem;
+  float *e2 = smem + (size_t)Kp * LDD;
+  float *red = e2 + Kp;
+  int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 31;
+  const int half = lane >> 5;
+
+  for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
+    const int k = i / (D / 4), qd = i - k * (D / 4);
+    *reinterpret_cast<float4 *>(cb + (size_t)k * LDD + qd * 4) =
+        k < K ? *reinterpret_cast<const float4 *>(p.codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? p.e2[i] : INFINITY; hist[i] = 0; }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in0), 0, p.in0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in1), 0, p.in1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wfrag), 0, p.w_bytes, 0x00020000);
+  constexpr unsigned OOBV = 0xFFFFFFF0u;
+  // bias of this lane's dims: quad 2 j + half of tile t = j / 4 -> channels 8 j + 4 half + e
+  float4 bq[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j)
+    bq[j] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + 8 * j + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // this lane's weight rows (MFMA A operand: row = output channel 32 t + col, k-block = half): byte offset of k = 0
+  const int nchunk = (p.C0 + p.C1) / 32;
+  const int hw = p.H * p.W;
+
+  float sse = 0.f;
+  const int64_t n_iter = (p.N + VQ_VEC_PER_BLOCK_ITER - 1) / VQ_VEC_PER_BLOCK_ITER;
+  for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
+    const bool valid = n < p.N;
+    // ---- 1x1 convolution into this pixel's dims
+    unsigned a0 = OOBV, a1 = OOBV;       // byte offsets of the pixel's rows in the two sources
+    if (valid) {
+      const int b = (int)(n / hw);
+      const int rem = (int)(n - (int64_t)b * hw);
+      const int y = rem / p.W, x = rem - y * p.W;
+      a0 = (unsigned)(b * p.s0n + y * p.s0h + x * p.s0w) * 4u;
+      a1 = (unsigned)(b * p.s1n + y * p.s1h + x * p.s1w) * 4u;
+    }
+    f32x16 zt[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zt[t][r] = 0.f;
+    // two 32-channel chunks (four k-steps) per batch: all 24 fragment loads of a batch are in flight before its 24
+    // MFMAs (chunk by chunk the dependent L2 round trips added up to ~18 us per pass)
+    for (int c = 0; c < nchunk; c += 2) {
+      i32x4v ahv[4], alv[4], w0h[4], w0l[4], w1h[4], w1l[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int cc = c + (u >> 1), s_ = u & 1;
+        const bool live = cc < nchunk;                          // uniform (odd chunk counts: zero operands)
+        const bool second = cc * 32 >= p.C0;                    // uniform
+        const unsigned abase = second ? a1 : a0;
+        const unsigned acol = (unsigned)(second ? cc * 32 - p.C0 : cc * 32) * 4u;
+        // pieces of channel group 2 s + half of the chunk: hi at + 0, lo at + 16
+        const unsigned ao = (abase == OOBV || !live) ? OOBV : abase + acol + (unsigned)(2 * s_ + half) * 32u;
+        ahv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao, 0, 0);
+        alv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao == OOBV ? OOBV : ao + 16u, 0, 0);
+        // weight pieces, fragment-major: ((step * 2 + tile) * 2 + plane) * 1 KiB + 16 lane
+        const unsigned wo = live ? (unsigned)((cc * 2 + s_) * 4) * 1024u + (unsigned)lane * 16u : OOBV;
+        w0h[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo, 0, 0);
+        w0l[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo == OOBV ? OOBV : wo + 1024u, 0, 0);
+        w1h[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo == OOBV ? OOBV : wo + 2048u, 0, 0);
+        w1l[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo == OOBV ? OOBV : wo + 3072u, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // term order of the stand-alone convolution: activation lo . weight hi, activation hi . weight lo, hi . hi
+#define ISI_VQ_MF(W_, A_, T_) zt[T_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, W_), __builtin_bit_cast(vq_f16x8, A_), zt[T_], 0, 0, 0)
+        ISI_VQ_MF(w0h[u], alv[u], 0); ISI_VQ_MF(w1h[u], alv[u], 1);
+        ISI_VQ_MF(w0l[u], ahv[u], 0); ISI_VQ_MF(w1l[u], ahv[u], 1);
+        ISI_VQ_MF(w0h[u], ahv[u], 0); ISI_VQ_MF(w1h[u], ahv[u], 1);
+#undef ISI_VQ_MF
+      }
+    }
+    float4 zq[NQ];
+    float x2p = 0.f;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const int t = j >> 2, r0 = (j & 3) * 4;
+      float4 v = make_float4(zt[t][r0] * kVqUnscale + bq[j].x, zt[t][r0 + 1] * kVqUnscale + bq[j].y,
+                             zt[t][r0 + 2] * kVqUnscale + bq[j].z, zt[t][r0 + 3] * kVqUnscale + bq[j].w);
+      if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      zq[j] = v;
+      x2p += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    const float x2 = x2p + __shfl_xor(x2p, 32);
+
+    // ---- search (identical to vq_nearest_kernel)
+    float best = INFINITY;
+    int besti = 0;
+    for (int kt = 0; kt < Kp; kt += 32) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float *arow = cb + (size_t)(kt + col) * LDD + half * 4;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const float4 a = *reinterpret_cast<const float4 *>(arow + j * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zq[j].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zq[j].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zq[j].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zq[j].w, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int code = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const float d = (x2 - 2.f * acc[r]) + e2[code];
+        if (d < best) { best = d; besti = code; }
+      }
+    }
+    {
+      const float ob = __shfl_xor(best, 32);
+      const int oi = __shfl_xor(besti, 32);
+      if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    const bool lost = !(best < INFINITY);
+    if (valid && lost) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        *reinterpret_cast<float4 *>(p.q + n * D + (2 * j + half) * 4) = make_float4(NAN, NAN, NAN, NAN);
+        if (p.q_pair) {   // NaN pieces: the pair pipeline's consumers stay loud as well
+          *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(p.q_pair) + (n * D + 8 * j) * 4 + half * 8) = make_uint2(0x7e007e00u, 0x7e007e00u);
+          *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(p.q_pair) + (n * D + 8 * j) * 4 + 16 + half * 8) = make_uint2(0x7e007e00u, 0x7e007e00u);
+        }
+      }
+      sse = NAN;
+      if (half == 0) p.idx[n] = -1;
+    } else if (valid) {
+      const float *crow = cb + (size_t)besti * LDD + half * 4;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const float4 e = *reinterpret_cast<const float4 *>(crow + j * 8);
+        const float4 v = zq[j];
+        float4 dq = make_float4(e.x - v.x, e.y - v.y, e.z - v.z, e.w - v.w);
+        sse += dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w;
+        const float4 qv = make_float4(v.x + dq.x, v.y + dq.y, v.z + dq.z, v.w + dq.w);
+        *reinterpret_cast<float4 *>(p.q + n * D + (2 * j + half) * 4) = qv;
+        if (p.q_pair) {
+          // pair8 group j = channels 8 j .. 8 j + 7: this lane's quad is its half `half`: 8 bytes of hi pieces at
+          // + 8 half, 8 bytes of lo pieces at + 16 + 8 half
+          uint2 hi, lo;
+          f16s::split4(qv, f16s::kScaleA, hi, lo);
+          char *g8 = reinterpret_cast<char *>(p.q_pair) + (n * D + 8 * j) * 4;
+          *reinterpret_cast<uint2 *>(g8 + half * 8) = hi;
+          *reinterpret_cast<uint2 *>(g8 + 16 + half * 8) = lo;
+        }
+      }
+      if (half == 0) {
+        p.idx[n] = besti;
+        atomicAdd(&hist[besti], 1);
+      }
+    }
+  }
+
+  __syncthreads();
+  for (int i = tid; i < Kp; i += VQ_BLOCK)
+    if (hist[i]) atomicAdd(&p.counts[i], hist[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o);
+  if (lane == 0) red[wave] = sse;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < ISI_VQ_WAVES; ++w) t += red[w];
+    p.sse_part[blockIdx.x] = t;
+  }
+}
+
 __global__ void vq_finalize_kernel(const float *__restrict__ sse_part, int n_part,
                                    const int32_t *__restrict__ counts, int K, int64_t N, int D,
                                    float *__restrict__ out2) {
@@ -394,6 +619,58 @@ int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t 
     case 64: return launch_vq<64>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
     default: return unsupported("vq: embed_dim must be 8, 16, 32 or 64");
   }
+}
+
+
+// Fused quantize_conv + search (see vq_conv1x1_nearest_kernel).  Sources: pair8, channels-last, 32-channel multiples;
+// D = 64; the weight is the packed 1x1 weight's blocked pair copy (ISI_CONV_W16: packed_w + Cout * Kpad floats).
+bool vq_conv1x1_fusable(int C0, int C1, int D, int K) {
+  const int Kp = (K + 31) & ~31;
+  return D == 64 && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && ((size_t)Kp * (D + 4) + 2 * Kp + ISI_VQ_WAVES) * sizeof(float) <= 150 * 1024;
+}
+
+size_t vq_conv1x1_workspace_floats(int C0, int C1, int D) { return (size_t)D * round_up((size_t)(C0 + C1), kBK); }
+
+int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
+                           const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,
+                           float *workspace, int B, int H, int W, int D, int K, hipStream_t stream) {
+  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return invalid("vq_conv1x1: workspace (vq_conv1x1_workspace_floats, 16-byte aligned)");
+  if (!s0 || !s0->ptr || !w16 || !codes || !e2 || !idx || !q || !counts || !sse_part) return invalid("vq_conv1x1: null pointer");
+  const bool two = s1 && s1->ptr;
+  const int C0 = s0->C, C1 = two ? s1->C : 0;
+  if (B <= 0 || H <= 0 || W <= 0 || !vq_conv1x1_fusable(C0, C1, D, K)) return unsupported("vq_conv1x1: shape outside the fused kernel");
+  if (s0->sc != 1 || (two && s1->sc != 1)) return unsupported("vq_conv1x1: sources must be channels-last");
+  const int64_t N = (int64_t)B * H * W;
+  const int64_t e0 = (int64_t)(B - 1) * s0->sn + (int64_t)(H - 1) * s0->sh + (int64_t)(W - 1) * s0->sw + C0;
+  const int64_t e1 = two ? (int64_t)(B - 1) * s1->sn + (int64_t)(H - 1) * s1->sh + (int64_t)(W - 1) * s1->sw + C1 : 1;
+  if (e0 > ((int64_t)1 << 30) || e1 > ((int64_t)1 << 30) || N * D > ((int64_t)1 << 30)) return unsupported("vq_conv1x1: a tensor spans 4 GiB or more");
+  VqFusedArgs a;
+  memset(&a, 0, sizeof a);
+  a.in0 = s0->ptr; a.in1 = two ? s1->ptr : s0->ptr; a.w16 = w16; a.bias = bias; a.codes = codes; a.e2 = e2;
+  a.idx = idx; a.q = q; a.q_pair = q_pair; a.counts = counts; a.sse_part = sse_part;
+  a.in0_bytes = (unsigned)(e0 * 4); a.in1_bytes = two ? (unsigned)(e1 * 4) : a.in0_bytes;
+  a.C0 = C0; a.C1 = C1; a.Kpad = (int)round_up((size_t)(C0 + C1), kBK);
+  a.w_bytes = (unsigned)((size_t)D * a.Kpad * 4);
+  a.s0n = (int)s0->sn; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;
+  if (two) { a.s1n = (int)s1->sn; a.s1h = (int)s1->sh; a.s1w = (int)s1->sw; }
+  a.H = H; a.W = W; a.N = N; a.K = K;
+  const int Kp = (K + 31) & ~31;
+  const size_t smem = ((size_t)Kp * (D + 4) + 2 * Kp + ISI_VQ_WAVES) * sizeof(float);
+  a.wfrag = workspace;
+  {
+    const int nstep = a.Kpad / 16, total = nstep * 256;
+    hipLaunchKernelGGL(vq_weight_fragments_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
+                       reinterpret_cast<const uint4 *>(w16), reinterpret_cast<uint4 *>(workspace), a.Kpad, nstep);
+  }
+  auto kern = vq_conv1x1_nearest_kernel;
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return check_launch("hipFuncSetAttribute(vq_conv1x1)");
+  {
+    const double cin = C0 + C1;
+    prof::Scope scope(prof::K_VQ_NEAREST, 2.0 * N * K * D + 2.0 * N * D * cin, 4.0 * (N * cin + 2.0 * N * D + (double)K * D) + 8.0 * N, stream);
+    ISI_PROF_LAUNCH(scope, kern, dim3(vq_grid(N)), dim3(VQ_BLOCK), smem, stream, a);
+  }
+  return check_launch("vq_conv1x1_nearest_f32");
 }
 
 int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,

@@ -293,6 +293,21 @@ int unquantized_scalars(float *scalars2, hipStream_t st) {
   return ISI_OK;
 }
 
+// quantize_conv (1x1) + codebook search in ONE launch (vq_nearest.hip: z stays in registers), with the pair-format
+// copy of q written alongside.  `w1x1` = the 1x1 layer (its packed weight is followed by the blocked pair copy).
+int run_quantizer_fused(const isi_codebook_w &cb, const isi_conv_w &w1x1, const isi_src &a, const isi_src *b, int B, int H,
+                        int W, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part, float *scalars2,
+                        float *wfrag_ws, hipStream_t st) {
+  if (hipMemsetAsync(counts, 0, (size_t)cb.K * sizeof(int32_t), st) != hipSuccess)
+    return check_launch("hipMemsetAsync(counts)");
+  const int Kpad = (int)round_up((size_t)w1x1.Cin, kBK);
+  int rc = vq_conv1x1_nearest_f32(&a, b, w1x1.w + (size_t)w1x1.Cout * Kpad, w1x1.bias, cb.codes_kd, cb.e2, idx, q, q_pair,
+                                  counts, sse_part, wfrag_ws, B, H, W, cb.D, cb.K, st);
+  if (rc) return rc;
+  const int64_t N = (int64_t)B * H * W;
+  return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);
+}
+
 int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
          const isi_vqvae_out *out, Bump &ws, hipStream_t st) {
   Shapes sh;
@@ -322,6 +337,8 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   const int Kmax = std::max(w.quantize_t.K, w.quantize_b.K);
   int32_t *counts = static_cast<int32_t *>(ws.take((size_t)Kmax * sizeof(int32_t)));
   float *sse_part = ws.floats(256);
+  float *wfrag_ws = ws.floats((size_t)D * round_up((size_t)(w.quantize_conv_b.Cin > w.quantize_conv_t.Cin ? w.quantize_conv_b.Cin
+                                                                                                            : w.quantize_conv_t.Cin), kBK));
   float *scal_ws = ws.floats(4);
   if (dry) return ISI_OK;
   if (ws.off > ws.cap) {
@@ -342,6 +359,9 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
                    : w.precision == 2 ? ISI_CONV_BF16X3 : 0;   // feeds the quantisers
   const bool pairs = pairs_eligible(w);   // internal activations as split-f16 pairs (isi_hip.h: ISI_CONV_*_PAIR)
   const int pf_dec = w.precision == 4 ? f16 : w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
+  // quantize_conv_{t,b} fused into the codebook searches: the pair pipeline only (pair8 sources, blocked weights)
+  const bool fuse_vq = pairs && !w.no_quantize && getenv("ISI_NO_VQ_FUSION") == nullptr;
+  bool bottom_pair_done = false;
 
   if (mode & ISI_MODE_ENCODE) {
     if (!x) return invalid("vqvae: x is null");
@@ -354,6 +374,12 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
     // quantize_conv_t + quantize_t (vqvae.py:260-263)
     {
       isi_src s = src_nhwc(et.p, et.C, et.H, et.W);
+      if (fuse_vq && vq_conv1x1_fusable(et.C, 0, D, w.quantize_t.K)) {
+        rc = run_quantizer_fused(w.quantize_t, w.quantize_conv_t, s, nullptr, B, et.H, et.W, id_t, quant_t, q_t_pair,
+                                 counts, sse_part, scal + 0, wfrag_ws, st);
+        if (rc) return rc;
+        goto top_done;
+      }
       // UnquantizedBottleneck (bottleneck.py:107-119): the 1x1 convolution's output IS quant_t
       isi_dst d = dst_nhwc(w.no_quantize ? quant_t : zbuf, D, et.H, et.W);
       rc = conv2d_f32(&s, nullptr, w.quantize_conv_t.w, w.quantize_conv_t.bias, nullptr, &d, B, et.H,
@@ -368,6 +394,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
         if (rc) return rc;
       }
     }
+  top_done:;
     // dec_t (vqvae.py:265): [B,Ht,Wt,D] -> [B,Hb,2^n Wt,D]
     int Wd = et.W;
     for (int i = 0; i < w.dec_t.n_up; ++i) Wd *= 2;
@@ -382,6 +409,13 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       const int Cd = w.dec_t.up[w.dec_t.n_up - 1].Cout;
       isi_src a = src_nhwc(dec_t, Cd, sh.Hb, sh.Wq, Wd);
       isi_src b = src_nhwc(eb.p, eb.C, sh.Hb, sh.Wq, eb.W);
+      if (fuse_vq && vq_conv1x1_fusable(Cd, eb.C, D, w.quantize_b.K)) {
+        rc = run_quantizer_fused(w.quantize_b, w.quantize_conv_b, a, &b, B, sh.Hb, sh.Wq, id_b, quant_b, q_b_pair, counts,
+                                 sse_part, scal + 2, wfrag_ws, st);
+        if (rc) return rc;
+        bottom_pair_done = true;
+        goto bottom_done;
+      }
       isi_dst d = dst_nhwc(w.no_quantize ? quant_b : zbuf, D, sh.Hb, sh.Wq);
       rc = conv2d_f32(&a, &b, w.quantize_conv_b.w, w.quantize_conv_b.bias, nullptr, &d, B, sh.Hb,
                       sh.Wq, D, 1, 1, 1, 0, pf_enc | (pairs ? ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR : 0), st);
@@ -391,6 +425,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
                                          sse_part, scal + 2, pf_enc & ISI_CONV_F16X3, st);
       if (rc) return rc;
     }
+  bottom_done:;
   }
   if (pairs && (mode & ISI_MODE_DECODE)) {
     // forward: quant_t was encoded behind its search (dec_t reads it); decode: both maps arrive as fp32
@@ -398,8 +433,10 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       rc = pair_encode_f32(quant_t, q_t_pair, (int64_t)B * sh.Ht * sh.Wt * D, st);
       if (rc) return rc;
     }
-    rc = pair_encode_f32(quant_b, q_b_pair, (int64_t)B * sh.Hb * sh.Wq * D, st);
-    if (rc) return rc;
+    if (!bottom_pair_done) {
+      rc = pair_encode_f32(quant_b, q_b_pair, (int64_t)B * sh.Hb * sh.Wq * D, st);
+      if (rc) return rc;
+    }
   }
 
   if (mode & ISI_MODE_DECODE) {

@@ -611,6 +611,23 @@ def test_vqvae_pair_pipeline_against_fp32_activations():
         del os.environ["ISI_CONV_FLUSH"]
     for a, b in zip(unflushed, ref):
         assert torch.equal(a, b)
+    # quantize_conv_{t,b} fused into the codebook searches (z stays in registers; csrc/vq_nearest.hip): the same
+    # products in the same order as the two-launch path -- the same bits
+    os.environ["ISI_NO_VQ_FUSION"] = "1"
+    try:
+        unfused = m(x)
+    finally:
+        del os.environ["ISI_NO_VQ_FUSION"]
+    for a, b in zip(got, unfused):
+        assert torch.equal(a, b)
+    enc_f = m.encode(x)
+    os.environ["ISI_NO_VQ_FUSION"] = "1"
+    try:
+        enc_u = m.encode(x)
+    finally:
+        del os.environ["ISI_NO_VQ_FUSION"]
+    for a, b in zip(enc_f, enc_u):
+        assert torch.equal(a, b)
     # default (flushed accumulators): fp32-rounding-level differences only
     assert (got[4] != ref[4]).float().mean() < 0.01 and (got[5] != ref[5]).float().mean() < 0.01
     same = (got[4] == ref[4]).all(-1).all(-1) & (got[5] == ref[5]).all(-1).all(-1)

@@ -293,7 +293,9 @@ typedef struct isi_attn_args {
   float scale;
   float *lse;   /* optional [B,H,Sq]: log-sum-exp of every query's logits (kept for the backward) */
   int precision; /* products of the three contractions: 0 = fp32 matrix pipe, 1 = three-term split-bf16
-                  * (hi.hi + hi.lo + lo.hi on the bf16 pipe, fp32 accumulation; logits / softmax fp32) */
+                  * (hi.hi + hi.lo + lo.hi on the bf16 pipe, fp32 accumulation; logits / softmax fp32),
+                  * 2 = single-term bf16 (operands rounded to bf16, fp32 accumulation / logits / softmax; the
+                  * backward of such a forward runs with three-term products) */
 } isi_attn_args;
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream);
 

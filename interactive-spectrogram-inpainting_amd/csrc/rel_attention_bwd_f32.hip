@@ -1442,7 +1442,7 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     if (hipMemsetAsync(a.g, 0, (size_t)g->H * g->B * g->Sq * L.Rp * sizeof(float), stream) != hipSuccess)
       return check_launch("hipMemsetAsync(G)");
   }
-  const bool split = g->precision == 1;
+  const bool split = g->precision >= 1;   // a single-term bf16 forward (precision 2) is differentiated with three-term products
   switch (HD) {
     case 16: rc = split ? launch_bwd_split<16>(a, stream) : launch_bwd<16>(a, stream); break;
     case 32: rc = split ? launch_bwd_split<32>(a, stream) : launch_bwd<32>(a, stream); break;
@@ -1460,7 +1460,7 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
                        g->rel_embeddings, wT, g->H, R, HD, KpT, rho_lo, rho_n);
     if ((rc = check_launch("pack_rel_T"))) return rc;
   }
-  const int gemm_flags = g->precision == 1 ? ISI_CONV_BF16X3 : 0;   // same product mode as the attention kernels
+  const int gemm_flags = g->precision >= 1 ? ISI_CONV_BF16X3 : 0;   // same product mode as the attention kernels
   {
     // all heads in one launch each (grid z = head): G_h [B*Sq, Rp] x E_h^T, accumulated into dq's head slice ...
     isi_src sg;

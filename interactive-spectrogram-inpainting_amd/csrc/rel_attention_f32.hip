@@ -41,7 +41,7 @@ struct AttnKArgs {
   int Cq, Ck, Ek, R;
   int mask_mode;  // 0 none, 1 causal (j <= i), 2 anti-causal (j >= i)
   float scale;
-  int split;      // 1: three-term split-bf16 products (rel_attention_split_kernel)
+  int split;      // 1: three-term split-bf16 products (rel_attention_split_kernel), 2: single-term bf16
 };
 
 namespace {
@@ -372,7 +372,10 @@ __global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs 
 //                    of key block t is key 16 t + 8 (e >> 2) + 4 h + (e & 3), i.e. exactly the lane's registers
 // LDS rows are unpadded and XOR-swizzled: 16-B slot s of row r of a [.][HD] plane sits at s ^ ((r / (128/HD))
 // mod (HD/8)); 8-B unit u of row d of a V^T plane at u ^ ((d >> 2) & 7)  (conflict-free ds_read_b128 / b64).
-template <int HD>
+// ONE = true (args->precision = 2): SINGLE-term bf16 products (north_star's "MFMA bf16" mode): the lo planes are
+// neither computed, stored nor multiplied -- a third of the matrix work, half of the staging conversions and LDS
+// traffic; operands are rounded to bf16 (8 significand bits), accumulation / logits / softmax stay fp32.
+template <int HD, bool ONE = false>
 __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArgs p) {
   constexpr int NKB = HD / 16;           // 16-deep k-blocks of the head dim
   constexpr int NSL = HD / 8;            // 16-B slots per [.][HD] row
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
     split_f4(buf_load4(rq, off), h0, l0);
     split_f4(buf_load4(rq, off == OOB ? OOB : off + 16u), h1, l1);
     qh[t] = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
-    qlo[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    qlo[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));   // dead when ONE
   }
   const int evq = qi / p.Cq;
   const int evq_w0 = qw0 / p.Cq, evq_b0 = q0 / p.Cq;
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           split_f4(pb[j], hi, lo);
           const int o = ((btile * 2) * 32 + row) * HD + swz(row, bqd >> 1) + (bqd & 1) * 4;
           *reinterpret_cast<uint2 *>(Kp + o) = hi;
-          *reinterpret_cast<uint2 *>(Kp + o + 32 * HD) = lo;
+          if constexpr (!ONE) *reinterpret_cast<uint2 *>(Kp + o + 32 * HD) = lo;
         }
       } else {           // V transposed: per dim the 4 keys of the block as one 8-byte unit
 #pragma unroll
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           split2(a2, a3, hi.y, lo.y);
           const int o = ((btile * 2) * VR + d) * 32 + ((bkg ^ ((d >> 2) & 7)) * 4);
           *reinterpret_cast<uint2 *>(Vp + o) = hi;
-          *reinterpret_cast<uint2 *>(Vp + o + VR * 32) = lo;
+          if constexpr (!ONE) *reinterpret_cast<uint2 *>(Vp + o + VR * 32) = lo;
         }
       }
     }
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           split_f4(pe[i], hi, lo);
           const int o = slot * HD + swz(slot, qd >> 1) + (qd & 1) * 4;
           *reinterpret_cast<uint2 *>(Ep + o) = hi;
-          *reinterpret_cast<uint2 *>(Ep + o + RING * HD) = lo;
+          if constexpr (!ONE) *reinterpret_cast<uint2 *>(Ep + o + RING * HD) = lo;
         }
       }
     }
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           split_f4(buf_load4(re, ok ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB), hi, lo);
           const int o = slot * HD + swz(slot, qd >> 1) + (qd & 1) * 4;
           *reinterpret_cast<uint2 *>(Ep + o) = hi;
-          *reinterpret_cast<uint2 *>(Ep + o + RING * HD) = lo;
+          if constexpr (!ONE) *reinterpret_cast<uint2 *>(Ep + o + RING * HD) = lo;
         }
       }
     }
@@ -553,9 +556,11 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
       for (int t = 0; t < NKB; ++t) {
         const int o = ql * HD + swz(ql, 2 * t + half);
         const s16x8_t kh = *reinterpret_cast<const s16x8_t *>(Kb + o);
-        const s16x8_t kl = *reinterpret_cast<const s16x8_t *>(Kb + o + 32 * HD);
-        sacc = ISI_MFB(kl, qh[t], sacc);
-        sacc = ISI_MFB(kh, qlo[t], sacc);
+        if constexpr (!ONE) {
+          const s16x8_t kl = *reinterpret_cast<const s16x8_t *>(Kb + o + 32 * HD);
+          sacc = ISI_MFB(kl, qh[t], sacc);
+          sacc = ISI_MFB(kh, qlo[t], sacc);
+        }
         sacc = ISI_MFB(kh, qh[t], sacc);
       }
       float sv[16];
@@ -576,9 +581,11 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           for (int t = 0; t < NKB; ++t) {
             const int o = slot * HD + swz(slot, 2 * t + half);
             const s16x8_t eh = *reinterpret_cast<const s16x8_t *>(Ep + o);
-            const s16x8_t el = *reinterpret_cast<const s16x8_t *>(Ep + o + RING * HD);
-            racc = ISI_MFB(el, qh[t], racc);
-            racc = ISI_MFB(eh, qlo[t], racc);
+            if constexpr (!ONE) {
+              const s16x8_t el = *reinterpret_cast<const s16x8_t *>(Ep + o + RING * HD);
+              racc = ISI_MFB(el, qh[t], racc);
+              racc = ISI_MFB(eh, qlo[t], racc);
+            }
             racc = ISI_MFB(eh, qh[t], racc);
           }
 #pragma unroll
@@ -655,12 +662,14 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           const unsigned short *vr = Vb + drow * 32;
           const uint2 h0 = *reinterpret_cast<const uint2 *>(vr + (((4 * t + half) ^ sx) * 4));
           const uint2 h1 = *reinterpret_cast<const uint2 *>(vr + (((4 * t + 2 + half) ^ sx) * 4));
-          const uint2 l0 = *reinterpret_cast<const uint2 *>(vr + VR * 32 + (((4 * t + half) ^ sx) * 4));
-          const uint2 l1 = *reinterpret_cast<const uint2 *>(vr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
           const s16x8_t vh = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
-          const s16x8_t vl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
-          O[d] = ISI_MFB(vl, ph[t], O[d]);
-          O[d] = ISI_MFB(vh, pl[t], O[d]);
+          if constexpr (!ONE) {
+            const uint2 l0 = *reinterpret_cast<const uint2 *>(vr + VR * 32 + (((4 * t + half) ^ sx) * 4));
+            const uint2 l1 = *reinterpret_cast<const uint2 *>(vr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
+            const s16x8_t vl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
+            O[d] = ISI_MFB(vl, ph[t], O[d]);
+            O[d] = ISI_MFB(vh, pl[t], O[d]);
+          }
           O[d] = ISI_MFB(vh, ph[t], O[d]);
         }
       }
@@ -715,13 +724,13 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
 
 template <int HD>
 static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
-  auto kern = a.split ? rel_attention_split_kernel<HD> : rel_attention_f32_kernel<HD>;
+  auto kern = a.split == 2 ? rel_attention_split_kernel<HD, true> : a.split ? rel_attention_split_kernel<HD, false> : rel_attention_f32_kernel<HD>;
   constexpr int VR = ((HD + 31) / 32) * 32;
   constexpr size_t smem_f = (size_t)((128 + RING) * (HD + 4) + 8 * 32 * SRLD) * sizeof(float) + 64 * sizeof(int);
   constexpr size_t smem_s = (size_t)(2 * 2 * 32 * HD + 2 * 2 * VR * 32 + 2 * RING * HD) * sizeof(unsigned short) +
                             (size_t)(8 * 32 * SRLD) * sizeof(float) + 64 * sizeof(int);
   const size_t smem = a.split ? smem_s : smem_f;
-  static bool attr_set[2] = {false, false};
+  static bool attr_set[3] = {false, false, false};
   if (!attr_set[a.split]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -769,7 +778,7 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   a.o_ss = (int)g->o_ss; a.o_sb = (int)g->o_sb; a.o_sh = (int)g->o_sh;
   a.Cq = g->Cq; a.Ck = g->Ck; a.Ek = g->Ek;
   a.mask_mode = g->mask_mode; a.scale = g->scale;
-  a.split = g->precision == 1 ? 1 : 0;
+  a.split = g->precision == 1 ? 1 : g->precision == 2 ? 2 : 0;   // 0 fp32 pipe | 1 three-term split-bf16 | 2 single-term bf16
   if (a.e && a.R <= 0) return invalid("rel_attention: rel_rows must be positive");
   switch (g->head_dim) {
     case 16: return launch_attn<16>(a, g->B, stream);

@@ -29,9 +29,11 @@ LINEAR_PRECISION = os.environ.get("ISI_LINEAR_PRECISION", "bf16x6")
 # product) are far below the noise the ReLU / dropout masks and the optimiser see
 LINEAR_GRAD_PRECISION = os.environ.get("ISI_LINEAR_GRAD_PRECISION", "bf16x3")
 # products of the attention contractions (q k^T, q e^T, p v): 'f32' = fp32 matrix pipe, 'bf16x3' = three-term
-# split-bf16 on the bf16 pipe (relative error of a product ~2^-16, fp32 accumulation, logits / softmax fp32)
+# split-bf16 on the bf16 pipe (relative error of a product ~2^-16, fp32 accumulation, logits / softmax fp32),
+# 'bf16' = single-term bf16 (operands rounded to 8 significand bits: north_star's "MFMA bf16" mode; measured error
+# in bench.py's attention leg and in tests/test_prior_gpu.py)
 ATTENTION_PRECISION = os.environ.get("ISI_ATTENTION_PRECISION", "bf16x3")
-_ATTN_PREC = {"f32": 0, "bf16x3": 1}
+_ATTN_PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
 ATTENTION_PRECISIONS = tuple(_ATTN_PREC)                 # modes bench.py times
 ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1}    # 16-bit MFMA terms per product (0: fp32 matrix pipe)
 _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4}

@@ -602,15 +602,19 @@ def test_vqvae_pair_pipeline_against_fp32_activations():
         ref = m(x)
     finally:
         del os.environ["ISI_NO_PAIRS"]
-    # same matrix operands, and the residual blocks' skip connections read fp32 on both paths: with the pair kernel's
-    # accumulator flush off (ISI_CONV_FLUSH=0: one accumulator chain like the register-staged kernel) the same bits
+    # The convolutions' matrix operands are the same bits on both paths (with the pair kernel's accumulator flush off,
+    # ISI_CONV_FLUSH=0, even the same sums); the residual blocks of the pair pipeline take their skip connection from
+    # the pair pieces ((hi + lo) / 4: the value to 2^-24) instead of the fp32 tensor: rounding-level differences
     os.environ["ISI_CONV_FLUSH"] = "0"
     try:
         unflushed = m(x)
     finally:
         del os.environ["ISI_CONV_FLUSH"]
-    for a, b in zip(unflushed, ref):
-        assert torch.equal(a, b)
+    for got_ in (unflushed, got):
+        assert (got_[4] != ref[4]).float().mean() < 0.01 and (got_[5] != ref[5]).float().mean() < 0.01
+        same_ = (got_[4] == ref[4]).all(-1).all(-1) & (got_[5] == ref[5]).all(-1).all(-1)
+        if same_.any():
+            _close(got_[0][same_], ref[0][same_], 3e-6, "dec (pair pipeline vs fp32 activations)")
     # quantize_conv_{t,b} fused into the codebook searches (z stays in registers; csrc/vq_nearest.hip): the same
     # products in the same order as the two-launch path -- the same bits
     os.environ["ISI_NO_VQ_FUSION"] = "1"
@@ -628,11 +632,7 @@ def test_vqvae_pair_pipeline_against_fp32_activations():
         del os.environ["ISI_NO_VQ_FUSION"]
     for a, b in zip(enc_f, enc_u):
         assert torch.equal(a, b)
-    # default (flushed accumulators): fp32-rounding-level differences only
-    assert (got[4] != ref[4]).float().mean() < 0.01 and (got[5] != ref[5]).float().mean() < 0.01
-    same = (got[4] == ref[4]).all(-1).all(-1) & (got[5] == ref[5]).all(-1).all(-1)
-    if same.any():
-        _close(got[0][same], ref[0][same], 2e-6, "dec (flushed vs single-chain accumulation)")
+
     assert torch.equal(m.decode_code(got[4], got[5]).isfinite().all(), torch.tensor(True, device=dev))
     oref = O.forward(x.cpu(), sd, cfg)
     assert (got[4].cpu() != oref[4]).float().mean() < 0.01 and (got[5].cpu() != oref[5]).float().mean() < 0.01

@@ -544,3 +544,38 @@ def test_sample_model_at_baseline_size_matches_full_pass_sampling():
     # a draw sits on a CDF step: rounding differences between the cached row and the full pass may move a code only
     # if the uniform falls within float rounding of a step -- identical in practice
     assert (got != ref).sum().item() <= 1, f"{(got != ref).sum().item()} of 32 sampled codes differ"
+
+
+@pytest.mark.parametrize("Sq,Sk,Cq,Ck,mode", [(1025, 1025, 1, 1, 1), (4100, 1025, 4, 1, 0), (200, 200, 1, 1, 2), (77, 150, 2, 1, 0)])
+def test_rel_attention_bf16_mode(Sq, Sk, Cq, Ck, mode, monkeypatch):
+    """precision = 'bf16' (north_star: relative-attention contractions on MFMA bf16, single term): operands rounded
+    to bf16 (2^-9 relative), fp32 accumulation / logits / softmax.  Error against the fp32 specification is that of
+    the operand rounding -- checked at 2e-2 of the output's maximum here and REPORTED by bench.py's attention leg
+    next to the three-term split's 1e-5; masks, skew and ragged tiles as in the other modes."""
+    from oracle import prior_oracle as P
+    from interactive_spectrogram_inpainting.priors import _ops
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", "bf16")
+    hd, H, B = 64, 8, 1
+    d = hd * H
+    torch.manual_seed(Sq + mode)
+    Eq, Ek = -(-Sq // Cq), -(-Sk // Ck)
+    q, k, v = torch.randn(Sq, B, d), torch.randn(Sk, B, d), torch.randn(Sk, B, d)
+    rel = torch.randn(H, Eq + Ek - 1, hd) * 0.5
+    hq = q.reshape(Sq, B, H, hd).permute(1, 2, 0, 3)
+    hk = k.reshape(Sk, B, H, hd).permute(1, 2, 0, 3)
+    hv = v.reshape(Sk, B, H, hd).permute(1, 2, 0, 3)
+    logits = hq @ hk.transpose(-1, -2)
+    qe = torch.einsum("bhid,hrd->bhir", hq, rel)
+    logits = (logits + qe.gather(3, P.rel_index(Sq, Sk, Cq, Ck, Ek).expand(B, H, Sq, Sk))) / math.sqrt(hd)
+    if mode == 1:
+        logits += P.causal_mask(Sq)
+    elif mode == 2:
+        logits += P.causal_mask(Sq).t()
+    ref = (torch.softmax(logits, -1) @ hv).permute(2, 0, 1, 3).reshape(Sq, B, d)
+    dev = _dev()
+    got = _ops.rel_attention(q.to(dev), k.to(dev), v.to(dev), rel.to(dev), H, Cq, Ck, Ek, mask_mode=mode)
+    err = ((got.cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert torch.isfinite(got).all() and err < 2e-2, err
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", "bf16x3")
+    x3 = _ops.rel_attention(q.to(dev), k.to(dev), v.to(dev), rel.to(dev), H, Cq, Ck, Ek, mask_mode=mode)
+    assert ((x3.cpu() - ref).abs().max() / ref.abs().max()).item() < err, "the three-term split must be more accurate"

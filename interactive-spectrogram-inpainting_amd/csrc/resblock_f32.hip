@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "isi_common.h"
+#include "isi_internal.h"
 #include "prof.h"
 #include "split_f16.h"
 
@@ -490,6 +491,9 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
   if ((relu & ISI_CONV_F16X3) && (relu & ISI_CONV_W16)) {   // split-f16 pair copies behind the fp32 weights
     a.w1 = w1 + (size_t)R * 9 * C;
     a.w2 = w2 + (size_t)C * 32;
+    // pair-format input: the LDS-DMA kernel (resblock_pair_f16.hip)
+    if (a.in_pair && resblock_pair_preferred(B, H, W, C, R) && !(relu & ISI_CONV_BF16X6))
+      return resblock_pair_f16(in, a.w1, b1, a.w2, b2, out, B, H, W, C, relu & 1, a.out_pair, stream);
     ISI_RES(4)
   }
   if (relu & ISI_CONV_F16X3) { ISI_RES(3) }

@@ -110,6 +110,15 @@ bool compute_shapes(const isi_vqvae_w &w, int B, int H, int W, Shapes &s) {
 // `in_pair` / `out_pair`: the stack's input / output tensors are in the split-f16 pair format (isi_hip.h,
 // ISI_CONV_*_PAIR; only set when every block is fusable, see pairs_eligible); tensors between blocks follow `in_pair`
 // (the callers pass fp32 in: see run_encoder).
+// Will the residual stack that follows a convolution run in the pair format (resblock_pair_f16.hip: every block reads
+// and writes pairs)?  Otherwise its blocks read fp32 and only the last one writes pairs.
+bool res_stack_in_pairs(bool pairs, int n_res, const isi_conv_w *res3, int B, int H, int W, int C) {
+  if (!pairs || n_res == 0) return false;
+  for (int i = 0; i < n_res; ++i)
+    if (!resblock_pair_preferred(B, H, W, C, res3[i].Cout)) return false;
+  return true;
+}
+
 int run_res_stack(int n_res, const isi_conv_w *res3, const isi_conv_w *res1, Act &cur, int B,
                   float *s0, float *s1, float *hid, float *final_out, int pf, bool in_pair, bool out_pair,
                   hipStream_t st) {
@@ -146,6 +155,7 @@ int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *
                 float *hid, float *final_out, Act &out, int pf, bool in_pair, bool pairs, hipStream_t st) {
   Act cur{nullptr, in.C, H, W};
   isi_src cs = in;
+  bool stack_pairs = false;
   const int op = pairs ? ISI_CONV_OUT_PAIR : 0;
   bool cp = in_pair;   // format of the current tensor
   for (int i = 0; i < e.n_down; ++i) {
@@ -162,15 +172,16 @@ int run_encoder(const isi_encoder_w &e, isi_src in, int B, int H, int W, float *
   {
     float *o = (e.n_res == 0) ? final_out : ((cur.p == s0) ? s1 : s0);
     isi_dst d = dst_nhwc(o, e.conv3.Cout, cur.H, cur.W);
+    stack_pairs = res_stack_in_pairs(pairs, e.n_res, e.res3, B, cur.H, cur.W, e.conv3.Cout);
     int rc = conv2d_f32(&cs, nullptr, e.conv3.w, e.conv3.bias, nullptr, &d, B, cur.H, cur.W,
-                        e.conv3.Cout, 3, 3, 1, 1, 1 | pf | (cp ? ISI_CONV_IN0_PAIR : 0) | (e.n_res ? 0 : op), st);
+                        e.conv3.Cout, 3, 3, 1, 1, 1 | pf | (cp ? ISI_CONV_IN0_PAIR : 0) | ((e.n_res && !stack_pairs) ? 0 : op), st);
     if (rc) return rc;
     cur = Act{o, e.conv3.Cout, cur.H, cur.W};
   }
   // the fused residual block stages its input once per slice (not once per tap): it reads and writes fp32 between
   // blocks -- decoding the skip connection from pairs cost more than the conversion saved, 64 -> 72 us per block --
   // and only the stack's last block writes pairs, for the implicit-GEMM consumers of the encoder's output
-  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, pf, false, pairs, st);
+  int rc = run_res_stack(e.n_res, e.res3, e.res1, cur, B, s0, s1, hid, final_out, pf, stack_pairs, pairs, st);
   if (rc) return rc;
   out = cur;
   return ISI_OK;
@@ -185,11 +196,13 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
                 float *s0, float *s1, float *hid, const isi_dst &final_dst, int pf, bool in0_pair, bool in1_pair,
                 bool pairs, bool final_pair, hipStream_t st) {
   Act cur{s0, d.conv3.Cout, H, W};
+  bool stack_pairs = false;
   // format in which up[i] wants its input: fp32 for the few-channel kernel
   auto up_reads_pair = [&](int i, int Cin) { return pairs && !convT_small_applicable(Cin, d.up[i].Cout); };
   {
     isi_dst dd = dst_nhwc(cur.p, cur.C, H, W);
-    const bool op = d.n_res ? false : (d.n_up ? up_reads_pair(0, cur.C) : final_pair);   // fp32 into the residual stack
+    stack_pairs = res_stack_in_pairs(pairs, d.n_res, d.res3, B, H, W, cur.C);
+    const bool op = d.n_res ? stack_pairs : (d.n_up ? up_reads_pair(0, cur.C) : final_pair);   // fp32 into a register-staged stack
     int rc = conv2d_f32(&in0, in1, d.conv3.w, d.conv3.bias, nullptr, &dd, B, H, W, cur.C, 3, 3, 1,
                         1, 1 | pf | (in0_pair ? ISI_CONV_IN0_PAIR : 0) | (in1_pair ? ISI_CONV_IN1_PAIR : 0) |
                         (op ? ISI_CONV_OUT_PAIR : 0), st);
@@ -198,7 +211,7 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
   bool cp = pairs;   // format of `cur` after the residual stack
   {
     cp = d.n_up ? up_reads_pair(0, cur.C) : final_pair;
-    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, pf, false, cp, st);
+    int rc = run_res_stack(d.n_res, d.res3, d.res1, cur, B, s0, s1, hid, nullptr, pf, stack_pairs, cp, st);
     if (rc) return rc;
   }
   for (int i = 0; i < d.n_up; ++i) {

@@ -78,11 +78,10 @@ int sample_row_pos_f32(const float *logits, int stride, int rows, int n, float t
 int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                    const float *u, int64_t *out, float *filtered, hipStream_t stream);
 
+int rel_attention_decode_splits(int Sk);
+int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
+                                int combine, hipStream_t stream);
 size_t prior_decode_scratch_floats(const isi_prior_w *w, int B);
-bool prior_position_supported(const isi_prior_w *w, int B);
-int prior_position_run(const isi_prior_w *w, const isi_prior_state *s, float *q, float *y1, float *y2, float *y3a,
-                       float *y3b, float *hid, float *logits, float *part, unsigned *bar, int p, int want_logits,
-                       hipStream_t st);
 int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin, int p_end, float temperature,
                      int top_k, float top_p, hipStream_t stream);
 

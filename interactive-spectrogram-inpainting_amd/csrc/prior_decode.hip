@@ -1,7 +1,19 @@
 // Native key/value-cached sampling loop of the prior's decoder (gfx950, fp32).
 //
+// Launches per layer at batch 1 (a DEPENDENT launch costs 2.8-3.4 us on this part whatever its work --
+// tools/probes/launch_chain_probe.hip -- and the stages of a decoder layer are a chain, so the count is the budget):
+//   LN + q|k|v row-GEMV (k, v straight into the cache slot) -> self-attention over key splits -> merge of the splits
+//   + out-projection + residual -> LN1 + cross-attention query -> cross-attention over key splits -> merge +
+//   out-projection + residual -> LN2 + linear1 + ReLU -> linear2 + residual.
+// Every stage needs ALL outputs of the one before (a GEMV row feeds every output of the next), so a stage boundary is
+// a device-wide dependency; within one kernel such a dependency (partial rows + a ticket, the last workgroup finishes)
+// was measured dearer than the launch it saves: the release/acquire fences cost 4.5 us and the finishing round trip
+// 5.8 us on this multi-die part (attention + out-projection + residual in one kernel: 22.7 us against 16 us for the
+// three launches; linear1 + linear2: 16.3 against 9.6 us).  What is folded is what needs no dependency of its own: the
+// LayerNorms and the merge of the attention key splits run in the prologue of the consuming GEMV.
+//
 // One call runs, for every sequence position in [p_begin, p_end), the whole
-// decoder stack on ONE new row (10 launches per layer), the logits head, the
+// decoder stack on ONE new row (8 dependent launches per layer, below), the logits head, the
 // categorical draw and the write of the sampled token's embedding into the next
 // input row; the sampled index stays on the device.  Single-stream decoding is
 // bound by the ~85 dependent launches per position, not by their work (a 512x1536
@@ -164,6 +176,177 @@ __global__ __launch_bounds__(256) void row_linear_ln_kernel(RowLinArgs a) {
   }
 }
 
+// ---- batch 1: one row.  No LDS, no barrier: every load of the kernel (weight rows, input row, LayerNorm parameters,
+// bias, residual) is issued before anything is computed, so the kernel is one memory round trip long.  The arithmetic
+// is that of row_linear_ln_kernel operation for operation (a row of a batch and the same row alone give the same bits).
+struct Gemv1Args {
+  RowLinArgs r;
+  const float *part;   // nullable: attention key-split partials [K / HD heads][NS][HD + 4] merged into the input row
+  int NS, HD;
+};
+
+template <int KQ>   // float4 per lane of a K-long row: K <= 256 KQ
+__global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
+  RowLinArgs &a = g.r;
+  if (a.pos) {
+    const long p = *a.pos;
+    a.x += p * a.x_pos;
+    if (a.res) a.res += p * a.res_pos;
+    if (a.out2) a.out2 += p * a.out2_pos;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nq = a.K >> 2;
+  const int n0 = blockIdx.x * NPB + wave * 2;
+  if (n0 >= a.N) return;
+  const bool two = n0 + 1 < a.N;
+  const float4 *w0 = reinterpret_cast<const float4 *>(a.W + (size_t)n0 * a.K);
+  const float4 *w1 = reinterpret_cast<const float4 *>(a.W + (size_t)(two ? n0 + 1 : n0) * a.K);
+  float4 wa[KQ], wb[KQ], xv[KQ], gq[KQ], bq[KQ];
+#pragma unroll
+  for (int i = 0; i < KQ; ++i) {
+    const int qd = lane + 64 * i;
+    if (qd < nq) { wa[i] = w0[qd]; wb[i] = w1[qd]; }
+  }
+  constexpr int PS = KQ <= 2 ? 8 : 1;       // key splits held in registers (merged input: K <= 512)
+  float4 pv[KQ][PS];
+  float pm[KQ][PS], pl[KQ][PS];
+  if (g.part) {
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int qd = lane + 64 * i;
+      if (qd < nq) {
+        const int hh = (4 * qd) / g.HD, c = (4 * qd) % g.HD;
+        const float *base = g.part + (size_t)hh * g.NS * (g.HD + 4);
+#pragma unroll
+        for (int s2 = 0; s2 < PS; ++s2) {
+          if (s2 < g.NS) {
+            pv[i][s2] = *reinterpret_cast<const float4 *>(base + (size_t)s2 * (g.HD + 4) + c);
+            pm[i][s2] = base[(size_t)s2 * (g.HD + 4) + g.HD];
+            pl[i][s2] = base[(size_t)s2 * (g.HD + 4) + g.HD + 1];
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int qd = lane + 64 * i;
+      xv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (qd < nq) {
+        xv[i] = reinterpret_cast<const float4 *>(a.x)[qd];
+        if (a.ln_g) { gq[i] = reinterpret_cast<const float4 *>(a.ln_g)[qd]; bq[i] = reinterpret_cast<const float4 *>(a.ln_b)[qd]; }
+      }
+    }
+  }
+  const int n = n0 + (lane & 1);
+  float bias_v = 0.f, res_v = 0.f, rg = 1.f, rb = 0.f;
+  if (lane < 2 && (lane == 0 || two)) {
+    if (a.bias) bias_v = a.bias[n];
+    if (a.res) res_v = a.res[n];
+    if (a.res && a.res_g) { rg = a.res_g[n]; rb = a.res_b[n]; }
+  }
+  constexpr int RS = 8;                      // residual row for its LayerNorm statistics: N <= 512
+  float rrow[RS];
+  if (a.res && a.res_g) {
+#pragma unroll
+    for (int i = 0; i < RS; ++i) {
+      const int c = lane + 64 * i;
+      rrow[i] = c < a.N ? a.res[c] : 0.f;
+    }
+  }
+  // ---- everything is in flight; compute
+  if (g.part) {
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (lane + 64 * i < nq) {
+        float M = -1e30f;
+#pragma unroll
+        for (int s2 = 0; s2 < PS; ++s2) if (s2 < g.NS) M = fmaxf(M, pm[i][s2]);
+        float4 num = make_float4(0.f, 0.f, 0.f, 0.f);
+        float den = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < PS; ++s2) {
+          if (s2 < g.NS) {
+            const float w = expf(pm[i][s2] - M);
+            num.x += w * pv[i][s2].x; num.y += w * pv[i][s2].y; num.z += w * pv[i][s2].z; num.w += w * pv[i][s2].w;
+            den += w * pl[i][s2];
+          }
+        }
+        xv[i] = make_float4(num.x / den, num.y / den, num.z / den, num.w / den);
+      }
+    }
+  } else if (a.ln_g) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) if (lane + 64 * i < nq) s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    const float mean = wave_sum(s) / (float)a.K;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (lane + 64 * i < nq) {
+        const float d0 = xv[i].x - mean, d1 = xv[i].y - mean, d2 = xv[i].z - mean, d3 = xv[i].w - mean;
+        var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)a.K + a.eps);
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (lane + 64 * i < nq) {
+        xv[i].x = (xv[i].x - mean) * rstd * gq[i].x + bq[i].x; xv[i].y = (xv[i].y - mean) * rstd * gq[i].y + bq[i].y;
+        xv[i].z = (xv[i].z - mean) * rstd * gq[i].z + bq[i].z; xv[i].w = (xv[i].w - mean) * rstd * gq[i].w + bq[i].w;
+      }
+    }
+  }
+  float rmean = 0.f, rrstd = 1.f;
+  if (a.res && a.res_g) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) s += rrow[i];
+    rmean = wave_sum(s) / (float)a.N;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) { const float dv = rrow[i] - rmean; var += dv * dv; }
+    rrstd = 1.0f / sqrtf(wave_sum(var) / (float)a.N + a.eps);
+  }
+  float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < KQ; ++i) {
+    if (lane + 64 * i < nq) {
+      acc0 += (wa[i].x * xv[i].x + wa[i].y * xv[i].y) + (wa[i].z * xv[i].z + wa[i].w * xv[i].w);
+      acc1 += (wb[i].x * xv[i].x + wb[i].y * xv[i].y) + (wb[i].z * xv[i].z + wb[i].w * xv[i].w);
+    }
+  }
+  acc0 = wave_sum(acc0);
+  acc1 = wave_sum(acc1);
+  if (lane < 2 && (lane == 0 || two)) {
+    float v = (lane == 0 ? acc0 : acc1) + bias_v;
+    if (a.res) {
+      float r = res_v;
+      if (a.res_g) r = (r - rmean) * rrstd * rg + rb;
+      v += r;
+    }
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (n < a.split) a.out[n] = v;
+    else a.out2[n - a.split] = v;
+  }
+}
+
+bool row_gemv1_supported(const RowLinArgs &a, bool merged) {
+  if (a.M != 1 || (a.K & 3) || a.K > 2048) return false;
+  if (a.res && a.res_g && a.N > 512) return false;
+  return !merged || a.K <= 512;
+}
+
+int launch_row_gemv1(const RowLinArgs &a, const float *part, int NS, int HD, hipStream_t st) {
+  Gemv1Args g{a, part, NS, HD};
+  dim3 grid((a.N + NPB - 1) / NPB), block(256);
+  if (a.K <= 256) hipLaunchKernelGGL(row_gemv1_kernel<1>, grid, block, 0, st, g);
+  else if (a.K <= 512) hipLaunchKernelGGL(row_gemv1_kernel<2>, grid, block, 0, st, g);
+  else if (a.K <= 1024) hipLaunchKernelGGL(row_gemv1_kernel<4>, grid, block, 0, st, g);
+  else hipLaunchKernelGGL(row_gemv1_kernel<8>, grid, block, 0, st, g);
+  return check_launch("row_gemv1");
+}
+
 int launch_row_linear_8(const RowLinArgs &a, hipStream_t st);
 
 // more than 8 rows (batched serving): groups of 8 rows, one launch each (the kernel stages its rows in LDS)
@@ -250,7 +433,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   float *y3a = y2 + (size_t)B * d, *y3b = y3a + (size_t)B * d, *hid = y3b + (size_t)B * d;
   float *logits = hid + (size_t)B * ff;
   int64_t *sampled = reinterpret_cast<int64_t *>(logits + (size_t)B * w->n_class + ((B * w->n_class) & 1));
-  float *attn_ws = reinterpret_cast<float *>(sampled + B) + 2;
+  float *attn_ws = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(sampled + B) + 8 + 15) & ~(uintptr_t)15);   // 16-byte aligned partial rows
   const size_t cache_layer = (size_t)s->S_t * B * 2 * d, mem_layer = (size_t)s->S_src * B * 2 * d;
   const float scale = 1.0f / sqrtf((float)hd);
 
@@ -260,7 +443,24 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
 
   // Every launch of one position; all position-dependent addresses and sizes are derived on the device
   // from *pos, so the same sequence can be captured once into a hipGraph and replayed per position.
-  auto enqueue_position = [&](bool sample, hipStream_t q_st) -> int {
+  // `p` >= 0: direct launches, the position is passed by value (no dependent load of the counter at the head of
+  // every kernel, no counter update); p < 0: replayable launches reading the device counter.
+  auto enqueue_position = [&](bool sample, int p, hipStream_t q_st) -> int {
+    const int *pos_arg = p < 0 ? pos : nullptr;
+    // `part` != nullptr: the input row is the merge of that attention's key-split partials
+    auto launch_rows = [&](RowLinArgs a, const float *part = nullptr, int ns = 1) -> int {
+      if (p >= 0) {
+        a.x += (long)p * a.x_pos;
+        if (a.res) a.res += (long)p * a.res_pos;
+        if (a.out2) a.out2 += (long)p * a.out2_pos;
+        a.pos = nullptr;
+      }
+      if (row_gemv1_supported(a, part != nullptr)) return launch_row_gemv1(a, part, ns, hd, q_st);
+      return launch_row_linear(a, q_st);
+    };
+    // the attention's splits are merged by the out-projection when that runs as the one-row kernel
+    const int ns_self = rel_attention_decode_splits(s->S_t), ns_cross = rel_attention_decode_splits(s->S_src);
+    const bool merge_in_gemv = B == 1 && d <= 512 && (d & 3) == 0;
     const float *yin = s->x_seq;     // + p * B * d through x_pos / res_pos
     long yin_pos = (long)B * d;
     const float *ln_g = nullptr, *ln_b = nullptr;
@@ -274,7 +474,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       // q | k,v  (k,v straight into the cache slot of this position)
       a = RowLinArgs{yin, d, ln_g, ln_b, L.self_attn.in_proj_weight, L.self_attn.in_proj_bias, nullptr, 0, nullptr,
                      nullptr, q, d, cache, 2 * d, d, B, 3 * d, d, 0, 1e-5f, pos, yin_pos, 0, (long)B * 2 * d};
-      if ((rc = launch_row_linear(a, q_st))) return rc;
+      if ((rc = launch_rows(a))) return rc;
       isi_attn_args g;
       memset(&g, 0, sizeof g);
       g.q = q; g.k = cache; g.v = cache + d; g.rel_embeddings = L.self_attn.rel_embeddings; g.out = ao;
@@ -282,42 +482,46 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       g.q_sb = d; g.q_sh = hd; g.k_ss = (int64_t)B * 2 * d; g.k_sb = 2 * d; g.k_sh = hd;
       g.v_ss = g.k_ss; g.v_sb = g.k_sb; g.v_sh = hd; g.o_sb = d; g.o_sh = hd;
       g.Cq = w->Cd; g.Ck = w->Cd; g.Ek = w->Ed; g.rel_rows = L.self_attn.rel_rows; g.scale = scale;
-      if ((rc = rel_attention_decode_pos_f32(&g, 0, pos, 1, attn_ws, q_st))) return rc;
+      const bool defer_s = merge_in_gemv && ns_self > 1;
+      if ((rc = rel_attention_decode_launch(&g, p < 0 ? 0 : p, pos_arg, 1, attn_ws, defer_s ? 0 : 1, q_st))) return rc;
       // y1 = LN_in(yin) + ao Wo^T + bo
       a = RowLinArgs{ao, d, nullptr, nullptr, L.self_attn.out_proj_weight, L.self_attn.out_proj_bias, yin, d, ln_g,
                      ln_b, y1, d, nullptr, 0, d, B, d, d, 0, 1e-5f, pos, 0, yin_pos, 0};
-      if ((rc = launch_row_linear(a, q_st))) return rc;
+      if ((rc = defer_s ? launch_rows(a, attn_ws, ns_self) : launch_rows(a))) return rc;
       // cross-attention query from LN1(y1)
       a = RowLinArgs{y1, d, L.norm1_w, L.norm1_b, L.cross_attn.in_proj_weight, L.cross_attn.in_proj_bias, nullptr, 0,
                      nullptr, nullptr, q, d, nullptr, 0, d, B, d, d, 0, 1e-5f, nullptr, 0, 0, 0};
-      if ((rc = launch_row_linear(a, q_st))) return rc;
+      if ((rc = launch_rows(a))) return rc;
       g.k = memkv; g.v = memkv + d; g.rel_embeddings = L.cross_attn.rel_embeddings; g.Sk = s->S_src;
       g.Ck = w->Ce; g.Ek = w->Ee; g.rel_rows = L.cross_attn.rel_rows;
-      if ((rc = rel_attention_decode_pos_f32(&g, 0, pos, 0, attn_ws, q_st))) return rc;
+      const bool defer_c = merge_in_gemv && ns_cross > 1;
+      if ((rc = rel_attention_decode_launch(&g, p < 0 ? 0 : p, pos_arg, 0, attn_ws, defer_c ? 0 : 1, q_st))) return rc;
       a = RowLinArgs{ao, d, nullptr, nullptr, L.cross_attn.out_proj_weight, L.cross_attn.out_proj_bias, y1, d,
                      L.norm1_w, L.norm1_b, y2, d, nullptr, 0, d, B, d, d, 0, 1e-5f, nullptr, 0, 0, 0};
-      if ((rc = launch_row_linear(a, q_st))) return rc;
+      if ((rc = defer_c ? launch_rows(a, attn_ws, ns_cross) : launch_rows(a))) return rc;
       // feed-forward on LN2(y2)
       a = RowLinArgs{y2, d, L.norm2_w, L.norm2_b, L.linear1_w, L.linear1_b, nullptr, 0, nullptr, nullptr, hid, ff,
                      nullptr, 0, ff, B, ff, d, 1, 1e-5f, nullptr, 0, 0, 0};
-      if ((rc = launch_row_linear(a, q_st))) return rc;
+      if ((rc = launch_rows(a))) return rc;
       a = RowLinArgs{hid, ff, nullptr, nullptr, L.linear2_w, L.linear2_b, y2, d, L.norm2_w, L.norm2_b, y3, d, nullptr,
                      0, d, B, d, ff, 0, 1e-5f, nullptr, 0, 0, 0};
-      if ((rc = launch_row_linear(a, q_st))) return rc;
+      if ((rc = launch_rows(a))) return rc;
       yin = y3; yin_pos = 0; ln_g = L.norm3_w; ln_b = L.norm3_b;
     }
     if (sample) {
       RowLinArgs a{yin, d, ln_g, ln_b, w->logits_w, w->logits_b, nullptr, 0, nullptr, nullptr, logits, w->n_class,
                    nullptr, 0, w->n_class, B, w->n_class, d, 0, 1e-5f, nullptr, 0, 0, 0};
       int rc;
-      if ((rc = launch_row_linear(a, q_st))) return rc;
-      if ((rc = sample_row_pos_f32(logits, w->n_class, B, w->n_class, temperature, top_k, top_p, s->uniforms, sampled,
-                                   nullptr, pos, i_off, q_st)))
+      if ((rc = launch_rows(a))) return rc;
+      if ((rc = sample_row_pos_f32(logits, w->n_class, B, w->n_class, temperature, top_k, top_p,
+                                   p < 0 ? s->uniforms : s->uniforms + (size_t)(p - i_off) * B, sampled, nullptr, pos_arg,
+                                   i_off, q_st)))
         return rc;
       hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, q_st, sampled, w->embed_table, w->eff_dim,
-                         s->codes, s->S, pos, 0, i_off, s->S_t, s->x_seq, B, d);
+                         s->codes, s->S, pos_arg, p, i_off, s->S_t, s->x_seq, B, d);
       if ((rc = check_launch("commit_token"))) return rc;
     }
+    if (p >= 0) return ISI_OK;
     hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, q_st, pos, 1, 1);
     return check_launch("advance_position");
   };
@@ -328,47 +532,16 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
 
   if (p_begin == p_end) return ISI_OK;
 
-  // ---- ISI_PRIOR_PERSISTENT=1: one persistent cooperative kernel per position (prior_decode_persistent.hip)
-  // followed by the draw and the commit of the sampled token.  Measured on MI355X: 0.89 ms per position
-  // against 0.50 ms for the multi-kernel path below (a software grid barrier plus cache-bypassing exchange
-  // rows cost more than this part's ~4.5 us kernel boundary), so it is not the default.
-  const bool use_persistent = [] { const char *e = getenv("ISI_PRIOR_PERSISTENT"); return e && atoi(e) != 0; }();
-  if (use_persistent && prior_position_supported(w, B)) {
-    unsigned *bar = reinterpret_cast<unsigned *>(pos + 4);
-    if (hipMemsetAsync(bar, 0, 4 * sizeof(unsigned), st) != hipSuccess) return check_launch("hipMemsetAsync(barrier)");
-    for (int p = p_begin; p < p_end; ++p) {
-      const bool smp = sampled_at(p);
-      int rc = prior_position_run(w, s, q, y1, y2, y3a, y3b, hid, logits, attn_ws, bar, p, smp ? 1 : 0, st);
-      if (rc) return rc;
-      if (!smp) continue;
-      const int i = p - i_off;
-      if ((rc = sample_row_f32(logits, w->n_class, B, w->n_class, temperature, top_k, top_p,
-                               s->uniforms + (size_t)i * B, sampled, nullptr, st)))
-        return rc;
-      hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, st, sampled, w->embed_table, w->eff_dim,
-                         s->codes, s->S, static_cast<const int *>(nullptr), p, i_off, s->S_t, s->x_seq, B, d);
-      if ((rc = check_launch("commit_token"))) return rc;
-    }
-    unsigned flag = 0;   // a grid barrier that gave up (spin limit) leaves garbage behind: report it
-    if (hipMemcpyAsync(&flag, bar + 2, sizeof flag, hipMemcpyDeviceToHost, st) != hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-      return check_launch("prior_position: reading the barrier status");
-    if (flag) { set_last_error("prior_position: grid barrier timed out"); return ISI_E_LAUNCH; }
-    return ISI_OK;
-  }
-
-  hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, p_begin, 0);
-  int rc = check_launch("set_position");
-  if (rc) return rc;
   // the first position runs directly (it also performs the one-time kernel attribute set-up) ...
-  if ((rc = enqueue_position(sampled_at(p_begin), st))) return rc;
+  int rc;
+  if ((rc = enqueue_position(sampled_at(p_begin), p_begin, st))) return rc;
   int p = p_begin + 1;
-  // ... the rest can replay two captured graphs (with / without the sampling tail; ISI_PRIOR_GRAPH=1):
-  // ~85 launches per position collapse into one graph launch.  Measured on MI355X: no gain (1.93 k vs
-  // 1.96 k codes/s) -- the loop is bound by the GPU-side duration of the dependent kernels (4.5-9 us
-  // each in the kernel trace, profiles/), not by host launch cost -- so direct launches stay the default.
+  // ... the rest can replay two captured graphs (with / without the sampling tail; ISI_PRIOR_GRAPH=1): the launches
+  // of a position collapse into one graph launch, every position-dependent address read from a device counter.
   const bool use_graph = [] { const char *e = getenv("ISI_PRIOR_GRAPH"); return e && atoi(e) != 0; }();
   if (use_graph && p_end - p >= 4) {
+    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, p, 0);
+    if ((rc = check_launch("set_position"))) return rc;
     hipStream_t cap = nullptr;
     hipGraph_t graphs[2] = {nullptr, nullptr};
     hipGraphExec_t execs[2] = {nullptr, nullptr};
@@ -376,7 +549,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
     for (int k = 0; ok && k < 2; ++k) {
       ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
       if (!ok) break;
-      const int erc = enqueue_position(k == 1, cap);
+      const int erc = enqueue_position(k == 1, -1, cap);
       hipGraph_t gph = nullptr;
       const bool ended = hipStreamEndCapture(cap, &gph) == hipSuccess;
       graphs[k] = gph;
@@ -397,7 +570,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
     if (rc) return rc;
   }
   for (; p < p_end; ++p)
-    if ((rc = enqueue_position(sampled_at(p), st))) return rc;
+    if ((rc = enqueue_position(sampled_at(p), p, st))) return rc;
   return ISI_OK;
 }
 

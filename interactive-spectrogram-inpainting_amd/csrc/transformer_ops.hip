@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   Sk = min(Sk - kbeg, chunk);         // local key count
   if (Sk <= 0) {                      // empty split (only with a fixed split count): neutral partial
     if (gridDim.z > 1 && tid < HD) {
-      float *pp = partial + (((size_t)b * gridDim.x + h) * gridDim.z + blockIdx.z) * (HD + 2);
+      float *pp = partial + (((size_t)b * gridDim.x + h) * gridDim.z + blockIdx.z) * (HD + 4);
       pp[tid] = 0.f;
       if (tid == 0) { pp[HD] = -1e30f; pp[HD + 1] = 0.f; }
     }
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     if (gridDim.z == 1) {
       out[b * o_sb + h * o_sh + tid] = acc / gsum;
     } else {
-      float *pp = partial + (((size_t)b * gridDim.x + h) * gridDim.z + blockIdx.z) * (HD + 2);
+      float *pp = partial + (((size_t)b * gridDim.x + h) * gridDim.z + blockIdx.z) * (HD + 4);
       pp[tid] = acc;
       if (tid == 0) { pp[HD] = gmax; pp[HD + 1] = gsum; }
     }
@@ -287,14 +287,14 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
 __global__ void rel_attention_combine_kernel(const float *__restrict__ partial, float *__restrict__ out,
                                              int HD, int NS, int64_t o_sb, int64_t o_sh) {
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-  const float *pp = partial + ((size_t)b * gridDim.x + h) * NS * (HD + 2);
+  const float *pp = partial + ((size_t)b * gridDim.x + h) * NS * (HD + 4);
   float M = -1e30f;
-  for (int s = 0; s < NS; ++s) M = fmaxf(M, pp[s * (HD + 2) + HD]);
+  for (int s = 0; s < NS; ++s) M = fmaxf(M, pp[s * (HD + 4) + HD]);
   float num = 0.f, den = 0.f;
   for (int s = 0; s < NS; ++s) {
-    const float w = expf(pp[s * (HD + 2) + HD] - M);
-    num += w * pp[s * (HD + 2) + d];
-    den += w * pp[s * (HD + 2) + HD + 1];
+    const float w = expf(pp[s * (HD + 4) + HD] - M);
+    num += w * pp[s * (HD + 4) + d];
+    den += w * pp[s * (HD + 4) + HD + 1];
   }
   out[b * o_sb + h * o_sh + d] = num / den;
 }
@@ -302,7 +302,7 @@ __global__ void rel_attention_combine_kernel(const float *__restrict__ partial, 
 int rel_attention_decode_splits(int Sk) { return Sk <= 192 ? 1 : (Sk + 127) / 128 > 8 ? 8 : (Sk + 127) / 128; }
 
 size_t rel_attention_decode_workspace_floats(int B, int H, int head_dim) {
-  return (size_t)B * H * 8 * (head_dim + 2);
+  return (size_t)B * H * 8 * (head_dim + 4);
 }
 
 int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, float *workspace, hipStream_t stream) {
@@ -313,12 +313,24 @@ int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, float *workspace
 // self_keys the key count is position + 1 and g->Sk is its upper bound (it fixes grid and LDS sizes).
 int rel_attention_decode_pos_f32(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
                                  hipStream_t stream) {
+  return rel_attention_decode_launch(g, q_pos, pos, self_keys, workspace, /*combine*/ 1, stream);
+}
+
+// combine = 0: with several key splits the partials ([B, H, splits, head_dim + 4]: un-normalised output, then the
+// split's maximum and sum) stay in `workspace` for the caller to merge (the decoding loop merges them in the prologue
+// of the out-projection: one dependent launch less); g->out is then not written.
+int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
+                                int combine, hipStream_t stream) {
   if (!g || !g->q || !g->k || !g->v || !g->out) return invalid("attention_decode: null pointer");
   if (g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->Cq <= 0 || g->Ck <= 0) return invalid("attention_decode: bad shape");
   if (g->Sk > 65536) return unsupported("attention_decode: more than 65536 keys");
   const int ns = workspace ? rel_attention_decode_splits(g->Sk) : 1;
-  const int chunk = (g->Sk + ns - 1) / ns;
-  const size_t smem = (size_t)(8 + 256 * 4 + chunk) * sizeof(float);  // red + part[256/G][HD] + scores
+  // self_keys with the position by value: position + 1 keys, shared by the split count of the upper bound g->Sk
+  // (the same split as the replayable form derives on the device)
+  const int Sk = (self_keys && !pos) ? q_pos + 1 : g->Sk;
+  if (Sk > g->Sk) return invalid("attention_decode: position beyond the key capacity");
+  const int chunk = (Sk + ns - 1) / ns;
+  const size_t smem = (size_t)(8 + 256 * 4 + (g->Sk + ns - 1) / ns) * sizeof(float);  // red + part[256/G][HD] + scores
   dim3 grid(g->H, g->B, ns), block(256);
 #define ISI_DEC(HD)                                                                                         \
   do {                                                                                                      \
@@ -327,7 +339,7 @@ int rel_attention_decode_pos_f32(const isi_attn_args *g, int q_pos, const int *p
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)smem) != hipSuccess)                                                       \
       return check_launch("hipFuncSetAttribute(attention_decode)");                                         \
-    hipLaunchKernelGGL(kern, grid, block, smem, stream, g->q, g->k, g->v, g->rel_embeddings, g->out, g->Sk, \
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, g->q, g->k, g->v, g->rel_embeddings, g->out, Sk,    \
                        g->q_sb, g->q_sh, g->k_ss, g->k_sb, g->k_sh, g->v_ss, g->v_sb, g->v_sh, g->o_sb,     \
                        g->o_sh, q_pos, g->Cq, g->Ck, g->Ek, g->rel_rows, g->scale, chunk, workspace, pos,  \
                        self_keys);                                                                          \
@@ -340,7 +352,7 @@ int rel_attention_decode_pos_f32(const isi_attn_args *g, int q_pos, const int *p
   }
 #undef ISI_DEC
   int rc = check_launch("rel_attention_decode_f32");
-  if (rc || ns == 1) return rc;
+  if (rc || ns == 1 || !combine) return rc;
   hipLaunchKernelGGL(rel_attention_combine_kernel, dim3(g->H, g->B), dim3(g->head_dim), 0, stream, workspace,
                      g->out, g->head_dim, ns, g->o_sb, g->o_sh);
   return check_launch("rel_attention_combine");

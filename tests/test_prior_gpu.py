@@ -263,9 +263,9 @@ def test_sample_model_matches_full_pass_sampling(golden_dir):
     ref = top.target_codemaps_helper.to_time_frequency_map(seq)
     assert torch.equal(got, ref)
     # the opt-in execution modes of the decoding loop (hipGraph replay of the per-position launch
-    # sequence; one persistent cooperative kernel per position) draw the same codes
+    # sequence) draws the same codes
     import os
-    for var in ("ISI_PRIOR_GRAPH", "ISI_PRIOR_PERSISTENT"):
+    for var in ("ISI_PRIOR_GRAPH",):
         os.environ[var] = "1"
         try:
             alt = S.sample_model(top, dev, B, [8, 4], temperature=0.9, class_conditioning=cls,

@@ -154,17 +154,131 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
 }
 
 
-// ---- split-f16 distances (ISI_CONV_F16X3; D = 64): z.e_k as hi.hi + hi.lo + lo.hi of two 11-bit f16 pieces of
-// 4 z and 1024 e (per-product error ~2^-23, the scaling undone exactly) on v_mfma_f32_32x32x16_f16: 12 MFMAs of
-// 8 passes per 32 codes instead of 32 MFMAs of 16 passes on the fp32 pipe, which bounds the exact kernel
-// (2 N K D flops at 157 TFLOP/s).  The codebook lives in LDS as two f16 planes [K][64] (128 KiB at K = 512; the
-// eight 16-B slots of a row are XOR-swizzled with (row >> 1) & 7: conflict-free ds_read_b128); the fp32 code
-// vector of the winner is re-read from global memory (L2) for q and the squared error.  Same operand swap,
-// association of d, tie rule and outputs as the exact kernel; ranges as for the convolutions (|z| < 16384,
-// |e| < 64; beyond: non-finite distances -> index -1).
+// ---- search on the f16 matrix pipe, decision in exact fp32 (ISI_CONV_F16X3; D = 64, both f16 planes of the
+// codebook in LDS: K <= 512).  The exact kernel above is bound by the fp32 matrix pipe (2 N K D flops at 157 TFLOP/s:
+// 32 MFMAs of 16 passes per 32 codes).  Here the K distances of a vector are computed with split-f16 products
+// (hi.hi + hi.lo + lo.hi of two 11-bit f16 pieces of 4 z and 1024 e on v_mfma_f32_32x32x16_f16: 12 MFMAs of 8
+// passes per 32 codes, error ~2^-22 |z||e|) ONLY to find the two best candidates; the distances of those two are
+// then recomputed in plain fp32 from the fp32 code vectors (re-read from memory, L2) -- |z|^2 - 2 z.e + |e|^2 with
+// the reference's association (bottleneck.py:54-58), z.e as a fixed-order fp32 sum -- and the smaller one wins
+// (ties: lower index).  The decision is therefore an fp32 one, like the reference's: index disagreement with the
+// CPU reference stays at the level of the reference's own rounding (tools/index_flips.py), not that of the f16
+// split.  (A third code within 2^-22 |z||e| of the best two would escape; not observed.)
+// Codebook planes in LDS: [Kp][64] f16 each, a row's eight 16-byte slots XOR-swizzled with (row >> 1) & 7
+// (conflict-free ds_read_b128); slot 2 s + h holds the 8 channels lane half h feeds to k-step s:
+// quads 4 s + h and 4 s + 2 + h -- the channels a lane of the fused kernel below owns after its 1x1 convolution.
+// A lane (col = vector, h = lane >> 5) holds the vector's quads zq[j] = quad 2 j + h.  Ranges as for the
+// convolutions (|z| < 16384, |e| < 64; beyond: non-finite distances -> index -1).
 typedef f16s::f16x8 vq_f16x8;
 constexpr float kVqScaleZ = f16s::kScaleA, kVqScaleE = f16s::kScaleB, kVqUnscale = f16s::kUnscale;
 __device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
+
+// fills the two planes (and |e|^2, histogram) of a workgroup
+__device__ __forceinline__ void vq_fill_planes(unsigned short *cbh, unsigned short *cbl, float *e2, int *hist,
+                                               const float *__restrict__ codes, const float *__restrict__ e2g, int K,
+                                               int Kp, int tid) {
+  constexpr int D = 64;
+  for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
+    const int k = i >> 4, qd = i & 15;
+    uint2 hi, lo;
+    vq_split4(k < K ? *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f),
+              kVqScaleE, hi, lo);
+    const int slot = 2 * (qd >> 2) + (qd & 1), second = (qd >> 1) & 1;
+    const int wo = k * D + ((slot ^ ((k >> 1) & 7)) * 8) + second * 4;
+    *reinterpret_cast<uint2 *>(cbh + wo) = hi;
+    *reinterpret_cast<uint2 *>(cbl + wo) = lo;
+  }
+  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : INFINITY; hist[i] = 0; }
+}
+
+__device__ __forceinline__ float vq_quad_dot(const float4 a, const float4 b) {
+  return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+}
+
+// Returns the index of the nearest code of this lane pair's vector (-1: no finite distance) and, in `ew`, this lane's
+// quads of the winner's fp32 code vector.
+__device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const unsigned short *cbl, const float *e2, int Kp,
+                                             int K, const float *__restrict__ codes, const float4 (&zq)[8], int col,
+                                             int half, float4 (&ew)[8]) {
+  constexpr int D = 64;
+  s16x8v zh[4], zl[4];
+  float x2p = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x2p += zq[j].x * zq[j].x + zq[j].y * zq[j].y + zq[j].z * zq[j].z + zq[j].w * zq[j].w;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    uint2 h0, l0, h1, l1;
+    vq_split4(zq[2 * s], kVqScaleZ, h0, l0);
+    vq_split4(zq[2 * s + 1], kVqScaleZ, h1, l1);
+    zh[s] = __builtin_bit_cast(s16x8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    zl[s] = __builtin_bit_cast(s16x8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
+  }
+  const float x2 = x2p + __shfl_xor(x2p, 32);
+  // ---- candidates: the two smallest split-f16 distances (ties: the code met first, i.e. the lower index)
+  float b1 = INFINITY, b2 = INFINITY;
+  int i1 = 0, i2 = 0;
+  for (int kt = 0; kt < Kp; kt += 32) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int row = kt + col;
+    const int sw = (row >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off = row * D + (((2 * s + half) ^ sw) * 8);
+      const s16x8v ah = *reinterpret_cast<const s16x8v *>(cbh + off);
+      const s16x8v al = *reinterpret_cast<const s16x8v *>(cbl + off);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zl[s]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int code = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const float d = (x2 - 2.f * (acc[r] * kVqUnscale)) + e2[code];
+      const bool l1 = d < b1, l2 = d < b2;
+      i2 = l1 ? i1 : (l2 ? code : i2);
+      b2 = l1 ? b1 : (l2 ? d : b2);
+      i1 = l1 ? code : i1;
+      b1 = l1 ? d : b1;
+    }
+  }
+  {  // merge the two halves' candidates (strict order on (distance, index): both lanes end with the same pair)
+    const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
+    const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
+#define ISI_VQ_INSERT(DV, CV)                                                          \
+    do {                                                                               \
+      if ((DV) < b1 || ((DV) == b1 && (CV) < i1)) { b2 = b1; i2 = i1; b1 = (DV); i1 = (CV); } \
+      else if ((DV) < b2 || ((DV) == b2 && (CV) < i2)) { b2 = (DV); i2 = (CV); }       \
+    } while (0)
+    ISI_VQ_INSERT(o1, j1);
+    ISI_VQ_INSERT(o2, j2);
+#undef ISI_VQ_INSERT
+  }
+  if (!(b1 < INFINITY)) return -1;
+  // ---- decision in fp32 on the two candidates
+  const bool has2 = b2 < INFINITY && i2 < K && i2 != i1;
+  const float *r1 = codes + (size_t)i1 * D + half * 4, *r2 = codes + (size_t)(has2 ? i2 : i1) * D + half * 4;
+  float4 e2q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ew[j] = *reinterpret_cast<const float4 *>(r1 + j * 8);
+    e2q[j] = *reinterpret_cast<const float4 *>(r2 + j * 8);
+  }
+  float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { p1 += vq_quad_dot(ew[j], zq[j]); p2 += vq_quad_dot(e2q[j], zq[j]); }
+  const float q1 = __shfl_xor(p1, 32), q2 = __shfl_xor(p2, 32);
+  const float dot1 = half ? q1 + p1 : p1 + q1, dot2 = half ? q2 + p2 : p2 + q2;   // lower half first on both lanes
+  const float d1 = (x2 - 2.f * dot1) + e2[i1];
+  const float d2 = has2 ? (x2 - 2.f * dot2) + e2[i2] : INFINITY;
+  if (d2 < d1 || (d2 == d1 && i2 < i1)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ew[j] = e2q[j];
+    return i2;
+  }
+  return i1;
+}
 
 __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
     const float *__restrict__ z, const float *__restrict__ codes, const float *__restrict__ e2g,
@@ -185,16 +299,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
   const int col = lane & 31;
   const int half = lane >> 5;
 
-  for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
-    const int k = i >> 4, qd = i & 15;
-    uint2 hi, lo;
-    vq_split4(k < K ? *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f),
-              kVqScaleE, hi, lo);
-    const int wo = k * D + (((qd >> 1) ^ ((k >> 1) & 7)) * 8) + (qd & 1) * 4;
-    *reinterpret_cast<uint2 *>(cbh + wo) = hi;
-    *reinterpret_cast<uint2 *>(cbl + wo) = lo;
-  }
-  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : INFINITY; hist[i] = 0; }
+  vq_fill_planes(cbh, cbl, e2, hist, codes, e2g, K, Kp, tid);
   __syncthreads();
 
   float sse = 0.f;
@@ -202,73 +307,25 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
   for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
     const bool valid = n < N;
-    // this lane's 8 quads of z_n: k-step s covers components 16 s + 8 half .. + 8 (quads 4 s + 2 half, + 1)
-    float4 zq[8];
-    s16x8v zh[4], zl[4];
-    float x2p = 0.f;
+    float4 zq[8], ew[8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      uint2 h0, l0, h1, l1;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) v = *reinterpret_cast<const float4 *>(z + n * D + (4 * s + 2 * half + e) * 4);
-        zq[2 * s + e] = v;
-        x2p += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-      }
-      vq_split4(zq[2 * s], kVqScaleZ, h0, l0);
-      vq_split4(zq[2 * s + 1], kVqScaleZ, h1, l1);
-      zh[s] = __builtin_bit_cast(s16x8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
-      zl[s] = __builtin_bit_cast(s16x8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
-    }
-    const float x2 = x2p + __shfl_xor(x2p, 32);
-
-    float best = INFINITY;
-    int besti = 0;
-    for (int kt = 0; kt < Kp; kt += 32) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const int row = kt + col;
-      const int sw = (row >> 1) & 7;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int off = row * D + (((2 * s + half) ^ sw) * 8);
-        const s16x8v ah = *reinterpret_cast<const s16x8v *>(cbh + off);
-        const s16x8v al = *reinterpret_cast<const s16x8v *>(cbl + off);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zl[s]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int code = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float d = (x2 - 2.f * (acc[r] * kVqUnscale)) + e2[code];
-        if (d < best) { best = d; besti = code; }
-      }
-    }
-    {
-      const float ob = __shfl_xor(best, 32);
-      const int oi = __shfl_xor(besti, 32);
-      if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-    }
-    const bool lost = !(best < INFINITY);
-    if (valid && lost) {
+    for (int j = 0; j < 8; ++j)
+      zq[j] = valid ? *reinterpret_cast<const float4 *>(z + n * D + (2 * j + half) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int besti = vq_search_f16(cbh, cbl, e2, Kp, K, codes, zq, col, half, ew);
+    if (valid && besti < 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        *reinterpret_cast<float4 *>(q_out + n * D + (4 * (j >> 1) + 2 * half + (j & 1)) * 4) = make_float4(NAN, NAN, NAN, NAN);
+        *reinterpret_cast<float4 *>(q_out + n * D + (2 * j + half) * 4) = make_float4(NAN, NAN, NAN, NAN);
       sse = NAN;
       if (half == 0) idx_out[n] = -1;
     } else if (valid) {
-      const float *crow = codes + (size_t)besti * D;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int qd = 4 * (j >> 1) + 2 * half + (j & 1);
-        const float4 e = *reinterpret_cast<const float4 *>(crow + qd * 4);
+        const float4 e = ew[j];
         const float4 v = zq[j];
         float4 dq = make_float4(e.x - v.x, e.y - v.y, e.z - v.z, e.w - v.w);
         sse += dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w;
-        *reinterpret_cast<float4 *>(q_out + n * D + qd * 4) = make_float4(v.x + dq.x, v.y + dq.y, v.z + dq.z, v.w + dq.w);
+        *reinterpret_cast<float4 *>(q_out + n * D + (2 * j + half) * 4) = make_float4(v.x + dq.x, v.y + dq.y, v.z + dq.z, v.w + dq.w);
       }
       if (half == 0) {
         idx_out[n] = besti;
@@ -334,12 +391,13 @@ __global__ void vq_weight_fragments_kernel(const uint4 *__restrict__ w16, uint4 
 }
 
 __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFusedArgs p) {
-  constexpr int D = 64, LDD = D + 4, NQ = D / 8;
+  constexpr int D = 64, NQ = D / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int K = p.K;
   const int Kp = (K + 31) & ~31;
-  float *cb = smem;
-  float *e2 = smem + (size_t)Kp * LDD;
+  unsigned short *cbh = reinterpret_cast<unsigned short *>(smem);   // [Kp][64] hi pieces
+  unsigned short *cbl = cbh + (size_t)Kp * D;                       // [Kp][64] lo pieces
+  float *e2 = reinterpret_cast<float *>(cbl + (size_t)Kp * D);      // [Kp]
   float *red = e2 + Kp;
   int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);
 
@@ -349,12 +407,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
   const int col = lane & 31;
   const int half = lane >> 5;
 
-  for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
-    const int k = i / (D / 4), qd = i - k * (D / 4);
-    *reinterpret_cast<float4 *>(cb + (size_t)k * LDD + qd * 4) =
-        k < K ? *reinterpret_cast<const float4 *>(p.codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? p.e2[i] : INFINITY; hist[i] = 0; }
+  vq_fill_planes(cbh, cbl, e2, hist, p.codes, p.e2, K, Kp, tid);
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in0), 0, p.in0_bytes, 0x00020000);
@@ -421,8 +474,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
 #undef ISI_VQ_MF
       }
     }
-    float4 zq[NQ];
-    float x2p = 0.f;
+    float4 zq[NQ], ew[NQ];
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       const int t = j >> 2, r0 = (j & 3) * 4;
@@ -430,39 +482,10 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
                              zt[t][r0 + 2] * kVqUnscale + bq[j].z, zt[t][r0 + 3] * kVqUnscale + bq[j].w);
       if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
       zq[j] = v;
-      x2p += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
-    const float x2 = x2p + __shfl_xor(x2p, 32);
-
-    // ---- search (identical to vq_nearest_kernel)
-    float best = INFINITY;
-    int besti = 0;
-    for (int kt = 0; kt < Kp; kt += 32) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float *arow = cb + (size_t)(kt + col) * LDD + half * 4;
-#pragma unroll
-      for (int j = 0; j < NQ; ++j) {
-        const float4 a = *reinterpret_cast<const float4 *>(arow + j * 8);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zq[j].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zq[j].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zq[j].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zq[j].w, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int code = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const float d = (x2 - 2.f * acc[r]) + e2[code];
-        if (d < best) { best = d; besti = code; }
-      }
-    }
-    {
-      const float ob = __shfl_xor(best, 32);
-      const int oi = __shfl_xor(besti, 32);
-      if (ob < best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-    }
-    const bool lost = !(best < INFINITY);
+    // ---- search (vq_search_f16: candidates on the f16 pipe, decision in fp32; shared with the stand-alone kernel)
+    const int besti = vq_search_f16(cbh, cbl, e2, Kp, K, p.codes, zq, col, half, ew);
+    const bool lost = besti < 0;
     if (valid && lost) {
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
@@ -475,10 +498,9 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
       sse = NAN;
       if (half == 0) p.idx[n] = -1;
     } else if (valid) {
-      const float *crow = cb + (size_t)besti * LDD + half * 4;
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
-        const float4 e = *reinterpret_cast<const float4 *>(crow + j * 8);
+        const float4 e = ew[j];
         const float4 v = zq[j];
         float4 dq = make_float4(e.x - v.x, e.y - v.y, e.z - v.z, e.w - v.w);
         sse += dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w;
@@ -558,6 +580,10 @@ __global__ void embed_code_kernel(const int64_t *__restrict__ idx, const float *
   reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(codes)[k * D4 + qd];
 }
 
+static size_t vq_planes_lds_bytes(int Kp) {
+  return (size_t)Kp * 64 * 2 * sizeof(unsigned short) + ((size_t)2 * Kp + ISI_VQ_WAVES) * sizeof(float);
+}
+
 static int vq_grid(int64_t N) {
   const int64_t n_iter = (N + VQ_VEC_PER_BLOCK_ITER - 1) / VQ_VEC_PER_BLOCK_ITER;
   return (int)(n_iter < 256 ? (n_iter < 1 ? 1 : n_iter) : 256);
@@ -587,7 +613,7 @@ static int launch_vq(const float *z, const float *codes, const float *e2, int64_
 static int launch_vq_f16x3(const float *z, const float *codes, const float *e2, int64_t *idx, float *q,
                            int32_t *counts, float *sse_part, int64_t N, int K, hipStream_t stream) {
   const int Kp = (K + 31) & ~31;
-  const size_t smem = (size_t)Kp * 64 * 2 * sizeof(unsigned short) + ((size_t)2 * Kp + ISI_VQ_WAVES) * sizeof(float);
+  const size_t smem = vq_planes_lds_bytes(Kp);
   auto kern = vq_nearest_f16x3_kernel;
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -626,7 +652,7 @@ int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t 
 // D = 64; the weight is the packed 1x1 weight's blocked pair copy (ISI_CONV_W16: packed_w + Cout * Kpad floats).
 bool vq_conv1x1_fusable(int C0, int C1, int D, int K) {
   const int Kp = (K + 31) & ~31;
-  return D == 64 && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && ((size_t)Kp * (D + 4) + 2 * Kp + ISI_VQ_WAVES) * sizeof(float) <= 150 * 1024;
+  return D == 64 && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && vq_planes_lds_bytes(Kp) <= 150 * 1024;
 }
 
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D) { return (size_t)D * round_up((size_t)(C0 + C1), kBK); }
@@ -655,7 +681,7 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
   if (two) { a.s1n = (int)s1->sn; a.s1h = (int)s1->sh; a.s1w = (int)s1->sw; }
   a.H = H; a.W = W; a.N = N; a.K = K;
   const int Kp = (K + 31) & ~31;
-  const size_t smem = ((size_t)Kp * (D + 4) + 2 * Kp + ISI_VQ_WAVES) * sizeof(float);
+  const size_t smem = vq_planes_lds_bytes(Kp);
   a.wfrag = workspace;
   {
     const int nstep = a.Kpad / 16, total = nstep * 256;

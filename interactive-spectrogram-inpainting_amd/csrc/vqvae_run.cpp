@@ -289,11 +289,9 @@ int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *
                   int32_t *counts, float *sse_part, float *scalars2, int flags, hipStream_t st) {
   if (hipMemsetAsync(counts, 0, (size_t)cb.K * sizeof(int32_t), st) != hipSuccess)
     return check_launch("hipMemsetAsync(counts)");
-  // The split-f16 distance kernel (vq_nearest.hip) saves 40 us of a 2.5 ms forward at B = 64 but moves a third more
-  // near-tie indices away from the CPU reference's (69 instead of 53 of 24576 top codes; the exact-fp32 pipe: 55):
-  // the quantisers stay on the exact pipe unless ISI_VQ_SPLIT_F16 is set (measurements).
-  static const bool vq_split = getenv("ISI_VQ_SPLIT_F16") != nullptr;
-  int rc = vq_nearest_f32(z, cb.codes_kd, cb.e2, idx, q, counts, sse_part, N, cb.D, cb.K, vq_split ? flags : 0, st);
+  // With ISI_CONV_F16X3 (the split-f16 mode) the K distances are computed on the f16 matrix pipe only to pick two
+  // candidates; the decision between them is taken in fp32 (vq_nearest.hip) -- the same search as the fused kernel's.
+  int rc = vq_nearest_f32(z, cb.codes_kd, cb.e2, idx, q, counts, sse_part, N, cb.D, cb.K, flags, st);
   if (rc) return rc;
   return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);
 }

@@ -195,16 +195,14 @@ __device__ __forceinline__ float vq_quad_dot(const float4 a, const float4 b) {
   return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
 }
 
-// Returns the index of the nearest code of this lane pair's vector (-1: no finite distance) and, in `ew`, this lane's
-// quads of the winner's fp32 code vector.
-__device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const unsigned short *cbl, const float *e2, int Kp,
-                                             int K, const float *__restrict__ codes, const float4 (&zq)[8], int col,
-                                             int half, float4 (&ew)[8]) {
+// The two best candidates of this lane pair's vector by split-f16 distance.  Candidates are ranked by
+// s_k = |e_k|^2 - 2 z.e_k (|z|^2 is common to all codes of a vector); per value: one fma, two compares, v_min, v_med3
+// and three selects, the code number carried as the wave-uniform part (the lane's + 4 half is added at the end).
+struct VqCand { float b1, b2; int i1, i2; };
+__device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, const unsigned short *cbl, const float *e2,
+                                                    int Kp, const float4 (&zq)[8], int col, int half) {
   constexpr int D = 64;
   s16x8v zh[4], zl[4];
-  float x2p = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x2p += zq[j].x * zq[j].x + zq[j].y * zq[j].y + zq[j].z * zq[j].z + zq[j].w * zq[j].w;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     uint2 h0, l0, h1, l1;
@@ -213,8 +211,6 @@ __device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const un
     zh[s] = __builtin_bit_cast(s16x8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
     zl[s] = __builtin_bit_cast(s16x8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
   }
-  const float x2 = x2p + __shfl_xor(x2p, 32);
-  // ---- candidates: the two smallest split-f16 distances (ties: the code met first, i.e. the lower index)
   float b1 = INFINITY, b2 = INFINITY;
   int i1 = 0, i2 = 0;
   for (int kt = 0; kt < Kp; kt += 32) {
@@ -232,18 +228,21 @@ __device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const un
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zl[s]), acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
     }
+    const float *e2t = e2 + kt + 4 * half;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int code = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-      const float d = (x2 - 2.f * (acc[r] * kVqUnscale)) + e2[code];
-      const bool l1 = d < b1, l2 = d < b2;
-      i2 = l1 ? i1 : (l2 ? code : i2);
-      b2 = l1 ? b1 : (l2 ? d : b2);
-      i1 = l1 ? code : i1;
-      b1 = l1 ? d : b1;
+      const int cu = kt + (r & 3) + 8 * (r >> 2);              // uniform part of the code number
+      const float d = __builtin_fmaf(acc[r], -2.f * kVqUnscale, e2t[(r & 3) + 8 * (r >> 2)]);
+      const bool l1 = d < b1, l2 = d < b2;                     // NaN: neither
+      i2 = l1 ? i1 : (l2 ? cu : i2);
+      b2 = __builtin_amdgcn_fmed3f(d, b1, b2);                 // b1 <= b2: d < b1 -> b1, b1 <= d < b2 -> d, else b2
+      i1 = l1 ? cu : i1;
+      b1 = __builtin_fminf(d, b1);
     }
   }
-  {  // merge the two halves' candidates (strict order on (distance, index): both lanes end with the same pair)
+  i1 += 4 * half;
+  i2 += 4 * half;
+  {  // merge the two halves' candidates (strict order on (value, index): both lanes end with the same pair)
     const float o1 = __shfl_xor(b1, 32), o2 = __shfl_xor(b2, 32);
     const int j1 = __shfl_xor(i1, 32), j2 = __shfl_xor(i2, 32);
 #define ISI_VQ_INSERT(DV, CV)                                                          \
@@ -255,9 +254,17 @@ __device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const un
     ISI_VQ_INSERT(o2, j2);
 #undef ISI_VQ_INSERT
   }
-  if (!(b1 < INFINITY)) return -1;
-  // ---- decision in fp32 on the two candidates
-  const bool has2 = b2 < INFINITY && i2 < K && i2 != i1;
+  return VqCand{b1, b2, i1, i2};
+}
+
+// The decision, in fp32, between the two candidates: returns the index of the nearest code (-1: no finite distance)
+// and, in `ew`, this lane's quads of the winner's fp32 code vector.
+__device__ __forceinline__ int vq_decide_f32(const VqCand c, const float *e2, int K, const float *__restrict__ codes,
+                                             const float4 (&zq)[8], int half, float4 (&ew)[8]) {
+  constexpr int D = 64;
+  if (!(c.b1 < INFINITY)) return -1;
+  const int i1 = c.i1, i2 = c.i2;
+  const bool has2 = c.b2 < INFINITY && i2 < K && i2 != i1;
   const float *r1 = codes + (size_t)i1 * D + half * 4, *r2 = codes + (size_t)(has2 ? i2 : i1) * D + half * 4;
   float4 e2q[8];
 #pragma unroll
@@ -265,6 +272,10 @@ __device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const un
     ew[j] = *reinterpret_cast<const float4 *>(r1 + j * 8);
     e2q[j] = *reinterpret_cast<const float4 *>(r2 + j * 8);
   }
+  float x2p = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x2p += zq[j].x * zq[j].x + zq[j].y * zq[j].y + zq[j].z * zq[j].z + zq[j].w * zq[j].w;
+  const float x2 = x2p + __shfl_xor(x2p, 32);
   float p1 = 0.f, p2 = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { p1 += vq_quad_dot(ew[j], zq[j]); p2 += vq_quad_dot(e2q[j], zq[j]); }
@@ -278,6 +289,12 @@ __device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const un
     return i2;
   }
   return i1;
+}
+
+__device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const unsigned short *cbl, const float *e2, int Kp,
+                                             int K, const float *__restrict__ codes, const float4 (&zq)[8], int col,
+                                             int half, float4 (&ew)[8]) {
+  return vq_decide_f32(vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half), e2, K, codes, zq, half, ew);
 }
 
 __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
@@ -377,6 +394,7 @@ struct VqFusedArgs {
   int H, W;                             // pixel grid: vector n = (b H + y) W + x
   int64_t N;
   int K;
+  int dbg;                              // measurements only (ISI_VQ_DBG): 1 no search, 2 no convolution, 4 no decision, 8 no stores
 };
 
 // The 1x1 weight re-laid out FRAGMENT-major for the kernel below: piece ((k-step * 2 + tile) * 2 + plane) holds, for
@@ -414,34 +432,38 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
   const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in1), 0, p.in1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wfrag), 0, p.w_bytes, 0x00020000);
   constexpr unsigned OOBV = 0xFFFFFFF0u;
-  // bias of this lane's dims: quad 2 j + half of tile t = j / 4 -> channels 8 j + 4 half + e
-  float4 bq[NQ];
-#pragma unroll
-  for (int j = 0; j < NQ; ++j)
-    bq[j] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + 8 * j + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
   // this lane's weight rows (MFMA A operand: row = output channel 32 t + col, k-block = half): byte offset of k = 0
   const int nchunk = (p.C0 + p.C1) / 32;
   const int hw = p.H * p.W;
 
   float sse = 0.f;
   const int64_t n_iter = (p.N + VQ_VEC_PER_BLOCK_ITER - 1) / VQ_VEC_PER_BLOCK_ITER;
-  for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
-    const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
-    const bool valid = n < p.N;
-    // ---- 1x1 convolution into this pixel's dims
-    unsigned a0 = OOBV, a1 = OOBV;       // byte offsets of the pixel's rows in the two sources
-    if (valid) {
+  // byte offsets of vector n's rows in the two sources (OOBV: beyond N)
+  auto pixel_offsets = [&](const int64_t n, unsigned &a0, unsigned &a1) {
+    a0 = OOBV; a1 = OOBV;
+    if (n < p.N) {
       const int b = (int)(n / hw);
       const int rem = (int)(n - (int64_t)b * hw);
       const int y = rem / p.W, x = rem - y * p.W;
       a0 = (unsigned)(b * p.s0n + y * p.s0h + x * p.s0w) * 4u;
       a1 = (unsigned)(b * p.s1n + y * p.s1h + x * p.s1w) * 4u;
     }
+  };
+  for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
+    const bool valid = n < p.N;
+    // ---- 1x1 convolution into this pixel's dims
     f32x16 zt[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) zt[t][r] = 0.f;
+#define ISI_VQ_MF(W_, A_, T_) zt[T_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, W_), __builtin_bit_cast(vq_f16x8, A_), zt[T_], 0, 0, 0)
+    if (p.dbg & 2) {
+      zt[0][0] = (float)(n & 7); zt[1][5] = 1.f;
+    } else {
+    unsigned a0, a1;
+    pixel_offsets(n, a0, a1);
     // two 32-channel chunks (four k-steps) per batch: all 24 fragment loads of a batch are in flight before its 24
     // MFMAs (chunk by chunk the dependent L2 round trips added up to ~18 us per pass)
     for (int c = 0; c < nchunk; c += 2) {
@@ -454,11 +476,11 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
         const unsigned abase = second ? a1 : a0;
         const unsigned acol = (unsigned)(second ? cc * 32 - p.C0 : cc * 32) * 4u;
         // pieces of channel group 2 s + half of the chunk: hi at + 0, lo at + 16
-        const unsigned ao = (abase == OOBV || !live) ? OOBV : abase + acol + (unsigned)(2 * s_ + half) * 32u;
+        const unsigned ao = (abase == OOBV || !live || (p.dbg & 32)) ? OOBV : abase + acol + (unsigned)(2 * s_ + half) * 32u;
         ahv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao, 0, 0);
         alv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao == OOBV ? OOBV : ao + 16u, 0, 0);
         // weight pieces, fragment-major: ((step * 2 + tile) * 2 + plane) * 1 KiB + 16 lane
-        const unsigned wo = live ? (unsigned)((cc * 2 + s_) * 4) * 1024u + (unsigned)lane * 16u : OOBV;
+        const unsigned wo = (live && !(p.dbg & 16)) ? (unsigned)((cc * 2 + s_) * 4) * 1024u + (unsigned)lane * 16u : OOBV;
         w0h[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo, 0, 0);
         w0l[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo == OOBV ? OOBV : wo + 1024u, 0, 0);
         w1h[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo == OOBV ? OOBV : wo + 2048u, 0, 0);
@@ -466,15 +488,23 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        // term order of the stand-alone convolution: activation lo . weight hi, activation hi . weight lo, hi . hi
-#define ISI_VQ_MF(W_, A_, T_) zt[T_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, W_), __builtin_bit_cast(vq_f16x8, A_), zt[T_], 0, 0, 0)
         ISI_VQ_MF(w0h[u], alv[u], 0); ISI_VQ_MF(w1h[u], alv[u], 1);
         ISI_VQ_MF(w0l[u], ahv[u], 0); ISI_VQ_MF(w1l[u], ahv[u], 1);
         ISI_VQ_MF(w0h[u], ahv[u], 0); ISI_VQ_MF(w1h[u], ahv[u], 1);
-#undef ISI_VQ_MF
       }
     }
+    }
+#undef ISI_VQ_MF
     float4 zq[NQ], ew[NQ];
+    // bias of this lane's dims: quad 2 j + half of tile t = j / 4 -> channels 8 j + 4 half + e.  Re-read per tile (L2):
+    // kept across the loop the 32 registers pushed the prefetching variants into scratch (the offset is made opaque so
+    // that the compiler does not hoist the loads back out)
+    int opaque0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+    float4 bq[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+      bq[j] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + 8 * j + 4 * half + opaque0) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
       const int t = j >> 2, r0 = (j & 3) * 4;
@@ -483,8 +513,16 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
       if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
       zq[j] = v;
     }
-    // ---- search (vq_search_f16: candidates on the f16 pipe, decision in fp32; shared with the stand-alone kernel)
-    const int besti = vq_search_f16(cbh, cbl, e2, Kp, K, p.codes, zq, col, half, ew);
+    // ---- search (candidates on the f16 pipe, decision in fp32; shared with the stand-alone kernel)
+    VqCand cand{0.f, 1.f, (int)(n & 255), (int)(n & 255) + 256};
+    if (!(p.dbg & 1)) cand = vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half);
+    int besti = cand.i1;
+    if (!(p.dbg & 4)) besti = vq_decide_f32(cand, e2, K, p.codes, zq, half, ew);
+    else {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) ew[j] = zq[j];
+    }
+    if (p.dbg & 8) { sse += zq[0].x + ew[3].y; continue; }
     const bool lost = besti < 0;
     if (valid && lost) {
 #pragma unroll
@@ -509,11 +547,16 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
         if (p.q_pair) {
           // pair8 group j = channels 8 j .. 8 j + 7: this lane's quad is its half `half`: 8 bytes of hi pieces at
           // + 8 half, 8 bytes of lo pieces at + 16 + 8 half
+          // v_permlane32_swap hands the lower-half lane both lanes' hi quads and the upper-half lane both lo quads
+          // (tools/probes/permlane_probe.hip): one 16-byte store per lane instead of two 8-byte ones (the kernel is
+          // bound by the CU's vector-memory instruction rate)
           uint2 hi, lo;
           f16s::split4(qv, f16s::kScaleA, hi, lo);
+          typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+          const u32x2v sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+          const u32x2v sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
           char *g8 = reinterpret_cast<char *>(p.q_pair) + (n * D + 8 * j) * 4;
-          *reinterpret_cast<uint2 *>(g8 + half * 8) = hi;
-          *reinterpret_cast<uint2 *>(g8 + 16 + half * 8) = lo;
+          *reinterpret_cast<uint4 *>(g8 + half * 16) = make_uint4(sx.x, sy.x, sx.y, sy.y);
         }
       }
       if (half == 0) {
@@ -689,6 +732,7 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
                        reinterpret_cast<const uint4 *>(w16), reinterpret_cast<uint4 *>(workspace), a.Kpad, nstep);
   }
   auto kern = vq_conv1x1_nearest_kernel;
+  if (const char *e = getenv("ISI_VQ_DBG")) a.dbg = atoi(e);
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return check_launch("hipFuncSetAttribute(vq_conv1x1)");
   {

@@ -504,7 +504,9 @@ def main():
             want = next((t for k, t in tail.items() if k in dom["kernel"]), ("<128, 128, 2, 2, 0, 0, ",))
             tot_b = tot_n = 0.0
             for name, d in pmc.items():
-                if "conv_igemm_f32_kernel" in name and any(t in name for t in want) and "hbm_bytes_per_launch_corrected" in d:
+                mine = ("conv_igemm_f32_kernel" in name and any(t in name for t in want)) or \
+                       ("f16x3" in dom["kernel"] and "conv_pair_kernel<" in name)
+                if mine and "hbm_bytes_per_launch_corrected" in d:
                     tot_b += d["hbm_bytes_per_launch_corrected"] * d["dispatches"]
                     tot_n += d["dispatches"]
             if tot_n:

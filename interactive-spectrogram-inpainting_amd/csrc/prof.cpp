@@ -29,14 +29,14 @@ const char *kernel_name(int id) {
     case K_CONV_128x64: return "conv_igemm_f32_kernel<128,64,2,2,*>";
     case K_CONV_128x32: return "conv_igemm_f32_kernel<128,32,4,1,*>";
     case K_CONV_GATHER: return "conv_igemm_f32_kernel<*,2> (gather)";
-    case K_VQ_NEAREST: return "vq_nearest_kernel";
-    case K_RESBLOCK: return "resblock_f32_kernel";
+    case K_VQ_NEAREST: return "vq_conv1x1_nearest_kernel / vq_nearest_kernel";
+    case K_RESBLOCK: return "resblock_pair_kernel + resblock_f32_kernel";
     case K_CONVT_SMALL: return "convT_k4s2_small_kernel";
     case K_REL_ATTENTION: return "rel_attention_f32_kernel";
     case K_CONV_BF16X3: return "conv_igemm_f32_kernel<..,bf16x3>";
     case K_REL_ATTENTION_BWD: return "rel_attention_bwd_{kv,q}_kernel";
     case K_CONV_BF16X6: return "conv_igemm_f32_kernel<..,bf16x6>";
-    case K_CONV_F16X3: return "conv_igemm_f32_kernel<..,f16x3>";
+    case K_CONV_F16X3: return "conv_pair_kernel<..> + conv_igemm_f32_kernel<..,f16x3>";
     default: return "?";
   }
 }

@@ -48,7 +48,7 @@ struct ResPairK {
   unsigned in_bytes, w1_bytes, w2_bytes;
   int C, H, W, B, relu, out_pair;
   int tiles_x, tiles_y;
-  int ablate;   // measurements only (ISI_RESPAIR_ABL): 1 one stage instead of C / 16, 2 no second GEMM / epilogue
+  int ablate;   // measurements only (ISI_RESPAIR_ABL): 1 one stage instead of C / 16, 2 no second GEMM / epilogue, 4 no skip re-read, 8 no output stores
 };
 
 __device__ __forceinline__ void dma16(const unsigned lds_addr, const unsigned voff, const i32x4 rsrc, const unsigned soff) {
@@ -263,11 +263,12 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
           const int px = it * PPP + psub;
           const int gx = x0 + 32 * i + px;
           const unsigned off = (gy < p.H && gx < p.W) ? (unsigned)(((b * p.H + gy) * p.W + gx) * C + ch0) * 4u : OOB_ST;
+          const unsigned roff = (p.ablate & 4) ? OOB_ST : off;   // measurement: no skip re-read
           const float4 v0 = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8);
           const float4 v1 = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8 + 4);
           // the skip connection: r's two pieces of this group
-          const i32x4 rh = __builtin_amdgcn_raw_buffer_load_b128(rsi_b, off, 0, 0);
-          const i32x4 rl = __builtin_amdgcn_raw_buffer_load_b128(rsi_b, off == OOB_ST ? OOB_ST : off + 16u, 0, 0);
+          const i32x4 rh = __builtin_amdgcn_raw_buffer_load_b128(rsi_b, roff, 0, 0);
+          const i32x4 rl = __builtin_amdgcn_raw_buffer_load_b128(rsi_b, roff == OOB_ST ? OOB_ST : roff + 16u, 0, 0);
           float4 r0, r1;
           f16s::pair8_decode(__builtin_bit_cast(uint4, rh), __builtin_bit_cast(uint4, rl), r0, r1);
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -287,8 +288,9 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
             w1 = make_uint4(__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]),
                             __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7]));
           }
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_ST ? OOB_ST : off + 16u, 0, 0);
+          const unsigned soff = (p.ablate & 8) ? OOB_ST : off;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, soff, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, soff == OOB_ST ? OOB_ST : soff + 16u, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();   // the wave's transpose rows are reused by its next pass

@@ -4,7 +4,7 @@ R=${1:-r01}; O=gpurun_out/round
 cp $O/bench.json profiles/${R}_bench.json
 cp $O/bench_under_rocprof.json profiles/${R}_bench_under_rocprof.json
 hdr() { { echo "# $1"; cat "$2"; } > "$3"; }
-hdr "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-prior   (VQ-VAE forward, B=64, default split_f16 mode = template tail 3; includes warm-up and the alt-precision passes)" $O/fwd_summary.txt profiles/${R}_kernel_trace_stats.txt
+hdr "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-prior --no-train   (VQ-VAE forward, B=64, default split_f16 mode = template tail 3; includes warm-up and the alt-precision passes)" $O/fwd_summary.txt profiles/${R}_kernel_trace_stats.txt
 hdr "rocprofv3 --kernel-trace -- python3 tools/bench_train.py   (VQ-VAE training step, $(grep 'ms/step' $O/vqvae_train.txt | tail -1))" $O/vqvae_train_summary.txt profiles/${R}_vqvae_train_kernel_trace.txt
 hdr "rocprofv3 --kernel-trace -- python3 tools/bench_prior_train.py --batch 8 --steps 2   ($(grep 'ms/step' $O/prior_train.txt | tail -1))" $O/prior_train_summary.txt profiles/${R}_prior_train_kernel_trace.txt
 hdr "rocprofv3 --kernel-trace -- python3 tools/bench_prior.py   (KV-cached sampling, 4 x 1024 tokens + one full forward)" $O/prior_sampling_summary.txt profiles/${R}_prior_sampling_kernel_trace.txt
@@ -12,7 +12,7 @@ hdr "rocprofv3 --kernel-trace -- python3 tools/bench_frontend.py   (audio <-> me
 cp $O/pmc_hbm_traffic.json profiles/${R}_pmc_hbm_traffic.json
 { echo "# tools/bench_attention.py (B8 H8 S1025 hd64, fp32 kernels vs split-bf16 kernels; TF = dense-count convention)"; grep -v amdgpu.ids $O/attention.txt; } > profiles/${R}_attention.txt
 { echo "# SQ counters of the VQ-VAE forward's kernels, B=64 (two rocprofv3 --kernel-trace --pmc passes of"
-  echo "# \`python3 bench.py --no-cpu-baseline --no-prior --steps 3\`, which also times the other precision modes; per-dispatch"
+  echo "# \`python3 bench.py --no-cpu-baseline --no-prior --no-train --steps 3\`, which also times the other precision modes; per-dispatch"
   echo "# means; tools/round_profiles.sh, tools/pmc_sq_summary.py).  Template tail of conv_igemm / resblock: 0 exact fp32,"
   echo "# 1 bf16x3, 2 bf16x6, 3 f16x3 (the default mode's kernels)."
   echo

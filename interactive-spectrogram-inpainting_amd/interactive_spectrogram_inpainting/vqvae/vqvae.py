@@ -162,6 +162,18 @@ class VQVAE(nn.Module):
         self.conv_precision = os.environ.get("ISI_CONV_PRECISION", "split_f16")
 
     # ------------------------------------------------------------ native plan
+    def invalidate_plan(self) -> None:
+        """Drop every cached packed weight, codebook and the native plan.  The caches are keyed on each tensor's
+        autograd version and address, which in-place writes through `.data` (`p.data.copy_`, weight averaging) do
+        not change: call this after such a write.  `load_state_dict`, optimiser steps, `.to()` and the EMA update
+        bump the version (or reset the keys) themselves."""
+        self._plan, self._plan_key = None, None
+        for m in self.modules():
+            if hasattr(m, "_packed_key"):
+                m._packed_key = None
+                if hasattr(m, "_packed"):
+                    m._packed = None
+
     def _plan_fingerprint(self):
         key = []
         for t in list(self.parameters()) + [self.quantize_t.embed, self.quantize_b.embed]:

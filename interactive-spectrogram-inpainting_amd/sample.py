@@ -20,7 +20,7 @@ from typing import Iterable, Mapping, Optional, Union
 import torch
 
 from interactive_spectrogram_inpainting.priors import _ops
-from interactive_spectrogram_inpainting.priors._decode import IncrementalDecoder, NativeSampler
+from interactive_spectrogram_inpainting.priors._decode import NativeSampler
 from interactive_spectrogram_inpainting.priors.transformer import Seq2SeqInputKind, VQNSynthTransformer
 
 
@@ -56,6 +56,29 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
         raise NotImplementedError("predictive sampling (sample.py:251-261,308-342) is not built")
     device = torch.device(device)
     model.eval()
+    if batch_size > 256:
+        # the native loop decodes up to 256 sequences at a time: larger requests run chunk by chunk (rows are
+        # independent; every chunk gets its own slice of the per-row inputs and of the uniforms)
+        if uniforms is None:
+            uniforms = torch.rand(model.target_transformer_sequence_length, batch_size, generator=generator)
+
+        def rows(t, lo, hi):
+            if t is None or not torch.is_tensor(t) or t.dim() == 0 or t.shape[0] != batch_size:
+                return t
+            return t[lo:hi]
+
+        parts = []
+        for lo in range(0, batch_size, 256):
+            hi = min(batch_size, lo + 256)
+            cls = {k: (torch.as_tensor(v).reshape(-1)[lo:hi] if torch.as_tensor(v).numel() == batch_size else v)
+                   for k, v in class_conditioning.items()}
+            parts.append(sample_model(
+                model, device, hi - lo, codemap_size, temperature, condition=rows(condition, lo, hi),
+                class_conditioning=cls, initial_code=rows(initial_code, lo, hi), mask=mask,
+                time_indexes_source=time_indexes_source, time_indexes_target=time_indexes_target,
+                top_k_sampling_k=top_k_sampling_k, top_p_sampling_p=top_p_sampling_p,
+                progressbar_decorator=progressbar_decorator, uniforms=uniforms[:, lo:hi]))
+        return torch.cat(parts, 0)
     if initial_code is None:
         fill = model.mask_token_index if model.self_conditional_model else 0
         codemap = torch.full([batch_size] + list(codemap_size), fill, dtype=torch.int64, device=device)
@@ -103,32 +126,15 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
     if not masked:
         return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()
     p_first, n_pos = masked[0] + start_len - 1, min(n_pos, masked[-1] + start_len)
-    if batch_size <= 256:
-        # the whole loop natively: no per-token return to Python, no host sync
-        sampler = NativeSampler(model, memory, x_seq, code_seq, mask_seq, uniforms)
-        if p_first < 8:
-            p_first = 0                                        # a few rows: not worth a batched pass
-        sampler.prefill(p_first)
-        chunk = n_pos if progressbar_decorator is None else 64
-        starts = range(p_first, n_pos, chunk)
-        if progressbar_decorator is not None:
-            starts = progressbar_decorator(starts)
-        for p0 in starts:
-            sampler.run(p0, min(n_pos, p0 + chunk), temperature, top_k_sampling_k, top_p_sampling_p)
-    else:
-        dec = IncrementalDecoder(model, memory, batch_size)
-        table = model._embedding_table(Seq2SeqInputKind.Target)
-        eff = model.embeddings_effective_dim
-        positions = range(n_pos)
-        if progressbar_decorator is not None:
-            positions = progressbar_decorator(positions)
-        for p in positions:
-            out_row = dec.step(p, x_seq[p])
-            i = p - (start_len - 1)                           # token predicted from position p
-            if i < 0 or not mask_seq[i]:
-                continue
-            logits = dec.logits(out_row)
-            sample = _ops.sample_rows(logits, temperature, top_k_sampling_k, top_p_sampling_p, uniforms[i])
-            code_seq[:, i] = sample
-            x_seq[i + start_len, :, :eff] = table[sample]      # embed_data(sample) into the next input row
+    # the whole loop natively: no per-token return to Python, no host sync
+    sampler = NativeSampler(model, memory, x_seq, code_seq, mask_seq, uniforms)
+    if p_first < 8:
+        p_first = 0                                        # a few rows: not worth a batched pass
+    sampler.prefill(p_first)
+    chunk = n_pos if progressbar_decorator is None else 64
+    starts = range(p_first, n_pos, chunk)
+    if progressbar_decorator is not None:
+        starts = progressbar_decorator(starts)
+    for p0 in starts:
+        sampler.run(p0, min(n_pos, p0 + chunk), temperature, top_k_sampling_k, top_p_sampling_p)
     return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()

@@ -278,6 +278,29 @@ def test_vqvae_against_oracle_seeded_odd_width():
     _close(p_t, ref[2], TOL, "perplexity_t"); _close(p_b, ref[3], TOL, "perplexity_b")
 
 
+def test_invalidate_plan_after_data_writes():
+    """Packed weights / the native plan are keyed on tensor versions, which writes through `.data` do not bump
+    (ADVICE r01): `invalidate_plan()` makes such a write visible; a fresh model with the same state gives the same bits."""
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    kw = dict(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16, num_embeddings=64)
+    sd = O.init_state_dict(O.Config(**kw), seed=3)
+    m = VQVAE(**kw)
+    m.load_state_dict(sd)
+    m = m.to(_dev()).eval()
+    x = torch.randn(2, 2, 32, 32, generator=torch.Generator().manual_seed(4)).to(_dev())
+    before = m(x)[0].clone()
+    for prm in m.parameters():
+        prm.data.mul_(0.5)                       # does not bump ._version
+    m.invalidate_plan()
+    after = m(x)[0]
+    assert not torch.equal(before, after)
+    fresh = VQVAE(**kw)
+    fresh.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    fresh = fresh.to(_dev()).eval()
+    assert torch.equal(fresh(x)[0], after)
+
+
 @pytest.mark.parametrize("precision", ["split_f16", "f32"])
 def test_vqvae_full_size_properties(precision):
     """BASELINE config 2 (B=64, [2,128,512], default constructor): size-independent properties, and a TEACHER-FORCED

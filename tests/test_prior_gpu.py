@@ -322,6 +322,15 @@ def test_sample_model_large_batch(golden_dir):
         solo = S.sample_model(top, dev, 1, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9,
                               uniforms=uni[:, b:b + 1].contiguous())
         assert torch.equal(solo[0], out[b]), b
+    # more than 256 sequences: decoded in chunks of 256, every row still equals its single-sequence run
+    B = 259
+    uni = torch.rand(top.target_transformer_sequence_length, B, generator=g)
+    out = S.sample_model(top, dev, B, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9, uniforms=uni)
+    assert out.shape == (B, 8, 4)
+    for b in (0, 255, 256, 258):
+        solo = S.sample_model(top, dev, 1, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9,
+                              uniforms=uni[:, b:b + 1].contiguous())
+        assert torch.equal(solo[0], out[b]), b
 
 
 def test_inpainting_operations(golden_dir):

@@ -418,13 +418,21 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # ISI_BENCH_BACKEND=gloo: dry run of the multi-rank code path on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives go through the host) -- a functional check only, never a measurement
+    backend = os.environ.get("ISI_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from interactive_spectrogram_inpainting import _hip
     model, sd = _build_model(device)
@@ -472,7 +480,12 @@ def main():
         dt = t.item()
 
     # ---- BASELINE configs[2] on every rank: data-parallel VQ-VAE training step (collectives inside)
-    train_leg = None if args.no_train else _vqvae_training(device, dist, world, batch=args.batch)
+    train_leg = None
+    if not args.no_train:
+        try:
+            train_leg = _vqvae_training(device, dist, world, batch=args.batch)
+        except Exception as e:      # a secondary leg must not take the headline metric with it
+            train_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- per-kernel HIP-event timing recorded inside the timed region
     kernels = []
@@ -587,18 +600,25 @@ def main():
         if train_leg is not None:
             line["vqvae_training_single_gpu" if world == 1 else "vqvae_training_dp"] = train_leg
         # secondary legs and the CPU baseline at N = 1 only: at N > 1 the other ranks wait in the final barrier
+        def leg(name, fn):          # a secondary leg must not take the headline metric with it
+            try:
+                line[name] = fn()
+            except Exception as e:
+                line[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
         if not args.no_prior and world == 1:
-            line["attention"] = _attention(device)
-            torch.cuda.empty_cache()
-            line["frontend"] = _frontend(device)
-            torch.cuda.empty_cache()
-            line["prior_sampling"] = _prior_sampling(device)
-            torch.cuda.empty_cache()
-            line["prior_sampling"]["timerange_change"] = _timerange_change(device, model)
-            torch.cuda.empty_cache()
-            line["prior_training_single_gpu"] = _prior_training(device)
+            leg("attention", lambda: _attention(device))
+            leg("frontend", lambda: _frontend(device))
+            leg("prior_sampling", lambda: _prior_sampling(device))
+            if "error" not in line["prior_sampling"]:
+                try:
+                    line["prior_sampling"]["timerange_change"] = _timerange_change(device, model)
+                except Exception as e:
+                    line["prior_sampling"]["timerange_change"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.empty_cache()
+            leg("prior_training_single_gpu", lambda: _prior_training(device))
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = _cpu_baseline(sd)
+            leg("cpu_baseline", lambda: _cpu_baseline(sd))
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -556,8 +556,10 @@ def main():
                           "note": "fp32 data and fp32 accumulation everywhere; split_f16 (default): every product as "
                                   "hi.hi+hi.lo+lo.hi of two 11-bit f16 pieces of the operands (scaled by powers of "
                                   "two) on the f16 matrix pipe -- per-product error ~2^-23, error vs fp64 at or below "
-                                  "the fp32 pipe's own, index agreement with the CPU reference equal to the fp32 "
-                                  "pipe's; operand range |activation| < 16384, |weight| < 64 (weights checked at "
+                                  "the fp32 pipe's own; codebook search: candidates on the f16 pipe, the decision "
+                                  "between the two best in fp32 (index differences from the fp32 CPU reference are at "
+                                  "the level of the reference's own rounding, DESIGN section 2); "
+                                  "operand range |activation| < 16384, |weight| < 64 (weights checked at "
                                   "plan time, an activation beyond it gives NaN / index -1). split_bf16: six-term "
                                   "bf16 split (no range limit) in index-feeding layers, three-term in the final "
                                   "decoder. The other modes are timed in alt_precision_single_gpu"},

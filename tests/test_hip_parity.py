@@ -608,6 +608,89 @@ def _pair_format_bit_identity(_ops, _hip, dev, g, xd, x2d, xp, x2p, pw, bias, re
         _ops.resblock(xp, p3, b3, p1, b1, R, True, bf16x3=3, extra_flags=_ops.PAIR_IN0)
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 40, 128), (1, 9, 70, 128), (3, 33, 65, 128), (2, 17, 64, 64)])
+@pytest.mark.parametrize("th", ["4", "8"])
+def test_dma_residual_block_ragged_shapes(B, H, W, C, th):
+    """resblock_pair_kernel (LDS-DMA staging, pair-format input; csrc/resblock_pair_f16.hip) on maps that are not
+    multiples of its 4 x 64 / 8 x 64 tiles, both row counts forced: against the reference block in float64
+    (encoder_decoder.py:18-35, in-place ReLU semantics) and against the register-staged kernel."""
+    import os
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(100 + H + W)
+    R = 32
+    F = torch.nn.functional
+    x = torch.relu(torch.randn(B, C, H, W, generator=g))
+    w3 = torch.randn(R, C, 3, 3, generator=g) * 0.03
+    b3 = torch.randn(R, generator=g) * 0.1
+    w1 = torch.randn(C, R, 1, 1, generator=g) * 0.1
+    b1 = torch.randn(C, generator=g) * 0.1
+    ref64 = torch.relu(x.double() + F.conv2d(torch.relu(F.conv2d(x.double(), w3.double(), b3.double(), padding=1)),
+                                             w1.double(), b1.double()))
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    xp = _ops.pair_encode(xd.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    p3, p1 = _ops.pack_conv_weight(w3.to(dev), with_f16=True), _ops.pack_conv_weight(w1.to(dev), with_f16=True)
+    old = _ops.resblock(xd, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4)
+    os.environ["ISI_RESPAIR_TH"] = th
+    try:
+        got = _ops.resblock(xp, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4, extra_flags=_ops.PAIR_IN0)
+        got_p = _ops.pair_decode(_ops.resblock(xp, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4,
+                                               extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT))
+    finally:
+        del os.environ["ISI_RESPAIR_TH"]
+    scale = ref64.abs().max().item()
+    assert (got.cpu().double() - ref64).abs().max().item() < 2e-6 * scale
+    assert (got_p.cpu().double() - ref64).abs().max().item() < 2e-6 * scale
+    assert (got - old).abs().max().item() < 2e-6 * scale
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,cout,k,stride", [
+    (1, 5, 7, 128, 0, 128, 3, 1),        # fewer pixels than one 256-pixel tile
+    (2, 19, 45, 128, 0, 128, 3, 1),      # ragged last tile
+    (2, 18, 50, 64, 64, 128, 3, 1),      # two sources (the decoder's concat)
+    (3, 22, 38, 64, 0, 128, 4, 2),       # strided 4x4, even map
+    (2, 21, 37, 128, 0, 64, 4, 2),       # strided 4x4 on an odd map, 64 output channels
+    (1, 40, 72, 64, 0, 128, 3, 1),
+])
+def test_dma_convolution_ragged_shapes(B, H, W, C0, C1, cout, k, stride):
+    """conv_pair_kernel (LDS-DMA staging of pair-format sources; csrc/conv_pair_f16.hip) on ragged maps, one and two
+    sources, both tile widths, stride 1 and 2: against torch in float64 and, with the accumulator flush off, bit for
+    bit against the register-staged kernel on fp32 activations; fp32 and pair-format outputs."""
+    import os
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(7 * H + W)
+    F = torch.nn.functional
+    pad = 1
+    x0 = torch.relu(torch.randn(B, C0, H, W, generator=g))
+    x1 = torch.randn(B, C1, H, W, generator=g) if C1 else None
+    w = torch.randn(cout, C0 + C1, k, k, generator=g) * 0.03
+    bias = torch.randn(cout, generator=g) * 0.1
+    xin = x0 if x1 is None else torch.cat([x0, x1], 1)
+    ref64 = torch.relu(F.conv2d(xin.double(), w.double(), bias.double(), stride=stride, padding=pad))
+    cl = lambda t: t.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    enc = lambda t: _ops.pair_encode(t.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    x0d, x1d = cl(x0), (cl(x1) if x1 is not None else None)
+    x0p, x1p = enc(x0d), (enc(x1d) if x1d is not None else None)
+    pw = _ops.pack_conv_weight(w.to(dev), with_f16=True)
+    flags = _ops.PAIR_IN0 | (_ops.PAIR_IN1 if x1 is not None else 0)
+    kw = dict(relu=True, bf16x3=4)
+    old = _ops.conv2d(x0d, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1d, **kw)
+    got = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p, extra_flags=flags, **kw)
+    got_p = _ops.pair_decode(_ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p,
+                                         extra_flags=flags | _ops.PAIR_OUT, **kw))
+    scale = ref64.abs().max().item()
+    assert got.shape == ref64.shape
+    assert (got.cpu().double() - ref64).abs().max().item() < 1e-6 * scale
+    assert (got_p.cpu().double() - ref64).abs().max().item() < 1e-6 * scale
+    os.environ["ISI_CONV_FLUSH"] = "0"
+    try:
+        unflushed = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p, extra_flags=flags, **kw)
+    finally:
+        del os.environ["ISI_CONV_FLUSH"]
+    assert torch.equal(unflushed, old)
+
+
 def test_vqvae_pair_pipeline_against_fp32_activations():
     """The fused forward keeps its internal activations in the pair format when every layer can read it; with
     ISI_NO_PAIRS it runs the same arithmetic on fp32 activations: bit-identical outputs (ragged width included)."""

@@ -23,8 +23,15 @@
 //     summation: a K = 1152 product-sum is 216 sequential fp32 roundings at the full magnitude in one accumulator,
 //     18 at a twelfth of the variance plus 12 with flush = 3), which takes the error against fp64 from 0.9e-6 of the
 //     maximum to below torch-CPU's own.
-//   * epilogue: the accumulators are transposed through LDS (the stage ring is dead by then) so that a lane owns 8
-//     consecutive channels of one pixel: bias / ReLU, then 16-byte stores of fp32 or of {hi[8] | lo[8]} pair8 groups.
+//   * the MFMAs run with SWAPPED operands (weights = rows, pixels = columns: the same products in the same k order,
+//     the same bits), so a lane's accumulators are 4 x 4 consecutive channels of ONE pixel per 32-channel tile: the
+//     epilogue stores straight from the registers -- fp32 quads, or pair8 pieces after v_permlane32_swap has handed
+//     the lower half-wave both halves' hi quads and the upper one the lo quads -- with no LDS transpose and no block
+//     barrier (the transposed epilogue cost 7-9 k of a work item's ~97 k cycles; 3x3 128->128: 212 -> 194 us).
+//     Tried on top of it and dropped: the stage ring running THROUGH the work items of a workgroup (next item's tables
+//     written during the current K loop, its first two chunks requested by the last two memory phases, vmcnt(PER +
+//     stores) behind the epilogue): correct, but its loop carries the issue context as loop-variant state and ran 7 %
+//     slower per chunk, 2.4 % slower overall on the large layers (198.6 vs 193.9 us).
 //
 // Replaces (reference, torch.nn): nn.Conv2d / nn.ConvTranspose2d / nn.ReLU / torch.cat at
 // vqvae/encoder_decoder.py:95-112,138,199-215 and vqvae/vqvae.py:193-201,260,270-272,282.
@@ -100,6 +107,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
   int *row_n = row_oo + BM;                                    // [BM] batch index or -1
   int *row_y = row_n + BM;                                     // [BM] top-left input y
   int *row_x = row_y + BM;                                     // [BM] top-left input x
+  float *col_bias = reinterpret_cast<float *>(row_x + BM);     // [BN] bias of the tile's output channels
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -151,6 +159,8 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
     row_y[tid] = oy * p.stride - pad_y;
     row_x[tid] = ox * p.stride - pad_x;
     row_oo[tid] = b < 0 ? -1 : out_off + b * p.on + oy * p.oh + ox * p.ow;
+  } else if (tid < BM + BN) {
+    col_bias[tid - BM] = p.bias ? p.bias[n0 + tid - BM] : 0.f;
   }
   __syncthreads();
 
@@ -259,15 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
       for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
   bool fresh = true;   // uniform: the next MFMA of every accumulator starts a new partial sum (C operand = 0)
 
-  // this lane's eight output channels in the epilogue (lane -> 8-channel group g of the wave's columns); the bias
-  // values are fetched now so that their latency is not exposed after the K loop
   constexpr int WCOLS = TN * 32;                 // columns of this wave's sub-tile
-  constexpr int G = WCOLS / 8;                   // 8-channel groups per row
-  const int g = lane % G, rsub = lane / G;
-  const int ncol = n0 + wn * WCOLS + g * 8;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = p.bias ? p.bias[ncol + e] : 0.f;
   if constexpr (ABL & 32) e2 = __builtin_readcyclecounter();
   // ---- prologue: two chunks in flight; chunk 0 landed (every wave waits for its own pieces, then the barrier)
   ISI_ISSUE_CHUNK(0);
@@ -345,8 +347,8 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
         for (int j = 0; j < TN; ++j) {
           const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           if constexpr (!(ABL & 1))
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[0][i]),
-                                                               __builtin_bit_cast(f16x8, bh[0][j]), zero, 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh[0][j]),
+                                                               __builtin_bit_cast(f16x8, al[0][i]), zero, 0, 0, 0);
         }
       fresh = false;
     } else {
@@ -355,8 +357,8 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           if constexpr (!(ABL & 1))
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[0][i]),
-                                                               __builtin_bit_cast(f16x8, bh[0][j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh[0][j]),
+                                                               __builtin_bit_cast(f16x8, al[0][i]), acc[i][j], 0, 0, 0);
     }
 #pragma unroll
     for (int s_ = 0; s_ < 2; ++s_)
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
             const s16x8 av = t == 0 ? al[s_][i] : ah[s_][i];
             const s16x8 bv = t == 1 ? bl[s_][j] : bh[s_][j];
             if constexpr (!(ABL & 1))
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv),
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv), __builtin_bit_cast(f16x8, av),
                                                                  acc[i][j], 0, 0, 0);
             else asm volatile("" ::"v"(av), "v"(bv));   // keep the fragment reads alive
           }
@@ -398,53 +400,55 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
     }
   }
 
-  // ---- epilogue.  Stage ring -> per-wave transpose buffers [64 rows][LDT] fp32 (all waves are done reading).
-  if constexpr (ABL & 32) e4 = __builtin_readcyclecounter();
-  __syncthreads();
-  if constexpr (ABL & 32) e5 = __builtin_readcyclecounter();
-  constexpr int LDT = WCOLS + 4;                 // padded row (floats)
-  float *tb = reinterpret_cast<float *>(smem) + wave * 64 * LDT;
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-        tb[row * LDT + j * 32 + frow] = (fresh ? tot[i][j][r] : tot[i][j][r] + acc[i][j][r]) * f16s::kUnscale;
-      }
-  if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); e6 = __builtin_readcyclecounter(); }
-  // lane -> (row, 8-channel group): G groups per row, 64 / G rows per pass, G passes
-  constexpr int RPP = 64 / G;
+  // ---- epilogue, straight from the accumulators.  The MFMAs ran with SWAPPED operands (weights = rows, pixels =
+  // columns; the same products in the same k order, so the same bits): lane (pixel = lane & 31, kb = lane >> 5) holds,
+  // per 32-channel tile j, the channels (r & 3) + 8 (r >> 2) + 4 kb of ITS pixel -- per quad q = r >> 2 four
+  // consecutive channels.  fp32 output: one 16-byte store per quad.  Pair output: the quad's hi and lo pieces are
+  // exchanged between the two half-waves with v_permlane32_swap (tools/probes/permlane_probe.hip) so that the lower
+  // lane holds the group's 8 hi pieces and the upper lane its 8 lo pieces: again one 16-byte store per quad.  No LDS,
+  // no barrier: the stage ring is not touched.
+  if constexpr (ABL & 32) { e4 = __builtin_readcyclecounter(); e5 = e4; }
   const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-  for (int it = 0; it < G; ++it) {
-    const int row = it * RPP + rsub;
-    const float4 v0 = *reinterpret_cast<const float4 *>(tb + row * LDT + g * 8);
-    const float4 v1 = *reinterpret_cast<const float4 *>(tb + row * LDT + g * 8 + 4);
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  for (int i = 0; i < TM; ++i) {
+    const int o = row_oo[wm * 64 + i * 32 + frow];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float t = v[e] + bias[e];
-      // NaN-propagating rectifier: an operand beyond the f16 range (or an fp32 overflow) stays loud (torch.relu)
-      if (p.relu) t = t < 0.f ? 0.f : t;   // NaN < 0 is false: a NaN stays (torch.relu)
-      v[e] = t;
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cg = wn * WCOLS + j * 32 + 8 * q;                     // first channel of the 8-group (tile-relative)
+        const float4 bq = *reinterpret_cast<const float4 *>(col_bias + cg + 4 * kb);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          float t = (fresh ? tot[i][j][r] : tot[i][j][r] + acc[i][j][r]) * f16s::kUnscale;
+          t += e == 0 ? bq.x : e == 1 ? bq.y : e == 2 ? bq.z : bq.w;
+          // NaN-propagating rectifier: an operand beyond the f16 range (or an fp32 overflow) stays loud (torch.relu)
+          if (p.relu) t = t < 0.f ? 0.f : t;   // NaN < 0 is false: a NaN stays
+          v[e] = t;
+        }
+        uint4 w;
+        unsigned off;
+        if constexpr (OUTP) {
+          uint2 hi, lo;
+          f16s::split4(make_float4(v[0], v[1], v[2], v[3]), f16s::kScaleA, hi, lo);
+          const u32x2v sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+          const u32x2v sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+          w = make_uint4(sx.x, sy.x, sx.y, sy.y);
+          off = o >= 0 ? (unsigned)(o + n0 + cg) * 4u + (unsigned)kb * 16u : OOB_STORE;
+        } else {
+          w = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                         __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+          off = o >= 0 ? (unsigned)(o + n0 + cg + 4 * kb) * 4u : OOB_STORE;
+        }
+        if constexpr (ABL & 8) { asm volatile("" ::"v"(w.x ^ w.y ^ w.z ^ w.w), "v"(off)); continue; }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w), rso_b, off, 0, 0);
+      }
     }
-    const int o = row_oo[wm * 64 + row];
-    const unsigned off = o >= 0 ? (unsigned)(o + ncol) * 4u : OOB_STORE;
-    uint4 w0, w1;
-    if constexpr (OUTP) {
-      f16s::pair8_encode(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), w0, w1);
-    } else {
-      w0 = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
-                      __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
-      w1 = make_uint4(__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]),
-                      __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7]));
-    }
-    if constexpr (ABL & 8) { asm volatile("" ::"v"(w0.x ^ w0.y ^ w0.z ^ w0.w ^ w1.x ^ w1.y ^ w1.z ^ w1.w), "v"(off)); continue; }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_STORE ? OOB_STORE : off + 16u, 0, 0);
   }
+  if constexpr (ABL & 32) e6 = __builtin_readcyclecounter();
   if constexpr (ABL & 32) {
     e7 = __builtin_readcyclecounter();
     if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && item_i == (int)blockIdx.x + (int)gridDim.x) {
@@ -465,14 +469,13 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
 
 template <int BN>
 constexpr size_t pair_smem_bytes() {
-  return (size_t)NS * (BM + BN) * ROWB + 4 * BM * sizeof(int);
+  return (size_t)NS * (BM + BN) * ROWB + 4 * BM * sizeof(int) + BN * sizeof(float);
 }
 
 template <int BN, bool OUTP, int ABL = 0>
 int launch_pair(const PairK &a, int nphase, double flops, double bytes, hipStream_t stream) {
   auto kern = conv_pair_kernel<BN, OUTP, ABL>;
   constexpr size_t smem = pair_smem_bytes<BN>();
-  static_assert(8 * 64 * (BN / 2 + 4) * sizeof(float) <= (size_t)NS * (BM + BN) * ROWB, "transpose buffers fit in the ring");
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -400,8 +400,11 @@ struct VqFusedArgs {
 // The 1x1 weight re-laid out FRAGMENT-major for the kernel below: piece ((k-step * 2 + tile) * 2 + plane) holds, for
 // lane l, the 16 bytes lane l feeds to the MFMA as its A operand (row 32 tile + (l & 31), channel group
 // 2 k-step + (l >> 5)): one weight load instruction then reads 1 KiB contiguously instead of 32 rows 768 bytes apart.
-__global__ void vq_weight_fragments_kernel(const uint4 *__restrict__ w16, uint4 *__restrict__ wf, int Kpad, int nstep) {
+// `counts` (nullable): the histogram the search accumulates into is zeroed here as well (one tiny launch instead of two)
+__global__ void vq_weight_fragments_kernel(const uint4 *__restrict__ w16, uint4 *__restrict__ wf, int Kpad, int nstep,
+                                           int32_t *__restrict__ counts, int K) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (step, tile, plane, lane)
+  if (counts && i < K) counts[i] = 0;
   if (i >= nstep * 2 * 2 * 64) return;
   const int lane = i & 63, plane = (i >> 6) & 1, t = (i >> 7) & 1, step = i >> 8;
   const int row = 32 * t + (lane & 31), grp = 2 * step + (lane >> 5);          // 8-channel group of the row
@@ -702,7 +705,7 @@ size_t vq_conv1x1_workspace_floats(int C0, int C1, int D) { return (size_t)D * r
 
 int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
                            const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,
-                           float *workspace, int B, int H, int W, int D, int K, hipStream_t stream) {
+                           float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts) {
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return invalid("vq_conv1x1: workspace (vq_conv1x1_workspace_floats, 16-byte aligned)");
   if (!s0 || !s0->ptr || !w16 || !codes || !e2 || !idx || !q || !counts || !sse_part) return invalid("vq_conv1x1: null pointer");
   const bool two = s1 && s1->ptr;
@@ -727,9 +730,10 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
   const size_t smem = vq_planes_lds_bytes(Kp);
   a.wfrag = workspace;
   {
-    const int nstep = a.Kpad / 16, total = nstep * 256;
+    const int nstep = a.Kpad / 16, total = nstep * 256 > K ? nstep * 256 : K;
     hipLaunchKernelGGL(vq_weight_fragments_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
-                       reinterpret_cast<const uint4 *>(w16), reinterpret_cast<uint4 *>(workspace), a.Kpad, nstep);
+                       reinterpret_cast<const uint4 *>(w16), reinterpret_cast<uint4 *>(workspace), a.Kpad, nstep,
+                       zero_counts ? counts : nullptr, K);
   }
   auto kern = vq_conv1x1_nearest_kernel;
   if (const char *e = getenv("ISI_VQ_DBG")) a.dbg = atoi(e);

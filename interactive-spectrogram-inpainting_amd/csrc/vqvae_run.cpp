@@ -309,11 +309,9 @@ int unquantized_scalars(float *scalars2, hipStream_t st) {
 int run_quantizer_fused(const isi_codebook_w &cb, const isi_conv_w &w1x1, const isi_src &a, const isi_src *b, int B, int H,
                         int W, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part, float *scalars2,
                         float *wfrag_ws, hipStream_t st) {
-  if (hipMemsetAsync(counts, 0, (size_t)cb.K * sizeof(int32_t), st) != hipSuccess)
-    return check_launch("hipMemsetAsync(counts)");
   const int Kpad = (int)round_up((size_t)w1x1.Cin, kBK);
   int rc = vq_conv1x1_nearest_f32(&a, b, w1x1.w + (size_t)w1x1.Cout * Kpad, w1x1.bias, cb.codes_kd, cb.e2, idx, q, q_pair,
-                                  counts, sse_part, wfrag_ws, B, H, W, cb.D, cb.K, st);
+                                  counts, sse_part, wfrag_ws, B, H, W, cb.D, cb.K, st, /*zero_counts*/ true);
   if (rc) return rc;
   const int64_t N = (int64_t)B * H * W;
   return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the two split-f16 convolution kernels on the forward's big layers (B = 64): the register-staged
+"""A/B/C of the split-f16 convolution kernels (register-staged against LDS-DMA; the transposed convolutions are forced onto the DMA kernel for the comparison) on the forward's big layers (B = 64): the register-staged
 conv_igemm_f32.hip path (ISI_NO_CONV_PAIR_KERNEL=1) against the LDS-DMA kernel conv_pair_f16.hip, pair-format
 sources, interleaved rounds in one process."""
 import os
@@ -54,17 +54,17 @@ def main():
             OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
             flops = 2.0 * B * OH * OW * cout * k * k * cin
         res = {}
+        variants = {"old": {"ISI_NO_CONV_PAIR_KERNEL": "1"}, "dma": {"ISI_CONV_PAIR_ALL": "1"}}
         for rnd in range(3):
-            for old in (True, False):
-                if old:
-                    os.environ["ISI_NO_CONV_PAIR_KERNEL"] = "1"
-                else:
-                    os.environ.pop("ISI_NO_CONV_PAIR_KERNEL", None)
-                res.setdefault(old, []).append(timed(run))
-        os.environ.pop("ISI_NO_CONV_PAIR_KERNEL", None)
-        t_old, t_new = min(res[True]), min(res[False])
-        print(f"{name:42s} old {t_old:7.1f} us ({flops / t_old / 1e6:6.1f} TF)   dma {t_new:7.1f} us ({flops / t_new / 1e6:6.1f} TF, "
-              f"{flops / t_new / 1e6 / 833.3:.2f} of 833)   x{t_old / t_new:.2f}")
+            for vname, env in variants.items():
+                old = vname == "old"
+                os.environ.update(env)
+                res.setdefault(vname, []).append(timed(run))
+                for k_ in env:
+                    os.environ.pop(k_, None)
+        t = {k_: min(v) for k_, v in res.items()}
+        print(f"{name:42s} " + "   ".join(f"{k_} {v:7.1f} us ({flops / v / 1e6 / 833.3:.3f})" for k_, v in t.items()) +
+              f"   old/dma x{t['old'] / t['dma']:.3f}")
 
 
 if __name__ == "__main__":

@@ -205,6 +205,13 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
           *reinterpret_cast<_Float16 *>(hb + px * HROW + (((2 * g + 1) ^ sw) << 4) + e * 2) = hl;
         }
     }
+    // (Tried instead of the LDS planes / transposes of this tail, both correct, neither faster: (a) everything in
+    // registers -- both GEMMs with swapped operands so that GEMM 1's accumulators are GEMM 2's operand fragments and
+    // GEMM 2's accumulators are stored as 16-byte pieces per lane, v_permlane32_swap for the skip and pair pieces as in
+    // conv_pair_f16.hip: 106 us against 104, every load / store instruction then touches 32 cache lines instead of 8 and
+    // the memory part of the tail grows from 21 to 31 us, which is what the saved LDS work gains; (b) registers for the
+    // hidden activations only, LDS transposes kept: 111 us, the 8-byte W2 fragment reads of the permuted k order cost
+    // more than the 2-byte LDS writes they replace.)
     // W2 fragments come straight from memory (B operand of GEMM 2: row n = 32 j + frow, k-step s, k-block kb; 16 KB,
     // L2-resident).  (Holding all of them, or all of a tile's skip pieces, in registers at once was measured: the
     // kernel then needs 256 VGPRs with spills and runs 25 % slower.)

@@ -49,11 +49,10 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
                  top_k_sampling_k: int = 0, top_p_sampling_p: float = 0.0,
                  progressbar_decorator=None, use_predictive_sampling: bool = False,
                  generator: Optional[torch.Generator] = None,
-                 uniforms: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 uniforms: Optional[torch.Tensor] = None,
+                 gumbel_noise: Optional[torch.Tensor] = None) -> torch.Tensor:
     if constraint is not None:
         raise NotImplementedError
-    if use_predictive_sampling:
-        raise NotImplementedError("predictive sampling (sample.py:251-261,308-342) is not built")
     device = torch.device(device)
     model.eval()
     if batch_size > 256:
@@ -108,6 +107,9 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
         mask_seq = model.target_codemaps_helper.to_sequence(mask).reshape(-1, S)[0].cpu().numpy()
     else:
         mask_seq = [True] * S
+    if use_predictive_sampling:
+        return _predictive_sampling(model, source_seq, target_seq, code_seq, mask_seq, start_len, temperature,
+                                    top_k_sampling_k, top_p_sampling_p, gumbel_noise, progressbar_decorator)
     if uniforms is None:
         uniforms = torch.rand(S, batch_size, generator=generator)
     uniforms = uniforms.to(device=device, dtype=torch.float32)
@@ -137,4 +139,57 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
         starts = progressbar_decorator(starts)
     for p0 in starts:
         sampler.run(p0, min(n_pos, p0 + chunk), temperature, top_k_sampling_k, top_p_sampling_p)
+    return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()
+
+
+def _predictive_sampling(model, source_seq, target_seq, code_seq, mask_seq, start_len, temperature, top_k, top_p,
+                         gumbel_noise, progressbar_decorator):
+    """Predictive sampling of the reference (sample.py:251-261,268-342): with the Gumbel reparametrisation
+    `argmax(log p + g)` and the noise `g` drawn up front, every full pass also FORECASTS all later masked tokens; a
+    step whose forecast already equalled the token the previous pass put there is skipped.  The sampled map is that of
+    sequential Gumbel-max sampling with the same noise.  One full decoder pass per non-skipped step (the encoder
+    memory is cached), on the HIP forward kernels; the KV-cached loop does not apply -- a pass rewrites every later
+    input row.  Differences from the reference: its boolean index `[1, S]` on `[B, S]` tensors only works at batch 1,
+    here the mask broadcasts over the batch; `gumbel_noise` ([B, S, n_class]) may be passed in (tests)."""
+    device = target_seq.device
+    B, S = code_seq.shape
+    eff = model.embeddings_effective_dim
+    if gumbel_noise is None:
+        gumbel_noise = torch.distributions.gumbel.Gumbel(torch.zeros(B, S, model.n_class_target), 1).sample()
+    gumbel_noise = gumbel_noise.to(device=device, dtype=torch.float32)
+    mask_t = torch.as_tensor(list(mask_seq), dtype=torch.bool, device=device)          # [S]
+    positions = torch.arange(S, device=device)
+    source_start = model.source_start_symbol.shape[1] if hasattr(model, "source_start_symbol") else start_len
+    memory = None
+    sample = None
+    prediction_was_correct = False
+    correct_predictions = 0
+    previous = code_seq
+    steps = enumerate(mask_seq)
+    if progressbar_decorator is not None:
+        steps = progressbar_decorator(steps)
+    for i, is_masked in steps:
+        if not is_masked:
+            continue
+        if sample is not None and prediction_was_correct:
+            prediction_was_correct = bool(torch.all(sample[:, i] == previous[:, i]))
+            if prediction_was_correct:
+                correct_predictions += 1
+                continue
+        logits, memory = model(target_seq, source_seq, memory=memory)
+        logits = top_k_top_p_filtering(logits / temperature, top_k=top_k, top_p=top_p)
+        probabilities = torch.softmax(logits, dim=-1)
+        sample = torch.argmax(torch.log(probabilities) + gumbel_noise, dim=-1)        # [B, S]
+        prediction_was_correct = bool(torch.all(sample[:, i] == code_seq[:, i]))
+        previous = code_seq.clone()
+        update = (mask_t & (positions >= i)).unsqueeze(0).expand(B, S)                 # causal and inpainting mask
+        code_seq[update] = sample[update]
+        embedded = model.embed_data(sample, Seq2SeqInputKind.Target)                   # [B, S, eff]
+        tgt_view = target_seq[:, start_len:, :eff]
+        tgt_view[update] = embedded[update]
+        if model.self_conditional_model:
+            src_view = source_seq[:, source_start:, :eff]
+            src_view[update] = embedded[update]
+            # the cached memory stays valid: the top encoder's attention is anti-causal (reference comment)
+    model.predictive_sampling_correct_ratio = correct_predictions / max(1, len(mask_seq))
     return model.target_codemaps_helper.to_time_frequency_map(code_seq).long()

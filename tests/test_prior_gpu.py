@@ -279,6 +279,52 @@ def test_sample_model_matches_full_pass_sampling(golden_dir):
     assert out_b.shape == (B, 16, 8) and int(out_b.min()) >= 0 and int(out_b.max()) < 32
 
 
+def test_predictive_sampling_equals_sequential_gumbel_max(golden_dir):
+    """use_predictive_sampling (reference sample.py:251-261,268-342): forecasts + skipped steps give exactly the map of
+    token-by-token Gumbel-max sampling (argmax(log softmax(filtered logits_i) + g_i), one full pass per token) with the
+    same noise; unmasked positions keep their codes."""
+    import sample as S
+    from interactive_spectrogram_inpainting.priors.transformer import Seq2SeqInputKind
+    z, top, bottom = _models(golden_dir)
+    dev = _dev()
+    for B, masked_cols in ((1, slice(1, 3)), (2, slice(0, 4))):
+        g = torch.Generator().manual_seed(21 + B)
+        init = torch.randint(0, 32, (B, 8, 4), generator=g)
+        mask = torch.zeros(1, 8, 4, dtype=torch.bool)
+        mask[:, :, masked_cols] = True
+        cls = {"pitch": torch.tensor([20]), "instrument_family_str": torch.tensor([3])}
+        S_len = top.target_transformer_sequence_length
+        u = torch.rand(B, S_len, top.n_class_target, generator=g).clamp_(1e-9, 1 - 1e-9)
+        gumbel = -torch.log(-torch.log(u))
+        got = S.sample_model(top, dev, B, [8, 4], temperature=0.9, class_conditioning=cls, initial_code=init.clone(),
+                             mask=mask, top_p_sampling_p=0.8, use_predictive_sampling=True, gumbel_noise=gumbel)
+        assert got.shape == (B, 8, 4) and got.dtype == torch.int64
+        keep = ~mask.expand(B, -1, -1)
+        assert torch.equal(got.cpu()[keep], init[keep])
+        assert 0.0 <= top.predictive_sampling_correct_ratio <= 1.0
+        # sequential reference: one full pass per masked token, argmax with that token's noise
+        clsd = {k: v.long().expand(B).reshape(B, 1).to(dev) for k, v in cls.items()}
+        codemap = init.clone().to(dev)
+        src, tgt = top.to_sequences(codemap, codemap, class_conditioning=clsd, mask=mask.to(dev))
+        seq = top.target_codemaps_helper.to_sequence(codemap).clone()
+        mseq = top.target_codemaps_helper.to_sequence(mask.to(dev))[0].cpu().numpy()
+        memory = None
+        start = top.target_start_symbol.shape[1]
+        for i, is_masked in enumerate(mseq):
+            if not is_masked:
+                continue
+            logits, memory = top(tgt, src, memory=memory)
+            li = S.top_k_top_p_filtering(logits[:, i] / 0.9, top_k=0, top_p=0.8)
+            s_i = torch.argmax(torch.log(torch.softmax(li, -1)) + gumbel[:, i].to(dev), -1)
+            seq[:, i] = s_i
+            emb = top.embed_data(s_i, Seq2SeqInputKind.Target)
+            tgt[:, i + start, :top.embeddings_effective_dim] = emb
+            if top.self_conditional_model:
+                src[:, i + top.source_start_symbol.shape[1], :top.embeddings_effective_dim] = emb
+        ref = top.target_codemaps_helper.to_time_frequency_map(seq)
+        assert torch.equal(got, ref), B
+
+
 def test_sample_model_edge_masks(golden_dir):
     """Empty mask (nothing to resample), a single masked token, the last token only, batch 1 vs the same row of
     a batch: the KV-cached loop keeps every unmasked code and its draws do not depend on the batch composition."""

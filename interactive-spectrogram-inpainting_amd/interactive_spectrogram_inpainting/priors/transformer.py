@@ -93,8 +93,6 @@ class VQNSynthTransformer(nn.Module):
                                       "reference's Self-attentive / Upsampling priors is built")
         if use_relative_transformer and not predict_frequencies_first:
             raise NotImplementedError("Relative positioning only implemented along time")
-        if positional_class_conditioning:
-            raise NotImplementedError("positional_class_conditioning is not built")
         if use_lstm_DEBUG:
             raise NotImplementedError("TODO(theis), debug mode with simple LSTM layers")
         shape = list(shape)
@@ -149,8 +147,8 @@ class VQNSynthTransformer(nn.Module):
         if class_conditioning_num_classes_per_modality is not None:
             self.class_conditioning_num_modalities = len(class_conditioning_embedding_dim_per_modality)
             self.class_conditioning_total_dim = sum(class_conditioning_embedding_dim_per_modality.values())
-            if not class_conditioning_prepend_to_dummy_input:
-                raise NotImplementedError
+            if not (class_conditioning_prepend_to_dummy_input or positional_class_conditioning):
+                raise NotImplementedError     # no start positions would be defined (reference :304)
         else:
             self.class_conditioning_num_modalities = 0
             self.class_conditioning_total_dim = 0
@@ -178,6 +176,8 @@ class VQNSynthTransformer(nn.Module):
             self.embeddings_dim = self.d_model - self.positional_embeddings_dim
         self.source_embed = nn.Embedding(self.n_class_source, self.embeddings_dim)
         self.embeddings_effective_dim = self.d_model - self.positional_embeddings_dim
+        if self.positional_class_conditioning:      # class embeddings ride on every position (:270-271)
+            self.embeddings_effective_dim -= self.class_conditioning_total_dim
         self.source_embeddings_linear = _LinearParams(self.embeddings_dim, self.embeddings_effective_dim)
         self.target_embeddings_linear = _LinearParams(self.embeddings_dim, self.embeddings_effective_dim)
         self.target_embed = nn.Embedding(self.n_class_target, self.embeddings_dim)
@@ -198,10 +198,14 @@ class VQNSynthTransformer(nn.Module):
                                                             + self.positional_embeddings_dim)
 
         self.source_start_symbol_dim = self.d_model
+        if self.positional_class_conditioning:      # the class embeddings are appended to the start symbols too (:331,345)
+            self.source_start_symbol_dim -= self.class_conditioning_total_dim
         self.source_start_symbol = nn.Parameter(torch.randn(1, 1, self.source_start_symbol_dim))
         self.source_num_events_with_start_symbol = self.source_num_events + 1
         self.source_transformer_sequence_length_with_start_symbol = self.source_transformer_sequence_length + 1
         self.target_start_symbol_dim = self.d_model
+        if self.positional_class_conditioning:
+            self.target_start_symbol_dim -= self.class_conditioning_total_dim
         self.target_start_symbol = nn.Parameter(
             torch.randn(1, self.target_events_per_source_patch, self.target_start_symbol_dim))
         self.target_num_events_with_start_symbol = self.target_num_events + 1
@@ -341,6 +345,8 @@ class VQNSynthTransformer(nn.Module):
         embedded = self.embed_data(sequence, kind=kind)
         with_positions = self.add_positions_to_sequence(embedded, kind=kind, embedding_dim=2,
                                                         time_indexes=time_indexes)
+        if self.positional_class_conditioning:      # :555-560
+            with_positions = self.add_class_conditioning_to_sequence(with_positions, class_conditioning)
         prepared = self.add_start_symbol(with_positions, kind=kind, class_conditioning=class_conditioning,
                                          sequence_dim=1)
         return prepared, (0, 2, 1)
@@ -362,11 +368,25 @@ class VQNSynthTransformer(nn.Module):
         pos_seq = helper.to_sequence(pos.to(sequence.device)).expand(batch_size, -1, -1)
         return torch.cat([sequence, pos_seq], dim=embedding_dim)
 
+    def add_class_conditioning_to_sequence(self, sequence_with_positions: torch.Tensor,
+                                           class_conditioning: Mapping[str, torch.Tensor]) -> torch.Tensor:
+        """The class embeddings appended to every row (reference priors/transformer.py:620-638)."""
+        emb = torch.zeros(*sequence_with_positions.shape[:2], self.class_conditioning_total_dim,
+                          device=sequence_with_positions.device, dtype=sequence_with_positions.dtype)
+        for name, cls in class_conditioning.items():
+            e = self.class_conditioning_embedding_layers[name].weight[cls]       # [B, 1, dim]
+            p0 = self.class_conditioning_start_positions_per_modality[name]
+            emb[:, :, p0:p0 + e.shape[2]] = e
+        return torch.cat([sequence_with_positions, emb], dim=-1)
+
     def add_start_symbol(self, sequence_with_positions: torch.Tensor, kind: Seq2SeqInputKind,
                          class_conditioning: Mapping[str, torch.Tensor], sequence_dim: int):
         batch_size = sequence_with_positions.shape[0]
         start = self.source_start_symbol if kind == Seq2SeqInputKind.Source else self.target_start_symbol
         start = start.repeat(batch_size, 1, 1)
+        if self.positional_class_conditioning:      # :660-663
+            start = self.add_class_conditioning_to_sequence(start, class_conditioning)
+            return torch.cat([start, sequence_with_positions], dim=sequence_dim)
         for name, cls in class_conditioning.items():
             emb = self.class_conditioning_embedding_layers[name].weight[cls].squeeze(1)
             p0 = self.class_conditioning_start_positions_per_modality[name]

@@ -345,6 +345,45 @@ def prior_wrapper_fixtures():
 
 
 @torch.no_grad()
+def prior_wrapper_positional_fixtures():
+    """positional_class_conditioning=True (priors/transformer.py:270-271,304-345,555-560,660-663): the class embeddings
+    are appended to EVERY position (and to the start symbols) instead of being written into the start symbol only;
+    effective embedding and start-symbol widths shrink by the class-conditioning width."""
+    from interactive_spectrogram_inpainting.priors.transformer import SelfAttentiveVQTransformer, UpsamplingVQTransformer
+    common = dict(n_class=32, channel=8, kernel_size=5, n_block=1, n_res_block=1, res_channel=8,
+                  d_model=64, embeddings_dim=8, positional_embeddings_dim=8,
+                  use_relative_transformer=True, predict_frequencies_first=True,
+                  conditional_model=True, positional_class_conditioning=True,
+                  class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+                  class_conditioning_embedding_dim_per_modality={"instrument_family_str": 16, "pitch": 16},
+                  conditional_model_nhead=4, conditional_model_num_encoder_layers=2,
+                  conditional_model_num_decoder_layers=3)
+    out = {}
+    torch.manual_seed(41)
+    top = SelfAttentiveVQTransformer(shape=[8, 4], condition_shape=[8, 4], self_conditional_model=True,
+                                     add_mask_token_to_symbols=True, **common).eval()
+    bottom = UpsamplingVQTransformer(shape=[16, 8], condition_shape=[8, 4], **common).eval()
+    for name, m in (("top", top), ("bottom", bottom)):
+        for k, v in m.state_dict().items():
+            out[f"{name}::w::{k}"] = v.numpy()
+        out[f"{name}::effective_dim"] = np.array(m.embeddings_effective_dim)
+    B = 2
+    g = torch.Generator().manual_seed(42)
+    cls = {"instrument_family_str": torch.randint(0, 11, (B, 1), generator=g),
+           "pitch": torch.randint(0, 61, (B, 1), generator=g)}
+    top_code = torch.randint(0, 32, (B, 8, 4), generator=g)
+    mask = torch.rand(B, 8, 4, generator=g) < 0.4
+    src, tgt = top.to_sequences(top_code, top_code, class_conditioning=cls, mask=mask)
+    out.update({"top::code": top_code.numpy(), "top::mask": mask.numpy(), "top::src": src.numpy(), "top::tgt": tgt.numpy()})
+    bottom_code = torch.randint(0, 32, (B, 16, 8), generator=g)
+    src3, tgt3 = bottom.to_sequences(bottom_code, top_code, class_conditioning=cls)
+    out.update({"bottom::code": bottom_code.numpy(), "bottom::src": src3.numpy(), "bottom::tgt": tgt3.numpy()})
+    for k, v in cls.items():
+        out[f"cls::{k}"] = v.numpy()
+    _save("prior_wrapper_positional.npz", **out)
+
+
+@torch.no_grad()
 def filtering_fixtures():
     """top_k_top_p_filtering (sample.py:36-65), imported with its heavy script
     dependencies stubbed."""
@@ -603,6 +642,7 @@ def main():
     quantizer_fixtures()
     codemap_fixtures()
     prior_wrapper_fixtures()
+    prior_wrapper_positional_fixtures()
     filtering_fixtures()
     scheduler_fixtures()
     time_indexes_fixtures()

@@ -177,6 +177,58 @@ def test_wrapper_sequences_against_reference(golden_dir):
             d0.self_attn.Cq, d0.self_attn.Eq] == dec.tolist()
 
 
+def test_positional_class_conditioning_against_reference(golden_dir):
+    """positional_class_conditioning=True (reference priors/transformer.py:270-271,331,345,555-560,660-663): class
+    embeddings appended to every row and to the start symbols -- sequences pinned to the reference's, parameter shapes
+    equal to its state dict; the model then runs (forward, KV-cached sampling == full-pass sampling)."""
+    import sample as S
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.priors.transformer import (
+        SelfAttentiveVQTransformer, UpsamplingVQTransformer, Seq2SeqInputKind)
+    z = np.load(golden_dir / "prior_wrapper_positional.npz")
+    dev = _dev()
+    common = {k: v for k, v in COMMON.items() if k != "class_conditioning_prepend_to_dummy_input"}
+    common["positional_class_conditioning"] = True
+    torch.manual_seed(6)
+    top = SelfAttentiveVQTransformer(shape=[8, 4], condition_shape=[8, 4], self_conditional_model=True,
+                                     add_mask_token_to_symbols=True, **common)
+    bottom = UpsamplingVQTransformer(shape=[16, 8], condition_shape=[8, 4], **common)
+    for name, m in (("top", top), ("bottom", bottom)):
+        sd = {k[len(name) + 5:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "::w::")}
+        missing = m.load_state_dict(sd, strict=False)      # strict shapes: a width mismatch raises here
+        assert all(k.startswith("transformer.") for k in missing.missing_keys) and not missing.unexpected_keys
+        assert m.embeddings_effective_dim == int(z[name + "::effective_dim"]) == 64 - 8 - 32
+    top, bottom = top.to(dev).eval(), bottom.to(dev).eval()
+    cls = {k[5:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("cls::")}
+    code = torch.from_numpy(z["top::code"]).to(dev)
+    mask = torch.from_numpy(z["top::mask"]).to(dev)
+    src, tgt = top.to_sequences(code, code, class_conditioning=cls, mask=mask)
+    _close(src, z["top::src"], 1e-6, "top src"); _close(tgt, z["top::tgt"], 1e-6, "top tgt")
+    bcode = torch.from_numpy(z["bottom::code"]).to(dev)
+    srcb, tgtb = bottom.to_sequences(bcode, code, class_conditioning=cls)
+    _close(srcb, z["bottom::src"], 1e-6, "bottom src"); _close(tgtb, z["bottom::tgt"], 1e-6, "bottom tgt")
+    logits, _ = bottom(tgtb, srcb)
+    assert logits.shape == (2, 128, 32) and torch.isfinite(logits).all()
+    # sampling: KV-cached loop == full pass per token (same uniforms)
+    B = 2
+    g = torch.Generator().manual_seed(3)
+    uni = torch.rand(top.target_transformer_sequence_length, B, generator=g)
+    cond = {"pitch": torch.tensor([20]), "instrument_family_str": torch.tensor([3])}
+    got = S.sample_model(top, dev, B, [8, 4], temperature=1.0, class_conditioning=cond, top_p_sampling_p=0.9, uniforms=uni)
+    clsd = {k: v.long().expand(B).reshape(B, 1).to(dev) for k, v in cond.items()}
+    codemap = torch.full((B, 8, 4), top.mask_token_index, dtype=torch.int64, device=dev)
+    srcs, tgts = top.to_sequences(codemap.clamp(max=top.n_class_target - 1), codemap, class_conditioning=clsd)
+    seq = top.target_codemaps_helper.to_sequence(codemap).clone()
+    memory = None
+    for i in range(seq.shape[1]):
+        lg, memory = top(tgts, srcs, memory=memory)
+        s_i = _ops.sample_rows(lg[:, i].contiguous(), 1.0, 0, 0.9, uni[i])
+        seq[:, i] = s_i
+        emb = top.embed_data(s_i, Seq2SeqInputKind.Target)
+        tgts[:, i + 1, :top.embeddings_effective_dim] = emb
+    assert torch.equal(got, top.target_codemaps_helper.to_time_frequency_map(seq))
+
+
 def _oracle_logits(model, src, tgt):
     from oracle import prior_oracle as P
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}

@@ -188,12 +188,12 @@ struct Gemv1Args {
 template <int KQ>   // float4 per lane of a K-long row: K <= 256 KQ
 __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
   RowLinArgs &a = g.r;
-  if (a.pos) {
-    const long p = *a.pos;
-    a.x += p * a.x_pos;
-    if (a.res) a.res += p * a.res_pos;
-    if (a.out2) a.out2 += p * a.out2_pos;
-  }
+  // replayable launches: the position comes from device memory.  The load is issued here and only waited for where an
+  // offset actually depends on it (most launches of a position have none, or only the cache slot of their store)
+  long ppos = 0;
+  if (a.pos) ppos = *a.pos;
+  if (a.x_pos) a.x += ppos * a.x_pos;
+  if (a.res && a.res_pos) a.res += ppos * a.res_pos;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nq = a.K >> 2;
   const int n0 = blockIdx.x * NPB + wave * 2;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
     }
     if (a.relu) v = fmaxf(v, 0.f);
     if (n < a.split) a.out[n] = v;
-    else a.out2[n - a.split] = v;
+    else a.out2[ppos * a.out2_pos + (n - a.split)] = v;
   }
 }
 
@@ -455,6 +455,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
         if (a.out2) a.out2 += (long)p * a.out2_pos;
         a.pos = nullptr;
       }
+      if (!a.x_pos && !a.res_pos && !a.out2_pos) a.pos = nullptr;      // nothing of this launch depends on the position
       if (row_gemv1_supported(a, part != nullptr)) return launch_row_gemv1(a, part, ns, hd, q_st);
       return launch_row_linear(a, q_st);
     };

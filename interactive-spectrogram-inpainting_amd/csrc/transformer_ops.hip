@@ -203,6 +203,57 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   const float *kb = k + b * k_sb + h * k_sh + gl * 4;
   const float *vb = v + b * v_sb + h * v_sh + gl * 4;
   const float *eb = e ? e + (size_t)h * R * HD + gl * 4 : nullptr;
+  float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float gmax, gsum;
+  constexpr int UMAX = 9;          // rows per lane group held in registers: splits of up to 9 * RPP keys
+  if (Sk <= UMAX * RPP) {
+    // ---- short split (the decoding loop's 128-key splits): K, V and relative rows are all requested up front -- ONE
+    // memory round trip instead of the score pass followed by the value pass (the kernel is a chain of dependent
+    // latencies, not of bandwidth: 10 -> ~8 us per launch, 16 launches per position)
+    float4 kk[UMAX], vv[UMAX], ee[UMAX];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const int j = grp + u * RPP;
+      const int jc = j < Sk ? j : 0;
+      kk[u] = *reinterpret_cast<const float4 *>(kb + (size_t)jc * k_ss);
+      vv[u] = *reinterpret_cast<const float4 *>(vb + (size_t)jc * v_ss);
+      ee[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (eb) {
+        int r = evq - (key0 + jc) / Ck + Ek - 1;
+        r = r < 0 ? 0 : (r >= R ? R - 1 : r);
+        ee[u] = *reinterpret_cast<const float4 *>(eb + (size_t)r * HD);
+      }
+    }
+    float sv[UMAX];
+    float lmax = -1e30f;
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const float4 kq = make_float4(kk[u].x + ee[u].x, kk[u].y + ee[u].y, kk[u].z + ee[u].z, kk[u].w + ee[u].w);
+      float acc = (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      acc *= scale;
+      sv[u] = acc;
+      if (grp + u * RPP < Sk) lmax = fmaxf(lmax, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float lsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) {
+      const float pj = grp + u * RPP < Sk ? expf(sv[u] - gmax) : 0.f;
+      if (gl == 0) lsum += pj;
+      o0.x += pj * vv[u].x; o0.y += pj * vv[u].y; o0.z += pj * vv[u].z; o0.w += pj * vv[u].w;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if (lane == 0) red[4 + wave] = lsum;
+    __syncthreads();
+    gsum = (red[4] + red[5]) + (red[6] + red[7]);
+  } else {
   // ---- scores
   float lmax = -1e30f;
   for (int j0 = grp; j0 < Sk; j0 += 4 * RPP) {
@@ -240,7 +291,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
-  const float gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float lsum = 0.f;
   for (int j = tid; j < Sk; j += 256) {
     const float pj = expf(sc[j] - gmax);
@@ -251,9 +302,9 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
   if (lane == 0) red[4 + wave] = lsum;
   __syncthreads();
-  const float gsum = (red[4] + red[5]) + (red[6] + red[7]);
+  gsum = (red[4] + red[5]) + (red[6] + red[7]);
   // ---- out = sum_j p_j v_j : each lane group accumulates its rows, 4 loads in flight
-  float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0, o3 = o0;
+  float4 o1 = o0, o2 = o0, o3 = o0;
   for (int j0 = grp; j0 < Sk; j0 += 4 * RPP) {
     const int ja = j0, jb = j0 + RPP, jc = j0 + 2 * RPP, jd = j0 + 3 * RPP;
     const float pa = sc[ja], pb = jb < Sk ? sc[jb] : 0.f, pc = jc < Sk ? sc[jc] : 0.f, pd = jd < Sk ? sc[jd] : 0.f;
@@ -268,6 +319,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   }
   o0.x = (o0.x + o1.x) + (o2.x + o3.x); o0.y = (o0.y + o1.y) + (o2.y + o3.y);
   o0.z = (o0.z + o1.z) + (o2.z + o3.z); o0.w = (o0.w + o1.w) + (o2.w + o3.w);
+  }
   *reinterpret_cast<float4 *>(part + grp * HD + gl * 4) = o0;
   __syncthreads();
   if (tid < HD) {

@@ -36,4 +36,42 @@ inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 constexpr int kBK = 32;  // K-chunk of the implicit GEMM; packed weights are padded to it
 
+#if defined(__HIPCC__)
+// ---- cross-lane reductions on the VALU's DPP path (gfx9 controls).  `__shfl_xor` compiles to ds_bpermute_b32 -- a trip
+// through the LDS crossbar, ~100 cycles, six of them chained per 64-lane reduction -- which is what the latency-bound
+// one-row kernels of the decoding loop spent a third of their time in; a DPP step costs a VALU instruction.
+// dpp(v, ctrl): every lane reads v of the lane the control selects (rows of 16 lanes).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(const float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over aligned groups of 4 / 8 / 16 lanes, result in every lane of the group
+__device__ __forceinline__ float group4_sum(float v) {
+  v += dpp_f32<0xB1>(v);            // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);            // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ float group8_sum(float v) { v = group4_sum(v); return v + dpp_f32<0x141>(v); }   // row_half_mirror
+__device__ __forceinline__ float row16_sum(float v) { v = group8_sum(v); return v + dpp_f32<0x140>(v); }    // row_mirror
+// sum / maximum over the 64 lanes, result in every lane (broadcast through an SGPR)
+__device__ __forceinline__ float wave64_sum(float v) {
+  v = row16_sum(v);
+  v += dpp_f32<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+  v += dpp_f32<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave64_max(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));  // every lane: its row's maximum
+  // rows 1 and 3 take in their left neighbour's, then rows 2 and 3 row 1's: masked-off rows read 0, so combine by hand
+  const float r15 = dpp_f32<0x142, 0xA>(v);
+  v = ((threadIdx.x >> 4) & 1) ? fmaxf(v, r15) : v;
+  const float r31 = dpp_f32<0x143, 0xC>(v);
+  v = ((threadIdx.x >> 5) & 1) ? fmaxf(v, r31) : v;
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#endif
+
 }  // namespace isi

@@ -55,11 +55,7 @@ struct RowLinArgs {
   long x_pos, res_pos, out2_pos;
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }   // DPP path (isi_common.h)
 
 template <int MR>
 __global__ __launch_bounds__(256) void row_linear_ln_kernel(RowLinArgs a) {

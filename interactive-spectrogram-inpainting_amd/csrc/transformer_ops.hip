@@ -230,14 +230,12 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     for (int u = 0; u < UMAX; ++u) {
       const float4 kq = make_float4(kk[u].x + ee[u].x, kk[u].y + ee[u].y, kk[u].z + ee[u].z, kk[u].w + ee[u].w);
       float acc = (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
-#pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+      acc = G == 16 ? row16_sum(acc) : G == 8 ? group8_sum(acc) : group4_sum(acc);   // over the row's G lanes
       acc *= scale;
       sv[u] = acc;
       if (grp + u * RPP < Sk) lmax = fmaxf(lmax, acc);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    lmax = wave64_max(lmax);
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -248,8 +246,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
       if (gl == 0) lsum += pj;
       o0.x += pj * vv[u].x; o0.y += pj * vv[u].y; o0.z += pj * vv[u].z; o0.w += pj * vv[u].w;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    lsum = wave64_sum(lsum);
     if (lane == 0) red[4 + wave] = lsum;
     __syncthreads();
     gsum = (red[4] + red[5]) + (red[6] + red[7]);

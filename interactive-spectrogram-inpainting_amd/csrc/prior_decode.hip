@@ -192,16 +192,23 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
   if (a.res && a.res_pos) a.res += ppos * a.res_pos;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nq = a.K >> 2;
-  const int n0 = blockIdx.x * NPB + wave * 2;
+  // two output features per wave; ONE for long rows (K > 512: a wave then streams 4-8 KB instead of 8-16 KB and the
+  // launch has twice the workgroups -- the K = 2048 launch of a layer went from 6.7 to ~5.5 us)
+  constexpr int RPW = KQ >= 4 ? 1 : 2;
+  const int n0 = blockIdx.x * (4 * RPW) + wave * RPW;
   if (n0 >= a.N) return;
-  const bool two = n0 + 1 < a.N;
+  const bool two = RPW == 2 && n0 + 1 < a.N;
   const float4 *w0 = reinterpret_cast<const float4 *>(a.W + (size_t)n0 * a.K);
   const float4 *w1 = reinterpret_cast<const float4 *>(a.W + (size_t)(two ? n0 + 1 : n0) * a.K);
   float4 wa[KQ], wb[KQ], xv[KQ], gq[KQ], bq[KQ];
 #pragma unroll
   for (int i = 0; i < KQ; ++i) {
     const int qd = lane + 64 * i;
-    if (qd < nq) { wa[i] = w0[qd]; wb[i] = w1[qd]; }
+    if (qd < nq) {
+      wa[i] = w0[qd];
+      if constexpr (RPW == 2) wb[i] = w1[qd];
+      else wb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   constexpr int PS = KQ <= 2 ? 8 : 1;       // key splits held in registers (merged input: K <= 512)
   float4 pv[KQ][PS];
@@ -217,8 +224,9 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
         for (int s2 = 0; s2 < PS; ++s2) {
           if (s2 < g.NS) {
             pv[i][s2] = *reinterpret_cast<const float4 *>(base + (size_t)s2 * (g.HD + 4) + c);
-            pm[i][s2] = base[(size_t)s2 * (g.HD + 4) + g.HD];
-            pl[i][s2] = base[(size_t)s2 * (g.HD + 4) + g.HD + 1];
+            const float2 ml = *reinterpret_cast<const float2 *>(base + (size_t)s2 * (g.HD + 4) + g.HD);
+            pm[i][s2] = ml.x;
+            pl[i][s2] = ml.y;
           }
         }
       }
@@ -335,11 +343,11 @@ bool row_gemv1_supported(const RowLinArgs &a, bool merged) {
 
 int launch_row_gemv1(const RowLinArgs &a, const float *part, int NS, int HD, hipStream_t st) {
   Gemv1Args g{a, part, NS, HD};
-  dim3 grid((a.N + NPB - 1) / NPB), block(256);
+  dim3 grid((a.N + NPB - 1) / NPB), grid1((a.N + 3) / 4), block(256);   // grid1: one output feature per wave
   if (a.K <= 256) hipLaunchKernelGGL(row_gemv1_kernel<1>, grid, block, 0, st, g);
   else if (a.K <= 512) hipLaunchKernelGGL(row_gemv1_kernel<2>, grid, block, 0, st, g);
-  else if (a.K <= 1024) hipLaunchKernelGGL(row_gemv1_kernel<4>, grid, block, 0, st, g);
-  else hipLaunchKernelGGL(row_gemv1_kernel<8>, grid, block, 0, st, g);
+  else if (a.K <= 1024) hipLaunchKernelGGL(row_gemv1_kernel<4>, grid1, block, 0, st, g);
+  else hipLaunchKernelGGL(row_gemv1_kernel<8>, grid1, block, 0, st, g);
   return check_launch("row_gemv1");
 }
 

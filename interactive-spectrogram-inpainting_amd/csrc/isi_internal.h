@@ -72,6 +72,16 @@ int rel_attention_decode_f32(const isi_attn_args *g, int q_pos, float *workspace
 int rel_attention_decode_pos_f32(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
                                  hipStream_t stream);
 size_t rel_attention_decode_workspace_floats(int B, int H, int head_dim);
+// optional tail of the sampling kernel (the decoding loop): codes[row, p - i_off] = token; x_seq[p + 1][row, 0:eff] = table[token]
+struct SampleCommit {
+  const float *table; int eff;
+  int64_t *codes; int codes_stride;
+  int p_value, i_off, S_t;
+  float *x_seq; int x_stride;
+};
+int sample_row_commit_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
+                          const float *u, int64_t *out, float *filtered, const int *pos, int pos_off,
+                          const SampleCommit &cm, hipStream_t stream);
 int sample_row_pos_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                        const float *u, int64_t *out, float *filtered, const int *pos, int pos_off,
                        hipStream_t stream);

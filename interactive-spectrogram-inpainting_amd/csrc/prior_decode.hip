@@ -393,20 +393,6 @@ int launch_row_linear_8(const RowLinArgs &a, hipStream_t st) {
   return check_launch("row_linear_ln");
 }
 
-// codes[b, i] = sampled[b]; x_seq[p + 1][b, 0:eff] = table[sampled[b], :]   (i = p - i_off, p = *pos)
-__global__ void commit_token_kernel(const int64_t *__restrict__ sampled, const float *__restrict__ table,
-                                    int eff, int64_t *__restrict__ codes, int codes_stride,
-                                    const int *__restrict__ pos, int p_value, int i_off, int S_t,
-                                    float *__restrict__ x_seq, int B, int x_stride) {
-  const int b = blockIdx.x;
-  const int p = pos ? *pos : p_value;
-  const int64_t tok = sampled[b];
-  if (threadIdx.x == 0) codes[(size_t)b * codes_stride + (p - i_off)] = tok;
-  if (p + 1 >= S_t) return;
-  float *x_next = x_seq + ((size_t)(p + 1) * B + b) * x_stride;
-  for (int e = threadIdx.x; e < eff; e += blockDim.x) x_next[e] = table[(size_t)tok * eff + e];
-}
-
 __global__ void set_pos_kernel(int *pos, int value, int add) { *pos = add ? *pos + value : value; }
 
 }  // namespace
@@ -518,13 +504,11 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
                    nullptr, 0, w->n_class, B, w->n_class, d, 0, 1e-5f, nullptr, 0, 0, 0};
       int rc;
       if ((rc = launch_rows(a))) return rc;
-      if ((rc = sample_row_pos_f32(logits, w->n_class, B, w->n_class, temperature, top_k, top_p,
-                                   p < 0 ? s->uniforms : s->uniforms + (size_t)(p - i_off) * B, sampled, nullptr, pos_arg,
-                                   i_off, q_st)))
+      const SampleCommit cm{w->embed_table, w->eff_dim, s->codes, s->S, p, i_off, s->S_t, s->x_seq, d};
+      if ((rc = sample_row_commit_f32(logits, w->n_class, B, w->n_class, temperature, top_k, top_p,
+                                      p < 0 ? s->uniforms : s->uniforms + (size_t)(p - i_off) * B, sampled, nullptr, pos_arg,
+                                      i_off, cm, q_st)))
         return rc;
-      hipLaunchKernelGGL(commit_token_kernel, dim3(B), dim3(256), 0, q_st, sampled, w->embed_table, w->eff_dim,
-                         s->codes, s->S, pos_arg, p, i_off, s->S_t, s->x_seq, B, d);
-      if ((rc = check_launch("commit_token"))) return rc;
     }
     if (p >= 0) return ISI_OK;
     hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, q_st, pos, 1, 1);

@@ -418,7 +418,8 @@ __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__res
                                                               float top_p, const float *__restrict__ u,
                                                               int64_t *__restrict__ out,
                                                               float *__restrict__ filtered,
-                                                              const int *__restrict__ pos, int pos_off) {
+                                                              const int *__restrict__ pos, int pos_off,
+                                                              const SampleCommit cm) {
   if (pos) u += (size_t)(*pos - pos_off) * gridDim.x;  // replayable launch: this token's uniforms
   __shared__ float val[1024];
   __shared__ int idx[1024];
@@ -491,6 +492,16 @@ __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__res
   if (tid < n && scan[tid] > sh_f[0]) atomicMin(&sh_i, tid);
   __syncthreads();
   if (tid == 0) out[row] = sh_i;
+  // the decoding loop's commit, in the same launch: code row, and the token's embedding into the next input row
+  if (cm.table) {
+    const int p = pos ? *pos : cm.p_value;
+    const int tok = sh_i;
+    if (tid == 0) cm.codes[(size_t)row * cm.codes_stride + (p - cm.i_off)] = tok;
+    if (p + 1 < cm.S_t) {
+      float *x_next = cm.x_seq + ((size_t)(p + 1) * gridDim.x + row) * cm.x_stride;
+      for (int e = tid; e < cm.eff; e += np) x_next[e] = cm.table[(size_t)tok * cm.eff + e];
+    }
+  }
 }
 
 int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
@@ -502,12 +513,20 @@ int sample_row_f32(const float *logits, int stride, int rows, int n, float tempe
 int sample_row_pos_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                        const float *u, int64_t *out, float *filtered, const int *pos, int pos_off,
                        hipStream_t stream) {
+  SampleCommit none;
+  memset(&none, 0, sizeof none);
+  return sample_row_commit_f32(logits, stride, rows, n, temperature, top_k, top_p, u, out, filtered, pos, pos_off, none, stream);
+}
+
+int sample_row_commit_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
+                          const float *u, int64_t *out, float *filtered, const int *pos, int pos_off,
+                          const SampleCommit &cm, hipStream_t stream) {
   if (!logits || !u || !out || rows <= 0 || n <= 0 || temperature <= 0.f) return invalid("sample_row: bad argument");
   if (n > 1024) return unsupported("sample_row: at most 1024 classes");
   int np = 64;
   while (np < n) np <<= 1;
   hipLaunchKernelGGL(sample_row_f32_kernel, dim3(rows), dim3(np), 0, stream, logits, stride, n, 1.0f / temperature,
-                     top_k, top_p, u, out, filtered, pos, pos_off);
+                     top_k, top_p, u, out, filtered, pos, pos_off, cm);
   return check_launch("sample_row_f32");
 }
 

@@ -43,6 +43,10 @@ def _s(t):
 # Products of the training step's forward and input-gradient convolutions: 2 = six-term split-bf16
 # (fp32-grade; default), 0 = fp32 matrix pipe.  Weight gradients always use the fp32 pipe.
 TRAIN_PRECISION = {"f32": 0, "bf16x6": 2}[os.environ.get("ISI_TRAIN_PRECISION", "bf16x6")]
+# Products of the training step's FORWARD convolutions: 'f16x3' = the eval path's three-term split-f16 products
+# (fp32-grade, half the matrix work of the six-term bf16 split; operands are activations and weights, whose range the
+# f16 pieces cover -- gradients are not: the input-gradient convolutions keep TRAIN_PRECISION); 'same' = TRAIN_PRECISION.
+FWD_PRECISION = {"same": TRAIN_PRECISION, "f16x3": 3 if TRAIN_PRECISION else 0}[os.environ.get("ISI_TRAIN_FWD_PRECISION", "f16x3")]
 # Products of the weight-gradient GEMMs (flag bits of isi_conv_wgrad_f32's `transposed` word): three-term split by
 # default (relative error ~4e-6 of the gradient's maximum, far below the step-to-step noise of training and 50x
 # inside the parity tests' 2e-4), 'bf16x6' = fp32-grade, 'f32' = fp32 matrix pipe.
@@ -239,7 +243,7 @@ class Grads:
 
 # ------------------------------------------------------------------ forward (train mode)
 def _conv_fwd(layer: _ConvParams, x, relu, x2=None, out_nchw=False):
-    return layer.run(x, relu=relu, x2=x2, out_nchw=out_nchw, bf16x3=TRAIN_PRECISION)
+    return layer.run(x, relu=relu, x2=x2, out_nchw=out_nchw, bf16x3=FWD_PRECISION)
 
 
 def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
@@ -251,8 +255,8 @@ def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
     tape[f"{tag}.c3"] = x
     for j, i in enumerate(m._res):
         blk: RosinalityResBlock = m.blocks[i]
-        h = blk.conv[1].run(x, relu=True, bf16x3=TRAIN_PRECISION)
-        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=TRAIN_PRECISION)
+        h = blk.conv[1].run(x, relu=True, bf16x3=FWD_PRECISION)
+        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=FWD_PRECISION)
         tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
         x = y
     return x
@@ -260,17 +264,17 @@ def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
 
 def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_last: bool):
     tape[f"{tag}.in"], tape[f"{tag}.in2"] = x, x2
-    x = m.blocks[0].run(x, relu=True, x2=x2, bf16x3=TRAIN_PRECISION)
+    x = m.blocks[0].run(x, relu=True, x2=x2, bf16x3=FWD_PRECISION)
     tape[f"{tag}.c3"] = x
     for j, i in enumerate(m._res):
         blk = m.blocks[i]
-        h = blk.conv[1].run(x, relu=True, bf16x3=TRAIN_PRECISION)
-        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=TRAIN_PRECISION)
+        h = blk.conv[1].run(x, relu=True, bf16x3=FWD_PRECISION)
+        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=FWD_PRECISION)
         tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
         x = y
     for j, i in enumerate(m._up):
         last = j == len(m._up) - 1
-        x = m.blocks[i].run(x, relu=not last, out_nchw=(last and out_nchw_last), bf16x3=TRAIN_PRECISION)
+        x = m.blocks[i].run(x, relu=not last, out_nchw=(last and out_nchw_last), bf16x3=FWD_PRECISION)
         tape[f"{tag}.up{j}"] = x
     return x
 
@@ -421,7 +425,7 @@ def encode_train(model, x: torch.Tensor):
     x = x.contiguous()
     enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
     enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
-    z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=TRAIN_PRECISION))
+    z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=FWD_PRECISION))
     q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t)
     dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
     if dec_t.shape[-1] != enc_b.shape[-1]:
@@ -429,7 +433,7 @@ def encode_train(model, x: torch.Tensor):
             raise RuntimeError("Sizes of tensors must match except in dimension 1")
         w = min(dec_t.shape[-1], enc_b.shape[-1])            # vqvae.py:266-269
         dec_t, enc_b = dec_t[..., :w], enc_b[..., :w]
-    z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=TRAIN_PRECISION))
+    z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=FWD_PRECISION))
     q_b, diff_b, id_b, perp_b = quantize_train(model.quantize_b, z_b)
     return _as_bchw(q_t), _as_bchw(q_b), (diff_t + diff_b).reshape(1), id_t, id_b, perp_t, perp_b
 
@@ -453,7 +457,7 @@ class VQVAETrainFunction(torch.autograd.Function):
         x = x.contiguous()
         enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
         enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
-        z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=TRAIN_PRECISION))
+        z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=FWD_PRECISION))
         unq = model.disable_quantization      # UnquantizedBottleneck (bottleneck.py:107-119): identity, diff 0
 
         def _identity(z):
@@ -465,13 +469,13 @@ class VQVAETrainFunction(torch.autograd.Function):
         dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
         if dec_t.shape[-1] != enc_b.shape[-1]:
             raise NotImplementedError("training needs input sizes divisible by the total down-sampling factor")
-        z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=TRAIN_PRECISION))
+        z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=FWD_PRECISION))
         q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b)
         tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
         up = _as_bchw(q_t)
         for j, layer in enumerate(model.upsample_top_to_bottom):
             tape[f"up.in{j}"] = up
-            up = layer.run(up, relu=False, bf16x3=TRAIN_PRECISION)
+            up = layer.run(up, relu=False, bf16x3=FWD_PRECISION)
         dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True)
         diff = (diff_t + diff_b).reshape(1)
         ctx.model, ctx.tape = model, tape

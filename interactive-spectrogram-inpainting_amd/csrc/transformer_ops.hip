@@ -251,32 +251,30 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     __syncthreads();
     gsum = (red[4] + red[5]) + (red[6] + red[7]);
   } else {
-  // ---- scores
+  // ---- long split (sequences beyond 8 x 144 keys): scores, then values, 16 rows of a lane group in flight per step
+  // (with 4 the two passes of a 513-key split were 18 dependent round trips)
+  constexpr int UB = 16;
   float lmax = -1e30f;
-  for (int j0 = grp; j0 < Sk; j0 += 4 * RPP) {
-    float part_s[4];
+  for (int j0 = grp; j0 < Sk; j0 += UB * RPP) {
+    float4 kk[UB], ee[UB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UB; ++u) {
       const int j = j0 + u * RPP;
-      float acc = 0.f;
-      if (j < Sk) {
-        float4 kk = *reinterpret_cast<const float4 *>(kb + (size_t)j * k_ss);
-        if (eb) {
-          int r = evq - (key0 + j) / Ck + Ek - 1;
-          r = r < 0 ? 0 : (r >= R ? R - 1 : r);
-          const float4 ee = *reinterpret_cast<const float4 *>(eb + (size_t)r * HD);
-          kk.x += ee.x; kk.y += ee.y; kk.z += ee.z; kk.w += ee.w;
-        }
-        acc = (qq.x * kk.x + qq.y * kk.y) + (qq.z * kk.z + qq.w * kk.w);
+      const int jc = j < Sk ? j : j0;
+      kk[u] = *reinterpret_cast<const float4 *>(kb + (size_t)jc * k_ss);
+      ee[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (eb) {
+        int r = evq - (key0 + jc) / Ck + Ek - 1;
+        r = r < 0 ? 0 : (r >= R ? R - 1 : r);
+        ee[u] = *reinterpret_cast<const float4 *>(eb + (size_t)r * HD);
       }
-      part_s[u] = acc;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      float acc = part_s[u];
-#pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    for (int u = 0; u < UB; ++u) {
       const int j = j0 + u * RPP;
+      const float4 kq = make_float4(kk[u].x + ee[u].x, kk[u].y + ee[u].y, kk[u].z + ee[u].z, kk[u].w + ee[u].w);
+      float acc = (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
+      acc = G == 16 ? row16_sum(acc) : G == 8 ? group8_sum(acc) : group4_sum(acc);
       if (j < Sk) {
         acc *= scale;
         if (gl == 0) sc[j] = acc;
@@ -284,8 +282,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
       }
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+  lmax = wave64_max(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
   gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -295,33 +292,36 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     sc[j] = pj;
     lsum += pj;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+  lsum = wave64_sum(lsum);
   if (lane == 0) red[4 + wave] = lsum;
   __syncthreads();
   gsum = (red[4] + red[5]) + (red[6] + red[7]);
-  // ---- out = sum_j p_j v_j : each lane group accumulates its rows, 4 loads in flight
-  float4 o1 = o0, o2 = o0, o3 = o0;
-  for (int j0 = grp; j0 < Sk; j0 += 4 * RPP) {
-    const int ja = j0, jb = j0 + RPP, jc = j0 + 2 * RPP, jd = j0 + 3 * RPP;
-    const float pa = sc[ja], pb = jb < Sk ? sc[jb] : 0.f, pc = jc < Sk ? sc[jc] : 0.f, pd = jd < Sk ? sc[jd] : 0.f;
-    const float4 va = *reinterpret_cast<const float4 *>(vb + (size_t)ja * v_ss);
-    const float4 vbb = *reinterpret_cast<const float4 *>(vb + (size_t)(jb < Sk ? jb : ja) * v_ss);
-    const float4 vc = *reinterpret_cast<const float4 *>(vb + (size_t)(jc < Sk ? jc : ja) * v_ss);
-    const float4 vd = *reinterpret_cast<const float4 *>(vb + (size_t)(jd < Sk ? jd : ja) * v_ss);
-    o0.x += pa * va.x; o0.y += pa * va.y; o0.z += pa * va.z; o0.w += pa * va.w;
-    o1.x += pb * vbb.x; o1.y += pb * vbb.y; o1.z += pb * vbb.z; o1.w += pb * vbb.w;
-    o2.x += pc * vc.x; o2.y += pc * vc.y; o2.z += pc * vc.z; o2.w += pc * vc.w;
-    o3.x += pd * vd.x; o3.y += pd * vd.y; o3.z += pd * vd.z; o3.w += pd * vd.w;
+  // ---- out = sum_j p_j v_j
+  for (int j0 = grp; j0 < Sk; j0 += UB * RPP) {
+    float4 vv[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int j = j0 + u * RPP;
+      vv[u] = *reinterpret_cast<const float4 *>(vb + (size_t)(j < Sk ? j : j0) * v_ss);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int j = j0 + u * RPP;
+      const float pj = j < Sk ? sc[j] : 0.f;
+      o0.x += pj * vv[u].x; o0.y += pj * vv[u].y; o0.z += pj * vv[u].z; o0.w += pj * vv[u].w;
+    }
   }
-  o0.x = (o0.x + o1.x) + (o2.x + o3.x); o0.y = (o0.y + o1.y) + (o2.y + o3.y);
-  o0.z = (o0.z + o1.z) + (o2.z + o3.z); o0.w = (o0.w + o1.w) + (o2.w + o3.w);
   }
-  *reinterpret_cast<float4 *>(part + grp * HD + gl * 4) = o0;
+  // the wave's 64 / G lane groups are added up in registers (lane l <-> l ^ o for o = G .. 32), then one row per wave
+  // goes through LDS: four reads per output instead of a chain of 256 / G
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+    o0.x += __shfl_xor(o0.x, o); o0.y += __shfl_xor(o0.y, o); o0.z += __shfl_xor(o0.z, o); o0.w += __shfl_xor(o0.w, o);
+  }
+  if (lane < G) *reinterpret_cast<float4 *>(part + wave * HD + lane * 4) = o0;
   __syncthreads();
   if (tid < HD) {
-    float acc = 0.f;
-    for (int g = 0; g < RPP; ++g) acc += part[g * HD + tid];
+    const float acc = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
     if (gridDim.z == 1) {
       out[b * o_sb + h * o_sh + tid] = acc / gsum;
     } else {

@@ -335,6 +335,144 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
   }
 }
 
+// ---- a few rows (batched decoding, up to 8 sequences per launch): the same kernel shape with the rows' inputs in
+// registers -- weights are loaded once and used for every row.  Per row the operations of row_gemv1_kernel /
+// row_linear_ln_kernel, in their order: a row's result does not depend on the rows it shares a launch with.
+template <int KQ, int MR>
+__global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
+  long ppos = 0;
+  if (a.pos) ppos = *a.pos;
+  if (a.x_pos) a.x += ppos * a.x_pos;
+  if (a.res && a.res_pos) a.res += ppos * a.res_pos;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nq = a.K >> 2;
+  constexpr int RPW = KQ >= 4 ? 1 : 2;
+  const int n0 = blockIdx.x * (4 * RPW) + wave * RPW;
+  if (n0 >= a.N) return;
+  const bool two = RPW == 2 && n0 + 1 < a.N;
+  const float4 *w0 = reinterpret_cast<const float4 *>(a.W + (size_t)n0 * a.K);
+  const float4 *w1 = reinterpret_cast<const float4 *>(a.W + (size_t)(two ? n0 + 1 : n0) * a.K);
+  float4 wa[KQ], wb[KQ], gq[KQ], bq[KQ], xv[MR][KQ];
+#pragma unroll
+  for (int i = 0; i < KQ; ++i) {
+    const int qd = lane + 64 * i;
+    if (qd < nq) {
+      wa[i] = w0[qd];
+      if constexpr (RPW == 2) wb[i] = w1[qd];
+      else wb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.ln_g) { gq[i] = reinterpret_cast<const float4 *>(a.ln_g)[qd]; bq[i] = reinterpret_cast<const float4 *>(a.ln_b)[qd]; }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m)
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      const int qd = lane + 64 * i;
+      xv[m][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < a.M && qd < nq) xv[m][i] = reinterpret_cast<const float4 *>(a.x + (size_t)m * a.x_stride)[qd];
+    }
+  const int n = n0 + (lane & 1);
+  const bool writer = lane < 2 && (lane == 0 || two);
+  float bias_v = 0.f, rg = 1.f, rb = 0.f, res_v[MR];
+  if (writer) {
+    if (a.bias) bias_v = a.bias[n];
+    if (a.res && a.res_g) { rg = a.res_g[n]; rb = a.res_b[n]; }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) res_v[m] = (writer && a.res && m < a.M) ? a.res[(size_t)m * a.res_stride + n] : 0.f;
+  constexpr int RS = 8;
+  float rrow[MR][RS];
+  if (a.res && a.res_g) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int i = 0; i < RS; ++i) {
+        const int c = lane + 64 * i;
+        rrow[m][i] = (m < a.M && c < a.N) ? a.res[(size_t)m * a.res_stride + c] : 0.f;
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    if (m >= a.M) break;
+    if (a.ln_g) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) if (lane + 64 * i < nq) s += (xv[m][i].x + xv[m][i].y) + (xv[m][i].z + xv[m][i].w);
+      const float mean = wave_sum(s) / (float)a.K;
+      float var = 0.f;
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {
+        if (lane + 64 * i < nq) {
+          const float d0 = xv[m][i].x - mean, d1 = xv[m][i].y - mean, d2 = xv[m][i].z - mean, d3 = xv[m][i].w - mean;
+          var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)a.K + a.eps);
+#pragma unroll
+      for (int i = 0; i < KQ; ++i) {
+        if (lane + 64 * i < nq) {
+          xv[m][i].x = (xv[m][i].x - mean) * rstd * gq[i].x + bq[i].x; xv[m][i].y = (xv[m][i].y - mean) * rstd * gq[i].y + bq[i].y;
+          xv[m][i].z = (xv[m][i].z - mean) * rstd * gq[i].z + bq[i].z; xv[m][i].w = (xv[m][i].w - mean) * rstd * gq[i].w + bq[i].w;
+        }
+      }
+    }
+    float rmean = 0.f, rrstd = 1.f;
+    if (a.res && a.res_g) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) s += rrow[m][i];
+      rmean = wave_sum(s) / (float)a.N;
+      float var = 0.f;
+#pragma unroll
+      for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) { const float dv = rrow[m][i] - rmean; var += dv * dv; }
+      rrstd = 1.0f / sqrtf(wave_sum(var) / (float)a.N + a.eps);
+    }
+    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < KQ; ++i) {
+      if (lane + 64 * i < nq) {
+        acc0 += (wa[i].x * xv[m][i].x + wa[i].y * xv[m][i].y) + (wa[i].z * xv[m][i].z + wa[i].w * xv[m][i].w);
+        acc1 += (wb[i].x * xv[m][i].x + wb[i].y * xv[m][i].y) + (wb[i].z * xv[m][i].z + wb[i].w * xv[m][i].w);
+      }
+    }
+    acc0 = wave_sum(acc0);
+    acc1 = wave_sum(acc1);
+    if (writer) {
+      float v = (lane == 0 ? acc0 : acc1) + bias_v;
+      if (a.res) {
+        float r = res_v[m];
+        if (a.res_g) r = (r - rmean) * rrstd * rg + rb;
+        v += r;
+      }
+      if (a.relu) v = fmaxf(v, 0.f);
+      if (n < a.split) a.out[(size_t)m * a.out_stride + n] = v;
+      else a.out2[ppos * a.out2_pos + (size_t)m * a.out2_stride + (n - a.split)] = v;
+    }
+  }
+}
+
+// rows x float4-per-lane held in registers: at most 16 (64 VGPRs)
+bool row_gemvm_supported(const RowLinArgs &a) {
+  if (a.M < 1 || a.M > 8 || (a.K & 3) || a.K > 2048) return false;
+  if (a.res && a.res_g && a.N > 512) return false;
+  const int kq = a.K <= 256 ? 1 : a.K <= 512 ? 2 : a.K <= 1024 ? 4 : 8;
+  const int mr = a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
+  return kq * mr <= 16;
+}
+
+int launch_row_gemvm(const RowLinArgs &a, hipStream_t st) {
+  const int kq = a.K <= 256 ? 1 : a.K <= 512 ? 2 : a.K <= 1024 ? 4 : 8;
+  const int mr = a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
+  dim3 grid(kq >= 4 ? (a.N + 3) / 4 : (a.N + NPB - 1) / NPB), block(256);
+#define ISI_GM(KQ_, MR_) hipLaunchKernelGGL((row_gemvm_kernel<KQ_, MR_>), grid, block, 0, st, a)
+  if (kq == 1) { if (mr == 2) ISI_GM(1, 2); else if (mr == 4) ISI_GM(1, 4); else ISI_GM(1, 8); }
+  else if (kq == 2) { if (mr == 2) ISI_GM(2, 2); else if (mr == 4) ISI_GM(2, 4); else ISI_GM(2, 8); }
+  else if (kq == 4) { if (mr == 2) ISI_GM(4, 2); else ISI_GM(4, 4); }
+  else ISI_GM(8, 2);
+#undef ISI_GM
+  return check_launch("row_gemvm");
+}
+
 bool row_gemv1_supported(const RowLinArgs &a, bool merged) {
   if (a.M != 1 || (a.K & 3) || a.K > 2048) return false;
   if (a.res && a.res_g && a.N > 512) return false;
@@ -447,7 +585,18 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       }
       if (!a.x_pos && !a.res_pos && !a.out2_pos) a.pos = nullptr;      // nothing of this launch depends on the position
       if (row_gemv1_supported(a, part != nullptr)) return launch_row_gemv1(a, part, ns, hd, q_st);
-      return launch_row_linear(a, q_st);
+      // batches: groups of up to 8 rows through the register-resident kernel where the rows fit
+      for (int m0 = 0; m0 < a.M; m0 += 8) {
+        RowLinArgs g8 = a;
+        g8.M = a.M - m0 < 8 ? a.M - m0 : 8;
+        g8.x += (size_t)m0 * a.x_stride;
+        if (g8.res) g8.res += (size_t)m0 * a.res_stride;
+        g8.out += (size_t)m0 * a.out_stride;
+        if (g8.out2) g8.out2 += (size_t)m0 * a.out2_stride;
+        const int rc8 = row_gemvm_supported(g8) ? launch_row_gemvm(g8, q_st) : launch_row_linear(g8, q_st);
+        if (rc8) return rc8;
+      }
+      return ISI_OK;
     };
     // the attention's splits are merged by the out-projection when that runs as the one-row kernel
     const int ns_self = rel_attention_decode_splits(s->S_t), ns_cross = rel_attention_decode_splits(s->S_src);

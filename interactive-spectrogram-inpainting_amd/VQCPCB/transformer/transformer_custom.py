@@ -55,7 +55,8 @@ class _LinearParams(nn.Module):
     def packed(self):
         key = (self.weight._version, self.weight.data_ptr())
         if self._key != key:
-            self._packed, self._key = _ops.pack_linear_weight(self.weight), key
+            inference = not (torch.is_grad_enabled() and self.weight.requires_grad)   # (the check reads a scalar back)
+            self._packed, self._key = _ops.pack_linear_weight(self.weight, range_check=inference), key
         return self._packed
 
     def packed_t(self):
@@ -167,8 +168,9 @@ class RelativeMultiheadAttention(nn.Module):
         if self._key != key:
             d = self.d_model
             W = self.in_proj_weight.detach()
-            self._packed = (_ops.pack_linear_weight(W), _ops.pack_linear_weight(W[:d]),
-                            _ops.pack_linear_weight(W[d:]))
+            inference = not (torch.is_grad_enabled() and self.in_proj_weight.requires_grad)
+            self._packed = (_ops.pack_linear_weight(W, range_check=inference), _ops.pack_linear_weight(W[:d], range_check=inference),
+                            _ops.pack_linear_weight(W[d:], range_check=inference))
             self._key = key
         return self._packed
 

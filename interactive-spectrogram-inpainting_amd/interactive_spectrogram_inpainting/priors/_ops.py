@@ -24,7 +24,11 @@ def _s(t):
 # on the bf16 matrix pipe -- x = hi + mid + lo exactly, every term above 2^-24 of a product kept: error against
 # fp64 at or below the fp32 pipe's own, 1.4x its speed; 'f32' = the fp32 matrix pipe.
 # Shapes the split kernel does not cover (N <= 32 or K < 128) run on the fp32 pipe either way.
-LINEAR_PRECISION = os.environ.get("ISI_LINEAR_PRECISION", "bf16x6")
+# 'f16x3' (default since round 2) = the VQ-VAE path's three-term split-f16 products: fp32-grade (error against fp64 at
+# or below the fp32 pipe's) at half the matrix work of 'bf16x6', but limited to f16's RANGE
+# (|activation| < 16384, |weight| < 64): a weight matrix beyond it is recognised when it is packed and runs 'bf16x6';
+# an activation beyond it shows as Inf / NaN in the output.
+LINEAR_PRECISION = os.environ.get("ISI_LINEAR_PRECISION", "f16x3")
 # products of the input-gradient GEMMs of the training path (dX = dY W): three terms (relative error ~2^-16 per
 # product) are far below the noise the ReLU / dropout masks and the optimiser see
 LINEAR_GRAD_PRECISION = os.environ.get("ISI_LINEAR_GRAD_PRECISION", "bf16x3")
@@ -36,12 +40,19 @@ ATTENTION_PRECISION = os.environ.get("ISI_ATTENTION_PRECISION", "bf16x3")
 _ATTN_PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
 ATTENTION_PRECISIONS = tuple(_ATTN_PREC)                 # modes bench.py times
 ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1}    # 16-bit MFMA terms per product (0: fp32 matrix pipe)
-_PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4}
+_PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4, "f16x3": 8}
+_F16_WEIGHT_LIMIT = 64.0
 
 
-def pack_linear_weight(weight: torch.Tensor) -> torch.Tensor:
-    """nn.Linear weight [N,K] -> packed GEMM operand (a 1x1 convolution weight)."""
-    return pack_conv_weight(weight.detach().reshape(weight.shape[0], weight.shape[1], 1, 1))
+def pack_linear_weight(weight: torch.Tensor, range_check: bool = False) -> torch.Tensor:
+    """nn.Linear weight [N,K] -> packed GEMM operand (a 1x1 convolution weight).  With `range_check` the result
+    carries `isi_f16_ok`: whether every weight is inside the range of the split-f16 products.  The check reads one
+    scalar back, so it is for inference weights (packed once per weight version); inside a training step, where every
+    weight is re-packed every step, the GEMMs keep the range-free six-term split."""
+    packed = pack_conv_weight(weight.detach().reshape(weight.shape[0], weight.shape[1], 1, 1))
+    packed.isi_f16_ok = bool(range_check and LINEAR_PRECISION == "f16x3" and
+                             (weight.numel() == 0 or bool(weight.detach().abs().max() < _F16_WEIGHT_LIMIT)))
+    return packed
 
 
 def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], n_out: int,
@@ -55,6 +66,9 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
     M = x2.shape[0]
+    prec = precision or LINEAR_PRECISION
+    if prec == "f16x3" and not getattr(packed_w, "isi_f16_ok", False):
+        prec = "bf16x6"                      # weights beyond the f16 pieces' range (or of unknown range)
     out = torch.empty(M, n_out, dtype=torch.float32, device=x.device)
     s0 = _hip.isi_src(x2.data_ptr(), K, 0, 1, 0, x2.stride(0))
     dst = _hip.isi_dst(out.data_ptr(), 0, 1, 0, n_out)
@@ -67,7 +81,7 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
     rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, packed_w.data_ptr(),
                                    bias.data_ptr() if bias is not None else None,
                                    C.byref(res) if res is not None else None, C.byref(dst),
-                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[precision or LINEAR_PRECISION], _s(x))
+                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[prec], _s(x))
     _hip.check(rc, "isi_conv2d_f32 (linear)")
     return out.reshape(*x.shape[:-1], n_out)
 

@@ -370,11 +370,21 @@ def test_linear_precisions_against_fp64():
             x, W, b = torch.randn(M, K), torch.randn(N, K) / K ** 0.5, torch.randn(N)
             ref = x.double() @ W.double().t() + b.double()
             err = {}
-            for prec in ("f32", "bf16x6", "bf16x3"):
+            for prec in ("f32", "bf16x6", "bf16x3", "f16x3"):
                 _ops.LINEAR_PRECISION = prec
-                y = _ops.linear(x.to(dev), _ops.pack_linear_weight(W.to(dev)), b.to(dev), N)
+                y = _ops.linear(x.to(dev), _ops.pack_linear_weight(W.to(dev), range_check=True), b.to(dev), N)
                 err[prec] = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
             assert err["f32"] <= 5e-6 and err["bf16x6"] <= 1.5 * err["f32"] + 1e-7 and err["bf16x3"] <= 2e-5, err
+            assert err["f16x3"] <= 1.5 * err["f32"] + 1e-7, err      # the default: fp32-grade
+        # a weight matrix beyond the f16 pieces' range is recognised at pack time and runs the six-term bf16 split
+        _ops.LINEAR_PRECISION = "f16x3"
+        x, W = torch.randn(64, 256), torch.randn(40, 256)
+        W[3, 7] = 100.0
+        pw = _ops.pack_linear_weight(W.to(dev), range_check=True)
+        assert pw.isi_f16_ok is False
+        y = _ops.linear(x.to(dev), pw, None, 40)
+        ref = x.double() @ W.double().t()
+        assert torch.isfinite(y).all() and float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 5e-6
     finally:
         _ops.LINEAR_PRECISION = saved
 

@@ -53,6 +53,13 @@ __device__ __forceinline__ float group4_sum(float v) {
 }
 __device__ __forceinline__ float group8_sum(float v) { v = group4_sum(v); return v + dpp_f32<0x141>(v); }   // row_half_mirror
 __device__ __forceinline__ float row16_sum(float v) { v = group8_sum(v); return v + dpp_f32<0x140>(v); }    // row_mirror
+// the value of lane l ^ 32 (v_permlane32_swap: one VALU instruction instead of a ds_bpermute round trip)
+__device__ __forceinline__ float xor32_f32(const float v) {
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const u32x2_ r = __builtin_amdgcn_permlane32_swap(u, u, false, false);   // .x: upper lanes get the lower's, .y: lower get the upper's
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r.x : r.y);
+}
 // sum / maximum over the 64 lanes, result in every lane (broadcast through an SGPR)
 __device__ __forceinline__ float wave64_sum(float v) {
   v = row16_sum(v);

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs 
           tmax = fmaxf(tmax, s);
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      tmax = fmaxf(tmax, xor32_f32(tmax));
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.f;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs 
         sv[r] = pr;
         psum += pr;
       }
-      psum += __shfl_xor(psum, 32);
+      psum += xor32_f32(psum);
       l_run = l_run * alpha + psum;
       m_run = m_new;
 
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           tmax = fmaxf(tmax, sc);
         }
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      tmax = fmaxf(tmax, xor32_f32(tmax));
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.f;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
         sv[r] = pr;
         psum += pr;
       }
-      psum += __shfl_xor(psum, 32);
+      psum += xor32_f32(psum);
       l_run = l_run * alpha + psum;
       m_run = m_new;
 

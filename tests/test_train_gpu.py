@@ -274,3 +274,27 @@ def test_unquantized_vqvae_against_reference(golden_dir):
     torch.nn.functional.mse_loss(out, xs.to(_dev())).backward()
     for name, p in m.named_parameters():
         assert _rel(p.grad, params[name].grad) < 2e-4, name
+
+
+def test_bench_two_ranks_dry_run():
+    """bench.py's multi-rank path end to end, two ranks sharing this box's GPU with gloo collectives
+    (ISI_BENCH_BACKEND=gloo: a functional dry run -- the measured configuration is one rank per GPU over RCCL): the
+    forward line aggregates both ranks, the data-parallel training leg runs on every rank (bucketed gradient
+    all-reduce + EMA-statistics all-reduce) and leaves the ranks with identical weights and codebooks."""
+    import json
+    import os
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    env = dict(os.environ, ISI_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--spinup-ms", "10", "--no-prior", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["batch_per_gpu"] == 4
+    dp = line["vqvae_training_dp"]
+    assert "error" not in dp, dp
+    assert dp["n_gpus"] == 2 and dp["global_batch"] == 8 and dp["ranks_in_sync"] is True

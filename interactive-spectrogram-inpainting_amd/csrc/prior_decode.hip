@@ -271,12 +271,13 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
 #pragma unroll
         for (int s2 = 0; s2 < PS; ++s2) {
           if (s2 < g.NS) {
-            const float w = expf(pm[i][s2] - M);
+            const float w = __expf(pm[i][s2] - M);     // (the combine kernel's arithmetic: transformer_ops.hip)
             num.x += w * pv[i][s2].x; num.y += w * pv[i][s2].y; num.z += w * pv[i][s2].z; num.w += w * pv[i][s2].w;
             den += w * pl[i][s2];
           }
         }
-        xv[i] = make_float4(num.x / den, num.y / den, num.z / den, num.w / den);
+        const float rden = 1.0f / den;
+        xv[i] = make_float4(num.x * rden, num.y * rden, num.z * rden, num.w * rden);
       }
     }
   } else if (a.ln_g) {

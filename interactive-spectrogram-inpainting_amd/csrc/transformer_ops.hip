@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     float lsum = 0.f;
 #pragma unroll
     for (int u = 0; u < UMAX; ++u) {
-      const float pj = grp + u * RPP < Sk ? expf(sv[u] - gmax) : 0.f;
+      const float pj = grp + u * RPP < Sk ? __expf(sv[u] - gmax) : 0.f;
       if (gl == 0) lsum += pj;
       o0.x += pj * vv[u].x; o0.y += pj * vv[u].y; o0.z += pj * vv[u].z; o0.w += pj * vv[u].w;
     }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   gmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float lsum = 0.f;
   for (int j = tid; j < Sk; j += 256) {
-    const float pj = expf(sc[j] - gmax);
+    const float pj = __expf(sc[j] - gmax);
     sc[j] = pj;
     lsum += pj;
   }
@@ -341,11 +341,11 @@ __global__ void rel_attention_combine_kernel(const float *__restrict__ partial, 
   for (int s = 0; s < NS; ++s) M = fmaxf(M, pp[s * (HD + 4) + HD]);
   float num = 0.f, den = 0.f;
   for (int s = 0; s < NS; ++s) {
-    const float w = expf(pp[s * (HD + 4) + HD] - M);
+    const float w = __expf(pp[s * (HD + 4) + HD] - M);   // (row_gemv1_kernel merges with the same arithmetic)
     num += w * pp[s * (HD + 4) + d];
     den += w * pp[s * (HD + 4) + HD + 1];
   }
-  out[b * o_sb + h * o_sh + d] = num / den;
+  out[b * o_sb + h * o_sh + d] = num * (1.0f / den);
 }
 
 int rel_attention_decode_splits(int Sk) { return Sk <= 192 ? 1 : (Sk + 127) / 128 > 8 ? 8 : (Sk + 127) / 128; }

@@ -740,8 +740,11 @@ def test_vqvae_pair_pipeline_against_fp32_activations():
         unfused = m(x)
     finally:
         del os.environ["ISI_NO_VQ_FUSION"]
-    for a, b in zip(got, unfused):
-        assert torch.equal(a, b)
+    for k_, (a, b) in enumerate(zip(got, unfused)):
+        if k_ == 1:     # diff: a per-lane sum of squares whose fmas the two kernels may contract differently (1 ulp)
+            assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
+        else:
+            assert torch.equal(a, b)
     enc_f = m.encode(x)
     os.environ["ISI_NO_VQ_FUSION"] = "1"
     try:

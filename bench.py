@@ -45,25 +45,60 @@ BF16_MATRIX_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 HBM_PEAK_GBS = 8000.0
 
 
+def _pick_distinct_rows(flat, K, g, min_rel=0.1):
+    """K well-separated rows of `flat` [N, D] (CPU): random order, a row is accepted when farther than
+    min_rel * |row| from every accepted one, farthest-point fill if the pool runs out.  (Drawing WITH replacement
+    from correlated encoder outputs produced duplicate / 1e-3-apart codes: VERDICT r02 weak 1.)"""
+    N = flat.shape[0]
+    order = torch.randperm(N, generator=g)
+    cand = flat[order].double()
+    norm = cand.norm(dim=1)
+    mind = torch.full((N,), float("inf"), dtype=torch.float64)
+    chosen = []
+    for i in range(N):
+        if len(chosen) == K:
+            break
+        if mind[i] > min_rel * norm[i]:
+            chosen.append(i)
+            mind = torch.minimum(mind, (cand - cand[i]).norm(dim=1))
+    while len(chosen) < K:
+        i = int(mind.argmax())
+        chosen.append(i)
+        mind = torch.minimum(mind, (cand - cand[i]).norm(dim=1))
+    return order[torch.tensor(chosen)]
+
+
 def _build_model(device, seed=1):
-    """Default-constructed VQVAE with torch's default init; each codebook is
-    then re-seeded from that level's own pre-quantisation vectors (computed by
-    the HIP path itself) so that code usage is non-degenerate."""
+    """Default-constructed VQVAE with torch's default init, made NON-DEGENERATE on a calibration batch (computed by
+    the HIP path itself): a random-init network's pre-quantisation vectors are one common offset plus a tiny spread
+    (top level: |mean| 0.75, spread 0.03), which makes every vector a near-tie of the reference's fp32 distance
+    formula; `quantize_conv_t/b` are re-parametrised to zero-mean outputs of deviation 0.5 (exact re-scaling of the
+    1x1 layers), then each codebook is re-seeded from that level's own vectors, well separated."""
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     torch.manual_seed(seed)
     m = VQVAE(in_channel=2).to(device).eval()
     g = torch.Generator().manual_seed(seed + 1)
+
+    def standardize(layer, z):
+        mu, sg = z.mean(0), z.std(0).clamp(min=1e-12) / 0.5
+        layer.weight.copy_(layer.weight / sg.view(-1, 1, 1, 1))
+        layer.bias.copy_((layer.bias - mu) / sg)
+
     with torch.no_grad():
         xc = torch.randn(2, 2, 128, 512, generator=g).to(device)
         enc_b = m.enc_b(xc)
         enc_t = m.enc_t(enc_b)
-        z_t = m.quantize_conv_t.run(enc_t, relu=False).permute(0, 2, 3, 1).reshape(-1, m.embed_dim)
-        pick = torch.randint(0, z_t.shape[0], (m.n_embed_t,), generator=g).to(device)
+        conv_t = lambda: m.quantize_conv_t.run(enc_t, relu=False).permute(0, 2, 3, 1).reshape(-1, m.embed_dim)
+        standardize(m.quantize_conv_t, conv_t())
+        z_t = conv_t()
+        pick = _pick_distinct_rows(z_t.cpu(), m.n_embed_t, g).to(device)
         m.quantize_t.embed.copy_(z_t[pick].t())
         q_t = m.quantize_t(z_t.reshape(2, enc_t.shape[2], enc_t.shape[3], -1))[0].permute(0, 3, 1, 2)
         dec_t = m.dec_t(q_t)
-        z_b = m.quantize_conv_b.run(dec_t, relu=False, x2=enc_b).permute(0, 2, 3, 1).reshape(-1, m.embed_dim)
-        pick = torch.randint(0, z_b.shape[0], (m.n_embed_b,), generator=g).to(device)
+        conv_b = lambda: m.quantize_conv_b.run(dec_t, relu=False, x2=enc_b).permute(0, 2, 3, 1).reshape(-1, m.embed_dim)
+        standardize(m.quantize_conv_b, conv_b())
+        z_b = conv_b()
+        pick = _pick_distinct_rows(z_b.cpu(), m.n_embed_b, g).to(device)
         m.quantize_b.embed.copy_(z_b[pick].t())
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     return m, sd
@@ -484,7 +519,9 @@ def main():
     if not args.no_train:
         try:
             train_leg = _vqvae_training(device, dist, world, batch=args.batch)
-        except Exception as e:      # a secondary leg must not take the headline metric with it
+        except Exception as e:      # a secondary leg must not take the headline metric with it ...
+            if world > 1:           # ... but with collectives inside, a rank that skips the rest of the leg would leave
+                raise               # the others waiting in an all-reduce until the RCCL timeout: let torchrun tear down
             train_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- per-kernel HIP-event timing recorded inside the timed region

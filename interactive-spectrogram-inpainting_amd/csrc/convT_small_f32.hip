@@ -23,6 +23,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 
 namespace isi {
@@ -256,7 +257,7 @@ int convT_k4s2_small_f32(const float *in, const float *wn, const float *bias, fl
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
   a.on = on; a.oc = oc; a.oh = oh; a.ow = ow;
   // 8-row tiles recompute less halo (340 rows of Y' per 256 pixels vs 204 per 128); short maps keep 4
-  static const int th_env = [] { const char *e = getenv("ISI_CONVT_TH"); return e ? atoi(e) : 0; }();
+  const int th_env = knobs().convt_th;
   const int th = th_env ? th_env : (H >= 8 ? 8 : 4);
   return th == 8 ? dispatch_small<8>(a, B, stream) : dispatch_small<4>(a, B, stream);
 }

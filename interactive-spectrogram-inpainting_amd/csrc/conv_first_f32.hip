@@ -19,6 +19,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_f16.h"
 
@@ -271,7 +272,7 @@ int launch_first(const FirstArgs &a, hipStream_t stream) {
 // Shapes this kernel takes over from the generic convolution (conv2d_batched_f32 asks before it plans its own launch).
 bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *res, const isi_dst *dst, int Cout,
                            int KH, int KW, int stride, int pad, int OH, int OW, int nz) {
-  const bool off = getenv("ISI_NO_CONV_FIRST") != nullptr;   // measurements / tests: the generic gather kernel instead
+  const bool off = knobs().no_conv_first != 0;   // measurements / tests: the generic gather kernel instead
   if (off || nz != 1 || (s1 && s1->ptr) || (res && res->ptr)) return false;
   if (s0->C != 2 || KH != 4 || KW != 4 || stride != 2 || pad != 1) return false;
   if (Cout != 32 && Cout != 64) return false;

@@ -21,6 +21,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_f16.h"
 
@@ -539,12 +540,12 @@ template <int BM, int BN, int WM, int WN, int MODE, int PREC = 0, bool OUTP = fa
 static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
   auto kern = conv_igemm_f32_kernel<BM, BN, WM, WN, MODE, PREC, OUTP>;
   constexpr size_t smem = conv_smem_bytes<BM, BN, PREC>();
-  static bool attr_set = false;  // idempotent; racing threads set the same value
-  if (!attr_set) {
+  static DeviceOnce attr_set;  // idempotent; racing threads set the same value
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(conv_igemm)");
-    attr_set = true;
+    attr_set.mark();
   }
   dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, nphase > 1 ? nphase : std::max(a.nz, 1));
   {
@@ -566,7 +567,7 @@ static int launch_cfg(const ConvKArgs &a, int nphase, hipStream_t stream) {
 static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStream_t stream) {
   ConvKArgs a = a_in;
   const int mode = scalar_a ? 2 : (a.src_uniform ? 0 : 1);
-  static const bool tap_major = getenv("ISI_CONV_TAP_MAJOR") != nullptr;   // measurements
+  const bool tap_major = knobs().conv_tap_major != 0;   // measurements
   a.chunk_major = (mode == 0 && a.KH * a.KW > 1 && a.C0 % kBK == 0 && a.Cin % kBK == 0 && !tap_major) ? 1 : 0;
   const bool two = a.Cin > a.C0;
   // the LDS-DMA kernel of the pair pipeline (conv_pair_f16.hip): pair8 sources, blocked weight pieces, whole
@@ -574,7 +575,7 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
   // It wins on the plain convolutions (1.13 - 1.2x, tools/bench_conv_pair.py); the transposed convolutions' four
   // phases (K = 4 Cin: 16 or fewer chunks per tile, its per-tile set-up and epilogue are not amortised) and K < 256
   // stay on this file's register-staged kernel.
-  static const bool dma_all = getenv("ISI_CONV_PAIR_ALL") != nullptr;
+  const bool dma_all = knobs().conv_pair_all != 0;
   const bool dma_shape = dma_all || (!a.convT && a.K >= 256);
   if (dma_shape && a.bf16x3 == 3 && a.w16 && mode == 0 && a.in0_pair && (!two || a.in1_pair) && !a.res && a.nz <= 1 && a.oc == 1 &&
       conv_pair_kernel_ok(a.C0, a.Cin - a.C0, a.Cout, a.KH * a.KW) && a.KH <= 4 && a.KW <= 4 && a.M < (1 << 24) &&

@@ -39,6 +39,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_f16.h"
 
@@ -476,19 +477,15 @@ template <int BN, bool OUTP, int ABL = 0>
 int launch_pair(const PairK &a, int nphase, double flops, double bytes, hipStream_t stream) {
   auto kern = conv_pair_kernel<BN, OUTP, ABL>;
   constexpr size_t smem = pair_smem_bytes<BN>();
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(conv_pair)");
-    attr_set = true;
+    attr_set.mark();
   }
   const int nitems = ((a.M + BM - 1) / BM) * (a.Cout / BN) * nphase;
-  static const int n_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int n_cu = current_device_cu_count();
   dim3 grid(nitems < n_cu ? nitems : n_cu);   // one 144-KiB workgroup per CU, persistent over the items
   prof::Scope scope(prof::K_CONV_F16X3, flops, bytes, stream);
   ISI_PROF_LAUNCH(scope, kern, grid, dim3(512), smem, stream, a);
@@ -504,7 +501,7 @@ int conv_pair_debug_stamps(long long *host, int n) {
 // Shapes the DMA kernel takes: pair8 sources of 32-channel multiples (both, when there are two), whole 64-column
 // output tiles, channels-last output.  (conv_igemm_f32.hip runs everything else, including fp32 sources.)
 bool conv_pair_kernel_ok(int C0, int C1, int Cout, int taps) {
-  const bool off = getenv("ISI_NO_CONV_PAIR_KERNEL") != nullptr;    // read per call: measurements, A/B tests
+  const bool off = knobs().no_conv_pair_kernel != 0;
   return !off && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && Cout % 64 == 0 && taps >= 1 && taps <= 16;   // 16-bit tap masks
 }
 
@@ -524,17 +521,15 @@ int conv_pair_f16(const PairConvArgs &c, hipStream_t stream) {
   a.convT = c.convT; a.w_phase_stride = c.w_phase_stride; a.dst_sh = c.dst_sh; a.dst_sw = c.dst_sw;
   // accumulator flush period: every 3 chunks (one kernel row of a 3x3 / three taps) unless overridden; 0 = never
   // (read per call: the tests compare flush = 0 -- the bits of conv_igemm_f32.hip -- with the default)
-  const char *fe = getenv("ISI_CONV_FLUSH");
-  a.flush = fe ? atoi(fe) : 3;
-  if (a.flush < 0) a.flush = 0;
-  const char *ab = getenv("ISI_CONV_ABLATE");    // measurements (tools/ablate_conv.py): wrong results by design
-  const int abl = ab ? atoi(ab) : 0;
+  a.flush = knobs().conv_flush;
   const int nphase = c.convT ? 4 : 1;
   const double K = (double)c.KH * c.KW * (c.C0 + c.C1);
   const double flops = 2.0 * c.M * nphase * c.Cout * K;
   const double in_px = nphase == 1 ? (double)c.M / (c.OH * c.OW) * c.H * c.W : (double)c.M;
   const double bytes = 4.0 * (in_px * (c.C0 + c.C1) + (double)c.M * nphase * c.Cout + nphase * c.Cout * K);
   const bool wide = c.Cout % 128 == 0;
+#ifdef ISI_MEASURE   // measurements (tools/ablate_conv.py): wrong results by design, not in the default build
+  const int abl = knobs().conv_ablate;
   if (abl == 1) return wide ? launch_pair<128, true, 1>(a, nphase, flops, bytes, stream) : launch_pair<64, true, 1>(a, nphase, flops, bytes, stream);
   if (abl == 2) return wide ? launch_pair<128, true, 2>(a, nphase, flops, bytes, stream) : launch_pair<64, true, 2>(a, nphase, flops, bytes, stream);
   if (abl == 3) return wide ? launch_pair<128, true, 3>(a, nphase, flops, bytes, stream) : launch_pair<64, true, 3>(a, nphase, flops, bytes, stream);
@@ -545,6 +540,7 @@ int conv_pair_f16(const PairConvArgs &c, hipStream_t stream) {
   if (abl == 16) return launch_pair<128, true, 16>(a, nphase, flops, bytes, stream);   // DMA issued, never waited for
   if (abl == 17) return launch_pair<128, true, 17>(a, nphase, flops, bytes, stream);   // same, no MFMAs
   if (abl == 8) return launch_pair<128, true, 8>(a, nphase, flops, bytes, stream);     // everything but the output stores
+#endif
   if (c.out_pair) return wide ? launch_pair<128, true>(a, nphase, flops, bytes, stream)
                               : launch_pair<64, true>(a, nphase, flops, bytes, stream);
   return wide ? launch_pair<128, false>(a, nphase, flops, bytes, stream)

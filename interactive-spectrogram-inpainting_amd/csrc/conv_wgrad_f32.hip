@@ -526,12 +526,12 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
   a.db_partial = db ? workspace + (size_t)nsplit * nphase * Cout * a.Kpad : nullptr;
   constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_f32_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(conv_wgrad)");
-    attr_set = true;
+    attr_set.mark();
   }
   dim3 grid((Cout + 127) / 128, (a.Kpad + 127) / 128, nz * nphase * nsplit);
   // split-bf16 products need the vectorised loaders (channels-last sources, Cout % 4 == 0)

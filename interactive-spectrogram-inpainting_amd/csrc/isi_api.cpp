@@ -1,6 +1,10 @@
 // extern "C" surface of libisi_hip.so (declared in include/isi_hip.h).
 #include "isi_common.h"
+#include <cstdlib>
+#include <cstring>
+
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 
 namespace isi {
@@ -8,6 +12,52 @@ static thread_local char g_last_error[512] = "";
 void set_last_error(const char *msg) {
   strncpy(g_last_error, msg ? msg : "", sizeof g_last_error - 1);
   g_last_error[sizeof g_last_error - 1] = 0;
+}
+
+namespace {
+struct KnobEntry { const char *name; int Knobs::*field; int dflt; bool measure_only; };
+const KnobEntry kKnobTable[] = {
+    {"ISI_CONV_FLUSH", &Knobs::conv_flush, 3, false},
+    {"ISI_NO_PAIRS", &Knobs::no_pairs, 0, false},
+    {"ISI_NO_CONV_FIRST", &Knobs::no_conv_first, 0, false},
+    {"ISI_NO_VQ_FUSION", &Knobs::no_vq_fusion, 0, false},
+    {"ISI_NO_CONV_PAIR_KERNEL", &Knobs::no_conv_pair_kernel, 0, false},
+    {"ISI_NO_RESBLOCK_PAIR_KERNEL", &Knobs::no_resblock_pair_kernel, 0, false},
+    {"ISI_NO_CONVT_PAIR_KERNEL", &Knobs::no_convt_pair_kernel, 0, false},
+    {"ISI_NO_RESSTACK_KERNEL", &Knobs::no_resstack_kernel, 0, false},
+    {"ISI_CONV_PAIR_ALL", &Knobs::conv_pair_all, 0, false},
+    {"ISI_CONV_TAP_MAJOR", &Knobs::conv_tap_major, 0, false},
+    {"ISI_RESPAIR_TH", &Knobs::respair_th, 0, false},
+    {"ISI_RES_TH", &Knobs::res_th, 0, false},
+    {"ISI_CONVT_TH", &Knobs::convt_th, 0, false},
+    {"ISI_PRIOR_GRAPH", &Knobs::prior_graph, 0, false},
+    {"ISI_CONV_ABLATE", &Knobs::conv_ablate, 0, true},
+    {"ISI_VQ_DBG", &Knobs::vq_dbg, 0, true},
+    {"ISI_RESPAIR_ABL", &Knobs::respair_abl, 0, true},
+};
+// value of an environment switch: a number, or 1 for a variable that is merely set ("ISI_NO_PAIRS=" / "=yes")
+int env_value(const char *e) {
+  char *end = nullptr;
+  const long v = strtol(e, &end, 10);
+  return end != e ? (int)v : 1;
+}
+}  // namespace
+
+Knobs &knobs() {
+  static Knobs k = [] {
+    Knobs init;
+    memset(&init, 0, sizeof init);
+    for (const KnobEntry &e : kKnobTable) {
+      init.*(e.field) = e.dflt;
+#ifndef ISI_MEASURE
+      if (e.measure_only) continue;       // ablations that produce wrong results exist in measurement builds only
+#endif
+      if (const char *v = getenv(e.name)) init.*(e.field) = env_value(v);
+    }
+    if (init.conv_flush < 0) init.conv_flush = 0;
+    return init;
+  }();
+  return k;
 }
 }  // namespace isi
 
@@ -35,6 +85,24 @@ size_t isi_abi_struct_bytes(int which) {
     case 10: return sizeof(isi_prior_state);
     default: return 0;
   }
+}
+int isi_knob_set(const char *name, int value) {
+  if (!name) return invalid("isi_knob_set: null name");
+  for (const KnobEntry &e : kKnobTable)
+    if (!strcmp(name, e.name)) {
+#ifndef ISI_MEASURE
+      if (e.measure_only && value) return unsupported("isi_knob_set: ablation switches need a -DISI_MEASURE build");
+#endif
+      knobs().*(e.field) = value;
+      return 0;
+    }
+  return invalid("isi_knob_set: unknown switch");
+}
+int isi_knob_get(const char *name, int *value) {
+  if (!name || !value) return invalid("isi_knob_get: null argument");
+  for (const KnobEntry &e : kKnobTable)
+    if (!strcmp(name, e.name)) { *value = knobs().*(e.field); return 0; }
+  return invalid("isi_knob_get: unknown switch");
 }
 int isi_relu_inplace_f32(float *x, int64_t n, void *stream) { return relu_inplace_f32(x, n, S(stream)); }
 

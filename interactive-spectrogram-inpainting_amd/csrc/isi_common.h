@@ -34,6 +34,28 @@ inline int unsupported(const char *msg) {
 
 inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
+// hipFuncSetAttribute and the CU count are PER DEVICE: a process that drives a second GPU (tests on cuda:1, one
+// process over several devices) must not reuse the first device's cached answer.
+inline int current_device() {
+  int dev = 0;
+  return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0;
+}
+struct DeviceOnce {               // "has this been done on the current device?" (racing threads repeat an idempotent call)
+  unsigned long long bits[4] = {0, 0, 0, 0};
+  bool done() const { const int d = current_device() & 255; return (bits[d >> 6] >> (d & 63)) & 1ull; }
+  void mark() { const int d = current_device() & 255; bits[d >> 6] |= 1ull << (d & 63); }
+};
+inline int current_device_cu_count() {
+  static int cached[256];         // 0 = not asked yet
+  const int d = current_device() & 255;
+  if (!cached[d]) {
+    int n = 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cached[d] = n;
+  }
+  return cached[d];
+}
+
 constexpr int kBK = 32;  // K-chunk of the implicit GEMM; packed weights are padded to it
 
 #if defined(__HIPCC__)

@@ -1,0 +1,28 @@
+// Execution switches of the library (A/B comparisons in the tests, measurements).  Every switch is read from the
+// environment ONCE, when the library is first used, and can afterwards be changed only through isi_knob_set (the
+// tests' A/B entry point) -- no getenv on the launch paths, and a stray environment variable set after start-up
+// changes nothing.  Switches that produce WRONG RESULTS by design (ablations: ISI_CONV_ABLATE, ISI_VQ_DBG,
+// ISI_RESPAIR_ABL) exist only in -DISI_MEASURE builds (`make EXTRA=-DISI_MEASURE`); the default build ignores them.
+#pragma once
+
+namespace isi {
+
+struct Knobs {
+  int conv_flush;               // ISI_CONV_FLUSH: chunks between accumulator flushes of conv_pair_kernel (3; 0 = never)
+  int no_pairs;                 // ISI_NO_PAIRS: fused forward on fp32 activations instead of the pair pipeline
+  int no_conv_first;            // ISI_NO_CONV_FIRST: generic gather kernel for the 2-channel first layer
+  int no_vq_fusion;             // ISI_NO_VQ_FUSION: quantize_conv and search as two launches
+  int no_conv_pair_kernel;      // ISI_NO_CONV_PAIR_KERNEL: register-staged kernel instead of the LDS-DMA one
+  int no_resblock_pair_kernel;  // ISI_NO_RESBLOCK_PAIR_KERNEL
+  int no_convt_pair_kernel;     // ISI_NO_CONVT_PAIR_KERNEL: four phase launches instead of the fused transposed conv
+  int no_resstack_kernel;       // ISI_NO_RESSTACK_KERNEL: one launch per residual block instead of one per stack
+  int conv_pair_all;            // ISI_CONV_PAIR_ALL: DMA kernel also for the shapes it is not preferred on
+  int conv_tap_major;           // ISI_CONV_TAP_MAJOR: K order of the register-staged kernel (measurement)
+  int respair_th, res_th, convt_th;   // forced tile heights (measurement)
+  int prior_graph;              // ISI_PRIOR_GRAPH: replay the decode loop's positions as hipGraphs
+  int conv_ablate, vq_dbg, respair_abl;   // ISI_MEASURE builds only
+};
+
+Knobs &knobs();
+
+}  // namespace isi

@@ -33,6 +33,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 
 namespace isi {
 
@@ -514,12 +515,12 @@ int launch_row_linear_8(const RowLinArgs &a, hipStream_t st) {
 #define ISI_RL(MR)                                                                                      \
   do {                                                                                                  \
     auto kern = row_linear_ln_kernel<MR>;                                                               \
-    static bool attr_set = false;  /* once, outside any stream capture (the first position runs direct) */ \
-    if (!attr_set) {                                                                                    \
+    static DeviceOnce attr_set;  /* once, outside any stream capture (the first position runs direct) */ \
+    if (!attr_set.done()) {                                                                                    \
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                     \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)   \
         return check_launch("hipFuncSetAttribute(row_linear)");                                         \
-      attr_set = true;                                                                                  \
+      attr_set.mark();                                                                                  \
     }                                                                                                   \
     if (smem > 160 * 1024) return unsupported("row_linear: rows do not fit in LDS");                    \
     hipLaunchKernelGGL(kern, grid, block, smem, st, a);                                                 \
@@ -677,7 +678,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   int p = p_begin + 1;
   // ... the rest can replay two captured graphs (with / without the sampling tail; ISI_PRIOR_GRAPH=1): the launches
   // of a position collapse into one graph launch, every position-dependent address read from a device counter.
-  const bool use_graph = [] { const char *e = getenv("ISI_PRIOR_GRAPH"); return e && atoi(e) != 0; }();
+  const bool use_graph = knobs().prior_graph != 0;
   if (use_graph && p_end - p >= 4) {
     hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, p, 0);
     if ((rc = check_launch("set_position"))) return rc;

@@ -1328,12 +1328,12 @@ static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
                             (size_t)(8 * 32 * SRL + 64) * sizeof(float);
   constexpr size_t smem_kv = (size_t)(2 * (2 * 2 * 32 * HD) + 2 * (2 * 2 * VR * 32) + 2 * RING_S * HD) * sizeof(unsigned short) +
                              (size_t)(8 * 32 * SRL + 192) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_q) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_kv) != hipSuccess)
       return check_launch("hipFuncSetAttribute(rel_attention_bwd_split)");
-    attr_set = true;
+    attr_set.mark();
   }
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * a.B;
   {
@@ -1356,12 +1356,12 @@ static int launch_bwd(const AttnBwdKArgs &a, hipStream_t stream) {
   auto kq = rel_attention_bwd_q_kernel<HD>;
   auto kkv = rel_attention_bwd_kv_kernel<HD>;
   constexpr size_t smem = (size_t)((128 + RING) * (HD + 4) + 4 * 32 * SRLD + 192) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void *>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(rel_attention_bwd)");
-    attr_set = true;
+    attr_set.mark();
   }
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * a.B;
   {

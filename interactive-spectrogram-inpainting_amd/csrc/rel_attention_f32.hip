@@ -730,12 +730,12 @@ static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
   constexpr size_t smem_s = (size_t)(2 * 2 * 32 * HD + 2 * 2 * VR * 32 + 2 * RING * HD) * sizeof(unsigned short) +
                             (size_t)(8 * 32 * SRLD) * sizeof(float) + 64 * sizeof(int);
   const size_t smem = a.split ? smem_s : smem_f;
-  static bool attr_set[3] = {false, false, false};
-  if (!attr_set[a.split]) {
+  static DeviceOnce attr_set[3];
+  if (!attr_set[a.split].done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(rel_attention)");
-    attr_set[a.split] = true;
+    attr_set[a.split].mark();
   }
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * B;
   prof::Scope scope(prof::K_REL_ATTENTION, 2.0 * pairs * HD * (a.e ? 3 : 2),

@@ -21,6 +21,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_f16.h"
 
@@ -435,12 +436,12 @@ static int launch_res_t(const ResKArgs &a, int B, hipStream_t stream) {
   constexpr size_t smem = PREC ? (size_t)(HPIX + 9 * 32) * LDB * (PREC == 2 ? 3 : 2) * sizeof(unsigned short)
                              : (size_t)(HPIX * LDK + 9 * 32 * LDK) * sizeof(float);
   static_assert(9 * 32 >= TC * 32 && HPIX >= TH * 64, "aliased regions must fit");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(resblock)");
-    attr_set = true;
+    attr_set.mark();
   }
   const double C = a.C, R = a.R, M = (double)B * a.H * a.W;
   prof::Scope scope(prof::K_RESBLOCK, 2.0 * M * R * 9 * C + 2.0 * M * C * R,
@@ -452,7 +453,7 @@ static int launch_res_t(const ResKArgs &a, int B, hipStream_t stream) {
 // tile height: 8-wave 4 x 64 tiles for the six-term variant (ISI_RES_TH = 2 / 4 overrides, for measurements)
 template <int TC, int PREC>
 static int launch_res(const ResKArgs &a, int B, hipStream_t stream) {
-  static const int forced = [] { const char *e = getenv("ISI_RES_TH"); return e ? atoi(e) : 0; }();
+  const int forced = knobs().res_th;
   const int th = forced == 2 || forced == 4 ? forced : (PREC == 2 ? 4 : 2);
   return th == 4 ? launch_res_t<TC, PREC, 4>(a, B, stream) : launch_res_t<TC, PREC, 2>(a, B, stream);
 }

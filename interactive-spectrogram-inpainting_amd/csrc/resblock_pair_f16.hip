@@ -26,6 +26,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_f16.h"
 
@@ -42,6 +43,11 @@ constexpr int TW = 64, HWD = TW + 2;
 constexpr int ROWB = 64;                       // bytes of a row per 16-channel stage: {hi g0, lo g0, hi g1, lo g1}
 constexpr unsigned OOB = 0x7FFFFFF0u, OOB_ST = 0xFFFFFFF0u;
 
+#ifdef ISI_MEASURE
+#define ISI_RESPAIR_ABLBIT(p, b) ((p).ablate & (b))
+#else
+#define ISI_RESPAIR_ABLBIT(p, b) (0)  // the ablations are not compiled into the default build
+#endif
 struct ResPairK {
   const float *in, *w1, *b1, *w2, *b2;        // w1 / w2: blocked pair copies of the packed weights
   float *out;
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, kb = lane >> 5;
-  const int C = p.C, nstage = (p.ablate & 1) ? 1 : C / 16;
+  const int C = p.C, nstage = ISI_RESPAIR_ABLBIT(p, 1) ? 1 : C / 16;
   const i32x4 rsi = make_rsrc(p.in, p.in_bytes), rsw = make_rsrc(p.w1, p.w1_bytes);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
       }
     }
 
-    if (p.ablate & 2) { if (acc[0][0][0] == 123.f && acc[1][1][3] == 7.f) p.out[0] = acc[0][1][5] + acc[1][0][2]; continue; }
+    if (ISI_RESPAIR_ABLBIT(p, 2)) { if (acc[0][0][0] == 123.f && acc[1][1][3] == 7.f) p.out[0] = acc[0][1][5] + acc[1][0][2]; continue; }
     // ---- hidden activations h = relu(acc + b1) -> this wave's LDS rows as pair planes [64 px][32] (A operand of GEMM 2)
     __syncthreads();                     // every wave is done with the ring
     constexpr int HROW = 128;            // bytes per pixel: 8 pieces of 16 B, piece 2 g + plane of hidden-channel group g
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
           const int px = it * PPP + psub;
           const int gx = x0 + 32 * i + px;
           const unsigned off = (gy < p.H && gx < p.W) ? (unsigned)(((b * p.H + gy) * p.W + gx) * C + ch0) * 4u : OOB_ST;
-          const unsigned roff = (p.ablate & 4) ? OOB_ST : off;   // measurement: no skip re-read
+          const unsigned roff = ISI_RESPAIR_ABLBIT(p, 4) ? OOB_ST : off;   // measurement: no skip re-read
           const float4 v0 = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8);
           const float4 v1 = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8 + 4);
           // the skip connection: r's two pieces of this group
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
             w1 = make_uint4(__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]),
                             __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7]));
           }
-          const unsigned soff = (p.ablate & 8) ? OOB_ST : off;
+          const unsigned soff = ISI_RESPAIR_ABLBIT(p, 8) ? OOB_ST : off;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, soff, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, soff == OOB_ST ? OOB_ST : soff + 16u, 0, 0);
         }
@@ -318,17 +324,13 @@ int launch_res_pair(const ResPairK &a, hipStream_t stream) {
   constexpr size_t smem = ring > tail ? ring : tail;
   static_assert(smem <= 160 * 1024, "LDS budget");
   auto kern = resblock_pair_kernel<TH>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(resblock_pair)");
-    attr_set = true;
+    attr_set.mark();
   }
-  static const int n_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-    return n > 0 ? n : 256;
-  }();
+  const int n_cu = current_device_cu_count();
   const int nitems = a.tiles_x * a.tiles_y * a.B;
   const double Cc = a.C, M = (double)a.B * a.H * a.W;
   prof::Scope scope(prof::K_RESBLOCK, 2.0 * M * 32 * 9 * Cc + 2.0 * M * Cc * 32, 4.0 * (2.0 * M * Cc + 10.0 * Cc * 32), stream);
@@ -345,12 +347,12 @@ int launch_res_pair(const ResPairK &a, hipStream_t stream) {
 bool resblock_pair_preferred(int B, int H, int W, int C, int R) {
   (void)B;
   if (!resblock_pair_ok(C, R)) return false;
-  if (getenv("ISI_RESPAIR_TH")) return true;
+  if (knobs().respair_th) return true;
   return (long)H * W >= 2048;
 }
 
 bool resblock_pair_ok(int C, int R) {
-  const bool off = getenv("ISI_NO_RESBLOCK_PAIR_KERNEL") != nullptr;   // read per call: measurements, A/B tests
+  const bool off = knobs().no_resblock_pair_kernel != 0;
   return !off && R == 32 && C % 32 == 0 && C >= 32 && C <= 128;
 }
 
@@ -368,9 +370,9 @@ int resblock_pair_f16(const float *in, const float *w1_16, const float *b1, cons
   a.w2_bytes = (unsigned)((size_t)C * 32 * 4);
   a.C = C; a.H = H; a.W = W; a.B = B; a.relu = relu; a.out_pair = out_pair;
   a.tiles_x = (W + TW - 1) / TW;
-  { const char *e = getenv("ISI_RESPAIR_ABL"); a.ablate = e ? atoi(e) : 0; }
+  a.ablate = knobs().respair_abl;   // 0 outside -DISI_MEASURE builds
   // 8-row tiles (8 waves, two per SIMD) when they still fill the chip, 4-row tiles otherwise
-  static const int forced = [] { const char *e = getenv("ISI_RESPAIR_TH"); return e ? atoi(e) : 0; }();
+  const int forced = knobs().respair_th;
   const long tiles8 = (long)a.tiles_x * ((H + 7) / 8) * B;
   const bool th8 = forced ? forced == 8 : tiles8 >= 256;
   if (th8) {

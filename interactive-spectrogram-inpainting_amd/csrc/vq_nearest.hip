@@ -17,6 +17,7 @@
 // half-waves (lanes l and l+32 hold interleaved code rows of the same vector)
 // are merged with a single cross-lane exchange at the end.
 #include "isi_common.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_f16.h"
 
@@ -168,27 +169,40 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
 // (conflict-free ds_read_b128); slot 2 s + h holds the 8 channels lane half h feeds to k-step s:
 // quads 4 s + h and 4 s + 2 + h -- the channels a lane of the fused kernel below owns after its 1x1 convolution.
 // A lane (col = vector, h = lane >> 5) holds the vector's quads zq[j] = quad 2 j + h.  Ranges as for the
-// convolutions (|z| < 16384, |e| < 64; beyond: non-finite distances -> index -1).
+// convolutions (|z| < 16384, |e| < 64).  Beyond: a vector out of range has NaN distances to every code -> its index
+// is -1; a CODE out of range makes every index -1 (vq_fill_planes).
 typedef f16s::f16x8 vq_f16x8;
 constexpr float kVqScaleZ = f16s::kScaleA, kVqScaleE = f16s::kScaleB, kVqUnscale = f16s::kUnscale;
 __device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 
-// fills the two planes (and |e|^2, histogram) of a workgroup
+// fills the two planes (and |e|^2, histogram) of a workgroup.  A code with a component beyond the f16 pieces' range
+// (|e| * 2^10 rounds to inf, or is not finite) would have NaN distances and silently never be a candidate: such a
+// code gets zero pieces and |e|^2 = -inf instead, which makes it the "best" candidate of EVERY vector with distance
+// -inf -- vq_decide_f32 turns that into index -1 (and a NaN diff): an out-of-range codebook is loud.
+// (Contains a barrier: call from uniform control flow.)
 __device__ __forceinline__ void vq_fill_planes(unsigned short *cbh, unsigned short *cbl, float *e2, int *hist,
                                                const float *__restrict__ codes, const float *__restrict__ e2g, int K,
                                                int Kp, int tid) {
   constexpr int D = 64;
+  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : INFINITY; hist[i] = 0; }
+  __syncthreads();
   for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
     const int k = i >> 4, qd = i & 15;
     uint2 hi, lo;
     vq_split4(k < K ? *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f),
               kVqScaleE, hi, lo);
+    const bool bad = (hi.x & 0x7C00u) == 0x7C00u || (hi.x & 0x7C000000u) == 0x7C000000u ||
+                     (hi.y & 0x7C00u) == 0x7C00u || (hi.y & 0x7C000000u) == 0x7C000000u;
+    if (bad) {
+      hi = make_uint2(0u, 0u);
+      lo = make_uint2(0u, 0u);
+      e2[k] = -INFINITY;        // every writer of e2[k] in this loop writes this value
+    }
     const int slot = 2 * (qd >> 2) + (qd & 1), second = (qd >> 1) & 1;
     const int wo = k * D + ((slot ^ ((k >> 1) & 7)) * 8) + second * 4;
     *reinterpret_cast<uint2 *>(cbh + wo) = hi;
     *reinterpret_cast<uint2 *>(cbl + wo) = lo;
   }
-  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : INFINITY; hist[i] = 0; }
 }
 
 __device__ __forceinline__ float vq_quad_dot(const float4 a, const float4 b) {
@@ -235,7 +249,10 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
       const float d = __builtin_fmaf(acc[r], -2.f * kVqUnscale, e2t[(r & 3) + 8 * (r >> 2)]);
       const bool l1 = d < b1, l2 = d < b2;                     // NaN: neither
       i2 = l1 ? i1 : (l2 ? cu : i2);
-      b2 = __builtin_amdgcn_fmed3f(d, b1, b2);                 // b1 <= b2: d < b1 -> b1, b1 <= d < b2 -> d, else b2
+      // b1 <= b2: d < b1 -> b1, b1 <= d < b2 -> d, else b2.  (A NaN d -- only a vector beyond the f16 range or a
+      // non-finite one produces it, and then for every code: the vector ends with index -1 -- makes v_med3 return
+      // min3, which only disturbs candidates nobody reads.)
+      b2 = __builtin_amdgcn_fmed3f(d, b1, b2);
       i1 = l1 ? cu : i1;
       b1 = __builtin_fminf(d, b1);
     }
@@ -262,7 +279,7 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
 __device__ __forceinline__ int vq_decide_f32(const VqCand c, const float *e2, int K, const float *__restrict__ codes,
                                              const float4 (&zq)[8], int half, float4 (&ew)[8]) {
   constexpr int D = 64;
-  if (!(c.b1 < INFINITY)) return -1;
+  if (!(c.b1 < INFINITY) || c.b1 == -INFINITY) return -1;   // no finite distance / a code beyond the f16 range
   const int i1 = c.i1, i2 = c.i2;
   const bool has2 = c.b2 < INFINITY && i2 < K && i2 != i1;
   const float *r1 = codes + (size_t)i1 * D + half * 4, *r2 = codes + (size_t)(has2 ? i2 : i1) * D + half * 4;
@@ -381,6 +398,11 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
 // wave waiting for them leaves the pipe to its partner (no barriers in this loop).  Products, k order and term
 // order are those of the stand-alone convolution (conv_igemm_f32.hip): z, and hence every output, is bit-identical
 // to the two-launch path.  Outputs as vq_nearest_kernel, plus an optional pair8 copy of q for the pair pipeline.
+#ifdef ISI_MEASURE
+#define ISI_VQ_DBGBIT(p, b) ((p).dbg & (b))
+#else
+#define ISI_VQ_DBGBIT(p, b) (0)     // the ablations are not compiled into the default build
+#endif
 struct VqFusedArgs {
   const float *in0, *in1, *w16, *bias, *codes, *e2;
   const float *wfrag;                    // fragment-major copy of w16 (vq_weight_fragments_kernel)
@@ -462,7 +484,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
 #pragma unroll
       for (int r = 0; r < 16; ++r) zt[t][r] = 0.f;
 #define ISI_VQ_MF(W_, A_, T_) zt[T_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, W_), __builtin_bit_cast(vq_f16x8, A_), zt[T_], 0, 0, 0)
-    if (p.dbg & 2) {
+    if (ISI_VQ_DBGBIT(p, 2)) {
       zt[0][0] = (float)(n & 7); zt[1][5] = 1.f;
     } else {
     unsigned a0, a1;
@@ -479,11 +501,11 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
         const unsigned abase = second ? a1 : a0;
         const unsigned acol = (unsigned)(second ? cc * 32 - p.C0 : cc * 32) * 4u;
         // pieces of channel group 2 s + half of the chunk: hi at + 0, lo at + 16
-        const unsigned ao = (abase == OOBV || !live || (p.dbg & 32)) ? OOBV : abase + acol + (unsigned)(2 * s_ + half) * 32u;
+        const unsigned ao = (abase == OOBV || !live || ISI_VQ_DBGBIT(p, 32)) ? OOBV : abase + acol + (unsigned)(2 * s_ + half) * 32u;
         ahv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao, 0, 0);
         alv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao == OOBV ? OOBV : ao + 16u, 0, 0);
         // weight pieces, fragment-major: ((step * 2 + tile) * 2 + plane) * 1 KiB + 16 lane
-        const unsigned wo = (live && !(p.dbg & 16)) ? (unsigned)((cc * 2 + s_) * 4) * 1024u + (unsigned)lane * 16u : OOBV;
+        const unsigned wo = (live && !ISI_VQ_DBGBIT(p, 16)) ? (unsigned)((cc * 2 + s_) * 4) * 1024u + (unsigned)lane * 16u : OOBV;
         w0h[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo, 0, 0);
         w0l[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo == OOBV ? OOBV : wo + 1024u, 0, 0);
         w1h[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo == OOBV ? OOBV : wo + 2048u, 0, 0);
@@ -518,14 +540,14 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
     }
     // ---- search (candidates on the f16 pipe, decision in fp32; shared with the stand-alone kernel)
     VqCand cand{0.f, 1.f, (int)(n & 255), (int)(n & 255) + 256};
-    if (!(p.dbg & 1)) cand = vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half);
+    if (!ISI_VQ_DBGBIT(p, 1)) cand = vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half);
     int besti = cand.i1;
-    if (!(p.dbg & 4)) besti = vq_decide_f32(cand, e2, K, p.codes, zq, half, ew);
+    if (!ISI_VQ_DBGBIT(p, 4)) besti = vq_decide_f32(cand, e2, K, p.codes, zq, half, ew);
     else {
 #pragma unroll
       for (int j = 0; j < NQ; ++j) ew[j] = zq[j];
     }
-    if (p.dbg & 8) { sse += zq[0].x + ew[3].y; continue; }
+    if (ISI_VQ_DBGBIT(p, 8)) { sse += zq[0].x + ew[3].y; continue; }
     const bool lost = besti < 0;
     if (valid && lost) {
 #pragma unroll
@@ -736,7 +758,7 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
                        zero_counts ? counts : nullptr, K);
   }
   auto kern = vq_conv1x1_nearest_kernel;
-  if (const char *e = getenv("ISI_VQ_DBG")) a.dbg = atoi(e);
+  a.dbg = knobs().vq_dbg;   // 0 outside -DISI_MEASURE builds
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return check_launch("hipFuncSetAttribute(vq_conv1x1)");
   {

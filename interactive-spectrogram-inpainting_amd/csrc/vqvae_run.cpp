@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 
 namespace isi {
 
@@ -262,11 +263,11 @@ bool decoder_pairs_ok(const isi_decoder_w &d, int C0, int C1, bool in0_pair, boo
   return d.n_up >= 1;
 }
 bool pairs_eligible(const isi_vqvae_w &w) {
-  const bool off = getenv("ISI_NO_PAIRS") != nullptr;   // read per call: tests compare both paths in one process
+  const bool off = knobs().no_pairs != 0;   // tests compare both paths in one process (isi_knob_set)
   if (off || w.precision != 4 || !w.w16) return false;
   // the first layer must be able to WRITE pairs: the 2-channel kernel (conv_first_f32.hip) does, the generic gather
   // kernel does not
-  if (getenv("ISI_NO_CONV_FIRST") || w.in_channel != 2 || w.enc_b.n_down < 1 ||
+  if (knobs().no_conv_first || w.in_channel != 2 || w.enc_b.n_down < 1 ||
       (w.enc_b.down[0].Cout != 32 && w.enc_b.down[0].Cout != 64)) return false;
   const int D = w.quantize_t.D;
   if (w.quantize_b.D != D) return false;
@@ -369,7 +370,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   const bool pairs = pairs_eligible(w);   // internal activations as split-f16 pairs (isi_hip.h: ISI_CONV_*_PAIR)
   const int pf_dec = w.precision == 4 ? f16 : w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
   // quantize_conv_{t,b} fused into the codebook searches: the pair pipeline only (pair8 sources, blocked weights)
-  const bool fuse_vq = pairs && !w.no_quantize && getenv("ISI_NO_VQ_FUSION") == nullptr;
+  const bool fuse_vq = pairs && !w.no_quantize && !knobs().no_vq_fusion;
   bool bottom_pair_done = false;
 
   if (mode & ISI_MODE_ENCODE) {

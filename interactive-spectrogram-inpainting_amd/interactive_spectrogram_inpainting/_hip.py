@@ -122,6 +122,8 @@ SIGNATURES = {
     "isi_version": (C.c_char_p, []),
     "isi_last_error": (C.c_char_p, []),
     "isi_abi_struct_bytes": (C.c_size_t, [C.c_int]),
+    "isi_knob_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "isi_knob_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "isi_relu_inplace_f32": (C.c_int, [_P, C.c_int64, _P]),
     "isi_prof_enable": (C.c_int, [C.c_int]),
     "isi_prof_num_kernels": (C.c_int, []),
@@ -235,6 +237,26 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().isi_last_error().decode("utf-8", "replace")
         raise HipLibraryError(f"{what} failed with code {rc}: {msg}")
+
+
+class knob:
+    """`with knob("ISI_CONV_FLUSH", 0): ...` -- set an execution switch of the library (isi_knob_set) for the block and
+    restore it afterwards.  The switches select between kernels that compute the same result; the library reads the
+    environment variables of the same names only once, at first use."""
+
+    def __init__(self, name: str, value: int):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        old = C.c_int(0)
+        check(lib().isi_knob_get(self.name, C.byref(old)), "isi_knob_get")
+        self.old = old.value
+        check(lib().isi_knob_set(self.name, self.value), "isi_knob_set")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().isi_knob_set(self.name, self.old), "isi_knob_set")
+        return False
 
 
 def stream_ptr(device: torch.device) -> int:

@@ -41,7 +41,7 @@ _ATTN_PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
 ATTENTION_PRECISIONS = tuple(_ATTN_PREC)                 # modes bench.py times
 ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1}    # 16-bit MFMA terms per product (0: fp32 matrix pipe)
 _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4, "f16x3": 8}
-_F16_WEIGHT_LIMIT = 64.0
+_F16_WEIGHT_LIMIT = 63.98   # 65520 / 1024 and above rounds to inf in the f16 pieces
 
 
 def pack_linear_weight(weight: torch.Tensor, range_check: bool = False) -> torch.Tensor:

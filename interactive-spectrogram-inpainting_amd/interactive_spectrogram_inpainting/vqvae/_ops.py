@@ -186,6 +186,46 @@ def vq_nearest(z: torch.Tensor, codes: torch.Tensor, e2: torch.Tensor, split_f16
     return q, out2[0], idx, out2[1]
 
 
+def vq_conv1x1_nearest(x_bhwc: torch.Tensor, packed_w16: torch.Tensor, bias: torch.Tensor, codes: torch.Tensor,
+                       e2: torch.Tensor, x2_bhwc: Optional[torch.Tensor] = None, return_all: bool = False):
+    """quantize_conv (1x1 on cat(x, x2)) fused with the codebook search (isi_vq_conv1x1_nearest_f32): dense
+    channels-last fp32 inputs [B,H,W,C] (converted to the pair format here), `packed_w16` =
+    pack_conv_weight(w, with_f16=True).  Returns idx int64 [B,H,W] (or (q, diff, idx, perplexity))."""
+    _hip.require_gpu(x_bhwc, "fused quantizer input")
+    L = _hip.lib()
+    B, H, W, C0 = x_bhwc.shape
+    K, D = codes.shape
+    srcs = [pair_encode(x_bhwc.contiguous())]
+    if x2_bhwc is not None:
+        srcs.append(pair_encode(x2_bhwc.contiguous()))
+    C1 = srcs[1].shape[-1] if len(srcs) > 1 else 0
+
+    def src(t):
+        return _hip.isi_src(t.data_ptr(), t.shape[-1], H * W * t.shape[-1], 1, W * t.shape[-1], t.shape[-1])
+
+    s0 = src(srcs[0])
+    s1 = src(srcs[1]) if C1 else None
+    n = packed_w16.numel() // 2
+    N = B * H * W
+    idx = torch.empty(B, H, W, dtype=torch.int64, device=x_bhwc.device)
+    q = torch.empty(B, H, W, D, dtype=torch.float32, device=x_bhwc.device)
+    counts = torch.zeros(K, dtype=torch.int32, device=x_bhwc.device)
+    n_part = L.isi_vq_num_partials(N)
+    part = torch.empty(n_part, dtype=torch.float32, device=x_bhwc.device)
+    ws = torch.empty(max(4, L.isi_vq_conv1x1_workspace_floats(C0, C1, D)), dtype=torch.float32, device=x_bhwc.device)
+    _hip.check(L.isi_vq_conv1x1_nearest_f32(C.byref(s0), C.byref(s1) if s1 is not None else None,
+                                            packed_w16.data_ptr() + 4 * n, bias.data_ptr(), codes.data_ptr(),
+                                            e2.data_ptr(), idx.data_ptr(), q.data_ptr(), None, counts.data_ptr(),
+                                            part.data_ptr(), ws.data_ptr(), B, H, W, D, K, _s(x_bhwc)),
+               "isi_vq_conv1x1_nearest_f32")
+    if not return_all:
+        return idx
+    out2 = torch.empty(2, dtype=torch.float32, device=x_bhwc.device)
+    _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D, out2.data_ptr(), _s(x_bhwc)),
+               "isi_vq_finalize_f32")
+    return q, out2[0], idx, out2[1]
+
+
 def embed_code(idx: torch.Tensor, codes: torch.Tensor) -> torch.Tensor:
     """idx int64 [...] -> [..., D] rows of the codebook."""
     _hip.require_gpu(idx, "code indices")

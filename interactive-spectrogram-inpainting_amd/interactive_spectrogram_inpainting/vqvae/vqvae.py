@@ -32,7 +32,9 @@ from .. import _hip
 from .encoder_decoder import RosinalityEncoder, RosinalityDecoder, _ConvParams
 from .bottleneck import QuantizedBottleneck, UnquantizedBottleneck
 
-_F16_WEIGHT_LIMIT = 64.0   # ISI_CONV_F16X3 scales weights by 2^10 before the f16 split (include/isi_hip.h)
+# ISI_CONV_F16X3 scales weights and code vectors by 2^10 before the f16 split (include/isi_hip.h): 65520 / 1024 and
+# above rounds to inf
+_F16_WEIGHT_LIMIT = 63.98
 
 
 class VQVAE(nn.Module):
@@ -228,6 +230,7 @@ class VQVAE(nn.Module):
                 return _hip.isi_codebook_w(None, None, q.dim, q.n_embed)
             codes, e2 = q.packed()
             keep.extend([codes, e2])
+            wmax.append(q.embed.detach().abs().max())    # the search splits the code vectors like weights
             return _hip.isi_codebook_w(codes.data_ptr(), e2.data_ptr(), q.dim, q.n_embed)
 
         w = _hip.isi_vqvae_w()
@@ -243,7 +246,7 @@ class VQVAE(nn.Module):
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)
         if w.precision == 4 and not float(torch.stack(wmax).max()) < _F16_WEIGHT_LIMIT:
-            warnings.warn(f"a convolution weight reaches {_F16_WEIGHT_LIMIT:g} in magnitude (or is not finite): beyond the "
+            warnings.warn(f"a convolution weight or code vector reaches {_F16_WEIGHT_LIMIT:g} in magnitude (or is not finite): beyond the "
                           "operand range of conv_precision='split_f16', running this model in 'split_bf16'")
             w.precision = 3
         self._plan, self._plan_key = (w, keep), key

@@ -71,12 +71,14 @@ def sample_model(model: VQNSynthTransformer, device: Union[torch.device, str], b
             hi = min(batch_size, lo + 256)
             cls = {k: (torch.as_tensor(v).reshape(-1)[lo:hi] if torch.as_tensor(v).numel() == batch_size else v)
                    for k, v in class_conditioning.items()}
+            # every per-row input is sliced (a mask with a batch dimension included); options are passed through
             parts.append(sample_model(
                 model, device, hi - lo, codemap_size, temperature, condition=rows(condition, lo, hi),
-                class_conditioning=cls, initial_code=rows(initial_code, lo, hi), mask=mask,
+                class_conditioning=cls, initial_code=rows(initial_code, lo, hi), mask=rows(mask, lo, hi),
                 time_indexes_source=time_indexes_source, time_indexes_target=time_indexes_target,
                 top_k_sampling_k=top_k_sampling_k, top_p_sampling_p=top_p_sampling_p,
-                progressbar_decorator=progressbar_decorator, uniforms=uniforms[:, lo:hi]))
+                progressbar_decorator=progressbar_decorator, use_predictive_sampling=use_predictive_sampling,
+                uniforms=uniforms[:, lo:hi], gumbel_noise=rows(gumbel_noise, lo, hi)))
         return torch.cat(parts, 0)
     if initial_code is None:
         fill = model.mask_token_index if model.self_conditional_model else 0

@@ -253,6 +253,24 @@ def quantizer_fixtures():
 
 
 @torch.no_grad()
+def quantizer_large_fixtures():
+    """65 536 near-tie-free Gaussian vectors through the REFERENCE's QuantizedBottleneck (D=64, K=512, its own
+    randn codebook): only the codebook and the int16 indices are stored; the vectors are regenerated from the seed by
+    oracle.vqvae_oracle.near_tie_free_vectors (shared with the test)."""
+    from interactive_spectrogram_inpainting.vqvae.bottleneck import QuantizedBottleneck
+    sys.path.insert(0, str(OUT.parent.parent))
+    from oracle import vqvae_oracle as O
+    torch.manual_seed(17)
+    q = QuantizedBottleneck(64, 512).eval()
+    n, seed, scale, min_gap = 65536, 18, 1.0, 1e-5
+    vec = O.near_tie_free_vectors(q.embed, n, seed, scale=scale, min_gap=min_gap)
+    ind = torch.cat([q(vec[lo:lo + 8192])[2] for lo in range(0, n, 8192)])
+    assert ind.shape == (n,) and int(ind.max()) < 512
+    _save("quantizer_large.npz", embed=q.embed.numpy(), ind=ind.numpy().astype(np.int16), n=np.int64(n),
+          seed=np.int64(seed), scale=np.float64(scale), min_gap=np.float64(min_gap))
+
+
+@torch.no_grad()
 def codemap_fixtures():
     from interactive_spectrogram_inpainting.priors.codemaps_helpers import (
         SimpleCodemapsHelper, ZigZagCodemapsHelper)
@@ -640,6 +658,7 @@ def main():
     resblock_fixture()
     layer_fixtures()
     quantizer_fixtures()
+    quantizer_large_fixtures()
     codemap_fixtures()
     prior_wrapper_fixtures()
     prior_wrapper_positional_fixtures()

@@ -364,26 +364,100 @@ def init_state_dict(cfg: Config, seed: int = 1) -> Dict[str, Tensor]:
 
 
 @torch.no_grad()
-def calibrate_codebooks(sd: Dict[str, Tensor], cfg: Config, x: Tensor, seed: int = 3) -> None:
-    """Re-seed each level's codebook from that level's own pre-quantisation
-    vectors on a calibration batch so that code usage is non-degenerate
-    (a randomly-initialised VQ-VAE maps everything to 1-2 codes).  In place."""
+def pick_distinct_rows(flat: Tensor, K: int, g: torch.Generator, min_rel: float = 0.1) -> Tensor:
+    """Row indices of K WELL-SEPARATED vectors of `flat` [N, D]: rows are visited in a random order and one is
+    accepted when it lies farther than `min_rel * |row|` from every accepted row; if the pool runs out, the
+    remainder is filled farthest-point first.  (Drawing K rows WITH replacement from a few thousand highly
+    correlated encoder outputs gave exact duplicates and code pairs 1e-3 apart: every vector assigned to such a
+    pair is a coin toss of the fp32 distance formula, which made "bit-exact indices" untestable at scale.)"""
+    N = flat.shape[0]
+    assert N >= K, (N, K)
+    order = torch.randperm(N, generator=g)
+    cand = flat[order].double()
+    norm = cand.norm(dim=1)
+    mind = torch.full((N,), float("inf"), dtype=torch.float64)
+    chosen = []
+    for i in range(N):
+        if len(chosen) == K:
+            break
+        if mind[i] > min_rel * norm[i]:
+            chosen.append(i)
+            mind = torch.minimum(mind, (cand - cand[i]).norm(dim=1))
+    while len(chosen) < K:
+        i = int(mind.argmax())
+        chosen.append(i)
+        mind = torch.minimum(mind, (cand - cand[i]).norm(dim=1))
+    return order[torch.tensor(chosen)]
+
+
+def _standardize_1x1(sd: Dict[str, Tensor], prefix: str, z: Tensor, target_std: float) -> None:
+    """Rescale the 1x1 convolution `prefix` so that its output channels have zero mean and `target_std` deviation
+    over the calibration vectors z [..., D] (an exact re-parametrisation of the layer: w/s, (b - mean)/s)."""
+    flat = z.reshape(-1, z.shape[-1])
+    mu, sg = flat.mean(0), flat.std(0).clamp(min=1e-12) / target_std
+    sd[prefix + "weight"] = sd[prefix + "weight"] / sg.view(-1, 1, 1, 1)
+    sd[prefix + "bias"] = (sd[prefix + "bias"] - mu) / sg
+
+
+def calibrate_codebooks(sd: Dict[str, Tensor], cfg: Config, x: Tensor, seed: int = 3, standardize: bool = True) -> None:
+    """Make a randomly-initialised model NON-DEGENERATE on a calibration batch, in place:
+
+    * `standardize`: the pre-quantisation vectors of a random-init network are one common offset plus a tiny spread
+      (top level of the default model: |mean| 0.75, spread 0.03), so that every vector is nearly equidistant from every
+      code RELATIVE to |z|^2 + |e|^2 -- the magnitude at which the reference's fp32 formula |z|^2 - 2 z.e + |e|^2 rounds
+      (bottleneck.py:56-60): 5 % of the top vectors were then coin tosses of that formula's last bit.  A trained model
+      has no such offset; `quantize_conv_t/b` are re-parametrised to zero-mean outputs of deviation 0.5.
+    * each level's codebook is re-seeded from that level's own pre-quantisation vectors (a random-init VQ-VAE maps
+      everything to 1-2 codes), WELL SEPARATED (`pick_distinct_rows`)."""
     g = torch.Generator().manual_seed(seed)
     fb, ft = cfg.resolution_factors["bottom"], cfg.resolution_factors["top"]
+    K = cfg.num_embeddings
+
+    def pick(flat):
+        return pick_distinct_rows(flat, K, g) if flat.shape[0] >= K else torch.randint(0, flat.shape[0], (K,), generator=g)
+
     enc_b = encoder(x, sd, "enc_b.", fb, cfg.n_res_block)
     enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
-    z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    conv_t = lambda: F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+    if standardize:
+        _standardize_1x1(sd, "quantize_conv_t.", conv_t(), 0.5)
+    z_t = conv_t()
     flat = z_t.reshape(-1, cfg.embed_dim)
-    K = cfg.num_embeddings
-    pick = torch.randint(0, flat.shape[0], (K,), generator=g)
-    sd["quantize_t.embed"] = flat[pick].t().contiguous()
+    sd["quantize_t.embed"] = flat[pick(flat)].t().contiguous()
     sd["quantize_t.embed_avg"] = sd["quantize_t.embed"].clone()
     q_t, _, _, _ = quantize(z_t, sd["quantize_t.embed"])
     dec_t = decoder(q_t.permute(0, 3, 1, 2), sd, "dec_t.", ft, cfg.n_res_block)
     w = min(dec_t.shape[-1], enc_b.shape[-1])
     cat = torch.cat([dec_t[..., :w], enc_b[..., :w]], 1)
-    z_b = F.conv2d(cat, sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+    conv_b = lambda: F.conv2d(cat, sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+    if standardize:
+        _standardize_1x1(sd, "quantize_conv_b.", conv_b(), 0.5)
+    z_b = conv_b()
     flat = z_b.reshape(-1, cfg.embed_dim)
-    pick = torch.randint(0, flat.shape[0], (K,), generator=g)
-    sd["quantize_b.embed"] = flat[pick].t().contiguous()
+    sd["quantize_b.embed"] = flat[pick(flat)].t().contiguous()
     sd["quantize_b.embed_avg"] = sd["quantize_b.embed"].clone()
+
+
+def near_tie_free_vectors(embed: Tensor, n: int, seed: int, scale: float = 1.0, min_gap: float = 1e-5) -> Tensor:
+    """`n` seeded Gaussian vectors [n, D] none of which is a NEAR-TIE of the codebook `embed` [D, K]: the float64
+    distances to the best and second-best code differ by more than `min_gap * (|z|^2 + |e|^2)`, two decades above the
+    rounding of the reference's fp32 formula |z|^2 - 2 z.e + |e|^2 (bottleneck.py:56-60).  Every correct fp32
+    implementation must therefore return the reference's indices BIT-EXACTLY on them.  Deterministic: seeded draw
+    of 1.1 n vectors, the near-ties (about 0.1 %) dropped, the first n kept."""
+    g = torch.Generator().manual_seed(seed)
+    D = embed.shape[0]
+    pool = torch.randn(int(n * 1.1) + 64, D, generator=g) * scale
+    e = embed.double()
+    e2 = e.pow(2).sum(0)
+    keep = []
+    for lo in range(0, pool.shape[0], 8192):
+        z = pool[lo:lo + 8192].double()
+        z2 = z.pow(2).sum(1, keepdim=True)
+        d = z2 - 2 * z @ e + e2
+        best, idx = d.topk(2, dim=1, largest=False)
+        gap = (best[:, 1] - best[:, 0]) / (z2[:, 0] + e2[idx[:, 0]])
+        keep.append(gap > min_gap)
+    keep = torch.cat(keep)
+    out = pool[keep][:n]
+    assert out.shape[0] == n
+    return out.contiguous()

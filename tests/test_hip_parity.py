@@ -12,6 +12,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+class _Hip:
+    """lazy `_hip` module (the package is importable only with the tests' sys.path set up by conftest)"""
+    def __getattr__(self, name):
+        from interactive_spectrogram_inpainting import _hip as real
+        return getattr(real, name)
+
+
+_hip = _Hip()
+
+
 def _dev():
     assert torch.cuda.is_available(), "gpu tests need an MI355X"
     return torch.device("cuda:0")
@@ -201,6 +211,70 @@ def test_quantizer_split_f16_products():
     assert i0[7] >= 0 and i0[9] == -1 and torch.isnan(d0)
 
 
+def test_quantizer_large_fixture_bit_exact(golden_dir):
+    """65 536 Gaussian vectors x the reference's own 512-code codebook, indices produced by the REFERENCE's
+    QuantizedBottleneck.forward (oracle/make_golden.py::quantizer_large_fixtures; stored as int16).  The vectors are
+    regenerated from the seed and are free of near-ties by construction (float64 gap between best and second-best code
+    > 1e-5 of |z|^2 + |e|^2: oracle.near_tie_free_vectors), so every search kernel must return the reference's
+    indices BIT-EXACTLY: the exact-fp32 kernel, the f16-candidate / fp32-decision kernel, and the fused
+    quantize_conv + search kernel (fed through an identity 1x1 convolution)."""
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    z = np.load(golden_dir / "quantizer_large.npz")
+    embed = torch.from_numpy(z["embed"])
+    n, seed = int(z["n"]), int(z["seed"])
+    vec = O.near_tie_free_vectors(embed, n, seed, scale=float(z["scale"]), min_gap=float(z["min_gap"]))
+    want = torch.from_numpy(z["ind"].astype(np.int64))
+    assert vec.shape == (n, 64) and n >= 65536 and want.shape == (n,)
+    assert torch.equal(O.quantize(vec, embed)[2], want), "the oracle restates the reference"
+    dev = _dev()
+    codes, e2 = _ops.pack_codebook(embed.to(dev))
+    for split in (False, True):
+        q, d, i, p = _ops.vq_nearest(vec.to(dev), codes, e2, split_f16=split)
+        assert torch.equal(i.cpu(), want), f"split_f16={split}: {(i.cpu() != want).sum().item()} indices differ"
+        assert torch.equal(q.cpu(), embed.t()[want]) or ((q.cpu() - embed.t()[want]).abs().max() < 1e-6)
+    # fused kernel: the vectors as a pair8 activation map [B, H, W, 64] through quantize_conv = identity
+    B, H, W = 16, 32, 128
+    assert B * H * W == n
+    pw = _ops.pack_conv_weight(torch.eye(64).reshape(64, 64, 1, 1).to(dev))
+    x = vec.reshape(B, H, W, 64).to(dev)
+    got = _ops.vq_conv1x1_nearest(x, pw, torch.zeros(64, device=dev), codes, e2)
+    assert torch.equal(got.reshape(-1).cpu(), want), f"fused: {(got.reshape(-1).cpu() != want).sum().item()} indices differ"
+
+
+def test_codebook_beyond_f16_range_is_loud():
+    """the split-f16 search stores code vectors as f16 pieces of 1024 e (|e| < 63.98).  A code beyond
+    that must never be skipped silently: the stand-alone kernel returns index -1 for every vector (NaN diff), and
+    the model recognises such a codebook when its plan is built and runs in split_bf16 (exact search) with a warning."""
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    embed = torch.randn(64, 512, generator=g)
+    vec = torch.randn(100, 64, generator=g)
+    vec[5] = 0
+    vec[5, 7] = 70.0
+    embed[:, 200] = vec[5]                      # the true nearest code of vector 5 has a component of 70
+    codes, e2 = _ops.pack_codebook(embed.to(dev))
+    q0, d0, i0, p0 = _ops.vq_nearest(vec.to(dev), codes, e2)
+    assert i0[5] == 200 and torch.equal(i0.cpu(), O.quantize(vec, embed)[2])
+    q1, d1, i1, p1 = _ops.vq_nearest(vec.to(dev), codes, e2, split_f16=True)
+    assert (i1 == -1).all() and torch.isnan(d1), "an out-of-range codebook must be loud in the split-f16 search"
+    cfg = O.Config(in_channel=2)
+    sd = O.init_state_dict(cfg, seed=2)
+    O.calibrate_codebooks(sd, cfg, torch.randn(2, 2, 32, 64, generator=g))
+    sd["quantize_t.embed"][3, 11] = 100.0
+    m = VQVAE(in_channel=2)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    x = torch.randn(1, 2, 32, 64, generator=g)
+    with pytest.warns(UserWarning, match="split_bf16"):
+        out = m(x.to(dev))
+    ref = O.forward(x, sd, cfg)
+    assert torch.equal(out[4].cpu(), ref[4]) and (out[5] >= 0).all()
+
+
 def _certify_index_mismatches(z_vecs, embed, got, ref, eps=2e-6):
     """Any index that differs from the reference must be a near-tie: the fp64
     distances of the two candidates differ by less than `eps` of the magnitude
@@ -346,14 +420,22 @@ def test_vqvae_full_size_properties(precision):
     enc_t = O.encoder(enc_b, sd, "enc_t.", 2, 2)
     z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
     ref_t = O.quantize(z_t, sd["quantize_t.embed"])[2]
+    # north_star: "bit-exact code indices".  The calibrated model is non-degenerate (oracle.calibrate_codebooks:
+    # standardised pre-quantisation vectors, well-separated codes), so no vector sits on a rounding coin toss of the
+    # reference's own fp32 formula: the exact-fp32 mode must EQUAL the oracle, the split-f16 mode (f16-pipe candidates,
+    # fp32 decision) may move at most 2 certified near-ties.
     n_t = _certify_index_mismatches(z_t, sd["quantize_t.embed"], gt, ref_t)
-    assert n_t <= 0.004 * ref_t.numel(), f"{n_t} of {ref_t.numel()} top indices differ from the oracle"
+    if precision == "f32":
+        assert torch.equal(gt, ref_t), f"{n_t} of {ref_t.numel()} top indices differ from the oracle"
+    assert n_t <= 2, f"{n_t} of {ref_t.numel()} top indices differ from the oracle"
     q_t_forced = O.embed_code(gt, sd["quantize_t.embed"]).permute(0, 3, 1, 2)
     cat = torch.cat([O.decoder(q_t_forced, sd, "dec_t.", 2, 2), enc_b], 1)
     z_b = F.conv2d(cat, sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
     ref_b = O.quantize(z_b, sd["quantize_b.embed"])[2]
     n_b = _certify_index_mismatches(z_b, sd["quantize_b.embed"], gb, ref_b)
-    assert n_b <= 0.002 * ref_b.numel(), f"{n_b} of {ref_b.numel()} bottom indices differ from the oracle"
+    if precision == "f32":
+        assert torch.equal(gb, ref_b), f"{n_b} of {ref_b.numel()} bottom indices differ from the oracle"
+    assert n_b <= 2, f"{n_b} of {ref_b.numel()} bottom indices differ from the oracle"
     _close(dec[pick.to(_dev())], O.decode_code(gt, gb, sd, cfg), TOL, "dec vs oracle decode_code(GPU codes)")
     print(f"[{precision}] indices differing from the torch-CPU oracle on 8 spectrograms: top {n_t}/{ref_t.numel()}, "
           f"bottom (teacher-forced) {n_b}/{ref_b.numel()}")
@@ -484,11 +566,8 @@ def test_first_layer_kernel(B, H, W, cout):
     pw = _ops.pack_conv_weight(w.to(dev))
     xd = x.to(dev)
     got = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True)
-    os.environ["ISI_NO_CONV_FIRST"] = "1"
-    try:
+    with _hip.knob("ISI_NO_CONV_FIRST", 1):
         generic = _ops.conv2d(xd, pw, b.to(dev), cout, 4, 2, 1, relu=True)
-    finally:
-        del os.environ["ISI_NO_CONV_FIRST"]
     assert torch.equal(got, generic)
     ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=2, padding=1))
     _close(got, ref, 2e-6, "first layer")
@@ -547,11 +626,8 @@ def test_split_f16_pair_format_activations():
     err_old = ((ref.cpu().double() - ref64).abs().max() / ref64.abs().max()).item()
     err_new = ((flushed.cpu().double() - ref64).abs().max() / ref64.abs().max()).item()
     assert err_new < 0.6 * err_old and err_new < 4e-7, (err_new, err_old)
-    os.environ["ISI_CONV_FLUSH"] = "0"
-    try:
+    with _hip.knob("ISI_CONV_FLUSH", 0):
         _pair_format_bit_identity(_ops, _hip, dev, g, xd, x2d, xp, x2p, pw, bias, ref, C, R, B)
-    finally:
-        del os.environ["ISI_CONV_FLUSH"]
 
 
 def _pair_format_bit_identity(_ops, _hip, dev, g, xd, x2d, xp, x2p, pw, bias, ref, C, R, B):
@@ -631,13 +707,10 @@ def test_dma_residual_block_ragged_shapes(B, H, W, C, th):
     xp = _ops.pair_encode(xd.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
     p3, p1 = _ops.pack_conv_weight(w3.to(dev), with_f16=True), _ops.pack_conv_weight(w1.to(dev), with_f16=True)
     old = _ops.resblock(xd, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4)
-    os.environ["ISI_RESPAIR_TH"] = th
-    try:
+    with _hip.knob("ISI_RESPAIR_TH", int(th)):
         got = _ops.resblock(xp, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4, extra_flags=_ops.PAIR_IN0)
         got_p = _ops.pair_decode(_ops.resblock(xp, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4,
                                                extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT))
-    finally:
-        del os.environ["ISI_RESPAIR_TH"]
     scale = ref64.abs().max().item()
     assert (got.cpu().double() - ref64).abs().max().item() < 2e-6 * scale
     assert (got_p.cpu().double() - ref64).abs().max().item() < 2e-6 * scale
@@ -683,11 +756,8 @@ def test_dma_convolution_ragged_shapes(B, H, W, C0, C1, cout, k, stride):
     assert got.shape == ref64.shape
     assert (got.cpu().double() - ref64).abs().max().item() < 1e-6 * scale
     assert (got_p.cpu().double() - ref64).abs().max().item() < 1e-6 * scale
-    os.environ["ISI_CONV_FLUSH"] = "0"
-    try:
+    with _hip.knob("ISI_CONV_FLUSH", 0):
         unflushed = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p, extra_flags=flags, **kw)
-    finally:
-        del os.environ["ISI_CONV_FLUSH"]
     assert torch.equal(unflushed, old)
 
 
@@ -715,19 +785,13 @@ def test_vqvae_pair_pipeline_against_fp32_activations():
                   num_embeddings=64).to(dev).eval()
     small(x)
     assert _hip.lib().isi_vqvae_pair_activations(ctypes.byref(small._native_weights())) == 0   # 32-channel layers
-    os.environ["ISI_NO_PAIRS"] = "1"
-    try:
+    with _hip.knob("ISI_NO_PAIRS", 1):
         ref = m(x)
-    finally:
-        del os.environ["ISI_NO_PAIRS"]
     # The convolutions' matrix operands are the same bits on both paths (with the pair kernel's accumulator flush off,
     # ISI_CONV_FLUSH=0, even the same sums); the residual blocks of the pair pipeline take their skip connection from
     # the pair pieces ((hi + lo) / 4: the value to 2^-24) instead of the fp32 tensor: rounding-level differences
-    os.environ["ISI_CONV_FLUSH"] = "0"
-    try:
+    with _hip.knob("ISI_CONV_FLUSH", 0):
         unflushed = m(x)
-    finally:
-        del os.environ["ISI_CONV_FLUSH"]
     for got_ in (unflushed, got):
         assert (got_[4] != ref[4]).float().mean() < 0.01 and (got_[5] != ref[5]).float().mean() < 0.01
         same_ = (got_[4] == ref[4]).all(-1).all(-1) & (got_[5] == ref[5]).all(-1).all(-1)
@@ -735,22 +799,16 @@ def test_vqvae_pair_pipeline_against_fp32_activations():
             _close(got_[0][same_], ref[0][same_], 3e-6, "dec (pair pipeline vs fp32 activations)")
     # quantize_conv_{t,b} fused into the codebook searches (z stays in registers; csrc/vq_nearest.hip): the same
     # products in the same order as the two-launch path -- the same bits
-    os.environ["ISI_NO_VQ_FUSION"] = "1"
-    try:
+    with _hip.knob("ISI_NO_VQ_FUSION", 1):
         unfused = m(x)
-    finally:
-        del os.environ["ISI_NO_VQ_FUSION"]
     for k_, (a, b) in enumerate(zip(got, unfused)):
         if k_ == 1:     # diff: a per-lane sum of squares whose fmas the two kernels may contract differently (1 ulp)
             assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
         else:
             assert torch.equal(a, b)
     enc_f = m.encode(x)
-    os.environ["ISI_NO_VQ_FUSION"] = "1"
-    try:
+    with _hip.knob("ISI_NO_VQ_FUSION", 1):
         enc_u = m.encode(x)
-    finally:
-        del os.environ["ISI_NO_VQ_FUSION"]
     for a, b in zip(enc_f, enc_u):
         assert torch.equal(a, b)
 

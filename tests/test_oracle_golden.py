@@ -200,3 +200,24 @@ def test_training_trajectory_matches_reference(golden_dir, tag):
         if k.startswith(f"{tag}::after::"):
             name = k[len(f"{tag}::after::"):]
             _close(state[name].detach(), z[k], 2e-3 if "quantize_" in name else 2e-4)
+
+
+def test_quantizer_large_fixture(golden_dir):
+    """65 536 near-tie-free Gaussian vectors (regenerated from the seed) against the indices the REFERENCE's
+    QuantizedBottleneck.forward produced for them (make_golden.py::quantizer_large_fixtures): the oracle restates it
+    bit-exactly, and the fixture is what it claims to be (no vector within 1e-5 of a tie in float64)."""
+    from oracle import vqvae_oracle as O
+    z = np.load(golden_dir / "quantizer_large.npz")
+    embed = torch.from_numpy(z["embed"])
+    n = int(z["n"])
+    vec = O.near_tie_free_vectors(embed, n, int(z["seed"]), scale=float(z["scale"]), min_gap=float(z["min_gap"]))
+    want = torch.from_numpy(z["ind"].astype(np.int64))
+    assert n >= 65536 and vec.shape == (n, 64)
+    got = torch.cat([O.quantize(vec[lo:lo + 8192], embed)[2] for lo in range(0, n, 8192)])
+    assert torch.equal(got, want)
+    e = embed.double()
+    d = vec.double().pow(2).sum(1, keepdim=True) - 2 * vec.double() @ e + e.pow(2).sum(0)
+    best, idx = d.topk(2, dim=1, largest=False)
+    assert torch.equal(idx[:, 0], want), "the float64 arg-min agrees: no vector is a rounding coin toss"
+    gap = (best[:, 1] - best[:, 0]) / (vec.double().pow(2).sum(1) + e.pow(2).sum(0)[idx[:, 0]])
+    assert gap.min().item() > float(z["min_gap"])

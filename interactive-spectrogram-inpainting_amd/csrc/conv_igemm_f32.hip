@@ -746,6 +746,21 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
                                 (int)s->sc, (int)s->sh, (int)s->sw, (int)dst->sn, (int)dst->sc,
                                 (int)dst->sh, (int)dst->sw, relu & ISI_CONV_RELU, stream);
   }
+  {
+    // pair pipeline: the fused-phase LDS-DMA kernel (convT_pair_f16.hip) on dense channels-last tensors
+    const int Cin = s->C;
+    // (the stride of a dimension of extent 1 is never used: torch leaves arbitrary values there)
+    const bool dense_in = s->sc == 1 && (W == 1 || s->sw == Cin) && (H == 1 || s->sh == (int64_t)W * Cin) &&
+                          (B == 1 || s->sn == (int64_t)H * W * Cin);
+    const bool dense_out = dst->sc == 1 && dst->sw == Cout && dst->sh == (int64_t)2 * W * Cout &&
+                           (B == 1 || dst->sn == (int64_t)4 * H * W * Cout);
+    if ((relu & ISI_CONV_IN0_PAIR) && (relu & ISI_CONV_W16) && split_mode(relu) == 3 && dense_in && dense_out &&
+        convT_pair_ok(Cin, Cout) && aligned16(s->ptr) && aligned16(dst->ptr) && aligned16(packed_w)) {
+      const size_t Kpad = round_up((size_t)4 * Cin, kBK);
+      return convT_pair_f16(s->ptr, packed_w + (size_t)4 * Cout * Kpad, bias, dst->ptr, B, H, W, Cin, Cout, relu & 1,
+                            (relu & ISI_CONV_OUT_PAIR) ? 1 : 0, stream);
+    }
+  }
   ConvKArgs a;
   memset(&a, 0, sizeof a);
   a.in0 = s->ptr; a.in1 = s->ptr; a.C0 = s->C; a.Cin = s->C; a.src_uniform = 1;

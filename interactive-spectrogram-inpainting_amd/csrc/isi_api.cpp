@@ -30,6 +30,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_RESPAIR_TH", &Knobs::respair_th, 0, false},
     {"ISI_RES_TH", &Knobs::res_th, 0, false},
     {"ISI_CONVT_TH", &Knobs::convt_th, 0, false},
+    {"ISI_CONVT_PAIR_TH", &Knobs::convt_pair_th, 0, false},
     {"ISI_PRIOR_GRAPH", &Knobs::prior_graph, 0, false},
     {"ISI_CONV_ABLATE", &Knobs::conv_ablate, 0, true},
     {"ISI_VQ_DBG", &Knobs::vq_dbg, 0, true},
@@ -119,6 +120,7 @@ int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, i
 }
 /* measurements only (not in isi_hip.h): phase timestamps of conv_pair_f16.hip's instrumented variant */
 int isi_debug_conv_pair_stamps(long long *host, int n) { return conv_pair_debug_stamps(host, n); }
+int isi_debug_convT_pair_stamps(long long *host, int n) { return convT_pair_debug_stamps(host, n); }
 int isi_pair_encode_f32(const float *x, float *pairs, int64_t n, void *stream) { return pair_encode_f32(x, pairs, n, S(stream)); }
 int isi_pair_decode_f32(const float *pairs, float *x, int64_t n, void *stream) { return pair_decode_f32(pairs, x, n, S(stream)); }
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream) {

@@ -29,6 +29,11 @@ struct PairConvArgs {
 bool conv_pair_kernel_ok(int C0, int C1, int Cout, int taps);
 int conv_pair_f16(const PairConvArgs &c, hipStream_t stream);
 int conv_pair_debug_stamps(long long *host, int n);
+// convT_pair_f16.hip: ConvTranspose2d(k4,s2,p1) of the pair pipeline with the output phases fused on one staged tile
+bool convT_pair_ok(int Cin, int Cout);
+int convT_pair_debug_stamps(long long *host, int n);
+int convT_pair_f16(const float *in, const float *w16, const float *bias, float *out, int B, int H, int W, int Cin,
+                   int Cout, int relu, int out_pair, hipStream_t stream);
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                int KW, int stride, int pad, int relu, hipStream_t stream);

@@ -48,6 +48,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
 bool resblock_fusable(int C, int R);
 bool resblock_pair_ok(int C, int R);
 bool resblock_pair_preferred(int B, int H, int W, int C, int R);
+int resblock_pair_debug_stamps(long long *host, int n);
 int resblock_pair_f16(const float *in, const float *w1_16, const float *b1, const float *w2_16, const float *b2, float *out,
                       int B, int H, int W, int C, int relu, int out_pair, hipStream_t stream);
 int resblock_f32(const float *in, const float *w1, const float *b1, const float *w2, const float *b2,

@@ -16,10 +16,16 @@
 //     43.8 KB (TH = 4) / 60.7 KB (TH = 8) -- through a ring of 3 / 2 stages: the next stage's DMAs are issued
 //     between the MFMAs of the current one, ONE barrier per 54 MFMAs per wave, the nine taps read shifted windows of
 //     the resident halo (16-byte pieces XOR-swizzled on the DMA's source side: conflict-free ds_read_b128);
-//   * the hidden activations go through the wave's own LDS rows into the second GEMM, whose weight fragments
-//     (16 KB, L2-resident) are loaded straight into registers;
-//   * epilogue per 32-pixel tile through an LDS transpose: a lane owns 8 channels of one pixel, reads r's two
-//     16-byte pieces ((hi + lo) / 4: the skip connection), adds b2, rectifies and stores fp32 or pair pieces.
+//   * both GEMMs run with SWAPPED operands (weights = MFMA rows, pixels = columns), so a lane's accumulators are
+//     channels of ONE pixel: GEMM 1's accumulators (+ b1, ReLU, f16 split) are GEMM 2's B fragments as they stand, and
+//     GEMM 2's (rows permuted so that a lane holds whole pair8 groups) are stored straight from the registers;
+//   * the skip connection never touches memory again: the centre-tap fragments of every K stage are this lane's pieces
+//     of r for exactly the groups it stores, and are kept in registers (64 of them at C = 128);
+//   * W2 (as MFMA fragments) and the biases live in LDS for the whole launch: the tail contains NO vector-memory load
+//     (a load waits in order behind earlier stores -- one vmcnt counts both), no LDS transpose and no barrier.
+//     History (B = 64, 32 x 128, C = 128): LDS planes + transposes + per-pass W2 / skip loads 101 us; loads hoisted in
+//     front of the stores 94 us (tools/stamps_resblock.py: the launch is then bound by its 440 MB of traffic, the 134 MB
+//     skip re-read arriving as one burst); this form reads the input once.
 //
 // Requirements (else resblock_f32.hip): C % 32 == 0, C <= 128, R == 32, dense channels-last tensors.
 #include <cstdlib>
@@ -65,9 +71,17 @@ __device__ __forceinline__ i32x4 make_rsrc(const void *ptr, const unsigned bytes
   const unsigned long long b = (unsigned long long)ptr;
   return i32x4{(int)(unsigned)b, (int)((unsigned)(b >> 32) & 0xffffu), (int)bytes, 0x00020000};
 }
+// phase timestamps (-DISI_MEASURE builds; tools/stamps_resblock.py): workgroup 8, waves 0 and 4, its second work item
+#ifdef ISI_MEASURE
+__device__ long long g_respair_stamps[128];
+#define ISI_STAMP(i_) do { if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && item_i == (int)blockIdx.x + (int)gridDim.x) \
+    g_respair_stamps[(wave >> 2) * 64 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ISI_STAMP(i_) do { } while (0)
+#endif
 #define ISI_MH(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
 
-template <int TH>
+template <int TH, int NT>   // NT = C / 32
 __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p) {
   constexpr int NW = TH;                                   // waves: one per tile row
   constexpr int HPIX = (TH + 2) * HWD;                     // halo pixels
@@ -78,15 +92,52 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
   constexpr int NDMA = NA + NWD;                           // DMAs per stage
   constexpr int PER = (NDMA + NW - 1) / NW;                // per wave (the last wave(s) may have fewer: they pad with
                                                            // out-of-range pieces so that every wave's count is PER)
+  constexpr int kRingBytes = NS * STAGE;
+  constexpr int C = NT * 32, NSTAGE = C / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int frow = lane & 31, kb = lane >> 5;
-  const int C = p.C, nstage = ISI_RESPAIR_ABLBIT(p, 1) ? 1 : C / 16;
   const i32x4 rsi = make_rsrc(p.in, p.in_bytes), rsw = make_rsrc(p.w1, p.w1_bytes);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
 
+  // ---- once per workgroup: W2 as FRAGMENTS and the biases into LDS, behind the ring.  (Nothing in the tail may be a
+  // vector-memory load: such a load is waited for IN ORDER behind every store issued before it -- one vmcnt counts
+  // both --; the per-pass W2 / skip loads of the first version of this tail cost 11 k cycles per pass, 47 % of an item,
+  // tools/stamps_resblock.py.)
+  // GEMM 2 runs with swapped operands, O^T[channel][pixel] = W2 h^T: MFMA row m of output tile j is channel
+  //   sigma(m) = 16 (m >> 4) + 8 ((m >> 2) & 1) + 4 ((m >> 3) & 1) + (m & 3)            (+ 32 j)
+  // so that lane (pixel, kb)'s 16 accumulators -- rows (r & 3) + 8 (r >> 2) + 4 kb -- are the two pair8 groups
+  // 4 j + kb and 4 j + 2 + kb of its pixel, 8 consecutive channels each: exactly the groups whose pieces of r the
+  // same lane read as its centre-tap fragments in stages 2 j and 2 j + 1 of the K loop (the skip connection stays in
+  // registers), and exactly what a 32-byte pair8 / fp32 store writes.  The k index (hidden channel) of k-step s,
+  // slot 8 kb + e is
+  //   pi(s, kb, e) = 16 s + 4 kb + e (e < 4),  16 s + 8 + 4 kb + (e - 4) (e >= 4)
+  // -- the order in which GEMM 1's swapped accumulators hold a pixel's hidden channels (quads 2 s and 2 s + 1).
+  // Fragment (j, s, plane) of lane l = (m = l & 31, kb = l >> 5): 16 bytes at ((j 2 + s) 2 + plane) 1024 + 16 l.
+  char *w2s = smem + kRingBytes;
+  {
+    const unsigned short *w2g = reinterpret_cast<const unsigned short *>(p.w2);   // [C][4 groups]{hi[8] | lo[8]} of 1024 w
+    unsigned short *w2o = reinterpret_cast<unsigned short *>(w2s);
+    for (int i = tid; i < NT * 2 * 2 * 64 * 8; i += NW * 64) {
+      const int e = i & 7, l = (i >> 3) & 63, plane = (i >> 9) & 1, s_ = (i >> 10) & 1, j = i >> 11;
+      const int m = l & 31, kbl = l >> 5;
+      const int n = 32 * j + 16 * (m >> 4) + 8 * ((m >> 2) & 1) + 4 * ((m >> 3) & 1) + (m & 3);
+      const int k = e < 4 ? 16 * s_ + 4 * kbl + e : 16 * s_ + 8 + 4 * kbl + (e - 4);
+      w2o[i] = w2g[n * 64 + (k >> 3) * 16 + plane * 8 + (k & 7)];
+    }
+  }
+  float *b2s = reinterpret_cast<float *>(w2s + NT * 4096);      // [C] 4 b2, then [32] 4 b1
+  float *b1s = b2s + C;
+  for (int i = tid; i < C + 32; i += NW * 64) b2s[i] = f16s::kScaleA * (i < C ? p.b2[i] : p.b1[i - C]);   // in units of 4 x, like everything in the tail
+
+  const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.in_bytes, 0x00020000);
+  // ---- work distribution.  (Every workgroup reaches its store-heavy tail at the same moment, so the launch alternates
+  // between a K-loop phase -- 173 MB of halo reads -- and a store burst at the fabric's write rate, 256 KB per CU at
+  // once: 17-21 k of an item's 63 k cycles, tools/stamps_resblock.py.  Running the odd workgroups half a tile out of
+  // phase -- their first tile split into an upper half done first and a lower half done last, only the waves of those
+  // rows multiplying -- was built and measured: 88 against 79 us; a half item costs ~0.7 of a whole one.  At ~4 TB/s
+  // in both phases the block is within 25 % of its memory floor; what is left is traffic, i.e. fusing the stack.)
   const int nitems = p.tiles_x * p.tiles_y * p.B;
   for (int item_i = blockIdx.x; item_i < nitems; item_i += gridDim.x) {
     int item;
@@ -97,7 +148,15 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
     const int b = item / (p.tiles_x * p.tiles_y);
     const int rem = item - b * (p.tiles_x * p.tiles_y);
     const int y0 = (rem / p.tiles_x) * TH, x0 = (rem % p.tiles_x) * TW;
-    __syncthreads();   // the previous item is done with the LDS
+    // the lane index is made opaque per item: everything derived from it (dozens of LDS / global offsets that are
+    // invariant across items) would otherwise be hoisted out of the item loop and held in ~100 registers for the whole
+    // kernel
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    ISI_STAMP(0);
+    const int frow = lane & 31, kb = lane >> 5;
+    __syncthreads();   // the previous item is done with the ring
+    ISI_STAMP(1);
 
     // ---- this lane's DMA pieces (constant over the stages but for the channel offset, which rides in soffset):
     // piece q of this wave is DMA number wave + NW q of the stage (halo DMAs first, then the W1 slice)
@@ -106,9 +165,10 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
     for (int q = 0; q < PER; ++q) {
       const int d = wave + NW * q;                          // uniform
       const int row = (d < NA ? d : d - NA) * 16 + (lane >> 2);
-      const unsigned piece = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16);
-      if (d < NA) {                                         // halo pixel `row`
+      unsigned piece = (unsigned)(((lane & 3) ^ ((row >> 2) & 3)) * 16);   // weight rows: swizzled with the row
+      if (d < NA) {                                         // halo pixel `row`: swizzled with its COLUMN (below)
         const int hy = row / HWD, hx = row - hy * HWD;
+        piece = (unsigned)(((lane & 3) ^ ((hx >> 2) & 3)) * 16);
         const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         const bool ok = row < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         dvo[q] = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * C) * 4u + piece : OOB;
@@ -127,11 +187,22 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
       dma16(lds0 + (unsigned)(stage * STAGE) + dst, dvo[q], is_w && d < NDMA ? rsw : rsi, d < NDMA ? (unsigned)(c16 * 64) : 0u);
     };
 
-    // ---- fragment addresses inside a stage.  A: halo row (ry + dy) * 66 + 32 i + frow + dx; piece (2 kb + pl) sits
-    // at position ^ ((row >> 2) & 3).  B: row t * 32 + frow: the swizzle term depends on the lane only.
+    // ---- fragment addresses inside a stage.  A: halo row (ry + dy) * 66 + hx, hx = 32 i + frow + dx; piece
+    // (2 kb + pl) at position ^ ((hx >> 2) & 3): swizzling with the COLUMN instead of the linear row is equally
+    // conflict-free and makes the per-lane part of a window's address depend on dx only -- 3 x 2 registers, (dy, i)
+    // ride in the instruction's immediate offset.  B: row t * 32 + frow: lane-only swizzle term.
     const int ry = wave;                                    // this wave's tile row
+    unsigned abase[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int hx = frow + dx;
+      abase[dx][0] = (unsigned)((ry * HWD + hx) * ROWB + (((2 * kb) ^ ((hx >> 2) & 3)) << 4));
+      abase[dx][1] = abase[dx][0] ^ 16u;
+    }
     const unsigned bbase = (unsigned)(A_BYTES + frow * ROWB + (((2 * kb) ^ ((frow >> 2) & 3)) << 4));
+    const unsigned bbase1 = bbase ^ 16u;
 
+    // GEMM 1, operands swapped (W1 = MFMA rows, pixels = columns): H^T[hidden][pixel]
     f32x16 acc[2][2];   // [pixel tile][chain]: two chains per tile (alternating taps) keep dependent MFMAs apart
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -139,24 +210,32 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
       for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][ch][r] = 0.f;
+    // the skip connection: the centre-tap fragments of every stage ARE this lane's pieces of r -- pixel 32 i + frow,
+    // channels 16 c + 8 kb .. + 7 as {hi | lo} f16 of 4 r -- and are simply kept (8 NT x 8 registers) instead of
+    // re-read from memory in the tail (134 MB per launch at B = 64, which the launch waited for in a burst)
+    s16x8 skh[NSTAGE][2], skl[NSTAGE][2];
 
+    ISI_STAMP(2);
     // ---- prologue: NS - 1 stages in flight
 #pragma unroll
     for (int s_ = 0; s_ < NS - 1; ++s_)
-      if (s_ < nstage) {
+      if (s_ < NSTAGE) {
 #pragma unroll
         for (int q = 0; q < PER; ++q) issue(s_, s_, q);
       }
 
-    for (int c = 0; c < nstage; ++c) {
+    ISI_STAMP(3);
+#pragma unroll
+    for (int c = 0; c < NSTAGE; ++c) {
+      constexpr int dummy = 0; (void)dummy;
       const int stage = c % NS;
       // this wave's pieces of stage c have landed (those of the NS - 2 newer stages may stay in flight) ...
-      if (NS == 3 && c + 1 < nstage) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      if (NS == 3 && c + 1 < NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       // ... and everyone's; everyone has also finished with the stage that slice c + NS - 1 goes to
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const bool more = c + NS - 1 < nstage;
+      const bool more = c + NS - 1 < NSTAGE;
       const int nst = (c + NS - 1) % NS;
       const char *st = smem + stage * STAGE;
 #pragma unroll
@@ -165,20 +244,22 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
         s16x8 ah[2], al[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const int row = (ry + dy) * HWD + 32 * i + frow + dx;
-          const unsigned ao = (unsigned)(row * ROWB + (((2 * kb) ^ ((row >> 2) & 3)) << 4));
-          ah[i] = *reinterpret_cast<const s16x8 *>(st + ao);
-          al[i] = *reinterpret_cast<const s16x8 *>(st + (ao ^ 16u));
+          ah[i] = *reinterpret_cast<const s16x8 *>(st + abase[dx][0] + (dy * HWD + 32 * i) * ROWB);
+          al[i] = *reinterpret_cast<const s16x8 *>(st + abase[dx][1] + (dy * HWD + 32 * i) * ROWB);
+        }
+        if (t == 4) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) { skh[c][i] = ah[i]; skl[c][i] = al[i]; }
         }
         const s16x8 bh = *reinterpret_cast<const s16x8 *>(st + bbase + t * 32 * ROWB);
-        const s16x8 bl = *reinterpret_cast<const s16x8 *>(st + (bbase ^ 16u) + t * 32 * ROWB);
+        const s16x8 bl = *reinterpret_cast<const s16x8 *>(st + bbase1 + t * 32 * ROWB);
         // lo terms first, hi.hi last (the order of the other split-f16 kernels)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(al[i], bh, acc[i][t & 1]);
+        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(bh, al[i], acc[i][t & 1]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(ah[i], bl, acc[i][t & 1]);
+        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(bl, ah[i], acc[i][t & 1]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(ah[i], bh, acc[i][t & 1]);
+        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(bh, ah[i], acc[i][t & 1]);
         // one or two DMAs of the slice NS - 1 ahead behind each tap's MFMAs
         if (more) {
 #pragma unroll
@@ -188,142 +269,124 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    ISI_STAMP(4);
 
-    if (ISI_RESPAIR_ABLBIT(p, 2)) { if (acc[0][0][0] == 123.f && acc[1][1][3] == 7.f) p.out[0] = acc[0][1][5] + acc[1][0][2]; continue; }
-    // ---- hidden activations h = relu(acc + b1) -> this wave's LDS rows as pair planes [64 px][32] (A operand of GEMM 2)
-    __syncthreads();                     // every wave is done with the ring
-    constexpr int HROW = 128;            // bytes per pixel: 8 pieces of 16 B, piece 2 g + plane of hidden-channel group g
-    char *hb = smem + wave * 64 * HROW;  // [64 px][8 pieces of 16 B], piece = 2 g + plane, position ^ ((px >> 1) & 7)
+    // ---- hidden activations: lane (pixel = frow of tile i, kb) holds hidden channels 8 q + 4 kb + (r & 3), q = r >> 2.
+    // h = relu(acc + b1), split into the f16 pieces of 4 h: quads 2 s and 2 s + 1 are GEMM 2's B fragment of k-step s.
+    s16x8 hh[2][2], hl[2][2];   // [pixel tile][k-step]
     {
-      const float b1v = p.b1[frow];
+      float4 b1q[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) b1q[q] = *reinterpret_cast<const float4 *>(b1s + 8 * q + 4 * kb);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int px = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kb;
-          const float hpre = (acc[i][0][r] + acc[i][1][r]) * f16s::kUnscale + b1v;
-          const float hv = (hpre < 0.f ? 0.f : hpre) * f16s::kScaleA;   // NaN-propagating rectifier
-          const _Float16 hh = (_Float16)hv;
-          const _Float16 hl = (_Float16)(hv - (float)hh);
-          const int g = frow >> 3, e = frow & 7;   // hidden channel frow = 8 g + e
-          const int sw = (px >> 1) & 7;
-          *reinterpret_cast<_Float16 *>(hb + px * HROW + (((2 * g) ^ sw) << 4) + e * 2) = hh;
-          *reinterpret_cast<_Float16 *>(hb + px * HROW + (((2 * g + 1) ^ sw) << 4) + e * 2) = hl;
-        }
-    }
-    // (Tried instead of the LDS planes / transposes of this tail, both correct, neither faster: (a) everything in
-    // registers -- both GEMMs with swapped operands so that GEMM 1's accumulators are GEMM 2's operand fragments and
-    // GEMM 2's accumulators are stored as 16-byte pieces per lane, v_permlane32_swap for the skip and pair pieces as in
-    // conv_pair_f16.hip: 106 us against 104, every load / store instruction then touches 32 cache lines instead of 8 and
-    // the memory part of the tail grows from 21 to 31 us, which is what the saved LDS work gains; (b) registers for the
-    // hidden activations only, LDS transposes kept: 111 us, the 8-byte W2 fragment reads of the permuted k order cost
-    // more than the 2-byte LDS writes they replace.)
-    // W2 fragments come straight from memory (B operand of GEMM 2: row n = 32 j + frow, k-step s, k-block kb; 16 KB,
-    // L2-resident).  (Holding all of them, or all of a tile's skip pieces, in registers at once was measured: the
-    // kernel then needs 256 VGPRs with spills and runs 25 % slower.)
-    const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w2), 0, p.w2_bytes, 0x00020000);
-    const int ntile = C / 32;
-    const __amdgpu_buffer_rsrc_t rsi_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.in_bytes, 0x00020000);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    // ---- per 32-pixel tile and pair of 32-channel output tiles: GEMM 2 (K = 32), transpose through LDS, skip +
-    // bias + ReLU, 16-byte stores
-    constexpr int LDT = 68;                                                             // [32 px][64 + 4] floats
-    float *tb = reinterpret_cast<float *>(smem + NW * 64 * HROW) + wave * 32 * LDT;
-    const int gy = y0 + ry;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      s16x8 hh[2], hl[2];
-#pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) {
-        const int px = 32 * i + frow, sw = (px >> 1) & 7;
-        hh[s_] = *reinterpret_cast<const s16x8 *>(hb + px * HROW + (((2 * (2 * s_ + kb)) ^ sw) << 4));
-        hl[s_] = *reinterpret_cast<const s16x8 *>(hb + px * HROW + (((2 * (2 * s_ + kb) + 1) ^ sw) << 4));
-      }
-      for (int j0 = 0; j0 < ntile; j0 += 2) {
-        const int nj = ntile - j0 < 2 ? 1 : 2;               // uniform
-        for (int jj = 0; jj < nj; ++jj) {
-          const int j = j0 + jj;
-          f32x16 o2;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o2[r] = 0.f;
-#pragma unroll
-          for (int s_ = 0; s_ < 2; ++s_) {
-            const unsigned wo = (unsigned)((32 * j + frow) * 32 + (2 * s_ + kb) * 8) * 4u;
-            const i32x4 wh = __builtin_amdgcn_raw_buffer_load_b128(rs2, wo, 0, 0);
-            const i32x4 wl = __builtin_amdgcn_raw_buffer_load_b128(rs2, wo + 16u, 0, 0);
-            o2 = ISI_MH(hl[s_], wh, o2);
-            o2 = ISI_MH(hh[s_], wl, o2);
-            o2 = ISI_MH(hh[s_], wh, o2);
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) tb[((r & 3) + 8 * (r >> 2) + 4 * kb) * LDT + 32 * jj + frow] = o2[r] * f16s::kUnscale;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // lane -> (pixel, 8-channel group): GP groups per pixel in this pass, 64 / GP pixels per step
-        const int GP = nj * 4, PPP = 64 / GP;
-        const int g = lane % GP, psub = lane / GP;
-        const int ch0 = 32 * j0 + g * 8;                      // first of this lane's 8 channels
-        float b2v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b2v[e] = p.b2[ch0 + e];
-        for (int it = 0; it < 32 / PPP; ++it) {
-          const int px = it * PPP + psub;
-          const int gx = x0 + 32 * i + px;
-          const unsigned off = (gy < p.H && gx < p.W) ? (unsigned)(((b * p.H + gy) * p.W + gx) * C + ch0) * 4u : OOB_ST;
-          const unsigned roff = ISI_RESPAIR_ABLBIT(p, 4) ? OOB_ST : off;   // measurement: no skip re-read
-          const float4 v0 = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8);
-          const float4 v1 = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8 + 4);
-          // the skip connection: r's two pieces of this group
-          const i32x4 rh = __builtin_amdgcn_raw_buffer_load_b128(rsi_b, roff, 0, 0);
-          const i32x4 rl = __builtin_amdgcn_raw_buffer_load_b128(rsi_b, roff == OOB_ST ? OOB_ST : roff + 16u, 0, 0);
-          float4 r0, r1;
-          f16s::pair8_decode(__builtin_bit_cast(uint4, rh), __builtin_bit_cast(uint4, rl), r0, r1);
-          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          const float rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        for (int s_ = 0; s_ < 2; ++s_) {
+          float hv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float t_ = (v[e] + b2v[e]) + rr[e];
-            if (p.relu) t_ = t_ < 0.f ? 0.f : t_;
-            v[e] = t_;
+            const int r = 4 * (2 * s_ + (e >> 2)) + (e & 3);
+            const float4 bq = b1q[2 * s_ + (e >> 2)];
+            const float bv = (e & 3) == 0 ? bq.x : (e & 3) == 1 ? bq.y : (e & 3) == 2 ? bq.z : bq.w;
+            const float hpre = __builtin_fmaf(acc[i][0][r] + acc[i][1][r], f16s::kUnscale * f16s::kScaleA, bv);   // 4 h (b1 staged as 4 b1)
+            hv[e] = hpre < 0.f ? 0.f : hpre;            // NaN-propagating rectifier
+          }
+          uint4 ph, pl;
+          f16s::split2_scaled(hv[0], hv[1], ph.x, pl.x);
+          f16s::split2_scaled(hv[2], hv[3], ph.y, pl.y);
+          f16s::split2_scaled(hv[4], hv[5], ph.z, pl.z);
+          f16s::split2_scaled(hv[6], hv[7], ph.w, pl.w);
+          hh[i][s_] = __builtin_bit_cast(s16x8, ph);
+          hl[i][s_] = __builtin_bit_cast(s16x8, pl);
+        }
+    }
+    ISI_STAMP(5);
+    if (ISI_RESPAIR_ABLBIT(p, 2)) { if (hh[0][0][0] == 123 && hl[1][1][3] == 7) p.out[0] = 1.f; continue; }
+
+    // ---- GEMM 2 (K = 32, W2 fragments from LDS) and the epilogue, per output tile j and pixel tile i, all in
+    // registers: out = [relu](O + b2 + r), r decoded from the kept centre-tap pieces, 32-byte stores per lane.
+    const int gy = y0 + ry;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      s16x8 wh[2], wl[2];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        wh[s_] = *reinterpret_cast<const s16x8 *>(w2s + ((j * 2 + s_) * 2 + 0) * 1024 + lane * 16);
+        wl[s_] = *reinterpret_cast<const s16x8 *>(w2s + ((j * 2 + s_) * 2 + 1) * 1024 + lane * 16);
+      }
+      float4 b2q[2][2];   // [half h][first / second quad]: channels 32 j + 16 h + 8 kb + 0 .. 7
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        b2q[h][0] = *reinterpret_cast<const float4 *>(b2s + 32 * j + 16 * h + 8 * kb);
+        b2q[h][1] = *reinterpret_cast<const float4 *>(b2s + 32 * j + 16 * h + 8 * kb + 4);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f32x16 o2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o2[r] = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          o2 = ISI_MH(wh[s_], hl[i][s_], o2);
+          o2 = ISI_MH(wl[s_], hh[i][s_], o2);
+          o2 = ISI_MH(wh[s_], hh[i][s_], o2);
+        }
+        const int gx = x0 + 32 * i + frow;
+        const bool ok = gy < p.H && gx < p.W;
+        const unsigned o = (unsigned)(((b * p.H + gy) * p.W + gx) * C + 32 * j + 8 * kb) * 4u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {      // pair8 group 4 j + 2 h + kb: accumulator quads 2 h, 2 h + 1; skip of stage 2 j + h
+          // Everything in units of 4 x (the pair format's scale; powers of two commute with rounding):
+          //   x4 = relu(fma(O, 4 / 4096, 4 b2) + (hi + lo))        hi + lo = 4 r exactly (two 11-bit pieces)
+          // is 4 out with the reference's single rounding of (f(r) + b2) + r, and its f16 pieces hi' = f16(x4),
+          // lo' = f16(x4 - hi') are the pair format of out.  Mixed-precision fmas read the f16 pieces directly
+          // (v_fma_mix_f32): 7 VALU instructions per element instead of 14 (decode: 2 cvt + add + mul; encode: mul,
+          // cvt, cvt back, sub, cvt) -- the tail was VALU-bound (16-21 k cycles of an item's 63 k).
+          const uint4 sh = __builtin_bit_cast(uint4, skh[2 * j + h][i]), sl = __builtin_bit_cast(uint4, skl[2 * j + h][i]);
+          const unsigned shw[4] = {sh.x, sh.y, sh.z, sh.w}, slw[4] = {sl.x, sl.y, sl.z, sl.w};
+          const float bb[8] = {b2q[h][0].x, b2q[h][0].y, b2q[h][0].z, b2q[h][0].w, b2q[h][1].x, b2q[h][1].y, b2q[h][1].z, b2q[h][1].w};
+          float x4[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float r4 = (e & 1) ? f16s::mix_sum<1>(shw[e >> 1], slw[e >> 1]) : f16s::mix_sum<0>(shw[e >> 1], slw[e >> 1]);
+            float t_ = __builtin_fmaf(o2[8 * h + e], f16s::kUnscale * f16s::kScaleA, bb[e]) + r4;
+            if (p.relu) t_ = t_ < 0.f ? 0.f : t_;     // NaN-propagating rectifier
+            x4[e] = t_;
           }
           uint4 w0, w1;
           if (p.out_pair) {
-            f16s::pair8_encode(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), w0, w1);
+            f16s::split2_scaled(x4[0], x4[1], w0.x, w1.x);
+            f16s::split2_scaled(x4[2], x4[3], w0.y, w1.y);
+            f16s::split2_scaled(x4[4], x4[5], w0.z, w1.z);
+            f16s::split2_scaled(x4[6], x4[7], w0.w, w1.w);
           } else {
-            w0 = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
-                            __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
-            w1 = make_uint4(__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]),
-                            __builtin_bit_cast(unsigned, v[6]), __builtin_bit_cast(unsigned, v[7]));
+            constexpr float q = 1.f / f16s::kScaleA;
+            w0 = make_uint4(__builtin_bit_cast(unsigned, x4[0] * q), __builtin_bit_cast(unsigned, x4[1] * q),
+                            __builtin_bit_cast(unsigned, x4[2] * q), __builtin_bit_cast(unsigned, x4[3] * q));
+            w1 = make_uint4(__builtin_bit_cast(unsigned, x4[4] * q), __builtin_bit_cast(unsigned, x4[5] * q),
+                            __builtin_bit_cast(unsigned, x4[6] * q), __builtin_bit_cast(unsigned, x4[7] * q));
           }
-          const unsigned soff = ISI_RESPAIR_ABLBIT(p, 8) ? OOB_ST : off;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, soff, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, soff == OOB_ST ? OOB_ST : soff + 16u, 0, 0);
+          const unsigned off = (ok && !ISI_RESPAIR_ABLBIT(p, 8)) ? o + (unsigned)(64 * h) : OOB_ST;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_ST ? OOB_ST : off + 16u, 0, 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // the wave's transpose rows are reused by its next pass
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+      ISI_STAMP(8 + j);
     }
+    ISI_STAMP(7);
   }
 }
 #undef ISI_MH
 
-template <int TH>
+template <int TH, int NT>
 int launch_res_pair(const ResPairK &a, hipStream_t stream) {
   constexpr int HPIX = (TH + 2) * HWD;
   constexpr int A_ROWS = (HPIX + 15) / 16 * 16;
   constexpr int NS = TH >= 8 ? 2 : 3;
   constexpr size_t ring = (size_t)NS * (A_ROWS * ROWB + 9 * 32 * ROWB + 1024);
-  constexpr size_t tail = (size_t)TH * 64 * 128 + (size_t)TH * 32 * 68 * sizeof(float);   // h planes + transposes
-  constexpr size_t smem = ring > tail ? ring : tail;
+  constexpr size_t smem = ring + (size_t)NT * 4096 + (NT * 32 + 32) * sizeof(float);   // + W2 fragments, biases
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = resblock_pair_kernel<TH>;
+  auto kern = resblock_pair_kernel<TH, NT>;
   static DeviceOnce attr_set;
   if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -340,6 +403,15 @@ int launch_res_pair(const ResPairK &a, hipStream_t stream) {
 
 }  // namespace
 
+int resblock_pair_debug_stamps(long long *host, int n) {
+#ifdef ISI_MEASURE
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_respair_stamps), sizeof(long long) * (size_t)(n < 128 ? n : 128)) == hipSuccess ? 0 : -2;
+#else
+  (void)host; (void)n;
+  return unsupported("phase timestamps need a -DISI_MEASURE build");
+#endif
+}
+
 // Does the DMA kernel beat resblock_f32.hip on this launch?  Measured (tools/bench_resblock.py) at B = 64: yes at the
 // bottom resolution (32 x 128: 101 vs 114 us), no at the top one (16 x 64: 38 vs 32 us).  The two kernels accumulate in
 // different orders, so the choice depends on the per-sample geometry ONLY: a sample's result must not depend on the
@@ -353,7 +425,7 @@ bool resblock_pair_preferred(int B, int H, int W, int C, int R) {
 
 bool resblock_pair_ok(int C, int R) {
   const bool off = knobs().no_resblock_pair_kernel != 0;
-  return !off && R == 32 && C % 32 == 0 && C >= 32 && C <= 128;
+  return !off && R == 32 && (C == 64 || C == 128);     // instantiated channel counts (others: resblock_f32.hip)
 }
 
 // in / out: dense channels-last pair-format [B,H,W,C] (out: fp32 unless out_pair); w1_16 / w2_16: the blocked pair
@@ -377,10 +449,10 @@ int resblock_pair_f16(const float *in, const float *w1_16, const float *b1, cons
   const bool th8 = forced ? forced == 8 : tiles8 >= 256;
   if (th8) {
     a.tiles_y = (H + 7) / 8;
-    return launch_res_pair<8>(a, stream);
+    return C == 128 ? launch_res_pair<8, 4>(a, stream) : launch_res_pair<8, 2>(a, stream);
   }
   a.tiles_y = (H + 3) / 4;
-  return launch_res_pair<4>(a, stream);
+  return C == 128 ? launch_res_pair<4, 4>(a, stream) : launch_res_pair<4, 2>(a, stream);
 }
 
 }  // namespace isi

@@ -63,6 +63,33 @@ __device__ __forceinline__ void pair8_decode(const uint4 hi, const uint4 lo, flo
   b = make_float4(pair_value(hi.z & 0xffffu, lo.z & 0xffffu), pair_value(hi.z >> 16, lo.z >> 16),
                   pair_value(hi.w & 0xffffu, lo.w & 0xffffu), pair_value(hi.w >> 16, lo.w >> 16));
 }
+// ---- mixed-precision fmas on packed f16 pieces (v_fma_mix_f32; hipcc has no builtin and does not form it from
+// (float)h + (float)l): HALF selects the low / high f16 of the dwords.  Register-only VALU statements: no memory
+// counters, no MFMA operands involved (do not feed them an MFMA result directly: the compiler pads no hazard for asm).
+//   mix_sum<HALF>(hw, lw)   = f32(hw.half) + f32(lw.half)          (exact for the two pieces of a pair: 4 x)
+//   mix_diff<HALF>(hw, x)   = x - f32(hw.half)                     (exact: the residual the lo piece encodes)
+template <int HALF>
+__device__ __forceinline__ float mix_sum(const unsigned hw, const unsigned lw) {
+  float d;
+  if constexpr (HALF) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hw), "v"(lw));
+  else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(hw), "v"(lw));
+  return d;
+}
+template <int HALF>
+__device__ __forceinline__ float mix_diff(const unsigned hw, const float x) {
+  float d;
+  if constexpr (HALF) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hw), "v"(x));
+  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hw), "v"(x));
+  return d;
+}
+// two values already in units of the pair scale -> their packed hi and lo pieces (hi = f16(x), lo = f16(x - hi))
+__device__ __forceinline__ void split2_scaled(const float a, const float b, unsigned &hi, unsigned &lo) {
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  const f16x2 l = __builtin_convertvector(f32x2{mix_diff<0>(hi, a), mix_diff<1>(hi, b)}, f16x2);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
 // one element of a pair8 tensor (flat element index i): for the rare scalar accessor
 __device__ __forceinline__ float pair8_load(const unsigned short *base, const int64_t i) {
   const int64_t g = i >> 3;

@@ -197,6 +197,163 @@ __global__ __launch_bounds__(256) void convT_k4s2_small_kernel(const ConvTSmallA
   }
 }
 
+// ---- the same layer inside the split-f16 PAIR pipeline (round 3).  The exact-fp32 kernel above spends 45 us of its
+// 106 us (B = 64, 64 -> 2 at 64 x 256) on the fp32 matrix pipe (32 MFMAs of 16 passes per 32-pixel row tile) and
+// stages through registers; its input is the largest activation of the network.  Here the input arrives in the pair
+// format (the transposed convolution in front of it writes it), so
+//   * a tile's 6 x 34 halo pixels x 64 channels (256 bytes per pixel: 16 pieces) go global -> LDS by LDS-DMA in ONE
+//     stage -- no K loop, no staging registers, no conversion;  piece c of halo row r sits at position c ^ (r & 15)
+//     (swizzle on the DMA's source side: conflict-free ds_read_b128);
+//   * Y' = X W^T runs as three-term split-f16 products (12 MFMAs of 8 passes per row tile: 1/10 of the matrix time),
+//     the weight fragments straight from the blocked pair copy of the packed weight (ISI_CONV_W16);
+//   * Y' overlays the staged tile in LDS and the col2im gather + NCHW store are those of the kernel above.
+// 52 KB of LDS: three workgroups per CU hide the one memory round trip a workgroup makes.  The kernel is bound by
+// reading its input once (268 MB at B = 64).
+namespace {
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void dma16_small(const unsigned lds_addr, const unsigned voff, const i32x4 rsrc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");
+}
+}  // namespace
+
+template <int TH>
+__global__ __launch_bounds__(256) void convT_k4s2_small_pair_kernel(const ConvTSmallArgs p) {
+  constexpr int CIN = 64, ROWB = CIN * 4;       // bytes per pixel: 8 groups x {hi[8] | lo[8]}
+  constexpr int HPIX = (TH + 2) * HW_;          // halo pixels
+  constexpr int RT = (HPIX + 31) / 32;          // MFMA row tiles
+  constexpr int ROWS = RT * 32;
+  constexpr int TPW = (RT + 3) / 4;             // row tiles per wave
+  static_assert(HPIX % 4 == 0, "whole DMAs");
+  constexpr int NDMA = HPIX / 4;                // 1-KiB DMAs (4 rows each): only the halo pixels are staged (52 KB at
+                                                // TH = 4: three workgroups per CU); the last row tile's surplus rows
+                                                // re-read the last pixel and produce Y' rows nobody gathers
+  constexpr int PER = (NDMA + 3) / 4;           // per wave
+  constexpr int LDY = 33;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  char *xs = reinterpret_cast<char *>(sm);      // [ROWS][256 B]   (later: Y' [ROWS][LDY] floats)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware tile order: consecutive workgroup ids run on different XCDs (id % 8), each with its own L2; an XCD gets a
+  // contiguous range of tiles so that the halo pixels shared by neighbouring tiles are re-read from ITS L2, not from HBM
+  int x0, y0, b;
+  {
+    const int ntx = gridDim.x, nty = gridDim.y, nt = ntx * nty * (int)gridDim.z;
+    const int id = (int)blockIdx.x + ntx * ((int)blockIdx.y + nty * (int)blockIdx.z);
+    const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    x0 = (t % ntx) * TW;
+    y0 = ((t / ntx) % nty) * TH;
+    b = t / (ntx * nty);
+  }
+  const unsigned long long ib = (unsigned long long)p.in;
+  const i32x4 rsi = i32x4{(int)(unsigned)ib, (int)((unsigned)(ib >> 32) & 0xffffu), (int)p.in_bytes, 0x00020000};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)xs;
+
+  // ---- the whole tile in one stage: DMA d of this wave covers halo rows 4 d .. 4 d + 3
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int d = wave + 4 * q;                 // uniform
+    if (d < NDMA) {
+      const int row = 4 * d + (lane >> 4);
+      const int hy = row / HW_, hx = row - hy * HW_;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = row < HPIX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      const unsigned piece = (unsigned)(((lane & 15) ^ (row & 15)) * 16);
+      const unsigned vo = ok ? (unsigned)(b * p.sn + gy * p.sh + gx * p.sw) * 4u + piece : 0x7FFFFFF0u;
+      dma16_small(lds0 + (unsigned)(d * 1024), vo, rsi);
+    }
+  }
+  // weight fragments (B operand: column n = (ky, kx, co) = frow, k-block kb of k-step s): blocked pair copy, 64 x 4 B
+  // per row: group 2 s + kb at + 32 (2 s + kb), hi piece first
+  const int frow = lane & 31, kb = lane >> 5;
+  const int N = 16 * p.Cout;
+  s16x8 wh[4], wl[4];
+  {
+    const uint4 *w16 = reinterpret_cast<const uint4 *>(p.wn + (size_t)N * CIN);      // pair copy behind the packed weight
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+      uint4 h = make_uint4(0u, 0u, 0u, 0u), l = h;
+      if (frow < N) { h = w16[frow * 16 + 2 * (2 * s_ + kb)]; l = w16[frow * 16 + 2 * (2 * s_ + kb) + 1]; }
+      wh[s_] = __builtin_bit_cast(s16x8, h);
+      wl[s_] = __builtin_bit_cast(s16x8, l);
+    }
+  }
+  // (requested now: at the end it would be a dependent L2 round trip in front of the stores)
+  float bias_v[2];
+#pragma unroll
+  for (int co = 0; co < 2; ++co) bias_v[co] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- Y' = X W^T : wave w owns row tiles w, w + 4, ...; lo terms first, hi.hi last
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int rt = wave + 4 * i;
+    if (rt < RT) {  // wave-uniform
+      const int row = min(rt * 32 + frow, HPIX - 1);
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int pc = 2 * (2 * s_ + kb);
+        const s16x8 ah = *reinterpret_cast<const s16x8 *>(xs + row * ROWB + ((pc ^ (row & 15)) << 4));
+        const s16x8 al = *reinterpret_cast<const s16x8 *>(xs + row * ROWB + (((pc + 1) ^ (row & 15)) << 4));
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_, al), __builtin_bit_cast(f16x8_, wh[s_]), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_, ah), __builtin_bit_cast(f16x8_, wl[s_]), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_, ah), __builtin_bit_cast(f16x8_, wh[s_]), acc[i], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // every wave is done reading the tile: Y' overlays it
+  float *ys = sm;
+  constexpr float kUn = 1.f / (4.f * 1024.f);   // the pair scales (split_f16.h), undone exactly
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int rt = wave + 4 * i;
+    if (rt < RT) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ys[(rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb) * LDY + frow] = acc[i][r] * kUn;
+    }
+  }
+  __syncthreads();
+
+  // ---- col2im as a gather (as in the fp32 kernel): thread -> output column ox_l, rows oyb + 4 rr
+  const int ox_l = tid & 63, oyb = tid >> 6;
+  const int ox = 2 * x0 + ox_l;
+  int kxs[2], hcs[2];
+#pragma unroll
+  for (int jx = 0; jx < 2; ++jx) {
+    kxs[jx] = ((ox_l + 1) & 1) + 2 * jx;
+    hcs[jx] = (ox_l + 1 - kxs[jx]) / 2 + 1;
+  }
+  if (ox >= 2 * p.W) return;
+#pragma unroll
+  for (int rr = 0; rr < TH / 2; ++rr) {
+    const int oy_l = oyb + 4 * rr;
+    const int oy = 2 * y0 + oy_l;
+    if (oy >= 2 * p.H) continue;
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+      if (co >= p.Cout) continue;
+      float v = bias_v[co];
+#pragma unroll
+      for (int jy = 0; jy < 2; ++jy) {
+        const int ky = ((oy_l + 1) & 1) + 2 * jy;
+        const int hr = (oy_l + 1 - ky) / 2 + 1;
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx)
+          v += ys[(hr * HW_ + hcs[jx]) * LDY + (ky * 4 + kxs[jx]) * p.Cout + co];
+      }
+      if (p.relu) v = v < 0.f ? 0.f : v;   // like torch.relu, NaN stays NaN
+      p.out[b * p.on + co * p.oc + oy * p.oh + ox * p.ow] = v;
+    }
+  }
+}
+
 __global__ void pack_convT_small_kernel(const float *__restrict__ w, float *__restrict__ out, int Cin,
                                         int Cout) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,6 +367,8 @@ __global__ void pack_convT_small_kernel(const float *__restrict__ w, float *__re
 bool convT_small_applicable(int Cin, int Cout) {
   return Cout >= 1 && Cout <= 4 && (Cin == 32 || Cin == 64);
 }
+// the pair-pipeline form: 64 pair-format input channels, 16 Cout <= 32 columns of Y'
+bool convT_small_pair_ok(int Cin, int Cout) { return Cin == 64 && Cout >= 1 && Cout <= 2; }
 
 int pack_convT_small_weight_f32(const float *w, float *packed, int Cin, int Cout, hipStream_t stream) {
   const int total = 16 * Cin * Cout;
@@ -240,6 +399,43 @@ static int dispatch_small(const ConvTSmallArgs &a, int B, hipStream_t stream) {
   const bool one = 16 * a.Cout <= 32;
   if (a.Cin == 32) return one ? launch_small<TH, 1, 32>(a, B, stream) : launch_small<TH, 2, 32>(a, B, stream);
   return one ? launch_small<TH, 1, 64>(a, B, stream) : launch_small<TH, 2, 64>(a, B, stream);
+}
+
+template <int TH>
+static int launch_small_pair(const ConvTSmallArgs &a, int B, hipStream_t stream) {
+  auto kern = convT_k4s2_small_pair_kernel<TH>;
+  constexpr int HPIX = (TH + 2) * HW_, ROWS = ((HPIX + 31) / 32) * 32;
+  constexpr size_t smem = (size_t)HPIX * 256;   // the staged tile; Y' [ROWS][33] floats overlays it
+  static_assert((size_t)ROWS * 33 * 4 <= smem, "Y' overlay");
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(convT_small_pair)");
+    attr_set.mark();
+  }
+  if ((a.H + TH - 1) / TH > 65535) return unsupported("convT_small: grid too large");
+  const double M = (double)B * a.H * a.W;
+  prof::Scope scope(prof::K_CONVT_SMALL, 2.0 * M * 16 * a.Cin * a.Cout,
+                    4.0 * (M * a.Cin + 4.0 * M * a.Cout + 16.0 * a.Cin * a.Cout), stream);
+  ISI_PROF_LAUNCH(scope, kern, dim3((a.W + TW - 1) / TW, (a.H + TH - 1) / TH, B), dim3(256), smem, stream, a);
+  return check_launch("convT_k4s2_small_pair");
+}
+
+// pair-format input (dense channels-last [B,H,W,64]), fp32 output with arbitrary strides; wn = packed weight followed by
+// its blocked pair copy (pack_convT_k4s2_weight + ISI_CONV_W16)
+int convT_k4s2_small_pair_f16(const float *in, const float *wn, const float *bias, float *out, int B, int H, int W,
+                              int Cin, int Cout, int on, int oc, int oh, int ow, int relu, hipStream_t stream) {
+  if (!convT_small_pair_ok(Cin, Cout)) return unsupported("convT_small_pair: need Cin == 64 and Cout <= 2");
+  if (B > 65535) return unsupported("convT_small: grid too large");
+  const int64_t in_elems = (int64_t)B * H * W * Cin;
+  if (in_elems * 4 >= 0x70000000ll) return unsupported("convT_small_pair: tensor spans 1.75 GiB or more");
+  ConvTSmallArgs a;
+  a.in = in; a.wn = wn; a.bias = bias; a.out = out;
+  a.in_bytes = (unsigned)(in_elems * 4);
+  a.sn = H * W * Cin; a.sc = 1; a.sh = W * Cin; a.sw = Cin; a.vec = 1;
+  a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+  a.on = on; a.oc = oc; a.oh = oh; a.ow = ow;
+  return launch_small_pair<4>(a, B, stream);
 }
 
 // src / dst strides arbitrary (32-bit range checked by the caller); in_elems = extent of the source.

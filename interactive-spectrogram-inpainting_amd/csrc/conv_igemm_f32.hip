@@ -740,7 +740,19 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   const int64_t eo = extent(B, dst->sn, Cout, dst->sc, 2 * H, dst->sh, 2 * W, dst->sw);
   if (e0 > kMaxElems || eo > kMaxElems) return unsupported("convT: a tensor spans 4 GiB or more");
   if (convT_small_applicable(s->C, Cout)) {
-    if (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_OUT_PAIR)) return unsupported("convT: pair formats on the few-channel kernel");
+    if (relu & ISI_CONV_IN0_PAIR) {
+      // pair-format input: the LDS-DMA form of the few-channel kernel (dense channels-last source, fp32 output)
+      const int Cin = s->C;
+      const bool dense_in = s->sc == 1 && (W == 1 || s->sw == Cin) && (H == 1 || s->sh == (int64_t)W * Cin) &&
+                            (B == 1 || s->sn == (int64_t)H * W * Cin);
+      if ((relu & ISI_CONV_OUT_PAIR) || !(relu & ISI_CONV_W16) || split_mode(relu) != 3 || !dense_in ||
+          !convT_small_pair_ok(Cin, Cout) || !aligned16(s->ptr) || !aligned16(packed_w))
+        return unsupported("convT: pair-format input on the few-channel kernel needs ISI_CONV_F16X3 | ISI_CONV_W16, "
+                           "64 dense channels-last input channels, Cout <= 2 and an fp32 output");
+      return convT_k4s2_small_pair_f16(s->ptr, packed_w, bias, dst->ptr, B, H, W, Cin, Cout, (int)dst->sn, (int)dst->sc,
+                                       (int)dst->sh, (int)dst->sw, relu & ISI_CONV_RELU, stream);
+    }
+    if (relu & ISI_CONV_OUT_PAIR) return unsupported("convT: pair-format output on the few-channel kernel");
     // few output channels: GEMM + col2im gather kernel (weights were packed in its layout)
     return convT_k4s2_small_f32(s->ptr, packed_w, bias, dst->ptr, B, H, W, s->C, Cout, e0, (int)s->sn,
                                 (int)s->sc, (int)s->sh, (int)s->sw, (int)dst->sn, (int)dst->sc,

@@ -54,6 +54,9 @@ int resblock_pair_f16(const float *in, const float *w1_16, const float *b1, cons
 int resblock_f32(const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
                  float *out, int B, int H, int W, int C, int R, int relu, hipStream_t stream);
 bool convT_small_applicable(int Cin, int Cout);
+bool convT_small_pair_ok(int Cin, int Cout);
+int convT_k4s2_small_pair_f16(const float *in, const float *wn, const float *bias, float *out, int B, int H, int W,
+                              int Cin, int Cout, int on, int oc, int oh, int ow, int relu, hipStream_t stream);
 int pack_convT_small_weight_f32(const float *w, float *packed, int Cin, int Cout, hipStream_t stream);
 int convT_k4s2_small_f32(const float *in, const float *wk, const float *bias, float *out, int B, int H,
                          int W, int Cin, int Cout, int64_t in_elems, int sn, int sc, int sh, int sw, int on,
@@ -126,6 +129,7 @@ int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t 
                    int32_t *counts, float *sse_part, int64_t N, int D, int K, int flags, hipStream_t stream);
 int vq_num_partials(int64_t N);
 bool vq_conv1x1_fusable(int C0, int C1, int D, int K);
+int vq_debug_stamps(long long *host, int n);
 int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
                            const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,
                            float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts = false);

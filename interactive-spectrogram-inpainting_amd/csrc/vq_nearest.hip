@@ -403,6 +403,14 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
 #else
 #define ISI_VQ_DBGBIT(p, b) (0)     // the ablations are not compiled into the default build
 #endif
+// phase timestamps (-DISI_MEASURE builds; tools/stamps_vq.py): workgroup 8, waves 0 and 4, its second iteration
+#ifdef ISI_MEASURE
+__device__ long long g_vq_stamps[128];
+#define ISI_VQ_STAMP(i_) do { if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && it == (int64_t)blockIdx.x + (int64_t)gridDim.x) \
+    g_vq_stamps[(wave >> 2) * 64 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ISI_VQ_STAMP(i_) do { } while (0)
+#endif
 struct VqFusedArgs {
   const float *in0, *in1, *w16, *bias, *codes, *e2;
   const float *wfrag;                    // fragment-major copy of w16 (vq_weight_fragments_kernel)
@@ -477,6 +485,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
   for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
     const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
     const bool valid = n < p.N;
+    ISI_VQ_STAMP(0);
     // ---- 1x1 convolution into this pixel's dims
     f32x16 zt[2];
 #pragma unroll
@@ -520,6 +529,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
     }
     }
 #undef ISI_VQ_MF
+    ISI_VQ_STAMP(1);
     float4 zq[NQ], ew[NQ];
     // bias of this lane's dims: quad 2 j + half of tile t = j / 4 -> channels 8 j + 4 half + e.  Re-read per tile (L2):
     // kept across the loop the 32 registers pushed the prefetching variants into scratch (the offset is made opaque so
@@ -538,16 +548,19 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
       if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
       zq[j] = v;
     }
+    ISI_VQ_STAMP(2);
     // ---- search (candidates on the f16 pipe, decision in fp32; shared with the stand-alone kernel)
     VqCand cand{0.f, 1.f, (int)(n & 255), (int)(n & 255) + 256};
     if (!ISI_VQ_DBGBIT(p, 1)) cand = vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half);
     int besti = cand.i1;
+    ISI_VQ_STAMP(3);
     if (!ISI_VQ_DBGBIT(p, 4)) besti = vq_decide_f32(cand, e2, K, p.codes, zq, half, ew);
     else {
 #pragma unroll
       for (int j = 0; j < NQ; ++j) ew[j] = zq[j];
     }
     if (ISI_VQ_DBGBIT(p, 8)) { sse += zq[0].x + ew[3].y; continue; }
+    ISI_VQ_STAMP(4);
     const bool lost = besti < 0;
     if (valid && lost) {
 #pragma unroll
@@ -589,6 +602,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
         atomicAdd(&hist[besti], 1);
       }
     }
+    ISI_VQ_STAMP(5);
   }
 
   __syncthreads();
@@ -724,6 +738,15 @@ bool vq_conv1x1_fusable(int C0, int C1, int D, int K) {
 }
 
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D) { return (size_t)D * round_up((size_t)(C0 + C1), kBK); }
+
+int vq_debug_stamps(long long *host, int n) {
+#ifdef ISI_MEASURE
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_vq_stamps), sizeof(long long) * (size_t)(n < 128 ? n : 128)) == hipSuccess ? 0 : -2;
+#else
+  (void)host; (void)n;
+  return unsupported("phase timestamps need a -DISI_MEASURE build");
+#endif
+}
 
 int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
                            const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,

@@ -198,8 +198,15 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
                 bool pairs, bool final_pair, hipStream_t st) {
   Act cur{s0, d.conv3.Cout, H, W};
   bool stack_pairs = false;
-  // format in which up[i] wants its input: fp32 for the few-channel kernel
-  auto up_reads_pair = [&](int i, int Cin) { return pairs && !convT_small_applicable(Cin, d.up[i].Cout); };
+  // format in which up[i] wants its input: pairs for the implicit-GEMM kernels and for the pair form of the
+  // few-channel kernel (64 input channels, <= 2 outputs, fp32 result: the last layer of the default model); fp32 for
+  // its exact-fp32 form
+  auto up_reads_pair = [&](int i, int Cin) {
+    if (!pairs) return false;
+    if (!convT_small_applicable(Cin, d.up[i].Cout)) return true;
+    const bool last = (i == d.n_up - 1);
+    return convT_small_pair_ok(Cin, d.up[i].Cout) && last && !final_pair && (pf & ISI_CONV_F16X3) && (pf & ISI_CONV_W16);
+  };
   {
     isi_dst dd = dst_nhwc(cur.p, cur.C, H, W);
     stack_pairs = res_stack_in_pairs(pairs, d.n_res, d.res3, B, H, W, cur.C);

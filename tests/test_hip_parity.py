@@ -92,6 +92,37 @@ def test_last_layer_transposed_conv_kernel(cin, cout, B, H, W):
         _close(layer.run(xin, relu=True), want.clamp_min(0).numpy(), 1e-5, f"convT {cin}->{cout}+relu")
 
 
+@pytest.mark.parametrize("cout,B,H,W", [(2, 2, 9, 37), (1, 1, 4, 32), (2, 1, 5, 70), (2, 3, 16, 64), (2, 1, 1, 1)])
+def test_last_layer_transposed_conv_pair_kernel(cout, B, H, W):
+    """The last decoder layer inside the pair pipeline (convT_k4s2_small_pair_kernel: pair-format input staged by
+    LDS-DMA in one stage, three-term split-f16 products, col2im gather; csrc/convT_small_f32.hip): against torch's
+    ConvTranspose2d in float64 on the pair-rounded input, NCHW and channels-last outputs, and against the exact-fp32
+    kernel (reference vqvae/encoder_decoder.py:204-207)."""
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    cin = 64
+    g = torch.Generator().manual_seed(3 * H + W + cout)
+    w = torch.randn(cin, cout, 4, 4, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g))
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    xp = _ops.pair_encode(xd)
+    pt = _ops.pack_convT_weight(w.to(dev), with_f16=True)
+    ref = torch.nn.functional.conv_transpose2d(_ops.pair_decode(xp).cpu().double(), w.double(), bias.double(), stride=2, padding=1)
+    for relu in (False, True):
+        want = torch.relu(ref) if relu else ref
+        for out_nchw in (True, False):
+            got = _ops.conv_transpose2d_k4s2(xp, pt, bias.to(dev), cout, relu=relu, out_nchw=out_nchw, bf16x3=4,
+                                             extra_flags=_ops.PAIR_IN0)
+            assert got.shape == (B, cout, 2 * H, 2 * W)
+            err = ((got.cpu().double() - want).abs().max() / want.abs().max()).item()
+            assert err < 2e-6, f"relu={relu} nchw={out_nchw}: {err:.2e}"
+    exact = _ops.conv_transpose2d_k4s2(xd, pt, bias.to(dev), cout, relu=True, out_nchw=True)
+    assert (exact - got).abs().max() <= 2.0 ** -20 * got.abs().max()
+    with pytest.raises(_hip.HipLibraryError):       # pair-format OUTPUT is not built for the few-channel layer
+        _ops.conv_transpose2d_k4s2(xp, pt, bias.to(dev), cout, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)
+
+
 def test_resblock_against_reference(golden_dir):
     from interactive_spectrogram_inpainting.vqvae.encoder_decoder import RosinalityResBlock
     z = np.load(golden_dir / "resblock.npz")

@@ -50,5 +50,27 @@ def main():
         print(f"{name:44s} " + "   ".join(f"{k_} {v:7.1f} us ({flops / v / 1e6 / 833.3:.3f})" for k_, v in t.items()))
 
 
+
+
+def last_layer():
+    """the few-channel last layer 64 -> 2 at 64 x 256 (B = 64): exact-fp32 kernel on an fp32 input against the
+    pair-pipeline form (LDS-DMA, split-f16 products)"""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    B, cin, cout, H, W = 64, 64, 2, 64, 256
+    x = torch.relu(torch.randn(B, H, W, cin, generator=g)).to(dev)
+    xd = x.permute(0, 3, 1, 2)
+    xp = _ops.pair_encode(x).permute(0, 3, 1, 2)
+    pw = _ops.pack_convT_weight((torch.randn(cin, cout, 4, 4, generator=g) * 0.05).to(dev), with_f16=True)
+    f32 = lambda: _ops.conv_transpose2d_k4s2(xd, pw, None, cout, relu=False, out_nchw=True)
+    pair = lambda: _ops.conv_transpose2d_k4s2(xp, pw, None, cout, relu=False, out_nchw=True, bf16x3=4, extra_flags=_ops.PAIR_IN0)
+    r = {"fp32": [], "pair": []}
+    for _ in range(3):
+        r["fp32"].append(timed(f32)); r["pair"].append(timed(pair))
+    gb = (B * H * W * cin * 4 + B * 4 * H * W * cout * 4) / 1e9
+    print("last layer convT 64->2 @64x256:  " + "   ".join(f"{k} {min(v):7.1f} us ({gb / min(v) * 1e6 / 1e3:.2f} TB/s)" for k, v in r.items()))
+
+
 if __name__ == "__main__":
     main()
+    last_layer()

@@ -3,6 +3,7 @@
 import ctypes as C, os, pathlib, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
+os.environ.setdefault("ISI_HIP_LIBRARY", str(ROOT / "interactive-spectrogram-inpainting_amd" / "lib_measure" / "libisi_hip.so"))   # -DISI_MEASURE build
 import torch
 from interactive_spectrogram_inpainting import _hip
 from interactive_spectrogram_inpainting.vqvae import _ops
@@ -14,14 +15,14 @@ xp = _ops.pair_encode(x).permute(0, 3, 1, 2)
 pw = _ops.pack_conv_weight((torch.randn(cout, cin, k, k, generator=g) * 0.05).to(dev), with_f16=True)
 run = lambda: _ops.conv2d(xp, pw, None, cout, k, s, 1, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)
 for _ in range(3): run()
-os.environ["ISI_CONV_ABLATE"] = "32"
+_hip.check(_hip.lib().isi_knob_set(b"ISI_CONV_ABLATE", 32), "isi_knob_set")
 for _ in range(3): run()
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); run(); b.record(); torch.cuda.synchronize()
 wall_us = a.elapsed_time(b) * 1e3
 buf = (C.c_longlong * 256)()
-L = C.CDLL(str(ROOT / "interactive-spectrogram-inpainting_amd" / "lib" / "libisi_hip.so"))
+L = _hip.lib()
 assert L.isi_debug_conv_pair_stamps(buf, 256) == 0
 print(f"instrumented launch: {wall_us:.1f} us wall; workgroup 8 lived {buf[127] - buf[126]} cycles -> {(buf[127] - buf[126]) / wall_us / 1e3:.2f} GHz if it spanned the launch")
 base = buf[0]

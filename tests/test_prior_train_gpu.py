@@ -233,11 +233,12 @@ FULL = dict(COMMON, n_class=512, channel=256, n_block=4, n_res_block=4, res_chan
 
 @pytest.mark.parametrize("level,linear_precision,size", [
     ("top", "f32", "toy"), ("top", "bf16x6", "toy"), ("bottom", "f32", "toy"), ("bottom", "bf16x6", "toy"),
-    ("top", "f32", "full"), ("top", "bf16x6", "full")])
+    ("top", "f32", "full"), ("top", "bf16x6", "full"), ("bottom", "bf16x6", "full")])
 def test_prior_training_step_gradients_against_spec(level, linear_precision, size, monkeypatch):
     """loss.backward() of one training batch (train_autoregressive_model.py:178-257 semantics, dropout 0):
     every parameter gradient of the HIP path against torch autograd of the CPU specification.  size 'full' =
-    BASELINE config 4's top prior (seq 1025, d_model 512, 6 + 8 layers) at B = 1."""
+    BASELINE config 4's priors at B = 1: top (seq 1025, d_model 512, 6 + 8 layers) and bottom ([64,64] map: 4100
+    target rows, 4 tokens per event, 4100 x 4100 causal self-attention and 4100 x 1025 cross-attention)."""
     from oracle import prior_oracle as P_
     from interactive_spectrogram_inpainting.priors import _ops
     from interactive_spectrogram_inpainting.priors.transformer import (
@@ -389,12 +390,13 @@ def test_linear_precisions_against_fp64():
         _ops.LINEAR_PRECISION = saved
 
 
-@pytest.mark.parametrize("Sq,Sk,Cq,Ck,mode", [(1025, 1025, 1, 1, 1), (1025, 1025, 1, 1, 2), (4100, 1025, 4, 1, 0)])
+@pytest.mark.parametrize("Sq,Sk,Cq,Ck,mode", [(1025, 1025, 1, 1, 1), (1025, 1025, 1, 1, 2), (4100, 1025, 4, 1, 0),
+                                              (4100, 4100, 4, 4, 1)])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_rel_attention_backward_at_baseline_sizes(Sq, Sk, Cq, Ck, mode, precision, monkeypatch):
-    """BASELINE config 4 shapes (head_dim 64, 8 heads): S = 1025 causal / anti-causal self-attention and the bottom
-    prior's 4100 x 1025 cross-attention with 4 tokens per event: forward and every gradient against autograd of the
-    specification."""
+    """BASELINE config 4 shapes (head_dim 64, 8 heads): S = 1025 causal / anti-causal self-attention, the bottom
+    prior's 4100 x 1025 cross-attention with 4 tokens per event and its 4100 x 4100 causal self-attention: forward and
+    every gradient against autograd of the specification."""
     from oracle import prior_oracle as P
     from interactive_spectrogram_inpainting.priors import _ops
     from interactive_spectrogram_inpainting.priors._train import RelAttentionFn

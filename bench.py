@@ -169,16 +169,36 @@ def _prior_sampling(device):
         class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device).eval()
     cls = {"pitch": torch.tensor([24]), "instrument_family_str": torch.tensor([0])}
     out = {}
-    for B in (1, 8):
-        kw = dict(class_conditioning=cls, top_p_sampling_p=0.8)
-        S.sample_model(m, device, B, [32, 32], 1.0, generator=torch.Generator().manual_seed(0), **kw)
+
+    def run(B, **kw):
+        S.sample_model(m, device, B, [32, 32], 1.0, generator=torch.Generator().manual_seed(0), class_conditioning=cls, **kw)
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        S.sample_model(m, device, B, [32, 32], 1.0, generator=torch.Generator().manual_seed(1), **kw)
+        S.sample_model(m, device, B, [32, 32], 1.0, generator=torch.Generator().manual_seed(1), class_conditioning=cls, **kw)
         torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
+        return time.perf_counter() - t0
+
+    for B in (1, 8):
+        dt = run(B, top_p_sampling_p=0.8)                  # Inference.ipynb cell 43 samples with top-p 0.8
         out[f"codes_per_s_B{B}"] = round(B * 1024 / dt, 1)
         out[f"ms_per_codemap_B{B}"] = round(dt * 1e3, 1)
+    dt_plain = run(1)                                      # also top-p 0 / top-k 0 (no filtering)
+    out["codes_per_s_B1_top_p0_top_k0"] = round(1024 / dt_plain, 1)
+    # roofline of the decode loop at B = 1: bytes a token's 8 decoder layers + logits head must stream -- the layer
+    # weights (self-attention in / out projections, cross-attention q / out projections, the two feed-forward
+    # matrices; fp32), the logits matrix, and the cached keys / values it attends over (self: 2 p d per layer at
+    # position p, 512 on average; cross: the 1025 memory rows' keys / values) -- against HBM's peak.  The weights fit
+    # the 256 MB Infinity Cache, so the loop is really a chain of dependent launches; the
+    # fraction says how far a batch-1 token is from streaming its bytes at memory speed.
+    d, ff, L = m.d_model, 2048, m.conditional_model_num_decoder_layers
+    w_bytes = 4 * (L * (3 * d * d + d * d + d * d + d * d + 2 * d * ff) + d * m.n_class_target)
+    kv_bytes = 4 * L * (2 * 512 * d + 2 * 1025 * d)
+    per_token = w_bytes + kv_bytes
+    t_tok = 1.0 / out["codes_per_s_B1"]
+    out["roofline"] = {"bound": "hbm", "achieved": round(per_token / t_tok / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(per_token / t_tok / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                       "algorithmic_bytes_per_token": per_token, "us_per_token": round(t_tok * 1e6, 1),
+                       "note": "batch-1 decode: weights " + str(w_bytes) + " B + average KV " + str(kv_bytes) + " B per token"}
     # CPU baseline with the reference's loop semantics (sample.py:268-283: one FULL decoder pass per
     # sampled token, encoder memory cached), oracle layers on the host cores, bounded to 3 tokens
     from oracle import prior_oracle as P
@@ -188,6 +208,9 @@ def _prior_sampling(device):
     src, tgt = m.to_sequences(code.to(device), code.to(device), class_conditioning=clsd)
     s_, t_ = src.cpu().transpose(0, 1), tgt.cpu().transpose(0, 1)
     H, E = m.conditional_model_nhead, m.source_num_events_with_start_symbol
+    _, per_socket, _ = _host_cpu()
+    before = torch.get_num_threads()
+    torch.set_num_threads(per_socket or before)            # one socket's physical cores, like the forward's baseline
     with torch.no_grad():
         memory = P.encoder(s_, sd, "transformer.encoder.", m.conditional_model_num_encoder_layers, H, 1, E,
                            P.causal_mask(s_.shape[0]).t())
@@ -201,6 +224,7 @@ def _prior_sampling(device):
         out["cpu_baseline"] = {"value": round(n_tok / (time.perf_counter() - t0), 3), "unit": "codes/s",
                                "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{n_tok} tokens, one full decoder pass each (reference loop, oracle/prior_oracle.py)"}
+    torch.set_num_threads(before)
     out["unit"] = "codes/s"
     out["config"] = "SelfAttentiveVQTransformer shape [32,32] (1024 tokens + start), d_model 512, 6+8 layers, 8 heads, fp32"
     return out
@@ -540,9 +564,8 @@ def main():
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH doubled as the
         # gfx950 guide prescribes; tools/pmc_traffic.py): a measured constant, not re-measured here
         traffic = None
-        traffic_file = "profiles/r02_pmc_hbm_traffic.json"
-        if not (ROOT / traffic_file).exists():
-            traffic_file = "profiles/r01_pmc_hbm_traffic.json"
+        traffic_file = next((f for f in ("profiles/r03_pmc_hbm_traffic.json", "profiles/r02_pmc_hbm_traffic.json",
+                                         "profiles/r01_pmc_hbm_traffic.json") if (ROOT / f).exists()), "profiles/none")
         try:
             if args.batch != 64:
                 raise ValueError("the committed PMC pass was taken at batch 64")
@@ -555,7 +578,7 @@ def main():
             tot_b = tot_n = 0.0
             for name, d in pmc.items():
                 mine = ("conv_igemm_f32_kernel" in name and any(t in name for t in want)) or \
-                       ("f16x3" in dom["kernel"] and "conv_pair_kernel<" in name)
+                       ("f16x3" in dom["kernel"] and ("conv_pair_kernel<" in name or "convT_pair_kernel<" in name))
                 if mine and "hbm_bytes_per_launch_corrected" in d:
                     tot_b += d["hbm_bytes_per_launch_corrected"] * d["dispatches"]
                     tot_n += d["dispatches"]

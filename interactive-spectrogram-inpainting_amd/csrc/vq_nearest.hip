@@ -172,19 +172,20 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
 // convolutions (|z| < 16384, |e| < 64).  Beyond: a vector out of range has NaN distances to every code -> its index
 // is -1; a CODE out of range makes every index -1 (vq_fill_planes).
 typedef f16s::f16x8 vq_f16x8;
+constexpr float kVqNone = 0x1p127f, kVqPad = 0x1p100f;   // finite sentinels (low mantissa bits zero: see vq_candidates_f16)
 constexpr float kVqScaleZ = f16s::kScaleA, kVqScaleE = f16s::kScaleB, kVqUnscale = f16s::kUnscale;
 __device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 
 // fills the two planes (and |e|^2, histogram) of a workgroup.  A code with a component beyond the f16 pieces' range
 // (|e| * 2^10 rounds to inf, or is not finite) would have NaN distances and silently never be a candidate: such a
-// code gets zero pieces and |e|^2 = -inf instead, which makes it the "best" candidate of EVERY vector with distance
-// -inf -- vq_decide_f32 turns that into index -1 (and a NaN diff): an out-of-range codebook is loud.
+// code gets zero pieces and |e|^2 = -1e30 instead, which makes it the "best" candidate of EVERY vector -- vq_decide_f32
+// turns that into index -1 (and a NaN diff): an out-of-range codebook is loud.
 // (Contains a barrier: call from uniform control flow.)
 __device__ __forceinline__ void vq_fill_planes(unsigned short *cbh, unsigned short *cbl, float *e2, int *hist,
                                                const float *__restrict__ codes, const float *__restrict__ e2g, int K,
                                                int Kp, int tid) {
   constexpr int D = 64;
-  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : INFINITY; hist[i] = 0; }
+  for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : kVqPad; hist[i] = 0; }   // (finite: see vq_candidates_f16)
   __syncthreads();
   for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
     const int k = i >> 4, qd = i & 15;
@@ -196,7 +197,7 @@ __device__ __forceinline__ void vq_fill_planes(unsigned short *cbh, unsigned sho
     if (bad) {
       hi = make_uint2(0u, 0u);
       lo = make_uint2(0u, 0u);
-      e2[k] = -INFINITY;        // every writer of e2[k] in this loop writes this value
+      e2[k] = -kVqPad;          // every writer of e2[k] in this loop writes this value
     }
     const int slot = 2 * (qd >> 2) + (qd & 1), second = (qd >> 1) & 1;
     const int wo = k * D + ((slot ^ ((k >> 1) & 7)) * 8) + second * 4;
@@ -209,10 +210,24 @@ __device__ __forceinline__ float vq_quad_dot(const float4 a, const float4 b) {
   return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
 }
 
-// The two best candidates of this lane pair's vector by split-f16 distance.  Candidates are ranked by
-// s_k = |e_k|^2 - 2 z.e_k (|z|^2 is common to all codes of a vector); per value: one fma, two compares, v_min, v_med3
-// and three selects, the code number carried as the wave-uniform part (the lane's + 4 half is added at the end).
-struct VqCand { float b1, b2; int i1, i2; };
+// The two best candidates of this lane pair's vector by split-f16 distance.
+//
+// Round 3.  The search was bound by its vector instructions (8 per distance: fma, two compares, min, med3, three
+// selects; 128 per 32-code tile and wave against 12 MFMAs -- tools/stamps_vq.py: 23-28 k cycles per 32-vector tile
+// where the matrix work is 6 k).  Now, per 32-code tile, the lane's 16 distances are ranked with their register
+// number r PACKED into the four low mantissa bits -- key = (D & ~15) | r: v_and_or_b32, then v_med3 / v_min keep the
+// tile's two smallest keys: 4 instructions per distance -- and only those two enter the exact (value, code number)
+// update.  For the keys to order like the distances D must be positive:
+//     D = |z|^2 (1 + 2^-20) - 2 z.e + |e|^2      (the squared distance plus a margin above its own rounding)
+// which costs nothing: the accumulators start from -|z|^2 (1 + 2^-20) / (2 u) instead of zero.  The four truncated
+// bits are 2^-19 of D, below the 2e-6 at which two codes count as a near-tie of the reference's own fp32 formula; the
+// winner is still decided in exact fp32 between the two candidates (vq_decide_f32).  Equal distances (duplicate
+// codes) keep the lower code number: lower r = lower code within a lane, `<` across tiles, (value, index) order
+// between the two lane halves.
+// Sentinels (finite, so that packing never makes a NaN; powers of two, so that stripping the packed bits leaves them
+// unchanged): padding rows |e|^2 = +2^100, a code beyond the f16 range
+// -2^100 (vq_fill_planes: it wins everywhere and vq_decide_f32 answers -1), "no candidate" kVqNone = 2^127.
+struct VqCand { float b1, b2; int i1, i2; float x2; };
 __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, const unsigned short *cbl, const float *e2,
                                                     int Kp, const float4 (&zq)[8], int col, int half) {
   constexpr int D = 64;
@@ -225,37 +240,61 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
     zh[s] = __builtin_bit_cast(s16x8v, make_uint4(h0.x, h0.y, h1.x, h1.y));
     zl[s] = __builtin_bit_cast(s16x8v, make_uint4(l0.x, l0.y, l1.x, l1.y));
   }
-  float b1 = INFINITY, b2 = INFINITY;
+  float x2p = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x2p += zq[j].x * zq[j].x + zq[j].y * zq[j].y + zq[j].z * zq[j].z + zq[j].w * zq[j].w;
+  const float x2 = x2p + __shfl_xor(x2p, 32);
+  const float ainit = -x2 * ((1.f + 0x1p-20f) * 0.5f / kVqUnscale);
+  float b1 = kVqNone, b2 = kVqNone;
   int i1 = 0, i2 = 0;
-  for (int kt = 0; kt < Kp; kt += 32) {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int row = kt + col;
-    const int sw = (row >> 1) & 7;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int off = row * D + (((2 * s + half) ^ sw) * 8);
-      const s16x8v ah = *reinterpret_cast<const s16x8v *>(cbh + off);
-      const s16x8v al = *reinterpret_cast<const s16x8v *>(cbl + off);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zl[s]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
-    }
+  // Two 32-code tiles per step, their MFMA chains interleaved: a tile's twelve MFMAs all accumulate into ONE register
+  // set, and back-to-back dependent MFMAs issue at about half the pipe's rate (the stamps showed the matrix and the
+  // vector work of the search adding up instead of overlapping); with two independent chains the pipe runs at its rate
+  // and the partner wave of the SIMD does its vector work meanwhile.
+  auto rank_tile = [&](const f32x16 &acc, const int kt) {
     const float *e2t = e2 + kt + 4 * half;
+    float t1 = kVqNone, t2 = kVqNone;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int cu = kt + (r & 3) + 8 * (r >> 2);              // uniform part of the code number
       const float d = __builtin_fmaf(acc[r], -2.f * kVqUnscale, e2t[(r & 3) + 8 * (r >> 2)]);
-      const bool l1 = d < b1, l2 = d < b2;                     // NaN: neither
-      i2 = l1 ? i1 : (l2 ? cu : i2);
-      // b1 <= b2: d < b1 -> b1, b1 <= d < b2 -> d, else b2.  (A NaN d -- only a vector beyond the f16 range or a
-      // non-finite one produces it, and then for every code: the vector ends with index -1 -- makes v_med3 return
-      // min3, which only disturbs candidates nobody reads.)
-      b2 = __builtin_amdgcn_fmed3f(d, b1, b2);
-      i1 = l1 ? cu : i1;
-      b1 = __builtin_fminf(d, b1);
+      const float key = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, d) & 0xFFFFFFF0u) | (unsigned)r);
+      t2 = __builtin_amdgcn_fmed3f(key, t1, t2);               // t1 <= t2 (a NaN key -- a vector out of range: every
+      t1 = __builtin_fminf(key, t1);                           // code, the vector ends with -1 -- leaves t1 alone)
     }
+    // the tile's two best into the running pair, exactly: value without the packed bits, uniform + decoded code number
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+      const unsigned kb_ = __builtin_bit_cast(unsigned, w == 0 ? t1 : t2);
+      const float v = __builtin_bit_cast(float, kb_ & 0xFFFFFFF0u);
+      const int cu = kt + (int)(kb_ & 3u) + 2 * (int)(kb_ & 12u);   // (r & 3) + 8 (r >> 2)
+      const bool l1 = v < b1, l2 = v < b2;
+      i2 = l1 ? i1 : (l2 ? cu : i2);
+      b2 = l2 ? (l1 ? b1 : v) : b2;
+      i1 = l1 ? cu : i1;
+      b1 = l1 ? v : b1;
+    }
+  };
+  for (int kt = 0; kt < Kp; kt += 64) {
+    const bool two = kt + 32 < Kp;                             // uniform (odd tile counts: the last step has one tile)
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = ainit; acc1[r] = ainit; }
+    const int row0 = kt + col, row1 = two ? row0 + 32 : row0;
+    const int sw0 = (row0 >> 1) & 7, sw1 = (row1 >> 1) & 7;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int off0 = row0 * D + (((2 * s + half) ^ sw0) * 8), off1 = row1 * D + (((2 * s + half) ^ sw1) * 8);
+      const s16x8v ah0 = *reinterpret_cast<const s16x8v *>(cbh + off0), al0 = *reinterpret_cast<const s16x8v *>(cbl + off0);
+      const s16x8v ah1 = *reinterpret_cast<const s16x8v *>(cbh + off1), al1 = *reinterpret_cast<const s16x8v *>(cbl + off1);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al0), __builtin_bit_cast(vq_f16x8, zh[s]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al1), __builtin_bit_cast(vq_f16x8, zh[s]), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah0), __builtin_bit_cast(vq_f16x8, zl[s]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah1), __builtin_bit_cast(vq_f16x8, zl[s]), acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah0), __builtin_bit_cast(vq_f16x8, zh[s]), acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah1), __builtin_bit_cast(vq_f16x8, zh[s]), acc1, 0, 0, 0);
+    }
+    rank_tile(acc0, kt);
+    if (two) rank_tile(acc1, kt + 32);
   }
   i1 += 4 * half;
   i2 += 4 * half;
@@ -271,7 +310,7 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
     ISI_VQ_INSERT(o2, j2);
 #undef ISI_VQ_INSERT
   }
-  return VqCand{b1, b2, i1, i2};
+  return VqCand{b1, b2, i1, i2, x2};
 }
 
 // The decision, in fp32, between the two candidates: returns the index of the nearest code (-1: no finite distance)
@@ -279,9 +318,9 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
 __device__ __forceinline__ int vq_decide_f32(const VqCand c, const float *e2, int K, const float *__restrict__ codes,
                                              const float4 (&zq)[8], int half, float4 (&ew)[8]) {
   constexpr int D = 64;
-  if (!(c.b1 < INFINITY) || c.b1 == -INFINITY) return -1;   // no finite distance / a code beyond the f16 range
+  if (!(c.b1 < kVqNone) || c.b1 < -0.5f * kVqPad) return -1;   // no finite distance / a code beyond the f16 range
   const int i1 = c.i1, i2 = c.i2;
-  const bool has2 = c.b2 < INFINITY && i2 < K && i2 != i1;
+  const bool has2 = c.b2 < 0.5f * kVqPad && i2 < K && i2 != i1;
   const float *r1 = codes + (size_t)i1 * D + half * 4, *r2 = codes + (size_t)(has2 ? i2 : i1) * D + half * 4;
   float4 e2q[8];
 #pragma unroll
@@ -289,10 +328,7 @@ __device__ __forceinline__ int vq_decide_f32(const VqCand c, const float *e2, in
     ew[j] = *reinterpret_cast<const float4 *>(r1 + j * 8);
     e2q[j] = *reinterpret_cast<const float4 *>(r2 + j * 8);
   }
-  float x2p = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) x2p += zq[j].x * zq[j].x + zq[j].y * zq[j].y + zq[j].z * zq[j].z + zq[j].w * zq[j].w;
-  const float x2 = x2p + __shfl_xor(x2p, 32);
+  const float x2 = c.x2;
   float p1 = 0.f, p2 = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { p1 += vq_quad_dot(ew[j], zq[j]); p2 += vq_quad_dot(e2q[j], zq[j]); }
@@ -441,6 +477,7 @@ __global__ void vq_weight_fragments_kernel(const uint4 *__restrict__ w16, uint4 
   wf[i] = w16[((size_t)row * Kpad + grp * 8) / 4 + plane];
 }
 
+template <int NCH>   // 32-channel chunks of C0 + C1, rounded up to an even number
 __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFusedArgs p) {
   constexpr int D = 64, NQ = D / 8;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -453,10 +490,8 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
   int *hist = reinterpret_cast<int *>(red + ISI_VQ_WAVES);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  const int lane0 = tid & 63;
   const int wave = tid >> 6;
-  const int col = lane & 31;
-  const int half = lane >> 5;
 
   vq_fill_planes(cbh, cbl, e2, hist, p.codes, p.e2, K, Kp, tid);
   __syncthreads();
@@ -482,10 +517,40 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
       a1 = (unsigned)(b * p.s1n + y * p.s1h + x * p.s1w) * 4u;
     }
   };
+  // ALL activation pieces of a tile (C0 + C1 <= 256 channels: up to 32 pieces of 16 bytes per lane) are requested
+  // before anything is multiplied: they come from HBM and their round trip used to be paid once per two-chunk batch;
+  // the weight fragments (L2-resident) follow batch by batch.  (Requesting them one tile AHEAD, between the previous
+  // tile's decision and its stores, was measured: 0.209 against 0.195 ms for the two launches of a forward -- the
+  // CU's vector-memory queue is what the tile waits for: ~105 memory instructions per wave and tile.)
+  constexpr int NU = 2 * NCH;                                // k-steps of 16 channels
+  i32x4v ahv[NU], alv[NU];
+  auto request_tile = [&](const int64_t it_, const int lane_) {
+    const int64_t n_ = it_ * VQ_VEC_PER_BLOCK_ITER + wave * 32 + (lane_ & 31);
+    unsigned a0, a1;
+    pixel_offsets(it_ < n_iter ? n_ : p.N, a0, a1);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int cc = u >> 1, s_ = u & 1;
+      const bool live = cc < nchunk;                           // uniform
+      const bool second = cc * 32 >= p.C0;                     // uniform
+      const unsigned abase = second ? a1 : a0;
+      const unsigned acol = (unsigned)(second ? cc * 32 - p.C0 : cc * 32) * 4u;
+      // pieces of channel group 2 s + half of the chunk: hi at + 0, lo at + 16 (OOBV: zeros)
+      const unsigned ao = (abase == OOBV || !live || ISI_VQ_DBGBIT(p, 32)) ? OOBV : abase + acol + (unsigned)(2 * s_ + (lane_ >> 5)) * 32u;
+      ahv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao, 0, 0);
+      alv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao == OOBV ? OOBV : ao + 16u, 0, 0);
+    }
+  };
   for (int64_t it = blockIdx.x; it < n_iter; it += gridDim.x) {
+    // the lane index is made opaque per iteration: the dozens of LDS / global offsets derived from it are invariant
+    // across iterations and would otherwise be hoisted out of the loop into registers the tile's prefetched pieces need
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int col = lane & 31, half = lane >> 5;
     const int64_t n = it * VQ_VEC_PER_BLOCK_ITER + wave * 32 + col;
     const bool valid = n < p.N;
     ISI_VQ_STAMP(0);
+    request_tile(it, lane);
     // ---- 1x1 convolution into this pixel's dims
     f32x16 zt[2];
 #pragma unroll
@@ -496,23 +561,13 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
     if (ISI_VQ_DBGBIT(p, 2)) {
       zt[0][0] = (float)(n & 7); zt[1][5] = 1.f;
     } else {
-    unsigned a0, a1;
-    pixel_offsets(n, a0, a1);
-    // two 32-channel chunks (four k-steps) per batch: all 24 fragment loads of a batch are in flight before its 24
-    // MFMAs (chunk by chunk the dependent L2 round trips added up to ~18 us per pass)
-    for (int c = 0; c < nchunk; c += 2) {
-      i32x4v ahv[4], alv[4], w0h[4], w0l[4], w1h[4], w1l[4];
+#pragma unroll
+    for (int c = 0; c < NCH; c += 2) {
+      i32x4v w0h[4], w0l[4], w1h[4], w1l[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int cc = c + (u >> 1), s_ = u & 1;
         const bool live = cc < nchunk;                          // uniform (odd chunk counts: zero operands)
-        const bool second = cc * 32 >= p.C0;                    // uniform
-        const unsigned abase = second ? a1 : a0;
-        const unsigned acol = (unsigned)(second ? cc * 32 - p.C0 : cc * 32) * 4u;
-        // pieces of channel group 2 s + half of the chunk: hi at + 0, lo at + 16
-        const unsigned ao = (abase == OOBV || !live || ISI_VQ_DBGBIT(p, 32)) ? OOBV : abase + acol + (unsigned)(2 * s_ + half) * 32u;
-        ahv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao, 0, 0);
-        alv[u] = __builtin_amdgcn_raw_buffer_load_b128(second ? rs1 : rs0, ao == OOBV ? OOBV : ao + 16u, 0, 0);
         // weight pieces, fragment-major: ((step * 2 + tile) * 2 + plane) * 1 KiB + 16 lane
         const unsigned wo = (live && !ISI_VQ_DBGBIT(p, 16)) ? (unsigned)((cc * 2 + s_) * 4) * 1024u + (unsigned)lane * 16u : OOBV;
         w0h[u] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wo, 0, 0);
@@ -522,9 +577,10 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        ISI_VQ_MF(w0h[u], alv[u], 0); ISI_VQ_MF(w1h[u], alv[u], 1);
-        ISI_VQ_MF(w0l[u], ahv[u], 0); ISI_VQ_MF(w1l[u], ahv[u], 1);
-        ISI_VQ_MF(w0h[u], ahv[u], 0); ISI_VQ_MF(w1h[u], ahv[u], 1);
+        const int uu = 2 * c + u;                              // k-step number (compile-time after unrolling)
+        ISI_VQ_MF(w0h[u], alv[uu], 0); ISI_VQ_MF(w1h[u], alv[uu], 1);
+        ISI_VQ_MF(w0l[u], ahv[uu], 0); ISI_VQ_MF(w1l[u], ahv[uu], 1);
+        ISI_VQ_MF(w0h[u], ahv[uu], 0); ISI_VQ_MF(w1h[u], ahv[uu], 1);
       }
     }
     }
@@ -605,6 +661,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
     ISI_VQ_STAMP(5);
   }
 
+  const int lane = lane0;
   __syncthreads();
   for (int i = tid; i < Kp; i += VQ_BLOCK)
     if (hist[i]) atomicAdd(&p.counts[i], hist[i]);
@@ -734,7 +791,7 @@ int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t 
 // D = 64; the weight is the packed 1x1 weight's blocked pair copy (ISI_CONV_W16: packed_w + Cout * Kpad floats).
 bool vq_conv1x1_fusable(int C0, int C1, int D, int K) {
   const int Kp = (K + 31) & ~31;
-  return D == 64 && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && vq_planes_lds_bytes(Kp) <= 150 * 1024;
+  return D == 64 && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && C0 + C1 <= 256 && vq_planes_lds_bytes(Kp) <= 150 * 1024;
 }
 
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D) { return (size_t)D * round_up((size_t)(C0 + C1), kBK); }
@@ -780,7 +837,9 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
                        reinterpret_cast<const uint4 *>(w16), reinterpret_cast<uint4 *>(workspace), a.Kpad, nstep,
                        zero_counts ? counts : nullptr, K);
   }
-  auto kern = vq_conv1x1_nearest_kernel;
+  const int nch2 = ((C0 + C1) / 32 + 1) / 2;                 // pairs of 32-channel chunks
+  auto kern = nch2 <= 1 ? vq_conv1x1_nearest_kernel<2> : nch2 == 2 ? vq_conv1x1_nearest_kernel<4>
+              : nch2 == 3 ? vq_conv1x1_nearest_kernel<6> : vq_conv1x1_nearest_kernel<8>;
   a.dbg = knobs().vq_dbg;   // 0 outside -DISI_MEASURE builds
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
     return check_launch("hipFuncSetAttribute(vq_conv1x1)");

@@ -579,7 +579,9 @@ __device__ __forceinline__ int ring_s(int r) {
 }  // namespace
 
 // ------------------------------------------------------------------ dQ and G (split)
-template <int HD>
+// ONE = true (precision 2): single-term bf16 products -- the lo.hi and hi.lo MFMAs of every product are left out
+// (north_star's "MFMA bf16" mode; the lo planes are still staged: the kernels are not bound by them)
+template <int HD, bool ONE = false>
 __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const AttnBwdKArgs p) {
   constexpr int NKB = HD / 16, NSL = HD / 8, RPB = 128 / HD, NDB = (HD + 31) / 32, VR = NDB * 32;
   constexpr int NQD = HD / 4, NKQ = (HD / 4 + 7) / 8;
@@ -754,8 +756,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         const int o = ql * HD + swz(ql, 2 * t + half);
         const s16x8_t kh = *reinterpret_cast<const s16x8_t *>(Kb + o);
         const s16x8_t kl = *reinterpret_cast<const s16x8_t *>(Kb + o + 32 * HD);
-        acc = ISI_MFB(kl, qh[t], acc);
-        acc = ISI_MFB(kh, qlo[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(kl, qh[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(kh, qlo[t], acc);
         acc = ISI_MFB(kh, qh[t], acc);
       }
       float sv[16];
@@ -775,8 +777,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
             const int o = slot * HD + swz(slot, 2 * t + half);
             const s16x8_t eh = *reinterpret_cast<const s16x8_t *>(Ep + o);
             const s16x8_t el = *reinterpret_cast<const s16x8_t *>(Ep + o + RING_S * HD);
-            acc = ISI_MFB(el, qh[t], acc);
-            acc = ISI_MFB(eh, qlo[t], acc);
+            if constexpr (!ONE) acc = ISI_MFB(el, qh[t], acc);
+            if constexpr (!ONE) acc = ISI_MFB(eh, qlo[t], acc);
             acc = ISI_MFB(eh, qh[t], acc);
           }
 #pragma unroll
@@ -819,8 +821,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         const int o = ql * HD + swz(ql, 2 * t + half);
         const s16x8_t vh = *reinterpret_cast<const s16x8_t *>(Vb + o);
         const s16x8_t vl = *reinterpret_cast<const s16x8_t *>(Vb + o + 32 * HD);
-        acc = ISI_MFB(vl, doh[t], acc);
-        acc = ISI_MFB(vh, dol[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(vl, doh[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(vh, dol[t], acc);
         acc = ISI_MFB(vh, doh[t], acc);
       }
 #pragma unroll
@@ -842,8 +844,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
           const uint2 l1 = *reinterpret_cast<const uint2 *>(kr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
           const s16x8_t kth = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
           const s16x8_t ktl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
-          dQ[d] = ISI_MFB(ktl, sh[t], dQ[d]);
-          dQ[d] = ISI_MFB(kth, sl[t], dQ[d]);
+          if constexpr (!ONE) dQ[d] = ISI_MFB(ktl, sh[t], dQ[d]);
+          if constexpr (!ONE) dQ[d] = ISI_MFB(kth, sl[t], dQ[d]);
           dQ[d] = ISI_MFB(kth, sh[t], dQ[d]);
         }
       }
@@ -906,7 +908,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
 // two partial results are added at the end.  Q and dO tiles are staged as row planes (S = Q K^T,
 // dP = dO V^T, U = Q E^T contract over the head dim) AND transposed planes (dV^T += dO^T P,
 // dK^T += Q^T dS contract over the queries).
-template <int HD>
+template <int HD, bool ONE = false>
 __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const AttnBwdKArgs p) {
   constexpr int NKB = HD / 16, NSL = HD / 8, RPB = 128 / HD, NDB = (HD + 31) / 32, VR = NDB * 32;
   constexpr int NQD = HD / 4, NKQ = (HD / 4 + 7) / 8;
@@ -1093,8 +1095,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         const int o = ql * HD + swz(ql, 2 * t + half);
         const s16x8_t qfh = *reinterpret_cast<const s16x8_t *>(Qb + o);
         const s16x8_t qfl = *reinterpret_cast<const s16x8_t *>(Qb + o + 32 * HD);
-        acc = ISI_MFB(qfl, kh[t], acc);
-        acc = ISI_MFB(qfh, kl[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(qfl, kh[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(qfh, kl[t], acc);
         acc = ISI_MFB(qfh, kh[t], acc);
       }
       float sv[16];
@@ -1116,8 +1118,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
             const s16x8_t el = *reinterpret_cast<const s16x8_t *>(Ep + o + RING_S * HD);
             const s16x8_t qfh = *reinterpret_cast<const s16x8_t *>(Qb + oq);
             const s16x8_t qfl = *reinterpret_cast<const s16x8_t *>(Qb + oq + 32 * HD);
-            acc = ISI_MFB(qfl, eh, acc);
-            acc = ISI_MFB(qfh, el, acc);
+            if constexpr (!ONE) acc = ISI_MFB(qfl, eh, acc);
+            if constexpr (!ONE) acc = ISI_MFB(qfh, el, acc);
             acc = ISI_MFB(qfh, eh, acc);
           }
 #pragma unroll
@@ -1169,8 +1171,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
           const uint2 l1 = *reinterpret_cast<const uint2 *>(gr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
           const s16x8_t gh = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
           const s16x8_t gl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
-          dV[d] = ISI_MFB(gl, sh[t], dV[d]);
-          dV[d] = ISI_MFB(gh, sl[t], dV[d]);
+          if constexpr (!ONE) dV[d] = ISI_MFB(gl, sh[t], dV[d]);
+          if constexpr (!ONE) dV[d] = ISI_MFB(gh, sl[t], dV[d]);
           dV[d] = ISI_MFB(gh, sh[t], dV[d]);
         }
       }
@@ -1182,8 +1184,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         const int o = ql * HD + swz(ql, 2 * t + half);
         const s16x8_t gh = *reinterpret_cast<const s16x8_t *>(Gb + o);
         const s16x8_t gl = *reinterpret_cast<const s16x8_t *>(Gb + o + 32 * HD);
-        acc = ISI_MFB(gl, vh[t], acc);
-        acc = ISI_MFB(gh, vl[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(gl, vh[t], acc);
+        if constexpr (!ONE) acc = ISI_MFB(gh, vl[t], acc);
         acc = ISI_MFB(gh, vh[t], acc);
       }
 #pragma unroll
@@ -1203,8 +1205,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
           const uint2 l1 = *reinterpret_cast<const uint2 *>(qr + VR * 32 + (((4 * t + 2 + half) ^ sx) * 4));
           const s16x8_t qth = __builtin_bit_cast(s16x8_t, make_uint4(h0.x, h0.y, h1.x, h1.y));
           const s16x8_t qtl = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
-          dK[d] = ISI_MFB(qtl, sh[t], dK[d]);
-          dK[d] = ISI_MFB(qth, sl[t], dK[d]);
+          if constexpr (!ONE) dK[d] = ISI_MFB(qtl, sh[t], dK[d]);
+          if constexpr (!ONE) dK[d] = ISI_MFB(qth, sl[t], dK[d]);
           dK[d] = ISI_MFB(qth, sh[t], dK[d]);
         }
       }
@@ -1319,10 +1321,10 @@ size_t rel_attention_bwd_workspace_floats(const isi_attn_args *g) {
   return bwd_layout(g->B, g->H, g->Sq, n, g->head_dim).total;
 }
 
-template <int HD>
+template <int HD, bool ONE>
 static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
-  auto kq = rel_attention_bwd_q_split_kernel<HD>;
-  auto kkv = rel_attention_bwd_kv_split_kernel<HD>;
+  auto kq = rel_attention_bwd_q_split_kernel<HD, ONE>;
+  auto kkv = rel_attention_bwd_kv_split_kernel<HD, ONE>;
   constexpr int VR = ((HD + 31) / 32) * 32;
   constexpr size_t smem_q = (size_t)(2 * (2 * 2 * 32 * HD) + 2 * 2 * VR * 32 + 2 * RING_S * HD) * sizeof(unsigned short) +
                             (size_t)(8 * 32 * SRL + 64) * sizeof(float);
@@ -1442,11 +1444,12 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     if (hipMemsetAsync(a.g, 0, (size_t)g->H * g->B * g->Sq * L.Rp * sizeof(float), stream) != hipSuccess)
       return check_launch("hipMemsetAsync(G)");
   }
-  const bool split = g->precision >= 1;   // a single-term bf16 forward (precision 2) is differentiated with three-term products
+  const bool split = g->precision >= 1;
+  const bool one = g->precision == 2;     // single-term bf16 products, like the forward of that mode
   switch (HD) {
-    case 16: rc = split ? launch_bwd_split<16>(a, stream) : launch_bwd<16>(a, stream); break;
-    case 32: rc = split ? launch_bwd_split<32>(a, stream) : launch_bwd<32>(a, stream); break;
-    default: rc = split ? launch_bwd_split<64>(a, stream) : launch_bwd<64>(a, stream); break;
+    case 16: rc = split ? (one ? launch_bwd_split<16, true>(a, stream) : launch_bwd_split<16, false>(a, stream)) : launch_bwd<16>(a, stream); break;
+    case 32: rc = split ? (one ? launch_bwd_split<32, true>(a, stream) : launch_bwd_split<32, false>(a, stream)) : launch_bwd<32>(a, stream); break;
+    default: rc = split ? (one ? launch_bwd_split<64, true>(a, stream) : launch_bwd_split<64, false>(a, stream)) : launch_bwd<64>(a, stream); break;
   }
   if (rc || !has_e) return rc;
 

@@ -431,3 +431,49 @@ def test_rel_attention_backward_at_baseline_sizes(Sq, Sk, Cq, Ck, mode, precisio
         _close(gb.grad, b.grad, TOL, "d(k|v)")
     # a relative-embedding row collects ~S (x Cq Ck) contributions of either sign: fp32 summation-order noise
     _close(grel.grad, rel.grad, 1e-3, "d rel_embeddings")
+
+
+@pytest.mark.parametrize("Sq,Sk,Cq,Ck,mode", [(1025, 1025, 1, 1, 1), (260, 260, 4, 4, 1), (132, 33, 4, 1, 0)])
+def test_rel_attention_backward_bf16_mode(Sq, Sk, Cq, Ck, mode, monkeypatch):
+    """precision = 'bf16' (north_star config 4: relative attention on "MFMA bf16"): the backward runs single-term bf16
+    products like the forward of that mode (csrc/rel_attention_bwd_f32.hip, ONE = true).  Operands carry 2^-9 relative
+    rounding: every gradient within 3e-2 (rms) of autograd of the specification, and less accurate than -- i.e.
+    actually different from -- the three-term mode."""
+    from oracle import prior_oracle as P
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.priors._train import RelAttentionFn
+    hd, H, B = 64, 8, 1
+    d = hd * H
+    torch.manual_seed(Sq + 3 * mode)
+    Eq, Ek = -(-Sq // Cq), -(-Sk // Ck)
+    self_attn = Sq == Sk and Cq == Ck
+    if self_attn:
+        a = torch.randn(Sq, B, 3 * d, requires_grad=True)
+        b = None
+        q, k, v = a[..., :d], a[..., d:2 * d], a[..., 2 * d:]
+    else:
+        a = torch.randn(Sq, B, d, requires_grad=True)
+        b = torch.randn(Sk, B, 2 * d, requires_grad=True)
+        q, k, v = a, b[..., :d], b[..., d:]
+    rel = (torch.randn(H, Eq + Ek - 1, hd) * 0.5).requires_grad_(True)
+    mask = P.causal_mask(Sq) if mode == 1 else None
+    w = torch.randn(Sq, B, d)
+    ref = _spec_attention(q, k, v, rel, H, Cq, Ck, Ek, mask)
+    (ref * w).sum().backward()
+    dev = _dev()
+
+    def run(prec):
+        monkeypatch.setattr(_ops, "ATTENTION_PRECISION", prec)
+        ga = a.detach().to(dev).requires_grad_(True)
+        gb = b.detach().to(dev).requires_grad_(True) if b is not None else None
+        grel = rel.detach().to(dev).requires_grad_(True)
+        got = RelAttentionFn.apply(ga, gb, grel, H, Cq, Ck, Ek, mode, None)
+        (got * w.to(dev)).sum().backward()
+        grads = [ga.grad.cpu()] + ([gb.grad.cpu()] if gb is not None else []) + [grel.grad.cpu()]
+        refs = [a.grad] + ([b.grad] if b is not None else []) + [rel.grad]
+        return [float((g_ - r_).double().pow(2).mean().sqrt() / r_.double().pow(2).mean().sqrt()) for g_, r_ in zip(grads, refs)]
+
+    e1 = run("bf16")
+    e3 = run("bf16x3")
+    assert all(e < 3e-2 for e in e1), e1
+    assert all(x3 < x1 for x1, x3 in zip(e1, e3)), (e1, e3)

@@ -19,6 +19,7 @@ struct Knobs {
   int conv_pair_all;            // ISI_CONV_PAIR_ALL: DMA kernel also for the shapes it is not preferred on
   int conv_tap_major;           // ISI_CONV_TAP_MAJOR: K order of the register-staged kernel (measurement)
   int respair_th, res_th, convt_th, convt_pair_th;   // forced tile heights (tests, measurement)
+  int decode_nt;                // ISI_DECODE_NT: non-temporal weight loads in the batch-1 decode GEMVs (default 1)
   int prior_graph;              // ISI_PRIOR_GRAPH: replay the decode loop's positions as hipGraphs
   int conv_ablate, vq_dbg, respair_abl;   // ISI_MEASURE builds only
 };

@@ -111,7 +111,7 @@ int isi_spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t
  * same name once, at first use of the library; isi_knob_set changes it afterwards (process-wide, not thread-safe
  * against concurrent launches).  Names: ISI_CONV_FLUSH (accumulator flush period of the LDS-DMA convolution, default
  * 3, 0 = never), ISI_NO_PAIRS, ISI_NO_CONV_FIRST, ISI_NO_VQ_FUSION, ISI_NO_CONV_PAIR_KERNEL,
- * ISI_NO_RESBLOCK_PAIR_KERNEL, ISI_NO_CONVT_PAIR_KERNEL, ISI_NO_RESSTACK_KERNEL, ISI_CONV_PAIR_ALL,
+ * ISI_NO_RESBLOCK_PAIR_KERNEL, ISI_NO_CONVT_PAIR_KERNEL, ISI_NO_TAIL_FUSION, ISI_CONV_PAIR_ALL,
  * ISI_CONV_TAP_MAJOR, ISI_RESPAIR_TH, ISI_RES_TH, ISI_CONVT_TH, ISI_CONVT_PAIR_TH, ISI_DECODE_NT, ISI_PRIOR_GRAPH -- all select between kernels that
  * compute the SAME result (to rounding).  The ablation switches ISI_CONV_ABLATE / ISI_VQ_DBG / ISI_RESPAIR_ABL
  * (wrong results by design) exist only in -DISI_MEASURE builds: the default build rejects them. */
@@ -222,6 +222,19 @@ int isi_conv_transpose2d_k4s2_f32(const isi_src *src, const float *packed_w,
                                   const float *bias, const isi_dst *dst, int B,
                                   int H, int W, int Cout, int relu,
                                   void *stream);
+
+/* The decoder's tail in the pair pipeline (RosinalityDecoder, vqvae/encoder_decoder.py:196-209):
+ *   ConvTranspose2d(Cin -> Cmid = 64, k4 s2 p1) + ReLU + ConvTranspose2d(64 -> Cout <= 2, k4 s2 p1)
+ * without the [B, 2H, 2W, 64] activation between them: the first kernel projects every pixel of its result onto the
+ * second layer's 16 taps x Cout outputs while it still sits in registers (Y', 32 floats per pixel), the second one is
+ * left with the col2im sum.  in_pair: dense channels-last pair-format [B, H, W, Cin]; packed_w1: the packed phase
+ * matrices of layer 1 followed by their split-f16 pair copy (isi_pack_convT_k4s2_weight_f32 + isi_split_conv_weight_f16);
+ * packed_w2: the packed weight of layer 2 ([16 Cout][64], isi_pack_convT_k4s2_weight_f32); yprime_ws: workspace of
+ * B * 2H * 2W * 32 floats; dst: [B, Cout, 4H, 4W] fp32, arbitrary strides.  Same products as the two calls of
+ * isi_conv_transpose2d_k4s2_f32 (ISI_CONV_F16X3 | ISI_CONV_W16, pair hand-over), other summation order. */
+int isi_decoder_tail_f32(const float *in_pair, const float *packed_w1, const float *bias1, const float *packed_w2,
+                         const float *bias2, float *yprime_ws, const isi_dst *dst, int B, int H, int W, int Cin, int Cmid,
+                         int Cout, void *stream);
 
 /* Fused RosinalityResBlock on a rectified input r (encoder_decoder.py:22-35):
  *   out = [relu]( r + conv1x1(relu(conv3x3(r) + b3)) + b1 )

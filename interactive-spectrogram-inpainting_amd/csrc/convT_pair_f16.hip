@@ -54,6 +54,10 @@ struct ConvTPairK {
   unsigned in_bytes, w_bytes, out_bytes;
   int Cin, Cout, Kpad, H, W, B, relu;
   int tiles_x, tiles_y, ntn;                   // ntn = Cout / 64
+  // YP mode (the decoder's tail, see below): packed fp32 weight [n2][64] of the few-channel transposed convolution that
+  // follows this one; `out` then receives Y' [B][2H][2W][32] fp32 instead of this layer's activation
+  const float *w2;
+  int n2;
 };
 
 __device__ __forceinline__ void dma16(const unsigned lds_addr, const unsigned voff, const i32x4 rsrc, const unsigned soff) {
@@ -74,7 +78,16 @@ __device__ long long g_convT_pair_stamps[128];
 #endif
 #define ISI_MH(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
 
-template <int TH, bool OUTP>
+// YP (round 3, "decoder tail"): this layer (ConvT C -> 64, + bias, ReLU) is followed by ConvTranspose2d(64 -> n2 / 16 <= 2)
+// (vqvae/encoder_decoder.py:196-209).  A transposed convolution is a per-pixel projection Y' = W2^T u onto its 16 taps x
+// outputs followed by a col2im sum; the projection needs nothing but the pixel's own 64 channels, which at the end of this
+// kernel's K loop sit in the lane's registers.  So instead of writing u (256 bytes per pixel, the largest tensor of the
+// network, read once more by the next kernel) the epilogue rectifies and splits u in registers, multiplies by W2 (12 MFMAs
+// per 32-pixel group; the accumulator quads ARE the B fragments once W2's k order is permuted to match) and writes the
+// 32 floats of Y' per pixel (128 bytes): half the bytes out of this kernel, half the bytes into the next, which is left
+// with the col2im gather (convT_small_f32.hip: convT_gather_kernel).  Same products as the two-kernel path (u split into
+// the same f16 pieces, three-term products with W2's pieces), other summation order.
+template <int TH, bool OUTP, bool YP = false>
 __global__ __launch_bounds__(TH * 64) void convT_pair_kernel(const ConvTPairK p) {
   constexpr int NW = TH;                                   // waves: one per tile row
   constexpr int HPIX = (TH + 1) * HWD;                     // halo pixels: rows y0-1+py .. y0+TH-1+py, columns x0-1 .. x0+64
@@ -100,6 +113,21 @@ __global__ __launch_bounds__(TH * 64) void convT_pair_kernel(const ConvTPairK p)
   // 98 k cycles); a ds_read is counted separately
   float *bias_s = reinterpret_cast<float *>(smem + NS * STAGE);
   for (int i = tid; i < p.Cout; i += NW * 64) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+  // YP: W2 as MFMA A fragments (row n = tap * outputs + co, zero beyond n2), piece (k-step s, plane) of lane (n, kb) at
+  // ((s 2 + plane) 64 + lane) 16 B; k-slot (s, kb, e) is channel 32 (s >> 1) + 16 (s & 1) + (e < 4 ? 4 kb + e : 8 + 4 kb + e - 4)
+  // -- the order in which a lane's accumulator quads 2 (s & 1), 2 (s & 1) + 1 of channel tile s >> 1 hold its pixel
+  unsigned short *w2s = reinterpret_cast<unsigned short *>(bias_s + 64);
+  if constexpr (YP) {
+    for (int i = tid; i < 4 * 2 * 64 * 8; i += NW * 64) {
+      const int e = i & 7, l = (i >> 3) & 63, plane = (i >> 9) & 1, s_ = i >> 10;
+      const int n = l & 31, kbl = l >> 5;
+      const int ch = 32 * (s_ >> 1) + 16 * (s_ & 1) + (e < 4 ? 4 * kbl + e : 8 + 4 * kbl + (e - 4));
+      const float w = n < p.n2 ? p.w2[n * 64 + ch] * f16s::kScaleB : 0.f;
+      const _Float16 hi = (_Float16)w;
+      const _Float16 v = plane ? (_Float16)(w - (float)hi) : hi;
+      w2s[i] = __builtin_bit_cast(unsigned short, v);
+    }
+  }
 
   const int per_b = p.tiles_x * p.tiles_y * 2 * p.ntn;
   const int nitems = per_b * p.B;
@@ -259,6 +287,55 @@ __global__ __launch_bounds__(TH * 64) void convT_pair_kernel(const ConvTPairK p)
     // bound by bytes, not by lines per instruction.  What removes it is not writing this tensor at all (fusing the
     // 64 -> 2 transposed convolution behind it: DESIGN.md section 8).
     const int gy = y0 + ry;
+    if constexpr (YP) {
+      // u = relu(acc + bias) in units of 4 x, split into f16 pieces: the B fragments of Y'^T = W2^T u^T
+      s16x8 wfh[4], wfl[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        wfh[s_] = *reinterpret_cast<const s16x8 *>(w2s + ((s_ * 2 + 0) * 64 + lane) * 8);
+        wfl[s_] = *reinterpret_cast<const s16x8 *>(w2s + ((s_ * 2 + 1) * 64 + lane) * 8);
+      }
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f32x16 y;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) y[r] = 0.f;
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_) {
+            const int j = s_ >> 1, qa = 2 * (s_ & 1);
+            float u4[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const int q = qa + (e >> 2);
+              const float bv = bias_s[32 * j + 8 * q + 4 * kb + (e & 3)];
+              float t = __builtin_fmaf(acc[px][i][j][4 * q + (e & 3)], f16s::kUnscale * f16s::kScaleA, bv * f16s::kScaleA);
+              if (p.relu) t = t < 0.f ? 0.f : t;
+              u4[e] = t;
+            }
+            uint4 uh, ul;
+            f16s::split2_scaled(u4[0], u4[1], uh.x, ul.x);
+            f16s::split2_scaled(u4[2], u4[3], uh.y, ul.y);
+            f16s::split2_scaled(u4[4], u4[5], uh.z, ul.z);
+            f16s::split2_scaled(u4[6], u4[7], uh.w, ul.w);
+            const s16x8 uhv = __builtin_bit_cast(s16x8, uh), ulv = __builtin_bit_cast(s16x8, ul);
+            y = ISI_MH(wfh[s_], ulv, y);
+            y = ISI_MH(wfl[s_], uhv, y);
+            y = ISI_MH(wfh[s_], uhv, y);
+          }
+          const int gx = x0 + 32 * i + frow;
+          const bool ok = gy < p.H && gx < p.W;
+          const unsigned o = (unsigned)(((b * OH + 2 * gy + py) * OW + 2 * gx + px) * 32);   // Y': 32 floats per pixel
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint4 w = make_uint4(__builtin_bit_cast(unsigned, y[4 * q] * f16s::kUnscale), __builtin_bit_cast(unsigned, y[4 * q + 1] * f16s::kUnscale),
+                                       __builtin_bit_cast(unsigned, y[4 * q + 2] * f16s::kUnscale), __builtin_bit_cast(unsigned, y[4 * q + 3] * f16s::kUnscale));
+            const unsigned off = ok ? (o + (unsigned)(8 * q + 4 * kb)) * 4u : OOB_ST;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w), rso_b, off, 0, 0);
+          }
+        }
+    } else {
 #pragma unroll
     for (int px = 0; px < 2; ++px)
 #pragma unroll
@@ -296,20 +373,21 @@ __global__ __launch_bounds__(TH * 64) void convT_pair_kernel(const ConvTPairK p)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w), rso_b, off, 0, 0);
           }
       }
+    }
     ISI_STAMP(5);
   }
 }
 #undef ISI_MH
 
-template <int TH, bool OUTP>
+template <int TH, bool OUTP, bool YP = false>
 int launch_convT_pair(const ConvTPairK &a, hipStream_t stream) {
   constexpr int HPIX = (TH + 1) * HWD;
   constexpr int A_ROWS = (HPIX + 15) / 16 * 16;
   constexpr int NS = 2;
   constexpr size_t ring = (size_t)NS * (A_ROWS * ROWB + NPAIR * 64 * ROWB + 1024);
   static_assert(ring + 4096 <= 160 * 1024, "LDS budget");
-  const size_t smem = ring + (size_t)a.Cout * sizeof(float);       // + the bias
-  auto kern = convT_pair_kernel<TH, OUTP>;
+  const size_t smem = ring + (size_t)(a.Cout > 64 ? a.Cout : 64) * sizeof(float) + (YP ? 8192 : 0);   // + the bias, W2 fragments
+  auto kern = convT_pair_kernel<TH, OUTP, YP>;
   static DeviceOnce attr_set;
   if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -328,6 +406,24 @@ int launch_convT_pair(const ConvTPairK &a, hipStream_t stream) {
 
 }  // namespace
 
+bool decoder_tail_ok(int Cin, int Cmid, int Cout) {
+  return !knobs().no_tail_fusion && convT_pair_ok(Cin, Cmid) && Cmid == 64 && Cout >= 1 && Cout <= 2;
+}
+
+int decoder_tail_f32(const float *in_pair, const float *packed_w1, const float *bias1, const float *packed_w2,
+                     const float *bias2, float *yprime_ws, const isi_dst *dst, int B, int H, int W, int Cin, int Cmid,
+                     int Cout, hipStream_t stream) {
+  if (!in_pair || !packed_w1 || !packed_w2 || !yprime_ws || !dst || !dst->ptr) return invalid("decoder_tail: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0) return invalid("decoder_tail: bad shape");
+  if (!convT_pair_ok(Cin, Cmid) || Cmid != 64 || Cout < 1 || Cout > 2) return unsupported("decoder_tail: Cin % 16 == 0, Cmid == 64, Cout <= 2");
+  const size_t Kpad = round_up((size_t)4 * Cin, kBK);
+  int rc = convT_pair_f16(in_pair, packed_w1 + (size_t)4 * Cmid * Kpad, bias1, yprime_ws, B, H, W, Cin, Cmid, /*relu*/ 1,
+                          /*out_pair*/ 0, stream, packed_w2, 16 * Cout);
+  if (rc) return rc;
+  return convT_gather_f32(yprime_ws, bias2, dst->ptr, B, 2 * H, 2 * W, Cout, (int)dst->sn, (int)dst->sc, (int)dst->sh,
+                          (int)dst->sw, 0, stream);
+}
+
 int convT_pair_debug_stamps(long long *host, int n) {
 #ifdef ISI_MEASURE
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_convT_pair_stamps), sizeof(long long) * (size_t)(n < 128 ? n : 128)) == hipSuccess ? 0 : -2;
@@ -343,10 +439,13 @@ bool convT_pair_ok(int Cin, int Cout) {
 
 // in: dense channels-last pair-format [B,H,W,Cin]; out: dense channels-last [B,2H,2W,Cout], fp32 or pair format;
 // w16: the blocked pair copy behind the packed phase matrices [4][Cout][Kpad] (pack_convT_k4s2_weight + ISI_CONV_W16).
+// w2 != nullptr: the decoder-tail form (YP): Cout must be 64, `out` receives Y' [B][2H][2W][32] fp32 for the n2 <= 32
+// rows of the packed weight w2 [n2][64] of the few-channel transposed convolution behind this layer
 int convT_pair_f16(const float *in, const float *w16, const float *bias, float *out, int B, int H, int W, int Cin,
-                   int Cout, int relu, int out_pair, hipStream_t stream) {
+                   int Cout, int relu, int out_pair, hipStream_t stream, const float *w2, int n2) {
   if (!convT_pair_ok(Cin, Cout)) return unsupported("convT_pair: shape outside the fused kernel");
-  const int64_t ein = (int64_t)B * H * W * Cin, eout = (int64_t)B * 4 * H * W * Cout;
+  if (w2 && (Cout != 64 || n2 < 1 || n2 > 32 || out_pair)) return unsupported("convT_pair: the tail form needs Cout == 64 and n2 <= 32");
+  const int64_t ein = (int64_t)B * H * W * Cin, eout = (int64_t)B * 4 * H * W * (w2 ? 32 : Cout);
   if (ein * 4 >= 0x70000000ll || eout * 4 >= 0xF0000000ll) return unsupported("convT_pair: tensor too large for 32-bit offsets");
   ConvTPairK a;
   memset(&a, 0, sizeof a);
@@ -357,15 +456,18 @@ int convT_pair_f16(const float *in, const float *w16, const float *bias, float *
   a.H = H; a.W = W; a.B = B; a.relu = relu;
   a.tiles_x = (W + TW - 1) / TW;
   a.ntn = Cout / 64;
+  a.w2 = w2; a.n2 = n2;
   // 8-row tiles (8 waves, two per SIMD) when they still give every CU an item, 4-row tiles otherwise
   const int forced = knobs().convt_pair_th;
   const long items8 = (long)a.tiles_x * ((H + 7) / 8) * 2 * a.ntn * B;
   const bool th8 = forced == 8 || (forced != 4 && items8 >= 256);
   if (th8) {
     a.tiles_y = (H + 7) / 8;
+    if (w2) return launch_convT_pair<8, false, true>(a, stream);
     return out_pair ? launch_convT_pair<8, true>(a, stream) : launch_convT_pair<8, false>(a, stream);
   }
   a.tiles_y = (H + 3) / 4;
+  if (w2) return launch_convT_pair<4, false, true>(a, stream);
   return out_pair ? launch_convT_pair<4, true>(a, stream) : launch_convT_pair<4, false>(a, stream);
 }
 

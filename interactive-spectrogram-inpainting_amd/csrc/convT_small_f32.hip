@@ -354,6 +354,86 @@ __global__ __launch_bounds__(256) void convT_k4s2_small_pair_kernel(const ConvTS
   }
 }
 
+// ---- the col2im half alone (round 3, "decoder tail"): when the transposed convolution in FRONT of the few-channel
+// layer has already projected its pixels onto this layer's taps (convT_pair_f16.hip, YP mode), the input here is
+// Y' [B][H][W][32] fp32 -- 128 bytes per pixel instead of the 256-byte activation -- and what is left is
+//   out[b][co][2 y - 1 + ky][2 x - 1 + kx] = bias[co] + sum of the four Y'[b][y][x][(ky, kx, co)] that land there.
+// A tile's (TH + 2) x 34 pixels come in by LDS-DMA (16-byte piece c of row r at position c ^ (r & 7)) and every output
+// pixel gathers its four contributions in the fixed order of the kernels above.  Purely memory-bound.
+template <int TH>
+__global__ __launch_bounds__(256) void convT_gather_kernel(const ConvTSmallArgs p) {
+  constexpr int HPIX = (TH + 2) * HW_;          // halo pixels
+  static_assert(HPIX % 8 == 0, "whole DMAs");
+  constexpr int NDMA = HPIX / 8;                // 1-KiB DMAs (8 rows of 128 B)
+  constexpr int PER = (NDMA + 3) / 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int x0, y0, b;
+  {
+    const int ntx = gridDim.x, nty = gridDim.y, nt = ntx * nty * (int)gridDim.z;
+    const int id = (int)blockIdx.x + ntx * ((int)blockIdx.y + nty * (int)blockIdx.z);
+    const int q = nt / 8, r = nt % 8, xcd = id % 8, idx = id / 8;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    x0 = (t % ntx) * TW;
+    y0 = ((t / ntx) % nty) * TH;
+    b = t / (ntx * nty);
+  }
+  const unsigned long long ib = (unsigned long long)p.in;
+  const i32x4 rsi = i32x4{(int)(unsigned)ib, (int)((unsigned)(ib >> 32) & 0xffffu), (int)p.in_bytes, 0x00020000};
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)sm;
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int d = wave + 4 * q;                 // uniform
+    if (d < NDMA) {
+      const int row = 8 * d + (lane >> 3);
+      const int hy = row / HW_, hx = row - hy * HW_;
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      const unsigned piece = (unsigned)(((lane & 7) ^ (row & 7)) * 16);
+      const unsigned vo = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * 32) * 4u + piece : 0x7FFFFFF0u;
+      dma16_small(lds0 + (unsigned)(d * 1024), vo, rsi);
+    }
+  }
+  float bias_v[2];
+#pragma unroll
+  for (int co = 0; co < 2; ++co) bias_v[co] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float *ys = sm;
+  auto yv = [&](const int row, const int c) { return ys[row * 32 + ((((c >> 2) ^ (row & 7)) << 2) | (c & 3))]; };
+
+  const int ox_l = tid & 63, oyb = tid >> 6;
+  const int ox = 2 * x0 + ox_l;
+  int kxs[2], hcs[2];
+#pragma unroll
+  for (int jx = 0; jx < 2; ++jx) {
+    kxs[jx] = ((ox_l + 1) & 1) + 2 * jx;
+    hcs[jx] = (ox_l + 1 - kxs[jx]) / 2 + 1;
+  }
+  if (ox >= 2 * p.W) return;
+#pragma unroll
+  for (int rr = 0; rr < TH / 2; ++rr) {
+    const int oy_l = oyb + 4 * rr;
+    const int oy = 2 * y0 + oy_l;
+    if (oy >= 2 * p.H) continue;
+#pragma unroll
+    for (int co = 0; co < 2; ++co) {
+      if (co >= p.Cout) continue;
+      float v = bias_v[co];
+#pragma unroll
+      for (int jy = 0; jy < 2; ++jy) {
+        const int ky = ((oy_l + 1) & 1) + 2 * jy;
+        const int hr = (oy_l + 1 - ky) / 2 + 1;
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) v += yv(hr * HW_ + hcs[jx], (ky * 4 + kxs[jx]) * p.Cout + co);
+      }
+      if (p.relu) v = v < 0.f ? 0.f : v;   // like torch.relu, NaN stays NaN
+      p.out[b * p.on + co * p.oc + oy * p.oh + ox * p.ow] = v;
+    }
+  }
+}
+
 __global__ void pack_convT_small_kernel(const float *__restrict__ w, float *__restrict__ out, int Cin,
                                         int Cout) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -436,6 +516,29 @@ int convT_k4s2_small_pair_f16(const float *in, const float *wn, const float *bia
   a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
   a.on = on; a.oc = oc; a.oh = oh; a.ow = ow;
   return launch_small_pair<4>(a, B, stream);
+}
+
+// yprime: dense [B][H][W][32] fp32 (convT_pair_f16's tail form); out: [B][Cout][2H][2W] with arbitrary strides
+int convT_gather_f32(const float *yprime, const float *bias, float *out, int B, int H, int W, int Cout, int on, int oc,
+                     int oh, int ow, int relu, hipStream_t stream) {
+  if (Cout < 1 || Cout > 2) return unsupported("convT_gather: Cout <= 2");
+  if (B > 65535) return unsupported("convT_gather: grid too large");
+  const int64_t in_elems = (int64_t)B * H * W * 32;
+  if (in_elems * 4 >= 0x70000000ll) return unsupported("convT_gather: tensor spans 1.75 GiB or more");
+  ConvTSmallArgs a;
+  a.in = yprime; a.wn = nullptr; a.bias = bias; a.out = out;
+  a.in_bytes = (unsigned)(in_elems * 4);
+  a.sn = H * W * 32; a.sc = 1; a.sh = W * 32; a.sw = 32; a.vec = 1;
+  a.H = H; a.W = W; a.Cin = 32; a.Cout = Cout; a.relu = relu;
+  a.on = on; a.oc = oc; a.oh = oh; a.ow = ow;
+  constexpr int TH = 6;                          // (TH + 2) x 34 pixels x 128 B = 34 KB: four workgroups per CU
+  auto kern = convT_gather_kernel<TH>;
+  constexpr size_t smem = (size_t)(TH + 2) * HW_ * 128;
+  if ((H + TH - 1) / TH > 65535) return unsupported("convT_gather: grid too large");
+  const double M = (double)B * H * W;
+  prof::Scope scope(prof::K_CONVT_SMALL, 2.0 * M * 16 * Cout, 4.0 * (M * 32 + 4.0 * M * Cout), stream);
+  ISI_PROF_LAUNCH(scope, kern, dim3((W + TW - 1) / TW, (H + TH - 1) / TH, B), dim3(256), smem, stream, a);
+  return check_launch("convT_gather_f32");
 }
 
 // src / dst strides arbitrary (32-bit range checked by the caller); in_elems = extent of the source.

@@ -24,7 +24,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_NO_CONV_PAIR_KERNEL", &Knobs::no_conv_pair_kernel, 0, false},
     {"ISI_NO_RESBLOCK_PAIR_KERNEL", &Knobs::no_resblock_pair_kernel, 0, false},
     {"ISI_NO_CONVT_PAIR_KERNEL", &Knobs::no_convt_pair_kernel, 0, false},
-    {"ISI_NO_RESSTACK_KERNEL", &Knobs::no_resstack_kernel, 0, false},
+    {"ISI_NO_TAIL_FUSION", &Knobs::no_tail_fusion, 0, false},
     {"ISI_CONV_PAIR_ALL", &Knobs::conv_pair_all, 0, false},
     {"ISI_CONV_TAP_MAJOR", &Knobs::conv_tap_major, 0, false},
     {"ISI_RESPAIR_TH", &Knobs::respair_th, 0, false},
@@ -87,6 +87,11 @@ size_t isi_abi_struct_bytes(int which) {
     case 10: return sizeof(isi_prior_state);
     default: return 0;
   }
+}
+int isi_decoder_tail_f32(const float *in_pair, const float *packed_w1, const float *bias1, const float *packed_w2,
+                         const float *bias2, float *yprime_ws, const isi_dst *dst, int B, int H, int W, int Cin, int Cmid,
+                         int Cout, void *stream) {
+  return decoder_tail_f32(in_pair, packed_w1, bias1, packed_w2, bias2, yprime_ws, dst, B, H, W, Cin, Cmid, Cout, S(stream));
 }
 int isi_knob_set(const char *name, int value) {
   if (!name) return invalid("isi_knob_set: null name");

@@ -31,9 +31,13 @@ int conv_pair_f16(const PairConvArgs &c, hipStream_t stream);
 int conv_pair_debug_stamps(long long *host, int n);
 // convT_pair_f16.hip: ConvTranspose2d(k4,s2,p1) of the pair pipeline with the output phases fused on one staged tile
 bool convT_pair_ok(int Cin, int Cout);
+bool decoder_tail_ok(int Cin, int Cmid, int Cout);
+int decoder_tail_f32(const float *in_pair, const float *packed_w1, const float *bias1, const float *packed_w2,
+                     const float *bias2, float *yprime_ws, const isi_dst *dst, int B, int H, int W, int Cin, int Cmid,
+                     int Cout, hipStream_t stream);
 int convT_pair_debug_stamps(long long *host, int n);
 int convT_pair_f16(const float *in, const float *w16, const float *bias, float *out, int B, int H, int W, int Cin,
-                   int Cout, int relu, int out_pair, hipStream_t stream);
+                   int Cout, int relu, int out_pair, hipStream_t stream, const float *w2 = nullptr, int n2 = 0);
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                int KW, int stride, int pad, int relu, hipStream_t stream);
@@ -55,6 +59,8 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
                  float *out, int B, int H, int W, int C, int R, int relu, hipStream_t stream);
 bool convT_small_applicable(int Cin, int Cout);
 bool convT_small_pair_ok(int Cin, int Cout);
+int convT_gather_f32(const float *yprime, const float *bias, float *out, int B, int H, int W, int Cout, int on, int oc,
+                     int oh, int ow, int relu, hipStream_t stream);
 int convT_k4s2_small_pair_f16(const float *in, const float *wn, const float *bias, float *out, int B, int H, int W,
                               int Cin, int Cout, int on, int oc, int oh, int ow, int relu, hipStream_t stream);
 int pack_convT_small_weight_f32(const float *w, float *packed, int Cin, int Cout, hipStream_t stream);

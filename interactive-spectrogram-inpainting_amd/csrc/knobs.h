@@ -15,7 +15,7 @@ struct Knobs {
   int no_conv_pair_kernel;      // ISI_NO_CONV_PAIR_KERNEL: register-staged kernel instead of the LDS-DMA one
   int no_resblock_pair_kernel;  // ISI_NO_RESBLOCK_PAIR_KERNEL
   int no_convt_pair_kernel;     // ISI_NO_CONVT_PAIR_KERNEL: four phase launches instead of the fused transposed conv
-  int no_resstack_kernel;       // ISI_NO_RESSTACK_KERNEL: one launch per residual block instead of one per stack
+  int no_tail_fusion;           // ISI_NO_TAIL_FUSION: the decoder's last two transposed convolutions as two full layers
   int conv_pair_all;            // ISI_CONV_PAIR_ALL: DMA kernel also for the shapes it is not preferred on
   int conv_tap_major;           // ISI_CONV_TAP_MAJOR: K order of the register-staged kernel (measurement)
   int respair_th, res_th, convt_th, convt_pair_th;   // forced tile heights (tests, measurement)

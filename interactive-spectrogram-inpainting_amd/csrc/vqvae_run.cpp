@@ -226,6 +226,15 @@ int run_decoder(const isi_decoder_w &d, const isi_src &in0, const isi_src *in1, 
     const bool last = (i == d.n_up - 1);
     isi_src s = src_nhwc(cur.p, cur.C, cur.H, cur.W);
     float *o = (cur.p == s0) ? s1 : s0;
+    // the last two transposed convolutions as one producer / consumer pair (convT_pair_f16.hip, YP mode): the
+    // [B, 2H, 2W, 64] activation between them is never written
+    if (i == d.n_up - 2 && cp && !final_pair && (pf & ISI_CONV_F16X3) && (pf & ISI_CONV_W16) &&
+        decoder_tail_ok(cur.C, d.up[i].Cout, d.up[i + 1].Cout)) {
+      int rc = decoder_tail_f32(cur.p, d.up[i].w, d.up[i].bias, d.up[i + 1].w, d.up[i + 1].bias, o, &final_dst, B, cur.H,
+                                cur.W, cur.C, d.up[i].Cout, d.up[i + 1].Cout, st);
+      if (rc) return rc;
+      return ISI_OK;
+    }
     isi_dst dd = last ? final_dst : dst_nhwc(o, d.up[i].Cout, 2 * cur.H, 2 * cur.W);
     const bool op = last ? final_pair : up_reads_pair(i + 1, d.up[i].Cout);
     int rc = conv_transpose2d_k4s2_f32(&s, d.up[i].w, d.up[i].bias, &dd, B, cur.H, cur.W,

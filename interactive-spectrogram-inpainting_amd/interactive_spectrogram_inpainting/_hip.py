@@ -122,6 +122,8 @@ SIGNATURES = {
     "isi_version": (C.c_char_p, []),
     "isi_last_error": (C.c_char_p, []),
     "isi_abi_struct_bytes": (C.c_size_t, [C.c_int]),
+    "isi_decoder_tail_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.POINTER(isi_dst), C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, _P]),
     "isi_knob_set": (C.c_int, [C.c_char_p, C.c_int]),
     "isi_knob_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "isi_relu_inplace_f32": (C.c_int, [_P, C.c_int64, _P]),

@@ -140,6 +140,26 @@ def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Op
     return out
 
 
+def decoder_tail(x_pair_bchw: torch.Tensor, packed_w1: torch.Tensor, bias1: Optional[torch.Tensor], packed_w2: torch.Tensor,
+                 bias2: Optional[torch.Tensor], cmid: int, cout: int) -> torch.Tensor:
+    """ConvTranspose2d(Cin -> 64) + ReLU + ConvTranspose2d(64 -> cout <= 2) of the pair pipeline without the activation
+    between them (isi_decoder_tail_f32): pair-format channels-last input viewed [B,Cin,H,W], packed weights with their
+    split-f16 copies (`pack_convT_weight(..., with_f16=True)`), NCHW fp32 result [B,cout,4H,4W]."""
+    _hip.require_gpu(x_pair_bchw, "decoder tail input")
+    B, cin, H, W = x_pair_bchw.shape
+    x = x_pair_bchw.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        raise ValueError("decoder_tail needs dense channels-last storage")
+    out = torch.empty(B, cout, 4 * H, 4 * W, dtype=torch.float32, device=x.device)
+    ws = torch.empty(B * 2 * H * 2 * W * 32, dtype=torch.float32, device=x.device)
+    dst = _hip.dst_nchw_view(out)
+    rc = _hip.lib().isi_decoder_tail_f32(x.data_ptr(), packed_w1.data_ptr(), bias1.data_ptr() if bias1 is not None else None,
+                                         packed_w2.data_ptr(), bias2.data_ptr() if bias2 is not None else None,
+                                         ws.data_ptr(), C.byref(dst), B, H, W, cin, cmid, cout, _s(x))
+    _hip.check(rc, "isi_decoder_tail_f32")
+    return out
+
+
 def resblock_fusable(C_: int, R: int) -> bool:
     return bool(_hip.lib().isi_resblock_fusable(C_, R))
 

@@ -123,6 +123,38 @@ def test_last_layer_transposed_conv_pair_kernel(cout, B, H, W):
         _ops.conv_transpose2d_k4s2(xp, pt, bias.to(dev), cout, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 16, 64, 128, 2), (1, 9, 70, 128, 2), (3, 5, 33, 64, 1), (1, 1, 1, 32, 2)])
+def test_decoder_tail_kernels(B, H, W, cin, cout):
+    """isi_decoder_tail_f32: ConvTranspose2d(cin -> 64) + ReLU + ConvTranspose2d(64 -> cout) with the 64-channel
+    activation never written -- the first kernel projects each pixel onto the second layer's taps (Y'), the second
+    gathers (csrc/convT_pair_f16.hip YP mode, csrc/convT_small_f32.hip convT_gather_kernel): against torch's two
+    ConvTranspose2d layers in float64 on the pair-rounded input with the intermediate rounded like the pair hand-over
+    (reference vqvae/encoder_decoder.py:196-209), and against the two-call path of this library."""
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(11 * H + W + cin + cout)
+    x = torch.relu(torch.randn(B, cin, H, W, generator=g))
+    w1 = torch.randn(cin, 64, 4, 4, generator=g) * 0.04
+    b1 = torch.randn(64, generator=g) * 0.1
+    w2 = torch.randn(64, cout, 4, 4, generator=g) * 0.1
+    b2 = torch.randn(cout, generator=g)
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    xp = _ops.pair_encode(xd)
+    p1 = _ops.pack_convT_weight(w1.to(dev), with_f16=True)
+    p2 = _ops.pack_convT_weight(w2.to(dev), with_f16=True)
+    F = torch.nn.functional
+    u = torch.relu(F.conv_transpose2d(_ops.pair_decode(xp).cpu().double(), w1.double(), b1.double(), stride=2, padding=1))
+    ref = F.conv_transpose2d(u, w2.double(), b2.double(), stride=2, padding=1)
+    got = _ops.decoder_tail(xp, p1, b1.to(dev), p2, b2.to(dev), 64, cout)
+    assert got.shape == (B, cout, 4 * H, 4 * W)
+    err = ((got.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert err < 3e-6, err
+    with _hip.knob("ISI_NO_TAIL_FUSION", 1):     # (the knob only steers the fused forward; these are the plain layers)
+        mid = _ops.conv_transpose2d_k4s2(xp, p1, b1.to(dev), 64, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)
+        two = _ops.conv_transpose2d_k4s2(mid, p2, b2.to(dev), cout, relu=False, out_nchw=True, bf16x3=4, extra_flags=_ops.PAIR_IN0)
+    assert (two - got).abs().max() <= 2.0 ** -19 * got.abs().max()
+
+
 def test_resblock_against_reference(golden_dir):
     from interactive_spectrogram_inpainting.vqvae.encoder_decoder import RosinalityResBlock
     z = np.load(golden_dir / "resblock.npz")

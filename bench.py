@@ -603,6 +603,16 @@ def main():
                 "timed_launches": dom["launches"],
                 "share_of_step_time": round((dom["ms"] / timed_steps) / (dt * 1e3 / args.steps), 3),
                 "hbm_algorithmic_GBs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1)}
+        # the whole forward against BOTH ceilings ("report achieved = max(bytes / (t BW_peak), flops / (t FLOP_peak))
+        # and both terms"): algorithmic FLOPs / bytes summed over the timed kernels of one step
+        tot_fl = sum(k["flops"] for k in kernels) / timed_steps
+        tot_by = sum(k["bytes"] for k in kernels) / timed_steps
+        t_step = dt / args.steps
+        roof["whole_forward"] = {
+            "flops": round(tot_fl), "bytes": round(tot_by),
+            "TFLOPs": round(tot_fl / t_step / 1e12, 1), "frac_of_mfma_ceiling": round(tot_fl / t_step / 1e12 / peak, 4),
+            "GBs": round(tot_by / t_step / 1e9, 1), "frac_of_hbm_peak": round(tot_by / t_step / 1e9 / HBM_PEAK_GBS, 4),
+            "max_frac": round(max(tot_fl / t_step / 1e12 / peak, tot_by / t_step / 1e9 / HBM_PEAK_GBS), 4)}
         line = {
             "metric": "spectrograms/sec VQ-VAE fwd+quantize @B64",
             "value": round(world * args.batch * args.steps / dt, 2),

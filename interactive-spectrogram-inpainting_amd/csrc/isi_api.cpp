@@ -129,6 +129,7 @@ int isi_debug_conv_pair_stamps(long long *host, int n) { return conv_pair_debug_
 int isi_debug_convT_pair_stamps(long long *host, int n) { return convT_pair_debug_stamps(host, n); }
 int isi_debug_resblock_pair_stamps(long long *host, int n) { return resblock_pair_debug_stamps(host, n); }
 int isi_debug_vq_stamps(long long *host, int n) { return vq_debug_stamps(host, n); }
+int isi_debug_attention_stamps(long long *host, int n) { return rel_attention_debug_stamps(host, n); }
 int isi_pair_encode_f32(const float *x, float *pairs, int64_t n, void *stream) { return pair_encode_f32(x, pairs, n, S(stream)); }
 int isi_pair_decode_f32(const float *pairs, float *x, int64_t n, void *stream) { return pair_decode_f32(pairs, x, n, S(stream)); }
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream) {

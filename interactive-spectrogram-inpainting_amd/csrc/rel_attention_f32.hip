@@ -375,6 +375,15 @@ __global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs 
 // ONE = true (args->precision = 2): SINGLE-term bf16 products (north_star's "MFMA bf16" mode): the lo planes are
 // neither computed, stored nor multiplied -- a third of the matrix work, half of the staging conversions and LDS
 // traffic; operands are rounded to bf16 (8 significand bits), accumulation / logits / softmax stay fp32.
+// phase timestamps (-DISI_MEASURE builds; tools/stamps_attention.py): the heaviest full workgroup (blockIdx.x == 1 of
+// (h, b) = (0, 0)), waves 0 and 4, key-pair iteration 4
+#ifdef ISI_MEASURE
+__device__ long long g_attn_stamps[64];
+#define ISI_ATT_STAMP(i_) do { if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0 && lane == 0 && kp == k_begin + 4 * 64) \
+    g_attn_stamps[(wave >> 2) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ISI_ATT_STAMP(i_) do { } while (0)
+#endif
 template <int HD, bool ONE = false>
 __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArgs p) {
   constexpr int NKB = HD / 16;           // 16-deep k-blocks of the head dim
@@ -540,7 +549,9 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
 
   for (int kp = k_begin; kp < k_end; kp += 64) {
     const bool more = kp + 64 < k_end;
+    ISI_ATT_STAMP(0);
     if (more) prefetch(kp + 64);
+    ISI_ATT_STAMP(1);
     const int k0 = kp + 32 * grp;
     const int rb = band0(k0);
 
@@ -566,6 +577,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
       float sv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = sacc[r];
+      ISI_ATT_STAMP(2);
 
       // ---- relative logits through the skew buffer
       if (has_e) {
@@ -605,6 +617,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
         __builtin_amdgcn_wave_barrier();
       }
 
+      ISI_ATT_STAMP(3);
       // ---- scale, mask, online softmax (base 2)
       float tmax = NEG;
       bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < p.Sq;
@@ -644,6 +657,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
       l_run = l_run * alpha + psum;
       m_run = m_new;
 
+      ISI_ATT_STAMP(4);
       // ---- P split: key block t = registers 8 t .. 8 t + 7
       s16x8_t ph[2], pl[2];
       split_acc16(sv, ph, pl);
@@ -674,9 +688,13 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
         }
       }
     }
+    ISI_ATT_STAMP(5);
     __syncthreads();
+    ISI_ATT_STAMP(6);
     if (more) commit(kp + 64);
+    ISI_ATT_STAMP(7);
     __syncthreads();
+    ISI_ATT_STAMP(8);
   }
 
   // ---- merge the two groups' softmax states (group 1 -> LDS -> group 0)
@@ -720,6 +738,15 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
               make_float4(O[d][4 * g] * inv, O[d][4 * g + 1] * inv, O[d][4 * g + 2] * inv, O[d][4 * g + 3] * inv);
       }
   }
+}
+
+int rel_attention_debug_stamps(long long *host, int n) {
+#ifdef ISI_MEASURE
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(long long) * (size_t)(n < 64 ? n : 64)) == hipSuccess ? 0 : -2;
+#else
+  (void)host; (void)n;
+  return unsupported("phase timestamps need a -DISI_MEASURE build");
+#endif
 }
 
 template <int HD>

@@ -259,7 +259,8 @@ def test_quantizer_split_f16_products():
         q0, d0, i0, p0 = _ops.vq_nearest(z.to(dev), codes, e2)
         q1, d1, i1, p1 = _ops.vq_nearest(z.to(dev), codes, e2, split_f16=True)
         moved = _certify_index_mismatches(z, embed, i1.cpu(), i0.cpu())
-        assert moved <= max(1, n // 2000), moved
+        print(f"[split-f16 search, n = {n}] indices differing from the exact kernel (certified near-ties): {moved}")
+        assert moved == 0, moved        # (seeded Gaussian data: the f16-candidate search equals the exact kernel)
         same = (i0 == i1)
         assert torch.equal(q0[same], q1[same])
         if n > 2:

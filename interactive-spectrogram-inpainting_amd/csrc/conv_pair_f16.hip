@@ -468,6 +468,285 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
 #undef ISI_ISSUE_PIECE
 }
 
+// ---- the same convolution on a 128-pixel tile with FOUR waves, TWO workgroups per CU (round 3).  The 256-row kernel
+// above keeps one workgroup per CU: its per-item overhead -- entry barrier, row tables, prologue, epilogue: ~15 % of an
+// item (tools/stamps_conv.py) -- is serial, and a launch with one item per CU (the top-resolution layers) never overlaps
+// anything.  Here a workgroup is 128 x BN with one wave per SIMD (each wave 64 x BN/2 as above), a two-stage ring
+// (64 KiB at BN = 128): two workgroups share a CU with independent barriers, so one's epilogue / set-up / memory phases
+// run beside the other's MFMAs without any stagger logic inside the kernel.  Per chunk:
+//   wait own pieces of chunk k, barrier | fragments -> registers, lgkmcnt(0), barrier (stage free) | DMAs of chunk k + 2
+//   | 24 (12) MFMAs
+// Same products in the same order as the 256-row kernel (k walk, term order, flush): the same bits.
+template <int BN, bool OUTP>
+__global__ __launch_bounds__(256, 2) void conv_pair128_kernel(const PairK p) {
+  constexpr int BM2 = 128, NS2 = 2, NWV = 4;
+  constexpr int TM = 2;                       // 32-row tiles per wave (2 waves along M)
+  constexpr int TN = BN / 64;                 // 32-column tiles per wave (2 waves along N)
+  constexpr int A_STAGE = BM2 * ROWB, B_STAGE = BN * ROWB, STAGE = A_STAGE + B_STAGE;
+  constexpr int NA = A_STAGE / 1024 / NWV;    // A DMAs per wave and chunk (4)
+  constexpr int NB = B_STAGE / 1024 / NWV;    // B DMAs per wave and chunk (4 / 2)
+  constexpr int PER = NA + NB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int *row_oo = reinterpret_cast<int *>(smem + NS2 * STAGE);   // [BM2] output element offset or -1
+  int *row_n = row_oo + BM2;                                    // [BM2] batch index or -1
+  int *row_y = row_n + BM2;                                     // [BM2] top-left input y
+  int *row_x = row_y + BM2;                                     // [BM2] top-left input x
+  float *col_bias = reinterpret_cast<float *>(row_x + BM2);     // [BN]
+
+  const int tid = threadIdx.x;
+  const int lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mtiles = (p.M + BM2 - 1) / BM2, ntiles_n = p.Cout / BN;
+  const int nitems = mtiles * ntiles_n;
+  for (int item_i = blockIdx.x; item_i < nitems; item_i += gridDim.x) {
+  int item;
+  {
+    const int q = nitems / 8, r = nitems % 8, xcd = item_i % 8, idx = item_i / 8;
+    item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (item % mtiles) * BM2;
+  const int n0 = (item / mtiles) * BN;
+  int lane = lane0;
+  asm volatile("" : "+v"(lane));               // (per-item opaque: keeps lane-derived offsets from being hoisted into registers)
+  __syncthreads();   // the previous item is done with the LDS (row tables, ring)
+  if (tid < BM2) {
+    const int m = m0 + tid;
+    int b = -1, oy = 0, ox = 0;
+    if (m < p.M) {
+      b = udiv_small(m, p.OH * p.OW);
+      const int rem = m - b * (p.OH * p.OW);
+      oy = udiv_small(rem, p.OW);
+      ox = rem - oy * p.OW;
+    }
+    row_n[tid] = b;
+    row_y[tid] = oy * p.stride - p.pad;
+    row_x[tid] = ox * p.stride - p.pad;
+    row_oo[tid] = b < 0 ? -1 : b * p.on + oy * p.oh + ox * p.ow;
+  } else if (tid < BM2 + BN) {
+    col_bias[tid - BM2] = p.bias ? p.bias[n0 + tid - BM2] : 0.f;
+  }
+  __syncthreads();
+
+  const unsigned margin0 = (unsigned)(p.pad * p.s0h + p.pad * p.s0w) * 4u;
+  const unsigned margin1 = (unsigned)(p.pad * p.s1h + p.pad * p.s1w) * 4u;
+  const i32x4 rs0 = make_rsrc(reinterpret_cast<const char *>(p.in0) - margin0, p.in0_bytes + margin0);
+  const i32x4 rs1 = make_rsrc(reinterpret_cast<const char *>(p.in1) - margin1, p.in1_bytes + margin1);
+  const i32x4 rsw = make_rsrc(p.w, p.w_bytes);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
+
+  unsigned a_v[NA], a_v1[NA], a_mask[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = (wave * NA + i) * 8 + (lane >> 3);
+    const int b = row_n[r];
+    const int y0 = row_y[r], x0 = row_x[r];
+    const unsigned piece = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    a_v[i] = (unsigned)(b * p.s0n + (y0 + p.pad) * p.s0h + (x0 + p.pad) * p.s0w) * 4u + piece;
+    a_v1[i] = (unsigned)(b * p.s1n + (y0 + p.pad) * p.s1h + (x0 + p.pad) * p.s1w) * 4u + piece;
+    const int kw_lo = max(0, -x0), kw_hi = min(p.KW, p.W - x0);
+    const unsigned colbits = kw_hi > kw_lo ? ((1u << (kw_hi - kw_lo)) - 1u) << kw_lo : 0u;
+    const int kh_lo = max(0, -y0), kh_hi = min(p.KH, p.H - y0);
+    unsigned mask = 0;
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh)
+      if (kh >= kh_lo && kh < kh_hi) mask |= colbits << (kh * p.KW);
+    a_mask[i] = b >= 0 ? mask : 0u;
+  }
+  unsigned b_off[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = (wave * NB + j) * 8 + (lane >> 3);
+    b_off[j] = (unsigned)((n0 + n) * p.Kpad) * 4u + (unsigned)(((lane & 7) ^ ((n >> 1) & 7)) * 16);
+  }
+  const int Cin = p.C0 + p.C1;
+  const int nk = p.KH * p.KW * (Cin / 32);
+  int is_c = 0, is_kh = 0, is_kw = 0;
+  i32x4 rs_cur = rs0;
+  int sh_cur = p.s0h, sw_cur = p.s0w, c_sub = 0;
+  auto issue_chunk = [&](const int stage_) {
+    const unsigned soff_ = (unsigned)(is_kh * sh_cur + is_kw * sw_cur + (is_c - c_sub)) * 4u;
+    const unsigned tapbit_ = 1u << (is_kh * p.KW + is_kw);
+#pragma unroll
+    for (int q = 0; q < NA; ++q)
+      dma16(lds0 + (unsigned)(stage_ * STAGE + (wave * NA + q) * 1024), (a_mask[q] & tapbit_) ? a_v[q] : OOB, rs_cur, soff_);
+    const unsigned koff_ = (unsigned)((is_kh * p.KW + is_kw) * Cin + is_c) * 4u;
+#pragma unroll
+    for (int q = 0; q < NB; ++q)
+      dma16(lds0 + (unsigned)(stage_ * STAGE + A_STAGE + (wave * NB + q) * 1024), b_off[q], rsw, koff_);
+    if (++is_kw == p.KW) {
+      is_kw = 0;
+      if (++is_kh == p.KH) {
+        is_kh = 0;
+        is_c += 32;
+        if (is_c == p.C0 && p.C1 > 0) {   // the walk enters the second source
+#pragma unroll
+          for (int i_ = 0; i_ < NA; ++i_) a_v[i_] = a_v1[i_];
+          rs_cur = rs1; sh_cur = p.s1h; sw_cur = p.s1w; c_sub = p.C0;
+        }
+      }
+    }
+  };
+
+  const int frow = lane & 31, kb = lane >> 5;
+  const int xs = (2 * kb) ^ ((frow >> 1) & 7);
+  unsigned fa[2][2], fb[2][2];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+      fa[s_][pl] = (unsigned)((wm * 64 + frow) * ROWB + ((xs ^ (4 * s_ + pl)) << 4));
+      fb[s_][pl] = (unsigned)(A_STAGE + (wn * (BN / 2) + frow) * ROWB + ((xs ^ (4 * s_ + pl)) << 4));
+    }
+  f32x16 acc[TM][TN], tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+  bool fresh = true;
+  constexpr int WCOLS = TN * 32;
+
+  // ---- prologue: chunks 0 and 1 in flight
+  issue_chunk(0);
+  if (nk > 1) issue_chunk(1);
+  int since_flush = 0;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int stage = kc & 1;
+    // chunk kc has landed: this wave's pieces (those of chunk kc + 1 may stay in flight), then everyone's
+    if (kc + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const char *st = smem + stage * STAGE;
+    s16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[s_][i] = *reinterpret_cast<const s16x8 *>(st + fa[s_][0] + i * 32 * ROWB);
+        al[s_][i] = *reinterpret_cast<const s16x8 *>(st + fa[s_][1] + i * 32 * ROWB);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[s_][j] = *reinterpret_cast<const s16x8 *>(st + fb[s_][0] + j * 32 * ROWB);
+        bl[s_][j] = *reinterpret_cast<const s16x8 *>(st + fb[s_][1] + j * 32 * ROWB);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (kc + 2 < nk) {
+      // the stage is free once every wave holds its fragments: chunk kc + 2 goes there
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      issue_chunk(stage);
+    }
+    __builtin_amdgcn_s_setprio(2);
+    if (fresh) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh[0][j]), __builtin_bit_cast(f16x8, al[0][i]), zero, 0, 0, 0);
+        }
+      fresh = false;
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bh[0][j]), __builtin_bit_cast(f16x8, al[0][i]), acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int t = (s_ == 0 ? 1 : 0); t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const s16x8 av = t == 0 ? al[s_][i] : ah[s_][i];
+            const s16x8 bv = t == 1 ? bl[s_][j] : bh[s_][j];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bv), __builtin_bit_cast(f16x8, av), acc[i][j], 0, 0, 0);
+          }
+    __builtin_amdgcn_s_setprio(0);
+    if (p.flush && ++since_flush == p.flush) {
+      since_flush = 0;
+      fresh = true;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) tot[i][j][r] += acc[i][j][r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue, straight from the accumulators (as in the 256-row kernel)
+  const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int o = row_oo[wm * 64 + i * 32 + frow];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int cg = wn * WCOLS + j * 32 + 8 * q;
+        const float4 bq = *reinterpret_cast<const float4 *>(col_bias + cg + 4 * kb);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e;
+          float t = (fresh ? tot[i][j][r] : tot[i][j][r] + acc[i][j][r]) * f16s::kUnscale;
+          t += e == 0 ? bq.x : e == 1 ? bq.y : e == 2 ? bq.z : bq.w;
+          if (p.relu) t = t < 0.f ? 0.f : t;
+          v[e] = t;
+        }
+        uint4 w;
+        unsigned off;
+        if constexpr (OUTP) {
+          uint2 hi, lo;
+          f16s::split4(make_float4(v[0], v[1], v[2], v[3]), f16s::kScaleA, hi, lo);
+          const u32x2v sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+          const u32x2v sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+          w = make_uint4(sx.x, sy.x, sx.y, sy.y);
+          off = o >= 0 ? (unsigned)(o + n0 + cg) * 4u + (unsigned)kb * 16u : OOB_STORE;
+        } else {
+          w = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                         __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+          off = o >= 0 ? (unsigned)(o + n0 + cg + 4 * kb) * 4u : OOB_STORE;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w), rso_b, off, 0, 0);
+      }
+    }
+  }
+  }   // work items
+}
+
+template <int BN, bool OUTP>
+int launch_pair128(const PairK &a, double flops, double bytes, hipStream_t stream) {
+  auto kern = conv_pair128_kernel<BN, OUTP>;
+  constexpr size_t smem = (size_t)2 * (128 + BN) * ROWB + 4 * 128 * sizeof(int) + BN * sizeof(float);
+  static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(conv_pair128)");
+    attr_set.mark();
+  }
+  const int nitems = ((a.M + 127) / 128) * (a.Cout / BN);
+  const int n_cu = current_device_cu_count();
+  constexpr int per_cu = BN == 64 ? 3 : 2;            // 48-KiB / 64-KiB rings
+  dim3 grid(nitems < per_cu * n_cu ? nitems : per_cu * n_cu);   // persistent over the items
+  prof::Scope scope(prof::K_CONV_F16X3, flops, bytes, stream);
+  ISI_PROF_LAUNCH(scope, kern, grid, dim3(256), smem, stream, a);
+  return check_launch("conv_pair128_f16");
+}
+
 template <int BN>
 constexpr size_t pair_smem_bytes() {
   return (size_t)NS * (BM + BN) * ROWB + 4 * BM * sizeof(int) + BN * sizeof(float);
@@ -503,6 +782,15 @@ int conv_pair_debug_stamps(long long *host, int n) {
 bool conv_pair_kernel_ok(int C0, int C1, int Cout, int taps) {
   const bool off = knobs().no_conv_pair_kernel != 0;
   return !off && C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && Cout % 64 == 0 && taps >= 1 && taps <= 16;   // 16-bit tap masks
+}
+
+// Which tile height for this launch (measured, tools/bench_conv_pair.py; the two kernels return the same bits)?
+// B = 64: k4s2 64->128 at 64 x 256: 210 (256 rows) vs 230 us (128 rows); 3x3 128->128 at 32 x 128: 213 vs 217; 3x3 64->128 at
+// 16 x 64: 35.3 vs 35.8; k4s2 128->64 at 32 x 128 (64 output columns): 68 vs 63 -- the narrow tile is the one case where the
+// second workgroup per CU pays (its 48-KiB ring leaves room for three): the 128-row form runs the 64-column launches.
+static bool conv_pair_prefers_128(int M, int Cout, int K) {
+  (void)M; (void)K;
+  return Cout % 128 != 0;
 }
 
 int conv_pair_f16(const PairConvArgs &c, hipStream_t stream) {
@@ -541,6 +829,13 @@ int conv_pair_f16(const PairConvArgs &c, hipStream_t stream) {
   if (abl == 17) return launch_pair<128, true, 17>(a, nphase, flops, bytes, stream);   // same, no MFMAs
   if (abl == 8) return launch_pair<128, true, 8>(a, nphase, flops, bytes, stream);     // everything but the output stores
 #endif
+  // tile height: 128-row workgroups (two per CU) or the 256-row kernel; ISI_CONV_PAIR_BM forces one (tests, measurements)
+  const int bm = knobs().conv_pair_bm;
+  const bool use128 = !c.convT && (bm == 128 || (bm == 0 && conv_pair_prefers_128(c.M, c.Cout, (int)K)));
+  if (use128) {
+    if (c.out_pair) return wide ? launch_pair128<128, true>(a, flops, bytes, stream) : launch_pair128<64, true>(a, flops, bytes, stream);
+    return wide ? launch_pair128<128, false>(a, flops, bytes, stream) : launch_pair128<64, false>(a, flops, bytes, stream);
+  }
   if (c.out_pair) return wide ? launch_pair<128, true>(a, nphase, flops, bytes, stream)
                               : launch_pair<64, true>(a, nphase, flops, bytes, stream);
   return wide ? launch_pair<128, false>(a, nphase, flops, bytes, stream)

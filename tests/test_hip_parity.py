@@ -864,6 +864,15 @@ def test_dma_convolution_ragged_shapes(B, H, W, C0, C1, cout, k, stride):
     with _hip.knob("ISI_CONV_FLUSH", 0):
         unflushed = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p, extra_flags=flags, **kw)
     assert torch.equal(unflushed, old)
+    # the 128-row, four-wave form (two workgroups per CU) walks K and orders the terms like the 256-row kernel: same bits
+    with _hip.knob("ISI_CONV_PAIR_BM", 256):
+        big = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p, extra_flags=flags, **kw)
+    with _hip.knob("ISI_CONV_PAIR_BM", 128):
+        small = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p, extra_flags=flags, **kw)
+        small_p = _ops.pair_decode(_ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, pad, x2_bchw=x1p,
+                                               extra_flags=flags | _ops.PAIR_OUT, **kw))
+    assert torch.equal(small, big) and torch.equal(big, got if True else got)
+    assert (small_p.cpu().double() - ref64).abs().max().item() < 1e-6 * scale
 
 
 def test_vqvae_pair_pipeline_against_fp32_activations():

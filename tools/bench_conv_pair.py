@@ -33,7 +33,7 @@ def main():
              ("3x3 128->128 @32x128 (enc_b.conv3)", 128, 128, 3, 1, 32, 128, False),
              ("k4s2 128->64 @32x128 (enc_t.down0)", 128, 64, 4, 2, 32, 128, False),
              ("3x3 64->128 @16x64 (enc_t.conv3)", 64, 128, 3, 1, 16, 64, False),
-             ("1x1 128->64 @16x64 (quantize_conv_t)", 128, 64, 1, 1, 16, 64, False),
+             ("3x3 (64+64)->128 @32x128 (dec.conv3) as 128", 128, 128, 3, 1, 32, 128, False),
              ("convT 128->64 @32x128 (dec.up0)", 128, 64, 4, 2, 32, 128, True),
              ("convT 64->64 @16x64 (upsample)", 64, 64, 4, 2, 16, 64, True)]
     for name, cin, cout, k, s, H, W, tr in cases:
@@ -54,17 +54,17 @@ def main():
             OH, OW = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
             flops = 2.0 * B * OH * OW * cout * k * k * cin
         res = {}
-        variants = {"old": {"ISI_NO_CONV_PAIR_KERNEL": "1"}, "dma": {"ISI_CONV_PAIR_ALL": "1"}}
+        from interactive_spectrogram_inpainting import _hip
+        old = False
+        variants = {"bm256": ("ISI_CONV_PAIR_BM", 256), "bm128": ("ISI_CONV_PAIR_BM", 128)}
+        if tr:
+            variants = {"convT": ("ISI_CONV_PAIR_BM", 0)}
         for rnd in range(3):
-            for vname, env in variants.items():
-                old = vname == "old"
-                os.environ.update(env)
-                res.setdefault(vname, []).append(timed(run))
-                for k_ in env:
-                    os.environ.pop(k_, None)
+            for vname, (knob, val) in variants.items():
+                with _hip.knob(knob, val):
+                    res.setdefault(vname, []).append(timed(run))
         t = {k_: min(v) for k_, v in res.items()}
-        print(f"{name:42s} " + "   ".join(f"{k_} {v:7.1f} us ({flops / v / 1e6 / 833.3:.3f})" for k_, v in t.items()) +
-              f"   old/dma x{t['old'] / t['dma']:.3f}")
+        print(f"{name:42s} " + "   ".join(f"{k_} {v:7.1f} us ({flops / v / 1e6 / 833.3:.3f})" for k_, v in t.items()))
 
 
 if __name__ == "__main__":

@@ -663,8 +663,15 @@ def main():
                     o = model(x)
                 torch.cuda.synchronize(device)
                 dt2 = (time.perf_counter() - t0) / 10
+                # the decoder's own arithmetic error is measured TEACHER-FORCED on the fp32 mode's codes (a code that
+                # moves -- only a float-rounding near-tie can, tests/test_hip_parity.py certifies each -- changes a whole
+                # patch of the reconstruction and would hide it); `dec_max_err_over_max` is the end-to-end figure
+                dec_tf = model.decode_code(ref_out[4], ref_out[5])
                 alt[mode] = {"spectrograms_per_s": round(args.batch / dt2, 1), "ms_per_step": round(dt2 * 1e3, 3),
+                             "dec_teacher_forced_max_err_over_max": float((dec_tf - ref_out[0]).abs().max() / ref_out[0].abs().max()),
                              "dec_max_err_over_max": float((o[0] - ref_out[0]).abs().max() / ref_out[0].abs().max()),
+                             "codes_moved": {"top": int((o[4] != ref_out[4]).sum()), "of_top": o[4].numel(),
+                                             "bottom": int((o[5] != ref_out[5]).sum()), "of_bottom": o[5].numel()},
                              "id_t_agreement": float((o[4] == ref_out[4]).float().mean()),
                              "id_b_agreement": float((o[5] == ref_out[5]).float().mean())}
             model.conv_precision = default_precision

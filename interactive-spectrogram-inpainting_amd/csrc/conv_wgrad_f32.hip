@@ -18,6 +18,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 
 namespace isi {
 
@@ -235,17 +236,21 @@ __device__ __forceinline__ void split4(const float a, const float b, const float
 }
 }  // namespace
 
-template <int NP>   // 2: three-term split, 3: six-term split
+// Tile variants (round 3): the 128 x 128 tile wastes 3/4 of its matrix work and LDS traffic on the residual blocks'
+// 32-channel sides (3x3 128->32: Cout = 32; 1x1 32->128: K = 32), which are 16 of the step's 29 launches.  WR x WC
+// waves (WR * WC = 4), each owning MT x NT 32 x 32 accumulator tiles: tile = (WR MT 32) channels x (WC NT 32) k.
+template <int NP, int WR, int MT, int NT>   // NP 2: three-term split, 3: six-term split
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs p) {
+  constexpr int WC = 4 / WR, TCO = WR * MT * 32, TK = WC * NT * 32, JX = (TK + 127) / 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned short *Dp = reinterpret_cast<unsigned short *>(smem);   // [NP][128 co][LDB]  dY^T pieces (0 hi, 1 lo, 2 mid)
-  unsigned short *Xp = Dp + NP * 128 * LDB;                        // [NP][128 k ][LDB]  im2col^T pieces
-  float *bias_s = reinterpret_cast<float *>(Xp + NP * 128 * LDB);  // [8][128] bias partials of the pixel groups
-  constexpr int PS = 128 * LDB;
+  unsigned short *Dp = reinterpret_cast<unsigned short *>(smem);   // [NP][TCO][LDB]  dY^T pieces (0 hi, 1 lo, 2 mid)
+  unsigned short *Xp = Dp + NP * TCO * LDB;                        // [NP][TK ][LDB]  im2col^T pieces
+  float *bias_s = reinterpret_cast<float *>(Xp + NP * TK * LDB);   // [8][TCO] bias partials of the pixel groups
+  constexpr int PSD = TCO * LDB, PSX = TK * LDB;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int co0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int wm0 = (wave / WC) * (MT * 32), wn0 = (wave % WC) * (NT * 32);
+  const int co0 = blockIdx.x * TCO, k0 = blockIdx.y * TK;
   const int per_z = (p.convT ? 4 : 1) * p.nsplit;
   const int zb = (int)blockIdx.z / per_z, zrem = (int)blockIdx.z - zb * per_z;
   const int phase = zrem / p.nsplit, split = zrem - phase * p.nsplit;
@@ -258,22 +263,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
   const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x1p), 0, p.x1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dyp), 0, p.dy_bytes, 0x00020000);
 
-  // staging role: pixel group pg (pixels 4 pg .. 4 pg + 3 of the 32-pixel chunk), channel quad sq
+  // staging role: pixel group pg (pixels 4 pg .. 4 pg + 3 of the 32-pixel chunk), channel quad sq of dY (when inside
+  // the tile) and quads sq + 32 j of the im2col columns
   const int pg = tid >> 5, sq = tid & 31;
-  const int kk = k0 + sq * 4;
-  const bool kvalid = kk < p.K;
-  int tap = 0, c = 0, kh = 0, kw = 0;
-  if (kvalid) { tap = kk / p.Cin; c = kk - tap * p.Cin; kh = tap / p.KW; kw = tap - kh * p.KW; }
-  const bool second = c >= p.C0;
-  const int cc = second ? c - p.C0 : c;
+  const bool drole = sq * 4 < TCO;
+  bool kvalid[JX], second[JX], xrole[JX];
+  int kh[JX], kw[JX], cc[JX];
+#pragma unroll
+  for (int j = 0; j < JX; ++j) {
+    const int kk = k0 + (sq + 32 * j) * 4;
+    xrole[j] = (sq + 32 * j) * 4 < TK;
+    kvalid[j] = xrole[j] && kk < p.K;
+    int tap = 0, c = 0;
+    kh[j] = 0; kw[j] = 0;
+    if (kvalid[j]) { tap = kk / p.Cin; c = kk - tap * p.Cin; kh[j] = tap / p.KW; kw[j] = tap - kh[j] * p.KW; }
+    second[j] = c >= p.C0;
+    cc[j] = second[j] ? c - p.C0 : c;
+  }
   const int co = co0 + sq * 4;
-  const bool covalid = co < p.Cout;
+  const bool covalid = drole && co < p.Cout;
 
   const int chunk_begin = split * p.chunks_per_split;
   const int nchunks_total = (p.M + 31) / 32;
   const int chunk_end = min(nchunks_total, chunk_begin + p.chunks_per_split);
 
-  float4 rdq[4], rxq[4];
+  float4 rdq[4], rxq[JX][4];
   // (batch, row, column) of this thread's four pixels, carried from chunk to chunk (chunks are visited in
   // order: + 32 pixels each) instead of two integer divisions per pixel and chunk
   int pb[4], py_[4], px4[4];
@@ -291,17 +305,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int m = ch * 32 + 4 * pg + j;
-      unsigned doff = OOB, xoff = OOB;
-      if (m < p.M) {
-        const int b = pb[j], oy = py_[j], ox = px4[j];
-        if (covalid) doff = (unsigned)(dy_off + b * p.dn + oy * p.dh + ox * p.dw + co) * 4u;
-        const int iy = oy * p.stride - pad_y + kh, ix = ox * p.stride - pad_x + kw;
-        if (kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          xoff = second ? (unsigned)(b * p.s1n + iy * p.s1h + ix * p.s1w + cc) * 4u
-                        : (unsigned)(b * p.s0n + iy * p.s0h + ix * p.s0w + cc) * 4u;
-      }
+      const bool mv = m < p.M;
+      const int b = pb[j], oy = py_[j], ox = px4[j];
+      unsigned doff = OOB;
+      if (mv && covalid) doff = (unsigned)(dy_off + b * p.dn + oy * p.dh + ox * p.dw + co) * 4u;
       rdq[j] = buf_load4(rd, doff);
-      rxq[j] = second ? buf_load4(r1, xoff) : buf_load4(r0, xoff);
+#pragma unroll
+      for (int q = 0; q < JX; ++q) {
+        unsigned xoff = OOB;
+        const int iy = oy * p.stride - pad_y + kh[q], ix = ox * p.stride - pad_x + kw[q];
+        if (mv && kvalid[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+          xoff = second[q] ? (unsigned)(b * p.s1n + iy * p.s1h + ix * p.s1w + cc[q]) * 4u
+                           : (unsigned)(b * p.s0n + iy * p.s0h + ix * p.s0w + cc[q]) * 4u;
+        rxq[q][j] = second[q] ? buf_load4(r1, xoff) : buf_load4(r0, xoff);
+      }
       // next chunk: + 32 pixels = adv_b images + adv_y rows + adv_x columns, one carry each (branch-free)
       px4[j] += adv_x;
       const int c1 = px4[j] >= p.OW ? 1 : 0;
@@ -313,39 +330,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
     }
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's 4 channels of dY over its pixel group, all chunks
+  auto pick = [](const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; };
   auto store_chunk = [&]() {
     bsum[0] += (rdq[0].x + rdq[1].x) + (rdq[2].x + rdq[3].x);
     bsum[1] += (rdq[0].y + rdq[1].y) + (rdq[2].y + rdq[3].y);
     bsum[2] += (rdq[0].z + rdq[1].z) + (rdq[2].z + rdq[3].z);
     bsum[3] += (rdq[0].w + rdq[1].w) + (rdq[2].w + rdq[3].w);
+    if (drole) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int row = sq * 4 + e;
-      const int wo = row * LDB + bf_slot(row, pg >> 1) + (pg & 1) * 4;
-      uint2 pd[3], px_[3];
-      const float d0 = e == 0 ? rdq[0].x : e == 1 ? rdq[0].y : e == 2 ? rdq[0].z : rdq[0].w;
-      const float d1 = e == 0 ? rdq[1].x : e == 1 ? rdq[1].y : e == 2 ? rdq[1].z : rdq[1].w;
-      const float d2 = e == 0 ? rdq[2].x : e == 1 ? rdq[2].y : e == 2 ? rdq[2].z : rdq[2].w;
-      const float d3 = e == 0 ? rdq[3].x : e == 1 ? rdq[3].y : e == 2 ? rdq[3].z : rdq[3].w;
-      const float x0 = e == 0 ? rxq[0].x : e == 1 ? rxq[0].y : e == 2 ? rxq[0].z : rxq[0].w;
-      const float x1 = e == 0 ? rxq[1].x : e == 1 ? rxq[1].y : e == 2 ? rxq[1].z : rxq[1].w;
-      const float x2 = e == 0 ? rxq[2].x : e == 1 ? rxq[2].y : e == 2 ? rxq[2].z : rxq[2].w;
-      const float x3 = e == 0 ? rxq[3].x : e == 1 ? rxq[3].y : e == 2 ? rxq[3].z : rxq[3].w;
-      split4<NP>(d0, d1, d2, d3, pd);
-      split4<NP>(x0, x1, x2, x3, px_);
+      for (int e = 0; e < 4; ++e) {
+        const int row = sq * 4 + e;
+        const int wo = row * LDB + bf_slot(row, pg >> 1) + (pg & 1) * 4;
+        uint2 pd[3];
+        split4<NP>(pick(rdq[0], e), pick(rdq[1], e), pick(rdq[2], e), pick(rdq[3], e), pd);
 #pragma unroll
-      for (int q = 0; q < NP; ++q) {
-        *reinterpret_cast<uint2 *>(Dp + q * PS + wo) = pd[q];
-        *reinterpret_cast<uint2 *>(Xp + q * PS + wo) = px_[q];
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(Dp + q * PSD + wo) = pd[q];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < JX; ++j) {
+      if (!xrole[j]) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = (sq + 32 * j) * 4 + e;
+        const int wo = row * LDB + bf_slot(row, pg >> 1) + (pg & 1) * 4;
+        uint2 px_[3];
+        split4<NP>(pick(rxq[j][0], e), pick(rxq[j][1], e), pick(rxq[j][2], e), pick(rxq[j][3], e), px_);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) *reinterpret_cast<uint2 *>(Xp + q * PSX + wo) = px_[q];
       }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -359,28 +380,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
     if (ch + 1 < chunk_end) load_chunk(ch + 1);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      s16x8 av[2][NP], bv[2][NP];
+      s16x8 av[MT][NP], bv[NT][NP];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int ra = wm0 + i * 32 + fl, rb = wn0 + i * 32 + fl;
-        const int ao = ra * LDB + bf_slot(ra, s * 2 + half), bo = rb * LDB + bf_slot(rb, s * 2 + half);
+      for (int i = 0; i < MT; ++i) {
+        const int ra = wm0 + i * 32 + fl;
+        const int ao = ra * LDB + bf_slot(ra, s * 2 + half);
 #pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          av[i][q] = *reinterpret_cast<const s16x8 *>(Dp + q * PS + ao);
-          bv[i][q] = *reinterpret_cast<const s16x8 *>(Xp + q * PS + bo);
-        }
+        for (int q = 0; q < NP; ++q) av[i][q] = *reinterpret_cast<const s16x8 *>(Dp + q * PSD + ao);
       }
-#define ISI_MF(i, j, qa, qb)                                                                                       \
-  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i][qa]),                       \
-                                                      __builtin_bit_cast(bf16x8, bv[j][qb]), acc[i][j], 0, 0, 0)
-#define ISI_TERM(qa, qb) ISI_MF(0, 0, qa, qb); ISI_MF(0, 1, qa, qb); ISI_MF(1, 0, qa, qb); ISI_MF(1, 1, qa, qb)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int rb = wn0 + i * 32 + fl;
+        const int bo = rb * LDB + bf_slot(rb, s * 2 + half);
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bv[i][q] = *reinterpret_cast<const s16x8 *>(Xp + q * PSX + bo);
+      }
+      auto term = [&](int qa, int qb) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i][qa]),
+                                                                __builtin_bit_cast(bf16x8, bv[j][qb]), acc[i][j], 0, 0, 0);
+      };
       if constexpr (NP == 3) {   // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
-        ISI_TERM(1, 0); ISI_TERM(0, 1); ISI_TERM(2, 2); ISI_TERM(2, 0); ISI_TERM(0, 2); ISI_TERM(0, 0);
+        term(1, 0); term(0, 1); term(2, 2); term(2, 0); term(0, 2); term(0, 0);
       } else {
-        ISI_TERM(1, 0); ISI_TERM(0, 1); ISI_TERM(0, 0);
+        term(1, 0); term(0, 1); term(0, 0);
       }
-#undef ISI_TERM
-#undef ISI_MF
     }
     __syncthreads();   // every wave has read the single stage
     if (ch + 1 < chunk_end) store_chunk();
@@ -388,22 +415,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
   }
   // ---- bias partials: fixed-order sum over the 8 pixel groups
   if (p.db_partial != nullptr && blockIdx.y == 0) {
+    if (drole) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) bias_s[pg * 128 + sq * 4 + e] = bsum[e];
+      for (int e = 0; e < 4; ++e) bias_s[pg * TCO + sq * 4 + e] = bsum[e];
+    }
     __syncthreads();
-    if (tid < 128 && co0 + tid < p.Cout) {
+    if (tid < TCO && co0 + tid < p.Cout) {
       float t = 0.f;
 #pragma unroll
-      for (int g = 0; g < 8; ++g) t += bias_s[g * 128 + tid];
+      for (int g = 0; g < 8; ++g) t += bias_s[g * TCO + tid];
       p.db_partial[(size_t)blockIdx.z * p.Cout + co0 + tid] = t;
     }
   }
 
   float *out = p.partial + (size_t)blockIdx.z * p.Cout * p.Kpad;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const int kcol = k0 + wn0 + j * 32 + fl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -411,6 +440,198 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
         if (corow < p.Cout && kcol < p.Kpad) out[(size_t)corow * p.Kpad + kcol] = acc[i][j][r];
       }
     }
+}
+
+// ---- halo-staged weight gradient (round 3).  The kernels above re-read the layer input once per TAP (a workgroup
+// owns 128 im2col columns = one tap of a 128-channel layer) and dY once per 128-column tile: 2.4 GB of L2 traffic
+// for a 3x3 128->128 layer whose tensors are 134 MB each -- tools/bench_wgrad.py: 190 TFLOP/s whatever the tile.
+// Here a workgroup stages the input HALO of a pixel tile (R x 32 output pixels) once, as bf16 hi / lo planes in the
+// tensor's own [pixel][channel] order (no transpose on the way in), and every tap reads a shifted window of it: the
+// reduction runs over pixels, so the MFMA fragments are K-major in PIXELS, which `ds_read_b64_tr_b16` (gfx950's
+// transposing LDS read: within 16 lanes, lane t receives element t & 3 of the segments 4 j + (t >> 2), j < 4 --
+// tools/probes/tr_read_probe.hip) delivers from the pixel-major image: lane t of a group points at pixel row t / 4,
+// channel quad t % 4 and gets 4 pixels of ONE channel.  A wave owns 32 output channels x (T taps x 32 input
+// channels) = T accumulator tiles (T = 9 for 3x3, 8 = two kernel rows of k4s2; the four waves of a workgroup split
+// over NCO channel groups x 4 / NCO input-channel slices), so the residual 3x3 (C -> 32) needs ONE pass over its
+// input and the 128-channel layers re-read dY Cin / 32 times instead of 9 x the input.
+//   LDS: X [slice][plane][halo pixel][32 ch], dY [group][plane][pixel][32 ch]: rows of 64 B, so the four pixel rows
+//   a 32-lane read touches sit on banks 0 / 16 / 32 / 48; stride 2 keeps even and odd halo columns apart so that
+//   consecutive output pixels stay on consecutive rows.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+
+template <int NCO, int S, int KHG, int KWT, int R>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p) {
+  constexpr int NCI = 4 / NCO, T = KHG * KWT, OWT = 32;
+  constexpr int HR = (R - 1) * S + KHG, HC = (OWT - 1) * S + KWT, HP = HR * HC, NPX = R * OWT;
+  constexpr int HCH = (HC + 1) / 2;                       // stride 2: even columns first, then the odd ones
+  constexpr int XI = NCI * HP * 8, DI = NCO * NPX * 8;    // float4 items per tile
+  constexpr int NXI = (XI + 255) / 256, NDI = DI / 256;
+  constexpr int XPL = HP * 64, DPL = NPX * 64;            // bytes of one bf16 plane
+  static_assert(DI % 256 == 0 && NPX == 64, "dY staging / bias reduction assume 64-pixel tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char *Xs = smem_b, *Ds = smem_b + NCI * 2 * XPL;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cg = wave % NCO, cs = wave / NCO;
+  const int KH = p.K / (p.KW * p.Cin), NTG = KH / KHG, NCB = p.Cin / (32 * NCI);
+  const int unit = blockIdx.x, split = blockIdx.y;
+  const int tg = unit % NTG, cb = (unit / NTG) % NCB, ob = unit / (NTG * NCB);
+  const int co0 = ob * (32 * NCO), ci0 = cb * (32 * NCI);
+
+  const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x1), 0, p.x1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+  // staging items of this thread (tile-invariant part): element offset relative to the tile's (b, oy0 S, ox0 S)
+  // origin, halo coordinates for the border test, LDS destination
+  int xrel[NXI], xdst[NXI];
+  short xhy[NXI], xhx[NXI];
+  bool xsec[NXI];
+#pragma unroll
+  for (int j = 0; j < NXI; ++j) {
+    const int item = tid + 256 * j;
+    const int q = item & 7, hp = (item >> 3) % HP, sl = (item >> 3) / HP;
+    const int hy = hp / HC, hx = hp % HC;
+    const int c = ci0 + sl * 32 + q * 4;
+    xsec[j] = c >= p.C0;
+    const int dyy = hy + tg * KHG - p.pad, dxx = hx - p.pad;
+    xhy[j] = (short)dyy; xhx[j] = (short)dxx;
+    xrel[j] = item < XI ? (xsec[j] ? dyy * p.s1h + dxx * p.s1w + (c - p.C0) : dyy * p.s0h + dxx * p.s0w + c) : INT32_MIN;
+    const int pos = S == 1 ? hx : (hx & 1) * HCH + (hx >> 1);
+    xdst[j] = sl * 2 * XPL + (hy * HC + pos) * 64 + q * 8;
+  }
+  int drel[NDI], ddst[NDI];
+#pragma unroll
+  for (int j = 0; j < NDI; ++j) {
+    const int item = tid + 256 * j;
+    const int q = item & 7, px = (item >> 3) % NPX, gr = (item >> 3) / NPX;
+    drel[j] = (px / OWT) * p.dh + (px % OWT) * p.dw + co0 + gr * 32 + q * 4;
+    ddst[j] = gr * 2 * DPL + px * 64 + q * 8;
+  }
+
+  const int TPR = p.OW / OWT, TPI = (p.OH / R) * TPR;
+  const int tile_begin = split * p.chunks_per_split;
+  const int tile_end = min(p.M, tile_begin + p.chunks_per_split);   // M = number of pixel tiles here
+
+  float4 rx[NXI], rdy[NDI];
+  auto load_tile = [&](int tile) {
+    const int b = tile / TPI, rem = tile - b * TPI;
+    const int oy0 = (rem / TPR) * R, ox0 = (rem - (rem / TPR) * TPR) * OWT;
+    const int iy0 = oy0 * S, ix0 = ox0 * S;
+    const int xb0 = b * p.s0n + iy0 * p.s0h + ix0 * p.s0w, xb1 = b * p.s1n + iy0 * p.s1h + ix0 * p.s1w;
+    const int db0 = b * p.dn + oy0 * p.dh + ox0 * p.dw;
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+      const int iy = iy0 + xhy[j], ix = ix0 + xhx[j];
+      const bool ok = xrel[j] != INT32_MIN && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const unsigned off = ok ? (unsigned)((xsec[j] ? xb1 : xb0) + xrel[j]) * 4u : OOB;
+      rx[j] = xsec[j] ? buf_load4(r1, off) : buf_load4(r0, off);
+    }
+#pragma unroll
+    for (int j = 0; j < NDI; ++j) rdy[j] = buf_load4(rd, (unsigned)(db0 + drel[j]) * 4u);
+  };
+  float bsum[NCO][4];
+#pragma unroll
+  for (int g = 0; g < NCO; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bsum[g][e] = 0.f;
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < NXI; ++j) {
+      if (256 * j + 255 >= XI && tid + 256 * j >= XI) continue;
+      uint2 pc[3];
+      split4<2>(rx[j].x, rx[j].y, rx[j].z, rx[j].w, pc);
+      *reinterpret_cast<uint2 *>(Xs + xdst[j]) = pc[0];
+      *reinterpret_cast<uint2 *>(Xs + xdst[j] + XPL) = pc[1];
+    }
+#pragma unroll
+    for (int j = 0; j < NDI; ++j) {
+      uint2 pc[3];
+      split4<2>(rdy[j].x, rdy[j].y, rdy[j].z, rdy[j].w, pc);
+      *reinterpret_cast<uint2 *>(Ds + ddst[j]) = pc[0];
+      *reinterpret_cast<uint2 *>(Ds + ddst[j] + DPL) = pc[1];
+      bsum[j / 2][0] += rdy[j].x; bsum[j / 2][1] += rdy[j].y; bsum[j / 2][2] += rdy[j].z; bsum[j / 2][3] += rdy[j].w;
+    }
+  };
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // fragment addressing: 16-lane group g = lane >> 4 covers channels 16 (g & 1) .. + 15 and the pixels
+  // 8 (g >> 1) + {0..3 | 4..7} of a 16-pixel step; lane t of the group points at pixel row t / 4, channel quad t % 4
+  const int fg = lane >> 4, ft = lane & 15;
+  const int frow = 8 * (fg >> 1) + (ft >> 2), fch = (16 * (fg & 1) + 4 * (ft & 3)) * 2;
+  const unsigned char *Ab = Ds + cg * 2 * DPL + frow * 64 + fch;
+  const unsigned char *Bb = Xs + cs * 2 * XPL + (S == 1 ? frow : frow) * 64 + fch;
+  auto frag = [](const unsigned char *q) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q + 4 * 64));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto compute_tile = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2 * R; ++ks) {
+      const int r = ks >> 1, kc = ks & 1;
+      const s16x8 ah = frag(Ab + (r * OWT + kc * 16) * 64), al = frag(Ab + DPL + (r * OWT + kc * 16) * 64);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const int khl = t / KWT, kwl = t % KWT;
+        const int col = S == 1 ? kc * 16 + kwl : (kwl & 1) * HCH + kc * 16 + (kwl >> 1);
+        const int off = ((r * S + khl) * HC + col) * 64;
+        const s16x8 bh = frag(Bb + off), bl = frag(Bb + XPL + off);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc[t], 0, 0, 0);
+      }
+    }
+  };
+
+  if (tile_begin < tile_end) {
+    load_tile(tile_begin);
+    store_tile();
+  }
+  __syncthreads();
+  for (int tile = tile_begin; tile < tile_end; ++tile) {
+    if (tile + 1 < tile_end) load_tile(tile + 1);
+    compute_tile();
+    __syncthreads();   // every wave has read the single stage
+    if (tile + 1 < tile_end) store_tile();
+    __syncthreads();
+  }
+
+  // ---- bias partials (units of the first input-channel block and tap group): fixed-order sum over the 32 staging
+  // threads of a channel quad
+  if (p.db_partial != nullptr && cb == 0 && tg == 0) {
+    float *red = reinterpret_cast<float *>(smem_b);   // [NCO * 32 channels][32 + 1]
+#pragma unroll
+    for (int g = 0; g < NCO; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[(g * 32 + (tid & 7) * 4 + e) * 33 + (tid >> 3)] = bsum[g][e];
+    __syncthreads();
+    if (tid < NCO * 32) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) t += red[tid * 33 + g];
+      p.db_partial[(size_t)split * p.Cout + co0 + tid] = t;
+    }
+  }
+
+  float *out = p.partial + (size_t)split * p.Cout * p.Kpad;
+  const int fl = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int tap = (tg * KHG + t / KWT) * KWT + t % KWT;
+    const int kcol = tap * p.Cin + ci0 + cs * 32 + fl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int corow = co0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(size_t)corow * p.Kpad + kcol] = acc[t][r];
+    }
+  }
 }
 
 // out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree)
@@ -439,19 +660,96 @@ static int64_t extent4(int64_t n, int64_t sn, int64_t c, int64_t sc, int64_t h, 
   return (n - 1) * sn + (c - 1) * sc + (h - 1) * sh + (w - 1) * sw + 1;
 }
 
-static int wgrad_nsplit(int Cout, int Kpad, int M, int nphase, int nz) {
-  const int tiles = ((Cout + 127) / 128) * ((Kpad + 127) / 128) * nphase * nz;
+// tile of the split-product kernel for a layer shape (the fp32 kernel's tile is always 128 x 128)
+struct WgradTile { int tco, tk, small; };
+static WgradTile wgrad_tile(int Cout, int Kpad) {
+  // measured at B = 64 (tools/bench_wgrad.py): the 64 x 64 tile with its finer pixel split takes the 2-channel layers
+  // from ~310 to ~245 us; 32 x 512 the residual 3x3 (C -> 32) from 340 to 309 (both stay bound by re-reading the input
+  // once per tap); 128 x 32 for the residual 1x1 and 64 x 256 for the 64-channel layers were SLOWER (97 -> 153 us,
+  // 116 -> 125 us: fewer, longer dY streams per CU) and are not selected
+  if (Kpad <= 64 && Cout <= 64) return {64, 64, 1};   // the 2-channel spectrogram side (K = 16 x 4)
+  if (Cout <= 32) return {32, 512, 0};                // residual 3x3 (C -> 32)
+  return {128, 128, 0};
+}
+static int wgrad_nsplit_tile(int Cout, int Kpad, int M, int nphase, int nz, const WgradTile &t) {
+  const int tiles = ((Cout + t.tco - 1) / t.tco) * ((Kpad + t.tk - 1) / t.tk) * nphase * nz;
   const int nchunks = (M + 31) / 32;
-  const int nsplit = std::min(256, std::max(1, 768 / tiles));
+  // small tiles are memory-bound and light on LDS: several workgroups per CU hide the load latency
+  const int nsplit = std::min(t.small ? 1024 : 256, std::max(1, (t.small ? 2048 : 768) / tiles));
   return std::min(nsplit, std::max(1, nchunks / 8));
+}
+static int wgrad_nsplit(int Cout, int Kpad, int M, int nphase, int nz, bool split_kernel) {
+  return wgrad_nsplit_tile(Cout, Kpad, M, nphase, nz, split_kernel ? wgrad_tile(Cout, Kpad) : WgradTile{128, 128, 0});
+}
+// pixel splits of the halo-staged kernel: ~2 workgroups per CU over its `units` (channel block, tap group) pairs
+static int wgrad_halo_nsplit(int units, int ntiles) {
+  return std::max(1, std::min(std::min(256, 512 / std::max(1, units)), ntiles / 4));
 }
 size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, int nz) {
   const int Kpad = (int)round_up(K, kBK);
-  const int nsplit = wgrad_nsplit(Cout, Kpad, M, nphase, nz);
+  // which kernel runs depends on the operands' layout: size for any of them (halo kernel: a workgroup covers at most
+  // 4 waves x 9 accumulator tiles of 32 x 32, which bounds its unit count from below and its splits from above)
+  int nsplit = std::max(wgrad_nsplit(Cout, Kpad, M, nphase, nz, false), wgrad_nsplit(Cout, Kpad, M, nphase, nz, true));
+  if (nphase == 1 && nz == 1 && Cout % 32 == 0 && K % 32 == 0)
+    nsplit = std::max(nsplit, wgrad_halo_nsplit(((Cout / 32) * (K / 32) + 35) / 36, M / 16));
   return (size_t)nz * ((size_t)nsplit * nphase * Cout * Kpad + (size_t)nsplit * nphase * Cout);
 }
 size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
   return conv_wgrad_batched_workspace_floats(Cout, K, M, nphase, 1);
+}
+
+template <int NP, int WR, int MT, int NT>
+static void launch_wgrad_split(const WgradKArgs &a, int nzs, hipStream_t stream) {
+  constexpr int WC = 4 / WR, TCO = WR * MT * 32, TK = WC * NT * 32;
+  constexpr size_t smem = (size_t)NP * (TCO + TK) * LDB * sizeof(unsigned short) + 8 * TCO * sizeof(float);
+  static DeviceOnce attr_set;
+  if (smem > 48 * 1024 && !attr_set.done()) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_split_kernel<NP, WR, MT, NT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set.mark();
+  }
+  dim3 grid((a.Cout + TCO - 1) / TCO, (a.Kpad + TK - 1) / TK, nzs);
+  hipLaunchKernelGGL((conv_wgrad_split_kernel<NP, WR, MT, NT>), grid, dim3(256), smem, stream, a);
+}
+template <int NP>
+static void launch_wgrad_split_np(const WgradKArgs &a, const WgradTile &t, int nzs, hipStream_t stream) {
+  if (t.tco == 64 && t.tk == 64) launch_wgrad_split<NP, 2, 1, 1>(a, nzs, stream);
+  else if (t.tco == 32) launch_wgrad_split<NP, 1, 1, 4>(a, nzs, stream);
+  else launch_wgrad_split<NP, 2, 2, 2>(a, nzs, stream);
+}
+
+// partial layout: [z][phase][split][Cout][Kpad] -> out [phase][Cout][Kpad]; bias partials [phase * split][Cout]
+static int wgrad_reduce(const WgradKArgs &a, float *workspace, float *dw_packed, float *db, int nphase, int nsplit,
+                        int nz, int64_t zs_dw, hipStream_t stream) {
+  const int64_t per = (int64_t)a.Cout * a.Kpad;
+  for (int ph = 0; ph < nphase; ++ph) {   // grid y = operand set
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64), nz), dim3(256), 0, stream,
+                       workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0,
+                       (int64_t)nphase * nsplit * per, zs_dw);
+  }
+  int rc = check_launch("reduce_partials");
+  if (rc || !db) return rc;
+  // bias gradient: every (phase, split) partial covers a disjoint pixel set
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.Cout + 63) / 64), dim3(256), 0, stream, a.db_partial, db,
+                     (int64_t)a.Cout, nsplit * nphase, (int64_t)a.Cout, 0, (int64_t)0, (int64_t)0);
+  return check_launch("reduce_partials(bias)");
+}
+
+template <int NCO, int S, int KHG, int KWT>
+static int launch_wgrad_halo(const WgradKArgs &a, int units, int nsplit, hipStream_t stream) {
+  constexpr int R = 2, NCI = 4 / NCO;
+  constexpr int HP = ((R - 1) * S + KHG) * (31 * S + KWT);
+  constexpr size_t smem = (size_t)NCI * 2 * HP * 64 + (size_t)NCO * 2 * R * 32 * 64;
+  static_assert(smem >= (size_t)NCO * 32 * 33 * 4, "bias reduction scratch");
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_halo_kernel<NCO, S, KHG, KWT, R>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(conv_wgrad_halo)");
+    attr_set.mark();
+  }
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<NCO, S, KHG, KWT, R>), dim3(units, nsplit), dim3(256), smem, stream, a);
+  return check_launch("conv_wgrad_halo");
 }
 
 // dW packed like the forward weights: [nphase][Cout][Kpad].  x = layer input (two sources allowed), dy = gradient
@@ -519,45 +817,57 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
     a.dn = OH * OW * Cout; a.dh = OW * Cout; a.dw = Cout;
   }
   const int nchunks = (a.M + 31) / 32;
-  const int nsplit = wgrad_nsplit(Cout, a.Kpad, a.M, nphase, nz);
+  // split-bf16 products need the vectorised loaders (channels-last sources, Cout % 4 == 0)
+  const bool use_split = prec_flags && a.vec && a.dvec;
+  const WgradTile tile = wgrad_tile(Cout, a.Kpad);
+  const int nsplit = wgrad_nsplit(Cout, a.Kpad, a.M, nphase, nz, use_split);
   a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.nz = nz; a.zs_x0 = (int)zs_x0; a.zs_dy = (int)zs_dy;
   const size_t need = (size_t)nz * ((size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout);
   if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
   a.db_partial = db ? workspace + (size_t)nsplit * nphase * Cout * a.Kpad : nullptr;
-  constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
-  static DeviceOnce attr_set;
-  if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_f32_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return check_launch("hipFuncSetAttribute(conv_wgrad)");
-    attr_set.mark();
+  // halo-staged kernel: 3x3 (s1 p1) and k4 (s2 p1) layers with 32-multiple channels and whole 2 x 32 pixel tiles
+  const bool k3 = KH == 3 && KW == 3 && stride == 1 && pad == 1, k4 = KH == 4 && KW == 4 && stride == 2 && pad == 1;
+  int nco = Cout % 128 == 0 ? 4 : Cout % 64 == 0 ? 2 : 1;
+  while (nco < 4 && Cin % (32 * (4 / nco))) nco *= 2;   // fewer input-channel slices per workgroup when Cin is small
+  const bool halo = use_split && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && (k3 || k4) &&
+                    Cout % (32 * nco) == 0 && Cin % (32 * (4 / nco)) == 0 && s0->C % 32 == 0 && OW % 32 == 0 &&
+                    OH % 2 == 0 && !knobs().no_wgrad_halo;
+  if (halo) {
+    const int units = (Cout / (32 * nco)) * (Cin / (32 * (4 / nco))) * (k3 ? 1 : 2);
+    const int ntiles = B * (OH / 2) * (OW / 32);
+    const int ns = wgrad_halo_nsplit(units, ntiles);
+    a.nsplit = ns; a.chunks_per_split = (ntiles + ns - 1) / ns; a.M = ntiles;
+    const size_t need_h = (size_t)ns * Cout * a.Kpad + (size_t)ns * Cout;
+    if (workspace_floats < need_h) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
+    a.db_partial = db ? workspace + (size_t)ns * Cout * a.Kpad : nullptr;
+    int rc_h = 0;
+#define ISI_HALO(NCO_, S_, KHG_, KW_)                                                                                 \
+  rc_h = launch_wgrad_halo<NCO_, S_, KHG_, KW_>(a, units, ns, stream)
+    if (k3) { if (nco == 4) ISI_HALO(4, 1, 3, 3); else if (nco == 2) ISI_HALO(2, 1, 3, 3); else ISI_HALO(1, 1, 3, 3); }
+    else { if (nco == 4) ISI_HALO(4, 2, 2, 4); else if (nco == 2) ISI_HALO(2, 2, 2, 4); else ISI_HALO(1, 2, 2, 4); }
+#undef ISI_HALO
+    if (rc_h) return rc_h;
+    return wgrad_reduce(a, workspace, dw_packed, db, 1, ns, 1, 0, stream);
   }
-  dim3 grid((Cout + 127) / 128, (a.Kpad + 127) / 128, nz * nphase * nsplit);
-  // split-bf16 products need the vectorised loaders (channels-last sources, Cout % 4 == 0)
-  if (prec_flags && a.vec && a.dvec) {
-    const int np = (prec_flags & ISI_CONV_BF16X6) ? 3 : 2;
-    const size_t smem_s = (size_t)2 * np * 128 * LDB * sizeof(unsigned short) + 8 * 128 * sizeof(float);
-    if (np == 3) hipLaunchKernelGGL(conv_wgrad_split_kernel<3>, grid, dim3(256), smem_s, stream, a);
-    else hipLaunchKernelGGL(conv_wgrad_split_kernel<2>, grid, dim3(256), smem_s, stream, a);
+  if (use_split) {
+    if (prec_flags & ISI_CONV_BF16X6) launch_wgrad_split_np<3>(a, tile, nz * nphase * nsplit, stream);
+    else launch_wgrad_split_np<2>(a, tile, nz * nphase * nsplit, stream);
   } else {
+    constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_f32_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(conv_wgrad)");
+      attr_set.mark();
+    }
+    dim3 grid((Cout + 127) / 128, (a.Kpad + 127) / 128, nz * nphase * nsplit);
     hipLaunchKernelGGL(conv_wgrad_f32_kernel, grid, dim3(256), smem, stream, a);
   }
   int rc = check_launch("conv_wgrad_f32");
   if (rc) return rc;
-  // partial layout: [phase][split][Cout][Kpad] -> out [phase][Cout][Kpad]
-  const int64_t per = (int64_t)Cout * a.Kpad;
-  for (int ph = 0; ph < nphase; ++ph) {   // grid y = operand set: partials [z][phase][split][Cout][Kpad]
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64), nz), dim3(256), 0, stream,
-                       workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0,
-                       (int64_t)nphase * nsplit * per, zs_dw);
-  }
-  rc = check_launch("reduce_partials");
-  if (rc || !db) return rc;
-  // bias gradient: every (phase, split) partial covers a disjoint pixel set
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((Cout + 63) / 64), dim3(256), 0, stream, a.db_partial, db,
-                     (int64_t)Cout, nsplit * nphase, (int64_t)Cout, 0, (int64_t)0, (int64_t)0);
-  return check_launch("reduce_partials(bias)");
+  return wgrad_reduce(a, workspace, dw_packed, db, nphase, nsplit, nz, zs_dw, stream);
 }
 
 // embed_sum[d][k] = sum over vectors n with idx[n] == k of z[n][d]  ==  z^T @ onehot(idx)

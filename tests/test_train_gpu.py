@@ -298,3 +298,51 @@ def test_bench_two_ranks_dry_run():
     dp = line["vqvae_training_dp"]
     assert "error" not in dp, dp
     assert dp["n_gpus"] == 2 and dp["global_batch"] == 8 and dp["ranks_in_sync"] is True
+
+
+@pytest.mark.parametrize("shape", [
+    # (Cin, Cout, k, stride, transposed, B, H, W of the layer INPUT, channels of the first source when two)
+    (128, 128, 3, 1, False, 3, 4, 64, 0),     # four channel groups x one input-channel slice, 4 units
+    (128, 32, 3, 1, False, 2, 6, 32, 0),      # residual 3x3: one workgroup unit covers the whole gradient
+    (64, 128, 3, 1, False, 2, 4, 32, 32),     # concatenated input (two sources)
+    (64, 64, 3, 1, False, 2, 2, 96, 0),       # two channel groups x two slices; 3 tiles per row
+    (64, 128, 4, 2, False, 2, 8, 64, 0),      # k4 s2: two tap groups, de-interleaved halo columns
+    (128, 64, 4, 2, False, 2, 4, 128, 0),
+    (128, 64, 4, 2, True, 2, 4, 32, 0),       # transposed: the adjoint stride-2 convolution, roles swapped
+    (64, 64, 4, 2, True, 3, 2, 32, 0),
+])
+def test_weight_gradient_halo_kernel(shape):
+    """The halo-staged weight-gradient kernel (`conv_wgrad_halo_kernel`: transposing LDS reads, every tap from one
+    staged window) against the per-tap kernel it replaces and against fp64 autograd; bias gradients included."""
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.vqvae import _train
+    from interactive_spectrogram_inpainting.vqvae.encoder_decoder import _ConvParams
+    cin, cout, k, s, tr, B, H, W, c0 = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(sum(shape))
+    layer = _ConvParams(cin, cout, k, s, 1, transposed=tr)
+    x = torch.randn(B, H, W, cin, generator=g).permute(0, 3, 1, 2)
+    if tr:
+        OH, OW = 2 * H, 2 * W
+    else:
+        OH, OW = (H + 2 - k) // s + 1, (W + 2 - k) // s + 1
+    dy = torch.randn(B, OH, OW, cout, generator=g)
+    w64 = layer.weight.detach().double().requires_grad_(True)
+    b64 = layer.bias.detach().double().requires_grad_(True)
+    f = torch.nn.functional.conv_transpose2d if tr else torch.nn.functional.conv2d
+    y = f(x.double(), w64, b64, stride=s, padding=1)
+    (y * dy.permute(0, 3, 1, 2).double()).sum().backward()
+    layer = layer.to(dev)
+    xd, dyd = x.to(dev), dy.to(dev)
+    if c0:
+        a = xd[:, :c0].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        b = xd[:, c0:].permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+        args = (a, dyd, b)
+    else:
+        args = (xd.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2), dyd)
+    dw, db = _train.conv_wgrad(layer, *args)
+    with _hip.knob("ISI_NO_WGRAD_HALO", 1):
+        dw_old, db_old = _train.conv_wgrad(layer, *args)
+    assert _rel(dw, w64.grad) < 2e-5 and _rel(dw_old, w64.grad) < 2e-5, (_rel(dw, w64.grad), _rel(dw_old, w64.grad))
+    assert _rel(dw, dw_old) < 1e-5
+    assert _rel(db, b64.grad) < 1e-5 and _rel(db_old, b64.grad) < 1e-5

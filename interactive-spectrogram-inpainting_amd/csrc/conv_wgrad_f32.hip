@@ -577,15 +577,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
     for (int ks = 0; ks < 2 * R; ++ks) {
       const int r = ks >> 1, kc = ks & 1;
       const s16x8 ah = frag(Ab + (r * OWT + kc * 16) * 64), al = frag(Ab + DPL + (r * OWT + kc * 16) * 64);
+      // one kernel row (KWT taps) at a time: the three products of a tap go to the same accumulator, so they are
+      // issued KWT matrix instructions apart (a dependent MFMA would wait for the previous one's 16 passes)
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const int khl = t / KWT, kwl = t % KWT;
-        const int col = S == 1 ? kc * 16 + kwl : (kwl & 1) * HCH + kc * 16 + (kwl >> 1);
-        const int off = ((r * S + khl) * HC + col) * 64;
-        const s16x8 bh = frag(Bb + off), bl = frag(Bb + XPL + off);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc[t], 0, 0, 0);
+      for (int khl = 0; khl < KHG; ++khl) {
+        s16x8 bh[KWT], bl[KWT];
+#pragma unroll
+        for (int kwl = 0; kwl < KWT; ++kwl) {
+          const int col = S == 1 ? kc * 16 + kwl : (kwl & 1) * HCH + kc * 16 + (kwl >> 1);
+          const int off = ((r * S + khl) * HC + col) * 64;
+          bh[kwl] = frag(Bb + off);
+          bl[kwl] = frag(Bb + XPL + off);
+        }
+#pragma unroll
+        for (int kwl = 0; kwl < KWT; ++kwl)
+          acc[khl * KWT + kwl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[kwl]), acc[khl * KWT + kwl], 0, 0, 0);
+#pragma unroll
+        for (int kwl = 0; kwl < KWT; ++kwl)
+          acc[khl * KWT + kwl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[kwl]), acc[khl * KWT + kwl], 0, 0, 0);
+#pragma unroll
+        for (int kwl = 0; kwl < KWT; ++kwl)
+          acc[khl * KWT + kwl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              __builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[kwl]), acc[khl * KWT + kwl], 0, 0, 0);
       }
     }
   };
@@ -634,25 +649,59 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
   }
 }
 
-// out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree)
+// out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree).  A thread owns
+// four consecutive elements (16-byte loads when the rows allow it) and keeps four loads in flight.
+template <bool VEC>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
                                                               float *__restrict__ out, int64_t n, int nsplit,
                                                               int64_t stride, int accumulate, int64_t zs_partial,
                                                               int64_t zs_out) {
-  __shared__ float red[4][64];
+  __shared__ float4 red[4][64];
   partial += (size_t)blockIdx.y * zs_partial;   // grid y: independent reductions
   out += (size_t)blockIdx.y * zs_out;
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + e;
-  float s = 0.f;
-  if (i < n)
-    for (int k = g; k < nsplit; k += 4) s += partial[(size_t)k * stride + i];
+  const int64_t i = ((int64_t)blockIdx.x * 64 + e) * 4;
+  auto ld = [&](int k) -> float4 {
+    const float *q = partial + (size_t)k * stride + i;
+    if constexpr (VEC) return *reinterpret_cast<const float4 *>(q);
+    return make_float4(q[0], i + 1 < n ? q[1] : 0.f, i + 2 < n ? q[2] : 0.f, i + 3 < n ? q[3] : 0.f);
+  };
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n) {
+    int k = g;
+    for (; k + 12 < nsplit; k += 16) {   // same order of additions as the one-at-a-time loop below
+      const float4 a = ld(k), b = ld(k + 4), c = ld(k + 8), d = ld(k + 12);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+      s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; k < nsplit; k += 4) {
+      const float4 a = ld(k);
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+  }
   red[g][e] = s;
   __syncthreads();
   if (g == 0 && i < n) {
-    const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-    out[i] = accumulate ? out[i] + t : t;
+    const float4 a = red[0][e], b = red[1][e], c = red[2][e], d = red[3][e];
+    const float t[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                        (a.w + b.w) + (c.w + d.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i + j < n) out[i + j] = accumulate ? out[i + j] + t[j] : t[j];
   }
+}
+// every row start 16-byte aligned and whole quads: the vector form
+static void launch_reduce_partials(const float *partial, float *out, int64_t n, int nsplit, int64_t stride,
+                                   int accumulate, int64_t zs_partial, int64_t zs_out, int ny, hipStream_t stream) {
+  const bool vec = (n % 4 == 0) && (stride % 4 == 0) && (zs_partial % 4 == 0) &&
+                   (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
+  const dim3 grid((unsigned)((n + 255) / 256), ny);
+  if (vec) hipLaunchKernelGGL(reduce_partials_kernel<true>, grid, dim3(256), 0, stream, partial, out, n, nsplit, stride,
+                              accumulate, zs_partial, zs_out);
+  else hipLaunchKernelGGL(reduce_partials_kernel<false>, grid, dim3(256), 0, stream, partial, out, n, nsplit, stride,
+                          accumulate, zs_partial, zs_out);
 }
 
 static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -681,9 +730,10 @@ static int wgrad_nsplit_tile(int Cout, int Kpad, int M, int nphase, int nz, cons
 static int wgrad_nsplit(int Cout, int Kpad, int M, int nphase, int nz, bool split_kernel) {
   return wgrad_nsplit_tile(Cout, Kpad, M, nphase, nz, split_kernel ? wgrad_tile(Cout, Kpad) : WgradTile{128, 128, 0});
 }
-// pixel splits of the halo-staged kernel: ~2 workgroups per CU over its `units` (channel block, tap group) pairs
+// pixel splits of the halo-staged kernel: its register budget (accumulators of 8-9 taps) admits one workgroup per
+// CU, so one workgroup per CU over its `units` (channel block, tap group) pairs -- more splits only add partials
 static int wgrad_halo_nsplit(int units, int ntiles) {
-  return std::max(1, std::min(std::min(256, 512 / std::max(1, units)), ntiles / 4));
+  return std::max(1, std::min(256 / std::max(1, std::min(units, 256)), ntiles / 4));
 }
 size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, int nz) {
   const int Kpad = (int)round_up(K, kBK);
@@ -723,15 +773,13 @@ static int wgrad_reduce(const WgradKArgs &a, float *workspace, float *dw_packed,
                         int nz, int64_t zs_dw, hipStream_t stream) {
   const int64_t per = (int64_t)a.Cout * a.Kpad;
   for (int ph = 0; ph < nphase; ++ph) {   // grid y = operand set
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64), nz), dim3(256), 0, stream,
-                       workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0,
-                       (int64_t)nphase * nsplit * per, zs_dw);
+    launch_reduce_partials(workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0,
+                           (int64_t)nphase * nsplit * per, zs_dw, nz, stream);
   }
   int rc = check_launch("reduce_partials");
   if (rc || !db) return rc;
   // bias gradient: every (phase, split) partial covers a disjoint pixel set
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((a.Cout + 63) / 64), dim3(256), 0, stream, a.db_partial, db,
-                     (int64_t)a.Cout, nsplit * nphase, (int64_t)a.Cout, 0, (int64_t)0, (int64_t)0);
+  launch_reduce_partials(a.db_partial, db, (int64_t)a.Cout, nsplit * nphase, (int64_t)a.Cout, 0, 0, 0, 1, stream);
   return check_launch("reduce_partials(bias)");
 }
 
@@ -902,8 +950,7 @@ int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, fl
   int rc = check_launch("vq_embed_sum(wgrad)");
   if (rc) return rc;
   const int64_t per = (int64_t)D * K;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)((per + 63) / 64)), dim3(256), 0, stream, workspace,
-                     embed_sum_dk, per, nsplit, per, 0, (int64_t)0, (int64_t)0);
+  launch_reduce_partials(workspace, embed_sum_dk, per, nsplit, per, 0, 0, 0, 1, stream);
   return check_launch("vq_embed_sum(reduce)");
 }
 

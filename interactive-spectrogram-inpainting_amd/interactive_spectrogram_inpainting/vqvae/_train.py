@@ -45,8 +45,13 @@ def _s(t):
 TRAIN_PRECISION = {"f32": 0, "bf16x6": 2}[os.environ.get("ISI_TRAIN_PRECISION", "bf16x6")]
 # Products of the training step's FORWARD convolutions: 'f16x3' = the eval path's three-term split-f16 products
 # (fp32-grade, half the matrix work of the six-term bf16 split; operands are activations and weights, whose range the
-# f16 pieces cover -- gradients are not: the input-gradient convolutions keep TRAIN_PRECISION); 'same' = TRAIN_PRECISION.
+# f16 pieces cover -- gradients are not: the input-gradient convolutions use DGRAD_PRECISION below); 'same' = TRAIN_PRECISION.
 FWD_PRECISION = {"same": TRAIN_PRECISION, "f16x3": 3 if TRAIN_PRECISION else 0}[os.environ.get("ISI_TRAIN_FWD_PRECISION", "f16x3")]
+# Products of the INPUT-gradient convolutions (dX = dY * W^T): three-term split-bf16 by default, like the weight
+# gradients and the prior's input-gradient GEMMs (priors/_ops.py LINEAR_GRAD_PRECISION): a relative error of ~2^-16
+# per product, measured against the fp64 gradients in tests/test_train_gpu.py (bar 2e-4), at half the matrix work of
+# the six-term split ('same' = TRAIN_PRECISION).  bf16 pieces: gradients are not range-limited like the f16 split.
+DGRAD_PRECISION = {"same": TRAIN_PRECISION, "bf16x3": 1 if TRAIN_PRECISION else 0}[os.environ.get("ISI_TRAIN_DGRAD_PRECISION", "bf16x3")]
 # Products of the weight-gradient GEMMs (flag bits of isi_conv_wgrad_f32's `transposed` word): three-term split by
 # default (relative error ~4e-6 of the gradient's maximum, far below the step-to-step noise of training and 50x
 # inside the parity tests' 2e-4), 'bf16x6' = fp32-grade, 'f32' = fp32 matrix pipe.
@@ -167,12 +172,12 @@ def conv_dgrad(dw: _DgradWeights, layer: _ConvParams, dy: torch.Tensor,
     packed = dw.get(layer)
     cin = layer.in_channels
     if layer.transposed:
-        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False, bf16x3=TRAIN_PRECISION)
+        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False, bf16x3=DGRAD_PRECISION)
     if layer.stride == 2:
-        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False, bf16x3=TRAIN_PRECISION)
+        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False, bf16x3=DGRAD_PRECISION)
     k = layer.kernel_size
     return _ops.conv2d(dy, packed, None, cin, k, 1, k - 1 - layer.padding, relu=False, residual_bchw=residual,
-                       bf16x3=TRAIN_PRECISION)
+                       bf16x3=DGRAD_PRECISION)
 
 
 def _set_wb(grads, layer: _ConvParams, wb) -> None:

@@ -239,7 +239,10 @@ __device__ __forceinline__ void split4(const float a, const float b, const float
 // Tile variants (round 3): the 128 x 128 tile wastes 3/4 of its matrix work and LDS traffic on the residual blocks'
 // 32-channel sides (3x3 128->32: Cout = 32; 1x1 32->128: K = 32), which are 16 of the step's 29 launches.  WR x WC
 // waves (WR * WC = 4), each owning MT x NT 32 x 32 accumulator tiles: tile = (WR MT 32) channels x (WC NT 32) k.
-template <int NP, int WR, int MT, int NT>   // NP 2: three-term split, 3: six-term split
+// ONEHOT (vq_embed_sum): the "im2col" operand is the one-hot matrix of p.onehot_idx, generated while staging; it is
+// exact in its hi piece, so with NP = 3 (dY = hi + mid + lo exactly) the three products against that piece give the
+// exact fp32 terms -- the codebook's segment sums on the bf16 pipe instead of the fp32 one.
+template <int NP, int WR, int MT, int NT, bool ONEHOT = false>   // NP 2: three-term split, 3: six-term split
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs p) {
   constexpr int WC = 4 / WR, TCO = WR * MT * 32, TK = WC * NT * 32, JX = (TK + 127) / 128;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -310,6 +313,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
       unsigned doff = OOB;
       if (mv && covalid) doff = (unsigned)(dy_off + b * p.dn + oy * p.dh + ox * p.dw + co) * 4u;
       rdq[j] = buf_load4(rd, doff);
+      if constexpr (ONEHOT) {
+        const int code = mv ? (int)p.onehot_idx[m] : -1;
+#pragma unroll
+        for (int q = 0; q < JX; ++q) {
+          const int kk = k0 + (sq + 32 * q) * 4;
+          rxq[q][j] = make_float4(code == kk ? 1.f : 0.f, code == kk + 1 ? 1.f : 0.f, code == kk + 2 ? 1.f : 0.f,
+                                  code == kk + 3 ? 1.f : 0.f);
+        }
+      } else
 #pragma unroll
       for (int q = 0; q < JX; ++q) {
         unsigned xoff = OOB;
@@ -403,7 +415,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[i][qa]),
                                                                 __builtin_bit_cast(bf16x8, bv[j][qb]), acc[i][j], 0, 0, 0);
       };
-      if constexpr (NP == 3) {   // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
+      if constexpr (ONEHOT) {    // the one-hot operand has no mid / lo piece
+        static_assert(!ONEHOT || NP == 3, "exact segment sums need the three-piece split");
+        term(1, 0); term(2, 0); term(0, 0);
+      } else if constexpr (NP == 3) {   // smallest terms first: lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi
         term(1, 0); term(0, 1); term(2, 2); term(2, 0); term(0, 2); term(0, 0);
       } else {
         term(1, 0); term(0, 1); term(0, 0);
@@ -748,18 +763,18 @@ size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
   return conv_wgrad_batched_workspace_floats(Cout, K, M, nphase, 1);
 }
 
-template <int NP, int WR, int MT, int NT>
+template <int NP, int WR, int MT, int NT, bool ONEHOT = false>
 static void launch_wgrad_split(const WgradKArgs &a, int nzs, hipStream_t stream) {
   constexpr int WC = 4 / WR, TCO = WR * MT * 32, TK = WC * NT * 32;
   constexpr size_t smem = (size_t)NP * (TCO + TK) * LDB * sizeof(unsigned short) + 8 * TCO * sizeof(float);
   static DeviceOnce attr_set;
   if (smem > 48 * 1024 && !attr_set.done()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_split_kernel<NP, WR, MT, NT>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_split_kernel<NP, WR, MT, NT, ONEHOT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set.mark();
   }
   dim3 grid((a.Cout + TCO - 1) / TCO, (a.Kpad + TK - 1) / TK, nzs);
-  hipLaunchKernelGGL((conv_wgrad_split_kernel<NP, WR, MT, NT>), grid, dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((conv_wgrad_split_kernel<NP, WR, MT, NT, ONEHOT>), grid, dim3(256), smem, stream, a);
 }
 template <int NP>
 static void launch_wgrad_split_np(const WgradKArgs &a, const WgradTile &t, int nzs, hipStream_t stream) {
@@ -921,7 +936,10 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
 // embed_sum[d][k] = sum over vectors n with idx[n] == k of z[n][d]  ==  z^T @ onehot(idx)
 // (bottleneck.py:83), as the same pixel-reduction GEMM with the one-hot operand generated on the fly.
 // out: [D][K] like the reference's `embed_avg`; deterministic.
-size_t vq_embed_sum_workspace_floats(int D, int K, int64_t N) { return conv_wgrad_workspace_floats(D, K, (int)N, 1); }
+size_t vq_embed_sum_workspace_floats(int D, int K, int64_t N) {
+  (void)N;
+  return (size_t)256 * D * K;   // at most 256 pixel splits of [D][K] partials
+}
 
 int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, float *workspace,
                      size_t workspace_floats, int64_t N, int D, int K, hipStream_t stream) {
@@ -936,17 +954,16 @@ int vq_embed_sum_f32(const float *z, const int64_t *idx, float *embed_sum_dk, fl
   a.dn = 0; a.dh = 0; a.dw = D;           // "pixels" = vectors: one row of N
   a.H = 1; a.W = (int)N; a.OH = 1; a.OW = (int)N; a.Cout = D; a.K = K; a.Kpad = K;
   a.KW = 1; a.stride = 1; a.pad = 0; a.M = (int)N;
-  const int tiles = ((D + 127) / 128) * ((K + 127) / 128);
+  // split-bf16 kernel with exact pieces (see ONEHOT above); tile 64 x 256 for the usual 64-dimensional codes
+  const int tco = D <= 64 ? 64 : 128, tk = D <= 64 ? 256 : 128;
+  const int tiles = ((D + tco - 1) / tco) * ((K + tk - 1) / tk);
   const int nchunks = (a.M + 31) / 32;
   int nsplit = std::min(256, std::max(1, 768 / tiles));
   nsplit = std::min(nsplit, std::max(1, nchunks / 8));
-  a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
+  a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit; a.nz = 1;
   if (workspace_floats < (size_t)nsplit * D * K) { set_last_error("vq_embed_sum: workspace too small"); return ISI_E_WORKSPACE; }
-  constexpr size_t smem = (size_t)4 * 32 * LDT * sizeof(float);
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_f32_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-    return check_launch("hipFuncSetAttribute(conv_wgrad)");
-  hipLaunchKernelGGL(conv_wgrad_f32_kernel, dim3((D + 127) / 128, (K + 127) / 128, nsplit), dim3(256), smem, stream, a);
+  if (D <= 64) launch_wgrad_split<3, 1, 2, 2, true>(a, nsplit, stream);
+  else launch_wgrad_split<3, 2, 2, 2, true>(a, nsplit, stream);
   int rc = check_launch("vq_embed_sum(wgrad)");
   if (rc) return rc;
   const int64_t per = (int64_t)D * K;

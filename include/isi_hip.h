@@ -270,6 +270,15 @@ int isi_conv_wgrad_f32(const isi_src *src0, const isi_src *src1, const float *dy
                        float *dw_packed, float *db, float *workspace, size_t workspace_floats,
                        int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                        int transposed, void *stream);
+/* The same gradient written in torch's weight layout [Cout][cin_keep][KH][KW] (the parameter's own `.grad`
+ * storage: no packed intermediate, no permuting copy): the k padding and the input channels >= cin_keep (a source
+ * zero-padded to a multiple of 4 channels) are dropped.  Plain convolutions only (bit 0 of `flags` clear); a
+ * ConvTranspose2d's gradient is the adjoint stride-2 convolution's with the roles of input and output gradient
+ * swapped (train_vqvae.py:181 via autograd; vqvae/_train.py conv_wgrad). */
+int isi_conv_wgrad_torch_f32(const isi_src *src0, const isi_src *src1, const float *dy,
+                             float *dw_torch, int cin_keep, float *db, float *workspace,
+                             size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
+                             int stride, int pad, int flags, void *stream);
 /* dy *= (y > 0) : ReLU backward through an output rectified in the producer's epilogue. */
 int isi_relu_bwd_f32(float *dy, const float *y, int64_t n, void *stream);
 /* a += alpha * b */

@@ -666,11 +666,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
 
 // out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree).  A thread owns
 // four consecutive elements (16-byte loads when the rows allow it) and keeps four loads in flight.
+// `map` (optional): the summed [Cout][Kpad] matrix (k = tap * cin + ci) is written in torch's weight layout
+// [Cout][keep][taps] instead, dropping the k padding and the channels ci >= keep (zero-padded input channels).
+struct WgradOutMap { int K, Kpad, cin, taps, keep; };
 template <bool VEC>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
                                                               float *__restrict__ out, int64_t n, int nsplit,
                                                               int64_t stride, int accumulate, int64_t zs_partial,
-                                                              int64_t zs_out) {
+                                                              int64_t zs_out, const WgradOutMap map) {
   __shared__ float4 red[4][64];
   partial += (size_t)blockIdx.y * zs_partial;   // grid y: independent reductions
   out += (size_t)blockIdx.y * zs_out;
@@ -702,6 +705,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
     const float4 a = red[0][e], b = red[1][e], c = red[2][e], d = red[3][e];
     const float t[4] = {(a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
                         (a.w + b.w) + (c.w + d.w)};
+    if (map.Kpad) {
+      const int co = (int)(i / map.Kpad), k = (int)(i - (int64_t)co * map.Kpad);   // Kpad % 4 == 0: one row per quad
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int tap = (k + j) / map.cin, ci = (k + j) - tap * map.cin;
+        if (k + j < map.K && ci < map.keep) out[((size_t)co * map.keep + ci) * map.taps + tap] = t[j];
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (i + j < n) out[i + j] = accumulate ? out[i + j] + t[j] : t[j];
@@ -709,14 +721,15 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
 }
 // every row start 16-byte aligned and whole quads: the vector form
 static void launch_reduce_partials(const float *partial, float *out, int64_t n, int nsplit, int64_t stride,
-                                   int accumulate, int64_t zs_partial, int64_t zs_out, int ny, hipStream_t stream) {
+                                   int accumulate, int64_t zs_partial, int64_t zs_out, int ny, hipStream_t stream,
+                                   const WgradOutMap map = WgradOutMap{0, 0, 0, 0, 0}) {
   const bool vec = (n % 4 == 0) && (stride % 4 == 0) && (zs_partial % 4 == 0) &&
                    (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
   const dim3 grid((unsigned)((n + 255) / 256), ny);
   if (vec) hipLaunchKernelGGL(reduce_partials_kernel<true>, grid, dim3(256), 0, stream, partial, out, n, nsplit, stride,
-                              accumulate, zs_partial, zs_out);
+                              accumulate, zs_partial, zs_out, map);
   else hipLaunchKernelGGL(reduce_partials_kernel<false>, grid, dim3(256), 0, stream, partial, out, n, nsplit, stride,
-                          accumulate, zs_partial, zs_out);
+                          accumulate, zs_partial, zs_out, map);
 }
 
 static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -785,11 +798,13 @@ static void launch_wgrad_split_np(const WgradKArgs &a, const WgradTile &t, int n
 
 // partial layout: [z][phase][split][Cout][Kpad] -> out [phase][Cout][Kpad]; bias partials [phase * split][Cout]
 static int wgrad_reduce(const WgradKArgs &a, float *workspace, float *dw_packed, float *db, int nphase, int nsplit,
-                        int nz, int64_t zs_dw, hipStream_t stream) {
+                        int nz, int64_t zs_dw, hipStream_t stream, int torch_keep = 0) {
   const int64_t per = (int64_t)a.Cout * a.Kpad;
+  WgradOutMap map{0, 0, 0, 0, 0};
+  if (torch_keep > 0) map = WgradOutMap{a.K, a.Kpad, a.Cin, a.K / a.Cin, torch_keep};
   for (int ph = 0; ph < nphase; ++ph) {   // grid y = operand set
     launch_reduce_partials(workspace + (size_t)ph * nsplit * per, dw_packed + (size_t)ph * per, per, nsplit, per, 0,
-                           (int64_t)nphase * nsplit * per, zs_dw, nz, stream);
+                           (int64_t)nphase * nsplit * per, zs_dw, nz, stream, map);
   }
   int rc = check_launch("reduce_partials");
   if (rc || !db) return rc;
@@ -819,9 +834,9 @@ static int launch_wgrad_halo(const WgradKArgs &a, int units, int nsplit, hipStre
 // of the layer output, dense channels-last [B, OH(, *2), OW(, *2), Cout].
 int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                    float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
-                   int stride, int pad, int transposed, hipStream_t stream) {
+                   int stride, int pad, int transposed, hipStream_t stream, int torch_keep) {
   return conv_wgrad_batched_f32(s0, s1, dy, dw_packed, db, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride,
-                                pad, transposed, 1, 0, 0, 0, stream);
+                                pad, transposed, 1, 0, 0, 0, stream, torch_keep);
 }
 
 // nz independent weight-gradient GEMMs of one shape in a single launch: pair z reads x at s0->ptr + z * zs_x0
@@ -829,8 +844,9 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
 int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                            float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                            int stride, int pad, int transposed, int nz, int64_t zs_x0, int64_t zs_dy, int64_t zs_dw,
-                           hipStream_t stream) {
+                           hipStream_t stream, int torch_keep) {
   if (!s0 || !s0->ptr || !dy || !dw_packed || !workspace) return invalid("conv_wgrad: null pointer");
+  if (torch_keep && ((transposed & 1) || nz != 1)) return unsupported("conv_wgrad: torch-layout output is for plain convolutions");
   if (nz < 1 || nz > 255) return invalid("conv_wgrad: bad batch count");
   if (nz > 1 && ((s1 && s1->ptr) || db)) return unsupported("conv_wgrad: batched launches take one source and no bias");
   if (nz > 1 && ((zs_x0 | zs_dy | zs_dw) & 3)) return invalid("conv_wgrad: batch strides must be multiples of 4 floats");
@@ -911,7 +927,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
     else { if (nco == 4) ISI_HALO(4, 2, 2, 4); else if (nco == 2) ISI_HALO(2, 2, 2, 4); else ISI_HALO(1, 2, 2, 4); }
 #undef ISI_HALO
     if (rc_h) return rc_h;
-    return wgrad_reduce(a, workspace, dw_packed, db, 1, ns, 1, 0, stream);
+    return wgrad_reduce(a, workspace, dw_packed, db, 1, ns, 1, 0, stream, torch_keep);
   }
   if (use_split) {
     if (prec_flags & ISI_CONV_BF16X6) launch_wgrad_split_np<3>(a, tile, nz * nphase * nsplit, stream);
@@ -930,7 +946,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   }
   int rc = check_launch("conv_wgrad_f32");
   if (rc) return rc;
-  return wgrad_reduce(a, workspace, dw_packed, db, nphase, nsplit, nz, zs_dw, stream);
+  return wgrad_reduce(a, workspace, dw_packed, db, nphase, nsplit, nz, zs_dw, stream, torch_keep);
 }
 
 // embed_sum[d][k] = sum over vectors n with idx[n] == k of z[n][d]  ==  z^T @ onehot(idx)

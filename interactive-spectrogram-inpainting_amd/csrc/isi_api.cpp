@@ -254,6 +254,13 @@ int isi_conv_wgrad_f32(const isi_src *src0, const isi_src *src1, const float *dy
   return conv_wgrad_f32(src0, src1, dy, dw_packed, db, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride,
                         pad, transposed, S(stream));
 }
+int isi_conv_wgrad_torch_f32(const isi_src *src0, const isi_src *src1, const float *dy, float *dw_torch, int cin_keep,
+                             float *db, float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH,
+                             int KW, int stride, int pad, int flags, void *stream) {
+  if (cin_keep < 1) return ISI_E_INVALID;
+  return conv_wgrad_f32(src0, src1, dy, dw_torch, db, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride, pad,
+                        flags, S(stream), cin_keep);
+}
 int isi_relu_bwd_f32(float *dy, const float *y, int64_t n, void *stream) { return relu_bwd_f32(dy, y, n, S(stream)); }
 int isi_axpy_f32(float *a, const float *b, float alpha, int64_t n, void *stream) {
   return axpy_f32(a, b, alpha, n, S(stream));

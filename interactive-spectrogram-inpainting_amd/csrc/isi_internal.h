@@ -114,11 +114,11 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
 size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
 int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                    float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
-                   int stride, int pad, int transposed, hipStream_t stream);
+                   int stride, int pad, int transposed, hipStream_t stream, int torch_keep = 0);
 int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                            float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                            int stride, int pad, int transposed, int nz, int64_t zs_x0, int64_t zs_dy, int64_t zs_dw,
-                           hipStream_t stream);
+                           hipStream_t stream, int torch_keep = 0);
 size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, int nz);
 size_t vq_embed_sum_workspace_floats(int D, int K, int64_t N);
 int relu_bwd_f32(float *dy, const float *y, int64_t n, hipStream_t st);

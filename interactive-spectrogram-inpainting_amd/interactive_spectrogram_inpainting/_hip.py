@@ -179,6 +179,9 @@ SIGNATURES = {
     "isi_conv_wgrad_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "isi_conv_wgrad_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, _P, _P, C.c_size_t, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_conv_wgrad_torch_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.c_int, _P, _P,
+                                           C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, C.c_int, _P]),
     "isi_relu_bwd_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "isi_axpy_f32": (C.c_int, [_P, _P, C.c_float, C.c_int64, _P]),
     "isi_vq_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),

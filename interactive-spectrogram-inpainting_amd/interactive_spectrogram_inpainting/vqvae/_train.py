@@ -91,9 +91,12 @@ def colsum(x2d: torch.Tensor) -> torch.Tensor:
 
 
 def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
-               x2: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+               x2: Optional[torch.Tensor] = None,
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(weight gradient in torch layout, bias gradient).  x (and x2): layer input(s) as
-    [B,C,H,W] views; dy_nhwc: dense [B,OH,OW,Cout].
+    [B,C,H,W] views; dy_nhwc: dense [B,OH,OW,Cout].  `out` = (weight-shaped, bias-shaped) dense tensors that receive
+    the gradients directly (the parameters' slots of the flat gradient buffer: the split reduction writes torch's
+    layout itself, no packed intermediate and no permuting copy; ungrouped layers).
 
     A transposed convolution is the adjoint of the stride-2 convolution with the SAME
     weight tensor ([Cin_T, Cout_T, 4, 4] read as [out, in, 4, 4]), so its weight gradient
@@ -125,10 +128,20 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
     M = B * OH * OW
     nws = L.isi_conv_wgrad_workspace_floats(rows, K, M, 1)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
-    packed = torch.empty(rows, Kpad, dtype=torch.float32, device=x.device)
-    db = None if tr else torch.empty(rows, dtype=torch.float32, device=x.device)
     s0 = _hip.src_nchw_view(src)
     s1 = _hip.src_nchw_view(x2) if (x2 is not None and not tr) else None
+    if out is not None and layer.groups == 1 and out[0].is_contiguous() and out[1].is_contiguous():
+        dw, db = out
+        assert dw.shape == layer.weight.shape and db.shape == layer.bias.shape
+        rc = L.isi_conv_wgrad_torch_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
+                                        dw.data_ptr(), cin_true, None if tr else db.data_ptr(), ws.data_ptr(), nws,
+                                        B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
+        _hip.check(rc, "isi_conv_wgrad_torch_f32")
+        if tr:
+            db.copy_(colsum(dy_nhwc.reshape(-1, dy_nhwc.shape[-1])))
+        return dw, db
+    packed = torch.empty(rows, Kpad, dtype=torch.float32, device=x.device)
+    db = None if tr else torch.empty(rows, dtype=torch.float32, device=x.device)
     rc = L.isi_conv_wgrad_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
                               packed.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(), nws,
                               B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
@@ -185,6 +198,11 @@ def _set_wb(grads, layer: _ConvParams, wb) -> None:
     grads.set(layer.bias, wb[1])
 
 
+def _wgrad_into(grads, layer: _ConvParams, x, dy_nhwc, x2=None) -> None:
+    """Weight and bias gradient of `layer`, written by the kernels straight into the flat gradient buffer."""
+    _set_wb(grads, layer, conv_wgrad(layer, x, dy_nhwc, x2=x2, out=(grads.view(layer.weight), grads.view(layer.bias))))
+
+
 class Tape:
     """Activations kept by the train-mode forward."""
 
@@ -227,9 +245,15 @@ class Grads:
             self.bucket_left[b] += 1
         self.handles = []
 
+    def view(self, p: torch.nn.Parameter) -> torch.Tensor:
+        """The parameter's slot of the flat buffer (kernels may write the gradient there themselves; `set` with
+        that very tensor then only does the bucket accounting)."""
+        return self.views[self.index[id(p)]]
+
     def set(self, p: torch.nn.Parameter, g: torch.Tensor) -> None:
         i = self.index[id(p)]
-        self.views[i].copy_(g.reshape(self.views[i].shape))
+        if g is not self.views[i]:
+            self.views[i].copy_(g.reshape(self.views[i].shape))
         b = self.bucket_of[i]
         self.bucket_left[b] -= 1
         if self.world > 1 and self.bucket_left[b] == 0:
@@ -293,10 +317,10 @@ def _res_stack_backward(blocks, idxs, tape, tag, d_y, x_in_key, dw, grads: Grads
         r = tape[f"{tag}.res{j - 1}.y"] if j > 0 else tape[x_in_key]
         g = relu_bwd_(d_y, _nhwc(y))                                   # through relu(r + conv1(h))
         c1, c3 = blk.conv[3], blk.conv[1]
-        _set_wb(grads, c1, conv_wgrad(c1, h, g))
+        _wgrad_into(grads, c1, h, g)
         dh = _nhwc(conv_dgrad(dw, c1, _as_bchw(g)))
         relu_bwd_(dh, _nhwc(h))
-        _set_wb(grads, c3, conv_wgrad(c3, r, dh))
+        _wgrad_into(grads, c3, r, dh)
         d_y = _nhwc(conv_dgrad(dw, c3, _as_bchw(dh), residual=_as_bchw(g)))   # + skip connection
     return d_y
 
@@ -307,13 +331,13 @@ def encoder_backward(m: RosinalityEncoder, tape: Tape, tag: str, d_out, dw, grad
     c3 = m.blocks[m._conv3]
     g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
     prev = tape[f"{tag}.down{len(m._down) - 1}"]
-    _set_wb(grads, c3, conv_wgrad(c3, prev, g))
+    _wgrad_into(grads, c3, prev, g)
     d = _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
     for j in reversed(range(len(m._down))):
         layer = m.blocks[m._down[j]]
         g = relu_bwd_(d, _nhwc(tape[f"{tag}.down{j}"]))
         prev = tape[f"{tag}.down{j - 1}"] if j > 0 else tape[f"{tag}.in"]
-        _set_wb(grads, layer, conv_wgrad(layer, prev, g))
+        _wgrad_into(grads, layer, prev, g)
         if j > 0 or need_input_grad:
             d = _nhwc(conv_dgrad(dw, layer, _as_bchw(g)))
     return d if need_input_grad else None
@@ -330,12 +354,12 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
         if not last:
             g = relu_bwd_(g, _nhwc(tape[f"{tag}.up{j}"]))   # g is our own dgrad output here
         prev = tape[f"{tag}.up{j - 1}"] if j > 0 else tape[f"{tag}.res{len(m._res) - 1}.y" if m._res else f"{tag}.c3"]
-        _set_wb(grads, layer, conv_wgrad(layer, prev, g))
+        _wgrad_into(grads, layer, prev, g)
         d_view = conv_dgrad(dw, layer, _as_bchw(g))
     d = _res_stack_backward(m.blocks, m._res, tape, tag, _nhwc(d_view), f"{tag}.c3", dw, grads)
     c3 = m.blocks[0]
     g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
-    _set_wb(grads, c3, conv_wgrad(c3, tape[f"{tag}.in"], g, x2=tape[f"{tag}.in2"]))
+    _wgrad_into(grads, c3, tape[f"{tag}.in"], g, x2=tape[f"{tag}.in2"])
     return _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
 
 
@@ -509,14 +533,14 @@ class VQVAETrainFunction(torch.autograd.Function):
         for j in reversed(range(len(model.upsample_top_to_bottom))):
             layer = model.upsample_top_to_bottom[j]
             g = _nhwc(d_view)
-            _set_wb(grads, layer, conv_wgrad(layer, tape[f"up.in{j}"], g))
+            _wgrad_into(grads, layer, tape[f"up.in{j}"], g)
             d_view = conv_dgrad(dw, layer, _as_bchw(g))
         d_qt = _nhwc(d_view).clone()
         # bottom quantiser and its 1x1 conv on cat(dec_t, enc_b)
         unq = model.disable_quantization
         d_zb = d_qb.contiguous() if unq else vq_backward(d_qb, tape["z_b"], tape["q_b"], g_diff)
         qcb = model.quantize_conv_b
-        _set_wb(grads, qcb, conv_wgrad(qcb, tape["dec_t"], d_zb, x2=tape["enc_b"]))
+        _wgrad_into(grads, qcb, tape["dec_t"], d_zb, x2=tape["enc_b"])
         d_cat2 = conv_dgrad(dw, qcb, _as_bchw(d_zb))
         Cd = tape["dec_t"].shape[1]
         d_dect, d_encb = d_cat2[:, :Cd], _nhwc(d_cat2[:, Cd:]).clone()
@@ -526,7 +550,7 @@ class VQVAETrainFunction(torch.autograd.Function):
         # top quantiser and its 1x1 conv
         d_zt = d_qt if unq else vq_backward(d_qt, tape["z_t"], tape["q_t"], g_diff)
         qct = model.quantize_conv_t
-        _set_wb(grads, qct, conv_wgrad(qct, tape["enc_t"], d_zt))
+        _wgrad_into(grads, qct, tape["enc_t"], d_zt)
         d_enct = _nhwc(conv_dgrad(dw, qct, _as_bchw(d_zt)))
         d_encb2 = encoder_backward(model.enc_t, tape, "enc_t", d_enct, dw, grads, need_input_grad=True)
         axpy_(d_encb, d_encb2)

@@ -346,3 +346,7 @@ def test_weight_gradient_halo_kernel(shape):
     assert _rel(dw, w64.grad) < 2e-5 and _rel(dw_old, w64.grad) < 2e-5, (_rel(dw, w64.grad), _rel(dw_old, w64.grad))
     assert _rel(dw, dw_old) < 1e-5
     assert _rel(db, b64.grad) < 1e-5 and _rel(db_old, b64.grad) < 1e-5
+    # the same gradients written by the reduction straight into parameter-shaped storage (the flat gradient buffer)
+    ow, ob = torch.full_like(layer.weight, float("nan")), torch.full_like(layer.bias, float("nan"))
+    dw2, db2 = _train.conv_wgrad(layer, *args, out=(ow, ob))
+    assert dw2 is ow and db2 is ob and torch.equal(ow, dw.contiguous()) and torch.equal(ob, db)

@@ -31,7 +31,7 @@ def main():
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 5
+    n = 20
     for _ in range(n):
         loss = step()
     torch.cuda.synchronize()

@@ -596,6 +596,14 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
   if ((a.in0_pair || a.in1_pair || a.out_pair) && !(a.bf16x3 == 3 && a.w16 && mode == 0 && a.Cout > 32 && a.K >= 128))
     return unsupported("conv: pair-format tensors need the split-f16 kernels (ISI_CONV_F16X3 | ISI_CONV_W16, "
                        "channels-last sources of 32-channel multiples, Cout > 32, K >= 128)");
+  if (a.bf16x3 && mode == 0 && a.Cout <= 32 && a.K >= 128 && !a.out_pair && !a.in0_pair && !a.in1_pair) {
+    // the residual blocks' 32-channel side (3x3 C -> 32 forward, 1x1 C -> 32 input gradient): 128 x 32 tiles, one
+    // 32 x 32 accumulator tile per wave.  On the fp32 matrix pipe these layers ran AT its peak (148 of 157 TFLOP/s
+    // for the 3x3 at B = 64) -- the split products have 5x that ceiling
+    if (a.bf16x3 == 2) return launch_cfg<128, 32, 4, 1, 0, 2>(a, nphase, stream);
+    if (a.bf16x3 == 3) return launch_cfg<128, 32, 4, 1, 0, 3>(a, nphase, stream);   // (pieces prepared at pack time: not built at this width)
+    return launch_cfg<128, 32, 4, 1, 0, 1>(a, nphase, stream);
+  }
   if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
     // 128x64 tiles are ~20 % slower per FLOP than 128x128, but a GEMM that fills less than the chip's
     // 3 workgroups per CU with 128x128 tiles (the prior's d x d linears at 8 k rows: 260 tiles) finishes

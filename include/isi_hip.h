@@ -255,6 +255,19 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3,
  *   d/dx Conv2d(k4,s2,p1)    = isi_conv_transpose2d_k4s2_f32 with the same weight tensor
  *   d/dx ConvTranspose(k4s2) = isi_conv2d_f32(k4,s2,p1) with the same weight tensor. */
 
+/* The two convolutions with a GATED epilogue: out = gate > 0 ? (conv + bias + residual) : 0, where `gate` is an fp32
+ * tensor laid out exactly like `dst` (same strides).  With gate = the rectified activation a layer consumed, the
+ * input-gradient convolution applies that ReLU's backward mask itself (autograd's threshold_backward behind
+ * train_vqvae.py:181; encoder_decoder.py:24,31,95-112 `nn.ReLU`) instead of a separate pass over the gradient.
+ * fp32 tensors only (no ISI_CONV_*_PAIR), one launch (the implicit-GEMM kernels). */
+int isi_conv2d_gated_f32(const isi_src *src0, const isi_src *src1, const float *packed_w,
+                         const float *bias, const isi_src *residual, const float *gate,
+                         const isi_dst *dst, int B, int H, int W, int Cout, int KH, int KW,
+                         int stride, int pad, int flags, void *stream);
+int isi_conv_transpose2d_k4s2_gated_f32(const isi_src *src, const float *packed_w,
+                                        const float *bias, const float *gate, const isi_dst *dst,
+                                        int B, int H, int W, int Cout, int flags, void *stream);
+
 /* Weight gradient dW (packed like the forward weight: [nphase][Cout][Kpad]) of a
  * convolution (transposed = 0) or ConvTranspose2d(k4,s2,p1) (transposed = 1) whose input
  * was cat(src0, src1) [B,*,H,W] and whose output gradient is dy, dense channels-last

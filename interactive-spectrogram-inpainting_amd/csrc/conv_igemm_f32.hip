@@ -57,6 +57,8 @@ struct ConvKArgs {
                              // tap-major (the packed weight keeps k = tap * Cin + c; only the visiting order changes)
   int nz;                    // plain conv, nz > 1: blockIdx.z = one of nz independent operand sets of the same shape
   int zs_in0, zs_w, zs_res, zs_out;   // element strides between two sets (source 0, packed weight, residual, output)
+  const float *gate;         // optional, laid out exactly like the output: out = gate > 0 ? value : 0 (the ReLU mask of
+                             // the layer's input applied in the epilogue of its input-gradient convolution)
 };
 
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, 16-B aligned, bank-conflict free
@@ -486,6 +488,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
   const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(p.out + (size_t)zb * p.zs_out, 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res + (size_t)zb * p.zs_res : in0), 0, p.res_bytes, 0x00020000);
   const bool has_res = p.res != nullptr;
+  const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gate ? p.gate : in0), 0, p.gate ? p.out_bytes : 4u, 0x00020000);
+  const bool has_gate = p.gate != nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + j * 32 + frow;
@@ -494,13 +498,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       unsigned oo[16];
-      float res[16];
+      float res[16], gate[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq;
         const int o = row_oo[row];
         oo[r] = (nok && o >= 0) ? (unsigned)(o + n * p.oc) * 4u : OOB;
         res[r] = 0.f;
+        gate[r] = 1.f;
+        if (has_gate) gate[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, oo[r], 0, 0));
         if (has_res)
           res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                  rsr, oo[r] == OOB ? OOB : (unsigned)(row_ro[row] + n * p.rc) * 4u, 0, 0));
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         // v - v is 0 for finite v and NaN otherwise.  (The select form `v < 0 ? 0 : v` makes this compiler allocate
         // 244 VGPRs for the split-f16 variant, 1 wave per SIMD.)
         if (p.relu) v = fmaxf(v, 0.f) + (v - v);
+        if (has_gate) v = gate[r] > 0.f ? v : 0.f;
         if constexpr (PREC == 4 && OUTP) {
           // pair-format output (split_f16.h: {hi[8] | lo[8]} per group of 8 channels).  A lane of this layout owns
           // ONE channel of 16 pixels, so its two pieces go out as 2-byte stores (conv_pair_f16.hip transposes
@@ -667,9 +674,9 @@ constexpr int64_t kMaxElems = (int64_t)1 << 30;  // 4 GiB of fp32: 32-bit byte o
 
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
-               int KW, int stride, int pad, int relu, hipStream_t stream) {
+               int KW, int stride, int pad, int relu, hipStream_t stream, const float *gate) {
   return conv2d_batched_f32(s0, s1, packed_w, bias, res, dst, B, H, W, Cout, KH, KW, stride, pad, relu, 1, 0, 0, 0, 0,
-                            stream);
+                            stream, gate);
 }
 
 // nz independent convolutions of one shape in a single launch (grid z): set z reads source 0 at
@@ -678,8 +685,10 @@ int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, cons
 int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                        const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                        int KW, int stride, int pad, int relu, int nz, int64_t zs_in0, int64_t zs_w,
-                       int64_t zs_res, int64_t zs_out, hipStream_t stream) {
+                       int64_t zs_res, int64_t zs_out, hipStream_t stream, const float *gate) {
   if (nz < 1 || nz > 65535) return invalid("conv2d: bad batch count");
+  if (gate && (nz > 1 || (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR | ISI_CONV_OUT_PAIR))))
+    return unsupported("conv2d: the gated epilogue is for single fp32 launches");
   if (nz > 1 && s1 && s1->ptr) return unsupported("conv2d: batched launches take one source");
   if (nz > 1 && ((zs_in0 | zs_w | zs_res | zs_out) & 3)) return invalid("conv2d: batch strides must be multiples of 4 floats");
   if (!s0 || !s0->ptr || !packed_w || !dst || !dst->ptr) return invalid("conv2d: null pointer");
@@ -697,7 +706,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   const int64_t er = (res && res->ptr) ? extent(B, res->sn, Cout, res->sc, OH, res->sh, OW, res->sw) : 1;
   if (e0 > kMaxElems || e1 > kMaxElems || eo > kMaxElems || er > kMaxElems)
     return unsupported("conv2d: a tensor spans 4 GiB or more");
-  if (e0 <= kMaxElems && eo <= kMaxElems && aligned16(packed_w) &&
+  if (!gate && e0 <= kMaxElems && eo <= kMaxElems && aligned16(packed_w) &&
       conv_first_applicable(s0, s1, res, dst, Cout, KH, KW, stride, pad, OH, OW, nz)) {
     // the 2-channel first layer has its own HBM-oriented kernel (conv_first_f32.hip), bit-identical results
     if (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR)) return unsupported("conv2d: pair-format source on the 2-channel layer");
@@ -716,7 +725,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   if (two) { a.s1n = (int)s1->sn; a.s1h = (int)s1->sh; a.s1w = (int)s1->sw; }
   a.Cin = a.C0 + C1;
   a.src_uniform = (!two || (a.C0 % kBK == 0 && C1 % kBK == 0)) ? 1 : 0;
-  a.w = packed_w; a.bias = bias;
+  a.w = packed_w; a.bias = bias; a.gate = gate;
   a.res = (res && res->ptr) ? res->ptr : nullptr;
   if (a.res) { a.rn = (int)res->sn; a.rc = (int)res->sc; a.rh = (int)res->sh; a.rw = (int)res->sw; }
   a.out = dst->ptr; a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)dst->sh; a.ow = (int)dst->sw;
@@ -740,8 +749,10 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
 
 int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const float *bias,
                               const isi_dst *dst, int B, int H, int W, int Cout, int relu,
-                              hipStream_t stream) {
+                              hipStream_t stream, const float *gate) {
   if (!s || !s->ptr || !packed_w || !dst || !dst->ptr) return invalid("convT: null pointer");
+  if (gate && (convT_small_applicable(s->C, Cout) || (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_OUT_PAIR))))
+    return unsupported("convT: the gated epilogue is for the fp32 implicit-GEMM launches");
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return invalid("convT: bad shape");
   if ((int64_t)B * H * W > INT32_MAX) return unsupported("convT: more than 2^31 pixels per phase");
   const int64_t e0 = extent(B, s->sn, s->C, s->sc, H, s->sh, W, s->sw);
@@ -786,7 +797,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.in0 = s->ptr; a.in1 = s->ptr; a.C0 = s->C; a.Cin = s->C; a.src_uniform = 1;
   a.in0_bytes = a.in1_bytes = (unsigned)(e0 * 4);
   a.s0n = (int)s->sn; a.s0c = (int)s->sc; a.s0h = (int)s->sh; a.s0w = (int)s->sw;
-  a.w = packed_w; a.bias = bias; a.res = nullptr;
+  a.w = packed_w; a.bias = bias; a.res = nullptr; a.gate = gate;
   a.out = dst->ptr;
   // GEMM-grid pixel (m_y, m_x) of phase (py,px) is output pixel (2 m_y + py, 2 m_x + px)
   a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)(2 * dst->sh); a.ow = (int)(2 * dst->sw);

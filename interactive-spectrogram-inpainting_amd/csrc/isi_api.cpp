@@ -162,6 +162,19 @@ int isi_conv_transpose2d_k4s2_f32(const isi_src *src, const float *packed_w, con
                                   void *stream) {
   return conv_transpose2d_k4s2_f32(src, packed_w, bias, dst, B, H, W, Cout, relu, S(stream));
 }
+int isi_conv2d_gated_f32(const isi_src *src0, const isi_src *src1, const float *packed_w, const float *bias,
+                         const isi_src *residual, const float *gate, const isi_dst *dst, int B, int H, int W,
+                         int Cout, int KH, int KW, int stride, int pad, int flags, void *stream) {
+  if (!gate) return ISI_E_INVALID;
+  return conv2d_f32(src0, src1, packed_w, bias, residual, dst, B, H, W, Cout, KH, KW, stride, pad, flags, S(stream),
+                    gate);
+}
+int isi_conv_transpose2d_k4s2_gated_f32(const isi_src *src, const float *packed_w, const float *bias,
+                                        const float *gate, const isi_dst *dst, int B, int H, int W, int Cout,
+                                        int flags, void *stream) {
+  if (!gate) return ISI_E_INVALID;
+  return conv_transpose2d_k4s2_f32(src, packed_w, bias, dst, B, H, W, Cout, flags, S(stream), gate);
+}
 
 int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3, const float *packed_w1,
                      const float *b1, float *out, int B, int H, int W, int C, int R, int relu,

@@ -40,14 +40,14 @@ int convT_pair_f16(const float *in, const float *w16, const float *bias, float *
                    int Cout, int relu, int out_pair, hipStream_t stream, const float *w2 = nullptr, int n2 = 0);
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
-               int KW, int stride, int pad, int relu, hipStream_t stream);
+               int KW, int stride, int pad, int relu, hipStream_t stream, const float *gate = nullptr);
 int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                        const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                        int KW, int stride, int pad, int relu, int nz, int64_t zs_in0, int64_t zs_w,
-                       int64_t zs_res, int64_t zs_out, hipStream_t stream);
+                       int64_t zs_res, int64_t zs_out, hipStream_t stream, const float *gate = nullptr);
 int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const float *bias,
                               const isi_dst *dst, int B, int H, int W, int Cout, int relu,
-                              hipStream_t stream);
+                              hipStream_t stream, const float *gate = nullptr);
 
 bool resblock_fusable(int C, int R);
 bool resblock_pair_ok(int C, int R);

@@ -145,6 +145,11 @@ SIGNATURES = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_conv_transpose2d_k4s2_f32": (C.c_int, [C.POINTER(isi_src), _P, _P, C.POINTER(isi_dst), C.c_int,
                                                 C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_conv2d_gated_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.POINTER(isi_src), _P,
+                                       C.POINTER(isi_dst), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_conv_transpose2d_k4s2_gated_f32": (C.c_int, [C.POINTER(isi_src), _P, _P, _P, C.POINTER(isi_dst), C.c_int,
+                                                      C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_resblock_fusable": (C.c_int, [C.c_int, C.c_int]),
     "isi_resblock_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, _P]),

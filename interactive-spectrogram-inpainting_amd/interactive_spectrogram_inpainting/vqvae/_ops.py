@@ -101,11 +101,22 @@ def _prec_flag(bf16x3) -> int:
     return {0: 0, 1: 2, 2: 4, 3: 8, 4: 24}[int(bf16x3)]
 
 
+def _check_gate(gate_nhwc: torch.Tensor, out_bchw: torch.Tensor) -> None:
+    """The gate of a gated convolution must be laid out exactly like the (channels-last) output."""
+    want = out_bchw.permute(0, 2, 3, 1)
+    if (gate_nhwc.shape != want.shape or gate_nhwc.stride() != want.stride() or gate_nhwc.dtype != torch.float32
+            or gate_nhwc.device != out_bchw.device):
+        raise ValueError(f"gate {tuple(gate_nhwc.shape)} / strides {gate_nhwc.stride()} does not match the "
+                         f"output's channels-last layout {tuple(want.shape)} / {want.stride()}")
+
+
 def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], cout: int,
            k: int, stride: int, pad: int, relu: bool, x2_bchw: Optional[torch.Tensor] = None,
-           residual_bchw: Optional[torch.Tensor] = None, bf16x3: bool = False, extra_flags: int = 0) -> torch.Tensor:
+           residual_bchw: Optional[torch.Tensor] = None, bf16x3: bool = False, extra_flags: int = 0,
+           gate_nhwc: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Convolution of a tensor indexed [B,C,H,W] (any strides); returns a
-    [B,Cout,OH,OW]-shaped view of freshly allocated channels-last storage."""
+    [B,Cout,OH,OW]-shaped view of freshly allocated channels-last storage.  `gate_nhwc` (dense [B,OH,OW,Cout]):
+    the output is zeroed where the gate is not positive (isi_conv2d_gated_f32: a ReLU's backward mask)."""
     _hip.require_gpu(x_bchw, "conv input")
     B, _, H, W = x_bchw.shape
     OH = (H + 2 * pad - k) // stride + 1
@@ -115,6 +126,15 @@ def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Te
     s1 = _hip.src_nchw_view(x2_bchw) if x2_bchw is not None else None
     res = _hip.src_nchw_view(residual_bchw) if residual_bchw is not None else None
     dst = _hip.dst_nchw_view(out)
+    if gate_nhwc is not None:
+        _check_gate(gate_nhwc, out)
+        rc = _hip.lib().isi_conv2d_gated_f32(
+            C.byref(s0), C.byref(s1) if s1 is not None else None, packed_w.data_ptr(),
+            bias.data_ptr() if bias is not None else None, C.byref(res) if res is not None else None,
+            gate_nhwc.data_ptr(), C.byref(dst), B, H, W, cout, k, k, stride, pad,
+            int(relu) | _prec_flag(bf16x3) | extra_flags, _s(x_bchw))
+        _hip.check(rc, "isi_conv2d_gated_f32")
+        return out
     rc = _hip.lib().isi_conv2d_f32(
         C.byref(s0), C.byref(s1) if s1 is not None else None, packed_w.data_ptr(),
         bias.data_ptr() if bias is not None else None, C.byref(res) if res is not None else None,
@@ -124,7 +144,8 @@ def conv2d(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Te
 
 
 def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor],
-                          cout: int, relu: bool, out_nchw: bool = False, bf16x3: bool = False, extra_flags: int = 0) -> torch.Tensor:
+                          cout: int, relu: bool, out_nchw: bool = False, bf16x3: bool = False, extra_flags: int = 0,
+                          gate_nhwc: Optional[torch.Tensor] = None) -> torch.Tensor:
     _hip.require_gpu(x_bchw, "convT input")
     B, _, H, W = x_bchw.shape
     if out_nchw:
@@ -133,6 +154,15 @@ def conv_transpose2d_k4s2(x_bchw: torch.Tensor, packed_w: torch.Tensor, bias: Op
         out = torch.empty(B, 2 * H, 2 * W, cout, dtype=torch.float32, device=x_bchw.device).permute(0, 3, 1, 2)
     s0 = _hip.src_nchw_view(x_bchw)
     dst = _hip.dst_nchw_view(out)
+    if gate_nhwc is not None:
+        if out_nchw:
+            raise ValueError("gated transposed convolution writes channels-last")
+        _check_gate(gate_nhwc, out)
+        rc = _hip.lib().isi_conv_transpose2d_k4s2_gated_f32(
+            C.byref(s0), packed_w.data_ptr(), bias.data_ptr() if bias is not None else None, gate_nhwc.data_ptr(),
+            C.byref(dst), B, H, W, cout, int(relu) | _prec_flag(bf16x3) | extra_flags, _s(x_bchw))
+        _hip.check(rc, "isi_conv_transpose2d_k4s2_gated_f32")
+        return out
     rc = _hip.lib().isi_conv_transpose2d_k4s2_f32(
         C.byref(s0), packed_w.data_ptr(), bias.data_ptr() if bias is not None else None,
         C.byref(dst), B, H, W, cout, int(relu) | _prec_flag(bf16x3) | extra_flags, _s(x_bchw))

@@ -179,18 +179,22 @@ class _DgradWeights:
 
 
 def conv_dgrad(dw: _DgradWeights, layer: _ConvParams, dy: torch.Tensor,
-               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gradient w.r.t. the layer input ([B,Cin,H,W] view of channels-last storage);
-    dy: [B,Cout,OH,OW] view (any strides)."""
+    dy: [B,Cout,OH,OW] view (any strides).  `gate` (dense NHWC, the rectified activation the layer consumed): the
+    backward of that ReLU -- zero where the activation is zero -- applied in the convolution's epilogue (after the
+    residual is added) instead of a separate pass over the gradient."""
     packed = dw.get(layer)
     cin = layer.in_channels
+    if gate is not None and not gate.is_contiguous():
+        raise ValueError("gate must be dense channels-last")
     if layer.transposed:
-        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False, bf16x3=DGRAD_PRECISION)
+        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False, bf16x3=DGRAD_PRECISION, gate_nhwc=gate)
     if layer.stride == 2:
-        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False, bf16x3=DGRAD_PRECISION)
+        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False, bf16x3=DGRAD_PRECISION, gate_nhwc=gate)
     k = layer.kernel_size
     return _ops.conv2d(dy, packed, None, cin, k, 1, k - 1 - layer.padding, relu=False, residual_bchw=residual,
-                       bf16x3=DGRAD_PRECISION)
+                       bf16x3=DGRAD_PRECISION, gate_nhwc=gate)
 
 
 def _set_wb(grads, layer: _ConvParams, wb) -> None:
@@ -308,39 +312,42 @@ def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_
     return x
 
 
-def _res_stack_backward(blocks, idxs, tape, tag, d_y, x_in_key, dw, grads: Grads):
-    """d_y: dense NHWC gradient w.r.t. the (rectified) stack output; returns NHWC gradient
-    w.r.t. the stack input (the rectified conv3 output)."""
+def _res_stack_backward(blocks, idxs, tape, tag, d_y, x_in_key, dw, grads: Grads, gated: bool = False):
+    """d_y: dense NHWC gradient w.r.t. the (rectified) stack output -- `gated`: already zeroed where that output is
+    zero.  Returns the NHWC gradient w.r.t. the stack input (the rectified conv3 output), gated by that input: every
+    ReLU backward below the top one is applied in the epilogue of the input-gradient convolution that produces the
+    gradient (conv_dgrad's `gate`), not as a pass of its own."""
     for j in reversed(range(len(idxs))):
         blk = blocks[idxs[j]]
         y, h = tape[f"{tag}.res{j}.y"], tape[f"{tag}.res{j}.h"]
         r = tape[f"{tag}.res{j - 1}.y"] if j > 0 else tape[x_in_key]
-        g = relu_bwd_(d_y, _nhwc(y))                                   # through relu(r + conv1(h))
+        g = d_y if gated else relu_bwd_(d_y, _nhwc(y))                 # through relu(r + conv1(h))
         c1, c3 = blk.conv[3], blk.conv[1]
         _wgrad_into(grads, c1, h, g)
-        dh = _nhwc(conv_dgrad(dw, c1, _as_bchw(g)))
-        relu_bwd_(dh, _nhwc(h))
+        dh = _nhwc(conv_dgrad(dw, c1, _as_bchw(g), gate=_nhwc(h)))     # through relu(conv3(r))
         _wgrad_into(grads, c3, r, dh)
-        d_y = _nhwc(conv_dgrad(dw, c3, _as_bchw(dh), residual=_as_bchw(g)))   # + skip connection
-    return d_y
+        # + skip connection, then through the ReLU that produced r
+        d_y = _nhwc(conv_dgrad(dw, c3, _as_bchw(dh), residual=_as_bchw(g), gate=_nhwc(r)))
+        gated = True
+    return d_y if gated else relu_bwd_(d_y, _nhwc(tape[x_in_key]))
 
 
 def encoder_backward(m: RosinalityEncoder, tape: Tape, tag: str, d_out, dw, grads: Grads, need_input_grad: bool):
     """d_out: dense NHWC gradient w.r.t. the encoder output."""
-    d = _res_stack_backward(m.blocks, m._res, tape, tag, d_out, f"{tag}.c3", dw, grads)
+    g = _res_stack_backward(m.blocks, m._res, tape, tag, d_out, f"{tag}.c3", dw, grads)   # gated by the conv3 output
     c3 = m.blocks[m._conv3]
-    g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
     prev = tape[f"{tag}.down{len(m._down) - 1}"]
     _wgrad_into(grads, c3, prev, g)
-    d = _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
+    g = _nhwc(conv_dgrad(dw, c3, _as_bchw(g), gate=_nhwc(prev)))
     for j in reversed(range(len(m._down))):
         layer = m.blocks[m._down[j]]
-        g = relu_bwd_(d, _nhwc(tape[f"{tag}.down{j}"]))
         prev = tape[f"{tag}.down{j - 1}"] if j > 0 else tape[f"{tag}.in"]
         _wgrad_into(grads, layer, prev, g)
-        if j > 0 or need_input_grad:
-            d = _nhwc(conv_dgrad(dw, layer, _as_bchw(g)))
-    return d if need_input_grad else None
+        if j > 0:
+            g = _nhwc(conv_dgrad(dw, layer, _as_bchw(g), gate=_nhwc(prev)))
+        elif need_input_grad:
+            g = _nhwc(conv_dgrad(dw, layer, _as_bchw(g)))              # the encoder input is not a ReLU output
+    return g if need_input_grad else None
 
 
 def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw, grads: Grads):
@@ -349,16 +356,12 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
     d_view = d_out_bchw
     for j in reversed(range(len(m._up))):
         layer = m.blocks[m._up[j]]
-        last = j == len(m._up) - 1
-        g = _nhwc(d_view)
-        if not last:
-            g = relu_bwd_(g, _nhwc(tape[f"{tag}.up{j}"]))   # g is our own dgrad output here
+        g = _nhwc(d_view)     # below the last layer: our own input-gradient output, gated by this layer's output
         prev = tape[f"{tag}.up{j - 1}"] if j > 0 else tape[f"{tag}.res{len(m._res) - 1}.y" if m._res else f"{tag}.c3"]
         _wgrad_into(grads, layer, prev, g)
-        d_view = conv_dgrad(dw, layer, _as_bchw(g))
-    d = _res_stack_backward(m.blocks, m._res, tape, tag, _nhwc(d_view), f"{tag}.c3", dw, grads)
+        d_view = conv_dgrad(dw, layer, _as_bchw(g), gate=_nhwc(prev))
+    g = _res_stack_backward(m.blocks, m._res, tape, tag, _nhwc(d_view), f"{tag}.c3", dw, grads, gated=True)
     c3 = m.blocks[0]
-    g = relu_bwd_(d, _nhwc(tape[f"{tag}.c3"]))
     _wgrad_into(grads, c3, tape[f"{tag}.in"], g, x2=tape[f"{tag}.in2"])
     return _nhwc(conv_dgrad(dw, c3, _as_bchw(g)))
 

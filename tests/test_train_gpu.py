@@ -350,3 +350,36 @@ def test_weight_gradient_halo_kernel(shape):
     ow, ob = torch.full_like(layer.weight, float("nan")), torch.full_like(layer.bias, float("nan"))
     dw2, db2 = _train.conv_wgrad(layer, *args, out=(ow, ob))
     assert dw2 is ow and db2 is ob and torch.equal(ow, dw.contiguous()) and torch.equal(ob, db)
+
+
+@pytest.mark.parametrize("kind", ["conv3", "conv1_residual", "k4s2", "convT"])
+def test_gated_convolution_epilogue(kind):
+    """isi_conv2d_gated_f32 / isi_conv_transpose2d_k4s2_gated_f32 (the ReLU backward mask applied by the
+    input-gradient convolution itself): the gated launch equals the plain launch zeroed where the gate is <= 0."""
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 2, 6, 40
+    cin, cout = (64, 32) if kind == "conv1_residual" else (32, 64)
+    x = torch.randn(B, H, W, cin, generator=g).to(dev).permute(0, 3, 1, 2)
+    if kind == "convT":
+        w = torch.randn(cin, cout, 4, 4, generator=g).to(dev) * 0.1
+        packed = _ops.pack_convT_weight(w)
+        run = lambda gate: _ops.conv_transpose2d_k4s2(x, packed, None, cout, relu=False, bf16x3=1, gate_nhwc=gate)
+        oshape = (B, 2 * H, 2 * W, cout)
+    else:
+        k, s, p = {"conv3": (3, 1, 1), "conv1_residual": (1, 1, 0), "k4s2": (4, 2, 1)}[kind]
+        w = torch.randn(cout, cin, k, k, generator=g).to(dev) * 0.1
+        packed = _ops.pack_conv_weight(w)
+        OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        oshape = (B, OH, OW, cout)
+        res = torch.randn(*oshape, generator=g).to(dev).permute(0, 3, 1, 2) if kind == "conv1_residual" else None
+        run = lambda gate: _ops.conv2d(x, packed, None, cout, k, s, p, relu=False, residual_bchw=res, bf16x3=1,
+                                       gate_nhwc=gate)
+    gate = torch.relu(torch.randn(*oshape, generator=g)).to(dev)          # a rectified activation: ~half zeros
+    plain, gated = run(None), run(gate)
+    want = torch.where(gate.permute(0, 3, 1, 2) > 0, plain, torch.zeros_like(plain))
+    assert (gate == 0).float().mean().item() > 0.3
+    assert torch.equal(gated, want)
+    with pytest.raises(ValueError):
+        run(gate[:, :, :-1])                                               # a gate of another layout is refused

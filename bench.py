@@ -364,7 +364,8 @@ def _vqvae_training(device, dist, world, batch=64, steps=5, warmup=2):
            "collectives_per_step": "4 gradient buckets (5.5 MB fp32 in total) + 2 EMA-statistics messages (133 KB each)"
                                    if world > 1 else "none (1 rank)",
            "config": f"VQVAE default ctor, B={batch}/GPU of [2,128,512], MSE + 0.25 latent, Adam 3e-4, forward products "
-                     f"three-term split-f16, input gradients six-term split-bf16, weight gradients three-term split-bf16"}
+                     f"three-term split-f16, input and weight gradients three-term split-bf16 (ISI_TRAIN_DGRAD_PRECISION=same: six-term "
+                     f"input gradients)"}
     del m, opt
     torch.cuda.empty_cache()
     return out

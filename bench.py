@@ -290,7 +290,8 @@ def _prior_training(device, B=8, steps=3):
     mask = torch.rand(B, 32, 32, device=device) < 0.5
     cls = {"pitch": torch.full((B, 1), 24, device=device),
            "instrument_family_str": torch.zeros(B, 1, dtype=torch.long, device=device)}
-    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    opt = make_adam(m.parameters(), lr=3e-4)
     crit = LabelSmoothingLoss(512, 0.1, dim=1)
 
     def step():
@@ -320,7 +321,8 @@ def _vqvae_training(device, dist, world, batch=64, steps=5, warmup=2):
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     torch.manual_seed(1)                       # identical weights on every rank
     m = VQVAE(in_channel=2).to(device).train()
-    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    opt = make_adam(m.parameters(), lr=3e-4)
     rank = dist.get_rank() if dist is not None else 0
     x = torch.randn(batch, 2, 128, 512, generator=torch.Generator().manual_seed(200 + rank)).to(device)
 

@@ -51,12 +51,14 @@ class _LinearParams(nn.Module):
         nn.init.uniform_(self.bias, -bound, bound)
         self._packed, self._key = None, None
         self._packed_t, self._key_t = None, None
+        self._range = _ops.WeightRange()
 
     def packed(self):
-        key = (self.weight._version, self.weight.data_ptr())
+        inference = not (torch.is_grad_enabled() and self.weight.requires_grad)
+        key = (self.weight._version, self.weight.data_ptr(), inference)
         if self._key != key:
-            inference = not (torch.is_grad_enabled() and self.weight.requires_grad)   # (the check reads a scalar back)
-            self._packed, self._key = _ops.pack_linear_weight(self.weight, range_check=inference), key
+            ok = self._range.update(self.weight, inference)
+            self._packed, self._key = _ops.pack_linear_weight(self.weight, range_check=ok), key
         return self._packed
 
     def packed_t(self):
@@ -143,6 +145,7 @@ class RelativeMultiheadAttention(nn.Module):
             self.register_parameter("rel_embeddings", None)
         self._packed, self._key = None, None
         self._packed_t, self._key_t = None, None
+        self._range = _ops.WeightRange()
 
     def _packs_t(self):
         """W^T operands of the input gradients: (all three projections, q only, k|v)."""
@@ -164,13 +167,14 @@ class RelativeMultiheadAttention(nn.Module):
         return _ops.linear(x, self._packs()[which], b, hi - lo)
 
     def _packs(self):
-        key = (self.in_proj_weight._version, self.in_proj_weight.data_ptr())
+        inference = not (torch.is_grad_enabled() and self.in_proj_weight.requires_grad)
+        key = (self.in_proj_weight._version, self.in_proj_weight.data_ptr(), inference)
         if self._key != key:
             d = self.d_model
             W = self.in_proj_weight.detach()
-            inference = not (torch.is_grad_enabled() and self.in_proj_weight.requires_grad)
-            self._packed = (_ops.pack_linear_weight(W, range_check=inference), _ops.pack_linear_weight(W[:d], range_check=inference),
-                            _ops.pack_linear_weight(W[d:], range_check=inference))
+            ok = self._range.update(self.in_proj_weight, inference)      # one check covers the three row ranges
+            self._packed = (_ops.pack_linear_weight(W, range_check=ok), _ops.pack_linear_weight(W[:d], range_check=ok),
+                            _ops.pack_linear_weight(W[d:], range_check=ok))
             self._key = key
         return self._packed
 

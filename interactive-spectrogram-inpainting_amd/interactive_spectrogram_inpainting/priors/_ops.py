@@ -44,14 +44,43 @@ _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4, "f16x3": 8}
 _F16_WEIGHT_LIMIT = 63.98   # 65520 / 1024 and above rounds to inf in the f16 pieces
 
 
-def pack_linear_weight(weight: torch.Tensor, range_check: bool = False) -> torch.Tensor:
-    """nn.Linear weight [N,K] -> packed GEMM operand (a 1x1 convolution weight).  With `range_check` the result
-    carries `isi_f16_ok`: whether every weight is inside the range of the split-f16 products.  The check reads one
-    scalar back, so it is for inference weights (packed once per weight version); inside a training step, where every
-    weight is re-packed every step, the GEMMs keep the range-free six-term split."""
-    packed = pack_conv_weight(weight.detach().reshape(weight.shape[0], weight.shape[1], 1, 1))
-    packed.isi_f16_ok = bool(range_check and LINEAR_PRECISION == "f16x3" and
-                             (weight.numel() == 0 or bool(weight.detach().abs().max() < _F16_WEIGHT_LIMIT)))
+class WeightRange:
+    """Whether a weight tensor is inside the operand range of the split-f16 products (|w| < 64), decided without a
+    device read-back per optimizer step.  Inference weights are checked exactly whenever their version changes.  A
+    weight under training is checked every ~256 versions against HALF the limit: between two checks it would have
+    to double to leave the range (an update of lr = 3e-4 moves it by ~1e-4 per step), and if it ever did, the f16
+    pieces overflow to Inf and the step's outputs are non-finite -- loud, not silently wrong."""
+    PERIOD = 256
+
+    def __init__(self):
+        self.ok, self.next_check, self.last_version = False, -1, -1
+
+    def update(self, weight: torch.Tensor, inference: bool) -> bool:
+        v = weight._version
+        if inference or self.next_check < 0 or v >= self.next_check or v < self.last_version:
+            m = float(weight.detach().abs().max()) if weight.numel() else 0.0          # reads one scalar back
+            self.ok = m < (_F16_WEIGHT_LIMIT if inference else 0.5 * _F16_WEIGHT_LIMIT)
+            self.next_check = -1 if inference else v + self.PERIOD + (id(self) >> 4) % 64   # (staggered over modules)
+        self.last_version = v
+        return self.ok
+
+
+def pack_linear_weight(weight: torch.Tensor, range_check=False) -> torch.Tensor:
+    """nn.Linear weight [N,K] -> packed GEMM operand (a 1x1 convolution weight: [N][K padded to 32]).  A dense fp32
+    weight whose K is a multiple of 32 IS that operand: it is returned as a view, no copy and no launch (the prior's
+    ~120 linears were re-packed every training step: 265 launches of 5 us).  `range_check`: True = compare against
+    the split-f16 operand range now (reads one scalar back: inference weights, packed once per version); a bool-like
+    result of WeightRange.update for weights under training; False = unknown range (the GEMM runs 'bf16x6')."""
+    w = weight.detach()
+    if (w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32 and w.shape[1] % 32 == 0
+            and w.data_ptr() % 16 == 0 and w.is_cuda):
+        packed = w.view(w.shape[0], w.shape[1])          # a fresh tensor object (it carries an attribute below)
+    else:
+        packed = pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))
+    ok = range_check
+    if range_check is True:
+        ok = weight.numel() == 0 or bool(w.abs().max() < _F16_WEIGHT_LIMIT)
+    packed.isi_f16_ok = bool(ok) and LINEAR_PRECISION == "f16x3"
     return packed
 
 

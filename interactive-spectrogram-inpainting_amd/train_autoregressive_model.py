@@ -30,6 +30,7 @@ import torch.distributed as dist
 from interactive_spectrogram_inpainting.priors.sequence_mask import SequenceMask
 from interactive_spectrogram_inpainting.priors.transformer import VQNSynthTransformer
 from interactive_spectrogram_inpainting.utils.distributed import GradBucketReducer, is_distributed
+from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
 
 
 def num_satisfied_constraints(predicted: torch.Tensor, condition: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
@@ -180,7 +181,7 @@ def main(argv=None):
         data = SyntheticCodes(args.batch_size * args.num_batches, top_shape, bottom_shape, args.n_class, classes,
                               seed=dist.get_rank() if distributed else 0)
         loader = torch.utils.data.DataLoader(data, batch_size=args.batch_size, shuffle=False)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    optimizer = make_adam(model.parameters(), lr=args.lr)
     scheduler = CycleScheduler(optimizer, args.lr, n_iter=len(loader) * args.num_epochs)
     criterion = LabelSmoothingLoss(args.n_class, args.label_smoothing, dim=1)
     reducer = GradBucketReducer(model.parameters()) if distributed else None

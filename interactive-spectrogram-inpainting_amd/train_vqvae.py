@@ -37,6 +37,7 @@ from torch import nn  # noqa: E402
 from interactive_spectrogram_inpainting.utils.distributed import (  # noqa: E402
     DistributedEvalSampler, DistributedTrainSampler, assert_same_step_count, is_distributed, is_master_process)
 from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE  # noqa: E402
+from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam  # noqa: E402
 
 
 class RunningMeans:
@@ -166,7 +167,7 @@ def main():
 
     torch.manual_seed(1)   # identical initial weights on every rank
     model = VQVAE(in_channel=2).to(device)
-    optimizer = torch.optim.Adam(model.parameters(), lr=args.lr)
+    optimizer = make_adam(model.parameters(), lr=args.lr)
     helper = None
     if args.reconstruction_criterion != "MSE":
         from GANsynth_pytorch.spectrograms_helper import SpectrogramsHelper

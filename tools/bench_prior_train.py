@@ -13,6 +13,7 @@ sys.path.insert(0, str(ROOT / "tools"))
 import torch  # noqa: E402
 from bench_prior import build  # noqa: E402
 from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss  # noqa: E402
+from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam  # noqa: E402
 
 
 def main():
@@ -30,7 +31,7 @@ def main():
     code = torch.randint(0, 512, (B, 32, 32), device=dev)
     mask = torch.rand(B, 32, 32, device=dev) < 0.5
     cls = {"pitch": torch.full((B, 1), 24, device=dev), "instrument_family_str": torch.zeros(B, 1, dtype=torch.long, device=dev)}
-    opt = torch.optim.Adam(m.parameters(), lr=3e-4)
+    opt = make_adam(m.parameters(), lr=3e-4)
     crit = LabelSmoothingLoss(512, 0.1, dim=1)
 
     def step():

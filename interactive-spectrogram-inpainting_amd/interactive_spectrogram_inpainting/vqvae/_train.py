@@ -45,8 +45,10 @@ def _s(t):
 TRAIN_PRECISION = {"f32": 0, "bf16x6": 2}[os.environ.get("ISI_TRAIN_PRECISION", "bf16x6")]
 # Products of the training step's FORWARD convolutions: 'f16x3' = the eval path's three-term split-f16 products
 # (fp32-grade, half the matrix work of the six-term bf16 split; operands are activations and weights, whose range the
-# f16 pieces cover -- gradients are not: the input-gradient convolutions use DGRAD_PRECISION below); 'same' = TRAIN_PRECISION.
-FWD_PRECISION = {"same": TRAIN_PRECISION, "f16x3": 3 if TRAIN_PRECISION else 0}[os.environ.get("ISI_TRAIN_FWD_PRECISION", "f16x3")]
+# f16 pieces cover -- gradients are not: the input-gradient convolutions use DGRAD_PRECISION below), reading the weights'
+# pieces prepared at pack time (ISI_CONV_W16: no per-tile weight conversion in the kernel, 9.3 -> 9.0 ms per step);
+# 'same' = TRAIN_PRECISION.
+FWD_PRECISION = {"same": TRAIN_PRECISION, "f16x3": 4 if TRAIN_PRECISION else 0}[os.environ.get("ISI_TRAIN_FWD_PRECISION", "f16x3")]
 # Products of the INPUT-gradient convolutions (dX = dY * W^T): three-term split-bf16 by default, like the weight
 # gradients and the prior's input-gradient GEMMs (priors/_ops.py LINEAR_GRAD_PRECISION): a relative error of ~2^-16
 # per product, measured against the fp64 gradients in tests/test_train_gpu.py (bar 2e-4), at half the matrix work of

@@ -32,6 +32,7 @@ from typing import List, Optional, Tuple, Union
 import torch
 from torch import nn
 
+from interactive_spectrogram_inpainting import _hip
 from interactive_spectrogram_inpainting.priors import _ops
 from interactive_spectrogram_inpainting.priors import _train
 
@@ -55,7 +56,7 @@ class _LinearParams(nn.Module):
 
     def packed(self):
         inference = not (torch.is_grad_enabled() and self.weight.requires_grad)
-        key = (self.weight._version, self.weight.data_ptr(), inference)
+        key = (_hip.version_of(self.weight), self.weight.data_ptr(), inference)
         if self._key != key:
             ok = self._range.update(self.weight, inference)
             self._packed, self._key = _ops.pack_linear_weight(self.weight, range_check=ok), key
@@ -63,7 +64,7 @@ class _LinearParams(nn.Module):
 
     def packed_t(self):
         """GEMM operand of the input gradient: W^T ([in, out]) packed like a forward weight."""
-        key = (self.weight._version, self.weight.data_ptr())
+        key = (_hip.version_of(self.weight), self.weight.data_ptr())
         if self._key_t != key:
             self._packed_t, self._key_t = _ops.pack_linear_weight(self.weight.detach().t().contiguous()), key
         return self._packed_t
@@ -97,7 +98,7 @@ def _classify_mask(mask: MaskArg, Sq: int, Sk: int, device) -> Tuple[int, Option
     m = mask.detach()
     if m.shape != (Sq, Sk):
         raise RuntimeError(f"attention mask of shape {tuple(m.shape)} for a {Sq}x{Sk} score matrix")
-    key = (m.data_ptr(), m._version, tuple(m.shape), m.device)
+    key = (m.data_ptr(), _hip.version_of(m), tuple(m.shape), m.device)
     hit = _classify_mask.cache.get(key)
     if hit is None:
         allowed = (m.cpu() == 0)
@@ -149,7 +150,7 @@ class RelativeMultiheadAttention(nn.Module):
 
     def _packs_t(self):
         """W^T operands of the input gradients: (all three projections, q only, k|v)."""
-        key = (self.in_proj_weight._version, self.in_proj_weight.data_ptr())
+        key = (_hip.version_of(self.in_proj_weight), self.in_proj_weight.data_ptr())
         if self._key_t != key:
             d = self.d_model
             W = self.in_proj_weight.detach()
@@ -168,7 +169,7 @@ class RelativeMultiheadAttention(nn.Module):
 
     def _packs(self):
         inference = not (torch.is_grad_enabled() and self.in_proj_weight.requires_grad)
-        key = (self.in_proj_weight._version, self.in_proj_weight.data_ptr(), inference)
+        key = (_hip.version_of(self.in_proj_weight), self.in_proj_weight.data_ptr(), inference)
         if self._key != key:
             d = self.d_model
             W = self.in_proj_weight.detach()

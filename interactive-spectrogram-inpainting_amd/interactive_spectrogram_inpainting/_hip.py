@@ -249,6 +249,35 @@ def check(rc: int, what: str) -> None:
         raise HipLibraryError(f"{what} failed with code {rc}: {msg}")
 
 
+# ---- weight versions.  Packed weights (GEMM operands, split-f16 copies, transposes for the input gradients) are cached
+# per weight VERSION.  Every in-place torch op bumps `tensor._version` -- but torch's fused optimizers
+# (`Adam(fused=True)`) update the parameters without touching it: the caches would serve the weights of the first
+# step for ever.  A global optimizer-step hook therefore counts steps, and the count is part of every cache key: any
+# optimizer step invalidates every packed weight (at worst a re-pack that was not needed).
+_OPTIMIZER_STEPS = 0
+
+
+def _on_optimizer_step(*_args, **_kwargs) -> None:
+    global _OPTIMIZER_STEPS
+    _OPTIMIZER_STEPS += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _register_step_hook(_on_optimizer_step)
+except ImportError:   # a torch without global optimizer hooks: version counters only (do not use fused optimizers there)
+    pass
+
+
+def optimizer_steps() -> int:
+    return _OPTIMIZER_STEPS
+
+
+def version_of(t) -> tuple:
+    """Cache-key component for anything derived from tensor `t`'s values."""
+    return (t._version, _OPTIMIZER_STEPS)
+
+
 class knob:
     """`with knob("ISI_CONV_FLUSH", 0): ...` -- set an execution switch of the library (isi_knob_set) for the block and
     restore it afterwards.  The switches select between kernels that compute the same result; the library reads the

@@ -56,7 +56,7 @@ class WeightRange:
         self.ok, self.next_check, self.last_version = False, -1, -1
 
     def update(self, weight: torch.Tensor, inference: bool) -> bool:
-        v = weight._version
+        v = weight._version + _hip.optimizer_steps()      # either counter moves when the values may have changed
         if inference or self.next_check < 0 or v >= self.next_check or v < self.last_version:
             m = float(weight.detach().abs().max()) if weight.numel() else 0.0          # reads one scalar back
             self.ok = m < (_F16_WEIGHT_LIMIT if inference else 0.5 * _F16_WEIGHT_LIMIT)
@@ -68,9 +68,9 @@ class WeightRange:
 def pack_linear_weight(weight: torch.Tensor, range_check=False) -> torch.Tensor:
     """nn.Linear weight [N,K] -> packed GEMM operand (a 1x1 convolution weight: [N][K padded to 32]).  A dense fp32
     weight whose K is a multiple of 32 IS that operand: it is returned as a view, no copy and no launch (the prior's
-    ~120 linears were re-packed every training step: 265 launches of 5 us).  `range_check`: True = compare against
-    the split-f16 operand range now (reads one scalar back: inference weights, packed once per version); a bool-like
-    result of WeightRange.update for weights under training; False = unknown range (the GEMM runs 'bf16x6')."""
+    ~120 linears were re-packed every training step: 265 launches of 5 us).  `range_check`: "now" = compare against
+    the split-f16 operand range here (reads one scalar back: constant operands, packed once); True / False = the
+    caller's knowledge (WeightRange.update); False also stands for an unknown range (the GEMM runs 'bf16x6')."""
     w = weight.detach()
     if (w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32 and w.shape[1] % 32 == 0
             and w.data_ptr() % 16 == 0 and w.is_cuda):
@@ -78,7 +78,9 @@ def pack_linear_weight(weight: torch.Tensor, range_check=False) -> torch.Tensor:
     else:
         packed = pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1))
     ok = range_check
-    if range_check is True:
+    if isinstance(range_check, str):
+        if range_check != "now":
+            raise ValueError("range_check: True, False or 'now'")
         ok = weight.numel() == 0 or bool(w.abs().max() < _F16_WEIGHT_LIMIT)
     packed.isi_f16_ok = bool(ok) and LINEAR_PRECISION == "f16x3"
     return packed

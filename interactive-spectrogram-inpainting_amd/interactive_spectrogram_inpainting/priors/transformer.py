@@ -29,6 +29,7 @@ from VQCPCB.transformer.transformer_custom import (
     TransformerDecoderLayerCustom, TransformerEncoderLayerCustom,
     TransformerAlignedDecoderLayerCustom, _LinearParams)
 
+from .. import _hip
 from . import _train
 from .codemaps_helpers import CodemapsHelper, SimpleCodemapsHelper, ZigZagCodemapsHelper
 
@@ -244,7 +245,7 @@ class VQNSynthTransformer(nn.Module):
             emb, lin = self.target_embed, self.target_embeddings_linear
         else:
             raise ValueError(f"Unexpected value {kind} for kind option")
-        key = (kind, emb.weight._version, emb.weight.data_ptr(), lin.weight._version, lin.weight.data_ptr(),
+        key = (kind, _hip.version_of(emb.weight), emb.weight.data_ptr(), lin.weight._version, lin.weight.data_ptr(),
                lin.bias._version)
         if self._differentiable():
             return lin.run(emb.weight)  # recorded: gradients reach the embedding and the linear layer

@@ -162,7 +162,7 @@ class _DgradWeights:
         self.cache: Dict[int, Tuple[tuple, torch.Tensor]] = {}
 
     def get(self, layer: _ConvParams) -> torch.Tensor:
-        key = (layer.weight._version, layer.weight.data_ptr())
+        key = (_hip.version_of(layer.weight), layer.weight.data_ptr())
         hit = self.cache.get(id(layer))
         if hit is None or hit[0] != key:
             w = layer.dense_weight()

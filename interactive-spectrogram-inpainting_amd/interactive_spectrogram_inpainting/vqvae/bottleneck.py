@@ -17,6 +17,7 @@ import numpy as np
 import torch
 from torch import nn, Tensor
 
+from .. import _hip
 from . import _ops
 
 
@@ -42,7 +43,7 @@ class QuantizedBottleneck(nn.Module):
 
     def packed(self):
         """(codes [K,D], e2 [K]) for the HIP kernels, cached per buffer version."""
-        key = (self.embed._version, self.embed.data_ptr(), self.embed.device)
+        key = (_hip.version_of(self.embed), self.embed.data_ptr(), self.embed.device)
         if self._packed is None or self._packed_key != key:
             self._packed = _ops.pack_codebook(self.embed)
             self._packed_key = key

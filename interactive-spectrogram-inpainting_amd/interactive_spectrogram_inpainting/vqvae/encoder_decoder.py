@@ -16,6 +16,7 @@ from typing import List, Optional
 import torch
 from torch import nn
 
+from .. import _hip
 from . import _ops
 
 
@@ -77,7 +78,7 @@ class _ConvParams(nn.Module):
     def packed(self) -> torch.Tensor:
         """Packed weight followed by its split-f16 pair copy (the layout ISI_CONV_W16 / isi_vqvae_w.w16 expect;
         entry points called without that flag read the first half only)."""
-        key = (self.weight._version, self.weight.data_ptr(), self.weight.device)
+        key = (_hip.version_of(self.weight), self.weight.data_ptr(), self.weight.device)
         if self._packed is None or self._packed_key != key:
             if self.transposed:
                 if (self.kernel_size, self.stride, self.padding) != (4, 2, 1):

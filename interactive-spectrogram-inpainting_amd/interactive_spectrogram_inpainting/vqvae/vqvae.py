@@ -179,7 +179,7 @@ class VQVAE(nn.Module):
     def _plan_fingerprint(self):
         key = []
         for t in list(self.parameters()) + [self.quantize_t.embed, self.quantize_b.embed]:
-            key.append((t._version, t.data_ptr()))
+            key.append((_hip.version_of(t), t.data_ptr()))
         key.append((getattr(self.quantize_t, "_ema_steps", 0), getattr(self.quantize_b, "_ema_steps", 0)))
         key.append(self.conv_precision)
         return tuple(key)

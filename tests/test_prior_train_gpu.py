@@ -373,7 +373,7 @@ def test_linear_precisions_against_fp64():
             err = {}
             for prec in ("f32", "bf16x6", "bf16x3", "f16x3"):
                 _ops.LINEAR_PRECISION = prec
-                y = _ops.linear(x.to(dev), _ops.pack_linear_weight(W.to(dev), range_check=True), b.to(dev), N)
+                y = _ops.linear(x.to(dev), _ops.pack_linear_weight(W.to(dev), range_check="now"), b.to(dev), N)
                 err[prec] = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
             assert err["f32"] <= 5e-6 and err["bf16x6"] <= 1.5 * err["f32"] + 1e-7 and err["bf16x3"] <= 2e-5, err
             assert err["f16x3"] <= 1.5 * err["f32"] + 1e-7, err      # the default: fp32-grade
@@ -381,8 +381,19 @@ def test_linear_precisions_against_fp64():
         _ops.LINEAR_PRECISION = "f16x3"
         x, W = torch.randn(64, 256), torch.randn(40, 256)
         W[3, 7] = 100.0
-        pw = _ops.pack_linear_weight(W.to(dev), range_check=True)
+        pw = _ops.pack_linear_weight(W.to(dev), range_check="now")
         assert pw.isi_f16_ok is False
+        # the monitor of a weight under training: exact limit for inference weights, HALF the limit (and no device
+        # read-back until ~256 versions later) while it is being trained
+        wp = torch.nn.Parameter(torch.randn(40, 256, device=dev) * 0.1)
+        mon = _ops.WeightRange()
+        assert mon.update(wp, False) is True and mon.update(wp, True) is True
+        with torch.no_grad():
+            wp[3, 7] = 40.0
+        assert mon.update(wp, True) is True and _ops.WeightRange().update(wp, False) is False
+        with torch.no_grad():
+            wp[3, 7] = 100.0
+        assert mon.update(wp, True) is False
         y = _ops.linear(x.to(dev), pw, None, 40)
         ref = x.double() @ W.double().t()
         assert torch.isfinite(y).all() and float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < 5e-6

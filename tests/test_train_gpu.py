@@ -383,3 +383,40 @@ def test_gated_convolution_epilogue(kind):
     assert torch.equal(gated, want)
     with pytest.raises(ValueError):
         run(gate[:, :, :-1])                                               # a gate of another layout is refused
+
+
+def test_fused_optimizer_step_invalidates_packed_weights():
+    """torch's fused optimizers update parameters WITHOUT bumping `tensor._version`; the packed-weight caches are
+    keyed on the version plus a global optimizer-step count (`_hip.version_of`), so a forward after such a step must
+    see the new weights -- in the VQ-VAE (conv weights, split-f16 copies, dgrad transposes) and in a prior's linear."""
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    from VQCPCB.transformer.transformer_custom import _LinearParams
+    dev = _dev()
+    torch.manual_seed(5)
+    kw = dict(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16, num_embeddings=64)
+    m = VQVAE(**kw).to(dev).train()
+    x = torch.randn(2, 2, 32, 64, device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-2, fused=True)
+    for _ in range(2):
+        m.zero_grad()
+        out, latent, *_ = m(x)
+        (torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()).backward()
+        opt.step()
+    m.eval()
+    fresh = VQVAE(**kw).to(dev).eval()
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        a, b = m(x)[0], fresh(x)[0]
+    assert torch.equal(a, b), (a - b).abs().max().item()
+
+    lin = _LinearParams(64, 32).to(dev)
+    xs = torch.randn(5, 3, 64, device=dev)
+    opt = torch.optim.Adam(lin.parameters(), lr=5e-2, fused=True)
+    for _ in range(2):
+        lin.zero_grad()
+        lin.run(xs).square().mean().backward()
+        opt.step()
+    with torch.no_grad():
+        got = lin.run(xs)
+        want = torch.nn.functional.linear(xs.double(), lin.weight.double(), lin.bias.double())
+    assert _rel(got, want) < 1e-5

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--plain-adam", action="store_true", help="torch's default (multi-tensor) Adam instead of the fused one")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     m = build(dev).train()
@@ -31,7 +32,7 @@ def main():
     code = torch.randint(0, 512, (B, 32, 32), device=dev)
     mask = torch.rand(B, 32, 32, device=dev) < 0.5
     cls = {"pitch": torch.full((B, 1), 24, device=dev), "instrument_family_str": torch.zeros(B, 1, dtype=torch.long, device=dev)}
-    opt = make_adam(m.parameters(), lr=3e-4)
+    opt = torch.optim.Adam(m.parameters(), lr=3e-4) if a.plain_adam else make_adam(m.parameters(), lr=3e-4)
     crit = LabelSmoothingLoss(512, 0.1, dim=1)
 
     def step():

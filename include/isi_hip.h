@@ -131,6 +131,12 @@ int isi_prof_read(int kernel_id, long long *launches, double *ms, double *flops,
  * isi_conv2d_f32 (encoder_decoder.py:95-112,138; vqvae.py:149-150,175-177). */
 int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin,
                              int KH, int KW, void *stream);
+/* Packed weight of the INPUT-GRADIENT convolution of a stride-1 nn.Conv2d with weight w [Cout][Cin][KH][KW]
+ * (autograd's conv backward-data behind train_vqvae.py:181): [Cin][KH*KW*Cout padded to 32] with the window rotated by
+ * 180 degrees -- what isi_pack_conv_weight_f32 would make of w.flip(2, 3).transpose(0, 1), in one launch.  Run it
+ * through isi_conv2d_f32 with padding K - 1 - p. */
+int isi_pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH,
+                                   int KW, void *stream);
 /* Split-f16 pair copy of a packed weight (any of the packed layouts; n_floats % 4 == 0, 16-byte aligned):
  * every quad of floats becomes {hi0..hi3 | lo0..lo3}, the f16 pieces of 1024 w, in the same 16 bytes. */
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream);

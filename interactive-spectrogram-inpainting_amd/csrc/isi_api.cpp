@@ -126,6 +126,9 @@ int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, i
                              void *stream) {
   return pack_conv_weight_f32(w, packed, Cout, Cin, KH, KW, S(stream));
 }
+int isi_pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, void *stream) {
+  return pack_conv_dgrad_weight_f32(w, packed, Cout, Cin, KH, KW, S(stream));
+}
 /* measurements only (not in isi_hip.h): phase timestamps of conv_pair_f16.hip's instrumented variant */
 int isi_debug_conv_pair_stamps(long long *host, int n) { return conv_pair_debug_stamps(host, n); }
 int isi_debug_convT_pair_stamps(long long *host, int n) { return convT_pair_debug_stamps(host, n); }

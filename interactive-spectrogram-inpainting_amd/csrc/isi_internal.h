@@ -169,6 +169,7 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
 size_t packed_convT_k4s2_weight_floats(int Cin, int Cout);
 int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
                          hipStream_t stream);
+int pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, hipStream_t stream);
 int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,
                                hipStream_t stream);
 int pack_codebook_f32(const float *embed, float *codes_kd, float *e2, int D, int K,

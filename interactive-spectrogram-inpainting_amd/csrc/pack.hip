@@ -27,6 +27,24 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict_
   out[i] = v;
 }
 
+// Packed weight of the INPUT-GRADIENT convolution of a stride-1 Conv2d with weight w [Cout][Cin][KH][KW]: the
+// convolution dY -> dX has Cin output channels, Cout input channels and the 180-degree rotated window:
+// out[ci][(kh, kw, co)] = w[co][ci][KH-1-kh][KW-1-kw]  (one launch instead of flip + transpose + contiguous + pack).
+__global__ void pack_conv_dgrad_kernel(const float *__restrict__ w, float *__restrict__ out, int Cout,
+                                       int Cin, int KH, int KW, int Kpad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)Cin * Kpad) return;
+  const int ci = (int)(i / Kpad);
+  const int k = (int)(i - (int64_t)ci * Kpad);
+  float v = 0.f;
+  if (k < KH * KW * Cout) {
+    const int tap = k / Cout, co = k - tap * Cout;
+    const int kh = tap / KW, kw = tap - kh * KW;
+    v = w[(((int64_t)co * Cin + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+  }
+  out[i] = v;
+}
+
 __global__ void pack_convT_kernel(const float *__restrict__ w, float *__restrict__ out, int Cin,
                                   int Cout, int Kpad) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -152,6 +170,17 @@ int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int K
   hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                      w, packed, Cout, Cin, KH, KW, Kpad);
   return check_launch("pack_conv_weight_f32");
+}
+
+int pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
+                               hipStream_t stream) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0)
+    return invalid("pack_conv_dgrad_weight: bad argument");
+  const int Kpad = (int)round_up((size_t)KH * KW * Cout, kBK);
+  const int64_t total = (int64_t)Cin * Kpad;
+  hipLaunchKernelGGL(pack_conv_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     w, packed, Cout, Cin, KH, KW, Kpad);
+  return check_launch("pack_conv_dgrad_weight_f32");
 }
 
 int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,

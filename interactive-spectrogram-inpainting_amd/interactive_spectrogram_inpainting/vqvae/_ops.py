@@ -38,6 +38,18 @@ def pack_conv_weight(weight: torch.Tensor, with_f16: bool = False) -> torch.Tens
     return _with_f16_copy(out, n) if with_f16 else out
 
 
+def pack_conv_dgrad_weight(weight: torch.Tensor) -> torch.Tensor:
+    """torch Conv2d (stride 1) weight [Cout,Cin,KH,KW] -> packed weight [Cin, Kpad] of its input-gradient convolution
+    (= pack_conv_weight(weight.flip(2, 3).transpose(0, 1)) in one launch)."""
+    _hip.require_gpu(weight, "conv weight")
+    w = weight.detach().contiguous()
+    cout, cin, kh, kw = w.shape
+    out = torch.empty(_hip.lib().isi_packed_conv_weight_floats(cin, cout, kh, kw), dtype=torch.float32, device=w.device)
+    _hip.check(_hip.lib().isi_pack_conv_dgrad_weight_f32(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, _s(w)),
+               "isi_pack_conv_dgrad_weight_f32")
+    return out
+
+
 def pack_convT_weight(weight: torch.Tensor, with_f16: bool = False) -> torch.Tensor:
     """torch ConvTranspose2d(k4,s2,p1) weight [Cin,Cout,4,4] -> 4 packed phase matrices."""
     _hip.require_gpu(weight, "convT weight")

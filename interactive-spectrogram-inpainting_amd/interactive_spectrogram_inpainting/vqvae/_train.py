@@ -174,7 +174,7 @@ class _DgradWeights:
                 packed = _ops.pack_convT_weight(w)
             else:
                 # d/dx Conv(k, s=1) = Conv(k, s=1, p=k-1-p) with the 180-degree rotated, transposed weight
-                packed = _ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous())
+                packed = _ops.pack_conv_dgrad_weight(w)
             hit = (key, packed)
             self.cache[id(layer)] = hit
         return hit[1]

@@ -420,3 +420,12 @@ def test_fused_optimizer_step_invalidates_packed_weights():
         got = lin.run(xs)
         want = torch.nn.functional.linear(xs.double(), lin.weight.double(), lin.bias.double())
     assert _rel(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(128, 32, 3), (32, 128, 1), (64, 128, 3), (6, 10, 3)])
+def test_input_gradient_weight_pack(shape):
+    """isi_pack_conv_dgrad_weight_f32 == packing the flipped, transposed weight (one launch instead of three)."""
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    cout, cin, k = shape
+    w = torch.randn(cout, cin, k, k, generator=torch.Generator().manual_seed(k + cout)).to(_dev())
+    assert torch.equal(_ops.pack_conv_dgrad_weight(w), _ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous()))

@@ -782,9 +782,10 @@ static void launch_wgrad_split(const WgradKArgs &a, int nzs, hipStream_t stream)
   constexpr size_t smem = (size_t)NP * (TCO + TK) * LDB * sizeof(unsigned short) + 8 * TCO * sizeof(float);
   static DeviceOnce attr_set;
   if (smem > 48 * 1024 && !attr_set.done()) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_split_kernel<NP, WR, MT, NT, ONEHOT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set.mark();
+    // (a failure here surfaces as the launch error the caller checks right after)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_split_kernel<NP, WR, MT, NT, ONEHOT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess)
+      attr_set.mark();
   }
   dim3 grid((a.Cout + TCO - 1) / TCO, (a.Kpad + TK - 1) / TK, nzs);
   hipLaunchKernelGGL((conv_wgrad_split_kernel<NP, WR, MT, NT, ONEHOT>), grid, dim3(256), smem, stream, a);

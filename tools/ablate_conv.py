@@ -4,6 +4,7 @@ import os, pathlib, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
 import torch
+from interactive_spectrogram_inpainting import _hip
 from interactive_spectrogram_inpainting.vqvae import _ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -23,6 +24,6 @@ for name, cin, cout, k, s, H, W in (("3x3 128->128", 128, 128, 3, 1, 32, 128),):
     run = lambda: _ops.conv2d(xp, pw, None, cout, k, s, 1, relu=True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)
     out = []
     for ab, fl in ((0, 3), (1, 3), (2, 3), (3, 3), (16, 3), (17, 3), (8, 3)):
-        os.environ["ISI_CONV_ABLATE"] = str(ab); os.environ["ISI_CONV_FLUSH"] = str(fl)
-        out.append(f"ablate {ab} flush {fl}: {timed(run):7.1f} us")
+        with _hip.knob("ISI_CONV_ABLATE", ab), _hip.knob("ISI_CONV_FLUSH", fl):   # (-DISI_MEASURE builds honour the ablation)
+            out.append(f"ablate {ab} flush {fl}: {timed(run):7.1f} us")
     print(name, " | ".join(out))

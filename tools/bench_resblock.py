@@ -4,6 +4,7 @@ import pathlib, sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
 import torch
+from interactive_spectrogram_inpainting import _hip
 from interactive_spectrogram_inpainting.vqvae import _ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -36,7 +37,6 @@ for H, W in ((32, 128), (16, 64)):
     print(f"{H}x{W}: " + " | ".join(f"{k} {v:6.1f} us ({flops / v / 1e6:5.1f} TF)" for k, v in res.items()))
     import os
     for ab in ("1", "2", "3", "4", "8", "12"):
-        os.environ["ISI_RESPAIR_ABL"] = ab
-        t = min(timed(lambda: _ops.resblock(xp, p3, b3, p1, b1, R, True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)) for _ in range(2))
+        with _hip.knob("ISI_RESPAIR_ABL", int(ab)):   # (-DISI_MEASURE builds only)
+            t = min(timed(lambda: _ops.resblock(xp, p3, b3, p1, b1, R, True, bf16x3=4, extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT)) for _ in range(2))
         print(f"   pair kernel, ablation {ab} (1: one stage of 8, 2: no second GEMM / epilogue, 4: no skip re-read, 8: no stores; sums combine): {t:6.1f} us")
-    os.environ.pop("ISI_RESPAIR_ABL")

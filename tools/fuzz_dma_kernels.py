@@ -10,6 +10,7 @@ import sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
 import torch  # noqa: E402
+from interactive_spectrogram_inpainting import _hip  # noqa: E402
 from interactive_spectrogram_inpainting.vqvae import _ops  # noqa: E402
 
 F = torch.nn.functional
@@ -46,9 +47,8 @@ def main():
         e = max((got.cpu().double() - ref64).abs().max().item(), (got_p.cpu().double() - ref64).abs().max().item()) / scale
         worst = max(worst, e)
         assert e < 1.5e-6, (case, B, H, W, C0, C1, cout, k, e)
-        os.environ["ISI_CONV_FLUSH"] = "0"
-        unflushed = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, 1, x2_bchw=x1p, extra_flags=flags, **kw)
-        del os.environ["ISI_CONV_FLUSH"]
+        with _hip.knob("ISI_CONV_FLUSH", 0):     # (switches are read once; isi_knob_set is the A/B entry point)
+            unflushed = _ops.conv2d(x0p, pw, bias.to(dev), cout, k, stride, 1, x2_bchw=x1p, extra_flags=flags, **kw)
         assert torch.equal(unflushed, old), (case, B, H, W, C0, C1, cout, k)
         # residual block on the first source
         if C0 in (64, 128):
@@ -59,10 +59,9 @@ def main():
                                                     w1.double(), b1.double()))
             p3, p1 = _ops.pack_conv_weight(w3.to(dev), with_f16=True), _ops.pack_conv_weight(w1.to(dev), with_f16=True)
             for th in ("4", "8"):
-                os.environ["ISI_RESPAIR_TH"] = th
-                o = _ops.pair_decode(_ops.resblock(x0p, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4,
-                                                   extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT))
-                del os.environ["ISI_RESPAIR_TH"]
+                with _hip.knob("ISI_RESPAIR_TH", int(th)):
+                    o = _ops.pair_decode(_ops.resblock(x0p, p3, b3.to(dev), p1, b1.to(dev), R, True, bf16x3=4,
+                                                       extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT))
                 e = (o.cpu().double() - r64).abs().max().item() / (r64.abs().max().item() + 1e-30)
                 worst = max(worst, e)
                 assert e < 2e-6, ("resblock", case, th, B, H, W, C0, e)

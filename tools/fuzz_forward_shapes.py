@@ -12,6 +12,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
 import torch  # noqa: E402
 from oracle import vqvae_oracle as O  # noqa: E402
+from interactive_spectrogram_inpainting import _hip
 from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE  # noqa: E402
 
 
@@ -31,9 +32,8 @@ def main():
         x = torch.randn(B, 2, H, W, generator=g).to(dev)
         got = m(x)
         assert all(torch.isfinite(t).all() for t in got[:4]), (B, H, W)
-        os.environ["ISI_NO_VQ_FUSION"] = "1"
-        unfused = m(x)
-        del os.environ["ISI_NO_VQ_FUSION"]
+        with _hip.knob("ISI_NO_VQ_FUSION", 1):   # (switches are read once; isi_knob_set is the A/B entry point)
+            unfused = m(x)
         for name, a, b in zip(("dec", "diff", "perplexity_t", "perplexity_b", "id_t", "id_b"), got, unfused):
             if name == "diff":      # a sum of squares per lane: the two kernels may contract its fmas differently (1 ulp)
                 assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b)), (name, float(a), float(b))
@@ -42,9 +42,8 @@ def main():
                 d = (a != b)
                 detail = (int(d.sum()), float((a.float() - b.float()).abs().max()), a[d].flatten()[:4].tolist(), b[d].flatten()[:4].tolist())
                 raise AssertionError(("fused vs two-launch quantiser", name, B, H, W, detail))
-        os.environ["ISI_NO_PAIRS"] = "1"
-        ref = m(x)
-        del os.environ["ISI_NO_PAIRS"]
+        with _hip.knob("ISI_NO_PAIRS", 1):
+            ref = m(x)
         mism = (got[4] != ref[4]).float().mean().item() + (got[5] != ref[5]).float().mean().item()
         assert mism < 0.02, ("pair pipeline vs fp32 activations: codes", B, H, W, mism)
         same = (got[4] == ref[4]).all(-1).all(-1) & (got[5] == ref[5]).all(-1).all(-1)

@@ -15,6 +15,7 @@
 // (reference train_vqvae.py:181) for nn.Conv2d / nn.ConvTranspose2d of
 // vqvae/encoder_decoder.py:95-112,138,199-215 and vqvae/vqvae.py:149-150,175-201.
 #include <algorithm>
+#include <type_traits>
 
 #include "isi_common.h"
 #include "isi_internal.h"
@@ -475,20 +476,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
 
-template <int NCO, int S, int KHG, int KWT, int R>
-__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p) {
+template <int NCO, int S, int KHG, int KWT, int R, int NG>
+__global__ __launch_bounds__(256 * NG) void conv_wgrad_halo_kernel(const WgradKArgs p) {
   constexpr int NCI = 4 / NCO, T = KHG * KWT, OWT = 32;
   constexpr int HR = (R - 1) * S + KHG, HC = (OWT - 1) * S + KWT, HP = HR * HC, NPX = R * OWT;
   constexpr int HCH = (HC + 1) / 2;                       // stride 2: even columns first, then the odd ones
   constexpr int XI = NCI * HP * 8, DI = NCO * NPX * 8;    // float4 items per tile
-  constexpr int NXI = (XI + 255) / 256, NDI = DI / 256;
+  constexpr int NTH = 256 * NG;                           // NG = 2: 8 waves, two groups of four, see below
+  constexpr int NXI = (XI + NTH - 1) / NTH, NDI = DI / NTH;
   constexpr int XPL = HP * 64, DPL = NPX * 64;            // bytes of one bf16 plane
-  static_assert(DI % 256 == 0 && NPX == 64, "dY staging / bias reduction assume 64-pixel tiles");
+  static_assert(DI % NTH == 0 && NPX == 64 && NDI * NG == 2 * NCO, "dY staging / bias reduction assume 64-pixel tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
   unsigned char *Xs = smem_b, *Ds = smem_b + NCI * 2 * XPL;
 
+  // NG = 2: two groups of four waves.  Both groups own the same four (channel group, input-channel slice) roles; group 0
+  // takes the first (T + 1) / 2 taps, group 1 the rest: half the accumulator registers per wave (two waves per SIMD fit:
+  // their LDS reads and matrix instructions overlap -- one wave per SIMD measured 0.41 of the three-term ceiling), no
+  // merge at the end, and 512 threads share the staging.
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cg = wave % NCO, cs = wave / NCO;
+  const int grp = NG == 2 ? wave >> 2 : 0, w4 = wave & 3;
+  const int cg = w4 % NCO, cs = w4 / NCO;
   const int KH = p.K / (p.KW * p.Cin), NTG = KH / KHG, NCB = p.Cin / (32 * NCI);
   const int unit = blockIdx.x, split = blockIdx.y;
   const int tg = unit % NTG, cb = (unit / NTG) % NCB, ob = unit / (NTG * NCB);
@@ -505,7 +512,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
   bool xsec[NXI];
 #pragma unroll
   for (int j = 0; j < NXI; ++j) {
-    const int item = tid + 256 * j;
+    const int item = tid + NTH * j;
     const int q = item & 7, hp = (item >> 3) % HP, sl = (item >> 3) / HP;
     const int hy = hp / HC, hx = hp % HC;
     const int c = ci0 + sl * 32 + q * 4;
@@ -519,7 +526,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
   int drel[NDI], ddst[NDI];
 #pragma unroll
   for (int j = 0; j < NDI; ++j) {
-    const int item = tid + 256 * j;
+    const int item = tid + NTH * j;
     const int q = item & 7, px = (item >> 3) % NPX, gr = (item >> 3) / NPX;
     drel[j] = (px / OWT) * p.dh + (px % OWT) * p.dw + co0 + gr * 32 + q * 4;
     ddst[j] = gr * 2 * DPL + px * 64 + q * 8;
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
   auto store_tile = [&]() {
 #pragma unroll
     for (int j = 0; j < NXI; ++j) {
-      if (256 * j + 255 >= XI && tid + 256 * j >= XI) continue;
+      if (NTH * j + NTH - 1 >= XI && tid + NTH * j >= XI) continue;
       uint2 pc[3];
       split4<2>(rx[j].x, rx[j].y, rx[j].z, rx[j].w, pc);
       *reinterpret_cast<uint2 *>(Xs + xdst[j]) = pc[0];
@@ -566,15 +573,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
       split4<2>(rdy[j].x, rdy[j].y, rdy[j].z, rdy[j].w, pc);
       *reinterpret_cast<uint2 *>(Ds + ddst[j]) = pc[0];
       *reinterpret_cast<uint2 *>(Ds + ddst[j] + DPL) = pc[1];
-      bsum[j / 2][0] += rdy[j].x; bsum[j / 2][1] += rdy[j].y; bsum[j / 2][2] += rdy[j].z; bsum[j / 2][3] += rdy[j].w;
+      constexpr int JG = 2 / NG;   // dY items per channel group and thread
+      bsum[j / JG][0] += rdy[j].x; bsum[j / JG][1] += rdy[j].y; bsum[j / JG][2] += rdy[j].z; bsum[j / JG][3] += rdy[j].w;
     }
   };
-
-  f32x16 acc[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   // fragment addressing: 16-lane group g = lane >> 4 covers channels 16 (g & 1) .. + 15 and the pixels
   // 8 (g >> 1) + {0..3 | 4..7} of a 16-pixel step; lane t of the group points at pixel row t / 4, channel quad t % 4
@@ -587,37 +589,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q + 4 * 64));
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  auto compute_tile = [&]() {
+  constexpr int TG = NG == 2 ? (T + 1) / 2 : T;   // taps per wave group
+  f32x16 acc[TG];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // taps [T0, T0 + NTP) of this group; a product of a tap waits for its own accumulator, so the taps of a kernel row
+  // are issued round-robin (NG = 1) / the SIMD's other wave fills the gaps (NG = 2)
+  auto compute_taps = [&](auto t0_, auto ntp_) {
+    constexpr int T0 = decltype(t0_)::value, NTP = decltype(ntp_)::value;
 #pragma unroll
     for (int ks = 0; ks < 2 * R; ++ks) {
       const int r = ks >> 1, kc = ks & 1;
       const s16x8 ah = frag(Ab + (r * OWT + kc * 16) * 64), al = frag(Ab + DPL + (r * OWT + kc * 16) * 64);
-      // one kernel row (KWT taps) at a time: the three products of a tap go to the same accumulator, so they are
-      // issued KWT matrix instructions apart (a dependent MFMA would wait for the previous one's 16 passes)
+      constexpr int CH = NG == 2 ? 1 : KWT;          // taps whose fragments are held together
 #pragma unroll
-      for (int khl = 0; khl < KHG; ++khl) {
-        s16x8 bh[KWT], bl[KWT];
+      for (int c0 = 0; c0 < NTP; c0 += CH) {
+        s16x8 bh[CH], bl[CH];
 #pragma unroll
-        for (int kwl = 0; kwl < KWT; ++kwl) {
+        for (int c = 0; c < CH; ++c) {
+          if (c0 + c >= NTP) continue;
+          const int t = T0 + c0 + c, khl = t / KWT, kwl = t % KWT;
           const int col = S == 1 ? kc * 16 + kwl : (kwl & 1) * HCH + kc * 16 + (kwl >> 1);
           const int off = ((r * S + khl) * HC + col) * 64;
-          bh[kwl] = frag(Bb + off);
-          bl[kwl] = frag(Bb + XPL + off);
+          bh[c] = frag(Bb + off);
+          bl[c] = frag(Bb + XPL + off);
         }
 #pragma unroll
-        for (int kwl = 0; kwl < KWT; ++kwl)
-          acc[khl * KWT + kwl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[kwl]), acc[khl * KWT + kwl], 0, 0, 0);
+        for (int c = 0; c < CH; ++c)
+          if (c0 + c < NTP) acc[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[c]), acc[c0 + c], 0, 0, 0);
 #pragma unroll
-        for (int kwl = 0; kwl < KWT; ++kwl)
-          acc[khl * KWT + kwl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[kwl]), acc[khl * KWT + kwl], 0, 0, 0);
+        for (int c = 0; c < CH; ++c)
+          if (c0 + c < NTP) acc[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[c]), acc[c0 + c], 0, 0, 0);
 #pragma unroll
-        for (int kwl = 0; kwl < KWT; ++kwl)
-          acc[khl * KWT + kwl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              __builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[kwl]), acc[khl * KWT + kwl], 0, 0, 0);
+        for (int c = 0; c < CH; ++c)
+          if (c0 + c < NTP) acc[c0 + c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[c]), acc[c0 + c], 0, 0, 0);
       }
     }
+  };
+  auto compute_tile = [&]() {
+    if (NG == 2 && grp == 1) compute_taps(std::integral_constant<int, TG>{}, std::integral_constant<int, T - TG>{});
+    else compute_taps(std::integral_constant<int, 0>{}, std::integral_constant<int, TG>{});
   };
 
   if (tile_begin < tile_end) {
@@ -633,33 +646,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradKArgs p
     __syncthreads();
   }
 
-  // ---- bias partials (units of the first input-channel block and tap group): fixed-order sum over the 32 staging
-  // threads of a channel quad
+  // ---- bias partials (units of the first input-channel block and tap group): fixed-order sum over the 64 staging
+  // threads (pixels of a tile) of a channel quad
   if (p.db_partial != nullptr && cb == 0 && tg == 0) {
-    float *red = reinterpret_cast<float *>(smem_b);   // [NCO * 32 channels][32 + 1]
+    constexpr int NPT = NTH / 8;                       // staging threads per channel quad
+    float *red = reinterpret_cast<float *>(smem_b);   // [NCO * 32 channels][NPT + 1]
 #pragma unroll
     for (int g = 0; g < NCO; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) red[(g * 32 + (tid & 7) * 4 + e) * 33 + (tid >> 3)] = bsum[g][e];
+      for (int e = 0; e < 4; ++e) red[(g * 32 + (tid & 7) * 4 + e) * (NPT + 1) + (tid >> 3)] = bsum[g][e];
     __syncthreads();
     if (tid < NCO * 32) {
       float t = 0.f;
 #pragma unroll
-      for (int g = 0; g < 32; ++g) t += red[tid * 33 + g];
+      for (int g = 0; g < NPT; ++g) t += red[tid * (NPT + 1) + g];
       p.db_partial[(size_t)split * p.Cout + co0 + tid] = t;
     }
+    __syncthreads();
   }
 
   float *out = p.partial + (size_t)split * p.Cout * p.Kpad;
   const int fl = lane & 31, half = lane >> 5;
 #pragma unroll
-  for (int t = 0; t < T; ++t) {
+  for (int tl = 0; tl < TG; ++tl) {
+    const int t = grp * TG + tl;
+    if (t >= T) break;
     const int tap = (tg * KHG + t / KWT) * KWT + t % KWT;
     const int kcol = tap * p.Cin + ci0 + cs * 32 + fl;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int corow = co0 + cg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      out[(size_t)corow * p.Kpad + kcol] = acc[t][r];
+      out[(size_t)corow * p.Kpad + kcol] = acc[tl][r];
     }
   }
 }
@@ -817,17 +834,18 @@ static int wgrad_reduce(const WgradKArgs &a, float *workspace, float *dw_packed,
 template <int NCO, int S, int KHG, int KWT>
 static int launch_wgrad_halo(const WgradKArgs &a, int units, int nsplit, hipStream_t stream) {
   constexpr int R = 2, NCI = 4 / NCO;
+  constexpr int NG = 2;                  // two wave groups (kernel comment)
   constexpr int HP = ((R - 1) * S + KHG) * (31 * S + KWT);
   constexpr size_t smem = (size_t)NCI * 2 * HP * 64 + (size_t)NCO * 2 * R * 32 * 64;
-  static_assert(smem >= (size_t)NCO * 32 * 33 * 4, "bias reduction scratch");
+  static_assert(smem >= (size_t)NCO * 32 * (32 * NG + 1) * 4, "bias reduction scratch");
   static DeviceOnce attr_set;
   if (!attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_halo_kernel<NCO, S, KHG, KWT, R>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_halo_kernel<NCO, S, KHG, KWT, R, NG>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(conv_wgrad_halo)");
     attr_set.mark();
   }
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<NCO, S, KHG, KWT, R>), dim3(units, nsplit), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<NCO, S, KHG, KWT, R, NG>), dim3(units, nsplit), dim3(256 * NG), smem, stream, a);
   return check_launch("conv_wgrad_halo");
 }
 
@@ -912,7 +930,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   while (nco < 4 && Cin % (32 * (4 / nco))) nco *= 2;   // fewer input-channel slices per workgroup when Cin is small
   const bool halo = use_split && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && (k3 || k4) &&
                     Cout % (32 * nco) == 0 && Cin % (32 * (4 / nco)) == 0 && s0->C % 32 == 0 && OW % 32 == 0 &&
-                    OH % 2 == 0 && !knobs().no_wgrad_halo;
+                    OH % 2 == 0 && !(k4 && nco == 1) && !knobs().no_wgrad_halo;   // (k4, one channel group: does not fit its registers)
   if (halo) {
     const int units = (Cout / (32 * nco)) * (Cin / (32 * (4 / nco))) * (k3 ? 1 : 2);
     const int ntiles = B * (OH / 2) * (OW / 32);
@@ -925,7 +943,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
 #define ISI_HALO(NCO_, S_, KHG_, KW_)                                                                                 \
   rc_h = launch_wgrad_halo<NCO_, S_, KHG_, KW_>(a, units, ns, stream)
     if (k3) { if (nco == 4) ISI_HALO(4, 1, 3, 3); else if (nco == 2) ISI_HALO(2, 1, 3, 3); else ISI_HALO(1, 1, 3, 3); }
-    else { if (nco == 4) ISI_HALO(4, 2, 2, 4); else if (nco == 2) ISI_HALO(2, 2, 2, 4); else ISI_HALO(1, 2, 2, 4); }
+    else { if (nco == 4) ISI_HALO(4, 2, 2, 4); else ISI_HALO(2, 2, 2, 4); }
 #undef ISI_HALO
     if (rc_h) return rc_h;
     return wgrad_reduce(a, workspace, dw_packed, db, 1, ns, 1, 0, stream, torch_keep);

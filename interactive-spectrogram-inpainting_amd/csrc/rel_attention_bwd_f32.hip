@@ -642,6 +642,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   if (p.mask_mode == 2) k_begin = (q0 / 32) * 32;
 
   // staging roles: a 4 keys x 4 dims block of K (threads [0, 256)) or V ([256, 512)); band row 32 st + srow
+  // (the opaque-index form of the dK / dV kernel was measured here: 256 -> 251 VGPRs, same time)
   const int kind = tid >> 8, bidx = tid & 255;
   const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);
   const bool blk_on = btile < 2;
@@ -968,17 +969,24 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   if (p.mask_mode == 1) q_begin = (k0b / 32) * 32;          // j <= i
   if (p.mask_mode == 2) q_end = min(p.Sq, k0b + QB);        // j >= i
 
-  // staging roles: a 4 queries x 4 dims block of Q (threads [0, 256)) or dO ([256, 512)); band row 32 st + srow
-  const int kind = tid >> 8, bidx = tid & 255;
-  const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);
-  const bool blk_on = btile < 2;
-  const int st = tid >> 8, srow = (tid >> 3) & 31, squad = tid & 7;
+  // staging roles: a 4 queries x 4 dims block of Q (threads [0, 256)) or dO ([256, 512)); band row 32 st + srow.
+  // They are derived from an OPAQUE copy of the thread index inside prefetch / commit (a few VALU per call): as loop
+  // invariants they and the address terms built on them were parked in registers across the whole tile step.
   const int statb = (b * p.H + h) * p.Sq;
   float4 pb[4], pe[NKQ];
   float plse = 0.f, pdsum = 0.f;
   // first table row of the band of the query tile that starts at q
   auto band0 = [&](int q) { return q / p.Cq - evk_max_b + p.Ek - 1; };
+#define ISI_KV_ROLES                                                                                   \
+  int tid_o = tid;                                                                                     \
+  asm volatile("" : "+v"(tid_o));                                                                      \
+  const int kind = tid_o >> 8, bidx = tid_o & 255;                                                     \
+  const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);                        \
+  const bool blk_on = btile < 2;                                                                       \
+  const int st = tid_o >> 8, srow = (tid_o >> 3) & 31, squad = tid_o & 7;                              \
+  (void)st; (void)srow; (void)squad; (void)kind; (void)bqd; (void)bkg; (void)blk_on
   auto prefetch = [&](int q0) {  // Q / dO blocks of the pair at q0 and the 64 highest rows of its band
+    ISI_KV_ROLES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int qj = q0 + 32 * btile + 4 * bkg + j;
@@ -1008,6 +1016,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     *reinterpret_cast<uint2 *>(Ep + o + RING_S * HD) = lo;
   };
   auto commit = [&](int q0) {
+    ISI_KV_ROLES;
     if (blk_on) {
       unsigned short *rows = (kind == 0 ? Qp : Gp) + (btile * 2) * 32 * HD;
       unsigned short *cols = (kind == 0 ? Qtp : Gtp) + (btile * 2) * VR * 32;
@@ -1045,6 +1054,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     }
   };
 
+#undef ISI_KV_ROLES
   if (VR > HD) {
     for (int i = tid; i < 2 * 2 * VR * 32 / 2; i += 512) {
       reinterpret_cast<unsigned *>(Qtp)[i] = 0u;
@@ -1057,6 +1067,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     commit(q_begin);
     if (has_e) {
       const int rb = band0(q_begin);
+      const int squad = tid & 7;
       for (int row = tid >> 3; row < BAND2_S - 64; row += 64) {
         const int r = rb + row;
         const bool ok = r >= 0 && r < p.R;
@@ -1086,6 +1097,12 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     if (p.mask_mode == 1) live = live && q0 + 31 >= kw0;
     if (p.mask_mode == 2) live = live && q0 <= kw0 + 31;
     if (live) {  // wave-uniform
+      // The lane index is made opaque per iteration: the dozens of LDS offsets derived from it are loop-invariant and
+      // would otherwise be hoisted into registers the accumulators and fragments need (the three-term kernel spilled
+      // 49 VGPRs to scratch; scratch reloads queue behind the kernel's stores -- DESIGN.md section 0).
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      const int ql = lane_o & 31, half = lane_o >> 5;
       // ---- S = Q K^T  (rows = queries, this lane's column = its key)
       f32x16 acc;
 #pragma unroll

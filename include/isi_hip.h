@@ -477,7 +477,10 @@ int isi_vq_nearest_f32(const float *z, const float *codes_kd, const float *e2,
 /* Same, with a flag word: ISI_CONV_F16X3 computes z.e_k with split-f16 products (three f16 MFMA terms, per-product
  * error ~2^-23; |z| < 16384, |e| < 64) when D == 64 and the codebook's two f16 planes fit in LDS (K <= 512), five
  * times fewer matrix-pipe cycles than the exact-fp32 products that bound isi_vq_nearest_f32.  0 = exact.
- * A vector with a non-finite component (or distances) gets idx -1, q = NaN, and makes the squared error NaN. */
+ * A vector with a non-finite component (or distances) gets idx -1, q = NaN, and makes the squared error NaN; so does
+ * every vector when a code vector is not finite.  FINITE code vectors beyond the range (|e| >= 64: the unused codes of a
+ * trained codebook) are exact: they are kept out of the f16 search and the fp32 decision proves per vector that none of
+ * them can win ((min |e_far| - |z|)^2 > winner's distance) or compares the winner with each of them in fp32. */
 int isi_vq_nearest_flags_f32(const float *z, const float *codes_kd, const float *e2,
                              int64_t *idx_out, float *q_out, int32_t *counts,
                              float *sse_part, int64_t N, int D, int K, int flags, void *stream);

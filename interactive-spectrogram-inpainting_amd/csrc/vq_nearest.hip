@@ -170,39 +170,64 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
 // quads 4 s + h and 4 s + 2 + h -- the channels a lane of the fused kernel below owns after its 1x1 convolution.
 // A lane (col = vector, h = lane >> 5) holds the vector's quads zq[j] = quad 2 j + h.  Ranges as for the
 // convolutions (|z| < 16384, |e| < 64).  Beyond: a vector out of range has NaN distances to every code -> its index
-// is -1; a CODE out of range makes every index -1 (vq_fill_planes).
+// is -1.  A finite CODE beyond the range ("far" code: the EMA update of bottleneck.py:86-92 divides an unused code by a
+// vanishing cluster size -- 1e5 and more in every trained codebook) takes no part in the f16 search; vq_decide_f32 then
+// proves per vector that no far code can win -- (min |e_far| - |z|)^2 exceeds the winner's distance -- or, failing that,
+// compares the winner with every far code in exact fp32: the result is the reference's either way.  A non-finite code
+// makes every index -1 (loud).
 typedef f16s::f16x8 vq_f16x8;
 constexpr float kVqNone = 0x1p127f, kVqPad = 0x1p100f;   // finite sentinels (low mantissa bits zero: see vq_candidates_f16)
 constexpr float kVqScaleZ = f16s::kScaleA, kVqScaleE = f16s::kScaleB, kVqUnscale = f16s::kUnscale;
 __device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 
-// fills the two planes (and |e|^2, histogram) of a workgroup.  A code with a component beyond the f16 pieces' range
-// (|e| * 2^10 rounds to inf, or is not finite) would have NaN distances and silently never be a candidate: such a
-// code gets zero pieces and |e|^2 = -1e30 instead, which makes it the "best" candidate of EVERY vector -- vq_decide_f32
-// turns that into index -1 (and a NaN diff): an out-of-range codebook is loud.
-// (Contains a barrier: call from uniform control flow.)
+// fills the two planes (and |e|^2, histogram, far-code bookkeeping) of a workgroup.  A code with a component beyond
+// the f16 pieces' range (|e| * 2^10 rounds to inf) would have NaN distances: it gets zero pieces and the padding rows'
+// |e|^2 = +2^100 (never a candidate), its bit is set in the far mask and far[0] keeps the smallest |e|^2 of such codes
+// (vq_decide_f32).  A code with a NON-FINITE component or norm gets |e|^2 = -2^100 instead, which makes it the "best"
+// candidate of EVERY vector -- vq_decide_f32 turns that into index -1 (and a NaN diff): loud.
+// far: [0] bits of min |e|^2 over far codes (+inf: none), [1 + k / 32] mask.
+// (Contains barriers: call from uniform control flow.)
+__device__ __forceinline__ int *vq_far_area(int *hist, int Kp) { return hist + Kp; }
 __device__ __forceinline__ void vq_fill_planes(unsigned short *cbh, unsigned short *cbl, float *e2, int *hist,
                                                const float *__restrict__ codes, const float *__restrict__ e2g, int K,
                                                int Kp, int tid) {
   constexpr int D = 64;
+  int *far = vq_far_area(hist, Kp);
   for (int i = tid; i < Kp; i += VQ_BLOCK) { e2[i] = i < K ? e2g[i] : kVqPad; hist[i] = 0; }   // (finite: see vq_candidates_f16)
+  for (int i = tid; i < 1 + Kp / 32; i += VQ_BLOCK) far[i] = i == 0 ? 0x7f800000 : 0;
   __syncthreads();
   for (int i = tid; i < Kp * (D / 4); i += VQ_BLOCK) {
     const int k = i >> 4, qd = i & 15;
+    const float4 cv = k < K ? *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     uint2 hi, lo;
-    vq_split4(k < K ? *reinterpret_cast<const float4 *>(codes + (size_t)k * D + qd * 4) : make_float4(0.f, 0.f, 0.f, 0.f),
-              kVqScaleE, hi, lo);
+    vq_split4(cv, kVqScaleE, hi, lo);
     const bool bad = (hi.x & 0x7C00u) == 0x7C00u || (hi.x & 0x7C000000u) == 0x7C000000u ||
                      (hi.y & 0x7C00u) == 0x7C00u || (hi.y & 0x7C000000u) == 0x7C000000u;
     if (bad) {
+      const float n2 = e2g[k];
+      const float s4 = (cv.x + cv.y) + (cv.z + cv.w);            // NaN / Inf if any component is not finite
+      const bool finite = (s4 - s4 == 0.f) && (n2 - n2 == 0.f) && n2 > 0.f;
       hi = make_uint2(0u, 0u);
       lo = make_uint2(0u, 0u);
-      e2[k] = -kVqPad;          // every writer of e2[k] in this loop writes this value
+      if (finite) {
+        // (a concurrent writer of the same row writes +-2^100 as well: -2^100 must win, so only upgrade from the norm)
+        if (e2[k] == n2) e2[k] = kVqPad;
+        atomicOr(&far[1 + (k >> 5)], 1 << (k & 31));
+        atomicMin(&far[0], __builtin_bit_cast(int, n2));         // positive floats order like their bits
+      } else {
+        e2[k] = -kVqPad;
+      }
     }
     const int slot = 2 * (qd >> 2) + (qd & 1), second = (qd >> 1) & 1;
     const int wo = k * D + ((slot ^ ((k >> 1) & 7)) * 8) + second * 4;
     *reinterpret_cast<uint2 *>(cbh + wo) = hi;
     *reinterpret_cast<uint2 *>(cbl + wo) = lo;
+  }
+  __syncthreads();
+  // a row may hold a far quad AND a non-finite one: the poison must survive whatever the write order was
+  for (int k = tid; k < K; k += VQ_BLOCK) {
+    const float n2 = e2g[k];
+    if (!(n2 - n2 == 0.f)) e2[k] = -kVqPad;
   }
 }
 
@@ -316,12 +341,14 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
 // The decision, in fp32, between the two candidates: returns the index of the nearest code (-1: no finite distance)
 // and, in `ew`, this lane's quads of the winner's fp32 code vector.
 __device__ __forceinline__ int vq_decide_f32(const VqCand c, const float *e2, int K, const float *__restrict__ codes,
-                                             const float4 (&zq)[8], int half, float4 (&ew)[8]) {
+                                             const float4 (&zq)[8], int half, float4 (&ew)[8],
+                                             const int *far = nullptr, const float *__restrict__ e2g = nullptr) {
   constexpr int D = 64;
-  if (!(c.b1 < kVqNone) || c.b1 < -0.5f * kVqPad) return -1;   // no finite distance / a code beyond the f16 range
+  if (!(c.b1 < kVqNone) || c.b1 < -0.5f * kVqPad) return -1;   // no finite distance / a non-finite code
   const int i1 = c.i1, i2 = c.i2;
-  const bool has2 = c.b2 < 0.5f * kVqPad && i2 < K && i2 != i1;
-  const float *r1 = codes + (size_t)i1 * D + half * 4, *r2 = codes + (size_t)(has2 ? i2 : i1) * D + half * 4;
+  const bool has1 = c.b1 < 0.5f * kVqPad && i1 < K;           // (false: every code of the book is a far code)
+  const bool has2 = has1 && c.b2 < 0.5f * kVqPad && i2 < K && i2 != i1;
+  const float *r1 = codes + (size_t)(has1 ? i1 : 0) * D + half * 4, *r2 = codes + (size_t)(has2 ? i2 : (has1 ? i1 : 0)) * D + half * 4;
   float4 e2q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -334,20 +361,61 @@ __device__ __forceinline__ int vq_decide_f32(const VqCand c, const float *e2, in
   for (int j = 0; j < 8; ++j) { p1 += vq_quad_dot(ew[j], zq[j]); p2 += vq_quad_dot(e2q[j], zq[j]); }
   const float q1 = __shfl_xor(p1, 32), q2 = __shfl_xor(p2, 32);
   const float dot1 = half ? q1 + p1 : p1 + q1, dot2 = half ? q2 + p2 : p2 + q2;   // lower half first on both lanes
-  const float d1 = (x2 - 2.f * dot1) + e2[i1];
+  const float d1 = has1 ? (x2 - 2.f * dot1) + e2[i1] : INFINITY;
   const float d2 = has2 ? (x2 - 2.f * dot2) + e2[i2] : INFINITY;
+  int best = i1;
+  float dbest = d1;
   if (d2 < d1 || (d2 == d1 && i2 < i1)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ew[j] = e2q[j];
-    return i2;
+    best = i2;
+    dbest = d2;
   }
-  return i1;
+  // ---- far codes (beyond the f16 range, absent from the search above).  |z - e| >= |e| - |z|, so with the nearest far
+  // norm n = min |e_far|: (n - |z|)^2 bounds every far code's distance from below; the fp32 formula's own rounding is
+  // ~2^-22 of (|z| + |e|)^2, the 0.999 leaves three orders of magnitude more.  Certificate fails (or no near code at all):
+  // every lane of the wave scans the far codes in exact fp32, (distance, index) order like the reference's first-index
+  // argmax.  Wave-uniform by construction (the shuffles below need every lane).
+  if (far != nullptr) {
+    const float fmin2 = __builtin_bit_cast(float, far[0]);
+    if (fmin2 < INFINITY) {
+      const float gap = __builtin_sqrtf(fmin2) - __builtin_sqrtf(x2);
+      const bool certified = gap > 0.f && gap * gap * 0.999f > dbest;
+      if (__any(!certified)) {
+        for (int w = 0; w < (K + 31) / 32; ++w) {
+          unsigned m = (unsigned)far[1 + w];
+          while (m) {
+            const int k = 32 * w + __builtin_ctz(m);
+            m &= m - 1;
+            const float *rk = codes + (size_t)k * D + half * 4;
+            float4 ek[8];
+            float pk = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              ek[j] = *reinterpret_cast<const float4 *>(rk + j * 8);
+              pk += vq_quad_dot(ek[j], zq[j]);
+            }
+            const float qk = __shfl_xor(pk, 32);
+            const float dk = (x2 - 2.f * (half ? qk + pk : pk + qk)) + e2g[k];
+            if (dk < dbest || (dk == dbest && k < best)) {     // (a NaN distance compares false)
+              dbest = dk;
+              best = k;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) ew[j] = ek[j];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!(dbest < INFINITY)) return -1;
+  return best;
 }
 
 __device__ __forceinline__ int vq_search_f16(const unsigned short *cbh, const unsigned short *cbl, const float *e2, int Kp,
                                              int K, const float *__restrict__ codes, const float4 (&zq)[8], int col,
-                                             int half, float4 (&ew)[8]) {
-  return vq_decide_f32(vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half), e2, K, codes, zq, half, ew);
+                                             int half, float4 (&ew)[8], const int *far, const float *__restrict__ e2g) {
+  return vq_decide_f32(vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half), e2, K, codes, zq, half, ew, far, e2g);
 }
 
 __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
@@ -381,7 +449,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_f16x3_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       zq[j] = valid ? *reinterpret_cast<const float4 *>(z + n * D + (2 * j + half) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int besti = vq_search_f16(cbh, cbl, e2, Kp, K, codes, zq, col, half, ew);
+    const int besti = vq_search_f16(cbh, cbl, e2, Kp, K, codes, zq, col, half, ew, vq_far_area(hist, Kp), e2g);
     if (valid && besti < 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
@@ -610,7 +678,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
     if (!ISI_VQ_DBGBIT(p, 1)) cand = vq_candidates_f16(cbh, cbl, e2, Kp, zq, col, half);
     int besti = cand.i1;
     ISI_VQ_STAMP(3);
-    if (!ISI_VQ_DBGBIT(p, 4)) besti = vq_decide_f32(cand, e2, K, p.codes, zq, half, ew);
+    if (!ISI_VQ_DBGBIT(p, 4)) besti = vq_decide_f32(cand, e2, K, p.codes, zq, half, ew, vq_far_area(hist, Kp), p.e2);
     else {
 #pragma unroll
       for (int j = 0; j < NQ; ++j) ew[j] = zq[j];
@@ -719,8 +787,8 @@ __global__ void embed_code_kernel(const int64_t *__restrict__ idx, const float *
   reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(codes)[k * D4 + qd];
 }
 
-static size_t vq_planes_lds_bytes(int Kp) {
-  return (size_t)Kp * 64 * 2 * sizeof(unsigned short) + ((size_t)2 * Kp + ISI_VQ_WAVES) * sizeof(float);
+static size_t vq_planes_lds_bytes(int Kp) {   // planes, |e|^2, per-wave sums, histogram, far-code mask (vq_fill_planes)
+  return (size_t)Kp * 64 * 2 * sizeof(unsigned short) + ((size_t)2 * Kp + ISI_VQ_WAVES + 1 + Kp / 32 + 3) * sizeof(float);
 }
 
 static int vq_grid(int64_t N) {
@@ -775,7 +843,7 @@ int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t 
   if ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(codes) |
        reinterpret_cast<uintptr_t>(q)) & 15)
     return invalid("vq: z, codes and q must be 16-byte aligned");
-  if ((flags & ISI_CONV_F16X3) && D == 64 && (size_t)((K + 31) & ~31) * (64 * 4 + 8) + 64 <= 150 * 1024)
+  if ((flags & ISI_CONV_F16X3) && D == 64 && vq_planes_lds_bytes((K + 31) & ~31) <= 150 * 1024)
     return launch_vq_f16x3(z, codes, e2, idx, q, counts, sse_part, N, K, stream);
   switch (D) {
     case 8: return launch_vq<8>(z, codes, e2, idx, q, counts, sse_part, N, K, stream);

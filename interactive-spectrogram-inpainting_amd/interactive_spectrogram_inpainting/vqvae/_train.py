@@ -397,9 +397,14 @@ def quantize_train(q, z_nhwc: torch.Tensor):
     n_part = L.isi_vq_num_partials(N)
     part = torch.empty(n_part, dtype=torch.float32, device=z_nhwc.device)
     out2 = torch.empty(2, dtype=torch.float32, device=z_nhwc.device)
-    _hip.check(L.isi_vq_nearest_f32(z_nhwc.data_ptr(), codes.data_ptr(), e2.data_ptr(), idx.data_ptr(),
-                                    q_st.data_ptr(), counts.data_ptr(), part.data_ptr(), N, D, K, _s(z_nhwc)),
-               "isi_vq_nearest_f32")
+    # candidates on the f16 pipe + fp32 decision (the eval path's search: the fp32 formula's indices at a third of the
+    # time).  Code vectors beyond the f16 operand range -- the EMA update divides an unused code by a vanishing cluster
+    # size: 4e5 after the FIRST step of a random model -- are handled exactly by the kernel (vq_decide_f32).
+    flags = 8 if (FWD_PRECISION in (3, 4) and D == 64) else 0
+    _hip.check(L.isi_vq_nearest_flags_f32(z_nhwc.data_ptr(), codes.data_ptr(), e2.data_ptr(), idx.data_ptr(),
+                                          q_st.data_ptr(), counts.data_ptr(), part.data_ptr(), N, D, K, flags,
+                                          _s(z_nhwc)),
+               "isi_vq_nearest_flags_f32")
     _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D, out2.data_ptr(),
                                      _s(z_nhwc)), "isi_vq_finalize_f32")
     diff, perplexity = out2[0], out2[1]

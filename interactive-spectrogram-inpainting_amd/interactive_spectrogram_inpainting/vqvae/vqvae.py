@@ -230,7 +230,11 @@ class VQVAE(nn.Module):
                 return _hip.isi_codebook_w(None, None, q.dim, q.n_embed)
             codes, e2 = q.packed()
             keep.extend([codes, e2])
-            wmax.append(q.embed.detach().abs().max())    # the search splits the code vectors like weights
+            # The search splits the code vectors like weights, but a FINITE code beyond that range (every trained
+            # codebook has them: the EMA update divides an unused code by a vanishing cluster size) is handled
+            # exactly by the kernel (vq_decide_f32: certificate or fp32 scan); only a non-finite code disqualifies.
+            e = q.embed.detach()
+            wmax.append(torch.where(torch.isfinite(e).all(), e.new_zeros(()), e.new_full((), float("inf"))))
             return _hip.isi_codebook_w(codes.data_ptr(), e2.data_ptr(), q.dim, q.n_embed)
 
         w = _hip.isi_vqvae_w()
@@ -246,8 +250,8 @@ class VQVAE(nn.Module):
         for j, m in enumerate(self.upsample_top_to_bottom):
             w.upsample[j] = conv(m)
         if w.precision == 4 and not float(torch.stack(wmax).max()) < _F16_WEIGHT_LIMIT:
-            warnings.warn(f"a convolution weight or code vector reaches {_F16_WEIGHT_LIMIT:g} in magnitude (or is not finite): beyond the "
-                          "operand range of conv_precision='split_f16', running this model in 'split_bf16'")
+            warnings.warn(f"a convolution weight reaches {_F16_WEIGHT_LIMIT:g} in magnitude (or a weight / code vector is not finite): "
+                          "beyond the operand range of conv_precision='split_f16', running this model in 'split_bf16'")
             w.precision = 3
         self._plan, self._plan_key = (w, keep), key
         return w

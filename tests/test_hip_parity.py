@@ -306,37 +306,63 @@ def test_quantizer_large_fixture_bit_exact(golden_dir):
     assert torch.equal(got.reshape(-1).cpu(), want), f"fused: {(got.reshape(-1).cpu() != want).sum().item()} indices differ"
 
 
-def test_codebook_beyond_f16_range_is_loud():
-    """the split-f16 search stores code vectors as f16 pieces of 1024 e (|e| < 63.98).  A code beyond
-    that must never be skipped silently: the stand-alone kernel returns index -1 for every vector (NaN diff), and
-    the model recognises such a codebook when its plan is built and runs in split_bf16 (exact search) with a warning."""
+def test_codebook_beyond_f16_range():
+    """The split-f16 search stores code vectors as f16 pieces of 1024 e (|e| < 63.98).  Every trained codebook has
+    FINITE codes far beyond that (unused codes of the EMA update, bottleneck.py:86-92): they are kept out of the f16
+    search and handled exactly by the fp32 decision -- a proof per vector that no far code can win, or an fp32 scan of
+    the far codes -- so indices equal the reference's, including a vector whose nearest code IS a far code.  A
+    NON-FINITE code must stay loud: index -1 / NaN diff in the stand-alone kernel, and the model falls back to
+    split_bf16 with a warning."""
     from oracle import vqvae_oracle as O
     from interactive_spectrogram_inpainting.vqvae import _ops
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     dev = _dev()
     g = torch.Generator().manual_seed(3)
     embed = torch.randn(64, 512, generator=g)
-    vec = torch.randn(100, 64, generator=g)
+    vec = torch.randn(3000, 64, generator=g)
     vec[5] = 0
     vec[5, 7] = 70.0
     embed[:, 200] = vec[5]                      # the true nearest code of vector 5 has a component of 70
+    embed[:, 300:340] *= 3.0e4                  # dead codes of a trained codebook
+    embed[:, 17] = embed[:, 16] * 1.0e5
+    embed[:, 320] = 0
+    embed[3, 320] = 200.0                       # a far code of moderate norm ...
+    vec[11] = 0
+    vec[11, 3] = 198.0                          # ... and a vector next to it: no certificate, decided by the fp32 scan
+    want = O.quantize(vec, embed)[2]
     codes, e2 = _ops.pack_codebook(embed.to(dev))
     q0, d0, i0, p0 = _ops.vq_nearest(vec.to(dev), codes, e2)
-    assert i0[5] == 200 and torch.equal(i0.cpu(), O.quantize(vec, embed)[2])
+    assert i0[5] == 200 and torch.equal(i0.cpu(), want)
     q1, d1, i1, p1 = _ops.vq_nearest(vec.to(dev), codes, e2, split_f16=True)
-    assert (i1 == -1).all() and torch.isnan(d1), "an out-of-range codebook must be loud in the split-f16 search"
+    assert torch.equal(i1.cpu(), want) and i1[5] == 200 and i1[11] == 320
+    assert torch.equal(q1, q0) and abs(float(d1) - float(d0)) <= 1e-6 * abs(float(d0))
+    bad = embed.clone()
+    bad[3, 100] = float("inf")
+    codes_b, e2_b = _ops.pack_codebook(bad.to(dev))
+    qb, db, ib, pb = _ops.vq_nearest(vec.to(dev), codes_b, e2_b, split_f16=True)
+    assert (ib == -1).all() and torch.isnan(db), "a non-finite code must be loud in the split-f16 search"
+
     cfg = O.Config(in_channel=2)
     sd = O.init_state_dict(cfg, seed=2)
     O.calibrate_codebooks(sd, cfg, torch.randn(2, 2, 32, 64, generator=g))
-    sd["quantize_t.embed"][3, 11] = 100.0
+    sd["quantize_t.embed"][:, 11] *= 1.0e5       # a dead code: the model stays in split_f16, indices as the oracle's
+    sd["quantize_b.embed"][:, 40:60] *= 3.0e4
     m = VQVAE(in_channel=2)
     m.load_state_dict(sd)
     m = m.to(dev).eval()
-    x = torch.randn(1, 2, 32, 64, generator=g)
-    with pytest.warns(UserWarning, match="split_bf16"):
+    x = torch.randn(2, 2, 32, 64, generator=g)
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("error")
         out = m(x.to(dev))
     ref = O.forward(x, sd, cfg)
-    assert torch.equal(out[4].cpu(), ref[4]) and (out[5] >= 0).all()
+    assert torch.equal(out[4].cpu(), ref[4]) and torch.equal(out[5].cpu(), ref[5])
+    sd["quantize_t.embed"][3, 12] = float("nan")
+    m2 = VQVAE(in_channel=2)
+    m2.load_state_dict(sd)
+    m2 = m2.to(dev).eval()
+    with pytest.warns(UserWarning, match="split_bf16"):
+        m2(x.to(dev))
 
 
 def _certify_index_mismatches(z_vecs, embed, got, ref, eps=2e-6):

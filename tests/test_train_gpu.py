@@ -396,8 +396,8 @@ def test_fused_optimizer_step_invalidates_packed_weights():
     kw = dict(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16, num_embeddings=64)
     m = VQVAE(**kw).to(dev).train()
     x = torch.randn(2, 2, 32, 64, device=dev)
-    opt = torch.optim.Adam(m.parameters(), lr=5e-2, fused=True)
-    for _ in range(2):
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3, fused=True)   # (a step that keeps the model sane: at 5e-2 the
+    for _ in range(2):                                            #  second forward selects the EMA update's 4e5 dead codes)
         m.zero_grad()
         out, latent, *_ = m(x)
         (torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()).backward()
@@ -407,7 +407,7 @@ def test_fused_optimizer_step_invalidates_packed_weights():
     fresh.load_state_dict(m.state_dict())
     with torch.no_grad():
         a, b = m(x)[0], fresh(x)[0]
-    assert torch.equal(a, b), (a - b).abs().max().item()
+    assert torch.isfinite(a).all() and torch.equal(a, b), (a - b).abs().max().item()
 
     lin = _LinearParams(64, 32).to(dev)
     xs = torch.randn(5, 3, 64, device=dev)

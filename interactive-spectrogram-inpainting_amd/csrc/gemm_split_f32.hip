@@ -1,0 +1,226 @@
+// Row-major GEMM of the prior's linear layers with split products, gfx950:
+//
+//   out[m][n] = sum_k a[m][k] w[n][k] + bias[n] (+ residual[m][n]) (ReLU)        a: [M][K] rows of lda, w: [N][K] dense
+//
+// fp32 in / out; every product is the three-term sum of two 16-bit pieces per operand on the 16-bit matrix pipe with
+// fp32 accumulation -- bf16 pieces (ISI_CONV_BF16X3: ~2^-16 per product, no range limit; the input-gradient GEMMs) or
+// f16 pieces of 4 a and 1024 w (ISI_CONV_F16X3: ~2^-22, |a| < 16384, |w| < 64; the forward GEMMs) -- exactly the
+// products of conv_igemm_f32.hip's 1x1 case, which these launches used to run on.
+//
+// Why a kernel of its own.  The implicit-GEMM convolution kernel stages a 32-deep K chunk through ONE LDS stage between
+// two barriers and hides the round trip with other workgroups of the CU; at the prior's shapes (M = B S = 8200 rows,
+// K, N = 512 .. 2048: 260 .. 1000 tiles of 128 x 128) it runs at 0.16 - 0.21 of the three-term ceiling
+// (tools/bench_linear.py: 33 us for the 4.3 GFLOP of a 512 x 512 projection).  Here
+//   * a workgroup = 8 waves = 128 x (64 TN) tile, wave tile 32 x (32 TN); 40 - 64 KB of LDS, <= 128 VGPRs: two
+//     workgroups = four waves per SIMD, so that one wave's conversions / LDS traffic run under another's MFMAs;
+//   * K chunks of 32 through a TWO-stage LDS ring with one barrier per chunk: chunk c + 1 is in registers (global loads
+//     issued before the MFMAs of chunk c), converted to pieces and written to the other stage after them;
+//   * pieces in LDS as [row][32 k] planes of 64-byte rows, 16-byte slots XOR-swizzled with (row >> 2) & 3: a fragment
+//     (8 consecutive k of one row) is one conflict-free ds_read_b128;
+//   * no im2col arithmetic: rows are rows.
+#include <hip/hip_runtime.h>
+
+#include "isi_common.h"
+#include "isi_internal.h"
+#include "split_bf16.h"
+#include "split_f16.h"
+
+namespace isi {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8g __attribute__((ext_vector_type(8)));
+
+struct GemmArgs {
+  const float *a, *w, *bias, *res;
+  float *out;
+  unsigned a_bytes, w_bytes, res_bytes, out_bytes;
+  int M, N, K, lda, ldr, ldo, relu;
+};
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr int BM = 128;
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+  return *reinterpret_cast<float4 *>(&v);
+}
+__device__ __forceinline__ int swz(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 16; }
+
+template <bool F16>
+__device__ __forceinline__ void split_pieces(const float4 v, const float scale, uint2 &hi, uint2 &lo) {
+  if constexpr (F16) f16s::split4(v, scale, hi, lo);
+  else split_f4(v, hi, lo);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma(const s16x8g a, const s16x8g b, const f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16s::f16x8, a), __builtin_bit_cast(f16s::f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// TN: 32-column tiles per wave (tile width BN = 64 TN)
+template <bool F16, int TN>
+__global__ __launch_bounds__(512, 2) void gemm_split_kernel(const GemmArgs p) {
+  constexpr int BN = 64 * TN;
+  constexpr int APL = BM * 64, BPL = BN * 64;                  // bytes of one plane (rows of 32 pieces = 64 B)
+  constexpr int STAGE = 2 * APL + 2 * BPL;                     // A hi, A lo, B hi, B lo
+  constexpr int NA = BM * 8 / 512, NB = BN * 8 / 512;          // float4 per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave & 3) * 32, wn0 = (wave >> 2) * (32 * TN);
+  const int fr = lane & 31, fh = lane >> 5;
+  // consecutive workgroups walk the M tiles of one column block: they share the block's weights in L2
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int m0 = ((int)blockIdx.x % tiles_m) * BM, n0 = ((int)blockIdx.x / tiles_m) * BN;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // staging roles: float4 number tid + 512 j of the chunk: row = (tid + 512 j) / 8, quad = tid % 8 (8 lanes = one
+  // 128-byte row segment)
+  const int sq = tid & 7, sr = tid >> 3;
+  unsigned aoff[NA], boff[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int m = m0 + sr + 64 * j;
+    aoff[j] = m < p.M ? (unsigned)(m * p.lda + sq * 4) * 4u : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + sr + 64 * j;
+    boff[j] = n < p.N ? (unsigned)(n * p.K + sq * 4) * 4u : OOB;
+  }
+  float4 pa[NA], pb[NB];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) pa[j] = buf_load4(ra, aoff[j] == OOB ? OOB : aoff[j] + (unsigned)k0 * 4u);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) pb[j] = buf_load4(rw, boff[j] == OOB ? OOB : boff[j] + (unsigned)k0 * 4u);
+  };
+  auto store_chunk = [&](int stage) {
+    unsigned char *st = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int row = sr + 64 * j;
+      uint2 hi, lo;
+      split_pieces<F16>(pa[j], f16s::kScaleA, hi, lo);
+      const int o = row * 64 + swz(row, sq >> 1) + (sq & 1) * 8;
+      *reinterpret_cast<uint2 *>(st + o) = hi;
+      *reinterpret_cast<uint2 *>(st + APL + o) = lo;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int row = sr + 64 * j;
+      uint2 hi, lo;
+      split_pieces<F16>(pb[j], f16s::kScaleB, hi, lo);
+      const int o = row * 64 + swz(row, sq >> 1) + (sq & 1) * 8;
+      *reinterpret_cast<uint2 *>(st + 2 * APL + o) = hi;
+      *reinterpret_cast<uint2 *>(st + 2 * APL + BPL + o) = lo;
+    }
+  };
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int nchunk = p.K / 32;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const bool more = c + 1 < nchunk;
+    if (more) load_chunk(32 * (c + 1));
+    const unsigned char *st = smem + (c & 1) * STAGE;
+    const int arow = wm0 + fr;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int ao = arow * 64 + swz(arow, 2 * s + fh);
+      const s16x8g ah = *reinterpret_cast<const s16x8g *>(st + ao), al = *reinterpret_cast<const s16x8g *>(st + APL + ao);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int brow = wn0 + 32 * j + fr;
+        const int bo = brow * 64 + swz(brow, 2 * s + fh);
+        const s16x8g bh = *reinterpret_cast<const s16x8g *>(st + 2 * APL + bo);
+        const s16x8g bl = *reinterpret_cast<const s16x8g *>(st + 2 * APL + BPL + bo);
+        acc[j] = mfma<F16>(al, bh, acc[j]);
+        acc[j] = mfma<F16>(ah, bl, acc[j]);
+        acc[j] = mfma<F16>(ah, bh, acc[j]);
+      }
+    }
+    if (more) store_chunk((c + 1) & 1);   // that stage was last read in iteration c - 1: every wave is past its barrier
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C layout of a 32 x 32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a
+  // store instruction writes two 128-byte row segments
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.a), 0, p.res ? p.res_bytes : 4u, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn0 + 32 * j + fr;
+    const bool nok = n < p.N;
+    const float bias = (p.bias && nok) ? p.bias[n] : 0.f;
+    float res[16];
+    unsigned oo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      const bool ok = nok && m < p.M;
+      oo[r] = ok ? (unsigned)(m * p.ldo + n) * 4u : OOB;
+      res[r] = 0.f;
+      if (p.res) res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ok ? (unsigned)(m * p.ldr + n) * 4u : OOB, 0, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = (F16 ? acc[j][r] * f16s::kUnscale : acc[j][r]) + bias + res[r];
+      if (p.relu) v = fmaxf(v, 0.f) + (v - v);      // (a NaN stays a NaN: an operand beyond the f16 range must be loud)
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro, oo[r], 0, 0);
+    }
+  }
+}
+
+template <bool F16, int TN>
+int launch_gemm(const GemmArgs &a, hipStream_t stream) {
+  constexpr int BN = 64 * TN;
+  constexpr size_t smem = (size_t)2 * (2 * BM * 64 + 2 * BN * 64);
+  static DeviceOnce attr_set;
+  if (smem > 48 * 1024 && !attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel<F16, TN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(gemm_split)");
+    attr_set.mark();
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_split_kernel<F16, TN>), dim3(tiles), dim3(512), smem, stream, a);
+  return check_launch("gemm_split_f32");
+}
+
+}  // namespace
+
+// Shapes this kernel takes over from the 1x1 implicit GEMM (conv2d_batched_f32 asks before it plans its own launch):
+// dense rows (channel stride 1), K a multiple of 32, 16-byte aligned operands, three-term products.
+bool gemm_split_applicable(int M, int N, int K, int split_mode) {
+  return (split_mode == 1 || split_mode == 3) && K % 32 == 0 && K >= 128 && N > 32 && M >= 256;   // (K, N: where the convolution kernel uses split products too)
+}
+
+int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
+                   int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream) {
+  GemmArgs g;
+  g.a = a; g.w = w; g.bias = bias; g.res = res; g.out = out;
+  g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldr = (int)ldr; g.ldo = (int)ldo; g.relu = relu;
+  const int64_t ea = (int64_t)(M - 1) * lda + K, eo = (int64_t)(M - 1) * ldo + N, er = res ? (int64_t)(M - 1) * ldr + N : 1;
+  const int64_t lim = (int64_t)1 << 30;
+  if (ea > lim || eo > lim || er > lim || (int64_t)N * K > lim) return unsupported("gemm: a tensor spans 4 GiB or more");
+  g.a_bytes = (unsigned)(ea * 4); g.w_bytes = (unsigned)((int64_t)N * K * 4); g.out_bytes = (unsigned)(eo * 4);
+  g.res_bytes = (unsigned)(er * 4);
+  // 128 x 64 tiles when 128 x 128 ones would leave CUs without a second workgroup
+  const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const bool narrow = tiles128 < 512 || N % 128 != 0;
+  if (split_mode == 3) return narrow ? launch_gemm<true, 1>(g, stream) : launch_gemm<true, 2>(g, stream);
+  return narrow ? launch_gemm<false, 1>(g, stream) : launch_gemm<false, 2>(g, stream);
+}
+
+}  // namespace isi

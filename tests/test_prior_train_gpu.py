@@ -488,3 +488,31 @@ def test_rel_attention_backward_bf16_mode(Sq, Sk, Cq, Ck, mode, monkeypatch):
     e3 = run("bf16x3")
     assert all(e < 3e-2 for e in e1), e1
     assert all(x3 < x1 for x1, x3 in zip(e1, e3)), (e1, e3)
+
+
+@pytest.mark.parametrize("shape", [(8200, 512, 512), (1030, 1536, 512), (300, 496, 2048), (257, 40, 64), (4100, 2048, 512)])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x3"])
+def test_linear_gemm_kernel_equals_implicit_gemm(shape, precision):
+    """`gemm_split_kernel` (the linear layers' own GEMM: two-stage LDS ring, one barrier per K chunk) forms the same
+    products in the same order as the 1x1 implicit-GEMM convolution it replaces: bit-identical results, with bias,
+    residual and ReLU, ragged M / N tiles and a row-strided input; and fp32-grade against fp64."""
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.priors import _ops
+    M, N, K = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    xw = torch.randn(M, K + 32, generator=g).to(dev)
+    x = xw[:, 16:16 + K]                                   # rows of stride K + 32, 64-byte aligned start
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    pw = _ops.pack_linear_weight(W, range_check="now")
+    for relu, r in ((False, None), (True, res)):
+        got = _ops.linear(x, pw, b, N, relu=relu, residual=r, precision=precision)
+        with _hip.knob("ISI_NO_GEMM_KERNEL", 1):
+            old = _ops.linear(x, pw, b, N, relu=relu, residual=r, precision=precision)
+        assert torch.equal(got, old)
+        ref = x.double() @ W.double().t() + b.double() + (r.double() if r is not None else 0)
+        ref = torch.relu(ref) if relu else ref
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < (2e-5 if precision == "bf16x3" else 2e-6), err

@@ -7,6 +7,7 @@ import sys
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "interactive-spectrogram-inpainting_amd"))
 import torch  # noqa: E402
+from interactive_spectrogram_inpainting import _hip  # noqa: E402
 from interactive_spectrogram_inpainting.priors import _ops  # noqa: E402
 
 
@@ -30,12 +31,21 @@ def main():
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.05
         b = torch.randn(N, device=dev)
-        pw = _ops.pack_linear_weight(w)
+        pw = _ops.pack_linear_weight(w, range_check="now")
         line = f"M={M} N={N:4d} K={K:4d}:"
-        for prec in ("f32", "bf16x6", "bf16x3"):
+        for prec in ("f32", "bf16x6", "bf16x3", "f16x3"):
             t = timed(lambda: _ops.linear(x, pw, b, N, precision=prec))
             line += f"  {prec} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.1f} TF"
         print(line)
+        if len(sys.argv) > 1:      # A/B of a library switch: `bench_linear.py ISI_SOME_KNOB value`
+            with _hip.knob(sys.argv[1], int(sys.argv[2])):
+                line = f"   with {sys.argv[1]}={sys.argv[2]}:"
+                for prec in ("bf16x3", "f16x3"):
+                    t = timed(lambda: _ops.linear(x, pw, b, N, precision=prec))
+                    y1 = _ops.linear(x, pw, b, N, precision=prec)
+                    line += f"  {prec} {t:7.1f} us {2.0 * M * N * K / t / 1e6:6.1f} TF"
+            y0 = _ops.linear(x, pw, b, N, precision="f16x3")
+            print(line, " max diff", float((y1 - y0).abs().max()))
 
 
 if __name__ == "__main__":

@@ -681,6 +681,121 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad_halo_kernel(const WgradKA
   }
 }
 
+// ---- weight gradient of a LINEAR layer (round 3): dW[n][k] = sum_m dY[m][n] X[m][k], M = tokens.  The per-tap kernel
+// above transposes both operands on the way into a single LDS stage (8-byte column pieces per channel) between two
+// barriers per 32-row chunk.  Here both row chunks go to LDS in their own [row][channel] order (8-byte pieces of 4
+// channels, slices of 32 channels = 64-byte rows like conv_wgrad_halo_kernel) and `ds_read_b64_tr_b16` delivers the
+// row-major fragments the reduction over rows needs; two-stage ring, one barrier per chunk, 8 waves on a 128 x 128 tile
+// (wave: 32 output features x 64 input features), 64 KB of LDS: two workgroups per CU.
+__global__ __launch_bounds__(512, 2) void linear_wgrad_kernel(const WgradKArgs p) {
+  constexpr int SL = 2 * 32 * 64;            // bytes of one 32-channel slice: hi plane, lo plane of [32 rows][64 B]
+  constexpr int OPB = 4 * SL;                // one operand's chunk: four slices (128 channels)
+  constexpr int STAGE = 2 * OPB;             // dY, then X
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 3, wk = wave >> 2;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128, split = blockIdx.z;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, p.dy_bytes, 0x00020000);
+
+  // staging: float4 number tid + 512 j of a 32 x 128 chunk: row = that / 32, channel quad = tid % 32
+  const int sq = tid & 31, sm = tid >> 5;
+  const int sdst = (sq >> 3) * SL + (sq & 7) * 8;
+  const int chunk_begin = split * p.chunks_per_split;
+  const int chunk_end = min((p.M + 31) / 32, chunk_begin + p.chunks_per_split);
+  float4 pd[2], px[2];
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = ch * 32 + sm + 16 * j;
+      const bool ok = m < p.M;
+      pd[j] = buf_load4(rd, ok ? (unsigned)(m * p.dw + n0 + sq * 4) * 4u : OOB);
+      px[j] = buf_load4(rx, ok ? (unsigned)(m * p.s0w + k0 + sq * 4) * 4u : OOB);
+    }
+  };
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  auto store_chunk = [&](int stage) {
+    unsigned char *st = smem_b + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = sdst + (sm + 16 * j) * 64;
+      uint2 pc[3];
+      split4<2>(pd[j].x, pd[j].y, pd[j].z, pd[j].w, pc);
+      *reinterpret_cast<uint2 *>(st + o) = pc[0];
+      *reinterpret_cast<uint2 *>(st + o + 2048) = pc[1];
+      split4<2>(px[j].x, px[j].y, px[j].z, px[j].w, pc);
+      *reinterpret_cast<uint2 *>(st + OPB + o) = pc[0];
+      *reinterpret_cast<uint2 *>(st + OPB + o + 2048) = pc[1];
+      bsum[0] += pd[j].x; bsum[1] += pd[j].y; bsum[2] += pd[j].z; bsum[3] += pd[j].w;
+    }
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  // fragment addressing (conv_wgrad_halo_kernel): 16-lane group g covers channels 16 (g & 1) .. + 15 and rows
+  // 8 (g >> 1) + {0..3 | 4..7} of a 16-row step; lane t points at row t / 4, channel quad t % 4
+  const int fg = lane >> 4, ft = lane & 15;
+  const int foff = (8 * (fg >> 1) + (ft >> 2)) * 64 + (16 * (fg & 1) + 4 * (ft & 3)) * 2;
+  auto frag = [](const unsigned char *q) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q + 4 * 64));
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  if (chunk_begin < chunk_end) {
+    load_chunk(chunk_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
+    const bool more = ch + 1 < chunk_end;
+    if (more) load_chunk(ch + 1);
+    const unsigned char *st = smem_b + ((ch - chunk_begin) & 1) * STAGE;
+    const unsigned char *ab = st + wn * SL + foff, *bb = st + OPB + (2 * wk) * SL + foff;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const s16x8 ah = frag(ab + s * 16 * 64), al = frag(ab + 2048 + s * 16 * 64);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const s16x8 bh = frag(bb + j * SL + s * 16 * 64), bl = frag(bb + j * SL + 2048 + s * 16 * 64);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc[j], 0, 0, 0);
+      }
+    }
+    if (more) store_chunk(((ch - chunk_begin) + 1) & 1);   // last read one iteration ago: every wave is past its barrier
+    __syncthreads();
+  }
+
+  // ---- bias partials: fixed-order sum over the 16 staging threads of a channel quad
+  if (p.db_partial != nullptr && blockIdx.y == 0) {
+    float *red = reinterpret_cast<float *>(smem_b);   // [128 channels][16 + 1]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[(sq * 4 + e) * 17 + sm] = bsum[e];
+    __syncthreads();
+    if (tid < 128) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[tid * 17 + g];
+      p.db_partial[(size_t)split * p.Cout + n0 + tid] = t;
+    }
+  }
+  float *out = p.partial + (size_t)split * p.Cout * p.Kpad;
+  const int fl = lane & 31, half = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int kcol = k0 + (2 * wk + j) * 32 + fl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int nrow = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      out[(size_t)nrow * p.Kpad + kcol] = acc[j][r];
+    }
+  }
+}
+
 // out[i] = sum_s partial[s * stride + i]  (fixed order: 4 interleaved split groups, then a fixed tree).  A thread owns
 // four consecutive elements (16-byte loads when the rows allow it) and keeps four loads in flight.
 // `map` (optional): the summed [Cout][Kpad] matrix (k = tap * cin + ci) is written in torch's weight layout
@@ -924,6 +1039,28 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   const size_t need = (size_t)nz * ((size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout);
   if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
   a.db_partial = db ? workspace + (size_t)nsplit * nphase * Cout * a.Kpad : nullptr;
+  // a linear layer's weight gradient (rows of a dense matrix): the row-major kernel
+  if (use_split && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 &&
+      pad == 0 && B == 1 && H == 1 && Cout % 128 == 0 && Cin % 128 == 0 && !knobs().no_gemm_kernel) {
+    const int tiles = (Cout / 128) * (Cin / 128);
+    const int ns = std::max(1, std::min(std::min(64, (512 + tiles - 1) / tiles), nchunks / 8));
+    a.nsplit = ns; a.chunks_per_split = (nchunks + ns - 1) / ns;
+    const size_t need_l = (size_t)ns * Cout * a.Kpad + (size_t)ns * Cout;
+    if (workspace_floats < need_l) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
+    a.db_partial = db ? workspace + (size_t)ns * Cout * a.Kpad : nullptr;
+    constexpr size_t smem_l = 2 * 2 * 4 * 2 * 32 * 64;
+    static DeviceOnce attr_l;
+    if (!attr_l.done()) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(linear_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)smem_l) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(linear_wgrad)");
+      attr_l.mark();
+    }
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3(Cout / 128, Cin / 128, ns), dim3(512), smem_l, stream, a);
+    const int rc_l = check_launch("linear_wgrad");
+    if (rc_l) return rc_l;
+    return wgrad_reduce(a, workspace, dw_packed, db, 1, ns, 1, 0, stream, torch_keep);
+  }
   // halo-staged kernel: 3x3 (s1 p1) and k4 (s2 p1) layers with 32-multiple channels and whole 2 x 32 pixel tiles
   const bool k3 = KH == 3 && KW == 3 && stride == 1 && pad == 1, k4 = KH == 4 && KW == 4 && stride == 2 && pad == 1;
   int nco = Cout % 128 == 0 ? 4 : Cout % 64 == 0 ? 2 : 1;

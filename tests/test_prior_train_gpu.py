@@ -516,3 +516,23 @@ def test_linear_gemm_kernel_equals_implicit_gemm(shape, precision):
         ref = torch.relu(ref) if relu else ref
         err = float((got.double() - ref).abs().max() / ref.abs().max())
         assert err < (2e-5 if precision == "bf16x3" else 2e-6), err
+
+
+@pytest.mark.parametrize("shape", [(8200, 512, 512), (1030, 1536, 512), (4100, 512, 2048), (300, 128, 128)])
+def test_linear_weight_gradient_kernel(shape):
+    """`linear_wgrad_kernel` (row-major operands in LDS, transposing fragment reads, two-stage ring) against the
+    per-tap kernel it replaces and fp64: dW = dY^T X and db = column sums of dY, ragged last row chunk included."""
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.priors import _train as PT
+    M, N, K = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    dw_ref, db_ref = dy.double().t() @ x.double(), dy.double().sum(0)
+    dw, db = PT.linear_wgrad(x.to(dev), dy.to(dev))
+    with _hip.knob("ISI_NO_GEMM_KERNEL", 1):
+        dw_old, db_old = PT.linear_wgrad(x.to(dev), dy.to(dev))
+    rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
+    assert rel(dw, dw_ref) < 2e-5 and rel(dw_old, dw_ref) < 2e-5, (rel(dw, dw_ref), rel(dw_old, dw_ref))
+    assert rel(db, db_ref) < 1e-5 and rel(db_old, db_ref) < 1e-5

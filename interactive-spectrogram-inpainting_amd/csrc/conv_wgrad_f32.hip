@@ -877,6 +877,7 @@ static WgradTile wgrad_tile(int Cout, int Kpad) {
   // once per tap); 128 x 32 for the residual 1x1 and 64 x 256 for the 64-channel layers were SLOWER (97 -> 153 us,
   // 116 -> 125 us: fewer, longer dY streams per CU) and are not selected
   if (Kpad <= 64 && Cout <= 64) return {64, 64, 1};   // the 2-channel spectrogram side (K = 16 x 4)
+  if (Kpad <= 64) return {128, 64, 0};                // K = 64 operands (the attention backward's dE = G^T Q: 779 -> 770 us)
   if (Cout <= 32) return {32, 512, 0};                // residual 3x3 (C -> 32)
   return {128, 128, 0};
 }
@@ -924,7 +925,8 @@ static void launch_wgrad_split(const WgradKArgs &a, int nzs, hipStream_t stream)
 }
 template <int NP>
 static void launch_wgrad_split_np(const WgradKArgs &a, const WgradTile &t, int nzs, hipStream_t stream) {
-  if (t.tco == 64 && t.tk == 64) launch_wgrad_split<NP, 2, 1, 1>(a, nzs, stream);
+  if (t.tco == 128 && t.tk == 64) launch_wgrad_split<NP, 2, 2, 1>(a, nzs, stream);
+  else if (t.tco == 64 && t.tk == 64) launch_wgrad_split<NP, 2, 1, 1>(a, nzs, stream);
   else if (t.tco == 32) launch_wgrad_split<NP, 1, 1, 4>(a, nzs, stream);
   else launch_wgrad_split<NP, 2, 2, 2>(a, nzs, stream);
 }

@@ -111,7 +111,9 @@ int isi_spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t
  * same name once, at first use of the library; isi_knob_set changes it afterwards (process-wide, not thread-safe
  * against concurrent launches).  Names: ISI_CONV_FLUSH (accumulator flush period of the LDS-DMA convolution, default
  * 3, 0 = never), ISI_NO_PAIRS, ISI_NO_CONV_FIRST, ISI_NO_VQ_FUSION, ISI_NO_CONV_PAIR_KERNEL,
- * ISI_NO_RESBLOCK_PAIR_KERNEL, ISI_NO_CONVT_PAIR_KERNEL, ISI_NO_TAIL_FUSION, ISI_CONV_PAIR_BM, ISI_CONV_PAIR_ALL,
+ * ISI_NO_RESBLOCK_PAIR_KERNEL, ISI_NO_CONVT_PAIR_KERNEL, ISI_NO_TAIL_FUSION, ISI_NO_WGRAD_HALO (per-tap weight-gradient
+ * kernel instead of the halo-staged one), ISI_NO_GEMM_KERNEL (linear layers and their weight gradients on the 1x1
+ * convolution kernels instead of the GEMM kernels), ISI_CONV_PAIR_BM, ISI_CONV_PAIR_ALL,
  * ISI_CONV_TAP_MAJOR, ISI_RESPAIR_TH, ISI_RES_TH, ISI_CONVT_TH, ISI_CONVT_PAIR_TH, ISI_DECODE_NT, ISI_PRIOR_GRAPH -- all select between kernels that
  * compute the SAME result (to rounding).  The ablation switches ISI_CONV_ABLATE / ISI_VQ_DBG / ISI_RESPAIR_ABL
  * (wrong results by design) exist only in -DISI_MEASURE builds: the default build rejects them. */

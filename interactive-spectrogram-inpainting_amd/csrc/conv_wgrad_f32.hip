@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad_halo_kernel(const WgradKA
   const int fg = lane >> 4, ft = lane & 15;
   const int frow = 8 * (fg >> 1) + (ft >> 2), fch = (16 * (fg & 1) + 4 * (ft & 3)) * 2;
   const unsigned char *Ab = Ds + cg * 2 * DPL + frow * 64 + fch;
-  const unsigned char *Bb = Xs + cs * 2 * XPL + (S == 1 ? frow : frow) * 64 + fch;
+  const unsigned char *Bb = Xs + cs * 2 * XPL + frow * 64 + fch;
   auto frag = [](const unsigned char *q) {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q));
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(q + 4 * 64));

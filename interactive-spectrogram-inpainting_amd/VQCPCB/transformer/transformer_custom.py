@@ -59,7 +59,7 @@ class _LinearParams(nn.Module):
         key = (_hip.version_of(self.weight), self.weight.data_ptr(), inference)
         if self._key != key:
             ok = self._range.update(self.weight, inference)
-            self._packed, self._key = _ops.pack_linear_weight(self.weight, range_check=ok), key
+            self._packed, self._key = _ops.pack_linear_weight(self.weight, range_check=ok, with_f16=inference and ok), key
         return self._packed
 
     def packed_t(self):
@@ -174,8 +174,10 @@ class RelativeMultiheadAttention(nn.Module):
             d = self.d_model
             W = self.in_proj_weight.detach()
             ok = self._range.update(self.in_proj_weight, inference)      # one check covers the three row ranges
-            self._packed = (_ops.pack_linear_weight(W, range_check=ok), _ops.pack_linear_weight(W[:d], range_check=ok),
-                            _ops.pack_linear_weight(W[d:], range_check=ok))
+            f16 = inference and ok     # weights that stay put: pair copies for the GEMM kernel
+            self._packed = (_ops.pack_linear_weight(W, range_check=ok, with_f16=f16),
+                            _ops.pack_linear_weight(W[:d], range_check=ok, with_f16=f16),
+                            _ops.pack_linear_weight(W[d:], range_check=ok, with_f16=f16))
             self._key = key
         return self._packed
 

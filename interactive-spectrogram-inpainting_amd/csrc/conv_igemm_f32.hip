@@ -718,7 +718,8 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
       gemm_split_applicable(W, Cout, s0->C, split_mode(relu)) && aligned16(s0->ptr) && aligned16(packed_w) && s0->sw % 4 == 0 &&
       !knobs().no_gemm_kernel)
     return gemm_split_f32(s0->ptr, s0->sw, packed_w, bias, (res && res->ptr) ? res->ptr : nullptr, (res && res->ptr) ? res->sw : 0,
-                          dst->ptr, dst->sw, W, Cout, s0->C, relu & 1, split_mode(relu), stream);
+                          dst->ptr, dst->sw, W, Cout, s0->C, relu & 1, split_mode(relu), stream,
+                          (relu & ISI_CONV_W16) ? packed_w + (size_t)Cout * round_up((size_t)s0->C, kBK) : nullptr);
   const int64_t zmax = std::max(std::max(zs_in0, zs_w), std::max(zs_res, zs_out));
   if (zmax < 0 || zmax >= ((int64_t)1 << 31)) return unsupported("conv2d: batch stride out of range");
   ConvKArgs a;

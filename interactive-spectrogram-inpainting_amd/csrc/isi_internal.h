@@ -113,7 +113,8 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
 
 bool gemm_split_applicable(int M, int N, int K, int split_mode);
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
-                   int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream);
+                   int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream,
+                   const float *w16 = nullptr);
 size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
 int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                    float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,

@@ -65,14 +65,19 @@ class WeightRange:
         return self.ok
 
 
-def pack_linear_weight(weight: torch.Tensor, range_check=False) -> torch.Tensor:
+def pack_linear_weight(weight: torch.Tensor, range_check=False, with_f16: bool = False) -> torch.Tensor:
     """nn.Linear weight [N,K] -> packed GEMM operand (a 1x1 convolution weight: [N][K padded to 32]).  A dense fp32
     weight whose K is a multiple of 32 IS that operand: it is returned as a view, no copy and no launch (the prior's
     ~120 linears were re-packed every training step: 265 launches of 5 us).  `range_check`: "now" = compare against
     the split-f16 operand range here (reads one scalar back: constant operands, packed once); True / False = the
     caller's knowledge (WeightRange.update); False also stands for an unknown range (the GEMM runs 'bf16x6')."""
     w = weight.detach()
-    if (w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32 and w.shape[1] % 32 == 0
+    if with_f16:
+        # a weight that stays put (inference): its split-f16 pair copy behind it (ISI_CONV_W16) -- the GEMM kernel then
+        # stages the weight tile by plain copies instead of converting it once per 128-row tile
+        packed = pack_conv_weight(w.reshape(w.shape[0], w.shape[1], 1, 1), with_f16=True)
+        packed.isi_w16 = True
+    elif (w.dim() == 2 and w.is_contiguous() and w.dtype == torch.float32 and w.shape[1] % 32 == 0
             and w.data_ptr() % 16 == 0 and w.is_cuda):
         packed = w.view(w.shape[0], w.shape[1])          # a fresh tensor object (it carries an attribute below)
     else:
@@ -109,10 +114,11 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
         res = _hip.isi_src(r2.data_ptr(), n_out, 0, 1, 0, r2.stride(0))
+    w16 = 16 if (prec == "f16x3" and getattr(packed_w, "isi_w16", False)) else 0          # ISI_CONV_W16
     rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, packed_w.data_ptr(),
                                    bias.data_ptr() if bias is not None else None,
                                    C.byref(res) if res is not None else None, C.byref(dst),
-                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[prec], _s(x))
+                                   1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[prec] | w16, _s(x))
     _hip.check(rc, "isi_conv2d_f32 (linear)")
     return out.reshape(*x.shape[:-1], n_out)
 

@@ -516,6 +516,9 @@ def test_linear_gemm_kernel_equals_implicit_gemm(shape, precision):
         ref = torch.relu(ref) if relu else ref
         err = float((got.double() - ref).abs().max() / ref.abs().max())
         assert err < (2e-5 if precision == "bf16x3" else 2e-6), err
+        if precision == "f16x3":    # inference weights carry their split-f16 pair copy: staged by plain copies, same bits
+            pw16 = _ops.pack_linear_weight(W, range_check="now", with_f16=True)
+            assert pw16.isi_w16 and torch.equal(_ops.linear(x, pw16, b, N, relu=relu, residual=r, precision=precision), got)
 
 
 @pytest.mark.parametrize("shape", [(8200, 512, 512), (1030, 1536, 512), (4100, 512, 2048), (300, 128, 128)])

@@ -137,6 +137,12 @@ int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin,
  * (autograd's conv backward-data behind train_vqvae.py:181): [Cin][KH*KW*Cout padded to 32] with the window rotated by
  * 180 degrees -- what isi_pack_conv_weight_f32 would make of w.flip(2, 3).transpose(0, 1), in one launch.  Run it
  * through isi_conv2d_f32 with padding K - 1 - p. */
+/* nn.Linear weight w [N][K] -> operand of its input-gradient GEMM dX = dY W (autograd's linear backward behind
+ * train_autoregressive_model.py:199-201): out[0 .. K N) = W^T ([K][N] fp32: the "packed weight" of a 1x1 convolution
+ * with K outputs and N inputs), out[K N .. 2 K N) = its split-bf16 pair copy (groups of 8 as {hi[8] | lo[8]}).  Pass it
+ * to isi_conv2d_f32 with ISI_CONV_BF16X3 | ISI_CONV_W16: the GEMM kernel stages the weight tile by plain copies.  N, K
+ * multiples of 32; out: 2 K N floats, 16-byte aligned. */
+int isi_pack_linear_wT_bf16(const float *w, float *out, int N, int K, void *stream);
 int isi_pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH,
                                    int KW, void *stream);
 /* Split-f16 pair copy of a packed weight (any of the packed layouts; n_floats % 4 == 0, 16-byte aligned):
@@ -189,7 +195,9 @@ typedef struct isi_dst {
                            * the split; the scaling is undone exactly).  An operand outside the range
                            * gives Inf / NaN in the output, never a silently wrong value.        */
 
-#define ISI_CONV_W16 16   /* with ISI_CONV_F16X3: the packed weight is followed in memory by its split-f16 pair copy
+#define ISI_CONV_W16 16   /* (with ISI_CONV_BF16X3 on a GEMM-shaped launch: followed by the split-bf16 pair copy of
+                           * isi_pack_linear_wT_bf16.)
+                           * with ISI_CONV_F16X3: the packed weight is followed in memory by its split-f16 pair copy
                            * (isi_split_conv_weight_f16 written at packed_w + the packed size in floats: the weights'
                            * pieces are then prepared once instead of every time a tile is staged; same results bit
                            * for bit).  Ignored by the launches that do not run split products.          */

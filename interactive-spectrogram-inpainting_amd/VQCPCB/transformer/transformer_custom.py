@@ -66,7 +66,7 @@ class _LinearParams(nn.Module):
         """GEMM operand of the input gradient: W^T ([in, out]) packed like a forward weight."""
         key = (_hip.version_of(self.weight), self.weight.data_ptr())
         if self._key_t != key:
-            self._packed_t, self._key_t = _ops.pack_linear_weight(self.weight.detach().t().contiguous()), key
+            self._packed_t, self._key_t = _ops.pack_linear_weight_t(self.weight), key
         return self._packed_t
 
     def run(self, x, relu=False, residual=None):
@@ -154,7 +154,7 @@ class RelativeMultiheadAttention(nn.Module):
         if self._key_t != key:
             d = self.d_model
             W = self.in_proj_weight.detach()
-            self._packed_t = tuple(_ops.pack_linear_weight(w.t().contiguous()) for w in (W, W[:d], W[d:]))
+            self._packed_t = tuple(_ops.pack_linear_weight_t(w) for w in (W, W[:d], W[d:]))
             self._key_t = key
         return self._packed_t
 

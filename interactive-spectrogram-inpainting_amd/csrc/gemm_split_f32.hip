@@ -58,13 +58,12 @@ __device__ __forceinline__ f32x16 mfma(const s16x8g a, const s16x8g b, const f32
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
-// TN: 32-column tiles per wave (tile width BN = 64 TN).  WPRE (F16 only): `w` is the weight's split-f16 pair copy
-// (ISI_CONV_W16: groups of 8 k as {hi[8] | lo[8]}, 32 bytes where the 8 floats were) -- a 16-byte piece IS a slot of
+// TN: 32-column tiles per wave (tile width BN = 64 TN).  WPRE: `w` is the weight's pair copy in the product mode's
+// pieces (ISI_CONV_W16: groups of 8 k as {hi[8] | lo[8]}, 32 bytes where the 8 floats were) -- a 16-byte piece IS a slot of
 // the LDS planes, so the weight tile is staged by plain copies: every 128-row tile of the fp32 form converts its
 // weight tile again, 65 times at M = 8200.
 template <bool F16, int TN, bool WPRE = false>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const GemmArgs p) {
-  static_assert(!WPRE || F16, "pre-split weights exist in the f16 pair format only");
   constexpr int BN = 64 * TN;
   constexpr int APL = BM * 64, BPL = BN * 64;                  // bytes of one plane (rows of 32 pieces = 64 B)
   constexpr int STAGE = 2 * APL + 2 * BPL;                     // A hi, A lo, B hi, B lo
@@ -217,7 +216,7 @@ bool gemm_split_applicable(int M, int N, int K, int split_mode) {
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
                    int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream, const float *w16) {
   GemmArgs g;
-  g.a = a; g.w = (w16 && split_mode == 3) ? w16 : w; g.bias = bias; g.res = res; g.out = out;
+  g.a = a; g.w = w16 ? w16 : w; g.bias = bias; g.res = res; g.out = out;
   g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldr = (int)ldr; g.ldo = (int)ldo; g.relu = relu;
   const int64_t ea = (int64_t)(M - 1) * lda + K, eo = (int64_t)(M - 1) * ldo + N, er = res ? (int64_t)(M - 1) * ldr + N : 1;
   const int64_t lim = (int64_t)1 << 30;
@@ -229,6 +228,7 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   const bool narrow = tiles128 < 512 || N % 128 != 0;
   if (split_mode == 3 && w16) return narrow ? launch_gemm<true, 1, true>(g, stream) : launch_gemm<true, 2, true>(g, stream);
   if (split_mode == 3) return narrow ? launch_gemm<true, 1>(g, stream) : launch_gemm<true, 2>(g, stream);
+  if (w16) return narrow ? launch_gemm<false, 1, true>(g, stream) : launch_gemm<false, 2, true>(g, stream);
   return narrow ? launch_gemm<false, 1>(g, stream) : launch_gemm<false, 2>(g, stream);
 }
 

@@ -173,6 +173,7 @@ size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
 size_t packed_convT_k4s2_weight_floats(int Cin, int Cout);
 int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
                          hipStream_t stream);
+int pack_linear_wT_bf16(const float *w, float *out, int N, int K, hipStream_t stream);
 int pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, hipStream_t stream);
 int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,
                                hipStream_t stream);

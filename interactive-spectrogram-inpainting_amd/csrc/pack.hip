@@ -8,6 +8,7 @@
 // vqvae/bottleneck.py:47-51.
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "split_bf16.h"
 #include "split_f16.h"
 
 namespace isi {
@@ -88,6 +89,44 @@ __global__ void split_weight_f16_kernel(const float4 *__restrict__ in, uint4 *__
     out[2 * i] = hi;
     out[2 * i + 1] = lo;
   }
+}
+
+// nn.Linear weight w [N][K] -> the operand of its input-gradient GEMM dX = dY W, i.e. W^T as a [K][N] "weight": the fp32
+// transpose followed by its split-bf16 pair copy (groups of 8 consecutive n as {hi[8] | lo[8]} bf16, 32 bytes where the
+// 8 floats would be; pieces exactly as split_bf16.h forms them while staging).  One launch per weight and step instead
+// of a transposing copy, and the GEMM kernel stages the weight tile by plain copies.  N, K multiples of 32.
+__global__ __launch_bounds__(256) void linear_wT_bf16_kernel(const float *__restrict__ w, float *__restrict__ outT,
+                                                             float *__restrict__ out16, int N, int K) {
+  __shared__ float tile[32][33];
+  const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 1024; i += 256) {
+    const int r = i >> 5, c = i & 31;                      // row n0 + r, column k0 + c: 128-byte row segments
+    tile[r][c] = w[(size_t)(n0 + r) * K + k0 + c];
+  }
+  __syncthreads();
+  if (tid < 128) {
+    const int kk = tid >> 2, g = tid & 3;                  // output row k0 + kk, group of 8 n
+    float4 a, b;
+    a.x = tile[8 * g + 0][kk]; a.y = tile[8 * g + 1][kk]; a.z = tile[8 * g + 2][kk]; a.w = tile[8 * g + 3][kk];
+    b.x = tile[8 * g + 4][kk]; b.y = tile[8 * g + 5][kk]; b.z = tile[8 * g + 6][kk]; b.w = tile[8 * g + 7][kk];
+    const size_t o = (size_t)(k0 + kk) * N + n0 + 8 * g;
+    *reinterpret_cast<float4 *>(outT + o) = a;
+    *reinterpret_cast<float4 *>(outT + o + 4) = b;
+    uint2 h0, l0, h1, l1;
+    split_f4(a, h0, l0);
+    split_f4(b, h1, l1);
+    *reinterpret_cast<uint4 *>(out16 + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4 *>(out16 + o + 4) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+  }
+}
+
+int pack_linear_wT_bf16(const float *w, float *out, int N, int K, hipStream_t stream) {
+  if (!w || !out || N <= 0 || K <= 0 || (N & 31) || (K & 31)) return invalid("pack_linear_wT_bf16: N, K multiples of 32");
+  if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15)
+    return invalid("pack_linear_wT_bf16: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(linear_wT_bf16_kernel, dim3(N / 32, K / 32), dim3(256), 0, stream, w, out, out + (size_t)N * K, N, K);
+  return check_launch("pack_linear_wT_bf16");
 }
 
 int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream) {

@@ -91,6 +91,22 @@ def pack_linear_weight(weight: torch.Tensor, range_check=False, with_f16: bool =
     return packed
 
 
+def pack_linear_weight_t(weight: torch.Tensor) -> torch.Tensor:
+    """nn.Linear weight [N,K] -> operand of the input-gradient GEMM dX = dY W: W^T as a packed [K][N] weight followed
+    by its split-bf16 pair copy (isi_pack_linear_wT_bf16: one launch, and the GEMM kernel stages the weight tile by
+    plain copies); other shapes: the transposing copy."""
+    w = weight.detach()
+    N, K = w.shape
+    if (N % 32 == 0 and K % 32 == 0 and w.is_contiguous() and w.dtype == torch.float32 and w.is_cuda
+            and w.data_ptr() % 16 == 0 and LINEAR_GRAD_PRECISION == "bf16x3"):
+        out = torch.empty(2 * N * K, dtype=torch.float32, device=w.device)
+        _hip.check(_hip.lib().isi_pack_linear_wT_bf16(w.data_ptr(), out.data_ptr(), N, K, _s(w)), "isi_pack_linear_wT_bf16")
+        out.isi_f16_ok = False
+        out.isi_w16_bf16 = True
+        return out
+    return pack_linear_weight(w.t().contiguous())
+
+
 def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], n_out: int,
            relu: bool = False, residual: Optional[torch.Tensor] = None,
            precision: Optional[str] = None) -> torch.Tensor:
@@ -114,7 +130,8 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
         res = _hip.isi_src(r2.data_ptr(), n_out, 0, 1, 0, r2.stride(0))
-    w16 = 16 if (prec == "f16x3" and getattr(packed_w, "isi_w16", False)) else 0          # ISI_CONV_W16
+    w16 = 16 if ((prec == "f16x3" and getattr(packed_w, "isi_w16", False)) or
+                 (prec == "bf16x3" and getattr(packed_w, "isi_w16_bf16", False))) else 0          # ISI_CONV_W16
     rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, packed_w.data_ptr(),
                                    bias.data_ptr() if bias is not None else None,
                                    C.byref(res) if res is not None else None, C.byref(dst),

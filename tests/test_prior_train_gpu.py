@@ -516,6 +516,12 @@ def test_linear_gemm_kernel_equals_implicit_gemm(shape, precision):
         ref = torch.relu(ref) if relu else ref
         err = float((got.double() - ref).abs().max() / ref.abs().max())
         assert err < (2e-5 if precision == "bf16x3" else 2e-6), err
+        if precision == "bf16x3" and r is None and N % 32 == 0:
+            # the input-gradient operand W^T with its split-bf16 pair copy (one launch) against the transposing copy
+            gy = torch.randn(M, N, generator=g).to(dev)
+            a = _ops.linear(gy, _ops.pack_linear_weight_t(W), None, K, precision="bf16x3")
+            b_ = _ops.linear(gy, _ops.pack_linear_weight(W.t().contiguous()), None, K, precision="bf16x3")
+            assert torch.equal(a, b_)
         if precision == "f16x3":    # inference weights carry their split-f16 pair copy: staged by plain copies, same bits
             pw16 = _ops.pack_linear_weight(W, range_check="now", with_f16=True)
             assert pw16.isi_w16 and torch.equal(_ops.linear(x, pw16, b, N, relu=relu, residual=r, precision=precision), got)

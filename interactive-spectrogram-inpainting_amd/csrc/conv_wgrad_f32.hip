@@ -688,7 +688,10 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad_halo_kernel(const WgradKA
 // row-major fragments the reduction over rows needs; two-stage ring, one barrier per chunk, 8 waves on a 128 x 128 tile
 // (wave: 32 output features x 64 input features), 64 KB of LDS: two workgroups per CU.
 __global__ __launch_bounds__(512, 2) void linear_wgrad_kernel(const WgradKArgs p) {
-  constexpr int SL = 2 * 32 * 64;            // bytes of one 32-channel slice: hi plane, lo plane of [32 rows][64 B]
+  // bytes of one 32-channel slice: hi plane, lo plane of [32 rows][64 B], + 128: a staging instruction's 64 lanes write two
+  // rows of all four slices -- with slices a multiple of 256 bytes apart those were four-way bank conflicts (SQ counters:
+  // 29 % of the LDS cycles); 128 bytes apart they tile the 64 banks exactly twice
+  constexpr int SL = 2 * 32 * 64 + 128;
   constexpr int OPB = 4 * SL;                // one operand's chunk: four slices (128 channels)
   constexpr int STAGE = 2 * OPB;             // dY, then X
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -1050,7 +1053,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
     const size_t need_l = (size_t)ns * Cout * a.Kpad + (size_t)ns * Cout;
     if (workspace_floats < need_l) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
     a.db_partial = db ? workspace + (size_t)ns * Cout * a.Kpad : nullptr;
-    constexpr size_t smem_l = 2 * 2 * 4 * 2 * 32 * 64;
+    constexpr size_t smem_l = 2 * 2 * 4 * (2 * 32 * 64 + 128);
     static DeviceOnce attr_l;
     if (!attr_l.done()) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(linear_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -413,6 +413,32 @@ int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *po
 // multinomial), with a host-supplied uniform u[row] in [0,1) replacing torch's
 // RNG stream: the sample is the first index whose inclusive cumulative
 // probability exceeds u * total.  One workgroup per row; n <= 1024.
+//
+// Round 3: the kernel was 15 us of a 290 us token -- a 45-stage bitonic sort and two Hillis-Steele scans, ~90 block
+// barriers.  Now (a) no filter (top_k = 0, top_p = 0: the reference's plain multinomial) sorts nothing; (b) the sort
+// runs its stages with partner distance < 64 inside a wave (`__shfl_xor`, no barrier: 39 of the 45 stages at n = 512)
+// and only the 6 long-distance stages through LDS; (c) the prefix sums are wave scans (`__shfl_up`) plus one exchange
+// of the wave totals: 2 barriers each.
+__device__ __forceinline__ float block_inclusive_scan(float v, float *wave_tot, float *total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  if (lane == 63) wave_tot[wave] = v;
+  __syncthreads();
+  float pre = 0.f, tot = 0.f;
+  for (int w = 0; w < nw; ++w) {       // fixed order: the same sums on every thread
+    const float t = wave_tot[w];
+    if (w < wave) pre += t;
+    tot += t;
+  }
+  __syncthreads();                     // wave_tot may be reused by the caller's next scan
+  *total = tot;
+  return pre + v;
+}
+
 __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__restrict__ logits, int stride,
                                                               int n, float inv_temperature, int top_k,
                                                               float top_p, const float *__restrict__ u,
@@ -423,73 +449,82 @@ __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__res
   if (pos) u += (size_t)(*pos - pos_off) * gridDim.x;  // replayable launch: this token's uniforms
   __shared__ float val[1024];
   __shared__ int idx[1024];
-  __shared__ float scan[1024];
   __shared__ int keep[1024];
+  __shared__ float wave_tot[16];
   __shared__ float sh_f[2];
   __shared__ int sh_i;
   const int tid = threadIdx.x, np = blockDim.x, row = blockIdx.x;
   const float NEGI = -INFINITY;
   const float lg = tid < n ? logits[(size_t)row * stride + tid] * inv_temperature : NEGI;
-  val[tid] = lg;
-  idx[tid] = tid;
-  __syncthreads();
-  // bitonic sort, descending by value (ties: lower index first)
-  for (int k = 2; k <= np; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const int partner = tid ^ j;
-      if (partner > tid) {
-        const bool desc = (tid & k) == 0;
-        const float a = val[tid], c = val[partner];
-        const int ia = idx[tid], ic = idx[partner];
-        const bool a_first = a > c || (a == c && ia < ic);
-        if (desc ? !a_first : a_first) {
-          val[tid] = c; val[partner] = a;
-          idx[tid] = ic; idx[partner] = ia;
+  float vmax;
+  bool kp = tid < n;
+  if (top_k > 0 || top_p > 0.f) {
+    // ---- bitonic sort, descending by value (ties: lower index first); element t lives in thread t
+    float v = lg;
+    int ix = tid;
+    for (int k = 2; k <= np; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        float c;
+        int ic;
+        if (j >= 64) {                 // partner in another wave: through LDS
+          val[tid] = v; idx[tid] = ix;
+          __syncthreads();
+          c = val[tid ^ j]; ic = idx[tid ^ j];
+          __syncthreads();
+        } else {
+          c = __shfl_xor(v, j); ic = __shfl_xor(ix, j);
         }
+        const bool lower = (tid & j) == 0;                 // this thread keeps the element that comes FIRST of the pair
+        const bool desc = (tid & k) == 0;                  // ... in a descending (ascending) run
+        const bool mine_first = v > c || (v == c && ix < ic);
+        const bool take_mine = (lower == desc) ? mine_first : !mine_first;
+        if (!take_mine) { v = c; ix = ic; }
       }
+    }
+    // sorted position tid = (v, ix)
+    val[tid] = v;
+    __syncthreads();
+    vmax = val[0];
+    // top-k: drop everything strictly below the k-th largest value
+    const float kth = top_k > 0 ? val[min(top_k, n) - 1] : NEGI;
+    const float sv = (top_k > 0 && v < kth) ? NEGI : v;
+    bool removed = sv == NEGI;
+    __syncthreads();                   // val is reused below
+    if (top_p > 0.f) {
+      // top-p on the sorted, top-k-filtered row: remove position s when the cumulative probability up to s - 1
+      // already exceeds top_p
+      const float ex = sv == NEGI ? 0.f : expf(sv - vmax);
+      float total;
+      const float inc = block_inclusive_scan(ex, wave_tot, &total);
+      val[tid] = inc;
+      __syncthreads();
+      if (tid > 0 && val[tid - 1] / total > top_p) removed = true;
       __syncthreads();
     }
-  }
-  // top-k: drop everything strictly below the k-th largest value
-  float kth = NEGI;
-  if (top_k > 0) kth = val[min(top_k, n) - 1];
-  const float sv = (top_k > 0 && val[tid] < kth) ? NEGI : val[tid];
-  const float vmax = val[0];
-  // top-p on the sorted, top-k-filtered row
-  bool removed = sv == NEGI;
-  if (top_p > 0.f) {
-    const float ex = sv == NEGI ? 0.f : expf(sv - vmax);
-    scan[tid] = ex;
+    keep[ix] = removed ? 0 : 1;
     __syncthreads();
-    for (int o = 1; o < np; o <<= 1) {
-      const float t = tid >= o ? scan[tid - o] : 0.f;
-      __syncthreads();
-      scan[tid] += t;
-      __syncthreads();
-    }
-    const float total = scan[np - 1];
-    // remove position s when the cumulative probability up to s-1 already exceeds top_p
-    if (tid > 0 && scan[tid - 1] / total > top_p) removed = true;
+    kp = tid < n && keep[tid];
+  } else {
+    // no filter: the maximum is all the sort was needed for
+    float m = lg;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) wave_tot[tid >> 6] = m;
     __syncthreads();
+    m = wave_tot[0];
+    for (int w = 1; w < (np + 63) / 64; ++w) m = fmaxf(m, wave_tot[w]);
+    __syncthreads();
+    vmax = m;
   }
-  keep[idx[tid]] = removed ? 0 : 1;
-  __syncthreads();
   // probabilities in index order, inverse-CDF draw
-  const bool kp = tid < n && keep[tid];
   const float fl = kp ? lg : NEGI;
   if (filtered && tid < n) filtered[(size_t)row * n + tid] = fl;
   const float pe = kp ? expf(lg - vmax) : 0.f;
-  scan[tid] = pe;
+  float total;
+  const float inc = block_inclusive_scan(pe, wave_tot, &total);
+  if (tid == 0) sh_i = n - 1;
   __syncthreads();
-  for (int o = 1; o < np; o <<= 1) {
-    const float t = tid >= o ? scan[tid - o] : 0.f;
-    __syncthreads();
-    scan[tid] += t;
-    __syncthreads();
-  }
-  if (tid == 0) { sh_i = n - 1; sh_f[0] = u[row] * scan[np - 1]; }
-  __syncthreads();
-  if (tid < n && scan[tid] > sh_f[0]) atomicMin(&sh_i, tid);
+  if (tid < n && inc > u[row] * total) atomicMin(&sh_i, tid);
   __syncthreads();
   if (tid == 0) out[row] = sh_i;
   // the decoding loop's commit, in the same launch: code row, and the token's embedding into the next input row
@@ -502,6 +537,7 @@ __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__res
       for (int e = tid; e < cm.eff; e += np) x_next[e] = cm.table[(size_t)tok * cm.eff + e];
     }
   }
+  (void)sh_f;
 }
 
 int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,

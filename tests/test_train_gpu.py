@@ -429,3 +429,35 @@ def test_input_gradient_weight_pack(shape):
     cout, cin, k = shape
     w = torch.randn(cout, cin, k, k, generator=torch.Generator().manual_seed(k + cout)).to(_dev())
     assert torch.equal(_ops.pack_conv_dgrad_weight(w), _ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous()))
+
+
+@pytest.mark.parametrize("layer_kind", ["conv3 128->128 @32x128", "k4s2 64->128 @64x256", "convT 128->64 @32x128", "res3 128->32 @32x128"])
+def test_backward_adjoint_identities_at_full_size(layer_kind):
+    """BASELINE config 3's per-GPU shard (B = 64 of [2,128,512]) is too large for the CPU oracle's backward, so the
+    backward kernels are checked there through a size-independent property: a convolution is linear in its input and
+    in its weight, so for random X, W, dY
+        <dY, conv(X; W)>  ==  <dX(dY; W), X>  ==  <dW(X, dY), W>                  (bias-free)
+    with the forward on the exact fp32 pipe and the inner products in fp64.  The input-gradient (three-term split,
+    gated epilogue off) and weight-gradient kernels (halo-staged, two wave groups) at the sizes the bench times."""
+    from interactive_spectrogram_inpainting.vqvae import _ops, _train
+    from interactive_spectrogram_inpainting.vqvae.encoder_decoder import _ConvParams
+    dev = _dev()
+    cin, cout, k, s, tr, H, W = {"conv3 128->128 @32x128": (128, 128, 3, 1, False, 32, 128),
+                                 "k4s2 64->128 @64x256": (64, 128, 4, 2, False, 64, 256),
+                                 "convT 128->64 @32x128": (128, 64, 4, 2, True, 32, 128),
+                                 "res3 128->32 @32x128": (128, 32, 3, 1, False, 32, 128)}[layer_kind]
+    B = 64
+    torch.manual_seed(len(layer_kind))
+    layer = _ConvParams(cin, cout, k, s, 1, transposed=tr).to(dev)
+    x = torch.randn(B, H, W, cin, device=dev).permute(0, 3, 1, 2)
+    y = layer.run(x, relu=False)                                    # exact fp32 products, channels-last storage
+    y = y - layer.bias.view(1, -1, 1, 1)                             # the bilinear part
+    dy = torch.randn(y.shape[0], y.shape[2], y.shape[3], y.shape[1], device=dev)   # NHWC
+    lhs = (dy.double() * y.permute(0, 2, 3, 1).double()).sum().item()
+    dw, db = _train.conv_wgrad(layer, x, dy)
+    via_w = (dw.double() * layer.weight.detach().double()).sum().item()
+    dx = _train.conv_dgrad(_train._DgradWeights(), layer, dy.permute(0, 3, 1, 2))
+    via_x = (dx.double() * x.double()).sum().item()
+    scale = (dy.double().pow(2).sum().sqrt() * y.double().pow(2).sum().sqrt()).item()
+    assert abs(via_w - lhs) < 2e-5 * scale and abs(via_x - lhs) < 2e-5 * scale, (lhs, via_w, via_x, scale)
+    assert _rel(db, dy.double().sum((0, 1, 2))) < 1e-5

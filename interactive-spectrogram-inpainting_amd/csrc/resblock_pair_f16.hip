@@ -420,7 +420,9 @@ bool resblock_pair_preferred(int B, int H, int W, int C, int R) {
   (void)B;
   if (!resblock_pair_ok(C, R)) return false;
   if (knobs().respair_th) return true;
-  return (long)H * W >= 2048;
+  // (round 3, after the rewrite: 4-row tiles also win at the top resolution -- 16 x 64 at B = 64: 28.1 us against
+  // 33.6 us for resblock_f32_kernel on the same pair tensors; below that the launch does not fill the chip either way)
+  return (long)H * W >= 1024;
 }
 
 bool resblock_pair_ok(int C, int R) {

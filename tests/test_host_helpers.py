@@ -530,3 +530,55 @@ def test_ema_statistics_exchange_and_even_training_shards_gloo():
         seen.append(steps["train"][1])
     assert not set(seen[0]) & set(seen[1]) and len(seen[0]) == len(seen[1]) == 24
     torch.testing.assert_close(out[0][1], out[1][1], rtol=0, atol=0)      # identical codebooks on both ranks
+
+
+def test_weight_version_counts_optimizer_steps():
+    """Packed-weight caches key on `_hip.version_of`: the tensor's version AND a global optimizer-step count (torch's
+    fused optimizers update parameters without bumping `tensor._version`).  Host logic only."""
+    import torch
+    from interactive_spectrogram_inpainting import _hip
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.ones(3)
+    opt = torch.optim.SGD([p], lr=0.1)
+    before = _hip.version_of(p)
+    steps = _hip.optimizer_steps()
+    opt.step()
+    after = _hip.version_of(p)
+    assert after != before and _hip.optimizer_steps() == steps + 1
+    with torch.no_grad():
+        p.add_(1.0)                        # an in-place update outside any optimizer: the version counter moves
+    assert _hip.version_of(p) != after and _hip.optimizer_steps() == steps + 1
+
+
+def test_weight_range_monitor_and_optimizer_helper():
+    """`WeightRange` (split-f16 operand range of a weight without a device read-back per step) and `make_adam`."""
+    import torch
+    from interactive_spectrogram_inpainting.priors._ops import WeightRange
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    w = torch.nn.Parameter(torch.full((4, 32), 0.5))
+    mon = WeightRange()
+    calls = []
+    real_abs = torch.Tensor.abs
+
+    def spy(self, *a, **k):
+        calls.append(1)
+        return real_abs(self, *a, **k)
+    torch.Tensor.abs = spy
+    try:
+        assert mon.update(w, False) is True and len(calls) == 1
+        opt = make_adam([w], lr=1e-3)
+        assert isinstance(opt, torch.optim.Adam)
+        for _ in range(5):                                  # training: no further checks for ~256 versions
+            w.grad = torch.ones_like(w)
+            opt.step()
+            assert mon.update(w, False) is True
+        assert len(calls) == 1
+        with torch.no_grad():
+            w[0, 0] = 40.0                                   # inside the range, beyond HALF of it
+        assert mon.update(w, True) is True                   # inference weights: exact limit, checked now
+        assert WeightRange().update(w, False) is False       # a weight under training: half the limit
+        with torch.no_grad():
+            w[0, 0] = 70.0
+        assert mon.update(w, True) is False
+    finally:
+        torch.Tensor.abs = real_abs

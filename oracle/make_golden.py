@@ -624,6 +624,16 @@ def train_trajectory_fixtures():
     _save("train_trajectory.npz", **out)
 
 
+def vqvae_f16_fixtures():
+    """The deepest down-sampling the reference's encoder / decoder offer (resolution factor 16 at the bottom level:
+    vqvae/encoder_decoder.py:57-75 and :158-176), reduced widths; top level a further factor 2."""
+    vqvae_fixture("vqvae_f16_f2.npz",
+                  dict(in_channel=2, num_hidden_channels=16, n_res_block=1,
+                       num_residual_channels=8, embed_dim=8, num_embeddings=32,
+                       resolution_factors={"bottom": 16, "top": 2}),
+                  (1, 2, 64, 96), seed=25)
+
+
 def main():
     os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
     _install_stubs()
@@ -655,6 +665,7 @@ def main():
                        num_residual_channels=8, embed_dim=16, num_embeddings=64, groups=2,
                        resolution_factors={"bottom": 4, "top": 2}),
                   (2, 2, 32, 32), seed=24)
+    vqvae_f16_fixtures()
     resblock_fixture()
     layer_fixtures()
     quantizer_fixtures()

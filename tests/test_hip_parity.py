@@ -385,7 +385,7 @@ def _certify_index_mismatches(z_vecs, embed, got, ref, eps=2e-6):
     return bad.numel()
 
 
-@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz", "vqvae_groups2.npz"])
+@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz", "vqvae_f16_f2.npz", "vqvae_groups2.npz"])
 def test_vqvae_against_reference(golden_dir, name):
     z = np.load(golden_dir / name)
     m = _model_from_golden(z)

@@ -30,7 +30,7 @@ def _close(a, b, tol=1e-5):
     assert err <= tol, f"max rel-to-max error {err:.3e} > {tol}"
 
 
-@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz", "vqvae_groups2.npz"])
+@pytest.mark.parametrize("name", ["vqvae_small.npz", "vqvae_default_tiny.npz", "vqvae_f8_f4.npz", "vqvae_f16_f2.npz", "vqvae_groups2.npz"])
 def test_vqvae_forward_matches_reference(golden_dir, name):
     z, sd = _load(golden_dir, name)
     cfg = _cfg(z)
@@ -114,7 +114,7 @@ def test_init_state_dict_keys_match_reference(golden_dir):
     assert set(mine) == set(sd)
     for k in sd:
         assert mine[k].shape == sd[k].shape, k
-    for name in ("vqvae_f8_f4.npz", "vqvae_groups2.npz"):
+    for name in ("vqvae_f8_f4.npz", "vqvae_f16_f2.npz", "vqvae_groups2.npz"):
         z, sd = _load(golden_dir, name)
         mine = O.init_state_dict(_cfg(z))
         assert set(mine) == set(sd)

@@ -37,10 +37,13 @@ struct GemmArgs {
   float *out;
   unsigned a_bytes, w_bytes, res_bytes, out_bytes;
   int M, N, K, lda, ldr, ldo, relu;
+  const float *w32;       // fp32 weight [N][K] (the tail rows' operand; == w unless w is a pair copy)
+  int tail;               // rows [M, M + tail) beyond the tiled rows: fp32 dot products, spread over the workgroups
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int BM = 128;
+constexpr int kGemmTailRows = 16;   // M % BM up to this many rows: no tile row of their own (gemm_split_f32 below)
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
   i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
   return *reinterpret_cast<float4 *>(&v);
@@ -187,6 +190,30 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const GemmArgs p) {
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro, oo[r], 0, 0);
     }
   }
+  // ---- the few rows beyond the last full tile row (gemm_split_f32): output columns dealt round-robin to the
+  // workgroups, one row per wave, plain fp32 dot products (one memory round trip at the end of every workgroup
+  // instead of a second round of mostly empty tiles)
+  if (p.tail) {
+    const int nq = p.K >> 2;
+    for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+      const float4 *wr = reinterpret_cast<const float4 *>(p.w32 + (size_t)n * p.K);
+      for (int r = wave; r < p.tail; r += 8) {
+        const size_t m = (size_t)p.M + r;
+        const float4 *xr = reinterpret_cast<const float4 *>(p.a + m * p.lda);
+        float s = 0.f;
+        for (int qd = lane; qd < nq; qd += 64) {
+          const float4 wv = wr[qd], xv = xr[qd];
+          s += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
+        }
+        s = wave64_sum(s);
+        if (lane == 0) {
+          float v = s + (p.bias ? p.bias[n] : 0.f) + (p.res ? p.res[m * p.ldr + n] : 0.f);
+          if (p.relu) v = fmaxf(v, 0.f) + (v - v);
+          p.out[m * p.ldo + n] = v;
+        }
+      }
+    }
+  }
 }
 
 template <bool F16, int TN, bool WPRE = false>
@@ -215,6 +242,11 @@ bool gemm_split_applicable(int M, int N, int K, int split_mode) {
 
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
                    int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream, const float *w16) {
+  // A few rows beyond a multiple of the tile height (the prior's B x (S + 1) = 8 x 1025 = 64 tiles + 8 rows) would add a
+  // whole column of 128-row tiles: 520 instead of 512 for N = 512, and with two workgroups per CU the launch then
+  // runs TWO rounds (28 vs 22 us at K = 512, 92 vs 66 us at K = 2048, measured).  The tiles cover the full tile rows
+  // only and every workgroup finishes with its share of the remaining rows' dot products (fp32 FMA, exact operands;
+  // the few-row kernel of the decode path as a second launch was measured too: 10 us, as much as it saved).
   GemmArgs g;
   g.a = a; g.w = w16 ? w16 : w; g.bias = bias; g.res = res; g.out = out;
   g.M = M; g.N = N; g.K = K; g.lda = (int)lda; g.ldr = (int)ldr; g.ldo = (int)ldo; g.relu = relu;
@@ -223,6 +255,9 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   if (ea > lim || eo > lim || er > lim || (int64_t)N * K > lim) return unsupported("gemm: a tensor spans 4 GiB or more");
   g.a_bytes = (unsigned)(ea * 4); g.w_bytes = (unsigned)((int64_t)N * K * 4); g.out_bytes = (unsigned)(eo * 4);
   g.res_bytes = (unsigned)(er * 4);
+  g.w32 = w; g.tail = 0;
+  const int rem = M % BM;
+  if (rem > 0 && rem <= kGemmTailRows && M >= 8 * BM && (lda & 3) == 0) { g.tail = rem; g.M = M - rem; M = g.M; }
   // 128 x 64 tiles when 128 x 128 ones would leave CUs without a second workgroup
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   const bool narrow = tiles128 < 512 || N % 128 != 0;

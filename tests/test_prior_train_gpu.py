@@ -511,7 +511,10 @@ def test_linear_gemm_kernel_equals_implicit_gemm(shape, precision):
         got = _ops.linear(x, pw, b, N, relu=relu, residual=r, precision=precision)
         with _hip.knob("ISI_NO_GEMM_KERNEL", 1):
             old = _ops.linear(x, pw, b, N, relu=relu, residual=r, precision=precision)
-        assert torch.equal(got, old)
+        # up to 16 rows beyond a multiple of 128 (of at least 1024) take the few-row fp32 kernel instead of a whole extra
+        # column of tiles: those rows are only held to the fp64 bound below
+        tail = M % 128 if (M % 128 <= 16 and M >= 1024) else 0
+        assert torch.equal(got[:M - tail], old[:M - tail])
         ref = x.double() @ W.double().t() + b.double() + (r.double() if r is not None else 0)
         ref = torch.relu(ref) if relu else ref
         err = float((got.double() - ref).abs().max() / ref.abs().max())
@@ -521,7 +524,7 @@ def test_linear_gemm_kernel_equals_implicit_gemm(shape, precision):
             gy = torch.randn(M, N, generator=g).to(dev)
             a = _ops.linear(gy, _ops.pack_linear_weight_t(W), None, K, precision="bf16x3")
             b_ = _ops.linear(gy, _ops.pack_linear_weight(W.t().contiguous()), None, K, precision="bf16x3")
-            assert torch.equal(a, b_)
+            assert torch.equal(a[:M - tail], b_[:M - tail]) and torch.allclose(a, b_, rtol=0, atol=2e-5 * float(b_.abs().max()))
         if precision == "f16x3":    # inference weights carry their split-f16 pair copy: staged by plain copies, same bits
             pw16 = _ops.pack_linear_weight(W, range_check="now", with_f16=True)
             assert pw16.isi_w16 and torch.equal(_ops.linear(x, pw16, b, N, relu=relu, residual=r, precision=precision), got)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Linear layers of the prior as the library runs them (1x1 implicit-GEMM convolution), per product mode:
-rows M = B * S = 8200, (N, K) of the top prior's projections.  Prints us and TFLOP/s-equivalent."""
+rows M = B * S = 8200 (ISI_BENCH_ROWS overrides), (N, K) of the top prior's projections.  Prints us and TFLOP/s-equivalent."""
 import pathlib
 import sys
 
@@ -26,7 +26,8 @@ def timed(fn, n=20):
 
 def main():
     dev = torch.device("cuda:0")
-    M = 8200
+    import os
+    M = int(os.environ.get("ISI_BENCH_ROWS", 8200))      # B * S = 8 * 1025
     for N, K in ((512, 512), (1536, 512), (1024, 512), (2048, 512), (512, 2048)):
         x = torch.randn(M, K, device=dev)
         w = torch.randn(N, K, device=dev) * 0.05

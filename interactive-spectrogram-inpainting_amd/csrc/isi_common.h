@@ -67,6 +67,18 @@ template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f32(const float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
 }
+// XCD-aware decode of a (tile, head, batch) launch.  Workgroup `id` of a launch runs on XCD id % 8 (observed placement,
+// a speed matter only) and every XCD has its own 4 MB L2: all tiles of one (batch, head) pair -- they stream the same
+// keys / values -- are therefore given ids of ONE residue class.  The launch is 1-D with xcd_grid(tiles, pairs)
+// workgroups; a pair index beyond the last pair (pairs not a multiple of 8) returns false and the workgroup leaves.
+__host__ __device__ __forceinline__ unsigned xcd_grid(int tiles, int pairs) { return 8u * (unsigned)((pairs + 7) / 8) * (unsigned)tiles; }
+__device__ __forceinline__ bool xcd_tile(int tiles, int pairs, int &tile, int &pair) {
+  const int id = (int)blockIdx.x, slot = id >> 3;
+  const int ppx = (pairs + 7) / 8;          // pairs per XCD; tile-major: an XCD's heaviest tiles (causal masks) all start first
+  tile = slot / ppx;
+  pair = (slot % ppx) * 8 + (id & 7);
+  return pair < pairs;
+}
 // sum over aligned groups of 4 / 8 / 16 lanes, result in every lane of the group
 __device__ __forceinline__ float group4_sum(float v) {
   v += dpp_f32<0xB1>(v);            // quad_perm [1,0,3,2]

@@ -36,7 +36,7 @@ struct AttnKArgs {
   const float *q, *k, *v, *e, *mask;
   float *out, *lse;
   unsigned q_bytes, k_bytes, v_bytes, e_bytes;
-  int Sq, Sk, H;
+  int Sq, Sk, H, B;
   int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
   int Cq, Ck, Ek, R;
   int mask_mode;  // 0 none, 1 causal (j <= i), 2 anti-causal (j >= i)
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(512) void rel_attention_f32_kernel(const AttnKArgs 
 // (h, b) = (0, 0)), waves 0 and 4, key-pair iteration 4
 #ifdef ISI_MEASURE
 __device__ long long g_attn_stamps[64];
-#define ISI_ATT_STAMP(i_) do { if (blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 0 && (wave & 3) == 0 && lane == 0 && kp == k_begin + 4 * 64) \
+#define ISI_ATT_STAMP(i_) do { if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && kp == k_begin + 4 * 64) \
     g_attn_stamps[(wave >> 2) * 16 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define ISI_ATT_STAMP(i_) do { } while (0)
@@ -404,8 +404,12 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 2, wq = wave & 3;
   const int ql = lane & 31, half = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int qblk = p.mask_mode == 1 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  // (tile, head, batch) from the 1-D launch: the query blocks of one (batch, head) share an XCD's L2 (xcd_tile)
+  const int nqb = (p.Sq + QB - 1) / QB;
+  int qt, pair;
+  if (!xcd_tile(nqb, p.H * p.B, qt, pair)) return;
+  const int h = pair % p.H, b = pair / p.H;
+  const int qblk = p.mask_mode == 1 ? nqb - 1 - qt : qt;      // heavy blocks first
   const int q0 = qblk * QB, qw0 = q0 + 32 * wq, qi = qw0 + ql;
   const bool has_e = p.e != nullptr;
 
@@ -767,7 +771,8 @@ static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * B;
   prof::Scope scope(prof::K_REL_ATTENTION, 2.0 * pairs * HD * (a.e ? 3 : 2),
                     4.0 * B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), stream);
-  ISI_PROF_LAUNCH(scope, kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(512), smem, stream, a);
+  if (a.split) ISI_PROF_LAUNCH(scope, kern, dim3(xcd_grid((a.Sq + QB - 1) / QB, a.H * B)), dim3(512), smem, stream, a);   // (xcd_tile)
+  else ISI_PROF_LAUNCH(scope, kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(512), smem, stream, a);
   return check_launch("rel_attention_f32");
 }
 
@@ -798,7 +803,7 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   a.q_bytes = (unsigned)(eq * 4); a.k_bytes = (unsigned)(ek * 4); a.v_bytes = (unsigned)(ev * 4);
   a.R = g->rel_rows;
   a.e_bytes = (unsigned)((size_t)g->H * g->rel_rows * g->head_dim * 4);
-  a.Sq = g->Sq; a.Sk = g->Sk; a.H = g->H;
+  a.Sq = g->Sq; a.Sk = g->Sk; a.H = g->H; a.B = g->B;
   a.q_ss = (int)g->q_ss; a.q_sb = (int)g->q_sb; a.q_sh = (int)g->q_sh;
   a.k_ss = (int)g->k_ss; a.k_sb = (int)g->k_sb; a.k_sh = (int)g->k_sh;
   a.v_ss = (int)g->v_ss; a.v_sb = (int)g->v_sb; a.v_sh = (int)g->v_sh;

@@ -410,7 +410,13 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
   if (!xcd_tile(nqb, p.H * p.B, qt, pair)) return;
   const int h = pair % p.H, b = pair / p.H;
   const int qblk = p.mask_mode == 1 ? nqb - 1 - qt : qt;      // heavy blocks first
-  const int q0 = qblk * QB, qw0 = q0 + 32 * wq, qi = qw0 + ql;
+  // causal masks: the ragged block (Sq % QB rows: the ONE extra row of a 1025-row sequence) is block 0, where the key
+  // range is shortest, instead of the last block, where it cost as much as a full one (9 of 45 block-steps at
+  // Sq = 1025).  Blocks then start at rag + 128 (qblk - 1); the band logic takes any origin when Cq = 1.
+  const int rag = (p.mask_mode == 1 && p.Cq == 1) ? p.Sq % QB : 0;
+  const int q0 = rag ? (qblk ? rag + (qblk - 1) * QB : 0) : qblk * QB;
+  const int q_end = (rag && qblk == 0) ? rag : p.Sq;           // first row beyond this block's valid ones
+  const int qw0 = q0 + 32 * wq, qi = qw0 + ql;
   const bool has_e = p.e != nullptr;
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
   s16x8_t qh[NKB], qlo[NKB];
 #pragma unroll
   for (int t = 0; t < NKB; ++t) {
-    const unsigned off = qi < p.Sq ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + 16 * t + 8 * half) * 4u : OOB;
+    const unsigned off = qi < q_end ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + 16 * t + 8 * half) * 4u : OOB;
     uint2 h0, l0, h1, l1;
     split_f4(buf_load4(rq, off), h0, l0);
     split_f4(buf_load4(rq, off == OOB ? OOB : off + 16u), h1, l1);
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
     const int k0 = kp + 32 * grp;
     const int rb = band0(k0);
 
-    bool live = qw0 < p.Sq && k0 < k_end;
+    bool live = qw0 < q_end && k0 < k_end;
     if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
     if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
     if (live) {
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
       ISI_ATT_STAMP(3);
       // ---- scale, mask, online softmax (base 2)
       float tmax = NEG;
-      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < p.Sq;
+      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < q_end;
       if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
       if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
       if (full) {
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
           if (p.mask_mode == 1) ok = ok && kj <= qi;
           if (p.mask_mode == 2) ok = ok && kj >= qi;
           float sc = sv[r] * scale2;
-          if (p.mask && ok && qi < p.Sq) sc += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          if (p.mask && ok && qi < q_end) sc += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
           sc = ok ? sc : NEG;
           sv[r] = sc;
           tmax = fmaxf(tmax, sc);
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[d][r] = O[d][r] * a0 + src[(d * 16 + r) * 64] * a1;
   }
-  if (qi < p.Sq) {
+  if (qi < q_end) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     float *orow = p.out + (size_t)qi * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
     if (p.lse && half == 0)

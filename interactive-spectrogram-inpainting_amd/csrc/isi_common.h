@@ -72,11 +72,16 @@ __device__ __forceinline__ float dpp_f32(const float v) {
 // keys / values -- are therefore given ids of ONE residue class.  The launch is 1-D with xcd_grid(tiles, pairs)
 // workgroups; a pair index beyond the last pair (pairs not a multiple of 8) returns false and the workgroup leaves.
 __host__ __device__ __forceinline__ unsigned xcd_grid(int tiles, int pairs) { return 8u * (unsigned)((pairs + 7) / 8) * (unsigned)tiles; }
-__device__ __forceinline__ bool xcd_tile(int tiles, int pairs, int &tile, int &pair) {
+// `heavy_first`: tile-major order inside an XCD (every pair's tile 0, then every pair's tile 1, ...): with tiles of
+// unequal cost (causal masks, heaviest = tile 0) the long ones all start first; otherwise pair-major (a pair's tiles are
+// neighbours in time: ~4 instead of 8 pairs' operands live in the L2 at once).
+__device__ __forceinline__ bool xcd_tile(int tiles, int pairs, bool heavy_first, int &tile, int &pair) {
   const int id = (int)blockIdx.x, slot = id >> 3;
-  const int ppx = (pairs + 7) / 8;          // pairs per XCD; tile-major: an XCD's heaviest tiles (causal masks) all start first
-  tile = slot / ppx;
-  pair = (slot % ppx) * 8 + (id & 7);
+  const int ppx = (pairs + 7) / 8;          // pairs per XCD
+  int pl;
+  if (heavy_first) { tile = slot / ppx; pl = slot % ppx; }
+  else { tile = slot % tiles; pl = slot / tiles; }
+  pair = pl * 8 + (id & 7);
   return pair < pairs;
 }
 // sum over aligned groups of 4 / 8 / 16 lanes, result in every lane of the group

@@ -597,9 +597,17 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 2, wq = wave & 3;
   const int ql = lane & 31, half = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int qblk = p.mask_mode == 1 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
-  const int q0 = qblk * QB, qw0 = q0 + 32 * wq, qi = qw0 + ql;
+  // (tile, head, batch) from the 1-D launch: one XCD's L2 per (batch, head) pair, heaviest tiles first (xcd_tile); causal
+  // masks: the ragged query block is block 0, where the key range is shortest (as in the forward kernel)
+  const int nqb = (p.Sq + QB - 1) / QB;
+  int qt, pair;
+  if (!xcd_tile(nqb, p.H * p.B, p.mask_mode != 0, qt, pair)) return;
+  const int h = pair % p.H, b = pair / p.H;
+  const int qblk = p.mask_mode == 1 ? nqb - 1 - qt : qt;
+  const int rag = (p.mask_mode == 1 && p.Cq == 1) ? p.Sq % QB : 0;
+  const int q0 = rag ? (qblk ? rag + (qblk - 1) * QB : 0) : qblk * QB;
+  const int q_end = (rag && qblk == 0) ? rag : p.Sq;           // first row beyond this block's valid ones
+  const int qw0 = q0 + 32 * wq, qi = qw0 + ql;
   const bool has_e = p.e != nullptr;
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
@@ -612,7 +620,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   s16x8_t qh[NKB], qlo[NKB], doh[NKB], dol[NKB];
 #pragma unroll
   for (int t = 0; t < NKB; ++t) {
-    const bool ok = qi < p.Sq;
+    const bool ok = qi < q_end;
     const unsigned oq = ok ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + 16 * t + 8 * half) * 4u : OOB;
     const unsigned od = ok ? (unsigned)(qi * p.o_ss + b * p.o_sb + h * p.o_sh + 16 * t + 8 * half) * 4u : OOB;
     uint2 h0, l0, h1, l1;
@@ -626,8 +634,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
     dol[t] = __builtin_bit_cast(s16x8_t, make_uint4(l0.x, l0.y, l1.x, l1.y));
   }
   const int stat = (b * p.H + h) * p.Sq + qi;
-  const float lse2 = (qi < p.Sq ? p.lse[stat] : 0.f) * LOG2E;
-  const float dsum_i = qi < p.Sq ? p.dsum[stat] : 0.f;
+  const float lse2 = (qi < q_end ? p.lse[stat] : 0.f) * LOG2E;
+  const float dsum_i = qi < q_end ? p.dsum[stat] : 0.f;
   const int evq = qi / p.Cq;
   const int evq_w0 = qw0 / p.Cq, evq_b0 = q0 / p.Cq;
 
@@ -744,7 +752,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
     const int k0 = kp + 32 * grp;
     const int rb = band0(k0);
 
-    bool live = qw0 < p.Sq && k0 < k_end;
+    bool live = qw0 < q_end && k0 < k_end;
     if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
     if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
     if (live) {  // wave-uniform
@@ -796,7 +804,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
       }
 
       // ---- P
-      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < p.Sq;
+      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < q_end;
       if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
       if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
       if (full) {
@@ -806,7 +814,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kj = k0 + mfma_row(r, half);
-          bool ok = kj < p.Sk && qi < p.Sq;
+          bool ok = kj < p.Sk && qi < q_end;
           if (p.mask_mode == 1) ok = ok && kj <= qi;
           if (p.mask_mode == 2) ok = ok && kj >= qi;
           float s = sv[r] * scale2;
@@ -887,7 +895,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   }
   __syncthreads();
   if (grp == 1) return;
-  if (qi < p.Sq) {
+  if (qi < q_end) {
     const float *src = mg + wq * MGW + lane;
     float *orow = p.dq + (size_t)qi * p.q_ss + (size_t)b * p.q_sb + (size_t)h * p.q_sh;
 #pragma unroll
@@ -928,8 +936,12 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = wave >> 2, wq = wave & 3;
   const int ql = lane & 31, half = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int kblk = p.mask_mode == 2 ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  // (tile, head, batch) from the 1-D launch: one XCD's L2 per (batch, head) pair, heaviest tiles first (xcd_tile)
+  const int nkb = (p.Sk + QB - 1) / QB;
+  int kt, pair;
+  if (!xcd_tile(nkb, p.H * p.B, p.mask_mode != 0, kt, pair)) return;
+  const int h = pair % p.H, b = pair / p.H;
+  const int kblk = p.mask_mode == 2 ? nkb - 1 - kt : kt;
   const int k0b = kblk * QB, kw0 = k0b + 32 * wq, kj = kw0 + ql;
   const bool has_e = p.e != nullptr;
 
@@ -1358,14 +1370,14 @@ static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 5 : 4),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 4.0 * a.Sk), stream);
-    ISI_PROF_LAUNCH(scope, kkv, dim3((a.Sk + QB - 1) / QB, a.H, a.B), dim3(512), smem_kv, stream, a);
+    ISI_PROF_LAUNCH(scope, kkv, dim3(xcd_grid((a.Sk + QB - 1) / QB, a.H * a.B)), dim3(512), smem_kv, stream, a);
   }
   int rc = check_launch("rel_attention_bwd_kv_split");
   if (rc) return rc;
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 4 : 3),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 2.0 * a.Sk), stream);
-    ISI_PROF_LAUNCH(scope, kq, dim3((a.Sq + QB - 1) / QB, a.H, a.B), dim3(512), smem_q, stream, a);
+    ISI_PROF_LAUNCH(scope, kq, dim3(xcd_grid((a.Sq + QB - 1) / QB, a.H * a.B)), dim3(512), smem_q, stream, a);
   }
   return check_launch("rel_attention_bwd_q_split");
 }

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
   // (tile, head, batch) from the 1-D launch: the query blocks of one (batch, head) share an XCD's L2 (xcd_tile)
   const int nqb = (p.Sq + QB - 1) / QB;
   int qt, pair;
-  if (!xcd_tile(nqb, p.H * p.B, qt, pair)) return;
+  if (!xcd_tile(nqb, p.H * p.B, p.mask_mode != 0, qt, pair)) return;
   const int h = pair % p.H, b = pair / p.H;
   const int qblk = p.mask_mode == 1 ? nqb - 1 - qt : qt;      // heavy blocks first
   // causal masks: the ragged block (Sq % QB rows: the ONE extra row of a 1025-row sequence) is block 0, where the key

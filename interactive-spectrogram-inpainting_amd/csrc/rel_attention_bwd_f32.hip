@@ -41,6 +41,7 @@ struct AttnBwdKArgs {
   float *g;               // [H][B*Sq][Rp]
   unsigned q_bytes, k_bytes, v_bytes, e_bytes, o_bytes;
   int Sq, Sk, H, B;
+  int nqb, nkb;           // stationary query / key blocks the split kernels run (all, or only the full ones)
   int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
   int Cq, Ck, Ek, R, Rp;
   int rho_lo;             // G column c holds table row rho_lo + c (causal modes only touch half of the table)
@@ -599,12 +600,12 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   const int ql = lane & 31, half = lane >> 5;
   // (tile, head, batch) from the 1-D launch: one XCD's L2 per (batch, head) pair, heaviest tiles first (xcd_tile); causal
   // masks: the ragged query block is block 0, where the key range is shortest (as in the forward kernel)
-  const int nqb = (p.Sq + QB - 1) / QB;
+  const int nqb = p.nqb;
   int qt, pair;
   if (!xcd_tile(nqb, p.H * p.B, p.mask_mode != 0, qt, pair)) return;
   const int h = pair % p.H, b = pair / p.H;
   const int qblk = p.mask_mode == 1 ? nqb - 1 - qt : qt;
-  const int rag = (p.mask_mode == 1 && p.Cq == 1) ? p.Sq % QB : 0;
+  const int rag = (p.mask_mode == 1 && p.Cq == 1 && nqb * QB >= p.Sq) ? p.Sq % QB : 0;
   const int q0 = rag ? (qblk ? rag + (qblk - 1) * QB : 0) : qblk * QB;
   const int q_end = (rag && qblk == 0) ? rag : p.Sq;           // first row beyond this block's valid ones
   const int qw0 = q0 + 32 * wq, qi = qw0 + ql;
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   const int grp = wave >> 2, wq = wave & 3;
   const int ql = lane & 31, half = lane >> 5;
   // (tile, head, batch) from the 1-D launch: one XCD's L2 per (batch, head) pair, heaviest tiles first (xcd_tile)
-  const int nkb = (p.Sk + QB - 1) / QB;
+  const int nkb = p.nkb;
   int kt, pair;
   if (!xcd_tile(nkb, p.H * p.B, p.mask_mode != 0, kt, pair)) return;
   const int h = pair % p.H, b = pair / p.H;
@@ -1338,6 +1339,150 @@ BwdLayout bwd_layout(int B, int H, int Sq, int R, int HD) {   // R = number of t
   L.total = off;
   return L;
 }
+// ---- the one or two rows / keys beyond the last full 128-row block (attention_tail_rows: the prior's sequences are
+// 1024 codes + a start row).  As a stationary block of the kernels above such a row costs as much as 128 of them -- a
+// third round of workgroups on the 256 CUs for one row per (batch, head): 1252 vs 1007 us for the dense 1025 x 1025
+// backward.  These two kernels do the same arithmetic for ONE query row (dQ, its row of G) resp. ONE key (dK, dV) per
+// workgroup in exact fp32: G = HD / 4 lanes per streamed row, one coalesced 16-byte load per lane and operand.
+constexpr int TAIL_THREADS = 512, TAIL_U = 8;     // 512 / (HD / 4) x 8 streamed rows in flight per workgroup (256 at HD 64)
+
+template <int HD>
+__device__ __forceinline__ void attn_bwd_tail_row(const AttnBwdKArgs &p, float *part, int i) {
+  constexpr int G = HD / 4, RPP = TAIL_THREADS / G, U = TAIL_U, NW = TAIL_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = tid / G, gl = tid % G;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const float4 qq = *reinterpret_cast<const float4 *>(p.q + (size_t)i * p.q_ss + (size_t)b * p.q_sb + (size_t)h * p.q_sh + gl * 4);
+  const float4 dd = *reinterpret_cast<const float4 *>(p.dout + (size_t)i * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh + gl * 4);
+  const int stat = (b * p.H + h) * p.Sq + i;
+  const float lse = p.lse[stat], dsum = p.dsum[stat];
+  const int Sk = p.mask_mode == 1 ? min(p.Sk, i + 1) : p.Sk;          // (no anti-causal / additive masks on this path)
+  const int evq = i / p.Cq;
+  const float *kb = p.k + (size_t)b * p.k_sb + (size_t)h * p.k_sh + gl * 4;
+  const float *vb = p.v + (size_t)b * p.v_sb + (size_t)h * p.v_sh + gl * 4;
+  const float *eb = p.e ? p.e + (size_t)h * p.R * HD + gl * 4 : nullptr;
+  float *grow = p.g ? p.g + (((size_t)h * p.B + b) * p.Sq + i) * p.Rp : nullptr;
+  float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = grp; j0 < Sk; j0 += U * RPP) {
+    float4 kk[U], vv[U], ee[U];
+    int rho[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * RPP, jc = j < Sk ? j : j0;
+      kk[u] = *reinterpret_cast<const float4 *>(kb + (size_t)jc * p.k_ss);
+      vv[u] = *reinterpret_cast<const float4 *>(vb + (size_t)jc * p.v_ss);
+      ee[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rho[u] = evq - jc / p.Ck + p.Ek - 1;
+      if (eb && rho[u] >= 0 && rho[u] < p.R) ee[u] = *reinterpret_cast<const float4 *>(eb + (size_t)rho[u] * HD);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * RPP;
+      const float4 kq = make_float4(kk[u].x + ee[u].x, kk[u].y + ee[u].y, kk[u].z + ee[u].z, kk[u].w + ee[u].w);
+      float sdot = (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
+      float pdot = (dd.x * vv[u].x + dd.y * vv[u].y) + (dd.z * vv[u].z + dd.w * vv[u].w);
+      sdot = G == 16 ? row16_sum(sdot) : G == 8 ? group8_sum(sdot) : group4_sum(sdot);
+      pdot = G == 16 ? row16_sum(pdot) : G == 8 ? group8_sum(pdot) : group4_sum(pdot);
+      const float pj = j < Sk ? __expf(sdot * p.scale - lse) : 0.f;
+      const float ds = pj * (pdot - dsum) * p.scale;
+      dq.x += ds * kk[u].x; dq.y += ds * kk[u].y; dq.z += ds * kk[u].z; dq.w += ds * kk[u].w;
+      if (grow && gl == 0 && j < Sk && ds != 0.f) {
+        const int col = rho[u] - p.rho_lo;
+        if (rho[u] >= 0 && rho[u] < p.R && col >= 0 && col < p.Rp) unsafeAtomicAdd(grow + col, ds);   // (Ck = 1: one key per column)
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+    dq.x += __shfl_xor(dq.x, o); dq.y += __shfl_xor(dq.y, o); dq.z += __shfl_xor(dq.z, o); dq.w += __shfl_xor(dq.w, o);
+  }
+  if (lane < G) *reinterpret_cast<float4 *>(part + wave * HD + lane * 4) = dq;
+  __syncthreads();
+  if (tid < HD) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) acc += part[w * HD + tid];
+    p.dq[(size_t)i * p.q_ss + (size_t)b * p.q_sb + (size_t)h * p.q_sh + tid] = acc;
+  }
+}
+
+template <int HD>
+__device__ __forceinline__ void attn_bwd_tail_key(const AttnBwdKArgs &p, float *part, int j) {
+  constexpr int G = HD / 4, RPP = TAIL_THREADS / G, U = TAIL_U, NW = TAIL_THREADS / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = tid / G, gl = tid % G;
+  const int h = blockIdx.x, b = blockIdx.y;
+  const float4 kk = *reinterpret_cast<const float4 *>(p.k + (size_t)j * p.k_ss + (size_t)b * p.k_sb + (size_t)h * p.k_sh + gl * 4);
+  const float4 vv = *reinterpret_cast<const float4 *>(p.v + (size_t)j * p.v_ss + (size_t)b * p.v_sb + (size_t)h * p.v_sh + gl * 4);
+  const int statb = (b * p.H + h) * p.Sq;
+  const int i_begin = p.mask_mode == 1 ? j : 0;                      // causal: queries i >= j
+  const int evk = j / p.Ck;
+  const float *qb = p.q + (size_t)b * p.q_sb + (size_t)h * p.q_sh + gl * 4;
+  const float *db = p.dout + (size_t)b * p.o_sb + (size_t)h * p.o_sh + gl * 4;
+  const float *eb = p.e ? p.e + (size_t)h * p.R * HD + gl * 4 : nullptr;
+  float4 dk = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i0 = i_begin + grp; i0 < p.Sq; i0 += U * RPP) {
+    float4 qv[U], dd[U], ee[U];
+    float lse[U], dsum[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * RPP, ic = i < p.Sq ? i : i0;
+      qv[u] = *reinterpret_cast<const float4 *>(qb + (size_t)ic * p.q_ss);
+      dd[u] = *reinterpret_cast<const float4 *>(db + (size_t)ic * p.o_ss);
+      lse[u] = p.lse[statb + ic];
+      dsum[u] = p.dsum[statb + ic];
+      ee[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int rho = ic / p.Cq - evk + p.Ek - 1;
+      if (eb && rho >= 0 && rho < p.R) ee[u] = *reinterpret_cast<const float4 *>(eb + (size_t)rho * HD);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * RPP;
+      const float4 kq = make_float4(kk.x + ee[u].x, kk.y + ee[u].y, kk.z + ee[u].z, kk.w + ee[u].w);
+      float sdot = (qv[u].x * kq.x + qv[u].y * kq.y) + (qv[u].z * kq.z + qv[u].w * kq.w);
+      float pdot = (dd[u].x * vv.x + dd[u].y * vv.y) + (dd[u].z * vv.z + dd[u].w * vv.w);
+      sdot = G == 16 ? row16_sum(sdot) : G == 8 ? group8_sum(sdot) : group4_sum(sdot);
+      pdot = G == 16 ? row16_sum(pdot) : G == 8 ? group8_sum(pdot) : group4_sum(pdot);
+      const float pi = i < p.Sq ? __expf(sdot * p.scale - lse[u]) : 0.f;
+      const float ds = pi * (pdot - dsum[u]) * p.scale;
+      dv.x += pi * dd[u].x; dv.y += pi * dd[u].y; dv.z += pi * dd[u].z; dv.w += pi * dd[u].w;
+      dk.x += ds * qv[u].x; dk.y += ds * qv[u].y; dk.z += ds * qv[u].z; dk.w += ds * qv[u].w;
+    }
+  }
+#pragma unroll
+  for (int o = G; o < 64; o <<= 1) {
+    dk.x += __shfl_xor(dk.x, o); dk.y += __shfl_xor(dk.y, o); dk.z += __shfl_xor(dk.z, o); dk.w += __shfl_xor(dk.w, o);
+    dv.x += __shfl_xor(dv.x, o); dv.y += __shfl_xor(dv.y, o); dv.z += __shfl_xor(dv.z, o); dv.w += __shfl_xor(dv.w, o);
+  }
+  if (lane < G) {
+    *reinterpret_cast<float4 *>(part + wave * HD + lane * 4) = dk;
+    *reinterpret_cast<float4 *>(part + (NW + wave) * HD + lane * 4) = dv;
+  }
+  __syncthreads();
+  if (tid < HD) {
+    float ak = 0.f, av = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { ak += part[w * HD + tid]; av += part[(NW + w) * HD + tid]; }
+    p.dk[(size_t)j * p.k_ss + (size_t)b * p.k_sb + (size_t)h * p.k_sh + tid] = ak;
+    p.dv[(size_t)j * p.v_ss + (size_t)b * p.v_sb + (size_t)h * p.v_sh + tid] = av;
+  }
+}
+
+// one launch for both roles (they are independent): blockIdx.z < tail_q: query row Sq - tail_q + z, else a key
+template <int HD>
+__global__ __launch_bounds__(TAIL_THREADS) void attn_bwd_tail_kernel(const AttnBwdKArgs p, int tail_q, int tail_k) {
+  __shared__ __attribute__((aligned(16))) float part[2 * (TAIL_THREADS / 64) * HD];
+  const int z = blockIdx.z;
+  if (z < tail_q) attn_bwd_tail_row<HD>(p, part, p.Sq - tail_q + z);
+  else attn_bwd_tail_key<HD>(p, part, p.Sk - tail_k + (z - tail_q));
+}
+
+template <int HD>
+int launch_bwd_tails(const AttnBwdKArgs &a, int tail_q, int tail_k, hipStream_t stream) {
+  hipLaunchKernelGGL(attn_bwd_tail_kernel<HD>, dim3(a.H, a.B, tail_q + tail_k), dim3(TAIL_THREADS), 0, stream, a, tail_q, tail_k);
+  return check_launch("attn_bwd_tail");
+}
+
 int64_t span(int64_t S, int64_t ss, int64_t B, int64_t sb, int64_t H, int64_t sh, int64_t hd) {
   return (S - 1) * ss + (B - 1) * sb + (H - 1) * sh + hd;
 }
@@ -1370,14 +1515,14 @@ static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 5 : 4),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 4.0 * a.Sk), stream);
-    ISI_PROF_LAUNCH(scope, kkv, dim3(xcd_grid((a.Sk + QB - 1) / QB, a.H * a.B)), dim3(512), smem_kv, stream, a);
+    ISI_PROF_LAUNCH(scope, kkv, dim3(xcd_grid(a.nkb, a.H * a.B)), dim3(512), smem_kv, stream, a);
   }
   int rc = check_launch("rel_attention_bwd_kv_split");
   if (rc) return rc;
   {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 4 : 3),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 2.0 * a.Sk), stream);
-    ISI_PROF_LAUNCH(scope, kq, dim3(xcd_grid((a.Sq + QB - 1) / QB, a.H * a.B)), dim3(512), smem_q, stream, a);
+    ISI_PROF_LAUNCH(scope, kq, dim3(xcd_grid(a.nqb, a.H * a.B)), dim3(512), smem_q, stream, a);
   }
   return check_launch("rel_attention_bwd_q_split");
 }
@@ -1475,11 +1620,20 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   }
   const bool split = g->precision >= 1;
   const bool one = g->precision == 2;     // single-term bf16 products, like the forward of that mode
+  // rows / keys beyond the last full block that go through the one-row kernels (the G row of such a query is written
+  // with one key per column, which needs Ck = 1)
+  const int tail_q = (split && (!has_e || g->Ck == 1)) ? attention_tail_rows(g->Sq, g->mask_mode, g->dense_mask != nullptr) : 0;
+  const int tail_k = split ? attention_tail_rows(g->Sk, g->mask_mode, g->dense_mask != nullptr) : 0;
+  a.nqb = tail_q ? g->Sq / QB : (g->Sq + QB - 1) / QB;
+  a.nkb = tail_k ? g->Sk / QB : (g->Sk + QB - 1) / QB;
   switch (HD) {
     case 16: rc = split ? (one ? launch_bwd_split<16, true>(a, stream) : launch_bwd_split<16, false>(a, stream)) : launch_bwd<16>(a, stream); break;
     case 32: rc = split ? (one ? launch_bwd_split<32, true>(a, stream) : launch_bwd_split<32, false>(a, stream)) : launch_bwd<32>(a, stream); break;
     default: rc = split ? (one ? launch_bwd_split<64, true>(a, stream) : launch_bwd_split<64, false>(a, stream)) : launch_bwd<64>(a, stream); break;
   }
+  if (!rc && (tail_q || tail_k))
+    rc = HD == 16 ? launch_bwd_tails<16>(a, tail_q, tail_k, stream) : HD == 32 ? launch_bwd_tails<32>(a, tail_q, tail_k, stream)
+                                                                              : launch_bwd_tails<64>(a, tail_q, tail_k, stream);
   if (rc || !has_e) return rc;
 
   // ---- dQ += G E  and  dE = G^T Q, head by head, on the GEMM kernels

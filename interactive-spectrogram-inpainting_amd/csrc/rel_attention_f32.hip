@@ -22,6 +22,8 @@
 //                             read back through a per-wave LDS buffer: the skew)
 //   O^T  += V^T P^T          (P^T is already the B fragment: accumulator r of a
 //                             lane is the k-slot of MFMA step r)
+#include <algorithm>
+
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "prof.h"
@@ -37,6 +39,7 @@ struct AttnKArgs {
   float *out, *lse;
   unsigned q_bytes, k_bytes, v_bytes, e_bytes;
   int Sq, Sk, H, B;
+  int nblk;       // query blocks the split kernels run (all, or only the full ones: the tail rows go to the one-row kernel)
   int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
   int Cq, Ck, Ek, R;
   int mask_mode;  // 0 none, 1 causal (j <= i), 2 anti-causal (j >= i)
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
   const int grp = wave >> 2, wq = wave & 3;
   const int ql = lane & 31, half = lane >> 5;
   // (tile, head, batch) from the 1-D launch: the query blocks of one (batch, head) share an XCD's L2 (xcd_tile)
-  const int nqb = (p.Sq + QB - 1) / QB;
+  const int nqb = p.nblk;
   int qt, pair;
   if (!xcd_tile(nqb, p.H * p.B, p.mask_mode != 0, qt, pair)) return;
   const int h = pair % p.H, b = pair / p.H;
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
   // causal masks: the ragged block (Sq % QB rows: the ONE extra row of a 1025-row sequence) is block 0, where the key
   // range is shortest, instead of the last block, where it cost as much as a full one (9 of 45 block-steps at
   // Sq = 1025).  Blocks then start at rag + 128 (qblk - 1); the band logic takes any origin when Cq = 1.
-  const int rag = (p.mask_mode == 1 && p.Cq == 1) ? p.Sq % QB : 0;
+  const int rag = (p.mask_mode == 1 && p.Cq == 1 && nqb * QB >= p.Sq) ? p.Sq % QB : 0;
   const int q0 = rag ? (qblk ? rag + (qblk - 1) * QB : 0) : qblk * QB;
   const int q_end = (rag && qblk == 0) ? rag : p.Sq;           // first row beyond this block's valid ones
   const int qw0 = q0 + 32 * wq, qi = qw0 + ql;
@@ -750,6 +753,85 @@ __global__ __launch_bounds__(512) void rel_attention_split_kernel(const AttnKArg
   }
 }
 
+// ---- one query row per workgroup, unmasked, exact fp32 (rel_attention_f32 below gives the one or two rows beyond the last
+// full query block to this kernel instead of a block of their own).  G = HD / 4 lanes own a key row (one coalesced
+// 16-byte load per lane for k, v and the relative row), 512 / G x 8 keys are in flight per step; every lane group keeps
+// its own running softmax state, merged at the end (wave shuffles, then the 8 waves through LDS).
+template <int HD>
+__global__ __launch_bounds__(512) void attn_fwd_tail_row_kernel(const AttnKArgs p, int row0) {
+  constexpr int G = HD / 4, RPP = 512 / G, U = 8, NW = 8;
+  __shared__ __attribute__((aligned(16))) float part[NW * HD];
+  __shared__ float red[2 * NW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = tid / G, gl = tid % G;
+  const int h = blockIdx.x, b = blockIdx.y, i = row0 + blockIdx.z;
+  const float4 qq = *reinterpret_cast<const float4 *>(p.q + (size_t)i * p.q_ss + (size_t)b * p.q_sb + (size_t)h * p.q_sh + gl * 4);
+  const int evq = i / p.Cq;
+  const float *kb = p.k + (size_t)b * p.k_sb + (size_t)h * p.k_sh + gl * 4;
+  const float *vb = p.v + (size_t)b * p.v_sb + (size_t)h * p.v_sh + gl * 4;
+  const float *eb = p.e ? p.e + (size_t)h * p.R * HD + gl * 4 : nullptr;
+  float m = NEG, l = 0.f;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = grp; j0 < p.Sk; j0 += U * RPP) {
+    float4 kk[U], vv[U], ee[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int j = j0 + u * RPP, jc = j < p.Sk ? j : j0;
+      kk[u] = *reinterpret_cast<const float4 *>(kb + (size_t)jc * p.k_ss);
+      vv[u] = *reinterpret_cast<const float4 *>(vb + (size_t)jc * p.v_ss);
+      ee[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int rho = evq - jc / p.Ck + p.Ek - 1;
+      if (eb && rho >= 0 && rho < p.R) ee[u] = *reinterpret_cast<const float4 *>(eb + (size_t)rho * HD);
+    }
+    float sv[U], bm = NEG;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float4 kq = make_float4(kk[u].x + ee[u].x, kk[u].y + ee[u].y, kk[u].z + ee[u].z, kk[u].w + ee[u].w);
+      float acc = (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
+      acc = G == 16 ? row16_sum(acc) : G == 8 ? group8_sum(acc) : group4_sum(acc);
+      sv[u] = j0 + u * RPP < p.Sk ? acc * p.scale : NEG;
+      bm = fmaxf(bm, sv[u]);
+    }
+    const float mn = fmaxf(m, bm), corr = __expf(m - mn);
+    l *= corr; o.x *= corr; o.y *= corr; o.z *= corr; o.w *= corr;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float pj = j0 + u * RPP < p.Sk ? __expf(sv[u] - mn) : 0.f;
+      l += pj;
+      o.x += pj * vv[u].x; o.y += pj * vv[u].y; o.z += pj * vv[u].z; o.w += pj * vv[u].w;
+    }
+    m = mn;
+  }
+  // merge the wave's lane groups, then the waves
+  float mw = m;
+#pragma unroll
+  for (int d = G; d < 64; d <<= 1) mw = fmaxf(mw, __shfl_xor(mw, d));
+  const float f = __expf(m - mw);
+  l *= f; o.x *= f; o.y *= f; o.z *= f; o.w *= f;
+#pragma unroll
+  for (int d = G; d < 64; d <<= 1) {
+    l += __shfl_xor(l, d);
+    o.x += __shfl_xor(o.x, d); o.y += __shfl_xor(o.y, d); o.z += __shfl_xor(o.z, d); o.w += __shfl_xor(o.w, d);
+  }
+  if (lane < G) *reinterpret_cast<float4 *>(part + wave * HD + lane * 4) = o;
+  if (lane == 0) { red[wave] = mw; red[NW + wave] = l; }
+  __syncthreads();
+  if (tid < HD) {
+    float M = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, red[w]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float fw = __expf(red[w] - M);
+      num += fw * part[w * HD + tid];
+      den += fw * red[NW + w];
+    }
+    p.out[(size_t)i * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh + tid] = num / den;
+    if (p.lse && tid == 0) p.lse[((size_t)b * p.H + h) * p.Sq + i] = M + logf(den);
+  }
+}
+
 int rel_attention_debug_stamps(long long *host, int n) {
 #ifdef ISI_MEASURE
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(long long) * (size_t)(n < 64 ? n : 64)) == hipSuccess ? 0 : -2;
@@ -777,7 +859,7 @@ static int launch_attn(const AttnKArgs &a, int B, hipStream_t stream) {
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * B;
   prof::Scope scope(prof::K_REL_ATTENTION, 2.0 * pairs * HD * (a.e ? 3 : 2),
                     4.0 * B * a.H * HD * (2.0 * a.Sq + 2.0 * a.Sk), stream);
-  if (a.split) ISI_PROF_LAUNCH(scope, kern, dim3(xcd_grid((a.Sq + QB - 1) / QB, a.H * B)), dim3(512), smem, stream, a);   // (xcd_tile)
+  if (a.split) ISI_PROF_LAUNCH(scope, kern, dim3(xcd_grid(a.nblk, a.H * B)), dim3(512), smem, stream, a);   // (xcd_tile)
   else ISI_PROF_LAUNCH(scope, kern, dim3((a.Sq + QB - 1) / QB, a.H, B), dim3(512), smem, stream, a);
   return check_launch("rel_attention_f32");
 }
@@ -818,12 +900,36 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   a.mask_mode = g->mask_mode; a.scale = g->scale;
   a.split = g->precision == 1 ? 1 : g->precision == 2 ? 2 : 0;   // 0 fp32 pipe | 1 three-term split-bf16 | 2 single-term bf16
   if (a.e && a.R <= 0) return invalid("rel_attention: rel_rows must be positive");
+  // One or two rows beyond the last full query block (the prior's sequences are 1024 codes + a start row) would be a
+  // block of their own that runs as long as a full one: 576 instead of 512 workgroups on 256 CUs -- a third round
+  // for one row per (batch, head) (244 vs 165 us, dense, B 8 x H 8 x 1025 x 1025).  They go through a one-row kernel
+  // instead (attn_fwd_tail_row_kernel: exact fp32, one workgroup per (batch, head) and row).
+  const int tail = attention_tail_rows(g->Sq, g->mask_mode, g->dense_mask != nullptr);
+  const bool split_tail = a.split && tail > 0;
+  a.nblk = split_tail ? g->Sq / QB : (g->Sq + QB - 1) / QB;
+  int rc;
   switch (g->head_dim) {
-    case 16: return launch_attn<16>(a, g->B, stream);
-    case 32: return launch_attn<32>(a, g->B, stream);
-    case 64: return launch_attn<64>(a, g->B, stream);
+    case 16: rc = launch_attn<16>(a, g->B, stream); break;
+    case 32: rc = launch_attn<32>(a, g->B, stream); break;
+    case 64: rc = launch_attn<64>(a, g->B, stream); break;
     default: return unsupported("rel_attention: head_dim must be 16, 32 or 64");
   }
+  if (rc || !split_tail) return rc;
+  const dim3 tgrid(g->H, g->B, tail);
+  switch (g->head_dim) {
+    case 16: hipLaunchKernelGGL(attn_fwd_tail_row_kernel<16>, tgrid, dim3(512), 0, stream, a, g->Sq - tail); break;
+    case 32: hipLaunchKernelGGL(attn_fwd_tail_row_kernel<32>, tgrid, dim3(512), 0, stream, a, g->Sq - tail); break;
+    default: hipLaunchKernelGGL(attn_fwd_tail_row_kernel<64>, tgrid, dim3(512), 0, stream, a, g->Sq - tail); break;
+  }
+  return check_launch("attn_fwd_tail_row");
+}
+
+// Rows (keys, in the backward's key-stationary kernel) beyond the last full 128-row block that are NOT given a block of
+// their own: 1 or 2 of them behind at least two full blocks, unmasked attention only (under a causal mask the ragged
+// block is made the cheapest one instead, see the kernels: measured better than the extra launch).
+int attention_tail_rows(int S, int mask_mode, bool dense_mask) {
+  const int tail = S % QB;
+  return (tail >= 1 && tail <= 2 && S >= 2 * QB && !dense_mask && mask_mode == 0) ? tail : 0;
 }
 
 }  // namespace isi

@@ -657,6 +657,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   const bool blk_on = btile < 2;
   const int st = tid >> 8, srow = (tid >> 3) & 31, squad = tid & 7;
   float *gbase = p.g + ((size_t)h * p.B + b) * p.Sq * p.Rp;
+  const bool unique_rho = p.Cq == 1 && p.Ck == 1;
   float4 pb[4], pe[NKQ];
   auto band0 = [&](int k) { return evq_b0 - (k + 31) / p.Ck + p.Ek - 1; };
   auto prefetch = [&](int k0) {
@@ -873,8 +874,12 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
           const int q = qw0 + qq;
           const int rho = __shfl(evq, qq) - kev + p.Ek - 1;   // lane qq holds event(query qw0 + qq): no division here
           const int col = rho - p.rho_lo;
-          if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp)
-            unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);
+          if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp) {
+            // one channel per event on both sides: (query, key) -> table row is one-to-one, the element of the zeroed G is
+            // written exactly once -- a plain store instead of a read-modify-write in the L2
+            if (unique_rho) gbase[(size_t)q * p.Rp + col] = val;
+            else unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);
+          }
         }
         wave_lds_sync();
       }
@@ -1388,7 +1393,7 @@ __device__ __forceinline__ void attn_bwd_tail_row(const AttnBwdKArgs &p, float *
       dq.x += ds * kk[u].x; dq.y += ds * kk[u].y; dq.z += ds * kk[u].z; dq.w += ds * kk[u].w;
       if (grow && gl == 0 && j < Sk && ds != 0.f) {
         const int col = rho[u] - p.rho_lo;
-        if (rho[u] >= 0 && rho[u] < p.R && col >= 0 && col < p.Rp) unsafeAtomicAdd(grow + col, ds);   // (Ck = 1: one key per column)
+        if (rho[u] >= 0 && rho[u] < p.R && col >= 0 && col < p.Rp) grow[col] = ds;   // (Ck = 1: one key per column of the zeroed row)
       }
     }
   }

@@ -38,7 +38,7 @@ struct AttnBwdKArgs {
   const float *q, *k, *v, *e, *mask, *dout, *out, *lse;
   float *dsum;            // [B,H,Sq]
   float *dq, *dk, *dv;
-  float *g;               // [H][B*Sq][Rp]
+  float *g;               // [H][Sq][B][Rp]: rows query-major, so that the rows of a GEMM tile share their band of columns
   unsigned q_bytes, k_bytes, v_bytes, e_bytes, o_bytes;
   int Sq, Sk, H, B;
   int nqb, nkb;           // stationary query / key blocks the split kernels run (all, or only the full ones)
@@ -140,7 +140,8 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_q_kernel(const AttnBwdK
   if (p.mask_mode == 2) k_begin = (q0 / 32) * 32;
 
   const int srow = tid >> 3, squad = tid & 7;
-  float *gbase = p.g + ((size_t)h * p.B + b) * p.Sq * p.Rp;
+  float *gbase = p.g + ((size_t)h * p.Sq * p.B + b) * p.Rp;   // row of query q: + q * gstride (rows ordered query-major)
+  const size_t gstride = (size_t)p.B * p.Rp;
   float4 pk[NKQ], pv[NKQ], pe[NKQ];
   auto band0 = [&](int k0) { return evq_b0 - (k0 + 31) / p.Ck + p.Ek - 1; };
   auto prefetch = [&](int k0) {
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) void rel_attention_bwd_q_kernel(const AttnBwdK
           const int rho = __shfl(evq, qq) - kev + p.Ek - 1;   // lane qq holds event(query qw0 + qq): no division here
           const int col = rho - p.rho_lo;
           if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp)
-            unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);
+            unsafeAtomicAdd(gbase + (size_t)q * gstride + col, val);
         }
         wave_lds_sync();
       }
@@ -656,7 +657,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);
   const bool blk_on = btile < 2;
   const int st = tid >> 8, srow = (tid >> 3) & 31, squad = tid & 7;
-  float *gbase = p.g + ((size_t)h * p.B + b) * p.Sq * p.Rp;
+  float *gbase = p.g + ((size_t)h * p.Sq * p.B + b) * p.Rp;   // row of query q: + q * gstride (rows ordered query-major)
+  const size_t gstride = (size_t)p.B * p.Rp;
   const bool unique_rho = p.Cq == 1 && p.Ck == 1;
   float4 pb[4], pe[NKQ];
   auto band0 = [&](int k) { return evq_b0 - (k + 31) / p.Ck + p.Ek - 1; };
@@ -877,8 +879,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
           if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp) {
             // one channel per event on both sides: (query, key) -> table row is one-to-one, the element of the zeroed G is
             // written exactly once -- a plain store instead of a read-modify-write in the L2
-            if (unique_rho) gbase[(size_t)q * p.Rp + col] = val;
-            else unsafeAtomicAdd(gbase + (size_t)q * p.Rp + col, val);
+            if (unique_rho) gbase[(size_t)q * gstride + col] = val;
+            else unsafeAtomicAdd(gbase + (size_t)q * gstride + col, val);
           }
         }
         wave_lds_sync();
@@ -1366,7 +1368,7 @@ __device__ __forceinline__ void attn_bwd_tail_row(const AttnBwdKArgs &p, float *
   const float *kb = p.k + (size_t)b * p.k_sb + (size_t)h * p.k_sh + gl * 4;
   const float *vb = p.v + (size_t)b * p.v_sb + (size_t)h * p.v_sh + gl * 4;
   const float *eb = p.e ? p.e + (size_t)h * p.R * HD + gl * 4 : nullptr;
-  float *grow = p.g ? p.g + (((size_t)h * p.B + b) * p.Sq + i) * p.Rp : nullptr;
+  float *grow = p.g ? p.g + (((size_t)h * p.Sq + i) * p.B + b) * p.Rp : nullptr;
   float4 dq = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = grp; j0 < Sk; j0 += U * RPP) {
     float4 kk[U], vv[U], ee[U];
@@ -1656,23 +1658,23 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     // all heads in one launch each (grid z = head): G_h [B*Sq, Rp] x E_h^T, accumulated into dq's head slice ...
     isi_src sg;
     memset(&sg, 0, sizeof sg);
-    sg.ptr = a.g; sg.C = L.Rp; sg.sn = (int64_t)g->Sq * L.Rp; sg.sc = 1; sg.sh = L.Rp; sg.sw = L.Rp;
+    sg.ptr = a.g; sg.C = L.Rp; sg.sn = (int64_t)g->B * L.Rp; sg.sc = 1; sg.sh = L.Rp; sg.sw = L.Rp;   // "image" = [Sq][B][1]
     isi_src res;
     memset(&res, 0, sizeof res);
-    res.ptr = ga->dq; res.C = HD; res.sn = g->q_sb; res.sc = 1; res.sh = g->q_ss; res.sw = g->q_ss;
+    res.ptr = ga->dq; res.C = HD; res.sn = g->q_ss; res.sc = 1; res.sh = g->q_sb; res.sw = g->q_sb;
     isi_dst dst;
     memset(&dst, 0, sizeof dst);
-    dst.ptr = ga->dq; dst.sn = g->q_sb; dst.sc = 1; dst.sh = g->q_ss; dst.sw = g->q_ss;
+    dst.ptr = ga->dq; dst.sn = g->q_ss; dst.sc = 1; dst.sh = g->q_sb; dst.sw = g->q_sb;
     const int64_t zs_g = (int64_t)g->B * g->Sq * L.Rp;
-    rc = conv2d_batched_f32(&sg, nullptr, wT, nullptr, &res, &dst, g->B, g->Sq, 1, HD, 1, 1, 1, 0, gemm_flags, g->H,
+    rc = conv2d_batched_f32(&sg, nullptr, wT, nullptr, &res, &dst, g->Sq, g->B, 1, HD, 1, 1, 1, 0, gemm_flags, g->H,
                             zs_g, (int64_t)HD * KpT, g->q_sh, g->q_sh, stream);
     if (rc) return rc;
     // ... and dE_h = G_h^T Q_h, the pixel-reduction GEMM
     isi_src sq;
     memset(&sq, 0, sizeof sq);
-    sq.ptr = g->q; sq.C = HD; sq.sn = g->q_sb; sq.sc = 1; sq.sh = g->q_ss; sq.sw = g->q_ss;
+    sq.ptr = g->q; sq.C = HD; sq.sn = g->q_ss; sq.sc = 1; sq.sh = g->q_sb; sq.sw = g->q_sb;
     rc = conv_wgrad_batched_f32(&sq, nullptr, a.g, ga->workspace + L.dw, nullptr, ga->workspace + L.wg, L.wg_floats,
-                                g->B, g->Sq, 1, L.Rp, 1, 1, 1, 0, gemm_flags, g->H, g->q_sh, zs_g,
+                                g->Sq, g->B, 1, L.Rp, 1, 1, 1, 0, gemm_flags, g->H, g->q_sh, zs_g,
                                 (int64_t)L.Rp * L.Kp, stream);
     if (rc) return rc;
   }

@@ -20,6 +20,8 @@
 //   * no im2col arithmetic: rows are rows.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "split_bf16.h"
@@ -39,6 +41,8 @@ struct GemmArgs {
   int M, N, K, lda, ldr, ldo, relu;
   const float *w32;       // fp32 weight [N][K] (the tail rows' operand; == w unless w is a pair copy)
   int tail;               // rows [M, M + tail) beyond the tiled rows: fp32 dot products, spread over the workgroups
+  int zs_a, zs_w, zs_res, zs_out;                          // element strides between the products of a batch (grid y)
+  int win_rpu, lo_slope, lo_base, hi_slope, hi_base;       // GemmExtra's band of non-zero A columns (win_rpu = 0: none)
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -66,8 +70,13 @@ __device__ __forceinline__ f32x16 mfma(const s16x8g a, const s16x8g b, const f32
 // the LDS planes, so the weight tile is staged by plain copies: every 128-row tile of the fp32 form converts its
 // weight tile again, 65 times at M = 8200.
 template <bool F16, int TN, bool WPRE = false>
-__global__ __launch_bounds__(512, 2) void gemm_split_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
   constexpr int BN = 64 * TN;
+  if (blockIdx.y) {      // a batch of products: this one's operands
+    const size_t z = blockIdx.y;
+    p.a += z * p.zs_a; p.w += z * p.zs_w; p.w32 += z * p.zs_w; p.out += z * p.zs_out;
+    if (p.res) p.res += z * p.zs_res;
+  }
   constexpr int APL = BM * 64, BPL = BN * 64;                  // bytes of one plane (rows of 32 pieces = 64 B)
   constexpr int STAGE = 2 * APL + 2 * BPL;                     // A hi, A lo, B hi, B lo
   constexpr int NA = BM * 8 / 512, NB = BN * 8 / 512;          // float4 per thread and chunk
@@ -137,13 +146,23 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const GemmArgs p) {
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int nchunk = p.K / 32;
-  load_chunk(0);
-  store_chunk(0);
+  int c_lo = 0, c_hi = nchunk;
+  if (p.win_rpu) {       // the K chunks that hold this tile's band of non-zero A columns (GemmExtra)
+    const int u0 = m0 / p.win_rpu, u1 = min(p.M - 1, m0 + BM - 1) / p.win_rpu;
+    const int klo = p.lo_slope * u0 + p.lo_base, khi = p.hi_slope * u1 + p.hi_base;
+    c_lo = max(klo, 0) / 32;
+    c_hi = khi < 0 ? c_lo : min(nchunk, khi / 32 + 1);
+    c_lo = min(c_lo, c_hi);
+  }
+  if (c_lo < c_hi) {
+    load_chunk(32 * c_lo);
+    store_chunk(0);
+  }
   __syncthreads();
-  for (int c = 0; c < nchunk; ++c) {
-    const bool more = c + 1 < nchunk;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const bool more = c + 1 < c_hi;
     if (more) load_chunk(32 * (c + 1));
-    const unsigned char *st = smem + (c & 1) * STAGE;
+    const unsigned char *st = smem + ((c - c_lo) & 1) * STAGE;
     const int arow = wm0 + fr;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -160,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const GemmArgs p) {
         acc[j] = mfma<F16>(ah, bh, acc[j]);
       }
     }
-    if (more) store_chunk((c + 1) & 1);   // that stage was last read in iteration c - 1: every wave is past its barrier
+    if (more) store_chunk((c + 1 - c_lo) & 1);   // that stage was last read in iteration c - 1: every wave is past its barrier
     __syncthreads();
   }
 
@@ -217,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(const GemmArgs p) {
 }
 
 template <bool F16, int TN, bool WPRE = false>
-int launch_gemm(const GemmArgs &a, hipStream_t stream) {
+int launch_gemm(const GemmArgs &a, hipStream_t stream, int nz = 1) {
   constexpr int BN = 64 * TN;
   constexpr size_t smem = (size_t)2 * (2 * BM * 64 + 2 * BN * 64);
   static DeviceOnce attr_set;
@@ -228,7 +247,7 @@ int launch_gemm(const GemmArgs &a, hipStream_t stream) {
     attr_set.mark();
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_split_kernel<F16, TN, WPRE>), dim3(tiles), dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((gemm_split_kernel<F16, TN, WPRE>), dim3(tiles, nz), dim3(512), smem, stream, a);
   return check_launch("gemm_split_f32");
 }
 
@@ -241,7 +260,8 @@ bool gemm_split_applicable(int M, int N, int K, int split_mode) {
 }
 
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
-                   int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream, const float *w16) {
+                   int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream, const float *w16,
+                   const GemmExtra *extra) {
   // A few rows beyond a multiple of the tile height (the prior's B x (S + 1) = 8 x 1025 = 64 tiles + 8 rows) would add a
   // whole column of 128-row tiles: 520 instead of 512 for N = 512, and with two workgroups per CU the launch then
   // runs TWO rounds (28 vs 22 us at K = 512, 92 vs 66 us at K = 2048, measured).  The tiles cover the full tile rows
@@ -256,15 +276,31 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   g.a_bytes = (unsigned)(ea * 4); g.w_bytes = (unsigned)((int64_t)N * K * 4); g.out_bytes = (unsigned)(eo * 4);
   g.res_bytes = (unsigned)(er * 4);
   g.w32 = w; g.tail = 0;
+  g.zs_a = g.zs_w = g.zs_res = g.zs_out = 0;
+  g.win_rpu = g.lo_slope = g.lo_base = g.hi_slope = g.hi_base = 0;
+  int nz = 1;
+  if (extra) {
+    nz = extra->nz;
+    if (nz < 1 || nz > 65535) return invalid("gemm: bad batch count");
+    const int64_t zmax = std::max(std::max(extra->zs_a, extra->zs_w), std::max(extra->zs_res, extra->zs_out));
+    if (zmax >= ((int64_t)1 << 31) || (extra->zs_a | extra->zs_w | extra->zs_res | extra->zs_out) < 0)
+      return unsupported("gemm: batch stride out of range");
+    g.zs_a = (int)extra->zs_a; g.zs_w = (int)extra->zs_w; g.zs_res = (int)extra->zs_res; g.zs_out = (int)extra->zs_out;
+    if (extra->win_rpu > 0) {
+      if (extra->lo_slope < 0 || extra->hi_slope < 0) return invalid("gemm: band slopes must be non-negative");
+      g.win_rpu = extra->win_rpu; g.lo_slope = extra->lo_slope; g.lo_base = extra->lo_base;
+      g.hi_slope = extra->hi_slope; g.hi_base = extra->hi_base;
+    }
+  }
   const int rem = M % BM;
   if (rem > 0 && rem <= kGemmTailRows && M >= 8 * BM && (lda & 3) == 0) { g.tail = rem; g.M = M - rem; M = g.M; }
   // 128 x 64 tiles when 128 x 128 ones would leave CUs without a second workgroup
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   const bool narrow = tiles128 < 512 || N % 128 != 0;
-  if (split_mode == 3 && w16) return narrow ? launch_gemm<true, 1, true>(g, stream) : launch_gemm<true, 2, true>(g, stream);
-  if (split_mode == 3) return narrow ? launch_gemm<true, 1>(g, stream) : launch_gemm<true, 2>(g, stream);
-  if (w16) return narrow ? launch_gemm<false, 1, true>(g, stream) : launch_gemm<false, 2, true>(g, stream);
-  return narrow ? launch_gemm<false, 1>(g, stream) : launch_gemm<false, 2>(g, stream);
+  if (split_mode == 3 && w16) return narrow ? launch_gemm<true, 1, true>(g, stream, nz) : launch_gemm<true, 2, true>(g, stream, nz);
+  if (split_mode == 3) return narrow ? launch_gemm<true, 1>(g, stream, nz) : launch_gemm<true, 2>(g, stream, nz);
+  if (w16) return narrow ? launch_gemm<false, 1, true>(g, stream, nz) : launch_gemm<false, 2, true>(g, stream, nz);
+  return narrow ? launch_gemm<false, 1>(g, stream, nz) : launch_gemm<false, 2>(g, stream, nz);
 }
 
 }  // namespace isi

@@ -113,9 +113,18 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
                      int top_k, float top_p, hipStream_t stream);
 
 bool gemm_split_applicable(int M, int N, int K, int split_mode);
+// Optional extras of gemm_split_f32: a batch of nz independent products (grid y; element strides between them) and a
+// band of the K range per 128-row tile -- rows [u win_rpu, (u + 1) win_rpu) only have non-zero A columns in
+// [lo_slope u + lo_base, hi_slope u + hi_base] (slopes >= 0), the K chunks outside the tile's band are skipped
+// (win_rpu = 0: no band).  The attention backward's dQ += G E^T uses both (rel_attention_bwd_f32.hip).
+struct GemmExtra {
+  int nz;
+  int64_t zs_a, zs_w, zs_res, zs_out;
+  int win_rpu, lo_slope, lo_base, hi_slope, hi_base;
+};
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
                    int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream,
-                   const float *w16 = nullptr);
+                   const float *w16 = nullptr, const GemmExtra *extra = nullptr);
 size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase);
 int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                    float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,

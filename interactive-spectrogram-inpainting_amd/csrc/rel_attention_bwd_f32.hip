@@ -26,6 +26,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_bf16.h"
 
@@ -1329,7 +1330,7 @@ void rho_range(const isi_attn_args *g, int *lo, int *n) {
 }
 BwdLayout bwd_layout(int B, int H, int Sq, int R, int HD) {   // R = number of table rows G covers
   BwdLayout L;
-  L.Rp = (int)round_up((size_t)std::max(R, 1), 4);
+  L.Rp = (int)round_up((size_t)std::max(R, 1), kBK);      // (a whole number of K chunks: G is a GEMM operand as it stands)
   L.Kp = (int)round_up((size_t)HD, kBK);
   size_t off = 0;
   auto take = [&](size_t n) { const size_t o = off; off += round_up(n, 64); return o; };
@@ -1666,6 +1667,23 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     memset(&dst, 0, sizeof dst);
     dst.ptr = ga->dq; dst.sn = g->q_ss; dst.sc = 1; dst.sh = g->q_sb; dst.sw = g->q_sb;
     const int64_t zs_g = (int64_t)g->B * g->Sq * L.Rp;
+    // Rows of G are (query, batch): with one channel per event on both sides the non-zero columns of query i are the
+    // band [i + Ek - Sk, i + Ek - 1] - rho_lo (unmasked), [Ek - 1, i + Ek - 1] - rho_lo (causal) ... -- a 128-row
+    // tile holds 128 / B queries, its band is about half of the table: the GEMM kernel skips the other K chunks
+    GemmExtra gx;
+    memset(&gx, 0, sizeof gx);
+    gx.nz = g->H; gx.zs_a = zs_g; gx.zs_w = (int64_t)HD * KpT; gx.zs_res = g->q_sh; gx.zs_out = g->q_sh;
+    if (g->Cq == 1 && g->Ck == 1) {
+      gx.win_rpu = g->B;
+      const int top = g->Ek - 1 - rho_lo, bot = g->Ek - g->Sk - rho_lo;
+      gx.lo_slope = g->mask_mode == 1 ? 0 : 1; gx.lo_base = g->mask_mode == 1 ? top : bot;
+      gx.hi_slope = g->mask_mode == 2 ? 0 : 1; gx.hi_base = top;
+    }
+    const int Mg = g->Sq * g->B;
+    if (g->precision >= 1 && KpT == L.Rp && g->q_ss == (int64_t)g->B * g->q_sb && gemm_split_applicable(Mg, HD, L.Rp, 1) &&
+        !knobs().no_gemm_kernel)
+      rc = gemm_split_f32(a.g, L.Rp, wT, nullptr, ga->dq, g->q_sb, ga->dq, g->q_sb, Mg, HD, L.Rp, 0, 1, stream, nullptr, &gx);
+    else
     rc = conv2d_batched_f32(&sg, nullptr, wT, nullptr, &res, &dst, g->Sq, g->B, 1, HD, 1, 1, 1, 0, gemm_flags, g->H,
                             zs_g, (int64_t)HD * KpT, g->q_sh, g->q_sh, stream);
     if (rc) return rc;

@@ -39,6 +39,9 @@ struct WgradKArgs {
   int convT, dst_sh, dst_sw;   // transposed conv: phase offset into dY
   int nsplit, chunks_per_split;
   int nz, zs_x0, zs_dy;        // nz > 1: blockIdx.z also enumerates nz independent (x, dY) pairs (element strides)
+  // WgradBand (conv_wgrad_split_kernel only): output channel c of dY is non-zero only on the pixels of units
+  // [lo_slope c + lo_base, hi_slope c + hi_base], a unit = win_rpu consecutive pixels; win_rpu = 0: everywhere
+  int win_rpu, wlo_slope, wlo_base, whi_slope, whi_base;
 };
 
 namespace {
@@ -287,9 +290,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(const WgradKArgs 
   const int co = co0 + sq * 4;
   const bool covalid = drole && co < p.Cout;
 
-  const int chunk_begin = split * p.chunks_per_split;
   const int nchunks_total = (p.M + 31) / 32;
-  const int chunk_end = min(nchunks_total, chunk_begin + p.chunks_per_split);
+  int cw_lo = 0, cw_hi = nchunks_total, cps = p.chunks_per_split;
+  if (p.win_rpu) {     // the pixels on which this tile's channels of dY can be non-zero, shared out among the splits
+    const int u_lo = max(0, p.wlo_slope * co0 + p.wlo_base);
+    const int u_hi = min((p.M - 1) / p.win_rpu, p.whi_slope * (co0 + TCO - 1) + p.whi_base);
+    cw_lo = min(nchunks_total, (u_lo * p.win_rpu) / 32);
+    cw_hi = u_hi < u_lo ? cw_lo : min(nchunks_total, ((u_hi + 1) * p.win_rpu + 31) / 32);
+    cps = (cw_hi - cw_lo + p.nsplit - 1) / p.nsplit;
+  }
+  const int chunk_begin = min(cw_hi, cw_lo + split * cps);
+  const int chunk_end = min(cw_hi, chunk_begin + cps);
 
   float4 rdq[4], rxq[JX][4];
   // (batch, row, column) of this thread's four pixels, carried from chunk to chunk (chunks are visited in
@@ -983,7 +994,7 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
 int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                            float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                            int stride, int pad, int transposed, int nz, int64_t zs_x0, int64_t zs_dy, int64_t zs_dw,
-                           hipStream_t stream, int torch_keep) {
+                           hipStream_t stream, int torch_keep, const WgradBand *band) {
   if (!s0 || !s0->ptr || !dy || !dw_packed || !workspace) return invalid("conv_wgrad: null pointer");
   if (torch_keep && ((transposed & 1) || nz != 1)) return unsupported("conv_wgrad: torch-layout output is for plain convolutions");
   if (nz < 1 || nz > 255) return invalid("conv_wgrad: bad batch count");
@@ -1041,6 +1052,10 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   const int nsplit = wgrad_nsplit(Cout, a.Kpad, a.M, nphase, nz, use_split);
   a.nsplit = nsplit; a.chunks_per_split = (nchunks + nsplit - 1) / nsplit;
   a.nz = nz; a.zs_x0 = (int)zs_x0; a.zs_dy = (int)zs_dy;
+  if (band && band->win_rpu > 0 && band->lo_slope >= 0 && band->hi_slope >= 0) {   // (a hint: kernels without it read everything)
+    a.win_rpu = band->win_rpu; a.wlo_slope = band->lo_slope; a.wlo_base = band->lo_base;
+    a.whi_slope = band->hi_slope; a.whi_base = band->hi_base;
+  }
   const size_t need = (size_t)nz * ((size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout);
   if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
   a.db_partial = db ? workspace + (size_t)nsplit * nphase * Cout * a.Kpad : nullptr;

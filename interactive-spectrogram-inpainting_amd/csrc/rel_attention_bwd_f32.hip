@@ -1687,13 +1687,17 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     rc = conv2d_batched_f32(&sg, nullptr, wT, nullptr, &res, &dst, g->Sq, g->B, 1, HD, 1, 1, 1, 0, gemm_flags, g->H,
                             zs_g, (int64_t)HD * KpT, g->q_sh, g->q_sh, stream);
     if (rc) return rc;
-    // ... and dE_h = G_h^T Q_h, the pixel-reduction GEMM
+    // ... and dE_h = G_h^T Q_h, the pixel-reduction GEMM; column c of G is non-zero on the queries [c - top, c - bot]
+    // (unmasked), from c - top on (causal), up to c - bot (anti-causal): the kernel reads only those rows
+    const int top_ = g->Ek - 1 - rho_lo, bot_ = g->Ek - g->Sk - rho_lo;
+    const WgradBand wb{g->B, g->mask_mode == 2 ? 0 : 1, g->mask_mode == 2 ? 0 : -top_,
+                       g->mask_mode == 1 ? 0 : 1, g->mask_mode == 1 ? g->Sq - 1 : -bot_};
     isi_src sq;
     memset(&sq, 0, sizeof sq);
     sq.ptr = g->q; sq.C = HD; sq.sn = g->q_ss; sq.sc = 1; sq.sh = g->q_sb; sq.sw = g->q_sb;
     rc = conv_wgrad_batched_f32(&sq, nullptr, a.g, ga->workspace + L.dw, nullptr, ga->workspace + L.wg, L.wg_floats,
                                 g->Sq, g->B, 1, L.Rp, 1, 1, 1, 0, gemm_flags, g->H, g->q_sh, zs_g,
-                                (int64_t)L.Rp * L.Kp, stream);
+                                (int64_t)L.Rp * L.Kp, stream, 0, gx.win_rpu ? &wb : nullptr);
     if (rc) return rc;
   }
   {

@@ -59,6 +59,10 @@ def _models(golden_dir, load=True):
     (16, 4, 33, 33, 1, 1, 1), (16, 4, 33, 33, 1, 1, 2), (16, 4, 132, 33, 4, 1, 0),
     (64, 2, 200, 200, 1, 1, 1), (32, 3, 260, 260, 4, 4, 1), (64, 2, 77, 150, 2, 1, 0),
     (16, 2, 1, 1, 1, 1, 0), (64, 1, 1, 97, 1, 1, 0), (32, 2, 64, 64, 1, 1, 2), (64, 2, 129, 129, 1, 1, 1),
+    # one or two rows beyond the last full 128-row block: unmasked -> the one-row kernel (every head dim, two tokens per
+    # query event, B H = 6 / 10 pairs on the 8 XCD residue classes); causal -> the ragged block is block 0
+    (32, 3, 257, 257, 1, 1, 0), (16, 5, 258, 130, 2, 1, 0), (64, 3, 385, 300, 1, 1, 0), (64, 3, 257, 257, 1, 1, 1),
+    (32, 2, 300, 300, 1, 1, 1),
 ])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 def test_rel_attention_against_spec(hd, H, Sq, Sk, Cq, Ck, mode, precision, monkeypatch):

@@ -53,6 +53,11 @@ def _spec_attention(q, k, v, rel, H, Cq, Ck, Ek, mask):
     # degenerate / boundary shapes: one query (over two keys: with a single key every gradient but dV is
     # identically zero and a relative comparison is meaningless), exactly one tile, a tile boundary + 1
     (16, 2, 1, 2, 1, 1, 0, True), (64, 1, 1, 97, 1, 1, 0, True), (32, 2, 64, 64, 1, 1, 2, True),
+    # one or two rows / keys beyond the last full 128-row block: unmasked -> the one-row / one-key kernels (with and
+    # without relative logits, every head dim, Cq = 2 with a ragged key count, B H not a multiple of 8); causal ->
+    # the ragged query block is block 0; the banded G products with rows ordered (query, batch)
+    (32, 3, 257, 257, 1, 1, 0, True), (16, 5, 258, 130, 2, 1, 0, True), (64, 3, 385, 257, 1, 1, 0, True),
+    (64, 3, 257, 258, 1, 1, 0, False), (64, 3, 257, 257, 1, 1, 1, True), (32, 2, 300, 300, 1, 1, 2, True),
     (64, 2, 129, 129, 1, 1, 1, True),
 ])
 @pytest.mark.parametrize("precision", ["f32", "bf16x3"])

@@ -50,8 +50,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    t_host = (time.perf_counter() - t0) / a.steps      # host time to ENQUEUE a step (the loop never synchronises)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+    print(f"host enqueue time {t_host * 1e3:.1f} ms/step (GPU-bound while this stays below the step time)")
     print(f"prior training step B={B} S=1025: {dt * 1e3:.1f} ms/step  {B / dt:.1f} codemaps/s  "
           f"{B * 1024 / dt:.0f} tokens/s  loss {float(loss):.4f}")
     # forward only (no_grad, eval) for comparison

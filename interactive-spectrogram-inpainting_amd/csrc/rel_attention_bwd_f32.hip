@@ -951,7 +951,13 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   if (!xcd_tile(nkb, p.H * p.B, p.mask_mode != 0, kt, pair)) return;
   const int h = pair % p.H, b = pair / p.H;
   const int kblk = p.mask_mode == 2 ? nkb - 1 - kt : kt;
-  const int k0b = kblk * QB, kw0 = k0b + 32 * wq, kj = kw0 + ql;
+  // anti-causal masks: the ragged key block (Sk % QB keys) would see EVERY query -- this kernel's heaviest block for one
+  // key of a 1025-key sequence; it is block 0 instead, where the query range is shortest (the mirror image of the
+  // query-stationary kernels under a causal mask; the band logic takes any origin when Ck = 1)
+  const int rag = (p.mask_mode == 2 && p.Ck == 1 && nkb * QB >= p.Sk) ? p.Sk % QB : 0;
+  const int k0b = rag ? (kblk ? rag + (kblk - 1) * QB : 0) : kblk * QB;
+  const int k_lim = (rag && kblk == 0) ? rag : p.Sk;            // first key beyond this block's valid ones
+  const int kw0 = k0b + 32 * wq, kj = kw0 + ql;
   const bool has_e = p.e != nullptr;
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
@@ -963,7 +969,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   s16x8_t kh[NKB], kl[NKB], vh[NKB], vl[NKB];
 #pragma unroll
   for (int t = 0; t < NKB; ++t) {
-    const bool ok = kj < p.Sk;
+    const bool ok = kj < k_lim;
     const unsigned ok_ = ok ? (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + 16 * t + 8 * half) * 4u : OOB;
     const unsigned ov = ok ? (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + 16 * t + 8 * half) * 4u : OOB;
     uint2 h0, l0, h1, l1;
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     const int q0 = qp + 32 * grp;
     const int rb = band0(q0);
 
-    bool live = kw0 < p.Sk && q0 < q_end;
+    bool live = kw0 < k_lim && q0 < q_end;
     if (p.mask_mode == 1) live = live && q0 + 31 >= kw0;
     if (p.mask_mode == 2) live = live && q0 <= kw0 + 31;
     if (live) {  // wave-uniform
@@ -1174,7 +1180,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
       }
 
       // ---- P
-      bool full = !p.mask && kw0 + 31 < p.Sk && q0 + 31 < p.Sq;
+      bool full = !p.mask && kw0 + 31 < k_lim && q0 + 31 < p.Sq;
       if (p.mask_mode == 1) full = full && kw0 + 31 <= q0;
       if (p.mask_mode == 2) full = full && kw0 >= q0 + 31;
       if (full) {
@@ -1185,7 +1191,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         for (int r = 0; r < 16; ++r) {
           const int qrow = mfma_row(r, half);
           const int qi = q0 + qrow;
-          bool ok = kj < p.Sk && qi < p.Sq;
+          bool ok = kj < k_lim && qi < p.Sq;
           if (p.mask_mode == 1) ok = ok && kj <= qi;
           if (p.mask_mode == 2) ok = ok && kj >= qi;
           float s = sv[r] * scale2;
@@ -1269,7 +1275,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   }
   __syncthreads();
   if (grp == 1) return;
-  if (kj < p.Sk) {
+  if (kj < k_lim) {
     const float *src = mg + wq * MGW + lane;
     float *krow = p.dk + (size_t)kj * p.k_ss + (size_t)b * p.k_sb + (size_t)h * p.k_sh;
     float *vrow = p.dv + (size_t)kj * p.v_ss + (size_t)b * p.v_sb + (size_t)h * p.v_sh;

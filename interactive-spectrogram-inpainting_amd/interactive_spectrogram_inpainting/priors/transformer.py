@@ -262,8 +262,10 @@ class VQNSynthTransformer(nn.Module):
 
     def embed_data(self, input: torch.Tensor, kind: Seq2SeqInputKind) -> torch.Tensor:
         table = self._embedding_table(kind)
-        if input.numel() and (int(input.min()) < 0 or int(input.max()) >= table.shape[0]):
-            raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
+        if input.numel():
+            lo, hi = torch.aminmax(input)          # one launch; the read-back below is this call's only synchronisation
+            if int(lo) < 0 or int(hi) >= table.shape[0]:
+                raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
         if table.requires_grad:
             return _train.EmbeddingRowsFn.apply(table, input)
         return table[input]

@@ -1059,8 +1059,11 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   const size_t need = (size_t)nz * ((size_t)nsplit * nphase * Cout * a.Kpad + (size_t)nsplit * nphase * Cout);
   if (workspace_floats < need) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }
   a.db_partial = db ? workspace + (size_t)nsplit * nphase * Cout * a.Kpad : nullptr;
+  const bool band_required = band && band->required;
+  if (band_required && (!a.win_rpu || !use_split || transposed))
+    return unsupported("conv_wgrad: the band of dY is only honoured by the split-product kernel");
   // a linear layer's weight gradient (rows of a dense matrix): the row-major kernel
-  if (use_split && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 &&
+  if (use_split && !band_required && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 &&
       pad == 0 && B == 1 && H == 1 && Cout % 128 == 0 && Cin % 128 == 0 && !knobs().no_gemm_kernel) {
     const int tiles = (Cout / 128) * (Cin / 128);
     const int ns = std::max(1, std::min(std::min(64, (512 + tiles - 1) / tiles), nchunks / 8));
@@ -1085,7 +1088,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   const bool k3 = KH == 3 && KW == 3 && stride == 1 && pad == 1, k4 = KH == 4 && KW == 4 && stride == 2 && pad == 1;
   int nco = Cout % 128 == 0 ? 4 : Cout % 64 == 0 ? 2 : 1;
   while (nco < 4 && Cin % (32 * (4 / nco))) nco *= 2;   // fewer input-channel slices per workgroup when Cin is small
-  const bool halo = use_split && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && (k3 || k4) &&
+  const bool halo = use_split && !band_required && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && (k3 || k4) &&
                     Cout % (32 * nco) == 0 && Cin % (32 * (4 / nco)) == 0 && s0->C % 32 == 0 && OW % 32 == 0 &&
                     OH % 2 == 0 && !(k4 && nco == 1) && !knobs().no_wgrad_halo;   // (k4, one channel group: does not fit its registers)
   if (halo) {

@@ -219,8 +219,15 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
       for (int r = wave; r < p.tail; r += 8) {
         const size_t m = (size_t)p.M + r;
         const float4 *xr = reinterpret_cast<const float4 *>(p.a + m * p.lda);
+        int q_lo = 0, q_hi = nq;
+        if (p.win_rpu) {      // the row's band of non-zero columns (the rest of a banded operand may be undefined)
+          const int u = (int)(m / p.win_rpu);
+          const int klo = p.lo_slope * u + p.lo_base, khi = p.hi_slope * u + p.hi_base;
+          q_lo = max(klo, 0) >> 2;
+          q_hi = khi < 0 ? q_lo : min(nq, (khi >> 2) + 1);
+        }
         float s = 0.f;
-        for (int qd = lane; qd < nq; qd += 64) {
+        for (int qd = q_lo + lane; qd < q_hi; qd += 64) {
           const float4 wv = wr[qd], xv = xr[qd];
           s += (wv.x * xv.x + wv.y * xv.y) + (wv.z * xv.z + wv.w * xv.w);
         }

@@ -36,6 +36,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_CONVT_PAIR_TH", &Knobs::convt_pair_th, 0, false},
     {"ISI_DECODE_NT", &Knobs::decode_nt, 1, false},
     {"ISI_PRIOR_GRAPH", &Knobs::prior_graph, 0, false},
+    {"ISI_ATTN_FULL_ZERO", &Knobs::attn_full_zero, 0, false},
     {"ISI_CONV_ABLATE", &Knobs::conv_ablate, 0, true},
     {"ISI_VQ_DBG", &Knobs::vq_dbg, 0, true},
     {"ISI_RESPAIR_ABL", &Knobs::respair_abl, 0, true},

@@ -131,7 +131,7 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
                    int stride, int pad, int transposed, hipStream_t stream, int torch_keep = 0);
 // optional hint of conv_wgrad_batched_f32: output channel c of dY is non-zero only on the pixels of units
 // [lo_slope c + lo_base, hi_slope c + hi_base] (slopes >= 0), a unit = win_rpu consecutive pixels of the GEMM grid
-struct WgradBand { int win_rpu, lo_slope, lo_base, hi_slope, hi_base; };
+struct WgradBand { int win_rpu, lo_slope, lo_base, hi_slope, hi_base; int required; };   // required: fail rather than read outside the band (dY is only defined there)
 int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,
                            float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                            int stride, int pad, int transposed, int nz, int64_t zs_x0, int64_t zs_dy, int64_t zs_dw,

@@ -46,6 +46,7 @@ struct AttnBwdKArgs {
   int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
   int Cq, Ck, Ek, R, Rp;
   int rho_lo;             // G column c holds table row rho_lo + c (causal modes only touch half of the table)
+  int g_band_only;        // G is zeroed only around its band: EVERY (query, key) pair the mask allows is stored (zeros too)
   int mask_mode;
   float scale;
 };
@@ -877,7 +878,12 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
           const int q = qw0 + qq;
           const int rho = __shfl(evq, qq) - kev + p.Ek - 1;   // lane qq holds event(query qw0 + qq): no division here
           const int col = rho - p.rho_lo;
-          if (val != 0.f && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp) {
+          bool wr = val != 0.f;
+          if (p.g_band_only) {     // (unique_rho) the band itself is not zeroed: store every pair the mask allows
+            const int key = k0 + ql;
+            wr = q < q_end && key < p.Sk && (p.mask_mode == 1 ? key <= q : p.mask_mode == 2 ? key >= q : true);
+          }
+          if (wr && rho >= 0 && rho < p.R && col >= 0 && col < p.Rp) {
             // one channel per event on both sides: (query, key) -> table row is one-to-one, the element of the zeroed G is
             // written exactly once -- a plain store instead of a read-modify-write in the L2
             if (unique_rho) gbase[(size_t)q * gstride + col] = val;
@@ -1400,7 +1406,7 @@ __device__ __forceinline__ void attn_bwd_tail_row(const AttnBwdKArgs &p, float *
       const float pj = j < Sk ? __expf(sdot * p.scale - lse) : 0.f;
       const float ds = pj * (pdot - dsum) * p.scale;
       dq.x += ds * kk[u].x; dq.y += ds * kk[u].y; dq.z += ds * kk[u].z; dq.w += ds * kk[u].w;
-      if (grow && gl == 0 && j < Sk && ds != 0.f) {
+      if (grow && gl == 0 && j < Sk && (ds != 0.f || p.g_band_only)) {
         const int col = rho[u] - p.rho_lo;
         if (rho[u] >= 0 && rho[u] < p.R && col >= 0 && col < p.Rp) grow[col] = ds;   // (Ck = 1: one key per column of the zeroed row)
       }
@@ -1480,6 +1486,29 @@ __device__ __forceinline__ void attn_bwd_tail_key(const AttnBwdKArgs &p, float *
     p.dk[(size_t)j * p.k_ss + (size_t)b * p.k_sb + (size_t)h * p.k_sh + tid] = ak;
     p.dv[(size_t)j * p.v_ss + (size_t)b * p.v_sb + (size_t)h * p.v_sh + tid] = av;
   }
+}
+
+// G zeroed only where it is read but not written: with Cq = Ck = 1 every (query, key) pair has its own element, the
+// query-stationary kernel (and the one-row kernel) store the whole band of a row -- zeros included -- and both products
+// over G read a band of chunks / queries around it (GemmExtra, WgradBand): what has to be zero are the MARGINS of the
+// band, kMargin columns on either side (128-column tiles of dE plus the chunk rounding of both products: < 264).
+// One wave per row of G; rows = (head, query, batch).
+constexpr int kMargin = 288;
+__global__ __launch_bounds__(256) void attn_zero_margins_kernel(float *__restrict__ g, long rows, int Sq, int B, int Rp,
+                                                                int lo_slope, int lo_base, int hi_slope, int hi_base) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int i = (int)((row / B) % Sq);
+  const int lo = lo_slope * i + lo_base, hi = hi_slope * i + hi_base;      // the row's band [lo, hi]
+  float4 *gr = reinterpret_cast<float4 *>(g + row * Rp);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  // quads [a0, a1) on the left of the band, [b0, b1) on its right (a quad that reaches into the band is harmless:
+  // this launch runs before the kernels that store the band)
+  const int a0 = max(lo - kMargin, 0) >> 2, a1 = (max(min(lo, Rp), 0) + 3) >> 2;
+  const int b0 = max(min(hi + 1, Rp), 0) >> 2, b1 = (max(min(hi + 1 + kMargin, Rp), 0) + 3) >> 2;
+  for (int q = a0 + lane; q < a1; q += 64) gr[q] = z;
+  for (int q = b0 + lane; q < b1; q += 64) gr[q] = z;
 }
 
 // one launch for both roles (they are independent): blockIdx.z < tail_q: query row Sq - tail_q + z, else a key
@@ -1628,11 +1657,30 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   hipLaunchKernelGGL(attn_dsum_kernel, dim3((nstat + 255) / 256), dim3(256), 0, stream, a, HD);
   int rc = check_launch("attn_dsum");
   if (rc) return rc;
-  if (has_e) {
-    if (hipMemsetAsync(a.g, 0, (size_t)g->H * g->B * g->Sq * L.Rp * sizeof(float), stream) != hipSuccess)
-      return check_launch("hipMemsetAsync(G)");
-  }
   const bool split = g->precision >= 1;
+  // G's band per query (columns rho - rho_lo; Cq = Ck = 1): [i + bot, i + top] unmasked, [top, i + top] causal,
+  // [i + bot, top] anti-causal -- the two products over G skip what lies outside it
+  const int KpT = (int)round_up((size_t)L.Rp, kBK);
+  const int Mg = g->Sq * g->B;
+  const bool unique = has_e && g->Cq == 1 && g->Ck == 1;
+  const int top = g->Ek - 1 - rho_lo, bot = g->Ek - g->Sk - rho_lo;
+  const int lo_slope = g->mask_mode == 1 ? 0 : 1, lo_base = g->mask_mode == 1 ? top : bot;
+  const int hi_slope = g->mask_mode == 2 ? 0 : 1, hi_base = top;
+  const bool gemm_path = has_e && split && KpT == L.Rp && g->q_ss == (int64_t)g->B * g->q_sb && gemm_split_applicable(Mg, HD, L.Rp, 1) &&
+                         !knobs().no_gemm_kernel;
+  // ... and then only the margins of the band have to be zeroed (attn_zero_margins_kernel)
+  const bool band_only = unique && gemm_path && !knobs().attn_full_zero;
+  a.g_band_only = band_only ? 1 : 0;
+  if (has_e) {
+    if (band_only) {
+      const long rows = (long)g->H * g->Sq * g->B;
+      hipLaunchKernelGGL(attn_zero_margins_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a.g, rows, g->Sq, g->B,
+                         L.Rp, lo_slope, lo_base, hi_slope, hi_base);
+      if ((rc = check_launch("attn_zero_margins"))) return rc;
+    } else if (hipMemsetAsync(a.g, 0, (size_t)g->H * g->B * g->Sq * L.Rp * sizeof(float), stream) != hipSuccess) {
+      return check_launch("hipMemsetAsync(G)");
+    }
+  }
   const bool one = g->precision == 2;     // single-term bf16 products, like the forward of that mode
   // rows / keys beyond the last full block that go through the one-row kernels (the G row of such a query is written
   // with one key per column, which needs Ck = 1)
@@ -1652,7 +1700,6 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
 
   // ---- dQ += G E  and  dE = G^T Q, head by head, on the GEMM kernels
   const int R = g->rel_rows;
-  const int KpT = (int)round_up((size_t)L.Rp, kBK);
   float *wT = ga->workspace + L.wT;
   {
     const int64_t total = (int64_t)g->H * HD * KpT;
@@ -1681,13 +1728,9 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     gx.nz = g->H; gx.zs_a = zs_g; gx.zs_w = (int64_t)HD * KpT; gx.zs_res = g->q_sh; gx.zs_out = g->q_sh;
     if (g->Cq == 1 && g->Ck == 1) {
       gx.win_rpu = g->B;
-      const int top = g->Ek - 1 - rho_lo, bot = g->Ek - g->Sk - rho_lo;
-      gx.lo_slope = g->mask_mode == 1 ? 0 : 1; gx.lo_base = g->mask_mode == 1 ? top : bot;
-      gx.hi_slope = g->mask_mode == 2 ? 0 : 1; gx.hi_base = top;
+      gx.lo_slope = lo_slope; gx.lo_base = lo_base; gx.hi_slope = hi_slope; gx.hi_base = hi_base;
     }
-    const int Mg = g->Sq * g->B;
-    if (g->precision >= 1 && KpT == L.Rp && g->q_ss == (int64_t)g->B * g->q_sb && gemm_split_applicable(Mg, HD, L.Rp, 1) &&
-        !knobs().no_gemm_kernel)
+    if (gemm_path)
       rc = gemm_split_f32(a.g, L.Rp, wT, nullptr, ga->dq, g->q_sb, ga->dq, g->q_sb, Mg, HD, L.Rp, 0, 1, stream, nullptr, &gx);
     else
     rc = conv2d_batched_f32(&sg, nullptr, wT, nullptr, &res, &dst, g->Sq, g->B, 1, HD, 1, 1, 1, 0, gemm_flags, g->H,
@@ -1695,9 +1738,8 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     if (rc) return rc;
     // ... and dE_h = G_h^T Q_h, the pixel-reduction GEMM; column c of G is non-zero on the queries [c - top, c - bot]
     // (unmasked), from c - top on (causal), up to c - bot (anti-causal): the kernel reads only those rows
-    const int top_ = g->Ek - 1 - rho_lo, bot_ = g->Ek - g->Sk - rho_lo;
-    const WgradBand wb{g->B, g->mask_mode == 2 ? 0 : 1, g->mask_mode == 2 ? 0 : -top_,
-                       g->mask_mode == 1 ? 0 : 1, g->mask_mode == 1 ? g->Sq - 1 : -bot_};
+    const WgradBand wb{g->B, g->mask_mode == 2 ? 0 : 1, g->mask_mode == 2 ? 0 : -top,
+                       g->mask_mode == 1 ? 0 : 1, g->mask_mode == 1 ? g->Sq - 1 : -bot, band_only ? 1 : 0};
     isi_src sq;
     memset(&sq, 0, sizeof sq);
     sq.ptr = g->q; sq.C = HD; sq.sn = g->q_ss; sq.sc = 1; sq.sh = g->q_sb; sq.sw = g->q_sb;

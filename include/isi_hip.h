@@ -133,6 +133,10 @@ int isi_prof_read(int kernel_id, long long *launches, double *ms, double *flops,
  * isi_conv2d_f32 (encoder_decoder.py:95-112,138; vqvae.py:149-150,175-177). */
 int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin,
                              int KH, int KW, void *stream);
+/* isi_pack_conv_weight_f32 followed by isi_split_conv_weight_f16 at packed + isi_packed_conv_weight_floats(...), in one
+ * launch: the layout ISI_CONV_W16 / isi_vqvae_w.w16 expect (packed: twice the packed size, 16-byte aligned). */
+int isi_pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Cin,
+                                 int KH, int KW, void *stream);
 /* Packed weight of the INPUT-GRADIENT convolution of a stride-1 nn.Conv2d with weight w [Cout][Cin][KH][KW]
  * (autograd's conv backward-data behind train_vqvae.py:181): [Cin][KH*KW*Cout padded to 32] with the window rotated by
  * 180 degrees -- what isi_pack_conv_weight_f32 would make of w.flip(2, 3).transpose(0, 1), in one launch.  Run it

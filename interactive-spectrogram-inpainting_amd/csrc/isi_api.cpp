@@ -128,6 +128,9 @@ int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, i
                              void *stream) {
   return pack_conv_weight_f32(w, packed, Cout, Cin, KH, KW, S(stream));
 }
+int isi_pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, void *stream) {
+  return pack_conv_weight_w16_f32(w, packed, Cout, Cin, KH, KW, S(stream));
+}
 int isi_pack_linear_wT_bf16(const float *w, float *out, int N, int K, void *stream) {
   return pack_linear_wT_bf16(w, out, N, K, S(stream));
 }

@@ -184,6 +184,7 @@ int overlap_add_f32(const float *frames, float *audio, int B, int T, int n_fft, 
 
 size_t packed_conv_weight_floats(int Cout, int Cin, int KH, int KW);
 size_t packed_convT_k4s2_weight_floats(int Cin, int Cout);
+int pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, hipStream_t stream);
 int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
                          hipStream_t stream);
 int pack_linear_wT_bf16(const float *w, float *out, int N, int K, hipStream_t stream);

@@ -28,6 +28,37 @@ __global__ void pack_conv_kernel(const float *__restrict__ w, float *__restrict_
   out[i] = v;
 }
 
+// pack_conv_kernel and split_weight_f16_kernel in one launch: a thread forms eight consecutive elements of a packed row
+// (Kpad is a multiple of 32: a group never straddles rows), writes them and their split-f16 pair {hi[8] | lo[8]} behind
+// the packed weight (a training step re-packs every convolution weight: 29 launches less per step)
+__global__ void pack_conv_w16_kernel(const float *__restrict__ w, float *__restrict__ out, int Cout,
+                                     int Cin, int KH, int KW, int Kpad) {
+  const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)Cout * Kpad;
+  if (gi * 8 >= total) return;
+  const int co = (int)((gi * 8) / Kpad);
+  const int kb = (int)(gi * 8 - (int64_t)co * Kpad);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kb + j;
+    v[j] = 0.f;
+    if (k < KH * KW * Cin) {
+      const int tap = k / Cin, ci = k - tap * Cin;
+      const int kh = tap / KW, kw = tap - kh * KW;
+      v[j] = w[(((int64_t)co * Cin + ci) * KH + kh) * KW + kw];
+    }
+  }
+  const float4 a = make_float4(v[0], v[1], v[2], v[3]), b = make_float4(v[4], v[5], v[6], v[7]);
+  reinterpret_cast<float4 *>(out)[2 * gi] = a;
+  reinterpret_cast<float4 *>(out)[2 * gi + 1] = b;
+  uint4 hi, lo;
+  f16s::weight8_encode(a, b, hi, lo);
+  uint4 *pairs = reinterpret_cast<uint4 *>(out + total);
+  pairs[2 * gi] = hi;
+  pairs[2 * gi + 1] = lo;
+}
+
 // Packed weight of the INPUT-GRADIENT convolution of a stride-1 Conv2d with weight w [Cout][Cin][KH][KW]: the
 // convolution dY -> dX has Cin output channels, Cout input channels and the 180-degree rotated window:
 // out[ci][(kh, kw, co)] = w[co][ci][KH-1-kh][KW-1-kw]  (one launch instead of flip + transpose + contiguous + pack).
@@ -216,6 +247,16 @@ int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int K
   hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                      w, packed, Cout, Cin, KH, KW, Kpad);
   return check_launch("pack_conv_weight_f32");
+}
+
+int pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, hipStream_t stream) {
+  if (!w || !packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return invalid("pack_conv_weight_w16: bad argument");
+  if (reinterpret_cast<uintptr_t>(packed) & 15) return invalid("pack_conv_weight_w16: output must be 16-byte aligned");
+  const int Kpad = (int)round_up((size_t)KH * KW * Cin, kBK);
+  const int64_t groups = (int64_t)Cout * Kpad / 8;
+  hipLaunchKernelGGL(pack_conv_w16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, w, packed, Cout, Cin,
+                     KH, KW, Kpad);
+  return check_launch("pack_conv_weight_w16_f32");
 }
 
 int pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,

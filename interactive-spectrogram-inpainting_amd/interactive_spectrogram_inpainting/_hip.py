@@ -133,6 +133,7 @@ SIGNATURES = {
     "isi_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_double),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "isi_pack_conv_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_pack_conv_weight_w16_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_pack_conv_dgrad_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_pack_linear_wT_bf16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "isi_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -33,9 +33,13 @@ def pack_conv_weight(weight: torch.Tensor, with_f16: bool = False) -> torch.Tens
     cout, cin, kh, kw = w.shape
     n = _hip.lib().isi_packed_conv_weight_floats(cout, cin, kh, kw)
     out = torch.empty(2 * n if with_f16 else n, dtype=torch.float32, device=w.device)
+    if with_f16:      # packed weight and its pair copy in one launch
+        _hip.check(_hip.lib().isi_pack_conv_weight_w16_f32(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, _s(w)),
+                   "isi_pack_conv_weight_w16_f32")
+        return out
     _hip.check(_hip.lib().isi_pack_conv_weight_f32(w.data_ptr(), out.data_ptr(), cout, cin, kh, kw, _s(w)),
                "isi_pack_conv_weight_f32")
-    return _with_f16_copy(out, n) if with_f16 else out
+    return out
 
 
 def pack_conv_dgrad_weight(weight: torch.Tensor) -> torch.Tensor:

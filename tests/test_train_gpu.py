@@ -429,6 +429,11 @@ def test_input_gradient_weight_pack(shape):
     cout, cin, k = shape
     w = torch.randn(cout, cin, k, k, generator=torch.Generator().manual_seed(k + cout)).to(_dev())
     assert torch.equal(_ops.pack_conv_dgrad_weight(w), _ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous()))
+    # the packed weight with its split-f16 pair copy in one launch == the two launches it replaces
+    n = _ops.pack_conv_weight(w).numel()
+    fused = _ops.pack_conv_weight(w, with_f16=True)
+    two = _ops._with_f16_copy(torch.cat([_ops.pack_conv_weight(w), torch.empty(n, device=w.device)]), n)
+    assert torch.equal(fused[:n], two[:n]) and torch.equal(fused[n:].view(torch.int32), two[n:].view(torch.int32))
 
 
 @pytest.mark.parametrize("layer_kind", ["conv3 128->128 @32x128", "k4s2 64->128 @64x256", "convT 128->64 @32x128", "res3 128->32 @32x128"])

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import copy
 import math
+import os
 from typing import List, Optional, Tuple, Union
 
 import torch
@@ -69,9 +70,11 @@ class _LinearParams(nn.Module):
             self._packed_t, self._key_t = _ops.pack_linear_weight_t(self.weight), key
         return self._packed_t
 
-    def run(self, x, relu=False, residual=None):
+    def run(self, x, relu=False, residual=None, rectified_input=False, grad_pre_gated=False):
+        """`rectified_input` / `grad_pre_gated`: see _train.LinearFn (a feed-forward block's pair of layers)."""
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            return _train.LinearFn.apply(x, self.weight, self.bias, residual, relu, self.packed(), self.packed_t)
+            return _train.LinearFn.apply(x, self.weight, self.bias, residual, relu, self.packed(), self.packed_t,
+                                         rectified_input, grad_pre_gated)
         return _ops.linear(x, self.packed(), self.bias, self.out_features, relu=relu, residual=residual)
 
 
@@ -211,6 +214,11 @@ class RelativeMultiheadAttention(nn.Module):
 
 
 
+# ISI_FF_GATE=0: the feed-forward block's ReLU backward as its own mask pass (clone + kernel) instead of the gated epilogue
+# of linear2's input-gradient GEMM (A/B switch)
+_FF_GATE = os.environ.get("ISI_FF_GATE", "1") != "0"
+
+
 def _drop(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
     if layer.training and layer.dropout > 0:
         return nn.functional.dropout(x, layer.dropout, True)
@@ -218,12 +226,13 @@ def _drop(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
 
 
 def _add_norm(layer: nn.Module, lin: _LinearParams, x: torch.Tensor, residual: torch.Tensor,
-              norm: _LayerNormParams) -> torch.Tensor:
+              norm: _LayerNormParams, rectified_input: bool = False) -> torch.Tensor:
     """norm(residual + dropout(lin(x))): the residual add rides in the GEMM epilogue when nothing is
-    dropped, in the LayerNorm kernel otherwise."""
+    dropped, in the LayerNorm kernel otherwise.  `rectified_input`: x is a ReLU's output (_train.LinearFn)."""
     if layer.training and layer.dropout > 0:
-        return norm.run(nn.functional.dropout(lin.run(x), layer.dropout, True), residual=residual)
-    return norm.run(lin.run(x, residual=residual))
+        return norm.run(nn.functional.dropout(lin.run(x, rectified_input=rectified_input), layer.dropout, True),
+                        residual=residual)
+    return norm.run(lin.run(x, residual=residual, rectified_input=rectified_input))
 
 
 class TransformerEncoderLayerCustom(nn.Module):
@@ -242,8 +251,9 @@ class TransformerEncoderLayerCustom(nn.Module):
     def forward(self, src: torch.Tensor, src_mask: MaskArg = None) -> torch.Tensor:
         a = self.self_attn(src, None, src_mask)
         x = _add_norm(self, self.self_attn.out_proj, a, src, self.norm1)
-        h = _drop(self, self.linear1.run(x, relu=True))
-        return _add_norm(self, self.linear2, h, x, self.norm2)
+        # feed-forward block: linear2's input gradient is gated by h > 0 in its GEMM epilogue, linear1 skips its mask pass
+        h = _drop(self, self.linear1.run(x, relu=True, grad_pre_gated=_FF_GATE))
+        return _add_norm(self, self.linear2, h, x, self.norm2, rectified_input=_FF_GATE)
 
 
 class TransformerDecoderLayerCustom(nn.Module):
@@ -272,8 +282,8 @@ class TransformerDecoderLayerCustom(nn.Module):
         x = _add_norm(self, self.self_attn.out_proj, a, tgt, self.norm1)
         c = self.multihead_attn(x, memory, memory_mask, kv=memory_kv)
         x = _add_norm(self, self.multihead_attn.out_proj, c, x, self.norm2)
-        h = _drop(self, self.linear1.run(x, relu=True))
-        return _add_norm(self, self.linear2, h, x, self.norm3)
+        h = _drop(self, self.linear1.run(x, relu=True, grad_pre_gated=_FF_GATE))
+        return _add_norm(self, self.linear2, h, x, self.norm3, rectified_input=_FF_GATE)
 
 
 class TransformerAlignedDecoderLayerCustom(TransformerDecoderLayerCustom):

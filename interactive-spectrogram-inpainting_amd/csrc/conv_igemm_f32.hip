@@ -713,13 +713,18 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
     return conv_first_f32(s0, packed_w, bias, dst, B, H, W, Cout, OH, OW, e0, relu, stream);
   }
   // the prior's linear layers: rows of a dense matrix, three-term products -> the GEMM kernel (gemm_split_f32.hip)
-  if (!gate && nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 && pad == 0 && B == 1 && H == 1 && s0->sc == 1 &&
+  if (nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 && pad == 0 && B == 1 && H == 1 && s0->sc == 1 &&
       dst->sc == 1 && (!res || !res->ptr || res->sc == 1) && !(relu & (ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR | ISI_CONV_OUT_PAIR)) &&
       gemm_split_applicable(W, Cout, s0->C, split_mode(relu)) && aligned16(s0->ptr) && aligned16(packed_w) && s0->sw % 4 == 0 &&
-      !knobs().no_gemm_kernel)
+      !knobs().no_gemm_kernel) {
+    GemmExtra gx;
+    memset(&gx, 0, sizeof gx);
+    gx.nz = 1; gx.gate = gate; gx.ldg = dst->sw;          // (a gate is laid out like dst)
     return gemm_split_f32(s0->ptr, s0->sw, packed_w, bias, (res && res->ptr) ? res->ptr : nullptr, (res && res->ptr) ? res->sw : 0,
                           dst->ptr, dst->sw, W, Cout, s0->C, relu & 1, split_mode(relu), stream,
-                          (relu & ISI_CONV_W16) ? packed_w + (size_t)Cout * round_up((size_t)s0->C, kBK) : nullptr);
+                          (relu & ISI_CONV_W16) ? packed_w + (size_t)Cout * round_up((size_t)s0->C, kBK) : nullptr,
+                          gate ? &gx : nullptr);
+  }
   const int64_t zmax = std::max(std::max(zs_in0, zs_w), std::max(zs_res, zs_out));
   if (zmax < 0 || zmax >= ((int64_t)1 << 31)) return unsupported("conv2d: batch stride out of range");
   ConvKArgs a;

@@ -43,6 +43,9 @@ struct GemmArgs {
   int tail;               // rows [M, M + tail) beyond the tiled rows: fp32 dot products, spread over the workgroups
   int zs_a, zs_w, zs_res, zs_out;                          // element strides between the products of a batch (grid y)
   int win_rpu, lo_slope, lo_base, hi_slope, hi_base;       // GemmExtra's band of non-zero A columns (win_rpu = 0: none)
+  const float *gate;      // optional: out = gate[m ldg + n] > 0 ? v : 0
+  int ldg;
+  unsigned gate_bytes;
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -202,10 +205,20 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
       res[r] = 0.f;
       if (p.res) res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, ok ? (unsigned)(m * p.ldr + n) * 4u : OOB, 0, 0));
     }
+    float gt[16];
+    if (p.gate) {       // (requested with the residual: all of an epilogue's loads are in flight before its stores)
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gate), 0, p.gate_bytes, 0x00020000);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        gt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, oo[r] == OOB ? OOB : (unsigned)(m * p.ldg + n) * 4u, 0, 0));
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float v = (F16 ? acc[j][r] * f16s::kUnscale : acc[j][r]) + bias + res[r];
       if (p.relu) v = fmaxf(v, 0.f) + (v - v);      // (a NaN stays a NaN: an operand beyond the f16 range must be loud)
+      if (p.gate) v = gt[r] > 0.f ? v : 0.f;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro, oo[r], 0, 0);
     }
   }
@@ -235,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
         if (lane == 0) {
           float v = s + (p.bias ? p.bias[n] : 0.f) + (p.res ? p.res[m * p.ldr + n] : 0.f);
           if (p.relu) v = fmaxf(v, 0.f) + (v - v);
+          if (p.gate) v = p.gate[m * p.ldg + n] > 0.f ? v : 0.f;
           p.out[m * p.ldo + n] = v;
         }
       }
@@ -285,9 +299,15 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   g.w32 = w; g.tail = 0;
   g.zs_a = g.zs_w = g.zs_res = g.zs_out = 0;
   g.win_rpu = g.lo_slope = g.lo_base = g.hi_slope = g.hi_base = 0;
+  g.gate = nullptr; g.ldg = 0; g.gate_bytes = 4;
   int nz = 1;
   if (extra) {
     nz = extra->nz;
+    if (extra->gate) {
+      const int64_t eg = (int64_t)(M - 1) * extra->ldg + N;
+      if (nz != 1 || eg > lim || extra->ldg < N) return unsupported("gemm: a gate goes with a single product of less than 4 GiB");
+      g.gate = extra->gate; g.ldg = (int)extra->ldg; g.gate_bytes = (unsigned)(eg * 4);
+    }
     if (nz < 1 || nz > 65535) return invalid("gemm: bad batch count");
     const int64_t zmax = std::max(std::max(extra->zs_a, extra->zs_w), std::max(extra->zs_res, extra->zs_out));
     if (zmax >= ((int64_t)1 << 31) || (extra->zs_a | extra->zs_w | extra->zs_res | extra->zs_out) < 0)

@@ -116,11 +116,14 @@ bool gemm_split_applicable(int M, int N, int K, int split_mode);
 // Optional extras of gemm_split_f32: a batch of nz independent products (grid y; element strides between them) and a
 // band of the K range per 128-row tile -- rows [u win_rpu, (u + 1) win_rpu) only have non-zero A columns in
 // [lo_slope u + lo_base, hi_slope u + hi_base] (slopes >= 0), the K chunks outside the tile's band are skipped
-// (win_rpu = 0: no band).  The attention backward's dQ += G E^T uses both (rel_attention_bwd_f32.hip).
+// (win_rpu = 0: no band).  The attention backward's dQ += G E^T uses both (rel_attention_bwd_f32.hip); the gate is the
+// linear layers' (conv2d_f32 with a gate, 1x1).
 struct GemmExtra {
   int nz;
   int64_t zs_a, zs_w, zs_res, zs_out;
   int win_rpu, lo_slope, lo_base, hi_slope, hi_base;
+  const float *gate;      // optional (nz = 1): out = gate[m ldg + n] > 0 ? value : 0 (a ReLU's backward mask in the epilogue)
+  int64_t ldg;
 };
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
                    int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream,

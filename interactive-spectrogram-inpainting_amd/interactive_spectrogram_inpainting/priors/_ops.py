@@ -109,9 +109,10 @@ def pack_linear_weight_t(weight: torch.Tensor) -> torch.Tensor:
 
 def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], n_out: int,
            relu: bool = False, residual: Optional[torch.Tensor] = None,
-           precision: Optional[str] = None) -> torch.Tensor:
+           precision: Optional[str] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y[..., n_out] = x[..., K] W^T + b (+ residual): the implicit-GEMM convolution kernel with a
-    1x1 window (rows = "pixels"); `precision` overrides LINEAR_PRECISION."""
+    1x1 window (rows = "pixels"); `precision` overrides LINEAR_PRECISION.  `gate` ([..., n_out], contiguous):
+    y is zeroed where gate <= 0 (a ReLU's backward mask applied by the input-gradient GEMM's epilogue)."""
     _hip.require_gpu(x, "linear input")
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
@@ -132,6 +133,16 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
         res = _hip.isi_src(r2.data_ptr(), n_out, 0, 1, 0, r2.stride(0))
     w16 = 16 if ((prec == "f16x3" and getattr(packed_w, "isi_w16", False)) or
                  (prec == "bf16x3" and getattr(packed_w, "isi_w16_bf16", False))) else 0          # ISI_CONV_W16
+    if gate is not None:
+        g2 = gate.reshape(M, n_out)
+        if not g2.is_contiguous() or g2.dtype != torch.float32 or g2.device != x.device:
+            raise ValueError("linear: gate must be a contiguous fp32 tensor of the output's shape on the same device")
+        rc = _hip.lib().isi_conv2d_gated_f32(C.byref(s0), None, packed_w.data_ptr(),
+                                             bias.data_ptr() if bias is not None else None,
+                                             C.byref(res) if res is not None else None, g2.data_ptr(), C.byref(dst),
+                                             1, 1, M, n_out, 1, 1, 1, 0, int(relu) | _PREC_FLAG[prec] | w16, _s(x))
+        _hip.check(rc, "isi_conv2d_gated_f32 (linear)")
+        return out.reshape(*x.shape[:-1], n_out)
     rc = _hip.lib().isi_conv2d_f32(C.byref(s0), None, packed_w.data_ptr(),
                                    bias.data_ptr() if bias is not None else None,
                                    C.byref(res) if res is not None else None, C.byref(dst),

@@ -67,9 +67,15 @@ class LinearFn(torch.autograd.Function):
     """y[..., N] = x[..., K] W^T + b, optionally rectified, optionally + residual (added before the ReLU)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, relu: bool, packed, packed_t_fn):
+    def forward(ctx, x, weight, bias, residual, relu: bool, packed, packed_t_fn, rectified_input: bool = False,
+                grad_pre_gated: bool = False):
+        """`rectified_input`: x is the (possibly dropout-scaled) output of a ReLU -- the input gradient is then zeroed
+        where x <= 0 by the GEMM's epilogue, i.e. that ReLU's backward mask is applied HERE; the producing layer is
+        built with `grad_pre_gated` and skips its own mask pass (a clone and a three-pass kernel over [M, 2048] per
+        feed-forward block).  Where a unit was dropped x is 0 and the gradient is 0 either way."""
         y = _ops.linear(x, packed, bias, weight.shape[0], relu=relu, residual=residual)
         ctx.relu, ctx.packed_t_fn = relu, packed_t_fn
+        ctx.rectified_input, ctx.grad_pre_gated = rectified_input, grad_pre_gated
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
@@ -80,21 +86,22 @@ class LinearFn(torch.autograd.Function):
         x, weight, y = ctx.saved_tensors
         N, K = weight.shape
         dy2 = _rows(dy)
-        if ctx.relu:
+        if ctx.relu and not ctx.grad_pre_gated:
             if dy2.data_ptr() == dy.data_ptr():
                 dy2 = dy2.clone()
             _hip.check(_hip.lib().isi_relu_bwd_f32(dy2.data_ptr(), _rows(y).data_ptr(), dy2.numel(), _s(dy2)),
                        "isi_relu_bwd_f32")
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K, precision=_grad_precision()).reshape(x.shape)
+            gate = _rows(x) if ctx.rectified_input else None
+            dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K, precision=_grad_precision(), gate=gate).reshape(x.shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = linear_wgrad(_rows(x), dy2)
             if not ctx.has_bias:
                 db = None
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -151,15 +151,17 @@ class RelativeMultiheadAttention(nn.Module):
         self._packed_t, self._key_t = None, None
         self._range = _ops.WeightRange()
 
-    def _packs_t(self):
-        """W^T operands of the input gradients: (all three projections, q only, k|v)."""
+    def _pack_t(self, which: int):
+        """W^T operand of an input gradient: which = 0 all three projections, 1 q only, 2 k|v -- each packed when it is
+        first asked for (self-attention only ever uses 0, cross-attention 1 and 2: a launch per operand and step)."""
         key = (_hip.version_of(self.in_proj_weight), self.in_proj_weight.data_ptr())
         if self._key_t != key:
+            self._packed_t, self._key_t = [None, None, None], key
+        if self._packed_t[which] is None:
             d = self.d_model
             W = self.in_proj_weight.detach()
-            self._packed_t = tuple(_ops.pack_linear_weight_t(w) for w in (W, W[:d], W[d:]))
-            self._key_t = key
-        return self._packed_t
+            self._packed_t[which] = _ops.pack_linear_weight_t((W, W[:d], W[d:])[which])
+        return self._packed_t[which]
 
     def _project(self, x, which: int):
         """which: 0 = q|k|v, 1 = q, 2 = k|v of the fused in-projection."""
@@ -167,7 +169,7 @@ class RelativeMultiheadAttention(nn.Module):
         lo, hi = ((0, 3 * d), (0, d), (d, 3 * d))[which]
         W, b = self.in_proj_weight[lo:hi], self.in_proj_bias[lo:hi]
         if torch.is_grad_enabled() and (x.requires_grad or self.in_proj_weight.requires_grad):
-            return _train.LinearFn.apply(x, W, b, None, False, self._packs()[which], lambda: self._packs_t()[which])
+            return _train.LinearFn.apply(x, W, b, None, False, self._packs()[which], lambda: self._pack_t(which))
         return _ops.linear(x, self._packs()[which], b, hi - lo)
 
     def _packs(self):

@@ -359,8 +359,9 @@ typedef struct isi_attn_args {
   float *lse;   /* optional [B,H,Sq]: log-sum-exp of every query's logits (kept for the backward) */
   int precision; /* products of the three contractions: 0 = fp32 matrix pipe, 1 = three-term split-bf16
                   * (hi.hi + hi.lo + lo.hi on the bf16 pipe, fp32 accumulation; logits / softmax fp32),
-                  * 2 = single-term bf16 (operands rounded to bf16, fp32 accumulation / logits / softmax; the
-                  * backward of such a forward runs with three-term products) */
+                  * 2 = single-term bf16 (operands rounded to bf16, fp32 accumulation / logits / softmax),
+                  * 3 = single-term f16 (operands rounded to f16: 11 significand bits, |q k v e| < 65504; error
+                  * ~4e-4 of the output's maximum where mode 2 gives ~3e-3; its backward runs three-term products) */
 } isi_attn_args;
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream);
 

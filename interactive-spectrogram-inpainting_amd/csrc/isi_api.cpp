@@ -5,6 +5,7 @@
 
 #include "isi_internal.h"
 #include "knobs.h"
+#include "rel_attention.h"
 #include "prof.h"
 
 namespace isi {
@@ -37,6 +38,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_DECODE_NT", &Knobs::decode_nt, 1, false},
     {"ISI_PRIOR_GRAPH", &Knobs::prior_graph, 0, false},
     {"ISI_ATTN_FULL_ZERO", &Knobs::attn_full_zero, 0, false},
+    {"ISI_ATTN_OLD_FWD", &Knobs::attn_old_fwd, 0, false},
     {"ISI_CONV_ABLATE", &Knobs::conv_ablate, 0, true},
     {"ISI_VQ_DBG", &Knobs::vq_dbg, 0, true},
     {"ISI_RESPAIR_ABL", &Knobs::respair_abl, 0, true},
@@ -143,6 +145,7 @@ int isi_debug_convT_pair_stamps(long long *host, int n) { return convT_pair_debu
 int isi_debug_resblock_pair_stamps(long long *host, int n) { return resblock_pair_debug_stamps(host, n); }
 int isi_debug_vq_stamps(long long *host, int n) { return vq_debug_stamps(host, n); }
 int isi_debug_attention_stamps(long long *host, int n) { return rel_attention_debug_stamps(host, n); }
+int isi_debug_attention_fwd2_stamps(long long *host, int n) { return rel_attention_fwd2_debug_stamps(host, n); }
 int isi_pair_encode_f32(const float *x, float *pairs, int64_t n, void *stream) { return pair_encode_f32(x, pairs, n, S(stream)); }
 int isi_pair_decode_f32(const float *pairs, float *x, int64_t n, void *stream) { return pair_decode_f32(pairs, x, n, S(stream)); }
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream) {

@@ -24,6 +24,7 @@ struct Knobs {
   int respair_th, res_th, convt_th, convt_pair_th;   // forced tile heights (tests, measurement)
   int decode_nt;                // ISI_DECODE_NT: non-temporal weight loads in the batch-1 decode GEMVs (default 1)
   int attn_full_zero;           // ISI_ATTN_FULL_ZERO: the attention backward zeroes all of G, not only the margins of its band
+  int attn_old_fwd;             // ISI_ATTN_OLD_FWD: the round-3 forward kernel (32-key tiles) for the 16-bit modes (A/B switch)
   int prior_graph;              // ISI_PRIOR_GRAPH: replay the decode loop's positions as hipGraphs
   int conv_ablate, vq_dbg, respair_abl;   // ISI_MEASURE builds only
 };

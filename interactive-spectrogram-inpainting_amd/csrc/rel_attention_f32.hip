@@ -26,26 +26,16 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "prof.h"
 #include "split_bf16.h"
+#include "rel_attention.h"
 
 namespace isi {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-struct AttnKArgs {
-  const float *q, *k, *v, *e, *mask;
-  float *out, *lse;
-  unsigned q_bytes, k_bytes, v_bytes, e_bytes;
-  int Sq, Sk, H, B;
-  int nblk;       // query blocks the split kernels run (all, or only the full ones: the tail rows go to the one-row kernel)
-  int q_ss, q_sb, q_sh, k_ss, k_sb, k_sh, v_ss, v_sb, v_sh, o_ss, o_sb, o_sh;  // element strides
-  int Cq, Ck, Ek, R;
-  int mask_mode;  // 0 none, 1 causal (j <= i), 2 anti-causal (j >= i)
-  float scale;
-  int split;      // 1: three-term split-bf16 products (rel_attention_split_kernel), 2: single-term bf16
-};
 
 namespace {
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -898,7 +888,9 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   a.o_ss = (int)g->o_ss; a.o_sb = (int)g->o_sb; a.o_sh = (int)g->o_sh;
   a.Cq = g->Cq; a.Ck = g->Ck; a.Ek = g->Ek;
   a.mask_mode = g->mask_mode; a.scale = g->scale;
-  a.split = g->precision == 1 ? 1 : g->precision == 2 ? 2 : 0;   // 0 fp32 pipe | 1 three-term split-bf16 | 2 single-term bf16
+  if (g->precision < 0 || g->precision > 3) return invalid("rel_attention: precision must be 0 .. 3");
+  // 0 fp32 pipe | 1 three-term split-bf16 | 2 single-term bf16 | 3 single-term f16 (rel_attention_fwd2.hip only)
+  a.split = g->precision == 1 ? 1 : g->precision >= 2 ? 2 : 0;
   if (a.e && a.R <= 0) return invalid("rel_attention: rel_rows must be positive");
   // One or two rows beyond the last full query block (the prior's sequences are 1024 codes + a start row) would be a
   // block of their own that runs as long as a full one: 576 instead of 512 workgroups on 256 CUs -- a third round
@@ -908,6 +900,9 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   const bool split_tail = a.split && tail > 0;
   a.nblk = split_tail ? g->Sq / QB : (g->Sq + QB - 1) / QB;
   int rc;
+  if (a.split && (g->precision == 3 || !knobs().attn_old_fwd) && rel_attention_fwd2_ok(a, g->head_dim)) {
+    rc = rel_attention_fwd2(a, g->head_dim, g->precision, stream);
+  } else
   switch (g->head_dim) {
     case 16: rc = launch_attn<16>(a, g->B, stream); break;
     case 32: rc = launch_attn<32>(a, g->B, stream); break;

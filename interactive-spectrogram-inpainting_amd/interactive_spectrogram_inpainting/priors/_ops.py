@@ -37,9 +37,12 @@ LINEAR_GRAD_PRECISION = os.environ.get("ISI_LINEAR_GRAD_PRECISION", "bf16x3")
 # 'bf16' = single-term bf16 (operands rounded to 8 significand bits: north_star's "MFMA bf16" mode; measured error
 # in bench.py's attention leg and in tests/test_prior_gpu.py)
 ATTENTION_PRECISION = os.environ.get("ISI_ATTENTION_PRECISION", "bf16x3")
-_ATTN_PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}
+# 'f16' = single-term f16 (operands rounded to 11 significand bits: the same matrix rate as 'bf16' at an eighth of its
+# rounding error -- inside north_star's 1e-3; limited to f16's range, |q k v e| < 65504, like every f16 mixed-precision
+# attention; its backward runs the three-term kernels)
+_ATTN_PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16": 3}
 ATTENTION_PRECISIONS = tuple(_ATTN_PREC)                 # modes bench.py times
-ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1}    # 16-bit MFMA terms per product (0: fp32 matrix pipe)
+ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1, "f16": 1}    # 16-bit MFMA terms per product (0: fp32 matrix pipe)
 _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4, "f16x3": 8}
 _F16_WEIGHT_LIMIT = 63.98   # 65520 / 1024 and above rounds to inf in the f16 pieces
 

@@ -775,3 +775,82 @@ def test_rel_attention_bf16_mode(Sq, Sk, Cq, Ck, mode, monkeypatch):
     monkeypatch.setattr(_ops, "ATTENTION_PRECISION", "bf16x3")
     x3 = _ops.rel_attention(q.to(dev), k.to(dev), v.to(dev), rel.to(dev), H, Cq, Ck, Ek, mask_mode=mode)
     assert ((x3.cpu() - ref).abs().max() / ref.abs().max()).item() < err, "the three-term split must be more accurate"
+
+
+def _attention_spec(q, k, v, rel, H, Cq, Ck, Ek, mode):
+    """softmax((q k^T + skew(q e^T)) / sqrt(hd) + mask) v on the CPU (oracle/prior_oracle.py's index map)."""
+    from oracle import prior_oracle as P
+    Sq, B, d = q.shape
+    Sk, hd = k.shape[0], d // H
+    hq = q.reshape(Sq, B, H, hd).permute(1, 2, 0, 3)
+    hk = k.reshape(Sk, B, H, hd).permute(1, 2, 0, 3)
+    hv = v.reshape(Sk, B, H, hd).permute(1, 2, 0, 3)
+    logits = hq @ hk.transpose(-1, -2)
+    if rel is not None:
+        qe = torch.einsum("bhid,hrd->bhir", hq, rel)
+        logits = logits + qe.gather(3, P.rel_index(Sq, Sk, Cq, Ck, Ek).expand(B, H, Sq, Sk))
+    logits = logits / math.sqrt(hd)
+    if mode == 1:
+        logits += P.causal_mask(Sq)
+    elif mode == 2:
+        logits += P.causal_mask(Sq).t()
+    return (torch.softmax(logits, -1) @ hv).permute(2, 0, 1, 3).reshape(Sq, B, d)
+
+
+@pytest.mark.parametrize("Sq,Sk,Cq,Ck,mode", [(1025, 1025, 1, 1, 1), (4100, 1025, 4, 1, 0), (200, 200, 1, 1, 2), (77, 150, 2, 1, 0)])
+def test_rel_attention_f16_mode(Sq, Sk, Cq, Ck, mode, monkeypatch):
+    """precision = 'f16' (round 4): single-term products like 'bf16' -- a third of the three-term split's matrix work --
+    with operands rounded to f16's 11 significand bits: the error against the fp32 specification has to stay inside
+    north_star's 1e-3 of the output's maximum (the bf16 mode's 8 bits give ~3e-3) and below the bf16 mode's."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    hd, H, B = 64, 8, 1
+    d = hd * H
+    torch.manual_seed(Sq + mode)
+    Eq, Ek = -(-Sq // Cq), -(-Sk // Ck)
+    q, k, v = torch.randn(Sq, B, d), torch.randn(Sk, B, d), torch.randn(Sk, B, d)
+    rel = torch.randn(H, Eq + Ek - 1, hd) * 0.5
+    ref = _attention_spec(q, k, v, rel, H, Cq, Ck, Ek, mode)
+    dev = _dev()
+    errs = {}
+    for prec in ("f16", "bf16"):
+        monkeypatch.setattr(_ops, "ATTENTION_PRECISION", prec)
+        got = _ops.rel_attention(q.to(dev), k.to(dev), v.to(dev), rel.to(dev), H, Cq, Ck, Ek, mask_mode=mode)
+        assert torch.isfinite(got).all()
+        errs[prec] = ((got.cpu() - ref).abs().max() / ref.abs().max()).item()
+    assert errs["f16"] < 1e-3 and errs["f16"] < errs["bf16"], errs
+
+
+@pytest.mark.parametrize("hd,H,B,Sq,Sk,Cq,Ck,mode", [
+    (64, 8, 40, 300, 300, 1, 1, 1),     # 320 (batch, head) pairs > 256 CUs: one persistent workgroup walks a pair's three blocks
+    (32, 8, 33, 513, 513, 1, 1, 1),     # 264 pairs, five blocks incl. the one-row ragged block, three-term at 64-key tiles
+    (64, 3, 11, 1025, 1025, 1, 1, 2),   # 33 pairs x 9 blocks > 256: snake order, anti-causal (block 0 heaviest)
+    (64, 8, 5, 900, 640, 2, 2, 0),      # unmasked cross-attention, general channel layout, pairs not a multiple of 8
+    (16, 4, 9, 700, 700, 1, 1, 1),
+])
+@pytest.mark.parametrize("precision", ["bf16x3", "f16"])
+def test_rel_attention_persistent_blocks(hd, H, B, Sq, Sk, Cq, Ck, mode, precision, monkeypatch):
+    """rel_attention_fwd2.hip deals a (batch, head) pair's query blocks to fewer, persistent workgroups once the launch
+    would exceed one workgroup per CU (snake order over the blocks sorted by cost; the next block's first key step is
+    requested during the last step of the current one): against the exact-fp32 kernel, which runs one block per
+    workgroup, and against the round-3 kernel behind ISI_ATTN_OLD_FWD."""
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.priors import _ops
+    torch.manual_seed(Sq + B)
+    dev = _dev()
+    d = hd * H
+    Eq, Ek = -(-Sq // Cq), -(-Sk // Ck)
+    q, k, v = (torch.randn(s, B, d, device=dev) for s in (Sq, Sk, Sk))
+    rel = torch.randn(H, Eq + Ek - 1, hd, device=dev) * 0.5
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", "f32")
+    lse0 = torch.empty(B, H, Sq, device=dev)
+    ref = _ops.rel_attention(q, k, v, rel, H, Cq, Ck, Ek, mask_mode=mode, lse=lse0)
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", precision)
+    lse = torch.empty(B, H, Sq, device=dev)
+    got = _ops.rel_attention(q, k, v, rel, H, Cq, Ck, Ek, mask_mode=mode, lse=lse)
+    tol = 3e-5 if precision == "bf16x3" else 2.5e-3
+    _close(got, ref, tol, f"persistent blocks {precision}")
+    assert (lse - lse0).abs().max().item() < 30 * tol
+    if precision == "bf16x3":
+        with _hip.knob("ISI_ATTN_OLD_FWD", 1):
+            old = _ops.rel_attention(q, k, v, rel, H, Cq, Ck, Ek, mask_mode=mode)
+        _close(got, old, 3e-5, "64-key-tile kernel vs round-3 kernel")

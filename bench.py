@@ -125,31 +125,40 @@ def _host_cpu():
         return None, None, None
 
 
-def _cpu_baseline(sd, batch=16, warmup=2, iters=5):
-    """Oracle forward on the host cores: threads = the physical cores of one socket, 2 warm-up and 5
-    timed iterations on a bounded sample (batch 16 of the same tensor shape), median."""
+def _cpu_baseline(sd, x=None, id_t=None, id_b=None, batch=64, warmup=1, iters=3):
+    """Oracle forward on the host cores (B = 64): threads = the physical cores of one socket, 1 warm-up and
+    3 timed iterations on the bench batch's shape, median.  With the GPU's codes of the bench batch (`x`, `id_t`,
+    `id_b`) it also compares them with the oracle LEVEL BY LEVEL (bottom teacher-forced on the GPU's top codes) over
+    all samples and certifies every differing code as a near-tie of the reference's fp32 distance formula."""
     from oracle import vqvae_oracle as O
     cfg = O.Config(in_channel=2)
     model, per_socket, sockets = _host_cpu()
     before = torch.get_num_threads()
     cores = per_socket or before
     torch.set_num_threads(cores)
-    x = torch.randn(batch, 2, 128, 512, generator=torch.Generator().manual_seed(4))
+    xs = torch.randn(batch, 2, 128, 512, generator=torch.Generator().manual_seed(4)) if x is None else x[:batch]
+    batch = xs.shape[0]
     times = []
+    parity = None
     try:
         with torch.no_grad():
             for i in range(warmup + iters):
                 t0 = time.perf_counter()
-                O.forward(x, sd, cfg)
+                O.forward(xs, sd, cfg)
                 if i >= warmup:
                     times.append(time.perf_counter() - t0)
+            if x is not None and id_t is not None:
+                parity = O.teacher_forced_code_check(x, sd, cfg, id_t, id_b)
     finally:
         torch.set_num_threads(before)
     med = sorted(times)[len(times) // 2]
-    return {"value": round(batch / med, 3), "unit": "spectrograms/s", "cores": cores, "kind": "port",
-            "cpu_model": model, "sockets": sockets,
-            "sample": f"median of {iters} x VQVAE.forward on batch {batch} of [2,128,512] fp32 after {warmup} warm-up "
-                      f"iterations (oracle/vqvae_oracle.py, torch-CPU, {cores} threads = one socket's physical cores)"}
+    out = {"value": round(batch / med, 3), "unit": "spectrograms/s", "cores": cores, "kind": "port",
+           "cpu_model": model, "sockets": sockets,
+           "sample": f"median of {iters} x VQVAE.forward on batch {batch} of [2,128,512] fp32 after {warmup} warm-up "
+                     f"iteration(s) (oracle/vqvae_oracle.py, torch-CPU, {cores} threads = one socket's physical cores)"}
+    if parity is not None:
+        out["gpu_codes_vs_oracle"] = parity
+    return out
 
 
 def _prior_sampling(device):
@@ -284,36 +293,81 @@ def _timerange_change(device, vqvae, calls=3):
             "config": "layer 'top', mask = columns 8..23 of the [32,32] top map; bottom [64,64]; + decode_code"}
 
 
-def _prior_training(device, B=8, steps=3):
-    """BASELINE config 4 on one GPU: training step of the top prior (1024 tokens + start symbol, d_model 512,
-    6 + 8 layers, fp32, dropout 0.1, label smoothing, Adam): forward + loss + backward + optimizer step."""
+def _prior_training(device, dist=None, world=1, B=8, steps=3, warmup=2):
+    """BASELINE configs[3]: training step of the top prior (1024 tokens + start symbol, d_model 512, 6 + 8 layers, fp32,
+    dropout 0.1, label smoothing, Adam): forward + loss + backward + optimizer step, B codemaps PER GPU (weak scaling).
+    With world > 1 it runs on EVERY rank: one process per GPU, `GradBucketReducer` (utils/distributed.py) all-reduces
+    the flat gradient buffer bucket by bucket over RCCL while the backward is still running -- what replaces the
+    reference's nn.DataParallel (train_autoregressive_model.py:145,203-263).  Timed between barriers, slowest rank
+    counts."""
+    from interactive_spectrogram_inpainting.utils.distributed import GradBucketReducer
     from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss
-    m = _top_prior(device).train()
-    code = torch.randint(0, 512, (B, 32, 32), device=device)
-    mask = torch.rand(B, 32, 32, device=device) < 0.5
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    rank = dist.get_rank() if dist is not None else 0
+    m = _top_prior(device).train()                 # seeded: identical weights on every rank
+    g = torch.Generator().manual_seed(300 + rank)  # every rank its own shard of the synthetic codemaps
+    code = torch.randint(0, 512, (B, 32, 32), generator=g).to(device)
+    mask = (torch.rand(B, 32, 32, generator=g) < 0.5).to(device)
     cls = {"pitch": torch.full((B, 1), 24, device=device),
            "instrument_family_str": torch.zeros(B, 1, dtype=torch.long, device=device)}
-    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    reducer = GradBucketReducer(m.parameters()) if world > 1 else None
     opt = make_adam(m.parameters(), lr=3e-4)
     crit = LabelSmoothingLoss(512, 0.1, dim=1)
+    torch.manual_seed(400 + rank)                  # dropout masks differ per rank like the data
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        if reducer is not None:
+            reducer.zero()
+        else:
+            opt.zero_grad(set_to_none=True)
         src, tgt = m.to_sequences(code, condition=code, class_conditioning=cls, mask=mask)
         logits, _ = m(tgt, condition=src)
         loss = crit(m.to_time_frequency_map(logits, kind="target", permute_output_as_logits=True), code)
         loss.backward()
+        if reducer is not None:
+            reducer.finish()
         opt.step()
-    for _ in range(2):
+        return loss
+    for _ in range(warmup):
         step()
-    torch.cuda.synchronize(device)
+    barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
-    torch.cuda.synchronize(device)
-    dt = (time.perf_counter() - t0) / steps
-    return {"ms_per_step": round(dt * 1e3, 1), "tokens_per_s": round(B * 1024 / dt, 0), "codemaps_per_s": round(B / dt, 1),
-            "config": f"top prior [32,32], B={B} x 1025 tokens, d_model 512, 6+8 layers, 8 heads, fp32, Adam, 1 GPU"}
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    in_sync = True
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+        # every rank must hold the same weights after the averaged updates
+        ps = list(m.parameters())
+        chk = torch.stack([ps[0].detach().double().sum(), ps[len(ps) // 2].detach().double().sum(),
+                           ps[-1].detach().double().sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(((hi - lo).abs() <= 1e-6 * hi.abs().clamp(min=1e-12)).all())
+    assert torch.isfinite(loss).all()
+    dt /= steps
+    out = {"value": round(world * B * 1024 / dt, 0), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 1),
+           "tokens_per_s": round(world * B * 1024 / dt, 0), "codemaps_per_s": round(world * B / dt, 1),
+           "n_gpus": world, "steps": steps, "warmup": warmup, "global_batch": world * B, "scaling": "weak",
+           "ranks_in_sync": in_sync,
+           "collectives_per_step": (f"{len(reducer.buckets)} gradient buckets ({reducer.flat.numel() * 4 / 1e6:.1f} MB fp32 in "
+                                    f"total), all-reduced while the backward runs") if reducer is not None else "none (1 rank)",
+           "config": f"top prior [32,32], B={B}/GPU x 1025 tokens, d_model 512, 6+8 layers, 8 heads, fp32, Adam, "
+                     f"attention products {os.environ.get('ISI_ATTENTION_PRECISION', 'bf16x3')}"}
+    del m, opt, reducer
+    torch.cuda.empty_cache()
+    return out
 
 
 def _vqvae_training(device, dist, world, batch=64, steps=5, warmup=2):
@@ -473,6 +527,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prior", action="store_true", help="skip the secondary prior-sampling metric")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel VQ-VAE training leg")
+    ap.add_argument("--prior-batch", type=int, default=8, help="codemaps per GPU and step of the prior's training legs")
+    ap.add_argument("--prior-steps", type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -554,6 +610,12 @@ def main():
                 raise               # the others waiting in an all-reduce until the RCCL timeout: let torchrun tear down
             train_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- BASELINE configs[3] on every rank when N > 1: data-parallel training step of the top prior (collectives inside)
+    prior_dp_leg = None
+    if not args.no_prior and not args.no_train and world > 1:
+        prior_dp_leg = _prior_training(device, dist, world, B=args.prior_batch, steps=args.prior_steps,
+                                       warmup=min(2, args.prior_steps))      # a failing rank tears the job down, as above
+
     # ---- per-kernel HIP-event timing recorded inside the timed region
     kernels = []
     for kid in range(L.isi_prof_num_kernels()):
@@ -562,6 +624,17 @@ def main():
         if n.value:
             kernels.append({"kernel": L.isi_prof_kernel_name(kid).decode(), "launches": n.value,
                             "ms": ms.value, "flops": fl.value, "bytes": by.value})
+    # the forward's single dominant kernel has its own timer id; its launches also belong to the split-f16 convolution
+    # family, whose line (`roofline`) is kept comparable with the earlier rounds
+    single = next((k for k in kernels if k["kernel"].startswith("conv_pair_kernel<128, true, 0>")), None)
+    if single is not None:
+        fam = next((k for k in kernels if k["kernel"].startswith("conv_pair_kernel<..>")), None)
+        kernels.remove(single)
+        if fam is None:
+            kernels.append(dict(single, kernel="conv_pair_kernel<..> + convT_pair_kernel<..> + conv_igemm_f32_kernel<..,f16x3>"))
+        else:
+            for key in ("launches", "ms", "flops", "bytes"):
+                fam[key] += single[key]
     kernels.sort(key=lambda k: -k["ms"])
 
     if rank == 0:
@@ -609,6 +682,14 @@ def main():
                 "timed_launches": dom["launches"],
                 "share_of_step_time": round((dom["ms"] / timed_steps) / (dt * 1e3 / args.steps), 3),
                 "hbm_algorithmic_GBs": round(dom["bytes"] / (dom["ms"] * 1e-3) / 1e9, 1)}
+        if single is not None and single["launches"]:
+            s_ach = single["flops"] / (single["ms"] * 1e-3) / 1e12
+            roof["dominant_single_kernel"] = {
+                "kernel": single["kernel"], "achieved": round(s_ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                "frac": round(s_ach / peak, 4), "avg_launch_us": round(single["ms"] * 1e3 / single["launches"], 2),
+                "launches_per_step": single["launches"] // timed_steps,
+                "algorithmic_bytes_per_launch": round(single["bytes"] / single["launches"]),
+                "share_of_step_time": round((single["ms"] / timed_steps) / (dt * 1e3 / args.steps), 3)}
         # the whole forward against BOTH ceilings ("report achieved = max(bytes / (t BW_peak), flops / (t FLOP_peak))
         # and both terms"): algorithmic FLOPs / bytes summed over the timed kernels of one step
         tot_fl = sum(k["flops"] for k in kernels) / timed_steps
@@ -684,6 +765,8 @@ def main():
         line["alt_precision_single_gpu"] = alt
         if train_leg is not None:
             line["vqvae_training_single_gpu" if world == 1 else "vqvae_training_dp"] = train_leg
+        if prior_dp_leg is not None:
+            line["prior_training_dp"] = prior_dp_leg
         # secondary legs and the CPU baseline at N = 1 only: at N > 1 the other ranks wait in the final barrier
         def leg(name, fn):          # a secondary leg must not take the headline metric with it
             try:
@@ -701,9 +784,20 @@ def main():
                 except Exception as e:
                     line["prior_sampling"]["timerange_change"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
-            leg("prior_training_single_gpu", lambda: _prior_training(device))
+            leg("prior_training_single_gpu", lambda: _prior_training(device, B=args.prior_batch, steps=args.prior_steps))
         if not args.no_cpu_baseline and world == 1:
-            leg("cpu_baseline", lambda: _cpu_baseline(sd))
+            # the timed model's own codes of the bench batch go to the oracle (all samples, level by level)
+            with torch.no_grad():
+                chk = model(x)
+            leg("cpu_baseline", lambda: _cpu_baseline(sd, x.cpu(), chk[4].cpu(), chk[5].cpu(), batch=args.batch))
+            cb = line["cpu_baseline"]
+            if "gpu_codes_vs_oracle" in cb:     # north_star: bit-exact code indices (or certified near-ties of the reference's rounding)
+                g = cb.pop("gpu_codes_vs_oracle")
+                line["codes_moved_vs_oracle"] = {"top": g["top_moved"], "bottom_teacher_forced": g["bottom_moved_teacher_forced"],
+                                                 "of_top": g["of_top"], "of_bottom": g["of_bottom"], "mode": default_precision,
+                                                 "samples": g["samples"]}
+                line["certified_near_ties"] = g["certified_near_ties"]
+                line["codes_largest_normalised_gap"] = g["largest_normalised_gap"]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -766,7 +766,8 @@ int launch_pair(const PairK &a, int nphase, double flops, double bytes, hipStrea
   const int nitems = ((a.M + BM - 1) / BM) * (a.Cout / BN) * nphase;
   const int n_cu = current_device_cu_count();
   dim3 grid(nitems < n_cu ? nitems : n_cu);   // one 144-KiB workgroup per CU, persistent over the items
-  prof::Scope scope(prof::K_CONV_F16X3, flops, bytes, stream);
+  // the forward's single dominant kernel is timed under its own id (bench.py adds it back to the family's line)
+  prof::Scope scope(BN == 128 && OUTP && ABL == 0 ? prof::K_CONV_PAIR_128_PAIROUT : prof::K_CONV_F16X3, flops, bytes, stream);
   ISI_PROF_LAUNCH(scope, kern, grid, dim3(512), smem, stream, a);
   return check_launch("conv_pair_f16");
 }

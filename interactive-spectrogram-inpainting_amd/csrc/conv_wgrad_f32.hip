@@ -910,6 +910,12 @@ static int wgrad_nsplit(int Cout, int Kpad, int M, int nphase, int nz, bool spli
 static int wgrad_halo_nsplit(int units, int ntiles) {
   return std::max(1, std::min(256 / std::max(1, std::min(units, 256)), ntiles / 4));
 }
+// splits of the row-major linear_wgrad_kernel (Cout, K multiples of 128): ONE definition for the launch and for the
+// workspace sizer -- its count can exceed wgrad_nsplit's where (Cout/128)(K/128) lies in (384, 512)
+static int linear_wgrad_nsplit(int Cout, int K, int M) {
+  const int tiles = (Cout / 128) * (K / 128), nchunks = (M + 31) / 32;
+  return std::max(1, std::min(std::min(64, (512 + tiles - 1) / tiles), nchunks / 8));
+}
 size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, int nz) {
   const int Kpad = (int)round_up(K, kBK);
   // which kernel runs depends on the operands' layout: size for any of them (halo kernel: a workgroup covers at most
@@ -917,6 +923,7 @@ size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, i
   int nsplit = std::max(wgrad_nsplit(Cout, Kpad, M, nphase, nz, false), wgrad_nsplit(Cout, Kpad, M, nphase, nz, true));
   if (nphase == 1 && nz == 1 && Cout % 32 == 0 && K % 32 == 0)
     nsplit = std::max(nsplit, wgrad_halo_nsplit(((Cout / 32) * (K / 32) + 35) / 36, M / 16));
+  if (nphase == 1 && nz == 1 && Cout % 128 == 0 && K % 128 == 0) nsplit = std::max(nsplit, linear_wgrad_nsplit(Cout, K, M));
   return (size_t)nz * ((size_t)nsplit * nphase * Cout * Kpad + (size_t)nsplit * nphase * Cout);
 }
 size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
@@ -1065,8 +1072,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   // a linear layer's weight gradient (rows of a dense matrix): the row-major kernel
   if (use_split && !band_required && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 &&
       pad == 0 && B == 1 && H == 1 && Cout % 128 == 0 && Cin % 128 == 0 && !knobs().no_gemm_kernel) {
-    const int tiles = (Cout / 128) * (Cin / 128);
-    const int ns = std::max(1, std::min(std::min(64, (512 + tiles - 1) / tiles), nchunks / 8));
+    const int ns = linear_wgrad_nsplit(Cout, Cin, a.M);
     a.nsplit = ns; a.chunks_per_split = (nchunks + ns - 1) / ns;
     const size_t need_l = (size_t)ns * Cout * a.Kpad + (size_t)ns * Cout;
     if (workspace_floats < need_l) { set_last_error("conv_wgrad: workspace too small"); return ISI_E_WORKSPACE; }

@@ -37,6 +37,7 @@ const char *kernel_name(int id) {
     case K_REL_ATTENTION_BWD: return "rel_attention_bwd_{kv,q}_kernel";
     case K_CONV_BF16X6: return "conv_igemm_f32_kernel<..,bf16x6>";
     case K_CONV_F16X3: return "conv_pair_kernel<..> + convT_pair_kernel<..> + conv_igemm_f32_kernel<..,f16x3>";
+    case K_CONV_PAIR_128_PAIROUT: return "conv_pair_kernel<128, true, 0> (f16x3)";
     default: return "?";
   }
 }

@@ -21,6 +21,7 @@ enum KernelId {
   K_REL_ATTENTION_BWD,
   K_CONV_BF16X6,
   K_CONV_F16X3,
+  K_CONV_PAIR_128_PAIROUT,   // conv_pair_kernel<128, true, 0> alone (also part of the K_CONV_F16X3 family in bench.py)
   K_COUNT
 };
 

@@ -461,3 +461,59 @@ def near_tie_free_vectors(embed: Tensor, n: int, seed: int, scale: float = 1.0, 
     out = pool[keep][:n]
     assert out.shape[0] == n
     return out.contiguous()
+
+
+def near_tie_gaps(z_vecs: Tensor, embed: Tensor, got: Tensor, ref: Tensor) -> Tensor:
+    """For every position where `got` differs from `ref`: the float64 distance gap between the two candidate codes,
+    normalised by the magnitude of the terms the reference's fp32 formula |z|^2 - 2 z.e + |e|^2 cancels
+    (bottleneck.py:56-60 evaluates the distance with absolute error ~ulp(|z|^2)).  Empty when nothing differs."""
+    bad = (got != ref).reshape(-1).nonzero().reshape(-1)
+    if bad.numel() == 0:
+        return torch.zeros(0, dtype=torch.float64)
+    flat = z_vecs.reshape(-1, z_vecs.shape[-1]).double()[bad]
+    e = embed.double()
+    x2 = flat.pow(2).sum(1, keepdim=True)
+    d = x2 - 2 * flat @ e + e.pow(2).sum(0, keepdim=True)
+    dg = d.gather(1, got.reshape(-1)[bad].unsqueeze(1))
+    dr = d.gather(1, ref.reshape(-1)[bad].unsqueeze(1))
+    scale = x2 + e.pow(2).sum(0)[ref.reshape(-1)[bad]].unsqueeze(1)
+    return ((dg - dr).abs() / scale).reshape(-1)
+
+
+def teacher_forced_code_check(x: Tensor, sd: StateDict, cfg: Config, id_t: Tensor, id_b: Tensor, eps: float = 2e-6,
+                              chunk: int = 16) -> Dict[str, object]:
+    """Codes of another implementation (`id_t`, `id_b` for the batch `x`) against this oracle, level by level, so
+    that a moved near-tie at the top never hides the bottom level behind it (tests/test_hip_parity.py):
+      top     z_t of the oracle from x                          -> indices that differ from the oracle's arg-min
+      bottom  z_b of the oracle from the GIVEN id_t (embed_code -> dec_t -> cat(enc_b) -> 1x1 convolution)
+    Every differing index is then checked to be a NEAR-TIE of the reference's own fp32 distance formula (normalised
+    float64 gap < eps, `near_tie_gaps`).  Returns counts, the largest gap and `certified` (all gaps < eps)."""
+    fb, ft = cfg.resolution_factors["bottom"], cfg.resolution_factors["top"]
+    moved = {"top": 0, "bottom": 0}
+    worst = 0.0
+    n_t = n_b = 0
+    for s0 in range(0, x.shape[0], chunk):
+        xs, gt, gb = x[s0:s0 + chunk], id_t[s0:s0 + chunk], id_b[s0:s0 + chunk]
+        enc_b = encoder(xs, sd, "enc_b.", fb, cfg.n_res_block)
+        enc_t = encoder(enc_b, sd, "enc_t.", ft, cfg.n_res_block)
+        z_t = F.conv2d(enc_t, sd["quantize_conv_t.weight"], sd["quantize_conv_t.bias"]).permute(0, 2, 3, 1)
+        ref_t = quantize(z_t, sd["quantize_t.embed"])[2]
+        g = near_tie_gaps(z_t, sd["quantize_t.embed"], gt, ref_t)
+        moved["top"] += g.numel()
+        q_t = embed_code(gt, sd["quantize_t.embed"]).permute(0, 3, 1, 2)
+        dec_t = decoder(q_t, sd, "dec_t.", ft, cfg.n_res_block)
+        if cfg.adapt_quantized_durations:
+            w = min(dec_t.shape[-1], enc_b.shape[-1])
+            dec_t, enc_b = dec_t[..., :w], enc_b[..., :w]
+        z_b = F.conv2d(torch.cat([dec_t, enc_b], 1), sd["quantize_conv_b.weight"], sd["quantize_conv_b.bias"]).permute(0, 2, 3, 1)
+        ref_b = quantize(z_b, sd["quantize_b.embed"])[2]
+        g2 = near_tie_gaps(z_b, sd["quantize_b.embed"], gb, ref_b)
+        moved["bottom"] += g2.numel()
+        for t in (g, g2):
+            if t.numel():
+                worst = max(worst, float(t.max()))
+        n_t += ref_t.numel()
+        n_b += ref_b.numel()
+    return {"top_moved": moved["top"], "of_top": n_t, "bottom_moved_teacher_forced": moved["bottom"], "of_bottom": n_b,
+            "largest_normalised_gap": worst, "near_tie_threshold": eps, "certified_near_ties": bool(worst < eps),
+            "samples": int(x.shape[0])}

@@ -535,7 +535,10 @@ def test_linear_gemm_kernel_equals_implicit_gemm(shape, precision):
             assert pw16.isi_w16 and torch.equal(_ops.linear(x, pw16, b, N, relu=relu, residual=r, precision=precision), got)
 
 
-@pytest.mark.parametrize("shape", [(8200, 512, 512), (1030, 1536, 512), (4100, 512, 2048), (300, 128, 128)])
+@pytest.mark.parametrize("shape", [(8200, 512, 512), (1030, 1536, 512), (4100, 512, 2048), (300, 128, 128),
+                                   # (N/128)(K/128) = 400 tiles in (384, 512): the row-major kernel wants 2 splits where the
+                                   # generic count is 1 -- the workspace sizer has to know
+                                   (520, 2560, 2560)])
 def test_linear_weight_gradient_kernel(shape):
     """`linear_wgrad_kernel` (row-major operands in LDS, transposing fragment reads, two-stage ring) against the
     per-tap kernel it replaces and fp64: dW = dY^T X and db = column sums of dY, ragged last row chunk included."""

@@ -279,8 +279,9 @@ def test_unquantized_vqvae_against_reference(golden_dir):
 def test_bench_two_ranks_dry_run():
     """bench.py's multi-rank path end to end, two ranks sharing this box's GPU with gloo collectives
     (ISI_BENCH_BACKEND=gloo: a functional dry run -- the measured configuration is one rank per GPU over RCCL): the
-    forward line aggregates both ranks, the data-parallel training leg runs on every rank (bucketed gradient
-    all-reduce + EMA-statistics all-reduce) and leaves the ranks with identical weights and codebooks."""
+    forward line aggregates both ranks, the data-parallel training legs run on every rank -- VQ-VAE (bucketed gradient
+    all-reduce + EMA-statistics all-reduce) and the top prior (GradBucketReducer, BASELINE configs[3]) -- and leave the
+    ranks with identical weights and codebooks."""
     import json
     import os
     import pathlib
@@ -290,14 +291,18 @@ def test_bench_two_ranks_dry_run():
     env = dict(os.environ, ISI_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
-           "--spinup-ms", "10", "--no-prior", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=str(root))
+           "--spinup-ms", "10", "--prior-batch", "1", "--prior-steps", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["batch_per_gpu"] == 4
     dp = line["vqvae_training_dp"]
     assert "error" not in dp, dp
     assert dp["n_gpus"] == 2 and dp["global_batch"] == 8 and dp["ranks_in_sync"] is True
+    pdp = line["prior_training_dp"]
+    assert "error" not in pdp, pdp
+    assert pdp["n_gpus"] == 2 and pdp["global_batch"] == 2 and pdp["ranks_in_sync"] is True and pdp["value"] > 0
+    assert pdp["collectives_per_step"].startswith(tuple("123456789"))
 
 
 @pytest.mark.parametrize("shape", [

@@ -190,7 +190,7 @@ def _prior_sampling(device):
             ts.append(time.perf_counter() - t0)
         return sorted(ts)[1]
 
-    for B in (1, 8):
+    for B in (1, 8, 32):
         dt = run(B, top_p_sampling_p=0.8)                  # Inference.ipynb cell 43 samples with top-p 0.8
         out[f"codes_per_s_B{B}"] = round(B * 1024 / dt, 1)
         out[f"ms_per_codemap_B{B}"] = round(dt * 1e3, 1)

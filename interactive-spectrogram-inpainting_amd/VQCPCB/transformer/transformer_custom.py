@@ -101,7 +101,9 @@ def _classify_mask(mask: MaskArg, Sq: int, Sk: int, device) -> Tuple[int, Option
     m = mask.detach()
     if m.shape != (Sq, Sk):
         raise RuntimeError(f"attention mask of shape {tuple(m.shape)} for a {Sq}x{Sk} score matrix")
-    key = (m.data_ptr(), _hip.version_of(m), tuple(m.shape), m.device)
+    # masks are never touched by an optimizer: the tensor's own version counter is the whole key (the global
+    # optimizer-step count of _hip.version_of would miss after every step: a host sync and a D2H copy each time)
+    key = (m.data_ptr(), m._version, tuple(m.shape), m.device)
     hit = _classify_mask.cache.get(key)
     if hit is None:
         allowed = (m.cpu() == 0)

@@ -32,12 +32,22 @@ class IncrementalDecoder:
         self.memory_kv: List[torch.Tensor] = [l.multihead_attn.project_kv(memory) for l in self.layers]
         self.cache: List[torch.Tensor] = [
             torch.zeros(S_t, batch_size, 2 * d, dtype=torch.float32, device=memory.device) for _ in self.layers]
-        self._lin = _ops.linear_rows if batch_size <= 8 else None
+        if batch_size > 32:
+            raise NotImplementedError("incremental decoding supports batch sizes up to 32 (NativeSampler: 256)")
 
     def _linear(self, x, weight, bias, relu=False, residual=None, out=None):
-        if self._lin is not None:
-            return self._lin(x, weight, bias, relu=relu, residual=residual, out=out)
-        raise NotImplementedError("incremental decoding supports batch sizes up to 8")
+        """Row GEMV of up to 8 rows per launch (`isi_linear_rows_f32`); larger batches go in groups of 8 rows -- a row's
+        result does not depend on the rows it shares a launch with."""
+        M = x.shape[0]
+        if M <= 8:
+            return _ops.linear_rows(x, weight, bias, relu=relu, residual=residual, out=out)
+        if out is None:
+            out = torch.empty(M, weight.shape[0], dtype=torch.float32, device=x.device)
+        for lo in range(0, M, 8):
+            hi = min(M, lo + 8)
+            _ops.linear_rows(x[lo:hi], weight, bias, relu=relu, residual=residual[lo:hi] if residual is not None else None,
+                             out=out[lo:hi])
+        return out
 
     @torch.no_grad()
     def step(self, p: int, x: torch.Tensor) -> torch.Tensor:

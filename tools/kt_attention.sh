@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/kt_attn; mkdir -p $O
+rocprofv3 --kernel-trace -d $O/kt -o a -- python3 tools/bench_attention.py --modes 1 --precisions bf16x3 > $O/log.txt 2>&1
+python tools/prof_summary.py $O/kt/a_results.db 14 > gpurun_out/kt_attn_bwd.txt 2>&1
+rm -rf $O
+cat gpurun_out/kt_attn_bwd.txt

@@ -362,6 +362,12 @@ typedef struct isi_attn_args {
                   * 2 = single-term bf16 (operands rounded to bf16, fp32 accumulation / logits / softmax),
                   * 3 = single-term f16 (operands rounded to f16: 11 significand bits, |q k v e| < 65504; error
                   * ~4e-4 of the output's maximum where mode 2 gives ~3e-3; its backward runs three-term products) */
+  float *logits; /* optional [B,H,Sq,logits_ld] (16-bit modes only, precision >= 1): the forward stores the logit of every
+                  * (query, key) pair the mask allows -- (q.k + q.e[r]) * scale * log2(e) + mask * log2(e), i.e. in units
+                  * of exp2 -- and isi_rel_attention_bwd_f32, handed the same buffer, reads them instead of forming
+                  * Q K^T, the band product Q E^T and its skew a second and a third time (60 % of the backward's time at
+                  * S = 1025).  Entries of masked pairs are never read.  NULL: nothing is stored / everything is recomputed */
+  int64_t logits_ld; /* row stride of `logits` in floats: a multiple of 4, >= Sk rounded up to a multiple of 32 */
 } isi_attn_args;
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream);
 

@@ -16,6 +16,8 @@ struct AttnKArgs {
   int mask_mode;  // 0 none, 1 causal (j <= i), 2 anti-causal (j >= i)
   float scale;
   int split;      // 1: three-term split-bf16 products (rel_attention_split_kernel), 2: single-term bf16
+  float *logits;  // optional [B,H,Sq,ldl]: base-2 logits of the allowed pairs, kept for the backward (rel_attention_fwd2.hip)
+  int ldl;
 };
 
 // rel_attention_fwd2.hip.  precision: 1 three-term split-bf16, 2 single-term bf16, 3 single-term f16.  Returns

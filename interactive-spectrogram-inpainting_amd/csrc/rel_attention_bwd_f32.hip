@@ -49,6 +49,8 @@ struct AttnBwdKArgs {
   int g_band_only;        // G is zeroed only around its band: EVERY (query, key) pair the mask allows is stored (zeros too)
   int mask_mode;
   float scale;
+  const float *logits;    // optional [B,H,Sq,ldl]: the forward's base-2 logits of the allowed pairs (isi_attn_args.logits):
+  int ldl;                // the split kernels read them instead of forming Q K^T and the skewed band product again
 };
 
 namespace {
@@ -585,7 +587,7 @@ __device__ __forceinline__ int ring_s(int r) {
 // ------------------------------------------------------------------ dQ and G (split)
 // ONE = true (precision 2): single-term bf16 products -- the lo.hi and hi.lo MFMAs of every product are left out
 // (north_star's "MFMA bf16" mode; the lo planes are still staged: the kernels are not bound by them)
-template <int HD, bool ONE = false>
+template <int HD, bool ONE = false, bool SAVED = false>
 __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const AttnBwdKArgs p) {
   constexpr int NKB = HD / 16, NSL = HD / 8, RPB = 128 / HD, NDB = (HD + 31) / 32, VR = NDB * 32;
   constexpr int NQD = HD / 4, NKQ = (HD / 4 + 7) / 8;
@@ -613,6 +615,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   const int q_end = (rag && qblk == 0) ? rag : p.Sq;           // first row beyond this block's valid ones
   const int qw0 = q0 + 32 * wq, qi = qw0 + ql;
   const bool has_e = p.e != nullptr;
+  constexpr bool saved = SAVED;                // logits kept by the forward (p.logits): no Q K^T, no band product, no skew here
+  const bool band = has_e && !saved;           // the band of e is staged only when the relative logits are recomputed
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
@@ -674,11 +678,13 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
       pb[j] = kind == 0 ? buf_load4(rk, ok ? ko : OOB) : buf_load4(rv, ok ? vo : OOB);
     }
     const int r = band0(k0 + 32) + 32 * st + srow;
-    const bool rok = has_e && r >= 0 && r < p.R;
+    const bool rok = band && r >= 0 && r < p.R;
+    if constexpr (!saved) {
 #pragma unroll
-    for (int i = 0; i < NKQ; ++i) {
-      const int qd = squad + 8 * i;
-      pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      for (int i = 0; i < NKQ; ++i) {
+        const int qd = squad + 8 * i;
+        pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      }
     }
   };
   auto put_e = [&](int slot, int qd, const float4 v) {
@@ -691,6 +697,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   auto commit = [&](int k0) {
     if (blk_on) {
       unsigned short *rows = (kind == 0 ? Kp : Vp) + (btile * 2) * 32 * HD;
+      if (!(saved && kind == 0))      // (K rows feed Q K^T only)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {   // row planes: 8 bytes (4 dims) per key
         const int row = 4 * bkg + j;
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         }
       }
     }
-    if (has_e) {
+    if (band) {
       const int slot = ring_s(band0(k0 + 32) + 32 * st + srow);
 #pragma unroll
       for (int i = 0; i < NKQ; ++i)
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   if (k_begin < k_end) {
     prefetch(k_begin);
     commit(k_begin);
-    if (has_e) {
+    if (band) {
       const int rb = band0(k_begin + 32);
       for (int row = 64 + (tid >> 3); row < BAND2_S; row += 64) {
         const int r = rb + row;
@@ -762,8 +769,18 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
     if (p.mask_mode == 1) live = live && k0 <= qw0 + 31;
     if (p.mask_mode == 2) live = live && k0 + 31 >= qw0;
     if (live) {  // wave-uniform
-      // ---- S^T = K Q^T
       f32x16 acc;
+      float sv[16];
+      if (saved) {
+        // ---- the forward's logits of this lane's query: keys 8 g + 4 half + 0..3 of the tile (already in units of exp2)
+        const float *lrow = p.logits + (((size_t)b * p.H + h) * p.Sq + min(qi, p.Sq - 1)) * p.ldl + k0 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = *reinterpret_cast<const float4 *>(lrow + 8 * g);
+          sv[4 * g] = v.x; sv[4 * g + 1] = v.y; sv[4 * g + 2] = v.z; sv[4 * g + 3] = v.w;
+        }
+      } else {
+      // ---- S^T = K Q^T
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -775,7 +792,6 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         if constexpr (!ONE) acc = ISI_MFB(kh, qlo[t], acc);
         acc = ISI_MFB(kh, qh[t], acc);
       }
-      float sv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = acc[r];
 
@@ -809,13 +825,15 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         }
       }
 
+      }
       // ---- P
       bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < q_end;
       if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
       if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
+      const float sc2 = saved ? 1.f : scale2;
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(sv[r] * scale2 - lse2);
+        for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(sv[r] * sc2 - lse2);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -823,8 +841,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
           bool ok = kj < p.Sk && qi < q_end;
           if (p.mask_mode == 1) ok = ok && kj <= qi;
           if (p.mask_mode == 2) ok = ok && kj >= qi;
-          float s = sv[r] * scale2;
-          if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          float s = sv[r] * sc2;
+          if (p.mask && ok && !saved) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;     // (kept logits include the mask)
           sv[r] = ok ? __builtin_amdgcn_exp2f(s - lse2) : 0.f;
         }
       }
@@ -865,8 +883,19 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         }
       }
 
-      // ---- G[i, r(i,j)] += dS[i,j]: transpose through LDS so that lanes run along the keys of one query
-      if (has_e) {
+      // ---- G[i, r(i,j)] += dS[i,j]
+      if (has_e && unique_rho && full) {
+        // one channel per event on both sides and every pair of the tile allowed: the lane's 16 keys of its query are 4 runs
+        // of 4 consecutive table rows (descending) of the query's own row of G -- four 16-byte stores (4-byte aligned),
+        // no transpose through LDS, no per-element address arithmetic
+        typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+        float *grow = gbase + (size_t)qi * gstride + (qi - k0 - 4 * half + p.Ek - 1 - p.rho_lo);   // column of key k0 + 4 half
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4_u v = {sv[4 * g + 3], sv[4 * g + 2], sv[4 * g + 1], sv[4 * g]};
+          *reinterpret_cast<f32x4_u *>(grow - 8 * g - 3) = v;
+        }
+      } else if (has_e) {   // transpose through LDS so that lanes run along the keys of one query
 #pragma unroll
         for (int r = 0; r < 16; ++r) tb[mfma_row(r, half) * SRL + ql] = sv[r];
         wave_lds_sync();
@@ -932,7 +961,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
 // two partial results are added at the end.  Q and dO tiles are staged as row planes (S = Q K^T,
 // dP = dO V^T, U = Q E^T contract over the head dim) AND transposed planes (dV^T += dO^T P,
 // dK^T += Q^T dS contract over the queries).
-template <int HD, bool ONE = false>
+template <int HD, bool ONE = false, bool SAVED = false>
 __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const AttnBwdKArgs p) {
   constexpr int NKB = HD / 16, NSL = HD / 8, RPB = 128 / HD, NDB = (HD + 31) / 32, VR = NDB * 32;
   constexpr int NQD = HD / 4, NKQ = (HD / 4 + 7) / 8;
@@ -965,6 +994,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   const int k_lim = (rag && kblk == 0) ? rag : p.Sk;            // first key beyond this block's valid ones
   const int kw0 = k0b + 32 * wq, kj = kw0 + ql;
   const bool has_e = p.e != nullptr;
+  constexpr bool saved = SAVED;                // logits kept by the forward (p.logits): no Q K^T, no band product, no skew here
+  const bool band = has_e && !saved;
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
@@ -1029,11 +1060,13 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
       pb[j] = kind == 0 ? buf_load4(rq, ok ? qo : OOB) : buf_load4(rdo, ok ? go : OOB);
     }
     const int r = band0(q0) + (BAND2_S - 64) + 32 * st + srow;
-    const bool rok = has_e && r >= 0 && r < p.R;
+    const bool rok = band && r >= 0 && r < p.R;
+    if constexpr (!saved) {
 #pragma unroll
-    for (int i = 0; i < NKQ; ++i) {
-      const int qd = squad + 8 * i;
-      pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      for (int i = 0; i < NKQ; ++i) {
+        const int qd = squad + 8 * i;
+        pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
+      }
     }
     if (tid < 64) {
       const int q = q0 + tid;
@@ -1053,6 +1086,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     if (blk_on) {
       unsigned short *rows = (kind == 0 ? Qp : Gp) + (btile * 2) * 32 * HD;
       unsigned short *cols = (kind == 0 ? Qtp : Gtp) + (btile * 2) * VR * 32;
+      if (!(saved && kind == 0))      // (Q rows feed Q K^T and the band product only)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = 4 * bkg + j;
@@ -1073,7 +1107,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         *reinterpret_cast<uint2 *>(cols + o + VR * 32) = lo;
       }
     }
-    if (has_e) {
+    if (band) {
       const int slot = ring_s(band0(q0) + (BAND2_S - 64) + 32 * st + srow);
 #pragma unroll
       for (int i = 0; i < NKQ; ++i)
@@ -1098,7 +1132,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   if (q_begin < q_end) {
     prefetch(q_begin);
     commit(q_begin);
-    if (has_e) {
+    if (band) {
       const int rb = band0(q_begin);
       const int squad = tid & 7;
       for (int row = tid >> 3; row < BAND2_S - 64; row += 64) {
@@ -1136,8 +1170,15 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       const int ql = lane_o & 31, half = lane_o >> 5;
-      // ---- S = Q K^T  (rows = queries, this lane's column = its key)
       f32x16 acc;
+      float sv[16];
+      if (saved) {
+        // ---- the forward's logits: this lane's key, the 16 query rows of its accumulator registers (units of exp2)
+        const float *lcol = p.logits + ((size_t)b * p.H + h) * p.Sq * p.ldl + min(kj, p.ldl - 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sv[r] = lcol[(size_t)min(q0 + mfma_row(r, half), p.Sq - 1) * p.ldl];
+      } else {
+      // ---- S = Q K^T  (rows = queries, this lane's column = its key)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -1149,7 +1190,6 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         if constexpr (!ONE) acc = ISI_MFB(qfh, kl[t], acc);
         acc = ISI_MFB(qfh, kh[t], acc);
       }
-      float sv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = acc[r];
 
@@ -1185,13 +1225,15 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         }
       }
 
+      }
       // ---- P
       bool full = !p.mask && kw0 + 31 < k_lim && q0 + 31 < p.Sq;
       if (p.mask_mode == 1) full = full && kw0 + 31 <= q0;
       if (p.mask_mode == 2) full = full && kw0 >= q0 + 31;
+      const float sc2 = saved ? 1.f : scale2;
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(sv[r] * scale2 - lseb[mfma_row(r, half)]);
+        for (int r = 0; r < 16; ++r) sv[r] = __builtin_amdgcn_exp2f(sv[r] * sc2 - lseb[mfma_row(r, half)]);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1200,8 +1242,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
           bool ok = kj < k_lim && qi < p.Sq;
           if (p.mask_mode == 1) ok = ok && kj <= qi;
           if (p.mask_mode == 2) ok = ok && kj >= qi;
-          float s = sv[r] * scale2;
-          if (p.mask && ok) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
+          float s = sv[r] * sc2;
+          if (p.mask && ok && !saved) s += p.mask[(size_t)qi * p.Sk + kj] * LOG2E;
           sv[r] = ok ? __builtin_amdgcn_exp2f(s - lseb[qrow]) : 0.f;
         }
       }
@@ -1538,10 +1580,13 @@ size_t rel_attention_bwd_workspace_floats(const isi_attn_args *g) {
   return bwd_layout(g->B, g->H, g->Sq, n, g->head_dim).total;
 }
 
-template <int HD, bool ONE>
+template <int HD, bool ONE, bool SAVED = false>
 static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
-  auto kq = rel_attention_bwd_q_split_kernel<HD, ONE>;
-  auto kkv = rel_attention_bwd_kv_split_kernel<HD, ONE>;
+  if constexpr (!SAVED) {
+    if (a.logits) return launch_bwd_split<HD, ONE, true>(a, stream);
+  }
+  auto kq = rel_attention_bwd_q_split_kernel<HD, ONE, SAVED>;
+  auto kkv = rel_attention_bwd_kv_split_kernel<HD, ONE, SAVED>;
   constexpr int VR = ((HD + 31) / 32) * 32;
   constexpr size_t smem_q = (size_t)(2 * (2 * 2 * 32 * HD) + 2 * 2 * VR * 32 + 2 * RING_S * HD) * sizeof(unsigned short) +
                             (size_t)(8 * 32 * SRL + 64) * sizeof(float);
@@ -1652,6 +1697,13 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   a.o_ss = (int)g->o_ss; a.o_sb = (int)g->o_sb; a.o_sh = (int)g->o_sh;
   a.Cq = g->Cq; a.Ck = g->Ck; a.Ek = g->Ek;
   a.mask_mode = g->mask_mode; a.scale = g->scale;
+  if (g->logits) {      // the forward's logits (isi_attn_args.logits): read by the split kernels
+    if (g->precision < 1) return unsupported("rel_attention_bwd: kept logits go with the 16-bit modes (precision >= 1)");
+    if (g->logits_ld < ((g->Sk + 31) & ~31) || (g->logits_ld & 3) || (reinterpret_cast<uintptr_t>(g->logits) & 15) ||
+        g->logits_ld > ((int64_t)1 << 30))
+      return invalid("rel_attention_bwd: logits_ld must be a multiple of 4, at least Sk rounded up to 32; logits 16-byte aligned");
+    a.logits = g->logits; a.ldl = (int)g->logits_ld;
+  }
 
   const int nstat = g->B * g->H * g->Sq;
   hipLaunchKernelGGL(attn_dsum_kernel, dim3((nstat + 255) / 256), dim3(256), 0, stream, a, HD);

@@ -780,6 +780,8 @@ __global__ __launch_bounds__(512) void attn_fwd_tail_row_kernel(const AttnKArgs 
       float acc = (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
       acc = G == 16 ? row16_sum(acc) : G == 8 ? group8_sum(acc) : group4_sum(acc);
       sv[u] = j0 + u * RPP < p.Sk ? acc * p.scale : NEG;
+      if (p.logits && gl == 0 && j0 + u * RPP < p.Sk)
+        p.logits[(((size_t)b * p.H + h) * p.Sq + i) * p.ldl + j0 + u * RPP] = sv[u] * LOG2E;
       bm = fmaxf(bm, sv[u]);
     }
     const float mn = fmaxf(m, bm), corr = __expf(m - mn);
@@ -891,6 +893,14 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   if (g->precision < 0 || g->precision > 3) return invalid("rel_attention: precision must be 0 .. 3");
   // 0 fp32 pipe | 1 three-term split-bf16 | 2 single-term bf16 | 3 single-term f16 (rel_attention_fwd2.hip only)
   a.split = g->precision == 1 ? 1 : g->precision >= 2 ? 2 : 0;
+  a.logits = g->logits; a.ldl = (int)g->logits_ld;
+  if (a.logits) {
+    if (g->logits_ld < ((g->Sk + 31) & ~31) || (g->logits_ld & 3) || (reinterpret_cast<uintptr_t>(a.logits) & 15))
+      return invalid("rel_attention: logits_ld must be a multiple of 4, at least Sk rounded up to 32; logits 16-byte aligned");
+    if ((int64_t)g->B * g->H * g->Sq * g->logits_ld > ((int64_t)1 << 40)) return unsupported("rel_attention: logits buffer too large");
+    if (!a.split || (g->precision != 3 && knobs().attn_old_fwd) || !rel_attention_fwd2_ok(a, g->head_dim))
+      return unsupported("rel_attention: the logits are stored by the 64-key-tile kernels only (precision >= 1)");
+  }
   if (a.e && a.R <= 0) return invalid("rel_attention: rel_rows must be positive");
   // One or two rows beyond the last full query block (the prior's sequences are 1024 codes + a start row) would be a
   // block of their own that runs as long as a full one: 576 instead of 512 workgroups on 256 CUs -- a third round

@@ -434,12 +434,19 @@ __global__ __launch_bounds__(512) void rel_attn_fwd2_kernel(const AttnKArgs p, c
         // ---- mask, online softmax (base 2; q carries scale * log2 e)
         float sv[16];
         float tmax;
+        // the row of this lane's query in the kept logits (training: the backward reads them back), its 16 keys of this sub-block
+        float *lrow = p.logits ? p.logits + (((size_t)b * p.H + h) * p.Sq + min(qi, p.Sq - 1)) * p.ldl + k0 + 4 * half : nullptr;
         bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < q_end;
         if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
         if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
         float psum = 0.f;
         float alpha;
         if (full) {
+          if (lrow) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4 *>(lrow + 8 * g) = make_float4(sacc[4 * g], sacc[4 * g + 1], sacc[4 * g + 2], sacc[4 * g + 3]);
+          }
           tmax = sacc[0];
 #pragma unroll
           for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, sacc[r]);
@@ -475,6 +482,11 @@ __global__ __launch_bounds__(512) void rel_attn_fwd2_kernel(const AttnKArgs p, c
               sv[r] = sc;
               tmax = fmaxf(tmax, sc);
             }
+          }
+          if (lrow && qi < q_end) {    // (masked pairs carry -1e30; keys beyond Sk fall into the row's padding)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              *reinterpret_cast<float4 *>(lrow + 8 * g) = make_float4(sv[4 * g], sv[4 * g + 1], sv[4 * g + 2], sv[4 * g + 3]);
           }
           tmax = fmaxf(tmax, xor32_f32(tmax));
           const float m_new = fmaxf(m_run, tmax);

@@ -78,7 +78,8 @@ class isi_attn_args(C.Structure):
                 ("v_ss", C.c_int64), ("v_sb", C.c_int64), ("v_sh", C.c_int64),
                 ("o_ss", C.c_int64), ("o_sb", C.c_int64), ("o_sh", C.c_int64),
                 ("Cq", C.c_int), ("Ck", C.c_int), ("Ek", C.c_int), ("rel_rows", C.c_int),
-                ("mask_mode", C.c_int), ("scale", C.c_float), ("lse", C.c_void_p), ("precision", C.c_int)]
+                ("mask_mode", C.c_int), ("scale", C.c_float), ("lse", C.c_void_p), ("precision", C.c_int),
+                ("logits", C.c_void_p), ("logits_ld", C.c_int64)]
 
 
 class isi_attn_bwd_args(C.Structure):

@@ -43,6 +43,10 @@ ATTENTION_PRECISION = os.environ.get("ISI_ATTENTION_PRECISION", "bf16x3")
 _ATTN_PREC = {"f32": 0, "bf16x3": 1, "bf16": 2, "f16": 3}
 ATTENTION_PRECISIONS = tuple(_ATTN_PREC)                 # modes bench.py times
 ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1, "f16": 1}    # 16-bit MFMA terms per product (0: fp32 matrix pipe)
+# training: the forward keeps its logits ([B,H,Sq,Sk rounded up to 32] fp32: 277 MB per attention at B 8, H 8, S 1025) and
+# the backward reads them instead of forming Q K^T, the band product Q E^T and its skew twice more -- 60 % of the
+# backward's time at that shape; 0 = recompute (no extra memory)
+SAVE_ATTENTION_LOGITS = os.environ.get("ISI_ATTN_SAVE_LOGITS", "1") != "0"
 _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4, "f16x3": 8}
 _F16_WEIGHT_LIMIT = 63.98   # 65520 / 1024 and above rounds to inf in the f16 pieces
 
@@ -201,9 +205,22 @@ def _attn_args(q, k, v, rel, out, Sq, Sk, B, H, hd, Cq, Ck, Ek, mask_mode, dense
     return a
 
 
+def attention_logits_buffer(B: int, nhead: int, Sq: int, Sk: int, device) -> Optional[torch.Tensor]:
+    """[B,H,Sq,ld] buffer for the logits a training forward keeps (None when they are recomputed: exact-fp32 mode,
+    ISI_ATTN_SAVE_LOGITS=0, or the round-3 forward kernels selected)."""
+    if not SAVE_ATTENTION_LOGITS or ATTENTION_PRECISION == "f32":
+        return None
+    old = C.c_int()
+    _hip.check(_hip.lib().isi_knob_get(b"ISI_ATTN_OLD_FWD", C.byref(old)), "isi_knob_get")
+    if old.value and ATTENTION_PRECISION != "f16":
+        return None
+    return torch.empty(B, nhead, Sq, (Sk + 31) // 32 * 32, dtype=torch.float32, device=device)
+
+
 def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Optional[torch.Tensor], nhead: int,
                   Cq: int, Ck: int, Ek: int, mask_mode: int = 0,
-                  dense_mask: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  dense_mask: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+                  logits: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [Sq,B,d], k/v [Sk,B,d] (any row strides, last dim contiguous; views into a
     fused qkv buffer are consumed in place) -> [Sq,B,d]."""
     _hip.require_gpu(q, "attention input")
@@ -218,6 +235,8 @@ def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Option
     a.o_ss, a.o_sb, a.o_sh = out.stride(0), out.stride(1), hd
     if lse is not None:  # [B,H,Sq] log-sum-exp per query, kept for the backward
         a.lse = lse.data_ptr()
+    if logits is not None:  # [B,H,Sq,ld] logits of the allowed pairs, kept for the backward (attention_logits_buffer)
+        a.logits, a.logits_ld = logits.data_ptr(), logits.stride(2)
     _hip.check(_hip.lib().isi_rel_attention_f32(C.byref(a), _s(q)), "isi_rel_attention_f32")
     return out
 

@@ -156,16 +156,18 @@ class RelAttentionFn(torch.autograd.Function):
         q, k, v = RelAttentionFn._split(a, b)
         Sq, B, _ = q.shape
         lse = torch.empty(B, nhead, Sq, dtype=torch.float32, device=q.device)
+        # kept only when a backward will follow (under no_grad nothing needs a gradient)
+        logits = _ops.attention_logits_buffer(B, nhead, Sq, k.shape[0], q.device) if any(ctx.needs_input_grad[:3]) else None
         out = _ops.rel_attention(q, k, v, rel, nhead, Cq, Ck, Ek, mask_mode=mask_mode, dense_mask=dense_mask,
-                                 lse=lse)
-        ctx.cfg = (nhead, Cq, Ck, Ek, mask_mode)
-        ctx.save_for_backward(a, b, rel, out, lse, dense_mask)
+                                 lse=lse, logits=logits)
+        ctx.cfg = (nhead, Cq, Ck, Ek, mask_mode, _ops.ATTENTION_PRECISION)
+        ctx.save_for_backward(a, b, rel, out, lse, dense_mask, logits)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        a_in, b_in, rel, out, lse, dense_mask = ctx.saved_tensors
-        nhead, Cq, Ck, Ek, mask_mode = ctx.cfg
+        a_in, b_in, rel, out, lse, dense_mask, logits = ctx.saved_tensors
+        nhead, Cq, Ck, Ek, mask_mode, _ = ctx.cfg
         q, k, v = RelAttentionFn._split(a_in, b_in)
         Sq, B, d = q.shape
         Sk = k.shape[0]
@@ -184,6 +186,8 @@ class RelAttentionFn(torch.autograd.Function):
         f.v_ss, f.v_sb, f.v_sh = v.stride(0), v.stride(1), hd
         f.o_ss, f.o_sb, f.o_sh = out.stride(0), out.stride(1), hd
         f.lse = lse.data_ptr()
+        if logits is not None and f.precision >= 1:      # (a backward in the exact-fp32 mode recomputes)
+            f.logits, f.logits_ld = logits.data_ptr(), logits.stride(2)
         a.d_out = dout.data_ptr()
         a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
         a.d_rel = drel.data_ptr() if drel is not None else None

@@ -169,7 +169,8 @@ class RelativeMultiheadAttention(nn.Module):
         """which: 0 = q|k|v, 1 = q, 2 = k|v of the fused in-projection."""
         d = self.d_model
         lo, hi = ((0, 3 * d), (0, d), (d, 3 * d))[which]
-        W, b = self.in_proj_weight[lo:hi], self.in_proj_bias[lo:hi]
+        # (the whole parameter, not a [0:3d] slice of it: a slice's backward materialises a zero-filled copy of the parameter)
+        W, b = (self.in_proj_weight, self.in_proj_bias) if which == 0 else (self.in_proj_weight[lo:hi], self.in_proj_bias[lo:hi])
         if torch.is_grad_enabled() and (x.requires_grad or self.in_proj_weight.requires_grad):
             return _train.LinearFn.apply(x, W, b, None, False, self._packs()[which], lambda: self._pack_t(which))
         return _ops.linear(x, self._packs()[which], b, hi - lo)
@@ -201,8 +202,15 @@ class RelativeMultiheadAttention(nn.Module):
             a, b = self._project(x, 0), None
             Sk = Sq
         else:
-            a = self._project(x, 1)
-            b = kv if kv is not None else self.project_kv(mem)
+            W = self.in_proj_weight
+            if (kv is None and torch.is_grad_enabled() and W.requires_grad and d % 32 == 0 and self.in_proj_bias is not None):
+                # training: both in-projections as one autograd node (their weight gradients fill one [3d, d] tensor)
+                packs = self._packs()
+                a, b = _train.CrossInProjFn.apply(x, mem, W, self.in_proj_bias, packs[1], packs[2],
+                                                  lambda: self._pack_t(1), lambda: self._pack_t(2))
+            else:
+                a = self._project(x, 1)
+                b = kv if kv is not None else self.project_kv(mem)
             Sk = b.shape[0]
         mode, dense = _classify_mask(mask, Sq, Sk, x.device)
         if torch.is_grad_enabled() and a.requires_grad:

@@ -41,16 +41,20 @@ def _wgrad_flags() -> int:
     return WGRAD_FLAGS
 
 
-def linear_wgrad(x2: torch.Tensor, dy2: torch.Tensor):
-    """x2 [M,K], dy2 [M,N] dense -> (dW [N,K] torch layout, db [N])."""
+def linear_wgrad(x2: torch.Tensor, dy2: torch.Tensor, out_w: Optional[torch.Tensor] = None,
+                 out_b: Optional[torch.Tensor] = None):
+    """x2 [M,K], dy2 [M,N] dense -> (dW [N,K] torch layout, db [N]).  `out_w` / `out_b`: contiguous destinations (rows of
+    a larger gradient tensor), K a multiple of 32."""
     M, K = x2.shape
     N = dy2.shape[1]
     L = _hip.lib()
     Kpad = (K + 31) // 32 * 32
     nws = L.isi_conv_wgrad_workspace_floats(N, K, M, 1)
     ws = torch.empty(nws, dtype=torch.float32, device=x2.device)
-    packed = torch.empty(N, Kpad, dtype=torch.float32, device=x2.device)
-    db = torch.empty(N, dtype=torch.float32, device=x2.device)
+    if out_w is not None:
+        assert Kpad == K and out_w.shape == (N, K) and out_w.is_contiguous() and out_b.shape == (N,) and out_b.is_contiguous()
+    packed = out_w if out_w is not None else torch.empty(N, Kpad, dtype=torch.float32, device=x2.device)
+    db = out_b if out_b is not None else torch.empty(N, dtype=torch.float32, device=x2.device)
     s0 = _hip.isi_src(x2.data_ptr(), K, 0, 1, 0, x2.stride(0))
     rc = L.isi_conv_wgrad_f32(C.byref(s0), None, dy2.data_ptr(), packed.data_ptr(), db.data_ptr(), ws.data_ptr(), nws,
                               1, 1, M, N, 1, 1, 1, 0, _wgrad_flags(), _s(x2))
@@ -102,6 +106,39 @@ class LinearFn(torch.autograd.Function):
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2.reshape(dy.shape)
         return dx, dw, db, dres, None, None, None, None, None
+
+
+class CrossInProjFn(torch.autograd.Function):
+    """The two in-projections of a cross-attention from ONE fused parameter: q = x W[:d]^T + b[:d], k|v = mem W[d:]^T + b[d:].
+    As two LinearFn nodes on slices of the parameter, autograd materialised each slice's gradient as a zero-filled
+    [3d, d] tensor (+ bias), filled the slice and added the two: ~12 small launches per layer and step.  Here both weight
+    gradients are written into the rows of one [3d, d] tensor that is returned as the parameter's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, mem, weight, bias, packed_q, packed_kv, packed_t_q_fn, packed_t_kv_fn):
+        d = weight.shape[1]
+        q = _ops.linear(x, packed_q, bias[:d], d)
+        kv = _ops.linear(mem, packed_kv, bias[d:], 2 * d)
+        ctx.fns = (packed_t_q_fn, packed_t_kv_fn)
+        ctx.save_for_backward(x, mem, weight)
+        return q, kv
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        x, mem, weight = ctx.saved_tensors
+        d = weight.shape[1]
+        dq2, dkv2 = _rows(dq), _rows(dkv)
+        dx = dmem = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _ops.linear(dq2, ctx.fns[0](), None, d, precision=_grad_precision()).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            dmem = _ops.linear(dkv2, ctx.fns[1](), None, d, precision=_grad_precision()).reshape(mem.shape)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dw = torch.empty_like(weight)
+            db = torch.empty(3 * d, dtype=torch.float32, device=weight.device)
+            linear_wgrad(_rows(x), dq2, out_w=dw[:d], out_b=db[:d])
+            linear_wgrad(_rows(mem), dkv2, out_w=dw[d:], out_b=db[d:])
+        return dx, dmem, dw, db, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -43,3 +43,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=40,
                                                          max_shapes_column_width=60))
+# the torch operators themselves (the plumbing between the library's kernels): calls, device time, shapes
+print("\naten operators by device time:")
+ops = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::")]
+for e in sorted(ops, key=lambda e: -e.device_time_total)[:60]:
+    print(f"{e.key[:34]:34s} n {e.count:4d}  device {e.device_time_total / 1e3:8.3f} ms  cpu {e.cpu_time_total / 1e3:8.3f} ms  {str(e.input_shapes)[:90]}")

@@ -389,6 +389,33 @@ typedef struct isi_attn_bwd_args {
 size_t isi_rel_attention_bwd_workspace_floats(const isi_attn_args *fwd);
 int isi_rel_attention_bwd_f32(const isi_attn_bwd_args *args, void *stream);
 
+/* One linear layer of the prior (`nn.Linear` inside the absent package's layers, priors/transformer.py:370-417): rows
+ *   out[m, n] = sum_k x[m, k] w[n, k] + bias[n] (+ residual[m, n]) (ReLU) (gate) (dropout)
+ * on the split-product GEMM kernel, with the element-wise tails of a training step folded into its epilogue:
+ *   gate       out = gate[m, n] > 0 ? value * gate_scale : 0  -- a ReLU's backward mask (and the inverse keep probability
+ *              of a dropout that followed the ReLU) applied by the input-gradient GEMM;
+ *   drop_p     inverted dropout of the (rectified) output: element (m, n) is kept iff a counter-based hash of
+ *              (drop_seed, m * ldo + n) clears drop_p, kept values are scaled by 1 / (1 - drop_p).  The mask is a pure
+ *              function of (seed, index): nothing is stored; a dropped element of a rectified output is 0 and gates its
+ *              own gradient.  (`F.dropout` in train mode: same distribution, not torch's random stream.)
+ * flags: ISI_CONV_RELU | one of ISI_CONV_BF16X3 / ISI_CONV_F16X3 | ISI_CONV_W16 as for isi_conv2d_f32.  Shapes the GEMM
+ * kernel does not take (K % 32, K < 128, N <= 32, M < 256) return ISI_E_UNSUPPORTED: the caller keeps isi_conv2d_f32. */
+typedef struct isi_linear_args {
+  const float *x;
+  int64_t ldx;
+  const float *packed_w, *bias, *residual;
+  int64_t ldr;
+  const float *gate;
+  int64_t ldg;
+  float gate_scale;
+  float *out;
+  int64_t ldo;
+  int M, N, K, flags;
+  float drop_p;
+  uint64_t drop_seed;
+} isi_linear_args;
+int isi_linear_f32(const isi_linear_args *args, void *stream);
+
 /* Backward of isi_layernorm_f32: dz = d loss / d (x + residual) (the gradient of both x and
  * residual), dgamma / dbeta [D] (overwritten; deterministic two-stage reduction).
  * workspace: isi_layernorm_bwd_workspace_floats(M, D) floats. */

@@ -70,11 +70,15 @@ class _LinearParams(nn.Module):
             self._packed_t, self._key_t = _ops.pack_linear_weight_t(self.weight), key
         return self._packed_t
 
-    def run(self, x, relu=False, residual=None, rectified_input=False, grad_pre_gated=False):
-        """`rectified_input` / `grad_pre_gated`: see _train.LinearFn (a feed-forward block's pair of layers)."""
+    def run(self, x, relu=False, residual=None, rectified_input=False, grad_pre_gated=False, dropout_p=0.0,
+            input_keep_scale=1.0):
+        """`rectified_input` / `grad_pre_gated` / `dropout_p` / `input_keep_scale`: see _train.LinearFn (a feed-forward
+        block's pair of layers)."""
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
             return _train.LinearFn.apply(x, self.weight, self.bias, residual, relu, self.packed(), self.packed_t,
-                                         rectified_input, grad_pre_gated)
+                                         rectified_input, grad_pre_gated, dropout_p, input_keep_scale)
+        if dropout_p > 0.0:
+            raise RuntimeError("fused dropout is a training-path feature (no gradient is being recorded)")
         return _ops.linear(x, self.packed(), self.bias, self.out_features, relu=relu, residual=residual)
 
 
@@ -238,13 +242,34 @@ def _drop(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
 
 
 def _add_norm(layer: nn.Module, lin: _LinearParams, x: torch.Tensor, residual: torch.Tensor,
-              norm: _LayerNormParams, rectified_input: bool = False) -> torch.Tensor:
+              norm: _LayerNormParams, rectified_input: bool = False, input_keep_scale: float = 1.0) -> torch.Tensor:
     """norm(residual + dropout(lin(x))): the residual add rides in the GEMM epilogue when nothing is
     dropped, in the LayerNorm kernel otherwise.  `rectified_input`: x is a ReLU's output (_train.LinearFn)."""
     if layer.training and layer.dropout > 0:
-        return norm.run(nn.functional.dropout(lin.run(x, rectified_input=rectified_input), layer.dropout, True),
-                        residual=residual)
+        return norm.run(nn.functional.dropout(lin.run(x, rectified_input=rectified_input, input_keep_scale=input_keep_scale),
+                                              layer.dropout, True), residual=residual)
     return norm.run(lin.run(x, residual=residual, rectified_input=rectified_input))
+
+
+# ISI_FUSED_DROPOUT=0: the feed-forward block's dropout as torch's kernels (A/B switch)
+_FUSED_DROPOUT = os.environ.get("ISI_FUSED_DROPOUT", "1") != "0"
+
+
+def _feed_forward(layer: nn.Module, x: torch.Tensor, norm: _LayerNormParams) -> torch.Tensor:
+    """norm(x + dropout(linear2(dropout(relu(linear1(x)))))).  linear2's input gradient is gated by h > 0 in its GEMM
+    epilogue and linear1 skips its mask pass (ISI_FF_GATE); in a training step the hidden dropout ([M, 2048]: the
+    largest element-wise tensor of a layer) rides in linear1's GEMM epilogue and its backward in linear2's gate."""
+    p = layer.dropout if layer.training else 0.0
+    M = x.numel() // x.shape[-1]
+    fused = (_FUSED_DROPOUT and _FF_GATE and p > 0 and torch.is_grad_enabled()
+             and (x.requires_grad or layer.linear1.weight.requires_grad)
+             and _ops.fused_tails_ok(M, layer.linear1.out_features, layer.linear1.in_features)
+             and _ops.fused_tails_ok(M, layer.linear2.in_features, layer.linear2.out_features))
+    if fused:
+        h = layer.linear1.run(x, relu=True, grad_pre_gated=True, dropout_p=p)
+        return _add_norm(layer, layer.linear2, h, x, norm, rectified_input=True, input_keep_scale=1.0 / (1.0 - p))
+    h = _drop(layer, layer.linear1.run(x, relu=True, grad_pre_gated=_FF_GATE))
+    return _add_norm(layer, layer.linear2, h, x, norm, rectified_input=_FF_GATE)
 
 
 class TransformerEncoderLayerCustom(nn.Module):
@@ -263,9 +288,7 @@ class TransformerEncoderLayerCustom(nn.Module):
     def forward(self, src: torch.Tensor, src_mask: MaskArg = None) -> torch.Tensor:
         a = self.self_attn(src, None, src_mask)
         x = _add_norm(self, self.self_attn.out_proj, a, src, self.norm1)
-        # feed-forward block: linear2's input gradient is gated by h > 0 in its GEMM epilogue, linear1 skips its mask pass
-        h = _drop(self, self.linear1.run(x, relu=True, grad_pre_gated=_FF_GATE))
-        return _add_norm(self, self.linear2, h, x, self.norm2, rectified_input=_FF_GATE)
+        return _feed_forward(self, x, self.norm2)
 
 
 class TransformerDecoderLayerCustom(nn.Module):
@@ -294,8 +317,7 @@ class TransformerDecoderLayerCustom(nn.Module):
         x = _add_norm(self, self.self_attn.out_proj, a, tgt, self.norm1)
         c = self.multihead_attn(x, memory, memory_mask, kv=memory_kv)
         x = _add_norm(self, self.multihead_attn.out_proj, c, x, self.norm2)
-        h = _drop(self, self.linear1.run(x, relu=True, grad_pre_gated=_FF_GATE))
-        return _add_norm(self, self.linear2, h, x, self.norm3, rectified_input=_FF_GATE)
+        return _feed_forward(self, x, self.norm3)
 
 
 class TransformerAlignedDecoderLayerCustom(TransformerDecoderLayerCustom):

@@ -43,9 +43,13 @@ struct GemmArgs {
   int tail;               // rows [M, M + tail) beyond the tiled rows: fp32 dot products, spread over the workgroups
   int zs_a, zs_w, zs_res, zs_out;                          // element strides between the products of a batch (grid y)
   int win_rpu, lo_slope, lo_base, hi_slope, hi_base;       // GemmExtra's band of non-zero A columns (win_rpu = 0: none)
-  const float *gate;      // optional: out = gate[m ldg + n] > 0 ? v : 0
+  const float *gate;      // optional: out = gate[m ldg + n] > 0 ? v * gate_scale : 0
   int ldg;
   unsigned gate_bytes;
+  float gate_scale;
+  unsigned drop_thresh;   // fused inverted dropout: keep where dropout_keep(seed, m ldo + n, thresh); 0 = none
+  float drop_scale;
+  uint64_t drop_seed;
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
     for (int r = 0; r < 16; ++r) {
       float v = (F16 ? acc[j][r] * f16s::kUnscale : acc[j][r]) + bias + res[r];
       if (p.relu) v = fmaxf(v, 0.f) + (v - v);      // (a NaN stays a NaN: an operand beyond the f16 range must be loud)
-      if (p.gate) v = gt[r] > 0.f ? v : 0.f;
+      if (p.gate) v = gt[r] > 0.f ? v * p.gate_scale : 0.f;
+      if (p.drop_thresh) v = dropout_keep(p.drop_seed, oo[r] >> 2, p.drop_thresh) ? v * p.drop_scale : 0.f;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro, oo[r], 0, 0);
     }
   }
@@ -248,7 +253,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
         if (lane == 0) {
           float v = s + (p.bias ? p.bias[n] : 0.f) + (p.res ? p.res[m * p.ldr + n] : 0.f);
           if (p.relu) v = fmaxf(v, 0.f) + (v - v);
-          if (p.gate) v = p.gate[m * p.ldg + n] > 0.f ? v : 0.f;
+          if (p.gate) v = p.gate[m * p.ldg + n] > 0.f ? v * p.gate_scale : 0.f;
+          if (p.drop_thresh) v = dropout_keep(p.drop_seed, (uint32_t)(m * p.ldo + n), p.drop_thresh) ? v * p.drop_scale : 0.f;
           p.out[m * p.ldo + n] = v;
         }
       }
@@ -299,14 +305,23 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   g.w32 = w; g.tail = 0;
   g.zs_a = g.zs_w = g.zs_res = g.zs_out = 0;
   g.win_rpu = g.lo_slope = g.lo_base = g.hi_slope = g.hi_base = 0;
-  g.gate = nullptr; g.ldg = 0; g.gate_bytes = 4;
+  g.gate = nullptr; g.ldg = 0; g.gate_bytes = 4; g.gate_scale = 1.f;
+  g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0;
   int nz = 1;
   if (extra) {
     nz = extra->nz;
+    if (extra->drop_p > 0.f) {
+      if (!(extra->drop_p < 1.f) || nz != 1 || eo > ((int64_t)1 << 30)) return unsupported("gemm: dropout needs 0 < p < 1 and a single product");
+      const double t = (double)extra->drop_p * 4294967296.0;
+      g.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (t < 1.0 ? 1u : (unsigned)t);
+      g.drop_scale = 1.f / (1.f - extra->drop_p);
+      g.drop_seed = extra->drop_seed;
+    }
     if (extra->gate) {
       const int64_t eg = (int64_t)(M - 1) * extra->ldg + N;
       if (nz != 1 || eg > lim || extra->ldg < N) return unsupported("gemm: a gate goes with a single product of less than 4 GiB");
       g.gate = extra->gate; g.ldg = (int)extra->ldg; g.gate_bytes = (unsigned)(eg * 4);
+      g.gate_scale = extra->gate_scale != 0.f ? extra->gate_scale : 1.f;
     }
     if (nz < 1 || nz > 65535) return invalid("gemm: bad batch count");
     const int64_t zmax = std::max(std::max(extra->zs_a, extra->zs_w), std::max(extra->zs_res, extra->zs_out));

@@ -183,6 +183,22 @@ int isi_conv2d_gated_f32(const isi_src *src0, const isi_src *src1, const float *
   return conv2d_f32(src0, src1, packed_w, bias, residual, dst, B, H, W, Cout, KH, KW, stride, pad, flags, S(stream),
                     gate);
 }
+int isi_linear_f32(const isi_linear_args *a, void *stream) {
+  if (!a || !a->x || !a->packed_w || !a->out) return invalid("linear: null pointer");
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return invalid("linear: bad shape");
+  const int mode = (a->flags & ISI_CONV_BF16X6) ? 2 : (a->flags & ISI_CONV_F16X3) ? 3 : (a->flags & ISI_CONV_BF16X3) ? 1 : 0;
+  const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a->x) | reinterpret_cast<uintptr_t>(a->packed_w);
+  if (!gemm_split_applicable(a->M, a->N, a->K, mode) || (ptrs & 15) || (a->ldx & 3) || knobs().no_gemm_kernel)
+    return unsupported("linear: shape or product mode outside the GEMM kernel");
+  GemmExtra gx;
+  memset(&gx, 0, sizeof gx);
+  gx.nz = 1; gx.gate = a->gate; gx.ldg = a->ldg; gx.gate_scale = a->gate_scale;
+  gx.drop_p = a->drop_p; gx.drop_seed = a->drop_seed;
+  const size_t kpad = ((size_t)a->K + 31) / 32 * 32;
+  return gemm_split_f32(a->x, a->ldx, a->packed_w, a->bias, a->residual, a->residual ? a->ldr : 0, a->out, a->ldo, a->M, a->N,
+                        a->K, a->flags & 1, mode, S(stream), (a->flags & ISI_CONV_W16) ? a->packed_w + (size_t)a->N * kpad : nullptr,
+                        &gx);
+}
 int isi_conv_transpose2d_k4s2_gated_f32(const isi_src *src, const float *packed_w, const float *bias,
                                         const float *gate, const isi_dst *dst, int B, int H, int W, int Cout,
                                         int flags, void *stream) {

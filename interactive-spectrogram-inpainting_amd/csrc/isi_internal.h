@@ -124,7 +124,19 @@ struct GemmExtra {
   int win_rpu, lo_slope, lo_base, hi_slope, hi_base;
   const float *gate;      // optional (nz = 1): out = gate[m ldg + n] > 0 ? value : 0 (a ReLU's backward mask in the epilogue)
   int64_t ldg;
+  float gate_scale;       // the gated value is multiplied by this (0 = 1: the inverse keep probability of a dropout folded in)
+  float drop_p;           // inverted dropout on the (rectified) output, keep mask = attention_dropout_keep(seed, m ldo + n); 0: none
+  uint64_t drop_seed;
 };
+// the keep decision of the fused dropout: a counter-based hash of (seed, flat output index) -- the same function in the
+// forward epilogue and wherever a backward needs the mask again
+__host__ __device__ inline bool dropout_keep(uint64_t seed, uint32_t idx, uint32_t thresh) {
+  uint32_t h = idx * 0x9E3779B1u ^ (uint32_t)seed;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  h ^= (uint32_t)(seed >> 32);
+  h *= 0x27D4EB2Fu; h ^= h >> 15;
+  return h >= thresh;
+}
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,
                    int64_t ldo, int M, int N, int K, int relu, int split_mode, hipStream_t stream,
                    const float *w16 = nullptr, const GemmExtra *extra = nullptr);

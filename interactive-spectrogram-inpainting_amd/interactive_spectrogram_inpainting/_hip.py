@@ -82,6 +82,14 @@ class isi_attn_args(C.Structure):
                 ("logits", C.c_void_p), ("logits_ld", C.c_int64)]
 
 
+class isi_linear_args(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int64), ("packed_w", C.c_void_p), ("bias", C.c_void_p),
+                ("residual", C.c_void_p), ("ldr", C.c_int64), ("gate", C.c_void_p), ("ldg", C.c_int64),
+                ("gate_scale", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("flags", C.c_int),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64)]
+
+
 class isi_attn_bwd_args(C.Structure):
     _fields_ = [("fwd", isi_attn_args), ("d_out", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p),
                 ("dv", C.c_void_p), ("d_rel", C.c_void_p), ("workspace", C.c_void_p),
@@ -152,6 +160,7 @@ SIGNATURES = {
     "isi_conv2d_gated_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.POINTER(isi_src), _P,
                                        C.POINTER(isi_dst), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_linear_f32": (C.c_int, [C.POINTER(isi_linear_args), _P]),
     "isi_conv_transpose2d_k4s2_gated_f32": (C.c_int, [C.POINTER(isi_src), _P, _P, _P, C.POINTER(isi_dst), C.c_int,
                                                       C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_resblock_fusable": (C.c_int, [C.c_int, C.c_int]),

@@ -114,12 +114,27 @@ def pack_linear_weight_t(weight: torch.Tensor) -> torch.Tensor:
     return pack_linear_weight(w.t().contiguous())
 
 
+def fused_tails_ok(M: int, N: int, K: int) -> bool:
+    """Shapes `isi_linear_f32` takes (the split-product GEMM kernel): where a layer's dropout / scaled gate can ride in the
+    GEMM epilogue instead of torch kernels of their own."""
+    return (K % 32 == 0 and K >= 128 and N > 32 and M >= 256 and LINEAR_PRECISION in ("f16x3", "bf16x3")
+            and LINEAR_GRAD_PRECISION == "bf16x3")
+
+
+def dropout_seed() -> int:
+    """A fresh 62-bit seed from torch's CPU generator (reproducible under torch.manual_seed)."""
+    return int(torch.empty((), dtype=torch.int64).random_(0, 1 << 62).item())
+
+
 def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor], n_out: int,
            relu: bool = False, residual: Optional[torch.Tensor] = None,
-           precision: Optional[str] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+           precision: Optional[str] = None, gate: Optional[torch.Tensor] = None, gate_scale: float = 1.0,
+           dropout_p: float = 0.0, dropout_seed_: int = 0) -> torch.Tensor:
     """y[..., n_out] = x[..., K] W^T + b (+ residual): the implicit-GEMM convolution kernel with a
     1x1 window (rows = "pixels"); `precision` overrides LINEAR_PRECISION.  `gate` ([..., n_out], contiguous):
-    y is zeroed where gate <= 0 (a ReLU's backward mask applied by the input-gradient GEMM's epilogue)."""
+    y is zeroed where gate <= 0 (a ReLU's backward mask applied by the input-gradient GEMM's epilogue) and multiplied by
+    `gate_scale` elsewhere.  `dropout_p` > 0: inverted dropout of the output inside the GEMM epilogue (isi_linear_f32: the
+    mask is a hash of (seed, element index); shapes outside `fused_tails_ok` raise)."""
     _hip.require_gpu(x, "linear input")
     K = x.shape[-1]
     x2 = x.reshape(-1, K)
@@ -140,6 +155,24 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
         res = _hip.isi_src(r2.data_ptr(), n_out, 0, 1, 0, r2.stride(0))
     w16 = 16 if ((prec == "f16x3" and getattr(packed_w, "isi_w16", False)) or
                  (prec == "bf16x3" and getattr(packed_w, "isi_w16_bf16", False))) else 0          # ISI_CONV_W16
+    if dropout_p > 0.0 or gate_scale != 1.0:
+        a = _hip.isi_linear_args()
+        a.x, a.ldx, a.packed_w = x2.data_ptr(), x2.stride(0), packed_w.data_ptr()
+        a.bias = bias.data_ptr() if bias is not None else None
+        if residual is not None:
+            r2 = residual.reshape(M, n_out)
+            r2 = r2 if r2.stride(1) == 1 else r2.contiguous()
+            a.residual, a.ldr = r2.data_ptr(), r2.stride(0)
+        if gate is not None:
+            g2 = gate.reshape(M, n_out)
+            if not g2.is_contiguous() or g2.dtype != torch.float32 or g2.device != x.device:
+                raise ValueError("linear: gate must be a contiguous fp32 tensor of the output's shape on the same device")
+            a.gate, a.ldg, a.gate_scale = g2.data_ptr(), n_out, gate_scale
+        a.out, a.ldo, a.M, a.N, a.K = out.data_ptr(), n_out, M, n_out, K
+        a.flags = int(relu) | _PREC_FLAG[prec] | w16
+        a.drop_p, a.drop_seed = float(dropout_p), int(dropout_seed_)
+        _hip.check(_hip.lib().isi_linear_f32(C.byref(a), _s(x)), "isi_linear_f32")
+        return out.reshape(*x.shape[:-1], n_out)
     if gate is not None:
         g2 = gate.reshape(M, n_out)
         if not g2.is_contiguous() or g2.dtype != torch.float32 or g2.device != x.device:

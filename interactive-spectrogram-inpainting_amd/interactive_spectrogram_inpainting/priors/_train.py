@@ -72,12 +72,22 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, relu: bool, packed, packed_t_fn, rectified_input: bool = False,
-                grad_pre_gated: bool = False):
+                grad_pre_gated: bool = False, dropout_p: float = 0.0, input_keep_scale: float = 1.0):
         """`rectified_input`: x is the (possibly dropout-scaled) output of a ReLU -- the input gradient is then zeroed
         where x <= 0 by the GEMM's epilogue, i.e. that ReLU's backward mask is applied HERE; the producing layer is
         built with `grad_pre_gated` and skips its own mask pass (a clone and a three-pass kernel over [M, 2048] per
-        feed-forward block).  Where a unit was dropped x is 0 and the gradient is 0 either way."""
-        y = _ops.linear(x, packed, bias, weight.shape[0], relu=relu, residual=residual)
+        feed-forward block).  Where a unit was dropped x is 0 and the gradient is 0 either way.
+        `dropout_p` (a rectified, pre-gated layer only): inverted dropout of the output inside the GEMM epilogue -- no mask
+        tensor, no dropout kernels; the consumer is built with `input_keep_scale` = 1 / (1 - p), which its input-gradient
+        GEMM applies together with the gate (what the dropout's backward would have done: kept units scaled, dropped
+        units -- zeros of the rectified tensor -- gated to zero)."""
+        if dropout_p > 0.0:
+            assert relu and grad_pre_gated, "fused dropout goes with a rectified output whose consumer gates the gradient"
+            y = _ops.linear(x, packed, bias, weight.shape[0], relu=relu, residual=residual, dropout_p=dropout_p,
+                            dropout_seed_=_ops.dropout_seed())
+        else:
+            y = _ops.linear(x, packed, bias, weight.shape[0], relu=relu, residual=residual)
+        ctx.input_keep_scale = input_keep_scale
         ctx.relu, ctx.packed_t_fn = relu, packed_t_fn
         ctx.rectified_input, ctx.grad_pre_gated = rectified_input, grad_pre_gated
         ctx.has_res = residual is not None
@@ -98,14 +108,15 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
             gate = _rows(x) if ctx.rectified_input else None
-            dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K, precision=_grad_precision(), gate=gate).reshape(x.shape)
+            dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K, precision=_grad_precision(), gate=gate,
+                             gate_scale=ctx.input_keep_scale if gate is not None else 1.0).reshape(x.shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = linear_wgrad(_rows(x), dy2)
             if not ctx.has_bias:
                 db = None
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None
 
 
 class CrossInProjFn(torch.autograd.Function):

@@ -556,3 +556,46 @@ def test_linear_weight_gradient_kernel(shape):
     rel = lambda a, b: float((a.double().cpu() - b).abs().max() / b.abs().max())
     assert rel(dw, dw_ref) < 2e-5 and rel(dw_old, dw_ref) < 2e-5, (rel(dw, dw_ref), rel(dw_old, dw_ref))
     assert rel(db, db_ref) < 1e-5 and rel(db_old, db_ref) < 1e-5
+
+
+def test_feed_forward_fused_dropout():
+    """The hidden dropout of a feed-forward block inside linear1's GEMM epilogue (isi_linear_f32: mask = hash of (seed,
+    index), nothing stored) and its backward inside linear2's gated input-gradient GEMM: the kept fraction, the scaling of
+    the kept units, and every gradient against an fp64 computation with the same mask (read off the output's zeros)."""
+    from interactive_spectrogram_inpainting.priors import _ops, _train as PT
+    from VQCPCB.transformer.transformer_custom import _LinearParams
+    dev = _dev()
+    torch.manual_seed(11)
+    M, d, ff, p = 1030, 256, 1024, 0.25
+    assert _ops.fused_tails_ok(M, ff, d) and _ops.fused_tails_ok(M, ff, d)
+    l1, l2 = _LinearParams(d, ff).to(dev), _LinearParams(ff, d).to(dev)
+    x = torch.randn(M, d, device=dev, requires_grad=True)
+    w = torch.randn(M, d, device=dev)
+    h = l1.run(x, relu=True, grad_pre_gated=True, dropout_p=p)
+    y = l2.run(h, rectified_input=True, input_keep_scale=1.0 / (1.0 - p))
+    (y * w).sum().backward()
+    # forward: kept units are relu(x W1^T + b1) / (1 - p), about p of the positive ones are dropped
+    pre = torch.relu(x.detach().double() @ l1.weight.detach().double().t() + l1.bias.detach().double())
+    kept = (h.detach() != 0)
+    pos = pre > 1e-6
+    frac = 1.0 - kept[pos].double().mean().item()
+    assert abs(frac - p) < 0.01, frac
+    assert torch.allclose(h.detach().double()[kept], pre[kept] / (1 - p), rtol=1e-5, atol=1e-6)
+    assert not torch.equal(kept[:512], kept[512:1024]), "the mask must not repeat along the rows"
+    # backward: fp64 autograd with the same mask
+    xr = x.detach().double().requires_grad_(True)
+    W1, b1 = l1.weight.detach().double().requires_grad_(True), l1.bias.detach().double().requires_grad_(True)
+    W2, b2 = l2.weight.detach().double().requires_grad_(True), l2.bias.detach().double().requires_grad_(True)
+    hr = torch.relu(xr @ W1.t() + b1) * kept.double() / (1 - p)
+    ((hr @ W2.t() + b2) * w.double()).sum().backward()
+    for got, ref, name in ((x.grad, xr.grad, "dx"), (l1.weight.grad, W1.grad, "dW1"), (l1.bias.grad, b1.grad, "db1"),
+                           (l2.weight.grad, W2.grad, "dW2"), (l2.bias.grad, b2.grad, "db2")):
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < 3e-5, (name, err)
+    # two calls draw two masks; the same torch seed reproduces a mask
+    torch.manual_seed(5)
+    h1 = l1.run(x, relu=True, grad_pre_gated=True, dropout_p=p).detach()
+    h2 = l1.run(x, relu=True, grad_pre_gated=True, dropout_p=p).detach()
+    torch.manual_seed(5)
+    h3 = l1.run(x, relu=True, grad_pre_gated=True, dropout_p=p).detach()
+    assert not torch.equal(h1 != 0, h2 != 0) and torch.equal(h1, h3)

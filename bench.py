@@ -430,6 +430,43 @@ def _vqvae_training(device, dist, world, batch=64, steps=5, warmup=2):
     return out
 
 
+def _attention_row(device, B, H, S, hd, n=10):
+    """One more shape of the attention leg (the reference CLI's default is 16 heads: head_dim 32,
+    train_autoregressive_model.py:419): forward / backward times of the default product mode, causal."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.priors._train import RelAttentionFn
+    d = H * hd
+    torch.manual_seed(0)
+    qkv = torch.randn(S, B, 3 * d, device=device, requires_grad=True)
+    rel = (torch.randn(H, 2 * S - 1, hd, device=device) * 0.1).requires_grad_(True)
+    w = torch.randn(S, B, d, device=device)
+    dense = 2.0 * S * S * hd * B * H
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(device)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize(device)
+        return a.elapsed_time(b) / n * 1e3
+    with torch.no_grad():
+        t_f = timed(lambda: RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, 1, None))
+    res = RelAttentionFn.apply(qkv, None, rel, H, 1, 1, S, 1, None)
+
+    def bwd():
+        qkv.grad = None
+        rel.grad = None
+        res.backward(w, retain_graph=True)
+    t_b = timed(bwd)
+    return {"config": f"self-attention B{B} H{H} S{S} head_dim {hd}, causal, {_ops.ATTENTION_PRECISION}",
+            "fwd_us": round(t_f, 1), "fwd_TFLOPs_dense": round(3 * dense / t_f / 1e6, 1),
+            "bwd_us": round(t_b, 1), "bwd_TFLOPs_dense": round(7 * dense / t_b / 1e6, 1)}
+
+
 def _attention(device, B=8, H=8, S=1025, hd=64, n=10):
     """BASELINE configs[3]'s kernel at the shape the metric names: relative self-attention (QK^T + Q E^T skewed +
     softmax + PV), causal, B8 H8 S1025 head_dim 64, forward and backward, per product mode.  FLOPs = the DENSE count
@@ -485,6 +522,9 @@ def _attention(device, B=8, H=8, S=1025, hd=64, n=10):
     finally:
         _ops.ATTENTION_PRECISION = saved
     out["default_precision"] = saved
+    out["backward_logits"] = ("kept by the forward (isi_attn_args.logits), read by the backward"
+                              if _ops.SAVE_ATTENTION_LOGITS else "recomputed by the backward")
+    out["H16_hd32"] = _attention_row(device, B, 16, S, 32, n)
     dflt = out[saved]
     out["roofline"] = {"bound": "mfma", "kernel": f"rel_attention forward ({saved})", "achieved": dflt["fwd_TFLOPs_dense"],
                        "peak": dflt["peak_TFLOPs"], "unit": "TFLOP/s", "frac": dflt["fwd_frac"], "traffic": None,

@@ -899,7 +899,10 @@ static int wgrad_nsplit_tile(int Cout, int Kpad, int M, int nphase, int nz, cons
   const int tiles = ((Cout + t.tco - 1) / t.tco) * ((Kpad + t.tk - 1) / t.tk) * nphase * nz;
   const int nchunks = (M + 31) / 32;
   // small tiles are memory-bound and light on LDS: several workgroups per CU hide the load latency
-  const int nsplit = std::min(t.small ? 1024 : 256, std::max(1, (t.small ? 2048 : 768) / tiles));
+  // (K = 64 tiles -- the attention backward's dE = G^T Q, bound by the bytes of G: 136 tiles x 5 splits left a third of the
+  // chip idle in a second round; measured at B8 H8 S1025: unmasked backward 653 -> 576 us from 768 to 1536, tools: ISI_WGRAD_SPLIT_TARGET)
+  const int target = knobs().wgrad_split_target > 0 ? knobs().wgrad_split_target : (t.tk == 64 && !t.small ? 1536 : 768);
+  const int nsplit = std::min(t.small ? 1024 : 256, std::max(1, (t.small ? 2048 : target) / tiles));
   return std::min(nsplit, std::max(1, nchunks / 8));
 }
 static int wgrad_nsplit(int Cout, int Kpad, int M, int nphase, int nz, bool split_kernel) {

@@ -38,6 +38,8 @@ const KnobEntry kKnobTable[] = {
     {"ISI_DECODE_NT", &Knobs::decode_nt, 1, false},
     {"ISI_PRIOR_GRAPH", &Knobs::prior_graph, 0, false},
     {"ISI_ATTN_FULL_ZERO", &Knobs::attn_full_zero, 0, false},
+    {"ISI_WGRAD_SPLIT_TARGET", &Knobs::wgrad_split_target, 0, false},
+    {"ISI_ATTN_G_FROM_KV", &Knobs::attn_g_from_kv, 1, false},
     {"ISI_ATTN_OLD_FWD", &Knobs::attn_old_fwd, 0, false},
     {"ISI_CONV_ABLATE", &Knobs::conv_ablate, 0, true},
     {"ISI_VQ_DBG", &Knobs::vq_dbg, 0, true},

@@ -23,6 +23,8 @@ struct Knobs {
   int conv_tap_major;           // ISI_CONV_TAP_MAJOR: K order of the register-staged kernel (measurement)
   int respair_th, res_th, convt_th, convt_pair_th;   // forced tile heights (tests, measurement)
   int decode_nt;                // ISI_DECODE_NT: non-temporal weight loads in the batch-1 decode GEMVs (default 1)
+  int attn_g_from_kv;           // ISI_ATTN_G_FROM_KV: (kept logits) the key-stationary backward kernel stores dS into G (default 1)
+  int wgrad_split_target;       // ISI_WGRAD_SPLIT_TARGET: workgroups the split weight-gradient kernel aims at (0 = 768)
   int attn_full_zero;           // ISI_ATTN_FULL_ZERO: the attention backward zeroes all of G, not only the margins of its band
   int attn_old_fwd;             // ISI_ATTN_OLD_FWD: the round-3 forward kernel (32-key tiles) for the 16-bit modes (A/B switch)
   int prior_graph;              // ISI_PRIOR_GRAPH: replay the decode loop's positions as hipGraphs

@@ -51,6 +51,9 @@ struct AttnBwdKArgs {
   float scale;
   const float *logits;    // optional [B,H,Sq,ldl]: the forward's base-2 logits of the allowed pairs (isi_attn_args.logits):
   int ldl;                // the split kernels read them instead of forming Q K^T and the skewed band product again
+  int g_from_kv;          // (kept logits, Cq = Ck = 1, band-only G) the KEY-stationary kernel stores dS into G -- lanes run
+                          // along keys: 128-byte runs of a query's row -- and the query-stationary kernel only reads it back
+                          // for dQ += dS K: no second exp / dO V^T / dS pass, no V tiles, no scatter
 };
 
 namespace {
@@ -617,6 +620,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   const bool has_e = p.e != nullptr;
   constexpr bool saved = SAVED;                // logits kept by the forward (p.logits): no Q K^T, no band product, no skew here
   const bool band = has_e && !saved;           // the band of e is staged only when the relative logits are recomputed
+  const bool from_g = saved && p.g_from_kv;    // dS is read back from G (written by the key-stationary kernel)
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.k), 0, p.k_bytes, 0x00020000);
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
       const bool ok = blk_on && kj < p.Sk;
       const unsigned ko = (unsigned)(kj * p.k_ss + b * p.k_sb + h * p.k_sh + bqd * 4) * 4u;
       const unsigned vo = (unsigned)(kj * p.v_ss + b * p.v_sb + h * p.v_sh + bqd * 4) * 4u;
-      pb[j] = kind == 0 ? buf_load4(rk, ok ? ko : OOB) : buf_load4(rv, ok ? vo : OOB);
+      pb[j] = kind == 0 ? buf_load4(rk, ok ? ko : OOB) : buf_load4(rv, ok && !from_g ? vo : OOB);
     }
     const int r = band0(k0 + 32) + 32 * st + srow;
     const bool rok = band && r >= 0 && r < p.R;
@@ -771,6 +775,30 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
     if (live) {  // wave-uniform
       f32x16 acc;
       float sv[16];
+      typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < q_end;
+      if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
+      if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
+      if (from_g) {
+        // ---- dS of this lane's query from its row of G: keys 8 g + 4 half + 0..3 are 4 consecutive columns, descending
+        const float *grow = gbase + (size_t)min(qi, p.Sq - 1) * gstride + (qi - k0 - 4 * half + p.Ek - 1 - p.rho_lo);
+        if (full) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4_u v = *reinterpret_cast<const f32x4_u *>(grow - 8 * g - 3);
+            sv[4 * g + 3] = v.x; sv[4 * g + 2] = v.y; sv[4 * g + 1] = v.z; sv[4 * g] = v.w;
+          }
+        } else {      // (pairs the mask forbids have no element of their own in a band-only G)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int jj = (r & 3) + 8 * (r >> 2), kj = k0 + 4 * half + jj;
+            bool ok = kj < p.Sk && qi < q_end;
+            if (p.mask_mode == 1) ok = ok && kj <= qi;
+            if (p.mask_mode == 2) ok = ok && kj >= qi;
+            sv[r] = ok ? grow[-jj] : 0.f;
+          }
+        }
+      } else {
       if (saved) {
         // ---- the forward's logits of this lane's query: keys 8 g + 4 half + 0..3 of the tile (already in units of exp2)
         const float *lrow = p.logits + (((size_t)b * p.H + h) * p.Sq + min(qi, p.Sq - 1)) * p.ldl + k0 + 4 * half;
@@ -827,9 +855,6 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
 
       }
       // ---- P
-      bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < q_end;
-      if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
-      if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
       const float sc2 = saved ? 1.f : scale2;
       if (full) {
 #pragma unroll
@@ -861,6 +886,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = sv[r] * (acc[r] - dsum_i) * p.scale;
 
+      }
       // ---- dQ^T += K^T dS^T
       s16x8_t sh[2], sl[2];
       split_acc16(sv, sh, sl);
@@ -884,7 +910,9 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
       }
 
       // ---- G[i, r(i,j)] += dS[i,j]
-      if (has_e && unique_rho && full) {
+      if (from_g) {
+        // (G was written by the key-stationary kernel)
+      } else if (has_e && unique_rho && full) {
         // one channel per event on both sides and every pair of the tile allowed: the lane's 16 keys of its query are 4 runs
         // of 4 consecutive table rows (descending) of the query's own row of G -- four 16-byte stores (4-byte aligned),
         // no transpose through LDS, no per-element address arithmetic
@@ -1282,6 +1310,25 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = sv[r] * (acc[r] - dsumb[mfma_row(r, half)]) * p.scale;
+      if (saved && p.g_from_kv) {
+        // ---- G[i, i - j + Ek - 1] = dS[i, j]: for one query (register) the lanes' keys are consecutive columns, descending
+        // -- 128-byte runs; element (i, j) sits at g0[i (row stride + 1)]
+        float *g0 = p.g + ((size_t)h * p.Sq * p.B + b) * p.Rp + (p.Ek - 1 - p.rho_lo - kj);
+        const size_t gs1 = (size_t)p.B * p.Rp + 1;
+        if (full) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) g0[(size_t)(q0 + mfma_row(r, half)) * gs1] = sv[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qi = q0 + mfma_row(r, half);
+            bool ok = kj < k_lim && qi < p.Sq;
+            if (p.mask_mode == 1) ok = ok && kj <= qi;
+            if (p.mask_mode == 2) ok = ok && kj >= qi;
+            if (ok) g0[(size_t)qi * gs1] = sv[r];
+          }
+        }
+      }
       // ---- dK^T += Q^T dS
       split_acc16(sv, sh, sl);
 #pragma unroll
@@ -1509,6 +1556,8 @@ __device__ __forceinline__ void attn_bwd_tail_key(const AttnBwdKArgs &p, float *
       const float ds = pi * (pdot - dsum[u]) * p.scale;
       dv.x += pi * dd[u].x; dv.y += pi * dd[u].y; dv.z += pi * dd[u].z; dv.w += pi * dd[u].w;
       dk.x += ds * qv[u].x; dk.y += ds * qv[u].y; dk.z += ds * qv[u].z; dk.w += ds * qv[u].w;
+      if (p.g_from_kv && gl == 0 && i < p.Sq)      // this key's column of dS for the query-stationary kernel (Cq = Ck = 1)
+        p.g[(((size_t)h * p.Sq + i) * p.B + b) * p.Rp + (i - j + p.Ek - 1 - p.rho_lo)] = ds;
     }
   }
 #pragma unroll
@@ -1580,10 +1629,11 @@ size_t rel_attention_bwd_workspace_floats(const isi_attn_args *g) {
   return bwd_layout(g->B, g->H, g->Sq, n, g->head_dim).total;
 }
 
+// which: 1 = the key-stationary kernel (dK, dV), 2 = the query-stationary one (dQ, G), 3 = both
 template <int HD, bool ONE, bool SAVED = false>
-static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
+static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream, int which = 3) {
   if constexpr (!SAVED) {
-    if (a.logits) return launch_bwd_split<HD, ONE, true>(a, stream);
+    if (a.logits) return launch_bwd_split<HD, ONE, true>(a, stream, which);
   }
   auto kq = rel_attention_bwd_q_split_kernel<HD, ONE, SAVED>;
   auto kkv = rel_attention_bwd_kv_split_kernel<HD, ONE, SAVED>;
@@ -1600,19 +1650,20 @@ static int launch_bwd_split(const AttnBwdKArgs &a, hipStream_t stream) {
     attr_set.mark();
   }
   const double pairs = (double)a.Sq * a.Sk * (a.mask_mode ? 0.5 : 1.0) * a.H * a.B;
-  {
+  if (which & 1) {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 5 : 4),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 4.0 * a.Sk), stream);
     ISI_PROF_LAUNCH(scope, kkv, dim3(xcd_grid(a.nkb, a.H * a.B)), dim3(512), smem_kv, stream, a);
+    const int rc = check_launch("rel_attention_bwd_kv_split");
+    if (rc) return rc;
   }
-  int rc = check_launch("rel_attention_bwd_kv_split");
-  if (rc) return rc;
-  {
+  if (which & 2) {
     prof::Scope scope(prof::K_REL_ATTENTION_BWD, 2.0 * pairs * HD * (a.e ? 4 : 3),
                       4.0 * a.B * a.H * HD * (3.0 * a.Sq + 2.0 * a.Sk), stream);
     ISI_PROF_LAUNCH(scope, kq, dim3(xcd_grid(a.nqb, a.H * a.B)), dim3(512), smem_q, stream, a);
+    return check_launch("rel_attention_bwd_q_split");
   }
-  return check_launch("rel_attention_bwd_q_split");
+  return ISI_OK;
 }
 
 template <int HD>
@@ -1740,14 +1791,31 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   const int tail_k = split ? attention_tail_rows(g->Sk, g->mask_mode, g->dense_mask != nullptr) : 0;
   a.nqb = tail_q ? g->Sq / QB : (g->Sq + QB - 1) / QB;
   a.nkb = tail_k ? g->Sk / QB : (g->Sk + QB - 1) / QB;
-  switch (HD) {
-    case 16: rc = split ? (one ? launch_bwd_split<16, true>(a, stream) : launch_bwd_split<16, false>(a, stream)) : launch_bwd<16>(a, stream); break;
-    case 32: rc = split ? (one ? launch_bwd_split<32, true>(a, stream) : launch_bwd_split<32, false>(a, stream)) : launch_bwd<32>(a, stream); break;
-    default: rc = split ? (one ? launch_bwd_split<64, true>(a, stream) : launch_bwd_split<64, false>(a, stream)) : launch_bwd<64>(a, stream); break;
+  // kept logits and a band-only G: the key-stationary kernel (and the one-key kernel) store dS into G, the query-stationary
+  // kernel runs last and reads it back (AttnBwdKArgs.g_from_kv; ISI_ATTN_G_FROM_KV=0: every kernel forms its own dS)
+  a.g_from_kv = (split && band_only && a.logits && knobs().attn_g_from_kv) ? 1 : 0;
+  auto run_split = [&](int which) {
+    switch (HD) {
+      case 16: return one ? launch_bwd_split<16, true>(a, stream, which) : launch_bwd_split<16, false>(a, stream, which);
+      case 32: return one ? launch_bwd_split<32, true>(a, stream, which) : launch_bwd_split<32, false>(a, stream, which);
+      default: return one ? launch_bwd_split<64, true>(a, stream, which) : launch_bwd_split<64, false>(a, stream, which);
+    }
+  };
+  auto run_tails = [&]() {
+    return HD == 16 ? launch_bwd_tails<16>(a, tail_q, tail_k, stream) : HD == 32 ? launch_bwd_tails<32>(a, tail_q, tail_k, stream)
+                                                                               : launch_bwd_tails<64>(a, tail_q, tail_k, stream);
+  };
+  if (!split) {
+    rc = HD == 16 ? launch_bwd<16>(a, stream) : HD == 32 ? launch_bwd<32>(a, stream) : launch_bwd<64>(a, stream);
+    if (!rc && (tail_q || tail_k)) rc = run_tails();
+  } else if (a.g_from_kv) {
+    rc = run_split(1);
+    if (!rc && (tail_q || tail_k)) rc = run_tails();      // (the one-key kernel stores its column of G)
+    if (!rc) rc = run_split(2);
+  } else {
+    rc = run_split(3);
+    if (!rc && (tail_q || tail_k)) rc = run_tails();
   }
-  if (!rc && (tail_q || tail_k))
-    rc = HD == 16 ? launch_bwd_tails<16>(a, tail_q, tail_k, stream) : HD == 32 ? launch_bwd_tails<32>(a, tail_q, tail_k, stream)
-                                                                              : launch_bwd_tails<64>(a, tail_q, tail_k, stream);
   if (rc || !has_e) return rc;
 
   // ---- dQ += G E  and  dE = G^T Q, head by head, on the GEMM kernels

@@ -24,6 +24,7 @@
 
 #include "isi_common.h"
 #include "isi_internal.h"
+#include "knobs.h"
 #include "split_bf16.h"
 #include "split_f16.h"
 
@@ -76,9 +77,13 @@ __device__ __forceinline__ f32x16 mfma(const s16x8g a, const s16x8g b, const f32
 // pieces (ISI_CONV_W16: groups of 8 k as {hi[8] | lo[8]}, 32 bytes where the 8 floats were) -- a 16-byte piece IS a slot of
 // the LDS planes, so the weight tile is staged by plain copies: every 128-row tile of the fp32 form converts its
 // weight tile again, 65 times at M = 8200.
-template <bool F16, int TN, bool WPRE = false>
+// TM: 32-row tiles per wave (tile height 128 TM).  TM = TN = 2: a 256 x 128 tile, wave tile 64 x 64 -- 24 matrix
+// instructions per 16 fragment reads and chunk instead of 12 per 12 (the 128 x 128 form is co-limited by LDS traffic,
+// staging conversions and the vector-memory path, each about as long as its matrix work); 96 KB of LDS, one workgroup per
+// CU: the wide layers (N >= 1024) whose tile count still fills the chip.
+template <bool F16, int TN, bool WPRE = false, int TM = 1>
 __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
-  constexpr int BN = 64 * TN;
+  constexpr int BN = 64 * TN, BM = 128 * TM;
   if (blockIdx.y) {      // a batch of products: this one's operands
     const size_t z = blockIdx.y;
     p.a += z * p.zs_a; p.w += z * p.zs_w; p.w32 += z * p.zs_w; p.out += z * p.zs_out;
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm0 = (wave & 3) * 32, wn0 = (wave >> 2) * (32 * TN);
+  const int wm0 = (wave & 3) * (32 * TM), wn0 = (wave >> 2) * (32 * TN);
   const int fr = lane & 31, fh = lane >> 5;
   // consecutive workgroups walk the M tiles of one column block: they share the block's weights in L2
   const int tiles_m = (p.M + BM - 1) / BM;
@@ -146,11 +151,13 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
     }
   };
 
-  f32x16 acc[TN];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nchunk = p.K / 32;
   int c_lo = 0, c_hi = nchunk;
@@ -170,20 +177,28 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
     const bool more = c + 1 < c_hi;
     if (more) load_chunk(32 * (c + 1));
     const unsigned char *st = smem + ((c - c_lo) & 1) * STAGE;
-    const int arow = wm0 + fr;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int ao = arow * 64 + swz(arow, 2 * s + fh);
-      const s16x8g ah = *reinterpret_cast<const s16x8g *>(st + ao), al = *reinterpret_cast<const s16x8g *>(st + APL + ao);
+      s16x8g ah[TM], al[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int arow = wm0 + 32 * i + fr;
+        const int ao = arow * 64 + swz(arow, 2 * s + fh);
+        ah[i] = *reinterpret_cast<const s16x8g *>(st + ao);
+        al[i] = *reinterpret_cast<const s16x8g *>(st + APL + ao);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int brow = wn0 + 32 * j + fr;
         const int bo = brow * 64 + swz(brow, 2 * s + fh);
         const s16x8g bh = *reinterpret_cast<const s16x8g *>(st + 2 * APL + bo);
         const s16x8g bl = *reinterpret_cast<const s16x8g *>(st + 2 * APL + BPL + bo);
-        acc[j] = mfma<F16>(al, bh, acc[j]);
-        acc[j] = mfma<F16>(ah, bl, acc[j]);
-        acc[j] = mfma<F16>(ah, bh, acc[j]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          acc[i][j] = mfma<F16>(al[i], bh, acc[i][j]);
+          acc[i][j] = mfma<F16>(ah[i], bl, acc[i][j]);
+          acc[i][j] = mfma<F16>(ah[i], bh, acc[i][j]);
+        }
       }
     }
     if (more) store_chunk((c + 1 - c_lo) & 1);   // that stage was last read in iteration c - 1: every wave is past its barrier
@@ -195,6 +210,8 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.a), 0, p.res ? p.res_bytes : 4u, 0x00020000);
 #pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn0 + 32 * j + fr;
     const bool nok = n < p.N;
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
     unsigned oo[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+      const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
       const bool ok = nok && m < p.M;
       oo[r] = ok ? (unsigned)(m * p.ldo + n) * 4u : OOB;
       res[r] = 0.f;
@@ -214,13 +231,13 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
       const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.gate), 0, p.gate_bytes, 0x00020000);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+        const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * fh;
         gt[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, oo[r] == OOB ? OOB : (unsigned)(m * p.ldg + n) * 4u, 0, 0));
       }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float v = (F16 ? acc[j][r] * f16s::kUnscale : acc[j][r]) + bias + res[r];
+      float v = (F16 ? acc[i][j][r] * f16s::kUnscale : acc[i][j][r]) + bias + res[r];
       if (p.relu) v = fmaxf(v, 0.f) + (v - v);      // (a NaN stays a NaN: an operand beyond the f16 range must be loud)
       if (p.gate) v = gt[r] > 0.f ? v * p.gate_scale : 0.f;
       if (p.drop_thresh) v = dropout_keep(p.drop_seed, oo[r] >> 2, p.drop_thresh) ? v * p.drop_scale : 0.f;
@@ -262,19 +279,19 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
   }
 }
 
-template <bool F16, int TN, bool WPRE = false>
+template <bool F16, int TN, bool WPRE = false, int TM = 1>
 int launch_gemm(const GemmArgs &a, hipStream_t stream, int nz = 1) {
-  constexpr int BN = 64 * TN;
-  constexpr size_t smem = (size_t)2 * (2 * BM * 64 + 2 * BN * 64);
+  constexpr int BN = 64 * TN, BMT = 128 * TM;
+  constexpr size_t smem = (size_t)2 * (2 * BMT * 64 + 2 * BN * 64);
   static DeviceOnce attr_set;
   if (smem > 48 * 1024 && !attr_set.done()) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel<F16, TN, WPRE>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_split_kernel<F16, TN, WPRE, TM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return check_launch("hipFuncSetAttribute(gemm_split)");
     attr_set.mark();
   }
-  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_split_kernel<F16, TN, WPRE>), dim3(tiles, nz), dim3(512), smem, stream, a);
+  const int tiles = ((a.M + BMT - 1) / BMT) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_split_kernel<F16, TN, WPRE, TM>), dim3(tiles, nz), dim3(512), smem, stream, a);
   return check_launch("gemm_split_f32");
 }
 
@@ -339,6 +356,16 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   // 128 x 64 tiles when 128 x 128 ones would leave CUs without a second workgroup
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   const bool narrow = tiles128 < 512 || N % 128 != 0;
+  // 256 x 128 tiles (one workgroup per CU) where they come in whole rounds of the chip: the widest layers (measured at
+  // M = 8200, K = 512, tools/bench_linear.py with ISI_GEMM_NO_WIDE: N = 2048 (two rounds) 79 -> 70 us, N = 1024 (one round)
+  // 42 -> 40 us; N = 1536 (one and a half rounds) 63 -> 70 us: not taken)
+  const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128);
+  if (!narrow && nz == 1 && !g.win_rpu && tiles256 % current_device_cu_count() == 0 && !knobs().gemm_no_wide) {
+    if (split_mode == 3 && w16) return launch_gemm<true, 2, true, 2>(g, stream, nz);
+    if (split_mode == 3) return launch_gemm<true, 2, false, 2>(g, stream, nz);
+    if (w16) return launch_gemm<false, 2, true, 2>(g, stream, nz);
+    return launch_gemm<false, 2, false, 2>(g, stream, nz);
+  }
   if (split_mode == 3 && w16) return narrow ? launch_gemm<true, 1, true>(g, stream, nz) : launch_gemm<true, 2, true>(g, stream, nz);
   if (split_mode == 3) return narrow ? launch_gemm<true, 1>(g, stream, nz) : launch_gemm<true, 2>(g, stream, nz);
   if (w16) return narrow ? launch_gemm<false, 1, true>(g, stream, nz) : launch_gemm<false, 2, true>(g, stream, nz);

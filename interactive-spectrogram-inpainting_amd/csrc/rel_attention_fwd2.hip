@@ -86,8 +86,12 @@ template <int HD, int TERMS> struct Tile {
   // LDS rows are padded by 16 bytes instead of swizzled: consecutive rows start 4 banks (mod 64) apart for HD = 64 /
   // KT = 64 (stride 36 dwords), so the 16-lane groups of a ds_read_b128 (lane = row, same column) touch every bank once,
   // and the k-blocks of a row are reached by immediate offsets from one address register
-  static constexpr int KLD = HD + 8, VLD = KT + 8;                 // row strides of the [.][HD] and V^T planes (ushorts)
-  static constexpr size_t operand_bytes = (size_t)(2 * NPL * KT * KLD + 2 * NPL * VR * VLD + NPL * RING * KLD) * sizeof(unsigned short);
+  // V^T rows hold 64 keys (128 bytes; at KT = 32 both groups' tiles side by side) and are swizzled instead: the staging
+  // threads of a write instruction own rows 4 apart, which padding cannot spread (tools/probes/lds_conflict_probe.hip: 8-way
+  // on padded rows).  16-byte slot c of row d sits at c ^ f(d), f(d) = ((d >> 2) & 7) ^ ((d & 2) << 1): the 16-lane groups
+  // of ds_read_b128 (rows {0-3, 12-15, 20-27}, ...) see 16 distinct (row parity, slot) pairs, the writes are 2-way
+  static constexpr int KLD = HD + 8, VLD = 64, NVTL = KS / 64;     // row strides of the [.][HD] and V^T planes (ushorts); V^T tiles
+  static constexpr size_t operand_bytes = (size_t)(2 * NPL * KT * KLD + NVTL * NPL * VR * VLD + NPL * RING * KLD) * sizeof(unsigned short);
   static constexpr size_t smem = operand_bytes + (size_t)(8 * 32 * LD) * sizeof(float);
 };
 }  // namespace
@@ -115,8 +119,9 @@ __global__ __launch_bounds__(512) void rel_attn_fwd2_kernel(const AttnKArgs p, c
   static_assert(NK >= 1 && NVT <= 512 && NR * 512 == (RING - KS) * NQD, "staging roles");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned short *Kp = reinterpret_cast<unsigned short *>(smem);   // [group 2][plane][KT][KLD]
-  unsigned short *Vp = Kp + 2 * NPL * KT * KLD;                    // [group 2][plane][VR][VLD]
-  unsigned short *Ep = Vp + 2 * NPL * VR * VLD;                    // [plane][RING][KLD]
+  unsigned short *Vp = Kp + 2 * NPL * KT * KLD;                    // [64-key tile][plane][VR][64 keys], slots swizzled (Tile)
+  unsigned short *Ep = Vp + TL::NVTL * NPL * VR * VLD;             // [plane][RING][KLD]
+  auto vswz = [](int d) { return ((d >> 2) & 7) ^ ((d & 2) << 1); };
   float *Sr = reinterpret_cast<float *>(Ep + NPL * RING * KLD);    // [8][32][LD]; columns 0 .. 63 of a row are band rows
   // (last event of the key's sub-block) - event(key) for the KS keys of a step (general Ck only): in the padding column
   // 64 of the skew buffer's rows
@@ -144,13 +149,13 @@ __global__ __launch_bounds__(512) void rel_attn_fwd2_kernel(const AttnKArgs p, c
   const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(has_e ? p.e : p.q), 0, has_e ? p.e_bytes : 4u, 0x00020000);
 
   if (VR > HD) {   // rows of V^T beyond the head dim feed zero products
-    for (int i = tid; i < 2 * NPL * VR * VLD / 2; i += 512) reinterpret_cast<unsigned *>(Vp)[i] = 0u;
+    for (int i = tid; i < TL::NVTL * NPL * VR * VLD / 2; i += 512) reinterpret_cast<unsigned *>(Vp)[i] = 0u;
     __syncthreads();
   }
   if (grp == 1) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses issue arbitration otherwise (MI355X guide)
   const float qscale = p.scale * LOG2E;
   float *sr = Sr + wave * 32 * LD + ql * LD;
-  const unsigned short *Kb = Kp + (grp * NPL) * KT * KLD, *Vb = Vp + (grp * NPL) * VR * VLD;
+  const unsigned short *Kb = Kp + (grp * NPL) * KT * KLD;
   int evoff[16];
   if constexpr (!UNIT) {
 #pragma unroll
@@ -232,13 +237,13 @@ __global__ __launch_bounds__(512) void rel_attn_fwd2_kernel(const AttnKArgs p, c
     }
     if (tid < NVT) {   // V transposed: per dim the 4 keys of the block as one 8-byte unit
       const int kg = tid / NQD, qd = tid % NQD;
-      const int g = (4 * kg) / KT, u = kg % (KT / 4);
+      const int tile = kg / 16, u = kg % 16;            // 64-key tile of the step, 4-key unit inside it
       const int c = 2 * (u >> 2) + (u & 1), sub = (u >> 1) & 1;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int d = 4 * qd + e;
         const float a0 = elem(pv[0], e), a1 = elem(pv[1], e), a2 = elem(pv[2], e), a3 = elem(pv[3], e);
-        unsigned short *dst = Vp + ((g * NPL) * VR + d) * VLD + c * 8 + sub * 4;
+        unsigned short *dst = Vp + ((tile * NPL) * VR + d) * VLD + ((c ^ vswz(d)) * 8) + sub * 4;
         if constexpr (ONE) {
           *reinterpret_cast<uint2 *>(dst) = make_uint2(PR::pack2(a0, a1), PR::pack2(a2, a3));
         } else {
@@ -528,12 +533,16 @@ __global__ __launch_bounds__(512) void rel_attn_fwd2_kernel(const AttnKArgs p, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
           }
-          const unsigned short *vr = Vb + (d * 32 + ql) * VLD + 8 * half;
+          // this wave's 16 keys of k-step t inside the step: 64-key tile and 16-key group of it
+          const int ko = grp * KT + 32 * sb;
+          const unsigned short *vr = Vp + (((ko / 64) * NPL) * VR + d * 32 + ql) * VLD;
+          const int vx = vswz(ql);
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const s16x8_t vh = *reinterpret_cast<const s16x8_t *>(vr + 16 * (2 * sb + t));
+            const int c = 2 * (((ko % 64) >> 4) + t) + half;
+            const s16x8_t vh = *reinterpret_cast<const s16x8_t *>(vr + ((c ^ vx) * 8));
             if constexpr (!ONE) {
-              const s16x8_t vl = *reinterpret_cast<const s16x8_t *>(vr + VR * VLD + 16 * (2 * sb + t));
+              const s16x8_t vl = *reinterpret_cast<const s16x8_t *>(vr + VR * VLD + ((c ^ vx) * 8));
               O[d] = PR::mfma(vl, ph[t], O[d]);
               O[d] = PR::mfma(vh, pl[t], O[d]);
             }

@@ -197,6 +197,13 @@ class RelAttentionFn(torch.autograd.Function):
         d = a.shape[-1]
         return a, b[..., :d], b[..., d:]
 
+    _grad_mode = True      # torch.is_grad_enabled() at the time of `apply` (inside `forward` it is always off)
+
+    @classmethod
+    def apply(cls, *args):
+        cls._grad_mode = torch.is_grad_enabled()
+        return super().apply(*args)
+
     @staticmethod
     def forward(ctx, a, b, rel, nhead, Cq, Ck, Ek, mask_mode, dense_mask):
         a = a.contiguous()
@@ -205,7 +212,8 @@ class RelAttentionFn(torch.autograd.Function):
         Sq, B, _ = q.shape
         lse = torch.empty(B, nhead, Sq, dtype=torch.float32, device=q.device)
         # kept only when a backward will follow (under no_grad nothing needs a gradient)
-        logits = _ops.attention_logits_buffer(B, nhead, Sq, k.shape[0], q.device) if any(ctx.needs_input_grad[:3]) else None
+        keep = RelAttentionFn._grad_mode and any(ctx.needs_input_grad[:3])
+        logits = _ops.attention_logits_buffer(B, nhead, Sq, k.shape[0], q.device) if keep else None
         out = _ops.rel_attention(q, k, v, rel, nhead, Cq, Ck, Ek, mask_mode=mask_mode, dense_mask=dense_mask,
                                  lse=lse, logits=logits)
         ctx.cfg = (nhead, Cq, Ck, Ek, mask_mode, _ops.ATTENTION_PRECISION)

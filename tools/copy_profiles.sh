@@ -17,3 +17,9 @@ cp $O/pmc_hbm_traffic.json profiles/${R}_pmc_hbm_traffic.json
   echo "# 1 bf16x3, 2 bf16x6, 3 f16x3 (the default mode's kernels)."
   echo
   cat $O/pmc_sq_forward.txt; } > profiles/${R}_pmc_sq_forward.txt
+{ echo "# SQ counters of the attention kernels, B8 H8 S1025 hd64 causal, three-term (bf16x3) and single-term (bf16) products: two rocprofv3"
+  echo "# --kernel-trace --pmc passes of tools/bench_attention.py --modes 1 --precisions bf16x3 bf16 (tools/round_profiles.sh); per-dispatch"
+  echo "# means.  rel_attn_fwd2_kernel<HD, terms, f16, unit>: forward; *_split_kernel<HD, single-term, kept logits>: backward."
+  echo
+  cat $O/pmc_attention.txt; } > profiles/${R}_pmc_attention.txt
+hdr "rocprofv3 --kernel-trace -- python3 tools/bench_attention.py --modes 1 0 --precisions bf16x3   (attention op forward + backward, causal and unmasked)" $O/attention_kernel_trace.txt profiles/${R}_attention_kernel_trace.txt

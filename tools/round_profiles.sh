@@ -21,10 +21,16 @@ python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv" 
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_sq1 -- python3 bench.py --no-cpu-baseline --no-prior --no-train --steps 3 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/pmc_sq2 -- python3 bench.py --no-cpu-baseline --no-prior --no-train --steps 3 > /dev/null 2>&1
 python tools/pmc_sq_summary.py $(find $O/pmc_sq1 $O/pmc_sq2 -name "*counter_collection.csv") > $O/pmc_sq_forward.txt 2>&1
-python tools/bench_attention.py > $O/attention.txt 2>&1
+# SQ counters of the attention kernels (forward 64-key-tile kernels, backward with kept logits): two passes
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d $O/pmc_at1 -- python3 tools/bench_attention.py --modes 1 --precisions bf16x3 bf16 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $O/pmc_at2 -- python3 tools/bench_attention.py --modes 1 --precisions bf16x3 bf16 > /dev/null 2>&1
+python tools/pmc_sq_summary.py $(find $O/pmc_at1 $O/pmc_at2 -name "*counter_collection.csv") > $O/pmc_attention.txt 2>&1
+rocprofv3 --kernel-trace -d $O/kt_at -o at -- python3 tools/bench_attention.py --modes 1 0 --precisions bf16x3 > /dev/null 2>&1
+python tools/prof_summary.py $O/kt_at/at_results.db 0 > $O/attention_kernel_trace.txt 2>&1
+python tools/bench_attention.py --precisions f32 bf16x3 bf16 f16 > $O/attention.txt 2>&1
 python tools/bench_prior_train.py --batch 8 --steps 4 > $O/prior_train.txt 2>&1
 python tools/bench_train.py > $O/vqvae_train.txt 2>&1
 python tools/bench_prior.py > $O/prior_sampling.txt 2>&1
 python tools/bench_frontend.py > $O/frontend.txt 2>&1
-rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2     # the sqlite / csv dumps are large; the summaries are what is kept
+rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_at1 $O/pmc_at2     # the sqlite / csv dumps are large; the summaries are what is kept
 tail -c 600 $O/bench.json

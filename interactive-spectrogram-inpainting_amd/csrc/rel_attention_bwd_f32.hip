@@ -80,19 +80,20 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 }  // namespace
 
-// D[b,h,i] = sum_d dO[i,b,h,d] * O[i,b,h,d]
-__global__ void attn_dsum_kernel(const AttnBwdKArgs p, int HD) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.B * p.H * p.Sq) return;
-  const int i = idx % p.Sq, bh = idx / p.Sq, h = bh % p.H, b = bh / p.H;
-  const float *o = p.out + (size_t)i * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
-  const float *d = p.dout + (size_t)i * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh;
-  float s = 0.f;
-  for (int c = 0; c < HD; c += 4) {
-    const float4 a = *reinterpret_cast<const float4 *>(o + c), g = *reinterpret_cast<const float4 *>(d + c);
-    s += a.x * g.x + a.y * g.y + a.z * g.z + a.w * g.w;
-  }
-  p.dsum[idx] = s;
+// D[b,h,i] = sum_d dO[i,b,h,d] * O[i,b,h,d].  HD / 4 lanes per (b, h, i) row: a row's 16-byte pieces are consecutive lanes
+// (one thread per row read 256-byte rows with a stride of whole rows: 14.5 us for 2 x 16.8 MB at B8 H8 S1025 hd64)
+__global__ __launch_bounds__(256) void attn_dsum_kernel(const AttnBwdKArgs p, int HD) {
+  const int G = HD >> 2;                                   // 4, 8 or 16 lanes per row
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = t / G, c = (t % G) * 4;
+  const int n = p.B * p.H * p.Sq;
+  const int ic = min(idx, n - 1);                          // (whole lane groups stay active for the DPP sums)
+  const int i = ic % p.Sq, bh = ic / p.Sq, h = bh % p.H, b = bh / p.H;
+  const size_t off = (size_t)i * p.o_ss + (size_t)b * p.o_sb + (size_t)h * p.o_sh + c;
+  const float4 a = *reinterpret_cast<const float4 *>(p.out + off), g = *reinterpret_cast<const float4 *>(p.dout + off);
+  float s = (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
+  s = G == 16 ? row16_sum(s) : G == 8 ? group8_sum(s) : group4_sum(s);
+  if (idx < n && c == 0) p.dsum[idx] = s;
 }
 
 // ------------------------------------------------------------------ dQ and G
@@ -1757,7 +1758,7 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
   }
 
   const int nstat = g->B * g->H * g->Sq;
-  hipLaunchKernelGGL(attn_dsum_kernel, dim3((nstat + 255) / 256), dim3(256), 0, stream, a, HD);
+  hipLaunchKernelGGL(attn_dsum_kernel, dim3((unsigned)(((int64_t)nstat * (HD / 4) + 255) / 256)), dim3(256), 0, stream, a, HD);
   int rc = check_launch("attn_dsum");
   if (rc) return rc;
   const bool split = g->precision >= 1;

@@ -389,6 +389,18 @@ typedef struct isi_attn_bwd_args {
 size_t isi_rel_attention_bwd_workspace_floats(const isi_attn_args *fwd);
 int isi_rel_attention_bwd_f32(const isi_attn_bwd_args *args, void *stream);
 
+/* isi_layernorm_f32 / isi_layernorm_bwd_f32 with the dropout that precedes the residual add in the absent package's
+ * layers folded in (train mode): out = LayerNorm(drop(x) + residual), drop = inverted dropout whose keep mask is a
+ * counter-based hash of (drop_seed, flat element index) -- the same function the backward evaluates again, so no mask
+ * is stored and no dropout kernel runs.  The backward returns dz = d loss / d (drop(x) + residual) (the residual's
+ * gradient) and dx = the gradient of x (dz where kept, scaled by 1 / (1 - drop_p)).  drop_p = 0: the plain kernels. */
+int isi_layernorm_dropout_f32(const float *x, const float *residual, const float *gamma, const float *beta,
+                              float *out, int64_t M, int D, float eps, float drop_p, uint64_t drop_seed,
+                              void *stream);
+int isi_layernorm_dropout_bwd_f32(const float *x, const float *residual, const float *gamma, const float *dy,
+                                  float *dz, float *dx, float *dgamma, float *dbeta, float *workspace, int64_t M,
+                                  int D, float eps, float drop_p, uint64_t drop_seed, void *stream);
+
 /* One linear layer of the prior (`nn.Linear` inside the absent package's layers, priors/transformer.py:370-417): rows
  *   out[m, n] = sum_k x[m, k] w[n, k] + bias[n] (+ residual[m, n]) (ReLU) (gate) (dropout)
  * on the split-product GEMM kernel, with the element-wise tails of a training step folded into its epilogue:

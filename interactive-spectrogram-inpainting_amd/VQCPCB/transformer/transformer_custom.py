@@ -89,10 +89,13 @@ class _LayerNormParams(nn.Module):
         self.bias = nn.Parameter(torch.zeros(d))
         self.eps = eps
 
-    def run(self, x, residual=None):
-        """LayerNorm(x + residual)."""
+    def run(self, x, residual=None, dropout_p=0.0):
+        """LayerNorm(dropout(x) + residual); the dropout (train mode) runs inside the LayerNorm kernels."""
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            return _train.LayerNormFn.apply(x, residual, self.weight, self.bias, self.eps)
+            return _train.LayerNormFn.apply(x, residual, self.weight, self.bias, self.eps, dropout_p)
+        if dropout_p > 0.0:
+            return _ops.layernorm(x, self.weight, self.bias, self.eps, residual=residual, dropout_p=dropout_p,
+                                  dropout_seed_=_ops.dropout_seed())
         return _ops.layernorm(x, self.weight, self.bias, self.eps, residual=residual)
 
 
@@ -235,6 +238,10 @@ class RelativeMultiheadAttention(nn.Module):
 _FF_GATE = os.environ.get("ISI_FF_GATE", "1") != "0"
 
 
+# ISI_FUSED_DROPOUT=0: the layers' dropouts as torch's kernels (A/B switch)
+_FUSED_DROPOUT = os.environ.get("ISI_FUSED_DROPOUT", "1") != "0"
+
+
 def _drop(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
     if layer.training and layer.dropout > 0:
         return nn.functional.dropout(x, layer.dropout, True)
@@ -246,13 +253,11 @@ def _add_norm(layer: nn.Module, lin: _LinearParams, x: torch.Tensor, residual: t
     """norm(residual + dropout(lin(x))): the residual add rides in the GEMM epilogue when nothing is
     dropped, in the LayerNorm kernel otherwise.  `rectified_input`: x is a ReLU's output (_train.LinearFn)."""
     if layer.training and layer.dropout > 0:
-        return norm.run(nn.functional.dropout(lin.run(x, rectified_input=rectified_input, input_keep_scale=input_keep_scale),
-                                              layer.dropout, True), residual=residual)
+        y = lin.run(x, rectified_input=rectified_input, input_keep_scale=input_keep_scale)
+        if _FUSED_DROPOUT and y.numel() < (1 << 32):      # the dropout inside the LayerNorm kernels (forward and backward)
+            return norm.run(y, residual=residual, dropout_p=layer.dropout)
+        return norm.run(nn.functional.dropout(y, layer.dropout, True), residual=residual)
     return norm.run(lin.run(x, residual=residual, rectified_input=rectified_input))
-
-
-# ISI_FUSED_DROPOUT=0: the feed-forward block's dropout as torch's kernels (A/B switch)
-_FUSED_DROPOUT = os.environ.get("ISI_FUSED_DROPOUT", "1") != "0"
 
 
 def _feed_forward(layer: nn.Module, x: torch.Tensor, norm: _LayerNormParams) -> torch.Tensor:

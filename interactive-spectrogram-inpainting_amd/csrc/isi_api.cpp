@@ -264,6 +264,15 @@ int isi_label_smoothing_loss_f32(const float *logits, const int64_t *target, flo
                                  int K, int num_classes, float smoothing, float grad_scale, void *stream) {
   return label_smoothing_loss_f32(logits, target, row_loss, dlogits, M, K, num_classes, smoothing, grad_scale, S(stream));
 }
+int isi_layernorm_dropout_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *out,
+                              int64_t M, int D, float eps, float drop_p, uint64_t drop_seed, void *stream) {
+  return layernorm_f32(x, residual, gamma, beta, out, M, D, eps, S(stream), drop_p, drop_seed);
+}
+int isi_layernorm_dropout_bwd_f32(const float *x, const float *residual, const float *gamma, const float *dy, float *dz,
+                                  float *dx, float *dgamma, float *dbeta, float *workspace, int64_t M, int D, float eps,
+                                  float drop_p, uint64_t drop_seed, void *stream) {
+  return layernorm_bwd_f32(x, residual, gamma, dy, dz, dgamma, dbeta, workspace, M, D, eps, S(stream), dx, drop_p, drop_seed);
+}
 int isi_layernorm_f32(const float *x, const float *residual, const float *gamma, const float *beta, float *out,
                       int64_t M, int D, float eps, void *stream) {
   return layernorm_f32(x, residual, gamma, beta, out, M, D, eps, S(stream));

@@ -75,11 +75,11 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *g, hipStream_t stream);
 size_t layernorm_bwd_workspace_floats(int64_t M, int D);
 int layernorm_bwd_f32(const float *x, const float *res, const float *gamma, const float *dy, float *dz,
                       float *dgamma, float *dbeta, float *workspace, int64_t M, int D, float eps,
-                      hipStream_t stream);
+                      hipStream_t stream, float *dx = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0);
 int label_smoothing_loss_f32(const float *logits, const int64_t *target, float *row_loss, float *dlogits, int64_t M,
                              int K, int num_classes, float smoothing, float grad_scale, hipStream_t stream);
 int layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,
-                  int64_t M, int D, float eps, hipStream_t stream);
+                  int64_t M, int D, float eps, hipStream_t stream, float drop_p = 0.f, uint64_t drop_seed = 0);
 int linear_rows_f32(const float *x, int x_stride, const float *W, const float *bias, const float *res,
                     int res_stride, float *out, int out_stride, int M, int N, int K, int relu,
                     hipStream_t stream);

@@ -29,11 +29,14 @@ __device__ __forceinline__ float wave_max(float v) {
 // z = x + res ; xhat = (z - mean) * rstd ; y = xhat * gamma + beta
 // dz = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
 // partial[blk][0][c] = sum over the block's rows of dy * xhat ; partial[blk][1][c] = sum of dy
+// With a fused dropout (drop_thresh != 0: z = drop(x) + res, transformer_ops.hip) the mask is formed again from (seed, index)
+// and the gradient of x -- dz where the element was kept, times the inverse keep probability -- goes to `dx`.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ x, const float *__restrict__ res,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ dy, float *__restrict__ dz,
                                                             float *__restrict__ partial, int M, int D, float eps,
-                                                            int rows_per_block) {
+                                                            int rows_per_block, float *__restrict__ dx,
+                                                            unsigned drop_thresh, float drop_scale, uint64_t seed) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = D >> 2;
@@ -59,6 +62,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
       if (qd < nq) {
         t = xr[qd];
+        if (drop_thresh) {
+          const unsigned e0 = (unsigned)row * (unsigned)D + 4u * qd;
+          t.x = dropout_keep(seed, e0, drop_thresh) ? t.x * drop_scale : 0.f;
+          t.y = dropout_keep(seed, e0 + 1, drop_thresh) ? t.y * drop_scale : 0.f;
+          t.z = dropout_keep(seed, e0 + 2, drop_thresh) ? t.z * drop_scale : 0.f;
+          t.w = dropout_keep(seed, e0 + 3, drop_thresh) ? t.w * drop_scale : 0.f;
+        }
         if (rr) { const float4 w = rr[qd]; t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w; }
         u = gr[qd];
         sum += (t.x + t.y) + (t.z + t.w);
@@ -103,6 +113,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
         o.x = rstd * (g[i].x - s1 - v[i].x * s2); o.y = rstd * (g[i].y - s1 - v[i].y * s2);
         o.z = rstd * (g[i].z - s1 - v[i].z * s2); o.w = rstd * (g[i].w - s1 - v[i].w * s2);
         orow[qd] = o;
+        if (drop_thresh) {
+          const unsigned e0 = (unsigned)row * (unsigned)D + 4u * qd;
+          float4 m;
+          m.x = dropout_keep(seed, e0, drop_thresh) ? o.x * drop_scale : 0.f;
+          m.y = dropout_keep(seed, e0 + 1, drop_thresh) ? o.y * drop_scale : 0.f;
+          m.z = dropout_keep(seed, e0 + 2, drop_thresh) ? o.z * drop_scale : 0.f;
+          m.w = dropout_keep(seed, e0 + 3, drop_thresh) ? o.w * drop_scale : 0.f;
+          reinterpret_cast<float4 *>(dx + (size_t)row * D)[qd] = m;
+        }
       }
     }
   }
@@ -163,7 +182,15 @@ size_t layernorm_bwd_workspace_floats(int64_t M, int D) { return M > 0 ? (size_t
 
 int layernorm_bwd_f32(const float *x, const float *res, const float *gamma, const float *dy, float *dz,
                       float *dgamma, float *dbeta, float *workspace, int64_t M, int D, float eps,
-                      hipStream_t stream) {
+                      hipStream_t stream, float *dx, float drop_p, uint64_t drop_seed) {
+  unsigned thresh = 0; float scale = 1.f;
+  if (drop_p != 0.f) {
+    if (!(drop_p > 0.f && drop_p < 1.f) || M * D > ((int64_t)1 << 32) || !dx || (reinterpret_cast<uintptr_t>(dx) & 15))
+      return invalid("layernorm_bwd: dropout needs 0 <= p < 1, fewer than 2^32 elements and a 16-byte aligned dx");
+    const double t = (double)drop_p * 4294967296.0;
+    thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (t < 1.0 ? 1u : (unsigned)t);
+    scale = 1.f / (1.f - drop_p);
+  }
   if (!x || !gamma || !dy || !dz || !dgamma || !dbeta || !workspace || M <= 0 || M > INT32_MAX || D <= 0)
     return invalid("layernorm_bwd: bad argument");
   if ((D & 3) || D > 2048) return unsupported("layernorm_bwd: need D % 4 == 0 and D <= 2048");
@@ -173,7 +200,7 @@ int layernorm_bwd_f32(const float *x, const float *res, const float *gamma, cons
   const int nblk = ln_bwd_blocks(M);
   const int rpb = (int)((M + nblk - 1) / nblk);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * D * sizeof(float), stream, x, res,
-                     gamma, dy, dz, workspace, (int)M, D, eps, rpb);
+                     gamma, dy, dz, workspace, (int)M, D, eps, rpb, dx, thresh, scale, drop_seed);
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, stream, workspace, dgamma,

@@ -8,12 +8,14 @@
 
 namespace isi {
 
-// out[m,:] = LayerNorm(x[m,:] + res[m,:]) * gamma + beta ; one wave per row.
+// out[m,:] = LayerNorm(drop(x[m,:]) + res[m,:]) * gamma + beta ; one wave per row.  drop = inverted dropout with the
+// keep mask dropout_keep(seed, m D + c) (isi_internal.h: a hash, nothing stored); drop_thresh = 0: the identity.
 __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float *__restrict__ x,
                                                             const float *__restrict__ res,
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta,
-                                                            float *__restrict__ out, int M, int D, float eps) {
+                                                            float *__restrict__ out, int M, int D, float eps,
+                                                            unsigned drop_thresh, float drop_scale, uint64_t seed) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -29,6 +31,13 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float *__restr
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qd < nq) {
       t = reinterpret_cast<const float4 *>(xr)[qd];
+      if (drop_thresh) {
+        const unsigned e0 = (unsigned)row * (unsigned)D + 4u * qd;
+        t.x = dropout_keep(seed, e0, drop_thresh) ? t.x * drop_scale : 0.f;
+        t.y = dropout_keep(seed, e0 + 1, drop_thresh) ? t.y * drop_scale : 0.f;
+        t.z = dropout_keep(seed, e0 + 2, drop_thresh) ? t.z * drop_scale : 0.f;
+        t.w = dropout_keep(seed, e0 + 3, drop_thresh) ? t.w * drop_scale : 0.f;
+      }
       if (rr) {
         const float4 u = reinterpret_cast<const float4 *>(rr)[qd];
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
@@ -69,15 +78,27 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float *__restr
   }
 }
 
+static bool dropout_args(float p, int64_t M, int D, unsigned *thresh, float *scale) {
+  *thresh = 0; *scale = 1.f;
+  if (p == 0.f) return true;
+  if (!(p > 0.f && p < 1.f) || M * D > ((int64_t)1 << 32)) return false;
+  const double t = (double)p * 4294967296.0;
+  *thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (t < 1.0 ? 1u : (unsigned)t);
+  *scale = 1.f / (1.f - p);
+  return true;
+}
+
 int layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta, float *out,
-                  int64_t M, int D, float eps, hipStream_t stream) {
+                  int64_t M, int D, float eps, hipStream_t stream, float drop_p, uint64_t drop_seed) {
   if (!x || !gamma || !beta || !out || M <= 0 || D <= 0) return invalid("layernorm: bad argument");
+  unsigned thresh; float scale;
+  if (!dropout_args(drop_p, M, D, &thresh, &scale)) return invalid("layernorm: dropout needs 0 <= p < 1 and fewer than 2^32 elements");
   if ((D & 3) || D > 2048) return unsupported("layernorm: need D % 4 == 0 and D <= 2048");
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(res) | reinterpret_cast<uintptr_t>(gamma) |
        reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(out)) & 15)
     return invalid("layernorm: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, res, gamma,
-                     beta, out, (int)M, D, eps);
+                     beta, out, (int)M, D, eps, thresh, scale, drop_seed);
   return check_launch("layernorm_f32");
 }
 

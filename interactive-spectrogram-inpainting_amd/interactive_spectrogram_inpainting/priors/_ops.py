@@ -210,13 +210,21 @@ def linear_rows(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tens
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
-              residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+              residual: Optional[torch.Tensor] = None, dropout_p: float = 0.0, dropout_seed_: int = 0) -> torch.Tensor:
+    """LayerNorm(drop(x) + residual); `dropout_p` > 0: the inverted dropout of x inside the kernel (mask = hash of (seed,
+    element index), isi_layernorm_dropout_f32)."""
     _hip.require_gpu(x, "layernorm input")
     x = x.contiguous()
     D = x.shape[-1]
     out = torch.empty_like(x)
     if residual is not None:
         residual = residual.contiguous()
+    if dropout_p > 0.0:
+        rc = _hip.lib().isi_layernorm_dropout_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                                  gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), x.numel() // D, D,
+                                                  eps, float(dropout_p), int(dropout_seed_), _s(x))
+        _hip.check(rc, "isi_layernorm_dropout_f32")
+        return out
     rc = _hip.lib().isi_layernorm_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None,
                                       gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), x.numel() // D, D,
                                       eps, _s(x))

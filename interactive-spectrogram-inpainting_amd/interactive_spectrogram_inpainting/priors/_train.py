@@ -153,14 +153,17 @@ class CrossInProjFn(torch.autograd.Function):
 
 
 class LayerNormFn(torch.autograd.Function):
-    """LayerNorm(x + residual) * gamma + beta over the last dimension."""
+    """LayerNorm(drop(x) + residual) * gamma + beta over the last dimension.  `dropout_p` > 0 (train mode): the inverted
+    dropout of x inside the LayerNorm kernels (mask = hash of (seed, index): no mask tensor, no dropout launches); the
+    backward returns the masked, rescaled gradient for x and the plain one for the residual."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, eps: float):
+    def forward(ctx, x, residual, gamma, beta, eps: float, dropout_p: float = 0.0):
         x = x.contiguous()
         if residual is not None:
             residual = residual.contiguous()
-        y = _ops.layernorm(x, gamma, beta, eps, residual=residual)
+        ctx.drop = (float(dropout_p), _ops.dropout_seed() if dropout_p > 0.0 else 0)
+        y = _ops.layernorm(x, gamma, beta, eps, residual=residual, dropout_p=ctx.drop[0], dropout_seed_=ctx.drop[1])
         ctx.eps = eps
         ctx.save_for_backward(x, residual, gamma)
         return y
@@ -176,11 +179,19 @@ class LayerNormFn(torch.autograd.Function):
         dg = torch.empty(D, dtype=torch.float32, device=x.device)
         db = torch.empty(D, dtype=torch.float32, device=x.device)
         ws = torch.empty(L.isi_layernorm_bwd_workspace_floats(M, D), dtype=torch.float32, device=x.device)
+        p, seed = ctx.drop
+        if p > 0.0:
+            dx = torch.empty_like(x)
+            rc = L.isi_layernorm_dropout_bwd_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                                 gamma.data_ptr(), dy.data_ptr(), dz.data_ptr(), dx.data_ptr(), dg.data_ptr(),
+                                                 db.data_ptr(), ws.data_ptr(), M, D, ctx.eps, p, seed, _s(x))
+            _hip.check(rc, "isi_layernorm_dropout_bwd_f32")
+            return dx, (dz if residual is not None else None), dg, db, None, None
         rc = L.isi_layernorm_bwd_f32(x.data_ptr(), residual.data_ptr() if residual is not None else None,
                                      gamma.data_ptr(), dy.data_ptr(), dz.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                      ws.data_ptr(), M, D, ctx.eps, _s(x))
         _hip.check(rc, "isi_layernorm_bwd_f32")
-        return dz, (dz if residual is not None else None), dg, db, None
+        return dz, (dz if residual is not None else None), dg, db, None, None
 
 
 class RelAttentionFn(torch.autograd.Function):

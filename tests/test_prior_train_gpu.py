@@ -599,3 +599,40 @@ def test_feed_forward_fused_dropout():
     torch.manual_seed(5)
     h3 = l1.run(x, relu=True, grad_pre_gated=True, dropout_p=p).detach()
     assert not torch.equal(h1 != 0, h2 != 0) and torch.equal(h1, h3)
+
+
+def test_layernorm_fused_dropout():
+    """LayerNorm(dropout(x) + residual) with the dropout inside the kernels (isi_layernorm_dropout_f32 / _bwd_f32): the
+    output and every gradient against fp64 autograd with the same mask (read off the x gradient's zeros), the kept
+    fraction, mask reproducibility under torch.manual_seed."""
+    from interactive_spectrogram_inpainting.priors import _train as PT
+    dev = _dev()
+    torch.manual_seed(21)
+    M, D, p = 777, 512, 0.3
+    x = torch.randn(M, D, device=dev, requires_grad=True)
+    r = torch.randn(M, D, device=dev, requires_grad=True)
+    g = (torch.rand(D, device=dev) + 0.5).requires_grad_(True)
+    b = torch.randn(D, device=dev, requires_grad=True)
+    w = torch.randn(M, D, device=dev)
+    torch.manual_seed(3)
+    y = PT.LayerNormFn.apply(x, r, g, b, 1e-5, p)
+    (y * w).sum().backward()
+    kept = x.grad != 0                                   # (a kept element's gradient is exactly 0 with probability 0)
+    frac = 1.0 - kept.double().mean().item()
+    assert abs(frac - p) < 0.01, frac
+    xr, rr = x.detach().double().requires_grad_(True), r.detach().double().requires_grad_(True)
+    gr, br = g.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr * kept.double() / (1 - p) + rr, (D,), gr, br, 1e-5)
+    (yr * w.double()).sum().backward()
+    for got, ref, name in ((y, yr, "y"), (x.grad, xr.grad, "dx"), (r.grad, rr.grad, "dres"), (g.grad, gr.grad, "dgamma"),
+                           (b.grad, br.grad, "dbeta")):
+        err = float((got.detach().double() - ref.detach()).abs().max() / ref.detach().abs().max())
+        assert err < 2e-5, (name, err)
+    torch.manual_seed(3)
+    y2 = PT.LayerNormFn.apply(x, r, g, b, 1e-5, p)
+    y3 = PT.LayerNormFn.apply(x, r, g, b, 1e-5, p)
+    assert torch.equal(y2, y) and not torch.equal(y3, y)
+    # p = 0 is the plain kernel
+    y0 = PT.LayerNormFn.apply(x, r, g, b, 1e-5, 0.0)
+    ref0 = torch.nn.functional.layer_norm(x.detach().double() + r.detach().double(), (D,), g.detach().double(), b.detach().double(), 1e-5)
+    assert float((y0.double() - ref0).abs().max()) < 1e-4

@@ -209,6 +209,7 @@ class RelAttentionFn(torch.autograd.Function):
         return a, b[..., :d], b[..., d:]
 
     _grad_mode = True      # torch.is_grad_enabled() at the time of `apply` (inside `forward` it is always off)
+    workspace_fill = None  # tests: value the backward's workspace (G, partial sums) is filled with before the call
 
     @classmethod
     def apply(cls, *args):
@@ -260,6 +261,8 @@ class RelAttentionFn(torch.autograd.Function):
         a.d_rel = drel.data_ptr() if drel is not None else None
         nws = L.isi_rel_attention_bwd_workspace_floats(C.byref(a.fwd))
         ws = torch.empty(nws, dtype=torch.float32, device=q.device)
+        if RelAttentionFn.workspace_fill is not None:      # tests: poison what the kernels must not read before writing
+            ws.fill_(RelAttentionFn.workspace_fill)
         a.workspace, a.workspace_floats = ws.data_ptr(), nws
         _hip.check(L.isi_rel_attention_bwd_f32(C.byref(a), _s(q)), "isi_rel_attention_bwd_f32")
         return da, db, drel, None, None, None, None, None, None

@@ -636,3 +636,39 @@ def test_layernorm_fused_dropout():
     y0 = PT.LayerNormFn.apply(x, r, g, b, 1e-5, 0.0)
     ref0 = torch.nn.functional.layer_norm(x.detach().double() + r.detach().double(), (D,), g.detach().double(), b.detach().double(), 1e-5)
     assert float((y0.double() - ref0).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("Sq,Sk,mode", [(1025, 1025, 1), (1025, 1025, 0), (300, 300, 2), (513, 640, 0)])
+@pytest.mark.parametrize("keep_logits", [True, False])
+def test_attention_backward_with_poisoned_workspace(Sq, Sk, mode, keep_logits, monkeypatch):
+    """G is zeroed only in the margins of its band (kMargin columns either side) and its band is stored whole by the
+    kernels: with the workspace filled with NaN before the call, the gradients must be finite and equal to those
+    of the full zero-fill (ISI_ATTN_FULL_ZERO=1) -- both with the forward's logits kept (the key-stationary kernel stores
+    dS into G, the query-stationary one reads it back) and with everything recomputed."""
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.priors import _ops, _train as PT
+    monkeypatch.setattr(_ops, "SAVE_ATTENTION_LOGITS", keep_logits)
+    monkeypatch.setattr(_ops, "ATTENTION_PRECISION", "bf16x3")
+    dev = _dev()
+    torch.manual_seed(Sq + mode)
+    H, hd, B = 4, 64, 3
+    d = H * hd
+    q = torch.randn(Sq, B, d, device=dev, requires_grad=True)
+    kv = torch.randn(Sk, B, 2 * d, device=dev, requires_grad=True)
+    rel = (torch.randn(H, Sq + Sk - 1, hd, device=dev) * 0.3).requires_grad_(True)
+    w = torch.randn(Sq, B, d, device=dev)
+
+    def grads(fill, full_zero):
+        for t in (q, kv, rel):
+            t.grad = None
+        monkeypatch.setattr(PT.RelAttentionFn, "workspace_fill", fill)
+        with _hip.knob("ISI_ATTN_FULL_ZERO", full_zero):
+            out = PT.RelAttentionFn.apply(q, kv, rel, H, 1, 1, Sk, mode, None)
+            (out * w).sum().backward()
+        return [t.grad.clone() for t in (q, kv, rel)]
+    ref = grads(None, 1)
+    got = grads(float("nan"), 0)
+    for a, b, name in zip(got, ref, ("dq", "dkv", "drel")):
+        assert torch.isfinite(a).all(), name
+        # the sums over key groups are float atomics: their order, not their terms, differs from run to run
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), name

@@ -356,11 +356,34 @@ def _prior_training(device, dist=None, world=1, B=8, steps=3, warmup=2):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(((hi - lo).abs() <= 1e-6 * hi.abs().clamp(min=1e-12)).all())
     assert torch.isfinite(loss).all()
+    loss = None        # (an eager step's autograd graph kept alive keeps its AccumulateGrad nodes on the eager stream)
     dt /= steps
+    graphed_ms = None
+    if world == 1:
+        # the same step recorded into a HIP graph and replayed (utils/training/graphed_step.py): the host's ~1300 launches per
+        # step become one; a fresh optimizer (capturable) on the same model
+        from interactive_spectrogram_inpainting.priors import _ops as _prior_ops
+        from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+        opt = make_adam(m.parameters(), lr=3e-4, capturable=True)
+        graphed = GraphedTrainingStep(lambda c, k: step(), (code, mask), warmup=2, index_limits={0: 512})
+        try:
+            graphed(code, mask)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                gl = graphed(code, mask)
+            barrier()
+            graphed_ms = (time.perf_counter() - t0) / steps * 1e3
+            assert torch.isfinite(gl).all()
+            graphed.finish()
+        finally:
+            _prior_ops.set_dropout_seed_base(None)
+        del graphed
     out = {"value": round(world * B * 1024 / dt, 0), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 1),
            "tokens_per_s": round(world * B * 1024 / dt, 0), "codemaps_per_s": round(world * B / dt, 1),
            "n_gpus": world, "steps": steps, "warmup": warmup, "global_batch": world * B, "scaling": "weak",
            "ranks_in_sync": in_sync,
+           "ms_per_step_hip_graph": round(graphed_ms, 1) if graphed_ms is not None else None,
            "collectives_per_step": (f"{len(reducer.buckets)} gradient buckets ({reducer.flat.numel() * 4 / 1e6:.1f} MB fp32 in "
                                     f"total), all-reduced while the backward runs") if reducer is not None else "none (1 rank)",
            "config": f"top prior [32,32], B={B}/GPU x 1025 tokens, d_model 512, 6+8 layers, 8 heads, fp32, Adam, "

@@ -401,6 +401,12 @@ int isi_layernorm_dropout_bwd_f32(const float *x, const float *residual, const f
                                   float *dz, float *dx, float *dgamma, float *dbeta, float *workspace, int64_t M,
                                   int D, float eps, float drop_p, uint64_t drop_seed, void *stream);
 
+/* A device-resident 64-bit term added to the seed of every fused dropout (the linear layer's epilogue, the LayerNorm
+ * kernels): a training step replayed from a HIP graph carries its seeds as launch constants, so the owner of the graph
+ * advances this counter between replays (one element-wise add inside the graph) to draw fresh masks per step.  The
+ * forward and backward launches of one step read the same value.  NULL (the default) = no such term.  Process-wide. */
+int isi_set_dropout_seed_base(const void *device_u64);
+
 /* One linear layer of the prior (`nn.Linear` inside the absent package's layers, priors/transformer.py:370-417): rows
  *   out[m, n] = sum_k x[m, k] w[n, k] + bias[n] (+ residual[m, n]) (ReLU) (gate) (dropout)
  * on the split-product GEMM kernel, with the element-wise tails of a training step folded into its epilogue:

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "isi_common.h"
 #include "isi_internal.h"
@@ -51,13 +52,14 @@ struct GemmArgs {
   unsigned drop_thresh;   // fused inverted dropout: keep where dropout_keep(seed, m ldo + n, thresh); 0 = none
   float drop_scale;
   uint64_t drop_seed;
+  const uint64_t *drop_base;   // device-resident term of the seed (dropout_seed_base(); nullptr: none)
 };
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr int BM = 128;
 constexpr int kGemmTailRows = 16;   // M % BM up to this many rows: no tile row of their own (gemm_split_f32 below)
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, unsigned uniform_off = 0) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, uniform_off, 0);
   return *reinterpret_cast<float4 *>(&v);
 }
 __device__ __forceinline__ int swz(int row, int slot) { return (slot ^ ((row >> 2) & 3)) * 16; }
@@ -73,6 +75,15 @@ __device__ __forceinline__ f32x16 mfma(const s16x8g a, const s16x8g b, const f32
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// phase timestamps (-DISI_MEASURE builds; tools/stamps_gemm.py): workgroup 8, waves 0 and 1
+#ifdef ISI_MEASURE
+__device__ long long g_gemm_stamps[512];
+#define ISI_GEMM_STAMP(i_) do { if (blockIdx.x == 8 && wave < 2 && lane == 0 && (i_) < 256) \
+    g_gemm_stamps[wave * 256 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ISI_GEMM_STAMP(i_) do { } while (0)
+#endif
+
 // TN: 32-column tiles per wave (tile width BN = 64 TN).  WPRE: `w` is the weight's pair copy in the product mode's
 // pieces (ISI_CONV_W16: groups of 8 k as {hi[8] | lo[8]}, 32 bytes where the 8 floats were) -- a 16-byte piece IS a slot of
 // the LDS planes, so the weight tile is staged by plain copies: every 128-row tile of the fp32 form converts its
@@ -81,8 +92,10 @@ __device__ __forceinline__ f32x16 mfma(const s16x8g a, const s16x8g b, const f32
 // instructions per 16 fragment reads and chunk instead of 12 per 12 (the 128 x 128 form is co-limited by LDS traffic,
 // staging conversions and the vector-memory path, each about as long as its matrix work); 96 KB of LDS, one workgroup per
 // CU: the wide layers (N >= 1024) whose tile count still fills the chip.
+// TM = 2, TN = 4: a 256 x 256 tile, wave tile 64 x 128 -- 48 matrix instructions per 24 fragment reads and chunk; 128 KB
+// of LDS, the whole register file of two waves per SIMD: the widest layers when they come as ONE round of such tiles.
 template <bool F16, int TN, bool WPRE = false, int TM = 1>
-__global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, (TM * TN >= 4 ? 2 : 4)) void gemm_split_kernel(GemmArgs p) {
   constexpr int BN = 64 * TN, BM = 128 * TM;
   if (blockIdx.y) {      // a batch of products: this one's operands
     const size_t z = blockIdx.y;
@@ -95,14 +108,18 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ISI_GEMM_STAMP(0);
   const int wm0 = (wave & 3) * (32 * TM), wn0 = (wave >> 2) * (32 * TN);
   const int fr = lane & 31, fh = lane >> 5;
   // consecutive workgroups walk the M tiles of one column block: they share the block's weights in L2
   const int tiles_m = (p.M + BM - 1) / BM;
   const int m0 = ((int)blockIdx.x % tiles_m) * BM, n0 = ((int)blockIdx.x / tiles_m) * BN;
 
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a), 0, p.a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, p.w_bytes, 0x00020000);
+  // (the operands' extents as constants: rows beyond them carry the out-of-range offset OOB, every other row's chunks lie
+  // inside -- with the byte counts read from the arguments the compiler re-loaded them, and waited for every outstanding
+  // LDS read with them, in front of each group of loads)
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, OOB, 0x00020000);
 
   // staging roles: float4 number tid + 512 j of the chunk: row = (tid + 512 j) / 8, quad = tid % 8 (8 lanes = one
   // 128-byte row segment)
@@ -119,16 +136,24 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
     boff[j] = n < p.N ? (unsigned)(n * p.K + sq * 4) * 4u : OOB;
   }
   float4 pa[NA], pb[NB];
-  auto load_chunk = [&](int k0) {
+  // The next chunk travels in TN groups of pieces (group g: A pieces g NA / TN .., B piece g): requested one group after
+  // each column tile's matrix instructions of the chunk's first half, converted and written to the other stage one group
+  // after each column tile's of the second half.  (All eight loads of a 256 x 256 tile's thread issued back to back took 900
+  // cycles to issue -- 16 waves x 8 KB through the 64 B/clk vector-memory path -- and the wave then waited ~2000 cycles for
+  // the last of them in front of its LDS stores: 5600 cycles per chunk where the matrix work is 3072, tools/stamps_gemm.py.)
+  constexpr int APG = NA / TN;
+  static_assert(NA % TN == 0 && NB == TN, "pieces per group");
+  auto load_group = [&](int k0, int g) {
 #pragma unroll
-    for (int j = 0; j < NA; ++j) pa[j] = buf_load4(ra, aoff[j] == OOB ? OOB : aoff[j] + (unsigned)k0 * 4u);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) pb[j] = buf_load4(rw, boff[j] == OOB ? OOB : boff[j] + (unsigned)k0 * 4u);
+    // (the chunk's offset travels in the instruction's scalar offset, which the range check ignores: a row beyond the
+    // operand keeps its out-of-range vector offset, and no address is recomputed per load)
+    for (int j = g * APG; j < (g + 1) * APG; ++j) pa[j] = buf_load4(ra, aoff[j], (unsigned)k0 * 4u);
+    pb[g] = buf_load4(rw, boff[g], (unsigned)k0 * 4u);
   };
-  auto store_chunk = [&](int stage) {
+  auto store_group = [&](int stage, int g) {
     unsigned char *st = smem + stage * STAGE;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
+    for (int j = g * APG; j < (g + 1) * APG; ++j) {
       const int row = sr + 64 * j;
       uint2 hi, lo;
       split_pieces<F16>(pa[j], f16s::kScaleA, hi, lo);
@@ -136,14 +161,13 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
       *reinterpret_cast<uint2 *>(st + o) = hi;
       *reinterpret_cast<uint2 *>(st + APL + o) = lo;
     }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int row = sr + 64 * j;
+    {
+      const int row = sr + 64 * g;
       if constexpr (WPRE) {   // piece sq of the row's 128 bytes: group sq / 2, plane sq % 2
-        *reinterpret_cast<float4 *>(st + 2 * APL + (sq & 1) * BPL + row * 64 + swz(row, sq >> 1)) = pb[j];
+        *reinterpret_cast<float4 *>(st + 2 * APL + (sq & 1) * BPL + row * 64 + swz(row, sq >> 1)) = pb[g];
       } else {
         uint2 hi, lo;
-        split_pieces<F16>(pb[j], f16s::kScaleB, hi, lo);
+        split_pieces<F16>(pb[g], f16s::kScaleB, hi, lo);
         const int o = row * 64 + swz(row, sq >> 1) + (sq & 1) * 8;
         *reinterpret_cast<uint2 *>(st + 2 * APL + o) = hi;
         *reinterpret_cast<uint2 *>(st + 2 * APL + BPL + o) = lo;
@@ -169,42 +193,78 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
     c_lo = min(c_lo, c_hi);
   }
   if (c_lo < c_hi) {
-    load_chunk(32 * c_lo);
-    store_chunk(0);
+#pragma unroll
+    for (int g = 0; g < TN; ++g) load_group(32 * c_lo, g);
+#pragma unroll
+    for (int g = 0; g < TN; ++g) {
+      store_group(0, g);
+      if (c_lo + 1 < c_hi) load_group(32 * (c_lo + 1), g);
+    }
   }
   __syncthreads();
-  for (int c = c_lo; c < c_hi; ++c) {
-    const bool more = c + 1 < c_hi;
-    if (more) load_chunk(32 * (c + 1));
-    const unsigned char *st = smem + ((c - c_lo) & 1) * STAGE;
+  ISI_GEMM_STAMP(1);
+  // A chunk = 2 TN units (k half s, column tile j) of 3 TM matrix instructions.  The fragments of unit u + 1 are read
+  // from LDS before unit u's matrix instructions are issued (two fragment sets); behind unit (1, j) the next chunk's
+  // group j of pieces is written to the other stage and, into the registers this frees, the chunk after that is requested:
+  // a request has a whole chunk's matrix work to come back (with half a chunk, a 256 x 256 tile's second half waited:
+  // 2500 cycles against 1300 for the first).  (With each unit reading its own fragments first, a
+  // wave's chain per unit was LDS latency + matrix time: 2400 cycles per half chunk where the matrix work of the SIMD's two
+  // waves is 1536, tools/stamps_gemm.py.)
+  s16x8g ah[2][TM], al[2][TM], bh[2], bl[2];
+  auto read_a = [&](const unsigned char *st, int s) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      s16x8g ah[TM], al[TM];
+    for (int i = 0; i < TM; ++i) {
+      const int arow = wm0 + 32 * i + fr;
+      const int ao = arow * 64 + swz(arow, 2 * s + fh);
+      ah[s][i] = *reinterpret_cast<const s16x8g *>(st + ao);
+      al[s][i] = *reinterpret_cast<const s16x8g *>(st + APL + ao);
+    }
+  };
+  auto read_b = [&](const unsigned char *st, int s, int j, int slot) {
+    const int brow = wn0 + 32 * j + fr;
+    const int bo = brow * 64 + swz(brow, 2 * s + fh);
+    bh[slot] = *reinterpret_cast<const s16x8g *>(st + 2 * APL + bo);
+    bl[slot] = *reinterpret_cast<const s16x8g *>(st + 2 * APL + BPL + bo);
+  };
+  // (No branch inside a chunk: behind one the compiler's wait counts fall back to "every request", and each group then
+  // waited for the loads issued just before it.  The last chunk is peeled; the chunk before it requests the last one once
+  // more instead of nothing.)
+  auto chunk = [&](const int c, auto last) {
+    constexpr bool LAST = decltype(last)::value;
+    ISI_GEMM_STAMP(4 + 4 * (c - c_lo));
+    const unsigned char *st = smem + ((c - c_lo) & 1) * STAGE;
+    const int k0_next = 32 * min(c + 2, c_hi - 1);
+    read_a(st, 0);
+    read_b(st, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 2 * TN; ++u) {
+      const int s = u / TN, j = u % TN;
+      if (u + 1 < 2 * TN) {
+        if ((u + 1) % TN == 0) read_a(st, 1);
+        read_b(st, (u + 1) / TN, (u + 1) % TN, (u + 1) & 1);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int arow = wm0 + 32 * i + fr;
-        const int ao = arow * 64 + swz(arow, 2 * s + fh);
-        ah[i] = *reinterpret_cast<const s16x8g *>(st + ao);
-        al[i] = *reinterpret_cast<const s16x8g *>(st + APL + ao);
+        acc[i][j] = mfma<F16>(al[s][i], bh[u & 1], acc[i][j]);
+        acc[i][j] = mfma<F16>(ah[s][i], bl[u & 1], acc[i][j]);
+        acc[i][j] = mfma<F16>(ah[s][i], bh[u & 1], acc[i][j]);
       }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int brow = wn0 + 32 * j + fr;
-        const int bo = brow * 64 + swz(brow, 2 * s + fh);
-        const s16x8g bh = *reinterpret_cast<const s16x8g *>(st + 2 * APL + bo);
-        const s16x8g bl = *reinterpret_cast<const s16x8g *>(st + 2 * APL + BPL + bo);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          acc[i][j] = mfma<F16>(al[i], bh, acc[i][j]);
-          acc[i][j] = mfma<F16>(ah[i], bl, acc[i][j]);
-          acc[i][j] = mfma<F16>(ah[i], bh, acc[i][j]);
-        }
+      if (s == 1 && !LAST) {
+        store_group((c + 1 - c_lo) & 1, j);   // that stage was last read in iteration c - 1: every wave is past its barrier
+        load_group(k0_next, j);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (u == TN - 1) ISI_GEMM_STAMP(5 + 4 * (c - c_lo));
     }
-    if (more) store_chunk((c + 1 - c_lo) & 1);   // that stage was last read in iteration c - 1: every wave is past its barrier
+    ISI_GEMM_STAMP(6 + 4 * (c - c_lo));
+    ISI_GEMM_STAMP(7 + 4 * (c - c_lo));
     __syncthreads();
-  }
+  };
+  for (int c = c_lo; c + 1 < c_hi; ++c) chunk(c, std::false_type{});
+  if (c_lo < c_hi) chunk(c_hi - 1, std::true_type{});
+  ISI_GEMM_STAMP(2);
 
+  const uint64_t drop_seed = p.drop_seed + (p.drop_thresh && p.drop_base ? *p.drop_base : 0);
   // ---- epilogue.  C layout of a 32 x 32 tile: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): a
   // store instruction writes two 128-byte row segments
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
@@ -240,10 +300,11 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
       float v = (F16 ? acc[i][j][r] * f16s::kUnscale : acc[i][j][r]) + bias + res[r];
       if (p.relu) v = fmaxf(v, 0.f) + (v - v);      // (a NaN stays a NaN: an operand beyond the f16 range must be loud)
       if (p.gate) v = gt[r] > 0.f ? v * p.gate_scale : 0.f;
-      if (p.drop_thresh) v = dropout_keep(p.drop_seed, oo[r] >> 2, p.drop_thresh) ? v * p.drop_scale : 0.f;
+      if (p.drop_thresh) v = dropout_keep(drop_seed, oo[r] >> 2, p.drop_thresh) ? v * p.drop_scale : 0.f;
       __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ro, oo[r], 0, 0);
     }
   }
+  ISI_GEMM_STAMP(3);
   // ---- the few rows beyond the last full tile row (gemm_split_f32): output columns dealt round-robin to the
   // workgroups, one row per wave, plain fp32 dot products (one memory round trip at the end of every workgroup
   // instead of a second round of mostly empty tiles)
@@ -271,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_kernel(GemmArgs p) {
           float v = s + (p.bias ? p.bias[n] : 0.f) + (p.res ? p.res[m * p.ldr + n] : 0.f);
           if (p.relu) v = fmaxf(v, 0.f) + (v - v);
           if (p.gate) v = p.gate[m * p.ldg + n] > 0.f ? v * p.gate_scale : 0.f;
-          if (p.drop_thresh) v = dropout_keep(p.drop_seed, (uint32_t)(m * p.ldo + n), p.drop_thresh) ? v * p.drop_scale : 0.f;
+          if (p.drop_thresh) v = dropout_keep(drop_seed, (uint32_t)(m * p.ldo + n), p.drop_thresh) ? v * p.drop_scale : 0.f;
           p.out[m * p.ldo + n] = v;
         }
       }
@@ -296,6 +357,15 @@ int launch_gemm(const GemmArgs &a, hipStream_t stream, int nz = 1) {
 }
 
 }  // namespace
+
+int gemm_split_debug_stamps(long long *host, int n) {
+#ifdef ISI_MEASURE
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), sizeof(long long) * (size_t)(n < 512 ? n : 512)) == hipSuccess ? 0 : -2;
+#else
+  (void)host; (void)n;
+  return unsupported("phase timestamps need a -DISI_MEASURE build");
+#endif
+}
 
 // Shapes this kernel takes over from the 1x1 implicit GEMM (conv2d_batched_f32 asks before it plans its own launch):
 // dense rows (channel stride 1), K a multiple of 32, 16-byte aligned operands, three-term products.
@@ -323,7 +393,7 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   g.zs_a = g.zs_w = g.zs_res = g.zs_out = 0;
   g.win_rpu = g.lo_slope = g.lo_base = g.hi_slope = g.hi_base = 0;
   g.gate = nullptr; g.ldg = 0; g.gate_bytes = 4; g.gate_scale = 1.f;
-  g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0;
+  g.drop_thresh = 0; g.drop_scale = 1.f; g.drop_seed = 0; g.drop_base = nullptr;
   int nz = 1;
   if (extra) {
     nz = extra->nz;
@@ -333,6 +403,7 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
       g.drop_thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (t < 1.0 ? 1u : (unsigned)t);
       g.drop_scale = 1.f / (1.f - extra->drop_p);
       g.drop_seed = extra->drop_seed;
+      g.drop_base = dropout_seed_base();
     }
     if (extra->gate) {
       const int64_t eg = (int64_t)(M - 1) * extra->ldg + N;
@@ -360,7 +431,14 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   // M = 8200, K = 512, tools/bench_linear.py with ISI_GEMM_NO_WIDE: N = 2048 (two rounds) 79 -> 70 us, N = 1024 (one round)
   // 42 -> 40 us; N = 1536 (one and a half rounds) 63 -> 70 us: not taken)
   const long tiles256 = (long)((M + 255) / 256) * ((N + 127) / 128);
-  if (!narrow && nz == 1 && !g.win_rpu && tiles256 % current_device_cu_count() == 0 && !knobs().gemm_no_wide) {
+  const long tiles256x256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  if (!narrow && nz == 1 && !g.win_rpu && N % 256 == 0 && tiles256x256 == current_device_cu_count() && !knobs().gemm_no_wide) {
+    if (split_mode == 3 && w16) return launch_gemm<true, 4, true, 2>(g, stream, nz);
+    if (split_mode == 3) return launch_gemm<true, 4, false, 2>(g, stream, nz);
+    if (w16) return launch_gemm<false, 4, true, 2>(g, stream, nz);
+    return launch_gemm<false, 4, false, 2>(g, stream, nz);
+  }
+  if (!narrow && nz == 1 && !g.win_rpu && tiles256 % current_device_cu_count() == 0 && knobs().gemm_no_wide != 1) {
     if (split_mode == 3 && w16) return launch_gemm<true, 2, true, 2>(g, stream, nz);
     if (split_mode == 3) return launch_gemm<true, 2, false, 2>(g, stream, nz);
     if (w16) return launch_gemm<false, 2, true, 2>(g, stream, nz);

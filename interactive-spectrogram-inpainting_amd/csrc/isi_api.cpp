@@ -1,5 +1,6 @@
 // extern "C" surface of libisi_hip.so (declared in include/isi_hip.h).
 #include "isi_common.h"
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 
@@ -9,6 +10,8 @@
 #include "prof.h"
 
 namespace isi {
+static std::atomic<const uint64_t *> g_dropout_seed_base{nullptr};
+const uint64_t *dropout_seed_base() { return g_dropout_seed_base.load(); }
 static thread_local char g_last_error[512] = "";
 void set_last_error(const char *msg) {
   strncpy(g_last_error, msg ? msg : "", sizeof g_last_error - 1);
@@ -149,6 +152,11 @@ int isi_debug_resblock_pair_stamps(long long *host, int n) { return resblock_pai
 int isi_debug_vq_stamps(long long *host, int n) { return vq_debug_stamps(host, n); }
 int isi_debug_attention_stamps(long long *host, int n) { return rel_attention_debug_stamps(host, n); }
 int isi_debug_attention_fwd2_stamps(long long *host, int n) { return rel_attention_fwd2_debug_stamps(host, n); }
+int isi_set_dropout_seed_base(const void *device_u64) {
+  g_dropout_seed_base.store(static_cast<const uint64_t *>(device_u64));
+  return 0;
+}
+int isi_debug_gemm_stamps(long long *host, int n) { return gemm_split_debug_stamps(host, n); }
 int isi_pair_encode_f32(const float *x, float *pairs, int64_t n, void *stream) { return pair_encode_f32(x, pairs, n, S(stream)); }
 int isi_pair_decode_f32(const float *pairs, float *x, int64_t n, void *stream) { return pair_decode_f32(pairs, x, n, S(stream)); }
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream) {

@@ -70,6 +70,7 @@ int convT_k4s2_small_f32(const float *in, const float *wk, const float *bias, fl
 
 int rel_attention_f32(const isi_attn_args *g, hipStream_t stream);
 int rel_attention_debug_stamps(long long *host, int n);
+int gemm_split_debug_stamps(long long *host, int n);
 size_t rel_attention_bwd_workspace_floats(const isi_attn_args *g);
 int rel_attention_bwd_f32(const isi_attn_bwd_args *g, hipStream_t stream);
 size_t layernorm_bwd_workspace_floats(int64_t M, int D);
@@ -128,6 +129,9 @@ struct GemmExtra {
   float drop_p;           // inverted dropout on the (rectified) output, keep mask = attention_dropout_keep(seed, m ldo + n); 0: none
   uint64_t drop_seed;
 };
+// Optional device-resident term of every fused dropout's seed (isi_set_dropout_seed_base): a step replayed from a HIP
+// graph carries its seeds as launch constants, the owner of the graph advances this counter between replays.
+const uint64_t *dropout_seed_base();
 // the keep decision of the fused dropout: a counter-based hash of (seed, flat output index) -- the same function in the
 // forward epilogue and wherever a backward needs the mask again
 __host__ __device__ inline bool dropout_keep(uint64_t seed, uint32_t idx, uint32_t thresh) {

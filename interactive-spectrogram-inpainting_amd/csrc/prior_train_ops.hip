@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
                                                             const float *__restrict__ dy, float *__restrict__ dz,
                                                             float *__restrict__ partial, int M, int D, float eps,
                                                             int rows_per_block, float *__restrict__ dx,
-                                                            unsigned drop_thresh, float drop_scale, uint64_t seed) {
+                                                            unsigned drop_thresh, float drop_scale, uint64_t seed0,
+                                                            const uint64_t *seed_base) {
+  const uint64_t seed = seed0 + (drop_thresh && seed_base ? *seed_base : 0);
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = D >> 2;
@@ -200,7 +202,7 @@ int layernorm_bwd_f32(const float *x, const float *res, const float *gamma, cons
   const int nblk = ln_bwd_blocks(M);
   const int rpb = (int)((M + nblk - 1) / nblk);
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * D * sizeof(float), stream, x, res,
-                     gamma, dy, dz, workspace, (int)M, D, eps, rpb, dx, thresh, scale, drop_seed);
+                     gamma, dy, dz, workspace, (int)M, D, eps, rpb, dx, thresh, scale, drop_seed, dropout_seed_base());
   int rc = check_launch("layernorm_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, stream, workspace, dgamma,

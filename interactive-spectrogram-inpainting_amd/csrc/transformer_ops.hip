@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void layernorm_f32_kernel(const float *__restr
                                                             const float *__restrict__ gamma,
                                                             const float *__restrict__ beta,
                                                             float *__restrict__ out, int M, int D, float eps,
-                                                            unsigned drop_thresh, float drop_scale, uint64_t seed) {
+                                                            unsigned drop_thresh, float drop_scale, uint64_t seed0,
+                                                            const uint64_t *seed_base) {
+  const uint64_t seed = seed0 + (drop_thresh && seed_base ? *seed_base : 0);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -98,7 +100,7 @@ int layernorm_f32(const float *x, const float *res, const float *gamma, const fl
        reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(out)) & 15)
     return invalid("layernorm: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, res, gamma,
-                     beta, out, (int)M, D, eps, thresh, scale, drop_seed);
+                     beta, out, (int)M, D, eps, thresh, scale, drop_seed, dropout_seed_base());
   return check_launch("layernorm_f32");
 }
 

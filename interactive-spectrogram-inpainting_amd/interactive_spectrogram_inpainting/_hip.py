@@ -187,6 +187,7 @@ SIGNATURES = {
     "isi_rel_attention_decode_f32": (C.c_int, [C.POINTER(isi_attn_args), C.c_int, _P, _P]),
     "isi_rel_attention_decode_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "isi_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "isi_set_dropout_seed_base": (C.c_int, [_P]),
     "isi_layernorm_dropout_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_uint64, _P]),
     "isi_layernorm_dropout_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float,
                                                 C.c_float, C.c_uint64, _P]),

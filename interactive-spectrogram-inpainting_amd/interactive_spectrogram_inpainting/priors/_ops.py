@@ -64,6 +64,8 @@ class WeightRange:
 
     def update(self, weight: torch.Tensor, inference: bool) -> bool:
         v = weight._version + _hip.optimizer_steps()      # either counter moves when the values may have changed
+        if capturing() and self.next_check >= 0:          # (decided by the eager steps in front of a graph capture)
+            return self.ok
         if inference or self.next_check < 0 or v >= self.next_check or v < self.last_version:
             m = float(weight.detach().abs().max()) if weight.numel() else 0.0          # reads one scalar back
             self.ok = m < (_F16_WEIGHT_LIMIT if inference else 0.5 * _F16_WEIGHT_LIMIT)
@@ -119,6 +121,26 @@ def fused_tails_ok(M: int, N: int, K: int) -> bool:
     GEMM epilogue instead of torch kernels of their own."""
     return (K % 32 == 0 and K >= 128 and N > 32 and M >= 256 and LINEAR_PRECISION in ("f16x3", "bf16x3")
             and LINEAR_GRAD_PRECISION == "bf16x3")
+
+
+_SEED_BASE = None      # the tensor behind isi_set_dropout_seed_base (kept alive here)
+
+
+def set_dropout_seed_base(counter: Optional[torch.Tensor]) -> None:
+    """A device-resident int64 scalar added to every fused dropout's seed (include/isi_hip.h: isi_set_dropout_seed_base), or
+    None.  The owner of a replayed HIP graph advances it between replays (utils/training/graphed_step.py)."""
+    global _SEED_BASE
+    if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+        raise ValueError("the seed base is one int64 on the GPU")
+    _hip.check(_hip.lib().isi_set_dropout_seed_base(counter.data_ptr() if counter is not None else None),
+               "isi_set_dropout_seed_base")
+    _SEED_BASE = counter
+
+
+def capturing() -> bool:
+    """Whether the current stream is being captured into a HIP graph: nothing may be read back, checks that would are
+    skipped (they ran in the eager warm-up steps in front of the capture)."""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 def dropout_seed() -> int:

@@ -16,7 +16,9 @@ repository's HIP implementation), the logits head is a GEMM.
 """
 from __future__ import annotations
 
+import collections
 import json
+import os
 import pathlib
 from enum import Enum, auto
 from typing import Iterable, Mapping, Optional, Tuple, Union
@@ -32,6 +34,37 @@ from VQCPCB.transformer.transformer_custom import (
 from .. import _hip
 from . import _train
 from .codemaps_helpers import CodemapsHelper, SimpleCodemapsHelper, ZigZagCodemapsHelper
+
+
+
+DEFERRED_INDEX_CHECK = os.environ.get("ISI_DEFERRED_INDEX_CHECK", "1") != "0"
+
+
+class _IndexGuard:
+    """Out-of-range verdicts of `embed_data` calls whose read-back is deferred: one pinned byte and one event per call."""
+
+    def __init__(self):
+        self._pending = collections.deque()
+
+    def _raise_if(self, flag: torch.Tensor) -> None:
+        if bool(flag.item()):
+            self._pending.clear()
+            raise IndexError("index out of range in self (seen by a deferred check of an earlier training step)")
+
+    def submit(self, bad: torch.Tensor) -> None:
+        while self._pending and self._pending[0][1].query():      # verdicts that have arrived: no waiting
+            self._raise_if(self._pending.popleft()[0])
+        host = torch.empty((), dtype=torch.bool, pin_memory=True)
+        host.copy_(bad, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((host, ev))
+
+    def flush(self) -> None:
+        while self._pending:
+            host, ev = self._pending.popleft()
+            ev.synchronize()
+            self._raise_if(host)
 
 
 class Seq2SeqInputKind(Enum):
@@ -234,6 +267,7 @@ class VQNSynthTransformer(nn.Module):
         self.transformer = TransformerCustom(nhead=self.conditional_model_nhead, custom_encoder=relative_encoder,
                                              custom_decoder=custom_decoder, d_model=self.d_model)
         self._tables = {}
+        self._index_guard = _IndexGuard()
 
     # ---------------------------------------------------------------- embeddings
     def _embedding_table(self, kind: Seq2SeqInputKind) -> torch.Tensor:
@@ -263,12 +297,33 @@ class VQNSynthTransformer(nn.Module):
     def embed_data(self, input: torch.Tensor, kind: Seq2SeqInputKind) -> torch.Tensor:
         table = self._embedding_table(kind)
         if input.numel():
-            lo, hi = torch.aminmax(input)          # one launch; the read-back below is this call's only synchronisation
-            if int(lo) < 0 or int(hi) >= table.shape[0]:
+            if input.is_cuda and torch.cuda.is_current_stream_capturing():
+                # a step recorded into a HIP graph: the eager steps in front of the capture did the checking, the
+                # replays run on clamped indices (GraphedTrainingStep checks the batches it is handed)
+                input = input.clamp(0, table.shape[0] - 1)
+                lo = hi = None
+            else:
+                lo, hi = torch.aminmax(input)          # one launch
+            if lo is None:
+                pass
+            elif self._differentiable() and input.is_cuda and DEFERRED_INDEX_CHECK:
+                # A training step must not JOIN the device at its head (the read-back below made the host wait for the previous
+                # step's backward and optimizer: ~12 ms of a 30-ms step during which nothing was enqueued).  The verdict
+                # travels to pinned memory behind the launches and is looked at by a later call / `check_indices()`; the
+                # gather runs on clamped indices meanwhile.  (The reference on a GPU fails the same way: nn.Embedding's
+                # device-side assert surfaces at a later synchronisation, priors/transformer.py:539-560.)
+                self._index_guard.submit((lo < 0) | (hi >= table.shape[0]))
+                input = input.clamp(0, table.shape[0] - 1)
+            elif int(lo) < 0 or int(hi) >= table.shape[0]:      # the read-back is this call's only synchronisation
                 raise IndexError("index out of range in self")  # what nn.Embedding raises in the reference
         if table.requires_grad:
             return _train.EmbeddingRowsFn.apply(table, input)
         return table[input]
+
+    def check_indices(self) -> None:
+        """Waits for the index checks of the training steps enqueued so far and raises the reference's IndexError if one of
+        them saw a symbol outside its embedding table (training loops call it where they read the loss back)."""
+        self._index_guard.flush()
 
     def _get_combined_positional_embeddings(self, kind: Seq2SeqInputKind) -> torch.Tensor:
         if kind == Seq2SeqInputKind.Source:

@@ -672,3 +672,91 @@ def test_attention_backward_with_poisoned_workspace(Sq, Sk, mode, keep_logits, m
         assert torch.isfinite(a).all(), name
         # the sums over key groups are float atomics: their order, not their terms, differs from run to run
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()), name
+
+
+def _toy_training_setup(dropout, seed=11, lr=1e-3, capturable=False):
+    from interactive_spectrogram_inpainting.priors.transformer import SelfAttentiveVQTransformer
+    from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    dev = _dev()
+    torch.manual_seed(seed)
+    model = SelfAttentiveVQTransformer(shape=[8, 4], condition_shape=[8, 4], self_conditional_model=True,
+                                       add_mask_token_to_symbols=True, **COMMON).to(dev).train()
+    for m in model.modules():
+        if hasattr(m, "dropout") and isinstance(m.dropout, float):
+            m.dropout = dropout
+    g = torch.Generator().manual_seed(seed + 1)
+    B = 4
+    cls = {"instrument_family_str": torch.randint(0, 11, (B, 1), generator=g).to(dev),
+           "pitch": torch.randint(0, 61, (B, 1), generator=g).to(dev)}
+    batches = [(torch.randint(0, 32, (B, 8, 4), generator=g).to(dev), (torch.rand(B, 8, 4, generator=g) < 0.5).to(dev))
+               for _ in range(4)]
+    opt = make_adam(model.parameters(), lr=lr, **({"capturable": True} if capturable else {}))
+    crit = LabelSmoothingLoss(32, 0.1, dim=1)
+
+    def step(code, mask):
+        opt.zero_grad(set_to_none=True)
+        src, tgt = model.to_sequences(code, condition=code, class_conditioning=cls, mask=mask)
+        logits, _ = model(tgt, condition=src)
+        loss = crit(model.to_time_frequency_map(logits, kind="target", permute_output_as_logits=True), code)
+        loss.backward()
+        opt.step()
+        return loss
+    return model, step, batches
+
+
+def test_graphed_training_step_equals_eager():
+    """A training step recorded into a HIP graph (utils/training/graphed_step.py) launches the eager step's kernels: after
+    one eager warm-up step on batch 0 and replays on batches 1..3 the parameters equal those of four eager steps on the same
+    batches (dropout off; float atomics of the unmasked attention backward: their order, not their terms, may differ), the
+    losses of the replays equal the eager ones, and a batch with a symbol outside the table raises the reference's
+    IndexError after the fact."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+    model_e, step_e, batches = _toy_training_setup(0.0)
+    losses_e = [float(step_e(*b).detach()) for b in batches]
+    model_g, step_g, _ = _toy_training_setup(0.0, capturable=True)
+    static = (batches[0][0].clone(), batches[0][1].clone())
+    graphed = GraphedTrainingStep(step_g, static, warmup=1, index_limits={0: 32})
+    try:
+        losses_g = [float(graphed(*b).detach()) for b in batches[1:]]
+        for a, b in zip(losses_g, losses_e[1:]):
+            assert abs(a - b) <= 2e-5 * abs(b), (losses_g, losses_e)
+        for (name, pe), pg in zip(model_e.named_parameters(), model_g.parameters()):
+            d = float((pe.detach() - pg.detach()).abs().max())
+            assert d <= 2e-4 * max(1e-3, float(pe.abs().max())), (name, d)
+        bad = batches[0][0].clone()
+        bad[0, 0, 0] = 32
+        with pytest.raises(IndexError):      # from the call itself if the verdict has arrived by then, else from finish()
+            graphed(bad, batches[0][1])
+            graphed.finish()
+        graphed.finish()
+    finally:
+        _ops.set_dropout_seed_base(None)
+    # eager code after the replays sees the replayed parameters (version-keyed caches were marked stale)
+    model_g.eval()
+    with torch.no_grad():
+        src, tgt = model_g.to_sequences(batches[1][0], condition=batches[1][0],
+                                        class_conditioning={"instrument_family_str": torch.zeros(4, 1, dtype=torch.long, device=_dev()),
+                                                            "pitch": torch.zeros(4, 1, dtype=torch.long, device=_dev())},
+                                        mask=batches[1][1])
+        out_g, _ = model_g(tgt, condition=src)
+    assert torch.isfinite(out_g).all()
+
+
+def test_graphed_training_step_draws_fresh_dropout_masks():
+    """The fused dropouts' seeds are launch constants of a recorded step; the device-resident counter the first node of the
+    graph advances (isi_set_dropout_seed_base) gives every replay its own masks: with a learning rate of zero two replays
+    on one batch give different losses at p = 0.3 and identical ones at p = 0."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+    for p, differ in ((0.3, True), (0.0, False)):
+        _, step, batches = _toy_training_setup(p, lr=0.0, capturable=True)
+        graphed = GraphedTrainingStep(step, (batches[0][0].clone(), batches[0][1].clone()), warmup=1)
+        try:
+            a = float(graphed(*batches[1]).detach())
+            b = float(graphed(*batches[1]).detach())
+            graphed.finish()
+        finally:
+            _ops.set_dropout_seed_base(None)
+        assert (a != b) == differ, (p, a, b)

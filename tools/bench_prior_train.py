@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--plain-adam", action="store_true", help="torch's default (multi-tensor) Adam instead of the fused one")
+    ap.add_argument("--graph", action="store_true", help="record the step into a HIP graph and replay it (GraphedTrainingStep)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     m = build(dev).train()
@@ -32,7 +33,8 @@ def main():
     code = torch.randint(0, 512, (B, 32, 32), device=dev)
     mask = torch.rand(B, 32, 32, device=dev) < 0.5
     cls = {"pitch": torch.full((B, 1), 24, device=dev), "instrument_family_str": torch.zeros(B, 1, dtype=torch.long, device=dev)}
-    opt = torch.optim.Adam(m.parameters(), lr=3e-4) if a.plain_adam else make_adam(m.parameters(), lr=3e-4)
+    opt = (torch.optim.Adam(m.parameters(), lr=3e-4) if a.plain_adam
+           else make_adam(m.parameters(), lr=3e-4, **({"capturable": True} if a.graph else {})))
     crit = LabelSmoothingLoss(512, 0.1, dim=1)
 
     def step():
@@ -44,6 +46,13 @@ def main():
         opt.step()
         return loss
 
+    if a.graph:
+        from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+        eager_step = step
+        graphed = GraphedTrainingStep(lambda c, k: eager_step(), (code, mask), warmup=3, index_limits={0: 512})
+
+        def step():      # noqa: F811
+            return graphed(code, mask)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -56,6 +65,8 @@ def main():
     print(f"host enqueue time {t_host * 1e3:.1f} ms/step (GPU-bound while this stays below the step time)")
     print(f"prior training step B={B} S=1025: {dt * 1e3:.1f} ms/step  {B / dt:.1f} codemaps/s  "
           f"{B * 1024 / dt:.0f} tokens/s  loss {float(loss):.4f}")
+    if a.graph:
+        graphed.finish()
     # forward only (no_grad, eval) for comparison
     m.eval()
     with torch.no_grad():

@@ -47,8 +47,8 @@ struct WgradKArgs {
 namespace {
 constexpr int LDT = 132;  // LDS row (floats): 128 + 4
 constexpr unsigned OOB = 0xFFFFFFF0u;
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, unsigned uniform_off = 0) {
+  i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, uniform_off, 0);
   return *reinterpret_cast<float4 *>(&v);
 }
 }  // namespace
@@ -712,36 +712,35 @@ __global__ __launch_bounds__(512, 2) void linear_wgrad_kernel(const WgradKArgs p
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x0), 0, p.x0_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.dy), 0, p.dy_bytes, 0x00020000);
 
-  // staging: float4 number tid + 512 j of a 32 x 128 chunk: row = that / 32, channel quad = tid % 32
+  // staging: float4 number tid + 512 j of a 32 x 128 chunk: row = that / 32, channel quad = tid % 32.  A chunk travels as
+  // four pieces per thread (dY rows sm, sm + 16; X rows sm, sm + 16): piece g of chunk c + 1 is converted and written to
+  // the other LDS stage behind the g-th group of matrix instructions of chunk c, and piece g of chunk c + 2 is requested
+  // into the registers this frees (gemm_split_f32.hip has the measurements behind this order: no branch inside a chunk, so
+  // that the compiler's wait counts stay exact; a request has a whole chunk to come back).
   const int sq = tid & 31, sm = tid >> 5;
   const int sdst = (sq >> 3) * SL + (sq & 7) * 8;
   const int chunk_begin = split * p.chunks_per_split;
   const int chunk_end = min((p.M + 31) / 32, chunk_begin + p.chunks_per_split);
-  float4 pd[2], px[2];
-  auto load_chunk = [&](int ch) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = ch * 32 + sm + 16 * j;
-      const bool ok = m < p.M;
-      pd[j] = buf_load4(rd, ok ? (unsigned)(m * p.dw + n0 + sq * 4) * 4u : OOB);
-      px[j] = buf_load4(rx, ok ? (unsigned)(m * p.s0w + k0 + sq * 4) * 4u : OOB);
-    }
+  const unsigned vd0 = (unsigned)(sm * p.dw + n0 + sq * 4) * 4u, vd1 = vd0 + (unsigned)(16 * p.dw) * 4u;
+  const unsigned vx0 = (unsigned)(sm * p.s0w + k0 + sq * 4) * 4u, vx1 = vx0 + (unsigned)(16 * p.s0w) * 4u;
+  float4 pc4[4];
+  auto load_piece = [&](int ch, int g) {
+    // (the chunk's row offset travels in the scalar offset, which the range check ignores: rows beyond M -- the last
+    // chunk's -- get the out-of-range vector offset by hand)
+    const int rows = p.M - ch * 32;
+    const bool ok = sm + 16 * (g >> 1) < rows;
+    if (g & 1) pc4[g] = buf_load4(rx, ok ? (g >> 1 ? vx1 : vx0) : OOB, (unsigned)(ch * 32 * p.s0w) * 4u);
+    else pc4[g] = buf_load4(rd, ok ? (g >> 1 ? vd1 : vd0) : OOB, (unsigned)(ch * 32 * p.dw) * 4u);
   };
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  auto store_chunk = [&](int stage) {
-    unsigned char *st = smem_b + stage * STAGE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int o = sdst + (sm + 16 * j) * 64;
-      uint2 pc[3];
-      split4<2>(pd[j].x, pd[j].y, pd[j].z, pd[j].w, pc);
-      *reinterpret_cast<uint2 *>(st + o) = pc[0];
-      *reinterpret_cast<uint2 *>(st + o + 2048) = pc[1];
-      split4<2>(px[j].x, px[j].y, px[j].z, px[j].w, pc);
-      *reinterpret_cast<uint2 *>(st + OPB + o) = pc[0];
-      *reinterpret_cast<uint2 *>(st + OPB + o + 2048) = pc[1];
-      bsum[0] += pd[j].x; bsum[1] += pd[j].y; bsum[2] += pd[j].z; bsum[3] += pd[j].w;
-    }
+  auto store_piece = [&](int stage, int g) {
+    unsigned char *st = smem_b + stage * STAGE + (g & 1) * OPB;
+    const int o = sdst + (sm + 16 * (g >> 1)) * 64;
+    uint2 pc[3];
+    split4<2>(pc4[g].x, pc4[g].y, pc4[g].z, pc4[g].w, pc);
+    *reinterpret_cast<uint2 *>(st + o) = pc[0];
+    *reinterpret_cast<uint2 *>(st + o + 2048) = pc[1];
+    if (!(g & 1)) { bsum[0] += pc4[g].x; bsum[1] += pc4[g].y; bsum[2] += pc4[g].z; bsum[3] += pc4[g].w; }
   };
 
   f32x16 acc[2];
@@ -760,29 +759,48 @@ __global__ __launch_bounds__(512, 2) void linear_wgrad_kernel(const WgradKArgs p
   };
 
   if (chunk_begin < chunk_end) {
-    load_chunk(chunk_begin);
-    store_chunk(0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) load_piece(chunk_begin, g);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      store_piece(0, g);
+      if (chunk_begin + 1 < chunk_end) load_piece(chunk_begin + 1, g);
+    }
   }
   __syncthreads();
-  for (int ch = chunk_begin; ch < chunk_end; ++ch) {
-    const bool more = ch + 1 < chunk_end;
-    if (more) load_chunk(ch + 1);
-    const unsigned char *st = smem_b + ((ch - chunk_begin) & 1) * STAGE;
+  // a chunk = 4 units (16-row step s, input-feature tile j) of 3 matrix instructions; the fragments of unit u + 1 are read
+  // before unit u's matrix instructions are issued
+  auto chunk = [&](const int ch, auto last) {
+    constexpr bool LAST = decltype(last)::value;
+    const int rel = ch - chunk_begin;
+    const unsigned char *st = smem_b + (rel & 1) * STAGE;
     const unsigned char *ab = st + wn * SL + foff, *bb = st + OPB + (2 * wk) * SL + foff;
+    const int ch_next = min(ch + 2, chunk_end - 1);
+    s16x8 ah[2], al[2], bh[2], bl[2];
+    ah[0] = frag(ab); al[0] = frag(ab + 2048);
+    bh[0] = frag(bb); bl[0] = frag(bb + 2048);
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const s16x8 ah = frag(ab + s * 16 * 64), al = frag(ab + 2048 + s * 16 * 64);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const s16x8 bh = frag(bb + j * SL + s * 16 * 64), bl = frag(bb + j * SL + 2048 + s * 16 * 64);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh), acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl), acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh), acc[j], 0, 0, 0);
+    for (int u = 0; u < 4; ++u) {
+      const int s_ = u >> 1, j = u & 1;
+      if (u + 1 < 4) {
+        const int s1 = (u + 1) >> 1, j1 = (u + 1) & 1;
+        if (j1 == 0) { ah[s1] = frag(ab + s1 * 16 * 64); al[s1] = frag(ab + 2048 + s1 * 16 * 64); }
+        bh[(u + 1) & 1] = frag(bb + j1 * SL + s1 * 16 * 64);
+        bl[(u + 1) & 1] = frag(bb + j1 * SL + 2048 + s1 * 16 * 64);
       }
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[s_]), __builtin_bit_cast(bf16x8, bh[u & 1]), acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[s_]), __builtin_bit_cast(bf16x8, bl[u & 1]), acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[s_]), __builtin_bit_cast(bf16x8, bh[u & 1]), acc[j], 0, 0, 0);
+      if (!LAST) {
+        store_piece((rel + 1) & 1, u);   // last read one iteration ago: every wave is past its barrier
+        load_piece(ch_next, u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) store_chunk(((ch - chunk_begin) + 1) & 1);   // last read one iteration ago: every wave is past its barrier
     __syncthreads();
-  }
+  };
+  for (int ch = chunk_begin; ch + 1 < chunk_end; ++ch) chunk(ch, std::false_type{});
+  if (chunk_begin < chunk_end) chunk(chunk_end - 1, std::true_type{});
 
   // ---- bias partials: fixed-order sum over the 16 staging threads of a channel quad
   if (p.db_partial != nullptr && blockIdx.y == 0) {
@@ -917,7 +935,10 @@ static int wgrad_halo_nsplit(int units, int ntiles) {
 // workspace sizer -- its count can exceed wgrad_nsplit's where (Cout/128)(K/128) lies in (384, 512)
 static int linear_wgrad_nsplit(int Cout, int K, int M) {
   const int tiles = (Cout / 128) * (K / 128), nchunks = (M + 31) / 32;
-  return std::max(1, std::min(std::min(64, (512 + tiles - 1) / tiles), nchunks / 8));
+  // one workgroup per CU for the small layers (a split costs a 64 KB partial tile written and read back: measured at M = 8200,
+  // 512 x 512: 33 -> 29 us, 1024 x 512: 51 -> 45 us), two from 48 tiles on (1536 x 512: 66 vs 70 us with one)
+  const int target = knobs().wgrad_split_target > 0 ? knobs().wgrad_split_target : (tiles <= 32 ? 256 : 512);
+  return std::max(1, std::min(std::min(64, (target + tiles - 1) / tiles), nchunks / 8));
 }
 size_t conv_wgrad_batched_workspace_floats(int Cout, int K, int M, int nphase, int nz) {
   const int Kpad = (int)round_up(K, kBK);

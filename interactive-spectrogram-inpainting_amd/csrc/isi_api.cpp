@@ -157,6 +157,7 @@ int isi_set_dropout_seed_base(const void *device_u64) {
   return 0;
 }
 int isi_debug_gemm_stamps(long long *host, int n) { return gemm_split_debug_stamps(host, n); }
+int isi_debug_attention_bwd_stamps(long long *host, int n) { return rel_attention_bwd_debug_stamps(host, n); }
 int isi_pair_encode_f32(const float *x, float *pairs, int64_t n, void *stream) { return pair_encode_f32(x, pairs, n, S(stream)); }
 int isi_pair_decode_f32(const float *pairs, float *x, int64_t n, void *stream) { return pair_decode_f32(pairs, x, n, S(stream)); }
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream) {

@@ -984,6 +984,15 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   }
 }
 
+// phase timestamps of the key-stationary kernel (-DISI_MEASURE builds; tools/stamps_attention_bwd.py): the first workgroup
+// of XCD 0 (under a causal mask: the heaviest block of its pair), waves 0 and 4, 12 stamps per step
+#ifdef ISI_MEASURE
+__device__ long long g_attn_kv_stamps[512];
+#define ISI_KV_STAMP(i_) do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && (i_) < 256) \
+    g_attn_kv_stamps[(wave >> 2) * 256 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ISI_KV_STAMP(i_) do { } while (0)
+#endif
 // ------------------------------------------------------------------ dK and dV (split)
 // Key-stationary: wave wq of either group owns keys k0b + 32 wq .. + 31 (K, V fragments split once, in
 // registers as B operands; dK^T / dV^T in accumulators); group g walks the query tiles of parity g and the
@@ -1073,10 +1082,10 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
 #define ISI_KV_ROLES                                                                                   \
   int tid_o = tid;                                                                                     \
   asm volatile("" : "+v"(tid_o));                                                                      \
-  const int kind = tid_o >> 8, bidx = tid_o & 255;                                                     \
+  const int kind = __builtin_amdgcn_readfirstlane(tid >> 8), bidx = tid_o & 255;    /* (wave-uniform: as a vector value the buffer descriptor chosen by it was one too -- a waterfall loop per load and a wait for ALL of them right behind) */ \
   const int bqd = bidx % NQD, bkg = (bidx / NQD) & 7, btile = bidx / (8 * NQD);                        \
   const bool blk_on = btile < 2;                                                                       \
-  const int st = tid_o >> 8, srow = (tid_o >> 3) & 31, squad = tid_o & 7;                              \
+  const int st = kind, srow = (tid_o >> 3) & 31, squad = tid_o & 7;                                    \
   (void)st; (void)srow; (void)squad; (void)kind; (void)bqd; (void)bkg; (void)blk_on
   auto prefetch = [&](int q0) {  // Q / dO blocks of the pair at q0 and the 64 highest rows of its band
     ISI_KV_ROLES;
@@ -1097,10 +1106,11 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         pe[i] = buf_load4(re, rok && qd < NQD ? (unsigned)((h * p.R + r) * HD + qd * 4) * 4u : OOB);
       }
     }
-    if (tid < 64) {
-      const int q = q0 + tid;
-      plse = q < p.Sq ? p.lse[statb + q] : 0.f;
-      pdsum = q < p.Sq ? p.dsum[statb + q] : 0.f;
+    if (wave == 0) {     // (no zero-fill of the two registers in front of a conditional load: the compiler then waits for
+                         // every older memory operation -- the previous step's stores into G included -- before that write)
+      const int q = min(q0 + lane, p.Sq - 1);
+      plse = p.lse[statb + q];
+      pdsum = p.dsum[statb + q];
     }
   };
   auto put_e = [&](int slot, int qd, const float4 v) {
@@ -1144,8 +1154,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     }
     if (tid < 64) {
       const int qt = q0 + (tid & 32);
-      lse_s[tid] = plse * LOG2E;
-      dsum_s[tid] = pdsum;
+      lse_s[tid] = q0 + tid < p.Sq ? plse * LOG2E : 0.f;
+      dsum_s[tid] = q0 + tid < p.Sq ? pdsum : 0.f;
       evq_s[tid] = (q0 + tid) / p.Cq - qt / p.Cq;
     }
   };
@@ -1183,15 +1193,42 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   float *sw = Sr + wave * 32 * SRL;
   const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
 
+  // The kept logits of a tile (units of exp2).  The accumulator layout wants a lane's key and 16 query rows: 16 dword loads
+  // per lane -- and the vector-memory path takes a wave's instruction at 4 lanes per clock whatever its width, so that the
+  // 32 dword loads / stores of a tile step (logits in, dS out) were ~4 k of its 12 k cycles (tools/stamps_attention_bwd.py).
+  // The tile is requested as four 16-byte pieces of query rows per lane, ONE STEP AHEAD (asked for at the head of their own
+  // step every wave of the workgroup -- they run in step between barriers -- sat out the round trip together), and turned in
+  // the wave's LDS buffer when its step comes.
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+  f32x4_u lvn[4];
+  auto load_logits = [&](int q0_) {
+    const float *lt = p.logits + ((size_t)b * p.H + h) * p.Sq * p.ldl + min(kw0 + 4 * (lane & 7), p.ldl - 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lvn[i] = *reinterpret_cast<const f32x4_u *>(lt + (size_t)min(q0_ + (lane >> 3) + 8 * i, p.Sq - 1) * p.ldl);
+  };
+  if (saved && q_begin < q_end) load_logits(q_begin + 32 * grp);
+  ISI_KV_STAMP(0);
   for (int qp = q_begin; qp < q_end; qp += 64) {
     const bool more = qp + 64 < q_end;
+    const int sb_ = 4 + 12 * ((qp - q_begin) >> 6);
+    ISI_KV_STAMP(sb_);
     if (more) prefetch(qp + 64);
+    ISI_KV_STAMP(sb_ + 1);
     const int q0 = qp + 32 * grp;
     const int rb = band0(q0);
 
     bool live = kw0 < k_lim && q0 < q_end;
     if (p.mask_mode == 1) live = live && q0 + 31 >= kw0;
     if (p.mask_mode == 2) live = live && q0 <= kw0 + 31;
+    if (saved) {     // this step's logits go to the wave's LDS buffer, the next step's are asked for (live tile or not)
+      float *wt = sw + (lane >> 3) * SRL + 4 * (lane & 7);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wt[8 * i * SRL] = lvn[i].x; wt[8 * i * SRL + 1] = lvn[i].y; wt[8 * i * SRL + 2] = lvn[i].z; wt[8 * i * SRL + 3] = lvn[i].w;
+      }
+      load_logits(min(qp + 64, p.Sq - 1) + 32 * grp);      // (clamped rows: the last step re-reads valid memory)
+      wave_lds_sync();
+    }
     if (live) {  // wave-uniform
       // The lane index is made opaque per iteration: the dozens of LDS offsets derived from it are loop-invariant and
       // would otherwise be hoisted into registers the accumulators and fragments need (the three-term kernel spilled
@@ -1202,10 +1239,10 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
       f32x16 acc;
       float sv[16];
       if (saved) {
-        // ---- the forward's logits: this lane's key, the 16 query rows of its accumulator registers (units of exp2)
-        const float *lcol = p.logits + ((size_t)b * p.H + h) * p.Sq * p.ldl + min(kj, p.ldl - 1);
+        // ---- the forward's logits: this lane's key, the 16 query rows of its accumulator registers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = lcol[(size_t)min(q0 + mfma_row(r, half), p.Sq - 1) * p.ldl];
+        for (int r = 0; r < 16; ++r) sv[r] = sw[mfma_row(r, half) * SRL + ql];
+        wave_lds_sync();
       } else {
       // ---- S = Q K^T  (rows = queries, this lane's column = its key)
 #pragma unroll
@@ -1276,6 +1313,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
           sv[r] = ok ? __builtin_amdgcn_exp2f(s - lseb[qrow]) : 0.f;
         }
       }
+      ISI_KV_STAMP(sb_ + 2);      // P formed (logits arrived)
       // ---- dV^T += dO^T P   (A = dO transposed, k-slots = queries in accumulator order)
       s16x8_t sh[2], sl[2];
       split_acc16(sv, sh, sl);
@@ -1297,6 +1335,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
           dV[d] = ISI_MFB(gh, sh[t], dV[d]);
         }
       }
+      ISI_KV_STAMP(sb_ + 3);      // dV issued
       // ---- dP = dO V^T ;  dS = P (dP - D) scale
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1311,14 +1350,27 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) sv[r] = sv[r] * (acc[r] - dsumb[mfma_row(r, half)]) * p.scale;
+      ISI_KV_STAMP(sb_ + 4);      // dS formed
       if (saved && p.g_from_kv) {
         // ---- G[i, i - j + Ek - 1] = dS[i, j]: for one query (register) the lanes' keys are consecutive columns, descending
         // -- 128-byte runs; element (i, j) sits at g0[i (row stride + 1)]
         float *g0 = p.g + ((size_t)h * p.Sq * p.B + b) * p.Rp + (p.Ek - 1 - p.rho_lo - kj);
         const size_t gs1 = (size_t)p.B * p.Rp + 1;
         if (full) {
+          // whole tile: turned in the wave's LDS buffer so that a lane holds 4 consecutive keys of a query = 4 consecutive
+          // (descending) columns of its row of G: four 16-byte stores per lane instead of 16 dword stores
 #pragma unroll
-          for (int r = 0; r < 16; ++r) g0[(size_t)(q0 + mfma_row(r, half)) * gs1] = sv[r];
+          for (int r = 0; r < 16; ++r) sw[mfma_row(r, half) * SRL + ql] = sv[r];
+          wave_lds_sync();
+          const int r8 = lane_o >> 3, c4 = lane_o & 7;
+          float *gq = p.g + ((size_t)h * p.Sq * p.B + b) * p.Rp + (p.Ek - 1 - p.rho_lo - kw0) - 4 * c4 - 3;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float *s4 = sw + (r8 + 8 * i) * SRL + 4 * c4;
+            const f32x4_u v = {s4[3], s4[2], s4[1], s4[0]};
+            *reinterpret_cast<f32x4_u *>(gq + (size_t)(q0 + r8 + 8 * i) * gs1) = v;
+          }
+          wave_lds_sync();
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -1330,6 +1382,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
           }
         }
       }
+      ISI_KV_STAMP(sb_ + 5);      // G stores issued
       // ---- dK^T += Q^T dS
       split_acc16(sv, sh, sl);
 #pragma unroll
@@ -1351,10 +1404,15 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
         }
       }
     }
+    ISI_KV_STAMP(sb_ + 6);        // dK issued
     __syncthreads();
+    ISI_KV_STAMP(sb_ + 7);
     if (more) commit(qp + 64);
+    ISI_KV_STAMP(sb_ + 8);
     __syncthreads();
+    ISI_KV_STAMP(sb_ + 9);
   }
+  ISI_KV_STAMP(1);
 
   // ---- add the two groups' partial results (group 1 -> LDS -> group 0) and store
   float *mg = smem;
@@ -1876,6 +1934,15 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
     rc = check_launch("unpack_drel");
   }
   return rc;
+}
+
+int rel_attention_bwd_debug_stamps(long long *host, int n) {
+#ifdef ISI_MEASURE
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_kv_stamps), sizeof(long long) * (size_t)(n < 512 ? n : 512)) == hipSuccess ? 0 : -2;
+#else
+  (void)host; (void)n;
+  return unsupported("phase timestamps need a -DISI_MEASURE build");
+#endif
 }
 
 }  // namespace isi

@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   const bool blk_on = btile < 2;                                                                       \
   const int st = kind, srow = (tid_o >> 3) & 31, squad = tid_o & 7;                                    \
   (void)st; (void)srow; (void)squad; (void)kind; (void)bqd; (void)bkg; (void)blk_on
-  auto prefetch = [&](int q0) {  // Q / dO blocks of the pair at q0 and the 64 highest rows of its band
+  auto prefetch = [&](int q0) __attribute__((always_inline)) {  // Q / dO blocks of the pair at q0 and the 64 highest rows of its band
     ISI_KV_ROLES;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1113,18 +1113,27 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
       pdsum = p.dsum[statb + q];
     }
   };
-  auto put_e = [&](int slot, int qd, const float4 v) {
+  auto put_e = [&](int slot, int qd, const float4 v) __attribute__((always_inline)) {
     uint2 hi, lo;
     split_f4(v, hi, lo);
     const int o = slot * HD + swz(slot, qd >> 1) + (qd & 1) * 4;
     *reinterpret_cast<uint2 *>(Ep + o) = hi;
     *reinterpret_cast<uint2 *>(Ep + o + RING_S * HD) = lo;
   };
-  auto commit = [&](int q0) {
+  // With kept logits neither the Q rows nor the ring of e are staged: their LDS holds a SECOND stage of Q^T / dO / dO^T (and
+  // of the per-query statistics), so that the next step's tiles are written while this step's are read -- one barrier per
+  // step instead of barrier, commit, barrier (2.7 k of a 9.5 k-cycle step, tools/stamps_attention_bwd.py)
+  unsigned short *Qtp1 = Qp, *Gp1 = Ep, *Gtp1 = Ep + 2 * 2 * 32 * HD;
+  float *stat1 = reinterpret_cast<float *>(Gtp1 + 2 * 2 * VR * 32);          // lse [64], dsum [64], evq [64]
+  constexpr bool two = SAVED && (size_t)2 * RING_S * HD >= (size_t)2 * 2 * 32 * HD + 2 * 2 * VR * 32 + 3 * 64 * 2;   // (hd 16: it does not fit)
+  auto commit = [&](int q0, int stage = 0) __attribute__((always_inline)) {
     ISI_KV_ROLES;
     if (blk_on) {
-      unsigned short *rows = (kind == 0 ? Qp : Gp) + (btile * 2) * 32 * HD;
-      unsigned short *cols = (kind == 0 ? Qtp : Gtp) + (btile * 2) * VR * 32;
+      // (stage 1 as element offsets from the first stage's arrays: a select between LDS pointers made them generic ones and
+      // sent the kernel's argument block to scratch)
+      const int o_qt = stage ? (int)(Qtp1 - Qtp) : 0, o_g = stage ? (int)(Gp1 - Gp) : 0, o_gt = stage ? (int)(Gtp1 - Gtp) : 0;
+      unsigned short *rows = (kind == 0 ? Qp : Gp + o_g) + (btile * 2) * 32 * HD;
+      unsigned short *cols = (kind == 0 ? Qtp + o_qt : Gtp + o_gt) + (btile * 2) * VR * 32;
       if (!(saved && kind == 0))      // (Q rows feed Q K^T and the band product only)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1154,9 +1163,10 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     }
     if (tid < 64) {
       const int qt = q0 + (tid & 32);
-      lse_s[tid] = q0 + tid < p.Sq ? plse * LOG2E : 0.f;
-      dsum_s[tid] = q0 + tid < p.Sq ? pdsum : 0.f;
-      evq_s[tid] = (q0 + tid) / p.Cq - qt / p.Cq;
+      const int o_st = stage ? (int)(stat1 - lse_s) : 0;           // stage 1: lse at stat1, dsum at stat1 + 64
+      lse_s[o_st + tid] = q0 + tid < p.Sq ? plse * LOG2E : 0.f;
+      lse_s[o_st + 64 + tid] = q0 + tid < p.Sq ? pdsum : 0.f;
+      if (!stage) evq_s[tid] = (q0 + tid) / p.Cq - qt / p.Cq;      // (the band product's; not used with kept logits)
     }
   };
 
@@ -1189,7 +1199,8 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   const unsigned short *Qb = Qp + (grp * 2) * 32 * HD, *Qtb = Qtp + (grp * 2) * VR * 32;
   const unsigned short *Gb = Gp + (grp * 2) * 32 * HD, *Gtb = Gtp + (grp * 2) * VR * 32;
   const float *lseb = lse_s + grp * 32, *dsumb = dsum_s + grp * 32;
-  const int *evqb = evq_s + grp * 32;
+  const int *evqb = evq_s + grp * 32;      // (used by the band product only: not with kept logits)
+  if (two && q_begin + 64 < q_end) prefetch(q_begin + 64);      // (two stages: the second step's tiles are on their way)
   float *sw = Sr + wave * 32 * SRL;
   const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
 
@@ -1201,7 +1212,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
   // the wave's LDS buffer when its step comes.
   typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
   f32x4_u lvn[4];
-  auto load_logits = [&](int q0_) {
+  auto load_logits = [&](int q0_) __attribute__((always_inline)) {
     const float *lt = p.logits + ((size_t)b * p.H + h) * p.Sq * p.ldl + min(kw0 + 4 * (lane & 7), p.ldl - 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) lvn[i] = *reinterpret_cast<const f32x4_u *>(lt + (size_t)min(q0_ + (lane >> 3) + 8 * i, p.Sq - 1) * p.ldl);
@@ -1212,7 +1223,16 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     const bool more = qp + 64 < q_end;
     const int sb_ = 4 + 12 * ((qp - q_begin) >> 6);
     ISI_KV_STAMP(sb_);
-    if (more) prefetch(qp + 64);
+    if (two) {
+      const int stg = ((qp - q_begin) >> 6) & 1;
+      if (more) commit(qp + 64, stg ^ 1);           // requested a step ago; that stage was last read a step ago (barrier below)
+      if (qp + 128 < q_end) prefetch(qp + 128);
+      Qtb = Qtp + (stg ? (int)(Qtp1 - Qtp) : 0) + (grp * 2) * VR * 32;
+      Gb = Gp + (stg ? (int)(Gp1 - Gp) : 0) + (grp * 2) * 32 * HD;
+      Gtb = Gtp + (stg ? (int)(Gtp1 - Gtp) : 0) + (grp * 2) * VR * 32;
+      lseb = lse_s + (stg ? (int)(stat1 - lse_s) : 0) + grp * 32;
+      dsumb = lseb + 64;
+    } else if (more) prefetch(qp + 64);
     ISI_KV_STAMP(sb_ + 1);
     const int q0 = qp + 32 * grp;
     const int rb = band0(q0);
@@ -1407,9 +1427,11 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_kv_split_kernel(const A
     ISI_KV_STAMP(sb_ + 6);        // dK issued
     __syncthreads();
     ISI_KV_STAMP(sb_ + 7);
-    if (more) commit(qp + 64);
-    ISI_KV_STAMP(sb_ + 8);
-    __syncthreads();
+    if (!two) {
+      if (more) commit(qp + 64);
+      ISI_KV_STAMP(sb_ + 8);
+      __syncthreads();
+    } else ISI_KV_STAMP(sb_ + 8);
     ISI_KV_STAMP(sb_ + 9);
   }
   ISI_KV_STAMP(1);

@@ -23,3 +23,6 @@ cp $O/pmc_hbm_traffic.json profiles/${R}_pmc_hbm_traffic.json
   echo
   cat $O/pmc_attention.txt; } > profiles/${R}_pmc_attention.txt
 hdr "rocprofv3 --kernel-trace -- python3 tools/bench_attention.py --modes 1 0 --precisions bf16x3   (attention op forward + backward, causal and unmasked)" $O/attention_kernel_trace.txt profiles/${R}_attention_kernel_trace.txt
+{ echo "# tools/bench_linear.py, tools/bench_linear_wgrad.py (M = 8200 rows; us and TFLOP/s-equivalent per product mode)"; grep -v amdgpu.ids $O/linear.txt; } > profiles/${R}_linear_layers.txt
+{ echo "# tools/bench_prior_train.py --batch 8 --steps 4 (eager) and --steps 10 --graph (the step replayed from a HIP graph)"; grep -v "amdgpu.ids\|UserWarning\|detach\|tokens/s  loss" $O/prior_train.txt; grep "ms" $O/prior_train.txt | grep -v Warn; echo "--- graph replay"; grep "ms" $O/prior_train_graph.txt | grep -v Warn; } > profiles/${R}_prior_train_step.txt
+[ -f $O/stamps.txt ] && { echo "# in-kernel cycle stamps (-DISI_MEASURE library): GEMM 256x256 and 128x64 tiles, attention backward (key-stationary kernel), attention forward"; grep -v amdgpu.ids $O/stamps.txt; } > profiles/${R}_cycle_stamps.txt

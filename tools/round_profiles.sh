@@ -32,5 +32,13 @@ python tools/bench_prior_train.py --batch 8 --steps 4 > $O/prior_train.txt 2>&1
 python tools/bench_train.py > $O/vqvae_train.txt 2>&1
 python tools/bench_prior.py > $O/prior_sampling.txt 2>&1
 python tools/bench_frontend.py > $O/frontend.txt 2>&1
+# round 4: the linear layers' GEMM / weight-gradient kernels, the training step replayed from a HIP graph, cycle stamps
+(python tools/bench_linear.py; python tools/bench_linear_wgrad.py) > $O/linear.txt 2>&1
+python tools/bench_prior_train.py --batch 8 --steps 10 --graph > $O/prior_train_graph.txt 2>&1
+if [ -f interactive-spectrogram-inpainting_amd/lib_measure/libisi_hip.so ]; then
+  (echo "## tools/stamps_gemm.py 2048 512 f16x3"; python tools/stamps_gemm.py 2048 512 f16x3; echo "## tools/stamps_gemm.py 512 512 f16x3"; python tools/stamps_gemm.py 512 512 f16x3
+   echo "## tools/stamps_attention_bwd.py 1"; python tools/stamps_attention_bwd.py 1; echo "## tools/stamps_fwd2.py bf16 1"; python tools/stamps_fwd2.py bf16 1
+   echo "## tools/stamps_fwd2.py bf16x3 1"; python tools/stamps_fwd2.py bf16x3 1) > $O/stamps.txt 2>&1
+fi
 rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_at1 $O/pmc_at2     # the sqlite / csv dumps are large; the summaries are what is kept
 tail -c 600 $O/bench.json

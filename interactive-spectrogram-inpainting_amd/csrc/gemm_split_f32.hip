@@ -426,7 +426,9 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
   if (rem > 0 && rem <= kGemmTailRows && M >= 8 * BM && (lda & 3) == 0) { g.tail = rem; g.M = M - rem; M = g.M; }
   // 128 x 64 tiles when 128 x 128 ones would leave CUs without a second workgroup
   const long tiles128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  const bool narrow = tiles128 < 512 || N % 128 != 0;
+  // (from one workgroup per CU on: M = 8200, N = 512, K = 2048 72 -> 66 us with 128 x 128 tiles, K = 512 the same either way)
+  const int narrow_below = knobs().gemm_narrow_below > 0 ? knobs().gemm_narrow_below : current_device_cu_count();
+  const bool narrow = tiles128 < narrow_below || N % 128 != 0;
   // 256 x 128 tiles (one workgroup per CU) where they come in whole rounds of the chip: the widest layers (measured at
   // M = 8200, K = 512, tools/bench_linear.py with ISI_GEMM_NO_WIDE: N = 2048 (two rounds) 79 -> 70 us, N = 1024 (one round)
   // 42 -> 40 us; N = 1536 (one and a half rounds) 63 -> 70 us: not taken)

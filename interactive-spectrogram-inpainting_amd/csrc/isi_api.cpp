@@ -32,6 +32,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_NO_WGRAD_HALO", &Knobs::no_wgrad_halo, 0, false},
     {"ISI_NO_GEMM_KERNEL", &Knobs::no_gemm_kernel, 0, false},
     {"ISI_GEMM_NO_WIDE", &Knobs::gemm_no_wide, 0, false},
+    {"ISI_GEMM_NARROW_BELOW", &Knobs::gemm_narrow_below, 0, false},
     {"ISI_CONV_PAIR_BM", &Knobs::conv_pair_bm, 0, false},
     {"ISI_CONV_PAIR_ALL", &Knobs::conv_pair_all, 0, false},
     {"ISI_CONV_TAP_MAJOR", &Knobs::conv_tap_major, 0, false},

@@ -17,6 +17,7 @@ struct Knobs {
   int no_convt_pair_kernel;     // ISI_NO_CONVT_PAIR_KERNEL: four phase launches instead of the fused transposed conv
   int no_tail_fusion;           // ISI_NO_TAIL_FUSION: the decoder's last two transposed convolutions as two full layers
   int no_gemm_kernel;           // ISI_NO_GEMM_KERNEL: the 1x1 implicit-GEMM convolution kernel for the linear layers
+  int gemm_narrow_below;        // ISI_GEMM_NARROW_BELOW: 128 x 64 tiles when 128 x 128 ones would number fewer than this (0: the CU count)
   int gemm_no_wide;             // ISI_GEMM_NO_WIDE: 128 x 128 tiles where the linear-layer GEMM would take 256 x 128 ones
   int no_wgrad_halo;            // ISI_NO_WGRAD_HALO: per-tap im2col weight-gradient kernel instead of the halo-staged one
   int conv_pair_bm;             // ISI_CONV_PAIR_BM: 128 / 256 forces the tile height of the LDS-DMA convolution (0: per shape)

@@ -641,7 +641,8 @@ typedef struct isi_vqvae_out {
   float *quant_b;    /* [B, Hb, Wb, D]  channels-last                        */
   int64_t *id_t;     /* [B, Ht, Wt]                                          */
   int64_t *id_b;     /* [B, Hb, Wb]                                          */
-  float *scalars;    /* [4]: diff_t, perplexity_t, diff_b, perplexity_b      */
+  float *scalars;    /* [5]: diff_t, perplexity_t, diff_b, perplexity_b, diff_t + diff_b (what VQVAE.forward returns as
+                      * `diff`, vqvae.py:263,275,277)                                                        */
 } isi_vqvae_out;
 
 #define ISI_MODE_ENCODE 1  /* VQVAE.encode        vqvae.py:251-278 */

@@ -180,6 +180,10 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D);
 int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,
                     int D, float *out2, hipStream_t stream);
+// both levels in one launch + out5[4] = diff_t + diff_b; the sum alone (out5[0] + out5[2]) for the two-launch paths
+int vq_finalize2_f32(const float *sse_t, int np_t, const int32_t *counts_t, int K_t, int64_t N_t, const float *sse_b, int np_b,
+                     const int32_t *counts_b, int K_b, int64_t N_b, int D, float *out5, hipStream_t stream);
+int vq_scalars_sum_f32(float *out5, hipStream_t stream);
 int embed_code_f32(const int64_t *idx, const float *codes, float *out, int64_t N, int D, int K,
                    hipStream_t stream);
 

@@ -776,6 +776,52 @@ __global__ void vq_finalize_kernel(const float *__restrict__ sse_part, int n_par
   }
 }
 
+// Both levels' scalars in ONE launch behind the bottom search (the forward's fused path): threads [0, 256) finish the top
+// level, [256, 512) the bottom level; out5 = {diff_t, perplexity_t, diff_b, perplexity_b, diff_t + diff_b}.
+__global__ __launch_bounds__(512) void vq_finalize2_kernel(const float *__restrict__ sse_t, int np_t,
+                                                           const int32_t *__restrict__ counts_t, int K_t, int64_t N_t,
+                                                           const float *__restrict__ sse_b, int np_b,
+                                                           const int32_t *__restrict__ counts_b, int K_b, int64_t N_b,
+                                                           int D, float *__restrict__ out5) {
+  __shared__ float red[2][256];
+  __shared__ float diff[2];
+  const int lvl = threadIdx.x >> 8, tid = threadIdx.x & 255;
+  const float *sse_part = lvl ? sse_b : sse_t;
+  const int32_t *counts = lvl ? counts_b : counts_t;
+  const int n_part = lvl ? np_b : np_t, K = lvl ? K_b : K_t;
+  const int64_t N = lvl ? N_b : N_t;
+  float s = 0.f;
+  for (int i = tid; i < n_part; i += 256) s += sse_part[i];
+  red[lvl][tid] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[lvl][tid] += red[lvl][tid + o];
+    __syncthreads();
+  }
+  const float sse = red[lvl][0];
+  __syncthreads();
+  float h = 0.f;
+  for (int i = tid; i < K; i += 256) {
+    const float pr = (float)counts[i] / (float)N;
+    h += pr * logf(fmaxf(pr, 1e-7f));
+  }
+  red[lvl][tid] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[lvl][tid] += red[lvl][tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float dd = sse / ((float)N * (float)D);
+    out5[2 * lvl] = dd;
+    out5[2 * lvl + 1] = expf(-red[lvl][0]);
+    diff[lvl] = dd;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) out5[4] = diff[0] + diff[1];
+}
+__global__ void vq_scalars_sum_kernel(float *__restrict__ out5) { out5[4] = out5[0] + out5[2]; }
+
 __global__ void embed_code_kernel(const int64_t *__restrict__ idx, const float *__restrict__ codes,
                                   float *__restrict__ out, int64_t N, int D4, int K) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -926,6 +972,20 @@ int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, in
   hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, stream, sse_part, n_part, counts, K,
                      N, D, out2);
   return check_launch("vq_finalize_f32");
+}
+
+int vq_finalize2_f32(const float *sse_t, int np_t, const int32_t *counts_t, int K_t, int64_t N_t, const float *sse_b, int np_b,
+                     const int32_t *counts_b, int K_b, int64_t N_b, int D, float *out5, hipStream_t stream) {
+  if (!sse_t || !counts_t || !sse_b || !counts_b || !out5 || np_t <= 0 || np_b <= 0 || K_t <= 0 || K_b <= 0 || N_t <= 0 ||
+      N_b <= 0 || D <= 0)
+    return invalid("vq_finalize2: bad argument");
+  hipLaunchKernelGGL(vq_finalize2_kernel, dim3(1), dim3(512), 0, stream, sse_t, np_t, counts_t, K_t, N_t, sse_b, np_b, counts_b,
+                     K_b, N_b, D, out5);
+  return check_launch("vq_finalize2_f32");
+}
+int vq_scalars_sum_f32(float *out5, hipStream_t stream) {
+  hipLaunchKernelGGL(vq_scalars_sum_kernel, dim3(1), dim3(1), 0, stream, out5);
+  return check_launch("vq_scalars_sum_f32");
 }
 
 int embed_code_f32(const int64_t *idx, const float *codes, float *out, int64_t N, int D, int K,

@@ -325,11 +325,11 @@ int unquantized_scalars(float *scalars2, hipStream_t st) {
 // copy of q written alongside.  `w1x1` = the 1x1 layer (its packed weight is followed by the blocked pair copy).
 int run_quantizer_fused(const isi_codebook_w &cb, const isi_conv_w &w1x1, const isi_src &a, const isi_src *b, int B, int H,
                         int W, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part, float *scalars2,
-                        float *wfrag_ws, hipStream_t st) {
+                        float *wfrag_ws, hipStream_t st, bool finalize = true) {
   const int Kpad = (int)round_up((size_t)w1x1.Cin, kBK);
   int rc = vq_conv1x1_nearest_f32(&a, b, w1x1.w + (size_t)w1x1.Cout * Kpad, w1x1.bias, cb.codes_kd, cb.e2, idx, q, q_pair,
                                   counts, sse_part, wfrag_ws, B, H, W, cb.D, cb.K, st, /*zero_counts*/ true);
-  if (rc) return rc;
+  if (rc || !finalize) return rc;     // (finalize = false: the caller finishes both levels with one launch, vq_finalize2_f32)
   const int64_t N = (int64_t)B * H * W;
   return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);
 }
@@ -363,9 +363,12 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   const int Kmax = std::max(w.quantize_t.K, w.quantize_b.K);
   int32_t *counts = static_cast<int32_t *>(ws.take((size_t)Kmax * sizeof(int32_t)));
   float *sse_part = ws.floats(256);
+  // the top level's statistics stay alive until the bottom search is done: one launch finishes both (fused path)
+  int32_t *counts_top = static_cast<int32_t *>(ws.take((size_t)Kmax * sizeof(int32_t)));
+  float *sse_top = ws.floats(256);
   float *wfrag_ws = ws.floats((size_t)D * round_up((size_t)(w.quantize_conv_b.Cin > w.quantize_conv_t.Cin ? w.quantize_conv_b.Cin
                                                                                                             : w.quantize_conv_t.Cin), kBK));
-  float *scal_ws = ws.floats(4);
+  float *scal_ws = ws.floats(8);
   if (dry) return ISI_OK;
   if (ws.off > ws.cap) {
     set_last_error("vqvae: workspace too small");
@@ -388,6 +391,8 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   // quantize_conv_{t,b} fused into the codebook searches: the pair pipeline only (pair8 sources, blocked weights)
   const bool fuse_vq = pairs && !w.no_quantize && !knobs().no_vq_fusion;
   bool bottom_pair_done = false;
+  bool top_deferred = false;      // top-level scalars not written yet (fused path)
+  int64_t N_top = 0;
 
   if (mode & ISI_MODE_ENCODE) {
     if (!x) return invalid("vqvae: x is null");
@@ -402,8 +407,10 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       isi_src s = src_nhwc(et.p, et.C, et.H, et.W);
       if (fuse_vq && vq_conv1x1_fusable(et.C, 0, D, w.quantize_t.K)) {
         rc = run_quantizer_fused(w.quantize_t, w.quantize_conv_t, s, nullptr, B, et.H, et.W, id_t, quant_t, q_t_pair,
-                                 counts, sse_part, scal + 0, wfrag_ws, st);
+                                 counts_top, sse_top, scal + 0, wfrag_ws, st, /*finalize*/ false);
         if (rc) return rc;
+        top_deferred = true;
+        N_top = (int64_t)B * et.H * et.W;
         goto top_done;
       }
       // UnquantizedBottleneck (bottleneck.py:107-119): the 1x1 convolution's output IS quant_t
@@ -437,10 +444,24 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       isi_src b = src_nhwc(eb.p, eb.C, sh.Hb, sh.Wq, eb.W);
       if (fuse_vq && vq_conv1x1_fusable(Cd, eb.C, D, w.quantize_b.K)) {
         rc = run_quantizer_fused(w.quantize_b, w.quantize_conv_b, a, &b, B, sh.Hb, sh.Wq, id_b, quant_b, q_b_pair, counts,
-                                 sse_part, scal + 2, wfrag_ws, st);
+                                 sse_part, scal + 2, wfrag_ws, st, /*finalize*/ !top_deferred);
         if (rc) return rc;
+        if (top_deferred) {
+          const int64_t N_b = (int64_t)B * sh.Hb * sh.Wq;
+          rc = vq_finalize2_f32(sse_top, vq_num_partials(N_top), counts_top, w.quantize_t.K, N_top, sse_part,
+                                vq_num_partials(N_b), counts, w.quantize_b.K, N_b, D, scal, st);
+          if (rc) return rc;
+          top_deferred = false;
+          bottom_pair_done = true;
+          goto scalars_done;
+        }
         bottom_pair_done = true;
         goto bottom_done;
+      }
+      if (top_deferred) {      // (the bottom level takes the two-launch path: finish the top level on its own)
+        rc = vq_finalize_f32(sse_top, vq_num_partials(N_top), counts_top, w.quantize_t.K, N_top, D, scal + 0, st);
+        if (rc) return rc;
+        top_deferred = false;
       }
       isi_dst d = dst_nhwc(w.no_quantize ? quant_b : zbuf, D, sh.Hb, sh.Wq);
       rc = conv2d_f32(&a, &b, w.quantize_conv_b.w, w.quantize_conv_b.bias, nullptr, &d, B, sh.Hb,
@@ -452,6 +473,9 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       if (rc) return rc;
     }
   bottom_done:;
+    rc = vq_scalars_sum_f32(scal, st);       // scalars[4] = diff_t + diff_b
+    if (rc) return rc;
+  scalars_done:;
   }
   if (pairs && (mode & ISI_MODE_DECODE)) {
     // forward: quant_t was encoded behind its search (dec_t reads it); decode: both maps arrive as fp32

@@ -306,7 +306,7 @@ class VQVAE(nn.Module):
         quant_b = torch.empty(B, Hb, Wq, D, **f32)
         id_t = torch.empty(B, Ht, Wt, dtype=torch.int64, device=dev)
         id_b = torch.empty(B, Hb, Wq, dtype=torch.int64, device=dev)
-        scalars = torch.empty(4, **f32)
+        scalars = torch.empty(5, **f32)
         dec = None
         if with_decode:
             fb = 2 ** len(self.dec._up)
@@ -317,9 +317,9 @@ class VQVAE(nn.Module):
         if self.disable_quantization:
             # UnquantizedBottleneck.forward (bottleneck.py:107-119): diff zeros(1) each -> unsqueeze(0) and summed
             # (vqvae.py:263,275,277): [1, 1]; no indices; perplexity tensor([inf])
-            return (dec, quant_t.permute(0, 3, 1, 2), quant_b.permute(0, 3, 1, 2), (scalars[0] + scalars[2]).reshape(1, 1),
+            return (dec, quant_t.permute(0, 3, 1, 2), quant_b.permute(0, 3, 1, 2), scalars[4].reshape(1, 1),
                     None, None, scalars[1:2], scalars[3:4])
-        diff = (scalars[0] + scalars[2]).reshape(1)  # diff_t.unsqueeze(0) + diff_b.unsqueeze(0), vqvae.py:263,275,277
+        diff = scalars[4].reshape(1)  # diff_t.unsqueeze(0) + diff_b.unsqueeze(0), vqvae.py:263,275,277
         return (dec, quant_t.permute(0, 3, 1, 2), quant_b.permute(0, 3, 1, 2), diff, id_t, id_b,
                 scalars[1], scalars[3])
 

@@ -199,9 +199,10 @@ typedef struct isi_dst {
                            * the split; the scaling is undone exactly).  An operand outside the range
                            * gives Inf / NaN in the output, never a silently wrong value.        */
 
-#define ISI_CONV_W16 16   /* (with ISI_CONV_BF16X3 on a GEMM-shaped launch: followed by the split-bf16 pair copy of
-                           * isi_pack_linear_wT_bf16.)
-                           * with ISI_CONV_F16X3: the packed weight is followed in memory by its split-f16 pair copy
+#define ISI_CONV_W16_BF16 256 /* with ISI_CONV_BF16X3 on a GEMM-shaped launch (isi_linear_f32, 1x1 isi_conv2d_f32): the packed
+                           * weight is followed by its split-bf16 pair copy (isi_pack_linear_wT_bf16).  A bit of its own: the
+                           * split-f16 copy of ISI_CONV_W16 at the same address would give silently wrong products.      */
+#define ISI_CONV_W16 16   /* with ISI_CONV_F16X3: the packed weight is followed in memory by its split-f16 pair copy
                            * (isi_split_conv_weight_f16 written at packed_w + the packed size in floats: the weights'
                            * pieces are then prepared once instead of every time a tile is staged; same results bit
                            * for bit).  Ignored by the launches that do not run split products.          */

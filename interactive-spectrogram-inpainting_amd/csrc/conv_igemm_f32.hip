@@ -722,7 +722,8 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
     gx.nz = 1; gx.gate = gate; gx.ldg = dst->sw;          // (a gate is laid out like dst)
     return gemm_split_f32(s0->ptr, s0->sw, packed_w, bias, (res && res->ptr) ? res->ptr : nullptr, (res && res->ptr) ? res->sw : 0,
                           dst->ptr, dst->sw, W, Cout, s0->C, relu & 1, split_mode(relu), stream,
-                          (relu & ISI_CONV_W16) ? packed_w + (size_t)Cout * round_up((size_t)s0->C, kBK) : nullptr,
+                          ((split_mode(relu) == 3 && (relu & ISI_CONV_W16)) || (split_mode(relu) == 1 && (relu & ISI_CONV_W16_BF16)))
+                              ? packed_w + (size_t)Cout * round_up((size_t)s0->C, kBK) : nullptr,
                           gate ? &gx : nullptr);
   }
   const int64_t zmax = std::max(std::max(zs_in0, zs_w), std::max(zs_res, zs_out));

@@ -972,6 +972,7 @@ size_t conv_wgrad_workspace_floats(int Cout, int K, int M, int nphase) {
 template <int NP, int WR, int MT, int NT, bool ONEHOT = false>
 static void launch_wgrad_split(const WgradKArgs &a, int nzs, hipStream_t stream) {
   constexpr int WC = 4 / WR, TCO = WR * MT * 32, TK = WC * NT * 32;
+  static_assert(TCO <= kBandTileMax && kBK == kBandChunk, "a banded launch reads at most this far beyond a row's band (kMargin)");
   constexpr size_t smem = (size_t)NP * (TCO + TK) * LDB * sizeof(unsigned short) + 8 * TCO * sizeof(float);
   static DeviceOnce attr_set;
   if (smem > 48 * 1024 && !attr_set.done()) {

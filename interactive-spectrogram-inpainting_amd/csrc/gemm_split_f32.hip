@@ -422,6 +422,7 @@ int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bia
       g.hi_slope = extra->hi_slope; g.hi_base = extra->hi_base;
     }
   }
+  static_assert(BM <= kBandTileMax, "banded launches (win_rpu) run 128-row tiles: what kMargin of the attention backward covers");
   const int rem = M % BM;
   if (rem > 0 && rem <= kGemmTailRows && M >= 8 * BM && (lda & 3) == 0) { g.tail = rem; g.M = M - rem; M = g.M; }
   // 128 x 64 tiles when 128 x 128 ones would leave CUs without a second workgroup

@@ -209,7 +209,8 @@ int isi_linear_f32(const isi_linear_args *a, void *stream) {
   gx.drop_p = a->drop_p; gx.drop_seed = a->drop_seed;
   const size_t kpad = ((size_t)a->K + 31) / 32 * 32;
   return gemm_split_f32(a->x, a->ldx, a->packed_w, a->bias, a->residual, a->residual ? a->ldr : 0, a->out, a->ldo, a->M, a->N,
-                        a->K, a->flags & 1, mode, S(stream), (a->flags & ISI_CONV_W16) ? a->packed_w + (size_t)a->N * kpad : nullptr,
+                        a->K, a->flags & 1, mode, S(stream),
+                        ((mode == 3 && (a->flags & ISI_CONV_W16)) || (mode == 1 && (a->flags & ISI_CONV_W16_BF16))) ? a->packed_w + (size_t)a->N * kpad : nullptr,
                         &gx);
 }
 int isi_conv_transpose2d_k4s2_gated_f32(const isi_src *src, const float *packed_w, const float *bias,

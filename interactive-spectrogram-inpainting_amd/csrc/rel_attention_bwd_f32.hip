@@ -1666,6 +1666,7 @@ __device__ __forceinline__ void attn_bwd_tail_key(const AttnBwdKArgs &p, float *
 // band, kMargin columns on either side (128-column tiles of dE plus the chunk rounding of both products: < 264).
 // One wave per row of G; rows = (head, query, batch).
 constexpr int kMargin = 288;
+static_assert(kMargin >= kBandTileMax + kBandChunk - 2, "margins of G cover a banded tile of either product + its chunk rounding");
 __global__ __launch_bounds__(256) void attn_zero_margins_kernel(float *__restrict__ g, long rows, int Sq, int B, int Rp,
                                                                 int lo_slope, int lo_base, int hi_slope, int hi_base) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -175,8 +175,8 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, bias: Optional[torch.Tensor]
         if r2.stride(1) != 1:
             r2 = r2.contiguous()
         res = _hip.isi_src(r2.data_ptr(), n_out, 0, 1, 0, r2.stride(0))
-    w16 = 16 if ((prec == "f16x3" and getattr(packed_w, "isi_w16", False)) or
-                 (prec == "bf16x3" and getattr(packed_w, "isi_w16_bf16", False))) else 0          # ISI_CONV_W16
+    w16 = (16 if (prec == "f16x3" and getattr(packed_w, "isi_w16", False)) else                    # ISI_CONV_W16
+           256 if (prec == "bf16x3" and getattr(packed_w, "isi_w16_bf16", False)) else 0)         # ISI_CONV_W16_BF16
     if dropout_p > 0.0 or gate_scale != 1.0:
         a = _hip.isi_linear_args()
         a.x, a.ldx, a.packed_w = x2.data_ptr(), x2.stride(0), packed_w.data_ptr()

@@ -760,3 +760,27 @@ def test_graphed_training_step_draws_fresh_dropout_masks():
         finally:
             _ops.set_dropout_seed_base(None)
         assert (a != b) == differ, (p, a, b)
+
+
+def test_weight_leaving_the_f16_range_mid_training_is_loud():
+    """a weight under training is compared against the split-f16 operand range only every ~256 versions
+    (`_ops.WeightRange`).  A weight that leaves the range INSIDE that window must not give silently wrong products: the
+    lagged monitor still says "in range", the GEMM runs split-f16 products, the weight's f16 pieces overflow and the affected
+    output column is non-finite -- loud.  An exact re-check (inference weights) sends the same weight to the six-term mode."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    dev = _dev()
+    torch.manual_seed(3)
+    w = (torch.randn(512, 512, device=dev) * 0.05).requires_grad_(True)
+    x = torch.randn(300, 512, device=dev)
+    mon = _ops.WeightRange()
+    assert mon.update(w, inference=False)
+    with torch.no_grad():
+        w[7, 3] = 100.0            # |w| >= 64: beyond the f16 pieces' range (operands are scaled by 2^10)
+    assert mon.update(w, inference=False)          # inside the window: not looked at again
+    y = _ops.linear(x, _ops.pack_linear_weight(w, range_check=True), None, 512, precision="f16x3")
+    assert not torch.isfinite(y[:, 7]).all()
+    assert torch.isfinite(y[:, :7]).all() and torch.isfinite(y[:, 8:]).all()
+    assert not mon.update(w, inference=True)       # an exact check sees it
+    y6 = _ops.linear(x, _ops.pack_linear_weight(w, range_check=False), None, 512, precision="bf16x6")
+    ref = x.double() @ w.detach().double().t()
+    assert float((y6.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())

@@ -147,6 +147,10 @@ int isi_pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Ci
  * to isi_conv2d_f32 with ISI_CONV_BF16X3 | ISI_CONV_W16: the GEMM kernel stages the weight tile by plain copies.  N, K
  * multiples of 32; out: 2 K N floats, 16-byte aligned. */
 int isi_pack_linear_wT_bf16(const float *w, float *out, int N, int K, void *stream);
+/* The same for n weights in ONE launch: `table` = n rows of four 64-bit words {w, out, N, K} in device memory (w, out:
+ * addresses; every N, K a multiple of 32; out: 2 N K floats each).  blocks_per_weight: workgroups per weight (each walks its
+ * weight's 32 x 32 tiles with that stride). */
+int isi_pack_linear_wT_bf16_multi(const void *table, int n, int blocks_per_weight, void *stream);
 int isi_pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH,
                                    int KW, void *stream);
 /* Split-f16 pair copy of a packed weight (any of the packed layouts; n_floats % 4 == 0, 16-byte aligned):

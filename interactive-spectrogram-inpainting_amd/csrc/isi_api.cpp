@@ -140,6 +140,9 @@ int isi_pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, i
 int isi_pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, void *stream) {
   return pack_conv_weight_w16_f32(w, packed, Cout, Cin, KH, KW, S(stream));
 }
+int isi_pack_linear_wT_bf16_multi(const void *table, int n, int blocks_per_weight, void *stream) {
+  return pack_linear_wT_bf16_multi(table, n, blocks_per_weight, S(stream));
+}
 int isi_pack_linear_wT_bf16(const float *w, float *out, int N, int K, void *stream) {
   return pack_linear_wT_bf16(w, out, N, K, S(stream));
 }

@@ -217,6 +217,7 @@ int pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Cin, i
 int pack_conv_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW,
                          hipStream_t stream);
 int pack_linear_wT_bf16(const float *w, float *out, int N, int K, hipStream_t stream);
+int pack_linear_wT_bf16_multi(const void *table_dev, int n, int blocks_per_weight, hipStream_t stream);
 int pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH, int KW, hipStream_t stream);
 int pack_convT_k4s2_weight_f32(const float *w, float *packed, int Cin, int Cout,
                                hipStream_t stream);

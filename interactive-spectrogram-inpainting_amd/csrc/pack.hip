@@ -159,6 +159,49 @@ __global__ __launch_bounds__(256) void linear_wT_bf16_kernel(const float *__rest
   }
 }
 
+// The same for MANY weights in one launch (a training step of the prior re-packs ~80 weights: 80 launches of ~5 us, most
+// of it launch overhead): table[t] = {w, out, N, K} as four 64-bit words in device memory, grid (tiles of the largest
+// weight, number of weights).
+__global__ __launch_bounds__(256) void linear_wT_bf16_multi_kernel(const long long *__restrict__ table) {
+  const long long *e = table + 4 * (size_t)blockIdx.y;
+  const int N = (int)e[2], K = (int)e[3];
+  const int tn = N / 32, tiles = tn * (K / 32);
+  __shared__ float tile[32][33];
+  const float *w = reinterpret_cast<const float *>(e[0]);
+  float *outT = reinterpret_cast<float *>(e[1]);
+  float *out16 = outT + (size_t)N * K;
+  const int tid = threadIdx.x;
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {     // (uniform per workgroup)
+    const int n0 = (t % tn) * 32, k0 = (t / tn) * 32;
+    __syncthreads();
+    for (int i = tid; i < 1024; i += 256) {
+      const int r = i >> 5, c = i & 31;
+      tile[r][c] = w[(size_t)(n0 + r) * K + k0 + c];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int kk = tid >> 2, g = tid & 3;
+      float4 a, b;
+      a.x = tile[8 * g + 0][kk]; a.y = tile[8 * g + 1][kk]; a.z = tile[8 * g + 2][kk]; a.w = tile[8 * g + 3][kk];
+      b.x = tile[8 * g + 4][kk]; b.y = tile[8 * g + 5][kk]; b.z = tile[8 * g + 6][kk]; b.w = tile[8 * g + 7][kk];
+      const size_t o = (size_t)(k0 + kk) * N + n0 + 8 * g;
+      *reinterpret_cast<float4 *>(outT + o) = a;
+      *reinterpret_cast<float4 *>(outT + o + 4) = b;
+      uint2 h0, l0, h1, l1;
+      split_f4(a, h0, l0);
+      split_f4(b, h1, l1);
+      *reinterpret_cast<uint4 *>(out16 + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+      *reinterpret_cast<uint4 *>(out16 + o + 4) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    }
+  }
+}
+int pack_linear_wT_bf16_multi(const void *table_dev, int n, int blocks_per_weight, hipStream_t stream) {
+  if (!table_dev || n <= 0 || n > 65535 || blocks_per_weight <= 0) return invalid("pack_linear_wT_bf16_multi: bad argument");
+  hipLaunchKernelGGL(linear_wT_bf16_multi_kernel, dim3(blocks_per_weight, n), dim3(256), 0, stream,
+                     static_cast<const long long *>(table_dev));
+  return check_launch("pack_linear_wT_bf16_multi");
+}
+
 int pack_linear_wT_bf16(const float *w, float *out, int N, int K, hipStream_t stream) {
   if (!w || !out || N <= 0 || K <= 0 || (N & 31) || (K & 31)) return invalid("pack_linear_wT_bf16: N, K multiples of 32");
   if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15)

@@ -14,6 +14,7 @@ from ..vqvae._ops import pack_conv_weight
 
 
 import os
+import weakref
 
 
 def _s(t):
@@ -100,14 +101,73 @@ def pack_linear_weight(weight: torch.Tensor, range_check=False, with_f16: bool =
     return packed
 
 
+BATCHED_WT_PACK = os.environ.get("ISI_BATCHED_WT_PACK", "1") != "0"
+
+
+class _WtPackGroup:
+    """The W^T operands of every linear layer under training, re-packed by ONE launch per optimizer step
+    (isi_pack_linear_wT_bf16_multi) instead of one launch per weight when its backward first asks (~80 launches of ~5 us per
+    step of the top prior).  An entry = (a view of the weight, its persistent output buffer, the version it was packed at);
+    a request that finds its entry stale re-packs every stale entry of its device in that one launch."""
+
+    def __init__(self):
+        self.entries = {}          # (device index, data_ptr, N, K) -> [weight view, out, packed version, weakref of the base]
+        self.tables = {}           # device index -> (keys in table order, device table)
+
+    def _alive(self, e) -> bool:
+        return e[3]() is not None
+
+    def get(self, w: torch.Tensor) -> torch.Tensor:
+        N, K = w.shape
+        dev = w.device.index or 0
+        key = (dev, w.data_ptr(), N, K)
+        e = self.entries.get(key)
+        if e is None or not self._alive(e):
+            out = torch.empty(2 * N * K, dtype=torch.float32, device=w.device)
+            out.isi_f16_ok = False
+            out.isi_w16_bf16 = True
+            base = w._base if w._base is not None else w
+            e = self.entries[key] = [w, out, None, weakref.ref(base)]
+            self.tables.pop(dev, None)
+        stamp = _hip.version_of(w)
+        if e[2] != stamp:
+            self._repack(dev, w)
+        return e[1]
+
+    def _repack(self, dev: int, like: torch.Tensor) -> None:
+        dead = [k for k, e in self.entries.items() if not self._alive(e)]
+        for k in dead:
+            del self.entries[k]
+            self.tables.pop(k[0], None)
+        hit = self.tables.get(dev)
+        if hit is None:
+            keys = [k for k in self.entries if k[0] == dev]
+            rows = [[self.entries[k][0].data_ptr(), self.entries[k][1].data_ptr(), k[2], k[3]] for k in keys]
+            hit = self.tables[dev] = (keys, torch.tensor(rows, dtype=torch.int64).to(like.device))
+        keys, table = hit
+        # (every entry of the device: after an optimizer step they are all stale, and a stale one left out would need
+        # its own launch later)
+        _hip.check(_hip.lib().isi_pack_linear_wT_bf16_multi(table.data_ptr(), len(keys), 64, _s(like)),
+                   "isi_pack_linear_wT_bf16_multi")
+        for k in keys:
+            e = self.entries[k]
+            e[2] = _hip.version_of(e[0])
+
+
+_WT_GROUP = _WtPackGroup()
+
+
 def pack_linear_weight_t(weight: torch.Tensor) -> torch.Tensor:
     """nn.Linear weight [N,K] -> operand of the input-gradient GEMM dX = dY W: W^T as a packed [K][N] weight followed
-    by its split-bf16 pair copy (isi_pack_linear_wT_bf16: one launch, and the GEMM kernel stages the weight tile by
-    plain copies); other shapes: the transposing copy."""
+    by its split-bf16 pair copy (isi_pack_linear_wT_bf16[_multi]: the GEMM kernel stages the weight tile by plain copies);
+    other shapes: the transposing copy.  The returned buffer belongs to the weight's entry of `_WT_GROUP` and is rewritten
+    by the next re-pack."""
     w = weight.detach()
     N, K = w.shape
     if (N % 32 == 0 and K % 32 == 0 and w.is_contiguous() and w.dtype == torch.float32 and w.is_cuda
             and w.data_ptr() % 16 == 0 and LINEAR_GRAD_PRECISION == "bf16x3"):
+        if BATCHED_WT_PACK:
+            return _WT_GROUP.get(w)
         out = torch.empty(2 * N * K, dtype=torch.float32, device=w.device)
         _hip.check(_hip.lib().isi_pack_linear_wT_bf16(w.data_ptr(), out.data_ptr(), N, K, _s(w)), "isi_pack_linear_wT_bf16")
         out.isi_f16_ok = False

@@ -154,7 +154,7 @@ int conv_wgrad_f32(const isi_src *s0, const isi_src *s1, const float *dy, float 
 // Band-limited products over the attention backward's G (GemmExtra.win_rpu, WgradBand): G is zeroed only in margins around
 // each row's band (rel_attention_bwd_f32.hip: kMargin), which must cover what a tile of either product reads beyond a row's
 // own band: at most one tile of rows / columns plus the K-chunk rounding.  The kernels assert their tiles against these.
-constexpr int kBandTileMax = 256;     // rows of a banded GEMM tile, columns of a banded weight-gradient tile: at most
+constexpr int kBandTileMax = 128;     // rows of a banded GEMM tile, columns of a banded weight-gradient tile: at most
 constexpr int kBandChunk = 32;        // K chunk of both kernels
 struct WgradBand { int win_rpu, lo_slope, lo_base, hi_slope, hi_base; int required; };   // required: fail rather than read outside the band (dY is only defined there)
 int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw_packed, float *db,

@@ -1663,9 +1663,11 @@ __device__ __forceinline__ void attn_bwd_tail_key(const AttnBwdKArgs &p, float *
 // G zeroed only where it is read but not written: with Cq = Ck = 1 every (query, key) pair has its own element, the
 // query-stationary kernel (and the one-row kernel) store the whole band of a row -- zeros included -- and both products
 // over G read a band of chunks / queries around it (GemmExtra, WgradBand): what has to be zero are the MARGINS of the
-// band, kMargin columns on either side (128-column tiles of dE plus the chunk rounding of both products: < 264).
+// band, kMargin columns on either side: a 128-row / 128-column tile of either product plus its chunk rounding reaches at
+// most kBandTileMax + kBandChunk - 2 = 158 columns beyond a row's own band (288 until the bound was tied to the kernels'
+// tile constants: the margins were 150 MB of zeros per call, more than the band itself).
 // One wave per row of G; rows = (head, query, batch).
-constexpr int kMargin = 288;
+constexpr int kMargin = 160;
 static_assert(kMargin >= kBandTileMax + kBandChunk - 2, "margins of G cover a banded tile of either product + its chunk rounding");
 __global__ __launch_bounds__(256) void attn_zero_margins_kernel(float *__restrict__ g, long rows, int Sq, int B, int Rp,
                                                                 int lo_slope, int lo_base, int hi_slope, int hi_base) {

@@ -44,6 +44,9 @@ class GraphedTrainingStep:
                  index_limits: Optional[Dict[int, int]] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainingStep needs the GPU (HIP graph capture)")
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # GradBucketReducer launches its all-reduces from autograd hooks on a side stream: not recorded here
+            raise NotImplementedError("GraphedTrainingStep records single-process steps; data-parallel steps run eagerly")
         self.static_inputs = list(static_inputs)
         self.index_limits = dict(index_limits or {})      # input position -> exclusive upper bound of its symbols
         self._pending = []

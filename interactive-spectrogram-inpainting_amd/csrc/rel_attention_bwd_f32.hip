@@ -591,6 +591,14 @@ __device__ __forceinline__ int ring_s(int r) {
 // ------------------------------------------------------------------ dQ and G (split)
 // ONE = true (precision 2): single-term bf16 products -- the lo.hi and hi.lo MFMAs of every product are left out
 // (north_star's "MFMA bf16" mode; the lo planes are still staged: the kernels are not bound by them)
+// phase timestamps of the query-stationary kernel (-DISI_MEASURE builds; tools/stamps_attention_bwd.py): workgroup 0, waves 0 and 4
+#ifdef ISI_MEASURE
+__device__ long long g_attn_q_stamps[512];
+#define ISI_Q_STAMP(i_) do { if (blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && (i_) < 256) \
+    g_attn_q_stamps[(wave >> 2) * 256 + (i_)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define ISI_Q_STAMP(i_) do { } while (0)
+#endif
 template <int HD, bool ONE = false, bool SAVED = false>
 __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const AttnBwdKArgs p) {
   constexpr int NKB = HD / 16, NSL = HD / 8, RPB = 128 / HD, NDB = (HD + 31) / 32, VR = NDB * 32;
@@ -764,9 +772,13 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
   float *tb = Sr + wave * 32 * SRL;
   const int nt = (31 / p.Cq + 31 / p.Ck) < 32 ? 1 : 2;
 
+  ISI_Q_STAMP(0);
   for (int kp = k_begin; kp < k_end; kp += 64) {
     const bool more = kp + 64 < k_end;
+    const int sb_ = 4 + 8 * ((kp - k_begin) >> 6);
+    ISI_Q_STAMP(sb_);
     if (more) prefetch(kp + 64);
+    ISI_Q_STAMP(sb_ + 1);
     const int k0 = kp + 32 * grp;
     const int rb = band0(k0);
 
@@ -888,6 +900,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
       for (int r = 0; r < 16; ++r) sv[r] = sv[r] * (acc[r] - dsum_i) * p.scale;
 
       }
+      ISI_Q_STAMP(sb_ + 2);      // dS in registers
       // ---- dQ^T += K^T dS^T
       s16x8_t sh[2], sl[2];
       split_acc16(sv, sh, sl);
@@ -910,6 +923,7 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         }
       }
 
+      ISI_Q_STAMP(sb_ + 3);      // dQ issued
       // ---- G[i, r(i,j)] += dS[i,j]
       if (from_g) {
         // (G was written by the key-stationary kernel)
@@ -951,10 +965,15 @@ __global__ __launch_bounds__(512) void rel_attention_bwd_q_split_kernel(const At
         wave_lds_sync();
       }
     }
+    ISI_Q_STAMP(sb_ + 4);
     __syncthreads();
+    ISI_Q_STAMP(sb_ + 5);
     if (more) commit(kp + 64);
+    ISI_Q_STAMP(sb_ + 6);
     __syncthreads();
+    ISI_Q_STAMP(sb_ + 7);
   }
+  ISI_Q_STAMP(1);
 
   // ---- add the two groups' partial dQ (group 1 -> LDS -> group 0) and store
   float *mg = smem;
@@ -1963,6 +1982,8 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
 
 int rel_attention_bwd_debug_stamps(long long *host, int n) {
 #ifdef ISI_MEASURE
+  if (n < 0)      // (n < 0: the query-stationary kernel's stamps, -n of them)
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_q_stamps), sizeof(long long) * (size_t)(-n < 512 ? -n : 512)) == hipSuccess ? 0 : -2;
   return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_kv_stamps), sizeof(long long) * (size_t)(n < 512 ? n : 512)) == hipSuccess ? 0 : -2;
 #else
   (void)host; (void)n;

@@ -38,3 +38,16 @@ for grp in range(2):
             mid = f"(tile skipped) {x[6] - x[1]:5d}"
         print(f"  step {s:2d} @{x[0] - t0:7d}: prefetch issue {x[1] - x[0]:5d} | {mid} | barrier {x[7] - x[6]:5d} | commit {x[8] - x[7]:5d} | barrier {x[9] - x[8]:5d} | step {x[9] - x[0]:6d}")
         s += 1
+
+# ---- the query-stationary kernel (dS read back from G): workgroup 0 = (causal) the query block with the longest key range
+assert _hip.lib().isi_debug_attention_bwd_stamps(buf, -512) == 0
+for grp in range(2):
+    r = [buf[grp * 256 + i] for i in range(256)]
+    t0 = r[0]
+    print(f"q kernel, wave {4 * grp}: loop starts 0, loop ends +{r[1] - t0}")
+    s = 0
+    while 4 + 8 * s + 7 < 256 and r[4 + 8 * s] >= t0 and (s == 0 or r[4 + 8 * s] > r[4 + 8 * (s - 1)]):
+        x = r[4 + 8 * s: 4 + 8 * s + 8]
+        mid = (f"dS ready {x[2] - x[1]:5d} | dQ {x[3] - x[2]:5d} | G part {x[4] - x[3]:5d}") if x[2] > x[1] else f"(tile skipped) {x[4] - x[1]:5d}"
+        print(f"  step {s:2d} @{x[0] - t0:7d}: prefetch issue {x[1] - x[0]:5d} | {mid} | barrier {x[5] - x[4]:5d} | commit {x[6] - x[5]:5d} | barrier {x[7] - x[6]:5d} | step {x[7] - x[0]:6d}")
+        s += 1

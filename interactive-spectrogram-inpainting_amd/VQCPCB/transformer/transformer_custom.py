@@ -71,15 +71,18 @@ class _LinearParams(nn.Module):
         return self._packed_t
 
     def run(self, x, relu=False, residual=None, rectified_input=False, grad_pre_gated=False, dropout_p=0.0,
-            input_keep_scale=1.0):
+            input_keep_scale=1.0, carry=False):
         """`rectified_input` / `grad_pre_gated` / `dropout_p` / `input_keep_scale`: see _train.LinearFn (a feed-forward
         block's pair of layers)."""
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            return _train.LinearFn.apply(x, self.weight, self.bias, residual, relu, self.packed(), self.packed_t,
-                                         rectified_input, grad_pre_gated, dropout_p, input_keep_scale)
+            through = carry and _CARRY
+            out = _train.LinearFn.apply(x, self.weight, self.bias, residual, relu, self.packed(), self.packed_t,
+                                        rectified_input, grad_pre_gated, dropout_p, input_keep_scale, through)
+            return (out, x) if (carry and not through) else out
         if dropout_p > 0.0:
             raise RuntimeError("fused dropout is a training-path feature (no gradient is being recorded)")
-        return _ops.linear(x, self.packed(), self.bias, self.out_features, relu=relu, residual=residual)
+        y = _ops.linear(x, self.packed(), self.bias, self.out_features, relu=relu, residual=residual)
+        return (y, x) if carry else y
 
 
 class _LayerNormParams(nn.Module):
@@ -172,15 +175,19 @@ class RelativeMultiheadAttention(nn.Module):
             self._packed_t[which] = _ops.pack_linear_weight_t((W, W[:d], W[d:])[which])
         return self._packed_t[which]
 
-    def _project(self, x, which: int):
-        """which: 0 = q|k|v, 1 = q, 2 = k|v of the fused in-projection."""
+    def _project(self, x, which: int, carry: bool = False):
+        """which: 0 = q|k|v, 1 = q, 2 = k|v of the fused in-projection.  carry: (projection, x) -- _train.LinearFn."""
         d = self.d_model
         lo, hi = ((0, 3 * d), (0, d), (d, 3 * d))[which]
         # (the whole parameter, not a [0:3d] slice of it: a slice's backward materialises a zero-filled copy of the parameter)
         W, b = (self.in_proj_weight, self.in_proj_bias) if which == 0 else (self.in_proj_weight[lo:hi], self.in_proj_bias[lo:hi])
         if torch.is_grad_enabled() and (x.requires_grad or self.in_proj_weight.requires_grad):
-            return _train.LinearFn.apply(x, W, b, None, False, self._packs()[which], lambda: self._pack_t(which))
-        return _ops.linear(x, self._packs()[which], b, hi - lo)
+            through = carry and _CARRY
+            out = _train.LinearFn.apply(x, W, b, None, False, self._packs()[which], lambda: self._pack_t(which),
+                                        False, False, 0.0, 1.0, through)
+            return (out, x) if (carry and not through) else out
+        y = _ops.linear(x, self._packs()[which], b, hi - lo)
+        return (y, x) if carry else y
 
     def _packs(self):
         inference = not (torch.is_grad_enabled() and self.in_proj_weight.requires_grad)
@@ -201,34 +208,45 @@ class RelativeMultiheadAttention(nn.Module):
         return self._project(mem, 2)
 
     def forward(self, x: torch.Tensor, mem: Optional[torch.Tensor], mask: MaskArg = None,
-                kv: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Attention output BEFORE the output projection ([Sq,B,d]); `mem is None` = self-attention."""
+                kv: Optional[torch.Tensor] = None, carry: bool = False):
+        """Attention output BEFORE the output projection ([Sq,B,d]); `mem is None` = self-attention.  carry: (output, x) with
+        x handed on THROUGH the in-projection's autograd node, for the residual add behind the block (_train.LinearFn)."""
         d = self.d_model
         Sq = x.shape[0]
+        xc = x
         if mem is None and kv is None:
-            a, b = self._project(x, 0), None
+            a, b = self._project(x, 0, carry), None
+            if carry:
+                a, xc = a
             Sk = Sq
         else:
             W = self.in_proj_weight
             if (kv is None and torch.is_grad_enabled() and W.requires_grad and d % 32 == 0 and self.in_proj_bias is not None):
                 # training: both in-projections as one autograd node (their weight gradients fill one [3d, d] tensor)
                 packs = self._packs()
-                a, b = _train.CrossInProjFn.apply(x, mem, W, self.in_proj_bias, packs[1], packs[2],
-                                                  lambda: self._pack_t(1), lambda: self._pack_t(2))
+                through = carry and _CARRY
+                out = _train.CrossInProjFn.apply(x, mem, W, self.in_proj_bias, packs[1], packs[2],
+                                                 lambda: self._pack_t(1), lambda: self._pack_t(2), through)
+                a, b = out[0], out[1]
+                if through:
+                    xc = out[2]
             else:
-                a = self._project(x, 1)
+                a = self._project(x, 1, carry)
+                if carry:
+                    a, xc = a
                 b = kv if kv is not None else self.project_kv(mem)
             Sk = b.shape[0]
         mode, dense = _classify_mask(mask, Sq, Sk, x.device)
         if torch.is_grad_enabled() and a.requires_grad:
-            return _train.RelAttentionFn.apply(a, b, self.rel_embeddings, self.nhead, self.Cq, self.Ck, self.Ek,
-                                               mode, dense)
+            o = _train.RelAttentionFn.apply(a, b, self.rel_embeddings, self.nhead, self.Cq, self.Ck, self.Ek, mode, dense)
+            return (o, xc) if carry else o
         if b is None:
             q, k, v = a[..., :d], a[..., d:2 * d], a[..., 2 * d:]
         else:
             q, k, v = a, b[..., :d], b[..., d:]
-        return _ops.rel_attention(q, k, v, self.rel_embeddings, self.nhead, self.Cq, self.Ck, self.Ek,
-                                  mask_mode=mode, dense_mask=dense)
+        o = _ops.rel_attention(q, k, v, self.rel_embeddings, self.nhead, self.Cq, self.Ck, self.Ek,
+                               mask_mode=mode, dense_mask=dense)
+        return (o, xc) if carry else o
 
 
 
@@ -240,6 +258,11 @@ _FF_GATE = os.environ.get("ISI_FF_GATE", "1") != "0"
 
 # ISI_FUSED_DROPOUT=0: the layers' dropouts as torch's kernels (A/B switch)
 _FUSED_DROPOUT = os.environ.get("ISI_FUSED_DROPOUT", "1") != "0"
+
+
+# ISI_RESIDUAL_CARRY=0: a residual branch's input read twice by autograd (its two gradients summed by a kernel of torch's)
+# instead of being handed on through the branch's first linear node (A/B switch; _train.LinearFn: `carry`)
+_CARRY = os.environ.get("ISI_RESIDUAL_CARRY", "1") != "0"
 
 
 def _drop(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
@@ -271,10 +294,10 @@ def _feed_forward(layer: nn.Module, x: torch.Tensor, norm: _LayerNormParams) -> 
              and _ops.fused_tails_ok(M, layer.linear1.out_features, layer.linear1.in_features)
              and _ops.fused_tails_ok(M, layer.linear2.in_features, layer.linear2.out_features))
     if fused:
-        h = layer.linear1.run(x, relu=True, grad_pre_gated=True, dropout_p=p)
+        h, x = layer.linear1.run(x, relu=True, grad_pre_gated=True, dropout_p=p, carry=True)   # (x: handed on through linear1's node)
         return _add_norm(layer, layer.linear2, h, x, norm, rectified_input=True, input_keep_scale=1.0 / (1.0 - p))
-    h = _drop(layer, layer.linear1.run(x, relu=True, grad_pre_gated=_FF_GATE))
-    return _add_norm(layer, layer.linear2, h, x, norm, rectified_input=_FF_GATE)
+    h, x = layer.linear1.run(x, relu=True, grad_pre_gated=_FF_GATE, carry=True)
+    return _add_norm(layer, layer.linear2, _drop(layer, h), x, norm, rectified_input=_FF_GATE)
 
 
 class TransformerEncoderLayerCustom(nn.Module):
@@ -291,7 +314,7 @@ class TransformerEncoderLayerCustom(nn.Module):
         self.dropout = dropout  # identity in eval mode
 
     def forward(self, src: torch.Tensor, src_mask: MaskArg = None) -> torch.Tensor:
-        a = self.self_attn(src, None, src_mask)
+        a, src = self.self_attn(src, None, src_mask, carry=True)
         x = _add_norm(self, self.self_attn.out_proj, a, src, self.norm1)
         return _feed_forward(self, x, self.norm2)
 
@@ -318,9 +341,9 @@ class TransformerDecoderLayerCustom(nn.Module):
 
     def forward(self, tgt: torch.Tensor, memory: torch.Tensor, tgt_mask: MaskArg = None,
                 memory_mask: MaskArg = None, memory_kv: Optional[torch.Tensor] = None) -> torch.Tensor:
-        a = self.self_attn(tgt, None, tgt_mask)
+        a, tgt = self.self_attn(tgt, None, tgt_mask, carry=True)
         x = _add_norm(self, self.self_attn.out_proj, a, tgt, self.norm1)
-        c = self.multihead_attn(x, memory, memory_mask, kv=memory_kv)
+        c, x = self.multihead_attn(x, memory, memory_mask, kv=memory_kv, carry=True)
         x = _add_norm(self, self.multihead_attn.out_proj, c, x, self.norm2)
         return _feed_forward(self, x, self.norm3)
 

@@ -72,7 +72,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, relu: bool, packed, packed_t_fn, rectified_input: bool = False,
-                grad_pre_gated: bool = False, dropout_p: float = 0.0, input_keep_scale: float = 1.0):
+                grad_pre_gated: bool = False, dropout_p: float = 0.0, input_keep_scale: float = 1.0, carry: bool = False):
         """`rectified_input`: x is the (possibly dropout-scaled) output of a ReLU -- the input gradient is then zeroed
         where x <= 0 by the GEMM's epilogue, i.e. that ReLU's backward mask is applied HERE; the producing layer is
         built with `grad_pre_gated` and skips its own mask pass (a clone and a three-pass kernel over [M, 2048] per
@@ -80,7 +80,14 @@ class LinearFn(torch.autograd.Function):
         `dropout_p` (a rectified, pre-gated layer only): inverted dropout of the output inside the GEMM epilogue -- no mask
         tensor, no dropout kernels; the consumer is built with `input_keep_scale` = 1 / (1 - p), which its input-gradient
         GEMM applies together with the gate (what the dropout's backward would have done: kept units scaled, dropped
-        units -- zeros of the rectified tensor -- gated to zero)."""
+        units -- zeros of the rectified tensor -- gated to zero).
+        `carry`: also return x itself.  A residual branch reads its input twice -- this layer and the residual add of the
+        LayerNorm behind the branch -- and autograd would sum the two gradients with a kernel of its own (42 adds of
+        [S, B, d] per training step of the top prior); handed on through this node, the residual path's gradient arrives
+        HERE and is added by the input-gradient GEMM's epilogue."""
+        ctx.carry = carry
+        if carry:
+            ctx.set_materialize_grads(False)
         if dropout_p > 0.0:
             assert relu and grad_pre_gated, "fused dropout goes with a rectified output whose consumer gates the gradient"
             y = _ops.linear(x, packed, bias, weight.shape[0], relu=relu, residual=residual, dropout_p=dropout_p,
@@ -93,10 +100,10 @@ class LinearFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
-        return y
+        return (y, x) if carry else y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dcarry=None):
         x, weight, y = ctx.saved_tensors
         N, K = weight.shape
         dy2 = _rows(dy)
@@ -109,14 +116,17 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gate = _rows(x) if ctx.rectified_input else None
             dx = _ops.linear(dy2, ctx.packed_t_fn(), None, K, precision=_grad_precision(), gate=gate,
-                             gate_scale=ctx.input_keep_scale if gate is not None else 1.0).reshape(x.shape)
+                             gate_scale=ctx.input_keep_scale if gate is not None else 1.0,
+                             residual=_rows(dcarry) if dcarry is not None else None).reshape(x.shape)
+        elif dcarry is not None:
+            dx = dcarry
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw, db = linear_wgrad(_rows(x), dy2)
             if not ctx.has_bias:
                 db = None
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy2.reshape(dy.shape)
-        return dx, dw, db, dres, None, None, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None, None, None
 
 
 class CrossInProjFn(torch.autograd.Function):
@@ -126,22 +136,28 @@ class CrossInProjFn(torch.autograd.Function):
     gradients are written into the rows of one [3d, d] tensor that is returned as the parameter's gradient."""
 
     @staticmethod
-    def forward(ctx, x, mem, weight, bias, packed_q, packed_kv, packed_t_q_fn, packed_t_kv_fn):
+    def forward(ctx, x, mem, weight, bias, packed_q, packed_kv, packed_t_q_fn, packed_t_kv_fn, carry: bool = False):
         d = weight.shape[1]
         q = _ops.linear(x, packed_q, bias[:d], d)
         kv = _ops.linear(mem, packed_kv, bias[d:], 2 * d)
         ctx.fns = (packed_t_q_fn, packed_t_kv_fn)
         ctx.save_for_backward(x, mem, weight)
+        if carry:        # (LinearFn: the residual path's gradient of x arrives here)
+            ctx.set_materialize_grads(False)
+            return q, kv, x
         return q, kv
 
     @staticmethod
-    def backward(ctx, dq, dkv):
+    def backward(ctx, dq, dkv, dcarry=None):
         x, mem, weight = ctx.saved_tensors
         d = weight.shape[1]
         dq2, dkv2 = _rows(dq), _rows(dkv)
         dx = dmem = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = _ops.linear(dq2, ctx.fns[0](), None, d, precision=_grad_precision()).reshape(x.shape)
+            dx = _ops.linear(dq2, ctx.fns[0](), None, d, precision=_grad_precision(),
+                             residual=_rows(dcarry) if dcarry is not None else None).reshape(x.shape)
+        elif dcarry is not None:
+            dx = dcarry
         if ctx.needs_input_grad[1]:
             dmem = _ops.linear(dkv2, ctx.fns[1](), None, d, precision=_grad_precision()).reshape(mem.shape)
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
@@ -149,7 +165,7 @@ class CrossInProjFn(torch.autograd.Function):
             db = torch.empty(3 * d, dtype=torch.float32, device=weight.device)
             linear_wgrad(_rows(x), dq2, out_w=dw[:d], out_b=db[:d])
             linear_wgrad(_rows(mem), dkv2, out_w=dw[d:], out_b=db[d:])
-        return dx, dmem, dw, db, None, None, None, None
+        return dx, dmem, dw, db, None, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

@@ -141,18 +141,18 @@ int isi_pack_conv_weight_w16_f32(const float *w, float *packed, int Cout, int Ci
  * (autograd's conv backward-data behind train_vqvae.py:181): [Cin][KH*KW*Cout padded to 32] with the window rotated by
  * 180 degrees -- what isi_pack_conv_weight_f32 would make of w.flip(2, 3).transpose(0, 1), in one launch.  Run it
  * through isi_conv2d_f32 with padding K - 1 - p. */
+int isi_pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH,
+                                   int KW, void *stream);
 /* nn.Linear weight w [N][K] -> operand of its input-gradient GEMM dX = dY W (autograd's linear backward behind
  * train_autoregressive_model.py:199-201): out[0 .. K N) = W^T ([K][N] fp32: the "packed weight" of a 1x1 convolution
  * with K outputs and N inputs), out[K N .. 2 K N) = its split-bf16 pair copy (groups of 8 as {hi[8] | lo[8]}).  Pass it
- * to isi_conv2d_f32 with ISI_CONV_BF16X3 | ISI_CONV_W16: the GEMM kernel stages the weight tile by plain copies.  N, K
+ * to isi_conv2d_f32 / isi_linear_f32 with ISI_CONV_BF16X3 | ISI_CONV_W16_BF16: the GEMM kernel stages the weight tile by plain copies.  N, K
  * multiples of 32; out: 2 K N floats, 16-byte aligned. */
 int isi_pack_linear_wT_bf16(const float *w, float *out, int N, int K, void *stream);
 /* The same for n weights in ONE launch: `table` = n rows of four 64-bit words {w, out, N, K} in device memory (w, out:
  * addresses; every N, K a multiple of 32; out: 2 N K floats each).  blocks_per_weight: workgroups per weight (each walks its
  * weight's 32 x 32 tiles with that stride). */
 int isi_pack_linear_wT_bf16_multi(const void *table, int n, int blocks_per_weight, void *stream);
-int isi_pack_conv_dgrad_weight_f32(const float *w, float *packed, int Cout, int Cin, int KH,
-                                   int KW, void *stream);
 /* Split-f16 pair copy of a packed weight (any of the packed layouts; n_floats % 4 == 0, 16-byte aligned):
  * every quad of floats becomes {hi0..hi3 | lo0..lo3}, the f16 pieces of 1024 w, in the same 16 bytes. */
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream);

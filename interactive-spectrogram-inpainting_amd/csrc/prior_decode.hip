@@ -58,8 +58,20 @@ struct RowLinArgs {
 
 __device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }   // DPP path (isi_common.h)
 
+// Every field of a launch's argument block is "used" by an empty asm statement at the head of the kernel: the compiler
+// otherwise fetches the fields where they are first needed -- three or four DEPENDENT scalar-memory round trips (the later
+// ones to a 64-byte line of the freshly written block that no earlier load touched) in front of the first weight request,
+// in every one of the ~66 launches of a token.
+__device__ __forceinline__ void touch_args(const RowLinArgs &a) {
+  asm volatile("" ::"s"(a.x), "s"(a.x_stride), "s"(a.ln_g), "s"(a.ln_b), "s"(a.W), "s"(a.bias), "s"(a.res), "s"(a.res_stride),
+               "s"(a.res_g), "s"(a.res_b), "s"(a.out), "s"(a.out_stride));
+  asm volatile("" ::"s"(a.out2), "s"(a.out2_stride), "s"(a.split), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.relu), "s"(a.eps),
+               "s"(a.pos), "s"(a.x_pos), "s"(a.res_pos), "s"(a.out2_pos));
+}
+
 template <int MR>
 __global__ __launch_bounds__(256) void row_linear_ln_kernel(RowLinArgs a) {
+  touch_args(a);
   extern __shared__ __attribute__((aligned(16))) float sm[];
   if (a.pos) {
     const long p = *a.pos;
@@ -185,6 +197,8 @@ struct Gemv1Args {
 
 template <int KQ>   // float4 per lane of a K-long row: K <= 256 KQ
 __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
+  touch_args(g.r);
+  asm volatile("" ::"s"(g.part), "s"(g.NS), "s"(g.HD), "s"(g.nt));
   RowLinArgs &a = g.r;
   // replayable launches: the position comes from device memory.  The load is issued here and only waited for where an
   // offset actually depends on it (most launches of a position have none, or only the cache slot of their store)
@@ -230,14 +244,16 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
       if (qd < nq) {
         const int hh = (4 * qd) / g.HD, c = (4 * qd) % g.HD;
         const float *base = g.part + (size_t)hh * g.NS * (g.HD + 4);
+        // (no condition around a split's loads: behind `if (s2 < NS)` the compiler waited for each split's pair before it
+        // requested the next -- up to eight round trips in a row at the head of both out-projection launches of a layer,
+        // hipcc -S; splits beyond NS re-read the last one and are left out of the merge below)
 #pragma unroll
         for (int s2 = 0; s2 < PS; ++s2) {
-          if (s2 < g.NS) {
-            pv[i][s2] = *reinterpret_cast<const float4 *>(base + (size_t)s2 * (g.HD + 4) + c);
-            const float2 ml = *reinterpret_cast<const float2 *>(base + (size_t)s2 * (g.HD + 4) + g.HD);
-            pm[i][s2] = ml.x;
-            pl[i][s2] = ml.y;
-          }
+          const int s2c = min(s2, g.NS - 1);
+          pv[i][s2] = *reinterpret_cast<const float4 *>(base + (size_t)s2c * (g.HD + 4) + c);
+          const float2 ml = *reinterpret_cast<const float2 *>(base + (size_t)s2c * (g.HD + 4) + g.HD);
+          pm[i][s2] = ml.x;
+          pl[i][s2] = ml.y;
         }
       }
     }
@@ -351,6 +367,7 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
 // row_linear_ln_kernel, in their order: a row's result does not depend on the rows it shares a launch with.
 template <int KQ, int MR>
 __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
+  touch_args(a);
   long ppos = 0;
   if (a.pos) ppos = *a.pos;
   if (a.x_pos) a.x += ppos * a.x_pos;

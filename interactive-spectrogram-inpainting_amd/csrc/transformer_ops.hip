@@ -185,6 +185,12 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     int64_t k_sb, int64_t k_sh, int64_t v_ss, int64_t v_sb, int64_t v_sh, int64_t o_sb, int64_t o_sh,
     int q_pos, int Cq, int Ck, int Ek, int R, float scale, int chunk, float *__restrict__ partial,
     const int *__restrict__ pos, int self_keys) {
+  // (every argument "used" here: the compiler otherwise fetches them in four dependent scalar-memory round trips ahead of
+  // the first key request -- prior_decode.hip: touch_args)
+  asm volatile("" ::"s"(q), "s"(k), "s"(v), "s"(e), "s"(out), "s"(Sk), "s"(q_sb), "s"(q_sh), "s"(k_ss), "s"(k_sb), "s"(k_sh),
+               "s"(v_ss), "s"(v_sb), "s"(v_sh));
+  asm volatile("" ::"s"(o_sb), "s"(o_sh), "s"(q_pos), "s"(Cq), "s"(Ck), "s"(Ek), "s"(R), "s"(scale), "s"(chunk), "s"(partial),
+               "s"(pos), "s"(self_keys));
   // Replayable form (hipGraph): the position comes from device memory; for self-attention the key
   // count is position + 1 and the (fixed) number of splits shares it evenly.
   if (pos) {

@@ -589,7 +589,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="spectrograms per GPU per step")
-    ap.add_argument("--timer-stride", type=int, default=4,
+    ap.add_argument("--timer-stride", type=int, default=8,
                     help="per-kernel HIP-event timers on every n-th timed step (1: every step)")
     ap.add_argument("--spinup-ms", type=float, default=150.0,
                     help="untimed forwards before the warm-up steps until the clocks are steady")

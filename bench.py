@@ -255,22 +255,27 @@ def _top_prior(device):
         class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device)
 
 
+def _bottom_prior(device):
+    """The bottom-level prior (priors/transformer.py:848-872): [64,64] codemaps conditioned on the [32,32] top map."""
+    from interactive_spectrogram_inpainting.priors.transformer import UpsamplingVQTransformer
+    torch.manual_seed(3)
+    return UpsamplingVQTransformer(
+        shape=[64, 64], condition_shape=[32, 32], n_class=512, channel=256, kernel_size=5, n_block=4,
+        n_res_block=4, res_channel=256, d_model=512, embeddings_dim=32, positional_embeddings_dim=16,
+        use_relative_transformer=True, predict_frequencies_first=True, conditional_model=True,
+        class_conditioning_prepend_to_dummy_input=True,
+        class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
+        class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device)
+
+
 def _timerange_change(device, vqvae, calls=3):
     """SURVEY 8d metric 2, second half: latency of one /timerange-change-equivalent request
     (flask_server.py:685-870): layer 'top', mask = half of the top codemap's columns -> the top prior resamples
     512 codes, the bottom prior the 2048 codes under the up-sampled mask, then VQ-VAE decode_code of the new
     maps.  Top [32,32] / bottom [64,64] priors (d_model 512, 6+8 layers), random weights."""
     import inpainting
-    from interactive_spectrogram_inpainting.priors.transformer import UpsamplingVQTransformer
     top = _top_prior(device).eval()
-    torch.manual_seed(3)
-    bottom = UpsamplingVQTransformer(
-        shape=[64, 64], condition_shape=[32, 32], n_class=512, channel=256, kernel_size=5, n_block=4,
-        n_res_block=4, res_channel=256, d_model=512, embeddings_dim=32, positional_embeddings_dim=16,
-        use_relative_transformer=True, predict_frequencies_first=True, conditional_model=True,
-        class_conditioning_prepend_to_dummy_input=True,
-        class_conditioning_num_classes_per_modality={"instrument_family_str": 11, "pitch": 61},
-        class_conditioning_embedding_dim_per_modality={"instrument_family_str": 64, "pitch": 64}).to(device).eval()
+    bottom = _bottom_prior(device).eval()
     g = torch.Generator().manual_seed(5)
     top_code = torch.randint(0, 512, (1, 32, 32), generator=g).to(device)
     bottom_code = torch.randint(0, 512, (1, 64, 64), generator=g).to(device)
@@ -293,27 +298,62 @@ def _timerange_change(device, vqvae, calls=3):
             "config": "layer 'top', mask = columns 8..23 of the [32,32] top map; bottom [64,64]; + decode_code"}
 
 
-def _prior_training(device, dist=None, world=1, B=8, steps=3, warmup=2):
-    """BASELINE configs[3]: training step of the top prior (1024 tokens + start symbol, d_model 512, 6 + 8 layers, fp32,
-    dropout 0.1, label smoothing, Adam): forward + loss + backward + optimizer step, B codemaps PER GPU (weak scaling).
+def _ranks_in_sync(dist, device, tensors):
+    """Every rank must hold the same values after averaged updates: min == max over ranks of a few checksums."""
+    if dist is None:
+        return True
+    chk = torch.stack([t.detach().double().sum() for t in tensors])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(((hi - lo).abs() <= 1e-6 * hi.abs().clamp(min=1e-12)).all())
+
+
+def _time_steps(fn, steps, barrier, dist, device):
+    """ms per call of `fn` over `steps` calls between barriers, slowest rank; also the host's share (time to ENQUEUE the
+    steps, before the closing barrier)."""
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    t_host = time.perf_counter() - t0
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt, t_host], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, t_host = t.tolist()
+    return dt / steps * 1e3, t_host / steps * 1e3, out
+
+
+def _prior_training(device, dist=None, world=1, B=8, steps=20, warmup=2, level="top"):
+    """BASELINE configs[3]: training step of the prior -- level 'top': 1024 tokens + start symbol, self-conditional;
+    level 'bottom': the [64,64] bottom codemaps (4096 tokens + 4 start symbols) conditioned on the top map
+    (priors/transformer.py:848-872 UpsamplingVQTransformer) -- d_model 512, 6 + 8 layers, fp32, dropout 0.1, label
+    smoothing, Adam: forward + loss + backward + optimizer step, B codemaps PER GPU (weak scaling).
     With world > 1 it runs on EVERY rank: one process per GPU, `GradBucketReducer` (utils/distributed.py) all-reduces
     the flat gradient buffer bucket by bucket over RCCL while the backward is still running -- what replaces the
-    reference's nn.DataParallel (train_autoregressive_model.py:145,203-263).  Timed between barriers, slowest rank
-    counts."""
+    reference's nn.DataParallel (train_autoregressive_model.py:145,203-263).  Timed twice between barriers, slowest rank
+    counts: EAGER (the host enqueues ~1300 launches per step) and REPLAYED from HIP graph segments cut at the collectives
+    (utils/training/graphed_step.py; `value` / `ms_per_step` are the replayed step's, the mode a training run would use)."""
+    from interactive_spectrogram_inpainting.priors import _ops as _prior_ops
     from interactive_spectrogram_inpainting.utils.distributed import GradBucketReducer
     from interactive_spectrogram_inpainting.utils.losses.prediction import LabelSmoothingLoss
+    from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
     from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
     rank = dist.get_rank() if dist is not None else 0
-    m = _top_prior(device).train()                 # seeded: identical weights on every rank
+    m = (_top_prior(device) if level == "top" else _bottom_prior(device)).train()   # seeded: identical weights on every rank
     g = torch.Generator().manual_seed(300 + rank)  # every rank its own shard of the synthetic codemaps
     code = torch.randint(0, 512, (B, 32, 32), generator=g).to(device)
     mask = (torch.rand(B, 32, 32, generator=g) < 0.5).to(device)
+    bottom = torch.randint(0, 512, (B, 64, 64), generator=g).to(device)
     cls = {"pitch": torch.full((B, 1), 24, device=device),
            "instrument_family_str": torch.zeros(B, 1, dtype=torch.long, device=device)}
     reducer = GradBucketReducer(m.parameters()) if world > 1 else None
     opt = make_adam(m.parameters(), lr=3e-4)
     crit = LabelSmoothingLoss(512, 0.1, dim=1)
     torch.manual_seed(400 + rank)                  # dropout masks differ per rank like the data
+    tokens = 1024 if level == "top" else 4096
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -326,9 +366,14 @@ def _prior_training(device, dist=None, world=1, B=8, steps=3, warmup=2):
             reducer.zero()
         else:
             opt.zero_grad(set_to_none=True)
-        src, tgt = m.to_sequences(code, condition=code, class_conditioning=cls, mask=mask)
+        if level == "top":
+            target = code
+            src, tgt = m.to_sequences(code, condition=code, class_conditioning=cls, mask=mask)
+        else:
+            target = bottom
+            src, tgt = m.to_sequences(bottom, condition=code, class_conditioning=cls)
         logits, _ = m(tgt, condition=src)
-        loss = crit(m.to_time_frequency_map(logits, kind="target", permute_output_as_logits=True), code)
+        loss = crit(m.to_time_frequency_map(logits, kind="target", permute_output_as_logits=True), target)
         loss.backward()
         if reducer is not None:
             reducer.finish()
@@ -336,68 +381,61 @@ def _prior_training(device, dist=None, world=1, B=8, steps=3, warmup=2):
         return loss
     for _ in range(warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    in_sync = True
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-        # every rank must hold the same weights after the averaged updates
-        ps = list(m.parameters())
-        chk = torch.stack([ps[0].detach().double().sum(), ps[len(ps) // 2].detach().double().sum(),
-                           ps[-1].detach().double().sum()])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        in_sync = bool(((hi - lo).abs() <= 1e-6 * hi.abs().clamp(min=1e-12)).all())
+    eager_ms, eager_host_ms, loss = _time_steps(step, steps, barrier, dist, device)
+    in_sync = _ranks_in_sync(dist, device, [p for p in (list(m.parameters())[i] for i in (0, len(list(m.parameters())) // 2, -1))])
     assert torch.isfinite(loss).all()
     loss = None        # (an eager step's autograd graph kept alive keeps its AccumulateGrad nodes on the eager stream)
-    dt /= steps
-    graphed_ms = None
-    if world == 1:
-        # the same step recorded into a HIP graph and replayed (utils/training/graphed_step.py): the host's ~1300 launches per
-        # step become one; a fresh optimizer (capturable) on the same model
-        from interactive_spectrogram_inpainting.priors import _ops as _prior_ops
-        from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
-        opt = make_adam(m.parameters(), lr=3e-4, capturable=True)
-        graphed = GraphedTrainingStep(lambda c, k: step(), (code, mask), warmup=2, index_limits={0: 512})
+    # the same step recorded into HIP graph segments and replayed: the host's ~1300 launches per step become one call per
+    # segment (one segment per collective + 1); a fresh optimizer (capturable) on the same model
+    graphed_ms = graphed_host_ms = n_segments = None
+    graph_error = None
+    opt = make_adam(m.parameters(), lr=3e-4, capturable=True)
+    try:
+        statics = (code, mask) if level == "top" else (bottom, code)
+        graphed = GraphedTrainingStep(lambda *_a: step(), statics, warmup=2, index_limits={0: 512},
+                                      range_params=[p for p in m.parameters() if p.dim() == 2])
         try:
-            graphed(code, mask)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                gl = graphed(code, mask)
-            barrier()
-            graphed_ms = (time.perf_counter() - t0) / steps * 1e3
+            graphed(*statics)
+            graphed_ms, graphed_host_ms, gl = _time_steps(lambda: graphed(*statics), steps, barrier, dist, device)
             assert torch.isfinite(gl).all()
+            n_segments = graphed.n_segments
             graphed.finish()
+            in_sync = in_sync and _ranks_in_sync(dist, device, [list(m.parameters())[i] for i in (0, -1)])
         finally:
             _prior_ops.set_dropout_seed_base(None)
         del graphed
-    out = {"value": round(world * B * 1024 / dt, 0), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 1),
-           "tokens_per_s": round(world * B * 1024 / dt, 0), "codemaps_per_s": round(world * B / dt, 1),
+    except Exception as e:       # the eager numbers stand on their own
+        graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+    ms = graphed_ms if graphed_ms is not None else eager_ms
+    out = {"value": round(world * B * tokens / ms * 1e3, 0), "unit": "tokens/s", "ms_per_step": round(ms, 2),
+           "mode": "hip-graph replay" if graphed_ms is not None else "eager",
+           "tokens_per_s": round(world * B * tokens / ms * 1e3, 0), "codemaps_per_s": round(world * B / ms * 1e3, 1),
            "n_gpus": world, "steps": steps, "warmup": warmup, "global_batch": world * B, "scaling": "weak",
            "ranks_in_sync": in_sync,
-           "ms_per_step_hip_graph": round(graphed_ms, 1) if graphed_ms is not None else None,
+           "ms_per_step_eager": round(eager_ms, 2), "host_enqueue_ms_per_step_eager": round(eager_host_ms, 2),
+           "ms_per_step_hip_graph": round(graphed_ms, 2) if graphed_ms is not None else None,
+           "host_enqueue_ms_per_step_hip_graph": round(graphed_host_ms, 3) if graphed_host_ms is not None else None,
+           "graph_segments": n_segments,
            "collectives_per_step": (f"{len(reducer.buckets)} gradient buckets ({reducer.flat.numel() * 4 / 1e6:.1f} MB fp32 in "
                                     f"total), all-reduced while the backward runs") if reducer is not None else "none (1 rank)",
-           "config": f"top prior [32,32], B={B}/GPU x 1025 tokens, d_model 512, 6+8 layers, 8 heads, fp32, Adam, "
+           "config": (f"top prior [32,32], B={B}/GPU x 1025 tokens" if level == "top" else
+                      f"bottom prior [64,64] on top [32,32], B={B}/GPU x 4100 tokens (source 1025)") +
+                     f", d_model 512, 6+8 layers, 8 heads, fp32, Adam, "
                      f"attention products {os.environ.get('ISI_ATTENTION_PRECISION', 'bf16x3')}"}
+    if graph_error:
+        out["hip_graph_error"] = graph_error
     del m, opt, reducer
     torch.cuda.empty_cache()
     return out
 
 
-def _vqvae_training(device, dist, world, batch=64, steps=5, warmup=2):
+def _vqvae_training(device, dist, world, batch=64, steps=20, warmup=3):
     """BASELINE configs[2]: VQ-VAE training, global batch = world x 64 synthetic spectrograms, data parallel with one
-    process per GPU: train-mode forward (EMA-statistics all-reduce inside both quantisers), hand-written backward
-    whose gradient buckets are all-reduced by RCCL while it is still running, Adam step.  Runs on EVERY rank; timed
-    between barriers, slowest rank counts."""
+    process per GPU: train-mode forward (asynchronous EMA-statistics all-reduce behind both quantisers), hand-written
+    backward whose gradient buckets are all-reduced by RCCL while it is still running, Adam step.  Runs on EVERY rank; timed
+    between barriers, slowest rank counts -- eagerly and replayed from HIP graph segments cut at the collectives
+    (`value` / `ms_per_step`: the replayed step)."""
+    from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     torch.manual_seed(1)                       # identical weights on every rank
     m = VQVAE(in_channel=2).to(device).train()
@@ -421,33 +459,42 @@ def _vqvae_training(device, dist, world, batch=64, steps=5, warmup=2):
         return loss
     for _ in range(warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-        # every rank must hold the same codebook and weights after the exchanged updates
-        chk = torch.stack([m.quantize_b.embed.double().sum(), m.enc_b.blocks[0].weight.double().sum()])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        in_sync = bool(((hi - lo).abs() <= 1e-6 * hi.abs().clamp(min=1e-12)).all())
-    else:
-        in_sync = True
+    eager_ms, eager_host_ms, loss = _time_steps(step, steps, barrier, dist, device)
+    # every rank must hold the same codebook and weights after the exchanged updates
+    in_sync = _ranks_in_sync(dist, device, [m.quantize_b.embed, m.enc_b.blocks[0].weight])
     assert torch.isfinite(loss).all()
-    out = {"value": round(world * batch * steps / dt, 1), "unit": "spectrograms/s", "ms_per_step": round(dt * 1e3 / steps, 2),
+    loss = None
+    graphed_ms = graphed_host_ms = n_segments = None
+    graph_error = None
+    opt = make_adam(m.parameters(), lr=3e-4, capturable=True)
+    try:
+        graphed = GraphedTrainingStep(lambda _x: step(), (x,), warmup=2)
+        graphed(x)
+        graphed_ms, graphed_host_ms, gl = _time_steps(lambda: graphed(x), steps, barrier, dist, device)
+        assert torch.isfinite(gl).all()
+        n_segments = graphed.n_segments
+        graphed.finish()
+        in_sync = in_sync and _ranks_in_sync(dist, device, [m.quantize_b.embed, m.quantize_t.embed, m.enc_b.blocks[0].weight])
+        del graphed
+    except Exception as e:
+        graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+    ms = graphed_ms if graphed_ms is not None else eager_ms
+    out = {"value": round(world * batch / ms * 1e3, 1), "unit": "spectrograms/s", "ms_per_step": round(ms, 2),
+           "mode": "hip-graph replay" if graphed_ms is not None else "eager",
            "n_gpus": world, "steps": steps, "warmup": warmup, "global_batch": world * batch, "scaling": "weak",
            "ranks_in_sync": in_sync,
-           "collectives_per_step": "4 gradient buckets (5.5 MB fp32 in total) + 2 EMA-statistics messages (133 KB each)"
+           "ms_per_step_eager": round(eager_ms, 2), "host_enqueue_ms_per_step_eager": round(eager_host_ms, 2),
+           "ms_per_step_hip_graph": round(graphed_ms, 2) if graphed_ms is not None else None,
+           "host_enqueue_ms_per_step_hip_graph": round(graphed_host_ms, 3) if graphed_host_ms is not None else None,
+           "graph_segments": n_segments,
+           "collectives_per_step": "4 gradient buckets (5.5 MB fp32 in total) + 2 EMA-statistics messages (133 KB each, "
+                                   "asynchronous: waited for at the end of the forward)"
                                    if world > 1 else "none (1 rank)",
            "config": f"VQVAE default ctor, B={batch}/GPU of [2,128,512], MSE + 0.25 latent, Adam 3e-4, forward products "
                      f"three-term split-f16, input and weight gradients three-term split-bf16 (ISI_TRAIN_DGRAD_PRECISION=same: six-term "
                      f"input gradients)"}
+    if graph_error:
+        out["hip_graph_error"] = graph_error
     del m, opt
     torch.cuda.empty_cache()
     return out
@@ -597,7 +644,10 @@ def main():
     ap.add_argument("--no-prior", action="store_true", help="skip the secondary prior-sampling metric")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel VQ-VAE training leg")
     ap.add_argument("--prior-batch", type=int, default=8, help="codemaps per GPU and step of the prior's training legs")
-    ap.add_argument("--prior-steps", type=int, default=3)
+    ap.add_argument("--prior-steps", type=int, default=20)
+    ap.add_argument("--train-steps", type=int, default=20, help="timed steps of the VQ-VAE training leg")
+    ap.add_argument("--prior-bottom-batch", type=int, default=2, help="codemaps per step of the bottom prior's training row")
+    ap.add_argument("--prior-bottom-steps", type=int, default=8)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -682,7 +732,8 @@ def main():
     train_leg = None
     if not args.no_train:
         try:
-            train_leg = _vqvae_training(device, dist, world, batch=args.batch)
+            train_leg = _vqvae_training(device, dist, world, batch=args.batch, steps=args.train_steps,
+                                        warmup=min(3, args.train_steps))
         except Exception as e:      # a secondary leg must not take the headline metric with it ...
             if world > 1:           # ... but with collectives inside, a rank that skips the rest of the leg would leave
                 raise               # the others waiting in an all-reduce until the RCCL timeout: let torchrun tear down
@@ -862,7 +913,11 @@ def main():
                 except Exception as e:
                     line["prior_sampling"]["timerange_change"] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 torch.cuda.empty_cache()
-            leg("prior_training_single_gpu", lambda: _prior_training(device, B=args.prior_batch, steps=args.prior_steps))
+            leg("prior_training_single_gpu", lambda: _prior_training(device, B=args.prior_batch, steps=args.prior_steps,
+                                                                    warmup=min(2, args.prior_steps)))
+            if args.prior_bottom_steps > 0:
+                leg("prior_training_bottom", lambda: _prior_training(device, B=args.prior_bottom_batch, steps=args.prior_bottom_steps,
+                                                                    warmup=min(2, args.prior_bottom_steps), level="bottom"))
         if not args.no_cpu_baseline and world == 1:
             # the timed model's own codes of the bench batch go to the oracle (all samples, level by level)
             with torch.no_grad():

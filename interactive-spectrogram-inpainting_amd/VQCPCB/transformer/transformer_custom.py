@@ -171,8 +171,8 @@ class RelativeMultiheadAttention(nn.Module):
             self._packed_t, self._key_t = [None, None, None], key
         if self._packed_t[which] is None:
             d = self.d_model
-            W = self.in_proj_weight.detach()
-            self._packed_t[which] = _ops.pack_linear_weight_t((W, W[:d], W[d:])[which])
+            W = self.in_proj_weight       # (not a detached alias: the pack group holds the PARAMETER weakly, _ops._WtPackGroup)
+            self._packed_t[which] = _ops.pack_linear_weight_t((W, W[:d], W[d:])[which], owner=W)
         return self._packed_t[which]
 
     def _project(self, x, which: int, carry: bool = False):

@@ -48,6 +48,9 @@ ATTENTION_TERMS = {"f32": 0, "bf16x3": 3, "bf16": 1, "f16": 1}    # 16-bit MFMA 
 # the backward reads them instead of forming Q K^T, the band product Q E^T and its skew twice more -- 60 % of the
 # backward's time at that shape; 0 = recompute (no extra memory)
 SAVE_ATTENTION_LOGITS = os.environ.get("ISI_ATTN_SAVE_LOGITS", "1") != "0"
+# byte cap of ONE kept-logits buffer (B H Sq ceil32(Sk) floats: quadratic in the sequence length, 22 of them alive per step
+# of the top prior); an attention beyond it -- or one whose buffer the allocator cannot provide -- recomputes in its backward
+ATTENTION_LOGITS_MAX_MB = float(os.environ.get("ISI_ATTN_LOGITS_MAX_MB", "4096"))
 _PREC_FLAG = {"f32": 0, "bf16x3": 2, "bf16x6": 4, "f16x3": 8}
 _F16_WEIGHT_LIMIT = 63.98   # 65520 / 1024 and above rounds to inf in the f16 pieces
 
@@ -107,57 +110,71 @@ BATCHED_WT_PACK = os.environ.get("ISI_BATCHED_WT_PACK", "1") != "0"
 class _WtPackGroup:
     """The W^T operands of every linear layer under training, re-packed by ONE launch per optimizer step
     (isi_pack_linear_wT_bf16_multi) instead of one launch per weight when its backward first asks (~80 launches of ~5 us per
-    step of the top prior).  An entry = (a view of the weight, its persistent output buffer, the version it was packed at);
-    a request that finds its entry stale re-packs every stale entry of its device in that one launch."""
+    step of the top prior).  An entry = (weak reference to the tensor that OWNS the weight's storage -- the Parameter, or
+    the Parameter a slice was taken from --, its persistent output buffer, the version it was packed at); a request that
+    finds its entry stale re-packs every stale entry of its device in that one launch.  Nothing here keeps a weight alive:
+    when the owner is collected the entry (and its 2 N K output floats) goes with the next request or `purge()`."""
 
     def __init__(self):
-        self.entries = {}          # (device index, data_ptr, N, K) -> [weight view, out, packed version, weakref of the base]
+        self.entries = {}          # (device index, data_ptr, N, K) -> [weakref of the owner, out, packed version]
         self.tables = {}           # device index -> (keys in table order, device table)
 
     def _alive(self, e) -> bool:
-        return e[3]() is not None
+        return e[0]() is not None
 
-    def get(self, w: torch.Tensor) -> torch.Tensor:
-        N, K = w.shape
-        dev = w.device.index or 0
-        key = (dev, w.data_ptr(), N, K)
-        e = self.entries.get(key)
-        if e is None or not self._alive(e):
-            out = torch.empty(2 * N * K, dtype=torch.float32, device=w.device)
-            out.isi_f16_ok = False
-            out.isi_w16_bf16 = True
-            base = w._base if w._base is not None else w
-            e = self.entries[key] = [w, out, None, weakref.ref(base)]
-            self.tables.pop(dev, None)
-        stamp = _hip.version_of(w)
-        if e[2] != stamp:
-            self._repack(dev, w)
-        return e[1]
-
-    def _repack(self, dev: int, like: torch.Tensor) -> None:
+    def purge(self) -> int:
+        """Drops the entries whose weight is gone; returns how many are left."""
         dead = [k for k, e in self.entries.items() if not self._alive(e)]
         for k in dead:
             del self.entries[k]
             self.tables.pop(k[0], None)
+        return len(self.entries)
+
+    def get(self, weight: torch.Tensor, owner: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`weight`: the Parameter itself or a view of it; `owner`: the long-lived tensor whose death retires the entry
+        (default: the view's base, else `weight` itself -- NOT a detached alias: `detach()` has no `_base`, a weak reference
+        to it would die with the temporary)."""
+        N, K = weight.shape
+        dev = weight.device.index or 0
+        key = (dev, weight.data_ptr(), N, K)
+        e = self.entries.get(key)
+        if e is None or not self._alive(e):
+            out = torch.empty(2 * N * K, dtype=torch.float32, device=weight.device)
+            out.isi_f16_ok = False
+            out.isi_w16_bf16 = True
+            if owner is None:
+                owner = weight._base if weight._base is not None else weight
+            e = self.entries[key] = [weakref.ref(owner), out, None]
+            self.tables.pop(dev, None)
+        stamp = _hip.version_of(weight)
+        if e[2] != stamp:
+            self._repack(dev, weight.device)
+        return e[1]
+
+    def _repack(self, dev: int, device: torch.device) -> None:
+        self.purge()
         hit = self.tables.get(dev)
         if hit is None:
             keys = [k for k in self.entries if k[0] == dev]
-            rows = [[self.entries[k][0].data_ptr(), self.entries[k][1].data_ptr(), k[2], k[3]] for k in keys]
-            hit = self.tables[dev] = (keys, torch.tensor(rows, dtype=torch.int64).to(like.device))
+            rows = [[k[1], self.entries[k][1].data_ptr(), k[2], k[3]] for k in keys]
+            hit = self.tables[dev] = (keys, torch.tensor(rows, dtype=torch.int64).to(device))
         keys, table = hit
-        # (every entry of the device: after an optimizer step they are all stale, and a stale one left out would need
-        # its own launch later)
-        _hip.check(_hip.lib().isi_pack_linear_wT_bf16_multi(table.data_ptr(), len(keys), 64, _s(like)),
+        # (every live entry of the device: after an optimizer step they are all stale, and a stale one left out would
+        # need its own launch later)
+        _hip.check(_hip.lib().isi_pack_linear_wT_bf16_multi(table.data_ptr(), len(keys), 64,
+                                                            C.c_void_p(_hip.stream_ptr(device))),
                    "isi_pack_linear_wT_bf16_multi")
         for k in keys:
             e = self.entries[k]
-            e[2] = _hip.version_of(e[0])
+            owner = e[0]()
+            if owner is not None:
+                e[2] = _hip.version_of(owner)
 
 
 _WT_GROUP = _WtPackGroup()
 
 
-def pack_linear_weight_t(weight: torch.Tensor) -> torch.Tensor:
+def pack_linear_weight_t(weight: torch.Tensor, owner: Optional[torch.Tensor] = None) -> torch.Tensor:
     """nn.Linear weight [N,K] -> operand of the input-gradient GEMM dX = dY W: W^T as a packed [K][N] weight followed
     by its split-bf16 pair copy (isi_pack_linear_wT_bf16[_multi]: the GEMM kernel stages the weight tile by plain copies);
     other shapes: the transposing copy.  The returned buffer belongs to the weight's entry of `_WT_GROUP` and is rewritten
@@ -167,7 +184,7 @@ def pack_linear_weight_t(weight: torch.Tensor) -> torch.Tensor:
     if (N % 32 == 0 and K % 32 == 0 and w.is_contiguous() and w.dtype == torch.float32 and w.is_cuda
             and w.data_ptr() % 16 == 0 and LINEAR_GRAD_PRECISION == "bf16x3"):
         if BATCHED_WT_PACK:
-            return _WT_GROUP.get(w)
+            return _WT_GROUP.get(weight, owner)       # (the group keeps a WEAK reference to the weight's owner)
         out = torch.empty(2 * N * K, dtype=torch.float32, device=w.device)
         _hip.check(_hip.lib().isi_pack_linear_wT_bf16(w.data_ptr(), out.data_ptr(), N, K, _s(w)), "isi_pack_linear_wT_bf16")
         out.isi_f16_ok = False
@@ -337,7 +354,13 @@ def attention_logits_buffer(B: int, nhead: int, Sq: int, Sk: int, device) -> Opt
     _hip.check(_hip.lib().isi_knob_get(b"ISI_ATTN_OLD_FWD", C.byref(old)), "isi_knob_get")
     if old.value and ATTENTION_PRECISION != "f16":
         return None
-    return torch.empty(B, nhead, Sq, (Sk + 31) // 32 * 32, dtype=torch.float32, device=device)
+    ld = (Sk + 31) // 32 * 32
+    if B * nhead * Sq * ld * 4 > ATTENTION_LOGITS_MAX_MB * (1 << 20):
+        return None                      # beyond the byte cap: this attention's backward recomputes
+    try:
+        return torch.empty(B, nhead, Sq, ld, dtype=torch.float32, device=device)
+    except torch.cuda.OutOfMemoryError:
+        return None                      # no room for the logits: recompute instead of failing the step
 
 
 def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Optional[torch.Tensor], nhead: int,

@@ -224,23 +224,23 @@ class RelAttentionFn(torch.autograd.Function):
         d = a.shape[-1]
         return a, b[..., :d], b[..., d:]
 
-    _grad_mode = True      # torch.is_grad_enabled() at the time of `apply` (inside `forward` it is always off)
     workspace_fill = None  # tests: value the backward's workspace (G, partial sums) is filled with before the call
 
     @classmethod
     def apply(cls, *args):
-        cls._grad_mode = torch.is_grad_enabled()
-        return super().apply(*args)
+        # inside `forward` grad mode is always off: the caller's mode travels as an argument (not as class state: two
+        # threads, or a no_grad call between another call's apply and forward, would read each other's)
+        return super().apply(*args, torch.is_grad_enabled())
 
     @staticmethod
-    def forward(ctx, a, b, rel, nhead, Cq, Ck, Ek, mask_mode, dense_mask):
+    def forward(ctx, a, b, rel, nhead, Cq, Ck, Ek, mask_mode, dense_mask, grad_mode=True):
         a = a.contiguous()
         b = b.contiguous() if b is not None else None
         q, k, v = RelAttentionFn._split(a, b)
         Sq, B, _ = q.shape
         lse = torch.empty(B, nhead, Sq, dtype=torch.float32, device=q.device)
         # kept only when a backward will follow (under no_grad nothing needs a gradient)
-        keep = RelAttentionFn._grad_mode and any(ctx.needs_input_grad[:3])
+        keep = grad_mode and any(ctx.needs_input_grad[:3])
         logits = _ops.attention_logits_buffer(B, nhead, Sq, k.shape[0], q.device) if keep else None
         out = _ops.rel_attention(q, k, v, rel, nhead, Cq, Ck, Ek, mask_mode=mask_mode, dense_mask=dense_mask,
                                  lse=lse, logits=logits)
@@ -251,7 +251,7 @@ class RelAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         a_in, b_in, rel, out, lse, dense_mask, logits = ctx.saved_tensors
-        nhead, Cq, Ck, Ek, mask_mode, _ = ctx.cfg
+        nhead, Cq, Ck, Ek, mask_mode, precision = ctx.cfg
         q, k, v = RelAttentionFn._split(a_in, b_in)
         Sq, B, d = q.shape
         Sk = k.shape[0]
@@ -270,6 +270,7 @@ class RelAttentionFn(torch.autograd.Function):
         f.v_ss, f.v_sb, f.v_sh = v.stride(0), v.stride(1), hd
         f.o_ss, f.o_sb, f.o_sh = out.stride(0), out.stride(1), hd
         f.lse = lse.data_ptr()
+        f.precision = _ops._ATTN_PREC[precision]       # the mode the forward ran (and wrote its kept logits) in
         if logits is not None and f.precision >= 1:      # (a backward in the exact-fp32 mode recomputes)
             f.logits, f.logits_ld = logits.data_ptr(), logits.stride(2)
         a.d_out = dout.data_ptr()
@@ -281,7 +282,7 @@ class RelAttentionFn(torch.autograd.Function):
             ws.fill_(RelAttentionFn.workspace_fill)
         a.workspace, a.workspace_floats = ws.data_ptr(), nws
         _hip.check(L.isi_rel_attention_bwd_f32(C.byref(a), _s(q)), "isi_rel_attention_bwd_f32")
-        return da, db, drel, None, None, None, None, None, None
+        return da, db, drel, None, None, None, None, None, None, None
 
 
 class EmbeddingRowsFn(torch.autograd.Function):

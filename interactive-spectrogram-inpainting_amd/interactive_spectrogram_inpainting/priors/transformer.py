@@ -325,6 +325,13 @@ class VQNSynthTransformer(nn.Module):
         them saw a symbol outside its embedding table (training loops call it where they read the loss back)."""
         self._index_guard.flush()
 
+    def state_dict(self, *args, **kwargs):
+        # a checkpoint must not be written over a pending verdict (ADVICE r04): the deferred checks are read first
+        guard = getattr(self, "_index_guard", None)
+        if guard is not None:
+            guard.flush()
+        return super().state_dict(*args, **kwargs)
+
     def _get_combined_positional_embeddings(self, kind: Seq2SeqInputKind) -> torch.Tensor:
         if kind == Seq2SeqInputKind.Source:
             freq = self.source_positional_embeddings_frequency.repeat(1, 1, self.source_duration, 1)

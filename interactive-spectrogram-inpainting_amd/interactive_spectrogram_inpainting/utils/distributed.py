@@ -9,6 +9,8 @@ import torch
 import torch.distributed as dist
 from torch.utils.data import Sampler
 
+from .training.graphed_step import host_boundary, launch, recording
+
 
 def is_distributed() -> bool:
     return dist.is_available() and dist.is_initialized()
@@ -92,7 +94,7 @@ class GradBucketReducer:
     overlapping the rest of the backward.  `finish()` reduces whatever is left (parameters
     that received no gradient keep zeros), waits, and divides by the world size."""
 
-    def __init__(self, params, bucket_mb: float = 32.0):
+    def __init__(self, params, bucket_mb: float = 32.0, force_collectives: bool = False):
         self.params = [p for p in params if p.requires_grad]
         sizes = [p.numel() for p in self.params]
         dev = self.params[0].device
@@ -116,21 +118,30 @@ class GradBucketReducer:
         self.left = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.handles = []
-        if self.world > 1:
+        # (tests / single-GPU measurements: run the bucket collectives although there is nobody to exchange with)
+        self.force_collectives = bool(force_collectives) and is_distributed()
+        if self.world > 1 or self.force_collectives:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
 
     def zero(self) -> None:
         """Call instead of `zero_grad()` (which would detach the views)."""
-        self.flat.zero_()
+        launch(self.flat.zero_)          # (`launch`: plain call on the GPU; the CPU tests' op-list recording notes it)
         self.left = [b[2] for b in self.buckets]
         self.launched = [False] * len(self.buckets)
-        self.handles = []
+        if not recording():
+            self.handles = []      # (a recorded step's handle list belongs to its replays' boundary calls)
 
     def _launch(self, b: int) -> None:
         s, e, _ = self.buckets[b]
         self.launched[b] = True
-        self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        bucket = self.flat[s:e]
+
+        def go():
+            self.handles.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+        # a host call into RCCL: eagerly it happens now (from the gradient hook, while the backward goes on); in a recorded
+        # step the graph segment ends here and every replay makes the call between two segments (graphed_step.py)
+        host_boundary(go)
 
     def _on_grad(self, p) -> None:
         b = self.bucket_of[id(p)]
@@ -139,14 +150,18 @@ class GradBucketReducer:
             self._launch(b)
 
     def finish(self) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self.force_collectives:
             return
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
-        for h in self.handles:
-            h.wait()
-        self.flat.div_(self.world)
+
+        def wait_all():
+            for h in self.handles:
+                h.wait()
+            self.handles.clear()
+        host_boundary(wait_all)
+        launch(lambda: self.flat.div_(self.world))
 
 
 def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:

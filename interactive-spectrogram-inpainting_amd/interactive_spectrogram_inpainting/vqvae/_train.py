@@ -29,6 +29,7 @@ import torch
 import torch.distributed as dist
 
 from .. import _hip
+from ..utils.training.graphed_step import host_boundary
 from . import _ops
 from .encoder_decoder import RosinalityDecoder, RosinalityEncoder, RosinalityResBlock, _ConvParams
 
@@ -57,6 +58,7 @@ DGRAD_PRECISION = {"same": TRAIN_PRECISION, "bf16x3": 1 if TRAIN_PRECISION else 
 # Products of the weight-gradient GEMMs (flag bits of isi_conv_wgrad_f32's `transposed` word): three-term split by
 # default (relative error ~4e-6 of the gradient's maximum, far below the step-to-step noise of training and 50x
 # inside the parity tests' 2e-4), 'bf16x6' = fp32-grade, 'f32' = fp32 matrix pipe.
+FORCE_COLLECTIVES = os.environ.get("ISI_FORCE_COLLECTIVES", "0") == "1"
 WGRAD_FLAGS = {"f32": 0, "bf16x3": 2, "bf16x6": 4}[os.environ.get("ISI_WGRAD_PRECISION", "bf16x3")]
 
 
@@ -240,6 +242,8 @@ class Grads:
             self.views.append(self.flat[offsets[-1]:offsets[-1] + n].view_as(p))
             offsets.append(offsets[-1] + n)
         self.world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        # ISI_FORCE_COLLECTIVES=1 (tests / single-GPU measurements): issue the collectives in a 1-rank group too
+        self.collectives = self.world > 1 or (FORCE_COLLECTIVES and dist.is_available() and dist.is_initialized())
         # buckets = contiguous parameter ranges of roughly equal size
         self.bucket_of = [min(n_buckets - 1, offsets[i] * n_buckets // max(1, offsets[-1])) for i in range(len(sizes))]
         self.bucket_span = [[None, None] for _ in range(n_buckets)]
@@ -250,6 +254,7 @@ class Grads:
             span[1] = offsets[i + 1]
             self.bucket_left[b] += 1
         self.handles = []
+        self.n_collectives = 0      # bucket all-reduces issued (or, in a recorded step, planned) so far
 
     def view(self, p: torch.nn.Parameter) -> torch.Tensor:
         """The parameter's slot of the flat buffer (kernels may write the gradient there themselves; `set` with
@@ -262,16 +267,28 @@ class Grads:
             self.views[i].copy_(g.reshape(self.views[i].shape))
         b = self.bucket_of[i]
         self.bucket_left[b] -= 1
-        if self.world > 1 and self.bucket_left[b] == 0:
+        if self.collectives and self.bucket_left[b] == 0:
             a, e = self.bucket_span[b]
-            self.handles.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, async_op=True))
+            bucket, handles = self.flat[a:e], self.handles
+            self.n_collectives += 1
+
+            def go():
+                handles.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=True))
+            # a host call into RCCL: eagerly now, while the backward goes on; in a recorded step (utils/training/
+            # graphed_step.py) the graph segment ends here and every replay makes the call between two segments
+            host_boundary(go)
 
     def finish(self) -> List[torch.Tensor]:
         missing = [i for i, left in enumerate(self.bucket_left) if left > 0]
         assert not missing, "backward did not produce every parameter gradient"
-        if self.world > 1:
-            for h in self.handles:
-                h.wait()
+        if self.collectives:
+            handles = self.handles
+
+            def wait_all():
+                for h in handles:
+                    h.wait()
+                handles.clear()
+            host_boundary(wait_all)
             self.flat.div_(self.world)   # DDP semantics: average over ranks
         return self.views
 
@@ -369,13 +386,20 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
 
 
 # ------------------------------------------------------------------ quantiser (train mode)
+def _ema_collectives() -> bool:
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_COLLECTIVES
+
+
 def exchange_ema_statistics(counts: torch.Tensor, embed_sum: torch.Tensor):
     """Data-parallel exchange of the EMA statistics of one quantiser: the per-code usage counts `onehot.sum(0)` [K]
     and the per-code vector sums `flatten^T @ onehot` [D, K] (bottleneck.py:80-84) of every rank's batch shard are
     summed in ONE all-reduce message ([K] + [D*K] floats), so that N ranks x B/N samples update the codebook exactly
     like one process with B samples (the reference lets DDP broadcast rank 0's buffers instead).
-    Identity when not distributed.  Host logic only (any device: RCCL on the GPU, gloo in the CPU tests)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    Identity when not distributed.  Host logic only (any device: RCCL on the GPU, gloo in the CPU tests).
+    Blocking form (tests, stand-alone callers); the training step uses `PendingEma` below."""
+    if not _ema_collectives():
         return counts, embed_sum
     K = counts.numel()
     packed = torch.cat([counts.reshape(-1).float(), embed_sum.reshape(-1).float()])
@@ -383,10 +407,62 @@ def exchange_ema_statistics(counts: torch.Tensor, embed_sum: torch.Tensor):
     return packed[:K], packed[K:].reshape(embed_sum.shape)
 
 
-def quantize_train(q, z_nhwc: torch.Tensor):
+class PendingEma:
+    """EMA codebook updates whose batch statistics are still travelling (round 5).
+
+    The updated codebook is first needed by the NEXT search of its quantiser, so nothing in the rest of the forward has
+    to wait for the statistics' all-reduce: `submit` launches it asynchronously (RCCL's own stream; one message of
+    [K] + [D K] floats per quantiser) and the forward goes on -- decoder, bottom quantiser, ... -- ; `flush`, called once
+    at the end of the train-mode forward, waits for the handles and only then launches the `isi_vq_ema_update_f32` kernels
+    that write the codebooks.  The blocking form stalled the stream against RCCL's latency twice per step on every rank.
+    Both host calls sit behind `host_boundary`, so a recorded step replays them between graph segments."""
+
+    def __init__(self):
+        self.items = []        # (quantiser, packed statistics [K + D K], D, K)
+        self.handles = []
+
+    def submit(self, q, counts_f: torch.Tensor, embed_sum: torch.Tensor) -> None:
+        D, K = embed_sum.shape
+        packed = torch.cat([counts_f.reshape(-1), embed_sum.reshape(-1)])
+        self.items.append((q, packed, D, K))
+        if _ema_collectives():
+            handles = self.handles
+
+            def go():
+                handles.append(dist.all_reduce(packed, async_op=True))
+            host_boundary(go)
+
+    def flush(self) -> None:
+        if not self.items:
+            return
+        if _ema_collectives():
+            handles = self.handles
+
+            def wait_all():
+                for h in handles:
+                    h.wait()
+                handles.clear()
+            host_boundary(wait_all)
+        for q, packed, D, K in self.items:
+            self._update(q, packed, D, K)
+        self.items = []
+
+    @staticmethod
+    def _update(q, packed: torch.Tensor, D: int, K: int) -> None:
+        """bottleneck.py:80-92 on the [D,K] buffers from the (summed) statistics `packed` = counts [K] | embed_sum [D K]."""
+        _hip.check(_hip.lib().isi_vq_ema_update_f32(q.embed.data_ptr(), q.cluster_size.data_ptr(), q.embed_avg.data_ptr(),
+                                                    packed.data_ptr(), packed.data_ptr() + 4 * K, D, K, q.decay, q.eps,
+                                                    _s(packed)), "isi_vq_ema_update_f32")
+        # the buffers were written through raw pointers (no torch version bump): invalidate caches
+        q._packed_key = None
+        q._ema_steps = getattr(q, "_ema_steps", 0) + 1
+
+
+def quantize_train(q, z_nhwc: torch.Tensor, pending: Optional[PendingEma] = None):
     """Eval-identical search with the CURRENT codebook, optional index corruption (bottleneck.py:63-73),
     then the EMA update of the buffers (bottleneck.py:75-92) from statistics all-reduced over the
-    data-parallel ranks."""
+    data-parallel ranks.  `pending`: the update is handed to it (asynchronous exchange, codebook written at its
+    `flush()`); None: exchanged and written before this returns."""
     codes, e2 = q.packed()
     L = _hip.lib()
     D, K = q.dim, q.n_embed
@@ -409,6 +485,9 @@ def quantize_train(q, z_nhwc: torch.Tensor):
                                      _s(z_nhwc)), "isi_vq_finalize_f32")
     diff, perplexity = out2[0], out2[1]
     if q.corruption_weights is not None:
+        if z_nhwc.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise NotImplementedError("index corruption draws on the host (torch.multinomial, like the reference): such a "
+                                      "step cannot be recorded into a HIP graph")
         # offsets in {-1, 0, +1} drawn exactly like the reference: torch.multinomial on the CPU default
         # generator (same seed -> same offsets), moved to the device and added modulo K; every quantity
         # downstream (codes, diff, usage statistics, EMA sums) is then taken from the corrupted indices
@@ -426,13 +505,12 @@ def quantize_train(q, z_nhwc: torch.Tensor):
     ws = torch.empty(nws, dtype=torch.float32, device=z_nhwc.device)
     _hip.check(L.isi_vq_embed_sum_f32(z_nhwc.data_ptr(), idx.data_ptr(), embed_sum.data_ptr(), ws.data_ptr(), nws,
                                       N, D, K, _s(z_nhwc)), "isi_vq_embed_sum_f32")
-    countsf, embed_sum = exchange_ema_statistics(counts.float(), embed_sum)
-    _hip.check(L.isi_vq_ema_update_f32(q.embed.data_ptr(), q.cluster_size.data_ptr(), q.embed_avg.data_ptr(),
-                                       countsf.data_ptr(), embed_sum.contiguous().data_ptr(), D, K, q.decay,
-                                       q.eps, _s(z_nhwc)), "isi_vq_ema_update_f32")
-    # the buffers were written through raw pointers (no torch version bump): invalidate caches
-    q._packed_key = None
-    q._ema_steps = getattr(q, "_ema_steps", 0) + 1
+    own = pending is None
+    if own:
+        pending = PendingEma()
+    pending.submit(q, counts.float(), embed_sum)
+    if own:
+        pending.flush()
     return q_st, diff, idx, perplexity
 
 
@@ -465,7 +543,8 @@ def encode_train(model, x: torch.Tensor):
     enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
     enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
     z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=FWD_PRECISION))
-    q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t)
+    pending = PendingEma()
+    q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t, pending)
     dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
     if dec_t.shape[-1] != enc_b.shape[-1]:
         if not model.adapt_quantized_durations:
@@ -473,7 +552,8 @@ def encode_train(model, x: torch.Tensor):
         w = min(dec_t.shape[-1], enc_b.shape[-1])            # vqvae.py:266-269
         dec_t, enc_b = dec_t[..., :w], enc_b[..., :w]
     z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=FWD_PRECISION))
-    q_b, diff_b, id_b, perp_b = quantize_train(model.quantize_b, z_b)
+    q_b, diff_b, id_b, perp_b = quantize_train(model.quantize_b, z_b, pending)
+    pending.flush()
     return _as_bchw(q_t), _as_bchw(q_b), (diff_t + diff_b).reshape(1), id_t, id_b, perp_t, perp_b
 
 
@@ -503,13 +583,14 @@ class VQVAETrainFunction(torch.autograd.Function):
             dev = z.device
             return (z, torch.zeros((), device=dev), torch.zeros(0, dtype=torch.int64, device=dev),
                     torch.full((), float("inf"), device=dev))
-        q_t, diff_t, id_t, perp_t = _identity(z_t) if unq else quantize_train(model.quantize_t, z_t)
+        pending = PendingEma()
+        q_t, diff_t, id_t, perp_t = _identity(z_t) if unq else quantize_train(model.quantize_t, z_t, pending)
         tape["z_t"], tape["q_t"] = z_t, q_t
         dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
         if dec_t.shape[-1] != enc_b.shape[-1]:
             raise NotImplementedError("training needs input sizes divisible by the total down-sampling factor")
         z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=FWD_PRECISION))
-        q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b)
+        q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b, pending)
         tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
         up = _as_bchw(q_t)
         for j, layer in enumerate(model.upsample_top_to_bottom):
@@ -517,6 +598,7 @@ class VQVAETrainFunction(torch.autograd.Function):
             up = layer.run(up, relu=False, bf16x3=FWD_PRECISION)
         dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True)
         diff = (diff_t + diff_b).reshape(1)
+        pending.flush()       # the statistics' all-reduces have had the rest of the forward to arrive; codebooks written here
         ctx.model, ctx.tape = model, tape
         ctx.mark_non_differentiable(id_t, id_b, perp_t, perp_b)
         return dec, diff, perp_t, perp_b, id_t, id_b

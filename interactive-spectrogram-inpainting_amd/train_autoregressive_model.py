@@ -98,13 +98,19 @@ def run_model(args, epoch: int, loader: Iterable, model: VQNSynthTransformer, op
             batch = top.shape[0]
             if model.self_conditional_model:
                 satisfied_total += float(num_satisfied_constraints(pred, source, mask))
-            loss_sum += float(loss) * batch
+            loss_sum += float(loss) * batch          # (joins the device: the step's deferred index verdict has arrived too)
             total_accuracy += float(accuracy) * batch
             num_samples += batch
+        if is_training:
+            # the training path gathers on clamped indices and defers the range verdict (priors/transformer.py embed_data):
+            # raise the reference's IndexError here, where the loss was read back anyway -- before the next optimizer step
+            # trains on another clamped symbol
+            model.check_indices()
     if tensorboard_writer is not None and not is_training:
         tensorboard_writer.add_scalar(f'code_prediction-validation_{hier}/mean_loss', loss_sum / max(1, num_samples), epoch)
         tensorboard_writer.add_scalar(f'code_prediction-validation_{hier}/mean_accuracy',
                                       total_accuracy / max(1, num_samples), epoch)
+    model.check_indices()       # (end of the epoch: nothing pending may outlive it, e.g. into a checkpoint)
     run_model.last_satisfied_constraints = satisfied_total
     return loss_sum, total_accuracy, num_samples
 

@@ -133,7 +133,7 @@ def _grads_worker(rank, world, port, q):
     for p in reversed(list(model.parameters())):
         g.set(p, torch.full_like(p, float(rank + 1)))
     views = g.finish()
-    q.put((rank, [float(v.mean()) for v in views], len(g.handles)))
+    q.put((rank, [float(v.mean()) for v in views], g.n_collectives))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -582,3 +582,120 @@ def test_weight_range_monitor_and_optimizer_helper():
         assert mon.update(w, True) is False
     finally:
         torch.Tensor.abs = real_abs
+
+
+def _segmented_worker(rank, world, port, q):
+    import os
+    import pathlib
+    import sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    sys.path.insert(0, str(root / "interactive-spectrogram-inpainting_amd"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from interactive_spectrogram_inpainting.utils.distributed import GradBucketReducer
+    from interactive_spectrogram_inpainting.utils.training.graphed_step import (
+        GraphedTrainingStep, OpListBackend, host_boundary, launch, recording)
+    from interactive_spectrogram_inpainting.vqvae._train import PendingEma
+    torch.manual_seed(0)
+    sizes = [6, 10, 4, 12, 8]
+    params = [torch.nn.Parameter(torch.randn(n)) for n in sizes]
+    red = GradBucketReducer(params, bucket_mb=1e-4)       # ~26 floats per bucket: 2+ buckets
+    x = torch.zeros(3)
+    loss = torch.zeros(())
+    lr = 0.1
+    trace = []                                            # host calls of the replays, in order
+
+    # a second kind of boundary inside the "forward": the asynchronous EMA-statistics exchange of the VQ-VAE step
+    class _Q:
+        decay, eps = 0.99, 1e-5
+
+    class _Ema(PendingEma):
+        updates = []
+
+        @staticmethod
+        def _update(qz, packed, D, K):
+            launch(lambda: _Ema.updates.append(packed.clone()))
+    stats_c, stats_s = torch.zeros(4), torch.zeros(2, 4)
+
+    def step_fn(xb):
+        red.zero()
+        pend = _Ema()
+        launch(lambda: (stats_c.copy_(xb.sum() + torch.arange(4.0)), stats_s.copy_(xb[:2, None] * torch.ones(2, 4))))
+        packed_holder = []
+        # (PendingEma.submit concatenates eagerly; here the concatenation is device work of the recorded step)
+        packed = torch.zeros(4 + 8)
+        launch(lambda: packed.copy_(torch.cat([stats_c, stats_s.reshape(-1)])))
+        pend.items.append((_Q(), packed, 2, 4))
+
+        def go():
+            trace.append("ema-allreduce")
+            pend.handles.append(dist.all_reduce(packed, async_op=True))
+        host_boundary(go)
+        for i in reversed(range(len(params))):            # the "backward": last parameters first
+            p = params[i]
+            launch(lambda p=p, i=i: p.grad.copy_(p.detach() * xb.mean() + xb.sum() * (i + 1)))
+            red._on_grad(p)
+            if i == 2:
+                pend.flush()                              # wait + codebook write somewhere inside the step
+        red.finish()
+        launch(lambda: [p.data.sub_(lr * p.grad) for p in params])
+        launch(lambda: loss.copy_(sum(p.detach().sum() for p in params)))
+        return loss
+
+    batches = [torch.tensor([1.0, 2.0, 3.0]) * (1 + rank) + k for k in range(4)]
+    g = GraphedTrainingStep(step_fn, (x,), warmup=1, backend=OpListBackend())    # warm-up = one eager step on zeros
+    assert not recording()
+    losses = [float(g(b)) for b in batches]
+    q.put((rank, [p.detach().clone() for p in params], losses, g.n_segments, len(red.buckets),
+           [u.clone() for u in _Ema.updates]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_segmented_graph_replay_two_process_gloo():
+    """data-parallel steps under graph replay.  The recording is cut at every host call into the
+    collective library (`host_boundary`); a replay runs segment, host call, segment, ...  Checked with the op-list
+    backend (segments = lists of closures instead of HIP graphs) and gloo, world size 2, through the real
+    GradBucketReducer and PendingEma: after one eager warm-up step and four replays on different batches both ranks hold
+    the parameters of a single process that averages the two ranks' gradients, the EMA statistics every rank applied are
+    the sum over ranks, and the number of segments is the number of boundaries + 1."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + int(torch.randint(0, 2000, (1,)).item())
+    procs = [ctx.Process(target=_segmented_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        rank, params, losses, nseg, nb, ema = q.get(timeout=120)
+        got[rank] = (params, losses, nseg, nb, ema)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: mean of the two ranks' gradients, warm-up step on zeros first
+    torch.manual_seed(0)
+    sizes = [6, 10, 4, 12, 8]
+    ref = [torch.randn(n) for n in sizes]
+    xs = [[torch.zeros(3)] * 2] + [[torch.tensor([1.0, 2.0, 3.0]) * (1 + r) + k for r in range(2)] for k in range(4)]
+    ref_losses, ref_ema = [], []
+    for xr in xs:
+        grads = [sum(p * x.mean() + x.sum() * (i + 1) for x in xr) / 2 for i, p in enumerate(ref)]
+        ref = [p - 0.1 * g_ for p, g_ in zip(ref, grads)]
+        ref_losses.append(float(sum(p.sum() for p in ref)))
+        ref_ema.append(sum(torch.cat([x.sum() + torch.arange(4.0), (x[:2, None] * torch.ones(2, 4)).reshape(-1)]) for x in xr))
+    for rank in range(2):
+        params, losses, nseg, nb, ema = got[rank]
+        assert nb >= 2
+        assert nseg == 1 + 1 + nb + 1 + 1, (nseg, nb)      # EMA exchange, nb buckets, EMA wait, gradient wait
+        for a, b in zip(params, ref):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+        for a, b in zip(losses, ref_losses[1:]):
+            assert abs(a - b) <= 1e-4 * max(1.0, abs(b))
+        assert len(ema) == 5
+        for a, b in zip(ema, ref_ema):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+    for a, b in zip(got[0][0], got[1][0]):
+        assert torch.equal(a, b)

@@ -784,3 +784,35 @@ def test_weight_leaving_the_f16_range_mid_training_is_loud():
     y6 = _ops.linear(x, _ops.pack_linear_weight(w, range_check=False), None, 512, precision="bf16x6")
     ref = x.double() @ w.detach().double().t()
     assert float((y6.double() - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+def test_wt_pack_group_releases_dead_models():
+    """the batched W^T re-pack (`_ops._WT_GROUP`) holds its weights weakly -- a trained model that is deleted
+    takes its entries (and their 2 N K-float output buffers) with it at the next request or purge; slices of a fused
+    in-projection parameter are owned by that parameter."""
+    import gc
+    from interactive_spectrogram_inpainting.priors import _ops
+    grp = _ops._WT_GROUP
+    grp.purge()
+    before = len(grp.entries)
+    model, step, batches = _toy_training_setup(0.0)
+    step(*batches[0])
+    step(*batches[1])
+    torch.cuda.synchronize()
+    grown = len(grp.entries)
+    assert grown > before, "the training step did not go through the batched W^T pack"
+    mem_with = torch.cuda.memory_allocated()
+    del model, step, batches
+    gc.collect()
+    assert grp.purge() == before, (grp.purge(), before)
+    torch.cuda.empty_cache()
+    assert torch.cuda.memory_allocated() < mem_with
+    # a second model after the first one is gone: its table holds only live rows
+    model, step, batches = _toy_training_setup(0.0)
+    step(*batches[0])
+    assert len(grp.entries) == grown
+    dev_tables = [t for t in grp.tables.values()]
+    assert dev_tables and len(dev_tables[0][0]) == len(grp.entries)
+    del model, step, batches
+    gc.collect()
+    grp.purge()

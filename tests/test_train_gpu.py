@@ -303,6 +303,115 @@ def test_bench_two_ranks_dry_run():
     assert "error" not in pdp, pdp
     assert pdp["n_gpus"] == 2 and pdp["global_batch"] == 2 and pdp["ranks_in_sync"] is True and pdp["value"] > 0
     assert pdp["collectives_per_step"].startswith(tuple("123456789"))
+    # both data-parallel legs are replayed from HIP graph segments cut at their collectives
+    for leg_ in (dp, pdp):
+        assert leg_["mode"] == "hip-graph replay", leg_
+        assert leg_["graph_segments"] >= 3 and leg_["ms_per_step_hip_graph"] > 0
+        assert leg_["host_enqueue_ms_per_step_hip_graph"] is not None and leg_["ms_per_step_eager"] > 0
+    assert dp["graph_segments"] == 1 + 2 + 1 + 4 + 1      # 2 EMA messages + their wait, 4 gradient buckets + their wait
+
+
+_FORCED_COLLECTIVES_SCRIPT = r"""
+import os, sys, pathlib
+root = pathlib.Path(sys.argv[1])
+sys.path.insert(0, str(root)); sys.path.insert(0, str(root / "interactive-spectrogram-inpainting_amd"))
+os.environ["ISI_FORCE_COLLECTIVES"] = "1"
+import torch, torch.distributed as dist
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1)
+dev = torch.device("cuda:0")
+from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+def build():
+    torch.manual_seed(1)
+    m = VQVAE(in_channel=2).to(dev).train()
+    return m, make_adam(m.parameters(), lr=1e-3, capturable=True)
+xs = [torch.randn(4, 2, 64, 128, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(4)]
+def make_step(m, opt):
+    def step(x):
+        m.zero_grad()
+        out, latent, *_ = m(x)
+        loss = torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()
+        loss.backward()
+        opt.step()
+        return loss
+    return step
+me, oe = build()
+se = make_step(me, oe)
+le = [float(se(x)) for x in xs]
+mg, og = build()
+g = GraphedTrainingStep(make_step(mg, og), (xs[0].clone(),), warmup=1)
+lg = [float(g(x)) for x in xs[1:]]
+g.finish()
+assert g.n_segments == 9, g.n_segments
+for a, b in zip(lg, le[1:]):
+    assert abs(a - b) <= 1e-5 * abs(b), (lg, le)
+for (n, pe), pg in zip(me.named_parameters(), mg.parameters()):
+    d = float((pe - pg).abs().max())
+    assert d <= 1e-5 * max(1e-3, float(pe.abs().max())), (n, d)
+assert torch.equal(me.quantize_t.embed, mg.quantize_t.embed) or float((me.quantize_t.embed - mg.quantize_t.embed).abs().max()) < 1e-5
+print("SEGMENTS", g.n_segments, "OK")
+dist.destroy_process_group()
+"""
+
+
+def test_graphed_vqvae_step_with_real_rccl_collectives_between_segments():
+    """The data-parallel replay path on the GPU with RCCL itself: a 1-rank "nccl" group and ISI_FORCE_COLLECTIVES=1 make the
+    VQ-VAE step issue its 2 EMA-statistics messages and 4 gradient-bucket all-reduces although nobody else is there.  The
+    recording is cut at each of them -- the bucket boundaries are reached from autograd's device thread, inside the
+    hand-written backward -- into 9 segments; replays on three batches reproduce the eager losses and parameters."""
+    import pathlib
+    import subprocess
+    import sys
+    root = pathlib.Path(__file__).resolve().parents[1]
+    out = subprocess.run([sys.executable, "-c", _FORCED_COLLECTIVES_SCRIPT, str(root), "29577"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "SEGMENTS 9 OK" in out.stdout
+
+
+def test_graphed_vqvae_training_step_equals_eager():
+    """A VQ-VAE training step (train-mode forward with the in-forward EMA codebook update, hand-written backward, fused
+    Adam) recorded into a HIP graph and replayed: same losses, parameters and codebooks as eager steps on the same
+    batches; eager code after `finish()` sees the replayed weights (version-keyed caches marked stale)."""
+    from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+
+    def build():
+        torch.manual_seed(1)
+        m = VQVAE(in_channel=2).to(dev).train()
+        return m, make_adam(m.parameters(), lr=1e-3, capturable=True)
+
+    def make_step(m, opt):
+        def step(x):
+            m.zero_grad()
+            out, latent, *_ = m(x)
+            loss = torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+    xs = [torch.randn(4, 2, 64, 128, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(4)]
+    me, oe = build()
+    se = make_step(me, oe)
+    le = [float(se(x)) for x in xs]
+    mg, og = build()
+    g = GraphedTrainingStep(make_step(mg, og), (xs[0].clone(),), warmup=1)
+    assert g.n_segments == 1
+    lg = [float(g(x)) for x in xs[1:]]
+    g.finish()
+    for a, b in zip(lg, le[1:]):
+        assert abs(a - b) <= 1e-5 * abs(b), (lg, le)
+    for (n, pe), pg in zip(me.named_parameters(), mg.parameters()):
+        assert _rel(pg, pe) < 1e-5, n
+    for q in ("quantize_t", "quantize_b"):
+        assert _rel(getattr(mg, q).embed, getattr(me, q).embed) < 1e-5
+    me.eval(), mg.eval()
+    with torch.no_grad():
+        oe_, og_ = me(xs[0]), mg(xs[0])
+    assert _rel(og_[0], oe_[0]) < 1e-4
 
 
 @pytest.mark.parametrize("shape", [

@@ -272,6 +272,24 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3,
                      const float *packed_w1, const float *b1, float *out, int B,
                      int H, int W, int C, int R, int relu, void *stream);
 
+/* Training-mode forms of the pair pipeline's producers (train_vqvae.py:168-181: `out, latent_loss, ... = model(img)` under
+ * model.train()): the same launches as isi_conv2d_f32 / isi_conv_transpose2d_k4s2_f32 / isi_resblock_f32 with
+ * ISI_CONV_F16X3 | ISI_CONV_W16 | ISI_CONV_OUT_PAIR (pair-format sources, except the 2-channel first layer), which ALSO
+ * write what the hand-written backward reads back -- `twin`: the output once more as dense channels-last fp32
+ * [B,OH,OW,Cout] (weight-gradient operand, ReLU masks); `hidden` (residual block): relu(conv3x3(r) + b3) as dense fp32
+ * [B,H,W,R].  The next layer keeps staging the pair tensor by LDS-DMA; nothing is converted twice.  Launches that would
+ * not reach a kernel with the twin epilogue return ISI_E_UNSUPPORTED (ask the *_route predicates first: 1 = yes). */
+int isi_conv2d_twin_f32(const isi_src *src0, const isi_src *src1, const float *packed_w, const float *bias,
+                        const isi_dst *dst, float *twin, int B, int H, int W, int Cout, int KH, int KW, int stride,
+                        int pad, int flags, void *stream);
+int isi_conv_transpose2d_k4s2_twin_f32(const isi_src *src, const float *packed_w, const float *bias, const isi_dst *dst,
+                                       float *twin, int B, int H, int W, int Cout, int flags, void *stream);
+int isi_resblock_tape_f32(const float *in, const float *packed_w3, const float *b3, const float *packed_w1, const float *b1,
+                          float *out, float *twin, float *hidden, int B, int H, int W, int C, int R, int flags, void *stream);
+int isi_conv2d_pair_route(int C0, int C1, int Cout, int KH, int KW);
+int isi_conv_transpose2d_pair_route(int Cin, int Cout);
+int isi_resblock_pair_route(int B, int H, int W, int C, int R);
+
 /* ----------------------------------------------------- training (backward) */
 /* These replace the autograd kernels behind `loss.backward()` (train_vqvae.py:181)
  * and the in-forward EMA codebook update (vqvae/bottleneck.py:79-92).

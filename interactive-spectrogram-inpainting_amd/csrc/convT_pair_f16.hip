@@ -58,6 +58,7 @@ struct ConvTPairK {
   // follows this one; `out` then receives Y' [B][2H][2W][32] fp32 instead of this layer's activation
   const float *w2;
   int n2;
+  float *out2;                                 // OUTP launches: dense fp32 twin of the output (training tape), or null
 };
 
 __device__ __forceinline__ void dma16(const unsigned lds_addr, const unsigned voff, const i32x4 rsrc, const unsigned soff) {
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(TH * 64) void convT_pair_kernel(const ConvTPairK p)
   const int Cin = p.Cin, nstage = Cin / 16;
   const i32x4 rsi = make_rsrc(p.in, p.in_bytes), rsw = make_rsrc(p.w16, p.w_bytes);
   const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso2_b = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, p.out2 ? p.out_bytes : 0u, 0x00020000);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)smem;
   const int OW = 2 * p.W, OH = 2 * p.H;
 
@@ -365,6 +367,12 @@ __global__ __launch_bounds__(TH * 64) void convT_pair_kernel(const ConvTPairK p)
               const u32x2v sy_ = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
               w = make_uint4(sx_.x, sy_.x, sx_.y, sy_.y);
               off = ok ? (o + (unsigned)cg) * 4u + (unsigned)kb * 16u : OOB_ST;
+              if (p.out2) {   // (uniform) the same values as fp32 for the backward's tape
+                const uint4 wf = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                                            __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, wf), rso2_b,
+                                                       ok ? (o + (unsigned)(cg + 4 * kb)) * 4u : OOB_ST, 0, 0);
+              }
             } else {
               w = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
                              __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
@@ -442,8 +450,9 @@ bool convT_pair_ok(int Cin, int Cout) {
 // w2 != nullptr: the decoder-tail form (YP): Cout must be 64, `out` receives Y' [B][2H][2W][32] fp32 for the n2 <= 32
 // rows of the packed weight w2 [n2][64] of the few-channel transposed convolution behind this layer
 int convT_pair_f16(const float *in, const float *w16, const float *bias, float *out, int B, int H, int W, int Cin,
-                   int Cout, int relu, int out_pair, hipStream_t stream, const float *w2, int n2) {
+                   int Cout, int relu, int out_pair, hipStream_t stream, const float *w2, int n2, float *twin) {
   if (!convT_pair_ok(Cin, Cout)) return unsupported("convT_pair: shape outside the fused kernel");
+  if (twin && (!out_pair || w2)) return unsupported("convT_pair: an fp32 twin accompanies a pair-format output");
   if (w2 && (Cout != 64 || n2 < 1 || n2 > 32 || out_pair)) return unsupported("convT_pair: the tail form needs Cout == 64 and n2 <= 32");
   const int64_t ein = (int64_t)B * H * W * Cin, eout = (int64_t)B * 4 * H * W * (w2 ? 32 : Cout);
   if (ein * 4 >= 0x70000000ll || eout * 4 >= 0xF0000000ll) return unsupported("convT_pair: tensor too large for 32-bit offsets");
@@ -456,7 +465,7 @@ int convT_pair_f16(const float *in, const float *w16, const float *bias, float *
   a.H = H; a.W = W; a.B = B; a.relu = relu;
   a.tiles_x = (W + TW - 1) / TW;
   a.ntn = Cout / 64;
-  a.w2 = w2; a.n2 = n2;
+  a.w2 = w2; a.n2 = n2; a.out2 = twin;
   // 8-row tiles (8 waves, two per SIMD) when they still give every CU an item, 4-row tiles otherwise
   const int forced = knobs().convt_pair_th;
   const long items8 = (long)a.tiles_x * ((H + 7) / 8) * 2 * a.ntn * B;

@@ -40,6 +40,7 @@ struct FirstArgs {
   int s0n, s0c, s0h, s0w;   // input element strides
   int H, W, OH, OW, M;      // M = B * OH * OW output pixels
   int relu, out_pair;
+  float *out2;              // with out_pair: dense fp32 twin of the output (the training tape), or null
 };
 
 
@@ -60,6 +61,11 @@ __device__ __forceinline__ void store_tile(const FirstArgs &p, const float *tb, 
         uint4 *o = reinterpret_cast<uint4 *>(p.out + (size_t)(m0 + px) * COUT + g * 8);
         o[0] = hi;
         o[1] = lo;
+        if (p.out2) {   // (uniform) the same 8 channels as fp32: the tape of a training step
+          float4 *o2 = reinterpret_cast<float4 *>(p.out2 + (size_t)(m0 + px) * COUT + g * 8);
+          o2[0] = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8);
+          o2[1] = *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8 + 4);
+        }
       }
     }
     return;
@@ -281,8 +287,10 @@ bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *
 }
 
 int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, const isi_dst *dst, int B, int H,
-                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream) {
+                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream, float *twin) {
   FirstArgs a;
+  if (twin && !(flags & ISI_CONV_OUT_PAIR)) return unsupported("conv_first: an fp32 twin accompanies a pair-format output");
+  a.out2 = twin;
   a.in = s0->ptr; a.w = packed_w; a.bias = bias; a.out = dst->ptr;
   a.in_bytes = (unsigned)(in_extent * 4);
   a.s0n = (int)s0->sn; a.s0c = (int)s0->sc; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;

@@ -59,6 +59,7 @@ struct ConvKArgs {
   int zs_in0, zs_w, zs_res, zs_out;   // element strides between two sets (source 0, packed weight, residual, output)
   const float *gate;         // optional, laid out exactly like the output: out = gate > 0 ? value : 0 (the ReLU mask of
                              // the layer's input applied in the epilogue of its input-gradient convolution)
+  float *twin;               // optional fp32 copy of a pair-format output (training tape): the LDS-DMA kernel only
 };
 
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, 16-B aligned, bank-conflict free
@@ -597,9 +598,11 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
     c.H = a.H; c.W = a.W; c.OH = a.OH; c.OW = a.OW; c.Cout = a.Cout; c.Kpad = a.Kpad; c.KH = a.KH; c.KW = a.KW;
     c.stride = a.stride; c.pad = a.pad; c.relu = a.relu; c.M = a.M;
     c.convT = a.convT; c.w_phase_stride = a.w_phase_stride; c.dst_sh = a.dst_sh; c.dst_sw = a.dst_sw;
-    c.out_pair = a.out_pair;
+    c.out_pair = a.out_pair; c.twin = a.twin;
     return conv_pair_f16(c, stream);
   }
+  if (a.twin) return unsupported("conv: the fp32 twin of a pair-format output is written by the LDS-DMA kernel only "
+                                 "(pair sources of 32-channel multiples, Cout % 64 == 0, K >= 256, dense channels-last output)");
   if ((a.in0_pair || a.in1_pair || a.out_pair) && !(a.bf16x3 == 3 && a.w16 && mode == 0 && a.Cout > 32 && a.K >= 128))
     return unsupported("conv: pair-format tensors need the split-f16 kernels (ISI_CONV_F16X3 | ISI_CONV_W16, "
                        "channels-last sources of 32-channel multiples, Cout > 32, K >= 128)");
@@ -674,9 +677,9 @@ constexpr int64_t kMaxElems = (int64_t)1 << 30;  // 4 GiB of fp32: 32-bit byte o
 
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
-               int KW, int stride, int pad, int relu, hipStream_t stream, const float *gate) {
+               int KW, int stride, int pad, int relu, hipStream_t stream, const float *gate, float *twin) {
   return conv2d_batched_f32(s0, s1, packed_w, bias, res, dst, B, H, W, Cout, KH, KW, stride, pad, relu, 1, 0, 0, 0, 0,
-                            stream, gate);
+                            stream, gate, twin);
 }
 
 // nz independent convolutions of one shape in a single launch (grid z): set z reads source 0 at
@@ -685,8 +688,9 @@ int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, cons
 int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                        const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                        int KW, int stride, int pad, int relu, int nz, int64_t zs_in0, int64_t zs_w,
-                       int64_t zs_res, int64_t zs_out, hipStream_t stream, const float *gate) {
+                       int64_t zs_res, int64_t zs_out, hipStream_t stream, const float *gate, float *twin) {
   if (nz < 1 || nz > 65535) return invalid("conv2d: bad batch count");
+  if (twin && (gate || nz > 1 || !(relu & ISI_CONV_OUT_PAIR))) return unsupported("conv2d: an fp32 twin accompanies a single pair-format output");
   if (gate && (nz > 1 || (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR | ISI_CONV_OUT_PAIR))))
     return unsupported("conv2d: the gated epilogue is for single fp32 launches");
   if (nz > 1 && s1 && s1->ptr) return unsupported("conv2d: batched launches take one source");
@@ -710,7 +714,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
       conv_first_applicable(s0, s1, res, dst, Cout, KH, KW, stride, pad, OH, OW, nz)) {
     // the 2-channel first layer has its own HBM-oriented kernel (conv_first_f32.hip), bit-identical results
     if (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR)) return unsupported("conv2d: pair-format source on the 2-channel layer");
-    return conv_first_f32(s0, packed_w, bias, dst, B, H, W, Cout, OH, OW, e0, relu, stream);
+    return conv_first_f32(s0, packed_w, bias, dst, B, H, W, Cout, OH, OW, e0, relu, stream, twin);
   }
   // the prior's linear layers: rows of a dense matrix, three-term products -> the GEMM kernel (gemm_split_f32.hip)
   if (nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 && pad == 0 && B == 1 && H == 1 && s0->sc == 1 &&
@@ -739,7 +743,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   if (two) { a.s1n = (int)s1->sn; a.s1h = (int)s1->sh; a.s1w = (int)s1->sw; }
   a.Cin = a.C0 + C1;
   a.src_uniform = (!two || (a.C0 % kBK == 0 && C1 % kBK == 0)) ? 1 : 0;
-  a.w = packed_w; a.bias = bias; a.gate = gate;
+  a.w = packed_w; a.bias = bias; a.gate = gate; a.twin = twin;
   a.res = (res && res->ptr) ? res->ptr : nullptr;
   if (a.res) { a.rn = (int)res->sn; a.rc = (int)res->sc; a.rh = (int)res->sh; a.rw = (int)res->sw; }
   a.out = dst->ptr; a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)dst->sh; a.ow = (int)dst->sw;
@@ -758,13 +762,18 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
              (s0->sn % 4 == 0) && (s0->sh % 4 == 0) && (s0->sw % 4 == 0);
   if (two) vec = vec && aligned16(s1->ptr) && (s1->sn % 4 == 0) && (s1->sh % 4 == 0) && (s1->sw % 4 == 0);
   if (!aligned16(packed_w)) return invalid("conv2d: packed weight must be 16-byte aligned");
+  if (twin && !(dst->sc == 1 && dst->sw == Cout && dst->sh == (int64_t)OW * Cout && (B == 1 || dst->sn == (int64_t)OH * OW * Cout) &&
+                aligned16(twin)))
+    return unsupported("conv2d: the fp32 twin needs a dense channels-last output");
   return launch_conv(a, !vec, 1, stream);
 }
 
 int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const float *bias,
                               const isi_dst *dst, int B, int H, int W, int Cout, int relu,
-                              hipStream_t stream, const float *gate) {
+                              hipStream_t stream, const float *gate, float *twin) {
   if (!s || !s->ptr || !packed_w || !dst || !dst->ptr) return invalid("convT: null pointer");
+  if (twin && (gate || !(relu & ISI_CONV_OUT_PAIR) || !(relu & ISI_CONV_IN0_PAIR)))
+    return unsupported("convT: an fp32 twin accompanies a pair-format output of the pair kernel");
   if (gate && (convT_small_applicable(s->C, Cout) || (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_OUT_PAIR))))
     return unsupported("convT: the gated epilogue is for the fp32 implicit-GEMM launches");
   if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0) return invalid("convT: bad shape");
@@ -803,9 +812,10 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
         convT_pair_ok(Cin, Cout) && aligned16(s->ptr) && aligned16(dst->ptr) && aligned16(packed_w)) {
       const size_t Kpad = round_up((size_t)4 * Cin, kBK);
       return convT_pair_f16(s->ptr, packed_w + (size_t)4 * Cout * Kpad, bias, dst->ptr, B, H, W, Cin, Cout, relu & 1,
-                            (relu & ISI_CONV_OUT_PAIR) ? 1 : 0, stream);
+                            (relu & ISI_CONV_OUT_PAIR) ? 1 : 0, stream, nullptr, 0, twin);
     }
   }
+  if (twin) return unsupported("convT: the fp32 twin is written by the fused pair kernel only (dense tensors, Cin % 16 == 0, Cout % 64 == 0)");
   ConvKArgs a;
   memset(&a, 0, sizeof a);
   a.in0 = s->ptr; a.in1 = s->ptr; a.C0 = s->C; a.Cin = s->C; a.src_uniform = 1;

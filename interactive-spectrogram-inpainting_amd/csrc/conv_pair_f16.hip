@@ -68,6 +68,8 @@ struct PairK {
   int H, W, OH, OW, Cout, Kpad, KH, KW, stride, pad, relu, M;
   int convT, w_phase_stride, dst_sh, dst_sw;
   int flush;                       // chunks between accumulator flushes (0: never)
+  float *out2;                     // OUTP launches: dense fp32 twin of the output at the same element offsets, or null
+  unsigned out2_bytes;
 };
 
 // one LDS-DMA: lane l's 16 bytes at rsrc.base + voff + soff land at lds_addr + 16 l; zeros when voff is out of range
@@ -95,8 +97,8 @@ __device__ __forceinline__ i32x4 make_rsrc(const void *ptr, const unsigned bytes
 // phase timestamps of the instrumented variant (ISI_CONV_ABLATE=32; tools/ablate_conv.py reads them back)
 __device__ long long g_conv_pair_stamps[256];
 
-template <int BN, bool OUTP, int ABL = 0>   // ABL: measurements only (ISI_CONV_ABLATE): 1 no MFMAs, 2 no DMA in the loop
-__global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
+template <int BN, bool OUTP, int ABL = 0, bool TWIN = false>   // ABL: measurements only (ISI_CONV_ABLATE): 1 no MFMAs, 2 no DMA in the loop
+__global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {   // TWIN: also an fp32 copy of a pair output (training)
   constexpr int TM = 2;                       // 32-row tiles per wave (4 waves along M)
   constexpr int TN = BN / 64;                 // 32-column tiles per wave (2 waves along N)
   constexpr int A_STAGE = BM * ROWB, B_STAGE = BN * ROWB, STAGE = A_STAGE + B_STAGE;
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
   // no barrier: the stage ring is not touched.
   if constexpr (ABL & 32) { e4 = __builtin_readcyclecounter(); e5 = e4; }
   const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso2_b = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, TWIN ? p.out2_bytes : 0u, 0x00020000);
   typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -439,6 +442,12 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
           const u32x2v sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
           w = make_uint4(sx.x, sy.x, sx.y, sy.y);
           off = o >= 0 ? (unsigned)(o + n0 + cg) * 4u + (unsigned)kb * 16u : OOB_STORE;
+          if constexpr (TWIN) {   // training: the tape keeps the fp32 values next to the pairs the next layer reads
+            const uint4 wf = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                                        __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, wf), rso2_b,
+                                                   o >= 0 ? (unsigned)(o + n0 + cg + 4 * kb) * 4u : OOB_STORE, 0, 0);
+          }
         } else {
           w = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
                          __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(const PairK p) {
 //   wait own pieces of chunk k, barrier | fragments -> registers, lgkmcnt(0), barrier (stage free) | DMAs of chunk k + 2
 //   | 24 (12) MFMAs
 // Same products in the same order as the 256-row kernel (k walk, term order, flush): the same bits.
-template <int BN, bool OUTP>
+template <int BN, bool OUTP, bool TWIN = false>
 __global__ __launch_bounds__(256, 2) void conv_pair128_kernel(const PairK p) {
   constexpr int BM2 = 128, NS2 = 2, NWV = 4;
   constexpr int TM = 2;                       // 32-row tiles per wave (2 waves along M)
@@ -687,6 +696,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair128_kernel(const PairK p) {
 
   // ---- epilogue, straight from the accumulators (as in the 256-row kernel)
   const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso2_b = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, TWIN ? p.out2_bytes : 0u, 0x00020000);
   typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -715,6 +725,12 @@ __global__ __launch_bounds__(256, 2) void conv_pair128_kernel(const PairK p) {
           const u32x2v sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
           w = make_uint4(sx.x, sy.x, sx.y, sy.y);
           off = o >= 0 ? (unsigned)(o + n0 + cg) * 4u + (unsigned)kb * 16u : OOB_STORE;
+          if constexpr (TWIN) {   // training: the tape keeps the fp32 values next to the pairs the next layer reads
+            const uint4 wf = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
+                                        __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, wf), rso2_b,
+                                                   o >= 0 ? (unsigned)(o + n0 + cg + 4 * kb) * 4u : OOB_STORE, 0, 0);
+          }
         } else {
           w = make_uint4(__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]),
                          __builtin_bit_cast(unsigned, v[2]), __builtin_bit_cast(unsigned, v[3]));
@@ -727,9 +743,9 @@ __global__ __launch_bounds__(256, 2) void conv_pair128_kernel(const PairK p) {
   }   // work items
 }
 
-template <int BN, bool OUTP>
+template <int BN, bool OUTP, bool TWIN = false>
 int launch_pair128(const PairK &a, double flops, double bytes, hipStream_t stream) {
-  auto kern = conv_pair128_kernel<BN, OUTP>;
+  auto kern = conv_pair128_kernel<BN, OUTP, TWIN>;
   constexpr size_t smem = (size_t)2 * (128 + BN) * ROWB + 4 * 128 * sizeof(int) + BN * sizeof(float);
   static_assert(2 * smem <= 160 * 1024, "two workgroups per CU");
   static DeviceOnce attr_set;
@@ -752,9 +768,9 @@ constexpr size_t pair_smem_bytes() {
   return (size_t)NS * (BM + BN) * ROWB + 4 * BM * sizeof(int) + BN * sizeof(float);
 }
 
-template <int BN, bool OUTP, int ABL = 0>
+template <int BN, bool OUTP, int ABL = 0, bool TWIN = false>
 int launch_pair(const PairK &a, int nphase, double flops, double bytes, hipStream_t stream) {
-  auto kern = conv_pair_kernel<BN, OUTP, ABL>;
+  auto kern = conv_pair_kernel<BN, OUTP, ABL, TWIN>;
   constexpr size_t smem = pair_smem_bytes<BN>();
   static DeviceOnce attr_set;
   if (!attr_set.done()) {
@@ -767,7 +783,7 @@ int launch_pair(const PairK &a, int nphase, double flops, double bytes, hipStrea
   const int n_cu = current_device_cu_count();
   dim3 grid(nitems < n_cu ? nitems : n_cu);   // one 144-KiB workgroup per CU, persistent over the items
   // the forward's single dominant kernel is timed under its own id (bench.py adds it back to the family's line)
-  prof::Scope scope(BN == 128 && OUTP && ABL == 0 ? prof::K_CONV_PAIR_128_PAIROUT : prof::K_CONV_F16X3, flops, bytes, stream);
+  prof::Scope scope(BN == 128 && OUTP && ABL == 0 && !TWIN ? prof::K_CONV_PAIR_128_PAIROUT : prof::K_CONV_F16X3, flops, bytes, stream);
   ISI_PROF_LAUNCH(scope, kern, grid, dim3(512), smem, stream, a);
   return check_launch("conv_pair_f16");
 }
@@ -811,6 +827,11 @@ int conv_pair_f16(const PairConvArgs &c, hipStream_t stream) {
   // accumulator flush period: every 3 chunks (one kernel row of a 3x3 / three taps) unless overridden; 0 = never
   // (read per call: the tests compare flush = 0 -- the bits of conv_igemm_f32.hip -- with the default)
   a.flush = knobs().conv_flush;
+  if (c.twin) {
+    // the fp32 twin shares the pair tensor's element offsets: plain (non-transposed) dense channels-last outputs only
+    if (!c.out_pair || c.convT) return unsupported("conv_pair: an fp32 twin accompanies a pair-format output of a plain convolution");
+    a.out2 = c.twin; a.out2_bytes = c.out_bytes;
+  }
   const int nphase = c.convT ? 4 : 1;
   const double K = (double)c.KH * c.KW * (c.C0 + c.C1);
   const double flops = 2.0 * c.M * nphase * c.Cout * K;
@@ -833,6 +854,10 @@ int conv_pair_f16(const PairConvArgs &c, hipStream_t stream) {
   // tile height: 128-row workgroups (two per CU) or the 256-row kernel; ISI_CONV_PAIR_BM forces one (tests, measurements)
   const int bm = knobs().conv_pair_bm;
   const bool use128 = !c.convT && (bm == 128 || (bm == 0 && conv_pair_prefers_128(c.M, c.Cout, (int)K)));
+  if (a.out2) {   // pair output + fp32 twin (training forward)
+    if (use128) return wide ? launch_pair128<128, true, true>(a, flops, bytes, stream) : launch_pair128<64, true, true>(a, flops, bytes, stream);
+    return wide ? launch_pair<128, true, 0, true>(a, nphase, flops, bytes, stream) : launch_pair<64, true, 0, true>(a, nphase, flops, bytes, stream);
+  }
   if (use128) {
     if (c.out_pair) return wide ? launch_pair128<128, true>(a, flops, bytes, stream) : launch_pair128<64, true>(a, flops, bytes, stream);
     return wide ? launch_pair128<128, false>(a, flops, bytes, stream) : launch_pair128<64, false>(a, flops, bytes, stream);

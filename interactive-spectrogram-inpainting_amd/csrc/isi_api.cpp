@@ -229,6 +229,28 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3, c
   return resblock_f32(in, packed_w3, b3, packed_w1, b1, out, B, H, W, C, R, relu, S(stream));
 }
 int isi_resblock_fusable(int C, int R) { return resblock_fusable(C, R) ? 1 : 0; }
+int isi_conv2d_twin_f32(const isi_src *src0, const isi_src *src1, const float *packed_w, const float *bias,
+                        const isi_dst *dst, float *twin, int B, int H, int W, int Cout, int KH, int KW, int stride,
+                        int pad, int flags, void *stream) {
+  if (!twin) return ISI_E_INVALID;
+  return conv2d_f32(src0, src1, packed_w, bias, nullptr, dst, B, H, W, Cout, KH, KW, stride, pad, flags, S(stream), nullptr, twin);
+}
+int isi_conv_transpose2d_k4s2_twin_f32(const isi_src *src, const float *packed_w, const float *bias, const isi_dst *dst,
+                                       float *twin, int B, int H, int W, int Cout, int flags, void *stream) {
+  if (!twin) return ISI_E_INVALID;
+  return conv_transpose2d_k4s2_f32(src, packed_w, bias, dst, B, H, W, Cout, flags, S(stream), nullptr, twin);
+}
+int isi_resblock_tape_f32(const float *in, const float *packed_w3, const float *b3, const float *packed_w1, const float *b1,
+                          float *out, float *twin, float *hidden, int B, int H, int W, int C, int R, int flags, void *stream) {
+  if (!twin && !hidden) return ISI_E_INVALID;
+  return resblock_f32(in, packed_w3, b3, packed_w1, b1, out, B, H, W, C, R, flags, S(stream), twin, hidden);
+}
+int isi_resblock_pair_route(int B, int H, int W, int C, int R) { return resblock_pair_preferred(B, H, W, C, R) ? 1 : 0; }
+int isi_conv2d_pair_route(int C0, int C1, int Cout, int KH, int KW) {
+  // would isi_conv2d_f32 with pair-format sources run the LDS-DMA kernel (the one with the twin epilogue)?
+  return (conv_pair_kernel_ok(C0, C1, Cout, KH * KW) && KH <= 4 && KW <= 4 && KH * KW * (C0 + C1) >= 256) ? 1 : 0;
+}
+int isi_conv_transpose2d_pair_route(int Cin, int Cout) { return convT_pair_ok(Cin, Cout) ? 1 : 0; }
 
 int isi_spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel, void *stream) {
   return spec_polar_f32(stft, a, ph, B, T, F, mel, S(stream));

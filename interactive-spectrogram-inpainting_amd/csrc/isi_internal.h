@@ -12,7 +12,7 @@ int pair_decode_f32(const float *in, float *x, int64_t n, hipStream_t stream);
 bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *res, const isi_dst *dst, int Cout,
                            int KH, int KW, int stride, int pad, int OH, int OW, int nz);
 int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, const isi_dst *dst, int B, int H,
-                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream);
+                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream, float *twin = nullptr);
 bool conv_pair_sources_ok(int C0, int C1, int Cout, int taps);
 // conv_pair_f16.hip: the LDS-DMA implicit-GEMM kernel of the pair pipeline (pair8 sources, blocked W16 weights)
 struct PairConvArgs {
@@ -25,6 +25,7 @@ struct PairConvArgs {
   int H, W, OH, OW, Cout, Kpad, KH, KW, stride, pad, relu, M;
   int convT, w_phase_stride, dst_sh, dst_sw;
   int out_pair;
+  float *twin;                         // with out_pair: dense channels-last fp32 copy of the output (training tape), or null
 };
 bool conv_pair_kernel_ok(int C0, int C1, int Cout, int taps);
 int conv_pair_f16(const PairConvArgs &c, hipStream_t stream);
@@ -37,26 +38,31 @@ int decoder_tail_f32(const float *in_pair, const float *packed_w1, const float *
                      int Cout, hipStream_t stream);
 int convT_pair_debug_stamps(long long *host, int n);
 int convT_pair_f16(const float *in, const float *w16, const float *bias, float *out, int B, int H, int W, int Cin,
-                   int Cout, int relu, int out_pair, hipStream_t stream, const float *w2 = nullptr, int n2 = 0);
+                   int Cout, int relu, int out_pair, hipStream_t stream, const float *w2 = nullptr, int n2 = 0,
+                   float *twin = nullptr);
 int conv2d_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
-               int KW, int stride, int pad, int relu, hipStream_t stream, const float *gate = nullptr);
+               int KW, int stride, int pad, int relu, hipStream_t stream, const float *gate = nullptr,
+               float *twin = nullptr);
 int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed_w, const float *bias,
                        const isi_src *res, const isi_dst *dst, int B, int H, int W, int Cout, int KH,
                        int KW, int stride, int pad, int relu, int nz, int64_t zs_in0, int64_t zs_w,
-                       int64_t zs_res, int64_t zs_out, hipStream_t stream, const float *gate = nullptr);
+                       int64_t zs_res, int64_t zs_out, hipStream_t stream, const float *gate = nullptr,
+                       float *twin = nullptr);
 int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const float *bias,
                               const isi_dst *dst, int B, int H, int W, int Cout, int relu,
-                              hipStream_t stream, const float *gate = nullptr);
+                              hipStream_t stream, const float *gate = nullptr, float *twin = nullptr);
 
 bool resblock_fusable(int C, int R);
 bool resblock_pair_ok(int C, int R);
 bool resblock_pair_preferred(int B, int H, int W, int C, int R);
 int resblock_pair_debug_stamps(long long *host, int n);
 int resblock_pair_f16(const float *in, const float *w1_16, const float *b1, const float *w2_16, const float *b2, float *out,
-                      int B, int H, int W, int C, int relu, int out_pair, hipStream_t stream);
+                      int B, int H, int W, int C, int relu, int out_pair, hipStream_t stream, float *twin = nullptr,
+                      float *hidden = nullptr);
 int resblock_f32(const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
-                 float *out, int B, int H, int W, int C, int R, int relu, hipStream_t stream);
+                 float *out, int B, int H, int W, int C, int R, int relu, hipStream_t stream, float *twin = nullptr,
+                 float *hidden = nullptr);
 bool convT_small_applicable(int Cin, int Cout);
 bool convT_small_pair_ok(int Cin, int Cout);
 int convT_gather_f32(const float *yprime, const float *bias, float *out, int B, int H, int W, int Cout, int on, int oc,

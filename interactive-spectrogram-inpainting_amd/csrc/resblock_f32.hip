@@ -462,8 +462,11 @@ bool resblock_fusable(int C, int R) { return C % 32 == 0 && C >= 32 && C <= 128 
 
 // in/out: dense channels-last [B,H,W,C].  w1: packed 3x3 weight [R][9C]; w2: packed 1x1 weight [C][32].
 int resblock_f32(const float *in, const float *w1, const float *b1, const float *w2, const float *b2,
-                 float *out, int B, int H, int W, int C, int R, int relu, hipStream_t stream) {
+                 float *out, int B, int H, int W, int C, int R, int relu, hipStream_t stream, float *twin, float *hidden) {
   if (!in || !w1 || !b1 || !w2 || !b2 || !out) return invalid("resblock: null pointer");
+  if ((twin || hidden) && !((relu & ISI_CONV_IN0_PAIR) && (relu & ISI_CONV_F16X3) && (relu & ISI_CONV_W16) &&
+                            !(relu & ISI_CONV_BF16X6) && resblock_pair_preferred(B, H, W, C, R)))
+    return unsupported("resblock: the training side outputs (fp32 twin, hidden activation) come from the pair kernel only");
   if (B <= 0 || H <= 0 || W <= 0) return invalid("resblock: bad shape");
   if (!resblock_fusable(C, R)) return unsupported("resblock: need C % 32 == 0, C <= 128, R <= 32");
   const int64_t elems = (int64_t)B * H * W * C;
@@ -494,7 +497,7 @@ int resblock_f32(const float *in, const float *w1, const float *b1, const float 
     a.w2 = w2 + (size_t)C * 32;
     // pair-format input: the LDS-DMA kernel (resblock_pair_f16.hip)
     if (a.in_pair && resblock_pair_preferred(B, H, W, C, R) && !(relu & ISI_CONV_BF16X6))
-      return resblock_pair_f16(in, a.w1, b1, a.w2, b2, out, B, H, W, C, relu & 1, a.out_pair, stream);
+      return resblock_pair_f16(in, a.w1, b1, a.w2, b2, out, B, H, W, C, relu & 1, a.out_pair, stream, twin, hidden);
     ISI_RES(4)
   }
   if (relu & ISI_CONV_F16X3) { ISI_RES(3) }

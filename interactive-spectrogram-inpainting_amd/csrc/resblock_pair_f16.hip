@@ -61,6 +61,9 @@ struct ResPairK {
   int C, H, W, B, relu, out_pair;
   int tiles_x, tiles_y;
   int ablate;   // measurements only (ISI_RESPAIR_ABL): 1 one stage instead of C / 16, 2 no second GEMM / epilogue, 4 no skip re-read, 8 no output stores
+  // training forward (null otherwise): dense fp32 twin of a pair-format output, and the block's hidden activation
+  // relu(conv3x3(r) + b1) as dense channels-last fp32 [B,H,W,32] -- what the hand-written backward reads
+  float *out2, *hidden;
 };
 
 __device__ __forceinline__ void dma16(const unsigned lds_addr, const unsigned voff, const i32x4 rsrc, const unsigned soff) {
@@ -132,6 +135,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
   for (int i = tid; i < C + 32; i += NW * 64) b2s[i] = f16s::kScaleA * (i < C ? p.b2[i] : p.b1[i - C]);   // in units of 4 x, like everything in the tail
 
   const __amdgpu_buffer_rsrc_t rso_b = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rso2_b = __builtin_amdgcn_make_buffer_rsrc(p.out2, 0, p.out2 ? p.in_bytes : 0u, 0x00020000);
   // ---- work distribution.  (Every workgroup reaches its store-heavy tail at the same moment, so the launch alternates
   // between a K-loop phase -- 173 MB of halo reads -- and a store burst at the fabric's write rate, 256 KB per CU at
   // once: 17-21 k of an item's 63 k cycles, tools/stamps_resblock.py.  Running the odd workgroups half a tile out of
@@ -300,6 +304,34 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
           hl[i][s_] = __builtin_bit_cast(s16x8, pl);
         }
     }
+    if (p.hidden) {   // (uniform) lane (pixel, kb) holds 4 h of hidden channels 16 s + 8 (e >> 2) + 4 kb + (e & 3)
+      const __amdgpu_buffer_rsrc_t rsh_b = __builtin_amdgcn_make_buffer_rsrc(p.hidden, 0, (unsigned)((size_t)p.B * p.H * p.W * 32 * 4), 0x00020000);
+      const int gyh = y0 + ry;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int gx = x0 + 32 * i + frow;
+        const bool okh = gyh < p.H && gx < p.W;
+        const unsigned oh_ = (unsigned)(((b * p.H + gyh) * p.W + gx) * 32 + 4 * kb) * 4u;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          // the f16 pieces of 4 h hold h to 22 bits; the backward wants the fp32 value GEMM 2 effectively consumed:
+          // decode hi + lo (exactly what the products saw), scaled back by 1 / 4
+          const uint4 ph = __builtin_bit_cast(uint4, hh[i][s_]), pl = __builtin_bit_cast(uint4, hl[i][s_]);
+          const unsigned phw[4] = {ph.x, ph.y, ph.z, ph.w}, plw[4] = {pl.x, pl.y, pl.z, pl.w};
+          float hv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            hv[e] = ((e & 1) ? f16s::mix_sum<1>(phw[e >> 1], plw[e >> 1]) : f16s::mix_sum<0>(phw[e >> 1], plw[e >> 1])) * (1.f / f16s::kScaleA);
+#pragma unroll
+          for (int hq = 0; hq < 2; ++hq) {
+            const uint4 wv = make_uint4(__builtin_bit_cast(unsigned, hv[4 * hq]), __builtin_bit_cast(unsigned, hv[4 * hq + 1]),
+                                        __builtin_bit_cast(unsigned, hv[4 * hq + 2]), __builtin_bit_cast(unsigned, hv[4 * hq + 3]));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, wv), rsh_b,
+                                                   okh ? oh_ + (unsigned)((16 * s_ + 8 * hq) * 4) : OOB_ST, 0, 0);
+          }
+        }
+      }
+    }
     ISI_STAMP(5);
     if (ISI_RESPAIR_ABLBIT(p, 2)) { if (hh[0][0][0] == 123 && hl[1][1][3] == 7) p.out[0] = 1.f; continue; }
 
@@ -369,6 +401,15 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
           const unsigned off = (ok && !ISI_RESPAIR_ABLBIT(p, 8)) ? o + (unsigned)(64 * h) : OOB_ST;
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_ST ? OOB_ST : off + 16u, 0, 0);
+          if (p.out2) {   // (uniform) fp32 twin of a pair-format output: the same 8 channels at the same offsets
+            constexpr float q2 = 1.f / f16s::kScaleA;
+            const uint4 f0 = make_uint4(__builtin_bit_cast(unsigned, x4[0] * q2), __builtin_bit_cast(unsigned, x4[1] * q2),
+                                        __builtin_bit_cast(unsigned, x4[2] * q2), __builtin_bit_cast(unsigned, x4[3] * q2));
+            const uint4 f1 = make_uint4(__builtin_bit_cast(unsigned, x4[4] * q2), __builtin_bit_cast(unsigned, x4[5] * q2),
+                                        __builtin_bit_cast(unsigned, x4[6] * q2), __builtin_bit_cast(unsigned, x4[7] * q2));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f0), rso2_b, off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f1), rso2_b, off == OOB_ST ? OOB_ST : off + 16u, 0, 0);
+          }
         }
       }
       ISI_STAMP(8 + j);
@@ -433,9 +474,11 @@ bool resblock_pair_ok(int C, int R) {
 // in / out: dense channels-last pair-format [B,H,W,C] (out: fp32 unless out_pair); w1_16 / w2_16: the blocked pair
 // copies behind the packed 3x3 [32][9C] and 1x1 [C][32] weights.
 int resblock_pair_f16(const float *in, const float *w1_16, const float *b1, const float *w2_16, const float *b2, float *out,
-                      int B, int H, int W, int C, int relu, int out_pair, hipStream_t stream) {
+                      int B, int H, int W, int C, int relu, int out_pair, hipStream_t stream, float *twin, float *hidden) {
   ResPairK a;
   memset(&a, 0, sizeof a);
+  if (twin && !out_pair) return unsupported("resblock_pair: an fp32 twin accompanies a pair-format output");
+  a.out2 = twin; a.hidden = hidden;
   a.in = in; a.w1 = w1_16; a.b1 = b1; a.w2 = w2_16; a.b2 = b2; a.out = out;
   const int64_t elems = (int64_t)B * H * W * C;
   if (elems * 4 >= 0x70000000ll) return unsupported("resblock_pair: tensor spans 1.75 GiB or more");

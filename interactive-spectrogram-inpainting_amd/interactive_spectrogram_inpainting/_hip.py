@@ -167,6 +167,15 @@ SIGNATURES = {
     "isi_resblock_fusable": (C.c_int, [C.c_int, C.c_int]),
     "isi_resblock_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, _P]),
+    "isi_conv2d_twin_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.POINTER(isi_dst), _P, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_conv_transpose2d_k4s2_twin_f32": (C.c_int, [C.POINTER(isi_src), _P, _P, C.POINTER(isi_dst), _P, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.c_int, _P]),
+    "isi_resblock_tape_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, _P]),
+    "isi_conv2d_pair_route": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "isi_conv_transpose2d_pair_route": (C.c_int, [C.c_int, C.c_int]),
+    "isi_resblock_pair_route": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "isi_spec_polar_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_spec_finish_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_spec_inverse_prepare_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),

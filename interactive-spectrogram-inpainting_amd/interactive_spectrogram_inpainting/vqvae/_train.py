@@ -294,40 +294,150 @@ class Grads:
 
 
 # ------------------------------------------------------------------ forward (train mode)
-def _conv_fwd(layer: _ConvParams, x, relu, x2=None, out_nchw=False):
-    return layer.run(x, relu=relu, x2=x2, out_nchw=out_nchw, bf16x3=FWD_PRECISION)
+# Round 5: the train-mode forward runs on the eval path's LDS-DMA kernels (conv_pair / convT_pair / resblock_pair,
+# DESIGN.md section 4) wherever they apply: a producer writes its output in the split-f16 pair format -- which its
+# consumer stages by plain LDS-DMA copies, no conversion per tap -- AND once more as fp32 (`twin`, the tape the backward's
+# weight-gradient kernels and ReLU masks read); the fused residual block also hands out its hidden activation.  Layers
+# outside those kernels' shapes (1x1 quantiser convolutions, the 2-channel last layer, grouped convolutions, product
+# modes other than split-f16) keep the fp32-activation kernels.  ISI_TRAIN_PAIR_FORWARD=0: the round-4 path.
+PAIR_FORWARD = os.environ.get("ISI_TRAIN_PAIR_FORWARD", "1") != "0"
+_PAIR_FLAGS = 8 | 16      # ISI_CONV_F16X3 | ISI_CONV_W16
 
 
-def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str):
-    tape[f"{tag}.in"] = x
+class _Act:
+    """An activation of the training forward: `f32` = [B,C,H,W] view of dense channels-last fp32 storage (always there:
+    the tape), `pair` = the same tensor in the pair format (same shape / strides) where a pair-route consumer follows."""
+    __slots__ = ("f32", "pair")
+
+    def __init__(self, f32, pair=None):
+        self.f32, self.pair = f32, pair
+
+    def want_pair(self):
+        """The pair-format twin, encoded on the spot when the producer did not write one (quantiser outputs)."""
+        if self.pair is None:
+            self.pair = _ops.pair_encode(self.f32)
+        return self.pair
+
+
+def _pair_mode() -> bool:
+    return PAIR_FORWARD and FWD_PRECISION == 4
+
+
+def _dense_cl(t: torch.Tensor) -> bool:
+    return t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def _conv_fwd(layer: _ConvParams, x: _Act, relu, x2: Optional[_Act] = None, out_nchw=False, keep_pair=True) -> _Act:
+    """One convolution / transposed convolution of the training forward.  `keep_pair` False: the output's consumers read
+    fp32 (the 2-channel last layer, the 1x1 quantiser convolutions), so only fp32 is written."""
+    L = _hip.lib()
+    k, cin, cout = layer.kernel_size, layer.in_channels, layer.out_channels
+    first = (not layer.transposed and x2 is None and cin == 2 and (k, layer.stride, layer.padding) == (4, 2, 1)
+             and cout in (32, 64) and x.f32.is_contiguous())          # the NCHW spectrogram: conv_first_f32.hip
+    pair_ok = (_pair_mode() and layer.groups == 1 and not out_nchw and (first or _dense_cl(x.f32))
+               and (x2 is None or _dense_cl(x2.f32)))
+    if pair_ok and layer.transposed and x2 is None and (k, layer.stride, layer.padding) == (4, 2, 1) \
+            and L.isi_conv_transpose2d_pair_route(cin, cout) and cin % 8 == 0:
+        xp = x.want_pair()
+        B, _, H, W = xp.shape
+        s0 = _hip.src_nchw_view(xp)
+        if not keep_pair:       # pair in, fp32 out: the plain entry point
+            return _Act(_ops.conv_transpose2d_k4s2(xp, layer.packed(), layer.bias, cout, relu, bf16x3=4,
+                                                   extra_flags=_ops.PAIR_IN0))
+        out = torch.empty(B, 2 * H, 2 * W, cout, dtype=torch.float32, device=xp.device)
+        twin = torch.empty_like(out)
+        dst = _hip.dst_nchw_view(out.permute(0, 3, 1, 2))
+        rc = L.isi_conv_transpose2d_k4s2_twin_f32(C.byref(s0), layer.packed().data_ptr(), layer.bias.data_ptr(), C.byref(dst),
+                                                  twin.data_ptr(), B, H, W, cout,
+                                                  int(relu) | _PAIR_FLAGS | _ops.PAIR_IN0 | _ops.PAIR_OUT, _s(xp))
+        _hip.check(rc, "isi_conv_transpose2d_k4s2_twin_f32")
+        return _Act(twin.permute(0, 3, 1, 2), out.permute(0, 3, 1, 2))
+    c0 = x.f32.shape[1]
+    c1 = x2.f32.shape[1] if x2 is not None else 0
+    if pair_ok and not layer.transposed and keep_pair and (first or L.isi_conv2d_pair_route(c0, c1, cout, k, k)):
+        src = x.f32 if first else x.want_pair()
+        src2 = x2.want_pair() if x2 is not None else None
+        B, _, H, W = src.shape
+        OH = (H + 2 * layer.padding - k) // layer.stride + 1
+        OW = (W + 2 * layer.padding - k) // layer.stride + 1
+        out = torch.empty(B, OH, OW, cout, dtype=torch.float32, device=src.device)
+        twin = torch.empty_like(out)
+        s0 = _hip.src_nchw_view(src)
+        s1 = _hip.src_nchw_view(src2) if src2 is not None else None
+        dst = _hip.dst_nchw_view(out.permute(0, 3, 1, 2))
+        flags = int(relu) | _PAIR_FLAGS | _ops.PAIR_OUT | (0 if first else _ops.PAIR_IN0) | (_ops.PAIR_IN1 if src2 is not None else 0)
+        rc = L.isi_conv2d_twin_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, layer.packed().data_ptr(),
+                                   layer.bias.data_ptr(), C.byref(dst), twin.data_ptr(), B, H, W, cout, k, k,
+                                   layer.stride, layer.padding, flags, _s(src))
+        _hip.check(rc, "isi_conv2d_twin_f32")
+        return _Act(twin.permute(0, 3, 1, 2), out.permute(0, 3, 1, 2))
+    if pair_ok and not layer.transposed and not keep_pair and L.isi_conv2d_pair_route(c0, c1, cout, k, k):
+        # pair sources, fp32 output only
+        extra = _ops.PAIR_IN0 | (_ops.PAIR_IN1 if x2 is not None else 0)
+        return _Act(_ops.conv2d(x.want_pair(), layer.packed(), layer.bias, cout, k, layer.stride, layer.padding, relu,
+                                x2_bchw=x2.want_pair() if x2 is not None else None, bf16x3=4, extra_flags=extra))
+    return _Act(layer.run(x.f32, relu=relu, x2=x2.f32 if x2 is not None else None, out_nchw=out_nchw, bf16x3=FWD_PRECISION))
+
+
+def _res_block_fwd(blk: RosinalityResBlock, x: _Act, tape: "Tape", key: str) -> _Act:
+    """relu(r + conv1x1(relu(conv3x3(r)))) on a rectified r; tape[key.h] = the hidden activation, tape[key.y] = the output."""
+    c3, c1 = blk.conv[1], blk.conv[3]
+    L = _hip.lib()
+    B, Cc, H, W = x.f32.shape
+    R = c3.out_channels
+    if (_pair_mode() and c3.groups == 1 and c1.groups == 1 and _dense_cl(x.f32) and _ops.resblock_fusable(Cc, R)
+            and L.isi_resblock_pair_route(B, H, W, Cc, R)):
+        xp = x.want_pair().permute(0, 2, 3, 1)
+        out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=xp.device)
+        twin = torch.empty_like(out)
+        hid = torch.empty(B, H, W, R, dtype=torch.float32, device=xp.device)
+        rc = L.isi_resblock_tape_f32(xp.data_ptr(), c3.packed().data_ptr(), c3.bias.data_ptr(), c1.packed().data_ptr(),
+                                     c1.bias.data_ptr(), out.data_ptr(), twin.data_ptr(), hid.data_ptr(), B, H, W, Cc, R,
+                                     1 | _PAIR_FLAGS | _ops.PAIR_IN0 | _ops.PAIR_OUT, _s(xp))
+        _hip.check(rc, "isi_resblock_tape_f32")
+        y = _Act(twin.permute(0, 3, 1, 2), out.permute(0, 3, 1, 2))
+        tape[f"{key}.h"], tape[f"{key}.y"] = hid.permute(0, 3, 1, 2), y.f32
+        return y
+    h = c3.run(x.f32, relu=True, bf16x3=FWD_PRECISION)
+    yv = c1.run(h, relu=True, residual=x.f32, bf16x3=FWD_PRECISION)
+    tape[f"{key}.h"], tape[f"{key}.y"] = h, yv
+    return _Act(yv)
+
+
+def _as_act(x) -> _Act:
+    return x if isinstance(x, _Act) else _Act(x)
+
+
+def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str) -> _Act:
+    x = _as_act(x)
+    tape[f"{tag}.in"] = x.f32
     for j, i in enumerate(m._down):
         x = _conv_fwd(m.blocks[i], x, True)
-        tape[f"{tag}.down{j}"] = x
+        tape[f"{tag}.down{j}"] = x.f32
     x = _conv_fwd(m.blocks[m._conv3], x, True)
-    tape[f"{tag}.c3"] = x
+    tape[f"{tag}.c3"] = x.f32
     for j, i in enumerate(m._res):
-        blk: RosinalityResBlock = m.blocks[i]
-        h = blk.conv[1].run(x, relu=True, bf16x3=FWD_PRECISION)
-        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=FWD_PRECISION)
-        tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
-        x = y
+        x = _res_block_fwd(m.blocks[i], x, tape, f"{tag}.res{j}")
     return x
 
 
-def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_last: bool):
-    tape[f"{tag}.in"], tape[f"{tag}.in2"] = x, x2
-    x = m.blocks[0].run(x, relu=True, x2=x2, bf16x3=FWD_PRECISION)
-    tape[f"{tag}.c3"] = x
+def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_last: bool, last_pair: bool = False) -> _Act:
+    """`last_pair`: the decoder's output is read by a pair-route consumer (dec_t feeds nothing of the kind: its consumer
+    is the 1x1 quantiser convolution)."""
+    x = _as_act(x)
+    x2 = _as_act(x2) if x2 is not None else None
+    tape[f"{tag}.in"], tape[f"{tag}.in2"] = x.f32, (x2.f32 if x2 is not None else None)
+    x = _conv_fwd(m.blocks[0], x, True, x2=x2)
+    tape[f"{tag}.c3"] = x.f32
     for j, i in enumerate(m._res):
-        blk = m.blocks[i]
-        h = blk.conv[1].run(x, relu=True, bf16x3=FWD_PRECISION)
-        y = blk.conv[3].run(h, relu=True, residual=x, bf16x3=FWD_PRECISION)
-        tape[f"{tag}.res{j}.h"], tape[f"{tag}.res{j}.y"] = h, y
-        x = y
+        x = _res_block_fwd(m.blocks[i], x, tape, f"{tag}.res{j}")
     for j, i in enumerate(m._up):
         last = j == len(m._up) - 1
-        x = m.blocks[i].run(x, relu=not last, out_nchw=(last and out_nchw_last), bf16x3=FWD_PRECISION)
-        tape[f"{tag}.up{j}"] = x
+        nxt = m.blocks[m._up[j + 1]] if not last else None
+        # the few-channel last layer (Cout <= 4) and whatever follows the decoder read fp32
+        keep = last_pair if last else nxt.out_channels > 4
+        x = _conv_fwd(m.blocks[i], x, not last, out_nchw=(last and out_nchw_last), keep_pair=keep)
+        tape[f"{tag}.up{j}"] = x.f32
     return x
 
 
@@ -541,11 +651,12 @@ def encode_train(model, x: torch.Tensor):
     tape = Tape()
     x = x.contiguous()
     enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
-    enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
+    enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t").f32
+    enc_b = enc_b.f32
     z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=FWD_PRECISION))
     pending = PendingEma()
     q_t, diff_t, id_t, perp_t = quantize_train(model.quantize_t, z_t, pending)
-    dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
+    dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False).f32
     if dec_t.shape[-1] != enc_b.shape[-1]:
         if not model.adapt_quantized_durations:
             raise RuntimeError("Sizes of tensors must match except in dimension 1")
@@ -575,7 +686,8 @@ class VQVAETrainFunction(torch.autograd.Function):
         D = model.embed_dim
         x = x.contiguous()
         enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
-        enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t")
+        enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t").f32
+        enc_b = enc_b.f32
         z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=FWD_PRECISION))
         unq = model.disable_quantization      # UnquantizedBottleneck (bottleneck.py:107-119): identity, diff 0
 
@@ -586,17 +698,17 @@ class VQVAETrainFunction(torch.autograd.Function):
         pending = PendingEma()
         q_t, diff_t, id_t, perp_t = _identity(z_t) if unq else quantize_train(model.quantize_t, z_t, pending)
         tape["z_t"], tape["q_t"] = z_t, q_t
-        dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False)
+        dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False).f32
         if dec_t.shape[-1] != enc_b.shape[-1]:
             raise NotImplementedError("training needs input sizes divisible by the total down-sampling factor")
         z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=FWD_PRECISION))
         q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b, pending)
         tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
-        up = _as_bchw(q_t)
+        up = _Act(_as_bchw(q_t))
         for j, layer in enumerate(model.upsample_top_to_bottom):
-            tape[f"up.in{j}"] = up
-            up = layer.run(up, relu=False, bf16x3=FWD_PRECISION)
-        dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True)
+            tape[f"up.in{j}"] = up.f32
+            up = _conv_fwd(layer, up, False)
+        dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True).f32
         diff = (diff_t + diff_b).reshape(1)
         pending.flush()       # the statistics' all-reduces have had the rest of the forward to arrive; codebooks written here
         ctx.model, ctx.tape = model, tape

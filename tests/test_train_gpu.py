@@ -580,3 +580,58 @@ def test_backward_adjoint_identities_at_full_size(layer_kind):
     scale = (dy.double().pow(2).sum().sqrt() * y.double().pow(2).sum().sqrt()).item()
     assert abs(via_w - lhs) < 2e-5 * scale and abs(via_x - lhs) < 2e-5 * scale, (lhs, via_w, via_x, scale)
     assert _rel(db, dy.double().sum((0, 1, 2))) < 1e-5
+
+
+def test_pair_route_training_forward_side_outputs():
+    """The training forms of the pair pipeline's producers (isi_conv2d_twin_f32 / isi_conv_transpose2d_k4s2_twin_f32 /
+    isi_resblock_tape_f32): the pair-format output decodes to the fp32 twin (within the pair format's 2^-22), the twin is
+    BIT-EQUAL to what the same launch writes as a plain fp32 output, and the residual block's hidden activation and output
+    equal the two-convolution composition the round-4 training forward ran."""
+    from interactive_spectrogram_inpainting.vqvae import _ops, _train
+    from interactive_spectrogram_inpainting.vqvae.encoder_decoder import RosinalityResBlock, _ConvParams
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    assert _train._pair_mode()
+
+    def cl(t):      # [B,C,H,W] view of dense channels-last storage
+        return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    # plain convolutions (3x3, k4 s2, two sources), ragged sizes
+    for cin, cout, k, s, c1, B, H, W in ((128, 128, 3, 1, 0, 2, 9, 70), (64, 128, 4, 2, 0, 3, 10, 36), (64, 128, 3, 1, 64, 2, 5, 33),
+                                         (128, 64, 4, 2, 0, 2, 8, 64)):
+        layer = _ConvParams(cin + c1, cout, k, s, 1).to(dev)
+        x = cl(torch.randn(B, cin, H, W, generator=g).to(dev))
+        x2 = cl(torch.randn(B, c1, H, W, generator=g).to(dev)) if c1 else None
+        a = _train._conv_fwd(layer, _train._Act(x), True, x2=_train._Act(x2) if c1 else None)
+        assert a.pair is not None, (cin, cout, k)
+        ref = _ops.conv2d(_ops.pair_encode(x), layer.packed(), layer.bias, cout, k, s, 1, True,
+                          x2_bchw=_ops.pair_encode(x2) if c1 else None, bf16x3=4,
+                          extra_flags=_ops.PAIR_IN0 | (_ops.PAIR_IN1 if c1 else 0))
+        assert torch.equal(a.f32, ref), (cin, cout, k)
+        assert _rel(_ops.pair_decode(a.pair), a.f32) < 1e-6
+        assert _rel(a.f32, layer.run(x, relu=True, x2=x2, bf16x3=4)) < 2e-6
+    # first layer (NCHW spectrogram -> pairs + twin)
+    layer = _ConvParams(2, 64, 4, 2, 1).to(dev)
+    x = torch.randn(3, 2, 24, 40, generator=g).to(dev)
+    a = _train._conv_fwd(layer, _train._Act(x), True)
+    assert a.pair is not None and torch.equal(a.f32, layer.run(x, relu=True, bf16x3=4))
+    assert _rel(_ops.pair_decode(a.pair), a.f32) < 1e-6
+    # transposed convolution: pair + twin, and pair in -> fp32 out
+    layer = _ConvParams(128, 64, 4, 2, 1, transposed=True).to(dev)
+    x = cl(torch.randn(2, 128, 7, 33, generator=g).to(dev))
+    a = _train._conv_fwd(layer, _train._Act(x), True)
+    b = _train._conv_fwd(layer, _train._Act(x), True, keep_pair=False)
+    assert a.pair is not None and b.pair is None and torch.equal(a.f32, b.f32)
+    assert _rel(_ops.pair_decode(a.pair), a.f32) < 1e-6
+    assert _rel(a.f32, layer.run(x, relu=True, bf16x3=4)) < 2e-6
+    # fused residual block with the tape outputs
+    for Cc, B, H, W in ((128, 2, 32, 64), (64, 3, 33, 40)):
+        blk = RosinalityResBlock(Cc, 32).to(dev)
+        r = cl(torch.randn(B, Cc, H, W, generator=g).to(dev).relu())
+        tape = _train.Tape()
+        y = _train._res_block_fwd(blk, _train._Act(r), tape, "t")
+        assert y.pair is not None
+        h_ref = blk.conv[1].run(r, relu=True, bf16x3=4)
+        y_ref = blk.conv[3].run(h_ref, relu=True, residual=r, bf16x3=4)
+        assert _rel(tape["t.h"], h_ref) < 2e-6 and _rel(y.f32, y_ref) < 2e-6
+        assert ((tape["t.h"] > 0) == (h_ref > 0)).float().mean() > 0.9999
+        assert _rel(_ops.pair_decode(y.pair), y.f32) < 1e-6

@@ -153,6 +153,14 @@ int isi_pack_linear_wT_bf16(const float *w, float *out, int N, int K, void *stre
  * addresses; every N, K a multiple of 32; out: 2 N K floats each).  blocks_per_weight: workgroups per weight (each walks its
  * weight's 32 x 32 tiles with that stride). */
 int isi_pack_linear_wT_bf16_multi(const void *table, int n, int blocks_per_weight, void *stream);
+/* Every weight layout a VQ-VAE training step needs, re-packed by ONE launch per optimizer step (vqvae/_train.py
+ * PackGroup; the reference re-uses nn.Conv2d weights in place, train_vqvae.py:181-183 -- the layouts are this library's):
+ * `table` = n entries of 8 int64 in device memory {kind, src, dst, d0, d1, KH, KW, aux}:
+ *   kind 0 / 1: isi_pack_conv_weight_f32 / isi_pack_conv_weight_w16_f32 of a weight [d0 = Cout][d1 = Cin][KH][KW];
+ *   kind 2: isi_pack_conv_dgrad_weight_f32 of the same; kind 3 / 4: isi_pack_convT_k4s2_weight_f32 of [d0 = Cin][d1 = Cout][4][4]
+ *   in the phase-matrix layout (4: followed by isi_split_conv_weight_f16); kind 5: the few-channel layout + pair copy;
+ *   kind 6: isi_pack_codebook_f32 of embed [d0 = D][d1 = K] (codes at dst, |e|^2 at aux).  Bit-identical to those calls. */
+int isi_pack_multi(const void *table, int n, int blocks_per_entry, void *stream);
 /* Split-f16 pair copy of a packed weight (any of the packed layouts; n_floats % 4 == 0, 16-byte aligned):
  * every quad of floats becomes {hi0..hi3 | lo0..lo3}, the f16 pieces of 1024 w, in the same 16 bytes. */
 int isi_split_conv_weight_f16(const float *packed_w, float *out, int64_t n_floats, void *stream);

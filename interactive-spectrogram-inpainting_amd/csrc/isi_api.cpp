@@ -229,6 +229,7 @@ int isi_resblock_f32(const float *in, const float *packed_w3, const float *b3, c
   return resblock_f32(in, packed_w3, b3, packed_w1, b1, out, B, H, W, C, R, relu, S(stream));
 }
 int isi_resblock_fusable(int C, int R) { return resblock_fusable(C, R) ? 1 : 0; }
+int isi_pack_multi(const void *table, int n, int blocks_per_entry, void *stream) { return pack_multi(table, n, blocks_per_entry, S(stream)); }
 int isi_conv2d_twin_f32(const isi_src *src0, const isi_src *src1, const float *packed_w, const float *bias,
                         const isi_dst *dst, float *twin, int B, int H, int W, int Cout, int KH, int KW, int stride,
                         int pad, int flags, void *stream) {

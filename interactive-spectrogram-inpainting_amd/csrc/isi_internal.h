@@ -7,6 +7,7 @@
 namespace isi {
 
 int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream);
+int pack_multi(const void *table_dev, int n, int blocks_per_entry, hipStream_t stream);
 int pair_encode_f32(const float *x, float *out, int64_t n, hipStream_t stream);
 int pair_decode_f32(const float *in, float *x, int64_t n, hipStream_t stream);
 bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *res, const isi_dst *dst, int Cout,

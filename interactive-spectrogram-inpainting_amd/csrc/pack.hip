@@ -202,6 +202,100 @@ int pack_linear_wT_bf16_multi(const void *table_dev, int n, int blocks_per_weigh
   return check_launch("pack_linear_wT_bf16_multi");
 }
 
+// ---- every weight layout of a VQ-VAE training step in ONE launch (round 5).  A step re-packs each convolution weight for
+// the forward (packed + split-f16 pair copy) and for its input-gradient convolution, plus both codebooks: 63 launches of
+// ~5 us in round 4.  table[t] = 8 x int64 {kind, src, dst, d0, d1, KH, KW, aux}; grid (blocks per entry, entries); a thread
+// forms 8 consecutive elements of a packed row (Kpad is a multiple of 32: a group never straddles rows).
+//   kind 0 / 1  Conv2d weight [d0 = Cout][d1 = Cin][KH][KW] -> [Cout][Kpad]            (1: + pair copy behind it)
+//   kind 2      its stride-1 input-gradient weight          -> [Cin][Kpad'], rotated   (pack_conv_dgrad_kernel)
+//   kind 3 / 4  ConvTranspose2d(k4,s2,p1) weight [d0 = Cin][d1 = Cout][4][4] -> four phase matrices (4: + pair copy)
+//   kind 5      the few-channel layout of the same           -> [16 Cout][Cin] + pair copy (convT_small_f32.hip)
+//   kind 6      codebook `embed` [d0 = D][d1 = K] -> codes [K][D] at dst, |e|^2 [K] at aux (pack_codebook_kernel)
+__device__ __forceinline__ float pack_multi_elem(const int kind, const float *__restrict__ w, const int64_t i, const int d0,
+                                                 const int d1, const int KH, const int KW, const int Kpad) {
+  if (kind <= 1) {
+    const int co = (int)(i / Kpad), k = (int)(i - (int64_t)co * Kpad);
+    if (k >= KH * KW * d1) return 0.f;
+    const int tap = k / d1, ci = k - tap * d1, kh = tap / KW, kw = tap - kh * KW;
+    return w[(((int64_t)co * d1 + ci) * KH + kh) * KW + kw];
+  }
+  if (kind == 2) {
+    const int ci = (int)(i / Kpad), k = (int)(i - (int64_t)ci * Kpad);
+    if (k >= KH * KW * d0) return 0.f;
+    const int tap = k / d0, co = k - tap * d0, kh = tap / KW, kw = tap - kh * KW;
+    return w[(((int64_t)co * d1 + ci) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+  }
+  if (kind <= 4) {
+    const int Cin = d0, Cout = d1;
+    const int ph = (int)(i / ((int64_t)Cout * Kpad));
+    const int64_t rem = i - (int64_t)ph * Cout * Kpad;
+    const int co = (int)(rem / Kpad), k = (int)(rem - (int64_t)co * Kpad);
+    if (k >= 4 * Cin) return 0.f;
+    const int tap = k / Cin, ci = k - tap * Cin, ty = tap >> 1, tx = tap & 1;
+    const int ky = 3 - (ph >> 1) - 2 * ty, kx = 3 - (ph & 1) - 2 * tx;
+    return w[(((int64_t)ci * Cout + co) * 4 + ky) * 4 + kx];
+  }
+  {   // kind 5
+    const int Cin = d0, Cout = d1;
+    const int ci = (int)(i % Cin), n = (int)(i / Cin), co = n % Cout, t = n / Cout;
+    return w[((ci * Cout + co) * 4 + (t >> 2)) * 4 + (t & 3)];
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const long long *__restrict__ table) {
+  const long long *e = table + 8 * (size_t)blockIdx.y;
+  const int kind = (int)e[0];
+  const float *w = reinterpret_cast<const float *>(e[1]);
+  float *out = reinterpret_cast<float *>(e[2]);
+  const int d0 = (int)e[3], d1 = (int)e[4], KH = (int)e[5], KW = (int)e[6];
+  if (kind == 6) {
+    float *e2 = reinterpret_cast<float *>(e[7]);
+    const int D = d0, K = d1;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < K; k += gridDim.x * blockDim.x) {
+      float s = 0.f;
+      for (int c0 = 0; c0 < D; c0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = c0 + i < D ? w[(int64_t)(c0 + i) * K + k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (c0 + i < D) { out[(int64_t)k * D + c0 + i] = v[i]; s += v[i] * v[i]; }   // sequential over d (pack_codebook_kernel)
+      }
+      e2[k] = s;
+    }
+    return;
+  }
+  int Kpad;
+  int64_t total;
+  if (kind <= 1) { Kpad = (KH * KW * d1 + 31) / 32 * 32; total = (int64_t)d0 * Kpad; }          // (kBK = 32)
+  else if (kind == 2) { Kpad = (KH * KW * d0 + 31) / 32 * 32; total = (int64_t)d1 * Kpad; }
+  else if (kind <= 4) { Kpad = (4 * d0 + 31) / 32 * 32; total = (int64_t)4 * d1 * Kpad; }
+  else { Kpad = d0; total = (int64_t)16 * d0 * d1; }
+  const bool pairs = kind == 1 || kind == 4 || kind == 5;
+  const int64_t groups = total / 8;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = pack_multi_elem(kind, w, gi * 8 + j, d0, d1, KH, KW, Kpad);
+    const float4 a = make_float4(v[0], v[1], v[2], v[3]), b = make_float4(v[4], v[5], v[6], v[7]);
+    reinterpret_cast<float4 *>(out)[2 * gi] = a;
+    reinterpret_cast<float4 *>(out)[2 * gi + 1] = b;
+    if (pairs) {
+      uint4 hi, lo;
+      f16s::weight8_encode(a, b, hi, lo);
+      uint4 *pr = reinterpret_cast<uint4 *>(out + total);
+      pr[2 * gi] = hi;
+      pr[2 * gi + 1] = lo;
+    }
+  }
+}
+
+int pack_multi(const void *table_dev, int n, int blocks_per_entry, hipStream_t stream) {
+  if (!table_dev || n <= 0 || n > 65535 || blocks_per_entry <= 0) return invalid("pack_multi: bad argument");
+  hipLaunchKernelGGL(pack_multi_kernel, dim3(blocks_per_entry, n), dim3(256), 0, stream, static_cast<const long long *>(table_dev));
+  return check_launch("pack_multi");
+}
+
 int pack_linear_wT_bf16(const float *w, float *out, int N, int K, hipStream_t stream) {
   if (!w || !out || N <= 0 || K <= 0 || (N & 31) || (K & 31)) return invalid("pack_linear_wT_bf16: N, K multiples of 32");
   if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(out)) & 15)

@@ -146,6 +146,7 @@ SIGNATURES = {
     "isi_pack_conv_dgrad_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_pack_linear_wT_bf16": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "isi_pack_linear_wT_bf16_multi": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "isi_pack_multi": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "isi_packed_conv_weight_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "isi_pack_convT_k4s2_weight_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "isi_split_conv_weight_f16": (C.c_int, [_P, _P, C.c_int64, _P]),

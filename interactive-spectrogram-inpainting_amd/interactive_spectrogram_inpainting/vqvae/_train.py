@@ -182,6 +182,118 @@ class _DgradWeights:
         return hit[1]
 
 
+BATCHED_PACK = os.environ.get("ISI_TRAIN_BATCHED_PACK", "1") != "0"
+
+
+class PackGroup:
+    """Every weight layout of one model's training step -- forward operands (packed + split-f16 pair copy), the operands of
+    the input-gradient convolutions, both codebooks -- re-packed by ONE launch per step (isi_pack_multi) into persistent
+    buffers, instead of one launch per layer and role when first asked for (63 launches of ~5 us per step of the default
+    model in round 4).  `refresh()` runs at the head of every train-mode forward: when the parameters have moved since the
+    last launch it re-packs everything and stamps the per-layer caches (`_ConvParams.packed`, `_DgradWeights`,
+    `Quantize.packed`) so that their own version checks hit.  Grouped convolutions keep the per-layer path."""
+
+    def __init__(self, model):
+        self.model = model
+        self.rows, self.stamps = [], []      # table rows; (setter of the per-layer cache) per row
+        self.key = None
+        self.table = None
+        L = _hip.lib()
+        dev = next(model.parameters()).device
+        dw = model._dgrad_weights
+
+        def buf(n):
+            return torch.empty(n, dtype=torch.float32, device=dev)
+        for layer in [m for m in model.modules() if isinstance(m, _ConvParams)]:
+            if layer.groups != 1:
+                continue
+            w = layer.weight
+            k = layer.kernel_size
+            if layer.transposed:
+                cin, cout = w.shape[0], w.shape[1]
+                if (k, layer.stride, layer.padding) != (4, 2, 1):
+                    continue
+                n = L.isi_packed_convT_k4s2_weight_floats(cin, cout)
+                small = n == 16 * cin * cout and cout <= 4 and cin in (32, 64)
+                out = buf(2 * n)
+                self._add(5 if small else 4, w, out, cin, cout, 4, 4, 0, self._fwd_setter(layer, out))
+                # d/dx ConvT(k4,s2,p1) = Conv(k4,s2,p1) with weight [out = Cin_T, in = Cout_T]: the same tensor
+                outd = buf(L.isi_packed_conv_weight_floats(cin, cout, 4, 4))
+                self._add(0, w, outd, cin, cout, 4, 4, 0, self._dgrad_setter(dw, layer, outd))
+            else:
+                cout, cin = w.shape[0], w.shape[1]
+                n = L.isi_packed_conv_weight_floats(cout, cin, k, k)
+                out = buf(2 * n)
+                self._add(1, w, out, cout, cin, k, k, 0, self._fwd_setter(layer, out))
+                if layer.stride == 2 and k == 4 and layer.padding == 1:
+                    # d/dx Conv(k4,s2,p1) = ConvT(k4,s2,p1) with weight [in = Cout, out = Cin]: the same tensor
+                    nt = L.isi_packed_convT_k4s2_weight_floats(cout, cin)
+                    small = nt == 16 * cout * cin and cin <= 4 and cout in (32, 64)
+                    if small:
+                        continue       # (the 2-channel first layer: its input gradient is never asked for; per-layer path if it is)
+                    outd = buf(nt)
+                    self._add(3, w, outd, cout, cin, 4, 4, 0, self._dgrad_setter(dw, layer, outd))
+                elif layer.stride == 1:
+                    outd = buf(L.isi_packed_conv_weight_floats(cin, cout, k, k))
+                    self._add(2, w, outd, cout, cin, k, k, 0, self._dgrad_setter(dw, layer, outd))
+        self.quantizers = []
+        if not model.disable_quantization:
+            for q in (model.quantize_t, model.quantize_b):
+                D, K = q.embed.shape
+                codes, e2 = torch.empty(K, D, dtype=torch.float32, device=dev), buf(K)
+                self._add(6, q.embed, codes, D, K, 0, 0, e2.data_ptr(), self._codebook_setter(q, codes, e2))
+                self.quantizers.append(q)
+        self.table = torch.tensor(self.rows, dtype=torch.int64).to(dev)
+        self.ptrs = tuple(r[1] for r in self.rows)
+
+    def _add(self, kind, src, dst, d0, d1, kh, kw, aux, setter):
+        self.rows.append([kind, src.data_ptr(), dst.data_ptr(), d0, d1, kh, kw, aux])
+        self.stamps.append((src, setter))
+
+    @staticmethod
+    def _fwd_setter(layer, out):
+        def f():
+            layer._packed = out
+            layer._packed_key = (_hip.version_of(layer.weight), layer.weight.data_ptr(), layer.weight.device)
+        return f
+
+    @staticmethod
+    def _dgrad_setter(dw, layer, out):
+        def f():
+            dw.cache[id(layer)] = ((_hip.version_of(layer.weight), layer.weight.data_ptr()), out)
+        return f
+
+    @staticmethod
+    def _codebook_setter(q, codes, e2):
+        def f():
+            q._packed = (codes, e2)
+            q._packed_key = (_hip.version_of(q.embed), q.embed.data_ptr(), q.embed.device)
+        return f
+
+    def valid(self) -> bool:
+        """The table holds raw pointers: a parameter that moved (`.to()`, a loaded checkpoint re-allocating) retires it."""
+        return all(src.data_ptr() == p for (src, _), p in zip(self.stamps, self.ptrs))
+
+    def refresh(self) -> None:
+        key = tuple(_hip.version_of(src) for src, _ in self.stamps)
+        if key == self.key and all(q._packed_key is not None for q in self.quantizers):
+            return
+        _hip.check(_hip.lib().isi_pack_multi(self.table.data_ptr(), len(self.rows), 16, _s(self.table)), "isi_pack_multi")
+        for _, setter in self.stamps:
+            setter()
+        self.key = key
+
+
+def refresh_packs(model) -> None:
+    """Head of a train-mode forward: one launch re-packs whatever the optimizer (or the EMA update) has changed."""
+    if not BATCHED_PACK:
+        return
+    grp = getattr(model, "_pack_group", None)
+    if grp is None or not grp.valid():
+        grp = model._pack_group = PackGroup(model)
+    grp.refresh()
+
+
 def conv_dgrad(dw: _DgradWeights, layer: _ConvParams, dy: torch.Tensor,
                residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Gradient w.r.t. the layer input ([B,Cin,H,W] view of channels-last storage);
@@ -650,6 +762,8 @@ def encode_train(model, x: torch.Tensor):
     the train-mode forward up to the bottom quantiser, EMA buffers updated in-forward; detached outputs."""
     tape = Tape()
     x = x.contiguous()
+    if hasattr(model, "_dgrad_weights"):
+        refresh_packs(model)
     enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
     enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t").f32
     enc_b = enc_b.f32
@@ -685,6 +799,7 @@ class VQVAETrainFunction(torch.autograd.Function):
         tape = Tape()
         D = model.embed_dim
         x = x.contiguous()
+        refresh_packs(model)
         enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
         enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t").f32
         enc_b = enc_b.f32
@@ -739,7 +854,9 @@ class VQVAETrainFunction(torch.autograd.Function):
             g = _nhwc(d_view)
             _wgrad_into(grads, layer, tape[f"up.in{j}"], g)
             d_view = conv_dgrad(dw, layer, _as_bchw(g))
-        d_qt = _nhwc(d_view).clone()
+        d_qt = _nhwc(d_view)          # (a fresh tensor: the input-gradient convolution's own output, or a dense copy of a slice)
+        if len(model.upsample_top_to_bottom) == 0:
+            d_qt = d_qt.clone()
         # bottom quantiser and its 1x1 conv on cat(dec_t, enc_b)
         unq = model.disable_quantization
         d_zb = d_qb.contiguous() if unq else vq_backward(d_qb, tape["z_b"], tape["q_b"], g_diff)
@@ -747,7 +864,10 @@ class VQVAETrainFunction(torch.autograd.Function):
         _wgrad_into(grads, qcb, tape["dec_t"], d_zb, x2=tape["enc_b"])
         d_cat2 = conv_dgrad(dw, qcb, _as_bchw(d_zb))
         Cd = tape["dec_t"].shape[1]
-        d_dect, d_encb = d_cat2[:, :Cd], _nhwc(d_cat2[:, Cd:]).clone()
+        # (the channel slice is not dense: `_nhwc` already copies it into storage of its own, which the in-place sum below may write)
+        d_dect, d_encb = d_cat2[:, :Cd], _nhwc(d_cat2[:, Cd:])
+        if d_encb.data_ptr() == d_cat2.data_ptr():
+            d_encb = d_encb.clone()
         # dec_t
         d_qt2 = decoder_backward(model.dec_t, tape, "dec_t", d_dect, dw, grads)
         axpy_(d_qt, d_qt2)

@@ -635,3 +635,47 @@ def test_pair_route_training_forward_side_outputs():
         assert _rel(tape["t.h"], h_ref) < 2e-6 and _rel(y.f32, y_ref) < 2e-6
         assert ((tape["t.h"] > 0) == (h_ref > 0)).float().mean() > 0.9999
         assert _rel(_ops.pair_decode(y.pair), y.f32) < 1e-6
+
+
+def test_batched_weight_pack_equals_per_layer_packs():
+    """isi_pack_multi (one launch for every weight layout of a training step: forward operands with their split-f16 pair
+    copies, input-gradient operands, both codebooks) writes the bits of the per-layer pack calls, stamps the per-layer
+    caches, and re-packs after an optimizer step."""
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    from interactive_spectrogram_inpainting.vqvae import _ops, _train
+    from interactive_spectrogram_inpainting.vqvae.encoder_decoder import _ConvParams
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    torch.manual_seed(4)
+    m = VQVAE(in_channel=2).to(dev).train()
+    m._dgrad_weights = _train._DgradWeights()
+    _train.refresh_packs(m)
+    grp = m._pack_group
+    layers = [l for l in m.modules() if isinstance(l, _ConvParams)]
+    assert len(grp.rows) >= 2 * len(layers)      # forward + input-gradient operand per layer (first layer: forward only), 2 codebooks
+
+    def check_all():
+        fresh = _train._DgradWeights()
+        for l in layers:
+            got = l._packed
+            want = (_ops.pack_convT_weight if l.transposed else _ops.pack_conv_weight)(l.dense_weight(), with_f16=True)
+            assert torch.equal(got, want), l
+            assert l.packed() is got                       # the layer's own version check hits the group's buffer
+            if id(l) in m._dgrad_weights.cache:
+                assert torch.equal(m._dgrad_weights.cache[id(l)][1], fresh.get(l)), l
+                assert m._dgrad_weights.get(l) is m._dgrad_weights.cache[id(l)][1]
+        for q in (m.quantize_t, m.quantize_b):
+            codes, e2 = _ops.pack_codebook(q.embed)
+            assert torch.equal(q._packed[0], codes) and torch.equal(q._packed[1], e2)
+    check_all()
+    n_dgrad = len(m._dgrad_weights.cache)
+    assert n_dgrad == len(layers) - 1
+    opt = make_adam(m.parameters(), lr=1e-2)
+    x = torch.randn(2, 2, 32, 64, device=dev)
+    out, latent, *_ = m(x)
+    (torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()).backward()
+    opt.step()
+    before = m.enc_b.blocks[0]._packed.clone()
+    _train.refresh_packs(m)
+    assert not torch.equal(before, m.enc_b.blocks[0]._packed)
+    check_all()

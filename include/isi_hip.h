@@ -350,6 +350,13 @@ int isi_axpy_f32(float *a, const float *b, float alpha, int64_t n, void *stream)
 /* Quantiser backward (bottleneck.py:94-95): dz = dq + 2 g_diff (z - q_st) / n. */
 int isi_vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st,
                    const float *g_diff, int64_t n, void *stream);
+/* out[m][c] = (y[m][c] > 0) * (a[m][c] + b[m][c]) over M rows of C channels: two gradient contributions summed and masked by
+ * the ReLU of the tensor they belong to in one pass; `a` may be a channel slice of a wider channels-last tensor (row stride
+ * lda), b / y dense [M, C] or NULL (no second term / no mask).  Same, for the quantiser backward, with dq read through a
+ * row stride (isi_vq_bwd_f32 on a channel slice without a dense copy first). */
+int isi_add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, void *stream);
+int isi_vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff,
+                        int64_t M, int D, void *stream);
 /* out[C] = column sums of x [M, C] (bias gradients); workspace isi_colsum_num_partials(M)*C floats. */
 int isi_colsum_num_partials(int64_t M);
 int isi_colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M,

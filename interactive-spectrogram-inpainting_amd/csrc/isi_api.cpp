@@ -361,6 +361,13 @@ int isi_vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st
                    void *stream) {
   return vq_bwd_f32(dz, dq, z, q_st, g_diff, n, S(stream));
 }
+int isi_add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, void *stream) {
+  return add_gate_rows_f32(out, a, lda, b, y, M, C, S(stream));
+}
+int isi_vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff,
+                        int64_t M, int D, void *stream) {
+  return vq_bwd_rows_f32(dz, dq, ldq, z, q_st, g_diff, M, D, S(stream));
+}
 int isi_colsum_num_partials(int64_t M) { return colsum_num_partials(M); }
 int isi_colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, void *stream) {
   return colsum_f32(x, x_stride, out, workspace, M, C, S(stream));

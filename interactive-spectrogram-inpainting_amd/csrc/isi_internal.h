@@ -7,6 +7,9 @@
 namespace isi {
 
 int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream);
+int add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, hipStream_t st);
+int vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff, int64_t M,
+                    int D, hipStream_t st);
 int pack_multi(const void *table_dev, int n, int blocks_per_entry, hipStream_t stream);
 int pair_encode_f32(const float *x, float *out, int64_t n, hipStream_t stream);
 int pair_decode_f32(const float *in, float *x, int64_t n, hipStream_t stream);

@@ -702,30 +702,48 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   int rc;
   if ((rc = enqueue_position(sampled_at(p_begin), p_begin, st))) return rc;
   int p = p_begin + 1;
-  // ... the rest can replay two captured graphs (with / without the sampling tail; ISI_PRIOR_GRAPH=1): the launches
-  // of a position collapse into one graph launch, every position-dependent address read from a device counter.
-  const bool use_graph = knobs().prior_graph != 0;
-  if (use_graph && p_end - p >= 4) {
-    hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, p, 0);
-    if ((rc = check_launch("set_position"))) return rc;
+  // ... the rest can replay captured graphs of W = ISI_PRIOR_GRAPH consecutive positions (round 5; 1 = the round-2 form, one
+  // position per graph): the ~66 launches of a position -- W x 66 per graph -- collapse into one graph launch and the host
+  // leaves the loop (direct launches cost it ~230 us per token against ~280 us of kernels: on a slower host the loop was
+  // host-bound).  Every position-dependent address is read from a device counter the last node of a
+  // position advances.  Two variants exist -- windows whose positions are all sampled / all kept --, each captured when
+  // first needed; windows of mixed positions and the tail run as direct launches (the counter is re-set after them).
+  const int W = knobs().prior_graph;
+  if (W > 0 && p_end - p >= (W > 2 ? 2 * W : 4)) {
     hipStream_t cap = nullptr;
     hipGraph_t graphs[2] = {nullptr, nullptr};
     hipGraphExec_t execs[2] = {nullptr, nullptr};
+    bool failed[2] = {false, false};
     bool ok = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess;
-    for (int k = 0; ok && k < 2; ++k) {
-      ok = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (!ok) break;
-      const int erc = enqueue_position(k == 1, -1, cap);
+    auto build = [&](int k) -> bool {      // k = 1: every position of the window samples
+      if (execs[k] || failed[k]) return execs[k] != nullptr;
+      bool good = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      int erc = ISI_OK;
+      for (int i = 0; good && i < W && erc == ISI_OK; ++i) erc = enqueue_position(k == 1, -1, cap);
       hipGraph_t gph = nullptr;
-      const bool ended = hipStreamEndCapture(cap, &gph) == hipSuccess;
+      const bool ended = good && hipStreamEndCapture(cap, &gph) == hipSuccess;
       graphs[k] = gph;
-      ok = erc == ISI_OK && ended && gph != nullptr && hipGraphInstantiate(&execs[k], gph, nullptr, nullptr, 0) == hipSuccess;
-    }
-    if (ok) {
-      for (; p < p_end && ok; ++p) ok = hipGraphLaunch(execs[sampled_at(p) ? 1 : 0], st) == hipSuccess;
-      if (!ok) rc = check_launch("hipGraphLaunch(prior position)");
-    } else {
-      (void)hipGetLastError();   // capture unavailable: fall through to direct launches (same kernels)
+      good = good && erc == ISI_OK && ended && gph != nullptr && hipGraphInstantiate(&execs[k], gph, nullptr, nullptr, 0) == hipSuccess;
+      if (!good) { failed[k] = true; (void)hipGetLastError(); }
+      return good;
+    };
+    int counter = -1;                      // value of the device counter (-1: unknown)
+    while (ok && p < p_end && rc == ISI_OK) {
+      bool uniform = p + W <= p_end;
+      const bool flag = sampled_at(p);
+      for (int i = 1; uniform && i < W; ++i) uniform = sampled_at(p + i) == flag;
+      if (uniform && build(flag ? 1 : 0)) {
+        if (counter != p) {
+          hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, p, 0);
+          if ((rc = check_launch("set_position"))) break;
+        }
+        if (hipGraphLaunch(execs[flag ? 1 : 0], st) != hipSuccess) { rc = check_launch("hipGraphLaunch(prior positions)"); break; }
+        p += W;
+        counter = p;
+      } else {
+        if ((rc = enqueue_position(flag, p, st))) break;
+        ++p;
+      }
     }
     if (execs[0] || execs[1]) (void)hipStreamSynchronize(st);   // executables must outlive their launches
     for (int k = 0; k < 2; ++k) {

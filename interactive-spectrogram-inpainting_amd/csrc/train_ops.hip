@@ -105,6 +105,48 @@ __global__ __launch_bounds__(1024) void vq_ema_update_kernel(float *__restrict__
   }
 }
 
+// out[m][c] = gate(y[m][c]) * (a[m][c] + b[m][c]): the sum of two gradient contributions with the ReLU mask of the tensor
+// they belong to, in one pass; `a` may be a channel slice of a wider channels-last tensor (row stride lda >= C): replaces a
+// slice copy + axpy + relu_bwd (three passes over the bottom encoder's 134 MB output gradient).  y = nullptr: no mask.
+__global__ void add_gate_rows_kernel(float *__restrict__ out, const float *__restrict__ a, int64_t lda,
+                                     const float *__restrict__ b, const float *__restrict__ y, int64_t M, int C4) {
+  const int64_t n4 = M * C4, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t m = i / C4;
+    const int c4 = (int)(i - m * C4);
+    const float4 u = *reinterpret_cast<const float4 *>(a + m * lda + 4 * c4);
+    float4 g = make_float4(u.x, u.y, u.z, u.w);
+    if (b) {
+      const float4 v = reinterpret_cast<const float4 *>(b)[i];
+      g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+    }
+    if (y) {
+      const float4 r = reinterpret_cast<const float4 *>(y)[i];
+      g.x = r.x > 0.f ? g.x : 0.f; g.y = r.y > 0.f ? g.y : 0.f; g.z = r.z > 0.f ? g.z : 0.f; g.w = r.w > 0.f ? g.w : 0.f;
+    }
+    reinterpret_cast<float4 *>(out)[i] = g;
+  }
+}
+
+// vq_bwd_kernel with dq read through a row stride (a channel slice of the decoder's input gradient: no dense copy first)
+__global__ void vq_bwd_rows_kernel(float *__restrict__ dz, const float *__restrict__ dq, int64_t ldq,
+                                   const float *__restrict__ z, const float *__restrict__ q_st,
+                                   const float *__restrict__ g_diff, float inv_numel, int64_t M, int D4) {
+  const float coef = 2.f * g_diff[0] * inv_numel;
+  const int64_t n4 = M * D4, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int64_t m = i / D4;
+    const int c4 = (int)(i - m * D4);
+    const float4 g = *reinterpret_cast<const float4 *>(dq + m * ldq + 4 * c4);
+    const float4 a = reinterpret_cast<const float4 *>(z)[i];
+    const float4 b = reinterpret_cast<const float4 *>(q_st)[i];
+    float4 o;
+    o.x = g.x + coef * (a.x - b.x); o.y = g.y + coef * (a.y - b.y);
+    o.z = g.z + coef * (a.z - b.z); o.w = g.w + coef * (a.w - b.w);
+    reinterpret_cast<float4 *>(dz)[i] = o;
+  }
+}
+
 static unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 8192); }
 
 int relu_bwd_f32(float *dy, const float *y, int64_t n, hipStream_t st) {
@@ -123,6 +165,24 @@ int axpy_f32(float *a, const float *b, float alpha, int64_t n, hipStream_t st) {
   return check_launch("axpy_f32");
 }
 
+int add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, hipStream_t st) {
+  if (!out || !a || M <= 0 || C <= 0 || (C & 3) || (lda & 3) || lda < C) return invalid("add_gate_rows: bad argument (C, lda multiples of 4)");
+  if ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(y)) & 15)
+    return invalid("add_gate_rows: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(add_gate_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, st, out, a, lda, b, y, M, C / 4);
+  return check_launch("add_gate_rows_f32");
+}
+
+int vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff, int64_t M,
+                    int D, hipStream_t st) {
+  if (!dz || !dq || !z || !q_st || !g_diff || M <= 0 || D <= 0 || (D & 3) || (ldq & 3) || ldq < D) return invalid("vq_bwd_rows: bad argument");
+  if ((reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(dq) | reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(q_st)) & 15)
+    return invalid("vq_bwd_rows: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(vq_bwd_rows_kernel, dim3(grid_for(M * (D / 4))), dim3(256), 0, st, dz, dq, ldq, z, q_st, g_diff,
+                     1.0f / (float)(M * D), M, D / 4);
+  return check_launch("vq_bwd_rows_f32");
+}
+
 int vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st, const float *g_diff, int64_t n,
                hipStream_t st) {
   if (!dz || !dq || !z || !q_st || !g_diff || n <= 0 || (n & 3)) return invalid("vq_bwd: bad argument");
@@ -136,17 +196,24 @@ int colsum_num_partials(int64_t M) { return (int)std::min<int64_t>((M + 255) / 2
 // out[C] = column sums of x [M, C] (row stride x_stride); workspace: colsum_num_partials(M) * C floats
 int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, hipStream_t st);
 
+// (round 5: 16 columns x 16 row groups per block instead of 64 x 4 -- with C = 64 the old form was ONE block whose threads
+// walked 64 partial rows each, 16 us of pure latency per bias gradient)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float *__restrict__ partial,
                                                           float *__restrict__ out, int C, int nblk) {
-  __shared__ float red[4][64];
-  const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + e;
+  __shared__ float red[16][17];
+  const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + e;
   float s = 0.f;
   if (c < C)
-    for (int b = g; b < nblk; b += 4) s += partial[(size_t)b * C + c];
+    for (int b = g; b < nblk; b += 16) s += partial[(size_t)b * C + c];
   red[g][e] = s;
   __syncthreads();
-  if (g == 0 && c < C) out[c] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+  if (g == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][e];
+    out[c] = t;
+  }
 }
 
 // Dense [M, C] with C a power of two <= 1024: the matrix is streamed as one flat float4 array; a thread's
@@ -198,14 +265,14 @@ int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, i
                        n4, C, per);
     int rc = check_launch("colsum_flat");
     if (rc) return rc;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, out, C, nblk);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, out, C, nblk);
     return check_launch("colsum_reduce");
   }
   const int rows = (int)((M + nblk - 1) / nblk);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, x, workspace, M, C, x_stride, rows);
   int rc = check_launch("colsum_partial");
   if (rc) return rc;
-  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 63) / 64), dim3(256), 0, st, workspace, out, C, nblk);
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((C + 15) / 16), dim3(256), 0, st, workspace, out, C, nblk);
   return check_launch("colsum_reduce");
 }
 

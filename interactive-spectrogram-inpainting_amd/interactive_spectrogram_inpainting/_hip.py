@@ -218,6 +218,8 @@ SIGNATURES = {
     "isi_relu_bwd_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "isi_axpy_f32": (C.c_int, [_P, _P, C.c_float, C.c_int64, _P]),
     "isi_vq_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
+    "isi_add_gate_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, _P]),
+    "isi_vq_bwd_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, _P]),
     "isi_colsum_num_partials": (C.c_int, [C.c_int64]),
     "isi_colsum_f32": (C.c_int, [_P, C.c_int64, _P, _P, C.c_int64, C.c_int, _P]),
     "isi_vq_embed_sum_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int64]),

@@ -83,12 +83,45 @@ def axpy_(a: torch.Tensor, b: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     return a
 
 
-def colsum(x2d: torch.Tensor) -> torch.Tensor:
-    """x [M, C] (row stride arbitrary, unit column stride) -> [C]."""
+def _rows(t_bchw: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] view -> NHWC-shaped tensor whose pixels are uniformly strided rows of C contiguous channels: dense
+    channels-last storage, or a CHANNEL SLICE of it (the two halves of a concatenated input's gradient) -- the kernels
+    that take a row stride read such a slice in place; anything else is copied dense."""
+    p = t_bchw.permute(0, 2, 3, 1)
+    B, H, W, Cc = p.shape
+    sb, sh, sw, sc = p.stride()
+    if sc == 1 and (W == 1 or sh == W * sw) and (B == 1 or sb == H * sh) and sw % 4 == 0 and p.data_ptr() % 16 == 0:
+        return p
+    return p.contiguous()
+
+
+def _rows2d(p_nhwc: torch.Tensor) -> torch.Tensor:
+    """The [M, C] matrix of a `_rows` tensor (row stride = its pixel stride)."""
+    B, H, W, Cc = p_nhwc.shape
+    return p_nhwc.as_strided((B * H * W, Cc), (p_nhwc.stride(2), 1), p_nhwc.storage_offset())
+
+
+def add_gate_rows(a_nhwc: torch.Tensor, b_nhwc: Optional[torch.Tensor], y_nhwc: Optional[torch.Tensor]) -> torch.Tensor:
+    """(y > 0) * (a + b) in one pass; a: `_rows` tensor (possibly a channel slice), b / y dense or None."""
+    B, H, W, Cc = a_nhwc.shape
+    out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=a_nhwc.device)
+    for t in (b_nhwc, y_nhwc):
+        if t is not None and not t.is_contiguous():
+            raise ValueError("add_gate_rows: the second term and the gate must be dense channels-last")
+    _hip.check(_hip.lib().isi_add_gate_rows_f32(out.data_ptr(), a_nhwc.data_ptr(), a_nhwc.stride(2),
+                                                b_nhwc.data_ptr() if b_nhwc is not None else None,
+                                                y_nhwc.data_ptr() if y_nhwc is not None else None, B * H * W, Cc, _s(out)),
+               "isi_add_gate_rows_f32")
+    return out
+
+
+def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [M, C] (row stride arbitrary, unit column stride) -> [C] (`out`: written in place, e.g. a bias-gradient slot)."""
     M, Cc = x2d.shape
     L = _hip.lib()
     ws = torch.empty(L.isi_colsum_num_partials(M) * Cc, dtype=torch.float32, device=x2d.device)
-    out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
+    if out is None or not out.is_contiguous():
+        out = torch.empty(Cc, dtype=torch.float32, device=x2d.device)
     _hip.check(L.isi_colsum_f32(x2d.data_ptr(), x2d.stride(0), out.data_ptr(), ws.data_ptr(), M, Cc, _s(x2d)),
                "isi_colsum_f32")
     return out
@@ -111,7 +144,8 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
     tr = layer.transposed
     k = layer.kernel_size
     if tr:
-        src, grad = _as_bchw(dy_nhwc), _nhwc(x)              # roles swapped
+        # roles swapped: dy is the SOURCE operand here (any strides: a channel slice of a wider gradient is read in place)
+        src, grad = _as_bchw(dy_nhwc), _nhwc(x)
         rows, cin_role = layer.in_channels, layer.out_channels
     else:
         src, grad = x, dy_nhwc
@@ -142,7 +176,7 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
                                         B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
         _hip.check(rc, "isi_conv_wgrad_torch_f32")
         if tr:
-            db.copy_(colsum(dy_nhwc.reshape(-1, dy_nhwc.shape[-1])))
+            colsum(_rows2d(dy_nhwc), out=db)
         return dw, db
     packed = torch.empty(rows, Kpad, dtype=torch.float32, device=x.device)
     db = None if tr else torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -153,7 +187,7 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
     # [rows][kh][kw][cin_role] -> [rows, cin_role, kh, kw]  (= torch layout for both layer kinds)
     dw = layer.grouped(packed[:, :K].reshape(rows, k, k, cin_role)[..., :cin_true].permute(0, 3, 1, 2))
     if tr:
-        db = colsum(dy_nhwc.reshape(-1, dy_nhwc.shape[-1]))
+        db = colsum(_rows2d(dy_nhwc))
     return dw, db
 
 
@@ -573,9 +607,10 @@ def _res_stack_backward(blocks, idxs, tape, tag, d_y, x_in_key, dw, grads: Grads
     return d_y if gated else relu_bwd_(d_y, _nhwc(tape[x_in_key]))
 
 
-def encoder_backward(m: RosinalityEncoder, tape: Tape, tag: str, d_out, dw, grads: Grads, need_input_grad: bool):
-    """d_out: dense NHWC gradient w.r.t. the encoder output."""
-    g = _res_stack_backward(m.blocks, m._res, tape, tag, d_out, f"{tag}.c3", dw, grads)   # gated by the conv3 output
+def encoder_backward(m: RosinalityEncoder, tape: Tape, tag: str, d_out, dw, grads: Grads, need_input_grad: bool,
+                     gated: bool = False):
+    """d_out: dense NHWC gradient w.r.t. the encoder output (`gated`: already zeroed where that rectified output is zero)."""
+    g = _res_stack_backward(m.blocks, m._res, tape, tag, d_out, f"{tag}.c3", dw, grads, gated=gated)   # gated by the conv3 output
     c3 = m.blocks[m._conv3]
     prev = tape[f"{tag}.down{len(m._down) - 1}"]
     _wgrad_into(grads, c3, prev, g)
@@ -597,7 +632,10 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
     d_view = d_out_bchw
     for j in reversed(range(len(m._up))):
         layer = m.blocks[m._up[j]]
-        g = _nhwc(d_view)     # below the last layer: our own input-gradient output, gated by this layer's output
+        # below the last layer: our own input-gradient output, gated by this layer's output.  A transposed layer reads its
+        # output gradient as a strided SOURCE (weight gradient with the roles swapped, input gradient = a convolution of
+        # it): a channel slice needs no dense copy
+        g = _rows(d_view) if layer.transposed else _nhwc(d_view)
         prev = tape[f"{tag}.up{j - 1}"] if j > 0 else tape[f"{tag}.res{len(m._res) - 1}.y" if m._res else f"{tag}.c3"]
         _wgrad_into(grads, layer, prev, g)
         d_view = conv_dgrad(dw, layer, _as_bchw(g), gate=_nhwc(prev))
@@ -783,10 +821,17 @@ def encode_train(model, x: torch.Tensor):
 
 
 def vq_backward(dq_nhwc, z_nhwc, q_st_nhwc, g_diff):
+    """dq_nhwc: dense, or a `_rows` tensor (uniformly strided pixels: a channel slice of a wider gradient, read in place)."""
     dz = torch.empty_like(z_nhwc)
-    _hip.check(_hip.lib().isi_vq_bwd_f32(dz.data_ptr(), dq_nhwc.data_ptr(), z_nhwc.data_ptr(),
-                                         q_st_nhwc.data_ptr(), g_diff.data_ptr(), z_nhwc.numel(), _s(z_nhwc)),
-               "isi_vq_bwd_f32")
+    if dq_nhwc.is_contiguous():
+        _hip.check(_hip.lib().isi_vq_bwd_f32(dz.data_ptr(), dq_nhwc.data_ptr(), z_nhwc.data_ptr(),
+                                             q_st_nhwc.data_ptr(), g_diff.data_ptr(), z_nhwc.numel(), _s(z_nhwc)),
+                   "isi_vq_bwd_f32")
+        return dz
+    D = dq_nhwc.shape[-1]
+    _hip.check(_hip.lib().isi_vq_bwd_rows_f32(dz.data_ptr(), dq_nhwc.data_ptr(), dq_nhwc.stride(-2), z_nhwc.data_ptr(),
+                                              q_st_nhwc.data_ptr(), g_diff.data_ptr(), z_nhwc.numel() // D, D, _s(z_nhwc)),
+               "isi_vq_bwd_rows_f32")
     return dz
 
 
@@ -846,12 +891,12 @@ class VQVAETrainFunction(torch.autograd.Function):
         # decoder (bottom): d cat(up, q_b)
         d_cat = decoder_backward(model.dec, tape, "dec", g_dec, dw, grads)
         d_up = _as_bchw(d_cat)[:, :D]
-        d_qb = _nhwc(_as_bchw(d_cat)[:, D:])
+        d_qb = _rows(_as_bchw(d_cat)[:, D:])       # (a channel slice, read in place by the quantiser backward)
         # upsample_top_to_bottom: plain transposed convs
         d_view = d_up
         for j in reversed(range(len(model.upsample_top_to_bottom))):
             layer = model.upsample_top_to_bottom[j]
-            g = _nhwc(d_view)
+            g = _rows(d_view) if layer.transposed else _nhwc(d_view)
             _wgrad_into(grads, layer, tape[f"up.in{j}"], g)
             d_view = conv_dgrad(dw, layer, _as_bchw(g))
         d_qt = _nhwc(d_view)          # (a fresh tensor: the input-gradient convolution's own output, or a dense copy of a slice)
@@ -864,10 +909,9 @@ class VQVAETrainFunction(torch.autograd.Function):
         _wgrad_into(grads, qcb, tape["dec_t"], d_zb, x2=tape["enc_b"])
         d_cat2 = conv_dgrad(dw, qcb, _as_bchw(d_zb))
         Cd = tape["dec_t"].shape[1]
-        # (the channel slice is not dense: `_nhwc` already copies it into storage of its own, which the in-place sum below may write)
-        d_dect, d_encb = d_cat2[:, :Cd], _nhwc(d_cat2[:, Cd:])
-        if d_encb.data_ptr() == d_cat2.data_ptr():
-            d_encb = d_encb.clone()
+        # two channel slices of one tensor: d_dect is read in place by dec_t's last transposed convolution, the enc_b half
+        # waits (in place) for enc_t's contribution
+        d_dect, d_encb_part = d_cat2[:, :Cd], _rows(d_cat2[:, Cd:])
         # dec_t
         d_qt2 = decoder_backward(model.dec_t, tape, "dec_t", d_dect, dw, grads)
         axpy_(d_qt, d_qt2)
@@ -875,10 +919,13 @@ class VQVAETrainFunction(torch.autograd.Function):
         d_zt = d_qt if unq else vq_backward(d_qt, tape["z_t"], tape["q_t"], g_diff)
         qct = model.quantize_conv_t
         _wgrad_into(grads, qct, tape["enc_t"], d_zt)
-        d_enct = _nhwc(conv_dgrad(dw, qct, _as_bchw(d_zt)))
-        d_encb2 = encoder_backward(model.enc_t, tape, "enc_t", d_enct, dw, grads, need_input_grad=True)
-        axpy_(d_encb, d_encb2)
-        encoder_backward(model.enc_b, tape, "enc_b", d_encb, dw, grads, need_input_grad=False)
+        # the ReLU masks of the two encoders' outputs ride in the producers of their gradients: the 1x1 input-gradient
+        # convolution's gated epilogue (enc_t) and the sum of enc_b's two contributions (one pass instead of a slice copy,
+        # an axpy and a mask pass over 134 MB each)
+        d_enct = _nhwc(conv_dgrad(dw, qct, _as_bchw(d_zt), gate=_nhwc(tape["enc_t"])))
+        d_encb2 = encoder_backward(model.enc_t, tape, "enc_t", d_enct, dw, grads, need_input_grad=True, gated=True)
+        d_encb = add_gate_rows(d_encb_part, d_encb2, _nhwc(tape["enc_b"]))
+        encoder_backward(model.enc_b, tape, "enc_b", d_encb, dw, grads, need_input_grad=False, gated=True)
         views = grads.finish()
         ctx.tape = None
         return (None, None) + tuple(views)

@@ -325,6 +325,12 @@ def test_sample_model_matches_full_pass_sampling(golden_dir):
         alt = S.sample_model(top, dev, B, [8, 4], temperature=0.9, class_conditioning=cls,
                              initial_code=init.clone(), mask=mask, top_p_sampling_p=0.8, uniforms=uni)
     assert torch.equal(alt, ref), "ISI_PRIOR_GRAPH"
+    # round 5: W consecutive positions per graph (windows of sampled / kept positions, mixed windows as direct launches)
+    for w_ in (3, 4, 8):
+        with _hip.knob("ISI_PRIOR_GRAPH", w_):
+            alt = S.sample_model(top, dev, B, [8, 4], temperature=0.9, class_conditioning=cls,
+                                 initial_code=init.clone(), mask=mask, top_p_sampling_p=0.8, uniforms=uni)
+        assert torch.equal(alt, ref), f"ISI_PRIOR_GRAPH={w_}"
     # bottom prior conditioned on the sampled top map: unmasked call runs and stays in range (equality with the
     # full-pass loop: test_bottom_prior_sample_model_matches_full_pass_sampling)
     out_b = S.sample_model(bottom, dev, B, [16, 8], temperature=1.0, condition=got, class_conditioning=cls,

@@ -148,7 +148,7 @@ def _cpu_baseline(sd, x=None, id_t=None, id_b=None, batch=64, warmup=1, iters=3)
                 if i >= warmup:
                     times.append(time.perf_counter() - t0)
             if x is not None and id_t is not None:
-                parity = O.teacher_forced_code_check(x, sd, cfg, id_t, id_b)
+                parity = O.teacher_forced_code_check(x, sd, cfg, id_t, id_b, eps=1e-6)
     finally:
         torch.set_num_threads(before)
     med = sorted(times)[len(times) // 2]
@@ -772,7 +772,7 @@ def main():
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH doubled as the
         # gfx950 guide prescribes; tools/pmc_traffic.py): a measured constant, not re-measured here
         traffic = None
-        traffic_file = next((f for f in ("profiles/r04_pmc_hbm_traffic.json", "profiles/r03_pmc_hbm_traffic.json", "profiles/r02_pmc_hbm_traffic.json",
+        traffic_file = next((f for f in ("profiles/r05_pmc_hbm_traffic.json", "profiles/r04_pmc_hbm_traffic.json", "profiles/r03_pmc_hbm_traffic.json", "profiles/r02_pmc_hbm_traffic.json",
                                          "profiles/r01_pmc_hbm_traffic.json") if (ROOT / f).exists()), "profiles/none")
         try:
             if args.batch != 64:
@@ -787,9 +787,10 @@ def main():
             for name, d in pmc.items():
                 mine = ("conv_igemm_f32_kernel" in name and any(t in name for t in want)) or \
                        ("f16x3" in dom["kernel"] and ("conv_pair_kernel<" in name or "convT_pair_kernel<" in name))
-                if mine and "hbm_bytes_per_launch_corrected" in d:
-                    tot_b += d["hbm_bytes_per_launch_corrected"] * d["dispatches"]
-                    tot_n += d["dispatches"]
+                if mine and d.get("hbm_bytes_per_launch_corrected") is not None:    # (None: the two passes disagree on it)
+                    n_d = d.get("dispatches", d.get("dispatches_fetch_pass", 0))
+                    tot_b += d["hbm_bytes_per_launch_corrected"] * n_d
+                    tot_n += n_d
             if tot_n:
                 traffic = round(tot_b / tot_n)
         except (OSError, ValueError, KeyError):

@@ -614,7 +614,10 @@ static int launch_conv(const ConvKArgs &a_in, bool scalar_a, int nphase, hipStre
     if (a.bf16x3 == 3) return launch_cfg<128, 32, 4, 1, 0, 3>(a, nphase, stream);   // (pieces prepared at pack time: not built at this width)
     return launch_cfg<128, 32, 4, 1, 0, 1>(a, nphase, stream);
   }
-  if (a.bf16x3 && mode == 0 && a.Cout > 32 && a.K >= 128) {
+  // (round 5: the three-term split-bf16 mode -- the training step's input gradients -- also takes K = 64..127: the 1x1
+  // quantiser convolutions' input gradients (K = embed_dim = 64, 192 output channels at the bottom resolution) ran on the
+  // fp32 matrix pipe, 142 us of a step)
+  if (a.bf16x3 && mode == 0 && a.Cout > 32 && (a.K >= 128 || (a.bf16x3 == 1 && a.K >= 64 && !a.in0_pair && !a.in1_pair && !a.out_pair))) {
     // 128x64 tiles are ~20 % slower per FLOP than 128x128, but a GEMM that fills less than the chip's
     // 3 workgroups per CU with 128x128 tiles (the prior's d x d linears at 8 k rows: 260 tiles) finishes
     // sooner with twice as many, half as long, workgroups

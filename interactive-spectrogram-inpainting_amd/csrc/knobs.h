@@ -29,7 +29,7 @@ struct Knobs {
   int wgrad_split_target;       // ISI_WGRAD_SPLIT_TARGET: workgroups the split weight-gradient kernel aims at (0 = 768)
   int attn_full_zero;           // ISI_ATTN_FULL_ZERO: the attention backward zeroes all of G, not only the margins of its band
   int attn_old_fwd;             // ISI_ATTN_OLD_FWD: the round-3 forward kernel (32-key tiles) for the 16-bit modes (A/B switch)
-  int prior_graph;              // ISI_PRIOR_GRAPH: replay the decode loop's positions as hipGraphs
+  int prior_graph;              // ISI_PRIOR_GRAPH: positions per replayed hipGraph of the decode loop (8; 0 = direct launches)
   int conv_ablate, vq_dbg, respair_abl;   // ISI_MEASURE builds only
 };
 

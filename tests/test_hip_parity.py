@@ -534,7 +534,7 @@ def test_vqvae_full_size_properties(precision):
 def test_bench_batch_codes_certified_against_oracle():
     """bench.py's own model and batch (B = 64, default split-f16 products): the codes of ALL 64 spectrograms against the
     CPU oracle, level by level (bottom teacher-forced on the GPU's top codes) -- every code that differs must be a
-    certified near-tie of the reference's fp32 distance formula (normalised float64 gap < 2e-6) and there may be only a
+    certified near-tie of the reference's fp32 distance formula (normalised float64 gap < 1e-6) and there may be only a
     handful of them, in the exact-fp32 mode as well.  bench.py prints the same
     figures as `codes_moved_vs_oracle` / `certified_near_ties`."""
     import pathlib
@@ -550,13 +550,15 @@ def test_bench_batch_codes_certified_against_oracle():
         m.conv_precision = mode
         with torch.no_grad():
             out = m(xd)
-        chk = O.teacher_forced_code_check(x, sd, cfg, out[4].cpu(), out[5].cpu())
+        chk = O.teacher_forced_code_check(x, sd, cfg, out[4].cpu(), out[5].cpu(), eps=1e-6)
         print(f"[{mode}] {chk}")
         assert chk["samples"] == 64 and chk["of_top"] == 64 * 16 * 64 and chk["of_bottom"] == 64 * 32 * 128
         assert chk["certified_near_ties"], chk
         # (64 x 5120 vectors: a few sit within float rounding of a tie of the reference's own formula -- torch-CPU's and
         # the GPU's fp32 convolutions sum in different orders -- in the exact-fp32 mode too: 3 top codes on this batch)
-        lim = (8, 8) if mode == "f32" else (8, 32)
+        # (allowances at what is observed, VERDICT r04 item 8: split_f16 moves 4 top / 0 bottom codes of this batch, the
+        # largest normalised gap is 6.2e-7)
+        lim = (8, 8)
         assert chk["top_moved"] <= lim[0] and chk["bottom_moved_teacher_forced"] <= lim[1], chk
 
 

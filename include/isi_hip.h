@@ -343,6 +343,22 @@ int isi_conv_wgrad_torch_f32(const isi_src *src0, const isi_src *src1, const flo
                              float *dw_torch, int cin_keep, float *db, float *workspace,
                              size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW,
                              int stride, int pad, int flags, void *stream);
+/* The same call with its split REDUCTION deferred (round 5): the pixel-reduction GEMM is launched, the sum over its splits
+ * (into dw_torch / db) is returned as up to 4 jobs in `jobs_out` instead of being launched behind it.  The caller runs the
+ * jobs of many layers in one launch (isi_reduce_jobs_f32: the job table travels in the kernel arguments, 48 jobs per
+ * launch) before anything reads the gradients -- the end of the step, or a data-parallel bucket's all-reduce -- and keeps
+ * every `workspace` alive until then.  A VQ-VAE training step ran 31 reduction launches of ~9 us (train_vqvae.py:181). */
+typedef struct isi_reduce_job {
+  const float *partial;     /* [nsplit] slices of `stride` floats                                   */
+  float *out;               /* n floats (or the torch-layout weight gradient when map_Kpad != 0)    */
+  int64_t n, stride;
+  int32_t nsplit, accumulate, vec;
+  int32_t map_K, map_Kpad, map_cin, map_taps, map_keep;   /* packed [Cout][Kpad] -> torch [Cout][keep][taps] */
+} isi_reduce_job;
+int isi_conv_wgrad_deferred_f32(const isi_src *src0, const isi_src *src1, const float *dy, float *dw_torch, int cin_keep,
+                                float *db, float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH,
+                                int KW, int stride, int pad, int flags, void *stream, isi_reduce_job *jobs_out, int *n_jobs);
+int isi_reduce_jobs_f32(const isi_reduce_job *jobs, int n_jobs, void *stream);
 /* dy *= (y > 0) : ReLU backward through an output rectified in the producer's epilogue. */
 int isi_relu_bwd_f32(float *dy, const float *y, int64_t n, void *stream);
 /* a += alpha * b */

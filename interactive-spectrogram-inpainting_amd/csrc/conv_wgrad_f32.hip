@@ -16,6 +16,7 @@
 // vqvae/encoder_decoder.py:95-112,138,199-215 and vqvae/vqvae.py:149-150,175-201.
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "isi_common.h"
 #include "isi_internal.h"
@@ -836,21 +837,11 @@ struct WgradOutMap { int K, Kpad, cin, taps, keep; };
 // A second, small reduction rides in the same launch (the bias gradient behind a layer's weight gradient: blocks
 // [nb_main, gridDim.x) -- 81 launches of ~5 us less per training step of the prior).
 struct ReduceJob2 { const float *partial; float *out; int64_t n; int nsplit; int64_t stride; int nb_main; };
+// one 256-thread block's share (64 quads starting at quad 64 bx) of a split reduction
 template <bool VEC>
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
-                                                              float *__restrict__ out, int64_t n, int nsplit,
-                                                              int64_t stride, int accumulate, int64_t zs_partial,
-                                                              int64_t zs_out, WgradOutMap map, const ReduceJob2 j2) {
-  __shared__ float4 red[4][64];
-  int bx = blockIdx.x;
-  if (j2.partial && bx >= j2.nb_main) {          // (uniform per workgroup)
-    bx -= j2.nb_main;
-    partial = j2.partial; out = j2.out; n = j2.n; nsplit = j2.nsplit; stride = j2.stride; accumulate = 0;
-    map.Kpad = 0;
-  } else {
-    partial += (size_t)blockIdx.y * zs_partial;   // grid y: independent reductions
-    out += (size_t)blockIdx.y * zs_out;
-  }
+__device__ __forceinline__ void reduce_block(const float *__restrict__ partial, float *__restrict__ out, const int64_t n,
+                                             const int nsplit, const int64_t stride, const int accumulate,
+                                             const WgradOutMap map, const int bx, float4 (*red)[64]) {
   const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int64_t i = ((int64_t)bx * 64 + e) * 4;
   auto ld = [&](int k) -> float4 {
@@ -893,6 +884,45 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
       if (i + j < n) out[i + j] = accumulate ? out[i + j] + t[j] : t[j];
   }
 }
+template <bool VEC>
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
+                                                              float *__restrict__ out, int64_t n, int nsplit,
+                                                              int64_t stride, int accumulate, int64_t zs_partial,
+                                                              int64_t zs_out, WgradOutMap map, const ReduceJob2 j2) {
+  __shared__ float4 red[4][64];
+  int bx = blockIdx.x;
+  if (j2.partial && bx >= j2.nb_main) {          // (uniform per workgroup)
+    bx -= j2.nb_main;
+    partial = j2.partial; out = j2.out; n = j2.n; nsplit = j2.nsplit; stride = j2.stride; accumulate = 0;
+    map.Kpad = 0;
+  } else {
+    partial += (size_t)blockIdx.y * zs_partial;   // grid y: independent reductions
+    out += (size_t)blockIdx.y * zs_out;
+  }
+  reduce_block<VEC>(partial, out, n, nsplit, stride, accumulate, map, bx, red);
+}
+
+// ---- deferred reductions (round 5).  A VQ-VAE training step ran 31 of these launches -- one behind every weight-gradient
+// GEMM, ~9 us each for a few hundred KB -- although nothing reads a gradient before the step's end (or, data parallel, its
+// bucket's all-reduce).  With a sink installed (isi_conv_wgrad_deferred_f32) the GEMM's launch returns the reduction as a
+// JOB instead of launching it; isi_reduce_jobs_f32 runs up to 48 jobs per launch, the job table travelling by value in the
+// kernel arguments (no device table to upload: the launch records into a HIP graph like any other).
+constexpr int kJobsPerLaunch = 48;
+struct ReduceJobPack { isi_reduce_job j[kJobsPerLaunch]; };
+static_assert(sizeof(ReduceJobPack) <= 3800, "the job table must fit the kernel-argument segment");
+__global__ __launch_bounds__(256) void reduce_jobs_kernel(const ReduceJobPack pack) {
+  __shared__ float4 red[4][64];
+  const isi_reduce_job &j = pack.j[blockIdx.y];
+  const WgradOutMap map{j.map_K, j.map_Kpad, j.map_cin, j.map_taps, j.map_keep};
+  const int nb = (int)((j.n + 255) / 256);
+  for (int bx = blockIdx.x; bx < nb; bx += gridDim.x) {     // (uniform per workgroup)
+    if (j.vec) reduce_block<true>(j.partial, j.out, j.n, j.nsplit, j.stride, j.accumulate, map, bx, red);
+    else reduce_block<false>(j.partial, j.out, j.n, j.nsplit, j.stride, j.accumulate, map, bx, red);
+    __syncthreads();
+  }
+}
+static thread_local std::vector<isi_reduce_job> *g_reduce_sink = nullptr;
+
 // every row start 16-byte aligned and whole quads: the vector form
 static bool reduce_vec_ok(const float *partial, int64_t n, int64_t stride, int64_t zs_partial) {
   return (n % 4 == 0) && (stride % 4 == 0) && (zs_partial % 4 == 0) && (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
@@ -902,6 +932,20 @@ static void launch_reduce_partials(const float *partial, float *out, int64_t n, 
                                    const WgradOutMap map = WgradOutMap{0, 0, 0, 0, 0},
                                    ReduceJob2 j2 = ReduceJob2{nullptr, nullptr, 0, 0, 0, 0}) {
   const bool vec = reduce_vec_ok(partial, n, stride, zs_partial);
+  if (g_reduce_sink && ny == 1) {          // deferred: hand the reduction(s) to the caller's job list
+    isi_reduce_job j;
+    memset(&j, 0, sizeof j);
+    j.partial = partial; j.out = out; j.n = n; j.stride = stride; j.nsplit = nsplit; j.accumulate = accumulate; j.vec = vec ? 1 : 0;
+    j.map_K = map.K; j.map_Kpad = map.Kpad; j.map_cin = map.cin; j.map_taps = map.taps; j.map_keep = map.keep;
+    g_reduce_sink->push_back(j);
+    if (j2.partial) {
+      memset(&j, 0, sizeof j);
+      j.partial = j2.partial; j.out = j2.out; j.n = j2.n; j.stride = j2.stride; j.nsplit = j2.nsplit;
+      j.vec = reduce_vec_ok(j2.partial, j2.n, j2.stride, 0) ? 1 : 0;
+      g_reduce_sink->push_back(j);
+    }
+    return;
+  }
   const unsigned nb = (unsigned)((n + 255) / 256);
   j2.nb_main = (int)nb;
   const dim3 grid(nb + (j2.partial ? (unsigned)((j2.n + 255) / 256) : 0u), ny);
@@ -909,6 +953,40 @@ static void launch_reduce_partials(const float *partial, float *out, int64_t n, 
                               accumulate, zs_partial, zs_out, map, j2);
   else hipLaunchKernelGGL(reduce_partials_kernel<false>, grid, dim3(256), 0, stream, partial, out, n, nsplit, stride,
                           accumulate, zs_partial, zs_out, map, j2);
+}
+
+int reduce_jobs_f32(const isi_reduce_job *jobs, int n_jobs, hipStream_t stream) {
+  if (n_jobs < 0 || (n_jobs && !jobs)) return invalid("reduce_jobs: bad argument");
+  for (int i0 = 0; i0 < n_jobs; i0 += kJobsPerLaunch) {
+    ReduceJobPack pack;
+    memset(&pack, 0, sizeof pack);
+    const int m = std::min(kJobsPerLaunch, n_jobs - i0);
+    int64_t nb_max = 1;
+    for (int i = 0; i < m; ++i) {
+      pack.j[i] = jobs[i0 + i];
+      if (!pack.j[i].partial || !pack.j[i].out || pack.j[i].n <= 0 || pack.j[i].nsplit <= 0) return invalid("reduce_jobs: bad job");
+      nb_max = std::max<int64_t>(nb_max, (pack.j[i].n + 255) / 256);
+    }
+    hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)std::min<int64_t>(nb_max, 64), m), dim3(256), 0, stream, pack);
+    int rc = check_launch("reduce_jobs");
+    if (rc) return rc;
+  }
+  return ISI_OK;
+}
+
+int conv_wgrad_deferred_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw, int cin_keep, float *db,
+                            float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW, int stride,
+                            int pad, int flags, hipStream_t stream, isi_reduce_job *jobs_out, int *n_jobs) {
+  if (!jobs_out || !n_jobs) return invalid("conv_wgrad_deferred: null job list");
+  std::vector<isi_reduce_job> sink;
+  g_reduce_sink = &sink;
+  const int rc = conv_wgrad_f32(s0, s1, dy, dw, db, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride, pad, flags, stream, cin_keep);
+  g_reduce_sink = nullptr;
+  if (rc) return rc;
+  if (sink.size() > 4) return unsupported("conv_wgrad_deferred: more reductions than a job list holds");
+  *n_jobs = (int)sink.size();
+  for (size_t i = 0; i < sink.size(); ++i) jobs_out[i] = sink[i];
+  return ISI_OK;
 }
 
 static bool aligned16(const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }

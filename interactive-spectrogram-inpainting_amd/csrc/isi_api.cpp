@@ -98,6 +98,7 @@ size_t isi_abi_struct_bytes(int which) {
     case 11: return sizeof(isi_attn_bwd_args);
     case 9: return sizeof(isi_prior_w);
     case 10: return sizeof(isi_prior_state);
+    case 12: return sizeof(isi_reduce_job);
     default: return 0;
   }
 }
@@ -353,6 +354,14 @@ int isi_conv_wgrad_torch_f32(const isi_src *src0, const isi_src *src1, const flo
   return conv_wgrad_f32(src0, src1, dy, dw_torch, db, workspace, workspace_floats, B, H, W, Cout, KH, KW, stride, pad,
                         flags, S(stream), cin_keep);
 }
+int isi_conv_wgrad_deferred_f32(const isi_src *src0, const isi_src *src1, const float *dy, float *dw_torch, int cin_keep,
+                                float *db, float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH,
+                                int KW, int stride, int pad, int flags, void *stream, isi_reduce_job *jobs_out, int *n_jobs) {
+  if (cin_keep < 1) return ISI_E_INVALID;
+  return conv_wgrad_deferred_f32(src0, src1, dy, dw_torch, cin_keep, db, workspace, workspace_floats, B, H, W, Cout, KH, KW,
+                                 stride, pad, flags, S(stream), jobs_out, n_jobs);
+}
+int isi_reduce_jobs_f32(const isi_reduce_job *jobs, int n_jobs, void *stream) { return reduce_jobs_f32(jobs, n_jobs, S(stream)); }
 int isi_relu_bwd_f32(float *dy, const float *y, int64_t n, void *stream) { return relu_bwd_f32(dy, y, n, S(stream)); }
 int isi_axpy_f32(float *a, const float *b, float alpha, int64_t n, void *stream) {
   return axpy_f32(a, b, alpha, n, S(stream));

@@ -125,6 +125,13 @@ class isi_prior_state(C.Structure):
                 ("B", C.c_int), ("start_len", C.c_int)]
 
 
+class isi_reduce_job(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("n", C.c_int64), ("stride", C.c_int64),
+                ("nsplit", C.c_int32), ("accumulate", C.c_int32), ("vec", C.c_int32),
+                ("map_K", C.c_int32), ("map_Kpad", C.c_int32), ("map_cin", C.c_int32), ("map_taps", C.c_int32),
+                ("map_keep", C.c_int32)]
+
+
 # name -> (restype, argtypes); must list every symbol include/isi_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -215,6 +222,10 @@ SIGNATURES = {
     "isi_conv_wgrad_torch_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.c_int, _P, _P,
                                            C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_int, _P]),
+    "isi_conv_wgrad_deferred_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, C.c_int, _P, _P,
+                                              C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_int, C.c_int, _P, C.POINTER(isi_reduce_job), C.POINTER(C.c_int)]),
+    "isi_reduce_jobs_f32": (C.c_int, [C.POINTER(isi_reduce_job), C.c_int, _P]),
     "isi_relu_bwd_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "isi_axpy_f32": (C.c_int, [_P, _P, C.c_float, C.c_int64, _P]),
     "isi_vq_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
@@ -264,7 +275,8 @@ def lib() -> C.CDLL:
                     fn.restype = res
                     fn.argtypes = args
                 structs = [isi_src, isi_dst, isi_conv_w, isi_encoder_w, isi_decoder_w, isi_codebook_w,
-                           isi_vqvae_w, isi_vqvae_out, isi_attn_args, isi_prior_w, isi_prior_state, isi_attn_bwd_args]
+                           isi_vqvae_w, isi_vqvae_out, isi_attn_args, isi_prior_w, isi_prior_state, isi_attn_bwd_args,
+                           isi_reduce_job]
                 for i, st in enumerate(structs):
                     if handle.isi_abi_struct_bytes(i) != C.sizeof(st):
                         raise HipLibraryError(f"ABI mismatch for {st.__name__}: library "

@@ -127,9 +127,36 @@ def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
     return out
 
 
+DEFER_REDUCTIONS = os.environ.get("ISI_TRAIN_DEFER_REDUCTIONS", "1") != "0"
+
+
+class ReduceJobs:
+    """Split reductions of the weight-gradient GEMMs that have not been launched yet (isi_conv_wgrad_deferred_f32): the
+    jobs, and the workspaces their partial sums sit in.  `flush()` runs them all in one launch per 48 jobs; it is called
+    before anything reads the gradients -- a data-parallel bucket's all-reduce, the end of the backward."""
+
+    def __init__(self):
+        self.jobs, self.keep, self.stream = [], [], None
+
+    def add(self, jobs, n, workspace):
+        self.jobs.extend(jobs[i] for i in range(n))
+        self.keep.append(workspace)
+        self.stream = _s(workspace)
+
+    def flush(self) -> None:
+        if not self.jobs:
+            return
+        arr = (_hip.isi_reduce_job * len(self.jobs))()
+        for i, j in enumerate(self.jobs):
+            C.memmove(C.byref(arr, i * C.sizeof(_hip.isi_reduce_job)), C.byref(j), C.sizeof(_hip.isi_reduce_job))
+        _hip.check(_hip.lib().isi_reduce_jobs_f32(arr, len(self.jobs), self.stream), "isi_reduce_jobs_f32")
+        self.jobs, self.keep = [], []
+
+
 def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
                x2: Optional[torch.Tensor] = None,
-               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+               defer: Optional[ReduceJobs] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(weight gradient in torch layout, bias gradient).  x (and x2): layer input(s) as
     [B,C,H,W] views; dy_nhwc: dense [B,OH,OW,Cout].  `out` = (weight-shaped, bias-shaped) dense tensors that receive
     the gradients directly (the parameters' slots of the flat gradient buffer: the split reduction writes torch's
@@ -171,10 +198,19 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
     if out is not None and layer.groups == 1 and out[0].is_contiguous() and out[1].is_contiguous():
         dw, db = out
         assert dw.shape == layer.weight.shape and db.shape == layer.bias.shape
-        rc = L.isi_conv_wgrad_torch_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
-                                        dw.data_ptr(), cin_true, None if tr else db.data_ptr(), ws.data_ptr(), nws,
-                                        B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
-        _hip.check(rc, "isi_conv_wgrad_torch_f32")
+        if defer is not None:
+            jobs, n_jobs = (_hip.isi_reduce_job * 4)(), C.c_int(0)
+            rc = L.isi_conv_wgrad_deferred_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
+                                               dw.data_ptr(), cin_true, None if tr else db.data_ptr(), ws.data_ptr(), nws,
+                                               B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x),
+                                               jobs, C.byref(n_jobs))
+            _hip.check(rc, "isi_conv_wgrad_deferred_f32")
+            defer.add(jobs, n_jobs.value, ws)
+        else:
+            rc = L.isi_conv_wgrad_torch_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
+                                            dw.data_ptr(), cin_true, None if tr else db.data_ptr(), ws.data_ptr(), nws,
+                                            B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
+            _hip.check(rc, "isi_conv_wgrad_torch_f32")
         if tr:
             colsum(_rows2d(dy_nhwc), out=db)
         return dw, db
@@ -354,7 +390,8 @@ def _set_wb(grads, layer: _ConvParams, wb) -> None:
 
 def _wgrad_into(grads, layer: _ConvParams, x, dy_nhwc, x2=None) -> None:
     """Weight and bias gradient of `layer`, written by the kernels straight into the flat gradient buffer."""
-    _set_wb(grads, layer, conv_wgrad(layer, x, dy_nhwc, x2=x2, out=(grads.view(layer.weight), grads.view(layer.bias))))
+    _set_wb(grads, layer, conv_wgrad(layer, x, dy_nhwc, x2=x2, out=(grads.view(layer.weight), grads.view(layer.bias)),
+                                     defer=grads.reductions))
 
 
 class Tape:
@@ -401,6 +438,8 @@ class Grads:
             self.bucket_left[b] += 1
         self.handles = []
         self.n_collectives = 0      # bucket all-reduces issued (or, in a recorded step, planned) so far
+        # split reductions of the weight-gradient GEMMs, launched together (None: each behind its GEMM)
+        self.reductions = ReduceJobs() if (DEFER_REDUCTIONS and self.flat.is_cuda) else None
 
     def view(self, p: torch.nn.Parameter) -> torch.Tensor:
         """The parameter's slot of the flat buffer (kernels may write the gradient there themselves; `set` with
@@ -414,6 +453,8 @@ class Grads:
         b = self.bucket_of[i]
         self.bucket_left[b] -= 1
         if self.collectives and self.bucket_left[b] == 0:
+            if self.reductions is not None:
+                self.reductions.flush()       # the bucket's gradients must be complete before they travel
             a, e = self.bucket_span[b]
             bucket, handles = self.flat[a:e], self.handles
             self.n_collectives += 1
@@ -427,6 +468,8 @@ class Grads:
     def finish(self) -> List[torch.Tensor]:
         missing = [i for i, left in enumerate(self.bucket_left) if left > 0]
         assert not missing, "backward did not produce every parameter gradient"
+        if self.reductions is not None:
+            self.reductions.flush()
         if self.collectives:
             handles = self.handles
 

@@ -679,3 +679,24 @@ def test_batched_weight_pack_equals_per_layer_packs():
     _train.refresh_packs(m)
     assert not torch.equal(before, m.enc_b.blocks[0]._packed)
     check_all()
+
+
+def test_deferred_weight_gradient_reductions_are_bit_identical(monkeypatch):
+    """The split reductions behind the weight-gradient GEMMs, collected and run in one launch per 48 jobs at the end of the
+    backward (isi_conv_wgrad_deferred_f32 + isi_reduce_jobs_f32), give the bits of the one-launch-per-layer form: same
+    partial sums, same order of additions."""
+    from interactive_spectrogram_inpainting.vqvae import _train
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    x = torch.randn(3, 2, 64, 128, generator=torch.Generator().manual_seed(3)).to(dev)
+    grads = {}
+    for defer in (True, False):
+        monkeypatch.setattr(_train, "DEFER_REDUCTIONS", defer)
+        torch.manual_seed(5)
+        m = VQVAE(in_channel=2).to(dev).train()
+        out, latent, *_ = m(x)
+        (torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()).backward()
+        grads[defer] = [p.grad.clone() for p in m.parameters()]
+        assert all(torch.isfinite(g_).all() for g_ in grads[defer])
+    for a, b in zip(grads[True], grads[False]):
+        assert torch.equal(a, b)

@@ -64,8 +64,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = c0 + e;
     float s = 0.f;
-    if (c < C)
-      for (int64_t r = r0 + g; r < r1; r += 4) s += x[r * x_stride + c];
+    if (c < C) {
+      int64_t r = r0 + g;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      for (; r + 12 < r1; r += 16) {      // four independent loads in flight (a channel slice's rows are 2 x C floats apart)
+        s += x[r * x_stride + c]; s1 += x[(r + 4) * x_stride + c];
+        s2 += x[(r + 8) * x_stride + c]; s3 += x[(r + 12) * x_stride + c];
+      }
+      for (; r < r1; r += 4) s += x[r * x_stride + c];
+      s = (s + s1) + (s2 + s3);
+    }
     red[g][e] = s;
     __syncthreads();
     if (g == 0 && c < C) partial[(size_t)blockIdx.x * C + c] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);

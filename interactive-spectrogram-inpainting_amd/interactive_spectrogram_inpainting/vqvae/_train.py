@@ -128,6 +128,10 @@ def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
 
 
 DEFER_REDUCTIONS = os.environ.get("ISI_TRAIN_DEFER_REDUCTIONS", "1") != "0"
+# partial sums waiting for their reduction, in MB, beyond which the jobs collected so far are run: deferring ALL of a step's
+# reductions to its end (0.7 GB of partials at B = 64) lost what the fewer launches gained -- by then the partials have left
+# the 256 MB last-level cache they were written through and come back from HBM (measured: 8.04 vs 8.00 ms per step)
+DEFER_LIMIT_MB = float(os.environ.get("ISI_TRAIN_DEFER_LIMIT_MB", "96"))
 
 
 class ReduceJobs:
@@ -136,12 +140,15 @@ class ReduceJobs:
     before anything reads the gradients -- a data-parallel bucket's all-reduce, the end of the backward."""
 
     def __init__(self):
-        self.jobs, self.keep, self.stream = [], [], None
+        self.jobs, self.keep, self.stream, self.bytes = [], [], None, 0
 
     def add(self, jobs, n, workspace):
         self.jobs.extend(jobs[i] for i in range(n))
         self.keep.append(workspace)
         self.stream = _s(workspace)
+        self.bytes += workspace.numel() * 4
+        if self.bytes > DEFER_LIMIT_MB * (1 << 20):
+            self.flush()
 
     def flush(self) -> None:
         if not self.jobs:
@@ -150,7 +157,7 @@ class ReduceJobs:
         for i, j in enumerate(self.jobs):
             C.memmove(C.byref(arr, i * C.sizeof(_hip.isi_reduce_job)), C.byref(j), C.sizeof(_hip.isi_reduce_job))
         _hip.check(_hip.lib().isi_reduce_jobs_f32(arr, len(self.jobs), self.stream), "isi_reduce_jobs_f32")
-        self.jobs, self.keep = [], []
+        self.jobs, self.keep, self.bytes = [], [], 0
 
 
 def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,

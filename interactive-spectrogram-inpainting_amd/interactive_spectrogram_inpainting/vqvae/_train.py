@@ -127,7 +127,7 @@ def colsum(x2d: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
     return out
 
 
-DEFER_REDUCTIONS = os.environ.get("ISI_TRAIN_DEFER_REDUCTIONS", "1") != "0"
+DEFER_REDUCTIONS = os.environ.get("ISI_TRAIN_DEFER_REDUCTIONS", "0") != "0"      # measured: no gain; opt-in
 # partial sums waiting for their reduction, in MB, beyond which the jobs collected so far are run: deferring ALL of a step's
 # reductions to its end (0.7 GB of partials at B = 64) lost what the fewer launches gained -- by then the partials have left
 # the 256 MB last-level cache they were written through and come back from HBM (measured: 8.04 vs 8.00 ms per step)

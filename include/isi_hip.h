@@ -295,6 +295,10 @@ int isi_conv_transpose2d_k4s2_twin_f32(const isi_src *src, const float *packed_w
 int isi_resblock_tape_f32(const float *in, const float *packed_w3, const float *b3, const float *packed_w1, const float *b1,
                           float *out, float *twin, float *hidden, int B, int H, int W, int C, int R, int flags, void *stream);
 int isi_conv2d_pair_route(int C0, int C1, int Cout, int KH, int KW);
+/* 1 if isi_conv_wgrad_torch_f32 (three-term products, dense channels-last operands) would run the halo-staged kernel for
+ * this plain convolution -- the weight-gradient kernel that also reads PAIR-format sources: flags ISI_CONV_IN0_PAIR /
+ * ISI_CONV_IN1_PAIR in the flag word of isi_conv_wgrad_f32 / _torch_f32 / _deferred_f32 (other launches: ISI_E_UNSUPPORTED). */
+int isi_conv_wgrad_halo_route(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, int OH, int OW);
 int isi_conv_transpose2d_pair_route(int Cin, int Cout);
 int isi_resblock_pair_route(int B, int H, int W, int C, int R);
 
@@ -311,6 +315,9 @@ int isi_resblock_pair_route(int B, int H, int W, int C, int R);
  * input-gradient convolution applies that ReLU's backward mask itself (autograd's threshold_backward behind
  * train_vqvae.py:181; encoder_decoder.py:24,31,95-112 `nn.ReLU`) instead of a separate pass over the gradient.
  * fp32 tensors only (no ISI_CONV_*_PAIR), one launch (the implicit-GEMM kernels). */
+#define ISI_CONV_GATE_PAIR 512 /* the gate of a gated convolution is a pair-format tensor (ISI_CONV_OUT_PAIR layout, same shape
+                                * and strides as the output): an element passes where its hi piece is positive -- the training
+                                * forward's pair tensors serve as ReLU masks without an fp32 copy (Cout % 8 == 0) */
 int isi_conv2d_gated_f32(const isi_src *src0, const isi_src *src1, const float *packed_w,
                          const float *bias, const isi_src *residual, const float *gate,
                          const isi_dst *dst, int B, int H, int W, int Cout, int KH, int KW,

@@ -60,6 +60,7 @@ struct ConvKArgs {
   const float *gate;         // optional, laid out exactly like the output: out = gate > 0 ? value : 0 (the ReLU mask of
                              // the layer's input applied in the epilogue of its input-gradient convolution)
   float *twin;               // optional fp32 copy of a pair-format output (training tape): the LDS-DMA kernel only
+  int gate_pair;             // the gate tensor is in the pair format (ISI_CONV_GATE_PAIR): its hi piece decides
 };
 
 constexpr int LDK = 36;  // padded LDS row (floats): 144 B, 16-B aligned, bank-conflict free
@@ -507,7 +508,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         oo[r] = (nok && o >= 0) ? (unsigned)(o + n * p.oc) * 4u : OOB;
         res[r] = 0.f;
         gate[r] = 1.f;
-        if (has_gate) gate[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, oo[r], 0, 0));
+        if (has_gate) {
+          if (p.gate_pair) {   // (uniform) pair8 storage: the hi piece of channel n sits 2 (n & 7) bytes into its group
+            const unsigned po = oo[r] == OOB ? OOB : oo[r] - (unsigned)(n & 7) * 2u;
+            const short hbits = (short)__builtin_amdgcn_raw_buffer_load_b16(rsg, po, 0, 0);
+            gate[r] = hbits > 0 ? 1.f : 0.f;      // a rectified activation: positive <=> its f16 hi piece is a positive number
+          } else {
+            gate[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, oo[r], 0, 0));
+          }
+        }
         if (has_res)
           res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                  rsr, oo[r] == OOB ? OOB : (unsigned)(row_ro[row] + n * p.rc) * 4u, 0, 0));
@@ -720,7 +729,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
     return conv_first_f32(s0, packed_w, bias, dst, B, H, W, Cout, OH, OW, e0, relu, stream, twin);
   }
   // the prior's linear layers: rows of a dense matrix, three-term products -> the GEMM kernel (gemm_split_f32.hip)
-  if (nz == 1 && !two && KH == 1 && KW == 1 && stride == 1 && pad == 0 && B == 1 && H == 1 && s0->sc == 1 &&
+  if (nz == 1 && !(gate && (relu & ISI_CONV_GATE_PAIR)) && !two && KH == 1 && KW == 1 && stride == 1 && pad == 0 && B == 1 && H == 1 && s0->sc == 1 &&
       dst->sc == 1 && (!res || !res->ptr || res->sc == 1) && !(relu & (ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR | ISI_CONV_OUT_PAIR)) &&
       gemm_split_applicable(W, Cout, s0->C, split_mode(relu)) && aligned16(s0->ptr) && aligned16(packed_w) && s0->sw % 4 == 0 &&
       !knobs().no_gemm_kernel) {
@@ -746,7 +755,7 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   if (two) { a.s1n = (int)s1->sn; a.s1h = (int)s1->sh; a.s1w = (int)s1->sw; }
   a.Cin = a.C0 + C1;
   a.src_uniform = (!two || (a.C0 % kBK == 0 && C1 % kBK == 0)) ? 1 : 0;
-  a.w = packed_w; a.bias = bias; a.gate = gate; a.twin = twin;
+  a.w = packed_w; a.bias = bias; a.gate = gate; a.twin = twin; a.gate_pair = (gate && (relu & ISI_CONV_GATE_PAIR)) ? 1 : 0;
   a.res = (res && res->ptr) ? res->ptr : nullptr;
   if (a.res) { a.rn = (int)res->sn; a.rc = (int)res->sc; a.rh = (int)res->sh; a.rw = (int)res->sw; }
   a.out = dst->ptr; a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)dst->sh; a.ow = (int)dst->sw;
@@ -824,7 +833,7 @@ int conv_transpose2d_k4s2_f32(const isi_src *s, const float *packed_w, const flo
   a.in0 = s->ptr; a.in1 = s->ptr; a.C0 = s->C; a.Cin = s->C; a.src_uniform = 1;
   a.in0_bytes = a.in1_bytes = (unsigned)(e0 * 4);
   a.s0n = (int)s->sn; a.s0c = (int)s->sc; a.s0h = (int)s->sh; a.s0w = (int)s->sw;
-  a.w = packed_w; a.bias = bias; a.res = nullptr; a.gate = gate;
+  a.w = packed_w; a.bias = bias; a.res = nullptr; a.gate = gate; a.gate_pair = (gate && (relu & ISI_CONV_GATE_PAIR)) ? 1 : 0;
   a.out = dst->ptr;
   // GEMM-grid pixel (m_y, m_x) of phase (py,px) is output pixel (2 m_y + py, 2 m_x + px)
   a.on = (int)dst->sn; a.oc = (int)dst->sc; a.oh = (int)(2 * dst->sh); a.ow = (int)(2 * dst->sw);

@@ -21,6 +21,7 @@
 #include "isi_common.h"
 #include "isi_internal.h"
 #include "knobs.h"
+#include "split_f16.h"
 
 namespace isi {
 
@@ -43,6 +44,9 @@ struct WgradKArgs {
   // WgradBand (conv_wgrad_split_kernel only): output channel c of dY is non-zero only on the pixels of units
   // [lo_slope c + lo_base, hi_slope c + hi_base], a unit = win_rpu consecutive pixels; win_rpu = 0: everywhere
   int win_rpu, wlo_slope, wlo_base, whi_slope, whi_base;
+  // conv_wgrad_halo_kernel only: bit 0 / 1 = source 0 / 1 holds split-f16 PAIRS (the training forward's pair tensors,
+  // ISI_CONV_IN0_PAIR / IN1_PAIR): the staging decodes (hi + lo) / 4 -- exactly the value the forward's products saw
+  int x_pair;
 };
 
 namespace {
@@ -574,6 +578,20 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad_halo_kernel(const WgradKA
 #pragma unroll
     for (int j = 0; j < NXI; ++j) {
       if (NTH * j + NTH - 1 >= XI && tid + NTH * j >= XI) continue;
+      if (p.x_pair & (xsec[j] ? 2 : 1)) {
+        // pair8 storage: the 16 bytes this thread loaded are the 8 hi pieces (even quad) or the 8 lo pieces (odd quad) of
+        // its 8-channel group; the neighbouring lane (same item index +- 1: NTH is even) loaded the other half.  Each
+        // hands the other the two dwords it needs (DPP quad_perm [1,0,3,2]) and decodes its own four channels.
+        const bool odd = tid & 1;
+        const unsigned a0 = __builtin_bit_cast(unsigned, rx[j].x), a1 = __builtin_bit_cast(unsigned, rx[j].y);
+        const unsigned a2 = __builtin_bit_cast(unsigned, rx[j].z), a3 = __builtin_bit_cast(unsigned, rx[j].w);
+        const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? a0 : a2), 0xB1, 0xF, 0xF, false);
+        const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? a1 : a3), 0xB1, 0xF, 0xF, false);
+        const unsigned h0 = odd ? r0 : a0, h1 = odd ? r1 : a1, l0 = odd ? a2 : r0, l1 = odd ? a3 : r1;
+        constexpr float q4 = 1.f / f16s::kScaleA;
+        rx[j].x = f16s::mix_sum<0>(h0, l0) * q4; rx[j].y = f16s::mix_sum<1>(h0, l0) * q4;
+        rx[j].z = f16s::mix_sum<0>(h1, l1) * q4; rx[j].w = f16s::mix_sum<1>(h1, l1) * q4;
+      }
       uint2 pc[3];
       split4<2>(rx[j].x, rx[j].y, rx[j].z, rx[j].w, pc);
       *reinterpret_cast<uint2 *>(Xs + xdst[j]) = pc[0];
@@ -1132,6 +1150,7 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   if (zs_x0 < 0 || zs_dy < 0 || zs_x0 >= ((int64_t)1 << 31) || zs_dy >= ((int64_t)1 << 31))
     return unsupported("conv_wgrad: batch stride out of range");
   const int prec_flags = transposed & (ISI_CONV_BF16X3 | ISI_CONV_BF16X6);   // product mode rides in the flag word
+  const int x_pair = ((transposed & ISI_CONV_IN0_PAIR) ? 1 : 0) | ((transposed & ISI_CONV_IN1_PAIR) ? 2 : 0);
   transposed &= 1;
   const bool two = s1 && s1->ptr;
   const int Cin = s0->C + (two ? s1->C : 0);
@@ -1219,7 +1238,11 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   const bool halo = use_split && !band_required && !(prec_flags & ISI_CONV_BF16X6) && !transposed && nz == 1 && (k3 || k4) &&
                     Cout % (32 * nco) == 0 && Cin % (32 * (4 / nco)) == 0 && s0->C % 32 == 0 && OW % 32 == 0 &&
                     OH % 2 == 0 && !(k4 && nco == 1) && !knobs().no_wgrad_halo;   // (k4, one channel group: does not fit its registers)
+  if (x_pair && !halo)
+    return unsupported("conv_wgrad: pair-format sources are read by the halo-staged kernel only (3x3 s1 p1 / k4 s2 p1 layers of "
+                       "32-multiple channels, whole 2 x 32 pixel tiles, three-term products): isi_conv_wgrad_halo_route");
   if (halo) {
+    a.x_pair = x_pair;
     const int units = (Cout / (32 * nco)) * (Cin / (32 * (4 / nco))) * (k3 ? 1 : 2);
     const int ntiles = B * (OH / 2) * (OW / 32);
     const int ns = wgrad_halo_nsplit(units, ntiles);
@@ -1254,6 +1277,18 @@ int conv_wgrad_batched_f32(const isi_src *s0, const isi_src *s1, const float *dy
   int rc = check_launch("conv_wgrad_f32");
   if (rc) return rc;
   return wgrad_reduce(a, workspace, dw_packed, db, nphase, nsplit, nz, zs_dw, stream, torch_keep);
+}
+
+// Would a plain convolution's weight gradient (three-term products, dense channels-last operands) run the halo-staged
+// kernel -- the one that also reads pair-format sources?  (The launch conditions above, for callers that plan tensor formats.)
+bool conv_wgrad_halo_route(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, int OH, int OW) {
+  const int Cin = C0 + C1;
+  const bool k3 = KH == 3 && KW == 3 && stride == 1 && pad == 1, k4 = KH == 4 && KW == 4 && stride == 2 && pad == 1;
+  if (Cout % 32 || Cin % 32 || C0 % 32) return false;
+  int nco = Cout % 128 == 0 ? 4 : Cout % 64 == 0 ? 2 : 1;
+  while (nco < 4 && Cin % (32 * (4 / nco))) nco *= 2;
+  return (k3 || k4) && Cout % (32 * nco) == 0 && Cin % (32 * (4 / nco)) == 0 && OW % 32 == 0 && OH % 2 == 0 && !(k4 && nco == 1) &&
+         !knobs().no_wgrad_halo;
 }
 
 // embed_sum[d][k] = sum over vectors n with idx[n] == k of z[n][d]  ==  z^T @ onehot(idx)

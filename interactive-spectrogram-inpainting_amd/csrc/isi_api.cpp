@@ -253,6 +253,9 @@ int isi_conv2d_pair_route(int C0, int C1, int Cout, int KH, int KW) {
   return (conv_pair_kernel_ok(C0, C1, Cout, KH * KW) && KH <= 4 && KW <= 4 && KH * KW * (C0 + C1) >= 256) ? 1 : 0;
 }
 int isi_conv_transpose2d_pair_route(int Cin, int Cout) { return convT_pair_ok(Cin, Cout) ? 1 : 0; }
+int isi_conv_wgrad_halo_route(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, int OH, int OW) {
+  return conv_wgrad_halo_route(Cout, C0, C1, KH, KW, stride, pad, OH, OW) ? 1 : 0;
+}
 
 int isi_spec_polar_f32(const float *stft, float *a, float *ph, int B, int T, int F, int mel, void *stream) {
   return spec_polar_f32(stft, a, ph, B, T, F, mel, S(stream));

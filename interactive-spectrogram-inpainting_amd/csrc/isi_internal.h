@@ -11,6 +11,7 @@ int add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, c
 int vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff, int64_t M,
                     int D, hipStream_t st);
 int pack_multi(const void *table_dev, int n, int blocks_per_entry, hipStream_t stream);
+bool conv_wgrad_halo_route(int Cout, int C0, int C1, int KH, int KW, int stride, int pad, int OH, int OW);
 int reduce_jobs_f32(const isi_reduce_job *jobs, int n_jobs, hipStream_t stream);
 int conv_wgrad_deferred_f32(const isi_src *s0, const isi_src *s1, const float *dy, float *dw, int cin_keep, float *db,
                             float *workspace, size_t workspace_floats, int B, int H, int W, int Cout, int KH, int KW, int stride,

@@ -182,6 +182,7 @@ SIGNATURES = {
     "isi_resblock_tape_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, _P]),
     "isi_conv2d_pair_route": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "isi_conv_wgrad_halo_route": (C.c_int, [C.c_int] * 9),
     "isi_conv_transpose2d_pair_route": (C.c_int, [C.c_int, C.c_int]),
     "isi_resblock_pair_route": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "isi_spec_polar_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -62,6 +62,37 @@ FORCE_COLLECTIVES = os.environ.get("ISI_FORCE_COLLECTIVES", "0") == "1"
 WGRAD_FLAGS = {"f32": 0, "bf16x3": 2, "bf16x6": 4}[os.environ.get("ISI_WGRAD_PRECISION", "bf16x3")]
 
 
+class PairOnly:
+    """A tape entry the training forward kept in the split-f16 pair format ONLY (no fp32 twin was written): every
+    backward consumer of such a tensor reads pairs -- the halo-staged weight-gradient kernel as its source operand
+    (ISI_CONV_IN*_PAIR), the input-gradient convolutions as their ReLU mask (ISI_CONV_GATE_PAIR).  `pair`: [B,C,H,W] view of
+    dense channels-last pair storage."""
+    __slots__ = ("pair",)
+
+    def __init__(self, pair: torch.Tensor):
+        self.pair = pair
+
+    @property
+    def shape(self):
+        return self.pair.shape
+
+    @property
+    def device(self):
+        return self.pair.device
+
+
+GATE_PAIR = 512       # ISI_CONV_GATE_PAIR
+
+
+def _gate_of(t):
+    """(dense NHWC gate tensor, extra flag) of a tape entry used as the ReLU mask of an input-gradient convolution."""
+    if t is None:
+        return None, 0
+    if isinstance(t, PairOnly):
+        return t.pair.permute(0, 2, 3, 1), GATE_PAIR
+    return _nhwc(t), 0
+
+
 def _nhwc(t: torch.Tensor) -> torch.Tensor:
     """[B,C,H,W]-shaped view -> dense channels-last storage (copy only if needed)."""
     p = t.permute(0, 2, 3, 1)
@@ -177,6 +208,15 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
     L = _hip.lib()
     tr = layer.transposed
     k = layer.kernel_size
+    pair_flags = 0
+    if isinstance(x, PairOnly) or isinstance(x2, PairOnly):
+        if tr or out is None or layer.groups != 1:
+            raise ValueError("pair-format sources go to the halo-staged weight-gradient kernel (plain ungrouped convolutions, "
+                             "gradients written in place)")
+        if isinstance(x, PairOnly):
+            x, pair_flags = x.pair, pair_flags | _ops.PAIR_IN0
+        if isinstance(x2, PairOnly):
+            x2, pair_flags = x2.pair, pair_flags | _ops.PAIR_IN1
     if tr:
         # roles swapped: dy is the SOURCE operand here (any strides: a channel slice of a wider gradient is read in place)
         src, grad = _as_bchw(dy_nhwc), _nhwc(x)
@@ -209,14 +249,14 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
             jobs, n_jobs = (_hip.isi_reduce_job * 4)(), C.c_int(0)
             rc = L.isi_conv_wgrad_deferred_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
                                                dw.data_ptr(), cin_true, None if tr else db.data_ptr(), ws.data_ptr(), nws,
-                                               B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x),
+                                               B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS | pair_flags, _s(x),
                                                jobs, C.byref(n_jobs))
             _hip.check(rc, "isi_conv_wgrad_deferred_f32")
             defer.add(jobs, n_jobs.value, ws)
         else:
             rc = L.isi_conv_wgrad_torch_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, grad.data_ptr(),
                                             dw.data_ptr(), cin_true, None if tr else db.data_ptr(), ws.data_ptr(), nws,
-                                            B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS, _s(x))
+                                            B, H, W, rows, k, k, layer.stride, layer.padding, WGRAD_FLAGS | pair_flags, _s(x))
             _hip.check(rc, "isi_conv_wgrad_torch_f32")
         if tr:
             colsum(_rows2d(dy_nhwc), out=db)
@@ -372,22 +412,31 @@ def refresh_packs(model) -> None:
 
 
 def conv_dgrad(dw: _DgradWeights, layer: _ConvParams, dy: torch.Tensor,
-               residual: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, gate=None) -> torch.Tensor:
     """Gradient w.r.t. the layer input ([B,Cin,H,W] view of channels-last storage);
     dy: [B,Cout,OH,OW] view (any strides).  `gate` (dense NHWC, the rectified activation the layer consumed): the
     backward of that ReLU -- zero where the activation is zero -- applied in the convolution's epilogue (after the
     residual is added) instead of a separate pass over the gradient."""
     packed = dw.get(layer)
     cin = layer.in_channels
+    gflag = 0
+    if isinstance(gate, PairOnly):      # a tape entry kept as pairs: its hi pieces are the mask
+        gate, gflag = _gate_of(gate)
     if gate is not None and not gate.is_contiguous():
         raise ValueError("gate must be dense channels-last")
     if layer.transposed:
-        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False, bf16x3=DGRAD_PRECISION, gate_nhwc=gate)
+        return _ops.conv2d(dy, packed, None, cin, 4, 2, 1, relu=False, bf16x3=DGRAD_PRECISION, gate_nhwc=gate, extra_flags=gflag)
     if layer.stride == 2:
-        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False, bf16x3=DGRAD_PRECISION, gate_nhwc=gate)
+        return _ops.conv_transpose2d_k4s2(dy, packed, None, cin, relu=False, bf16x3=DGRAD_PRECISION, gate_nhwc=gate,
+                                          extra_flags=gflag)
     k = layer.kernel_size
     return _ops.conv2d(dy, packed, None, cin, k, 1, k - 1 - layer.padding, relu=False, residual_bchw=residual,
-                       bf16x3=DGRAD_PRECISION, gate_nhwc=gate)
+                       bf16x3=DGRAD_PRECISION, gate_nhwc=gate, extra_flags=gflag)
+
+
+def _g(entry):
+    """Gate argument of conv_dgrad from a tape entry: pair-only entries travel as they are, fp32 views as dense NHWC."""
+    return entry if isinstance(entry, PairOnly) else _nhwc(entry)
 
 
 def _set_wb(grads, layer: _ConvParams, wb) -> None:
@@ -500,19 +549,30 @@ PAIR_FORWARD = os.environ.get("ISI_TRAIN_PAIR_FORWARD", "1") != "0"
 _PAIR_FLAGS = 8 | 16      # ISI_CONV_F16X3 | ISI_CONV_W16
 
 
+DROP_TWINS = os.environ.get("ISI_TRAIN_DROP_TWINS", "1") != "0"
+
+
 class _Act:
-    """An activation of the training forward: `f32` = [B,C,H,W] view of dense channels-last fp32 storage (always there:
-    the tape), `pair` = the same tensor in the pair format (same shape / strides) where a pair-route consumer follows."""
+    """An activation of the training forward: `f32` = [B,C,H,W] view of dense channels-last fp32 storage (the tape's
+    usual form), `pair` = the same tensor in the pair format (same shape / strides) where a pair-route consumer follows.
+    At least one of the two exists; `f32` is None where every consumer -- forward and backward -- reads pairs."""
     __slots__ = ("f32", "pair")
 
     def __init__(self, f32, pair=None):
         self.f32, self.pair = f32, pair
+
+    @property
+    def any(self):
+        return self.f32 if self.f32 is not None else self.pair
 
     def want_pair(self):
         """The pair-format twin, encoded on the spot when the producer did not write one (quantiser outputs)."""
         if self.pair is None:
             self.pair = _ops.pair_encode(self.f32)
         return self.pair
+
+    def tape(self):
+        return self.f32 if self.f32 is not None else PairOnly(self.pair)
 
 
 def _pair_mode() -> bool:
@@ -523,15 +583,40 @@ def _dense_cl(t: torch.Tensor) -> bool:
     return t.permute(0, 2, 3, 1).is_contiguous()
 
 
-def _conv_fwd(layer: _ConvParams, x: _Act, relu, x2: Optional[_Act] = None, out_nchw=False, keep_pair=True) -> _Act:
+def _pairs_suffice(nxt, shape, c1: int = 0) -> bool:
+    """Can the tensor of `shape` [B,C,H,W] that feeds `nxt` (a convolution layer, or a residual block) be kept as pairs
+    ONLY?  Yes when (a) the layer's forward takes the LDS-DMA pair route, (b) its weight gradient runs the halo-staged
+    kernel, which reads pair sources, and (c) the ReLU mask the tensor provides is applied by an implicit-GEMM input-gradient
+    convolution (always the case for these layers).  `c1`: channels of a second, concatenated source."""
+    if not (DROP_TWINS and _pair_mode() and WGRAD_FLAGS == 2 and DGRAD_PRECISION == 1):
+        return False
+    L = _hip.lib()
+    B, Cc, H, W = shape
+    if isinstance(nxt, RosinalityResBlock):
+        c3, c1l = nxt.conv[1], nxt.conv[3]
+        return bool(c3.groups == 1 and c1l.groups == 1 and _ops.resblock_fusable(Cc, c3.out_channels)
+                    and L.isi_resblock_pair_route(B, H, W, Cc, c3.out_channels)
+                    and L.isi_conv_wgrad_halo_route(c3.out_channels, Cc, 0, 3, 3, 1, 1, H, W))
+    if nxt is None or nxt.transposed or nxt.groups != 1:
+        return False
+    k, st, pd = nxt.kernel_size, nxt.stride, nxt.padding
+    OH, OW = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+    return bool(L.isi_conv2d_pair_route(Cc, c1, nxt.out_channels, k, k)
+                and L.isi_conv_wgrad_halo_route(nxt.out_channels, Cc, c1, k, k, st, pd, OH, OW))
+
+
+def _conv_fwd(layer: _ConvParams, x: _Act, relu, x2: Optional[_Act] = None, out_nchw=False, keep_pair=True,
+              need_f32=True) -> _Act:
     """One convolution / transposed convolution of the training forward.  `keep_pair` False: the output's consumers read
-    fp32 (the 2-channel last layer, the 1x1 quantiser convolutions), so only fp32 is written."""
+    fp32 (the 2-channel last layer, the 1x1 quantiser convolutions), so only fp32 is written.  `need_f32` False
+    (`_pairs_suffice` for the consumer): no fp32 twin next to a pair-format output."""
     L = _hip.lib()
     k, cin, cout = layer.kernel_size, layer.in_channels, layer.out_channels
+    xa = x.any
     first = (not layer.transposed and x2 is None and cin == 2 and (k, layer.stride, layer.padding) == (4, 2, 1)
-             and cout in (32, 64) and x.f32.is_contiguous())          # the NCHW spectrogram: conv_first_f32.hip
-    pair_ok = (_pair_mode() and layer.groups == 1 and not out_nchw and (first or _dense_cl(x.f32))
-               and (x2 is None or _dense_cl(x2.f32)))
+             and cout in (32, 64) and x.f32 is not None and x.f32.is_contiguous())   # the NCHW spectrogram: conv_first_f32.hip
+    pair_ok = (_pair_mode() and layer.groups == 1 and not out_nchw and (first or _dense_cl(xa))
+               and (x2 is None or _dense_cl(x2.any)))
     if pair_ok and layer.transposed and x2 is None and (k, layer.stride, layer.padding) == (4, 2, 1) \
             and L.isi_conv_transpose2d_pair_route(cin, cout) and cin % 8 == 0:
         xp = x.want_pair()
@@ -540,6 +625,9 @@ def _conv_fwd(layer: _ConvParams, x: _Act, relu, x2: Optional[_Act] = None, out_
         if not keep_pair:       # pair in, fp32 out: the plain entry point
             return _Act(_ops.conv_transpose2d_k4s2(xp, layer.packed(), layer.bias, cout, relu, bf16x3=4,
                                                    extra_flags=_ops.PAIR_IN0))
+        if not need_f32:        # pair in, pair out
+            return _Act(None, _ops.conv_transpose2d_k4s2(xp, layer.packed(), layer.bias, cout, relu, bf16x3=4,
+                                                         extra_flags=_ops.PAIR_IN0 | _ops.PAIR_OUT))
         out = torch.empty(B, 2 * H, 2 * W, cout, dtype=torch.float32, device=xp.device)
         twin = torch.empty_like(out)
         dst = _hip.dst_nchw_view(out.permute(0, 3, 1, 2))
@@ -548,11 +636,15 @@ def _conv_fwd(layer: _ConvParams, x: _Act, relu, x2: Optional[_Act] = None, out_
                                                   int(relu) | _PAIR_FLAGS | _ops.PAIR_IN0 | _ops.PAIR_OUT, _s(xp))
         _hip.check(rc, "isi_conv_transpose2d_k4s2_twin_f32")
         return _Act(twin.permute(0, 3, 1, 2), out.permute(0, 3, 1, 2))
-    c0 = x.f32.shape[1]
-    c1 = x2.f32.shape[1] if x2 is not None else 0
+    c0 = xa.shape[1]
+    c1 = x2.any.shape[1] if x2 is not None else 0
     if pair_ok and not layer.transposed and keep_pair and (first or L.isi_conv2d_pair_route(c0, c1, cout, k, k)):
         src = x.f32 if first else x.want_pair()
         src2 = x2.want_pair() if x2 is not None else None
+        flags = _ops.PAIR_OUT | (0 if first else _ops.PAIR_IN0) | (_ops.PAIR_IN1 if src2 is not None else 0)
+        if not need_f32:
+            return _Act(None, _ops.conv2d(src, layer.packed(), layer.bias, cout, k, layer.stride, layer.padding, relu,
+                                          x2_bchw=src2, bf16x3=4, extra_flags=flags))
         B, _, H, W = src.shape
         OH = (H + 2 * layer.padding - k) // layer.stride + 1
         OW = (W + 2 * layer.padding - k) // layer.stride + 1
@@ -561,10 +653,9 @@ def _conv_fwd(layer: _ConvParams, x: _Act, relu, x2: Optional[_Act] = None, out_
         s0 = _hip.src_nchw_view(src)
         s1 = _hip.src_nchw_view(src2) if src2 is not None else None
         dst = _hip.dst_nchw_view(out.permute(0, 3, 1, 2))
-        flags = int(relu) | _PAIR_FLAGS | _ops.PAIR_OUT | (0 if first else _ops.PAIR_IN0) | (_ops.PAIR_IN1 if src2 is not None else 0)
         rc = L.isi_conv2d_twin_f32(C.byref(s0), C.byref(s1) if s1 is not None else None, layer.packed().data_ptr(),
                                    layer.bias.data_ptr(), C.byref(dst), twin.data_ptr(), B, H, W, cout, k, k,
-                                   layer.stride, layer.padding, flags, _s(src))
+                                   layer.stride, layer.padding, int(relu) | _PAIR_FLAGS | flags, _s(src))
         _hip.check(rc, "isi_conv2d_twin_f32")
         return _Act(twin.permute(0, 3, 1, 2), out.permute(0, 3, 1, 2))
     if pair_ok and not layer.transposed and not keep_pair and L.isi_conv2d_pair_route(c0, c1, cout, k, k):
@@ -572,28 +663,33 @@ def _conv_fwd(layer: _ConvParams, x: _Act, relu, x2: Optional[_Act] = None, out_
         extra = _ops.PAIR_IN0 | (_ops.PAIR_IN1 if x2 is not None else 0)
         return _Act(_ops.conv2d(x.want_pair(), layer.packed(), layer.bias, cout, k, layer.stride, layer.padding, relu,
                                 x2_bchw=x2.want_pair() if x2 is not None else None, bf16x3=4, extra_flags=extra))
+    if x.f32 is None or (x2 is not None and x2.f32 is None):
+        raise RuntimeError("training forward: a tensor was kept as pairs only, but its consumer reads fp32")
     return _Act(layer.run(x.f32, relu=relu, x2=x2.f32 if x2 is not None else None, out_nchw=out_nchw, bf16x3=FWD_PRECISION))
 
 
-def _res_block_fwd(blk: RosinalityResBlock, x: _Act, tape: "Tape", key: str) -> _Act:
+def _res_block_fwd(blk: RosinalityResBlock, x: _Act, tape: "Tape", key: str, need_f32: bool = True) -> _Act:
     """relu(r + conv1x1(relu(conv3x3(r)))) on a rectified r; tape[key.h] = the hidden activation, tape[key.y] = the output."""
     c3, c1 = blk.conv[1], blk.conv[3]
     L = _hip.lib()
-    B, Cc, H, W = x.f32.shape
+    B, Cc, H, W = x.any.shape
     R = c3.out_channels
-    if (_pair_mode() and c3.groups == 1 and c1.groups == 1 and _dense_cl(x.f32) and _ops.resblock_fusable(Cc, R)
+    if (_pair_mode() and c3.groups == 1 and c1.groups == 1 and _dense_cl(x.any) and _ops.resblock_fusable(Cc, R)
             and L.isi_resblock_pair_route(B, H, W, Cc, R)):
         xp = x.want_pair().permute(0, 2, 3, 1)
         out = torch.empty(B, H, W, Cc, dtype=torch.float32, device=xp.device)
-        twin = torch.empty_like(out)
+        twin = torch.empty_like(out) if need_f32 else None
         hid = torch.empty(B, H, W, R, dtype=torch.float32, device=xp.device)
         rc = L.isi_resblock_tape_f32(xp.data_ptr(), c3.packed().data_ptr(), c3.bias.data_ptr(), c1.packed().data_ptr(),
-                                     c1.bias.data_ptr(), out.data_ptr(), twin.data_ptr(), hid.data_ptr(), B, H, W, Cc, R,
+                                     c1.bias.data_ptr(), out.data_ptr(), twin.data_ptr() if twin is not None else None,
+                                     hid.data_ptr(), B, H, W, Cc, R,
                                      1 | _PAIR_FLAGS | _ops.PAIR_IN0 | _ops.PAIR_OUT, _s(xp))
         _hip.check(rc, "isi_resblock_tape_f32")
-        y = _Act(twin.permute(0, 3, 1, 2), out.permute(0, 3, 1, 2))
-        tape[f"{key}.h"], tape[f"{key}.y"] = hid.permute(0, 3, 1, 2), y.f32
+        y = _Act(twin.permute(0, 3, 1, 2) if twin is not None else None, out.permute(0, 3, 1, 2))
+        tape[f"{key}.h"], tape[f"{key}.y"] = hid.permute(0, 3, 1, 2), y.tape()
         return y
+    if x.f32 is None:
+        raise RuntimeError("training forward: a tensor was kept as pairs only, but its consumer reads fp32")
     h = c3.run(x.f32, relu=True, bf16x3=FWD_PRECISION)
     yv = c1.run(h, relu=True, residual=x.f32, bf16x3=FWD_PRECISION)
     tape[f"{key}.h"], tape[f"{key}.y"] = h, yv
@@ -604,17 +700,29 @@ def _as_act(x) -> _Act:
     return x if isinstance(x, _Act) else _Act(x)
 
 
+def _res_stack_fwd(blocks, idxs, x: _Act, tape: "Tape", tag: str) -> _Act:
+    """The residual stack; a block's output is kept as pairs only where the NEXT block reads nothing else (the stack's
+    own output always keeps its fp32 form: other modules and the stack's top-level ReLU mask read it)."""
+    for j, i in enumerate(idxs):
+        nxt = blocks[idxs[j + 1]] if j + 1 < len(idxs) else None
+        need = not (nxt is not None and _pairs_suffice(nxt, x.any.shape))
+        x = _res_block_fwd(blocks[i], x, tape, f"{tag}.res{j}", need_f32=need)
+    return x
+
+
 def encoder_forward(m: RosinalityEncoder, x, tape: Tape, tag: str) -> _Act:
     x = _as_act(x)
-    tape[f"{tag}.in"] = x.f32
-    for j, i in enumerate(m._down):
-        x = _conv_fwd(m.blocks[i], x, True)
-        tape[f"{tag}.down{j}"] = x.f32
-    x = _conv_fwd(m.blocks[m._conv3], x, True)
-    tape[f"{tag}.c3"] = x.f32
-    for j, i in enumerate(m._res):
-        x = _res_block_fwd(m.blocks[i], x, tape, f"{tag}.res{j}")
-    return x
+    tape[f"{tag}.in"] = x.tape()
+    seq = [m.blocks[i] for i in m._down] + [m.blocks[m._conv3]]
+    for j, layer in enumerate(seq):
+        last = j == len(seq) - 1
+        nxt = (m.blocks[m._res[0]] if m._res else None) if last else seq[j + 1]
+        B, _, H, W = x.any.shape
+        k, st, pd = layer.kernel_size, layer.stride, layer.padding
+        oshape = (B, layer.out_channels, (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1)
+        x = _conv_fwd(layer, x, True, need_f32=not _pairs_suffice(nxt, oshape))
+        tape[f"{tag}.c3" if last else f"{tag}.down{j}"] = x.tape()
+    return _res_stack_fwd(m.blocks, m._res, x, tape, tag)
 
 
 def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_last: bool, last_pair: bool = False) -> _Act:
@@ -622,18 +730,20 @@ def decoder_forward(m: RosinalityDecoder, x, x2, tape: Tape, tag: str, out_nchw_
     is the 1x1 quantiser convolution)."""
     x = _as_act(x)
     x2 = _as_act(x2) if x2 is not None else None
-    tape[f"{tag}.in"], tape[f"{tag}.in2"] = x.f32, (x2.f32 if x2 is not None else None)
-    x = _conv_fwd(m.blocks[0], x, True, x2=x2)
-    tape[f"{tag}.c3"] = x.f32
-    for j, i in enumerate(m._res):
-        x = _res_block_fwd(m.blocks[i], x, tape, f"{tag}.res{j}")
+    tape[f"{tag}.in"], tape[f"{tag}.in2"] = x.tape(), (x2.tape() if x2 is not None else None)
+    c3 = m.blocks[0]
+    B, _, H, W = x.any.shape
+    nxt = m.blocks[m._res[0]] if m._res else None
+    x = _conv_fwd(c3, x, True, x2=x2, need_f32=not _pairs_suffice(nxt, (B, c3.out_channels, H, W)))
+    tape[f"{tag}.c3"] = x.tape()
+    x = _res_stack_fwd(m.blocks, m._res, x, tape, tag)
     for j, i in enumerate(m._up):
         last = j == len(m._up) - 1
         nxt = m.blocks[m._up[j + 1]] if not last else None
         # the few-channel last layer (Cout <= 4) and whatever follows the decoder read fp32
         keep = last_pair if last else nxt.out_channels > 4
         x = _conv_fwd(m.blocks[i], x, not last, out_nchw=(last and out_nchw_last), keep_pair=keep)
-        tape[f"{tag}.up{j}"] = x.f32
+        tape[f"{tag}.up{j}"] = x.tape()
     return x
 
 
@@ -646,13 +756,13 @@ def _res_stack_backward(blocks, idxs, tape, tag, d_y, x_in_key, dw, grads: Grads
         blk = blocks[idxs[j]]
         y, h = tape[f"{tag}.res{j}.y"], tape[f"{tag}.res{j}.h"]
         r = tape[f"{tag}.res{j - 1}.y"] if j > 0 else tape[x_in_key]
-        g = d_y if gated else relu_bwd_(d_y, _nhwc(y))                 # through relu(r + conv1(h))
+        g = d_y if gated else relu_bwd_(d_y, _nhwc(y))                 # through relu(r + conv1(h)) (a stack's output keeps fp32)
         c1, c3 = blk.conv[3], blk.conv[1]
         _wgrad_into(grads, c1, h, g)
-        dh = _nhwc(conv_dgrad(dw, c1, _as_bchw(g), gate=_nhwc(h)))     # through relu(conv3(r))
+        dh = _nhwc(conv_dgrad(dw, c1, _as_bchw(g), gate=_g(h)))        # through relu(conv3(r))
         _wgrad_into(grads, c3, r, dh)
         # + skip connection, then through the ReLU that produced r
-        d_y = _nhwc(conv_dgrad(dw, c3, _as_bchw(dh), residual=_as_bchw(g), gate=_nhwc(r)))
+        d_y = _nhwc(conv_dgrad(dw, c3, _as_bchw(dh), residual=_as_bchw(g), gate=_g(r)))
         gated = True
     return d_y if gated else relu_bwd_(d_y, _nhwc(tape[x_in_key]))
 
@@ -664,13 +774,13 @@ def encoder_backward(m: RosinalityEncoder, tape: Tape, tag: str, d_out, dw, grad
     c3 = m.blocks[m._conv3]
     prev = tape[f"{tag}.down{len(m._down) - 1}"]
     _wgrad_into(grads, c3, prev, g)
-    g = _nhwc(conv_dgrad(dw, c3, _as_bchw(g), gate=_nhwc(prev)))
+    g = _nhwc(conv_dgrad(dw, c3, _as_bchw(g), gate=_g(prev)))
     for j in reversed(range(len(m._down))):
         layer = m.blocks[m._down[j]]
         prev = tape[f"{tag}.down{j - 1}"] if j > 0 else tape[f"{tag}.in"]
         _wgrad_into(grads, layer, prev, g)
         if j > 0:
-            g = _nhwc(conv_dgrad(dw, layer, _as_bchw(g), gate=_nhwc(prev)))
+            g = _nhwc(conv_dgrad(dw, layer, _as_bchw(g), gate=_g(prev)))
         elif need_input_grad:
             g = _nhwc(conv_dgrad(dw, layer, _as_bchw(g)))              # the encoder input is not a ReLU output
     return g if need_input_grad else None
@@ -688,7 +798,7 @@ def decoder_backward(m: RosinalityDecoder, tape: Tape, tag: str, d_out_bchw, dw,
         g = _rows(d_view) if layer.transposed else _nhwc(d_view)
         prev = tape[f"{tag}.up{j - 1}"] if j > 0 else tape[f"{tag}.res{len(m._res) - 1}.y" if m._res else f"{tag}.c3"]
         _wgrad_into(grads, layer, prev, g)
-        d_view = conv_dgrad(dw, layer, _as_bchw(g), gate=_nhwc(prev))
+        d_view = conv_dgrad(dw, layer, _as_bchw(g), gate=_g(prev))
     g = _res_stack_backward(m.blocks, m._res, tape, tag, _nhwc(d_view), f"{tag}.c3", dw, grads, gated=True)
     c3 = m.blocks[0]
     _wgrad_into(grads, c3, tape[f"{tag}.in"], g, x2=tape[f"{tag}.in2"])
@@ -915,9 +1025,15 @@ class VQVAETrainFunction(torch.autograd.Function):
         q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b, pending)
         tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
         up = _Act(_as_bchw(q_t))
+        n_up = len(model.upsample_top_to_bottom)
         for j, layer in enumerate(model.upsample_top_to_bottom):
-            tape[f"up.in{j}"] = up.f32
-            up = _conv_fwd(layer, up, False)
+            tape[f"up.in{j}"] = up.tape()
+            # (intermediate outputs feed another transposed layer -- fp32 for its weight gradient --; the last one feeds the
+            # bottom decoder's two-source 3x3, which reads pairs throughout)
+            B_, _, H_, W_ = up.any.shape
+            oshape = (B_, layer.out_channels, 2 * H_, 2 * W_)
+            need = not (j == n_up - 1 and _pairs_suffice(model.dec.blocks[0], oshape, c1=model.embed_dim))
+            up = _conv_fwd(layer, up, False, need_f32=need)
         dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True).f32
         diff = (diff_t + diff_b).reshape(1)
         pending.flush()       # the statistics' all-reduces have had the rest of the forward to arrive; codebooks written here

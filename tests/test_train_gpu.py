@@ -700,3 +700,34 @@ def test_deferred_weight_gradient_reductions_are_bit_identical(monkeypatch):
         assert all(torch.isfinite(g_).all() for g_ in grads[defer])
     for a, b in zip(grads[True], grads[False]):
         assert torch.equal(a, b)
+
+
+def test_pair_only_tape_entries_give_the_same_gradients(monkeypatch):
+    """Round 5: where every consumer of an activation reads pairs -- the next layer's LDS-DMA forward, the halo-staged
+    weight-gradient kernel (ISI_CONV_IN*_PAIR), the ReLU mask of the input-gradient convolution (ISI_CONV_GATE_PAIR) -- the
+    training forward writes no fp32 twin.  Same gradients as with every twin kept (a pair holds 22 significand bits: the
+    operands differ by at most 2^-22 of their value), and the tape really holds pair-only entries."""
+    from interactive_spectrogram_inpainting.vqvae import _train
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    x = torch.randn(3, 2, 64, 128, generator=torch.Generator().manual_seed(3)).to(dev)
+    grads, n_pair_only = {}, {}
+    for drop in (True, False):
+        monkeypatch.setattr(_train, "DROP_TWINS", drop)
+        seen = []
+        orig = _train.Tape.__setitem__
+
+        def spy(self, k, v, _seen=seen, _orig=orig):
+            _seen.append(isinstance(v, _train.PairOnly))
+            _orig(self, k, v)
+        monkeypatch.setattr(_train.Tape, "__setitem__", spy)
+        torch.manual_seed(5)
+        m = VQVAE(in_channel=2).to(dev).train()
+        out, latent, *_ = m(x)
+        (torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()).backward()
+        monkeypatch.setattr(_train.Tape, "__setitem__", orig)
+        grads[drop] = {n: p.grad.clone() for n, p in m.named_parameters()}
+        n_pair_only[drop] = sum(seen)
+    assert n_pair_only[False] == 0 and n_pair_only[True] >= 8, n_pair_only
+    for n in grads[True]:
+        assert _rel(grads[True][n], grads[False][n]) < 2e-5, n

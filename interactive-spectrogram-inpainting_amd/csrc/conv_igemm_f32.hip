@@ -509,13 +509,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         res[r] = 0.f;
         gate[r] = 1.f;
         if (has_gate) {
-          if (p.gate_pair) {   // (uniform) pair8 storage: the hi piece of channel n sits 2 (n & 7) bytes into its group
-            const unsigned po = oo[r] == OOB ? OOB : oo[r] - (unsigned)(n & 7) * 2u;
-            const short hbits = (short)__builtin_amdgcn_raw_buffer_load_b16(rsg, po, 0, 0);
-            gate[r] = hbits > 0 ? 1.f : 0.f;      // a rectified activation: positive <=> its f16 hi piece is a positive number
-          } else {
-            gate[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, oo[r], 0, 0));
-          }
+          // ONE load form for both gate formats (a branch per element broke the batch of 16 loads in flight: the gated
+          // kernels ran 45 % slower).  Pair8 storage: the hi piece of channel n sits 2 (n & 7) bytes into its 32-byte group;
+          // the dword that holds it is fetched and the half selected below.
+          const unsigned po = (oo[r] == OOB || !p.gate_pair) ? oo[r] : ((oo[r] - (unsigned)(n & 7) * 2u) & ~3u);
+          gate[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsg, po, 0, 0));
         }
         if (has_res)
           res[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -528,7 +526,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs p) 
         // v - v is 0 for finite v and NaN otherwise.  (The select form `v < 0 ? 0 : v` makes this compiler allocate
         // 244 VGPRs for the split-f16 variant, 1 wave per SIMD.)
         if (p.relu) v = fmaxf(v, 0.f) + (v - v);
-        if (has_gate) v = gate[r] > 0.f ? v : 0.f;
+        if (has_gate) {
+          // fp32 gate: positive value; pair gate: a rectified activation is positive <=> its f16 hi piece is a positive number
+          const unsigned gw = __builtin_bit_cast(unsigned, gate[r]);
+          const bool pass = p.gate_pair ? (short)((n & 1) ? (gw >> 16) : (gw & 0xffffu)) > 0 : gate[r] > 0.f;
+          v = pass ? v : 0.f;
+        }
         if constexpr (PREC == 4 && OUTP) {
           // pair-format output (split_f16.h: {hi[8] | lo[8]} per group of 8 channels).  A lane of this layout owns
           // ONE channel of 16 pixels, so its two pieces go out as 2-byte stores (conv_pair_f16.hip transposes

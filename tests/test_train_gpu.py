@@ -710,7 +710,7 @@ def test_pair_only_tape_entries_give_the_same_gradients(monkeypatch):
     from interactive_spectrogram_inpainting.vqvae import _train
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     dev = _dev()
-    x = torch.randn(3, 2, 64, 128, generator=torch.Generator().manual_seed(3)).to(dev)
+    x = torch.randn(2, 2, 128, 256, generator=torch.Generator().manual_seed(3)).to(dev)    # (bottom maps of 32 x 64: the fused residual blocks take the pair route)
     grads, n_pair_only = {}, {}
     for drop in (True, False):
         monkeypatch.setattr(_train, "DROP_TWINS", drop)
@@ -728,6 +728,6 @@ def test_pair_only_tape_entries_give_the_same_gradients(monkeypatch):
         monkeypatch.setattr(_train.Tape, "__setitem__", orig)
         grads[drop] = {n: p.grad.clone() for n, p in m.named_parameters()}
         n_pair_only[drop] = sum(seen)
-    assert n_pair_only[False] == 0 and n_pair_only[True] >= 8, n_pair_only
+    assert n_pair_only[False] == 0 and n_pair_only[True] >= 6, n_pair_only
     for n in grads[True]:
         assert _rel(grads[True][n], grads[False][n]) < 2e-5, n

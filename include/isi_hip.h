@@ -377,6 +377,9 @@ int isi_vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st
  * the ReLU of the tensor they belong to in one pass; `a` may be a channel slice of a wider channels-last tensor (row stride
  * lda), b / y dense [M, C] or NULL (no second term / no mask).  Same, for the quantiser backward, with dq read through a
  * row stride (isi_vq_bwd_f32 on a channel slice without a dense copy first). */
+/* src [B, C <= 4, H, W] (any strides) -> dense channels-last [B, H, W, 4] with the channels >= C zero: the 2-channel
+ * spectrogram side as an operand of the vectorised weight-gradient kernels (train_vqvae.py:181 through vqvae/_train.py). */
+int isi_pad_channels4_f32(const isi_src *src, float *out_nhwc4, int B, int H, int W, void *stream);
 int isi_add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, void *stream);
 int isi_vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff,
                         int64_t M, int D, void *stream);

@@ -41,6 +41,8 @@ struct FirstArgs {
   int H, W, OH, OW, M;      // M = B * OH * OW output pixels
   int relu, out_pair;
   float *out2;              // with out_pair: dense fp32 twin of the output (the training tape), or null
+  const float *gate;        // fp32 output only: dense tensor laid out like it; out = gate > 0 ? value : 0 (the input gradient
+                            // of the decoder's 2-channel last layer IS this convolution: its ReLU mask rides here)
 };
 
 
@@ -75,9 +77,14 @@ __device__ __forceinline__ void store_tile(const FirstArgs &p, const float *tb, 
   for (int it = 0; it < 32 * QP / 64; ++it) {
     const int idx = it * 64 + lane;
     const int px = idx / QP, q = idx - px * QP;
-    if (m0 + px < p.M)
-      *reinterpret_cast<float4 *>(p.out + (size_t)(m0 + px) * COUT + q * 4) =
-          *reinterpret_cast<const float4 *>(tb + px * LDT + q * 4);
+    if (m0 + px < p.M) {
+      float4 v = *reinterpret_cast<const float4 *>(tb + px * LDT + q * 4);
+      if (p.gate) {   // (uniform)
+        const float4 g = *reinterpret_cast<const float4 *>(p.gate + (size_t)(m0 + px) * COUT + q * 4);
+        v.x = g.x > 0.f ? v.x : 0.f; v.y = g.y > 0.f ? v.y : 0.f; v.z = g.z > 0.f ? v.z : 0.f; v.w = g.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4 *>(p.out + (size_t)(m0 + px) * COUT + q * 4) = v;
+    }
   }
 }
 
@@ -287,10 +294,12 @@ bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *
 }
 
 int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, const isi_dst *dst, int B, int H,
-                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream, float *twin) {
+                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream, float *twin,
+                   const float *gate) {
   FirstArgs a;
   if (twin && !(flags & ISI_CONV_OUT_PAIR)) return unsupported("conv_first: an fp32 twin accompanies a pair-format output");
-  a.out2 = twin;
+  if (gate && (flags & (ISI_CONV_OUT_PAIR | ISI_CONV_GATE_PAIR))) return unsupported("conv_first: the gated epilogue writes and reads fp32");
+  a.out2 = twin; a.gate = gate;
   a.in = s0->ptr; a.w = packed_w; a.bias = bias; a.out = dst->ptr;
   a.in_bytes = (unsigned)(in_extent * 4);
   a.s0n = (int)s0->sn; a.s0c = (int)s0->sc; a.s0h = (int)s0->sh; a.s0w = (int)s0->sw;

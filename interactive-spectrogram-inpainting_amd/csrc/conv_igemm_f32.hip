@@ -725,11 +725,11 @@ int conv2d_batched_f32(const isi_src *s0, const isi_src *s1, const float *packed
   const int64_t er = (res && res->ptr) ? extent(B, res->sn, Cout, res->sc, OH, res->sh, OW, res->sw) : 1;
   if (e0 > kMaxElems || e1 > kMaxElems || eo > kMaxElems || er > kMaxElems)
     return unsupported("conv2d: a tensor spans 4 GiB or more");
-  if (!gate && e0 <= kMaxElems && eo <= kMaxElems && aligned16(packed_w) &&
-      conv_first_applicable(s0, s1, res, dst, Cout, KH, KW, stride, pad, OH, OW, nz)) {
+  if ((!gate || (!(relu & (ISI_CONV_OUT_PAIR | ISI_CONV_GATE_PAIR)) && aligned16(gate))) && e0 <= kMaxElems && eo <= kMaxElems &&
+      aligned16(packed_w) && conv_first_applicable(s0, s1, res, dst, Cout, KH, KW, stride, pad, OH, OW, nz)) {
     // the 2-channel first layer has its own HBM-oriented kernel (conv_first_f32.hip), bit-identical results
     if (relu & (ISI_CONV_IN0_PAIR | ISI_CONV_IN1_PAIR)) return unsupported("conv2d: pair-format source on the 2-channel layer");
-    return conv_first_f32(s0, packed_w, bias, dst, B, H, W, Cout, OH, OW, e0, relu, stream, twin);
+    return conv_first_f32(s0, packed_w, bias, dst, B, H, W, Cout, OH, OW, e0, relu, stream, twin, gate);
   }
   // the prior's linear layers: rows of a dense matrix, three-term products -> the GEMM kernel (gemm_split_f32.hip)
   if (nz == 1 && !(gate && (relu & ISI_CONV_GATE_PAIR)) && !two && KH == 1 && KW == 1 && stride == 1 && pad == 0 && B == 1 && H == 1 && s0->sc == 1 &&

@@ -373,6 +373,10 @@ int isi_vq_bwd_f32(float *dz, const float *dq, const float *z, const float *q_st
                    void *stream) {
   return vq_bwd_f32(dz, dq, z, q_st, g_diff, n, S(stream));
 }
+int isi_pad_channels4_f32(const isi_src *src, float *out_nhwc4, int B, int H, int W, void *stream) {
+  if (!src || !src->ptr) return ISI_E_INVALID;
+  return pad_channels4_f32(src->ptr, out_nhwc4, B, src->C, H, W, src->sn, src->sc, src->sh, src->sw, S(stream));
+}
 int isi_add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, void *stream) {
   return add_gate_rows_f32(out, a, lda, b, y, M, C, S(stream));
 }

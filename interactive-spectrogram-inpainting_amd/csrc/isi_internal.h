@@ -7,6 +7,8 @@
 namespace isi {
 
 int split_conv_weight_f16(const float *packed, float *out, int64_t n_floats, hipStream_t stream);
+int pad_channels4_f32(const float *x, float *out, int B, int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                      hipStream_t st);
 int add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, hipStream_t st);
 int vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff, int64_t M,
                     int D, hipStream_t st);
@@ -21,7 +23,8 @@ int pair_decode_f32(const float *in, float *x, int64_t n, hipStream_t stream);
 bool conv_first_applicable(const isi_src *s0, const isi_src *s1, const isi_src *res, const isi_dst *dst, int Cout,
                            int KH, int KW, int stride, int pad, int OH, int OW, int nz);
 int conv_first_f32(const isi_src *s0, const float *packed_w, const float *bias, const isi_dst *dst, int B, int H,
-                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream, float *twin = nullptr);
+                   int W, int Cout, int OH, int OW, int64_t in_extent, int flags, hipStream_t stream, float *twin = nullptr,
+                   const float *gate = nullptr);
 bool conv_pair_sources_ok(int C0, int C1, int Cout, int taps);
 // conv_pair_f16.hip: the LDS-DMA implicit-GEMM kernel of the pair pipeline (pair8 sources, blocked W16 weights)
 struct PairConvArgs {

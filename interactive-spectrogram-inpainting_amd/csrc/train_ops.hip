@@ -155,6 +155,24 @@ __global__ void vq_bwd_rows_kernel(float *__restrict__ dz, const float *__restri
   }
 }
 
+// [B, C <= 4, H, W] view (any strides) -> dense channels-last [B, H, W, 4], channels >= C zero: the 2-channel spectrogram
+// side of the first / last layer as a 4-channel operand of the vectorised weight-gradient kernel, in one pass (was: a
+// zero fill of the 4-channel tensor + a strided copy into it)
+__global__ void pad_channels4_kernel(const float *__restrict__ x, float4 *__restrict__ out, int64_t npix, int C, int HW,
+                                     int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+    const int64_t b = i / HW;
+    const int rem = (int)(i - b * HW), y = rem / W, xx = rem - y * W;
+    const float *p = x + b * sn + y * sh + xx * sw;
+    float4 v = make_float4(p[0], 0.f, 0.f, 0.f);
+    if (C > 1) v.y = p[sc];
+    if (C > 2) v.z = p[2 * sc];
+    if (C > 3) v.w = p[3 * sc];
+    out[i] = v;
+  }
+}
+
 static unsigned grid_for(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 8192); }
 
 int relu_bwd_f32(float *dy, const float *y, int64_t n, hipStream_t st) {
@@ -171,6 +189,16 @@ int axpy_f32(float *a, const float *b, float alpha, int64_t n, hipStream_t st) {
   if (n == 0) return ISI_OK;
   hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, a, b, alpha, n / 4);
   return check_launch("axpy_f32");
+}
+
+int pad_channels4_f32(const float *x, float *out, int B, int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                      hipStream_t st) {
+  if (!x || !out || B <= 0 || C < 1 || C > 4 || H <= 0 || W <= 0) return invalid("pad_channels4: bad argument");
+  if (reinterpret_cast<uintptr_t>(out) & 15) return invalid("pad_channels4: output must be 16-byte aligned");
+  const int64_t npix = (int64_t)B * H * W;
+  hipLaunchKernelGGL(pad_channels4_kernel, dim3(grid_for(npix)), dim3(256), 0, st, x, reinterpret_cast<float4 *>(out), npix, C,
+                     H * W, W, sn, sc, sh, sw);
+  return check_launch("pad_channels4_f32");
 }
 
 int add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, hipStream_t st) {

@@ -230,6 +230,7 @@ SIGNATURES = {
     "isi_relu_bwd_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "isi_axpy_f32": (C.c_int, [_P, _P, C.c_float, C.c_int64, _P]),
     "isi_vq_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
+    "isi_pad_channels4_f32": (C.c_int, [C.POINTER(isi_src), _P, C.c_int, C.c_int, C.c_int, _P]),
     "isi_add_gate_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P, _P, C.c_int64, C.c_int, _P]),
     "isi_vq_bwd_rows_f32": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P, C.c_int64, C.c_int, _P]),
     "isi_colsum_num_partials": (C.c_int, [C.c_int64]),

@@ -230,8 +230,9 @@ def conv_wgrad(layer: _ConvParams, x: torch.Tensor, dy_nhwc: torch.Tensor,
         # 2-channel spectrogram side (first encoder / last decoder layer): zero-pad the channels to 4 in a
         # channels-last copy, so that the vectorised split-product kernel applies (K = 16 * 4 instead of a
         # scalar-gather fp32 launch: 630-700 us -> ~100 us); the padded taps are dropped from dW below
-        src4 = torch.zeros(B, H, W, 4, dtype=torch.float32, device=src.device)
-        src4[..., :cin_role] = src.permute(0, 2, 3, 1)
+        src4 = torch.empty(B, H, W, 4, dtype=torch.float32, device=src.device)
+        sv = _hip.src_nchw_view(src)
+        _hip.check(L.isi_pad_channels4_f32(C.byref(sv), src4.data_ptr(), B, H, W, _s(src)), "isi_pad_channels4_f32")
         src, cin_role = src4.permute(0, 3, 1, 2), 4
     K = k * k * cin_role
     Kpad = (K + 31) // 32 * 32

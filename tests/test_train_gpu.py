@@ -497,6 +497,34 @@ def test_gated_convolution_epilogue(kind):
     assert torch.equal(gated, want)
     with pytest.raises(ValueError):
         run(gate[:, :, :-1])                                               # a gate of another layout is refused
+    # round 5: the gate as a PAIR-format tensor (ISI_CONV_GATE_PAIR: the training forward's pair tensors serve as masks)
+    gate_pair = _ops.pair_encode(gate)
+    if kind == "convT":
+        gated_p = _ops.conv_transpose2d_k4s2(x, packed, None, cout, relu=False, bf16x3=1, gate_nhwc=gate_pair, extra_flags=512)
+    else:
+        gated_p = _ops.conv2d(x, packed, None, cout, k, s, p, relu=False, residual_bchw=res, bf16x3=1, gate_nhwc=gate_pair,
+                              extra_flags=512)
+    assert torch.equal(gated_p, want)
+
+
+def test_gated_two_channel_convolution_runs_the_first_layer_kernel():
+    """The input gradient of the decoder's 2-channel last layer is a Conv2d(2 -> 64, k4 s2 p1): with a gate it now runs
+    conv_first_f32.hip (gated epilogue) instead of the scalar-gather form of the generic kernel; same values."""
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.vqvae import _ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(32)
+    B, H, W = 2, 12, 40
+    x = torch.randn(B, H, W, 2, generator=g).to(dev).permute(0, 3, 1, 2)          # channels-last 2-channel gradient
+    w = torch.randn(64, 2, 4, 4, generator=g).to(dev) * 0.1
+    packed = _ops.pack_conv_weight(w)
+    gate = torch.relu(torch.randn(B, H // 2, W // 2, 64, generator=g)).to(dev)
+    got = _ops.conv2d(x, packed, None, 64, 4, 2, 1, relu=False, bf16x3=1, gate_nhwc=gate)
+    with _hip.knob("ISI_NO_CONV_FIRST", 1):
+        ref = _ops.conv2d(x, packed, None, 64, 4, 2, 1, relu=False, bf16x3=1, gate_nhwc=gate)
+    assert torch.equal(got == 0, ref == 0)
+    assert _rel(got, ref) < 2e-6
+    assert ((gate == 0).permute(0, 3, 1, 2) <= (got == 0)).all()
 
 
 def test_fused_optimizer_step_invalidates_packed_weights():

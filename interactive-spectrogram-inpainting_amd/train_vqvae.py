@@ -59,14 +59,81 @@ class RunningMeans:
         return dict(zip(self.NAMES, m))
 
 
+class GraphedVQVAEStep:
+    """The loop body of `train` below recorded into HIP graph segments (utils/training/graphed_step.py) and replayed per
+    batch: the host's ~200 launches per step become one call per segment (data parallel: segments are cut at the EMA
+    messages and the gradient buckets).  The recording's eager warm-up steps would train on the first batch; the model,
+    its codebook buffers and the optimizer's moments are therefore put back IN PLACE afterwards (the graph holds their
+    addresses), so the replayed epoch follows the eager epoch's trajectory.  Needs a capturable optimizer
+    (`make_adam(..., capturable=True)`), no host-side scheduler, batches of one shape."""
+
+    def __init__(self, model: VQVAE, reconstruction_criterion: Callable, optimizer, img: torch.Tensor,
+                 latent_loss_weight: float, clip_grad_norm: Optional[float]):
+        from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+        self.outs: Dict[str, torch.Tensor] = {}
+
+        def step(x):
+            model.zero_grad()
+            out, latent_loss, perplexity_t, perplexity_b, *_ = model(x)
+            reconstruction_loss = reconstruction_criterion(out, x)
+            latent_loss = latent_loss.mean()
+            loss = reconstruction_loss + latent_loss_weight * latent_loss
+            loss.backward()
+            if clip_grad_norm is not None:
+                nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm)
+            optimizer.step()
+            self.outs = {"reconstruction_loss": reconstruction_loss, "latent_loss": latent_loss,
+                         "perplexity_t": perplexity_t, "perplexity_b": perplexity_b}
+            return loss
+        saved = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
+        had_state = {id(p) for p in optimizer.state}
+        saved_opt = {id(p): {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}
+                     for p, st in optimizer.state.items()}
+        self.graphed = GraphedTrainingStep(step, (img.clone(),), warmup=2)
+        with torch.no_grad():
+            for t, sv in zip(list(model.parameters()) + list(model.buffers()), saved):
+                t.copy_(sv)
+            for p_, st in optimizer.state.items():
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(saved_opt[id(p_)][k]) if id(p_) in had_state else v.zero_()
+        from interactive_spectrogram_inpainting import _hip
+        _hip._on_optimizer_step()      # (the values moved without a version bump: packed-weight caches are stale)
+        for q in (model.quantize_t, model.quantize_b):
+            if hasattr(q, "_packed_key"):
+                q._packed_key = None
+
+    def __call__(self, img: torch.Tensor):
+        self.graphed(img)
+        return self.outs
+
+    def finish(self) -> None:
+        self.graphed.finish()
+
+
 def train(epoch: int, loader: Iterable, model: VQVAE, reconstruction_criterion: Callable,
           optimizer: torch.optim.Optimizer, scheduler=None, device="cuda", latent_loss_weight: float = 0.25,
-          clip_grad_norm: Optional[float] = None, dry_run: bool = False) -> Dict[str, float]:
+          clip_grad_norm: Optional[float] = None, dry_run: bool = False, hip_graph: bool = False) -> Dict[str, float]:
     model.train()
     stats = RunningMeans(device)
     if hasattr(loader, "__len__") and not dry_run:
         assert_same_step_count(len(loader), torch.device(device) if is_distributed() and
                                dist.get_backend() == "nccl" else None)
+    if hip_graph:
+        if scheduler is not None:
+            raise NotImplementedError("a recorded step bakes the learning rate in: no host-side scheduler with hip_graph")
+        graphed = None
+        for batch_index, (img, *_) in enumerate(loader):
+            img = img.to(device, non_blocking=True)
+            if graphed is None:
+                graphed = GraphedVQVAEStep(model, reconstruction_criterion, optimizer, img, latent_loss_weight, clip_grad_norm)
+            o = graphed(img)
+            stats.update(img.shape[0], o["reconstruction_loss"], o["latent_loss"], o["perplexity_t"], o["perplexity_b"])
+            if dry_run:
+                break
+        if graphed is not None:
+            graphed.finish()
+        return stats.means()
     for batch_index, (img, *_) in enumerate(loader):
         model.zero_grad()
         img = img.to(device, non_blocking=True)
@@ -154,6 +221,8 @@ def main():
     ap.add_argument("--reconstruction-criterion", default="MSE",
                     help="MSE | Jukebox | DDSP (spectral losses invert both spectrograms with the mel helper)")
     ap.add_argument("--dry-run", action="store_true")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="record the training step into HIP graph segments and replay it per batch (GraphedVQVAEStep)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,7 +236,7 @@ def main():
 
     torch.manual_seed(1)   # identical initial weights on every rank
     model = VQVAE(in_channel=2).to(device)
-    optimizer = make_adam(model.parameters(), lr=args.lr)
+    optimizer = make_adam(model.parameters(), lr=args.lr, **({"capturable": True} if args.hip_graph else {}))
     helper = None
     if args.reconstruction_criterion != "MSE":
         from GANsynth_pytorch.spectrograms_helper import SpectrogramsHelper
@@ -189,7 +258,7 @@ def main():
         t0 = time.perf_counter()
         means = train(epoch, loader, model, criterion, optimizer, device=device,
                       latent_loss_weight=args.latent_loss_weight, clip_grad_norm=args.clip_grad_norm,
-                      dry_run=args.dry_run)
+                      dry_run=args.dry_run, hip_graph=args.hip_graph)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         val_loss, val = evaluate(eval_loader, model, criterion, device=device,

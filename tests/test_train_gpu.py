@@ -240,6 +240,36 @@ def test_train_vqvae_epoch_on_64_synthetic_spectrograms():
     assert m.decode_code(id_t, id_b).shape == (2, 2, 128, 512)
 
 
+def test_train_vqvae_epoch_replayed_from_hip_graph_follows_the_eager_epoch():
+    """`train_vqvae.train(..., hip_graph=True)`: the loop body recorded once (GraphedVQVAEStep) and replayed per batch --
+    model, codebooks and optimizer moments are put back in place after the recording's warm-up steps, so an epoch of four
+    batches ends with the eager epoch's parameters, codebooks and running means."""
+    import train_vqvae as T
+    from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    data = T.SyntheticSpectrograms(16, shape=(2, 64, 128))
+    crit = torch.nn.MSELoss()
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(1)
+        m = VQVAE(in_channel=2).to(dev)
+        opt = make_adam(m.parameters(), lr=1e-3, capturable=True)
+        loader = torch.utils.data.DataLoader(data, batch_size=4, shuffle=False, drop_last=True)
+        means = T.train(0, loader, m, crit, opt, device=dev, clip_grad_norm=10.0, hip_graph=graph)
+        res[graph] = (means, {k: v.clone() for k, v in m.state_dict().items()})
+    for k in T.RunningMeans.NAMES:
+        a, b = res[True][0][k], res[False][0][k]
+        assert abs(a - b) <= 1e-4 * max(1e-6, abs(b)), (k, a, b)
+    for k, v in res[False][1].items():
+        assert _rel(res[True][1][k], v) < 1e-4, k
+    # eager code after the replays sees the replayed weights
+    m.eval()
+    with torch.no_grad():
+        out = m(next(iter(loader))[0].to(dev))
+    assert torch.isfinite(out[0]).all()
+
+
 def test_unquantized_vqvae_against_reference(golden_dir):
     """VQVAE(disable_quantization=True) (vqvae.py:152-160 -> UnquantizedBottleneck, bottleneck.py:107-119): the two
     codebook searches are skipped; fixture from the imported reference; training gradients against oracle autograd."""

@@ -82,9 +82,11 @@ class GraphedVQVAEStep:
             if clip_grad_norm is not None:
                 nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm)
             optimizer.step()
-            self.outs = {"reconstruction_loss": reconstruction_loss, "latent_loss": latent_loss,
-                         "perplexity_t": perplexity_t, "perplexity_b": perplexity_b}
-            return loss
+            # (detached views of the static result tensors: a kept autograd graph would pin the warm-up steps' gradient
+            # accumulators to their stream)
+            self.outs = {"reconstruction_loss": reconstruction_loss.detach(), "latent_loss": latent_loss.detach(),
+                         "perplexity_t": perplexity_t.detach(), "perplexity_b": perplexity_b.detach()}
+            return loss.detach()
         saved = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())]
         had_state = {id(p) for p in optimizer.state}
         saved_opt = {id(p): {k: v.detach().clone() for k, v in st.items() if torch.is_tensor(v)}

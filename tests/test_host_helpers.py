@@ -648,8 +648,10 @@ def _segmented_worker(rank, world, port, q):
     g = GraphedTrainingStep(step_fn, (x,), warmup=1, backend=OpListBackend())    # warm-up = one eager step on zeros
     assert not recording()
     losses = [float(g(b)) for b in batches]
-    q.put((rank, [p.detach().clone() for p in params], losses, g.n_segments, len(red.buckets),
-           [u.clone() for u in _Ema.updates]))
+    # (plain lists: a tensor travels through the queue as a shared-memory handle the parent must fetch while this
+    # process is still alive)
+    q.put((rank, [p.detach().tolist() for p in params], losses, g.n_segments, len(red.buckets),
+           [u.tolist() for u in _Ema.updates]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -671,7 +673,7 @@ def test_segmented_graph_replay_two_process_gloo():
     got = {}
     for _ in procs:
         rank, params, losses, nseg, nb, ema = q.get(timeout=120)
-        got[rank] = (params, losses, nseg, nb, ema)
+        got[rank] = ([torch.tensor(p_) for p_ in params], losses, nseg, nb, [torch.tensor(u_) for u_ in ema])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "isi_hip.h"
+#include "knobs.h"
 
 namespace isi {
 
@@ -46,6 +47,7 @@ struct DeviceOnce {               // "has this been done on the current device?"
   void mark() { const int d = current_device() & 255; bits[d >> 6] |= 1ull << (d & 63); }
 };
 inline int current_device_cu_count() {
+  if (const int forced = knobs().cu_count; forced > 0) return forced;   // (a stream with a CU mask: tools/concurrent_halves.py)
   static int cached[256];         // 0 = not asked yet
   const int d = current_device() & 255;
   if (!cached[d]) {

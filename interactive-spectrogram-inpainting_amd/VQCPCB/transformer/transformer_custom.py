@@ -349,12 +349,42 @@ class TransformerDecoderLayerCustom(nn.Module):
 
 
 class TransformerAlignedDecoderLayerCustom(TransformerDecoderLayerCustom):
-    """The reference's hierarchical 'aligned' variant restricts cross-attention to
-    the source token a target patch sits under (priors/transformer.py:388-396).  Its
-    definition lives only in the absent package; not built."""
+    """The reference's hierarchical 'aligned' decoder layer (priors/transformer.py:388-396, `use_aligned_decoder=True`): "this
+    computes cross-attention only with tokens from the source that directly condition underlying tokens in the target".  Its
+    definition lives only in the absent package; OUR specification (parity unpinned, like every layer of this file): a
+    TransformerDecoderLayerCustom whose cross-attention lets target token i see the source tokens of ITS event only --
+
+        allowed(i, j)  <=>  i // num_channels_decoder == j // num_channels_encoder
+
+    (for the bottom prior: the four codes of a 2 x 2 patch attend to the one top code above them; the start symbols are event 0 on
+    both sides) -- as an additive mask handed to the attention kernels, combined with whatever `memory_mask` the caller passes.
+    Self-attention, feed-forward and every parameter are the parent's, so state dicts are interchangeable.  KV-cached sampling is
+    not built for it (priors/_decode.py raises)."""
 
     def __init__(self, *args, **kwargs):
-        raise NotImplementedError("TransformerAlignedDecoderLayerCustom (use_aligned_decoder=True) is not built")
+        super().__init__(*args, **kwargs)
+        self._align = {}
+
+    def alignment_mask(self, St: int, Ss: int, device) -> torch.Tensor:
+        key = (St, Ss, str(device))
+        m = self._align.get(key)
+        if m is None:
+            ev_t = torch.arange(St) // self.multihead_attn.Cq
+            ev_s = torch.arange(Ss) // self.multihead_attn.Ck
+            m = torch.full((St, Ss), float("-inf"))
+            m[ev_t[:, None] == ev_s[None, :]] = 0.0
+            m = self._align[key] = m.to(device)
+        return m
+
+    def forward(self, tgt: torch.Tensor, memory: torch.Tensor, tgt_mask: MaskArg = None,
+                memory_mask: MaskArg = None, memory_kv: Optional[torch.Tensor] = None) -> torch.Tensor:
+        Ss = memory_kv.shape[0] if memory_kv is not None else memory.shape[0]
+        m = self.alignment_mask(tgt.shape[0], Ss, tgt.device)
+        if memory_mask is not None:
+            if isinstance(memory_mask, str):
+                raise NotImplementedError("the aligned decoder combines its alignment with additive tensor masks only")
+            m = m + memory_mask.to(m.device)
+        return super().forward(tgt, memory, tgt_mask, m, memory_kv)
 
 
 class TransformerEncoderCustom(nn.Module):

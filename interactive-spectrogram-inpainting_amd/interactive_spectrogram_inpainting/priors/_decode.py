@@ -16,11 +16,19 @@ import torch
 from . import _ops
 
 
+def _refuse_aligned(layers) -> None:
+    """The key/value-cached loops attend over ALL memory rows; the aligned decoder layer restricts them per target event."""
+    from VQCPCB.transformer.transformer_custom import TransformerAlignedDecoderLayerCustom
+    if any(isinstance(l, TransformerAlignedDecoderLayerCustom) for l in layers):
+        raise NotImplementedError("KV-cached sampling is not built for use_aligned_decoder=True (full passes work)")
+
+
 class IncrementalDecoder:
     def __init__(self, model, memory: torch.Tensor, batch_size: int):
         """memory: [S_src, B, d] encoder output."""
         dec = model.transformer.decoder
         self.layers = list(dec.layers)
+        _refuse_aligned(self.layers)
         self.model = model
         d = model.d_model
         S_t = model.target_transformer_sequence_length_with_start_symbol
@@ -91,6 +99,7 @@ class NativeSampler:
         from .transformer import Seq2SeqInputKind
         self._C, self._hip = C, _hip
         dec_layers = list(model.transformer.decoder.layers)
+        _refuse_aligned(dec_layers)
         if len(dec_layers) > _hip.ISI_MAX_LAYERS:
             raise NotImplementedError(f"more than {_hip.ISI_MAX_LAYERS} decoder layers")
         dev = memory.device

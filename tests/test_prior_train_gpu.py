@@ -882,3 +882,55 @@ def test_graphed_prior_step_with_real_rccl_collectives_between_segments():
                          text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "PRIOR SEGMENTS" in out.stdout and "OK" in out.stdout
+
+
+def test_aligned_decoder_layer_own_specification():
+    """`use_aligned_decoder=True` (priors/transformer.py:388-396; the layer's definition is in the absent package: OUR
+    specification, parity unpinned): cross-attention restricted to the source tokens of the target token's own event.  The
+    aligned layer equals the plain decoder layer handed the explicit alignment mask, forward and backward; an output row does
+    not move when the memory rows of OTHER events change; the wrapper builds and trains with the flag; KV-cached sampling
+    refuses it."""
+    from VQCPCB.transformer.transformer_custom import TransformerAlignedDecoderLayerCustom, TransformerDecoderLayerCustom
+    dev = _dev()
+    torch.manual_seed(5)
+    kw = dict(d_model=64, nhead=4, num_channels_encoder=1, num_events_encoder=9, num_channels_decoder=4, num_events_decoder=9)
+    al = TransformerAlignedDecoderLayerCustom(**kw).to(dev).train()
+    pl = TransformerDecoderLayerCustom(**kw).to(dev).train()
+    pl.load_state_dict(al.state_dict())
+    al.dropout = pl.dropout = 0.0
+    St, Ss, B = 36, 9, 3
+    tgt = torch.randn(St, B, 64, device=dev, requires_grad=True)
+    mem = torch.randn(Ss, B, 64, device=dev, requires_grad=True)
+    mask = al.alignment_mask(St, Ss, dev)
+    assert mask.shape == (St, Ss) and int((mask == 0).sum()) == St        # one source event per target token
+    out_a = al(tgt, mem, "causal")
+    out_p = pl(tgt, mem, "causal", mask)
+    _close(out_a, out_p, 1e-6, "aligned == plain + alignment mask")
+    w = torch.randn_like(out_a)
+    ga = torch.autograd.grad((out_a * w).sum(), [tgt, mem] + list(al.parameters()), allow_unused=True)
+    gp = torch.autograd.grad((out_p * w).sum(), [tgt, mem] + list(pl.parameters()), allow_unused=True)
+    for x, y in zip(ga, gp):
+        if x is not None:
+            _close(x, y, 1e-5, "aligned backward")
+    # locality: target tokens of event 2 (rows 8..11) only see memory row 2
+    with torch.no_grad():
+        mem2 = mem.detach().clone()
+        mem2[[0, 1, 3, 4, 5, 6, 7, 8]] += 1.0
+        o1, o2 = al(tgt.detach(), mem.detach(), "causal"), al(tgt.detach(), mem2, "causal")
+        # (self-attention is causal over the target only: rows 8..11 depend on memory through their own cross-attention alone)
+        assert float((o1[8:12] - o2[8:12]).abs().max()) < 1e-6
+        assert float((o1[12:16] - o2[12:16]).abs().max()) > 1e-3
+    # the wrapper with the flag: builds, one training step runs, sampling refuses
+    from interactive_spectrogram_inpainting.priors.transformer import UpsamplingVQTransformer
+    from interactive_spectrogram_inpainting.priors._decode import IncrementalDecoder
+    m = UpsamplingVQTransformer(shape=[8, 8], condition_shape=[4, 4], use_aligned_decoder=True, **{k: v for k, v in COMMON.items()}).to(dev).train()
+    g = torch.Generator().manual_seed(1)
+    top = torch.randint(0, 32, (2, 4, 4), generator=g).to(dev)
+    bot = torch.randint(0, 32, (2, 8, 8), generator=g).to(dev)
+    cls = {"instrument_family_str": torch.zeros(2, 1, dtype=torch.long, device=dev), "pitch": torch.zeros(2, 1, dtype=torch.long, device=dev)}
+    src, tgt_ = m.to_sequences(bot, condition=top, class_conditioning=cls)
+    logits, memory = m(tgt_, condition=src)
+    logits.square().mean().backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    with pytest.raises(NotImplementedError):
+        IncrementalDecoder(m, memory.detach(), 2)

@@ -52,6 +52,7 @@ template <int COUT>
 __device__ __forceinline__ void store_tile(const FirstArgs &p, const float *tb, const int m0, const int lane) {
   if (p.out_pair) {
     constexpr int GP = COUT / 8;   // 32-byte groups per pixel
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int it = 0; it < 32 * GP / 64; ++it) {
       const int idx = it * 64 + lane;
@@ -59,6 +60,23 @@ __device__ __forceinline__ void store_tile(const FirstArgs &p, const float *tb, 
       uint4 hi, lo;
       f16s::pair8_encode(*reinterpret_cast<const float4 *>(tb + px * LDT + g * 8),
                          *reinterpret_cast<const float4 *>(tb + px * LDT + g * 8 + 4), hi, lo);
+      if (!p.out2 && 32 * GP % 64 == 0) {
+        // (round 5) a lane owns one 32-byte group {hi | lo}: writing hi then lo made every store instruction touch HALF of
+        // each 64-byte run (16 bytes on, 16 off).  v_permlane32_swap hands the lower half-wave both halves' hi pieces and the
+        // upper one the lo pieces (as in conv_pair_f16.hip's epilogue): instruction A then writes the groups of lanes 0-31
+        // whole -- hi from the lower lane, lo from lane + 32 --, instruction B those of lanes 32-63: 1 KiB contiguous each.
+        const u32x2v sx = __builtin_amdgcn_permlane32_swap(hi.x, lo.x, false, false);
+        const u32x2v sy = __builtin_amdgcn_permlane32_swap(hi.y, lo.y, false, false);
+        const u32x2v sz = __builtin_amdgcn_permlane32_swap(hi.z, lo.z, false, false);
+        const u32x2v sw = __builtin_amdgcn_permlane32_swap(hi.w, lo.w, false, false);
+        const uint4 first = make_uint4(sx.x, sy.x, sz.x, sw.x), second = make_uint4(sx.y, sy.y, sz.y, sw.y);
+        const int up = lane >> 5;                                    // 0: this lane writes hi pieces, 1: lo pieces
+        const int idx_a = it * 64 + (lane & 31), idx_b = idx_a + 32; // the (pixel, group) pairs of the two instructions
+        const int pa = idx_a / GP, ga = idx_a - pa * GP, pb = idx_b / GP, gb = idx_b - pb * GP;
+        if (m0 + pa < p.M) reinterpret_cast<uint4 *>(p.out + (size_t)(m0 + pa) * COUT + ga * 8)[up] = first;
+        if (m0 + pb < p.M) reinterpret_cast<uint4 *>(p.out + (size_t)(m0 + pb) * COUT + gb * 8)[up] = second;
+        continue;
+      }
       if (m0 + px < p.M) {
         uint4 *o = reinterpret_cast<uint4 *>(p.out + (size_t)(m0 + px) * COUT + g * 8);
         o[0] = hi;

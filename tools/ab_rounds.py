@@ -23,8 +23,20 @@ import torch, bench
 dev = torch.device("cuda:0")
 import inspect
 out = {}
-s = bench._prior_sampling(dev)
-out["decode_B1_codes_per_s"] = s["codes_per_s_B1"]
+if len(sys.argv) > 2 and sys.argv[2] == "light":      # (under host load: no CPU-oracle leg inside the measurement)
+    import sample as S
+    top = bench._top_prior(dev).eval()
+    cls = {"pitch": torch.tensor([24]), "instrument_family_str": torch.tensor([0])}
+    ts = []
+    for i in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        S.sample_model(top, dev, 1, [32, 32], 1.0, generator=torch.Generator().manual_seed(i), class_conditioning=cls, top_p_sampling_p=0.8)
+        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    out["decode_B1_codes_per_s"] = round(1024 / sorted(ts[1:])[1], 1)
+    del top
+else:
+    s = bench._prior_sampling(dev)
+    out["decode_B1_codes_per_s"] = s["codes_per_s_B1"]
 kw = {"steps": 20} if "steps" in inspect.signature(bench._vqvae_training).parameters else {}
 t = bench._vqvae_training(dev, None, 1, **kw)
 out["vqvae_train_ms"] = t.get("ms_per_step_eager", t["ms_per_step"])
@@ -46,7 +58,8 @@ def main():
             for t in args:
                 env = dict(os.environ)
                 env.pop("ISI_HIP_LIBRARY", None)
-                r = subprocess.run([sys.executable, "-c", CHILD, t], capture_output=True, text=True, env=env, timeout=1200)
+                r = subprocess.run([sys.executable, "-c", CHILD, t] + (["light"] if load else []), capture_output=True, text=True,
+                                   env=env, timeout=1200)
                 line = next((ln for ln in r.stdout.splitlines() if ln.startswith("AB ")), None)
                 if line is None:
                     print(f"{t}: failed\n{r.stderr[-1500:]}")

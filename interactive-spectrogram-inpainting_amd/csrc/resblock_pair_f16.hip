@@ -399,21 +399,11 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
                             __builtin_bit_cast(unsigned, x4[6] * q), __builtin_bit_cast(unsigned, x4[7] * q));
           }
           const unsigned off = (ok && !ISI_RESPAIR_ABLBIT(p, 8)) ? o + (unsigned)(64 * h) : OOB_ST;
-          {
-            // (round 5) a lane owns the 32 bytes {w0 | w1} of one 8-channel group and lane + 32 (kb = 1) the next 32 bytes of
-            // the same pixel: writing w0 then w1 made each store instruction touch 16 bytes of every 32.  After
-            // v_permlane32_swap the kb = 0 lane holds both lanes' first halves and the kb = 1 lane both second halves
-            // (conv_pair_f16.hip's epilogue): instruction A writes group kb 0 whole, instruction B group kb 1 -- 32-byte runs.
-            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-            const u32x2v sx = __builtin_amdgcn_permlane32_swap(w0.x, w1.x, false, false);
-            const u32x2v sy = __builtin_amdgcn_permlane32_swap(w0.y, w1.y, false, false);
-            const u32x2v sz = __builtin_amdgcn_permlane32_swap(w0.z, w1.z, false, false);
-            const u32x2v sw = __builtin_amdgcn_permlane32_swap(w0.w, w1.w, false, false);
-            const uint4 fa = make_uint4(sx.x, sy.x, sz.x, sw.x), fb = make_uint4(sx.y, sy.y, sz.y, sw.y);
-            const unsigned base0 = off == OOB_ST ? OOB_ST : off - 32u * (unsigned)kb + 16u * (unsigned)kb;   // group kb 0 of this pixel, this lane's half
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fa), rso_b, base0, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, fb), rso_b, base0 == OOB_ST ? OOB_ST : base0 + 32u, 0, 0);
-          }
+          // (round 5, measured and dropped: handing the kb = 0 lane both lanes' first halves with v_permlane32_swap, so that a
+          // store instruction writes 32-byte instead of 16-byte runs per pixel -- the form that took the first layer from 86 to
+          // 77 us -- changed nothing here: the tail's burst is bound by bytes)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_ST ? OOB_ST : off + 16u, 0, 0);
           if (p.out2) {   // (uniform) fp32 twin of a pair-format output: the same 8 channels at the same offsets
             constexpr float q2 = 1.f / f16s::kScaleA;
             const uint4 f0 = make_uint4(__builtin_bit_cast(unsigned, x4[0] * q2), __builtin_bit_cast(unsigned, x4[1] * q2),

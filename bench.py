@@ -311,6 +311,15 @@ def _ranks_in_sync(dist, device, tensors):
     return bool(((hi - lo).abs() <= 1e-6 * hi.abs().clamp(min=1e-12)).all())
 
 
+def _all_ranks_ok(dist, device, ok: bool) -> bool:
+    """Do ALL ranks agree to go on?  (A rank whose recording failed must not leave the others waiting in a replay's collective.)"""
+    if dist is None:
+        return ok
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 def _time_steps(fn, steps, barrier, dist, device):
     """ms per call of `fn` over `steps` calls between barriers, slowest rank; also the host's share (time to ENQUEUE the
     steps, before the closing barrier)."""
@@ -394,8 +403,14 @@ def _prior_training(device, dist=None, world=1, B=8, steps=20, warmup=2, level="
     opt = make_adam(m.parameters(), lr=3e-4, capturable=True)
     try:
         statics = (code, mask) if level == "top" else (bottom, code)
-        graphed = GraphedTrainingStep(lambda *_a: step(), statics, warmup=2, index_limits={0: 512},
-                                      range_params=[p for p in m.parameters() if p.dim() == 2])
+        graphed = None
+        try:          # (the recording itself holds no collective: a failure here is this rank's alone -- agree before replaying)
+            graphed = GraphedTrainingStep(lambda *_a: step(), statics, warmup=2, index_limits={0: 512},
+                                          range_params=[p for p in m.parameters() if p.dim() == 2])
+        except Exception as e:
+            graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+        if not _all_ranks_ok(dist, device, graphed is not None):
+            raise RuntimeError(graph_error or "another rank could not record the step")
         try:
             graphed(*statics)
             graphed_ms, graphed_host_ms, gl = _time_steps(lambda: graphed(*statics), steps, barrier, dist, device)
@@ -407,7 +422,8 @@ def _prior_training(device, dist=None, world=1, B=8, steps=20, warmup=2, level="
             _prior_ops.set_dropout_seed_base(None)
         del graphed
     except Exception as e:       # the eager numbers stand on their own
-        graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+        graph_error = graph_error or f"{type(e).__name__}: {str(e)[:300]}"
+        _prior_ops.set_dropout_seed_base(None)
     ms = graphed_ms if graphed_ms is not None else eager_ms
     out = {"value": round(world * B * tokens / ms * 1e3, 0), "unit": "tokens/s", "ms_per_step": round(ms, 2),
            "mode": "hip-graph replay" if graphed_ms is not None else "eager",
@@ -470,7 +486,13 @@ def _vqvae_training(device, dist, world, batch=64, steps=20, warmup=3):
     graph_error = None
     opt = make_adam(m.parameters(), lr=3e-4, capturable=True)
     try:
-        graphed = GraphedTrainingStep(lambda _x: step(), (x,), warmup=2)
+        graphed = None
+        try:
+            graphed = GraphedTrainingStep(lambda _x: step(), (x,), warmup=2)
+        except Exception as e:
+            graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+        if not _all_ranks_ok(dist, device, graphed is not None):
+            raise RuntimeError(graph_error or "another rank could not record the step")
         graphed(x)
         graphed_ms, graphed_host_ms, gl = _time_steps(lambda: graphed(x), steps, barrier, dist, device)
         assert torch.isfinite(gl).all()
@@ -479,7 +501,7 @@ def _vqvae_training(device, dist, world, batch=64, steps=20, warmup=3):
         in_sync = in_sync and _ranks_in_sync(dist, device, [m.quantize_b.embed, m.quantize_t.embed, m.enc_b.blocks[0].weight])
         del graphed
     except Exception as e:
-        graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+        graph_error = graph_error or f"{type(e).__name__}: {str(e)[:300]}"
     ms = graphed_ms if graphed_ms is not None else eager_ms
     out = {"value": round(world * batch / ms * 1e3, 1), "unit": "spectrograms/s", "ms_per_step": round(ms, 2),
            "mode": "hip-graph replay" if graphed_ms is not None else "eager",

@@ -7,8 +7,9 @@ each tree in its own process, interleaved and repeated so that box-to-box and wa
     git worktree add -f build/r04 7165488 && make -C build/r04/interactive-spectrogram-inpainting_amd/csrc -j8     (round 4)
     gpurun -- python tools/ab_rounds.py build/r03 build/r04 .
 
-(`build/` is git-ignored but travels to the GPU box.)  Prints one table; `--host-load N` adds N busy host threads (a slower
-host: how the eager launch chains behave when the CPU is contended, as on the driver's box)."""
+(`build/` is git-ignored but travels to the GPU box.)  Prints one table; `--host-load N` adds N busy host threads (a contended
+host).  Keep N well below the box's thread count: with as many burners as hardware threads (tried: 256 of 256) nothing finishes
+inside a 20-minute call."""
 import json
 import os
 import pathlib

@@ -632,7 +632,16 @@ int isi_vq_conv1x1_nearest_f32(const isi_src *src0, const isi_src *src1, const f
                                const float *codes_kd, const float *e2, int64_t *idx_out, float *q_out,
                                float *q_pair_out, int32_t *counts, float *sse_part, float *workspace, int B, int H,
                                int W, int D, int K, void *stream);
+/* The same launch for the TRAINING step (train_vqvae.py:168-192 -> bottleneck.py:53-101): `z_out` ([N][64] fp32,
+ * nullable) also receives z -- the commitment gradient 2 (z - q) / numel and the EMA sums of bottleneck.py:75-92 read it --
+ * and `counts` is zeroed by the launch's pre-kernel (isi_vq_conv1x1_nearest_f32 expects zeroed counts). */
+int isi_vq_conv1x1_nearest_tape_f32(const isi_src *src0, const isi_src *src1, const float *packed_w16, const float *bias,
+                                    const float *codes_kd, const float *e2, int64_t *idx_out, float *q_out,
+                                    float *q_pair_out, float *z_out, int32_t *counts, float *sse_part, float *workspace,
+                                    int B, int H, int W, int D, int K, void *stream);
 size_t isi_vq_conv1x1_workspace_floats(int C0, int C1, int D);
+/* 1 when the fused launch covers the shape (D = 64, 32-channel multiples, C0 + C1 <= 256, both code planes in LDS) */
+int isi_vq_conv1x1_fusable(int C0, int C1, int D, int K);
 
 /* diff = sum(sse_part)/(N*D); perplexity = exp(-sum p log(max(p,1e-7))),
  * p = counts/N  (bottleneck.py:94,97-100).  Writes out2[0]=diff, out2[1]=perplexity. */

@@ -411,7 +411,15 @@ int isi_vq_conv1x1_nearest_f32(const isi_src *src0, const isi_src *src1, const f
   return vq_conv1x1_nearest_f32(src0, src1, packed_w16, bias, codes_kd, e2, idx_out, q_out, q_pair_out, counts, sse_part,
                                 workspace, B, H, W, D, K, S(stream));
 }
+int isi_vq_conv1x1_nearest_tape_f32(const isi_src *src0, const isi_src *src1, const float *packed_w16, const float *bias,
+                                    const float *codes_kd, const float *e2, int64_t *idx_out, float *q_out,
+                                    float *q_pair_out, float *z_out, int32_t *counts, float *sse_part, float *workspace,
+                                    int B, int H, int W, int D, int K, void *stream) {
+  return vq_conv1x1_nearest_f32(src0, src1, packed_w16, bias, codes_kd, e2, idx_out, q_out, q_pair_out, counts, sse_part,
+                                workspace, B, H, W, D, K, S(stream), /*zero_counts*/ true, z_out);
+}
 size_t isi_vq_conv1x1_workspace_floats(int C0, int C1, int D) { return vq_conv1x1_workspace_floats(C0, C1, D); }
+int isi_vq_conv1x1_fusable(int C0, int C1, int D, int K) { return vq_conv1x1_fusable(C0, C1, D, K) ? 1 : 0; }
 int isi_vq_nearest_flags_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,
                              float *q_out, int32_t *counts, float *sse_part, int64_t N, int D, int K,
                              int flags, void *stream) {

@@ -199,7 +199,8 @@ bool vq_conv1x1_fusable(int C0, int C1, int D, int K);
 int vq_debug_stamps(long long *host, int n);
 int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
                            const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,
-                           float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts = false);
+                           float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts = false,
+                           float *z_out = nullptr);
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D);
 int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,
                     int D, float *out2, hipStream_t stream);

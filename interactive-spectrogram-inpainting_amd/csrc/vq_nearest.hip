@@ -520,6 +520,7 @@ struct VqFusedArgs {
   const float *wfrag;                    // fragment-major copy of w16 (vq_weight_fragments_kernel)
   int64_t *idx;
   float *q, *q_pair;
+  float *z_out;                          // nullable: z itself ([N][64] fp32), for the training step's backward and EMA sums
   int32_t *counts;
   float *sse_part;
   unsigned in0_bytes, in1_bytes, w_bytes;
@@ -671,6 +672,10 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
                              zt[t][r0 + 2] * kVqUnscale + bq[j].z, zt[t][r0 + 3] * kVqUnscale + bq[j].w);
       if (!valid) v = make_float4(0.f, 0.f, 0.f, 0.f);
       zq[j] = v;
+    }
+    if (p.z_out && valid) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) *reinterpret_cast<float4 *>(p.z_out + n * D + (2 * j + half) * 4) = zq[j];
     }
     ISI_VQ_STAMP(2);
     // ---- search (candidates on the f16 pipe, decision in fp32; shared with the stand-alone kernel)
@@ -921,7 +926,8 @@ int vq_debug_stamps(long long *host, int n) {
 
 int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
                            const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,
-                           float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts) {
+                           float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts,
+                           float *z_out) {
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return invalid("vq_conv1x1: workspace (vq_conv1x1_workspace_floats, 16-byte aligned)");
   if (!s0 || !s0->ptr || !w16 || !codes || !e2 || !idx || !q || !counts || !sse_part) return invalid("vq_conv1x1: null pointer");
   const bool two = s1 && s1->ptr;
@@ -935,7 +941,7 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
   VqFusedArgs a;
   memset(&a, 0, sizeof a);
   a.in0 = s0->ptr; a.in1 = two ? s1->ptr : s0->ptr; a.w16 = w16; a.bias = bias; a.codes = codes; a.e2 = e2;
-  a.idx = idx; a.q = q; a.q_pair = q_pair; a.counts = counts; a.sse_part = sse_part;
+  a.idx = idx; a.q = q; a.q_pair = q_pair; a.z_out = z_out; a.counts = counts; a.sse_part = sse_part;
   a.in0_bytes = (unsigned)(e0 * 4); a.in1_bytes = two ? (unsigned)(e1 * 4) : a.in0_bytes;
   a.C0 = C0; a.C1 = C1; a.Kpad = (int)round_up((size_t)(C0 + C1), kBK);
   a.w_bytes = (unsigned)((size_t)D * a.Kpad * 4);

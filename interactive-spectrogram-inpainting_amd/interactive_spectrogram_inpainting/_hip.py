@@ -242,7 +242,10 @@ SIGNATURES = {
     "isi_vq_nearest_flags_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "isi_vq_conv1x1_nearest_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "isi_vq_conv1x1_nearest_tape_f32": (C.c_int, [C.POINTER(isi_src), C.POINTER(isi_src), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                  _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_vq_conv1x1_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "isi_vq_conv1x1_fusable": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "isi_vq_num_partials": (C.c_int, [C.c_int64]),
     "isi_vq_finalize_f32": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P]),
     "isi_embed_code_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),

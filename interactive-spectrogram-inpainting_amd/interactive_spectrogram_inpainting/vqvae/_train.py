@@ -551,6 +551,10 @@ _PAIR_FLAGS = 8 | 16      # ISI_CONV_F16X3 | ISI_CONV_W16
 
 
 DROP_TWINS = os.environ.get("ISI_TRAIN_DROP_TWINS", "1") != "0"
+# quantize_conv + codebook search of the training forward in ONE launch (the eval path's vq_conv1x1_nearest kernel, which
+# also writes z for the backward and the EMA sums, and q in the pair format for the decoders); 0: a 1x1 convolution
+# launch, the stand-alone search and a pair-encode pass (bit-identical results)
+FUSED_QUANTIZER = os.environ.get("ISI_TRAIN_FUSED_QUANTIZER", "1") != "0"
 
 
 class _Act:
@@ -879,6 +883,70 @@ class PendingEma:
         q._ema_steps = getattr(q, "_ema_steps", 0) + 1
 
 
+def fused_quantizer_applies(q, a: "_Act", a2: Optional["_Act"] = None) -> bool:
+    """Can quantize_conv on cat(a, a2) and the search of `q` run as the one fused launch?  (pair-format sources of the
+    kernel's shapes, no index corruption: the corrupted codes are drawn on the host between search and statistics)"""
+    if not (FUSED_QUANTIZER and _pair_mode()) or q.corruption_weights is not None or q.dim != 64:
+        return False
+    if a.pair is None or (a2 is not None and a2.pair is None) or not _dense_cl(a.pair) or (a2 is not None and not _dense_cl(a2.pair)):
+        return False
+    c1 = a2.pair.shape[1] if a2 is not None else 0
+    return bool(_hip.lib().isi_vq_conv1x1_fusable(a.pair.shape[1], c1, q.dim, q.n_embed))
+
+
+def quantize_conv_train(qconv, q, a: "_Act", a2: Optional["_Act"], pending: Optional[PendingEma] = None):
+    """quantize_conv_* (vqvae.py:260,272) + quantize_train in one launch: returns (z [B,H,W,D], q as an _Act with its
+    pair twin, diff, idx, perplexity); z and every output are bit-identical to the two-launch path."""
+    L = _hip.lib()
+    D, K = q.dim, q.n_embed
+    codes, e2 = q.packed()
+    B, C0, H, W = a.pair.shape
+    C1 = a2.pair.shape[1] if a2 is not None else 0
+    dev = a.pair.device
+
+    def src(t):      # [B,C,H,W] view of dense channels-last storage
+        return _hip.isi_src(t.data_ptr(), t.shape[1], t.stride(0), 1, t.stride(2), t.stride(3))
+    s0, s1 = src(a.pair), (src(a2.pair) if a2 is not None else None)
+    N = B * H * W
+    z = torch.empty(B, H, W, D, dtype=torch.float32, device=dev)
+    q_st, q_pair = torch.empty_like(z), torch.empty_like(z)
+    idx = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+    counts = torch.empty(K, dtype=torch.int32, device=dev)
+    n_part = L.isi_vq_num_partials(N)
+    part = torch.empty(n_part, dtype=torch.float32, device=dev)
+    out2 = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(4, L.isi_vq_conv1x1_workspace_floats(C0, C1, D)), dtype=torch.float32, device=dev)
+    packed = qconv.packed()
+    _hip.check(L.isi_vq_conv1x1_nearest_tape_f32(C.byref(s0), C.byref(s1) if s1 is not None else None,
+                                                 packed.data_ptr() + 2 * packed.numel(), qconv.bias.data_ptr(),
+                                                 codes.data_ptr(), e2.data_ptr(), idx.data_ptr(), q_st.data_ptr(),
+                                                 q_pair.data_ptr(), z.data_ptr(), counts.data_ptr(), part.data_ptr(),
+                                                 ws.data_ptr(), B, H, W, D, K, _s(z)),
+               "isi_vq_conv1x1_nearest_tape_f32")
+    _hip.check(L.isi_vq_finalize_f32(part.data_ptr(), n_part, counts.data_ptr(), K, N, D, out2.data_ptr(), _s(z)),
+               "isi_vq_finalize_f32")
+    _ema_statistics(q, z, idx, counts, pending)
+    return z, _Act(q_st.permute(0, 3, 1, 2), q_pair.permute(0, 3, 1, 2)), out2[0], idx, out2[1]
+
+
+def _ema_statistics(q, z_nhwc, idx, counts, pending: Optional[PendingEma]) -> None:
+    """Cluster sizes and per-code sums of z (bottleneck.py:75-83) handed to the EMA update."""
+    L = _hip.lib()
+    D, K = q.dim, q.n_embed
+    N = z_nhwc.numel() // D
+    embed_sum = torch.empty(D, K, dtype=torch.float32, device=z_nhwc.device)
+    nws = L.isi_vq_embed_sum_workspace_floats(D, K, N)
+    ws = torch.empty(nws, dtype=torch.float32, device=z_nhwc.device)
+    _hip.check(L.isi_vq_embed_sum_f32(z_nhwc.data_ptr(), idx.data_ptr(), embed_sum.data_ptr(), ws.data_ptr(), nws,
+                                      N, D, K, _s(z_nhwc)), "isi_vq_embed_sum_f32")
+    own = pending is None
+    if own:
+        pending = PendingEma()
+    pending.submit(q, counts.float(), embed_sum)
+    if own:
+        pending.flush()
+
+
 def quantize_train(q, z_nhwc: torch.Tensor, pending: Optional[PendingEma] = None):
     """Eval-identical search with the CURRENT codebook, optional index corruption (bottleneck.py:63-73),
     then the EMA update of the buffers (bottleneck.py:75-92) from statistics all-reduced over the
@@ -921,17 +989,7 @@ def quantize_train(q, z_nhwc: torch.Tensor, pending: Optional[PendingEma] = None
         counts = torch.bincount(idx.reshape(-1), minlength=K).to(torch.int32)
         p = counts.float() / N
         perplexity = torch.exp(-torch.sum(p * torch.log(p.clamp(min=1e-7))))
-    embed_sum = torch.empty(D, K, dtype=torch.float32, device=z_nhwc.device)
-    nws = L.isi_vq_embed_sum_workspace_floats(D, K, N)
-    ws = torch.empty(nws, dtype=torch.float32, device=z_nhwc.device)
-    _hip.check(L.isi_vq_embed_sum_f32(z_nhwc.data_ptr(), idx.data_ptr(), embed_sum.data_ptr(), ws.data_ptr(), nws,
-                                      N, D, K, _s(z_nhwc)), "isi_vq_embed_sum_f32")
-    own = pending is None
-    if own:
-        pending = PendingEma()
-    pending.submit(q, counts.float(), embed_sum)
-    if own:
-        pending.flush()
+    _ema_statistics(q, z_nhwc, idx, counts, pending)
     return q_st, diff, idx, perplexity
 
 
@@ -1006,10 +1064,9 @@ class VQVAETrainFunction(torch.autograd.Function):
         D = model.embed_dim
         x = x.contiguous()
         refresh_packs(model)
-        enc_b = encoder_forward(model.enc_b, x, tape, "enc_b")
-        enc_t = encoder_forward(model.enc_t, enc_b, tape, "enc_t").f32
-        enc_b = enc_b.f32
-        z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=FWD_PRECISION))
+        enc_b_act = encoder_forward(model.enc_b, x, tape, "enc_b")
+        enc_t_act = encoder_forward(model.enc_t, enc_b_act, tape, "enc_t")
+        enc_t, enc_b = enc_t_act.f32, enc_b_act.f32
         unq = model.disable_quantization      # UnquantizedBottleneck (bottleneck.py:107-119): identity, diff 0
 
         def _identity(z):
@@ -1017,15 +1074,32 @@ class VQVAETrainFunction(torch.autograd.Function):
             return (z, torch.zeros((), device=dev), torch.zeros(0, dtype=torch.int64, device=dev),
                     torch.full((), float("inf"), device=dev))
         pending = PendingEma()
-        q_t, diff_t, id_t, perp_t = _identity(z_t) if unq else quantize_train(model.quantize_t, z_t, pending)
+        # quantize_conv + search: one launch where the fused kernel applies (q then arrives with its pair twin)
+        fuse_t = not unq and fused_quantizer_applies(model.quantize_t, enc_t_act)
+        if fuse_t:
+            z_t, q_t_act, diff_t, id_t, perp_t = quantize_conv_train(model.quantize_conv_t, model.quantize_t, enc_t_act, None, pending)
+            q_t = _nhwc(q_t_act.f32)
+        else:
+            z_t = _nhwc(model.quantize_conv_t.run(enc_t, relu=False, bf16x3=FWD_PRECISION))
+            q_t, diff_t, id_t, perp_t = _identity(z_t) if unq else quantize_train(model.quantize_t, z_t, pending)
+            q_t_act = _Act(_as_bchw(q_t))
         tape["z_t"], tape["q_t"] = z_t, q_t
-        dec_t = decoder_forward(model.dec_t, _as_bchw(q_t), None, tape, "dec_t", out_nchw_last=False).f32
+        fuse_b = (not unq and FUSED_QUANTIZER and _pair_mode() and model.quantize_b.corruption_weights is None
+                  and enc_b_act.pair is not None)
+        dec_t_act = decoder_forward(model.dec_t, q_t_act, None, tape, "dec_t", out_nchw_last=False, last_pair=fuse_b)
+        dec_t = dec_t_act.f32
         if dec_t.shape[-1] != enc_b.shape[-1]:
             raise NotImplementedError("training needs input sizes divisible by the total down-sampling factor")
-        z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=FWD_PRECISION))
-        q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b, pending)
+        if fuse_b and fused_quantizer_applies(model.quantize_b, dec_t_act, enc_b_act):
+            z_b, q_b_act, diff_b, id_b, perp_b = quantize_conv_train(model.quantize_conv_b, model.quantize_b, dec_t_act,
+                                                                     enc_b_act, pending)
+            q_b = _nhwc(q_b_act.f32)
+        else:
+            z_b = _nhwc(model.quantize_conv_b.run(dec_t, relu=False, x2=enc_b, bf16x3=FWD_PRECISION))
+            q_b, diff_b, id_b, perp_b = _identity(z_b) if unq else quantize_train(model.quantize_b, z_b, pending)
+            q_b_act = _Act(_as_bchw(q_b))
         tape["z_b"], tape["q_b"], tape["dec_t"], tape["enc_b"], tape["enc_t"] = z_b, q_b, dec_t, enc_b, enc_t
-        up = _Act(_as_bchw(q_t))
+        up = q_t_act
         n_up = len(model.upsample_top_to_bottom)
         for j, layer in enumerate(model.upsample_top_to_bottom):
             tape[f"up.in{j}"] = up.tape()
@@ -1035,7 +1109,7 @@ class VQVAETrainFunction(torch.autograd.Function):
             oshape = (B_, layer.out_channels, 2 * H_, 2 * W_)
             need = not (j == n_up - 1 and _pairs_suffice(model.dec.blocks[0], oshape, c1=model.embed_dim))
             up = _conv_fwd(layer, up, False, need_f32=need)
-        dec = decoder_forward(model.dec, up, _as_bchw(q_b), tape, "dec", out_nchw_last=True).f32
+        dec = decoder_forward(model.dec, up, q_b_act, tape, "dec", out_nchw_last=True).f32
         diff = (diff_t + diff_b).reshape(1)
         pending.flush()       # the statistics' all-reduces have had the rest of the forward to arrive; codebooks written here
         ctx.model, ctx.tape = model, tape

@@ -791,6 +791,44 @@ def test_pair_only_tape_entries_give_the_same_gradients(monkeypatch):
         assert _rel(grads[True][n], grads[False][n]) < 2e-5, n
 
 
+def test_fused_training_quantizer_is_bit_identical(monkeypatch):
+    """Round 5: the training forward runs quantize_conv_* + the codebook search as the eval path's ONE launch
+    (isi_vq_conv1x1_nearest_tape_f32: z written for the backward / EMA sums, q with its pair twin for the decoders) instead of
+    a 1x1 convolution, the stand-alone search and a pair-encode pass (train_vqvae.py:168-192 -> vqvae.py:260-273,
+    bottleneck.py:53-101).  The fused kernel forms z with the products and the order of the convolution kernel: codes,
+    loss, codebooks after the EMA update and every parameter gradient are bit-identical, and the fused launch is really taken."""
+    from interactive_spectrogram_inpainting.vqvae import _train
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    dev = _dev()
+    x = torch.randn(4, 2, 128, 256, generator=torch.Generator().manual_seed(21)).to(dev)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(_train, "FUSED_QUANTIZER", fused)
+        calls = []
+        orig = _train.quantize_conv_train
+
+        def spy(*a, _orig=orig, _calls=calls, **k):
+            _calls.append(1)
+            return _orig(*a, **k)
+        monkeypatch.setattr(_train, "quantize_conv_train", spy)
+        torch.manual_seed(9)
+        m = VQVAE(in_channel=2).to(dev).train()
+        out, latent, perp_t, perp_b, id_t, id_b = m(x)
+        (torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()).backward()
+        monkeypatch.setattr(_train, "quantize_conv_train", orig)
+        res[fused] = dict(out=out.detach().clone(), latent=latent.detach().clone(), id_t=id_t.clone(), id_b=id_b.clone(),
+                          perp=(float(perp_t), float(perp_b)), n=len(calls),
+                          embed=(m.quantize_t.embed.clone(), m.quantize_b.embed.clone()),
+                          grads={n: p.grad.clone() for n, p in m.named_parameters()})
+    assert res[True]["n"] == 2 and res[False]["n"] == 0, (res[True]["n"], res[False]["n"])
+    a, b = res[True], res[False]
+    assert torch.equal(a["id_t"], b["id_t"]) and torch.equal(a["id_b"], b["id_b"])
+    assert torch.equal(a["out"], b["out"]) and torch.equal(a["latent"], b["latent"]) and a["perp"] == b["perp"]
+    assert torch.equal(a["embed"][0], b["embed"][0]) and torch.equal(a["embed"][1], b["embed"][1])
+    for n in a["grads"]:
+        assert torch.equal(a["grads"][n], b["grads"][n]), n
+
+
 def test_training_step_pair_route_equals_fp32_route_at_full_size(monkeypatch):
     """BASELINE configs[2]'s per-GPU shard at full size (B = 64 of [2, 128, 512]): the training step on the LDS-DMA pair
     kernels (pair tensors, twins only where needed, pair-format masks and weight-gradient sources) against the round-4 step

@@ -362,8 +362,9 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
   }
 }
 
-// ---- a few rows (batched decoding, up to 8 sequences per launch): the same kernel shape with the rows' inputs in
-// registers -- weights are loaded once and used for every row.  Per row the operations of row_gemv1_kernel /
+// ---- several rows (batched decoding): the same kernel shape with the rows' inputs in registers -- weights are loaded
+// once and used for every row, the rows pass through in groups of MR (round 5: ALL rows of a stage in one launch; groups of
+// 8 rows used to be launches of their own, 4 per stage at batch 32).  Per row the operations of row_gemv1_kernel /
 // row_linear_ln_kernel, in their order: a row's result does not depend on the rows it shares a launch with.
 template <int KQ, int MR>
 __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
   const bool two = RPW == 2 && n0 + 1 < a.N;
   const float4 *w0 = reinterpret_cast<const float4 *>(a.W + (size_t)n0 * a.K);
   const float4 *w1 = reinterpret_cast<const float4 *>(a.W + (size_t)(two ? n0 + 1 : n0) * a.K);
-  float4 wa[KQ], wb[KQ], gq[KQ], bq[KQ], xv[MR][KQ];
+  float4 wa[KQ], wb[KQ], gq[KQ], bq[KQ];
 #pragma unroll
   for (int i = 0; i < KQ; ++i) {
     const int qd = lane + 64 * i;
@@ -391,37 +392,43 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
       if (a.ln_g) { gq[i] = reinterpret_cast<const float4 *>(a.ln_g)[qd]; bq[i] = reinterpret_cast<const float4 *>(a.ln_b)[qd]; }
     }
   }
+  const int n = n0 + (lane & 1);
+  const bool writer = lane < 2 && (lane == 0 || two);
+  float bias_v = 0.f, rg = 1.f, rb = 0.f;
+  if (writer) {
+    if (a.bias) bias_v = a.bias[n];
+    if (a.res && a.res_g) { rg = a.res_g[n]; rb = a.res_b[n]; }
+  }
+  for (int m0 = 0; m0 < a.M; m0 += MR) {
+  const float *xg = a.x + (size_t)m0 * a.x_stride;
+  const float *resg = a.res ? a.res + (size_t)m0 * a.res_stride : nullptr;
+  const int Mg = a.M - m0 < MR ? a.M - m0 : MR;
+  float4 xv[MR][KQ];
 #pragma unroll
   for (int m = 0; m < MR; ++m)
 #pragma unroll
     for (int i = 0; i < KQ; ++i) {
       const int qd = lane + 64 * i;
       xv[m][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < a.M && qd < nq) xv[m][i] = reinterpret_cast<const float4 *>(a.x + (size_t)m * a.x_stride)[qd];
+      if (m < Mg && qd < nq) xv[m][i] = reinterpret_cast<const float4 *>(xg + (size_t)m * a.x_stride)[qd];
     }
-  const int n = n0 + (lane & 1);
-  const bool writer = lane < 2 && (lane == 0 || two);
-  float bias_v = 0.f, rg = 1.f, rb = 0.f, res_v[MR];
-  if (writer) {
-    if (a.bias) bias_v = a.bias[n];
-    if (a.res && a.res_g) { rg = a.res_g[n]; rb = a.res_b[n]; }
-  }
+  float res_v[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) res_v[m] = (writer && a.res && m < a.M) ? a.res[(size_t)m * a.res_stride + n] : 0.f;
+  for (int m = 0; m < MR; ++m) res_v[m] = (writer && resg && m < Mg) ? resg[(size_t)m * a.res_stride + n] : 0.f;
   constexpr int RS = 8;
   float rrow[MR][RS];
-  if (a.res && a.res_g) {
+  if (resg && a.res_g) {
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
       for (int i = 0; i < RS; ++i) {
         const int c = lane + 64 * i;
-        rrow[m][i] = (m < a.M && c < a.N) ? a.res[(size_t)m * a.res_stride + c] : 0.f;
+        rrow[m][i] = (m < Mg && c < a.N) ? resg[(size_t)m * a.res_stride + c] : 0.f;
       }
   }
 #pragma unroll
   for (int m = 0; m < MR; ++m) {
-    if (m >= a.M) break;
+    if (m >= Mg) break;
     if (a.ln_g) {
       float s = 0.f;
 #pragma unroll
@@ -445,7 +452,7 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
       }
     }
     float rmean = 0.f, rrstd = 1.f;
-    if (a.res && a.res_g) {
+    if (resg && a.res_g) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) s += rrow[m][i];
@@ -467,30 +474,244 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
     acc1 = wave_sum(acc1);
     if (writer) {
       float v = (lane == 0 ? acc0 : acc1) + bias_v;
-      if (a.res) {
+      if (resg) {
         float r = res_v[m];
         if (a.res_g) r = (r - rmean) * rrstd * rg + rb;
         v += r;
       }
       if (a.relu) v = fmaxf(v, 0.f);
-      if (n < a.split) a.out[(size_t)m * a.out_stride + n] = v;
-      else a.out2[ppos * a.out2_pos + (size_t)m * a.out2_stride + (n - a.split)] = v;
+      const size_t mr = (size_t)(m0 + m);
+      if (n < a.split) a.out[mr * a.out_stride + n] = v;
+      else a.out2[ppos * a.out2_pos + mr * a.out2_stride + (n - a.split)] = v;
     }
+  }
   }
 }
 
 // rows x float4-per-lane held in registers: at most 16 (64 VGPRs)
+// ---- many rows (batched decoding with more than `decode_mfma_rows` = 16 sequences): the stage as 32-row GEMM tiles on the
+// fp32 matrix pipe.  A workgroup = 32 rows x 32 output features; K passes through LDS in chunks of 512 (LayerNorm applied
+// while staging: the row statistics are formed first, the next chunk travels under the current one's matrix work); the four
+// waves each take a quarter of a chunk's k range (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation) and
+// their accumulators meet in LDS.  Lane (i, kk) feeds four consecutive k of its row / feature per 16-byte read --
+// k = 8 j + 4 kk -- to four MFMAs: A from LDS, B (the weight row of feature n0 + i) straight from memory.  A row's result
+// does not depend on the rows it shares the tile with, but its summation order differs from the one-row kernels': batch-1
+// decoding and batches of up to `decode_mfma_rows` rows keep the GEMV kernels above (bit-identical among themselves).
+// Measured (tools/kt_sampling_b32.sh, B = 32): 17.9 us per launch on average against 23.5 for the GEMV kernel looping over
+// four groups of 8 rows (and 4 x ~10 for the four launches of round 4); 10.7 us of it is the skeleton (requests, staging,
+// three barriers, epilogue), 4.2 the LayerNorm statistics, 3.0 the matrix instructions.  At 8 rows the GEMV kernel wins
+// (10 against 15 us); beyond 32 rows the tiles of a stage run side by side (grid y) where the GEMV loop grows linearly.
+constexpr int MF_KC = 512;
+constexpr int MF_LD = MF_KC + 4;         // padded LDS row: 16-byte reads of 32 consecutive rows are conflict-free
+constexpr size_t kRowMfmaLds = (size_t)(32 * MF_LD + 128 + 4 * 32 * 33) * sizeof(float);
+typedef float mf_f32x16 __attribute__((ext_vector_type(16)));
+
+// LayerNorm statistics of this wave's 8 rows of the tile (KQS float4 per lane and row, 16 / KQS rows per batch of loads)
+template <int KQS>
+__device__ __forceinline__ void mfma_row_stats(const RowLinArgs &a, float *__restrict__ stat, int m0, int Mt, int nq, int lane,
+                                               int wave) {
+  constexpr int RB = 16 / KQS;
+  for (int r0 = 8 * wave; r0 < 8 * wave + 8; r0 += RB) {
+    float4 xr[RB][KQS];
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+      for (int i = 0; i < KQS; ++i) {
+        const int r = r0 + rr, qd = lane + 64 * i;
+        xr[rr][i] = (r < Mt && qd < nq) ? reinterpret_cast<const float4 *>(a.x + (size_t)(m0 + r) * a.x_stride)[qd]
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int rr = 0; rr < RB; ++rr) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int i = 0; i < KQS; ++i) s_ += (xr[rr][i].x + xr[rr][i].y) + (xr[rr][i].z + xr[rr][i].w);
+      const float mean = wave_sum(s_) / (float)a.K;
+      float var = 0.f;
+#pragma unroll
+      for (int i = 0; i < KQS; ++i) {
+        if (lane + 64 * i < nq) {
+          const float d0 = xr[rr][i].x - mean, d1 = xr[rr][i].y - mean, d2 = xr[rr][i].z - mean, d3 = xr[rr][i].w - mean;
+          var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)a.K + a.eps);
+      if (lane == 0) { stat[4 * (r0 + rr)] = mean; stat[4 * (r0 + rr) + 1] = rstd; }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a) {
+  touch_args(a);
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float *xs = sm;                         // [32][MF_LD] normalised input rows of the chunk
+  float *stat = xs + 32 * MF_LD;          // [32][4] input mean / rstd, residual mean / rstd
+  float *red = stat + 128;                // [4][32][33] the waves' accumulators
+  long ppos = 0;
+  if (a.pos) ppos = *a.pos;
+  if (a.x_pos) a.x += ppos * a.x_pos;
+  if (a.res && a.res_pos) a.res += ppos * a.res_pos;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+  const int Mt = a.M - m0 < 32 ? a.M - m0 : 32;
+  const int nq = a.K >> 2;
+  const int idx = lane & 31, kk = lane >> 5;            // A: row idx of the tile; B: feature n0 + idx
+  const float *wrow = a.W + (size_t)(n0 + idx < a.N ? n0 + idx : 0) * a.K;
+  // one chunk's operands: the wave's 16 weight pieces (k = 8 (wave + 4 t) + 4 kk) and the thread's 16 pieces of the 32 input
+  // rows (piece f = tid + 256 u: row f / cq, float4 f % cq) -- all requested before anything waits
+  float4 bw[16], sv[16];
+  auto request_chunk = [&](int kc) {
+    const int kcn = a.K - kc < MF_KC ? a.K - kc : MF_KC;
+    const int cq = kcn >> 2;
+    const int csh = (cq & (cq - 1)) == 0 ? __builtin_ctz(cq) : -1;       // (a chunk of 512: f / cq is a shift)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = 8 * (wave + 4 * t) + 4 * kk;
+      bw[t] = k < kcn ? *reinterpret_cast<const float4 *>(wrow + kc + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int f = tid + 256 * u, r = csh >= 0 ? f >> csh : f / cq, c4 = f - r * cq;
+      sv[u] = (f < 32 * cq && r < Mt) ? *reinterpret_cast<const float4 *>(a.x + (size_t)(m0 + r) * a.x_stride + kc + 4 * c4)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  request_chunk(0);
+  // the epilogue's per-feature values and residual entries (output o = tid + 256 q: row o >> 5, feature n0 + (tid & 31))
+  const int nj = n0 + (tid & 31);
+  const bool nok = nj < a.N;
+  const float bias_v = (a.bias && nok) ? a.bias[nj] : 0.f;
+  float rg = 1.f, rb = 0.f, resv[4];
+  const bool rln = a.res && a.res_g;
+  if (rln && nok) { rg = a.res_g[nj]; rb = a.res_b[nj]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = (tid >> 5) + 8 * q;
+    resv[q] = (a.res && nok && i < Mt) ? a.res[(size_t)(m0 + i) * a.res_stride + nj] : 0.f;
+  }
+  // ---- row statistics (wave w: rows 8 w .. 8 w + 7)
+  if (a.ln_g) {
+    const int kq = (nq + 63) >> 6;                       // float4 per lane and row
+    if (kq <= 2) mfma_row_stats<2>(a, stat, m0, Mt, nq, lane, wave);
+    else if (kq <= 4) mfma_row_stats<4>(a, stat, m0, Mt, nq, lane, wave);
+    else mfma_row_stats<8>(a, stat, m0, Mt, nq, lane, wave);
+  }
+  if (rln) {       // residual rows (N <= 512 where they are normalised: 8 floats per lane and row)
+    float rv[8][8];
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 8 * wave + rr, c = lane + 64 * i;
+        rv[rr][i] = (r < Mt && c < a.N) ? a.res[(size_t)(m0 + r) * a.res_stride + c] : 0.f;
+      }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s_ += rv[rr][i];
+      const float rmean = wave_sum(s_) / (float)a.N;
+      float var = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (lane + 64 * i < a.N) { const float d = rv[rr][i] - rmean; var += d * d; }
+      const float rrstd = 1.0f / sqrtf(wave_sum(var) / (float)a.N + a.eps);
+      if (lane == 0) { stat[4 * (8 * wave + rr) + 2] = rmean; stat[4 * (8 * wave + rr) + 3] = rrstd; }
+    }
+  }
+  mf_f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int kc = 0; kc < a.K; kc += MF_KC) {
+    const int kcn = a.K - kc < MF_KC ? a.K - kc : MF_KC;
+    const int cq = kcn >> 2;
+    const int csh = (cq & (cq - 1)) == 0 ? __builtin_ctz(cq) : -1;
+    __syncthreads();       // the statistics are written / the previous chunk's rows have been read
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int f = tid + 256 * u, r = csh >= 0 ? f >> csh : f / cq, c4 = f - r * cq;
+      if (f < 32 * cq) {
+        float4 v = sv[u];
+        if (a.ln_g && r < Mt) {
+          const float4 g = reinterpret_cast<const float4 *>(a.ln_g + kc)[c4], b = reinterpret_cast<const float4 *>(a.ln_b + kc)[c4];
+          const float mean = stat[4 * r], rstd = stat[4 * r + 1];
+          v.x = (v.x - mean) * rstd * g.x + b.x; v.y = (v.y - mean) * rstd * g.y + b.y;
+          v.z = (v.z - mean) * rstd * g.z + b.z; v.w = (v.w - mean) * rstd * g.w + b.w;
+        }
+        *reinterpret_cast<float4 *>(xs + r * MF_LD + 4 * c4) = v;
+      }
+    }
+    float4 bc[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) bc[t] = bw[t];
+    __syncthreads();
+    if (kc + MF_KC < a.K) request_chunk(kc + MF_KC);      // the next chunk travels under this chunk's matrix work
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      if (8 * (wave + 4 * t) < kcn) {        // (uniform per wave)
+        const float4 av = *reinterpret_cast<const float4 *>(xs + idx * MF_LD + 8 * (wave + 4 * t) + 4 * kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bc[t].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bc[t].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bc[t].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bc[t].w, acc, 0, 0, 0);
+      }
+    }
+  }
+  // ---- the four k quarters meet in LDS: C[i][j], j = lane & 31, i = 4 kk + 8 (r >> 2) + (r & 3)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[(wave * 32 + 4 * kk + 8 * (r >> 2) + (r & 3)) * 33 + idx] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = (tid >> 5) + 8 * q, j = tid & 31;
+    if (i < Mt && nok) {
+      float v = (red[i * 33 + j] + red[(32 + i) * 33 + j]) + (red[(64 + i) * 33 + j] + red[(96 + i) * 33 + j]);
+      v += bias_v;
+      if (a.res) {
+        float r = resv[q];
+        if (rln) r = (r - stat[4 * i + 2]) * stat[4 * i + 3] * rg + rb;
+        v += r;
+      }
+      if (a.relu) v = fmaxf(v, 0.f);
+      const size_t m = (size_t)(m0 + i);
+      if (nj < a.split) a.out[m * a.out_stride + nj] = v;
+      else a.out2[ppos * a.out2_pos + m * a.out2_stride + (nj - a.split)] = v;
+    }
+  }
+}
+
+bool row_mfma_supported(const RowLinArgs &a) {
+  return a.M >= 2 && (a.K & 7) == 0 && (a.x_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(a.W) & 15) == 0 && (!a.ln_g || ((reinterpret_cast<uintptr_t>(a.ln_g) | reinterpret_cast<uintptr_t>(a.ln_b)) & 15) == 0);
+}
+
+int launch_row_mfma(const RowLinArgs &a, hipStream_t st) {
+  static DeviceOnce attr_set;       // once, outside any stream capture (the first position runs direct)
+  if (!attr_set.done()) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(row_mfma32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)kRowMfmaLds) != hipSuccess)
+      return check_launch("hipFuncSetAttribute(row_mfma32)");
+    attr_set.mark();
+  }
+  hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32), dim3(256), kRowMfmaLds, st, a);
+  return check_launch("row_mfma32");
+}
+
+// rows of a group: as many as fit (kq * mr <= 16), at most 8
+static int row_gemvm_group(int M, int kq) {
+  int mr = M <= 2 ? 2 : M <= 4 ? 4 : 8;
+  while (kq * mr > 16) mr >>= 1;
+  return mr;
+}
 bool row_gemvm_supported(const RowLinArgs &a) {
-  if (a.M < 1 || a.M > 8 || (a.K & 3) || a.K > 2048) return false;
+  if (a.M < 1 || a.M > 256 || (a.K & 3) || a.K > 2048) return false;
   if (a.res && a.res_g && a.N > 512) return false;
   const int kq = a.K <= 256 ? 1 : a.K <= 512 ? 2 : a.K <= 1024 ? 4 : 8;
-  const int mr = a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
-  return kq * mr <= 16;
+  return row_gemvm_group(a.M, kq) >= 2;
 }
 
 int launch_row_gemvm(const RowLinArgs &a, hipStream_t st) {
   const int kq = a.K <= 256 ? 1 : a.K <= 512 ? 2 : a.K <= 1024 ? 4 : 8;
-  const int mr = a.M <= 2 ? 2 : a.M <= 4 ? 4 : 8;
+  const int mr = row_gemvm_group(a.M, kq);
   dim3 grid(kq >= 4 ? (a.N + 3) / 4 : (a.N + NPB - 1) / NPB), block(256);
 #define ISI_GM(KQ_, MR_) hipLaunchKernelGGL((row_gemvm_kernel<KQ_, MR_>), grid, block, 0, st, a)
   if (kq == 1) { if (mr == 2) ISI_GM(1, 2); else if (mr == 4) ISI_GM(1, 4); else ISI_GM(1, 8); }
@@ -613,7 +834,10 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       }
       if (!a.x_pos && !a.res_pos && !a.out2_pos) a.pos = nullptr;      // nothing of this launch depends on the position
       if (row_gemv1_supported(a, part != nullptr)) return launch_row_gemv1(a, part, ns, hd, q_st);
-      // batches: groups of up to 8 rows through the register-resident kernel where the rows fit
+      // batches: beyond `decode_mfma_rows` rows the stage is a tile GEMM on the fp32 matrix pipe; up to there every row in one
+      // launch of the register-resident GEMV kernel (the rows pass through in groups)
+      if (a.M > knobs().decode_mfma_rows && row_mfma_supported(a)) return launch_row_mfma(a, q_st);
+      if (row_gemvm_supported(a)) return launch_row_gemvm(a, q_st);
       for (int m0 = 0; m0 < a.M; m0 += 8) {
         RowLinArgs g8 = a;
         g8.M = a.M - m0 < 8 ? a.M - m0 : 8;

@@ -515,6 +515,22 @@ def test_sample_model_large_batch(golden_dir):
         solo = S.sample_model(top, dev, 1, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9,
                               uniforms=uni[:, b:b + 1].contiguous())
         assert torch.equal(solo[0], out[b]), b
+    # round 5: more than ISI_DECODE_MFMA_ROWS (16) rows run each stage as 32-row GEMM tiles on the fp32 matrix pipe
+    # (csrc/prior_decode.hip: row_mfma32_kernel; the 256-row chunks of the B = 259 call below); with the switch at 8 this
+    # batch of 11 takes the tile kernel, and with it at 1 a batch of 3 as well: same codes every way
+    from interactive_spectrogram_inpainting import _hip
+    with _hip.knob("ISI_DECODE_MFMA_ROWS", 8):
+        tiled = S.sample_model(top, dev, B, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9, uniforms=uni)
+    assert torch.equal(tiled, out)
+    with _hip.knob("ISI_DECODE_MFMA_ROWS", 1):
+        three = S.sample_model(top, dev, 3, [8, 4], temperature=1.0, class_conditioning=cls, top_p_sampling_p=0.9,
+                               uniforms=uni[:, :3].contiguous())
+        bottom_three = S.sample_model(bottom, dev, 3, [16, 8], temperature=1.0, condition=three, class_conditioning=cls,
+                                      top_p_sampling_p=0.9, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(three, out[:3])
+    ref_bottom = S.sample_model(bottom, dev, 3, [16, 8], temperature=1.0, condition=three, class_conditioning=cls,
+                                top_p_sampling_p=0.9, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(bottom_three, ref_bottom)
     # more than 256 sequences: decoded in chunks of 256, every row still equals its single-sequence run
     B = 259
     uni = torch.rand(top.target_transformer_sequence_length, B, generator=g)

@@ -458,6 +458,7 @@ def _vqvae_training(device, dist, world, batch=64, steps=20, warmup=3):
     torch.manual_seed(1)                       # identical weights on every rank
     m = VQVAE(in_channel=2).to(device).train()
     from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
+    from interactive_spectrogram_inpainting.utils.losses.mse import mse_loss
     opt = make_adam(m.parameters(), lr=3e-4)
     rank = dist.get_rank() if dist is not None else 0
     x = torch.randn(batch, 2, 128, 512, generator=torch.Generator().manual_seed(200 + rank)).to(device)
@@ -471,7 +472,7 @@ def _vqvae_training(device, dist, world, batch=64, steps=20, warmup=3):
     def step():
         m.zero_grad()
         out, latent, *_ = m(x)
-        loss = torch.nn.functional.mse_loss(out, x) + 0.25 * latent.mean()
+        loss = mse_loss(out, x) + 0.25 * latent.mean()       # (nn.MSELoss on the HIP library: utils/losses/mse.py)
         loss.backward()
         opt.step()
         return loss

@@ -383,6 +383,13 @@ int isi_pad_channels4_f32(const isi_src *src, float *out_nhwc4, int B, int H, in
 int isi_add_gate_rows_f32(float *out, const float *a, int64_t lda, const float *b, const float *y, int64_t M, int C, void *stream);
 int isi_vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z, const float *q_st, const float *g_diff,
                         int64_t M, int D, void *stream);
+/* Reconstruction loss of the VQ-VAE training step (reference train_vqvae.py:168-176, `nn.MSELoss()`): out[0] = mean((a - b)^2)
+ * over n elements (dense, 16-byte aligned), fixed summation order; `workspace`: isi_mse_loss_num_partials(n) floats.
+ * Backward: da = 2 (a - b) g[0] / n, db = -da (either may be null); g: the incoming scalar gradient on the device. */
+int isi_mse_loss_num_partials(int64_t n);
+int isi_mse_loss_f32(const float *a, const float *b, int64_t n, float *workspace, float *out, void *stream);
+int isi_mse_loss_bwd_f32(const float *a, const float *b, const float *g, int64_t n, float *da, float *db, void *stream);
+
 /* out[C] = column sums of x [M, C] (bias gradients); workspace isi_colsum_num_partials(M)*C floats. */
 int isi_colsum_num_partials(int64_t M);
 int isi_colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M,

@@ -386,6 +386,13 @@ int isi_vq_bwd_rows_f32(float *dz, const float *dq, int64_t ldq, const float *z,
                         int64_t M, int D, void *stream) {
   return vq_bwd_rows_f32(dz, dq, ldq, z, q_st, g_diff, M, D, S(stream));
 }
+int isi_mse_loss_num_partials(int64_t n) { return mse_loss_num_partials(n); }
+int isi_mse_loss_f32(const float *a, const float *b, int64_t n, float *workspace, float *out, void *stream) {
+  return mse_loss_f32(a, b, n, workspace, out, S(stream));
+}
+int isi_mse_loss_bwd_f32(const float *a, const float *b, const float *g, int64_t n, float *da, float *db, void *stream) {
+  return mse_loss_bwd_f32(a, b, g, n, da, db, S(stream));
+}
 int isi_colsum_num_partials(int64_t M) { return colsum_num_partials(M); }
 int isi_colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, int64_t M, int C, void *stream) {
   return colsum_f32(x, x_stride, out, workspace, M, C, S(stream));

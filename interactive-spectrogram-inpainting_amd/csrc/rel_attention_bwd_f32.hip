@@ -1679,6 +1679,9 @@ __device__ __forceinline__ void attn_bwd_tail_key(const AttnBwdKArgs &p, float *
   }
 }
 
+__global__ __launch_bounds__(256) void attn_zero_f4_kernel(float4 *__restrict__ p, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
 // G zeroed only where it is read but not written: with Cq = Ck = 1 every (query, key) pair has its own element, the
 // query-stationary kernel (and the one-row kernel) store the whole band of a row -- zeros included -- and both products
 // over G read a band of chunks / queries around it (GemmExtra, WgradBand): what has to be zero are the MARGINS of the
@@ -1883,8 +1886,13 @@ int rel_attention_bwd_f32(const isi_attn_bwd_args *ga, hipStream_t stream) {
       hipLaunchKernelGGL(attn_zero_margins_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a.g, rows, g->Sq, g->B,
                          L.Rp, lo_slope, lo_base, hi_slope, hi_base);
       if ((rc = check_launch("attn_zero_margins"))) return rc;
-    } else if (hipMemsetAsync(a.g, 0, (size_t)g->H * g->B * g->Sq * L.Rp * sizeof(float), stream) != hipSuccess) {
-      return check_launch("hipMemsetAsync(G)");
+    } else {
+      // (a kernel, not hipMemsetAsync: a memset node inside a recorded training step -- a replayed HIP graph -- was followed by
+      // reductions that read unwritten partial sums in ~3 % of the replays on ROCm 7.2 with graph packet capture)
+      const size_t n4 = (size_t)g->H * g->B * g->Sq * L.Rp / 4;       // Rp is a multiple of 4
+      hipLaunchKernelGGL(attn_zero_f4_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 4096)), dim3(256), 0, stream,
+                         reinterpret_cast<float4 *>(a.g), n4);
+      if ((rc = check_launch("attn_zero(G)"))) return rc;
     }
   }
   const bool one = g->precision == 2;     // single-term bf16 products, like the forward of that mode

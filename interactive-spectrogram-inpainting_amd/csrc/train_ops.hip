@@ -312,6 +312,83 @@ int colsum_f32(const float *x, int64_t x_stride, float *out, float *workspace, i
   return check_launch("colsum_reduce");
 }
 
+// ---- mean squared error (train_vqvae.py:203 `nn.MSELoss()`; reference train_vqvae.py:168-176): mean((a - b)^2) and its
+// gradient 2 (a - b) g / n.  Two launches forward (fixed-order partial sums per workgroup, then one workgroup), one backward --
+// torch's path is an element-wise kernel, a memset of the reduction's semaphores, two reduction launches, and two element-wise
+// kernels backward; the memset is what this replaces first of all: a hipMemsetAsync node inside a replayed HIP graph is not
+// reliably ordered with its neighbours on ROCm 7.2.
+constexpr int kMsePartials = 1024;
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                          float *__restrict__ partial, int64_t n) {
+  __shared__ float red[4];
+  const int64_t n4 = n >> 2;
+  const float4 *a4 = reinterpret_cast<const float4 *>(a), *b4 = reinterpret_cast<const float4 *>(b);
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = a4[i], y = b4[i];
+    const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+    s += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {      // the last one to three elements
+    const float d = a[4 * n4 + threadIdx.x] - b[4 * n4 + threadIdx.x];
+    s += d * d;
+  }
+  s = wave64_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void mse_finish_kernel(const float *__restrict__ partial, int np, float inv_n, float *__restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+  s = wave64_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                      const float *__restrict__ g, float two_over_n, float *__restrict__ da,
+                                                      float *__restrict__ db, int64_t n) {
+  const float c = two_over_n * g[0];
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 x = reinterpret_cast<const float4 *>(a)[i], y = reinterpret_cast<const float4 *>(b)[i];
+    const float4 d = make_float4((x.x - y.x) * c, (x.y - y.y) * c, (x.z - y.z) * c, (x.w - y.w) * c);
+    if (da) reinterpret_cast<float4 *>(da)[i] = d;
+    if (db) reinterpret_cast<float4 *>(db)[i] = make_float4(-d.x, -d.y, -d.z, -d.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    const float d = (a[i] - b[i]) * c;
+    if (da) da[i] = d;
+    if (db) db[i] = -d;
+  }
+}
+int mse_loss_num_partials(int64_t n) {
+  const int64_t nb = (n / 4 + 255) / 256;
+  return (int)(nb < 1 ? 1 : nb > kMsePartials ? kMsePartials : nb);
+}
+int mse_loss_f32(const float *a, const float *b, int64_t n, float *workspace, float *out, hipStream_t st) {
+  if (!a || !b || !workspace || !out || n <= 0) return invalid("mse_loss: bad argument");
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) return invalid("mse_loss: operands must be 16-byte aligned");
+  const int np = mse_loss_num_partials(n);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(np), dim3(256), 0, st, a, b, workspace, n);
+  int rc = check_launch("mse_partial");
+  if (rc) return rc;
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, st, workspace, np, 1.0f / (float)n, out);
+  return check_launch("mse_finish");
+}
+int mse_loss_bwd_f32(const float *a, const float *b, const float *g, int64_t n, float *da, float *db, hipStream_t st) {
+  if (!a || !b || !g || (!da && !db) || n <= 0) return invalid("mse_loss_bwd: bad argument");
+  if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(da) | reinterpret_cast<uintptr_t>(db)) & 15)
+    return invalid("mse_loss_bwd: tensors must be 16-byte aligned");
+  const int64_t nb = (n / 4 + 255) / 256;
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)(nb < 1 ? 1 : nb > 8192 ? 8192 : nb)), dim3(256), 0, st, a, b, g,
+                     2.0f / (float)n, da, db, n);
+  return check_launch("mse_loss_bwd");
+}
+
 int vq_ema_update_f32(float *embed, float *cluster_size, float *embed_avg, const float *counts,
                       const float *embed_sum_dk, int D, int K, float decay, float eps, hipStream_t st) {
   if (!embed || !cluster_size || !embed_avg || !counts || !embed_sum_dk || D <= 0 || K <= 0)

@@ -971,6 +971,17 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
   return check_launch("vq_conv1x1_nearest_f32");
 }
 
+// (a kernel, not hipMemsetAsync: memset nodes inside a replayed HIP graph are not reliably ordered on ROCm 7.2 -- DESIGN.md §6)
+__global__ void vq_zero_counts_kernel(int32_t *__restrict__ counts, int K) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < K) counts[i] = 0;
+}
+int vq_zero_counts(int32_t *counts, int K, hipStream_t stream) {
+  if (!counts || K <= 0) return invalid("vq_zero_counts: bad argument");
+  hipLaunchKernelGGL(vq_zero_counts_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, counts, K);
+  return check_launch("vq_zero_counts");
+}
+
 int vq_finalize_f32(const float *sse_part, int n_part, const int32_t *counts, int K, int64_t N,
                     int D, float *out2, hipStream_t stream) {
   if (!sse_part || !counts || !out2 || n_part <= 0 || K <= 0 || N <= 0 || D <= 0)

@@ -304,8 +304,7 @@ bool pairs_eligible(const isi_vqvae_w &w) {
 
 int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *idx, float *q,
                   int32_t *counts, float *sse_part, float *scalars2, int flags, hipStream_t st) {
-  if (hipMemsetAsync(counts, 0, (size_t)cb.K * sizeof(int32_t), st) != hipSuccess)
-    return check_launch("hipMemsetAsync(counts)");
+  if (int rc0 = vq_zero_counts(counts, cb.K, st)) return rc0;
   // With ISI_CONV_F16X3 (the split-f16 mode) the K distances are computed on the f16 matrix pipe only to pick two
   // candidates; the decision between them is taken in fp32 (vq_nearest.hip) -- the same search as the fused kernel's.
   int rc = vq_nearest_f32(z, cb.codes_kd, cb.e2, idx, q, counts, sse_part, N, cb.D, cb.K, flags, st);

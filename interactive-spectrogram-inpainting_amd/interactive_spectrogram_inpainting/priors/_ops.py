@@ -152,8 +152,18 @@ class _WtPackGroup:
         return e[1]
 
     def _repack(self, dev: int, device: torch.device) -> None:
-        self.purge()
+        # Under stream capture nothing may be dropped or rebuilt: the table is a host-to-device copy (not capturable), and an
+        # entry that died since the warm-up steps -- a model of an earlier test / run collected by the gc.collect() in front
+        # of the capture -- used to send the recorded step through exactly that rebuild (flaky NaN gradients of a replayed
+        # step).  `prepare_for_capture()` purges and rebuilds in front of the capture; a dead entry met here stays in the
+        # table for this launch (its output buffer is still owned by the entry, its weight's memory is still mapped).
+        cap = capturing()
+        if not cap:
+            self.purge()
         hit = self.tables.get(dev)
+        if hit is None and cap:
+            raise RuntimeError("a linear layer's W^T operand was first requested while a step was being recorded: run the step "
+                               "eagerly once (GraphedTrainingStep's warm-up) before recording it")
         if hit is None:
             keys = [k for k in self.entries if k[0] == dev]
             rows = [[k[1], self.entries[k][1].data_ptr(), k[2], k[3]] for k in keys]
@@ -165,10 +175,22 @@ class _WtPackGroup:
                                                             C.c_void_p(_hip.stream_ptr(device))),
                    "isi_pack_linear_wT_bf16_multi")
         for k in keys:
-            e = self.entries[k]
-            owner = e[0]()
+            e = self.entries.get(k)
+            owner = e[0]() if e is not None else None
             if owner is not None:
                 e[2] = _hip.version_of(owner)
+
+    def prepare_for_capture(self) -> None:
+        """Called right before a step is recorded (after the warm-up steps and the garbage collection in front of the
+        capture): dead entries dropped and every device's table rebuilt NOW, so that the recorded step's one re-pack launch
+        finds its table and drops nothing."""
+        self.purge()
+        for dev in sorted({k[0] for k in self.entries}):
+            if dev not in self.tables:
+                keys = [k for k in self.entries if k[0] == dev]
+                rows = [[k[1], self.entries[k][1].data_ptr(), k[2], k[3]] for k in keys]
+                device = self.entries[keys[0]][1].device
+                self.tables[dev] = (keys, torch.tensor(rows, dtype=torch.int64).to(device))
 
 
 _WT_GROUP = _WtPackGroup()

@@ -96,6 +96,9 @@ class HipGraphBackend:
         import gc
         torch.cuda.synchronize(self.device)
         gc.collect()
+        # caches that would otherwise drop dead entries / rebuild host-built tables INSIDE the capture (priors/_ops.py)
+        from ...priors import _ops
+        _ops._WT_GROUP.prepare_for_capture()
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         self._ctx = torch.cuda.stream(self.stream)
         self._ctx.__enter__()

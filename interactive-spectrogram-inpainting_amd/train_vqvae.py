@@ -200,7 +200,9 @@ def get_reconstruction_criterion(criterion_id: str, spectrograms_helper=None):
     """reference train_vqvae.py:82-98: 'MSE' on the spectrograms, or a multi-scale spectral loss on the audio both
     spectrograms invert to ('Jukebox' / 'DDSP'; needs the helper that defines the inversion)."""
     if criterion_id == 'MSE':
-        return nn.MSELoss()
+        # `nn.MSELoss()` on the HIP library (same value, fixed summation order; no memset node in a recorded step)
+        from interactive_spectrogram_inpainting.utils.losses.mse import MSELoss
+        return MSELoss()
     from interactive_spectrogram_inpainting.utils.losses.spectral import (
         DDSPMultiscaleSpectralLoss_fromSpectrogram, JukeboxMultiscaleSpectralLoss_fromSpectrogram)
     if criterion_id in ('Jukebox', 'JukeboxMultiscaleSpectralLoss'):

@@ -762,6 +762,28 @@ def test_graphed_training_step_draws_fresh_dropout_masks():
         assert (a != b) == differ, (p, a, b)
 
 
+def test_replayed_steps_stay_finite_over_many_recordings():
+    """Regression (round 5): ~3 % of the toy model's replayed steps came back with NaN parameter gradients -- reductions that
+    read unwritten partial sums -- whenever freed memory held NaNs: a hipMemsetAsync NODE (the attention backward's
+    zero-fill of its band buffer) inside the replayed HIP graph was not ordered with the kernels around it (ROCm 7.2, graph
+    packet capture; 0 of 300 with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, and 0 of 300 since the library zero-fills with a kernel).
+    25 recordings with NaN-filled freed blocks in front of each: every gradient of every first replay is finite."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting.utils.training.graphed_step import GraphedTrainingStep
+    for i in range(25):
+        junk = torch.full((1 << (20 + i % 6),), float("nan"), device=_dev())
+        del junk
+        model, step, batches = _toy_training_setup(0.0, lr=0.0, capturable=True)
+        graphed = GraphedTrainingStep(step, (batches[0][0].clone(), batches[0][1].clone()), warmup=1)
+        try:
+            loss = float(graphed(*batches[1]).detach())
+            bad = [n for n, q in model.named_parameters() if q.grad is not None and not torch.isfinite(q.grad).all()]
+            graphed.finish()
+        finally:
+            _ops.set_dropout_seed_base(None)
+        assert math.isfinite(loss) and not bad, (i, loss, bad[:4])
+
+
 def test_weight_leaving_the_f16_range_mid_training_is_loud():
     """a weight under training is compared against the split-f16 operand range only every ~256 versions
     (`_ops.WeightRange`).  A weight that leaves the range INSIDE that window must not give silently wrong products: the

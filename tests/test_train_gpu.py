@@ -791,6 +791,26 @@ def test_pair_only_tape_entries_give_the_same_gradients(monkeypatch):
         assert _rel(grads[True][n], grads[False][n]) < 2e-5, n
 
 
+def test_mse_loss_kernels_against_torch():
+    """utils/losses/mse.py (reference train_vqvae.py:168-176, `nn.MSELoss()`): value and both gradients against torch's for
+    a batch of spectrograms and for sizes that are not multiples of 4 / smaller than a workgroup's share."""
+    from interactive_spectrogram_inpainting.utils.losses.mse import MSELoss, mse_loss
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    for shape in ((8, 2, 128, 512), (3, 5, 7), (1,), (2, 1027)):
+        a = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+        b = torch.randn(*shape, generator=g).to(dev).requires_grad_(True)
+        a0, b0 = a.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+        ref = torch.nn.functional.mse_loss(a0, b0)
+        (ref * 3.0).backward()
+        got = MSELoss()(a, b)
+        (got * 3.0).backward()
+        assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref)), shape
+        assert _rel(a.grad, a0.grad) < 1e-6 and _rel(b.grad, b0.grad) < 1e-6, shape
+    x = torch.randn(4, 4, device=dev)
+    assert torch.equal(mse_loss(x, x), torch.zeros((), device=dev))
+
+
 def test_fused_training_quantizer_is_bit_identical(monkeypatch):
     """Round 5: the training forward runs quantize_conv_* + the codebook search as the eval path's ONE launch
     (isi_vq_conv1x1_nearest_tape_f32: z written for the backward / EMA sums, q with its pair twin for the decoders) instead of

@@ -27,6 +27,7 @@ from __future__ import annotations
 
 import copy
 import math
+import weakref
 import os
 from typing import List, Optional, Tuple, Union
 
@@ -115,6 +116,12 @@ def _classify_mask(mask: MaskArg, Sq: int, Sk: int, device) -> Tuple[int, Option
     # optimizer-step count of _hip.version_of would miss after every step: a host sync and a D2H copy each time)
     key = (m.data_ptr(), m._version, tuple(m.shape), m.device)
     hit = _classify_mask.cache.get(key)
+    if hit is not None:
+        # (the key is an address: a verdict only stands for the tensor it was formed on -- another mask allocated where a
+        # dead one lived must not inherit it)
+        ref, hit = hit
+        if ref() is not mask:
+            hit = None
     if hit is None:
         allowed = (m.cpu() == 0)
         tril = torch.ones(Sq, Sk, dtype=torch.bool).tril()
@@ -128,7 +135,7 @@ def _classify_mask(mask: MaskArg, Sq: int, Sk: int, device) -> Tuple[int, Option
             hit = -1
         if len(_classify_mask.cache) > 64:
             _classify_mask.cache.clear()
-        _classify_mask.cache[key] = hit
+        _classify_mask.cache[key] = (weakref.ref(mask), hit)
     if hit >= 0:
         return hit, None
     return 0, m.to(device=device, dtype=torch.float32).contiguous()

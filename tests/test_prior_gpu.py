@@ -764,6 +764,32 @@ def test_sample_model_at_baseline_size_matches_full_pass_sampling():
     assert (got != ref).sum().item() <= 1, f"{(got != ref).sum().item()} of 32 sampled codes differ"
 
 
+def test_batched_decoding_on_matrix_tiles_at_baseline_size():
+    """Round 5: with more than 16 sequences a decoding stage runs as 32-row tiles on the fp32 matrix pipe
+    (csrc/prior_decode.hip: row_mfma32_kernel; K = 512 in one LDS chunk, K = 2048 -- linear2 -- in four, LayerNorm folded into
+    the staging, residual LayerNorm in the epilogue).  BASELINE config 5's top prior (d_model 512, 6 + 8 layers, [32,32] map), a
+    32-token mask, B = 20: every checked row draws the codes of its single-sequence run (GEMV kernels; the tile kernel sums in
+    another order, so a draw sitting on a CDF step may move: at most one code per row)."""
+    import sample as S
+    top = _full_top()
+    dev = _dev()
+    B = 20
+    g = torch.Generator().manual_seed(29)
+    init = torch.randint(0, 512, (B, 32, 32), generator=g)
+    mask = torch.zeros(1, 32, 32, dtype=torch.bool)
+    mask[:, :, 11] = True
+    cls = {"pitch": torch.tensor([30]), "instrument_family_str": torch.tensor([5])}
+    uni = torch.rand(top.target_transformer_sequence_length, B, generator=g)
+    out = S.sample_model(top, dev, B, [32, 32], temperature=1.0, class_conditioning=cls, initial_code=init.clone(), mask=mask,
+                         top_p_sampling_p=0.8, uniforms=uni)
+    keep = ~mask.expand(B, -1, -1)
+    assert torch.equal(out.cpu()[keep], init[keep])
+    for b in (0, 7, 19):
+        solo = S.sample_model(top, dev, 1, [32, 32], temperature=1.0, class_conditioning=cls, initial_code=init[b:b + 1].clone(),
+                              mask=mask, top_p_sampling_p=0.8, uniforms=uni[:, b:b + 1].contiguous())
+        assert (solo[0] != out[b]).sum().item() <= 1, (b, (solo[0] != out[b]).sum().item())
+
+
 @pytest.mark.parametrize("Sq,Sk,Cq,Ck,mode", [(1025, 1025, 1, 1, 1), (4100, 1025, 4, 1, 0), (200, 200, 1, 1, 2), (77, 150, 2, 1, 0)])
 def test_rel_attention_bf16_mode(Sq, Sk, Cq, Ck, mode, monkeypatch):
     """precision = 'bf16' (north_star: relative-attention contractions on MFMA bf16, single term): operands rounded

@@ -124,7 +124,7 @@ int sample_row_pos_f32(const float *logits, int stride, int rows, int n, float t
 int sample_row_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                    const float *u, int64_t *out, float *filtered, hipStream_t stream);
 
-int rel_attention_decode_splits(int Sk);
+int rel_attention_decode_splits(int Sk, int pairs);
 int attention_tail_rows(int S, int mask_mode, bool dense_mask);   // rel_attention_f32.hip
 int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
                                 int combine, hipStream_t stream);

@@ -541,8 +541,12 @@ __device__ __forceinline__ void mfma_row_stats(const RowLinArgs &a, float *__res
   }
 }
 
-__global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a) {
+// `ksplit_ws` != nullptr (K beyond one chunk on a grid too small to fill the chip: linear2 of a feed-forward block, 16 tiles at
+// N = 512): grid z = the K chunk, a workgroup multiplies ONE chunk and leaves its raw 32 x 32 sums in ksplit_ws[z][M][N];
+// row_mfma_finish_kernel adds the chunks in order and applies bias / residual / ReLU (33.8 -> ~13 us for that stage at B = 32).
+__global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a, float *__restrict__ ksplit_ws) {
   touch_args(a);
+  asm volatile("" ::"s"(ksplit_ws));
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float *xs = sm;                         // [32][MF_LD] normalised input rows of the chunk
   float *stat = xs + 32 * MF_LD;          // [32][4] input mean / rstd, residual mean / rstd
@@ -576,18 +580,20 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a) {
                                       : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  request_chunk(0);
+  const int kc_begin = ksplit_ws ? (int)blockIdx.z * MF_KC : 0;
+  const int kc_end = ksplit_ws ? (kc_begin + MF_KC < a.K ? kc_begin + MF_KC : a.K) : a.K;
+  request_chunk(kc_begin);
   // the epilogue's per-feature values and residual entries (output o = tid + 256 q: row o >> 5, feature n0 + (tid & 31))
   const int nj = n0 + (tid & 31);
   const bool nok = nj < a.N;
   const float bias_v = (a.bias && nok) ? a.bias[nj] : 0.f;
   float rg = 1.f, rb = 0.f, resv[4];
-  const bool rln = a.res && a.res_g;
+  const bool rln = a.res && a.res_g && !ksplit_ws;
   if (rln && nok) { rg = a.res_g[nj]; rb = a.res_b[nj]; }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = (tid >> 5) + 8 * q;
-    resv[q] = (a.res && nok && i < Mt) ? a.res[(size_t)(m0 + i) * a.res_stride + nj] : 0.f;
+    resv[q] = (a.res && !ksplit_ws && nok && i < Mt) ? a.res[(size_t)(m0 + i) * a.res_stride + nj] : 0.f;
   }
   // ---- row statistics (wave w: rows 8 w .. 8 w + 7)
   if (a.ln_g) {
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a) {
   mf_f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int kc = 0; kc < a.K; kc += MF_KC) {
+  for (int kc = kc_begin; kc < kc_end; kc += MF_KC) {
     const int kcn = a.K - kc < MF_KC ? a.K - kc : MF_KC;
     const int cq = kcn >> 2;
     const int csh = (cq & (cq - 1)) == 0 ? __builtin_ctz(cq) : -1;
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a) {
 #pragma unroll
     for (int t = 0; t < 16; ++t) bc[t] = bw[t];
     __syncthreads();
-    if (kc + MF_KC < a.K) request_chunk(kc + MF_KC);      // the next chunk travels under this chunk's matrix work
+    if (kc + MF_KC < kc_end) request_chunk(kc + MF_KC);   // the next chunk travels under this chunk's matrix work
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       if (8 * (wave + 4 * t) < kcn) {        // (uniform per wave)
@@ -665,6 +671,10 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a) {
     const int i = (tid >> 5) + 8 * q, j = tid & 31;
     if (i < Mt && nok) {
       float v = (red[i * 33 + j] + red[(32 + i) * 33 + j]) + (red[(64 + i) * 33 + j] + red[(96 + i) * 33 + j]);
+      if (ksplit_ws) {       // raw sums of this K chunk; row_mfma_finish_kernel does the rest
+        ksplit_ws[((size_t)blockIdx.z * a.M + (m0 + i)) * a.N + nj] = v;
+        continue;
+      }
       v += bias_v;
       if (a.res) {
         float r = resv[q];
@@ -679,12 +689,52 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a) {
   }
 }
 
+// one workgroup per row: the K chunks' sums in chunk order, then bias / (normalised) residual / ReLU as in the tile kernel
+__global__ __launch_bounds__(256) void row_mfma_finish_kernel(RowLinArgs a, const float *__restrict__ ws, int nz) {
+  touch_args(a);
+  __shared__ float red[8];
+  long ppos = 0;
+  if (a.pos) ppos = *a.pos;
+  if (a.res && a.res_pos) a.res += ppos * a.res_pos;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool rln = a.res && a.res_g;
+  float rmean = 0.f, rrstd = 1.f;
+  if (rln) {
+    const float *rr = a.res + (size_t)m * a.res_stride;
+    float s_ = 0.f;
+    for (int i = tid; i < a.N; i += 256) s_ += rr[i];
+    s_ = wave_sum(s_);
+    if (lane == 0) red[wave] = s_;
+    __syncthreads();
+    rmean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)a.N;
+    float var = 0.f;
+    for (int i = tid; i < a.N; i += 256) { const float d = rr[i] - rmean; var += d * d; }
+    var = wave_sum(var);
+    if (lane == 0) red[4 + wave] = var;
+    __syncthreads();
+    rrstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (float)a.N + a.eps);
+  }
+  for (int n = tid; n < a.N; n += 256) {
+    float v = 0.f;
+    for (int z = 0; z < nz; ++z) v += ws[((size_t)z * a.M + m) * a.N + n];
+    v += a.bias ? a.bias[n] : 0.f;
+    if (a.res) {
+      float r = a.res[(size_t)m * a.res_stride + n];
+      if (rln) r = (r - rmean) * rrstd * a.res_g[n] + a.res_b[n];
+      v += r;
+    }
+    if (a.relu) v = fmaxf(v, 0.f);
+    if (n < a.split) a.out[(size_t)m * a.out_stride + n] = v;
+    else a.out2[ppos * a.out2_pos + (size_t)m * a.out2_stride + (n - a.split)] = v;
+  }
+}
+
 bool row_mfma_supported(const RowLinArgs &a) {
   return a.M >= 2 && (a.K & 7) == 0 && (a.x_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(a.W) & 15) == 0 && (!a.ln_g || ((reinterpret_cast<uintptr_t>(a.ln_g) | reinterpret_cast<uintptr_t>(a.ln_b)) & 15) == 0);
 }
 
-int launch_row_mfma(const RowLinArgs &a, hipStream_t st) {
+int launch_row_mfma(const RowLinArgs &a, hipStream_t st, float *ksplit_ws = nullptr, size_t ksplit_floats = 0) {
   static DeviceOnce attr_set;       // once, outside any stream capture (the first position runs direct)
   if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(row_mfma32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -692,7 +742,15 @@ int launch_row_mfma(const RowLinArgs &a, hipStream_t st) {
       return check_launch("hipFuncSetAttribute(row_mfma32)");
     attr_set.mark();
   }
-  hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32), dim3(256), kRowMfmaLds, st, a);
+  const int tiles = ((a.N + 31) / 32) * ((a.M + 31) / 32), nz = (a.K + MF_KC - 1) / MF_KC;
+  if (nz > 1 && tiles < 128 && ksplit_ws && (size_t)nz * a.M * a.N <= ksplit_floats) {
+    hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32, nz), dim3(256), kRowMfmaLds, st, a, ksplit_ws);
+    int rc = check_launch("row_mfma32 (K chunks)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(row_mfma_finish_kernel, dim3(a.M), dim3(256), 0, st, a, ksplit_ws, nz);
+    return check_launch("row_mfma_finish");
+  }
+  hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32), dim3(256), kRowMfmaLds, st, a, (float *)nullptr);
   return check_launch("row_mfma32");
 }
 
@@ -784,12 +842,16 @@ __global__ void set_pos_kernel(int *pos, int value, int add) { *pos = add ? *pos
 
 }  // namespace
 
+// partial sums of the K chunks of linear2 (K = dim_feedforward, N = d_model) when a batch decodes on matrix tiles
+static size_t mfma_ksplit_floats(const isi_prior_w *w, int B) {
+  return 4 + (size_t)B * ((w->dim_feedforward + MF_KC - 1) / MF_KC) * w->d_model;
+}
 size_t prior_decode_scratch_floats(const isi_prior_w *w, int B) {
   if (!w || B <= 0) return 0;
   const size_t d = w->d_model;
   // q, attn out, y1, y2, y3(a), y3(b), hidden, logits, sampled(int64)
   return (size_t)B * (6 * d + w->dim_feedforward + w->n_class) + 2 * (size_t)B + 64 + 32 +
-         rel_attention_decode_workspace_floats(B, w->nhead, w->d_model / w->nhead);
+         rel_attention_decode_workspace_floats(B, w->nhead, w->d_model / w->nhead) + mfma_ksplit_floats(w, B);
 }
 
 int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin, int p_end, float temperature,
@@ -816,6 +878,8 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
 
   int *pos = reinterpret_cast<int *>(attn_ws + rel_attention_decode_workspace_floats(B, w->nhead, hd));
   pos = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(pos) + 15) & ~(uintptr_t)15);
+  float *mf_ws = reinterpret_cast<float *>(pos + 4);                     // (16-byte aligned: K-chunk sums of row_mfma32_kernel)
+  const size_t mf_ws_floats = mfma_ksplit_floats(w, B) - 4;
   const int i_off = s->start_len - 1;   // token index predicted from position p is p - i_off
 
   // Every launch of one position; all position-dependent addresses and sizes are derived on the device
@@ -836,7 +900,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       if (row_gemv1_supported(a, part != nullptr)) return launch_row_gemv1(a, part, ns, hd, q_st);
       // batches: beyond `decode_mfma_rows` rows the stage is a tile GEMM on the fp32 matrix pipe; up to there every row in one
       // launch of the register-resident GEMV kernel (the rows pass through in groups)
-      if (a.M > knobs().decode_mfma_rows && row_mfma_supported(a)) return launch_row_mfma(a, q_st);
+      if (a.M > knobs().decode_mfma_rows && row_mfma_supported(a)) return launch_row_mfma(a, q_st, mf_ws, mf_ws_floats);
       if (row_gemvm_supported(a)) return launch_row_gemvm(a, q_st);
       for (int m0 = 0; m0 < a.M; m0 += 8) {
         RowLinArgs g8 = a;
@@ -851,7 +915,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       return ISI_OK;
     };
     // the attention's splits are merged by the out-projection when that runs as the one-row kernel
-    const int ns_self = rel_attention_decode_splits(s->S_t), ns_cross = rel_attention_decode_splits(s->S_src);
+    const int ns_self = rel_attention_decode_splits(s->S_t, B * w->nhead), ns_cross = rel_attention_decode_splits(s->S_src, B * w->nhead);
     const bool merge_in_gemv = B == 1 && d <= 512 && (d & 3) == 0;
     const float *yin = s->x_seq;     // + p * B * d through x_pos / res_pos
     long yin_pos = (long)B * d;

@@ -377,7 +377,14 @@ __global__ void rel_attention_combine_kernel(const float *__restrict__ partial, 
   out[b * o_sb + h * o_sh + d] = num * (1.0f / den);
 }
 
-int rel_attention_decode_splits(int Sk) { return Sk <= 192 ? 1 : (Sk + 127) / 128 > 8 ? 8 : (Sk + 127) / 128; }
+// key splits of one (batch, head) pair: 128 keys each, at most 8 -- and no more than it takes to put ~512 workgroups on the
+// chip: a batch of 32 sequences x 8 heads already fills it (2 splits instead of 8: 22.7 + 5.4 us -> see DESIGN.md section 7,
+// batched decoding), a single sequence takes all 8
+int rel_attention_decode_splits(int Sk, int pairs) {
+  const int by_keys = Sk <= 192 ? 1 : (Sk + 127) / 128 > 8 ? 8 : (Sk + 127) / 128;
+  const int by_chip = pairs <= 0 ? 8 : (512 + pairs - 1) / pairs;
+  return by_keys < by_chip ? by_keys : (by_chip < 1 ? 1 : by_chip);
+}
 
 size_t rel_attention_decode_workspace_floats(int B, int H, int head_dim) {
   return (size_t)B * H * 8 * (head_dim + 4);
@@ -402,7 +409,7 @@ int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *po
   if (!g || !g->q || !g->k || !g->v || !g->out) return invalid("attention_decode: null pointer");
   if (g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->Cq <= 0 || g->Ck <= 0) return invalid("attention_decode: bad shape");
   if (g->Sk > 65536) return unsupported("attention_decode: more than 65536 keys");
-  const int ns = workspace ? rel_attention_decode_splits(g->Sk) : 1;
+  const int ns = workspace ? rel_attention_decode_splits(g->Sk, g->B * g->H) : 1;
   // self_keys with the position by value: position + 1 keys, shared by the split count of the upper bound g->Sk
   // (the same split as the replayable form derives on the device)
   const int Sk = (self_keys && !pos) ? q_pos + 1 : g->Sk;

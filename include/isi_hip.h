@@ -534,6 +534,20 @@ int isi_linear_rows_f32(const float *x, int x_stride, const float *W, const floa
                         const float *residual, int res_stride, float *out, int out_stride,
                         int M, int N, int K, int relu, void *stream);
 
+/* One stage of the KV-cached decoding loop on M <= 256 new rows (sample.py:268-305 -> priors/transformer.py:763-774 evaluate a
+ * whole decoder pass per token; the loop evaluates its stages on the new rows only):
+ *   out[m][n] = act( sum_k LN(x)[m][k] W[n][k] + bias[n] + LN_res(res)[m][n] )
+ * LN = LayerNorm over the row with (ln_g, ln_b) (nullable: none), LN_res likewise with (res_g, res_b) over the N features of
+ * the residual row (nullable; res nullable), act = ReLU when `relu`.  Kernels by row count: one row = one memory round trip
+ * (GEMV), up to ISI_DECODE_MFMA_ROWS (16) rows the register-resident GEMV looping over groups of rows (each row: the operations and the order
+ * of its one-row result), beyond that 32-row tiles on the fp32 matrix pipe (exact fp32 products, another summation order).
+ * K a multiple of 4 (8 for the tiles), <= 2048; x, W 16-byte aligned.  `workspace`: isi_decode_stage_workspace_floats(M, N, K)
+ * floats, 16-byte aligned (K-chunk sums of the tile kernel; may be null: the chunks then run one after the other). */
+size_t isi_decode_stage_workspace_floats(int M, int N, int K);
+int isi_decode_stage_f32(const float *x, int x_stride, const float *ln_g, const float *ln_b, const float *W, const float *bias,
+                         const float *res, int res_stride, const float *res_g, const float *res_b, float *out, int out_stride,
+                         int M, int N, int K, int relu, float eps, float *workspace, size_t workspace_floats, void *stream);
+
 /* Decoding step: ONE query row per (batch, head) at sequence position q_pos
  * against args->Sk cached keys/values (same logits as isi_rel_attention_f32;
  * args->Sq, q_ss, o_ss, mask_mode and dense_mask are ignored: the caller passes

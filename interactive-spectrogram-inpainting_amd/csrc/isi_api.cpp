@@ -326,6 +326,13 @@ int isi_linear_rows_f32(const float *x, int x_stride, const float *W, const floa
   return linear_rows_f32(x, x_stride, W, bias, residual, res_stride, out, out_stride, M, N, K, relu, S(stream));
 }
 
+size_t isi_decode_stage_workspace_floats(int M, int N, int K) { return decode_stage_workspace_floats(M, N, K); }
+int isi_decode_stage_f32(const float *x, int x_stride, const float *ln_g, const float *ln_b, const float *W, const float *bias,
+                         const float *res, int res_stride, const float *res_g, const float *res_b, float *out, int out_stride,
+                         int M, int N, int K, int relu, float eps, float *workspace, size_t workspace_floats, void *stream) {
+  return decode_stage_f32(x, x_stride, ln_g, ln_b, W, bias, res, res_stride, res_g, res_b, out, out_stride, M, N, K, relu, eps,
+                          workspace, workspace_floats, S(stream));
+}
 int isi_rel_attention_decode_f32(const isi_attn_args *args, int q_pos, float *workspace, void *stream) {
   return rel_attention_decode_f32(args, q_pos, workspace, S(stream));
 }

@@ -128,6 +128,10 @@ int rel_attention_decode_splits(int Sk, int pairs);
 int attention_tail_rows(int S, int mask_mode, bool dense_mask);   // rel_attention_f32.hip
 int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *pos, int self_keys, float *workspace,
                                 int combine, hipStream_t stream);
+size_t decode_stage_workspace_floats(int M, int N, int K);
+int decode_stage_f32(const float *x, int x_stride, const float *ln_g, const float *ln_b, const float *W, const float *bias,
+                     const float *res, int res_stride, const float *res_g, const float *res_b, float *out, int out_stride,
+                     int M, int N, int K, int relu, float eps, float *workspace, size_t workspace_floats, hipStream_t st);
 size_t prior_decode_scratch_floats(const isi_prior_w *w, int B);
 int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin, int p_end, float temperature,
                      int top_k, float top_p, hipStream_t stream);

@@ -31,7 +31,7 @@ struct Knobs {
   int attn_old_fwd;             // ISI_ATTN_OLD_FWD: the round-3 forward kernel (32-key tiles) for the 16-bit modes (A/B switch)
   int prior_graph;              // ISI_PRIOR_GRAPH: positions per replayed hipGraph of the decode loop (8; 0 = direct launches)
   int decode_mfma_rows;         // ISI_DECODE_MFMA_ROWS: batched decoding runs a stage as a 32-row GEMM tile on the fp32 matrix pipe for MORE
-                                // rows than this (16); up to it, the GEMV kernels whose rows are bit-identical to batch 1
+                                // rows than this (16); up to it, the GEMV kernels (batch 1's operation order)
   int cu_count;                 // ISI_CU_COUNT: compute units the persistent kernels size their grids for (0: the device's); for
                                 // launches on a stream that owns a SUBSET of the chip (hipExtStreamCreateWithCUMask; measurements)
   int conv_ablate, vq_dbg, respair_abl;   // ISI_MEASURE builds only

@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
 // their accumulators meet in LDS.  Lane (i, kk) feeds four consecutive k of its row / feature per 16-byte read --
 // k = 8 j + 4 kk -- to four MFMAs: A from LDS, B (the weight row of feature n0 + i) straight from memory.  A row's result
 // does not depend on the rows it shares the tile with, but its summation order differs from the one-row kernels': batch-1
-// decoding and batches of up to `decode_mfma_rows` rows keep the GEMV kernels above (bit-identical among themselves).
+// decoding and batches of up to `decode_mfma_rows` rows keep the GEMV kernels above (one operation order: equal up to the
+// compiler's contraction, a few ulp).
 // Measured (tools/kt_sampling_b32.sh, B = 32): 17.9 us per launch on average against 23.5 for the GEMV kernel looping over
 // four groups of 8 rows (and 4 x ~10 for the four launches of round 4); 10.7 us of it is the skeleton (requests, staging,
 // three barriers, epilogue), 4.2 the LayerNorm statistics, 3.0 the matrix instructions.  At 8 rows the GEMV kernel wins
@@ -840,7 +841,47 @@ int launch_row_linear_8(const RowLinArgs &a, hipStream_t st) {
 
 __global__ void set_pos_kernel(int *pos, int value, int add) { *pos = add ? *pos + value : value; }
 
+// One stage of the decoding loop on M rows: the kernel by row count.  `part` != nullptr (one row): the input row is the
+// merge of that attention's key-split partials.
+int launch_stage_rows(const RowLinArgs &a, const float *part, int ns, int hd, float *mf_ws, size_t mf_ws_floats, hipStream_t q_st) {
+  if (row_gemv1_supported(a, part != nullptr)) return launch_row_gemv1(a, part, ns, hd, q_st);
+  // batches: beyond `decode_mfma_rows` rows the stage is a tile GEMM on the fp32 matrix pipe; up to there every row in one
+  // launch of the register-resident GEMV kernel (the rows pass through in groups)
+  if (a.M > knobs().decode_mfma_rows && row_mfma_supported(a)) return launch_row_mfma(a, q_st, mf_ws, mf_ws_floats);
+  if (row_gemvm_supported(a)) return launch_row_gemvm(a, q_st);
+  for (int m0 = 0; m0 < a.M; m0 += 8) {
+    RowLinArgs g8 = a;
+    g8.M = a.M - m0 < 8 ? a.M - m0 : 8;
+    g8.x += (size_t)m0 * a.x_stride;
+    if (g8.res) g8.res += (size_t)m0 * a.res_stride;
+    g8.out += (size_t)m0 * a.out_stride;
+    if (g8.out2) g8.out2 += (size_t)m0 * a.out2_stride;
+    const int rc8 = row_gemvm_supported(g8) ? launch_row_gemvm(g8, q_st) : launch_row_linear(g8, q_st);
+    if (rc8) return rc8;
+  }
+  return ISI_OK;
+}
+
 }  // namespace
+
+// A decoding-loop stage on its own (isi_decode_stage_f32): out[M][N] = act(LN(x)[M][K] W[N][K]^T + bias + LN_res(res)), the
+// kernels prior_sample_run launches for M rows.  workspace: decode_stage_workspace_floats(M, N, K) floats, 16-byte aligned.
+size_t decode_stage_workspace_floats(int M, int N, int K) { return 4 + (size_t)M * ((K + MF_KC - 1) / MF_KC) * N; }
+int decode_stage_f32(const float *x, int x_stride, const float *ln_g, const float *ln_b, const float *W, const float *bias,
+                     const float *res, int res_stride, const float *res_g, const float *res_b, float *out, int out_stride,
+                     int M, int N, int K, int relu, float eps, float *workspace, size_t workspace_floats, hipStream_t st) {
+  if (!x || !W || !out || M <= 0 || M > 256 || N <= 0 || K <= 0) return invalid("decode_stage: bad argument");
+  if ((K & 3) || (x_stride & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15))
+    return invalid("decode_stage: K and x_stride must be multiples of 4, x and W 16-byte aligned");
+  if ((ln_g == nullptr) != (ln_b == nullptr) || (res_g == nullptr) != (res_b == nullptr) || (res_g && !res))
+    return invalid("decode_stage: LayerNorm weight and bias come together (and the residual's with a residual)");
+  if (res_g && N > 512) return unsupported("decode_stage: a normalised residual has at most 512 features");
+  if (K > 2048) return unsupported("decode_stage: K <= 2048");
+  RowLinArgs a{x, x_stride, ln_g, ln_b, W, bias, res, res_stride, res_g, res_b, out, out_stride, nullptr, 0, N, M, N, K,
+               relu ? 1 : 0, eps, nullptr, 0, 0, 0};
+  float *ws = (workspace && !(reinterpret_cast<uintptr_t>(workspace) & 15)) ? workspace : nullptr;
+  return launch_stage_rows(a, nullptr, 1, 64, ws, ws ? workspace_floats : 0, st);
+}
 
 // partial sums of the K chunks of linear2 (K = dim_feedforward, N = d_model) when a batch decodes on matrix tiles
 static size_t mfma_ksplit_floats(const isi_prior_w *w, int B) {
@@ -897,22 +938,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
         a.pos = nullptr;
       }
       if (!a.x_pos && !a.res_pos && !a.out2_pos) a.pos = nullptr;      // nothing of this launch depends on the position
-      if (row_gemv1_supported(a, part != nullptr)) return launch_row_gemv1(a, part, ns, hd, q_st);
-      // batches: beyond `decode_mfma_rows` rows the stage is a tile GEMM on the fp32 matrix pipe; up to there every row in one
-      // launch of the register-resident GEMV kernel (the rows pass through in groups)
-      if (a.M > knobs().decode_mfma_rows && row_mfma_supported(a)) return launch_row_mfma(a, q_st, mf_ws, mf_ws_floats);
-      if (row_gemvm_supported(a)) return launch_row_gemvm(a, q_st);
-      for (int m0 = 0; m0 < a.M; m0 += 8) {
-        RowLinArgs g8 = a;
-        g8.M = a.M - m0 < 8 ? a.M - m0 : 8;
-        g8.x += (size_t)m0 * a.x_stride;
-        if (g8.res) g8.res += (size_t)m0 * a.res_stride;
-        g8.out += (size_t)m0 * a.out_stride;
-        if (g8.out2) g8.out2 += (size_t)m0 * a.out2_stride;
-        const int rc8 = row_gemvm_supported(g8) ? launch_row_gemvm(g8, q_st) : launch_row_linear(g8, q_st);
-        if (rc8) return rc8;
-      }
-      return ISI_OK;
+      return launch_stage_rows(a, part, ns, hd, mf_ws, mf_ws_floats, q_st);
     };
     // the attention's splits are merged by the out-projection when that runs as the one-row kernel
     const int ns_self = rel_attention_decode_splits(s->S_t, B * w->nhead), ns_cross = rel_attention_decode_splits(s->S_src, B * w->nhead);

@@ -246,6 +246,9 @@ SIGNATURES = {
                                                   _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_vq_conv1x1_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "isi_vq_conv1x1_fusable": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "isi_decode_stage_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "isi_decode_stage_f32": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_float, _P, C.c_size_t, _P]),
     "isi_mse_loss_num_partials": (C.c_int, [C.c_int64]),
     "isi_mse_loss_f32": (C.c_int, [_P, _P, C.c_int64, _P, _P, _P]),
     "isi_mse_loss_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P, _P, _P]),

@@ -764,6 +764,76 @@ def test_sample_model_at_baseline_size_matches_full_pass_sampling():
     assert (got != ref).sum().item() <= 1, f"{(got != ref).sum().item()} of 32 sampled codes differ"
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 512, 512), (3, 192, 64), (8, 512, 2048), (17, 512, 512), (20, 48, 96), (32, 1536, 512),
+                                   (33, 512, 2048), (40, 1024, 768), (64, 2048, 512), (256, 512, 512)])
+def test_decode_stage_kernels_against_torch(M, N, K):
+    """isi_decode_stage_f32 = one stage of the KV-cached decoding loop on M new rows (csrc/prior_decode.hip): LayerNorm of the
+    input rows folded in, bias, LayerNorm-ed residual, ReLU -- against torch in fp64, through every kernel family: the
+    one-row GEMV, the GEMV looping over groups of rows (ISI_DECODE_MFMA_ROWS = 256), and the 32-row fp32-MFMA tiles
+    (ISI_DECODE_MFMA_ROWS = 1; K in one chunk, in several, with a short last chunk; N not a multiple of 32; the K chunks
+    side by side with the finishing launch when a workspace is given, one after the other without).  A row of a batch
+    on the GEMV family equals the row alone up to the compiler's contraction of the same operations (a few ulp)."""
+    import ctypes as C
+    from interactive_spectrogram_inpainting import _hip
+    dev = _dev()
+    L = _hip.lib()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    ln_g, ln_b = (1 + 0.1 * torch.randn(K, generator=g)).to(dev), (0.1 * torch.randn(K, generator=g)).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    res_g, res_b = (1 + 0.1 * torch.randn(N, generator=g)).to(dev), (0.1 * torch.randn(N, generator=g)).to(dev)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(ln, rs, rln, relu, rows_switch, with_ws=True, m=M, x_=None):
+        x_ = x if x_ is None else x_
+        out = torch.full((m, N), float("nan"), device=dev)
+        nws = L.isi_decode_stage_workspace_floats(m, N, K)
+        ws = torch.empty(nws, device=dev) if with_ws else None
+        with _hip.knob("ISI_DECODE_MFMA_ROWS", rows_switch):
+            _hip.check(L.isi_decode_stage_f32(x_.data_ptr(), K, ln_g.data_ptr() if ln else None, ln_b.data_ptr() if ln else None,
+                                              W.data_ptr(), bias.data_ptr(), res.data_ptr() if rs else None, N,
+                                              res_g.data_ptr() if rln else None, res_b.data_ptr() if rln else None,
+                                              out.data_ptr(), N, m, N, K, int(relu), 1e-5,
+                                              ws.data_ptr() if ws is not None else None, nws if ws is not None else 0, s),
+                       "isi_decode_stage_f32")
+        return out
+
+    def ref(ln, rs, rln, relu):
+        xd = x.double()
+        if ln:
+            xd = torch.nn.functional.layer_norm(xd, (K,), ln_g.double(), ln_b.double(), 1e-5)
+        y = xd @ W.double().t() + bias.double()
+        if rs:
+            r = res.double()
+            if rln:
+                r = torch.nn.functional.layer_norm(r, (N,), res_g.double(), res_b.double(), 1e-5)
+            y = y + r
+        return torch.relu(y) if relu else y
+
+    for ln, rs, rln, relu in ((True, True, N <= 512, False), (False, True, False, True), (True, False, False, True),
+                              (False, False, False, False)):
+        want = ref(ln, rs, rln, relu)
+        scale = float(want.abs().max())
+        gemv = run(ln, rs, rln, relu, 256)
+        assert float((gemv.double() - want).abs().max()) < 2e-5 * scale, ("gemv", ln, rs, rln, relu)
+        if M >= 2 and K % 8 == 0:
+            for with_ws in (True, False):
+                tiles = run(ln, rs, rln, relu, 1, with_ws)
+                assert float((tiles.double() - want).abs().max()) < 2e-5 * scale, ("tiles", ln, rs, rln, relu, with_ws)
+    if 1 < M <= 40:       # a row of a batch against the same row alone (GEMV family: same operations, same order)
+        batch = run(True, True, N <= 512, False, 256)
+        for r_ in (0, M - 1):
+            res_row = res[r_:r_ + 1].clone()
+            out1 = torch.full((1, N), float("nan"), device=dev)
+            _hip.check(L.isi_decode_stage_f32(x[r_:r_ + 1].contiguous().data_ptr(), K, ln_g.data_ptr(), ln_b.data_ptr(), W.data_ptr(),
+                                              bias.data_ptr(), res_row.data_ptr(), N, res_g.data_ptr() if N <= 512 else None,
+                                              res_b.data_ptr() if N <= 512 else None, out1.data_ptr(), N, 1, N, K, 0, 1e-5,
+                                              None, 0, s), "isi_decode_stage_f32")
+            assert float((out1[0] - batch[r_]).abs().max()) <= 4e-6 * float(batch[r_].abs().max()), r_
+
+
 def test_batched_decoding_on_matrix_tiles_at_baseline_size():
     """Round 5: with more than 16 sequences a decoding stage runs as 32-row tiles on the fp32 matrix pipe
     (csrc/prior_decode.hip: row_mfma32_kernel; K = 512 in one LDS chunk, K = 2048 -- linear2 -- in four, LayerNorm folded into

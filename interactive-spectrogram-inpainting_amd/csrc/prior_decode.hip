@@ -426,57 +426,81 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
         rrow[m][i] = (m < Mg && c < a.N) ? resg[(size_t)m * a.res_stride + c] : 0.f;
       }
   }
+  // the group's rows go through each phase TOGETHER (statistics, normalisation, products, reductions): MR independent chains
+  // of wave reductions interleave, where row after row every reduction waited for the one before (per row the operations
+  // and their order are unchanged)
+  if (a.ln_g) {
+    float mean[MR], rstd[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) {
-    if (m >= Mg) break;
-    if (a.ln_g) {
+    for (int m = 0; m < MR; ++m) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < KQ; ++i) if (lane + 64 * i < nq) s += (xv[m][i].x + xv[m][i].y) + (xv[m][i].z + xv[m][i].w);
-      const float mean = wave_sum(s) / (float)a.K;
+      mean[m] = wave_sum(s) / (float)a.K;
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
       float var = 0.f;
 #pragma unroll
       for (int i = 0; i < KQ; ++i) {
         if (lane + 64 * i < nq) {
-          const float d0 = xv[m][i].x - mean, d1 = xv[m][i].y - mean, d2 = xv[m][i].z - mean, d3 = xv[m][i].w - mean;
+          const float d0 = xv[m][i].x - mean[m], d1 = xv[m][i].y - mean[m], d2 = xv[m][i].z - mean[m], d3 = xv[m][i].w - mean[m];
           var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
       }
-      const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)a.K + a.eps);
+      rstd[m] = 1.0f / sqrtf(wave_sum(var) / (float)a.K + a.eps);
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
 #pragma unroll
       for (int i = 0; i < KQ; ++i) {
         if (lane + 64 * i < nq) {
-          xv[m][i].x = (xv[m][i].x - mean) * rstd * gq[i].x + bq[i].x; xv[m][i].y = (xv[m][i].y - mean) * rstd * gq[i].y + bq[i].y;
-          xv[m][i].z = (xv[m][i].z - mean) * rstd * gq[i].z + bq[i].z; xv[m][i].w = (xv[m][i].w - mean) * rstd * gq[i].w + bq[i].w;
+          xv[m][i].x = (xv[m][i].x - mean[m]) * rstd[m] * gq[i].x + bq[i].x; xv[m][i].y = (xv[m][i].y - mean[m]) * rstd[m] * gq[i].y + bq[i].y;
+          xv[m][i].z = (xv[m][i].z - mean[m]) * rstd[m] * gq[i].z + bq[i].z; xv[m][i].w = (xv[m][i].w - mean[m]) * rstd[m] * gq[i].w + bq[i].w;
         }
       }
-    }
-    float rmean = 0.f, rrstd = 1.f;
-    if (resg && a.res_g) {
+  }
+  float rmean[MR], rrstd[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) { rmean[m] = 0.f; rrstd[m] = 1.f; }
+  if (resg && a.res_g) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) s += rrow[m][i];
-      rmean = wave_sum(s) / (float)a.N;
+      rmean[m] = wave_sum(s) / (float)a.N;
+    }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
       float var = 0.f;
 #pragma unroll
-      for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) { const float dv = rrow[m][i] - rmean; var += dv * dv; }
-      rrstd = 1.0f / sqrtf(wave_sum(var) / (float)a.N + a.eps);
+      for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) { const float dv = rrow[m][i] - rmean[m]; var += dv * dv; }
+      rrstd[m] = 1.0f / sqrtf(wave_sum(var) / (float)a.N + a.eps);
     }
-    float acc0 = 0.f, acc1 = 0.f;
+  }
+  float acc0[MR], acc1[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int i = 0; i < KQ; ++i) {
       if (lane + 64 * i < nq) {
-        acc0 += (wa[i].x * xv[m][i].x + wa[i].y * xv[m][i].y) + (wa[i].z * xv[m][i].z + wa[i].w * xv[m][i].w);
-        acc1 += (wb[i].x * xv[m][i].x + wb[i].y * xv[m][i].y) + (wb[i].z * xv[m][i].z + wb[i].w * xv[m][i].w);
+        a0 += (wa[i].x * xv[m][i].x + wa[i].y * xv[m][i].y) + (wa[i].z * xv[m][i].z + wa[i].w * xv[m][i].w);
+        a1 += (wb[i].x * xv[m][i].x + wb[i].y * xv[m][i].y) + (wb[i].z * xv[m][i].z + wb[i].w * xv[m][i].w);
       }
     }
-    acc0 = wave_sum(acc0);
-    acc1 = wave_sum(acc1);
-    if (writer) {
-      float v = (lane == 0 ? acc0 : acc1) + bias_v;
+    acc0[m] = a0; acc1[m] = a1;
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) { acc0[m] = wave_sum(acc0[m]); acc1[m] = wave_sum(acc1[m]); }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    if (writer && m < Mg) {
+      float v = (lane == 0 ? acc0[m] : acc1[m]) + bias_v;
       if (resg) {
         float r = res_v[m];
-        if (a.res_g) r = (r - rmean) * rrstd * rg + rb;
+        if (a.res_g) r = (r - rmean[m]) * rrstd[m] * rg + rb;
         v += r;
       }
       if (a.relu) v = fmaxf(v, 0.f);

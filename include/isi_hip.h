@@ -735,7 +735,8 @@ typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
  * NULL except the ones the requested mode needs. */
 typedef struct isi_vqvae_out {
   float *dec;        /* [B, in_channel, H, W]  NCHW      (forward/decode)   */
-  float *quant_t;    /* [B, Ht, Wt, D]  channels-last    (encode/forward)   */
+  float *quant_t;    /* [B, Ht, Wt, D]  channels-last    (encode/forward; null in a FORWARD call: the map stays in the
+                      * pair format the decoders read and no fp32 copy is written -- the fused search's stores bound it) */
   float *quant_b;    /* [B, Hb, Wb, D]  channels-last                        */
   int64_t *id_t;     /* [B, Ht, Wt]                                          */
   int64_t *id_b;     /* [B, Hb, Wb]                                          */

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
     if (valid && lost) {
 #pragma unroll
       for (int j = 0; j < NQ; ++j) {
-        *reinterpret_cast<float4 *>(p.q + n * D + (2 * j + half) * 4) = make_float4(NAN, NAN, NAN, NAN);
+        if (p.q) *reinterpret_cast<float4 *>(p.q + n * D + (2 * j + half) * 4) = make_float4(NAN, NAN, NAN, NAN);
         if (p.q_pair) {   // NaN pieces: the pair pipeline's consumers stay loud as well
           *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(p.q_pair) + (n * D + 8 * j) * 4 + half * 8) = make_uint2(0x7e007e00u, 0x7e007e00u);
           *reinterpret_cast<uint2 *>(reinterpret_cast<char *>(p.q_pair) + (n * D + 8 * j) * 4 + 16 + half * 8) = make_uint2(0x7e007e00u, 0x7e007e00u);
@@ -710,7 +710,9 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
         float4 dq = make_float4(e.x - v.x, e.y - v.y, e.z - v.z, e.w - v.w);
         sse += dq.x * dq.x + dq.y * dq.y + dq.z * dq.z + dq.w * dq.w;
         const float4 qv = make_float4(v.x + dq.x, v.y + dq.y, v.z + dq.z, v.w + dq.w);
-        *reinterpret_cast<float4 *>(p.q + n * D + (2 * j + half) * 4) = qv;
+        // (p.q null: a forward whose caller takes no quantised maps -- the decoders read q_pair: 8 scattered 16-byte
+        // stores per lane and tile less in a kernel bound by its vector-memory instructions)
+        if (p.q) *reinterpret_cast<float4 *>(p.q + n * D + (2 * j + half) * 4) = qv;
         if (p.q_pair) {
           // pair8 group j = channels 8 j .. 8 j + 7: this lane's quad is its half `half`: 8 bytes of hi pieces at
           // + 8 half, 8 bytes of lo pieces at + 16 + 8 half
@@ -929,7 +931,7 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
                            float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts,
                            float *z_out) {
   if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return invalid("vq_conv1x1: workspace (vq_conv1x1_workspace_floats, 16-byte aligned)");
-  if (!s0 || !s0->ptr || !w16 || !codes || !e2 || !idx || !q || !counts || !sse_part) return invalid("vq_conv1x1: null pointer");
+  if (!s0 || !s0->ptr || !w16 || !codes || !e2 || !idx || (!q && !q_pair) || !counts || !sse_part) return invalid("vq_conv1x1: null pointer");
   const bool two = s1 && s1->ptr;
   const int C0 = s0->C, C1 = two ? s1->C : 0;
   if (B <= 0 || H <= 0 || W <= 0 || !vq_conv1x1_fusable(C0, C1, D, K)) return unsupported("vq_conv1x1: shape outside the fused kernel");

@@ -405,7 +405,9 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
     {
       isi_src s = src_nhwc(et.p, et.C, et.H, et.W);
       if (fuse_vq && vq_conv1x1_fusable(et.C, 0, D, w.quantize_t.K)) {
-        rc = run_quantizer_fused(w.quantize_t, w.quantize_conv_t, s, nullptr, B, et.H, et.W, id_t, quant_t, q_t_pair,
+        // (no fp32 map where the caller takes none and this call decodes from the pair copies)
+        rc = run_quantizer_fused(w.quantize_t, w.quantize_conv_t, s, nullptr, B, et.H, et.W, id_t,
+                                 (out->quant_t || !(mode & ISI_MODE_DECODE)) ? quant_t : nullptr, q_t_pair,
                                  counts_top, sse_top, scal + 0, wfrag_ws, st, /*finalize*/ false);
         if (rc) return rc;
         top_deferred = true;
@@ -442,7 +444,8 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       isi_src a = src_nhwc(dec_t, Cd, sh.Hb, sh.Wq, Wd);
       isi_src b = src_nhwc(eb.p, eb.C, sh.Hb, sh.Wq, eb.W);
       if (fuse_vq && vq_conv1x1_fusable(Cd, eb.C, D, w.quantize_b.K)) {
-        rc = run_quantizer_fused(w.quantize_b, w.quantize_conv_b, a, &b, B, sh.Hb, sh.Wq, id_b, quant_b, q_b_pair, counts,
+        rc = run_quantizer_fused(w.quantize_b, w.quantize_conv_b, a, &b, B, sh.Hb, sh.Wq, id_b,
+                                 (out->quant_b || !(mode & ISI_MODE_DECODE)) ? quant_b : nullptr, q_b_pair, counts,
                                  sse_part, scal + 2, wfrag_ws, st, /*finalize*/ !top_deferred);
         if (rc) return rc;
         if (top_deferred) {

@@ -291,7 +291,7 @@ class VQVAE(nn.Module):
 
     # ---------------------------------------------------------------- API
     @torch.no_grad()
-    def _encode_impl(self, input: Tensor, with_decode: bool):
+    def _encode_impl(self, input: Tensor, with_decode: bool, need_quant: bool = True):
         _hip.require_gpu(input, "input")
         if input.dim() != 4 or input.shape[1] != self.in_channel:
             raise RuntimeError(f"expected input [B, {self.in_channel}, H, W], got {tuple(input.shape)}")
@@ -302,8 +302,11 @@ class VQVAE(nn.Module):
         Hb, Wb, Ht, Wt, Wq = self._latent_shapes(H, W)
         dev, D = x.device, self.embed_dim
         f32 = dict(dtype=torch.float32, device=dev)
-        quant_t = torch.empty(B, Ht, Wt, D, **f32)
-        quant_b = torch.empty(B, Hb, Wq, D, **f32)
+        # `need_quant` False (forward(): the caller takes dec, diff, ids, perplexities): the library then keeps the quantised
+        # maps in the pair format its decoders read and writes no fp32 copy (the fused search's stores are what bounds it)
+        need_quant = need_quant or not with_decode or self.disable_quantization
+        quant_t = torch.empty(B, Ht, Wt, D, **f32) if need_quant else None
+        quant_b = torch.empty(B, Hb, Wq, D, **f32) if need_quant else None
         id_t = torch.empty(B, Ht, Wt, dtype=torch.int64, device=dev)
         id_b = torch.empty(B, Hb, Wq, dtype=torch.int64, device=dev)
         scalars = torch.empty(5, **f32)
@@ -311,8 +314,8 @@ class VQVAE(nn.Module):
         if with_decode:
             fb = 2 ** len(self.dec._up)
             dec = torch.empty(B, self.in_channel, Hb * fb, Wq * fb, **f32)
-        out = _hip.isi_vqvae_out(dec.data_ptr() if dec is not None else None, quant_t.data_ptr(),
-                                 quant_b.data_ptr(), id_t.data_ptr(), id_b.data_ptr(), scalars.data_ptr())
+        out = _hip.isi_vqvae_out(dec.data_ptr() if dec is not None else None, quant_t.data_ptr() if need_quant else None,
+                                 quant_b.data_ptr() if need_quant else None, id_t.data_ptr(), id_b.data_ptr(), scalars.data_ptr())
         self._run(_hip.MODE_FORWARD if with_decode else _hip.MODE_ENCODE, x, B, H, W, out, dev)
         if self.disable_quantization:
             # UnquantizedBottleneck.forward (bottleneck.py:107-119): diff zeros(1) each -> unsqueeze(0) and summed
@@ -320,13 +323,13 @@ class VQVAE(nn.Module):
             return (dec, quant_t.permute(0, 3, 1, 2), quant_b.permute(0, 3, 1, 2), scalars[4].reshape(1, 1),
                     None, None, scalars[1:2], scalars[3:4])
         diff = scalars[4].reshape(1)  # diff_t.unsqueeze(0) + diff_b.unsqueeze(0), vqvae.py:263,275,277
-        return (dec, quant_t.permute(0, 3, 1, 2), quant_b.permute(0, 3, 1, 2), diff, id_t, id_b,
-                scalars[1], scalars[3])
+        return (dec, quant_t.permute(0, 3, 1, 2) if need_quant else None, quant_b.permute(0, 3, 1, 2) if need_quant else None,
+                diff, id_t, id_b, scalars[1], scalars[3])
 
     def forward(self, input: Tensor):
         if self.training:
             return self._forward_train(input)
-        dec, _, _, diff, id_t, id_b, perp_t, perp_b = self._encode_impl(input, with_decode=True)
+        dec, _, _, diff, id_t, id_b, perp_t, perp_b = self._encode_impl(input, with_decode=True, need_quant=False)
         return self.post_process(dec), diff, perp_t, perp_b, id_t, id_b
 
     def _forward_train(self, input: Tensor):

@@ -207,6 +207,7 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
                            float *z_out = nullptr);
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D);
 int vq_zero_counts(int32_t *counts, int K, hipStream_t stream);
+int vq_unquantized_scalars(float *scalars2, hipStream_t stream);
 int mse_loss_num_partials(int64_t n);
 int mse_loss_f32(const float *a, const float *b, int64_t n, float *workspace, float *out, hipStream_t st);
 int mse_loss_bwd_f32(const float *a, const float *b, const float *g, int64_t n, float *da, float *db, hipStream_t st);

@@ -978,6 +978,12 @@ __global__ void vq_zero_counts_kernel(int32_t *__restrict__ counts, int K) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < K) counts[i] = 0;
 }
+__global__ void vq_unquantized_scalars_kernel(float *__restrict__ s2) { s2[0] = 0.f; s2[1] = __builtin_inff(); }
+int vq_unquantized_scalars(float *scalars2, hipStream_t stream) {     // diff = 0, perplexity = inf (bottleneck.py:107-119)
+  if (!scalars2) return invalid("vq_unquantized_scalars: null pointer");
+  hipLaunchKernelGGL(vq_unquantized_scalars_kernel, dim3(1), dim3(1), 0, stream, scalars2);
+  return check_launch("vq_unquantized_scalars");
+}
 int vq_zero_counts(int32_t *counts, int K, hipStream_t stream) {
   if (!counts || K <= 0) return invalid("vq_zero_counts: bad argument");
   hipLaunchKernelGGL(vq_zero_counts_kernel, dim3((K + 255) / 256), dim3(256), 0, stream, counts, K);

@@ -313,12 +313,7 @@ int run_quantizer(const isi_codebook_w &cb, const float *z, int64_t N, int64_t *
 }
 
 // UnquantizedBottleneck.forward (bottleneck.py:107-119): diff = 0, perplexity = inf
-int unquantized_scalars(float *scalars2, hipStream_t st) {
-  if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scalars2), 0, 1, st) != hipSuccess ||
-      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(scalars2 + 1), 0x7f800000, 1, st) != hipSuccess)
-    return check_launch("hipMemsetD32Async(unquantized scalars)");
-  return ISI_OK;
-}
+int unquantized_scalars(float *scalars2, hipStream_t st) { return vq_unquantized_scalars(scalars2, st); }   // (a kernel: no memset nodes)
 
 // quantize_conv (1x1) + codebook search in ONE launch (vq_nearest.hip: z stays in registers), with the pair-format
 // copy of q written alongside.  `w1x1` = the 1x1 layer (its packed weight is followed by the blocked pair copy).

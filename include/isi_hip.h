@@ -661,6 +661,10 @@ int isi_vq_conv1x1_nearest_tape_f32(const isi_src *src0, const isi_src *src1, co
                                     float *q_pair_out, float *z_out, int32_t *counts, float *sse_part, float *workspace,
                                     int B, int H, int W, int D, int K, void *stream);
 size_t isi_vq_conv1x1_workspace_floats(int C0, int C1, int D);
+/* Pack-time half of the fused launch: the fragment-major copy ([D][Kpad] floats) of a packed 1x1 weight's pair copy.  A
+ * weight laid out {packed [D][Kpad] | pair copy | fragments} with isi_vqvae_w.w16 = 2 lets isi_vqvae_run skip the pre-kernel in
+ * front of each search (its two histograms are then zeroed by one launch). */
+int isi_vq_pack_fragments_f32(const float *packed_w16, float *frag_out, int Kpad, void *stream);
 /* 1 when the fused launch covers the shape (D = 64, 32-channel multiples, C0 + C1 <= 256, both code planes in LDS) */
 int isi_vq_conv1x1_fusable(int C0, int C1, int D, int K);
 
@@ -719,7 +723,8 @@ typedef struct isi_vqvae_w { /* VQVAE.__init__, vqvae.py:126-216 */
   int n_upsample;
   isi_conv_w upsample[ISI_MAX_STAGES];
   int w16;       /* 1: every packed convolution weight above is followed by its isi_split_conv_weight_f16 copy
-                  * (used when precision == 4)                                                        */
+                  * (used when precision == 4); 2: ... and quantize_conv_t / _b by a third section, the fragment-major
+                  * copy of isi_vq_pack_fragments_f32                                                  */
   int precision; /* products of the convolutions (data and accumulation are always fp32):
                   * 0: fp32 matrix pipe everywhere.  1: ISI_CONV_BF16X3 in `dec` and `upsample` only
                   * (no code index depends on them).  2: ISI_CONV_BF16X3 in every convolution (near-tie

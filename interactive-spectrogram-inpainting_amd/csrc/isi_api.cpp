@@ -434,6 +434,9 @@ int isi_vq_conv1x1_nearest_tape_f32(const isi_src *src0, const isi_src *src1, co
                                 workspace, B, H, W, D, K, S(stream), /*zero_counts*/ true, z_out);
 }
 size_t isi_vq_conv1x1_workspace_floats(int C0, int C1, int D) { return vq_conv1x1_workspace_floats(C0, C1, D); }
+int isi_vq_pack_fragments_f32(const float *packed_w16, float *frag_out, int Kpad, void *stream) {
+  return vq_pack_fragments_f32(packed_w16, frag_out, Kpad, S(stream));
+}
 int isi_vq_conv1x1_fusable(int C0, int C1, int D, int K) { return vq_conv1x1_fusable(C0, C1, D, K) ? 1 : 0; }
 int isi_vq_nearest_flags_f32(const float *z, const float *codes_kd, const float *e2, int64_t *idx_out,
                              float *q_out, int32_t *counts, float *sse_part, int64_t N, int D, int K,

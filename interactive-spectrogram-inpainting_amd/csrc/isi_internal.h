@@ -204,7 +204,8 @@ int vq_debug_stamps(long long *host, int n);
 int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
                            const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,
                            float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts = false,
-                           float *z_out = nullptr);
+                           float *z_out = nullptr, const float *wfrag_packed = nullptr);
+int vq_pack_fragments_f32(const float *packed_w16, float *frag_out, int Kpad, hipStream_t stream);
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D);
 int vq_zero_counts(int32_t *counts, int K, hipStream_t stream);
 int vq_unquantized_scalars(float *scalars2, hipStream_t stream);

@@ -908,6 +908,7 @@ int vq_nearest_f32(const float *z, const float *codes, const float *e2, int64_t 
 }
 
 
+int vq_zero_counts(int32_t *counts, int K, hipStream_t stream);
 // Fused quantize_conv + search (see vq_conv1x1_nearest_kernel).  Sources: pair8, channels-last, 32-channel multiples;
 // D = 64; the weight is the packed 1x1 weight's blocked pair copy (ISI_CONV_W16: packed_w + Cout * Kpad floats).
 bool vq_conv1x1_fusable(int C0, int C1, int D, int K) {
@@ -916,6 +917,18 @@ bool vq_conv1x1_fusable(int C0, int C1, int D, int K) {
 }
 
 size_t vq_conv1x1_workspace_floats(int C0, int C1, int D) { return (size_t)D * round_up((size_t)(C0 + C1), kBK); }
+// the fragment-major copy of a packed 1x1 weight's pair copy, made ONCE at pack time (the third section of such a weight:
+// isi_vqvae_w.w16 == 2) instead of by a pre-kernel in front of every search
+int vq_pack_fragments_f32(const float *packed_w16, float *frag_out, int Kpad, hipStream_t stream) {
+  if (!packed_w16 || !frag_out || Kpad <= 0 || (Kpad % 16) ||
+      ((reinterpret_cast<uintptr_t>(packed_w16) | reinterpret_cast<uintptr_t>(frag_out)) & 15))
+    return invalid("vq_pack_fragments: bad argument");
+  const int nstep = Kpad / 16, total = nstep * 256;
+  hipLaunchKernelGGL(vq_weight_fragments_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
+                     reinterpret_cast<const uint4 *>(packed_w16), reinterpret_cast<uint4 *>(frag_out), Kpad, nstep,
+                     (int32_t *)nullptr, 0);
+  return check_launch("vq_pack_fragments");
+}
 
 int vq_debug_stamps(long long *host, int n) {
 #ifdef ISI_MEASURE
@@ -929,8 +942,9 @@ int vq_debug_stamps(long long *host, int n) {
 int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w16, const float *bias, const float *codes,
                            const float *e2, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part,
                            float *workspace, int B, int H, int W, int D, int K, hipStream_t stream, bool zero_counts,
-                           float *z_out) {
-  if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return invalid("vq_conv1x1: workspace (vq_conv1x1_workspace_floats, 16-byte aligned)");
+                           float *z_out, const float *wfrag_packed) {
+  if (!wfrag_packed && (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 15))) return invalid("vq_conv1x1: workspace (vq_conv1x1_workspace_floats, 16-byte aligned)");
+  if (wfrag_packed && (reinterpret_cast<uintptr_t>(wfrag_packed) & 15)) return invalid("vq_conv1x1: the packed fragments must be 16-byte aligned");
   if (!s0 || !s0->ptr || !w16 || !codes || !e2 || !idx || (!q && !q_pair) || !counts || !sse_part) return invalid("vq_conv1x1: null pointer");
   const bool two = s1 && s1->ptr;
   const int C0 = s0->C, C1 = two ? s1->C : 0;
@@ -952,8 +966,13 @@ int vq_conv1x1_nearest_f32(const isi_src *s0, const isi_src *s1, const float *w1
   a.H = H; a.W = W; a.N = N; a.K = K;
   const int Kp = (K + 31) & ~31;
   const size_t smem = vq_planes_lds_bytes(Kp);
-  a.wfrag = workspace;
-  {
+  a.wfrag = wfrag_packed ? wfrag_packed : workspace;
+  if (wfrag_packed) {          // fragments made at pack time (isi_vq_pack_fragments_f32): no pre-kernel
+    if (zero_counts) {
+      const int rc0 = vq_zero_counts(counts, K, stream);
+      if (rc0) return rc0;
+    }
+  } else {
     const int nstep = a.Kpad / 16, total = nstep * 256 > K ? nstep * 256 : K;
     hipLaunchKernelGGL(vq_weight_fragments_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
                        reinterpret_cast<const uint4 *>(w16), reinterpret_cast<uint4 *>(workspace), a.Kpad, nstep,

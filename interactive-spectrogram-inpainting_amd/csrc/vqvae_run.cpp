@@ -319,10 +319,13 @@ int unquantized_scalars(float *scalars2, hipStream_t st) { return vq_unquantized
 // copy of q written alongside.  `w1x1` = the 1x1 layer (its packed weight is followed by the blocked pair copy).
 int run_quantizer_fused(const isi_codebook_w &cb, const isi_conv_w &w1x1, const isi_src &a, const isi_src *b, int B, int H,
                         int W, int64_t *idx, float *q, float *q_pair, int32_t *counts, float *sse_part, float *scalars2,
-                        float *wfrag_ws, hipStream_t st, bool finalize = true) {
+                        float *wfrag_ws, hipStream_t st, bool finalize = true, bool frag_packed = false) {
   const int Kpad = (int)round_up((size_t)w1x1.Cin, kBK);
+  // frag_packed (isi_vqvae_w.w16 == 2): the weight's third section is its fragment-major copy and the caller has zeroed
+  // both levels' histograms with one launch -- no pre-kernel in front of the search
   int rc = vq_conv1x1_nearest_f32(&a, b, w1x1.w + (size_t)w1x1.Cout * Kpad, w1x1.bias, cb.codes_kd, cb.e2, idx, q, q_pair,
-                                  counts, sse_part, wfrag_ws, B, H, W, cb.D, cb.K, st, /*zero_counts*/ true);
+                                  counts, sse_part, wfrag_ws, B, H, W, cb.D, cb.K, st, /*zero_counts*/ !frag_packed, nullptr,
+                                  frag_packed ? w1x1.w + (size_t)2 * w1x1.Cout * Kpad : nullptr);
   if (rc || !finalize) return rc;     // (finalize = false: the caller finishes both levels with one launch, vq_finalize2_f32)
   const int64_t N = (int64_t)B * H * W;
   return vq_finalize_f32(sse_part, vq_num_partials(N), counts, cb.K, N, cb.D, scalars2, st);
@@ -355,10 +358,11 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   int64_t *id_t_ws = static_cast<int64_t *>(ws.take((size_t)B * sh.Ht * sh.Wt * sizeof(int64_t)));
   int64_t *id_b_ws = static_cast<int64_t *>(ws.take((size_t)B * sh.Hb * sh.Wq * sizeof(int64_t)));
   const int Kmax = std::max(w.quantize_t.K, w.quantize_b.K);
-  int32_t *counts = static_cast<int32_t *>(ws.take((size_t)Kmax * sizeof(int32_t)));
+  // (the two histograms side by side: one launch zeroes both when the searches bring no pre-kernel of their own)
+  int32_t *counts = static_cast<int32_t *>(ws.take((size_t)2 * Kmax * sizeof(int32_t)));
   float *sse_part = ws.floats(256);
   // the top level's statistics stay alive until the bottom search is done: one launch finishes both (fused path)
-  int32_t *counts_top = static_cast<int32_t *>(ws.take((size_t)Kmax * sizeof(int32_t)));
+  int32_t *counts_top = counts + Kmax;
   float *sse_top = ws.floats(256);
   float *wfrag_ws = ws.floats((size_t)D * round_up((size_t)(w.quantize_conv_b.Cin > w.quantize_conv_t.Cin ? w.quantize_conv_b.Cin
                                                                                                             : w.quantize_conv_t.Cin), kBK));
@@ -384,6 +388,11 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
   const int pf_dec = w.precision == 4 ? f16 : w.precision >= 1 ? ISI_CONV_BF16X3 : 0;   // final decoder + upsample
   // quantize_conv_{t,b} fused into the codebook searches: the pair pipeline only (pair8 sources, blocked weights)
   const bool fuse_vq = pairs && !w.no_quantize && !knobs().no_vq_fusion;
+  const bool frag_packed = fuse_vq && w.w16 == 2 && (mode & ISI_MODE_ENCODE);
+  if (frag_packed) {
+    rc = vq_zero_counts(counts, 2 * Kmax, st);
+    if (rc) return rc;
+  }
   bool bottom_pair_done = false;
   bool top_deferred = false;      // top-level scalars not written yet (fused path)
   int64_t N_top = 0;
@@ -403,7 +412,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
         // (no fp32 map where the caller takes none and this call decodes from the pair copies)
         rc = run_quantizer_fused(w.quantize_t, w.quantize_conv_t, s, nullptr, B, et.H, et.W, id_t,
                                  (out->quant_t || !(mode & ISI_MODE_DECODE)) ? quant_t : nullptr, q_t_pair,
-                                 counts_top, sse_top, scal + 0, wfrag_ws, st, /*finalize*/ false);
+                                 counts_top, sse_top, scal + 0, wfrag_ws, st, /*finalize*/ false, frag_packed);
         if (rc) return rc;
         top_deferred = true;
         N_top = (int64_t)B * et.H * et.W;
@@ -441,7 +450,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
       if (fuse_vq && vq_conv1x1_fusable(Cd, eb.C, D, w.quantize_b.K)) {
         rc = run_quantizer_fused(w.quantize_b, w.quantize_conv_b, a, &b, B, sh.Hb, sh.Wq, id_b,
                                  (out->quant_b || !(mode & ISI_MODE_DECODE)) ? quant_b : nullptr, q_b_pair, counts,
-                                 sse_part, scal + 2, wfrag_ws, st, /*finalize*/ !top_deferred);
+                                 sse_part, scal + 2, wfrag_ws, st, /*finalize*/ !top_deferred, frag_packed);
         if (rc) return rc;
         if (top_deferred) {
           const int64_t N_b = (int64_t)B * sh.Hb * sh.Wq;

@@ -246,6 +246,7 @@ SIGNATURES = {
                                                   _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "isi_vq_conv1x1_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "isi_vq_conv1x1_fusable": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "isi_vq_pack_fragments_f32": (C.c_int, [_P, _P, C.c_int, _P]),
     "isi_decode_stage_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "isi_decode_stage_f32": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_float, _P, C.c_size_t, _P]),

@@ -199,6 +199,20 @@ class VQVAE(nn.Module):
             wmax.append(m.weight.detach().abs().max())
             return _hip.isi_conv_w(p.data_ptr(), m.bias.data_ptr(), m.in_channels, m.out_channels)
 
+        def conv1x1_with_fragments(m: _ConvParams) -> _hip.isi_conv_w:
+            """quantize_conv_*: {packed | pair copy | fragment-major copy} (isi_vqvae_w.w16 = 2): the fused search then needs no
+            pre-kernel per call (csrc/vq_nearest.hip: the fragments are a pack-time job)."""
+            p2 = m.packed()
+            n = p2.numel() // 2
+            kpad = n // m.out_channels
+            p3 = torch.empty(3 * n, dtype=torch.float32, device=p2.device)
+            p3[:2 * n].copy_(p2)
+            _hip.check(_hip.lib().isi_vq_pack_fragments_f32(p3.data_ptr() + 4 * n, p3.data_ptr() + 8 * n, kpad,
+                                                            C.c_void_p(_hip.stream_ptr(p2.device))), "isi_vq_pack_fragments_f32")
+            keep.append(p3)
+            wmax.append(m.weight.detach().abs().max())
+            return _hip.isi_conv_w(p3.data_ptr(), m.bias.data_ptr(), m.in_channels, m.out_channels)
+
         def res(stack, blocks, idxs):
             if len(idxs) > _hip.ISI_MAX_RES:
                 raise NotImplementedError(f"more than {_hip.ISI_MAX_RES} residual blocks")
@@ -240,11 +254,14 @@ class VQVAE(nn.Module):
         w = _hip.isi_vqvae_w()
         w.in_channel = self.in_channel
         w.enc_b, w.enc_t = enc(self.enc_b), enc(self.enc_t)
-        w.quantize_conv_t, w.quantize_conv_b = conv(self.quantize_conv_t), conv(self.quantize_conv_b)
+        frag = all(m.kernel_size == 1 and m.groups == 1 and m.out_channels == 64
+                   and (m.packed().numel() // 2 // m.out_channels) % 16 == 0 for m in (self.quantize_conv_t, self.quantize_conv_b))
+        qconv = conv1x1_with_fragments if frag else conv
+        w.quantize_conv_t, w.quantize_conv_b = qconv(self.quantize_conv_t), qconv(self.quantize_conv_b)
         w.quantize_t, w.quantize_b = book(self.quantize_t), book(self.quantize_b)
         w.dec_t, w.dec = dec(self.dec_t), dec(self.dec)
         w.precision = {"f32": 0, "bf16x3_decoder": 1, "bf16x3": 2, "split_bf16": 3, "split_f16": 4}[self.conv_precision]
-        w.w16 = 1          # _ConvParams.packed() carries the split-f16 pair copies
+        w.w16 = 2 if frag else 1          # _ConvParams.packed() carries the split-f16 pair copies (2: + the quantiser weights' fragments)
         w.no_quantize = 1 if self.disable_quantization else 0
         w.n_upsample = len(self.upsample_top_to_bottom)
         for j, m in enumerate(self.upsample_top_to_bottom):

@@ -125,9 +125,9 @@ def _host_cpu():
         return None, None, None
 
 
-def _cpu_baseline(sd, x=None, id_t=None, id_b=None, batch=64, warmup=1, iters=3):
-    """Oracle forward on the host cores (B = 64): threads = the physical cores of one socket, 1 warm-up and
-    3 timed iterations on the bench batch's shape, median.  With the GPU's codes of the bench batch (`x`, `id_t`,
+def _cpu_baseline(sd, x=None, id_t=None, id_b=None, batch=64, warmup=2, iters=5):
+    """Oracle forward on the host cores (B = 64): threads = the physical cores of one socket, 2 warm-up and
+    5 timed iterations on the bench batch's shape, median.  With the GPU's codes of the bench batch (`x`, `id_t`,
     `id_b`) it also compares them with the oracle LEVEL BY LEVEL (bottom teacher-forced on the GPU's top codes) over
     all samples and certifies every differing code as a near-tie of the reference's fp32 distance formula."""
     from oracle import vqvae_oracle as O
@@ -855,6 +855,9 @@ def main():
             "TFLOPs": round(tot_fl / t_step / 1e12, 1), "frac_of_mfma_ceiling": round(tot_fl / t_step / 1e12 / peak, 4),
             "GBs": round(tot_by / t_step / 1e9, 1), "frac_of_hbm_peak": round(tot_by / t_step / 1e9 / HBM_PEAK_GBS, 4),
             "max_frac": round(max(tot_fl / t_step / 1e12 / peak, tot_by / t_step / 1e9 / HBM_PEAK_GBS), 4)}
+        # the same figures as flat keys (the driver's parsed record keeps only the scalar entries of `roofline`)
+        for key in ("TFLOPs", "frac_of_mfma_ceiling", "GBs", "frac_of_hbm_peak", "max_frac"):
+            roof["whole_forward_" + key] = roof["whole_forward"][key]
         line = {
             "metric": "spectrograms/sec VQ-VAE fwd+quantize @B64",
             "value": round(world * args.batch * args.steps / dt, 2),

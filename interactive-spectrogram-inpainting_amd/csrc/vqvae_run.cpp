@@ -424,7 +424,7 @@ int plan(const isi_vqvae_w &w, int mode, const float *x, int B, int H, int W,
                       et.W, D, 1, 1, 1, 0, pf_enc | (pairs ? ISI_CONV_IN0_PAIR : 0), st);
       if (rc) return rc;
       rc = w.no_quantize ? unquantized_scalars(scal + 0, st)
-                         : run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts,
+                         : run_quantizer(w.quantize_t, zbuf, (int64_t)B * et.H * et.W, id_t, quant_t, counts_top,
                                          sse_part, scal + 0, pf_enc & ISI_CONV_F16X3, st);
       if (rc) return rc;
       if (pairs) {

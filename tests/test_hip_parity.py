@@ -398,12 +398,38 @@ def test_vqvae_against_reference(golden_dir, name):
     # the bottom level, the reconstruction) legitimately differs, so those comparisons are then teacher-forced.
     moved = _certify_index_mismatches(torch.from_numpy(z["z_t"]).permute(0, 2, 3, 1), torch.from_numpy(z["w::quantize_t.embed"]),
                                       id_t.cpu(), torch.from_numpy(z["id_t"]))
+    # the stacks on their own: whatever the codes do (the default-constructor fixture takes the moved-code branch)
+    enc_b = m.enc_b(x)
+    enc_t = m.enc_t(enc_b)
+    _close(enc_b, z["enc_b"], TOL, "enc_b")
+    _close(enc_t, z["enc_t"], TOL, "enc_t")
     if moved:
         assert moved <= 1, moved
+        dev = _dev()
         same = (id_t.cpu() == torch.from_numpy(z["id_t"]))
         _close(q_t.cpu().permute(0, 2, 3, 1)[same], torch.from_numpy(z["quant_t"]).permute(0, 2, 3, 1)[same].numpy(), TOL, "quant_t")
-        dec_code = m.decode_code(torch.from_numpy(z["id_t"]).to(_dev()), torch.from_numpy(z["id_b"]).to(_dev()))
-        _close(dec_code, z["dec_code"], TOL, "decode_code(reference ids)")
+        ref_t, ref_b = torch.from_numpy(z["id_t"]).to(dev), torch.from_numpy(z["id_b"]).to(dev)
+        _close(m.decode_code(ref_t, ref_b), z["dec_code"], TOL, "decode_code(reference ids)")
+        # ---- everything behind the moved code, TEACHER-FORCED on the reference's top ids (vqvae.py:258-278): the top
+        # code vectors, dec_t, the bottom 1x1 + search (ids, quantised map, perplexity, commitment term), the decoder
+        qt_ref = m.quantize_t.embed_code(ref_t).permute(0, 3, 1, 2).contiguous()
+        _close(qt_ref, z["quant_t"], TOL, "embed_code(reference id_t)")
+        cat = torch.cat([m.dec_t(qt_ref), enc_b], 1).permute(0, 2, 3, 1)
+        w_b = m.quantize_conv_b.weight[:, :, 0, 0]
+        z_b = (cat.reshape(-1, cat.shape[-1]).double() @ w_b.double().t() + m.quantize_conv_b.bias.double()).float().reshape(*cat.shape[:3], -1)
+        qb, diff_b, idb, pb = m.quantize_b(z_b)
+        n_b = _certify_index_mismatches(z_b.cpu(), torch.from_numpy(z["w::quantize_b.embed"]), idb.cpu(), torch.from_numpy(z["id_b"]))
+        assert n_b <= 1, n_b
+        if n_b == 0:
+            _close(qb.permute(0, 3, 1, 2), z["quant_b"], TOL, "quant_b (teacher-forced)")
+            _close(pb, z["perplexity_b"], TOL, "perplexity_b (teacher-forced)")
+            z_t = torch.from_numpy(z["z_t"]).to(dev)
+            diff_t = (qt_ref - z_t).pow(2).mean()
+            _close((diff_t + diff_b).reshape(1), z["diff"], TOL, "diff (teacher-forced)")
+            _close(m.decode(qt_ref, qb.permute(0, 3, 1, 2)), z["dec"], TOL, "decode (teacher-forced)")
+        # perplexity_t is a function of the code histogram alone (bottleneck.py:96-100): the GPU's figure against that of its own ids
+        onehot = torch.nn.functional.one_hot(id_t.reshape(-1), m.n_embed_t).float().mean(0)
+        _close(p_t, torch.exp(-(onehot * torch.log(onehot.clamp(min=1e-7))).sum()), TOL, "perplexity_t of the GPU's ids")
         return
     assert torch.equal(id_b.cpu(), torch.from_numpy(z["id_b"]))
     _close(q_t, z["quant_t"], TOL, "quant_t"); _close(q_b, z["quant_b"], TOL, "quant_b")
@@ -414,9 +440,6 @@ def test_vqvae_against_reference(golden_dir, name):
     _close(dec, z["dec"], TOL, "dec")
     _close(m.decode_code(id_t, id_b), z["dec_code"], TOL, "decode_code")
     _close(m.decode(q_t, q_b), z["dec"], TOL, "decode")
-    # stacks on their own
-    _close(m.enc_b(x), z["enc_b"], TOL, "enc_b")
-    _close(m.enc_t(m.enc_b(x)), z["enc_t"], TOL, "enc_t")
 
 
 def test_vqvae_against_oracle_seeded_odd_width():
@@ -440,6 +463,41 @@ def test_vqvae_against_oracle_seeded_odd_width():
     assert torch.equal(id_t.cpu(), ref[4]) and torch.equal(id_b.cpu(), ref[5])
     _close(dec, ref[0], TOL, "dec"); _close(diff, ref[1], TOL, "diff")
     _close(p_t, ref[2], TOL, "perplexity_t"); _close(p_b, ref[3], TOL, "perplexity_b")
+
+
+def test_unequal_codebook_sizes_keep_their_histograms_apart():
+    """num_embeddings = (1024, 512) on the default constructor (vqvae_run.cpp): the 1024-code top level is too
+    large for the fused 1x1 + search kernel and takes the two-launch path, the bottom level takes the fused one; the two
+    levels must count their codes in separate histograms -- perplexity_b against the oracle is what a shared one breaks."""
+    from oracle import vqvae_oracle as O
+    from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
+    cfg = O.Config(in_channel=2)
+    sd = O.init_state_dict(cfg, seed=11)
+    g = torch.Generator().manual_seed(12)
+    O.calibrate_codebooks(sd, cfg, torch.randn(2, 2, 64, 128, generator=g))
+    # 512 more top codes: jittered copies of the calibrated ones (in use, well apart from them)
+    e = sd["quantize_t.embed"]
+    sd["quantize_t.embed"] = torch.cat([e, e * 1.25 + 0.05 * torch.randn(e.shape, generator=g)], 1).contiguous()
+    sd["quantize_t.embed_avg"] = sd["quantize_t.embed"].clone()
+    sd["quantize_t.cluster_size"] = torch.zeros(1024)
+    x = torch.randn(3, 2, 64, 128, generator=g)
+    ref = O.forward(x, sd, cfg)
+    m = VQVAE(in_channel=2, num_embeddings=(1024, 512))
+    m.load_state_dict(sd)
+    m = m.to(_dev()).eval()
+    dec, diff, p_t, p_b, id_t, id_b = m(x.to(_dev()))
+    assert int(id_t.max()) < 1024 and id_t.shape == ref[4].shape
+    if torch.equal(id_t.cpu(), ref[4]) and torch.equal(id_b.cpu(), ref[5]):
+        _close(dec, ref[0], TOL, "dec"); _close(diff, ref[1], TOL, "diff")
+        _close(p_t, ref[2], TOL, "perplexity_t"); _close(p_b, ref[3], TOL, "perplexity_b")
+    # whatever a near-tie did to single codes: each level's perplexity is that of ITS OWN ids (bottleneck.py:96-100)
+    for ids, K, got, what in ((id_t, 1024, p_t, "perplexity_t"), (id_b, 512, p_b, "perplexity_b")):
+        pr = torch.nn.functional.one_hot(ids.reshape(-1), K).float().mean(0)
+        _close(got, torch.exp(-(pr * torch.log(pr.clamp(min=1e-7))).sum()), 1e-5, what + " of the level's own ids")
+    # encode() (the fp32 maps requested) takes the same launches
+    q_t, q_b, diff2, id_t2, id_b2, p_t2, p_b2 = m.encode(x.to(_dev()))
+    assert torch.equal(id_t2, id_t) and torch.equal(id_b2, id_b)
+    _close(p_b2, p_b, 1e-6, "perplexity_b encode vs forward")
 
 
 def test_invalidate_plan_after_data_writes():
@@ -558,7 +616,8 @@ def test_bench_batch_codes_certified_against_oracle():
         # the GPU's fp32 convolutions sum in different orders -- in the exact-fp32 mode too: 3 top codes on this batch)
         # (allowances at what is observed, VERDICT r04 item 8: split_f16 moves 4 top / 0 bottom codes of this batch, the
         # largest normalised gap is 6.2e-7)
-        lim = (8, 8)
+        # observed + 1: split_f16 4 top / 0 bottom, exact fp32 3 top / 0 bottom
+        lim = {"split_f16": (5, 1), "f32": (4, 1)}[mode]
         assert chk["top_moved"] <= lim[0] and chk["bottom_moved_teacher_forced"] <= lim[1], chk
 
 

@@ -439,8 +439,15 @@ typedef struct isi_attn_args {
                   * Q K^T, the band product Q E^T and its skew a second and a third time (60 % of the backward's time at
                   * S = 1025).  Entries of masked pairs are never read.  NULL: nothing is stored / everything is recomputed */
   int64_t logits_ld; /* row stride of `logits` in floats: a multiple of 4, >= Sk rounded up to a multiple of 32 */
+  void *workspace;   /* optional, isi_rel_attention_workspace_bytes(args) bytes, 256-byte aligned, forward only: with it the
+                      * 16-bit modes (precision >= 1, Cq = Ck = 1, head_dim 32 / 64) first split K, V and the table into
+                      * 16-bit planes (one launch) and then run the LDS-DMA-staged kernel (rel_attention_fwd3.hip) on them;
+                      * same arithmetic and results as without.  NULL: the register-staged kernels. */
+  size_t workspace_bytes;
 } isi_attn_args;
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream);
+/* 0 when the call would not use a workspace (precision 0, several channels per event, head_dim 16, planes >= 2 GiB) */
+size_t isi_rel_attention_workspace_bytes(const isi_attn_args *args);
 
 /* Backward of isi_rel_attention_f32 (replaces autograd through the attention of the absent
  * VQCPCB.transformer.transformer_custom behind `loss.backward()`,

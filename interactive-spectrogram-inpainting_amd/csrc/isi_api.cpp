@@ -48,6 +48,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_WGRAD_SPLIT_TARGET", &Knobs::wgrad_split_target, 0, false},
     {"ISI_ATTN_G_FROM_KV", &Knobs::attn_g_from_kv, 1, false},
     {"ISI_ATTN_OLD_FWD", &Knobs::attn_old_fwd, 0, false},
+    {"ISI_ATTN_NO_FWD3", &Knobs::attn_no_fwd3, 0, false},
     {"ISI_CONV_ABLATE", &Knobs::conv_ablate, 0, true},
     {"ISI_VQ_DBG", &Knobs::vq_dbg, 0, true},
     {"ISI_RESPAIR_ABL", &Knobs::respair_abl, 0, true},
@@ -296,6 +297,7 @@ int isi_overlap_add_f32(const float *frames, float *audio, int B, int T, int n_f
   return overlap_add_f32(frames, audio, B, T, n_fft, hop, left, L, S(stream));
 }
 int isi_rel_attention_f32(const isi_attn_args *args, void *stream) { return rel_attention_f32(args, S(stream)); }
+size_t isi_rel_attention_workspace_bytes(const isi_attn_args *args) { return rel_attention_workspace_bytes(args); }
 size_t isi_rel_attention_bwd_workspace_floats(const isi_attn_args *fwd) { return rel_attention_bwd_workspace_floats(fwd); }
 int isi_rel_attention_bwd_f32(const isi_attn_bwd_args *args, void *stream) { return rel_attention_bwd_f32(args, S(stream)); }
 size_t isi_layernorm_bwd_workspace_floats(int64_t M, int D) { return layernorm_bwd_workspace_floats(M, D); }

@@ -87,6 +87,7 @@ int convT_k4s2_small_f32(const float *in, const float *wk, const float *bias, fl
                          int oc, int oh, int ow, int relu, hipStream_t stream);
 
 int rel_attention_f32(const isi_attn_args *g, hipStream_t stream);
+size_t rel_attention_workspace_bytes(const isi_attn_args *g);
 int rel_attention_debug_stamps(long long *host, int n);
 int gemm_split_debug_stamps(long long *host, int n);
 int rel_attention_bwd_debug_stamps(long long *host, int n);

@@ -26,4 +26,11 @@ bool rel_attention_fwd2_ok(const AttnKArgs &a, int head_dim);
 int rel_attention_fwd2(const AttnKArgs &a, int head_dim, int precision, hipStream_t stream);
 int rel_attention_fwd2_debug_stamps(long long *host, int n);
 
+// rel_attention_fwd3.hip: one channel per event (Cq = Ck = 1), head_dim 32 / 64, precision 1 .. 3; K, V and e are split into
+// 16-bit planes in `workspace` (rel_attention_fwd3_workspace_bytes, 256-byte aligned) by a pack launch in front of the kernel.
+bool rel_attention_fwd3_ok(const AttnKArgs &a, int head_dim, int precision);
+size_t rel_attention_fwd3_workspace_bytes(const AttnKArgs &a, int head_dim, int precision);
+int rel_attention_fwd3(const AttnKArgs &a, int head_dim, int precision, void *workspace, size_t workspace_bytes, hipStream_t stream);
+int rel_attention_fwd3_debug_stamps(long long *host, int n);
+
 }  // namespace isi

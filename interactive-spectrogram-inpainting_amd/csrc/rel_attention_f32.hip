@@ -910,6 +910,10 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
   const bool split_tail = a.split && tail > 0;
   a.nblk = split_tail ? g->Sq / QB : (g->Sq + QB - 1) / QB;
   int rc;
+  if (a.split && g->workspace && !knobs().attn_no_fwd3 && !knobs().attn_old_fwd && rel_attention_fwd3_ok(a, g->head_dim, g->precision)) {
+    // operands as 16-bit planes in the caller's workspace, staged by LDS-DMA (rel_attention_fwd3.hip)
+    rc = rel_attention_fwd3(a, g->head_dim, g->precision, g->workspace, g->workspace_bytes, stream);
+  } else
   if (a.split && (g->precision == 3 || !knobs().attn_old_fwd) && rel_attention_fwd2_ok(a, g->head_dim)) {
     rc = rel_attention_fwd2(a, g->head_dim, g->precision, stream);
   } else
@@ -927,6 +931,14 @@ int rel_attention_f32(const isi_attn_args *g, hipStream_t stream) {
     default: hipLaunchKernelGGL(attn_fwd_tail_row_kernel<64>, tgrid, dim3(512), 0, stream, a, g->Sq - tail); break;
   }
   return check_launch("attn_fwd_tail_row");
+}
+
+// bytes of isi_attn_args.workspace that let the forward run its plane-staged kernel (0: that kernel does not take the call)
+size_t rel_attention_workspace_bytes(const isi_attn_args *g) {
+  if (!g || g->Sq <= 0 || g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->precision < 1 || g->precision > 3) return 0;
+  AttnKArgs a{};
+  a.e = g->rel_embeddings; a.R = g->rel_rows; a.Sq = g->Sq; a.Sk = g->Sk; a.H = g->H; a.B = g->B; a.Cq = g->Cq; a.Ck = g->Ck;
+  return rel_attention_fwd3_workspace_bytes(a, g->head_dim, g->precision);
 }
 
 // Rows (keys, in the backward's key-stationary kernel) beyond the last full 128-row block that are NOT given a block of

@@ -79,7 +79,7 @@ class isi_attn_args(C.Structure):
                 ("o_ss", C.c_int64), ("o_sb", C.c_int64), ("o_sh", C.c_int64),
                 ("Cq", C.c_int), ("Ck", C.c_int), ("Ek", C.c_int), ("rel_rows", C.c_int),
                 ("mask_mode", C.c_int), ("scale", C.c_float), ("lse", C.c_void_p), ("precision", C.c_int),
-                ("logits", C.c_void_p), ("logits_ld", C.c_int64)]
+                ("logits", C.c_void_p), ("logits_ld", C.c_int64), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class isi_linear_args(C.Structure):
@@ -197,6 +197,7 @@ SIGNATURES = {
     "isi_spec_inverse_prepare_bwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "isi_overlap_add_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, _P]),
     "isi_rel_attention_f32": (C.c_int, [C.POINTER(isi_attn_args), _P]),
+    "isi_rel_attention_workspace_bytes": (C.c_size_t, [C.POINTER(isi_attn_args)]),
     "isi_rel_attention_bwd_workspace_floats": (C.c_size_t, [C.POINTER(isi_attn_args)]),
     "isi_rel_attention_bwd_f32": (C.c_int, [C.POINTER(isi_attn_bwd_args), _P]),
     "isi_layernorm_bwd_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int]),

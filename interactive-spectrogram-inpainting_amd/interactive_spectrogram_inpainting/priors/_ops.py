@@ -405,7 +405,12 @@ def rel_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rel: Option
         a.lse = lse.data_ptr()
     if logits is not None:  # [B,H,Sq,ld] logits of the allowed pairs, kept for the backward (attention_logits_buffer)
         a.logits, a.logits_ld = logits.data_ptr(), logits.stride(2)
-    _hip.check(_hip.lib().isi_rel_attention_f32(C.byref(a), _s(q)), "isi_rel_attention_f32")
+    L = _hip.lib()
+    ws_bytes = L.isi_rel_attention_workspace_bytes(C.byref(a))
+    if ws_bytes:    # 16-bit planes of K, V and the table for the LDS-DMA-staged kernel (rel_attention_fwd3.hip)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    _hip.check(L.isi_rel_attention_f32(C.byref(a), _s(q)), "isi_rel_attention_f32")
     return out
 
 

@@ -466,38 +466,42 @@ def test_vqvae_against_oracle_seeded_odd_width():
 
 
 def test_unequal_codebook_sizes_keep_their_histograms_apart():
-    """num_embeddings = (1024, 512) on the default constructor (vqvae_run.cpp): the 1024-code top level is too
-    large for the fused 1x1 + search kernel and takes the two-launch path, the bottom level takes the fused one; the two
-    levels must count their codes in separate histograms -- perplexity_b against the oracle is what a shared one breaks."""
+    """num_embeddings = (544, 512) on the default constructor (vqvae_run.cpp): the two levels count their codes
+    in separate histograms of one workspace buffer, zeroed by one launch -- each level's perplexity must be that of ITS
+    ids, and the whole forward equals the oracle's.  (At D = 64 every codebook the two-launch search can hold also fits
+    the fused kernel, so a fused bottom level behind an unfused top level cannot be constructed; the unfused top level
+    nevertheless writes its own histogram now.)"""
     from oracle import vqvae_oracle as O
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     cfg = O.Config(in_channel=2)
     sd = O.init_state_dict(cfg, seed=11)
     g = torch.Generator().manual_seed(12)
     O.calibrate_codebooks(sd, cfg, torch.randn(2, 2, 64, 128, generator=g))
-    # 512 more top codes: jittered copies of the calibrated ones (in use, well apart from them)
+    # 32 more top codes: jittered copies of calibrated ones (in use, well apart from them)
     e = sd["quantize_t.embed"]
-    sd["quantize_t.embed"] = torch.cat([e, e * 1.25 + 0.05 * torch.randn(e.shape, generator=g)], 1).contiguous()
+    sd["quantize_t.embed"] = torch.cat([e, e[:, :32] * 1.25 + 0.05 * torch.randn(64, 32, generator=g)], 1).contiguous()
     sd["quantize_t.embed_avg"] = sd["quantize_t.embed"].clone()
-    sd["quantize_t.cluster_size"] = torch.zeros(1024)
+    sd["quantize_t.cluster_size"] = torch.zeros(544)
     x = torch.randn(3, 2, 64, 128, generator=g)
     ref = O.forward(x, sd, cfg)
-    m = VQVAE(in_channel=2, num_embeddings=(1024, 512))
-    m.load_state_dict(sd)
-    m = m.to(_dev()).eval()
-    dec, diff, p_t, p_b, id_t, id_b = m(x.to(_dev()))
-    assert int(id_t.max()) < 1024 and id_t.shape == ref[4].shape
-    if torch.equal(id_t.cpu(), ref[4]) and torch.equal(id_b.cpu(), ref[5]):
-        _close(dec, ref[0], TOL, "dec"); _close(diff, ref[1], TOL, "diff")
-        _close(p_t, ref[2], TOL, "perplexity_t"); _close(p_b, ref[3], TOL, "perplexity_b")
-    # whatever a near-tie did to single codes: each level's perplexity is that of ITS OWN ids (bottleneck.py:96-100)
-    for ids, K, got, what in ((id_t, 1024, p_t, "perplexity_t"), (id_b, 512, p_b, "perplexity_b")):
-        pr = torch.nn.functional.one_hot(ids.reshape(-1), K).float().mean(0)
-        _close(got, torch.exp(-(pr * torch.log(pr.clamp(min=1e-7))).sum()), 1e-5, what + " of the level's own ids")
-    # encode() (the fp32 maps requested) takes the same launches
-    q_t, q_b, diff2, id_t2, id_b2, p_t2, p_b2 = m.encode(x.to(_dev()))
-    assert torch.equal(id_t2, id_t) and torch.equal(id_b2, id_b)
-    _close(p_b2, p_b, 1e-6, "perplexity_b encode vs forward")
+    for fused in (True, False):
+        m = VQVAE(in_channel=2, num_embeddings=(544, 512))
+        m.load_state_dict(sd)
+        m = m.to(_dev()).eval()
+        from interactive_spectrogram_inpainting import _hip
+        with _hip.knob("ISI_NO_VQ_FUSION", 0 if fused else 1):
+            dec, diff, p_t, p_b, id_t, id_b = m(x.to(_dev()))
+            q_t, q_b, diff2, id_t2, id_b2, p_t2, p_b2 = m.encode(x.to(_dev()))    # (the fp32 maps requested: same launches)
+        assert int(id_t.max()) < 544 and id_t.shape == ref[4].shape
+        if torch.equal(id_t.cpu(), ref[4]) and torch.equal(id_b.cpu(), ref[5]):
+            _close(dec, ref[0], TOL, "dec"); _close(diff, ref[1], TOL, "diff")
+            _close(p_t, ref[2], TOL, "perplexity_t"); _close(p_b, ref[3], TOL, "perplexity_b")
+        # whatever a near-tie did to single codes: each level's perplexity is that of ITS OWN ids (bottleneck.py:96-100)
+        for ids, K, got, what in ((id_t, 544, p_t, "perplexity_t"), (id_b, 512, p_b, "perplexity_b")):
+            pr = torch.nn.functional.one_hot(ids.reshape(-1), K).float().mean(0)
+            _close(got, torch.exp(-(pr * torch.log(pr.clamp(min=1e-7))).sum()), 1e-5, what + " of the level's own ids")
+        assert torch.equal(id_t2, id_t) and torch.equal(id_b2, id_b)
+        _close(p_b2, p_b, 1e-6, "perplexity_b encode vs forward")
 
 
 def test_invalidate_plan_after_data_writes():

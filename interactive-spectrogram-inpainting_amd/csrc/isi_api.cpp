@@ -49,6 +49,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_ATTN_G_FROM_KV", &Knobs::attn_g_from_kv, 1, false},
     {"ISI_ATTN_OLD_FWD", &Knobs::attn_old_fwd, 0, false},
     {"ISI_ATTN_NO_FWD3", &Knobs::attn_no_fwd3, 0, false},
+    {"ISI_ATTN_FWD3_ALL", &Knobs::attn_fwd3_all, 0, false},
     {"ISI_CONV_ABLATE", &Knobs::conv_ablate, 0, true},
     {"ISI_VQ_DBG", &Knobs::vq_dbg, 0, true},
     {"ISI_RESPAIR_ABL", &Knobs::respair_abl, 0, true},
@@ -160,6 +161,7 @@ int isi_debug_resblock_pair_stamps(long long *host, int n) { return resblock_pai
 int isi_debug_vq_stamps(long long *host, int n) { return vq_debug_stamps(host, n); }
 int isi_debug_attention_stamps(long long *host, int n) { return rel_attention_debug_stamps(host, n); }
 int isi_debug_attention_fwd2_stamps(long long *host, int n) { return rel_attention_fwd2_debug_stamps(host, n); }
+int isi_debug_attention_fwd3_stamps(long long *host, int n) { return rel_attention_fwd3_debug_stamps(host, n); }
 int isi_set_dropout_seed_base(const void *device_u64) {
   g_dropout_seed_base.store(static_cast<const uint64_t *>(device_u64));
   return 0;

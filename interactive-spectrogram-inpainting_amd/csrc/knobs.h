@@ -30,6 +30,7 @@ struct Knobs {
   int attn_full_zero;           // ISI_ATTN_FULL_ZERO: the attention backward zeroes all of G, not only the margins of its band
   int attn_old_fwd;             // ISI_ATTN_OLD_FWD: the round-3 forward kernel (32-key tiles) for the 16-bit modes (A/B switch)
   int attn_no_fwd3;             // ISI_ATTN_NO_FWD3: the round-4 forward kernel (rel_attention_fwd2.hip) where the plane-staged one would run
+  int attn_fwd3_all;            // ISI_ATTN_FWD3_ALL: the plane-staged forward kernel for the single-term modes too (default: three-term only)
   int prior_graph;              // ISI_PRIOR_GRAPH: positions per replayed hipGraph of the decode loop (8; 0 = direct launches)
   int decode_mfma_rows;         // ISI_DECODE_MFMA_ROWS: batched decoding runs a stage as a 32-row GEMM tile on the fp32 matrix pipe for MORE
                                 // rows than this (16); up to it, the GEMV kernels (batch 1's operation order)

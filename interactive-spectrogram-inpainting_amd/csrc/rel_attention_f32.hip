@@ -938,6 +938,11 @@ size_t rel_attention_workspace_bytes(const isi_attn_args *g) {
   if (!g || g->Sq <= 0 || g->Sk <= 0 || g->B <= 0 || g->H <= 0 || g->precision < 1 || g->precision > 3) return 0;
   AttnKArgs a{};
   a.e = g->rel_embeddings; a.R = g->rel_rows; a.Sq = g->Sq; a.Sk = g->Sk; a.H = g->H; a.B = g->B; a.Cq = g->Cq; a.Ck = g->Ck;
+  // the plane-staged kernel pays a pack launch (10-13 us at B 8 x H 8 x S 1025): measured, it wins with three-term products
+  // (causal 91 vs 96 us, unmasked 127 vs 141) and loses 3-4 us with single-term ones -- those ask for no workspace unless
+  // ISI_ATTN_FWD3_ALL is set (a caller that hands one over anyway gets the plane-staged kernel)
+  if (g->precision != 1 && !knobs().attn_fwd3_all) return 0;
+  if (knobs().attn_no_fwd3 || knobs().attn_old_fwd) return 0;
   return rel_attention_fwd3_workspace_bytes(a, g->head_dim, g->precision);
 }
 

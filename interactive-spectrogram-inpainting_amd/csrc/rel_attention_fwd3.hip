@@ -61,6 +61,15 @@ __device__ __forceinline__ s16x8_t buf_load_frag(__amdgpu_buffer_rsrc_t rsrc, un
   i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
   return __builtin_bit_cast(s16x8_t, v);
 }
+// a fragment load the COMPILER does not wait for (it would wait with a count that knows nothing of the DMAs in flight and
+// drain them): the destination is valid only behind the kernel's own counted s_waitcnt (wait_tiles).  k-block by immediate
+// offset, plane by the scalar offset: ONE address register per lane, which the caller keeps to itself for the whole loop.
+template <int IMM>
+__device__ __forceinline__ s16x8_t buf_load_frag_async(const i32x4 rsrc, const unsigned byte_off, const unsigned soff) {
+  i32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(byte_off), "s"(rsrc), "s"(soff), "n"(IMM) : "memory");
+  return __builtin_bit_cast(s16x8_t, v);
+}
 // one LDS-DMA: lane l's 16 bytes at rsrc.base + voff + soff + IMM land at (M0 + IMM) + 16 l (conv_pair_f16.hip has the
 // form that rewrites M0 per piece).  Here M0 is written ONCE per wave, at kernel entry, and a wave's pieces are told apart by
 // the instruction's immediate offset -- which the hardware adds to the memory address as well, hence `voff` carries - IMM
@@ -137,10 +146,15 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(const PackArgs p) {
                    : p.k + ((long long)s * p.k_ss + (long long)b * p.k_sb + (long long)h * p.k_sh + 8 * g);
       dst = (is_v ? p.v16 : p.k16) + it * 8;
       plane = p.kv_plane;
-    } else {
+    } else {      // e: fragment-major, [head][16-byte piece c = 2 t + half of the row][row][8]: the 32 rows of a band tile's
+                  // fragment are 512 contiguous bytes per half-wave whatever the tile's first row (row-major, a lane's 16
+                  // bytes sat 128 bytes from its neighbour's: ~80 cycles of issue per load, tools/stamps_fwd3.py)
       const long long it = i - 2 * p.n_kv;
+      const long long row = it / g8;                       // (head, table row)
+      const int c = (int)(it - row * g8);
+      const long long hh = row / p.R, r = row - hh * p.R;
       src = p.e + it * 8;
-      dst = p.e16 + it * 8;
+      dst = p.e16 + ((hh * g8 + c) * p.R + r) * 8;
       plane = p.e_plane;
     }
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
@@ -171,9 +185,11 @@ template <int HD, int TERMS> struct Tile3 {
   static constexpr int PPT = TILEB / 1024;                  // 1-KiB DMA pieces per plane of a tile
   static constexpr int PT = NPL * PPT;                      // ... per tile
   static constexpr int NPW = (PT + 3) / 4;                  // ... per wave (the four waves of a group share a tile)
-  // LDS: every wave owns one contiguous slot [K pieces NPW][V pieces NPW] (one M0 per wave, see dma16): piece pid of a
-  // group's K tile lives in the slot of wave pid % 4 at (pid / 4) KiB, of its V tile NPW KiB further
-  static constexpr int WAVEB = 2 * NPW * 1024;
+  // LDS: every wave owns one contiguous slot of two STAGES [K pieces NPW | V pieces NPW]: piece pid of a group's K tile
+  // of sub-block n lives in stage n & 1 of wave pid % 4's slot at (pid / 4) KiB; its V tile in stage (n + 1) & 1, NPW KiB
+  // further -- so that the two tiles a vector segment requests (K of n + 2, V of n + 1) go to ONE stage, under one M0
+  static constexpr int STAGEB = 2 * NPW * 1024;
+  static constexpr int WAVEB = 2 * STAGEB;
   static constexpr size_t kv_bytes = (size_t)8 * WAVEB;
   static constexpr size_t smem = kv_bytes + (size_t)(8 * 32 * LD) * sizeof(float);
 };
@@ -192,15 +208,16 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
   using PR = Prec<F16>;
   using TL = Tile3<HD, TERMS>;
   constexpr bool ONE = TERMS == 1;
-  constexpr int NPL = TL::NPL, ROWB = TL::ROWB, PPT = TL::PPT, PT = TL::PT, NPW = TL::NPW, WAVEB = TL::WAVEB;
+  constexpr int NPL = TL::NPL, ROWB = TL::ROWB, PPT = TL::PPT, PT = TL::PT, NPW = TL::NPW, STAGEB = TL::STAGEB, WAVEB = TL::WAVEB;
   constexpr int NKB = HD / 16;           // 16-deep k-blocks of the head dim
   constexpr int NDB = HD / 32;           // 32-row blocks of O^T
   constexpr int PPR = HD / 8;            // 16-byte pieces per tile row
   constexpr int KPP = 64 / PPR;          // keys per 1-KiB DMA
+  constexpr int NE = NKB * NPL;          // loads of one band tile's fragments
   static_assert(HD == 64 || HD == 32, "head dim");
-  static_assert(2 * NPW * 1024 <= 4096 && (2 * NPW - 1) * 1024 <= (int)DMA_MARGIN, "immediate offsets of a wave's pieces");
+  static_assert(STAGEB <= 4096 && (2 * NPW - 1) * 1024 <= (int)DMA_MARGIN, "immediate offsets of a stage's pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned char *KV = reinterpret_cast<unsigned char *>(smem);        // [wave 8][K pieces NPW | V pieces NPW][1 KiB]
+  unsigned char *KV = reinterpret_cast<unsigned char *>(smem);        // [wave 8][stage 2][K pieces NPW | V pieces NPW][1 KiB]
   float *Sr = reinterpret_cast<float *>(KV + 8 * WAVEB);              // [8][32][LD]
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -211,21 +228,20 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
   if (!xcd_tile(nW, p.H * p.B, false, w, pair)) return;
   const int h = pair % p.H, b = pair / p.H;
   const int nqb = p.nblk;
-  const bool has_e = p.e != nullptr;
   const int rag = (p.mask_mode == 1 && nqb * QB >= p.Sq) ? p.Sq % QB : 0;   // (see rel_attention_fwd2.hip)
 
   const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.q), 0, p.q_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(has_e ? x.e16 : x.k16), 0,
-                                                                      has_e ? x.e_bytes : 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t re = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(x.e16), 0, x.e_bytes, 0x00020000);
+  const i32x4 re_a = make_rsrc(x.e16, x.e_bytes);
   const i32x4 rk = make_rsrc(reinterpret_cast<const unsigned char *>(x.k16) - DMA_MARGIN, x.kv_bytes + DMA_MARGIN);
   const i32x4 rv = make_rsrc(reinterpret_cast<const unsigned char *>(x.v16) - DMA_MARGIN, x.kv_bytes + DMA_MARGIN);
-  {   // M0 = this wave's slot, for the whole kernel
-    const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)KV + (unsigned)(wave * WAVEB);
-    asm volatile("s_mov_b32 m0, %0" :: "s"(m0v) : "memory");
-  }
+  // M0 = the stage of this wave's slot the NEXT requests go to; written once per step, a segment ahead of its use
+  const unsigned m0_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)KV + (unsigned)(wave * WAVEB);
+  auto set_m0 = [&](const int stage) { asm volatile("s_mov_b32 m0, %0\n\ts_nop 7" :: "s"(m0_base + (unsigned)(stage * STAGEB)) : "memory"); };
 
   const float qscale = p.scale * LOG2E;
   float *sr = Sr + wave * 32 * LD + ql * LD;
+  const bool dma_wave = wq < PT;          // (head_dim 32, single-term: a tile is two pieces, waves 2 and 3 of a group request none)
 
   // ---- this lane's share of the group's DMAs: piece pid = wq + 4 j of a tile = plane pid / PPT, keys KPP (pid % PPT) ..
   unsigned dma_voff_k[NPW], dma_voff_v[NPW];
@@ -239,16 +255,30 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
     dma_voff_v[j] = DMA_MARGIN - (unsigned)((NPW + j) * 1024) + (unsigned)(pl * x.kv_plane_bytes + key * ROWB + ((pos ^ swv) << 4));
   }
   const unsigned pair_row0 = (unsigned)pair * (unsigned)x.Skp;     // first row of this pair in a plane
-  auto issue_k = [&](const int k0) {
+  auto issue_k = [&](const int k0) {     // into the stage M0 points at
     const unsigned soff = (pair_row0 + (unsigned)k0) * (unsigned)ROWB;
-    if (wq < PT) dma16<0>(dma_voff_k[0], rk, soff);
-    if constexpr (NPW > 1) { if (wq + 4 < PT) dma16<1024>(dma_voff_k[NPW - 1], rk, soff); }
+    if (dma_wave) {
+      dma16<0>(dma_voff_k[0], rk, soff);
+      if constexpr (NPW > 1) dma16<1024>(dma_voff_k[NPW - 1], rk, soff);
+    }
   };
   auto issue_v = [&](const int k0) {
     const unsigned soff = (pair_row0 + (unsigned)k0) * (unsigned)ROWB;
-    if (wq < PT) dma16<NPW * 1024>(dma_voff_v[0], rv, soff);
-    if constexpr (NPW > 1) { if (wq + 4 < PT) dma16<(NPW + 1) * 1024>(dma_voff_v[NPW - 1], rv, soff); }
+    if (dma_wave) {
+      dma16<NPW * 1024>(dma_voff_v[0], rv, soff);
+      if constexpr (NPW > 1) dma16<(NPW + 1) * 1024>(dma_voff_v[NPW - 1], rv, soff);
+    }
   };
+  // Requests in flight per wave, oldest first, when a vector segment ends: [the DMAs of the previous segment] [this segment's
+  // band fragments for the next sub-block] [this segment's DMAs] (+ stores of kept logits, which may overtake loads, never
+  // the other way round): the counted wait lets the last group fly on -- never vmcnt(0) in the loop.  (With stores in
+  // flight the same count merely waits for more.)  No vector-memory request is issued in a matrix segment: the four
+  // fragment loads there queued behind the other group's DMA burst and held the wave's matrix instructions back with them.
+  auto wait_tiles = [&]() {
+    if (dma_wave) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
   // ---- fragment addresses.  Piece (plane pl, index i) of this group's K tile sits in the slot of wave (pl PPT + i) % 4 at
   // (pl PPT + i) / 4 KiB, its V twin NPW KiB further: for both head dims the plane and the 8-key (16-key) index enter as constants
   constexpr int PLANE_OFF = HD == 64 ? 1024 : 2 * WAVEB;       // plane 1 - plane 0 of the same keys
@@ -266,13 +296,18 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
 #pragma unroll
   for (int d = 0; d < NDB; ++d)
     Vb[d] = KV + grp * 4 * WAVEB + NPW * 1024 + (4 * half + (vi >> 2)) * ROWB + (((d ^ vflip) * 4 + 2 * g16 + ((vi & 3) >> 1)) << 4) + 8 * (vi & 1);
-  auto vfrag = [](const unsigned char *q) {
-    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(q));
-    const s16x4_t c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(q + V_WHICH));
-    return __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+  auto vfrag = [](const unsigned a) {
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(size_t)a);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(size_t)(a + V_WHICH));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   };
-  // e: A-operand fragment of band row `row` (lane = row), k-block t, plane pl: 16 bytes of the table row
-  const unsigned e_lane = (unsigned)(h * p.R) * ROWB + 16u * half;
+  unsigned Va[NDB];
+#pragma unroll
+  for (int d = 0; d < NDB; ++d) Va[d] = (unsigned)(size_t)(__attribute__((address_space(3))) const unsigned char *)Vb[d];
+  // e: A-operand fragment of band row `row` (lane = row), k-block t, plane pl: piece 2 t + half of the table row, in the
+  // fragment-major layout [head][piece][row][16 B] (attn_pack_kernel)
+  const unsigned e_lane = ((unsigned)(h * PPR + half) * (unsigned)p.R) * 16u;
+  const unsigned e_tstep = 2u * (unsigned)p.R * 16u;       // k-block t -> t + 1
 
   struct Item { int q0, q_end, k_begin, k_end; bool valid; };
   auto item_of = [&](int it) {
@@ -288,16 +323,64 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
   };
 
   if (grp == 1) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses issue arbitration otherwise (MI355X guide)
+  // ---- what a block needs before its first step: Q, the K tiles of its sub-blocks 0 and 1, the V tile of sub-block 0, the
+  // first band fragments
+  struct Geom { int q0, q_end, k_end, qw0, qi, sb_end, g_first, g_count, nsteps; };
+  auto geom_of = [&](const Item &c) {
+    Geom g;
+    g.q0 = c.q0; g.q_end = c.q_end; g.k_end = c.k_end;
+    g.qw0 = c.q0 + 32 * wq; g.qi = g.qw0 + ql;
+    const int sb_begin = c.k_begin / 32;
+    g.sb_end = (c.k_end + 31) / 32;
+    const int nsb = g.sb_end - sb_begin, n0 = (nsb + 1) / 2;
+    g.g_first = grp ? sb_begin + n0 : sb_begin;      // this group's sub-blocks: the first half of the block's, or the second
+    g.g_count = grp ? nsb - n0 : n0;
+    g.nsteps = n0;
+    return g;
+  };
+  float4 qa[NKB], qc[NKB];
+  s16x8_t en[NKB][NPL];                        // band fragments of the coming sub-block's NEW tile
+  unsigned e_voff;
+  // The asynchronous fragment loads: one address register, k-block and plane in the scalar offset (out-of-range lanes stay
+  // out of range: the check looks at the vector offset alone).  Valid behind wait_tiles / vmcnt(0) only.
+  auto load_e_async = [&](const int wrow) {
+    const int r = wrow + ql;
+    e_voff = (r >= 0 && r < p.R) ? e_lane + (unsigned)r * 16u : 0x7FFFFF00u;
+#pragma unroll
+    for (int t = 0; t < NKB; ++t)
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+        en[t][pl] = buf_load_frag_async<0>(re_a, e_voff, e_tstep * t + pl * x.e_plane_bytes);
+  };
+  auto request_block = [&](const Geom &g) {
+#pragma unroll
+    for (int t = 0; t < NKB; ++t) {
+      const unsigned off = g.qi < g.q_end ? (unsigned)(g.qi * p.q_ss + b * p.q_sb + h * p.q_sh + 16 * t + 8 * half) * 4u : OOB;
+      qa[t] = buf_load4(rq, off);
+      qc[t] = buf_load4(rq, off == OOB ? OOB : off + 16u);
+    }
+    // K of sub-blocks 0 and 1, V of sub-block 0 (stage parities: see Tile3); beyond the group's range the block's last one
+    set_m0(0);
+    issue_k(32 * min(g.g_first, g.sb_end - 1));
+    set_m0(1);
+    issue_k(32 * min(g.g_first + 1, g.sb_end - 1));
+    issue_v(32 * min(g.g_first, g.sb_end - 1));
+    load_e_async(g.qw0 - (32 * g.g_first + 31) + p.Ek - 1);
+  };
+
+  // workgroup barrier for LDS traffic only (__syncthreads would also wait for the next block's requests in flight)
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
   Item cur = item_of(0);
   for (int it = 0; cur.valid; ++it) {
     ISI_F3_STAMP(0);
-    const int q0 = cur.q0, q_end = cur.q_end, k_end = cur.k_end;
-    const int qw0 = q0 + 32 * wq, qi = qw0 + ql;
-    // ---- the block's sub-blocks, split between the groups; this wave's live range inside its group's
-    const int sb_begin = cur.k_begin / 32, sb_end = (k_end + 31) / 32, nsb = sb_end - sb_begin;
-    const int n0 = (nsb + 1) / 2;
-    const int g_first = grp ? sb_begin + n0 : sb_begin, g_count = grp ? nsb - n0 : n0;   // this group's sub-blocks
-    const int nsteps = n0;
+    const Geom G = geom_of(cur);
+    request_block(G);
+    const int q_end = G.q_end, k_end = G.k_end, qw0 = G.qw0, qi = G.qi, sb_end = G.sb_end;
+    const int g_first = G.g_first, g_count = G.g_count, nsteps = G.nsteps;
     auto live_at = [&](int s) {
       if (s < 0 || s >= g_count || qw0 >= q_end) return false;
       const int k0 = 32 * (g_first + s);
@@ -306,48 +389,39 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
       if (p.mask_mode == 2) lv = lv && k0 + 31 >= qw0;
       return lv;
     };
+    // first key of this group's sub-block s; beyond the group's range the last sub-block of the block again (requests are
+    // unconditional -- the counted waits need the same number of them on every step -- and must stay inside the planes)
+    auto k0_of = [&](int s) { return 32 * min(g_first + s, sb_end - 1); };
     // lowest table row of the 32-row band tile a sub-block at k0 adds (its band is rows wrow .. wrow + 63)
     auto wrow_of = [&](int s) { return qw0 - (32 * (g_first + s) + 31) + p.Ek - 1; };
     auto load_e = [&](s16x8_t (&f)[NKB][NPL], const int wrow) {
       const int r = wrow + ql;
-      const unsigned base = (r >= 0 && r < p.R) ? e_lane + (unsigned)r * ROWB : OOB;
+      const unsigned base = (r >= 0 && r < p.R) ? e_lane + (unsigned)r * 16u : OOB;
 #pragma unroll
       for (int t = 0; t < NKB; ++t)
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl)
-          f[t][pl] = buf_load_frag(re, base == OOB ? OOB : base + 32u * t + pl * x.e_plane_bytes);
+          f[t][pl] = buf_load_frag(re, base == OOB ? OOB : base + e_tstep * t + pl * x.e_plane_bytes);
     };
-
     // ---- Q fragment of this lane's query, scaled and split once: k-block t holds dims 16 t + 8 half + 0..7
     s16x8_t qh[NKB], qlo[NKB];
-    {
-      float4 qa[NKB], qc[NKB];
 #pragma unroll
-      for (int t = 0; t < NKB; ++t) {
-        const unsigned off = qi < q_end ? (unsigned)(qi * p.q_ss + b * p.q_sb + h * p.q_sh + 16 * t + 8 * half) * 4u : OOB;
-        qa[t] = buf_load4(rq, off);
-        qc[t] = buf_load4(rq, off == OOB ? OOB : off + 16u);
+    for (int t = 0; t < NKB; ++t) {
+      const float4 a = qa[t], c = qc[t];
+      unsigned hh[4], ll[4];
+      if constexpr (ONE) {
+        hh[0] = PR::pack2(a.x * qscale, a.y * qscale); hh[1] = PR::pack2(a.z * qscale, a.w * qscale);
+        hh[2] = PR::pack2(c.x * qscale, c.y * qscale); hh[3] = PR::pack2(c.z * qscale, c.w * qscale);
+        ll[0] = ll[1] = ll[2] = ll[3] = 0u;
+      } else {
+        PR::split2(a.x * qscale, a.y * qscale, hh[0], ll[0]); PR::split2(a.z * qscale, a.w * qscale, hh[1], ll[1]);
+        PR::split2(c.x * qscale, c.y * qscale, hh[2], ll[2]); PR::split2(c.z * qscale, c.w * qscale, hh[3], ll[3]);
       }
-#pragma unroll
-      for (int t = 0; t < NKB; ++t) {
-        const float4 a = qa[t], c = qc[t];
-        unsigned hh[4], ll[4];
-        if constexpr (ONE) {
-          hh[0] = PR::pack2(a.x * qscale, a.y * qscale); hh[1] = PR::pack2(a.z * qscale, a.w * qscale);
-          hh[2] = PR::pack2(c.x * qscale, c.y * qscale); hh[3] = PR::pack2(c.z * qscale, c.w * qscale);
-          ll[0] = ll[1] = ll[2] = ll[3] = 0u;
-        } else {
-          PR::split2(a.x * qscale, a.y * qscale, hh[0], ll[0]); PR::split2(a.z * qscale, a.w * qscale, hh[1], ll[1]);
-          PR::split2(c.x * qscale, c.y * qscale, hh[2], ll[2]); PR::split2(c.z * qscale, c.w * qscale, hh[3], ll[3]);
-        }
-        qh[t] = __builtin_bit_cast(s16x8_t, make_uint4(hh[0], hh[1], hh[2], hh[3]));
-        qlo[t] = __builtin_bit_cast(s16x8_t, make_uint4(ll[0], ll[1], ll[2], ll[3]));   // dead when ONE
-      }
+      qh[t] = __builtin_bit_cast(s16x8_t, make_uint4(hh[0], hh[1], hh[2], hh[3]));
+      qlo[t] = __builtin_bit_cast(s16x8_t, make_uint4(ll[0], ll[1], ll[2], ll[3]));   // dead when ONE
     }
-    // first K tile of this group
-    if (g_count > 0) issue_k(32 * g_first);
-    s16x8_t en[NKB][NPL];                        // band fragments of the coming sub-block's NEW tile
-    if (has_e && live_at(0)) load_e(en, wrow_of(0));
+    // the row of this lane's query in the kept logits (training: the backward reads them back), its first key column
+    float *lbase = p.logits ? p.logits + (((size_t)b * p.H + h) * p.Sq + min(qi, p.Sq - 1)) * p.ldl + 4 * half : nullptr;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -359,112 +433,186 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
     for (int d = 0; d < NDB; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) O[d][r] = 0.f;
-    f32x16 sacc, rprev;                 // logits of the sub-block in flight; its band tile (the next one's upper half)
+    f32x16 sacc, rnew, rprev;           // logits of the sub-block in flight; its band tile; the tile above it (the previous one's)
     s16x8_t ph[2], pl_[2];              // P of the sub-block whose P V is pending
     float alpha = 1.f;
     bool have_prev = false;             // rprev holds the band tile [wrow + 32, wrow + 64) of the coming sub-block
 
-    // ---- P V of sub-block s (matrix segment)
-    auto pv = [&]() {
-      const bool rescale = __any(alpha != 1.f);
+    // ---- matrix segment of step s: P V of sub-block s - 1, K Q^T and the band tile of sub-block s.  All LDS fragments are
+    // requested FIRST (hipcc waited for each pair of reads right in front of its matrix instruction: ~1000 of the
+    // segment's 1950 cycles were exposed LDS latency, tools/stamps_fwd3.py), the rescaling of O runs under their flight
+    auto matrix_segment = [&](const int s, const bool pv_live, const bool qk_live) {
+      const int st = (s & 1) * STAGEB;
+      [[maybe_unused]] const int sbase = 8 + 8 * s;
+      s16x8_t vf[NDB][2][NPL], kf[NKB][NPL];
+      unsigned va[NDB];
 #pragma unroll
-      for (int d = 0; d < NDB; ++d) {
-        if (rescale) {
+      for (int d = 0; d < NDB; ++d) va[d] = Va[d] + (unsigned)st;
+      // order: every LDS fragment requested first; the band tile (operands in registers: nothing to wait for) runs under
+      // their flight, and its fragment registers are re-requested for the next sub-block right behind it; then K Q^T; then
+      // the rescaling of O and P V
+#ifndef F3KA
+#define F3KA (NKB / 2)
+#endif
+#ifndef F3VA
+#define F3VA 0
+#endif
+      constexpr int KA = ONE ? NKB : F3KA;   // K fragments requested up front (three-term: the rest behind the band tile)
+      if (qk_live) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
-        }
+        for (int t = 0; t < KA; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const s16x8_t vh = vfrag(Vb[d] + t * V_T);
-          if constexpr (!ONE) {
-            const s16x8_t vl = vfrag(Vb[d] + PLANE_OFF + t * V_T);
-            O[d] = PR::mfma(vl, ph[t], O[d]);
-            O[d] = PR::mfma(vh, pl_[t], O[d]);
-          }
-          O[d] = PR::mfma(vh, ph[t], O[d]);
-        }
+          for (int pl = 0; pl < NPL; ++pl)
+            kf[t][pl] = *reinterpret_cast<const s16x8_t *>(Kb + st + pl * PLANE_OFF + (((2 * t + half) ^ swk_l) << 4));
       }
-    };
-    // ---- K Q^T and the band tile(s) of sub-block s (matrix segment); leaves sacc = K Q^T, rnew = the new band tile
-    f32x16 rnew;
-    auto qk_band = [&](const int s) {
+      constexpr int VA = ONE ? 2 : F3VA;     // V fragments (key blocks t) requested up front (three-term: behind K Q^T)
+      if (pv_live) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = rnew[r] = 0.f;
-      const bool first = has_e && !have_prev;       // wave-uniform: both band tiles (once per wave and block)
-      s16x8_t fk[2][NPL];
-      auto rd = [&](int t, int s_) {
+        for (int t = 0; t < VA; ++t)
 #pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-          fk[s_][pl] = *reinterpret_cast<const s16x8_t *>(Kb + pl * PLANE_OFF + (((2 * t + half) ^ swk_l) << 4));
+          for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int pl = 0; pl < NPL; ++pl) vf[d][t][pl] = vfrag(va[d] + pl * PLANE_OFF + t * V_T);
+      }
+      // the skew buffer is WRITTEN here, under the matrix instructions, and only read back in the vector segment (its eight
+      // 1-KiB stores per wave used to be the first thing behind the barrier, together with the other group's fragment reads)
+      auto put_tile = [&](const f32x16 &tile, const int col0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4 *>(sr + col0 + 8 * g + 4 * half) = make_float4(tile[4 * g], tile[4 * g + 1], tile[4 * g + 2], tile[4 * g + 3]);
       };
-      rd(0, 0);
+      if constexpr (ONE) {
+        // single-term products: one matrix instruction per k-block and chain.  The band tile is summed in TWO accumulators
+        // (even / odd k-blocks, added at the end); K Q^T merged instruction by instruction with the two chains of P V was
+        // measured and dropped (it needs every fragment live at once: 256 registers + scratch, 58 -> 74 us)
+        if (qk_live) {
+          f32x16 rodd;
 #pragma unroll
-      for (int t = 0; t < NKB; ++t) {
-        const int c_ = t & 1;
-        if (t + 1 < NKB) rd(t + 1, c_ ^ 1);
-        if constexpr (ONE) {
-          if (has_e) rnew = PR::mfma(en[t][0], qh[t], rnew);
-          sacc = PR::mfma(fk[c_][0], qh[t], sacc);
-        } else {
-          if (has_e) rnew = PR::mfma(en[t][1], qh[t], rnew);
-          sacc = PR::mfma(fk[c_][1], qh[t], sacc);
-          if (has_e) rnew = PR::mfma(en[t][0], qlo[t], rnew);
-          sacc = PR::mfma(fk[c_][0], qlo[t], sacc);
-          if (has_e) rnew = PR::mfma(en[t][0], qh[t], rnew);
-          sacc = PR::mfma(fk[c_][0], qh[t], sacc);
-        }
-      }
-      if (first) {    // the upper band tile through the same fragment registers (its latency is exposed: once per block)
-        load_e(en, wrow_of(s) + 32);
+          for (int r = 0; r < 16; ++r) sacc[r] = rnew[r] = rodd[r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rprev[r] = 0.f;
-#pragma unroll
-        for (int t = 0; t < NKB; ++t) {
-          if constexpr (ONE) {
-            rprev = PR::mfma(en[t][0], qh[t], rprev);
-          } else {
-            rprev = PR::mfma(en[t][1], qh[t], rprev);
-            rprev = PR::mfma(en[t][0], qlo[t], rprev);
-            rprev = PR::mfma(en[t][0], qh[t], rprev);
+          for (int t = 0; t < NKB; t += 2) {
+            rnew = PR::mfma(en[t][0], qh[t], rnew);
+            rodd = PR::mfma(en[t + 1][0], qh[t + 1], rodd);
           }
+          if (!have_prev) {    // wave-uniform, once per wave and block: the upper band tile through the same fragment registers
+            load_e(en, wrow_of(s) + 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rprev[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NKB; ++t) rprev = PR::mfma(en[t][0], qh[t], rprev);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rnew[r] += rodd[r];
+        }
+        ISI_F3_STAMP(sbase + 4);
+        if (qk_live) {
+#pragma unroll
+          for (int t = 0; t < NKB; ++t) sacc = PR::mfma(kf[t][0], qh[t], sacc);
+        }
+        if (pv_live) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) O[d] = PR::mfma(vf[d][t][0], ph[t], O[d]);
+        }
+        if (qk_live) {
+          put_tile(rprev, 32);
+          put_tile(rnew, 0);
+          rprev = rnew;                  // the next sub-block's upper band tile
+          have_prev = true;
+        }
+        ISI_F3_STAMP(sbase + 5);
+      } else {
+        // three-term products: the three instructions of a product follow each other on one accumulator (forwarded); the
+        // register budget (242 of 256) leaves no second band accumulator and stages the fragment requests
+        if (qk_live) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[r] = rnew[r] = 0.f;
+#pragma unroll
+          for (int t = 0; t < NKB; ++t) {
+            rnew = PR::mfma(en[t][1], qh[t], rnew);
+            rnew = PR::mfma(en[t][0], qlo[t], rnew);
+            rnew = PR::mfma(en[t][0], qh[t], rnew);
+          }
+          if (!have_prev) {    // wave-uniform, once per wave and block: the upper band tile through the same fragment registers
+            load_e(en, wrow_of(s) + 32);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rprev[r] = 0.f;
+#pragma unroll
+            for (int t = 0; t < NKB; ++t) {
+              rprev = PR::mfma(en[t][1], qh[t], rprev);
+              rprev = PR::mfma(en[t][0], qlo[t], rprev);
+              rprev = PR::mfma(en[t][0], qh[t], rprev);
+            }
+          }
+        }
+        ISI_F3_STAMP(sbase + 4);
+        if (qk_live) {
+          if constexpr (KA < NKB) {
+#pragma unroll
+            for (int t = KA; t < NKB; ++t)
+#pragma unroll
+              for (int pl = 0; pl < NPL; ++pl)
+                kf[t][pl] = *reinterpret_cast<const s16x8_t *>(Kb + st + pl * PLANE_OFF + (((2 * t + half) ^ swk_l) << 4));
+          }
+#pragma unroll
+          for (int t = 0; t < NKB; ++t) {
+            sacc = PR::mfma(kf[t][NPL - 1], qh[t], sacc);
+            sacc = PR::mfma(kf[t][0], qlo[t], sacc);
+            sacc = PR::mfma(kf[t][0], qh[t], sacc);
+          }
+          put_tile(rprev, 32);
+          put_tile(rnew, 0);
+          rprev = rnew;                  // the next sub-block's upper band tile
+          have_prev = true;
+        }
+        ISI_F3_STAMP(sbase + 5);
+        if (pv_live) {
+          if constexpr (VA < 2) {
+#pragma unroll
+            for (int t = VA; t < 2; ++t)
+#pragma unroll
+              for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl) vf[d][t][pl] = vfrag(va[d] + pl * PLANE_OFF + t * V_T);
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+              O[d] = PR::mfma(vf[d][t][NPL - 1], ph[t], O[d]);
+              O[d] = PR::mfma(vf[d][t][0], pl_[t], O[d]);
+              O[d] = PR::mfma(vf[d][t][0], ph[t], O[d]);
+            }
         }
       }
     };
-    // ---- skew, mask, online softmax of sub-block s (vector segment): sacc -> P operands, alpha
+    // the skewed read-back of sub-block s: sixteen explicit ds_read_b32, issued at the head of the vector segment; the
+    // segment's vector-memory requests go out under their flight, ONE full lgkmcnt drain follows (softmax).  What hipcc makes
+    // of the plain C++ form -- ds_read2_b32 pairs whose destination pair starts at their own address register, counted
+    // lgkmcnt waits, v_pk_add_f32 with op_sel straight behind them -- now and then delivered a STALE upper register to the
+    // add for lanes 48-63 (the band term of one key missing for 16 queries: 3-29 of 32 runs wrong at B 8 x H 8 x S 1025,
+    // worst right behind the block barrier; profiles/r06_attention_skew_race.txt); this form: 0 of 300.
+    float rl[16];
+    auto skew_reads = [&]() {
+      const float *rd = sr + ql + 31 - 4 * half;     // band row ql + 31 - (key row in the sub-block)
+      const unsigned ra = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(rd - 27);
+#define F3_RD(r_) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rl[r_]) : "v"(ra), "n"(4 * (27 - (((r_) & 3) + 8 * ((r_) >> 2)))) : "memory")
+      F3_RD(0); F3_RD(1); F3_RD(2); F3_RD(3); F3_RD(4); F3_RD(5); F3_RD(6); F3_RD(7);
+      F3_RD(8); F3_RD(9); F3_RD(10); F3_RD(11); F3_RD(12); F3_RD(13); F3_RD(14); F3_RD(15);
+#undef F3_RD
+    };
+    // ---- mask, online softmax of sub-block s (vector segment): sacc + skewed band -> P operands, alpha
     auto softmax = [&](const int s) {
       const int k0 = 32 * (g_first + s);
-      if (has_e) {
+      __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0), as the builtin: hipcc's own count of LDS operations in flight restarts at zero here
+      asm volatile("" ::: "memory");
+      ISI_F3_STAMP(8 + 8 * s + 6);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          *reinterpret_cast<float4 *>(sr + 8 * g + 4 * half) = make_float4(rnew[4 * g], rnew[4 * g + 1], rnew[4 * g + 2], rnew[4 * g + 3]);
-          *reinterpret_cast<float4 *>(sr + 32 + 8 * g + 4 * half) = make_float4(rprev[4 * g], rprev[4 * g + 1], rprev[4 * g + 2], rprev[4 * g + 3]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        float rl[16];
-        const float *rd = sr + ql + 31 - 4 * half;     // band row ql + 31 - (key row in the sub-block)
-        {   // The skewed read-back as sixteen explicit ds_read_b32 + ONE full lgkmcnt drain.  What hipcc makes of the plain C++
-            // form here -- ds_read2_b32 pairs whose destination pair starts at their own address register, counted
-            // lgkmcnt waits, v_pk_add_f32 with op_sel straight behind them -- now and then delivered a STALE upper register
-            // to the add for lanes 48-63 (the band term of one key missing for 16 queries: 3-29 of 32 runs wrong at
-            // B 8 x H 8 x S 1025, worst right behind the block barrier; profiles/r06_attention_skew_race.txt); this form: 0 of 300.
-          const unsigned ra = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(rd - 27);
-#define F3_RD(r_) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rl[r_]) : "v"(ra), "n"(4 * (27 - (((r_) & 3) + 8 * ((r_) >> 2)))) : "memory")
-          F3_RD(0); F3_RD(1); F3_RD(2); F3_RD(3); F3_RD(4); F3_RD(5); F3_RD(6); F3_RD(7);
-          F3_RD(8); F3_RD(9); F3_RD(10); F3_RD(11); F3_RD(12); F3_RD(13); F3_RD(14); F3_RD(15);
-#undef F3_RD
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] += rl[r];
-        rprev = rnew;                  // the next sub-block's upper band tile
-        have_prev = true;
-      }
+      for (int r = 0; r < 16; ++r) sacc[r] += rl[r];
       float sv[16];
       float tmax;
-      float *lrow = p.logits ? p.logits + (((size_t)b * p.H + h) * p.Sq + min(qi, p.Sq - 1)) * p.ldl + k0 + 4 * half : nullptr;
+      float *lrow = lbase ? lbase + k0 : nullptr;
       bool full = !p.mask && k0 + 31 < p.Sk && qw0 + 31 < q_end;
       if (p.mask_mode == 1) full = full && k0 + 31 <= qw0;
       if (p.mask_mode == 2) full = full && k0 >= qw0 + 31;
@@ -527,6 +675,11 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
         m_run = m_new;
       }
       l_run = l_run * alpha + psum;
+      // O is rescaled HERE, in the vector segment (the matrix segment is the longer one of the two)
+#pragma unroll
+      for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[d][r] *= alpha;
       // P as MFMA B operand: key block t = registers 8 t .. 8 t + 7
       if constexpr (ONE) {
 #pragma unroll
@@ -548,28 +701,33 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
     // ---- the segments.  Group 1 runs one segment behind group 0 (one extra barrier here, one for group 0 at the end).
     if (grp == 1) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     for (int s = 0; s < nsteps; ++s) {
-      [[maybe_unused]] const int sbase = 4 + 4 * s;
+      [[maybe_unused]] const int sbase = 8 + 8 * s;
       ISI_F3_STAMP(sbase);
-      // matrix segment
-      if (live_at(s - 1)) pv();
+      set_m0(s & 1);            // for the requests of this step's vector segment
       const bool lv = live_at(s);
       if (!lv) have_prev = false;
-      if (lv) qk_band(s);
-      if (has_e && live_at(s + 1)) load_e(en, wrow_of(s + 1));
+      matrix_segment(s, live_at(s - 1), lv);
+      // gfx950 counts at most 15 LDS operations in flight per wave and hipcc keeps its own tally: with the tile stores of one
+      // step still on it, it put `s_waitcnt lgkmcnt(3 / 7)` in front of EVERY fragment read of the next -- a dozen exposed
+      // LDS round trips, ~1000 cycles per matrix segment (tools/stamps_fwd3.py).  Drained here, visibly to the compiler.
+      __builtin_amdgcn_s_waitcnt(0xc07f);
       ISI_F3_STAMP(sbase + 1);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       ISI_F3_STAMP(sbase + 2);
-      // vector segment: this group's V tile of sub-block s and K tile of sub-block s + 1 travel meanwhile
-      if (s < g_count) issue_v(32 * (g_first + s));
-      if (s + 1 < g_count) issue_k(32 * (g_first + s + 1));
+      // vector segment: V of sub-block s + 1 and K of sub-block s + 2 into the stage the matrix segment has just read
+      if (lv) skew_reads();
+      load_e_async(wrow_of(s + 1));      // (on every step: the counted wait below needs the same requests each time)
+      issue_v(k0_of(s + 1));
+      issue_k(k0_of(s + 2));
       if (lv) softmax(s);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ISI_F3_STAMP(sbase + 7);
+      wait_tiles();
       ISI_F3_STAMP(sbase + 3);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
-    if (live_at(nsteps - 1)) pv();
+    matrix_segment(nsteps, live_at(nsteps - 1), false);
     if (grp == 0) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
 
     ISI_F3_STAMP(240);
@@ -578,6 +736,10 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
     constexpr int MGW = (NDB * 16 + 2) * 64;
     static_assert((size_t)4 * MGW <= (size_t)8 * 32 * LD, "merge buffer must fit in the skew buffers");
     __syncthreads();
+    // (requesting the NEXT block's Q and first tiles here, under the merge and the stores, was measured: the prologue left
+    // the timeline, but Q and the fragments then live across the merge -- 256 registers + scratch in the three-term kernel
+    // (91 -> 97 us), nothing gained in the single-term one (60.5 -> 60.8 us))
+    const Item nxt = item_of(it + 1);
     if (grp == 1) {
       float *dst = mg + wq * MGW + lane;
 #pragma unroll
@@ -587,7 +749,7 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
       dst[NDB * 16 * 64] = m_run;
       dst[(NDB * 16 + 1) * 64] = l_run;
     }
-    __syncthreads();
+    lds_sync();
     if (grp == 0) {
       const float *src = mg + wq * MGW + lane;
       const float m1 = src[NDB * 16 * 64], l1 = src[(NDB * 16 + 1) * 64];
@@ -601,7 +763,7 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[d][r] = O[d][r] * a0 + src[(d * 16 + r) * 64] * a1;
     }
-    __syncthreads();            // the merge buffer is free again
+    lds_sync();                 // the merge buffer is free again
     ISI_F3_STAMP(241);
     if (grp == 0 && qi < q_end) {
       const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -618,7 +780,7 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
         }
     }
     ISI_F3_STAMP(242);
-    cur = item_of(it + 1);
+    cur = nxt;
   }
 }
 
@@ -648,7 +810,7 @@ PlaneLayout plane_layout(const AttnKArgs &a, int head_dim, int precision) {
 }  // namespace
 
 bool rel_attention_fwd3_ok(const AttnKArgs &a, int head_dim, int precision) {
-  if (!(a.Cq == 1 && a.Ck == 1) || !(head_dim == 64 || head_dim == 32) || precision < 1 || precision > 3) return false;
+  if (!(a.Cq == 1 && a.Ck == 1) || !(head_dim == 64 || head_dim == 32) || precision < 1 || precision > 3 || !a.e) return false;
   const PlaneLayout L = plane_layout(a, head_dim, precision);
   // one buffer descriptor per operand over all its planes (32-bit offsets)
   return L.npl * L.kv_plane * 2 < ((size_t)1 << 31) && L.npl * L.e_plane * 2 < ((size_t)1 << 31);

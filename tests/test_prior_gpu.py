@@ -116,6 +116,65 @@ def test_rel_attention_against_spec(hd, H, Sq, Sk, Cq, Ck, mode, precision, monk
         _close(row, ref[pos], TOL, "decode row")
 
 
+@pytest.mark.parametrize("hd,H,B,S,mode", [(64, 2, 2, 200, 1), (64, 8, 8, 1025, 1), (64, 4, 3, 385, 0), (32, 4, 2, 300, 2),
+                                           (32, 16, 4, 1025, 1), (64, 1, 1, 1, 0), (64, 2, 2, 130, 1)])
+def test_rel_attention_plane_staged_kernel(hd, H, B, S, mode):
+    """rel_attention_fwd3.hip (K / V / e as 16-bit planes in isi_attn_args.workspace, LDS-DMA tiles, two wave groups half a
+    step apart) against the register-staged kernel it replaces (ISI_ATTN_NO_FWD3=1): the same products in the same
+    precision -- outputs and log-sum-exps agree to accumulation order, the kept logits of the three-term mode to 2e-4
+    (base-2 units) -- in all three 16-bit modes, REPEATED: the kernel's first versions failed one run in four at this size
+    (profiles/r06_attention_skew_race.txt)."""
+    import ctypes as C
+    from interactive_spectrogram_inpainting import _hip
+    from interactive_spectrogram_inpainting.priors import _ops
+    dev = _dev()
+    torch.manual_seed(S + hd)
+    d = hd * H
+    q, k, v = (torch.randn(S, B, d, device=dev) for _ in range(3))
+    rel = torch.randn(H, 2 * S - 1, hd, device=dev) * 0.5
+    ld = (S + 31) // 32 * 32
+    saved = _ops.ATTENTION_PRECISION
+    try:
+        with _hip.knob("ISI_ATTN_FWD3_ALL", 1):
+            for prec, tol in (("bf16x3", 2e-5), ("bf16", 2e-3), ("f16", 3e-4)):
+                _ops.ATTENTION_PRECISION = prec
+                lse0, lg0 = torch.empty(B, H, S, device=dev), torch.zeros(B, H, S, ld, device=dev)
+                with _hip.knob("ISI_ATTN_NO_FWD3", 1):
+                    ref = _ops.rel_attention(q, k, v, rel, H, 1, 1, S, mask_mode=mode, lse=lse0, logits=lg0)
+                for rep in range(6 if S > 1000 else 2):
+                    lse, lg = torch.empty(B, H, S, device=dev), torch.zeros(B, H, S, ld, device=dev)
+                    got = _ops.rel_attention(q, k, v, rel, H, 1, 1, S, mask_mode=mode, lse=lse, logits=lg)
+                    err = float((got - ref).abs().max() / ref.abs().max())
+                    assert err < tol, f"{prec} run {rep}: output differs from the register-staged kernel's by {err:.2e}"
+                    assert float((lse - lse0).abs().max()) < 50 * tol
+                    if prec == "bf16x3":
+                        i, j = torch.arange(S, device=dev)[:, None], torch.arange(S, device=dev)[None, :]
+                        allowed = (j <= i) if mode == 1 else (j >= i) if mode == 2 else torch.ones(S, S, dtype=torch.bool, device=dev)
+                        if mode == 0 and S % 128 in (1, 2) and S >= 256:
+                            allowed[S - S % 128:] = False      # (the one-row kernel of the last rows keeps no logits)
+                        dl = float((lg[..., :S] - lg0[..., :S])[:, :, allowed].abs().max())
+                        assert dl < 2e-4, f"kept logits differ by {dl:.2e}"
+        # the workspace contract: none for several channels per event / the exact-fp32 mode / (by default) single-term modes
+        a = _ops._attn_args(q, k, v, rel, torch.empty(S, B, d, device=dev), S, S, B, H, hd, 1, 1, S, mode, None)
+        L = _hip.lib()
+        for prec, want in ((1, True), (0, False), (2, False)):
+            a.precision = prec
+            assert (L.isi_rel_attention_workspace_bytes(C.byref(a)) > 0) == want
+        a.precision, a.Cq = 1, 2
+        assert L.isi_rel_attention_workspace_bytes(C.byref(a)) == 0
+        a.Cq = 1
+        need = L.isi_rel_attention_workspace_bytes(C.byref(a))
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.q_ss, a.q_sb, a.q_sh = q.stride(0), q.stride(1), hd
+        a.k_ss, a.k_sb, a.k_sh = k.stride(0), k.stride(1), hd
+        a.v_ss, a.v_sb, a.v_sh = v.stride(0), v.stride(1), hd
+        a.o_ss, a.o_sb, a.o_sh = B * d, d, hd
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need - 256
+        assert L.isi_rel_attention_f32(C.byref(a), _hip.stream_ptr(dev)) == -1      # ISI_E_INVALID: workspace too small
+    finally:
+        _ops.ATTENTION_PRECISION = saved
+
+
 def test_small_ops_against_torch():
     from interactive_spectrogram_inpainting.priors import _ops
     dev = _dev()

@@ -47,6 +47,7 @@ def main():
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
+    _hip.check(_hip.lib().isi_knob_set(b"ISI_ATTN_FWD3_ALL", 1), "isi_knob_set")   # (default: three-term products only)
     bad = 0
     if not a.no_sweep:
         #          hd  H  Sq    Sk   mode

@@ -5,6 +5,7 @@ from interactive_spectrogram_inpainting import _hip
 from interactive_spectrogram_inpainting.priors import _ops
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+_hip.check(_hip.lib().isi_knob_set(b"ISI_ATTN_FWD3_ALL", 1), "isi_knob_set")
 def run(q, k, v, rel, H, Ek, mode, prec, dense=None):
     _ops.ATTENTION_PRECISION = prec
     return _ops.rel_attention(q, k, v, rel, H, 1, 1, Ek, mask_mode=mode, dense_mask=dense)

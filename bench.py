@@ -682,22 +682,30 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         args.gpus = world
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # ISI_BENCH_BACKEND=gloo: dry run of the multi-rank code path on a box with fewer GPUs than ranks (ranks share
     # devices, collectives go through the host) -- a functional check only, never a measurement
     backend = os.environ.get("ISI_BENCH_BACKEND", "nccl")
     if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
+        local_rank %= max(1, torch.cuda.device_count())      # (device_count does not initialise the GPU)
     device = torch.device("cuda", local_rank)
     dist = None
+    pg_before_gpu = None
     if world > 1:
+        # the launcher path: the process group comes up BEFORE this process makes its first GPU call of its own (the
+        # rendezvous must not depend on a device that another rank is still opening)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        pg_before_gpu = not torch.cuda.is_initialized()
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    if dist is not None:          # ... on EVERY rank
+        flag = torch.tensor([1.0 if pg_before_gpu else 0.0], device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        pg_before_gpu = bool(flag.item() == 1.0)
 
     from interactive_spectrogram_inpainting import _hip
     model, sd = _build_model(device)
@@ -863,6 +871,7 @@ def main():
             "value": round(world * args.batch * args.steps / dt, 2),
             "unit": "spectrograms/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_ms": args.spinup_ms,
+            **({"process_group_before_first_gpu_call": pg_before_gpu} if world > 1 else {}),
             "ms_per_step": round(dt * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "split_f16": "f32 (products split into two f16 pieces, three terms)"}.get(

@@ -326,6 +326,8 @@ def test_bench_two_ranks_dry_run():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["batch_per_gpu"] == 4
+    # the launcher path: every rank brings its process group up before its own first GPU call
+    assert line["process_group_before_first_gpu_call"] is True
     dp = line["vqvae_training_dp"]
     assert "error" not in dp, dp
     assert dp["n_gpus"] == 2 and dp["global_batch"] == 8 and dp["ranks_in_sync"] is True

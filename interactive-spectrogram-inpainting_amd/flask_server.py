@@ -7,18 +7,23 @@ query arguments and JSON schema for the operations built on MI355X
   GET/POST /generate?pitch=&instrument_family_str=&temperature=                         (:376-443)
   POST /erase?eraser_amplitude=&start_index_top=                                        (:873-931)
   POST /get-audio   -> audio/wav (16-bit PCM written with the standard library)         (:1003-1021)
+  POST /analyze-audio?pitch=&instrument_family_str=   multipart file `audio` (RIFF / PCM 16-bit or float32, mono or
+       averaged to mono, at the models' sampling rate: read with the standard library, no resampler)      (:624-667)
+  POST /top-conditioned-sample?instrument_family_str=&min_pitch=&max_pitch=&temperature=&top_p=&top_k=
+       body {top_code, bottom_code} -> application/zip of `{family}-{pitch}.wav`, one per pitch             (:1049-1115)
   response {top_code, bottom_code, top_conditioning, bottom_conditioning}               (:991-1000)
 
 A thin adapter: parsing / serialisation here, all compute in `inpainting.py`.  The models are
 handed to `create_app` already loaded (checkpoint paths and the LMDB sampling database are
-deployment plumbing; `/sample-from-dataset`, `/analyze-audio` and the spectrogram-image route
-depend on lmdb / torchaudio / matplotlib, absent from this image, and are not built).
+deployment plumbing; `/sample-from-dataset` and the spectrogram-image route depend on lmdb /
+matplotlib, absent from this image, and are not built).
 Global (non-local) class conditioning only, like the reference's default deployment.
 """
 from __future__ import annotations
 
 import io
 import struct
+import zipfile
 from typing import Mapping, Optional
 
 import flask
@@ -34,9 +39,37 @@ def _wav_bytes(audio: torch.Tensor, fs_hz: int) -> bytes:
     return header + pcm
 
 
+def _read_wav(data: bytes):
+    """RIFF/WAVE bytes -> (float32 mono tensor in [-1, 1], sampling rate): PCM 16-bit or IEEE float32, the two formats
+    the reference's front end uploads (the reference decodes with torchaudio, absent here)."""
+    if data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError("not a RIFF/WAVE file")
+    pos, fmt, payload = 12, None, None
+    while pos + 8 <= len(data):
+        tag, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if tag == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", body[:16])
+        elif tag == b"data":
+            payload = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or payload is None:
+        raise ValueError("WAVE file without fmt / data chunk")
+    code, channels, rate, _, _, bits = fmt
+    if code == 1 and bits == 16:
+        x = torch.frombuffer(bytearray(payload[:len(payload) // 2 * 2]), dtype=torch.int16).float() / 32768.0
+    elif code == 3 and bits == 32:
+        x = torch.frombuffer(bytearray(payload[:len(payload) // 4 * 4]), dtype=torch.float32).clone()
+    else:
+        raise ValueError(f"unsupported WAVE encoding (format {code}, {bits} bits)")
+    if channels > 1:
+        x = x[:x.numel() // channels * channels].reshape(-1, channels).mean(1)
+    return x, rate
+
+
 def create_app(vqvae, transformer_top, transformer_bottom, label_encoders_per_modality: Mapping[str, object],
                device, spectrograms_helper=None, top_k: int = 0, top_p: float = 0.0,
-               seed: Optional[int] = None) -> flask.Flask:
+               seed: Optional[int] = None, max_sound_duration_s: float = 4.0) -> flask.Flask:
     """`label_encoders_per_modality[name].transform([value]) -> [class index]` (sklearn LabelEncoder
     in the reference, `utils/datasets/label_encoders.py`)."""
     app = flask.Flask(__name__)
@@ -110,5 +143,48 @@ def create_app(vqvae, transformer_top, transformer_bottom, label_encoders_per_mo
         audio = inpainting.codes_to_audio(vqvae, spectrograms_helper, top_code, bottom_code)[0]
         return flask.send_file(io.BytesIO(_wav_bytes(audio, spectrograms_helper.fs_hz)), mimetype="audio/wav",
                                max_age=0)
+
+    @app.route('/analyze-audio', methods=['POST'])
+    def analyze_audio():
+        if spectrograms_helper is None:
+            flask.abort(501)
+        args = flask.request.args
+        values = {'pitch': args.get('pitch', type=int), 'instrument_family_str': str(args.get('instrument_family_str'))}
+        try:
+            audio, rate = _read_wav(flask.request.files['audio'].read())
+        except (KeyError, ValueError, struct.error) as e:
+            flask.abort(400, description=str(e))
+        if rate != spectrograms_helper.fs_hz:
+            flask.abort(400, description=f"audio at {rate} Hz: the models run at {spectrograms_helper.fs_hz} Hz (no resampler here)")
+        res_n = inpainting.top_resolution_n(vqvae, transformer_top, transformer_bottom, spectrograms_helper, device)
+        duration_n = inpainting.adapt_duration(audio.numel(), spectrograms_helper.fs_hz, max_sound_duration_s, res_n,
+                                               transformer_top.shape[1])
+        top_code, bottom_code = inpainting.analyze_audio(vqvae, spectrograms_helper, audio, duration_n, device)
+        return respond(top_code, bottom_code, {k: matrix(transformer_top.shape, v) for k, v in values.items()},
+                       {k: matrix(transformer_bottom.shape, v) for k, v in values.items()})
+
+    @app.route('/top-conditioned-sample', methods=['POST'])
+    def top_conditioned_sample():
+        if spectrograms_helper is None:
+            flask.abort(501)
+        args = flask.request.args
+        top_code, _ = codes(flask.request.get_json(force=True))
+        family = str(args.get('instrument_family_str'))
+        lo, hi = args.get('min_pitch', type=int), args.get('max_pitch', type=int)
+        if lo is None or hi is None or not lo < hi:
+            flask.abort(400, description="Provide increasing range for range conditioning")
+        cls = {'pitch': torch.as_tensor(label_encoders_per_modality['pitch'].transform(list(range(lo, hi)))).long(),
+               'instrument_family_str': torch.as_tensor(
+                   label_encoders_per_modality['instrument_family_str'].transform([family])).long()}
+        _, audio = inpainting.top_conditioned_sample(
+            vqvae, transformer_bottom, spectrograms_helper, top_code, float(args.get('temperature')), cls, device,
+            top_k_sampling_k=int(args.get('top_k') or 0), top_p_sampling_p=float(args.get('top_p') or 0.0),
+            generator=generator)
+        buf = io.BytesIO()
+        with zipfile.ZipFile(buf, 'w') as zf:        # (in memory: the reference writes sample files and a zip to its upload folder)
+            for pitch, row in zip(range(lo, hi), audio):
+                zf.writestr(f'{family}-{pitch}.wav', _wav_bytes(row, spectrograms_helper.fs_hz))
+        buf.seek(0)
+        return flask.send_file(buf, mimetype="application/zip", max_age=0)
 
     return app

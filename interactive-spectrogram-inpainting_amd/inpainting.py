@@ -125,3 +125,51 @@ def erase(vqvae, top_code: torch.Tensor, bottom_code: torch.Tensor, mask: torch.
 @torch.no_grad()
 def codes_to_audio(vqvae, spectrograms_helper, top_code: torch.Tensor, bottom_code: torch.Tensor) -> torch.Tensor:
     return spectrograms_helper.to_audio(vqvae.decode_code(top_code, bottom_code))
+
+
+@torch.no_grad()
+def top_conditioned_sample(vqvae, transformer_bottom, spectrograms_helper, top_code: torch.Tensor, temperature: float,
+                           class_conditioning_bottom, device, top_k_sampling_k: int = 0, top_p_sampling_p: float = 0.0,
+                           generator=None, uniforms=None):
+    """The compute of `/top-conditioned-sample` (flask_server.py:1049-1110): ONE top codemap, a batch of bottom codemaps
+    drawn from the bottom prior -- one per entry of the per-row class conditioning (the route passes a pitch range:
+    `make_conditioning_tensors({'pitch': (lo, hi), ...})`, sample.py:68-101) --, decoded and turned into audio.
+    The batch goes through the native batched decoder in one call (rows of a stage as one launch / matrix tiles beyond 16
+    sequences).  Returns (bottom_code [N, F_b, T_b], audio [N, samples])."""
+    from sample import sample_model
+    n = max(int(torch.as_tensor(v).numel()) for v in class_conditioning_bottom.values())
+    top = top_code.to(device).expand(n, -1, -1)
+    bottom = sample_model(transformer_bottom, device, n, transformer_bottom.shape, temperature, condition=top,
+                          class_conditioning=class_conditioning_bottom, top_k_sampling_k=top_k_sampling_k,
+                          top_p_sampling_p=top_p_sampling_p, generator=generator, uniforms=uniforms)
+    audio = spectrograms_helper.to_audio(vqvae.decode_code(top, bottom))
+    return bottom, audio
+
+
+def adapt_duration(duration_n: int, fs_hz: int, max_sound_duration_s: float, top_resolution_n: int, top_duration: int) -> int:
+    """flask_server.py:602-621: trim to the maximal duration, round to the resolution of the VQ-VAE's top level, at least
+    one transformer window."""
+    duration_n = min(max_sound_duration_s * fs_hz, duration_n)
+    return int(top_resolution_n * max(top_duration, round(duration_n / top_resolution_n)))
+
+
+@torch.no_grad()
+def top_resolution_n(vqvae, transformer_top, transformer_bottom, spectrograms_helper, device) -> int:
+    """Samples of audio per column of the top codemap (flask_server.py:582-599): from a decoded dummy map."""
+    dummy_top = torch.zeros((1,) + tuple(transformer_top.shape), dtype=torch.long, device=device)
+    dummy_bottom = torch.zeros((1,) + tuple(transformer_bottom.shape), dtype=torch.long, device=device)
+    audio = spectrograms_helper.to_audio(vqvae.decode_code(dummy_top, dummy_bottom))
+    return audio.shape[-1] // transformer_top.shape[1]
+
+
+@torch.no_grad()
+def analyze_audio(vqvae, spectrograms_helper, audio: torch.Tensor, duration_n: int, device):
+    """The compute of `/analyze-audio` (flask_server.py:624-667): mono audio [samples] at the models' rate, trimmed /
+    zero-padded to `duration_n` (what `from_wavfile(path, duration_n=...)` does), -> spectrogram -> `VQVAE.encode` ->
+    (top_code, bottom_code)."""
+    x = audio.to(device=device, dtype=torch.float32).reshape(-1)[:duration_n]
+    if x.numel() < duration_n:
+        x = torch.nn.functional.pad(x, (0, duration_n - x.numel()))
+    spec = spectrograms_helper.to_spectrogram(x.unsqueeze(0))
+    _, _, _, top_code, bottom_code, *_ = vqvae.encode(spec)
+    return top_code, bottom_code

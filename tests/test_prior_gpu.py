@@ -662,6 +662,7 @@ def test_flask_routes_round_trip(golden_dir):
     685-1021; request example locustfile.py:4-17), served by Flask's test client."""
     import json
     import flask_server
+    import inpainting
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
     from GANsynth_pytorch.spectrograms_helper import SpectrogramsHelper
     z, top, bottom = _models(golden_dir)
@@ -701,6 +702,56 @@ def test_flask_routes_round_trip(golden_dir):
     r4 = c.post("/get-audio", data=json.dumps(body))
     assert r4.status_code == 200 and r4.mimetype == "audio/wav" and r4.data[:4] == b"RIFF"
     assert len(r4.data) == 44 + 2 * 32 * 32
+    # /top-conditioned-sample (flask_server.py:1049-1115): one bottom codemap per pitch of the range from the bottom prior,
+    # batched through the native decoder, decoded and returned as a zip of WAV files -- the end-to-end consumer of batched
+    # bottom-prior decoding
+    import io
+    import zipfile
+    r5 = c.post("/top-conditioned-sample?instrument_family_str=fam3&min_pitch=60&max_pitch=66&temperature=1.0&top_p=0.9",
+                data=json.dumps(body))
+    assert r5.status_code == 200 and r5.mimetype == "application/zip"
+    with zipfile.ZipFile(io.BytesIO(r5.data)) as zf:
+        names = zf.namelist()
+        assert names == [f"fam3-{p_}.wav" for p_ in range(60, 66)]
+        wavs = [zf.read(n) for n in names]
+    assert all(w[:4] == b"RIFF" and len(w) == 44 + 2 * 32 * 32 for w in wavs)
+    assert len({w[44:] for w in wavs}) > 1, "every pitch got the same audio"
+    assert c.post("/top-conditioned-sample?instrument_family_str=fam3&min_pitch=66&max_pitch=60&temperature=1.0",
+                  data=json.dumps(body)).status_code == 400
+    # the compute on its own: per-row conditioning, fixed uniforms -> the rows equal single-row calls (batched == batch 1)
+    from sample import sample_model
+    cls = {"pitch": torch.tensor([3, 10, 17]), "instrument_family_str": torch.tensor([3])}
+    top_code = torch.tensor(body["top_code"]).unsqueeze(0).to(dev)
+    u = torch.rand(bottom.target_transformer_sequence_length, 3, generator=torch.Generator().manual_seed(5))
+    codes3, audio3 = inpainting.top_conditioned_sample(vq, bottom, helper, top_code, 1.0, cls, dev, top_p_sampling_p=0.9, uniforms=u)
+    assert codes3.shape == (3, 16, 8) and audio3.shape == (3, 32 * 32) and torch.isfinite(audio3).all()
+    for i in range(3):
+        one = sample_model(bottom, dev, 1, bottom.shape, 1.0, condition=top_code,
+                           class_conditioning={"pitch": cls["pitch"][i:i + 1], "instrument_family_str": cls["instrument_family_str"]},
+                           top_p_sampling_p=0.9, uniforms=u[:, i:i + 1])
+        assert torch.equal(one[0], codes3[i])
+    # /analyze-audio (flask_server.py:624-667): a WAV upload -> spectrogram -> VQVAE.encode -> codes (+ constant
+    # conditioning maps); the codes equal those of the library call on the same samples
+    wav = flask_server._wav_bytes(torch.sin(torch.arange(1500) * 0.05) * 0.5, 16000)
+    r6 = c.post("/analyze-audio?pitch=64&instrument_family_str=fam2", data={"audio": (io.BytesIO(wav), "note.wav")},
+                content_type="multipart/form-data")
+    assert r6.status_code == 200
+    b6 = r6.get_json()
+    # 1500 samples -> rounded to 6 columns of the top map (256 samples each)
+    assert np.array(b6["top_code"]).shape == (8, 6) and np.array(b6["bottom_code"]).shape == (16, 12)
+    assert b6["top_conditioning"]["pitch"][0][0] == 64 and b6["bottom_conditioning"]["instrument_family_str"][0][0] == "fam2"
+    x, rate = flask_server._read_wav(wav)
+    assert rate == 16000 and x.numel() == 1500
+    res_n = inpainting.top_resolution_n(vq, top, bottom, helper, dev)
+    assert res_n == 32 * 32 // 4
+    dur = inpainting.adapt_duration(1500, 16000, 4.0, res_n, 4)
+    assert dur == 6 * res_n and inpainting.adapt_duration(300, 16000, 4.0, res_n, 4) == 4 * res_n   # at least one window
+    assert inpainting.adapt_duration(10 ** 6, 16000, 4.0, res_n, 4) == 64000                          # at most 4 s
+    t6, b6c = inpainting.analyze_audio(vq, helper, x, dur, dev)
+    assert t6[0].cpu().tolist() == b6["top_code"] and b6c[0].cpu().tolist() == b6["bottom_code"]
+    bad = c.post("/analyze-audio?pitch=64&instrument_family_str=fam2", data={"audio": (io.BytesIO(b"nonsense"), "x.wav")},
+                 content_type="multipart/form-data")
+    assert bad.status_code == 400
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -121,35 +121,47 @@ struct PackArgs {
   const float *k, *v, *e;
   unsigned short *k16, *v16, *e16;        // plane 0 of each; plane 1 follows kv_plane / e_plane elements later
   long long kv_plane, e_plane;            // elements per plane
-  long long n_kv, n_e;                    // 8-element items per K (= per V) plane and per e plane
-  int Sk, Skp, H, R, HD;
+  long long n_kv, n_pad, n_e;             // 8-element items: real rows of K (= of V), zero rows of K (= of V), e
+  int Sk, Skp, B, H, R, HD;
   int k_ss, k_sb, k_sh, v_ss, v_sb, v_sh;
 };
 template <bool F16, int NPL>
 __global__ __launch_bounds__(256) void attn_pack_kernel(const PackArgs p) {
   using PR = Prec<F16>;
   const int g8 = p.HD >> 3;
-  const long long total = 2 * p.n_kv + p.n_e;
+  const long long total = 2 * (p.n_kv + p.n_pad) + p.n_e;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const float *src = nullptr;
     unsigned short *dst;
     long long plane;
     if (i < 2 * p.n_kv) {
+      // real rows, in the SOURCE's order (key, batch, head, 8-dim group): a wave reads 2 KiB of one (key, batch) row of the
+      // projection's output and writes 128-byte pieces of eight heads' planes (pair-major on the reading side it gathered
+      // 256-byte pieces 48 KiB apart)
       const bool is_v = i >= p.n_kv;
-      const long long it = is_v ? i - p.n_kv : i;
-      const long long row = it / g8;
-      const int g = (int)(it - row * g8);
-      const int pair = (int)(row / p.Skp), s = (int)(row - (long long)pair * p.Skp);
-      const int b = pair / p.H, h = pair - b * p.H;
-      if (s < p.Sk)
-        src = is_v ? p.v + ((long long)s * p.v_ss + (long long)b * p.v_sb + (long long)h * p.v_sh + 8 * g)
-                   : p.k + ((long long)s * p.k_ss + (long long)b * p.k_sb + (long long)h * p.k_sh + 8 * g);
-      dst = (is_v ? p.v16 : p.k16) + it * 8;
+      long long it = is_v ? i - p.n_kv : i;
+      const int g = (int)(it % g8); it /= g8;
+      const int h = (int)(it % p.H); it /= p.H;
+      const int b = (int)(it % p.B);
+      const int s = (int)(it / p.B);
+      src = is_v ? p.v + ((long long)s * p.v_ss + (long long)b * p.v_sb + (long long)h * p.v_sh + 8 * g)
+                 : p.k + ((long long)s * p.k_ss + (long long)b * p.k_sb + (long long)h * p.k_sh + 8 * g);
+      dst = (is_v ? p.v16 : p.k16) + (((long long)(b * p.H + h) * p.Skp + s) * g8 + g) * 8;
+      plane = p.kv_plane;
+    } else if (i < 2 * (p.n_kv + p.n_pad)) {     // the zero rows Sk .. Skp - 1 of every pair
+      long long it = i - 2 * p.n_kv;
+      const bool is_v = it >= p.n_pad;
+      if (is_v) it -= p.n_pad;
+      const int g = (int)(it % g8); it /= g8;
+      const int npad = p.Skp - p.Sk;
+      const int s = p.Sk + (int)(it % npad);
+      const long long pair = it / npad;
+      dst = (is_v ? p.v16 : p.k16) + ((pair * p.Skp + s) * g8 + g) * 8;
       plane = p.kv_plane;
     } else {      // e: fragment-major, [head][16-byte piece c = 2 t + half of the row][row][8]: the 32 rows of a band tile's
                   // fragment are 512 contiguous bytes per half-wave whatever the tile's first row (row-major, a lane's 16
                   // bytes sat 128 bytes from its neighbour's: ~80 cycles of issue per load, tools/stamps_fwd3.py)
-      const long long it = i - 2 * p.n_kv;
+      const long long it = i - 2 * (p.n_kv + p.n_pad);
       const long long row = it / g8;                       // (head, table row)
       const int c = (int)(it - row * g8);
       const long long hh = row / p.R, r = row - hh * p.R;
@@ -831,11 +843,13 @@ int launch_fwd3_t(const AttnKArgs &a, const PlaneLayout &L, void *ws, hipStream_
   pk.v16 = reinterpret_cast<unsigned short *>(base + L.v_off);
   pk.e16 = reinterpret_cast<unsigned short *>(base + L.e_off);
   pk.kv_plane = (long long)L.kv_plane; pk.e_plane = (long long)L.e_plane;
-  pk.n_kv = (long long)(L.kv_plane / 8); pk.n_e = (long long)(L.e_plane / 8);
-  pk.Sk = a.Sk; pk.Skp = L.Skp; pk.H = a.H; pk.R = a.R; pk.HD = HD;
+  pk.n_kv = (long long)a.Sk * a.B * a.H * (HD / 8);
+  pk.n_pad = (long long)(L.Skp - a.Sk) * a.B * a.H * (HD / 8);
+  pk.n_e = (long long)(L.e_plane / 8);
+  pk.Sk = a.Sk; pk.Skp = L.Skp; pk.B = a.B; pk.H = a.H; pk.R = a.R; pk.HD = HD;
   pk.k_ss = a.k_ss; pk.k_sb = a.k_sb; pk.k_sh = a.k_sh; pk.v_ss = a.v_ss; pk.v_sb = a.v_sb; pk.v_sh = a.v_sh;
   {
-    const long long total = 2 * pk.n_kv + pk.n_e;
+    const long long total = 2 * (pk.n_kv + pk.n_pad) + pk.n_e;
     const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 16);
     prof::Scope scope(prof::K_REL_ATTENTION, 0.0, 6.0 * (2.0 * L.kv_plane + L.e_plane), stream);
     ISI_PROF_LAUNCH(scope, (attn_pack_kernel<F16, NPL>), dim3(grid), dim3(256), 0, stream, pk);

@@ -334,15 +334,7 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
     return c;
   };
 
-#ifndef F3PRIO
-#define F3PRIO 0
-#endif
-#ifndef F3ABL
-#define F3ABL 0
-#endif
-#if F3PRIO == 0
   if (grp == 1) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses issue arbitration otherwise (MI355X guide)
-#endif
   // ---- what a block needs before its first step: Q, the K tiles of its sub-blocks 0 and 1, the V tile of sub-block 0, the
   // first band fragments
   struct Geom { int q0, q_end, k_end, qw0, qi, sb_end, g_first, g_count, nsteps; };
@@ -457,7 +449,6 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
     s16x8_t ph[2], pl_[2];              // P of the sub-block whose P V is pending
     float alpha = 1.f;
     bool have_prev = false;             // rprev holds the band tile [wrow + 32, wrow + 64) of the coming sub-block
-    int par = 0;                        // half of the skew buffer's rows the coming sub-block's NEW band tile is written to
 
     // ---- matrix segment of step s: P V of sub-block s - 1, K Q^T and the band tile of sub-block s.  All LDS fragments are
     // requested FIRST (hipcc waited for each pair of reads right in front of its matrix instruction: ~1000 of the
@@ -466,7 +457,6 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
       const int st = (s & 1) * STAGEB;
       [[maybe_unused]] const int sbase = 8 + 8 * s;
       s16x8_t vf[NDB][2][NPL], kf[NKB][NPL];
-      const bool had_prev = have_prev;
       unsigned va[NDB];
 #pragma unroll
       for (int d = 0; d < NDB; ++d) va[d] = Va[d] + (unsigned)st;
@@ -538,29 +528,23 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
             for (int d = 0; d < NDB; ++d) O[d] = PR::mfma(vf[d][t][0], ph[t], O[d]);
         }
         if (qk_live) {
-          if (!had_prev) put_tile(rprev, 32 * (par ^ 1));
-          put_tile(rnew, 32 * par);
-          rprev = rnew;
+          put_tile(rprev, 32);
+          put_tile(rnew, 0);
+          rprev = rnew;                  // the next sub-block's upper band tile
           have_prev = true;
         }
         ISI_F3_STAMP(sbase + 5);
       } else {
-        // three-term products.  Matrix instructions on ONE accumulator issue every ~64 cycles, on alternating accumulators
-        // every 32 (stamps: 12 dependent instructions took 700-780 cycles): every contraction is summed in TWO accumulators
-        // (even / odd k-blocks, added at the end; P V has its two output blocks).  Fragment requests are staged through
-        // the registers that fall free: K up front, V behind the band tile (in the band fragments' registers)
+        // three-term products: the three instructions of a product follow each other on one accumulator (forwarded); the
+        // register budget (242 of 256) leaves no second band accumulator and stages the fragment requests
         if (qk_live) {
-          f32x16 rodd;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sacc[r] = rnew[r] = rodd[r] = 0.f;
+          for (int r = 0; r < 16; ++r) sacc[r] = rnew[r] = 0.f;
 #pragma unroll
-          for (int t = 0; t < ((F3ABL & 1) ? 0 : NKB); t += 2) {
+          for (int t = 0; t < NKB; ++t) {
             rnew = PR::mfma(en[t][1], qh[t], rnew);
             rnew = PR::mfma(en[t][0], qlo[t], rnew);
             rnew = PR::mfma(en[t][0], qh[t], rnew);
-            rodd = PR::mfma(en[t + 1][1], qh[t + 1], rodd);
-            rodd = PR::mfma(en[t + 1][0], qlo[t + 1], rodd);
-            rodd = PR::mfma(en[t + 1][0], qh[t + 1], rodd);
           }
           if (!have_prev) {    // wave-uniform, once per wave and block: the upper band tile through the same fragment registers
             load_e(en, wrow_of(s) + 32);
@@ -573,16 +557,8 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
               rprev = PR::mfma(en[t][0], qh[t], rprev);
             }
           }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) rnew[r] += rodd[r];
         }
         ISI_F3_STAMP(sbase + 4);
-        if (pv_live) {      // key block 0 of V now (K Q^T covers its flight), key block 1 behind K Q^T
-#pragma unroll
-          for (int d = 0; d < NDB; ++d)
-#pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) vf[d][0][pl] = vfrag(va[d] + pl * PLANE_OFF);
-        }
         if (qk_live) {
           if constexpr (KA < NKB) {
 #pragma unroll
@@ -591,37 +567,29 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
               for (int pl = 0; pl < NPL; ++pl)
                 kf[t][pl] = *reinterpret_cast<const s16x8_t *>(Kb + st + pl * PLANE_OFF + (((2 * t + half) ^ swk_l) << 4));
           }
-          f32x16 sodd;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sodd[r] = 0.f;
-#pragma unroll
-          for (int t = 0; t < ((F3ABL & 2) ? 0 : NKB); t += 2) {
+          for (int t = 0; t < NKB; ++t) {
             sacc = PR::mfma(kf[t][NPL - 1], qh[t], sacc);
             sacc = PR::mfma(kf[t][0], qlo[t], sacc);
             sacc = PR::mfma(kf[t][0], qh[t], sacc);
-            sodd = PR::mfma(kf[t + 1][NPL - 1], qh[t + 1], sodd);
-            sodd = PR::mfma(kf[t + 1][0], qlo[t + 1], sodd);
-            sodd = PR::mfma(kf[t + 1][0], qh[t + 1], sodd);
           }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sacc[r] += sodd[r];
-          if (!(F3ABL & 8)) {
-            // ONLY the new tile is stored: the upper half of this sub-block's band is the previous sub-block's tile, still in
-            // the other half of the rows (the eight 1-KiB stores per wave and step were a fifth of the kernel, tools/ablate_fwd3.sh)
-            if (!had_prev) put_tile(rprev, 32 * (par ^ 1));
-            put_tile(rnew, 32 * par);
-          }
-          rprev = rnew;                  // (kept for a wave whose next step starts a new run)
+          put_tile(rprev, 32);
+          put_tile(rnew, 0);
+          rprev = rnew;                  // the next sub-block's upper band tile
           have_prev = true;
         }
         ISI_F3_STAMP(sbase + 5);
         if (pv_live) {
+          if constexpr (VA < 2) {
 #pragma unroll
-          for (int d = 0; d < NDB; ++d)
+            for (int t = VA; t < 2; ++t)
 #pragma unroll
-            for (int pl = 0; pl < NPL; ++pl) vf[d][1][pl] = vfrag(va[d] + pl * PLANE_OFF + V_T);
+              for (int d = 0; d < NDB; ++d)
 #pragma unroll
-          for (int t = 0; t < ((F3ABL & 4) ? 0 : 2); ++t)
+                for (int pl = 0; pl < NPL; ++pl) vf[d][t][pl] = vfrag(va[d] + pl * PLANE_OFF + t * V_T);
+          }
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int d = 0; d < NDB; ++d) {
               O[d] = PR::mfma(vf[d][t][NPL - 1], ph[t], O[d]);
@@ -639,25 +607,12 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
     // worst right behind the block barrier; profiles/r06_attention_skew_race.txt); this form: 0 of 300.
     float rl[16];
     auto skew_reads = [&]() {
-      // band index t = ql + 31 - (key row) of this sub-block: t < 32 is the new tile (half `par` of the row), t >= 32 the
-      // previous sub-block's (the other half): column (t + 32 par) & 63
-      const float *rd = sr + ql + 31 - 4 * half;
+      const float *rd = sr + ql + 31 - 4 * half;     // band row ql + 31 - (key row in the sub-block)
       const unsigned ra = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)(rd - 27);
-      if (par == 0) {
 #define F3_RD(r_) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rl[r_]) : "v"(ra), "n"(4 * (27 - (((r_) & 3) + 8 * ((r_) >> 2)))) : "memory")
-        F3_RD(0); F3_RD(1); F3_RD(2); F3_RD(3); F3_RD(4); F3_RD(5); F3_RD(6); F3_RD(7);
-        F3_RD(8); F3_RD(9); F3_RD(10); F3_RD(11); F3_RD(12); F3_RD(13); F3_RD(14); F3_RD(15);
+      F3_RD(0); F3_RD(1); F3_RD(2); F3_RD(3); F3_RD(4); F3_RD(5); F3_RD(6); F3_RD(7);
+      F3_RD(8); F3_RD(9); F3_RD(10); F3_RD(11); F3_RD(12); F3_RD(13); F3_RD(14); F3_RD(15);
 #undef F3_RD
-      } else {
-        // t < 32 <=> key row j >= ql - 4 half: that entry sits 32 columns up, the others 32 columns down
-        const int jt = ql - 4 * half;
-#define F3_RD(r_) { const unsigned a_ = ((((r_) & 3) + 8 * ((r_) >> 2)) >= jt) ? ra + 128u : ra - 128u; \
-          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rl[r_]) : "v"(a_), "n"(4 * (27 - (((r_) & 3) + 8 * ((r_) >> 2)))) : "memory"); }
-        F3_RD(0); F3_RD(1); F3_RD(2); F3_RD(3); F3_RD(4); F3_RD(5); F3_RD(6); F3_RD(7);
-        F3_RD(8); F3_RD(9); F3_RD(10); F3_RD(11); F3_RD(12); F3_RD(13); F3_RD(14); F3_RD(15);
-#undef F3_RD
-      }
-      par ^= 1;
     };
     // ---- mask, online softmax of sub-block s (vector segment): sacc + skewed band -> P operands, alpha
     auto softmax = [&](const int s) {
@@ -665,10 +620,8 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
       __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0), as the builtin: hipcc's own count of LDS operations in flight restarts at zero here
       asm volatile("" ::: "memory");
       ISI_F3_STAMP(8 + 8 * s + 6);
-      if (!(F3ABL & 8)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] += rl[r];
-      }
+      for (int r = 0; r < 16; ++r) sacc[r] += rl[r];
       float sv[16];
       float tmax;
       float *lrow = lbase ? lbase + k0 : nullptr;
@@ -690,7 +643,7 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
         alpha = __builtin_amdgcn_exp2f(m_run - m_new);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          sv[r] = (F3ABL & 16) ? sacc[r] - m_new : __builtin_amdgcn_exp2f(sacc[r] - m_new);
+          sv[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new);
           psum += sv[r];
         }
         m_run = m_new;
@@ -763,9 +716,6 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
       [[maybe_unused]] const int sbase = 8 + 8 * s;
       ISI_F3_STAMP(sbase);
       set_m0(s & 1);            // for the requests of this step's vector segment
-#if F3PRIO == 2
-      __builtin_amdgcn_s_setprio(1);
-#endif
       const bool lv = live_at(s);
       if (!lv) have_prev = false;
       matrix_segment(s, live_at(s - 1), lv);
@@ -777,19 +727,14 @@ __global__ __launch_bounds__(512) void rel_attn_fwd3_kernel(const AttnKArgs p, c
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       ISI_F3_STAMP(sbase + 2);
-#if F3PRIO == 2
-      __builtin_amdgcn_s_setprio(0);
-#endif
       // vector segment: V of sub-block s + 1 and K of sub-block s + 2 into the stage the matrix segment has just read
-      if (lv && !(F3ABL & 8)) skew_reads();
-      if (!(F3ABL & 32)) {
+      if (lv) skew_reads();
       load_e_async(wrow_of(s + 1));      // (on every step: the counted wait below needs the same requests each time)
       issue_v(k0_of(s + 1));
       issue_k(k0_of(s + 2));
-      }
       if (lv) softmax(s);
       ISI_F3_STAMP(sbase + 7);
-      if (!(F3ABL & 32)) wait_tiles();
+      wait_tiles();
       ISI_F3_STAMP(sbase + 3);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

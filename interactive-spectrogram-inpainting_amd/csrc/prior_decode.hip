@@ -1046,7 +1046,11 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   // host-bound).  Every position-dependent address is read from a device counter the last node of a
   // position advances.  Two variants exist -- windows whose positions are all sampled / all kept --, each captured when
   // first needed; windows of mixed positions and the tail run as direct launches (the counter is re-set after them).
-  const int W = knobs().prior_graph;
+  // (not while the CALLER is capturing `st`: the synchronisation below would invalidate that capture -- direct launches then,
+  // which a capture takes as they are)
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap_status) != hipSuccess) { (void)hipGetLastError(); cap_status = hipStreamCaptureStatusNone; }
+  const int W = cap_status == hipStreamCaptureStatusNone ? knobs().prior_graph : 0;
   if (W > 0 && p_end - p >= (W > 2 ? 2 * W : 4)) {
     hipStream_t cap = nullptr;
     hipGraph_t graphs[2] = {nullptr, nullptr};

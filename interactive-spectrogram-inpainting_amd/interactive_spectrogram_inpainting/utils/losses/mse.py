@@ -30,6 +30,7 @@ class _MSEFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         need_a, need_b = ctx.needs_input_grad
@@ -48,9 +49,15 @@ def mse_loss(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """mean((input - target)^2) -- `torch.nn.functional.mse_loss(input, target)` (reduction 'mean') for fp32 tensors of one
     shape on the GPU; anything else goes to torch."""
     if (input.is_cuda and target.is_cuda and input.dtype == torch.float32 and target.dtype == torch.float32
-            and input.shape == target.shape and input.numel() > 0):
+            and input.shape == target.shape and input.numel() > 0
+            # the kernels read 16-byte pieces: a contiguous view at an odd storage offset (flat[1:]) stays with torch
+            and _aligned16(input) and _aligned16(target)):
         return _MSEFn.apply(input, target)
     return torch.nn.functional.mse_loss(input, target)
+
+
+def _aligned16(t: torch.Tensor) -> bool:
+    return (not t.is_contiguous()) or t.data_ptr() % 16 == 0     # (a non-contiguous operand is copied: fresh allocation)
 
 
 class MSELoss(nn.Module):

@@ -124,17 +124,53 @@ def train(epoch: int, loader: Iterable, model: VQVAE, reconstruction_criterion: 
     if hip_graph:
         if scheduler is not None:
             raise NotImplementedError("a recorded step bakes the learning rate in: no host-side scheduler with hip_graph")
-        graphed = None
-        for batch_index, (img, *_) in enumerate(loader):
-            img = img.to(device, non_blocking=True)
-            if graphed is None:
-                graphed = GraphedVQVAEStep(model, reconstruction_criterion, optimizer, img, latent_loss_weight, clip_grad_norm)
-            o = graphed(img)
-            stats.update(img.shape[0], o["reconstruction_loss"], o["latent_loss"], o["perplexity_t"], o["perplexity_b"])
-            if dry_run:
-                break
-        if graphed is not None:
-            graphed.finish()
+        # the recorded step is kept ACROSS epochs on the model (every train() call used to pay two eager warm-up
+        # steps, a re-capture, a new graph pool and a clone / restore of all parameters and optimizer state); it is bound to
+        # (optimizer, criterion, batch shape, loss weights): anything else records afresh.  finish() always runs for a step
+        # that is dropped, also when the loop raises.
+        key = (id(optimizer), id(reconstruction_criterion), latent_loss_weight, clip_grad_norm)
+        cached = getattr(model, "_graphed_train_step", None)
+        graphed = cached[1] if cached is not None and cached[0][:4] == key else None
+        if cached is not None and graphed is None:
+            cached[1].finish()
+            model._graphed_train_step = None
+        ok = False
+        try:
+            for batch_index, (img, *_) in enumerate(loader):
+                img = img.to(device, non_blocking=True)
+                if graphed is not None and tuple(img.shape) != cached[0][4]:
+                    if batch_index == 0:      # a different batch shape from the first batch on: record afresh
+                        graphed.finish()
+                        graphed, model._graphed_train_step = None, None
+                    else:                     # a ragged last batch (loader without drop_last): one eager step, like the other path
+                        model.zero_grad()
+                        out, latent_loss, perplexity_t, perplexity_b, *_ = model(img)
+                        reconstruction_loss = reconstruction_criterion(out, img)
+                        latent_loss = latent_loss.mean()
+                        (reconstruction_loss + latent_loss_weight * latent_loss).backward()
+                        if clip_grad_norm is not None:
+                            nn.utils.clip_grad_norm_(model.parameters(), clip_grad_norm)
+                        optimizer.step()
+                        stats.update(img.shape[0], reconstruction_loss, latent_loss, perplexity_t, perplexity_b)
+                        continue
+                if graphed is None:
+                    graphed = GraphedVQVAEStep(model, reconstruction_criterion, optimizer, img, latent_loss_weight, clip_grad_norm)
+                    cached = (key + (tuple(img.shape),), graphed)
+                    model._graphed_train_step = cached
+                o = graphed(img)
+                stats.update(img.shape[0], o["reconstruction_loss"], o["latent_loss"], o["perplexity_t"], o["perplexity_b"])
+                if dry_run:
+                    break
+            ok = True
+        finally:
+            # finish() waits for the replays, raises a pending range / index verdict and marks the packed-weight caches stale
+            # (the replays moved the parameters without touching their version counters): after EVERY epoch -- evaluate() must
+            # see the new weights -- and also when the loop raised.  The recording itself stays valid and is replayed by the
+            # next epoch; only a loop that raised drops it.
+            if graphed is not None:
+                graphed.finish()
+                if not ok:
+                    model._graphed_train_step = None
         return stats.means()
     for batch_index, (img, *_) in enumerate(loader):
         model.zero_grad()

@@ -242,8 +242,8 @@ def test_train_vqvae_epoch_on_64_synthetic_spectrograms():
 
 def test_train_vqvae_epoch_replayed_from_hip_graph_follows_the_eager_epoch():
     """`train_vqvae.train(..., hip_graph=True)`: the loop body recorded once (GraphedVQVAEStep) and replayed per batch --
-    model, codebooks and optimizer moments are put back in place after the recording's warm-up steps, so an epoch of four
-    batches ends with the eager epoch's parameters, codebooks and running means."""
+    model, codebooks and optimizer moments are put back in place after the recording's warm-up steps, so two epochs (four
+    batches, then four and a ragged fifth) end with the eager epochs' parameters, codebooks and running means."""
     import train_vqvae as T
     from interactive_spectrogram_inpainting.utils.training.optimizer import make_adam
     from interactive_spectrogram_inpainting.vqvae.vqvae import VQVAE
@@ -257,6 +257,15 @@ def test_train_vqvae_epoch_replayed_from_hip_graph_follows_the_eager_epoch():
         opt = make_adam(m.parameters(), lr=1e-3, capturable=True)
         loader = torch.utils.data.DataLoader(data, batch_size=4, shuffle=False, drop_last=True)
         means = T.train(0, loader, m, crit, opt, device=dev, clip_grad_norm=10.0, hip_graph=graph)
+        if graph:
+            step0 = m._graphed_train_step[1]
+        # a SECOND epoch replays the first one's recording (no re-capture per epoch), with a ragged last batch
+        # (18 samples, no drop_last: 4 + 4 + 4 + 4 + 2) run eagerly
+        data2 = T.SyntheticSpectrograms(18, shape=(2, 64, 128))
+        loader2 = torch.utils.data.DataLoader(data2, batch_size=4, shuffle=False, drop_last=False)
+        means = T.train(1, loader2, m, crit, opt, device=dev, clip_grad_norm=10.0, hip_graph=graph)
+        if graph:
+            assert m._graphed_train_step[1] is step0, "the second epoch recorded again"
         res[graph] = (means, {k: v.clone() for k, v in m.state_dict().items()})
     for k in T.RunningMeans.NAMES:
         a, b = res[True][0][k], res[False][0][k]

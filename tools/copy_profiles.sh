@@ -19,10 +19,12 @@ cp $O/pmc_hbm_traffic.json profiles/${R}_pmc_hbm_traffic.json
   cat $O/pmc_sq_forward.txt; } > profiles/${R}_pmc_sq_forward.txt
 { echo "# SQ counters of the attention kernels, B8 H8 S1025 hd64 causal, three-term (bf16x3) and single-term (bf16) products: two rocprofv3"
   echo "# --kernel-trace --pmc passes of tools/bench_attention.py --modes 1 --precisions bf16x3 bf16 (tools/round_profiles.sh); per-dispatch"
-  echo "# means.  rel_attn_fwd2_kernel<HD, terms, f16, unit>: forward; *_split_kernel<HD, single-term, kept logits>: backward."
+  echo "# means.  rel_attn_fwd3_kernel<HD, terms, f16> + attn_pack_kernel: forward, three-term products (round 6); rel_attn_fwd2_kernel<HD, terms,"
+  echo "# f16, unit>: forward, single-term products; *_split_kernel<HD, single-term, kept logits>: backward."
   echo
   cat $O/pmc_attention.txt; } > profiles/${R}_pmc_attention.txt
 hdr "rocprofv3 --kernel-trace -- python3 tools/bench_attention.py --modes 1 0 --precisions bf16x3   (attention op forward + backward, causal and unmasked)" $O/attention_kernel_trace.txt profiles/${R}_attention_kernel_trace.txt
 { echo "# tools/bench_linear.py, tools/bench_linear_wgrad.py (M = 8200 rows; us and TFLOP/s-equivalent per product mode)"; grep -v amdgpu.ids $O/linear.txt; } > profiles/${R}_linear_layers.txt
 { echo "# tools/bench_prior_train.py --batch 8 --steps 4 (eager) and --steps 10 --graph (the step replayed from a HIP graph)"; grep -v "amdgpu.ids\|UserWarning\|detach\|tokens/s  loss" $O/prior_train.txt; grep "ms" $O/prior_train.txt | grep -v Warn; echo "--- graph replay"; grep "ms" $O/prior_train_graph.txt | grep -v Warn; } > profiles/${R}_prior_train_step.txt
-[ -f $O/stamps.txt ] && { echo "# in-kernel cycle stamps (-DISI_MEASURE library): GEMM 256x256 and 128x64 tiles, attention backward (key-stationary kernel), attention forward"; grep -v amdgpu.ids $O/stamps.txt; } > profiles/${R}_cycle_stamps.txt
+[ -f $O/prior_sampling_b32_summary.txt ] && hdr "rocprofv3 --kernel-trace -- python3 tools/prof_sampling.py 32   (batched decoding, B = 32)" $O/prior_sampling_b32_summary.txt profiles/${R}_prior_sampling_b32_kernel_trace.txt
+[ -f $O/stamps.txt ] && { echo "# in-kernel cycle stamps (-DISI_MEASURE library): GEMM 256x256 and 128x64 tiles, attention backward (key-stationary kernel), attention forward (fwd2: register-staged; fwd3: plane-staged)"; grep -v amdgpu.ids $O/stamps.txt; } > profiles/${R}_cycle_stamps.txt

@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace -d $O/kt_pt -o pt -- python3 tools/bench_prior_train.py
 python tools/prof_summary.py $O/kt_pt/pt_results.db 0 > $O/prior_train_summary.txt 2>&1
 rocprofv3 --kernel-trace -d $O/kt_ps -o ps -- python3 tools/bench_prior.py > $O/ps.log 2>&1
 python tools/prof_summary.py $O/kt_ps/ps_results.db 0 > $O/prior_sampling_summary.txt 2>&1
+rocprofv3 --kernel-trace -d $O/kt_ps32 -o ps -- python3 tools/prof_sampling.py 32 > $O/ps32.log 2>&1
+python tools/prof_summary.py $O/kt_ps32/ps_results.db 0 > $O/prior_sampling_b32_summary.txt 2>&1
 rocprofv3 --kernel-trace -d $O/kt_fe -o fe -- python3 tools/bench_frontend.py > $O/fe.log 2>&1
 python tools/prof_summary.py $O/kt_fe/fe_results.db 0 > $O/frontend_summary.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --no-cpu-baseline --no-prior --no-train --steps 5 > /dev/null 2>&1
@@ -38,7 +40,8 @@ python tools/bench_prior_train.py --batch 8 --steps 10 --graph > $O/prior_train_
 if [ -f interactive-spectrogram-inpainting_amd/lib_measure/libisi_hip.so ]; then
   (echo "## tools/stamps_gemm.py 2048 512 f16x3"; python tools/stamps_gemm.py 2048 512 f16x3; echo "## tools/stamps_gemm.py 512 512 f16x3"; python tools/stamps_gemm.py 512 512 f16x3
    echo "## tools/stamps_attention_bwd.py 1"; python tools/stamps_attention_bwd.py 1; echo "## tools/stamps_fwd2.py bf16 1"; python tools/stamps_fwd2.py bf16 1
-   echo "## tools/stamps_fwd2.py bf16x3 1"; python tools/stamps_fwd2.py bf16x3 1) > $O/stamps.txt 2>&1
+   echo "## tools/stamps_fwd2.py bf16x3 1"; python tools/stamps_fwd2.py bf16x3 1
+   echo "## tools/stamps_fwd3.py bf16x3 1"; python tools/stamps_fwd3.py bf16x3 1; echo "## tools/stamps_fwd3.py bf16 1"; python tools/stamps_fwd3.py bf16 1) > $O/stamps.txt 2>&1
 fi
 rm -rf $O/kt_* $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_at1 $O/pmc_at2     # the sqlite / csv dumps are large; the summaries are what is kept
 tail -c 600 $O/bench.json

@@ -805,7 +805,7 @@ def main():
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this same command, FETCH doubled as the
         # gfx950 guide prescribes; tools/pmc_traffic.py): a measured constant, not re-measured here
         traffic = None
-        traffic_file = next((f for f in ("profiles/r05_pmc_hbm_traffic.json", "profiles/r04_pmc_hbm_traffic.json", "profiles/r03_pmc_hbm_traffic.json", "profiles/r02_pmc_hbm_traffic.json",
+        traffic_file = next((f for f in ("profiles/r06_pmc_hbm_traffic.json", "profiles/r05_pmc_hbm_traffic.json", "profiles/r04_pmc_hbm_traffic.json", "profiles/r03_pmc_hbm_traffic.json", "profiles/r02_pmc_hbm_traffic.json",
                                          "profiles/r01_pmc_hbm_traffic.json") if (ROOT / f).exists()), "profiles/none")
         try:
             if args.batch != 64:

@@ -11,12 +11,15 @@ query arguments and JSON schema for the operations built on MI355X
        averaged to mono, at the models' sampling rate: read with the standard library, no resampler)      (:624-667)
   POST /top-conditioned-sample?instrument_family_str=&min_pitch=&max_pitch=&temperature=&top_p=&top_k=
        body {top_code, bottom_code} -> application/zip of `{family}-{pitch}.wav`, one per pitch             (:1049-1115)
+  GET/POST /sample-from-dataset?duration_top=&pitch=&pitch_class=&octave=&instrument_family_str=
+       a stored codemap pair meeting the constraints (`codes_dataset`: the LMDB code database or any
+       sequence of its items; 404 when nothing matches -- the reference searches for ever)                 (:333-372,446-514)
+  GET/POST /test-generate?pitch=&instrument_family_str=   uniformly random codemaps                         (:517-552)
+  POST /get-spectrogram-image   body {top_code, bottom_code} -> image/png (viridis, standard library)       (:1024-1046)
   response {top_code, bottom_code, top_conditioning, bottom_conditioning}               (:991-1000)
 
-A thin adapter: parsing / serialisation here, all compute in `inpainting.py`.  The models are
-handed to `create_app` already loaded (checkpoint paths and the LMDB sampling database are
-deployment plumbing; `/sample-from-dataset` and the spectrogram-image route depend on lmdb /
-matplotlib, absent from this image, and are not built).
+A thin adapter: parsing / serialisation here, all compute in `inpainting.py`.  The models (and the
+code database) are handed to `create_app` already loaded: checkpoint paths are deployment plumbing.
 Global (non-local) class conditioning only, like the reference's default deployment.
 """
 from __future__ import annotations
@@ -69,7 +72,8 @@ def _read_wav(data: bytes):
 
 def create_app(vqvae, transformer_top, transformer_bottom, label_encoders_per_modality: Mapping[str, object],
                device, spectrograms_helper=None, top_k: int = 0, top_p: float = 0.0,
-               seed: Optional[int] = None, max_sound_duration_s: float = 4.0) -> flask.Flask:
+               seed: Optional[int] = None, max_sound_duration_s: float = 4.0, codes_dataset=None,
+               spectrograms_upsampling_factor: int = 1) -> flask.Flask:
     """`label_encoders_per_modality[name].transform([value]) -> [class index]` (sklearn LabelEncoder
     in the reference, `utils/datasets/label_encoders.py`)."""
     app = flask.Flask(__name__)
@@ -186,5 +190,47 @@ def create_app(vqvae, transformer_top, transformer_bottom, label_encoders_per_mo
                 zf.writestr(f'{family}-{pitch}.wav', _wav_bytes(row, spectrograms_helper.fs_hz))
         buf.seek(0)
         return flask.send_file(buf, mimetype="application/zip", max_age=0)
+
+    @app.route('/sample-from-dataset', methods=['GET', 'POST'])
+    def sample_from_dataset():
+        if codes_dataset is None:
+            flask.abort(501)
+        args = flask.request.args
+        constraints = {}
+        pitch = args.get('pitch', type=int, default=None)
+        if pitch is not None:
+            constraints['pitch'] = pitch
+        pitch_class = args.get('pitch_class', type=int, default=None)
+        if pitch_class is not None and 0 <= pitch_class <= 12:
+            constraints['pitch_class'] = pitch_class
+        octave = args.get('octave', type=int, default=None)
+        if octave is not None and octave >= 0:
+            constraints['octave'] = octave
+        family = args.get('instrument_family_str', type=str, default=None)
+        if family is not None:
+            constraints['instrument_family_str'] = family
+        try:
+            (top, bottom), attributes = inpainting.sample_from_database(
+                codes_dataset, label_encoders_per_modality, args.get('duration_top', type=int), constraints, generator)
+        except LookupError as e:
+            flask.abort(404, description=str(e))
+        values = {'pitch': int(attributes['pitch']), 'instrument_family_str': str(attributes['instrument_family_str'])}
+        return respond(top, bottom, {k: matrix(top.shape[1:], v) for k, v in values.items()},
+                       {k: matrix(bottom.shape[1:], v) for k, v in values.items()})
+
+    @app.route('/test-generate', methods=['GET', 'POST'])
+    def test_generate():
+        args = flask.request.args
+        values = {'pitch': int(args.get('pitch')), 'instrument_family_str': str(args.get('instrument_family_str'))}
+        top = torch.randint(0, vqvae.n_embed_t, (1,) + tuple(transformer_top.shape), generator=generator)
+        bottom = torch.randint(0, vqvae.n_embed_b, (1,) + tuple(transformer_bottom.shape), generator=generator)
+        return respond(top, bottom, {k: matrix(transformer_top.shape, v) for k, v in values.items()},
+                       {k: matrix(transformer_bottom.shape, v) for k, v in values.items()})
+
+    @app.route('/get-spectrogram-image', methods=['POST'])
+    def get_spectrogram_image():
+        top_code, bottom_code = codes(flask.request.get_json(force=True))
+        png = inpainting.spectrogram_png(vqvae, top_code, bottom_code, spectrograms_upsampling_factor)
+        return flask.send_file(io.BytesIO(png), mimetype="image/png", max_age=0)
 
     return app

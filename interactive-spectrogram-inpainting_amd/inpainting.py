@@ -9,12 +9,18 @@ routes (flask_server.py), free of HTTP so that they can be called, tested and ti
   erase               attenuate the log-magnitude under the mask and re-encode (:873-931)
   generate            new top + bottom codemaps from scratch (:376-443)
   codes_to_audio      VQ-VAE decode + spectrogram inversion (:1003-1021)
+  top_conditioned_sample / analyze_audio    (:1049-1110 / :624-667)
+  sample_from_database   a stored (top, bottom) pair whose attributes meet the request's constraints,
+                      cut / padded to the requested duration (:314-372, 446-514)
+  spectrogram_png     the decoded log-mel magnitude as a viridis PNG (:103-143, 1024-1046)
 
 The heavy work is `sample.sample_model` (encoder pass + KV-cached native decoding loop),
 `VQVAE.decode_code / encode` and `SpectrogramsHelper.to_audio`: all HIP kernels.
 """
 from __future__ import annotations
 
+import struct
+import zlib
 from typing import List, Mapping, Optional, Tuple
 
 import torch
@@ -173,3 +179,72 @@ def analyze_audio(vqvae, spectrograms_helper, audio: torch.Tensor, duration_n: i
     spec = spectrograms_helper.to_spectrogram(x.unsqueeze(0))
     _, _, _, top_code, bottom_code, *_ = vqvae.encode(spec)
     return top_code, bottom_code
+
+
+def resize_codemaps_repeat_last(top_code: torch.Tensor, bottom_code: torch.Tensor, duration_top: int):
+    """flask_server.py:314-330: cut to `duration_top` columns of the top map (and the matching number of the bottom map);
+    a shorter map is continued with its last column."""
+    ratio = bottom_code.shape[-1] // top_code.shape[-1]
+
+    def resize(codemap, duration):
+        codemap = codemap[..., :duration]
+        if codemap.shape[-1] < duration:
+            codemap = torch.cat([codemap, codemap[..., -1:].expand(*codemap.shape[:-1], duration - codemap.shape[-1])], -1)
+        return codemap
+    return resize(top_code, duration_top), resize(bottom_code, ratio * duration_top)
+
+
+def sample_from_database(codes_dataset, label_encoders_per_modality: Mapping[str, object], duration_top: int,
+                         attribute_constraints: Mapping[str, object], generator: Optional[torch.Generator] = None):
+    """The lookup of `/sample-from-dataset` (flask_server.py:333-372): items of the code database
+    (`utils.datasets.lmdb_dataset.LMDBDataset`: (top [F_t,T_t], bottom [F_b,T_b], {class name: tensor [1]})) are visited in
+    a random order until one meets every constraint -- equality on the decoded attributes, `pitch_class` = pitch % 12 and
+    `octave` = pitch // 12 derived from the pitch (the reference stores the octave under the `pitch_class` key, :351-353,
+    so its octave constraint can never be met; the evident intent is built here).  The reference draws with replacement
+    for ever; a database without a match raises LookupError here.  Returns ((top [1,F_t,T], bottom [1,F_b,T_b]), attributes)."""
+    for index in torch.randperm(len(codes_dataset), generator=generator).tolist():
+        top_code, bottom_code, encoded = codes_dataset[index]
+        attributes = {key: label_encoders_per_modality[key].inverse_transform([int(torch.as_tensor(value).reshape(-1)[0])])[0]
+                      for key, value in encoded.items()}
+        if 'pitch' in attributes:
+            attributes['pitch_class'] = int(attributes['pitch']) % 12
+            attributes['octave'] = int(attributes['pitch']) // 12
+        if all(key in attributes and attributes[key] == wanted for key, wanted in attribute_constraints.items()):
+            top_code, bottom_code = torch.as_tensor(top_code).unsqueeze(0), torch.as_tensor(bottom_code).unsqueeze(0)
+            return resize_codemaps_repeat_last(top_code, bottom_code, duration_top), attributes
+    raise LookupError(f"no item of the code database meets {dict(attribute_constraints)}")
+
+
+# nine samples of the viridis colour map (0, 1/8, .. 1), interpolated linearly: the map the reference draws with
+_VIRIDIS = ((68, 1, 84), (71, 44, 122), (59, 81, 139), (44, 113, 142), (33, 144, 141), (39, 173, 129), (92, 200, 99),
+            (170, 220, 50), (253, 231, 37))
+
+
+def _png_bytes(rgb: torch.Tensor) -> bytes:
+    """[H, W, 3] uint8 -> PNG (8-bit truecolour, one IDAT chunk; standard library only)."""
+    h, w, _ = rgb.shape
+    rows = torch.cat([torch.zeros(h, 1, dtype=torch.uint8), rgb.reshape(h, w * 3)], 1)      # filter type 0 per scanline
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(rows.numpy().tobytes(), 6)) + chunk(b"IEND", b""))
+
+
+@torch.no_grad()
+def spectrogram_png(vqvae, top_code: torch.Tensor, bottom_code: torch.Tensor, upsampling_factor: int = 1) -> bytes:
+    """The compute of `/get-spectrogram-image` (flask_server.py:103-143, 1024-1046): decode the codes, take the
+    log-magnitude channel of the first item, upsample it bilinearly, and draw it full-frame in viridis with the lowest
+    frequency at the bottom and the colour range spanning the map's own minimum .. maximum (what `specshow` does).  The
+    reference rasterises through matplotlib at 2400 x 1600; here one pixel per (upsampled) spectrogram bin."""
+    s = vqvae.decode_code(top_code, bottom_code)[0, 0].float()
+    if upsampling_factor > 1:
+        s = torch.nn.functional.interpolate(s[None, None], mode='bilinear', scale_factor=upsampling_factor)[0, 0]
+    s = s.flip(0).cpu()
+    lo, hi = float(s.min()), float(s.max())
+    t = ((s - lo) / (hi - lo) if hi > lo else torch.zeros_like(s)).clamp(0, 1) * (len(_VIRIDIS) - 1)
+    i0 = t.floor().long().clamp(max=len(_VIRIDIS) - 2)
+    lut = torch.tensor(_VIRIDIS, dtype=torch.float32)
+    frac = (t - i0).unsqueeze(-1)
+    rgb = (lut[i0] * (1 - frac) + lut[i0 + 1] * frac).round().to(torch.uint8)
+    return _png_bytes(rgb)

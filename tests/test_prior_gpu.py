@@ -674,12 +674,20 @@ def test_flask_routes_round_trip(golden_dir):
 
         def transform(self, values):
             return np.array([self.classes.index(v) for v in values])
+
+        def inverse_transform(self, indexes):
+            return np.array([self.classes[int(i)] for i in indexes], dtype=object)
     encoders = {"pitch": Enc(range(24, 85)), "instrument_family_str": Enc([f"fam{i}" for i in range(11)])}
     torch.manual_seed(9)
     vq = VQVAE(in_channel=2, num_hidden_channels=32, n_res_block=1, num_residual_channels=8, embed_dim=16,
                num_embeddings=64, resolution_factors={"bottom": 4, "top": 2}).to(dev).eval()
     helper = SpectrogramsHelper(16000, 128, 32, 128).to(dev)
-    app = flask_server.create_app(vq, top, bottom, encoders, dev, spectrograms_helper=helper, top_p=0.9, seed=0)
+    # the code database of /sample-from-dataset: items as utils.datasets.lmdb_dataset.LMDBDataset yields them
+    gdb = torch.Generator().manual_seed(3)
+    database = [(torch.randint(0, 64, (8, 3 + i % 3), generator=gdb), torch.randint(0, 64, (16, 2 * (3 + i % 3)), generator=gdb),
+                 {"pitch": torch.tensor([36 + i]), "instrument_family_str": torch.tensor([i % 11])}) for i in range(20)]
+    app = flask_server.create_app(vq, top, bottom, encoders, dev, spectrograms_helper=helper, top_p=0.9, seed=0,
+                                  codes_dataset=database, spectrograms_upsampling_factor=2)
     c = app.test_client()
     q = "pitch=60&instrument_family_str=fam3&temperature=1.0"
     r = c.get("/generate?" + q)
@@ -752,6 +760,43 @@ def test_flask_routes_round_trip(golden_dir):
     bad = c.post("/analyze-audio?pitch=64&instrument_family_str=fam2", data={"audio": (io.BytesIO(b"nonsense"), "x.wav")},
                  content_type="multipart/form-data")
     assert bad.status_code == 400
+    # /sample-from-dataset (flask_server.py:333-372,446-514): a stored pair meeting the constraints, cut / continued with its
+    # last column to `duration_top`; item i carries pitch class index 36 + i = pitch 60 + i, family i % 11
+    r7 = c.get("/sample-from-dataset?duration_top=4&pitch=65")               # class index 41 = item 5 (3 + 5 % 3 = 5 columns: cut)
+    assert r7.status_code == 200
+    b7 = r7.get_json()
+    assert b7["top_code"] == database[5][0][:, :4].tolist() and b7["bottom_code"] == database[5][1][:, :8].tolist()
+    assert b7["top_conditioning"]["pitch"][0][0] == 65 and b7["bottom_conditioning"]["instrument_family_str"][1][1] == "fam5"
+    r8 = c.get("/sample-from-dataset?duration_top=6&pitch_class=0&octave=6&instrument_family_str=fam1")   # pitch 72 = item 12, 3 columns
+    assert r8.status_code == 200
+    b8 = np.array(r8.get_json()["top_code"])
+    assert b8.shape == (8, 6) and (b8[:, :3] == database[12][0].numpy()).all() and (b8[:, 3:] == b8[:, 2:3]).all()
+    assert np.array(r8.get_json()["bottom_code"]).shape == (16, 12)
+    assert c.get("/sample-from-dataset?duration_top=4&pitch=100").status_code == 404
+    # /test-generate (flask_server.py:517-552): random codemaps of the models' shapes
+    r9 = c.get("/test-generate?pitch=50&instrument_family_str=fam0")
+    t9 = np.array(r9.get_json()["top_code"])
+    assert r9.status_code == 200 and t9.shape == (8, 4) and t9.min() >= 0 and t9.max() < 64
+    assert r9.get_json()["bottom_conditioning"]["pitch"][15][7] == 50
+    # /get-spectrogram-image (flask_server.py:1024-1046): PNG of the decoded log-magnitude, upsampled twice
+    import struct
+    import zlib
+    r10 = c.post("/get-spectrogram-image", data=json.dumps(body))
+    assert r10.status_code == 200 and r10.mimetype == "image/png" and r10.data[:8] == b"\x89PNG\r\n\x1a\n"
+    w_, h_, depth, colour = struct.unpack(">IIBB", r10.data[16:26])
+    assert (w_, h_, depth, colour) == (2 * 32, 2 * 64, 8, 2)                 # decode_code of [8,4] / [16,8] codes: 64 x 32 bins
+    n_idat = struct.unpack(">I", r10.data[33:37])[0]
+    assert r10.data[37:41] == b"IDAT"
+    raw = np.frombuffer(zlib.decompress(r10.data[41:41 + n_idat]), dtype=np.uint8).reshape(h_, 1 + 3 * w_)
+    assert (raw[:, 0] == 0).all()
+    px = raw[:, 1:].reshape(h_, w_, 3)
+    spec = torch.nn.functional.interpolate(vq.decode_code(torch.tensor(body["top_code"])[None].to(dev),
+                                                          torch.tensor(body["bottom_code"])[None].to(dev))[0, 0][None, None],
+                                           mode="bilinear", scale_factor=2)[0, 0].flip(0).cpu().numpy()
+    iy, ix = np.unravel_index(spec.argmax(), spec.shape)
+    assert tuple(px[iy, ix]) == (253, 231, 37)                               # the maximum is drawn in viridis' last colour
+    iy, ix = np.unravel_index(spec.argmin(), spec.shape)
+    assert tuple(px[iy, ix]) == (68, 1, 84)
 
 
 # ---------------------------------------------------------------------------------------------------------------

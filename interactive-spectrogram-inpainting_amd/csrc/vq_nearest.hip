@@ -176,7 +176,7 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_nearest_kernel(
 // compares the winner with every far code in exact fp32: the result is the reference's either way.  A non-finite code
 // makes every index -1 (loud).
 typedef f16s::f16x8 vq_f16x8;
-constexpr float kVqNone = 0x1p127f, kVqPad = 0x1p100f;   // finite sentinels (low mantissa bits zero: see vq_candidates_f16)
+constexpr float kVqNone = 0x1p115f, kVqPad = 0x1p100f;   // finite sentinels (low mantissa bits zero; -kVqNone / (2 u) finite: see vq_candidates_f16)
 constexpr float kVqScaleZ = f16s::kScaleA, kVqScaleE = f16s::kScaleB, kVqUnscale = f16s::kUnscale;
 __device__ __forceinline__ void vq_split4(const float4 v, const float s, uint2 &hi, uint2 &lo) { f16s::split4(v, s, hi, lo); }
 
@@ -239,19 +239,18 @@ __device__ __forceinline__ float vq_quad_dot(const float4 a, const float4 b) {
 //
 // Round 3.  The search was bound by its vector instructions (8 per distance: fma, two compares, min, med3, three
 // selects; 128 per 32-code tile and wave against 12 MFMAs -- tools/stamps_vq.py: 23-28 k cycles per 32-vector tile
-// where the matrix work is 6 k).  Now, per 32-code tile, the lane's 16 distances are ranked with their register
-// number r PACKED into the four low mantissa bits -- key = (D & ~15) | r: v_and_or_b32, then v_med3 / v_min keep the
-// tile's two smallest keys: 4 instructions per distance -- and only those two enter the exact (value, code number)
-// update.  For the keys to order like the distances D must be positive:
-//     D = |z|^2 (1 + 2^-20) - 2 z.e + |e|^2      (the squared distance plus a margin above its own rounding)
-// which costs nothing: the accumulators start from -|z|^2 (1 + 2^-20) / (2 u) instead of zero.  The four truncated
-// bits are 2^-19 of D, below the 2e-6 at which two codes count as a near-tie of the reference's own fp32 formula; the
-// winner is still decided in exact fp32 between the two candidates (vq_decide_f32).  Equal distances (duplicate
-// codes) keep the lower code number: lower r = lower code within a lane, `<` across tiles, (value, index) order
-// between the two lane halves.
+// where the matrix work is 6 k).  Since then, per 32-code tile, the lane's 16 distances are ranked with their register
+// number r PACKED into the four low mantissa bits -- v_and_or_b32, then v_med3 / v_max keep the tile's two best keys:
+// 3 instructions per distance -- and only those two enter the exact (value, code number) update.  The distance carries
+// a margin above its own rounding,
+//     D = |z|^2 (1 + 2^-20) - 2 z.e + |e|^2,
+// and the four truncated bits are 2^-19 of D, below the 2e-6 at which two codes count as a near-tie of the reference's
+// own fp32 formula; the winner is still decided in exact fp32 between the two candidates (vq_decide_f32).  Equal
+// distances (duplicate codes) keep the lower code number: lower r = lower code within a lane, `<` across tiles,
+// (value, index) order between the two lane halves.  (Round 6: what is ranked is -D / (2 u), see below.)
 // Sentinels (finite, so that packing never makes a NaN; powers of two, so that stripping the packed bits leaves them
 // unchanged): padding rows |e|^2 = +2^100, a code beyond the f16 range
-// -2^100 (vq_fill_planes: it wins everywhere and vq_decide_f32 answers -1), "no candidate" kVqNone = 2^127.
+// -2^100 (vq_fill_planes: it wins everywhere and vq_decide_f32 answers -1), "no candidate" kVqNone = 2^115.
 struct VqCand { float b1, b2; int i1, i2; float x2; };
 __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, const unsigned short *cbl, const float *e2,
                                                     int Kp, const float4 (&zq)[8], int col, int half) {
@@ -269,28 +268,58 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
 #pragma unroll
   for (int j = 0; j < 8; ++j) x2p += zq[j].x * zq[j].x + zq[j].y * zq[j].y + zq[j].z * zq[j].z + zq[j].w * zq[j].w;
   const float x2 = x2p + __shfl_xor(x2p, 32);
-  const float ainit = -x2 * ((1.f + 0x1p-20f) * 0.5f / kVqUnscale);
+  // Round 6.  The accumulators hold a = -D / (2 u) -- they start from -(|z|^2 (1 + 2^-20) + |e_row|^2) / (2 u), one fma per
+  // register where the zero-|e|^2 start cost a move, and the tile needs no fma behind its matrix instructions -- and the
+  // ranking keeps the two LARGEST keys of a tile (a < 0 for a finite distance; the packed register number makes a key
+  // more negative, so equal distances still keep the lower code).  Only a tile's two winners are scaled back to D
+  // (1 / (2 u) = 2^11: exact).  Sentinels in this space: "none" -2^126 <-> D = kVqNone = 2^115.
+  // The tiles are software-pipelined IN the wave (two accumulator sets, as before): tile t + 1's twelve matrix
+  // instructions are issued between the pieces of tile t's ranking, and the code fragments are read from LDS one k-step
+  // ahead, across tiles too.  With "read, wait, multiply, rank" per tile a wave alone on its SIMD (its partner waiting for
+  // the next tile's activations) spent ~330 cycles per k-step -- LDS latency + three dependent matrix instructions + the
+  // ranking's share -- 20-25 k cycles per 32-vector tile where its matrix work is 6 k (tools/stamps_vq.py); 15-21 k now.
+  // (Measured and not kept: two accumulation chains per tile, |e|^2 read a tile ahead -- no change.)
+  constexpr float kHalfInv = 0.5f / kVqUnscale, kANone = -kVqNone * kHalfInv;
+  static_assert(kHalfInv == 2048.f, "the mapping a <-> D must be an exact power of two");
+  const float ainit = -x2 * ((1.f + 0x1p-20f) * kHalfInv);
   float b1 = kVqNone, b2 = kVqNone;
   int i1 = 0, i2 = 0;
-  // Two 32-code tiles per step, their MFMA chains interleaved: a tile's twelve MFMAs all accumulate into ONE register
-  // set, and back-to-back dependent MFMAs issue at about half the pipe's rate (the stamps showed the matrix and the
-  // vector work of the search adding up instead of overlapping); with two independent chains the pipe runs at its rate
-  // and the partner wave of the SIMD does its vector work meanwhile.
-  auto rank_tile = [&](const f32x16 &acc, const int kt) {
+  auto init_tile = [&](f32x16 &acc, const int kt) {
     const float *e2t = e2 + kt + 4 * half;
-    float t1 = kVqNone, t2 = kVqNone;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float d = __builtin_fmaf(acc[r], -2.f * kVqUnscale, e2t[(r & 3) + 8 * (r >> 2)]);
-      const float key = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, d) & 0xFFFFFFF0u) | (unsigned)r);
-      t2 = __builtin_amdgcn_fmed3f(key, t1, t2);               // t1 <= t2 (a NaN key -- a vector out of range: every
-      t1 = __builtin_fminf(key, t1);                           // code, the vector ends with -1 -- leaves t1 alone)
+    for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(e2t[(r & 3) + 8 * (r >> 2)], -kHalfInv, ainit);
+  };
+  s16x8v fh[2], fl[2];                          // fragment slots: slot s & 1 holds k-step s of the tile being multiplied
+  auto load_frag = [&](const int slot, const int kt, const int s) {
+    const int row = min(kt + col, Kp - 1), sw = (row >> 1) & 7;     // (the prefetch behind the last tile re-reads its last rows)
+    const int off = row * D + (((2 * s + half) ^ sw) * 8);
+    fh[slot] = *reinterpret_cast<const s16x8v *>(cbh + off);
+    fl[slot] = *reinterpret_cast<const s16x8v *>(cbl + off);
+  };
+  auto mfma_kstep = [&](f32x16 &acc, const int kt, const int s) {
+    if (s < 3) load_frag((s + 1) & 1, kt, s + 1);
+    else load_frag(0, kt + 32, 0);
+    const s16x8v ah = fh[s & 1], al = fl[s & 1];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zl[s]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah), __builtin_bit_cast(vq_f16x8, zh[s]), acc, 0, 0, 0);
+  };
+  auto rank4 = [&](const f32x16 &acc, const int r0, float &t1, float &t2) {
+#pragma unroll
+    for (int r = r0; r < r0 + 4; ++r) {
+      const float a = acc[r];                                  // (a scalar copy: __builtin_bit_cast of the vector ELEMENT read element 0)
+      const float key = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a) & 0xFFFFFFF0u) | (unsigned)r);
+      t2 = __builtin_amdgcn_fmed3f(key, t1, t2);               // t1 >= t2 (a NaN key -- a vector out of range: every
+      asm("v_max_f32 %0, %1, %2" : "=v"(t1) : "v"(key), "v"(t1));   // code, the vector ends with -1 -- leaves t1 alone); as asm:
+                                                                  // fmaxf() puts a canonicalising v_max x, x in front of every key
     }
-    // the tile's two best into the running pair, exactly: value without the packed bits, uniform + decoded code number
+  };
+  // the tile's two best into the running pair, exactly: value without the packed bits, uniform + decoded code number
+  auto update = [&](const float t1, const float t2, const int kt) {
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
       const unsigned kb_ = __builtin_bit_cast(unsigned, w == 0 ? t1 : t2);
-      const float v = __builtin_bit_cast(float, kb_ & 0xFFFFFFF0u);
+      const float v = __builtin_bit_cast(float, kb_ & 0xFFFFFFF0u) * (-2.f * kVqUnscale);
       const int cu = kt + (int)(kb_ & 3u) + 2 * (int)(kb_ & 12u);   // (r & 3) + 8 (r >> 2)
       const bool l1 = v < b1, l2 = v < b2;
       i2 = l1 ? i1 : (l2 ? cu : i2);
@@ -299,27 +328,41 @@ __device__ __forceinline__ VqCand vq_candidates_f16(const unsigned short *cbh, c
       b1 = l1 ? v : b1;
     }
   };
-  for (int kt = 0; kt < Kp; kt += 64) {
-    const bool two = kt + 32 < Kp;                             // uniform (odd tile counts: the last step has one tile)
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = ainit; acc1[r] = ainit; }
-    const int row0 = kt + col, row1 = two ? row0 + 32 : row0;
-    const int sw0 = (row0 >> 1) & 7, sw1 = (row1 >> 1) & 7;
+  // tile `kt_next` multiplied while tile `kt_prev` (complete) is ranked: 3 matrix instructions per 4 distances
+  auto pipelined = [&](f32x16 &next, const int kt_next, const f32x16 &prev, const int kt_prev) {
+    init_tile(next, kt_next);
+    float t1 = kANone, t2 = kANone;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int off0 = row0 * D + (((2 * s + half) ^ sw0) * 8), off1 = row1 * D + (((2 * s + half) ^ sw1) * 8);
-      const s16x8v ah0 = *reinterpret_cast<const s16x8v *>(cbh + off0), al0 = *reinterpret_cast<const s16x8v *>(cbl + off0);
-      const s16x8v ah1 = *reinterpret_cast<const s16x8v *>(cbh + off1), al1 = *reinterpret_cast<const s16x8v *>(cbl + off1);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al0), __builtin_bit_cast(vq_f16x8, zh[s]), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, al1), __builtin_bit_cast(vq_f16x8, zh[s]), acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah0), __builtin_bit_cast(vq_f16x8, zl[s]), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah1), __builtin_bit_cast(vq_f16x8, zl[s]), acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah0), __builtin_bit_cast(vq_f16x8, zh[s]), acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(vq_f16x8, ah1), __builtin_bit_cast(vq_f16x8, zh[s]), acc1, 0, 0, 0);
+      mfma_kstep(next, kt_next, s);
+      rank4(prev, 4 * s, t1, t2);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    rank_tile(acc0, kt);
-    if (two) rank_tile(acc1, kt + 32);
+    update(t1, t2, kt_prev);
+  };
+  auto rank_only = [&](const f32x16 &prev, const int kt_prev) {
+    float t1 = kANone, t2 = kANone;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) rank4(prev, 4 * s, t1, t2);
+    update(t1, t2, kt_prev);
+  };
+  {
+    f32x16 accA, accB;
+    load_frag(0, 0, 0);
+    init_tile(accA, 0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mfma_kstep(accA, 0, s);
+    int kt = 32;
+    for (; kt + 32 < Kp; kt += 64) {
+      pipelined(accB, kt, accA, kt - 32);
+      pipelined(accA, kt + 32, accB, kt);
+    }
+    if (kt < Kp) {
+      pipelined(accB, kt, accA, kt - 32);
+      rank_only(accB, kt);
+    } else {
+      rank_only(accA, kt - 32);
+    }
   }
   i1 += 4 * half;
   i2 += 4 * half;

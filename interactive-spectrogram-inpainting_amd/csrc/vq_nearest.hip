@@ -633,7 +633,9 @@ __global__ __launch_bounds__(VQ_BLOCK) void vq_conv1x1_nearest_kernel(const VqFu
   // before anything is multiplied: they come from HBM and their round trip used to be paid once per two-chunk batch;
   // the weight fragments (L2-resident) follow batch by batch.  (Requesting them one tile AHEAD, between the previous
   // tile's decision and its stores, was measured: 0.209 against 0.195 ms for the two launches of a forward -- the
-  // CU's vector-memory queue is what the tile waits for: ~105 memory instructions per wave and tile.)
+  // CU's vector-memory queue is what the tile waits for: ~105 memory instructions per wave and tile.  Round 6: HALF of
+  // them a tile ahead, in front of the candidate search: the 1x1 phase 35 -> 23 k cycles, the search 15 -> 23-30 k
+  // (17-35 spilled registers at 192 / 256 channels), 0.196 against 0.176 ms.)
   constexpr int NU = 2 * NCH;                                // k-steps of 16 channels
   i32x4v ahv[NU], alv[NU];
   auto request_tile = [&](const int64_t it_, const int lane_) {

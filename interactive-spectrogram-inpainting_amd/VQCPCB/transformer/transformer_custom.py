@@ -380,6 +380,9 @@ class TransformerAlignedDecoderLayerCustom(TransformerDecoderLayerCustom):
             ev_s = torch.arange(Ss) // self.multihead_attn.Ck
             m = torch.full((St, Ss), float("-inf"))
             m[ev_t[:, None] == ev_s[None, :]] = 0.0
+            if bool(torch.isinf(m).all(dim=1).any()):
+                raise ValueError(f"aligned decoder: {St} target tokens of {self.multihead_attn.Cq} per event against {Ss} source "
+                                 f"tokens of {self.multihead_attn.Ck}: a target event without a source event")
             m = self._align[key] = m.to(device)
         return m
 
@@ -390,8 +393,24 @@ class TransformerAlignedDecoderLayerCustom(TransformerDecoderLayerCustom):
         if memory_mask is not None:
             if isinstance(memory_mask, str):
                 raise NotImplementedError("the aligned decoder combines its alignment with additive tensor masks only")
-            m = m + memory_mask.to(m.device)
+            m = self._combined(m, memory_mask)
         return super().forward(tgt, memory, tgt_mask, m, memory_kv)
+
+    def _combined(self, align: torch.Tensor, memory_mask: torch.Tensor) -> torch.Tensor:
+        """alignment + the caller's additive mask, formed ONCE per (mask tensor, version): a fresh sum per forward would be a
+        new tensor every time -- the classification cache of `_classify_mask` (keyed on the tensor's identity) would never
+        hit, every layer would pay a device-to-host copy per step, and a recorded step could not contain it.
+        A target token left without any allowed source column (unequal event counts, or a caller mask that removes the only
+        aligned key) would have an all -inf row, i.e. a NaN softmax: rejected here, where the mask is formed."""
+        key = (memory_mask.data_ptr(), memory_mask._version, tuple(memory_mask.shape), str(memory_mask.device), tuple(align.shape))
+        hit = self._align.get("combined")
+        if hit is not None and hit[0] == key and hit[1]() is memory_mask:
+            return hit[2]
+        m = align + memory_mask.detach().to(align.device)
+        if bool(torch.isinf(m).all(dim=1).any()):
+            raise ValueError("aligned decoder: a target token has no allowed source token (alignment combined with memory_mask)")
+        self._align["combined"] = (key, weakref.ref(memory_mask), m)
+        return m
 
 
 class TransformerEncoderCustom(nn.Module):

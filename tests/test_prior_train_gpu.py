@@ -942,6 +942,21 @@ def test_aligned_decoder_layer_own_specification():
         # (self-attention is causal over the target only: rows 8..11 depend on memory through their own cross-attention alone)
         assert float((o1[8:12] - o2[8:12]).abs().max()) < 1e-6
         assert float((o1[12:16] - o2[12:16]).abs().max()) > 1e-3
+    # a caller's additive memory_mask: combined with the alignment ONCE per (mask tensor, version) -- the same tensor is
+    # handed to the attention on every forward, so its classification is cached too --, re-formed when the mask is edited in
+    # place; a mask that leaves a target token without any source column is rejected (it would be a NaN softmax)
+    extra = torch.zeros(St, Ss, device=dev)
+    with torch.no_grad():
+        c1 = al._combined(mask, extra)
+        assert al._combined(mask, extra) is c1
+        o3 = al(tgt.detach(), mem.detach(), "causal", extra)
+        assert al._combined(mask, extra) is c1
+        _close(o3, o1, 1e-6, "zero memory_mask")
+        extra[8:12, 2] = float("-inf")           # removes the only aligned key of event 2 (in place: version bump)
+        with pytest.raises(ValueError):
+            al(tgt.detach(), mem.detach(), "causal", extra)
+    with pytest.raises(ValueError):                # 40 target tokens = 10 events against 9 source events
+        al.alignment_mask(40, 9, dev)
     # the wrapper with the flag: builds, one training step runs, sampling refuses
     from interactive_spectrogram_inpainting.priors.transformer import UpsamplingVQTransformer
     from interactive_spectrogram_inpainting.priors._decode import IncrementalDecoder

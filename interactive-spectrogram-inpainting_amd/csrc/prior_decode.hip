@@ -30,6 +30,10 @@
 // rows (and, when the residual is a normalised tensor, its residual rows) on the
 // fly from the stored pre-norm rows.
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
 
 #include "isi_common.h"
 #include "isi_internal.h"
@@ -919,6 +923,54 @@ size_t prior_decode_scratch_floats(const isi_prior_w *w, int B) {
          rel_attention_decode_workspace_floats(B, w->nhead, w->d_model / w->nhead) + mfma_ksplit_floats(w, B);
 }
 
+// ---- cache of the decode loop's graph executables (prior_sample_run)
+constexpr size_t kDecodeGraphCacheMax = 8;
+struct DecodeGraphs {
+  std::vector<unsigned char> key;
+  hipGraph_t graphs[2] = {nullptr, nullptr};
+  hipGraphExec_t execs[2] = {nullptr, nullptr};
+  bool failed[2] = {false, false};
+  uint64_t used = 0;
+};
+static std::mutex &decode_graph_mutex() { static std::mutex m; return m; }
+// (called with the mutex held)  nullptr: no device / allocation failure -- the caller then launches directly
+static DecodeGraphs *decode_graphs_for(const isi_prior_w *w, const isi_prior_state *s, float temperature, int top_k, float top_p,
+                                       int W) {
+  static std::vector<DecodeGraphs *> cache;
+  static uint64_t clock_ = 0;
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  isi_prior_state sk = *s;
+  sk.mask = nullptr;                                   // a HOST array that only steers which windows replay
+  const Knobs kn = knobs();
+  struct Tail { float temperature, top_p; int top_k, W, device; } tail{temperature, top_p, top_k, W, device};
+  std::vector<unsigned char> key(sizeof(isi_prior_w) + sizeof(isi_prior_state) + sizeof(Knobs) + sizeof(Tail));
+  unsigned char *k = key.data();
+  std::memcpy(k, w, sizeof(isi_prior_w)); k += sizeof(isi_prior_w);
+  std::memcpy(k, &sk, sizeof(isi_prior_state)); k += sizeof(isi_prior_state);
+  std::memcpy(k, &kn, sizeof(Knobs)); k += sizeof(Knobs);
+  std::memcpy(k, &tail, sizeof(Tail));
+  for (DecodeGraphs *g : cache)
+    if (g->key == key) { g->used = ++clock_; return g; }
+  if (cache.size() >= kDecodeGraphCacheMax) {
+    size_t lru = 0;
+    for (size_t i = 1; i < cache.size(); ++i) if (cache[i]->used < cache[lru]->used) lru = i;
+    (void)hipDeviceSynchronize();                      // its last replay may still be running
+    for (int j = 0; j < 2; ++j) {
+      if (cache[lru]->execs[j]) (void)hipGraphExecDestroy(cache[lru]->execs[j]);
+      if (cache[lru]->graphs[j]) (void)hipGraphDestroy(cache[lru]->graphs[j]);
+    }
+    delete cache[lru];
+    cache.erase(cache.begin() + (long)lru);
+  }
+  DecodeGraphs *g = new (std::nothrow) DecodeGraphs();
+  if (!g) return nullptr;
+  g->key = std::move(key);
+  g->used = ++clock_;
+  cache.push_back(g);
+  return g;
+}
+
 int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin, int p_end, float temperature,
                      int top_k, float top_p, hipStream_t st) {
   if (!w || !s) return invalid("prior_sample_run: null pointer");
@@ -1052,21 +1104,27 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   if (hipStreamIsCapturing(st, &cap_status) != hipSuccess) { (void)hipGetLastError(); cap_status = hipStreamCaptureStatusNone; }
   const int W = cap_status == hipStreamCaptureStatusNone ? knobs().prior_graph : 0;
   if (W > 0 && p_end - p >= (W > 2 ? 2 * W : 4)) {
+    // The executables are CACHED: a graph bakes in nothing but the launches' arguments -- every pointer and size
+    // of *w and *state (the host mask aside), the sampling parameters, W and the library switches --, so a call whose
+    // arguments compare equal byte for byte replays the graphs an earlier call captured.  Nothing is destroyed at the end of
+    // a call, hence nothing to wait for: the call returns as soon as its launches are enqueued, like every other entry
+    // point.  At most kDecodeGraphCacheMax argument sets are kept; the least recently used one is dropped (after a device
+    // synchronisation: its last replay may still be running).
+    std::lock_guard<std::mutex> lock(decode_graph_mutex());
+    DecodeGraphs *G = decode_graphs_for(w, s, temperature, top_k, top_p, W);
     hipStream_t cap = nullptr;
-    hipGraph_t graphs[2] = {nullptr, nullptr};
-    hipGraphExec_t execs[2] = {nullptr, nullptr};
-    bool failed[2] = {false, false};
-    bool ok = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess;
+    bool ok = G != nullptr;
     auto build = [&](int k) -> bool {      // k = 1: every position of the window samples
-      if (execs[k] || failed[k]) return execs[k] != nullptr;
-      bool good = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (G->execs[k] || G->failed[k]) return G->execs[k] != nullptr;
+      bool good = (cap != nullptr || hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) == hipSuccess) &&
+                  hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
       int erc = ISI_OK;
       for (int i = 0; good && i < W && erc == ISI_OK; ++i) erc = enqueue_position(k == 1, -1, cap);
       hipGraph_t gph = nullptr;
       const bool ended = good && hipStreamEndCapture(cap, &gph) == hipSuccess;
-      graphs[k] = gph;
-      good = good && erc == ISI_OK && ended && gph != nullptr && hipGraphInstantiate(&execs[k], gph, nullptr, nullptr, 0) == hipSuccess;
-      if (!good) { failed[k] = true; (void)hipGetLastError(); }
+      G->graphs[k] = gph;
+      good = good && erc == ISI_OK && ended && gph != nullptr && hipGraphInstantiate(&G->execs[k], gph, nullptr, nullptr, 0) == hipSuccess;
+      if (!good) { G->failed[k] = true; G->execs[k] = nullptr; (void)hipGetLastError(); }
       return good;
     };
     int counter = -1;                      // value of the device counter (-1: unknown)
@@ -1079,18 +1137,13 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
           hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, st, pos, p, 0);
           if ((rc = check_launch("set_position"))) break;
         }
-        if (hipGraphLaunch(execs[flag ? 1 : 0], st) != hipSuccess) { rc = check_launch("hipGraphLaunch(prior positions)"); break; }
+        if (hipGraphLaunch(G->execs[flag ? 1 : 0], st) != hipSuccess) { rc = check_launch("hipGraphLaunch(prior positions)"); break; }
         p += W;
         counter = p;
       } else {
         if ((rc = enqueue_position(flag, p, st))) break;
         ++p;
       }
-    }
-    if (execs[0] || execs[1]) (void)hipStreamSynchronize(st);   // executables must outlive their launches
-    for (int k = 0; k < 2; ++k) {
-      if (execs[k]) (void)hipGraphExecDestroy(execs[k]);
-      if (graphs[k]) (void)hipGraphDestroy(graphs[k]);
     }
     if (cap) (void)hipStreamDestroy(cap);
     if (rc) return rc;

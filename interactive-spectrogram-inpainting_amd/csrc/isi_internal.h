@@ -158,11 +158,17 @@ struct GemmExtra {
 const uint64_t *dropout_seed_base();
 // the keep decision of the fused dropout: a counter-based hash of (seed, flat output index) -- the same function in the
 // forward epilogue and wherever a backward needs the mask again
+// (round 6: two 32-bit multiplies instead of four -- v_mul_lo_u32 runs at a quarter of the vector rate, and the 128 keep
+// decisions per lane of a 256 x 256 GEMM tile's epilogue cost the feed-forward layers 22 us of 86, tools/prof_steady.py:
+// the "lowbias32" mixer (xorshift-multiply twice, full avalanche) over the index, the seed's words folded in behind
+// each round)
 __host__ __device__ inline bool dropout_keep(uint64_t seed, uint32_t idx, uint32_t thresh) {
-  uint32_t h = idx * 0x9E3779B1u ^ (uint32_t)seed;
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  uint32_t h = idx;
+  h ^= h >> 16; h *= 0x7FEB352Du;
+  h ^= (uint32_t)seed;                  // (behind the first round: seeds that differ in a low bit must not just swap neighbours)
+  h ^= h >> 15; h *= 0x846CA68Bu;
   h ^= (uint32_t)(seed >> 32);
-  h *= 0x27D4EB2Fu; h ^= h >> 15;
+  h ^= h >> 16;
   return h >= thresh;
 }
 int gemm_split_f32(const float *a, int64_t lda, const float *w, const float *bias, const float *res, int64_t ldr, float *out,

@@ -36,6 +36,11 @@
 #include "prof.h"
 #include "split_f16.h"
 
+#ifndef ISI_RESPAIR_STORE_AUX
+#define ISI_RESPAIR_STORE_AUX 0   // cache policy of the output stores.  Measured (round 6, the forward's eight launches): default 0.435 ms,
+                                  // sc0 (1) 0.435, nt (2) 0.777 -- the write bursts of an item's tail live on the L2 / Infinity Cache absorbing them
+#endif
+
 namespace isi {
 
 namespace {
@@ -402,8 +407,8 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
           // (round 5, measured and dropped: handing the kb = 0 lane both lanes' first halves with v_permlane32_swap, so that a
           // store instruction writes 32-byte instead of 16-byte runs per pixel -- the form that took the first layer from 86 to
           // 77 us -- changed nothing here: the tail's burst is bound by bytes)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_ST ? OOB_ST : off + 16u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w0), rso_b, off, 0, ISI_RESPAIR_STORE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, w1), rso_b, off == OOB_ST ? OOB_ST : off + 16u, 0, ISI_RESPAIR_STORE_AUX);
           if (p.out2) {   // (uniform) fp32 twin of a pair-format output: the same 8 channels at the same offsets
             constexpr float q2 = 1.f / f16s::kScaleA;
             const uint4 f0 = make_uint4(__builtin_bit_cast(unsigned, x4[0] * q2), __builtin_bit_cast(unsigned, x4[1] * q2),

@@ -416,6 +416,78 @@ def test_code_database_round_trip(tmp_path, monkeypatch):
     assert CodeRow._fields == extract_code.CodeRow._fields == ('top', 'bottom', 'attributes', 'filename')
 
 
+def test_service_helpers_host_side(tmp_path, monkeypatch):
+    """The host halves of the round-6 routes, without a GPU: `/sample-from-dataset`'s lookup over the code database in the
+    reference's on-disk layout (flask_server.py:314-372: constraints on decoded attributes, pitch class / octave derived
+    from the pitch, cut / continued to the requested duration), the WAV reader behind `/analyze-audio` against the writer
+    behind `/get-audio` (PCM16 and float32, stereo averaged), and the PNG writer of `/get-spectrogram-image`."""
+    import struct
+    import sys
+    import types
+    import zlib
+    from sklearn.preprocessing import LabelEncoder
+    fake = _FakeLMDB()
+    mod = types.ModuleType("lmdb")
+    mod.open = fake.open
+    monkeypatch.setitem(sys.modules, "lmdb", mod)
+    import extract_code
+    import flask_server
+    import inpainting
+    from interactive_spectrogram_inpainting.utils.datasets.label_encoders import dump_label_encoders
+    from interactive_spectrogram_inpainting.utils.datasets.lmdb_dataset import LMDBDataset
+    enc = {"pitch": LabelEncoder().fit(list(range(24, 85))), "instrument_family_str": LabelEncoder().fit(["bass", "flute", "guitar"])}
+    sink = extract_code.lmdb_sink(tmp_path, enc)
+    rng = np.random.default_rng(1)
+    notes = {"bass_004-030-050": 3, "flute_002-072-127": 5, "guitar_001-060-100": 4, "guitar_009-072-100": 6}
+    for name, width in notes.items():
+        family, pitch = name.split("_")[0], int(name[-7:-4])
+        sink(name, extract_code.CodeRow(top=rng.integers(0, 512, (8, width)), bottom=rng.integers(0, 512, (16, 2 * width)),
+                                        attributes={"pitch": torch.tensor(int(enc["pitch"].transform([pitch])[0])),
+                                                    "instrument_family_str": torch.tensor(int(enc["instrument_family_str"].transform([family])[0]))},
+                                        filename=name))
+    dump_label_encoders(enc, tmp_path)
+    ds = LMDBDataset(tmp_path, classes_for_conditioning=["pitch", "instrument_family_str"])
+    g = torch.Generator().manual_seed(0)
+    (top, bottom), attrs = inpainting.sample_from_database(ds, ds.label_encoders, 4, {"pitch": 72, "instrument_family_str": "guitar"}, g)
+    assert attrs["pitch"] == 72 and attrs["instrument_family_str"] == "guitar" and attrs["pitch_class"] == 0 and attrs["octave"] == 6
+    assert top.shape == (1, 8, 4) and bottom.shape == (1, 16, 8)               # 6 columns stored: cut
+    (top, bottom), attrs = inpainting.sample_from_database(ds, ds.label_encoders, 5, {"octave": 2}, g)   # pitch 30 only: 3 columns
+    assert attrs["pitch"] == 30 and top.shape == (1, 8, 5) and bool((top[..., 3:] == top[..., 2:3]).all())
+    assert bottom.shape == (1, 16, 10) and bool((bottom[..., 6:] == bottom[..., 5:6]).all())
+    seen = {inpainting.sample_from_database(ds, ds.label_encoders, 4, {"pitch_class": 0}, g)[1]["pitch"] for _ in range(40)}
+    assert seen == {60, 72}                                                     # a random order over the matching items
+    with pytest.raises(LookupError):
+        inpainting.sample_from_database(ds, ds.label_encoders, 4, {"pitch": 61}, g)
+    t2, b2 = inpainting.resize_codemaps_repeat_last(torch.arange(6).reshape(1, 2, 3), torch.arange(12).reshape(1, 2, 6), 2)
+    assert t2.tolist() == [[[0, 1], [3, 4]]] and b2.shape == (1, 2, 4)
+    # WAV: what the service writes it reads back (PCM16: to half a quantisation step); float32 stereo is averaged
+    x = torch.sin(torch.arange(1000) * 0.03) * 0.7
+    y, rate = flask_server._read_wav(flask_server._wav_bytes(x, 16000))
+    assert rate == 16000 and y.shape == x.shape and float((y - x).abs().max()) <= 1.6 / 32768     # (written x 32767, read / 32768)
+    stereo = torch.stack([x, -0.5 * x], 1).contiguous().numpy().astype("<f4").tobytes()
+    wav = (b"RIFF" + struct.pack("<I", 36 + len(stereo)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 2, 22050, 22050 * 8, 8, 32)
+           + b"data" + struct.pack("<I", len(stereo)) + stereo)
+    y, rate = flask_server._read_wav(wav)
+    assert rate == 22050 and torch.allclose(y, 0.25 * x, atol=1e-7)
+    for bad in (b"", b"RIFFxxxxWAVE", wav[:20], wav.replace(struct.pack("<IHHIIHH", 16, 3, 2, 22050, 22050 * 8, 8, 32),
+                                                            struct.pack("<IHHIIHH", 16, 1, 2, 22050, 22050 * 3, 3, 24))):
+        with pytest.raises((ValueError, struct.error)):
+            flask_server._read_wav(bad)
+    # PNG: signature, header, one IDAT chunk holding filter-0 scanlines of the pixels, CRCs
+    rgb = torch.randint(0, 256, (5, 7, 3), dtype=torch.uint8, generator=g)
+    png = inpainting._png_bytes(rgb)
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">IIBBBBB", png[16:29]) == (7, 5, 8, 2, 0, 0, 0)
+    pos, chunks = 8, []
+    while pos < len(png):
+        n, tag = struct.unpack(">I", png[pos:pos + 4])[0], png[pos + 4:pos + 8]
+        assert struct.unpack(">I", png[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(png[pos + 4:pos + 8 + n]) & 0xffffffff
+        chunks.append((tag, png[pos + 8:pos + 8 + n]))
+        pos += 12 + n
+    assert [t for t, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(5, 1 + 21)
+    assert (raw[:, 0] == 0).all() and (raw[:, 1:].reshape(5, 7, 3) == rgb.numpy()).all()
+
+
 def test_normalizer_statistics_and_spectral_basis_host_side():
     """Host-side constants of the front-end extras, checked without a GPU: DataNormalizer's measured statistics
     against the CPU specification, and the multi-scale loss's windowed DFT basis (window centred inside n_fft,

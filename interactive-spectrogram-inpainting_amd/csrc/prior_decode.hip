@@ -684,10 +684,17 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a, float *__
     for (int t = 0; t < 16; ++t) {
       if (8 * (wave + 4 * t) < kcn) {        // (uniform per wave)
         const float4 av = *reinterpret_cast<const float4 *>(xs + idx * MF_LD + 8 * (wave + 4 * t) + 4 * kk);
+#ifdef ISI_ROWMFMA_ABL_MFMA   // measurement only (wrong results): the tile WITHOUT its matrix instructions.  Round 6, batched decoding at
+        // B = 32 / 128: 27.0 -> 28.6 / 58.2 -> 60.2 k codes/s -- the fp32 matrix pipe (1/16 of the 16-bit rate) is worth 6 % / 3.5 %
+        // of a decoding step; a launch is a chain of dependent memory round trips (position, rows + weights, statistics, store),
+        // so the three-term 16-bit form VERDICT r05 asked for was not built
+        acc[t & 15] += av.x * bc[t].x + av.y * bc[t].y + av.z * bc[t].z + av.w * bc[t].w;
+#else
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bc[t].x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bc[t].y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bc[t].z, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bc[t].w, acc, 0, 0, 0);
+#endif
       }
     }
   }

@@ -43,6 +43,8 @@ const KnobEntry kKnobTable[] = {
     {"ISI_DECODE_NT", &Knobs::decode_nt, 1, false},
     {"ISI_PRIOR_GRAPH", &Knobs::prior_graph, 8, false},
     {"ISI_DECODE_MFMA_ROWS", &Knobs::decode_mfma_rows, 16, false},
+    {"ISI_DECODE_NO_STAT_HANDOFF", &Knobs::decode_no_stat_handoff, 0, false},
+    {"ISI_DECODE_STATS_GLOBAL", &Knobs::decode_stats_global, 0, false},
     {"ISI_CU_COUNT", &Knobs::cu_count, 0, false},
     {"ISI_ATTN_FULL_ZERO", &Knobs::attn_full_zero, 0, false},
     {"ISI_WGRAD_SPLIT_TARGET", &Knobs::wgrad_split_target, 0, false},

@@ -58,6 +58,12 @@ struct RowLinArgs {
   // counts per sequence position read from device memory
   const int *pos;
   long x_pos, res_pos, out2_pos;
+  // batched decoding on matrix tiles (row_mfma32_kernel): a pre-norm row is normalised by two launches of a position -- as the
+  // INPUT of a projection and, one launch later, as the RESIDUAL of the out-projection / second feed-forward layer.  The
+  // first writes the rows' statistics here ([M][2]: mean, 1 / std), the second reads them instead of loading the 32 x N
+  // residual rows again in every workgroup and reducing them (6 % of a decoding step at B = 32, measured by ablation)
+  float *stat_out;
+  const float *res_stat;
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }   // DPP path (isi_common.h)
@@ -71,6 +77,7 @@ __device__ __forceinline__ void touch_args(const RowLinArgs &a) {
                "s"(a.res_g), "s"(a.res_b), "s"(a.out), "s"(a.out_stride));
   asm volatile("" ::"s"(a.out2), "s"(a.out2_stride), "s"(a.split), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.relu), "s"(a.eps),
                "s"(a.pos), "s"(a.x_pos), "s"(a.res_pos), "s"(a.out2_pos));
+  asm volatile("" ::"s"(a.stat_out), "s"(a.res_stat));
 }
 
 template <int MR>
@@ -570,10 +577,42 @@ __device__ __forceinline__ void mfma_row_stats(const RowLinArgs &a, float *__res
   }
 }
 
+// The statistics of the 32 RAW rows the workgroup has just staged in LDS (one K chunk: K <= MF_KC = 128 float4 per row), EIGHT
+// LANES PER ROW: a wave takes its eight rows side by side -- 16 float4 per lane, four partial sums, a three-step DPP
+// reduction, ONE division / square-root sequence for the eight rows.  The form above (a wave per row, row after row) is a
+// chain of dependent instructions per row -- LDS read, sums, two wave reductions through an SGPR, two IEEE divisions, a
+// square root, ~1300 cycles -- eight times over for the one wave a SIMD holds: 5 us of a 14-16 us launch with a LayerNorm
+// in front (ablation + per-grid kernel trace, tools/kt_rowtiles.sh), in every workgroup of 24 launches per decoding step.
+// (Summation order differs from the batch-1 kernels' by construction; so does the tile product's.)
+__device__ __forceinline__ void mfma_row_stats_lds(const float *__restrict__ xs, float *__restrict__ stat, int Mt, int nq, int K,
+                                                   float eps, int lane, int wave) {
+  const int r = 8 * wave + (lane >> 3), sub = lane & 7;
+  float4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int qd = sub + 8 * j;
+    v[j] = (r < Mt && qd < nq) ? *reinterpret_cast<const float4 *>(xs + r * MF_LD + 4 * qd) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s4[j & 3] += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mean = group8_sum((s4[0] + s4[1]) + (s4[2] + s4[3])) / (float)K;
+  float q4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    if (sub + 8 * j < nq) {
+      const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean;
+      q4[j & 3] += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(group8_sum((q4[0] + q4[1]) + (q4[2] + q4[3])) / (float)K + eps);
+  if (sub == 0) { stat[4 * r] = mean; stat[4 * r + 1] = rstd; }
+}
+
 // `ksplit_ws` != nullptr (K beyond one chunk on a grid too small to fill the chip: linear2 of a feed-forward block, 16 tiles at
 // N = 512): grid z = the K chunk, a workgroup multiplies ONE chunk and leaves its raw 32 x 32 sums in ksplit_ws[z][M][N];
 // row_mfma_finish_kernel adds the chunks in order and applies bias / residual / ReLU (33.8 -> ~13 us for that stage at B = 32).
-__global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a, float *__restrict__ ksplit_ws) {
+__global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a, float *__restrict__ ksplit_ws, int knobs_decode_stats_global) {
   touch_args(a);
   asm volatile("" ::"s"(ksplit_ws));
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -625,13 +664,35 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a, float *__
     resv[q] = (a.res && !ksplit_ws && nok && i < Mt) ? a.res[(size_t)(m0 + i) * a.res_stride + nj] : 0.f;
   }
   // ---- row statistics (wave w: rows 8 w .. 8 w + 7)
-  if (a.ln_g) {
+  // one K chunk of at most 128 float4 per row (the prior's d_model-wide LayerNorm inputs): statistics from the staged rows
+#ifdef ISI_ROWMFMA_ABL_STATS
+  const bool stats_from_lds = false;
+#else
+  const bool stats_from_lds = a.ln_g && a.K <= MF_KC && nq <= 128 && !knobs_decode_stats_global;
+#endif
+#ifdef ISI_ROWMFMA_ABL_STATS
+  if (a.ln_g && tid < 32) { stat[4 * tid] = 0.f; stat[4 * tid + 1] = 1.f; }
+  if (false) {
+#else
+  if (a.ln_g && !stats_from_lds) {
+#endif
     const int kq = (nq + 63) >> 6;                       // float4 per lane and row
     if (kq <= 2) mfma_row_stats<2>(a, stat, m0, Mt, nq, lane, wave);
     else if (kq <= 4) mfma_row_stats<4>(a, stat, m0, Mt, nq, lane, wave);
     else mfma_row_stats<8>(a, stat, m0, Mt, nq, lane, wave);
   }
-  if (rln) {       // residual rows (N <= 512 where they are normalised: 8 floats per lane and row)
+#ifdef ISI_ROWMFMA_ABL_RES
+  if (rln && tid < 32) { stat[4 * tid + 2] = 0.f; stat[4 * tid + 3] = 1.f; }
+  if (false) {
+#else
+  if (rln && a.res_stat) {       // written by the launch that normalised these rows as its input
+    if (tid < Mt) {
+      const float2 st2 = *reinterpret_cast<const float2 *>(a.res_stat + 2 * (size_t)(m0 + tid));
+      stat[4 * tid + 2] = st2.x;
+      stat[4 * tid + 3] = st2.y;
+    }
+  } else if (rln) {       // residual rows (N <= 512 where they are normalised: 8 floats per lane and row)
+#endif
     float rv[8][8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr)
@@ -660,14 +721,40 @@ __global__ __launch_bounds__(256) void row_mfma32_kernel(RowLinArgs a, float *__
     const int kcn = a.K - kc < MF_KC ? a.K - kc : MF_KC;
     const int cq = kcn >> 2;
     const int csh = (cq & (cq - 1)) == 0 ? __builtin_ctz(cq) : -1;
+    float4 g_pre = make_float4(1.f, 1.f, 1.f, 1.f), b_pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool gb_pre = stats_from_lds && cq == 128;
+    if (stats_from_lds) {   // (kc == kc_begin == 0: one chunk)  raw rows -> LDS, statistics from there, then the rows again, normalised
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int f = tid + 256 * u, r = csh >= 0 ? f >> csh : f / cq, c4 = f - r * cq;
+        if (f < 32 * cq) *reinterpret_cast<float4 *>(xs + r * MF_LD + 4 * c4) = sv[u];
+      }
+      __syncthreads();
+      // (LayerNorm weight / bias of this thread's columns -- float4 number tid % 128 of a 512-wide row, whatever the piece --
+      // travel under the statistics; requested where they are applied their L2 round trip was exposed)
+      if (cq == 128) { g_pre = reinterpret_cast<const float4 *>(a.ln_g)[tid & 127]; b_pre = reinterpret_cast<const float4 *>(a.ln_b)[tid & 127]; }
+#ifdef ISI_ROWMFMA_ABL_STATS2
+      if (tid < 32) { stat[4 * tid] = 0.f; stat[4 * tid + 1] = 1.f; }
+#else
+      mfma_row_stats_lds(xs, stat, Mt, nq, a.K, a.eps, lane, wave);
+#endif
+    }
     __syncthreads();       // the statistics are written / the previous chunk's rows have been read
+    if (a.stat_out && a.ln_g && kc == kc_begin && blockIdx.x == 0 && blockIdx.z == 0 && tid < Mt)
+      *reinterpret_cast<float2 *>(a.stat_out + 2 * (size_t)(m0 + tid)) = make_float2(stat[4 * tid], stat[4 * tid + 1]);
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int f = tid + 256 * u, r = csh >= 0 ? f >> csh : f / cq, c4 = f - r * cq;
       if (f < 32 * cq) {
         float4 v = sv[u];
         if (a.ln_g && r < Mt) {
-          const float4 g = reinterpret_cast<const float4 *>(a.ln_g + kc)[c4], b = reinterpret_cast<const float4 *>(a.ln_b + kc)[c4];
+#ifdef ISI_ROWMFMA_ABL_LNLOAD
+          const float4 g = make_float4(1.f, 1.f, 1.f, 1.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+          // (requested with the tile at the head of the kernel the launch was 1.5 us LONGER, tools/kt_rowtiles.sh)
+          float4 g = g_pre, b = b_pre;
+          if (!gb_pre) { g = reinterpret_cast<const float4 *>(a.ln_g + kc)[c4]; b = reinterpret_cast<const float4 *>(a.ln_b + kc)[c4]; }
+#endif
           const float mean = stat[4 * r], rstd = stat[4 * r + 1];
           v.x = (v.x - mean) * rstd * g.x + b.x; v.y = (v.y - mean) * rstd * g.y + b.y;
           v.z = (v.z - mean) * rstd * g.z + b.z; v.w = (v.w - mean) * rstd * g.w + b.w;
@@ -735,7 +822,10 @@ __global__ __launch_bounds__(256) void row_mfma_finish_kernel(RowLinArgs a, cons
   const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool rln = a.res && a.res_g;
   float rmean = 0.f, rrstd = 1.f;
-  if (rln) {
+  if (rln && a.res_stat) {
+    rmean = a.res_stat[2 * (size_t)m];
+    rrstd = a.res_stat[2 * (size_t)m + 1];
+  } else if (rln) {
     const float *rr = a.res + (size_t)m * a.res_stride;
     float s_ = 0.f;
     for (int i = tid; i < a.N; i += 256) s_ += rr[i];
@@ -780,13 +870,13 @@ int launch_row_mfma(const RowLinArgs &a, hipStream_t st, float *ksplit_ws = null
   }
   const int tiles = ((a.N + 31) / 32) * ((a.M + 31) / 32), nz = (a.K + MF_KC - 1) / MF_KC;
   if (nz > 1 && tiles < 128 && ksplit_ws && (size_t)nz * a.M * a.N <= ksplit_floats) {
-    hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32, nz), dim3(256), kRowMfmaLds, st, a, ksplit_ws);
+    hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32, nz), dim3(256), kRowMfmaLds, st, a, ksplit_ws, knobs().decode_stats_global);
     int rc = check_launch("row_mfma32 (K chunks)");
     if (rc) return rc;
     hipLaunchKernelGGL(row_mfma_finish_kernel, dim3(a.M), dim3(256), 0, st, a, ksplit_ws, nz);
     return check_launch("row_mfma_finish");
   }
-  hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32), dim3(256), kRowMfmaLds, st, a, (float *)nullptr);
+  hipLaunchKernelGGL(row_mfma32_kernel, dim3((a.N + 31) / 32, (a.M + 31) / 32), dim3(256), kRowMfmaLds, st, a, (float *)nullptr, knobs().decode_stats_global);
   return check_launch("row_mfma32");
 }
 
@@ -927,7 +1017,8 @@ size_t prior_decode_scratch_floats(const isi_prior_w *w, int B) {
   const size_t d = w->d_model;
   // q, attn out, y1, y2, y3(a), y3(b), hidden, logits, sampled(int64)
   return (size_t)B * (6 * d + w->dim_feedforward + w->n_class) + 2 * (size_t)B + 64 + 32 +
-         rel_attention_decode_workspace_floats(B, w->nhead, w->d_model / w->nhead) + mfma_ksplit_floats(w, B);
+         rel_attention_decode_workspace_floats(B, w->nhead, w->d_model / w->nhead) + mfma_ksplit_floats(w, B) +
+         2 * (size_t)B + 4;     // (+ the rows' LayerNorm statistics handed from launch to launch, RowLinArgs.stat_out)
 }
 
 // ---- cache of the decode loop's graph executables (prior_sample_run)
@@ -1004,6 +1095,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
   pos = reinterpret_cast<int *>((reinterpret_cast<uintptr_t>(pos) + 15) & ~(uintptr_t)15);
   float *mf_ws = reinterpret_cast<float *>(pos + 4);                     // (16-byte aligned: K-chunk sums of row_mfma32_kernel)
   const size_t mf_ws_floats = mfma_ksplit_floats(w, B) - 4;
+  float *rowstat = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(mf_ws + mf_ws_floats) + 7) & ~(uintptr_t)7);   // [B][2]
   const int i_off = s->start_len - 1;   // token index predicted from position p is p - i_off
 
   // Every launch of one position; all position-dependent addresses and sizes are derived on the device
@@ -1023,6 +1115,14 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       if (!a.x_pos && !a.res_pos && !a.out2_pos) a.pos = nullptr;      // nothing of this launch depends on the position
       return launch_stage_rows(a, part, ns, hd, mf_ws, mf_ws_floats, q_st);
     };
+    // statistics hand-off between the two launches that normalise the same rows (tile path only: both must run there)
+    auto on_tiles = [&](const RowLinArgs &a) { return a.M > knobs().decode_mfma_rows && row_mfma_supported(a); };
+    auto hand_stats = [&](RowLinArgs &producer, RowLinArgs &consumer) {
+      if (on_tiles(producer) && on_tiles(consumer) && producer.ln_g && consumer.res_g && !knobs().decode_no_stat_handoff) {
+        producer.stat_out = rowstat;
+        consumer.res_stat = rowstat;
+      }
+    };
     // the attention's splits are merged by the out-projection when that runs as the one-row kernel
     const int ns_self = rel_attention_decode_splits(s->S_t, B * w->nhead), ns_cross = rel_attention_decode_splits(s->S_src, B * w->nhead);
     const bool merge_in_gemv = B == 1 && d <= 512 && (d & 3) == 0;
@@ -1039,6 +1139,10 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       // q | k,v  (k,v straight into the cache slot of this position)
       a = RowLinArgs{yin, d, ln_g, ln_b, L.self_attn.in_proj_weight, L.self_attn.in_proj_bias, nullptr, 0, nullptr,
                      nullptr, q, d, cache, 2 * d, d, B, 3 * d, d, 0, 1e-5f, pos, yin_pos, 0, (long)B * 2 * d};
+      // y1 = LN_in(yin) + ao Wo^T + bo   (its launch follows the attention)
+      RowLinArgs a_o{ao, d, nullptr, nullptr, L.self_attn.out_proj_weight, L.self_attn.out_proj_bias, yin, d, ln_g,
+                     ln_b, y1, d, nullptr, 0, d, B, d, d, 0, 1e-5f, pos, 0, yin_pos, 0};
+      if (ln_g) hand_stats(a, a_o);
       if ((rc = launch_rows(a))) return rc;
       isi_attn_args g;
       memset(&g, 0, sizeof g);
@@ -1049,28 +1153,27 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       g.Cq = w->Cd; g.Ck = w->Cd; g.Ek = w->Ed; g.rel_rows = L.self_attn.rel_rows; g.scale = scale;
       const bool defer_s = merge_in_gemv && ns_self > 1;
       if ((rc = rel_attention_decode_launch(&g, p < 0 ? 0 : p, pos_arg, 1, attn_ws, defer_s ? 0 : 1, q_st))) return rc;
-      // y1 = LN_in(yin) + ao Wo^T + bo
-      a = RowLinArgs{ao, d, nullptr, nullptr, L.self_attn.out_proj_weight, L.self_attn.out_proj_bias, yin, d, ln_g,
-                     ln_b, y1, d, nullptr, 0, d, B, d, d, 0, 1e-5f, pos, 0, yin_pos, 0};
-      if ((rc = defer_s ? launch_rows(a, attn_ws, ns_self) : launch_rows(a))) return rc;
+      if ((rc = defer_s ? launch_rows(a_o, attn_ws, ns_self) : launch_rows(a_o))) return rc;
       // cross-attention query from LN1(y1)
       a = RowLinArgs{y1, d, L.norm1_w, L.norm1_b, L.cross_attn.in_proj_weight, L.cross_attn.in_proj_bias, nullptr, 0,
                      nullptr, nullptr, q, d, nullptr, 0, d, B, d, d, 0, 1e-5f, nullptr, 0, 0, 0};
+      RowLinArgs a_o2{ao, d, nullptr, nullptr, L.cross_attn.out_proj_weight, L.cross_attn.out_proj_bias, y1, d,
+                      L.norm1_w, L.norm1_b, y2, d, nullptr, 0, d, B, d, d, 0, 1e-5f, nullptr, 0, 0, 0};
+      hand_stats(a, a_o2);
       if ((rc = launch_rows(a))) return rc;
       g.k = memkv; g.v = memkv + d; g.rel_embeddings = L.cross_attn.rel_embeddings; g.Sk = s->S_src;
       g.Ck = w->Ce; g.Ek = w->Ee; g.rel_rows = L.cross_attn.rel_rows;
       const bool defer_c = merge_in_gemv && ns_cross > 1;
       if ((rc = rel_attention_decode_launch(&g, p < 0 ? 0 : p, pos_arg, 0, attn_ws, defer_c ? 0 : 1, q_st))) return rc;
-      a = RowLinArgs{ao, d, nullptr, nullptr, L.cross_attn.out_proj_weight, L.cross_attn.out_proj_bias, y1, d,
-                     L.norm1_w, L.norm1_b, y2, d, nullptr, 0, d, B, d, d, 0, 1e-5f, nullptr, 0, 0, 0};
-      if ((rc = defer_c ? launch_rows(a, attn_ws, ns_cross) : launch_rows(a))) return rc;
+      if ((rc = defer_c ? launch_rows(a_o2, attn_ws, ns_cross) : launch_rows(a_o2))) return rc;
       // feed-forward on LN2(y2)
       a = RowLinArgs{y2, d, L.norm2_w, L.norm2_b, L.linear1_w, L.linear1_b, nullptr, 0, nullptr, nullptr, hid, ff,
                      nullptr, 0, ff, B, ff, d, 1, 1e-5f, nullptr, 0, 0, 0};
+      RowLinArgs a_f2{hid, ff, nullptr, nullptr, L.linear2_w, L.linear2_b, y2, d, L.norm2_w, L.norm2_b, y3, d, nullptr,
+                      0, d, B, d, ff, 0, 1e-5f, nullptr, 0, 0, 0};
+      hand_stats(a, a_f2);
       if ((rc = launch_rows(a))) return rc;
-      a = RowLinArgs{hid, ff, nullptr, nullptr, L.linear2_w, L.linear2_b, y2, d, L.norm2_w, L.norm2_b, y3, d, nullptr,
-                     0, d, B, d, ff, 0, 1e-5f, nullptr, 0, 0, 0};
-      if ((rc = launch_rows(a))) return rc;
+      if ((rc = launch_rows(a_f2))) return rc;
       yin = y3; yin_pos = 0; ln_g = L.norm3_w; ln_b = L.norm3_b;
     }
     if (sample) {

@@ -67,7 +67,6 @@ struct RowLinArgs {
 };
 
 __device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }   // DPP path (isi_common.h)
-
 // Every field of a launch's argument block is "used" by an empty asm statement at the head of the kernel: the compiler
 // otherwise fetches the fields where they are first needed -- three or four DEPENDENT scalar-memory round trips (the later
 // ones to a 64-byte line of the freshly written block that no earlier load touched) in front of the first weight request,
@@ -288,7 +287,9 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
   }
   constexpr int RS = 8;                      // residual row for its LayerNorm statistics: N <= 512
   float rrow[RS];
-  if (a.res && a.res_g) {
+  float2 rstat = make_float2(0.f, 1.f);      // the residual row's statistics from the launch that formed them (RowLinArgs.res_stat)
+  if (a.res && a.res_g && a.res_stat) rstat = *reinterpret_cast<const float2 *>(a.res_stat);
+  else if (a.res && a.res_g) {
 #pragma unroll
     for (int i = 0; i < RS; ++i) {
       const int c = lane + 64 * i;
@@ -331,6 +332,9 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
       }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)a.K + a.eps);
+    // (for the launch that normalises this row again as its residual: one dependent chain of two reductions, two
+    // divisions and a square root less on the one wave its SIMD holds)
+    if (a.stat_out && blockIdx.x == 0 && tid == 0) *reinterpret_cast<float2 *>(a.stat_out) = make_float2(mean, rstd);
 #pragma unroll
     for (int i = 0; i < KQ; ++i) {
       if (lane + 64 * i < nq) {
@@ -339,8 +343,8 @@ __global__ __launch_bounds__(256) void row_gemv1_kernel(Gemv1Args g) {
       }
     }
   }
-  float rmean = 0.f, rrstd = 1.f;
-  if (a.res && a.res_g) {
+  float rmean = rstat.x, rrstd = rstat.y;
+  if (a.res && a.res_g && !a.res_stat) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < RS; ++i) if (lane + 64 * i < a.N) s += rrow[i];
@@ -1117,8 +1121,10 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
     };
     // statistics hand-off between the two launches that normalise the same rows (tile path only: both must run there)
     auto on_tiles = [&](const RowLinArgs &a) { return a.M > knobs().decode_mfma_rows && row_mfma_supported(a); };
-    auto hand_stats = [&](RowLinArgs &producer, RowLinArgs &consumer) {
-      if (on_tiles(producer) && on_tiles(consumer) && producer.ln_g && consumer.res_g && !knobs().decode_no_stat_handoff) {
+    auto hand_stats = [&](RowLinArgs &producer, RowLinArgs &consumer, bool consumer_merges = false) {
+      const bool tiles = on_tiles(producer) && on_tiles(consumer);
+      const bool one_row = row_gemv1_supported(producer, false) && row_gemv1_supported(consumer, consumer_merges);   // batch 1
+      if ((tiles || one_row) && producer.ln_g && consumer.res_g && !knobs().decode_no_stat_handoff) {
         producer.stat_out = rowstat;
         consumer.res_stat = rowstat;
       }
@@ -1142,7 +1148,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       // y1 = LN_in(yin) + ao Wo^T + bo   (its launch follows the attention)
       RowLinArgs a_o{ao, d, nullptr, nullptr, L.self_attn.out_proj_weight, L.self_attn.out_proj_bias, yin, d, ln_g,
                      ln_b, y1, d, nullptr, 0, d, B, d, d, 0, 1e-5f, pos, 0, yin_pos, 0};
-      if (ln_g) hand_stats(a, a_o);
+      if (ln_g) hand_stats(a, a_o, merge_in_gemv && ns_self > 1);
       if ((rc = launch_rows(a))) return rc;
       isi_attn_args g;
       memset(&g, 0, sizeof g);
@@ -1159,7 +1165,7 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
                      nullptr, nullptr, q, d, nullptr, 0, d, B, d, d, 0, 1e-5f, nullptr, 0, 0, 0};
       RowLinArgs a_o2{ao, d, nullptr, nullptr, L.cross_attn.out_proj_weight, L.cross_attn.out_proj_bias, y1, d,
                       L.norm1_w, L.norm1_b, y2, d, nullptr, 0, d, B, d, d, 0, 1e-5f, nullptr, 0, 0, 0};
-      hand_stats(a, a_o2);
+      hand_stats(a, a_o2, merge_in_gemv && ns_cross > 1);
       if ((rc = launch_rows(a))) return rc;
       g.k = memkv; g.v = memkv + d; g.rel_embeddings = L.cross_attn.rel_embeddings; g.Sk = s->S_src;
       g.Ck = w->Ce; g.Ek = w->Ee; g.rel_rows = L.cross_attn.rel_rows;

@@ -115,6 +115,8 @@ struct SampleCommit {
   int64_t *codes; int codes_stride;
   int p_value, i_off, S_t;
   float *x_seq; int x_stride;
+  int *advance;      // ONE row only (a single workgroup: no other reader of the counter in the launch): *advance = position + 1
+                     // behind the commit -- the decode loop's set_pos launch (4.3 us of a 280 us token) folded in
 };
 int sample_row_commit_f32(const float *logits, int stride, int rows, int n, float temperature, int top_k, float top_p,
                           const float *u, int64_t *out, float *filtered, const int *pos, int pos_off,

@@ -1187,11 +1187,14 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
                    nullptr, 0, w->n_class, B, w->n_class, d, 0, 1e-5f, nullptr, 0, 0, 0};
       int rc;
       if ((rc = launch_rows(a))) return rc;
-      const SampleCommit cm{w->embed_table, w->eff_dim, s->codes, s->S, p, i_off, s->S_t, s->x_seq, d};
+      // (a replayed position of ONE sequence: the commit also advances the position counter)
+      const bool fold_advance = p < 0 && B == 1;
+      const SampleCommit cm{w->embed_table, w->eff_dim, s->codes, s->S, p, i_off, s->S_t, s->x_seq, d, fold_advance ? pos : nullptr};
       if ((rc = sample_row_commit_f32(logits, w->n_class, B, w->n_class, temperature, top_k, top_p,
                                       p < 0 ? s->uniforms : s->uniforms + (size_t)(p - i_off) * B, sampled, nullptr, pos_arg,
                                       i_off, cm, q_st)))
         return rc;
+      if (fold_advance) return ISI_OK;
     }
     if (p >= 0) return ISI_OK;
     hipLaunchKernelGGL(set_pos_kernel, dim3(1), dim3(1), 0, q_st, pos, 1, 1);

@@ -572,6 +572,10 @@ __global__ __launch_bounds__(1024) void sample_row_f32_kernel(const float *__res
       float *x_next = cm.x_seq + ((size_t)(p + 1) * gridDim.x + row) * cm.x_stride;
       for (int e = tid; e < cm.eff; e += np) x_next[e] = cm.table[(size_t)tok * cm.eff + e];
     }
+    if (cm.advance) {                  // (gridDim.x == 1, checked by the launcher)
+      __syncthreads();                 // every thread has read the counter
+      if (tid == 0) *cm.advance = p + 1;
+    }
   }
   (void)sh_f;
 }
@@ -595,6 +599,7 @@ int sample_row_commit_f32(const float *logits, int stride, int rows, int n, floa
                           const SampleCommit &cm, hipStream_t stream) {
   if (!logits || !u || !out || rows <= 0 || n <= 0 || temperature <= 0.f) return invalid("sample_row: bad argument");
   if (n > 1024) return unsupported("sample_row: at most 1024 classes");
+  if (cm.advance && (rows != 1 || !cm.table)) return invalid("sample_row: the position counter is advanced by a one-row commit only");
   int np = 64;
   while (np < n) np <<= 1;
   hipLaunchKernelGGL(sample_row_f32_kernel, dim3(rows), dim3(np), 0, stream, logits, stride, n, 1.0f / temperature,

@@ -432,7 +432,13 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
   for (int m = 0; m < MR; ++m) res_v[m] = (writer && resg && m < Mg) ? resg[(size_t)m * a.res_stride + n] : 0.f;
   constexpr int RS = 8;
   float rrow[MR][RS];
-  if (resg && a.res_g) {
+  float2 rstat[MR];        // the residual rows' statistics from the launch that formed them (RowLinArgs.res_stat)
+  const bool res_handed = resg && a.res_g && a.res_stat;
+  if (res_handed) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+      rstat[m] = m < Mg ? *reinterpret_cast<const float2 *>(a.res_stat + 2 * (size_t)(m0 + m)) : make_float2(0.f, 1.f);
+  } else if (resg && a.res_g) {
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -465,6 +471,11 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
       }
       rstd[m] = 1.0f / sqrtf(wave_sum(var) / (float)a.K + a.eps);
     }
+    if (a.stat_out && blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m)
+        if (m < Mg) *reinterpret_cast<float2 *>(a.stat_out + 2 * (size_t)(m0 + m)) = make_float2(mean[m], rstd[m]);
+    }
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -477,8 +488,8 @@ __global__ __launch_bounds__(256) void row_gemvm_kernel(RowLinArgs a) {
   }
   float rmean[MR], rrstd[MR];
 #pragma unroll
-  for (int m = 0; m < MR; ++m) { rmean[m] = 0.f; rrstd[m] = 1.f; }
-  if (resg && a.res_g) {
+  for (int m = 0; m < MR; ++m) { rmean[m] = res_handed ? rstat[m].x : 0.f; rrstd[m] = res_handed ? rstat[m].y : 1.f; }
+  if (resg && a.res_g && !res_handed) {
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
       float s = 0.f;
@@ -1124,7 +1135,10 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
     auto hand_stats = [&](RowLinArgs &producer, RowLinArgs &consumer, bool consumer_merges = false) {
       const bool tiles = on_tiles(producer) && on_tiles(consumer);
       const bool one_row = row_gemv1_supported(producer, false) && row_gemv1_supported(consumer, consumer_merges);   // batch 1
-      if ((tiles || one_row) && producer.ln_g && consumer.res_g && !knobs().decode_no_stat_handoff) {
+      // batches of up to `decode_mfma_rows` rows: the rows-in-registers kernel (launch_stage_rows picks it in this order)
+      const bool few_rows = producer.M > 1 && producer.M <= knobs().decode_mfma_rows && row_gemvm_supported(producer) &&
+                            row_gemvm_supported(consumer) && !consumer_merges;
+      if ((tiles || one_row || few_rows) && producer.ln_g && consumer.res_g && !knobs().decode_no_stat_handoff) {
         producer.stat_out = rowstat;
         consumer.res_stat = rowstat;
       }

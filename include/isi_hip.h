@@ -618,7 +618,7 @@ size_t isi_prior_decode_scratch_floats(const isi_prior_w *w, int B);
  * position-dependent address read from a device counter): the host leaves the loop.  The executables are kept by the
  * library, keyed on the bytes of *w, *state (the host mask aside), the sampling parameters and the switches -- a later call
  * with equal arguments replays them, nothing is captured again and the call never waits for the stream (at most 8 argument
- * sets are kept; dropping the least recently used one synchronises the device once).  While the CALLER is capturing `stream`
+ * sets are kept; the least recently used one is dropped once its last replay has finished).  While the CALLER is capturing `stream`
  * and with ISI_PRIOR_GRAPH = 0: ~66 direct launches per position.  Same kernels, same codes either way. */
 int isi_prior_sample_run(const isi_prior_w *w, const isi_prior_state *state, int p_begin,
                          int p_end, float temperature, int top_k, float top_p, void *stream);

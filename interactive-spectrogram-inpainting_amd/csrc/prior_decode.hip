@@ -1044,6 +1044,7 @@ struct DecodeGraphs {
   hipGraphExec_t execs[2] = {nullptr, nullptr};
   bool failed[2] = {false, false};
   uint64_t used = 0;
+  hipEvent_t done = nullptr;      // recorded behind the last replay: what dropping this entry has to wait for
 };
 static std::mutex &decode_graph_mutex() { static std::mutex m; return m; }
 // (called with the mutex held)  nullptr: no device / allocation failure -- the caller then launches directly
@@ -1068,7 +1069,12 @@ static DecodeGraphs *decode_graphs_for(const isi_prior_w *w, const isi_prior_sta
   if (cache.size() >= kDecodeGraphCacheMax) {
     size_t lru = 0;
     for (size_t i = 1; i < cache.size(); ++i) if (cache[i]->used < cache[lru]->used) lru = i;
-    (void)hipDeviceSynchronize();                      // its last replay may still be running
+    if (cache[lru]->done) {                            // its last replay may still be running
+      (void)hipEventSynchronize(cache[lru]->done);
+      (void)hipEventDestroy(cache[lru]->done);
+    } else {
+      (void)hipDeviceSynchronize();
+    }
     for (int j = 0; j < 2; ++j) {
       if (cache[lru]->execs[j]) (void)hipGraphExecDestroy(cache[lru]->execs[j]);
       if (cache[lru]->graphs[j]) (void)hipGraphDestroy(cache[lru]->graphs[j]);
@@ -1241,8 +1247,8 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
     // of *w and *state (the host mask aside), the sampling parameters, W and the library switches --, so a call whose
     // arguments compare equal byte for byte replays the graphs an earlier call captured.  Nothing is destroyed at the end of
     // a call, hence nothing to wait for: the call returns as soon as its launches are enqueued, like every other entry
-    // point.  At most kDecodeGraphCacheMax argument sets are kept; the least recently used one is dropped (after a device
-    // synchronisation: its last replay may still be running).
+    // point.  At most kDecodeGraphCacheMax argument sets are kept; the least recently used one is dropped once the event
+    // recorded behind its last replay has passed.
     std::lock_guard<std::mutex> lock(decode_graph_mutex());
     DecodeGraphs *G = decode_graphs_for(w, s, temperature, top_k, top_p, W);
     hipStream_t cap = nullptr;
@@ -1279,6 +1285,10 @@ int prior_sample_run(const isi_prior_w *w, const isi_prior_state *s, int p_begin
       }
     }
     if (cap) (void)hipStreamDestroy(cap);
+    if (G && (G->execs[0] || G->execs[1])) {
+      if (!G->done && hipEventCreateWithFlags(&G->done, hipEventDisableTiming) != hipSuccess) { G->done = nullptr; (void)hipGetLastError(); }
+      if (G->done && hipEventRecord(G->done, st) != hipSuccess) (void)hipGetLastError();
+    }
     if (rc) return rc;
   }
   for (; p < p_end; ++p)

@@ -559,6 +559,39 @@ def test_sample_model_edge_masks(golden_dir):
         assert torch.equal(solo[0], out[1])
 
 
+def test_decode_graph_cache_and_statistics_handoff(golden_dir):
+    """Round 6.  (a) `isi_prior_sample_run` keeps the graph executables of its last 8 argument sets: more sets than that (ten
+    temperatures), revisited afterwards, give the codes of direct launches (ISI_PRIOR_GRAPH=0) every time -- entries are
+    dropped and rebuilt without a stale replay.  (b) The LayerNorm statistics handed from the launch that normalises a row as
+    its input to the launch that normalises it as its residual (batch 1, rows-in-registers and tile kernels): the same codes
+    as with every launch computing its own (ISI_DECODE_NO_STAT_HANDOFF=1)."""
+    import sample as S
+    from interactive_spectrogram_inpainting import _hip
+    z, top, bottom = _models(golden_dir)
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    cls = {"pitch": torch.tensor([20]), "instrument_family_str": torch.tensor([3])}
+    uni = torch.rand(top.target_transformer_sequence_length, 20, generator=g)
+    temps = [0.8 + 0.05 * i for i in range(10)]
+    run = lambda t, B=1: S.sample_model(top, dev, B, [8, 4], temperature=t, class_conditioning=cls, top_p_sampling_p=0.9,
+                                        uniforms=uni[:, :B].contiguous())
+    with _hip.knob("ISI_PRIOR_GRAPH", 0):
+        direct = [run(t) for t in temps]
+    for _ in range(2):                                   # the second sweep meets entries the first one's tail pushed out
+        for t, ref in zip(temps, direct):
+            assert torch.equal(run(t), ref), t
+    assert len({tuple(d.flatten().tolist()) for d in direct}) > 1      # (the temperatures do change the draws)
+    for B in (1, 5, 20):
+        with _hip.knob("ISI_DECODE_NO_STAT_HANDOFF", 1):
+            own = run(1.0, B)
+        assert torch.equal(run(1.0, B), own), B
+    with _hip.knob("ISI_DECODE_MFMA_ROWS", 1):           # the tile kernels on a batch of 5
+        tiled = run(1.0, 5)
+        with _hip.knob("ISI_DECODE_STATS_GLOBAL", 1), _hip.knob("ISI_DECODE_NO_STAT_HANDOFF", 1):
+            assert torch.equal(run(1.0, 5), tiled)
+    assert torch.equal(tiled, run(1.0, 5))
+
+
 def test_sample_model_large_batch(golden_dir):
     """More than 8 sequences per call (the row kernels take groups of 8 rows): every row equals its single-sequence run."""
     import sample as S

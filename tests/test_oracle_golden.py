@@ -195,7 +195,9 @@ def test_training_trajectory_matches_reference(golden_dir, tag):
         for got, key in ((id_t, "id_t"), (id_b, "id_b")):
             ref = torch.from_numpy(z[f"{tag}::{key}{i}"].astype(np.int64))
             agree = (got == ref).float().mean().item()
-            assert agree == 1.0 if i == 0 else agree > 0.995, (tag, i, key, agree)
+            # step 0: identical on the machine that made the fixture; another host's torch-CPU convolutions (thread count,
+            # instruction set) sum in another order and move a few near-tie codes -- 3 of 4096 on the GPU boxes' EPYC 9575F
+            assert agree > 0.998 if i == 0 else agree > 0.995, (tag, i, key, agree)
     for k in z.files:
         if k.startswith(f"{tag}::after::"):
             name = k[len(f"{tag}::after::"):]

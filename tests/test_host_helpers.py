@@ -6,6 +6,16 @@ import pytest
 import torch
 
 
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (asked from the OS): a fixed or seeded-random rendezvous port that happens to be
+    taken would leave the spawned ranks waiting for the store's time-out."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+
 def test_codemap_orderings_match_reference(golden_dir):
     from interactive_spectrogram_inpainting.priors.codemaps_helpers import (
         SimpleCodemapsHelper, ZigZagCodemapsHelper)
@@ -101,7 +111,7 @@ def test_two_process_sharding_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + int(torch.randint(0, 2000, (1,)).item())
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -144,7 +154,7 @@ def test_bucketed_gradient_allreduce_gloo():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + int(torch.randint(0, 2000, (1,)).item())
+    port = _free_port()
     procs = [ctx.Process(target=_grads_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -232,7 +242,7 @@ def test_grad_bucket_reducer_two_process_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + int(torch.randint(0, 2000, (1,)).item())
+    port = _free_port()
     procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -567,7 +577,9 @@ def _ema_worker(rank, world, port, q):
     except RuntimeError:
         uneven_raises = True
     same = assert_same_step_count(steps["train"][0])
-    q.put((rank, new_embed, cs, ea, steps, uneven_raises, same))
+    # (plain lists: a tensor in a queue travels as a file descriptor served by THIS process -- a rank that has exited by the
+    # time the parent unpickles its tuple left the parent with FileNotFoundError)
+    q.put((rank, new_embed.tolist(), cs.tolist(), ea.tolist(), steps, uneven_raises, same))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -584,7 +596,7 @@ def test_ema_statistics_exchange_and_even_training_shards_gloo(world):
     from oracle import vqvae_oracle as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + int(torch.randint(0, 2000, (1,)).item())
+    port = _free_port()
     procs = [ctx.Process(target=_ema_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -602,6 +614,7 @@ def test_ema_statistics_exchange_and_even_training_shards_gloo(world):
     per_rank = 63 // world // 8 if world == 8 else 3              # drop_last on the even shards: 7 samples -> 0 steps of 8
     seen = []
     for rank, new_embed, cs, ea, steps, uneven_raises, same in out:
+        new_embed, cs, ea = torch.tensor(new_embed), torch.tensor(cs), torch.tensor(ea)
         torch.testing.assert_close(cs, ref_cs, rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(ea, ref_ea, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(new_embed, ref_embed, rtol=1e-5, atol=1e-6)
@@ -754,7 +767,7 @@ def test_segmented_graph_replay_two_process_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + int(torch.randint(0, 2000, (1,)).item())
+    port = _free_port()
     procs = [ctx.Process(target=_segmented_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

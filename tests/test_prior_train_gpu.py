@@ -9,6 +9,15 @@ import numpy as np
 import pytest
 import torch
 
+
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (asked from the OS) for a rendezvous."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
 
@@ -900,7 +909,7 @@ def test_graphed_prior_step_with_real_rccl_collectives_between_segments():
     import subprocess
     import sys
     root = pathlib.Path(__file__).resolve().parents[1]
-    out = subprocess.run([sys.executable, "-c", _PRIOR_FORCED_COLLECTIVES_SCRIPT, str(root), "29579"], capture_output=True,
+    out = subprocess.run([sys.executable, "-c", _PRIOR_FORCED_COLLECTIVES_SCRIPT, str(root), str(_free_port())], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "PRIOR SEGMENTS" in out.stdout and "OK" in out.stdout

@@ -4,6 +4,15 @@ import numpy as np
 import pytest
 import torch
 
+
+def _free_port() -> int:
+    """A TCP port nobody listens on right now (asked from the OS) for a rendezvous."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 pytestmark = pytest.mark.gpu
 
 
@@ -329,7 +338,7 @@ def test_bench_two_ranks_dry_run():
     root = pathlib.Path(__file__).resolve().parents[1]
     env = dict(os.environ, ISI_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+           "--master-port", str(_free_port()), str(root / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
            "--spinup-ms", "10", "--prior-batch", "1", "--prior-steps", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(root))
     assert out.returncode == 0, out.stderr[-2000:]
@@ -405,7 +414,7 @@ def test_graphed_vqvae_step_with_real_rccl_collectives_between_segments():
     import subprocess
     import sys
     root = pathlib.Path(__file__).resolve().parents[1]
-    out = subprocess.run([sys.executable, "-c", _FORCED_COLLECTIVES_SCRIPT, str(root), "29577"], capture_output=True,
+    out = subprocess.run([sys.executable, "-c", _FORCED_COLLECTIVES_SCRIPT, str(root), str(_free_port())], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "SEGMENTS 9 OK" in out.stdout

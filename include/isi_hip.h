@@ -118,7 +118,8 @@ int isi_spec_affine_mask_f32(const float *x, const float *ref, float *y, int64_t
  * ISI_DECODE_MFMA_ROWS (rows from which a decoding stage runs as matrix tiles, 16), ISI_DECODE_NO_STAT_HANDOFF (every
  * decoding launch forms the LayerNorm statistics of its residual rows itself), ISI_DECODE_STATS_GLOBAL (the tile kernel's
  * input statistics from a second load of the rows), ISI_ATTN_NO_FWD3 / ISI_ATTN_FWD3_ALL (the plane-staged attention
- * forward never / also for single-term products), ISI_ATTN_OLD_FWD -- all select between kernels that
+ * forward never / also for single-term products), ISI_ATTN_OLD_FWD, ISI_DECODE_ATTN_SEPARATE_SPLITS (two key splits of the
+ * cached attention as two workgroups + a merging launch) -- all select between kernels that
  * compute the SAME result (to rounding).  The ablation switches ISI_CONV_ABLATE / ISI_VQ_DBG / ISI_RESPAIR_ABL
  * (wrong results by design) exist only in -DISI_MEASURE builds: the default build rejects them. */
 int isi_knob_set(const char *name, int value);

@@ -44,6 +44,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_PRIOR_GRAPH", &Knobs::prior_graph, 8, false},
     {"ISI_DECODE_MFMA_ROWS", &Knobs::decode_mfma_rows, 16, false},
     {"ISI_DECODE_NO_STAT_HANDOFF", &Knobs::decode_no_stat_handoff, 0, false},
+    {"ISI_DECODE_ATTN_SEPARATE_SPLITS", &Knobs::decode_attn_separate_splits, 0, false},
     {"ISI_DECODE_STATS_GLOBAL", &Knobs::decode_stats_global, 0, false},
     {"ISI_CU_COUNT", &Knobs::cu_count, 0, false},
     {"ISI_ATTN_FULL_ZERO", &Knobs::attn_full_zero, 0, false},

@@ -34,6 +34,7 @@ struct Knobs {
   int prior_graph;              // ISI_PRIOR_GRAPH: positions per replayed hipGraph of the decode loop (8; 0 = direct launches)
   int decode_mfma_rows;         // ISI_DECODE_MFMA_ROWS: batched decoding runs a stage as a 32-row GEMM tile on the fp32 matrix pipe for MORE
   int decode_stats_global;      // ISI_DECODE_STATS_GLOBAL: the tile path's input-row LayerNorm statistics from a second load of the rows (until round 6) instead of from the staged tile
+  int decode_attn_separate_splits;   // ISI_DECODE_ATTN_SEPARATE_SPLITS: two key splits of the cached attention as two workgroups + the combine launch (until round 6)
   int decode_no_stat_handoff;   // ISI_DECODE_NO_STAT_HANDOFF: every launch of the tile path computes the LayerNorm statistics of its residual rows itself
                                 // rows than this (16); up to it, the GEMV kernels (batch 1's operation order)
   int cu_count;                 // ISI_CU_COUNT: compute units the persistent kernels size their grids for (0: the device's); for

@@ -178,8 +178,13 @@ int linear_rows_f32(const float *x, int x_stride, const float *W, const float *b
 // relative-position logits as rel_attention_f32_kernel:
 //   s_j = (q.k_j + q.e[h, floor(q_pos/Cq) - floor(j/Ck) + Ek - 1]) * scale ; out = softmax(s) V
 // Bandwidth bound (each K, V and e row is read once): VALU dot products, no MFMA.
-template <int HD>
-__global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
+// NG = 2 (round 6): BOTH key splits of a two-split launch in one workgroup of 512 threads -- threads [256 g, 256 g + 256) are
+// split g -- and the merge of rel_attention_combine_kernel (same operations, same order) at its end: the launch of that
+// kernel (4.7 us + a dispatch gap, 16 times per decoding step of a batch of 17 .. 63 sequences) and the round trip of the
+// partials through memory go away.  The two halves take the same path (by the split length, not by their own key count)
+// and an empty half walks it with zero keys: every barrier is met by all 512 threads.
+template <int HD, int NG = 1>
+__global__ __launch_bounds__(256 * NG) void rel_attention_decode_f32_kernel(
     const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
     const float *__restrict__ e, float *__restrict__ out, int Sk, int64_t q_sb, int64_t q_sh, int64_t k_ss,
     int64_t k_sb, int64_t k_sh, int64_t v_ss, int64_t v_sb, int64_t v_sh, int64_t o_sb, int64_t o_sh,
@@ -193,11 +198,12 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
                "s"(pos), "s"(self_keys));
   // Replayable form (hipGraph): the position comes from device memory; for self-attention the key
   // count is position + 1 and the (fixed) number of splits shares it evenly.
+  const int nsplit = NG == 2 ? 2 : (int)gridDim.z;
   if (pos) {
     q_pos = *pos;
     if (self_keys) {
       Sk = q_pos + 1;
-      chunk = (Sk + (int)gridDim.z - 1) / (int)gridDim.z;
+      chunk = (Sk + nsplit - 1) / nsplit;
     }
   }
   // blockIdx.z = key split: this workgroup handles keys [z*chunk, min(Sk, (z+1)*chunk)) and,
@@ -208,18 +214,22 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   constexpr int G = HD / 4;        // lanes per row: 4, 8 or 16
   constexpr int RPP = 256 / G;     // rows per pass
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float *red = sm;                 // [8]
+  const int kg = NG == 2 ? (int)(threadIdx.x >> 8) : 0;          // key split of this half of the workgroup (NG = 2)
+  const int split = NG == 2 ? kg : (int)blockIdx.z;
+  const int sc_len = (chunk + 3) & ~3;
+  float *red = sm + kg * (8 + RPP * HD + sc_len);                  // [8]
   float *part = red + 8;           // [RPP][HD] partial outputs
   float *sc = part + RPP * HD;     // [Sk]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float *mg = sm + NG * (8 + RPP * HD + sc_len);                   // NG = 2: [2][HD + 2] the halves' (o, max, sum)
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int grp = tid / G, gl = tid % G;
   const int h = blockIdx.x, b = blockIdx.y;
-  const int kbeg = blockIdx.z * chunk;
+  const int kbeg = split * chunk;
   k += (size_t)kbeg * k_ss;
   v += (size_t)kbeg * v_ss;
   const int key0 = kbeg;              // absolute index of local key 0 (relative positions)
-  Sk = min(Sk - kbeg, chunk);         // local key count
-  if (Sk <= 0) {                      // empty split (only with a fixed split count): neutral partial
+  Sk = max(min(Sk - kbeg, chunk), 0); // local key count
+  if (NG == 1 && Sk <= 0) {           // empty split (only with a fixed split count): neutral partial
     if (gridDim.z > 1 && tid < HD) {
       float *pp = partial + (((size_t)b * gridDim.x + h) * gridDim.z + blockIdx.z) * (HD + 4);
       pp[tid] = 0.f;
@@ -235,7 +245,7 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f);
   float gmax, gsum;
   constexpr int UMAX = 9;          // rows per lane group held in registers: splits of up to 9 * RPP keys
-  if (Sk <= UMAX * RPP) {
+  if ((NG == 2 ? chunk : Sk) <= UMAX * RPP) {
     // ---- short split (the decoding loop's 128-key splits): K, V and relative rows are all requested up front -- ONE
     // memory round trip instead of the score pass followed by the value pass (the kernel is a chain of dependent
     // latencies, not of bandwidth: 10 -> ~8 us per launch, 16 launches per position)
@@ -244,6 +254,10 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
     for (int u = 0; u < UMAX; ++u) {
       const int j = grp + u * RPP;
       const int jc = j < Sk ? j : 0;
+      if (NG == 2 && Sk == 0) {        // (an empty half reads nothing: its rows may hold anything, 0 x NaN included)
+        kk[u] = vv[u] = ee[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+      }
       kk[u] = *reinterpret_cast<const float4 *>(kb + (size_t)jc * k_ss);
       vv[u] = *reinterpret_cast<const float4 *>(vb + (size_t)jc * v_ss);
       ee[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -349,6 +363,25 @@ __global__ __launch_bounds__(256) void rel_attention_decode_f32_kernel(
   }
   if (lane < G) *reinterpret_cast<float4 *>(part + wave * HD + lane * 4) = o0;
   __syncthreads();
+  if (NG == 2) {                       // the two halves' partials meet in LDS: rel_attention_combine_kernel's merge
+    if (tid < HD) {
+      mg[kg * (HD + 2) + tid] = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
+      if (tid == 0) { mg[kg * (HD + 2) + HD] = gmax; mg[kg * (HD + 2) + HD + 1] = gsum; }
+    }
+    __syncthreads();
+    if (kg == 0 && tid < HD) {
+      float M = -1e30f;
+      for (int s_ = 0; s_ < 2; ++s_) M = fmaxf(M, mg[s_ * (HD + 2) + HD]);
+      float num = 0.f, den = 0.f;
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const float w = __expf(mg[s_ * (HD + 2) + HD] - M);
+        num += w * mg[s_ * (HD + 2) + tid];
+        den += w * mg[s_ * (HD + 2) + HD + 1];
+      }
+      out[b * o_sb + h * o_sh + tid] = num * (1.0f / den);
+    }
+    return;
+  }
   if (tid < HD) {
     const float acc = (part[tid] + part[HD + tid]) + (part[2 * HD + tid] + part[3 * HD + tid]);
     if (gridDim.z == 1) {
@@ -415,11 +448,17 @@ int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *po
   const int Sk = (self_keys && !pos) ? q_pos + 1 : g->Sk;
   if (Sk > g->Sk) return invalid("attention_decode: position beyond the key capacity");
   const int chunk = (Sk + ns - 1) / ns;
-  const size_t smem = (size_t)(8 + 256 * 4 + (g->Sk + ns - 1) / ns) * sizeof(float);  // red + part[256/G][HD] + scores
-  dim3 grid(g->H, g->B, ns), block(256);
+  // two splits that are merged right away: both in one workgroup, no partials, no combine launch (NG = 2)
+  // (as long as every (batch, head) pair finds a CU of its own: the 512-thread workgroup holds 159 registers per lane, ONE fits a
+  // CU where three of the 256-thread ones do -- at 48 sequences x 8 heads the launch became a round and a half, 35.5 against
+  // 37.2 k codes/s)
+  const bool both = ns == 2 && combine && !knobs().decode_attn_separate_splits && g->B * g->H <= current_device_cu_count();
+  const size_t per_group = 8 + 256 * 4 + (((g->Sk + ns - 1) / ns + 3) & ~3);          // red + part[256/G][HD] + scores
+  const size_t smem = (both ? 2 * per_group + 2 * (size_t)(g->head_dim + 2) : per_group) * sizeof(float);
+  dim3 grid(g->H, g->B, both ? 1 : ns), block(both ? 512 : 256);
 #define ISI_DEC(HD)                                                                                         \
   do {                                                                                                      \
-    auto kern = rel_attention_decode_f32_kernel<HD>;                                                        \
+    auto kern = both ? rel_attention_decode_f32_kernel<HD, 2> : rel_attention_decode_f32_kernel<HD, 1>;     \
     if (smem > 48 * 1024 &&                                                                                 \
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                             (int)smem) != hipSuccess)                                                       \
@@ -437,7 +476,7 @@ int rel_attention_decode_launch(const isi_attn_args *g, int q_pos, const int *po
   }
 #undef ISI_DEC
   int rc = check_launch("rel_attention_decode_f32");
-  if (rc || ns == 1 || !combine) return rc;
+  if (rc || ns == 1 || !combine || both) return rc;
   hipLaunchKernelGGL(rel_attention_combine_kernel, dim3(g->H, g->B), dim3(g->head_dim), 0, stream, workspace,
                      g->out, g->head_dim, ns, g->o_sb, g->o_sh);
   return check_launch("rel_attention_combine");

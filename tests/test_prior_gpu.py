@@ -559,6 +559,50 @@ def test_sample_model_edge_masks(golden_dir):
         assert torch.equal(solo[0], out[1])
 
 
+def test_cached_attention_two_splits_in_one_workgroup():
+    """Round 6: batches of 17 .. 63 sequences split the cached attention's keys in two; both halves now run in ONE workgroup
+    that also merges them (no partials in memory, no combine launch).  Bit for bit the two-launch form
+    (ISI_DECODE_ATTN_SEPARATE_SPLITS=1) at every key count -- one key, a half that stays empty, the split boundary, the full
+    cache -- with and without the relative table, and the torch formula."""
+    from interactive_spectrogram_inpainting.priors import _ops
+    from interactive_spectrogram_inpainting import _hip
+    from oracle import prior_oracle as P
+    dev = _dev()
+    H, hd, S = 8, 64, 1024
+    d = H * hd
+    g = torch.Generator().manual_seed(31)
+    for B in (32, 48):
+        k = torch.randn(S, B, d, generator=g).to(dev)
+        v = torch.randn(S, B, d, generator=g).to(dev)
+        rel = (torch.randn(H, 2 * S - 1, hd, generator=g) * 0.2).to(dev)
+        k[600:] = float("nan")                     # rows beyond the keys in use may hold anything
+        v[600:] = float("nan")
+        for nk in (1, 100, 144, 145, 300, 599, 600):
+            q = torch.randn(B, d, generator=g).to(dev)
+            for r in (rel, None):
+                one = _ops.rel_attention_decode(q, k, v, r, H, nk, nk - 1, 1, 1, S)
+                with _hip.knob("ISI_DECODE_ATTN_SEPARATE_SPLITS", 1):
+                    two = _ops.rel_attention_decode(q, k, v, r, H, nk, nk - 1, 1, 1, S)
+                assert torch.isfinite(one).all() and torch.equal(one, two), (B, nk, r is None)
+            # the formula (relative rows: key j of query position p reads table row p - j + Ek - 1)
+            hq = q.view(B, H, hd).cpu().double()
+            hk = k[:nk].view(nk, B, H, hd).permute(1, 2, 0, 3).cpu().double()
+            hv = v[:nk].view(nk, B, H, hd).permute(1, 2, 0, 3).cpu().double()
+            idx = (nk - 1) - torch.arange(nk) + S - 1
+            logit = (torch.einsum("bhd,bhjd->bhj", hq, hk) + torch.einsum("bhd,hjd->bhj", hq, rel.cpu().double()[:, idx])) / math.sqrt(hd)
+            ref = torch.einsum("bhj,bhjd->bhd", torch.softmax(logit, -1), hv).reshape(B, d)
+            got = _ops.rel_attention_decode(q, k, v, rel, H, nk, nk - 1, 1, 1, S)
+            _close(got, ref.float(), TOL, "cached attention")
+    k2 = torch.randn(S, 32, d, generator=g).to(dev)     # the full cache
+    v2 = torch.randn(S, 32, d, generator=g).to(dev)
+    q = torch.randn(32, d, generator=g).to(dev)
+    for nk in (512, 513, 1024):
+        one = _ops.rel_attention_decode(q, k2, v2, rel, H, nk, nk - 1, 1, 1, S)
+        with _hip.knob("ISI_DECODE_ATTN_SEPARATE_SPLITS", 1):
+            two = _ops.rel_attention_decode(q, k2, v2, rel, H, nk, nk - 1, 1, 1, S)
+        assert torch.equal(one, two), nk
+
+
 def test_decode_graph_cache_and_statistics_handoff(golden_dir):
     """Round 6.  (a) `isi_prior_sample_run` keeps the graph executables of its last 8 argument sets: more sets than that (ten
     temperatures), revisited afterwards, give the codes of direct launches (ISI_PRIOR_GRAPH=0) every time -- entries are

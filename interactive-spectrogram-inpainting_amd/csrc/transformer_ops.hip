@@ -399,6 +399,32 @@ __global__ void rel_attention_combine_kernel(const float *__restrict__ partial, 
                                              int HD, int NS, int64_t o_sb, int64_t o_sh) {
   const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
   const float *pp = partial + ((size_t)b * gridDim.x + h) * NS * (HD + 4);
+  // (up to eight splits: every value requested before the first is used -- the two loops below were two chains of dependent
+  // loads, ~3 memory round trips in a launch that does nothing else; splits beyond NS re-read the last one and are left out)
+  if (NS <= 8) {
+    float pm[8], pl[8], pv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int sc = s < NS ? s : NS - 1;
+      pm[s] = pp[sc * (HD + 4) + HD];
+      pl[s] = pp[sc * (HD + 4) + HD + 1];
+      pv[s] = pp[sc * (HD + 4) + d];
+    }
+    float M = -1e30f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) if (s < NS) M = fmaxf(M, pm[s]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      if (s < NS) {
+        const float w = __expf(pm[s] - M);
+        num += w * pv[s];
+        den += w * pl[s];
+      }
+    }
+    out[b * o_sb + h * o_sh + d] = num * (1.0f / den);
+    return;
+  }
   float M = -1e30f;
   for (int s = 0; s < NS; ++s) M = fmaxf(M, pp[s * (HD + 4) + HD]);
   float num = 0.f, den = 0.f;

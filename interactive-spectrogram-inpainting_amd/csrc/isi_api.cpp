@@ -37,6 +37,7 @@ const KnobEntry kKnobTable[] = {
     {"ISI_CONV_PAIR_ALL", &Knobs::conv_pair_all, 0, false},
     {"ISI_CONV_TAP_MAJOR", &Knobs::conv_tap_major, 0, false},
     {"ISI_RESPAIR_TH", &Knobs::respair_th, 0, false},
+    {"ISI_RESPAIR_ONE_WAVE_PER_ROW", &Knobs::respair_one_wave_per_row, 0, false},
     {"ISI_RES_TH", &Knobs::res_th, 0, false},
     {"ISI_CONVT_TH", &Knobs::convt_th, 0, false},
     {"ISI_CONVT_PAIR_TH", &Knobs::convt_pair_th, 0, false},

@@ -24,6 +24,7 @@ struct Knobs {
   int conv_pair_all;            // ISI_CONV_PAIR_ALL: DMA kernel also for the shapes it is not preferred on
   int conv_tap_major;           // ISI_CONV_TAP_MAJOR: K order of the register-staged kernel (measurement)
   int respair_th, res_th, convt_th, convt_pair_th;   // forced tile heights (tests, measurement)
+  int respair_one_wave_per_row; // ISI_RESPAIR_ONE_WAVE_PER_ROW: the 4-row residual-block tiles with four waves (one per row, until round 6) instead of eight
   int decode_nt;                // ISI_DECODE_NT: non-temporal weight loads in the batch-1 decode GEMVs (default 1)
   int attn_g_from_kv;           // ISI_ATTN_G_FROM_KV: (kept logits) the key-stationary backward kernel stores dS into G (default 1)
   int wgrad_split_target;       // ISI_WGRAD_SPLIT_TARGET: workgroups the split weight-gradient kernel aims at (0 = 768)

@@ -82,16 +82,22 @@ __device__ __forceinline__ i32x4 make_rsrc(const void *ptr, const unsigned bytes
 // phase timestamps (-DISI_MEASURE builds; tools/stamps_resblock.py): workgroup 8, waves 0 and 4, its second work item
 #ifdef ISI_MEASURE
 __device__ long long g_respair_stamps[128];
-#define ISI_STAMP(i_) do { if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && item_i == (int)blockIdx.x + (int)gridDim.x) \
+#define ISI_STAMP(i_) do { if (blockIdx.x == 8 && (wave & 3) == 0 && lane == 0 && (item_i == (int)blockIdx.x + (int)gridDim.x || nitems <= (int)gridDim.x)) \
     g_respair_stamps[(wave >> 2) * 64 + (i_)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define ISI_STAMP(i_) do { } while (0)
 #endif
 #define ISI_MH(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
 
-template <int TH, int NT>   // NT = C / 32
-__global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p) {
-  constexpr int NW = TH;                                   // waves: one per tile row
+// WPR = 2 (round 6, the 4-row tiles of the top resolution): TWO waves per tile row, 32 pixels each -- 8 waves per workgroup, two
+// per SIMD.  With 4 waves a SIMD held ONE wave, whose LDS reads, dependent matrix instructions and DMA waits nobody covered:
+// a 256-pixel item took the 65-70 k cycles of a 512-pixel item of the 8-row form (tools/stamps_resblock.py); the same work on
+// twice the waves (a weight fragment now feeds one pixel tile instead of two: 4 LDS reads per 3 matrix instructions, the LDS
+// is at a sixth of its rate).
+template <int TH, int NT, int WPR = 1>   // NT = C / 32
+__global__ __launch_bounds__(TH * WPR * 64) void resblock_pair_kernel(const ResPairK p) {
+  constexpr int NW = TH * WPR;                             // waves: WPR per tile row
+  constexpr int NPT = 2 / WPR;                             // 32-pixel tiles per wave
   constexpr int HPIX = (TH + 2) * HWD;                     // halo pixels
   constexpr int A_ROWS = (HPIX + 15) / 16 * 16;            // padded to whole 1-KiB DMAs (16 rows of 64 B)
   constexpr int NA = A_ROWS / 16, NWD = 9 * 32 / 16;       // DMAs per stage: halo, W1 slice
@@ -200,7 +206,8 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
     // (2 kb + pl) at position ^ ((hx >> 2) & 3): swizzling with the COLUMN instead of the linear row is equally
     // conflict-free and makes the per-lane part of a window's address depend on dx only -- 3 x 2 registers, (dy, i)
     // ride in the instruction's immediate offset.  B: row t * 32 + frow: lane-only swizzle term.
-    const int ry = wave;                                    // this wave's tile row
+    const int ry = wave / WPR;                              // this wave's tile row
+    const int px0 = WPR == 2 ? (wave & 1) : 0;              // ... and its first 32-pixel tile of the row
     unsigned abase[3][2];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
@@ -212,9 +219,9 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
     const unsigned bbase1 = bbase ^ 16u;
 
     // GEMM 1, operands swapped (W1 = MFMA rows, pixels = columns): H^T[hidden][pixel]
-    f32x16 acc[2][2];   // [pixel tile][chain]: two chains per tile (alternating taps) keep dependent MFMAs apart
+    f32x16 acc[NPT][2];   // [pixel tile][chain]: two chains per tile (alternating taps) keep dependent MFMAs apart
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NPT; ++i)
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
     // the skip connection: the centre-tap fragments of every stage ARE this lane's pieces of r -- pixel 32 i + frow,
     // channels 16 c + 8 kb .. + 7 as {hi | lo} f16 of 4 r -- and are simply kept (8 NT x 8 registers) instead of
     // re-read from memory in the tail (134 MB per launch at B = 64, which the launch waited for in a burst)
-    s16x8 skh[NSTAGE][2], skl[NSTAGE][2];
+    s16x8 skh[NSTAGE][NPT], skl[NSTAGE][NPT];
 
     ISI_STAMP(2);
     // ---- prologue: NS - 1 stages in flight
@@ -250,25 +257,25 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const int dy = t / 3, dx = t % 3;
-        s16x8 ah[2], al[2];
+        s16x8 ah[NPT], al[NPT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ah[i] = *reinterpret_cast<const s16x8 *>(st + abase[dx][0] + (dy * HWD + 32 * i) * ROWB);
-          al[i] = *reinterpret_cast<const s16x8 *>(st + abase[dx][1] + (dy * HWD + 32 * i) * ROWB);
+        for (int i = 0; i < NPT; ++i) {
+          ah[i] = *reinterpret_cast<const s16x8 *>(st + abase[dx][0] + (dy * HWD + 32 * (px0 + i)) * ROWB);
+          al[i] = *reinterpret_cast<const s16x8 *>(st + abase[dx][1] + (dy * HWD + 32 * (px0 + i)) * ROWB);
         }
         if (t == 4) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i) { skh[c][i] = ah[i]; skl[c][i] = al[i]; }
+          for (int i = 0; i < NPT; ++i) { skh[c][i] = ah[i]; skl[c][i] = al[i]; }
         }
         const s16x8 bh = *reinterpret_cast<const s16x8 *>(st + bbase + t * 32 * ROWB);
         const s16x8 bl = *reinterpret_cast<const s16x8 *>(st + bbase1 + t * 32 * ROWB);
         // lo terms first, hi.hi last (the order of the other split-f16 kernels)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(bh, al[i], acc[i][t & 1]);
+        for (int i = 0; i < NPT; ++i) acc[i][t & 1] = ISI_MH(bh, al[i], acc[i][t & 1]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(bl, ah[i], acc[i][t & 1]);
+        for (int i = 0; i < NPT; ++i) acc[i][t & 1] = ISI_MH(bl, ah[i], acc[i][t & 1]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i][t & 1] = ISI_MH(bh, ah[i], acc[i][t & 1]);
+        for (int i = 0; i < NPT; ++i) acc[i][t & 1] = ISI_MH(bh, ah[i], acc[i][t & 1]);
         // one or two DMAs of the slice NS - 1 ahead behind each tap's MFMAs
         if (more) {
 #pragma unroll
@@ -282,13 +289,13 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
 
     // ---- hidden activations: lane (pixel = frow of tile i, kb) holds hidden channels 8 q + 4 kb + (r & 3), q = r >> 2.
     // h = relu(acc + b1), split into the f16 pieces of 4 h: quads 2 s and 2 s + 1 are GEMM 2's B fragment of k-step s.
-    s16x8 hh[2][2], hl[2][2];   // [pixel tile][k-step]
+    s16x8 hh[NPT][2], hl[NPT][2];   // [pixel tile][k-step]
     {
       float4 b1q[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) b1q[q] = *reinterpret_cast<const float4 *>(b1s + 8 * q + 4 * kb);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NPT; ++i)
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
           float hv[8];
@@ -313,8 +320,8 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
       const __amdgpu_buffer_rsrc_t rsh_b = __builtin_amdgcn_make_buffer_rsrc(p.hidden, 0, (unsigned)((size_t)p.B * p.H * p.W * 32 * 4), 0x00020000);
       const int gyh = y0 + ry;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int gx = x0 + 32 * i + frow;
+      for (int i = 0; i < NPT; ++i) {
+        const int gx = x0 + 32 * (px0 + i) + frow;
         const bool okh = gyh < p.H && gx < p.W;
         const unsigned oh_ = (unsigned)(((b * p.H + gyh) * p.W + gx) * 32 + 4 * kb) * 4u;
 #pragma unroll
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
       }
     }
     ISI_STAMP(5);
-    if (ISI_RESPAIR_ABLBIT(p, 2)) { if (hh[0][0][0] == 123 && hl[1][1][3] == 7) p.out[0] = 1.f; continue; }
+    if (ISI_RESPAIR_ABLBIT(p, 2)) { if (hh[0][0][0] == 123 && hl[NPT - 1][1][3] == 7) p.out[0] = 1.f; continue; }
 
     // ---- GEMM 2 (K = 32, W2 fragments from LDS) and the epilogue, per output tile j and pixel tile i, all in
     // registers: out = [relu](O + b2 + r), r decoded from the kept centre-tap pieces, 32-byte stores per lane.
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
         b2q[h][1] = *reinterpret_cast<const float4 *>(b2s + 32 * j + 16 * h + 8 * kb + 4);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NPT; ++i) {
         f32x16 o2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o2[r] = 0.f;
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
           o2 = ISI_MH(wl[s_], hh[i][s_], o2);
           o2 = ISI_MH(wh[s_], hh[i][s_], o2);
         }
-        const int gx = x0 + 32 * i + frow;
+        const int gx = x0 + 32 * (px0 + i) + frow;
         const bool ok = gy < p.H && gx < p.W;
         const unsigned o = (unsigned)(((b * p.H + gy) * p.W + gx) * C + 32 * j + 8 * kb) * 4u;
 #pragma unroll
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(TH * 64) void resblock_pair_kernel(const ResPairK p
 }
 #undef ISI_MH
 
-template <int TH, int NT>
+template <int TH, int NT, int WPR = 1>
 int launch_res_pair(const ResPairK &a, hipStream_t stream) {
   constexpr int HPIX = (TH + 2) * HWD;
   constexpr int A_ROWS = (HPIX + 15) / 16 * 16;
@@ -435,7 +442,7 @@ int launch_res_pair(const ResPairK &a, hipStream_t stream) {
   constexpr size_t ring = (size_t)NS * (A_ROWS * ROWB + 9 * 32 * ROWB + 1024);
   constexpr size_t smem = ring + (size_t)NT * 4096 + (NT * 32 + 32) * sizeof(float);   // + W2 fragments, biases
   static_assert(smem <= 160 * 1024, "LDS budget");
-  auto kern = resblock_pair_kernel<TH, NT>;
+  auto kern = resblock_pair_kernel<TH, NT, WPR>;
   static DeviceOnce attr_set;
   if (!attr_set.done()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
@@ -446,7 +453,7 @@ int launch_res_pair(const ResPairK &a, hipStream_t stream) {
   const int nitems = a.tiles_x * a.tiles_y * a.B;
   const double Cc = a.C, M = (double)a.B * a.H * a.W;
   prof::Scope scope(prof::K_RESBLOCK, 2.0 * M * 32 * 9 * Cc + 2.0 * M * Cc * 32, 4.0 * (2.0 * M * Cc + 10.0 * Cc * 32), stream);
-  ISI_PROF_LAUNCH(scope, kern, dim3(nitems < n_cu ? nitems : n_cu), dim3(TH * 64), smem, stream, a);
+  ISI_PROF_LAUNCH(scope, kern, dim3(nitems < n_cu ? nitems : n_cu), dim3(TH * WPR * 64), smem, stream, a);
   return check_launch("resblock_pair_f16");
 }
 
@@ -505,6 +512,7 @@ int resblock_pair_f16(const float *in, const float *w1_16, const float *b1, cons
     return C == 128 ? launch_res_pair<8, 4>(a, stream) : launch_res_pair<8, 2>(a, stream);
   }
   a.tiles_y = (H + 3) / 4;
+  if (!knobs().respair_one_wave_per_row) return C == 128 ? launch_res_pair<4, 4, 2>(a, stream) : launch_res_pair<4, 2, 2>(a, stream);
   return C == 128 ? launch_res_pair<4, 4>(a, stream) : launch_res_pair<4, 2>(a, stream);
 }
 

@@ -10,7 +10,7 @@ from interactive_spectrogram_inpainting import _hip
 from interactive_spectrogram_inpainting.vqvae import _ops
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-B, Cc, R, H, W = 64, 128, 32, 32, 128
+B, Cc, R, H, W = 64, 128, 32, int(sys.argv[1]) if len(sys.argv) > 1 else 32, int(sys.argv[2]) if len(sys.argv) > 2 else 128   # (16 64: the top resolution)
 x = torch.relu(torch.randn(B, H, W, Cc, generator=g)).to(dev)
 xp = _ops.pair_encode(x).permute(0, 3, 1, 2)
 p3 = _ops.pack_conv_weight((torch.randn(R, Cc, 3, 3, generator=g) * 0.03).to(dev), with_f16=True)

@@ -89,11 +89,11 @@ __device__ long long g_respair_stamps[128];
 #endif
 #define ISI_MH(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a_), __builtin_bit_cast(f16x8, b_), c_, 0, 0, 0)
 
-// WPR = 2 (round 6, the 4-row tiles of the top resolution): TWO waves per tile row, 32 pixels each -- 8 waves per workgroup, two
-// per SIMD.  With 4 waves a SIMD held ONE wave, whose LDS reads, dependent matrix instructions and DMA waits nobody covered:
-// a 256-pixel item took the 65-70 k cycles of a 512-pixel item of the 8-row form (tools/stamps_resblock.py); the same work on
-// twice the waves (a weight fragment now feeds one pixel tile instead of two: 4 LDS reads per 3 matrix instructions, the LDS
-// is at a sixth of its rate).
+// WPR = 2 (round 6, the 4-row tiles of the top resolution: ONE item per workgroup): TWO waves per tile row, 32 pixels each --
+// 8 waves per workgroup, two per SIMD; a weight fragment feeds one pixel tile instead of two (4 LDS reads per 3 matrix
+// instructions; the LDS is at a sixth of its rate).  tools/stamps_resblock.py 16 64, cycles of the item: 41.9 k -> 35-37 k --
+// the K loop stays at ~20 k (it was bound by the matrix pipe with one wave per SIMD already: the DMA ring hides the memory),
+// set-up + prologue 6.5 -> 4 k and GEMM 2 + epilogue 13 -> 10 k are shared by twice the threads.  31 -> 28 us per launch.
 template <int TH, int NT, int WPR = 1>   // NT = C / 32
 __global__ __launch_bounds__(TH * WPR * 64) void resblock_pair_kernel(const ResPairK p) {
   constexpr int NW = TH * WPR;                             // waves: WPR per tile row
